@@ -1,0 +1,422 @@
+"""CPU oracle for the DGL-KE training hot path (gather -> score -> negative score -> loss ->
+analytic gradients -> row-sparse Adagrad).
+
+*** TEST INFRASTRUCTURE ONLY. ***  Nothing under dgl-ke_amd/ (the product) may import this
+module.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, and only as
+the checker / the CPU baseline, never as the thing measured or shipped.
+
+This is a restatement in numpy of the reference's algorithm (awslabs/dgl-ke, all citations are
+relative to /root/reference/python/dglke/).  The reference computes gradients with torch autograd;
+here they are written out analytically because that is exactly what the HIP
+kernels implement.  Parity status: PINNED - tests/test_oracle_golden.py checks every function
+below against tests/golden/*.npz, which were produced by running the unmodified reference
+(`KEModel.forward -> loss.backward() -> KEModel.update`) in the build container
+(tests/golden/gen_golden.py).
+
+All functions take/return numpy arrays; `dtype` selects float32 (reference precision) or float64
+(tight checking).  Embedding rows of the complex models are stored as [re | im] halves
+(models/pytorch/score_fun.py:298-300, 461-462).
+"""
+import numpy as np
+
+MODELS = ("TransE_l1", "TransE_l2", "DistMult", "ComplEx", "RotatE")
+LOSSES = ("Logsigmoid", "Logistic", "Hinge", "BCE")
+
+
+def _canon(model):
+    return "TransE_l2" if model == "TransE" else model
+
+
+# --------------------------------------------------------------------------------------------
+# small numerics helpers
+# --------------------------------------------------------------------------------------------
+def _logsigmoid(x):
+    # torch.nn.functional.logsigmoid: min(x,0) - log1p(exp(-|x|))
+    return np.minimum(x, 0) - np.log1p(np.exp(-np.abs(x)))
+
+
+def _sigmoid(x):
+    out = np.empty_like(x)
+    pos = x >= 0
+    out[pos] = 1.0 / (1.0 + np.exp(-x[pos]))
+    e = np.exp(x[~pos])
+    out[~pos] = e / (1.0 + e)
+    return out
+
+
+def _softplus(x):
+    # torch softplus(beta=1, threshold=20)
+    return np.where(x > 20, x, np.log1p(np.exp(np.minimum(x, 20))))
+
+
+def _halves(x):
+    d = x.shape[-1] // 2
+    return x[..., :d], x[..., d:]
+
+
+# --------------------------------------------------------------------------------------------
+# A2: ExternalEmbedding.__call__ (models/pytorch/tensor_models.py:270-302): row gather
+# --------------------------------------------------------------------------------------------
+def gather_rows(table, idx):
+    return table[idx].copy()
+
+
+# --------------------------------------------------------------------------------------------
+# A3: positive score, edge_func of each score function
+# --------------------------------------------------------------------------------------------
+def score_pos(model, h, r, t, gamma, emb_init=None):
+    """TransE: score_fun.py:54-59; DistMult: :229-235; ComplEx: :297-307; RotatE: :460-472."""
+    model = _canon(model)
+    if model == "TransE_l1":
+        return gamma - np.abs(h + r - t).sum(-1)
+    if model == "TransE_l2":
+        return gamma - np.sqrt(((h + r - t) ** 2).sum(-1))
+    if model == "DistMult":
+        return (h * r * t).sum(-1)
+    if model == "ComplEx":
+        rh, ih = _halves(h)
+        rt, it = _halves(t)
+        rr, ir = _halves(r)
+        return (rh * rt * rr + ih * it * rr + rh * it * ir - ih * rt * ir).sum(-1)
+    if model == "RotatE":
+        rh, ih = _halves(h)
+        rt, it = _halves(t)
+        phase = r / (h.dtype.type(emb_init) / h.dtype.type(np.pi))
+        c, s = np.cos(phase), np.sin(phase)
+        re = rh * c - ih * s - rt
+        im = rh * s + ih * c - it
+        return gamma - np.sqrt(re * re + im * im).sum(-1)
+    raise ValueError(model)
+
+
+def score_pos_bwd(model, h, r, t, dp, gamma, emb_init=None):
+    """d(sum_i dp_i * p_i)/d(h,r,t): analytic form of autograd through edge_func."""
+    model = _canon(model)
+    dp = dp[:, None]
+    if model in ("TransE_l1", "TransE_l2"):
+        u = h + r - t
+        if model == "TransE_l1":
+            g = np.sign(u)
+        else:
+            nrm = np.sqrt((u * u).sum(-1, keepdims=True))
+            g = np.where(nrm > 0, u / np.where(nrm > 0, nrm, 1), 0)
+        return -dp * g, -dp * g, dp * g
+    if model == "DistMult":
+        return dp * r * t, dp * h * t, dp * h * r
+    if model == "ComplEx":
+        rh, ih = _halves(h)
+        rt, it = _halves(t)
+        rr, ir = _halves(r)
+        gh = np.concatenate([rt * rr + it * ir, it * rr - rt * ir], -1)
+        gt = np.concatenate([rh * rr - ih * ir, ih * rr + rh * ir], -1)
+        gr = np.concatenate([rh * rt + ih * it, rh * it - ih * rt], -1)
+        return dp * gh, dp * gr, dp * gt
+    if model == "RotatE":
+        rh, ih = _halves(h)
+        rt, it = _halves(t)
+        scale = h.dtype.type(np.pi) / h.dtype.type(emb_init)
+        phase = r * scale
+        c, s = np.cos(phase), np.sin(phase)
+        re = rh * c - ih * s - rt
+        im = rh * s + ih * c - it
+        m = np.sqrt(re * re + im * im)
+        inv = np.where(m > 0, 1.0 / np.where(m > 0, m, 1), 0)
+        # p = gamma - sum m ; upstream on (re, im) of the rotated head is -dp * (re,im)/m
+        gre = -dp * re * inv
+        gim = -dp * im * inv
+        gh = np.concatenate([gre * c + gim * s, -gre * s + gim * c], -1)
+        gt = np.concatenate([-gre, -gim], -1)
+        gphi = gre * (-rh * s - ih * c) + gim * (rh * c - ih * s)
+        return gh, gphi * scale, gt
+    raise ValueError(model)
+
+
+# --------------------------------------------------------------------------------------------
+# A4/A5: negative score = create_neg closures.  Split as: pos_side() builds the per-positive
+# vector a_i from the uncorrupted entity and the relation, score_neg() scores a_i against the
+# chunk's corrupt entities.
+# --------------------------------------------------------------------------------------------
+def pos_side(model, neg_head, x, r, emb_init=None):
+    """x = tail rows if neg_head else head rows (general_models.py:384-388 / :410-414).
+    TransE score_fun.py:94-107; DistMult :270-284; ComplEx :347-371; RotatE :516-545."""
+    model = _canon(model)
+    if model in ("TransE_l1", "TransE_l2"):
+        return x - r if neg_head else x + r
+    if model == "DistMult":
+        return x * r
+    if model in ("ComplEx", "RotatE"):
+        rx, ix = _halves(x)
+        if model == "ComplEx":
+            rr, ir = _halves(r)
+        else:
+            phase = r / (x.dtype.type(emb_init) / x.dtype.type(np.pi))
+            rr, ir = np.cos(phase), np.sin(phase)
+        if neg_head:
+            return np.concatenate([rx * rr + ix * ir, -rx * ir + ix * rr], -1)
+        return np.concatenate([rx * rr - ix * ir, rx * ir + ix * rr], -1)
+    raise ValueError(model)
+
+
+def score_neg(model, a, neg, C, chunk, N, gamma):
+    """[C,chunk,N] scores.  L2 uses the reference's expansion with clamp
+    (score_fun.py:26-34 batched_l2_dist); L1 = cdist p=1 (:36-38); DistMult/ComplEx = bmm
+    (:275,284,359,375); RotatE = complex modulus of the broadcast difference (:526-531)."""
+    model = _canon(model)
+    D = a.shape[-1]
+    A = a.reshape(C, chunk, D)
+    Bn = neg.reshape(C, N, D)
+    if model == "TransE_l2":
+        asq = np.sqrt((A * A).sum(-1)) ** 2
+        bsq = np.sqrt((Bn * Bn).sum(-1)) ** 2
+        sq = bsq[:, None, :] - 2 * np.einsum("cik,cjk->cij", A, Bn) + asq[:, :, None]
+        return gamma - np.sqrt(np.maximum(sq, a.dtype.type(1e-30)))
+    if model == "TransE_l1":
+        return gamma - np.abs(A[:, :, None, :] - Bn[:, None, :, :]).sum(-1)
+    if model in ("DistMult", "ComplEx"):
+        return np.einsum("cik,cjk->cij", A, Bn)
+    if model == "RotatE":
+        d = A[:, :, None, :] - Bn[:, None, :, :]
+        re, im = _halves(d)
+        return gamma - np.sqrt(re * re + im * im).sum(-1)
+    raise ValueError(model)
+
+
+def score_neg_bwd(model, a, neg, dneg, C, chunk, N, gamma):
+    """(dL/da [B,D], dL/dneg [C*N,D]) given dL/dn [C,chunk,N]."""
+    model = _canon(model)
+    D = a.shape[-1]
+    A = a.reshape(C, chunk, D)
+    Bn = neg.reshape(C, N, D)
+    G = dneg.reshape(C, chunk, N)
+    if model == "TransE_l2":
+        asq = np.sqrt((A * A).sum(-1)) ** 2
+        bsq = np.sqrt((Bn * Bn).sum(-1)) ** 2
+        sq = bsq[:, None, :] - 2 * np.einsum("cik,cjk->cij", A, Bn) + asq[:, :, None]
+        ok = sq >= 1e-30
+        dist = np.sqrt(np.maximum(sq, a.dtype.type(1e-30)))
+        Cw = np.where(ok, G / dist, 0)
+        ga = -A * Cw.sum(2)[:, :, None] + np.einsum("cij,cjk->cik", Cw, Bn)
+        gb = np.einsum("cij,cik->cjk", Cw, A) - Bn * Cw.sum(1)[:, :, None]
+    elif model == "TransE_l1":
+        sg = np.sign(A[:, :, None, :] - Bn[:, None, :, :])
+        ga = -(G[..., None] * sg).sum(2)
+        gb = (G[..., None] * sg).sum(1)
+    elif model in ("DistMult", "ComplEx"):
+        ga = np.einsum("cij,cjk->cik", G, Bn)
+        gb = np.einsum("cij,cik->cjk", G, A)
+    elif model == "RotatE":
+        d = A[:, :, None, :] - Bn[:, None, :, :]
+        re, im = _halves(d)
+        m = np.sqrt(re * re + im * im)
+        inv = np.where(m > 0, 1.0 / np.where(m > 0, m, 1), 0)
+        wre = G[..., None] * re * inv
+        wim = G[..., None] * im * inv
+        w = np.concatenate([wre, wim], -1)
+        ga = -w.sum(2)
+        gb = w.sum(1)
+    else:
+        raise ValueError(model)
+    return ga.reshape(-1, D), gb.reshape(-1, D)
+
+
+def pos_side_bwd(model, neg_head, x, r, ga, emb_init=None):
+    """chain dL/da -> (dL/dx, dL/dr)."""
+    model = _canon(model)
+    if model in ("TransE_l1", "TransE_l2"):
+        return ga, (-ga if neg_head else ga)
+    if model == "DistMult":
+        return ga * r, ga * x
+    rx, ix = _halves(x)
+    gre, gim = _halves(ga)
+    if model == "ComplEx":
+        rr, ir = _halves(r)
+        if neg_head:
+            gx = np.concatenate([gre * rr - gim * ir, gre * ir + gim * rr], -1)
+            gr = np.concatenate([gre * rx + gim * ix, gre * ix - gim * rx], -1)
+        else:
+            gx = np.concatenate([gre * rr + gim * ir, -gre * ir + gim * rr], -1)
+            gr = np.concatenate([gre * rx + gim * ix, -gre * ix + gim * rx], -1)
+        return gx, gr
+    if model == "RotatE":
+        scale = x.dtype.type(np.pi) / x.dtype.type(emb_init)
+        phase = r * scale
+        c, s = np.cos(phase), np.sin(phase)
+        if neg_head:
+            gx = np.concatenate([gre * c - gim * s, gre * s + gim * c], -1)
+            gphi = gre * (-rx * s + ix * c) + gim * (-rx * c - ix * s)
+        else:
+            gx = np.concatenate([gre * c + gim * s, -gre * s + gim * c], -1)
+            gphi = gre * (-rx * s - ix * c) + gim * (rx * c - ix * s)
+        return gx, gphi * scale
+    raise ValueError(model)
+
+
+# --------------------------------------------------------------------------------------------
+# A6: LossGenerator.get_total_loss (models/pytorch/loss.py:69-98) and its gradient
+# --------------------------------------------------------------------------------------------
+def _criterion(genre, score, label, margin):
+    """loss.py:10-38 ; returns (loss, dloss/dscore)"""
+    if genre in ("Logsigmoid", "Logistic"):
+        # -logsigmoid(l*s) (loss.py:37-38) == softplus(-l*s) (loss.py:23-24)
+        z = label * score
+        return -_logsigmoid(z), -label * _sigmoid(-z)
+    if genre == "Hinge":
+        v = margin - label * score
+        return np.where(v < 0, 0, v), np.where(v < 0, 0, -label).astype(score.dtype)
+    if genre == "BCE":
+        # -(l*log(sig(s)) + (1-l)*log(1-sig(s)))  (loss.py:30-31); labels 1 / 0 (loss.py:54-56)
+        sg = _sigmoid(score)
+        val = -(label * np.log(sg) + (1 - label) * np.log(1 - sg))
+        return val, (sg - label).astype(score.dtype)
+    raise ValueError(genre)
+
+
+def loss_fwd_bwd(pos, neg, w=None, genre="Logsigmoid", adv=False, adv_temp=1.0, pairwise=False,
+                 margin=1.0):
+    """pos [B], neg [B,N] (reshaped at general_models.py:560), w = edge importance [B] or None.
+    Returns (pos_loss, neg_loss, loss), dL/dpos [B], dL/dneg [B,N]."""
+    dt = pos.dtype
+    B, N = neg.shape
+    wcol = np.ones((B, 1), dt) if w is None else w.reshape(B, 1).astype(dt)
+    if pairwise:
+        # loss.py:76-80
+        diff = pos[:, None] - neg
+        val, dval = _criterion(genre, diff, 1, margin)
+        loss = (val * wcol).mean()
+        dd = dval * wcol / dt.type(B * N)
+        return (np.nan, np.nan, loss), dd.sum(1), -dd
+    neg_label = 0 if genre == "BCE" else -1
+    pl, dpl = _criterion(genre, pos, 1, margin)
+    nl, dnl = _criterion(genre, neg, neg_label, margin)
+    pl = pl * wcol[:, 0]
+    nl = nl * wcol
+    if adv:
+        # loss.py:87-88 ; softmax is detached
+        z = neg * dt.type(adv_temp)
+        z = z - z.max(1, keepdims=True)
+        e = np.exp(z)
+        A = e / e.sum(1, keepdims=True)
+        neg_i = (A * nl).sum(1)
+    else:
+        A = np.full((B, N), 1.0 / N, dt)
+        neg_i = nl.mean(1)
+    neg_loss = neg_i.mean()
+    pos_loss = pl.mean()
+    loss = (neg_loss + pos_loss) / 2
+    dpos = dpl * wcol[:, 0] / dt.type(2 * B)
+    dneg = dnl * wcol * A / dt.type(2 * B)
+    return (pos_loss, neg_loss, loss), dpos.astype(dt), dneg.astype(dt)
+
+
+# --------------------------------------------------------------------------------------------
+# A7: regularisation (general_models.py:572-576; norm = x.norm(p)**p, tensor_models.py:54)
+# --------------------------------------------------------------------------------------------
+def reg_value(rows_list, coef, p):
+    return coef * sum((np.abs(x) ** p).sum() for x in rows_list)
+
+
+def reg_grad(x, coef, p):
+    return coef * p * np.abs(x) ** (p - 1) * np.sign(x)
+
+
+# --------------------------------------------------------------------------------------------
+# A9: ExternalEmbedding.update (tensor_models.py:304-362): row-sparse Adagrad for one trace
+# --------------------------------------------------------------------------------------------
+def adagrad_update(table, state, idx, grad, lr, eps=1e-10):
+    """in place.  state += index_add(mean(g^2)) with duplicates accumulating (:352); std is read
+    AFTER all adds (:353-356); emb.index_add_(-lr*g/std) (:357-361)."""
+    gs = (grad * grad).mean(1)
+    np.add.at(state, idx, gs.astype(state.dtype))
+    std = np.sqrt(state[idx]) + state.dtype.type(eps)
+    np.add.at(table, idx, (-lr * grad / std[:, None]).astype(table.dtype))
+
+
+# --------------------------------------------------------------------------------------------
+# one whole training step: KEModel.forward (general_models.py:529-578) + loss.backward()
+# (train_pytorch.py:145) + KEModel.update (general_models.py:580-588)
+# --------------------------------------------------------------------------------------------
+class Config(object):
+    def __init__(self, model, gamma, hidden, lr, adv=False, adv_temp=1.0, reg_coef=0.0,
+                 reg_norm=3, loss_genre="Logsigmoid", pairwise=False, margin=1.0,
+                 double_ent=False, double_rel=False):
+        self.model = _canon(model)
+        self.gamma = gamma
+        self.hidden = hidden
+        self.emb_init = (gamma + 2.0) / hidden        # general_models.py:217-218, EMB_INIT_EPS=2
+        self.lr = lr
+        self.adv, self.adv_temp = adv, adv_temp
+        self.reg_coef, self.reg_norm = reg_coef, reg_norm
+        self.loss_genre, self.pairwise, self.margin = loss_genre, pairwise, margin
+        self.ent_dim = 2 * hidden if double_ent else hidden
+        self.rel_dim = 2 * hidden if double_rel else hidden
+
+
+def forward_backward(cfg, ent, rel, nid, h_local, t_local, rel_ids, neg_ids, neg_head, chunk, N,
+                     w=None):
+    """Returns dict with pos_score, neg_score [C,chunk,N], log (pos_loss,neg_loss,loss,reg),
+    g_pos_ent [U,D], g_rel [B,D], g_neg [C*N,D] - the three trace gradients of the reference."""
+    dt = ent.dtype
+    B = h_local.shape[0]
+    C = B // chunk
+    pos_emb = gather_rows(ent, nid)                    # trace 0 of entity_emb
+    r = gather_rows(rel, rel_ids)                      # trace 0 of relation_emb
+    neg = gather_rows(ent, neg_ids)                    # trace 1 of entity_emb
+    h = pos_emb[h_local]
+    t = pos_emb[t_local]
+    gamma = dt.type(cfg.gamma)
+    p = score_pos(cfg.model, h, r, t, gamma, cfg.emb_init)
+    x = t if neg_head else h
+    a = pos_side(cfg.model, neg_head, x, r, cfg.emb_init)
+    n = score_neg(cfg.model, a, neg, C, chunk, N, gamma)
+    (pl, nl, loss), dpos, dneg = loss_fwd_bwd(p, n.reshape(B, N), w, cfg.loss_genre, cfg.adv,
+                                              cfg.adv_temp, cfg.pairwise, cfg.margin)
+    reg = 0.0
+    use_reg = cfg.reg_coef > 0.0 and cfg.reg_norm > 0
+    if use_reg:
+        reg = reg_value([pos_emb, neg], cfg.reg_coef, cfg.reg_norm) + \
+            reg_value([r], cfg.reg_coef, cfg.reg_norm)
+    gh, gr, gt = score_pos_bwd(cfg.model, h, r, t, dpos, gamma, cfg.emb_init)
+    ga, g_neg = score_neg_bwd(cfg.model, a, neg, dneg.reshape(C, chunk, N), C, chunk, N, gamma)
+    gx, gr2 = pos_side_bwd(cfg.model, neg_head, x, r, ga, cfg.emb_init)
+    gr = gr + gr2
+    if neg_head:
+        gt = gt + gx
+    else:
+        gh = gh + gx
+    g_pos = np.zeros_like(pos_emb)
+    np.add.at(g_pos, h_local, gh.astype(dt))
+    np.add.at(g_pos, t_local, gt.astype(dt))
+    if use_reg:
+        g_pos += reg_grad(pos_emb, cfg.reg_coef, cfg.reg_norm).astype(dt)
+        g_neg = g_neg + reg_grad(neg, cfg.reg_coef, cfg.reg_norm)
+        gr = gr + reg_grad(r, cfg.reg_coef, cfg.reg_norm)
+    return dict(pos_score=p, neg_score=n, log=(pl, nl, loss, reg), loss_total=loss + reg,
+                g_pos_ent=g_pos.astype(dt), g_rel=gr.astype(dt), g_neg=g_neg.astype(dt))
+
+
+def train_step(cfg, ent, ent_state, rel, rel_state, nid, h_local, t_local, rel_ids, neg_ids,
+               neg_head, chunk, N, w=None):
+    """forward + backward + update, tables modified in place.  Update order:
+    entity trace 0 (pos-unique rows) then entity trace 1 (negative rows), then the relation
+    trace (general_models.py:586-588 ; tensor_models.py:316)."""
+    out = forward_backward(cfg, ent, rel, nid, h_local, t_local, rel_ids, neg_ids, neg_head,
+                           chunk, N, w)
+    adagrad_update(ent, ent_state, nid, out["g_pos_ent"], cfg.lr)
+    adagrad_update(ent, ent_state, neg_ids, out["g_neg"], cfg.lr)
+    adagrad_update(rel, rel_state, rel_ids, out["g_rel"], cfg.lr)
+    return out
+
+
+def synth_batch(rng, n_ent, n_rel, B, N, chunk, step):
+    """Seeded synthetic id batch (same generator as tests/golden/gen_golden.py:make_batch):
+    uniform h,t,r; C*N uniform negatives with replacement, positives not excluded
+    (dataloader/sampler.py:376-419 call-site semantics); odd steps corrupt tails, even steps
+    corrupt heads (dataloader/sampler.py:853-859)."""
+    C = B // chunk
+    h = rng.randint(0, n_ent, size=B).astype(np.int64)
+    t = rng.randint(0, n_ent, size=B).astype(np.int64)
+    r = rng.randint(0, n_rel, size=B).astype(np.int64)
+    neg = rng.randint(0, n_ent, size=C * N).astype(np.int64)
+    nid, inv = np.unique(np.concatenate([h, t]), return_inverse=True)
+    return dict(h=h, t=t, r=r, neg=neg, neg_head=(step % 2 == 0), nid=nid.astype(np.int64),
+                h_local=inv[:B].astype(np.int64), t_local=inv[B:].astype(np.int64), C=C)

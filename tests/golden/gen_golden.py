@@ -1,0 +1,293 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the UNMODIFIED reference (awslabs/dgl-ke) on CPU.
+
+TEST INFRASTRUCTURE ONLY.  This script runs in the build container only (it needs
+/root/reference, which does not exist on the GPU box); the .npz files it writes are committed
+under tests/golden/ and are what the oracle (oracle/kge_oracle.py) and the HIP path are pinned
+against.
+
+How the reference is made importable here: `dgl` and `ogb` are not
+installed, so stub modules are registered in sys.modules before `from dglke.models import
+KEModel`; the stub only provides the thin tensor shim `dgl.backend` and placeholder classes, no
+arithmetic.  The batches are duck-typed objects exposing the members the reference reads
+(general_models.py:376-427, 548-569): PosG / NegG below.
+
+Every case runs `KEModel.forward -> loss.backward() -> KEModel.update` (train_pytorch.py:141-152)
+for a few steps and records, per step: the id batch, pos_score, neg_score, the log dict, the three
+trace gradients (pos-entity [U,D], relation [B,D], negative-entity [C*N,D]); plus the initial and
+final tables and state_sum.
+"""
+import os
+import sys
+import types
+import json
+
+import numpy as np
+import torch as th
+
+REF = os.environ.get("DGLKE_REFERENCE", "/root/reference/python")
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def install_stubs():
+    """Register fake dgl / ogb modules (members listed in SURVEY.md Appendix A)."""
+    def mod(name):
+        m = types.ModuleType(name)
+        sys.modules[name] = m
+        return m
+
+    dgl = mod("dgl")
+    F = mod("dgl.backend")
+    F.float32 = th.float32
+    F.int64 = th.int64
+    F.cpu = lambda: th.device("cpu")
+    F.ones = lambda shape, dtype, ctx: th.ones(shape, dtype=dtype, device=ctx)
+    F.context = lambda t: t.device
+    F.cat = lambda seq, dim: th.cat(seq, dim=dim)
+    F.copy_to = lambda t, ctx: t.to(ctx)
+    F.tensor = lambda x, dtype=None: th.tensor(x, dtype=dtype)
+    F.asnumpy = lambda t: t.detach().cpu().numpy()
+    F.sum = lambda t, dim: th.sum(t, dim=dim)
+    F.shape = lambda t: t.shape
+    F.reshape = lambda t, s: t.reshape(s)
+    F.arange = lambda a, b: th.arange(a, b)
+    F.argsort = lambda t, dim, descending: th.argsort(t, dim=dim, descending=descending)
+    dgl.backend = F
+    dep = mod("dgl._deprecate")
+    depg = mod("dgl._deprecate.graph")
+
+    class DGLGraph(object):
+        pass
+    depg.DGLGraph = DGLGraph
+    dep.graph = depg
+    dgl._deprecate = dep
+    base = mod("dgl.base")
+    base.NID = "_ID"
+    base.EID = "_ID"
+    dgl.base = base
+    contrib = mod("dgl.contrib")
+    contrib.KVClient = object
+    contrib.KVServer = object
+    contrib.sampling = mod("dgl.contrib.sampling")
+    dgl.contrib = contrib
+    ogb = mod("ogb")
+    lsc = mod("ogb.lsc")
+    lsc.WikiKG90MDataset = object
+    lsc.WikiKG90MEvaluator = object
+    ogb.lsc = lsc
+
+
+class Args(dict):
+    """attribute dict, like the reference's own tests use (tests/test_score.py:45-49)."""
+    __getattr__ = dict.get
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+class _Edges(object):
+    def __init__(self, src, dst, data):
+        self.src, self.dst, self.data = src, dst, data
+
+
+class PosG(object):
+    """Duck type of the positive DGL subgraph (members: SURVEY.md section 8b)."""
+
+    def __init__(self, nid, h_local, t_local, rel_id, impts=None):
+        self.ndata = {"id": nid}
+        self.edata = {"id": rel_id}
+        if impts is not None:
+            self.edata["impts"] = impts
+        self._h, self._t = h_local, t_local
+
+    def all_edges(self, order="eid"):
+        return self._h, self._t
+
+    def number_of_edges(self):
+        return int(self._h.shape[0])
+
+    def apply_edges(self, fn):
+        e = _Edges({"emb": self.ndata["emb"][self._h]}, {"emb": self.ndata["emb"][self._t]},
+                   self.edata)
+        self.edata.update(fn(e))
+
+
+class NegG(object):
+    def __init__(self, ids, num_chunks, chunk_size, neg_sample_size, neg_head):
+        self.ndata = {"id": ids}
+        self.edata = {}
+        n = ids.shape[0]
+        self.head_nid = th.arange(n)
+        self.tail_nid = th.arange(n)
+        self.num_chunks = num_chunks
+        self.chunk_size = chunk_size
+        self.neg_sample_size = neg_sample_size
+        self.neg_head = neg_head
+
+
+def make_args(case):
+    a = Args()
+    a.gpu = [-1]
+    a.mix_cpu_gpu = False
+    a.has_edge_importance = bool(case.get("impts", False))
+    a.strict_rel_part = False
+    a.soft_rel_part = False
+    a.lr = case["lr"]
+    a.neg_deg_sample = False
+    a.neg_deg_sample_eval = False
+    a.eval_filter = False
+    a.regularization_coef = case["reg_coef"]
+    a.regularization_norm = case["reg_norm"]
+    a.loss_genre = case.get("loss_genre", "Logsigmoid")
+    a.neg_adversarial_sampling = case["adv"]
+    a.adversarial_temperature = case["adv_temp"]
+    a.pairwise = case.get("pairwise", False)
+    a.margin = case.get("margin", 1.0)
+    a.num_thread = 1
+    return a
+
+
+def make_batch(rng, case, step):
+    """Seeded id batch: uniform h,t,r; C*N negatives with replacement (sampler.py:376-419
+    semantics restated in SURVEY.md 8c); odd steps corrupt tails, even steps heads
+    (sampler.py:853-859, step counter starts at 1)."""
+    B, N, chunk = case["B"], case["N"], case["chunk"]
+    C = B // chunk
+    h = rng.randint(0, case["n_ent"], size=B).astype(np.int64)
+    t = rng.randint(0, case["n_ent"], size=B).astype(np.int64)
+    r = rng.randint(0, case["n_rel"], size=B).astype(np.int64)
+    neg = rng.randint(0, case["n_ent"], size=C * N).astype(np.int64)
+    neg_head = (step % 2 == 0)
+    nid, inv = np.unique(np.concatenate([h, t]), return_inverse=True)
+    h_local, t_local = inv[:B].astype(np.int64), inv[B:].astype(np.int64)
+    w = rng.uniform(0.5, 1.5, size=B).astype(np.float32) if case.get("impts", False) else None
+    return dict(h=h, t=t, r=r, neg=neg, neg_head=neg_head, nid=nid.astype(np.int64),
+                h_local=h_local, t_local=t_local, C=C, w=w)
+
+
+def run_case(name, case):
+    from dglke.models import KEModel
+    th.manual_seed(case["seed"])
+    rng = np.random.RandomState(case["seed"])
+    args = make_args(case)
+    model = KEModel(args, case["model"], case["n_ent"], case["n_rel"], case["hidden"],
+                    case["gamma"], double_entity_emb=case["de"], double_relation_emb=case["dr"])
+    out = {}
+    out["init_entity"] = model.entity_emb.emb.numpy().copy()
+    out["init_relation"] = model.relation_emb.emb.numpy().copy()
+    out["emb_init"] = np.float64(model.emb_init)
+    for s in range(1, case["steps"] + 1):
+        b = make_batch(rng, case, s)
+        pos_g = PosG(th.from_numpy(b["nid"]), th.from_numpy(b["h_local"]),
+                     th.from_numpy(b["t_local"]), th.from_numpy(b["r"]),
+                     th.from_numpy(b["w"]) if b["w"] is not None else None)
+        neg_g = NegG(th.from_numpy(b["neg"]), b["C"], case["chunk"], case["N"], b["neg_head"])
+        loss, log = model.forward(pos_g, neg_g, -1)
+        loss.backward()
+        p = "s%d_" % s
+        for k in ("h", "t", "r", "neg", "nid", "h_local", "t_local"):
+            out[p + k] = b[k]
+        if b["w"] is not None:
+            out[p + "w"] = b["w"]
+        out[p + "neg_head"] = np.int64(b["neg_head"])
+        out[p + "pos_score"] = pos_g.edata["score"].detach().numpy().copy()
+        # neg score recomputed without trace for recording (same tensors, no side effect)
+        with th.no_grad():
+            ns = model.predict_neg_score(pos_g, neg_g, trace=False)
+        out[p + "neg_score"] = ns.detach().numpy().copy()
+        out[p + "log"] = np.array([log.get("pos_loss", np.nan), log.get("neg_loss", np.nan),
+                                   log["loss"], log.get("regularization", 0.0)], dtype=np.float64)
+        out[p + "loss_total"] = np.float64(loss.item())
+        et = model.entity_emb.trace
+        rt = model.relation_emb.trace
+        assert len(et) == 2 and len(rt) == 1
+        out[p + "g_pos_ent"] = et[0][1].grad.numpy().copy()
+        out[p + "g_neg"] = et[1][1].grad.numpy().copy()
+        out[p + "g_rel"] = rt[0][1].grad.numpy().copy()
+        model.update(-1)
+        out[p + "entity_state"] = model.entity_emb.state_sum.numpy().copy()
+        out[p + "relation_state"] = model.relation_emb.state_sum.numpy().copy()
+        if case.get("save_tables_each_step", True):
+            out[p + "entity"] = model.entity_emb.emb.numpy().copy()
+            out[p + "relation"] = model.relation_emb.emb.numpy().copy()
+    out["final_entity"] = model.entity_emb.emb.numpy().copy()
+    out["final_relation"] = model.relation_emb.emb.numpy().copy()
+    out["final_entity_state"] = model.entity_emb.state_sum.numpy().copy()
+    out["final_relation_state"] = model.relation_emb.state_sum.numpy().copy()
+    out["case_json"] = np.array(json.dumps(case))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print("wrote", name, "loss", out["s%d_loss_total" % case["steps"]])
+
+
+def base(model, **kw):
+    c = dict(model=model, n_ent=60, n_rel=7, hidden=16, gamma=12.0, de=False, dr=False,
+             B=16, N=4, chunk=4, lr=0.1, adv=True, adv_temp=1.0, reg_coef=1e-3, reg_norm=3,
+             steps=3, seed=7)
+    c.update(kw)
+    return c
+
+
+CASES = {
+    # the five in-scope score functions (score_fun.py:40,222,289,451), both corruption modes
+    # (3 steps: tail, head, tail), -adv on, regularisation on.
+    "transe_l2_small": base("TransE_l2"),
+    "transe_l1_small": base("TransE_l1", seed=8),
+    "distmult_small": base("DistMult", gamma=6.0, hidden=16, lr=0.08, seed=9),
+    "complex_small": base("ComplEx", gamma=6.0, de=True, dr=True, seed=10),
+    "rotate_small": base("RotatE", gamma=12.0, de=True, seed=11),
+    # no adversarial weighting, no regularisation
+    "transe_l2_noadv": base("TransE_l2", adv=False, reg_coef=0.0, seed=12),
+    "distmult_noadv": base("DistMult", adv=False, reg_coef=0.0, seed=13),
+    # duplicate-heavy: 9 entities / 2 relations -> exercises ExternalEmbedding.update
+    # duplicate semantics (tensor_models.py:352-361)
+    "transe_l2_dups": base("TransE_l2", n_ent=9, n_rel=2, steps=4, seed=14),
+    "complex_dups": base("ComplEx", n_ent=9, n_rel=2, de=True, dr=True, steps=4, seed=15),
+    "rotate_dups": base("RotatE", n_ent=9, n_rel=2, de=True, steps=4, seed=16),
+    # ragged tile shapes: chunk != N, dims not multiples of 16/64
+    "transe_l2_ragged": base("TransE_l2", hidden=20, B=30, N=7, chunk=10, seed=17),
+    "transe_l1_ragged": base("TransE_l1", hidden=20, B=30, N=7, chunk=10, seed=18),
+    "distmult_ragged": base("DistMult", hidden=20, B=30, N=7, chunk=10, seed=19),
+    "complex_ragged": base("ComplEx", hidden=10, de=True, dr=True, B=30, N=7, chunk=10, seed=20),
+    "rotate_ragged": base("RotatE", hidden=10, de=True, B=30, N=7, chunk=10, seed=21),
+    # edge-importance weights (general_models.py:568, loss.py:72-75)
+    "transe_l2_impts": base("TransE_l2", impts=True, seed=22),
+    # a mid-size case shaped like the FB15k config (chunk == N, several MFMA tiles, D=64)
+    "transe_l2_mid": base("TransE_l2", n_ent=400, n_rel=30, hidden=64, gamma=19.9, B=96, N=32,
+                          chunk=32, lr=0.25, reg_coef=1e-9, steps=2, seed=23,
+                          save_tables_each_step=False),
+    "distmult_mid": base("DistMult", n_ent=400, n_rel=30, hidden=64, gamma=30.0, B=96, N=32,
+                         chunk=32, lr=0.08, reg_coef=2e-6, steps=2, seed=24,
+                         save_tables_each_step=False),
+    "complex_mid": base("ComplEx", n_ent=400, n_rel=30, hidden=32, gamma=14.0, de=True, dr=True,
+                        B=96, N=32, chunk=32, lr=0.1, reg_coef=2e-6, steps=2, seed=25,
+                        save_tables_each_step=False),
+    "rotate_mid": base("RotatE", n_ent=400, n_rel=30, hidden=32, gamma=12.0, de=True,
+                       B=96, N=32, chunk=32, lr=0.01, reg_coef=1e-7, steps=2, seed=26,
+                       save_tables_each_step=False),
+    "transe_l1_mid": base("TransE_l1", n_ent=400, n_rel=30, hidden=64, gamma=16.0, B=96, N=32,
+                          chunk=32, lr=0.01, reg_coef=1e-7, steps=2, seed=27,
+                          save_tables_each_step=False),
+    # other loss genres (loss.py:10-38, 44-61), pointwise
+    "transe_l2_logistic": base("TransE_l2", loss_genre="Logistic", adv=False, seed=28),
+    "transe_l2_hinge": base("TransE_l2", loss_genre="Hinge", margin=2.0, adv=False, seed=29),
+    "distmult_bce": base("DistMult", loss_genre="BCE", gamma=1.0, adv=False, seed=30),
+    "transe_l2_hinge_pairwise": base("TransE_l2", loss_genre="Hinge", margin=2.0, adv=False,
+                                     pairwise=True, seed=31),
+    "distmult_logistic_pairwise": base("DistMult", loss_genre="Logistic", adv=False,
+                                       pairwise=True, seed=32),
+}
+
+
+def main():
+    install_stubs()
+    sys.path.insert(0, REF)
+    th.set_num_threads(1)
+    only = sys.argv[1:]
+    for name, case in CASES.items():
+        if only and name not in only:
+            continue
+        run_case(name, case)
+
+
+if __name__ == "__main__":
+    main()

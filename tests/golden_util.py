@@ -1,0 +1,27 @@
+"""Helpers shared by the golden-vector tests (test infrastructure)."""
+import glob
+import json
+import os
+
+import numpy as np
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def golden_names():
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    case = json.loads(str(z["case_json"]))
+    return z, case
+
+
+def oracle_config(case):
+    from oracle import kge_oracle as O
+    return O.Config(case["model"], case["gamma"], case["hidden"], case["lr"], adv=case["adv"],
+                    adv_temp=case["adv_temp"], reg_coef=case["reg_coef"],
+                    reg_norm=case["reg_norm"], loss_genre=case.get("loss_genre", "Logsigmoid"),
+                    pairwise=case.get("pairwise", False), margin=case.get("margin", 1.0),
+                    double_ent=case["de"], double_rel=case["dr"])

@@ -1,0 +1,78 @@
+"""Pin the CPU oracle (oracle/kge_oracle.py) against golden vectors produced by the unmodified
+reference (tests/golden/gen_golden.py).  CPU-only; runs in seconds."""
+import numpy as np
+import pytest
+
+from golden_util import golden_names, load_golden, oracle_config
+from oracle import kge_oracle as O
+
+
+def _close(a, b, rtol, atol, what):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    err = np.abs(a - b)
+    lim = atol + rtol * np.abs(b)
+    assert np.all(err <= lim), "%s: max err %.3e (limit %.3e) at %s" % (
+        what, err.max(), lim.flat[np.argmax(err - lim)], np.unravel_index(np.argmax(err - lim), err.shape))
+
+
+@pytest.mark.parametrize("name", golden_names())
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_step_matches_reference(name, dtype):
+    z, case = load_golden(name)
+    cfg = oracle_config(case)
+    ent = z["init_entity"].astype(dtype)
+    rel = z["init_relation"].astype(dtype)
+    assert abs(cfg.emb_init - float(z["emb_init"])) < 1e-12
+    ent_state = np.zeros(ent.shape[0], dtype)
+    rel_state = np.zeros(rel.shape[0], dtype)
+    # fp64 oracle vs the fp32 reference: differences are the reference's own fp32 rounding
+    tol = dict(rtol=2e-4, atol=2e-5)
+    # Post-update rows: Adagrad's first steps normalise the gradient (delta = -lr*g/sqrt(mean g^2)),
+    # which turns the reference's own fp32 rounding of small gradient components into O(1e-3*lr)
+    # differences; table tolerances are therefore stated relative to lr.
+    for s in range(1, case["steps"] + 1):
+        p = "s%d_" % s
+        if dtype == np.float64 and s > 1:
+            # re-synchronise on the reference's fp32 tables so fp32 drift does not accumulate
+            ent = z["s%d_entity" % (s - 1)].astype(dtype) if ("s%d_entity" % (s - 1)) in z else ent
+            rel = z["s%d_relation" % (s - 1)].astype(dtype) if ("s%d_relation" % (s - 1)) in z else rel
+        w = z[p + "w"].astype(dtype) if (p + "w") in z else None
+        out = O.train_step(cfg, ent, ent_state, rel, rel_state, z[p + "nid"], z[p + "h_local"],
+                           z[p + "t_local"], z[p + "r"], z[p + "neg"], bool(z[p + "neg_head"]),
+                           case["chunk"], case["N"], w)
+        _close(out["pos_score"], z[p + "pos_score"], what=name + " pos_score", **tol)
+        _close(out["neg_score"], z[p + "neg_score"], what=name + " neg_score", **tol)
+        log = z[p + "log"]
+        if not case.get("pairwise", False):
+            _close(out["log"][0], log[0], 1e-4, 1e-5, name + " pos_loss")
+            _close(out["log"][1], log[1], 1e-4, 1e-5, name + " neg_loss")
+        _close(out["log"][2], log[2], 1e-4, 1e-5, name + " loss")
+        _close(out["log"][3], log[3], 1e-4, 1e-7, name + " reg")
+        _close(out["loss_total"], z[p + "loss_total"], 1e-4, 1e-5, name + " total")
+        gscale = max(np.abs(z[p + "g_pos_ent"]).max(), 1e-12)
+        _close(out["g_pos_ent"], z[p + "g_pos_ent"], 2e-4, 3e-4 * gscale, name + " g_pos_ent")
+        _close(out["g_rel"], z[p + "g_rel"], 2e-4, 3e-4 * max(np.abs(z[p + "g_rel"]).max(), 1e-12),
+               name + " g_rel")
+        _close(out["g_neg"], z[p + "g_neg"], 2e-4, 3e-4 * max(np.abs(z[p + "g_neg"]).max(), 1e-12),
+               name + " g_neg")
+        _close(ent_state, z[p + "entity_state"], 1e-3, 1e-9, name + " ent state")
+        _close(rel_state, z[p + "relation_state"], 1e-3, 1e-9, name + " rel state")
+        if (p + "entity") in z:
+            _close(ent, z[p + "entity"], 1e-4, 5e-3 * case["lr"], name + " entity table step %d" % s)
+            _close(rel, z[p + "relation"], 1e-4, 5e-3 * case["lr"], name + " relation table step %d" % s)
+    _close(ent, z["final_entity"], 1e-4, 1e-2 * case["lr"], name + " final entity")
+    _close(rel, z["final_relation"], 1e-4, 1e-2 * case["lr"], name + " final relation")
+
+
+def test_duplicate_adagrad_semantics():
+    """tensor_models.py:352-361: state gets sum_k mean(g_k^2) over duplicates, every duplicate is
+    scaled by the SAME post-accumulation std."""
+    table = np.zeros((3, 4), np.float64)
+    state = np.zeros(3, np.float64)
+    idx = np.array([1, 1, 2])
+    g = np.array([[1, 1, 1, 1], [3, 3, 3, 3], [2, 2, 2, 2]], np.float64)
+    O.adagrad_update(table, state, idx, g, lr=0.5)
+    assert np.allclose(state, [0, 10, 4])
+    assert np.allclose(table[1], -0.5 * (1 + 3) / (np.sqrt(10) + 1e-10))
+    assert np.allclose(table[2], -0.5 * 2 / (2 + 1e-10))
