@@ -1,0 +1,397 @@
+// kge_api.hip - the C ABI of libkge_hip.so (include/kge_hip.h): argument checking, workspace
+// carving and the kernel sequence of each entry point.  No allocation, no synchronisation: every
+// function only enqueues kernels on the caller's stream.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include "kge_common.hpp"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define KGE_TRY(expr)                                                                  \
+    do {                                                                               \
+        const int rc_ = (expr);                                                        \
+        if (rc_ != KGE_OK) return fail(rc_, "%s failed (%d) at %s:%d", #expr, rc_, __FILE__, __LINE__); \
+    } while (0)
+
+inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// bump allocator over the caller's workspace
+struct Carver {
+    char *base; size_t size, off;
+    Carver(void *p, size_t n) : base((char *)p), size(n), off(0) {}
+    float *f(size_t n_floats) {
+        const size_t o = off;
+        off = align_up(off + n_floats * sizeof(float));
+        return (float *)(base + o);
+    }
+    bool ok() const { return off <= size; }
+};
+
+int check_model(int model, int d_e, int d_r) {
+    if (model < KGE_TRANSE_L1 || model > KGE_ROTATE) return fail(KGE_ERR_ARG, "unknown model %d", model);
+    if (d_e <= 0 || d_r <= 0) return fail(KGE_ERR_ARG, "bad dims d_e=%d d_r=%d", d_e, d_r);
+    if (model == KGE_COMPLEX) {
+        if (d_e % 2 || d_r != d_e) return fail(KGE_ERR_ARG, "ComplEx needs even d_e and d_r == d_e (got %d, %d)", d_e, d_r);
+    } else if (model == KGE_ROTATE) {
+        if (d_e % 2 || d_r != d_e / 2) return fail(KGE_ERR_ARG, "RotatE needs d_r == d_e/2 (got d_e=%d d_r=%d)", d_e, d_r);
+    } else if (d_r != d_e) {
+        return fail(KGE_ERR_ARG, "%s needs d_r == d_e (got %d, %d)", "TransE/DistMult", d_e, d_r);
+    }
+    return KGE_OK;
+}
+
+inline float rot_div_of(float emb_init) { return (float)((double)emb_init / M_PI); }
+
+bool use_mfma(int model, int d_e, int N, unsigned flags) {
+    return !(flags & KGE_FLAG_FORCE_PAIRWISE) && neg_mfma_supported(model, d_e, N);
+}
+
+__global__ void l2_scale_kernel(const float *dneg, const float *score, float gamma, float *W, int64_t n) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const float d = gamma - score[k];
+    W[k] = d > 1e-15f ? dneg[k] / d : 0.f;
+}
+
+}  // namespace
+
+extern "C" {
+
+int kge_abi_version(void) { return KGE_ABI_VERSION; }
+const char *kge_last_error(void) { return g_err; }
+
+int kge_gather_rows(const float *table, int64_t n_rows, int dim, const int64_t *idx, int64_t n_idx,
+                    float *out, void *stream) {
+    if (!table || !out || (!idx && n_idx) || dim <= 0 || n_rows < 0 || n_idx < 0)
+        return fail(KGE_ERR_ARG, "kge_gather_rows: bad argument");
+    KGE_TRY(launch_gather_rows(table, dim, idx, n_idx, out, (hipStream_t)stream));
+    return KGE_OK;
+}
+
+int kge_score_pos(int model, const float *h, const float *r, const float *t, int64_t B, int d_e,
+                  int d_r, float gamma, float emb_init, float *out, void *stream) {
+    if (int rc = check_model(model, d_e, d_r)) return rc;
+    if (!h || !r || !t || !out || B < 0) return fail(KGE_ERR_ARG, "kge_score_pos: bad argument");
+    EdgeFwdArgs a{};
+    a.src = EdgeSrc{h, nullptr, t, nullptr, r, nullptr};
+    a.B = (int)B; a.d_e = d_e; a.d_r = d_r; a.neg_head = 0; a.model = model;
+    a.gamma = gamma; a.rot_div = rot_div_of(emb_init);
+    a.pos_score = out;
+    KGE_TRY(launch_edge_fwd(a, (hipStream_t)stream));
+    return KGE_OK;
+}
+
+int kge_score_pos_bwd(int model, const float *h, const float *r, const float *t, const float *dpos,
+                      int64_t B, int d_e, int d_r, float gamma, float emb_init, float *gh, float *gr,
+                      float *gt, void *stream) {
+    if (int rc = check_model(model, d_e, d_r)) return rc;
+    if (!h || !r || !t || !dpos || B < 0) return fail(KGE_ERR_ARG, "kge_score_pos_bwd: bad argument");
+    EdgeBwdArgs a{};
+    a.src = EdgeSrc{h, nullptr, t, nullptr, r, nullptr};
+    a.B = (int)B; a.d_e = d_e; a.d_r = d_r; a.neg_head = 0; a.model = model;
+    a.gamma = gamma; a.rot_div = rot_div_of(emb_init);
+    a.dpos = dpos; a.GA = nullptr; a.reg_coef = 0.f; a.reg_norm = 0;
+    a.GH = gh; a.GT = gt; a.GR = gr;
+    KGE_TRY(launch_edge_bwd(a, (hipStream_t)stream));
+    return KGE_OK;
+}
+
+size_t kge_score_neg_workspace_bytes(int model, int C, int chunk, int N, int d_e) {
+    (void)model;
+    const size_t B = (size_t)C * chunk, CN = (size_t)C * N;
+    size_t n = 0;
+    n += align_up(B * d_e * sizeof(float));      // A
+    n += align_up(B * sizeof(float));            // asq
+    n += align_up(CN * sizeof(float));           // bsq
+    n += align_up(B * (size_t)N * sizeof(float)); // W (L2-scaled dneg)
+    n += align_up(B * d_e * sizeof(float));      // GA
+    return n;
+}
+
+static int neg_prepare(int model, int neg_head, const float *pos_side, const float *rel,
+                       const float *neg, int C, int chunk, int N, int d_e, int d_r, float gamma,
+                       float emb_init, bool mfma, Carver &cv, NegArgs &na, hipStream_t s) {
+    const int B = C * chunk, CN = C * N;
+    float *A = cv.f((size_t)B * d_e), *asq = cv.f(B), *bsq = cv.f(CN);
+    if (!cv.ok()) return fail(KGE_ERR_WORKSPACE, "workspace too small");
+    EdgeFwdArgs a{};
+    a.src = EdgeSrc{pos_side, nullptr, pos_side, nullptr, rel, nullptr};
+    a.B = B; a.d_e = d_e; a.d_r = d_r; a.neg_head = neg_head; a.model = model;
+    a.gamma = gamma; a.rot_div = rot_div_of(emb_init);
+    a.A = A;
+    const bool l2m = mfma && model == KGE_TRANSE_L2;
+    a.asq = l2m ? asq : nullptr;
+    a.nbase = neg; a.nidx = nullptr; a.n_neg = CN; a.bsq = l2m ? bsq : nullptr;
+    KGE_TRY(launch_edge_fwd(a, s));
+    na = NegArgs{};
+    na.model = model; na.C = C; na.chunk = chunk; na.N = N; na.d_e = d_e; na.gamma = gamma;
+    na.A = A; na.asq = asq; na.nbase = neg; na.nidx = nullptr; na.bsq = bsq;
+    return KGE_OK;
+}
+
+int kge_score_neg_fwd(int model, int neg_head, const float *pos_side, const float *rel,
+                      const float *neg, int C, int chunk, int N, int d_e, int d_r, float gamma,
+                      float emb_init, float *out, void *ws, size_t ws_bytes, unsigned flags,
+                      void *stream) {
+    if (int rc = check_model(model, d_e, d_r)) return rc;
+    if (!pos_side || !rel || !neg || !out || !ws || C < 0 || chunk <= 0 || N <= 0)
+        return fail(KGE_ERR_ARG, "kge_score_neg_fwd: bad argument");
+    if (C == 0) return KGE_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const bool mfma = use_mfma(model, d_e, N, flags);
+    Carver cv(ws, ws_bytes);
+    NegArgs na;
+    if (int rc = neg_prepare(model, neg_head, pos_side, rel, neg, C, chunk, N, d_e, d_r, gamma,
+                             emb_init, mfma, cv, na, s)) return rc;
+    na.S = out;
+    if (mfma) KGE_TRY(launch_neg_fwd_mfma(na, s)); else KGE_TRY(launch_neg_fwd_pair(na, s));
+    return KGE_OK;
+}
+
+int kge_score_neg_bwd(int model, int neg_head, const float *pos_side, const float *rel,
+                      const float *neg, const float *neg_score, const float *dneg, int C,
+                      int chunk, int N, int d_e, int d_r, float gamma, float emb_init,
+                      float *g_pos_side, float *g_rel, float *g_neg, void *ws, size_t ws_bytes,
+                      unsigned flags, void *stream) {
+    if (int rc = check_model(model, d_e, d_r)) return rc;
+    if (!pos_side || !rel || !neg || !dneg || !g_pos_side || !g_rel || !g_neg || !ws || C < 0 ||
+        chunk <= 0 || N <= 0)
+        return fail(KGE_ERR_ARG, "kge_score_neg_bwd: bad argument");
+    if (model == KGE_TRANSE_L2 && !neg_score)
+        return fail(KGE_ERR_ARG, "kge_score_neg_bwd: TransE_l2 needs the forward scores");
+    if (C == 0) return KGE_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const bool mfma = use_mfma(model, d_e, N, flags);
+    const int B = C * chunk;
+    Carver cv(ws, ws_bytes);
+    NegArgs na;
+    if (int rc = neg_prepare(model, neg_head, pos_side, rel, neg, C, chunk, N, d_e, d_r, gamma,
+                             emb_init, mfma, cv, na, s)) return rc;
+    float *W = cv.f((size_t)B * N), *GA = cv.f((size_t)B * d_e);
+    if (!cv.ok()) return fail(KGE_ERR_WORKSPACE, "workspace too small: need %zu bytes",
+                              kge_score_neg_workspace_bytes(model, C, chunk, N, d_e));
+    if (model == KGE_TRANSE_L2) {
+        const int64_t n = (int64_t)B * N;
+        hipLaunchKernelGGL(l2_scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dneg,
+                           neg_score, gamma, W, n);
+        na.W = W;
+    } else {
+        na.W = dneg;
+    }
+    na.GA = GA; na.GN = g_neg; na.reg_coef = 0.f; na.reg_norm = 0;
+    if (mfma) KGE_TRY(launch_neg_bwd_mfma(na, s)); else KGE_TRY(launch_neg_bwd_pair(na, s));
+    EdgeBwdArgs e{};
+    e.src = EdgeSrc{pos_side, nullptr, pos_side, nullptr, rel, nullptr};
+    e.B = B; e.d_e = d_e; e.d_r = d_r; e.neg_head = neg_head; e.model = model;
+    e.gamma = gamma; e.rot_div = rot_div_of(emb_init);
+    e.dpos = nullptr; e.GA = GA; e.reg_coef = 0.f; e.reg_norm = 0;
+    e.GH = neg_head ? nullptr : g_pos_side;
+    e.GT = neg_head ? g_pos_side : nullptr;
+    e.GR = g_rel;
+    KGE_TRY(launch_edge_bwd(e, s));
+    return KGE_OK;
+}
+
+int kge_loss_fwd_bwd(int loss_genre, int adv, float adv_temp, int pairwise, float margin,
+                     const float *pos, const float *neg, const float *w, int64_t B, int N,
+                     float *loss3, float *dpos, float *dneg, void *ws, size_t ws_bytes,
+                     void *stream) {
+    if (loss_genre < KGE_LOSS_LOGSIGMOID || loss_genre > KGE_LOSS_BCE)
+        return fail(KGE_ERR_ARG, "unknown loss genre %d", loss_genre);
+    if (pairwise && adv) return fail(KGE_ERR_ARG, "loss cannot be pairwise and adversarial sampled");
+    if (pairwise && loss_genre != KGE_LOSS_LOGISTIC && loss_genre != KGE_LOSS_HINGE)
+        return fail(KGE_ERR_ARG, "this loss cannot be applied to pairwise loss function");
+    if (!pos || !neg || !dpos || !dneg || !ws || B <= 0 || N <= 0)
+        return fail(KGE_ERR_ARG, "kge_loss_fwd_bwd: bad argument");
+    Carver cv(ws, ws_bytes);
+    float *row_pos = cv.f(B), *row_neg = cv.f(B);
+    if (!cv.ok()) return fail(KGE_ERR_WORKSPACE, "workspace too small");
+    LossArgs a{};
+    a.B = (int)B; a.N = N; a.genre = loss_genre; a.adv = adv; a.pairwise = pairwise;
+    a.adv_temp = adv_temp; a.margin = margin; a.pos = pos; a.neg = neg; a.w = w;
+    a.dpos = dpos; a.dneg = dneg; a.row_pos = row_pos; a.row_neg = row_neg;
+    a.l2_scale = 0; a.gamma = 0.f; a.neg_copy = nullptr;
+    KGE_TRY(launch_loss(a, (hipStream_t)stream));
+    if (loss3) {
+        // finalize writes 4 floats {pos, neg, loss, reg}; loss3 has room for 3 -> stage in ws
+        float *l4 = cv.f(4);
+        if (!cv.ok()) return fail(KGE_ERR_WORKSPACE, "workspace too small");
+        FinalizeArgs f{};
+        f.B = (int)B; f.UE = 0; f.UR = 0; f.pairwise = pairwise;
+        f.row_pos = row_pos; f.row_neg = row_neg; f.loss4 = l4;
+        KGE_TRY(launch_finalize(f, (hipStream_t)stream));
+        if (hipMemcpyAsync(loss3, l4, 3 * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
+            return fail(KGE_ERR_LAUNCH, "hipMemcpyAsync failed");
+    }
+    return KGE_OK;
+}
+
+int kge_adagrad_scatter(float *table, float *state_sum, int64_t n_rows, int dim, const int64_t *idx,
+                        const float *grad, int64_t n_idx, float lr, float eps, void *stream) {
+    if (!table || !state_sum || (!idx && n_idx) || (!grad && n_idx) || dim <= 0 || n_rows < 0)
+        return fail(KGE_ERR_ARG, "kge_adagrad_scatter: bad argument");
+    KGE_TRY(launch_adagrad_scatter(table, state_sum, dim, idx, grad, n_idx, lr, eps, (hipStream_t)stream));
+    return KGE_OK;
+}
+
+int kge_adagrad_apply_rows(float *table, float *state_sum, int64_t n_rows, int dim,
+                           const int64_t *idx, const float *g, const float *gs, int64_t n, float lr,
+                           float eps, void *stream) {
+    if (!table || !state_sum || (n && (!idx || !g || !gs)) || dim <= 0 || n_rows < 0)
+        return fail(KGE_ERR_ARG, "kge_adagrad_apply_rows: bad argument");
+    KGE_TRY(launch_adagrad_apply_rows(table, state_sum, dim, idx, g, gs, n, lr, eps, (hipStream_t)stream));
+    return KGE_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// fused step
+// ------------------------------------------------------------------------------------------
+size_t kge_step_workspace_bytes(const kge_hparams *hp, int B, int C, int chunk, int N, int UE, int UR) {
+    (void)chunk;
+    const size_t d_e = hp->d_e, d_r = hp->d_r, CN = (size_t)C * N;
+    size_t n = 0;
+    auto add = [&](size_t floats) { n += align_up(floats * sizeof(float)); };
+    add(B * d_e);        // A
+    add(B); add(CN);     // asq, bsq
+    add(B); add(B);      // pos score, dpos
+    add((size_t)B * N);  // S / W
+    add(B * d_e);        // GA
+    add(CN * d_e);       // GN
+    add(B * d_e); add(B * d_e); add(B * d_r);   // GH, GT, GR
+    add(B); add(B); add(UE); add(UR);           // row_pos, row_neg, reg_ent, reg_rel
+    return n;
+}
+
+static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batch *b,
+                     const kge_step_out *out, const kge_emit *emit, void *ws, size_t ws_bytes,
+                     void *stream) {
+    if (!hp || !tb || !b || !ws) return fail(KGE_ERR_ARG, "kge_step: null argument");
+    if (int rc = check_model(hp->model, hp->d_e, hp->d_r)) return rc;
+    if (b->B <= 0 || b->C <= 0 || b->chunk <= 0 || b->N <= 0 || (int64_t)b->C * b->chunk != b->B)
+        return fail(KGE_ERR_ARG, "kge_step: need C*chunk == B (B=%d C=%d chunk=%d)", b->B, b->C, b->chunk);
+    if (hp->pairwise && hp->adv) return fail(KGE_ERR_ARG, "loss cannot be pairwise and adversarial sampled");
+    if (hp->pairwise && hp->loss_genre != KGE_LOSS_LOGISTIC && hp->loss_genre != KGE_LOSS_HINGE)
+        return fail(KGE_ERR_ARG, "this loss cannot be applied to pairwise loss function");
+    if (!tb->ent || !tb->ent_state || !tb->rel || !tb->rel_state || !b->h_gid || !b->t_gid ||
+        !b->rel_ids || !b->neg_ids || !b->ue_id || !b->ue_pos_ptr || !b->ue_pos_adj ||
+        !b->ue_neg_ptr || !b->ue_neg_slot || !b->ur_id || !b->ur_ptr || !b->ur_edge)
+        return fail(KGE_ERR_ARG, "kge_step: null table / batch pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int B = b->B, C = b->C, chunk = b->chunk, N = b->N, CN = C * N;
+    const int d_e = hp->d_e, d_r = hp->d_r;
+    const bool mfma = use_mfma(hp->model, d_e, N, hp->flags);
+    const bool l2m = mfma && hp->model == KGE_TRANSE_L2;      // GEMM form with rank-1 terms
+    const bool l2p = !mfma && hp->model == KGE_TRANSE_L2;     // direct pairwise form
+    const bool reg = hp->reg_coef > 0.f && hp->reg_norm > 0;
+
+    Carver cv(ws, ws_bytes);
+    float *A = cv.f((size_t)B * d_e), *asq = cv.f(B), *bsq = cv.f(CN);
+    float *P = cv.f(B), *dP = cv.f(B);
+    float *S = cv.f((size_t)B * N);
+    float *GA = cv.f((size_t)B * d_e), *GN = cv.f((size_t)CN * d_e);
+    float *GH = cv.f((size_t)B * d_e), *GT = cv.f((size_t)B * d_e), *GR = cv.f((size_t)B * d_r);
+    float *row_pos = cv.f(B), *row_neg = cv.f(B), *reg_ent = cv.f(b->UE), *reg_rel = cv.f(b->UR);
+    if (!cv.ok())
+        return fail(KGE_ERR_WORKSPACE, "kge_step: workspace too small (%zu < %zu)", ws_bytes,
+                    kge_step_workspace_bytes(hp, B, C, chunk, N, b->UE, b->UR));
+    if (out && out->pos_score) P = out->pos_score;
+    if (out && out->g_neg) GN = out->g_neg;
+    if (out && out->g_rel) GR = out->g_rel;
+
+    const EdgeSrc src{tb->ent, b->h_gid, tb->ent, b->t_gid, tb->rel, b->rel_ids};
+    const float rot_div = rot_div_of(hp->emb_init);
+
+    // 1. gather + positive score + pos-side vectors (+ squared norms for the L2 GEMM form)
+    EdgeFwdArgs ef{};
+    ef.src = src; ef.B = B; ef.d_e = d_e; ef.d_r = d_r; ef.neg_head = b->neg_head; ef.model = hp->model;
+    ef.gamma = hp->gamma; ef.rot_div = rot_div;
+    ef.pos_score = P; ef.A = A; ef.asq = l2m ? asq : nullptr;
+    ef.nbase = tb->ent; ef.nidx = b->neg_ids; ef.n_neg = CN; ef.bsq = l2m ? bsq : nullptr;
+    KGE_TRY(launch_edge_fwd(ef, s));
+
+    // 2. chunked negative scores
+    NegArgs na{};
+    na.model = hp->model; na.C = C; na.chunk = chunk; na.N = N; na.d_e = d_e; na.gamma = hp->gamma;
+    na.A = A; na.asq = asq; na.nbase = tb->ent; na.nidx = b->neg_ids; na.bsq = bsq; na.S = S;
+    if (mfma) KGE_TRY(launch_neg_fwd_mfma(na, s)); else KGE_TRY(launch_neg_fwd_pair(na, s));
+
+    // 3. loss and d loss / d score (S is overwritten in place by W)
+    LossArgs la{};
+    la.B = B; la.N = N; la.genre = hp->loss_genre; la.adv = hp->adv; la.pairwise = hp->pairwise;
+    la.adv_temp = hp->adv_temp; la.margin = hp->margin;
+    la.pos = P; la.neg = S; la.w = b->edge_w; la.dpos = dP; la.dneg = S;
+    la.row_pos = row_pos; la.row_neg = row_neg;
+    la.l2_scale = (l2m || l2p) ? 1 : 0; la.gamma = hp->gamma;
+    la.neg_copy = out ? out->neg_score : nullptr;
+    KGE_TRY(launch_loss(la, s));
+
+    // 4. gradients w.r.t. the pos-side vectors and the negative rows
+    na.W = S; na.GA = GA; na.GN = GN;
+    na.reg_coef = reg ? hp->reg_coef : 0.f; na.reg_norm = hp->reg_norm;
+    if (mfma) KGE_TRY(launch_neg_bwd_mfma(na, s)); else KGE_TRY(launch_neg_bwd_pair(na, s));
+
+    // 5. per-edge gradients of head / tail / relation rows
+    EdgeBwdArgs eb{};
+    eb.src = src; eb.B = B; eb.d_e = d_e; eb.d_r = d_r; eb.neg_head = b->neg_head; eb.model = hp->model;
+    eb.gamma = hp->gamma; eb.rot_div = rot_div;
+    eb.dpos = dP; eb.GA = GA; eb.reg_coef = reg ? hp->reg_coef : 0.f; eb.reg_norm = hp->reg_norm;
+    eb.GH = GH; eb.GT = GT; eb.GR = GR;
+    KGE_TRY(launch_edge_bwd(eb, s));
+
+    // 6. owner-computes Adagrad on both tables (or gradient emission for sharded training)
+    UpdateArgs ua{};
+    ua.model_d_e = d_e; ua.d_r = d_r; ua.UE = b->UE; ua.UR = b->UR; ua.reg_norm = hp->reg_norm;
+    ua.lr = hp->lr; ua.eps = hp->eps; ua.reg_coef = reg ? hp->reg_coef : 0.f;
+    ua.ent = tb->ent; ua.ent_state = tb->ent_state; ua.rel = tb->rel; ua.rel_state = tb->rel_state;
+    ua.ue_id = b->ue_id; ua.ue_pos_ptr = b->ue_pos_ptr; ua.ue_pos_adj = b->ue_pos_adj;
+    ua.ue_neg_ptr = b->ue_neg_ptr; ua.ue_neg_slot = b->ue_neg_slot;
+    ua.ur_id = b->ur_id; ua.ur_ptr = b->ur_ptr; ua.ur_edge = b->ur_edge;
+    ua.GH = GH; ua.GT = GT; ua.GN = GN; ua.GR = GR;
+    ua.reg_ent = reg_ent; ua.reg_rel = reg_rel;
+    if (emit) {
+        ua.g0 = emit->g0; ua.gs0 = emit->gs0; ua.g1 = emit->g1; ua.gs1 = emit->gs1;
+        ua.gr = emit->gr; ua.gsr = emit->gsr;
+        ua.emit_ent = 1; ua.emit_rel = emit->gr ? 1 : 0;
+    }
+    if (out && out->g_pos_ent) ua.g0 = out->g_pos_ent;
+    KGE_TRY(launch_update(ua, s));
+
+    // 7. deterministic loss reduction
+    if (out && (out->loss4 || out->loss_accum)) {
+        FinalizeArgs f{};
+        f.B = B; f.UE = b->UE; f.UR = b->UR; f.pairwise = hp->pairwise;
+        f.row_pos = row_pos; f.row_neg = row_neg; f.reg_ent = reg_ent; f.reg_rel = reg_rel;
+        f.loss4 = out->loss4; f.accum = out->loss_accum;
+        KGE_TRY(launch_finalize(f, s));
+    }
+    return KGE_OK;
+}
+
+int kge_step_fused(const kge_hparams *hp, const kge_tables *tb, const kge_batch *b,
+                   const kge_step_out *out, void *ws, size_t ws_bytes, void *stream) {
+    return step_impl(hp, tb, b, out, nullptr, ws, ws_bytes, stream);
+}
+
+int kge_step_grads(const kge_hparams *hp, const kge_tables *tb, const kge_batch *b,
+                   const kge_step_out *out, const kge_emit *emit, void *ws, size_t ws_bytes,
+                   void *stream) {
+    if (!emit || !emit->g0 || !emit->gs0 || !emit->g1 || !emit->gs1)
+        return fail(KGE_ERR_ARG, "kge_step_grads: emit buffers g0/gs0/g1/gs1 are required");
+    if ((emit->gr == nullptr) != (emit->gsr == nullptr))
+        return fail(KGE_ERR_ARG, "kge_step_grads: gr and gsr must be given together");
+    return step_impl(hp, tb, b, out, emit, ws, ws_bytes, stream);
+}
+
+}  // extern "C"

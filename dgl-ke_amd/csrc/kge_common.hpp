@@ -1,0 +1,187 @@
+// kge_common.hpp - shared device helpers for the gfx950 KGE kernels.
+// Wavefront = 64 lanes everywhere in this library (CDNA4); one wavefront per embedding row is the
+// unit of work of all row-wise kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/kge_hip.h"
+
+#define KGE_WAVE 64
+#define KGE_BLOCK 256              // 4 wavefronts per workgroup, one per SIMD
+#define KGE_WAVES_PER_BLOCK (KGE_BLOCK / KGE_WAVE)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace kge {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// row pointer with optional one-level indirection: base + (idx ? idx[i] : i) * ld
+__device__ __forceinline__ const float *row_ptr(const float *base, const int64_t *idx, int64_t i,
+                                                int ld) {
+    const int64_t r = idx ? idx[i] : i;
+    return base + r * (int64_t)ld;
+}
+
+// V-wide load/store (V = 4: one 16-byte access; V = 1: scalar)
+template <int V> struct Pack { float v[V]; };
+template <int V> __device__ __forceinline__ Pack<V> ld(const float *p);
+template <> __device__ __forceinline__ Pack<4> ld<4>(const float *p) {
+    const float4 t = *reinterpret_cast<const float4 *>(p);
+    Pack<4> r; r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w; return r;
+}
+template <> __device__ __forceinline__ Pack<1> ld<1>(const float *p) {
+    Pack<1> r; r.v[0] = *p; return r;
+}
+template <int V> __device__ __forceinline__ void st(float *p, const Pack<V> &x);
+template <> __device__ __forceinline__ void st<4>(float *p, const Pack<4> &x) {
+    *reinterpret_cast<float4 *>(p) = make_float4(x.v[0], x.v[1], x.v[2], x.v[3]);
+}
+template <> __device__ __forceinline__ void st<1>(float *p, const Pack<1> &x) { *p = x.v[0]; }
+template <int V> __device__ __forceinline__ Pack<V> zero_pack() {
+    Pack<V> r;
+#pragma unroll
+    for (int e = 0; e < V; ++e) r.v[e] = 0.f;
+    return r;
+}
+
+__device__ __forceinline__ float sgnf(float x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); }
+
+// d/dx coef*|x|^q  (general_models.py:572-576; norm = x.norm(p)**p, tensor_models.py:54)
+__device__ __forceinline__ float reg_grad(float x, float coef, int q) {
+    const float ax = fabsf(x);
+    float pw;
+    if (q == 3) pw = ax * ax;
+    else if (q == 2) pw = ax;
+    else if (q == 1) pw = 1.f;
+    else pw = powf(ax, (float)(q - 1));
+    return coef * (float)q * pw * sgnf(x);
+}
+__device__ __forceinline__ float reg_val(float x, int q) {
+    const float ax = fabsf(x);
+    if (q == 3) return ax * ax * ax;
+    if (q == 2) return ax * ax;
+    if (q == 1) return ax;
+    return powf(ax, (float)q);
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) {
+    // numerically safe logistic
+    if (x >= 0.f) { return 1.f / (1.f + expf(-x)); }
+    const float e = expf(x);
+    return e / (1.f + e);
+}
+// -logsigmoid(z) = softplus(-z) = max(-z,0) + log1p(exp(-|z|))
+__device__ __forceinline__ float neg_logsigmoid(float z) {
+    return fmaxf(-z, 0.f) + log1pf(expf(-fabsf(z)));
+}
+
+constexpr bool is_complex_model(int m) { return m == KGE_COMPLEX || m == KGE_ROTATE; }
+
+}  // namespace kge
+
+// ------------------------------------------------------------------------------------------
+// kernel launch entry points implemented in the .hip files (host side, all enqueue on `stream`)
+// ------------------------------------------------------------------------------------------
+struct EdgeSrc {           // where the rows of one positive edge come from
+    const float *hbase; const int64_t *hidx;   // head rows  hbase + (hidx? hidx[i] : i)*d_e
+    const float *tbase; const int64_t *tidx;   // tail rows
+    const float *rbase; const int64_t *ridx;   // relation rows, ld = d_r
+};
+
+struct EdgeFwdArgs {
+    EdgeSrc src;
+    int B, d_e, d_r, neg_head, model;
+    float gamma, rot_div;            // rot_div = emb_init / pi (RotatE: phase = r / rot_div, score_fun.py:464)
+    float *pos_score;                // [B] or null
+    float *A;                        // [B,d_e] pos-side vectors or null
+    float *asq;                      // [B] |a|^2 (TransE_l2 GEMM form) or null
+    // extra row jobs folded into the same launch (fused step):
+    const float *nbase; const int64_t *nidx; int n_neg;  // negative rows -> bsq
+    float *bsq;                      // [n_neg] or null
+};
+
+struct EdgeBwdArgs {
+    EdgeSrc src;
+    int B, d_e, d_r, neg_head, model;
+    float gamma, rot_div;
+    const float *dpos;               // [B] dL/dp or null (no positive-score part)
+    const float *GA;                 // [B,d_e] dL/da or null (no negative-score part)
+    float reg_coef; int reg_norm;    // regularisation gradient added to the relation row grad
+    float *GH, *GT;                  // [B,d_e] (either may be null)
+    float *GR;                       // [B,d_r] or null
+};
+
+struct NegArgs {                     // chunked negative scoring, forward and backward
+    int model, C, chunk, N, d_e;
+    float gamma;
+    const float *A;                  // [C*chunk, d_e] pos-side vectors (dense)
+    const float *asq;                // [C*chunk] (L2 GEMM form) or null
+    const float *nbase; const int64_t *nidx;   // negative rows nbase + (nidx? nidx[j] : j)*d_e
+    const float *bsq;                // [C*N] or null
+    float *S;                        // fwd: out [C,chunk,N]
+    const float *W;                  // bwd: dL/dn (for L2: already divided by the distance)
+    float *GA;                       // bwd out [C*chunk, d_e]
+    float *GN;                       // bwd out [C*N, d_e]
+    float reg_coef; int reg_norm;    // (unused by the GEMM/pair kernels; regularisation is added
+                                     //  by the consumers of GN)
+};
+
+struct LossArgs {
+    int B, N, genre, adv, pairwise;
+    float adv_temp, margin;
+    const float *pos, *neg, *w;
+    float *dpos, *dneg;              // dneg may alias neg (in place)
+    float *row_pos, *row_neg;        // [B] per-row loss terms (already divided by B)
+    int l2_scale; float gamma;       // if set: dneg /= (gamma - n)   (TransE_l2 GEMM backward)
+    float *neg_copy;                 // optional copy of the scores before overwrite
+};
+
+struct UpdateArgs {
+    int model_d_e, d_r, UE, UR, reg_norm;
+    float lr, eps, reg_coef;
+    float *ent, *ent_state, *rel, *rel_state;
+    const int64_t *ue_id; const int32_t *ue_pos_ptr, *ue_pos_adj, *ue_neg_ptr, *ue_neg_slot;
+    const int64_t *ur_id; const int32_t *ur_ptr, *ur_edge;
+    const float *GH, *GT, *GN, *GR;
+    float *reg_ent, *reg_rel;        // [UE], [UR] regularisation value partials (or null)
+    // emit mode (sharded training): write gradients instead of updating the entity table
+    float *g0, *gs0, *g1, *gs1, *gr, *gsr;
+    int emit_ent, emit_rel;
+    float *out_g_pos;                // optional [UE,d_e] copy of the trace-0 gradient
+};
+
+struct FinalizeArgs {
+    int B, UE, UR, pairwise;
+    const float *row_pos, *row_neg, *reg_ent, *reg_rel;
+    float *loss4, *accum;
+};
+
+int launch_gather_rows(const float *table, int dim, const int64_t *idx, int64_t n, float *out,
+                       hipStream_t s);
+int launch_edge_fwd(const EdgeFwdArgs &a, hipStream_t s);
+int launch_edge_bwd(const EdgeBwdArgs &a, hipStream_t s);
+int launch_loss(const LossArgs &a, hipStream_t s);
+int launch_finalize(const FinalizeArgs &a, hipStream_t s);
+int launch_update(const UpdateArgs &a, hipStream_t s);
+int launch_adagrad_scatter(float *table, float *state, int dim, const int64_t *idx,
+                           const float *grad, int64_t n, float lr, float eps, hipStream_t s);
+int launch_adagrad_apply_rows(float *table, float *state, int dim, const int64_t *idx,
+                              const float *g, const float *gs, int64_t n, float lr, float eps,
+                              hipStream_t s);
+int launch_add_reg_rows(float *G, const float *base, const int64_t *idx, int64_t n, int dim,
+                        float coef, int q, hipStream_t s);
+bool neg_mfma_supported(int model, int d_e, int N);
+int launch_neg_fwd_mfma(const NegArgs &a, hipStream_t s);
+int launch_neg_bwd_mfma(const NegArgs &a, hipStream_t s);
+int launch_neg_fwd_pair(const NegArgs &a, hipStream_t s);
+int launch_neg_bwd_pair(const NegArgs &a, hipStream_t s);

@@ -1,0 +1,708 @@
+// kge_rowwise.hip - the row-wise (one wavefront per embedding row) kernels of the KGE hot path:
+//   gather                       ExternalEmbedding.__call__      tensor_models.py:292
+//   edge_fwd  (A3 + pos-side)    score_func.edge_func, head of create_neg closures
+//                                score_fun.py:54-59,94-105,229-235,270-283,297-307,347-371,
+//                                460-472,516-545
+//   loss      (A6)               LossGenerator.get_total_loss    loss.py:69-98
+//   edge_bwd  (A8)               autograd of the above, analytic
+//   update    (A9)               ExternalEmbedding.update        tensor_models.py:304-362
+// All of them are HBM/L2-bandwidth work: 16-byte loads per lane, one row per wavefront,
+// reductions by cross-lane shuffles, no LDS, no atomics on the fused path.
+#include "kge_common.hpp"
+
+using namespace kge;
+
+#define WAVE_ID() ((int64_t)blockIdx.x * KGE_WAVES_PER_BLOCK + (threadIdx.x >> 6))
+#define LANE() (threadIdx.x & 63)
+
+static inline int blocks_for_waves(int64_t waves) {
+    return (int)((waves + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK);
+}
+static inline int check_launch() {
+    return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
+}
+
+// ------------------------------------------------------------------------------------------
+// gather
+// ------------------------------------------------------------------------------------------
+template <int V>
+__global__ __launch_bounds__(KGE_BLOCK) void gather_kernel(const float *__restrict__ table, int dim,
+                                                           const int64_t *__restrict__ idx,
+                                                           int64_t n, float *__restrict__ out) {
+    const int64_t k = WAVE_ID();
+    if (k >= n) return;
+    const int lane = LANE();
+    const float *src = table + idx[k] * (int64_t)dim;
+    float *dst = out + k * (int64_t)dim;
+    for (int it = lane; it < dim / V; it += 64) st<V>(dst + it * V, ld<V>(src + it * V));
+}
+
+int launch_gather_rows(const float *table, int dim, const int64_t *idx, int64_t n, float *out,
+                       hipStream_t s) {
+    if (n == 0) return KGE_OK;
+    const int nb = blocks_for_waves(n);
+    if (dim % 4 == 0)
+        hipLaunchKernelGGL(gather_kernel<4>, dim3(nb), dim3(KGE_BLOCK), 0, s, table, dim, idx, n, out);
+    else
+        hipLaunchKernelGGL(gather_kernel<1>, dim3(nb), dim3(KGE_BLOCK), 0, s, table, dim, idx, n, out);
+    return check_launch();
+}
+
+// ------------------------------------------------------------------------------------------
+// edge forward: positive score p_i, pos-side vector a_i (and |a_i|^2), |neg_j|^2
+// ------------------------------------------------------------------------------------------
+template <int MODEL, int V>
+__global__ __launch_bounds__(KGE_BLOCK) void edge_fwd_kernel(EdgeFwdArgs a) {
+    const int64_t w = WAVE_ID();
+    const int lane = LANE();
+    if (w < a.B) {
+        const int64_t i = w;
+        const float *h = row_ptr(a.src.hbase, a.src.hidx, i, a.d_e);
+        const float *t = row_ptr(a.src.tbase, a.src.tidx, i, a.d_e);
+        const float *r = row_ptr(a.src.rbase, a.src.ridx, i, a.d_r);
+        float *A = a.A ? a.A + i * (int64_t)a.d_e : nullptr;
+        float ps = 0.f, as = 0.f;
+        if constexpr (!is_complex_model(MODEL)) {
+            const int nit = a.d_e / V;
+            for (int it = lane; it < nit; it += 64) {
+                const int off = it * V;
+                const Pack<V> hv = ld<V>(h + off), rv = ld<V>(r + off), tv = ld<V>(t + off);
+                Pack<V> av;
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    const float hh = hv.v[e], rr = rv.v[e], tt = tv.v[e];
+                    const float x = a.neg_head ? tt : hh;
+                    if constexpr (MODEL == KGE_DISTMULT) {
+                        ps += hh * rr * tt;
+                        av.v[e] = x * rr;
+                    } else {
+                        const float u = hh + rr - tt;
+                        if constexpr (MODEL == KGE_TRANSE_L1) ps += fabsf(u); else ps += u * u;
+                        av.v[e] = a.neg_head ? (x - rr) : (x + rr);
+                    }
+                    as += av.v[e] * av.v[e];
+                }
+                if (A) st<V>(A + off, av);
+            }
+        } else {
+            const int hd = a.d_e / 2;
+            const int nit = hd / V;
+            for (int it = lane; it < nit; it += 64) {
+                const int off = it * V;
+                const Pack<V> rh = ld<V>(h + off), ih = ld<V>(h + hd + off);
+                const Pack<V> rt = ld<V>(t + off), it_ = ld<V>(t + hd + off);
+                Pack<V> rr, ir;
+                if constexpr (MODEL == KGE_COMPLEX) {
+                    rr = ld<V>(r + off); ir = ld<V>(r + hd + off);
+                } else {
+                    const Pack<V> ph = ld<V>(r + off);
+#pragma unroll
+                    for (int e = 0; e < V; ++e) sincosf(ph.v[e] / a.rot_div, &ir.v[e], &rr.v[e]);
+                }
+                Pack<V> are, aim;
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    const float c = rr.v[e], s = ir.v[e];
+                    if constexpr (MODEL == KGE_COMPLEX) {
+                        ps += rh.v[e] * rt.v[e] * c + ih.v[e] * it_.v[e] * c +
+                              rh.v[e] * it_.v[e] * s - ih.v[e] * rt.v[e] * s;
+                    } else {
+                        const float re = rh.v[e] * c - ih.v[e] * s - rt.v[e];
+                        const float im = rh.v[e] * s + ih.v[e] * c - it_.v[e];
+                        ps += sqrtf(re * re + im * im);
+                    }
+                    if (a.neg_head) {   // a = t o conj(r)
+                        are.v[e] = rt.v[e] * c + it_.v[e] * s;
+                        aim.v[e] = -rt.v[e] * s + it_.v[e] * c;
+                    } else {            // a = h o r
+                        are.v[e] = rh.v[e] * c - ih.v[e] * s;
+                        aim.v[e] = rh.v[e] * s + ih.v[e] * c;
+                    }
+                    as += are.v[e] * are.v[e] + aim.v[e] * aim.v[e];
+                }
+                if (A) { st<V>(A + off, are); st<V>(A + hd + off, aim); }
+            }
+        }
+        if (a.pos_score) {
+            ps = wave_sum(ps);
+            if (lane == 0) {
+                float p;
+                if constexpr (MODEL == KGE_TRANSE_L1 || MODEL == KGE_ROTATE) p = a.gamma - ps;
+                else if constexpr (MODEL == KGE_TRANSE_L2) p = a.gamma - sqrtf(ps);
+                else p = ps;
+                a.pos_score[i] = p;
+            }
+        }
+        if (a.asq) {
+            as = wave_sum(as);
+            if (lane == 0) a.asq[i] = as;
+        }
+    } else if (w < (int64_t)a.B + a.n_neg) {
+        const int64_t j = w - a.B;
+        const float *x = row_ptr(a.nbase, a.nidx, j, a.d_e);
+        float s = 0.f;
+        for (int it = lane; it < a.d_e / V; it += 64) {
+            const Pack<V> v = ld<V>(x + it * V);
+#pragma unroll
+            for (int e = 0; e < V; ++e) s += v.v[e] * v.v[e];
+        }
+        s = wave_sum(s);
+        if (lane == 0) a.bsq[j] = s;
+    }
+}
+
+template <int MODEL>
+static int launch_edge_fwd_m(const EdgeFwdArgs &a, hipStream_t s) {
+    const int64_t waves = (int64_t)a.B + (a.bsq ? a.n_neg : 0);
+    EdgeFwdArgs b = a;
+    if (!a.bsq) b.n_neg = 0;
+    const int nb = blocks_for_waves(waves);
+    const bool cx = is_complex_model(MODEL);
+    const bool vec = cx ? ((a.d_e / 2) % 4 == 0 && a.d_r % 4 == 0) : (a.d_e % 4 == 0);
+    if (vec)
+        hipLaunchKernelGGL((edge_fwd_kernel<MODEL, 4>), dim3(nb), dim3(KGE_BLOCK), 0, s, b);
+    else
+        hipLaunchKernelGGL((edge_fwd_kernel<MODEL, 1>), dim3(nb), dim3(KGE_BLOCK), 0, s, b);
+    return check_launch();
+}
+
+int launch_edge_fwd(const EdgeFwdArgs &a, hipStream_t s) {
+    if (a.B == 0) return KGE_OK;
+    switch (a.model) {
+        case KGE_TRANSE_L1: return launch_edge_fwd_m<KGE_TRANSE_L1>(a, s);
+        case KGE_TRANSE_L2: return launch_edge_fwd_m<KGE_TRANSE_L2>(a, s);
+        case KGE_DISTMULT: return launch_edge_fwd_m<KGE_DISTMULT>(a, s);
+        case KGE_COMPLEX: return launch_edge_fwd_m<KGE_COMPLEX>(a, s);
+        case KGE_ROTATE: return launch_edge_fwd_m<KGE_ROTATE>(a, s);
+    }
+    return KGE_ERR_ARG;
+}
+
+// ------------------------------------------------------------------------------------------
+// edge backward: per-edge gradients of the head row, the tail row and the relation row
+//   = dpos_i * d p_i/d(h,r,t)  +  chain of GA_i = dL/da_i through a_i = T(x_i, r_i)
+//   (+ regularisation gradient of the relation row copy)
+// ------------------------------------------------------------------------------------------
+template <int MODEL, int V>
+__global__ __launch_bounds__(KGE_BLOCK) void edge_bwd_kernel(EdgeBwdArgs a) {
+    const int64_t i = WAVE_ID();
+    if (i >= a.B) return;
+    const int lane = LANE();
+    const float *h = row_ptr(a.src.hbase, a.src.hidx, i, a.d_e);
+    const float *t = row_ptr(a.src.tbase, a.src.tidx, i, a.d_e);
+    const float *r = row_ptr(a.src.rbase, a.src.ridx, i, a.d_r);
+    const float dp = a.dpos ? a.dpos[i] : 0.f;
+    const float *ga = a.GA ? a.GA + i * (int64_t)a.d_e : nullptr;
+    float *GH = a.GH ? a.GH + i * (int64_t)a.d_e : nullptr;
+    float *GT = a.GT ? a.GT + i * (int64_t)a.d_e : nullptr;
+    float *GR = a.GR ? a.GR + i * (int64_t)a.d_r : nullptr;
+    const bool reg = a.reg_coef > 0.f && a.reg_norm > 0;
+
+    if constexpr (!is_complex_model(MODEL)) {
+        const int nit = a.d_e / V;
+        float inv = 0.f;
+        if constexpr (MODEL == KGE_TRANSE_L2) {
+            if (a.dpos) {   // |h + r - t|_2 for the positive-score gradient
+                float ss = 0.f;
+                for (int it = lane; it < nit; it += 64) {
+                    const int off = it * V;
+                    const Pack<V> hv = ld<V>(h + off), rv = ld<V>(r + off), tv = ld<V>(t + off);
+#pragma unroll
+                    for (int e = 0; e < V; ++e) { const float u = hv.v[e] + rv.v[e] - tv.v[e]; ss += u * u; }
+                }
+                ss = sqrtf(wave_sum(ss));
+                inv = ss > 0.f ? 1.f / ss : 0.f;
+            }
+        }
+        for (int it = lane; it < nit; it += 64) {
+            const int off = it * V;
+            const Pack<V> hv = ld<V>(h + off), rv = ld<V>(r + off), tv = ld<V>(t + off);
+            const Pack<V> gav = ga ? ld<V>(ga + off) : zero_pack<V>();
+            Pack<V> gh, gt, gr;
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const float hh = hv.v[e], rr = rv.v[e], tt = tv.v[e], g = gav.v[e];
+                float o_h, o_t, o_r;
+                if constexpr (MODEL == KGE_DISTMULT) {
+                    o_h = dp * rr * tt; o_r = dp * hh * tt; o_t = dp * hh * rr;
+                    if (a.neg_head) { o_t += g * rr; o_r += g * tt; }
+                    else            { o_h += g * rr; o_r += g * hh; }
+                } else {
+                    const float u = hh + rr - tt;
+                    const float d = (MODEL == KGE_TRANSE_L1) ? sgnf(u) : u * inv;
+                    o_h = -dp * d; o_r = -dp * d; o_t = dp * d;
+                    if (a.neg_head) { o_t += g; o_r -= g; }
+                    else            { o_h += g; o_r += g; }
+                }
+                if (reg) o_r += reg_grad(rr, a.reg_coef, a.reg_norm);
+                gh.v[e] = o_h; gt.v[e] = o_t; gr.v[e] = o_r;
+            }
+            if (GH) st<V>(GH + off, gh);
+            if (GT) st<V>(GT + off, gt);
+            if (GR) st<V>(GR + off, gr);
+        }
+    } else {
+        const int hd = a.d_e / 2;
+        const int nit = hd / V;
+        for (int it = lane; it < nit; it += 64) {
+            const int off = it * V;
+            const Pack<V> rh = ld<V>(h + off), ih = ld<V>(h + hd + off);
+            const Pack<V> rt = ld<V>(t + off), it_ = ld<V>(t + hd + off);
+            const Pack<V> gre = ga ? ld<V>(ga + off) : zero_pack<V>();
+            const Pack<V> gim = ga ? ld<V>(ga + hd + off) : zero_pack<V>();
+            Pack<V> o_rh, o_ih, o_rt, o_it;
+            if constexpr (MODEL == KGE_COMPLEX) {
+                const Pack<V> rr = ld<V>(r + off), ir = ld<V>(r + hd + off);
+                Pack<V> o_rr, o_ir;
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    const float a_rh = rh.v[e], a_ih = ih.v[e], a_rt = rt.v[e], a_it = it_.v[e];
+                    const float c = rr.v[e], s = ir.v[e], gr_ = gre.v[e], gi_ = gim.v[e];
+                    float v_rh = dp * (a_rt * c + a_it * s);
+                    float v_ih = dp * (a_it * c - a_rt * s);
+                    float v_rt = dp * (a_rh * c - a_ih * s);
+                    float v_it = dp * (a_ih * c + a_rh * s);
+                    float v_rr = dp * (a_rh * a_rt + a_ih * a_it);
+                    float v_ir = dp * (a_rh * a_it - a_ih * a_rt);
+                    if (a.neg_head) {   // a = t o conj(r)
+                        v_rt += gr_ * c - gi_ * s;
+                        v_it += gr_ * s + gi_ * c;
+                        v_rr += gr_ * a_rt + gi_ * a_it;
+                        v_ir += gr_ * a_it - gi_ * a_rt;
+                    } else {            // a = h o r
+                        v_rh += gr_ * c + gi_ * s;
+                        v_ih += -gr_ * s + gi_ * c;
+                        v_rr += gr_ * a_rh + gi_ * a_ih;
+                        v_ir += -gr_ * a_ih + gi_ * a_rh;
+                    }
+                    if (reg) {
+                        v_rr += reg_grad(c, a.reg_coef, a.reg_norm);
+                        v_ir += reg_grad(s, a.reg_coef, a.reg_norm);
+                    }
+                    o_rh.v[e] = v_rh; o_ih.v[e] = v_ih; o_rt.v[e] = v_rt; o_it.v[e] = v_it;
+                    o_rr.v[e] = v_rr; o_ir.v[e] = v_ir;
+                }
+                if (GR) { st<V>(GR + off, o_rr); st<V>(GR + hd + off, o_ir); }
+            } else {   // RotatE
+                const Pack<V> ph = ld<V>(r + off);
+                Pack<V> o_r;
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    float s, c;
+                    sincosf(ph.v[e] / a.rot_div, &s, &c);
+                    const float a_rh = rh.v[e], a_ih = ih.v[e], a_rt = rt.v[e], a_it = it_.v[e];
+                    const float re = a_rh * c - a_ih * s - a_rt;
+                    const float im = a_rh * s + a_ih * c - a_it;
+                    const float m = sqrtf(re * re + im * im);
+                    const float iv = m > 0.f ? 1.f / m : 0.f;
+                    // p = gamma - sum m  ->  upstream on the rotated head is -dp*(re,im)/m
+                    const float ure = -dp * re * iv, uim = -dp * im * iv;
+                    float v_rh = ure * c + uim * s;
+                    float v_ih = -ure * s + uim * c;
+                    float v_rt = -ure, v_it = -uim;
+                    float gphi = ure * (-a_rh * s - a_ih * c) + uim * (a_rh * c - a_ih * s);
+                    const float gr_ = gre.v[e], gi_ = gim.v[e];
+                    if (a.neg_head) {   // a = t o e^{-i phi}
+                        v_rt += gr_ * c - gi_ * s;
+                        v_it += gr_ * s + gi_ * c;
+                        gphi += gr_ * (-a_rt * s + a_it * c) + gi_ * (-a_rt * c - a_it * s);
+                    } else {            // a = h o e^{i phi}
+                        v_rh += gr_ * c + gi_ * s;
+                        v_ih += -gr_ * s + gi_ * c;
+                        gphi += gr_ * (-a_rh * s - a_ih * c) + gi_ * (a_rh * c - a_ih * s);
+                    }
+                    float v_r = gphi / a.rot_div;
+                    if (reg) v_r += reg_grad(ph.v[e], a.reg_coef, a.reg_norm);
+                    o_rh.v[e] = v_rh; o_ih.v[e] = v_ih; o_rt.v[e] = v_rt; o_it.v[e] = v_it;
+                    o_r.v[e] = v_r;
+                }
+                if (GR) st<V>(GR + off, o_r);
+            }
+            if (GH) { st<V>(GH + off, o_rh); st<V>(GH + hd + off, o_ih); }
+            if (GT) { st<V>(GT + off, o_rt); st<V>(GT + hd + off, o_it); }
+        }
+    }
+}
+
+template <int MODEL>
+static int launch_edge_bwd_m(const EdgeBwdArgs &a, hipStream_t s) {
+    const int nb = blocks_for_waves(a.B);
+    const bool cx = is_complex_model(MODEL);
+    const bool vec = cx ? ((a.d_e / 2) % 4 == 0 && a.d_r % 4 == 0) : (a.d_e % 4 == 0);
+    if (vec)
+        hipLaunchKernelGGL((edge_bwd_kernel<MODEL, 4>), dim3(nb), dim3(KGE_BLOCK), 0, s, a);
+    else
+        hipLaunchKernelGGL((edge_bwd_kernel<MODEL, 1>), dim3(nb), dim3(KGE_BLOCK), 0, s, a);
+    return check_launch();
+}
+
+int launch_edge_bwd(const EdgeBwdArgs &a, hipStream_t s) {
+    if (a.B == 0) return KGE_OK;
+    switch (a.model) {
+        case KGE_TRANSE_L1: return launch_edge_bwd_m<KGE_TRANSE_L1>(a, s);
+        case KGE_TRANSE_L2: return launch_edge_bwd_m<KGE_TRANSE_L2>(a, s);
+        case KGE_DISTMULT: return launch_edge_bwd_m<KGE_DISTMULT>(a, s);
+        case KGE_COMPLEX: return launch_edge_bwd_m<KGE_COMPLEX>(a, s);
+        case KGE_ROTATE: return launch_edge_bwd_m<KGE_ROTATE>(a, s);
+    }
+    return KGE_ERR_ARG;
+}
+
+// ------------------------------------------------------------------------------------------
+// loss + d loss / d score.  One wavefront per positive edge (row of the [B,N] negative scores).
+// ------------------------------------------------------------------------------------------
+// criterion value and derivative w.r.t. the score for label l (loss.py:10-38)
+__device__ __forceinline__ void criterion(int genre, float s, float label, float margin,
+                                          float &val, float &dval) {
+    if (genre == KGE_LOSS_HINGE) {
+        const float v = margin - label * s;
+        val = v < 0.f ? 0.f : v;
+        dval = v < 0.f ? 0.f : -label;
+    } else if (genre == KGE_LOSS_BCE) {
+        // -(l*log(sig(s)) + (1-l)*log(1-sig(s))), written with softplus for stability
+        val = label * neg_logsigmoid(s) + (1.f - label) * neg_logsigmoid(-s);
+        dval = sigmoidf_(s) - label;
+    } else {   // Logsigmoid / Logistic: -logsigmoid(l*s) == softplus(-l*s)
+        const float z = label * s;
+        val = neg_logsigmoid(z);
+        dval = -label * sigmoidf_(-z);
+    }
+}
+
+__global__ __launch_bounds__(KGE_BLOCK) void loss_kernel(LossArgs a) {
+    const int64_t i = WAVE_ID();
+    if (i >= a.B) return;
+    const int lane = LANE();
+    const int N = a.N;
+    const float *n = a.neg + i * (int64_t)N;
+    float *dn = a.dneg + i * (int64_t)N;
+    float *cp = a.neg_copy ? a.neg_copy + i * (int64_t)N : nullptr;
+    const float w = a.w ? a.w[i] : 1.f;
+    const float p = a.pos[i];
+    const float invB = 1.f / (float)a.B;
+    if (a.pairwise) {   // loss.py:76-80
+        const float sc = w / ((float)a.B * (float)N);
+        float lsum = 0.f, dsum = 0.f;
+        for (int j = lane; j < N; j += 64) {
+            const float nv = n[j];
+            float val, dv;
+            criterion(a.genre, p - nv, 1.f, a.margin, val, dv);
+            lsum += val * sc;
+            const float dd = dv * sc;
+            dsum += dd;
+            if (cp) cp[j] = nv;
+            float g = -dd;
+            if (a.l2_scale) { const float d = a.gamma - nv; g = d > 1e-15f ? g / d : 0.f; }
+            dn[j] = g;
+        }
+        lsum = wave_sum(lsum);
+        dsum = wave_sum(dsum);
+        if (lane == 0) { a.dpos[i] = dsum; a.row_pos[i] = 0.f; a.row_neg[i] = lsum; }
+        return;
+    }
+    if (lane == 0) {
+        float pl, dpl;
+        criterion(a.genre, p, 1.f, a.margin, pl, dpl);
+        a.dpos[i] = dpl * w * 0.5f * invB;
+        a.row_pos[i] = pl * w * invB;
+    }
+    const float neg_label = a.genre == KGE_LOSS_BCE ? 0.f : -1.f;
+    float mx = -INFINITY, Z = 1.f;
+    if (a.adv) {   // softmax(neg * T) over the row, detached (loss.py:87-88)
+        for (int j = lane; j < N; j += 64) mx = fmaxf(mx, n[j] * a.adv_temp);
+        mx = wave_max(mx);
+        float z = 0.f;
+        for (int j = lane; j < N; j += 64) z += expf(n[j] * a.adv_temp - mx);
+        Z = wave_sum(z);
+    }
+    const float invZ = 1.f / Z, invN = 1.f / (float)N;
+    float acc = 0.f;
+    for (int j = lane; j < N; j += 64) {
+        const float nv = n[j];
+        float nl, dnl;
+        criterion(a.genre, nv, neg_label, a.margin, nl, dnl);
+        const float A = a.adv ? expf(nv * a.adv_temp - mx) * invZ : invN;
+        acc += A * nl * w;
+        float g = dnl * w * A * 0.5f * invB;
+        if (cp) cp[j] = nv;
+        if (a.l2_scale) { const float d = a.gamma - nv; g = d > 1e-15f ? g / d : 0.f; }
+        dn[j] = g;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) a.row_neg[i] = acc * invB;
+}
+
+int launch_loss(const LossArgs &a, hipStream_t s) {
+    if (a.B == 0) return KGE_OK;
+    hipLaunchKernelGGL(loss_kernel, dim3(blocks_for_waves(a.B)), dim3(KGE_BLOCK), 0, s, a);
+    return check_launch();
+}
+
+// deterministic final reduction of the per-row loss terms (fixed summation order)
+__device__ float block_sum_det(const float *x, int n, float *sh) {
+    float v = 0.f;
+    if (x) for (int k = threadIdx.x; k < n; k += KGE_BLOCK) v += x[k];
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__global__ __launch_bounds__(KGE_BLOCK) void finalize_kernel(FinalizeArgs a) {
+    __shared__ float sh[KGE_WAVES_PER_BLOCK];
+    const float lp = block_sum_det(a.row_pos, a.B, sh);
+    const float ln = block_sum_det(a.row_neg, a.B, sh);
+    const float re = block_sum_det(a.reg_ent, a.UE, sh);
+    const float rr = block_sum_det(a.reg_rel, a.UR, sh);
+    if (threadIdx.x == 0) {
+        float o[4];
+        if (a.pairwise) { o[0] = NAN; o[1] = NAN; o[2] = ln; }
+        else { o[0] = lp; o[1] = ln; o[2] = 0.5f * (lp + ln); }
+        o[3] = re + rr;
+        if (a.loss4) for (int k = 0; k < 4; ++k) a.loss4[k] = o[k];
+        if (a.accum) for (int k = 0; k < 4; ++k) a.accum[k] += o[k];
+    }
+}
+
+int launch_finalize(const FinalizeArgs &a, hipStream_t s) {
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(KGE_BLOCK), 0, s, a);
+    return check_launch();
+}
+
+// ------------------------------------------------------------------------------------------
+// owner-computes row-sparse Adagrad (fused path).  One wavefront owns one table row, gathers
+// every gradient contribution of that row in a fixed order, and applies the reference's
+// sequential trace semantics (tensor_models.py:316-361):
+//   entity row x:  trace 0 (pos-unique):  s0 = state + mean(g0^2);   x += (-lr*g0)/(sqrt(s0)+eps)
+//                  trace 1 (negatives):   s1 = s0 + sum_k mean(gk^2); x += (-lr*gk)/(sqrt(s1)+eps)
+//   relation row:  one trace with duplicates, same rule.
+// No atomics, bit-reproducible.
+// ------------------------------------------------------------------------------------------
+template <int V>
+__global__ __launch_bounds__(KGE_BLOCK) void update_kernel(UpdateArgs a, int nb_ent) {
+    const int lane = LANE();
+    const bool reg = a.reg_coef > 0.f && a.reg_norm > 0;
+    if ((int)blockIdx.x < nb_ent) {
+        const int64_t u = WAVE_ID();
+        if (u >= a.UE) return;
+        const int d = a.model_d_e;
+        const int64_t id = a.ue_id[u];
+        float *row = a.ent + id * (int64_t)d;
+        const int p0 = a.ue_pos_ptr[u], p1 = a.ue_pos_ptr[u + 1];
+        const int n0 = a.ue_neg_ptr[u], n1 = a.ue_neg_ptr[u + 1];
+        const bool has_pos = p1 > p0, has_neg = n1 > n0;
+        const int nit = d / V;
+        float s0 = 0.f, s1 = 0.f, rv = 0.f;
+        for (int it = lane; it < nit; it += 64) {
+            const int off = it * V;
+            const Pack<V> x = ld<V>(row + off);
+            Pack<V> g0 = zero_pack<V>();
+            if (reg) {
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    rv += reg_val(x.v[e], a.reg_norm);
+                    g0.v[e] = reg_grad(x.v[e], a.reg_coef, a.reg_norm);
+                }
+            }
+            if (has_pos) {
+                for (int p = p0; p < p1; ++p) {
+                    const int adj = a.ue_pos_adj[p];
+                    const float *src = ((adj & 1) ? a.GT : a.GH) + (int64_t)(adj >> 1) * d + off;
+                    const Pack<V> g = ld<V>(src);
+#pragma unroll
+                    for (int e = 0; e < V; ++e) g0.v[e] += g.v[e];
+                }
+#pragma unroll
+                for (int e = 0; e < V; ++e) s0 += g0.v[e] * g0.v[e];
+            }
+            for (int k = n0; k < n1; ++k) {
+                const Pack<V> g = ld<V>(a.GN + (int64_t)a.ue_neg_slot[k] * d + off);
+#pragma unroll
+                for (int e = 0; e < V; ++e) s1 += g.v[e] * g.v[e];
+            }
+        }
+        s0 = wave_sum(s0) / (float)d;
+        s1 = wave_sum(s1) / (float)d;
+        const float st0 = a.ent_state[id];
+        const float sA = has_pos ? st0 + s0 : st0;
+        const float sB = has_neg ? sA + s1 : sA;
+        const float std0 = sqrtf(sA) + a.eps, std1 = sqrtf(sB) + a.eps;
+        for (int it = lane; it < nit; it += 64) {
+            const int off = it * V;
+            Pack<V> x = ld<V>(row + off);
+            Pack<V> g0 = zero_pack<V>(), g1 = zero_pack<V>();
+            if (has_pos) {
+                if (reg) {
+#pragma unroll
+                    for (int e = 0; e < V; ++e) g0.v[e] = reg_grad(x.v[e], a.reg_coef, a.reg_norm);
+                }
+                for (int p = p0; p < p1; ++p) {
+                    const int adj = a.ue_pos_adj[p];
+                    const float *src = ((adj & 1) ? a.GT : a.GH) + (int64_t)(adj >> 1) * d + off;
+                    const Pack<V> g = ld<V>(src);
+#pragma unroll
+                    for (int e = 0; e < V; ++e) g0.v[e] += g.v[e];
+                }
+#pragma unroll
+                for (int e = 0; e < V; ++e) x.v[e] += (-a.lr * g0.v[e]) / std0;
+            }
+            for (int k = n0; k < n1; ++k) {
+                const Pack<V> g = ld<V>(a.GN + (int64_t)a.ue_neg_slot[k] * d + off);
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    x.v[e] += (-a.lr * g.v[e]) / std1;
+                    g1.v[e] += g.v[e];
+                }
+            }
+            if (!a.emit_ent) st<V>(row + off, x);
+            if (a.g0) st<V>(a.g0 + u * (int64_t)d + off, g0);
+            if (a.g1) st<V>(a.g1 + u * (int64_t)d + off, g1);
+        }
+        if (lane == 0) {
+            if (!a.emit_ent) a.ent_state[id] = sB;
+            if (a.gs0) a.gs0[u] = has_pos ? s0 : 0.f;
+            if (a.gs1) a.gs1[u] = has_neg ? s1 : 0.f;
+        }
+        if (a.reg_ent) {
+            rv = wave_sum(rv);
+            if (lane == 0) a.reg_ent[u] = reg ? a.reg_coef * rv * (float)((has_pos ? 1 : 0) + (n1 - n0)) : 0.f;
+        }
+    } else {
+        const int64_t u = ((int64_t)blockIdx.x - nb_ent) * KGE_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+        if (u >= a.UR) return;
+        const int d = a.d_r;
+        const int64_t id = a.ur_id[u];
+        float *row = a.rel + id * (int64_t)d;
+        const int e0 = a.ur_ptr[u], e1 = a.ur_ptr[u + 1];
+        const int nit = d / V;
+        float ss = 0.f, rv = 0.f;
+        for (int it = lane; it < nit; it += 64) {
+            const int off = it * V;
+            if (reg && a.reg_rel) {
+                const Pack<V> x = ld<V>(row + off);
+#pragma unroll
+                for (int e = 0; e < V; ++e) rv += reg_val(x.v[e], a.reg_norm);
+            }
+            for (int k = e0; k < e1; ++k) {
+                const Pack<V> g = ld<V>(a.GR + (int64_t)a.ur_edge[k] * d + off);
+#pragma unroll
+                for (int e = 0; e < V; ++e) ss += g.v[e] * g.v[e];
+            }
+        }
+        ss = wave_sum(ss) / (float)d;
+        const float sN = a.rel_state[id] + ss;
+        const float sd = sqrtf(sN) + a.eps;
+        for (int it = lane; it < nit; it += 64) {
+            const int off = it * V;
+            Pack<V> x = ld<V>(row + off);
+            Pack<V> gsum = zero_pack<V>();
+            for (int k = e0; k < e1; ++k) {
+                const Pack<V> g = ld<V>(a.GR + (int64_t)a.ur_edge[k] * d + off);
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    x.v[e] += (-a.lr * g.v[e]) / sd;
+                    gsum.v[e] += g.v[e];
+                }
+            }
+            if (!a.emit_rel) st<V>(row + off, x);
+            if (a.gr) st<V>(a.gr + u * (int64_t)d + off, gsum);
+        }
+        if (lane == 0) {
+            if (!a.emit_rel) a.rel_state[id] = sN;
+            if (a.gsr) a.gsr[u] = ss;
+        }
+        if (a.reg_rel) {
+            rv = wave_sum(rv);
+            if (lane == 0) a.reg_rel[u] = reg ? a.reg_coef * rv * (float)(e1 - e0) : 0.f;
+        }
+    }
+}
+
+int launch_update(const UpdateArgs &a, hipStream_t s) {
+    const int nbE = blocks_for_waves(a.UE), nbR = blocks_for_waves(a.UR);
+    if (nbE + nbR == 0) return KGE_OK;
+    if (a.model_d_e % 4 == 0 && a.d_r % 4 == 0)
+        hipLaunchKernelGGL(update_kernel<4>, dim3(nbE + nbR), dim3(KGE_BLOCK), 0, s, a, nbE);
+    else
+        hipLaunchKernelGGL(update_kernel<1>, dim3(nbE + nbR), dim3(KGE_BLOCK), 0, s, a, nbE);
+    return check_launch();
+}
+
+// ------------------------------------------------------------------------------------------
+// stand-alone ExternalEmbedding.update for one trace with arbitrary duplicate indices and no
+// plan: lock-free float atomics, two phases (state accumulate, then apply).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(KGE_BLOCK) void adagrad_state_kernel(float *state, int dim,
+                                                                  const int64_t *idx,
+                                                                  const float *grad, int64_t n) {
+    const int64_t k = WAVE_ID();
+    if (k >= n) return;
+    const int lane = LANE();
+    const float *g = grad + k * (int64_t)dim;
+    float ss = 0.f;
+    for (int d = lane; d < dim; d += 64) ss += g[d] * g[d];
+    ss = wave_sum(ss) / (float)dim;
+    if (lane == 0) atomicAdd(&state[idx[k]], ss);
+}
+__global__ __launch_bounds__(KGE_BLOCK) void adagrad_apply_kernel(float *table, const float *state,
+                                                                  int dim, const int64_t *idx,
+                                                                  const float *grad, int64_t n,
+                                                                  float lr, float eps) {
+    const int64_t k = WAVE_ID();
+    if (k >= n) return;
+    const int lane = LANE();
+    const int64_t id = idx[k];
+    const float sd = sqrtf(state[id]) + eps;
+    const float *g = grad + k * (int64_t)dim;
+    float *row = table + id * (int64_t)dim;
+    for (int d = lane; d < dim; d += 64) atomicAdd(&row[d], (-lr * g[d]) / sd);
+}
+
+int launch_adagrad_scatter(float *table, float *state, int dim, const int64_t *idx,
+                           const float *grad, int64_t n, float lr, float eps, hipStream_t s) {
+    if (n == 0) return KGE_OK;
+    const int nb = blocks_for_waves(n);
+    hipLaunchKernelGGL(adagrad_state_kernel, dim3(nb), dim3(KGE_BLOCK), 0, s, state, dim, idx, grad, n);
+    hipLaunchKernelGGL(adagrad_apply_kernel, dim3(nb), dim3(KGE_BLOCK), 0, s, table, state, dim, idx,
+                       grad, n, lr, eps);
+    return check_launch();
+}
+
+// owner-side apply of pushed (row gradient, Adagrad increment) pairs; unique idx per call.
+template <int V>
+__global__ __launch_bounds__(KGE_BLOCK) void apply_rows_kernel(float *table, float *state, int dim,
+                                                               const int64_t *idx, const float *g,
+                                                               const float *gs, int64_t n, float lr,
+                                                               float eps) {
+    const int64_t k = WAVE_ID();
+    if (k >= n) return;
+    const int lane = LANE();
+    const int64_t id = idx[k];
+    const float inc = gs[k];
+    if (id < 0 || inc == 0.f) return;
+    const float sN = state[id] + inc;
+    const float sd = sqrtf(sN) + eps;
+    float *row = table + id * (int64_t)dim;
+    const float *gg = g + k * (int64_t)dim;
+    for (int it = lane; it < dim / V; it += 64) {
+        Pack<V> x = ld<V>(row + it * V);
+        const Pack<V> gv = ld<V>(gg + it * V);
+#pragma unroll
+        for (int e = 0; e < V; ++e) x.v[e] += (-lr * gv.v[e]) / sd;
+        st<V>(row + it * V, x);
+    }
+    if (lane == 0) state[id] = sN;
+}
+
+int launch_adagrad_apply_rows(float *table, float *state, int dim, const int64_t *idx,
+                              const float *g, const float *gs, int64_t n, float lr, float eps,
+                              hipStream_t s) {
+    if (n == 0) return KGE_OK;
+    const int nb = blocks_for_waves(n);
+    if (dim % 4 == 0)
+        hipLaunchKernelGGL(apply_rows_kernel<4>, dim3(nb), dim3(KGE_BLOCK), 0, s, table, state, dim, idx, g, gs, n, lr, eps);
+    else
+        hipLaunchKernelGGL(apply_rows_kernel<1>, dim3(nb), dim3(KGE_BLOCK), 0, s, table, state, dim, idx, g, gs, n, lr, eps);
+    return check_launch();
+}

@@ -1,0 +1,133 @@
+"""ctypes binding of libkge_hip.so (C ABI: include/kge_hip.h).
+
+The library is the product: every op in this package runs through it.  There is NO CPU / eager
+fallback - if the shared object is missing (not built) importing an op raises, and calling an op
+with a non-CUDA tensor raises.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkge_hip.so")
+
+KGE_ABI_VERSION = 1
+MODEL_IDS = {"TransE_l1": 0, "TransE_l2": 1, "TransE": 1, "DistMult": 2, "ComplEx": 3, "RotatE": 4}
+LOSS_IDS = {"Logsigmoid": 0, "Logistic": 1, "Hinge": 2, "BCE": 3}
+FLAG_FORCE_PAIRWISE = 1
+
+c_f = C.c_float
+c_i = C.c_int
+c_i32 = C.c_int32
+c_i64 = C.c_int64
+c_p = C.c_void_p
+c_sz = C.c_size_t
+c_u = C.c_uint
+
+
+class KgeBatch(C.Structure):
+    _fields_ = [("B", c_i32), ("C", c_i32), ("chunk", c_i32), ("N", c_i32), ("neg_head", c_i32),
+                ("U", c_i32), ("UE", c_i32), ("UR", c_i32),
+                ("h_gid", c_p), ("t_gid", c_p), ("rel_ids", c_p), ("neg_ids", c_p), ("edge_w", c_p),
+                ("ue_id", c_p), ("ue_pos_ptr", c_p), ("ue_pos_adj", c_p), ("ue_neg_ptr", c_p),
+                ("ue_neg_slot", c_p), ("ur_id", c_p), ("ur_ptr", c_p), ("ur_edge", c_p)]
+
+
+class KgeHParams(C.Structure):
+    _fields_ = [("model", c_i32), ("d_e", c_i32), ("d_r", c_i32), ("loss_genre", c_i32),
+                ("adv", c_i32), ("pairwise", c_i32), ("reg_norm", c_i32), ("flags", C.c_uint32),
+                ("gamma", c_f), ("emb_init", c_f), ("lr", c_f), ("adv_temp", c_f), ("margin", c_f),
+                ("reg_coef", c_f), ("eps", c_f)]
+
+
+class KgeTables(C.Structure):
+    _fields_ = [("ent", c_p), ("ent_state", c_p), ("rel", c_p), ("rel_state", c_p),
+                ("n_ent", c_i64), ("n_rel", c_i64)]
+
+
+class KgeStepOut(C.Structure):
+    _fields_ = [("loss4", c_p), ("loss_accum", c_p), ("pos_score", c_p), ("neg_score", c_p),
+                ("g_pos_ent", c_p), ("g_neg", c_p), ("g_rel", c_p)]
+
+
+class KgeEmit(C.Structure):
+    _fields_ = [("g0", c_p), ("gs0", c_p), ("g1", c_p), ("gs1", c_p), ("gr", c_p), ("gsr", c_p)]
+
+
+_SIGNATURES = {
+    "kge_abi_version": (c_i, []),
+    "kge_last_error": (C.c_char_p, []),
+    "kge_gather_rows": (c_i, [c_p, c_i64, c_i, c_p, c_i64, c_p, c_p]),
+    "kge_score_pos": (c_i, [c_i, c_p, c_p, c_p, c_i64, c_i, c_i, c_f, c_f, c_p, c_p]),
+    "kge_score_pos_bwd": (c_i, [c_i, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_f, c_f, c_p, c_p, c_p,
+                                c_p]),
+    "kge_score_neg_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i]),
+    "kge_score_neg_fwd": (c_i, [c_i, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_p,
+                                c_p, c_sz, c_u, c_p]),
+    "kge_score_neg_bwd": (c_i, [c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f,
+                                c_f, c_p, c_p, c_p, c_p, c_sz, c_u, c_p]),
+    "kge_loss_fwd_bwd": (c_i, [c_i, c_i, c_f, c_i, c_f, c_p, c_p, c_p, c_i64, c_i, c_p, c_p, c_p,
+                               c_p, c_sz, c_p]),
+    "kge_adagrad_scatter": (c_i, [c_p, c_p, c_i64, c_i, c_p, c_p, c_i64, c_f, c_f, c_p]),
+    "kge_adagrad_apply_rows": (c_i, [c_p, c_p, c_i64, c_i, c_p, c_p, c_p, c_i64, c_f, c_f, c_p]),
+    "kge_step_workspace_bytes": (c_sz, [C.POINTER(KgeHParams), c_i, c_i, c_i, c_i, c_i, c_i]),
+    "kge_step_fused": (c_i, [C.POINTER(KgeHParams), C.POINTER(KgeTables), C.POINTER(KgeBatch),
+                             C.POINTER(KgeStepOut), c_p, c_sz, c_p]),
+    "kge_step_grads": (c_i, [C.POINTER(KgeHParams), C.POINTER(KgeTables), C.POINTER(KgeBatch),
+                             C.POINTER(KgeStepOut), C.POINTER(KgeEmit), c_p, c_sz, c_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES.keys())
+
+_lib = None
+
+
+class KgeError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the HIP library has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise KgeError(
+                "libkge_hip.so is missing (%s). Build it with `python __graft_entry__.py` or "
+                "`make -C dgl-ke_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        if handle.kge_abi_version() != KGE_ABI_VERSION:
+            raise KgeError("libkge_hip.so ABI version mismatch")
+        _lib = handle
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise KgeError("libkge_hip: %s (status %d)" % (lib().kge_last_error().decode(), rc))
+
+
+def ptr(t):
+    """device pointer of a CUDA tensor (None -> NULL); refuses host tensors: no CPU path."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise KgeError("libkge_hip ops need CUDA (HIP) tensors; got a %s tensor. There is no CPU "
+                       "fallback in the product path." % t.device)
+    if not t.is_contiguous():
+        raise KgeError("libkge_hip ops need contiguous tensors")
+    return t.data_ptr()
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def model_id(name):
+    if name not in MODEL_IDS:
+        raise KgeError("model %r has no HIP kernel (supported: %s)" % (name, sorted(MODEL_IDS)))
+    return MODEL_IDS[name]

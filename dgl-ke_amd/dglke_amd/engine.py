@@ -1,0 +1,136 @@
+"""Fused-step driver: one C-ABI call (`kge_step_fused`) = KEModel.forward + loss.backward() +
+KEModel.update of the reference (train_pytorch.py:141-152) for one batch, enqueued on the current
+HIP stream with no host synchronisation.  `StepEngine.capture()` records a sequence of steps over
+pre-staged batches into a HIP graph so that the launch-bound inner loop is replayed without host
+work (one step is only a few microseconds of HBM traffic, SURVEY.md 7 'hard parts')."""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import check, lib, model_id, ptr, stream_ptr
+
+
+class StepEngine(object):
+    def __init__(self, model_name, n_entities, n_relations, hidden_dim, gamma, lr, device,
+                 double_entity_emb=False, double_relation_emb=False, neg_adversarial_sampling=False,
+                 adversarial_temperature=1.0, regularization_coef=0.0, regularization_norm=3,
+                 loss_genre='Logsigmoid', pairwise=False, margin=1.0, flags=0,
+                 tables=None):
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise _lib.KgeError("StepEngine needs a CUDA (HIP) device; there is no CPU fallback")
+        self.model_name = model_name
+        self.n_entities, self.n_relations = n_entities, n_relations
+        self.hidden_dim = hidden_dim
+        self.gamma = gamma
+        self.emb_init = (gamma + 2.0) / hidden_dim          # general_models.py:217-218
+        self.d_e = 2 * hidden_dim if double_entity_emb else hidden_dim
+        self.d_r = 2 * hidden_dim if double_relation_emb else hidden_dim
+        hp = _lib.KgeHParams()
+        hp.model = model_id(model_name)
+        hp.d_e, hp.d_r = self.d_e, self.d_r
+        hp.loss_genre = _lib.LOSS_IDS[loss_genre]
+        hp.adv = int(bool(neg_adversarial_sampling))
+        hp.pairwise = int(bool(pairwise))
+        hp.reg_norm = int(regularization_norm)
+        hp.flags = int(flags)
+        hp.gamma = float(gamma)
+        hp.emb_init = float(self.emb_init)
+        hp.lr = float(lr)
+        hp.adv_temp = float(adversarial_temperature)
+        hp.margin = float(margin if margin is not None else 1.0)
+        hp.reg_coef = float(regularization_coef)
+        hp.eps = 1e-10
+        self.hp = hp
+        if tables is None:
+            self.ent = torch.empty(n_entities, self.d_e, dtype=torch.float32, device=self.device)
+            self.ent_state = torch.zeros(n_entities, dtype=torch.float32, device=self.device)
+            self.rel = torch.empty(n_relations, self.d_r, dtype=torch.float32, device=self.device)
+            self.rel_state = torch.zeros(n_relations, dtype=torch.float32, device=self.device)
+            self.reset_parameters()
+        else:
+            self.ent, self.ent_state, self.rel, self.rel_state = tables
+        self._bind_tables()
+        self.loss4 = torch.zeros(4, dtype=torch.float32, device=self.device)
+        self.loss_accum = torch.zeros(4, dtype=torch.float32, device=self.device)
+        self._ws = None
+        self._ws_bytes = 0
+        self._graphs = []
+
+    def _bind_tables(self):
+        tb = _lib.KgeTables()
+        tb.ent, tb.ent_state = ptr(self.ent), ptr(self.ent_state)
+        tb.rel, tb.rel_state = ptr(self.rel), ptr(self.rel_state)
+        tb.n_ent, tb.n_rel = self.ent.shape[0], self.rel.shape[0]
+        self.tb = tb
+
+    def reset_parameters(self):
+        torch.nn.init.uniform_(self.ent, -self.emb_init, self.emb_init)
+        torch.nn.init.uniform_(self.rel, -self.emb_init, self.emb_init)
+        self.ent_state.zero_()
+        self.rel_state.zero_()
+
+    def load_tables(self, ent, rel, ent_state=None, rel_state=None):
+        self.ent.copy_(torch.as_tensor(ent))
+        self.rel.copy_(torch.as_tensor(rel))
+        if ent_state is None:
+            self.ent_state.zero_()
+        else:
+            self.ent_state.copy_(torch.as_tensor(ent_state))
+        if rel_state is None:
+            self.rel_state.zero_()
+        else:
+            self.rel_state.copy_(torch.as_tensor(rel_state))
+
+    def workspace_for(self, b):
+        need = lib().kge_step_workspace_bytes(C.byref(self.hp), b.B, b.C, b.chunk, b.N, b.UE, b.UR)
+        if need > self._ws_bytes:
+            if self._graphs:
+                raise _lib.KgeError("workspace would be re-allocated after graph capture")
+            self._ws = torch.empty(int(need * 1.25) + 4096, dtype=torch.uint8, device=self.device)
+            self._ws_bytes = self._ws.numel()
+        return self._ws
+
+    def step(self, batch, want=None, emit=None):
+        """enqueue one fused step.  `want`: dict of optional output tensors (pos_score, neg_score,
+        g_pos_ent, g_neg, g_rel).  `emit`: KgeEmit for the sharded path."""
+        ws = self.workspace_for(batch)
+        out = _lib.KgeStepOut()
+        out.loss4 = ptr(self.loss4)
+        out.loss_accum = ptr(self.loss_accum)
+        if want:
+            for k, t in want.items():
+                setattr(out, k, ptr(t))
+        if emit is None:
+            check(lib().kge_step_fused(C.byref(self.hp), C.byref(self.tb), C.byref(batch.c),
+                                       C.byref(out), ptr(ws), self._ws_bytes, stream_ptr()))
+        else:
+            check(lib().kge_step_grads(C.byref(self.hp), C.byref(self.tb), C.byref(batch.c),
+                                       C.byref(out), C.byref(emit), ptr(ws), self._ws_bytes,
+                                       stream_ptr()))
+
+    def alloc_outputs(self, batch):
+        dev = self.device
+        return dict(pos_score=torch.empty(batch.B, device=dev),
+                    neg_score=torch.empty(batch.C, batch.chunk, batch.N, device=dev),
+                    g_pos_ent=torch.empty(batch.UE, self.d_e, device=dev),
+                    g_neg=torch.empty(batch.C * batch.N, self.d_e, device=dev),
+                    g_rel=torch.empty(batch.B, self.d_r, device=dev))
+
+    def capture(self, batches):
+        """record `len(batches)` consecutive steps into one HIP graph; returns the graph."""
+        for b in batches:
+            self.workspace_for(b)
+        # warm-up on a side stream is not needed: the library allocates nothing
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for b in batches:
+                self.step(b)
+        self._graphs.append((g, batches))
+        return g
+
+    def read_loss(self):
+        """one 16-byte D2H copy: [pos_loss, neg_loss, loss, regularization] of the last step."""
+        return self.loss4.tolist()

@@ -1,0 +1,206 @@
+/*
+ * kge_hip.h - C ABI of libkge_hip.so, the MI355X (gfx950) implementation of the DGL-KE training
+ * hot path: gather -> positive score -> chunked negative score -> loss -> analytic gradients ->
+ * row-sparse Adagrad.
+ *
+ * The reference (awslabs/dgl-ke) has no FFI boundary for this path: it is Python calling torch
+ * ops.  Each entry point below replaces one reference function (cited as file:line relative to
+ * python/dglke/) and is what a maintainer would bind from those call sites (see INTEGRATION.md
+ * for the ctypes stubs).
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller (a torch tensor); fp32 data, int64 ids
+ *    (the reference's dtypes), int32 for the batch-plan CSR arrays this library defines;
+ *  - no allocation, no host synchronisation and no global mutable state inside; every call takes
+ *    an explicit stream (hipStream_t passed as void*) and only enqueues kernels on it, so calls
+ *    can be captured into a hipGraph;
+ *  - return value 0 = success, negative = kge_status; kge_last_error() returns the message of
+ *    the last failure on the calling thread;
+ *  - embedding rows of ComplEx / RotatE are [re | im] halves (models/pytorch/score_fun.py:298-300).
+ */
+#ifndef KGE_HIP_H
+#define KGE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KGE_ABI_VERSION 1
+
+/* score functions (models/general_models.py:248-268 model_name strings) */
+enum kge_model {
+    KGE_TRANSE_L1 = 0, /* score_fun.py:40  TransEScore(dist_func='l1') */
+    KGE_TRANSE_L2 = 1, /* score_fun.py:40  TransEScore(dist_func='l2') */
+    KGE_DISTMULT  = 2, /* score_fun.py:222 DistMultScore */
+    KGE_COMPLEX   = 3, /* score_fun.py:289 ComplExScore */
+    KGE_ROTATE    = 4  /* score_fun.py:451 RotatEScore */
+};
+
+/* loss criteria (models/pytorch/loss.py:44-59) */
+enum kge_loss {
+    KGE_LOSS_LOGSIGMOID = 0,
+    KGE_LOSS_LOGISTIC   = 1,
+    KGE_LOSS_HINGE      = 2,
+    KGE_LOSS_BCE        = 3
+};
+
+enum kge_status {
+    KGE_OK            = 0,
+    KGE_ERR_ARG       = -1, /* bad argument (shape / model / null pointer) */
+    KGE_ERR_WORKSPACE = -2, /* workspace too small */
+    KGE_ERR_LAUNCH    = -3  /* HIP launch error */
+};
+
+/* flags for kge_score_neg_* / kge_step_* : force the VALU pairwise kernels instead of the MFMA
+ * GEMM kernels for the models that have a GEMM form (validation aid; TransE_l1 / RotatE always
+ * use the pairwise kernels). */
+#define KGE_FLAG_FORCE_PAIRWISE 1u
+
+int         kge_abi_version(void);
+const char *kge_last_error(void);
+
+/* ---- A2: ExternalEmbedding.__call__  (models/pytorch/tensor_models.py:270-302, line 292) ----
+ * out[k,:] = table[idx[k],:] */
+int kge_gather_rows(const float *table, int64_t n_rows, int dim, const int64_t *idx,
+                    int64_t n_idx, float *out, void *stream);
+
+/* ---- A3: score_func.edge_func  (score_fun.py:54-59, 229-235, 297-307, 460-472) ----
+ * out[i] = positive score of (h[i], r[i], t[i]); h,t: [B,d_e]  r: [B,d_r] dense rows. */
+int kge_score_pos(int model, const float *h, const float *r, const float *t, int64_t B, int d_e,
+                  int d_r, float gamma, float emb_init, float *out, void *stream);
+/* autograd of edge_func: (gh, gr, gt) = dpos[i] * d score/d (h, r, t) */
+int kge_score_pos_bwd(int model, const float *h, const float *r, const float *t,
+                      const float *dpos, int64_t B, int d_e, int d_r, float gamma,
+                      float emb_init, float *gh, float *gr, float *gt, void *stream);
+
+/* ---- A4/A5: score_func.create_neg(neg_head) closures (score_fun.py:91-108, 268-286, 345-376,
+ * 512-554) called from KEModel.predict_neg_score (general_models.py:405, 426) ----
+ * pos_side: the uncorrupted entity rows [C*chunk, d_e] (tails if neg_head else heads);
+ * rel: [C*chunk, d_r]; neg: corrupt entity rows [C*N, d_e]; out: [C, chunk, N].
+ * ws: scratch of at least kge_score_neg_workspace_bytes(). */
+size_t kge_score_neg_workspace_bytes(int model, int C, int chunk, int N, int d_e);
+int kge_score_neg_fwd(int model, int neg_head, const float *pos_side, const float *rel,
+                      const float *neg, int C, int chunk, int N, int d_e, int d_r, float gamma,
+                      float emb_init, float *out, void *ws, size_t ws_bytes, unsigned flags,
+                      void *stream);
+/* autograd of the closure: given dneg [C,chunk,N] -> g_pos_side [C*chunk,d_e], g_rel
+ * [C*chunk,d_r], g_neg [C*N,d_e]. */
+int kge_score_neg_bwd(int model, int neg_head, const float *pos_side, const float *rel,
+                      const float *neg, const float *neg_score, const float *dneg, int C,
+                      int chunk, int N, int d_e, int d_r, float gamma, float emb_init,
+                      float *g_pos_side, float *g_rel, float *g_neg, void *ws, size_t ws_bytes,
+                      unsigned flags, void *stream);
+
+/* ---- A6: LossGenerator.get_total_loss (models/pytorch/loss.py:69-98) + its gradient ----
+ * pos [B], neg [B,N], w = edge importance [B] or NULL.  loss3 = {pos_loss, neg_loss, loss}
+ * (pairwise: {nan, nan, loss}); dpos [B], dneg [B,N] = d loss / d score.
+ * ws: scratch of >= 2*B floats. */
+int kge_loss_fwd_bwd(int loss_genre, int adv, float adv_temp, int pairwise, float margin,
+                     const float *pos, const float *neg, const float *w, int64_t B, int N,
+                     float *loss3, float *dpos, float *dneg, void *ws, size_t ws_bytes,
+                     void *stream);
+
+/* ---- A9: ExternalEmbedding.update for ONE trace (tensor_models.py:304-362) ----
+ * state[idx[k]] += mean_d(grad[k,d]^2) for all k (duplicates accumulate, :352), then
+ * table[idx[k],:] += -lr*grad[k,:]/(sqrt(state[idx[k]])+eps) using the state AFTER all adds
+ * (:353-361).  Lock-free (float atomics), two kernels. */
+int kge_adagrad_scatter(float *table, float *state_sum, int64_t n_rows, int dim,
+                        const int64_t *idx, const float *grad, int64_t n_idx, float lr, float eps,
+                        void *stream);
+
+/* ---- fused step: KEModel.forward + loss.backward() + KEModel.update
+ * (train_pytorch.py:141-152; general_models.py:529-588) for one batch ----
+ *
+ * The batch is the content of the reference's (pos_g, neg_g) pair (general_models.py:376-427,
+ * dataloader/sampler.py:421-457) as flat id arrays, plus a "plan": the grouping of duplicate rows
+ * that lets every table row be updated by exactly one wavefront, deterministically and without
+ * atomics, with the reference's trace order (entity pos-unique trace, then entity negative trace,
+ * then relation trace; tensor_models.py:316). */
+typedef struct kge_batch {
+    int32_t B;      /* positive edges                                                       */
+    int32_t C;      /* neg_g.num_chunks                                                     */
+    int32_t chunk;  /* neg_g.chunk_size  (C*chunk == B)                                     */
+    int32_t N;      /* neg_g.neg_sample_size                                                */
+    int32_t neg_head;
+    int32_t U;      /* number of unique positive entities (len(pos_g.ndata['id']))          */
+    int32_t UE;     /* unique entities in (pos nodes U negative nodes)                      */
+    int32_t UR;     /* unique relations                                                     */
+    const int64_t *h_gid;   /* [B]   global head entity id  = nid[h_local]                   */
+    const int64_t *t_gid;   /* [B]   global tail entity id                                   */
+    const int64_t *rel_ids; /* [B]   pos_g.edata['id']                                       */
+    const int64_t *neg_ids; /* [C*N] neg_g.ndata['id'][head_nid|tail_nid]                    */
+    const float   *edge_w;  /* [B] pos_g.edata['impts'] or NULL                              */
+    /* plan */
+    const int64_t *ue_id;       /* [UE]   global entity id of union entry u                  */
+    const int32_t *ue_pos_ptr;  /* [UE+1] CSR into ue_pos_adj (empty list: not a pos node)   */
+    const int32_t *ue_pos_adj;  /* [2B]   edge*2 + side (0 = head end, 1 = tail end)         */
+    const int32_t *ue_neg_ptr;  /* [UE+1] CSR into ue_neg_slot                               */
+    const int32_t *ue_neg_slot; /* [C*N]  positions in neg_ids holding this entity           */
+    const int64_t *ur_id;       /* [UR]   unique relation id                                 */
+    const int32_t *ur_ptr;      /* [UR+1] CSR into ur_edge                                   */
+    const int32_t *ur_edge;     /* [B]    edges carrying this relation                       */
+} kge_batch;
+
+typedef struct kge_hparams {
+    int32_t model;       /* enum kge_model                                                   */
+    int32_t d_e, d_r;    /* entity / relation row widths in floats                           */
+    int32_t loss_genre;  /* enum kge_loss                                                    */
+    int32_t adv;         /* args.neg_adversarial_sampling                                    */
+    int32_t pairwise;
+    int32_t reg_norm;    /* args.regularization_norm                                         */
+    uint32_t flags;
+    float gamma, emb_init, lr, adv_temp, margin, reg_coef, eps /* 1e-10 */;
+} kge_hparams;
+
+typedef struct kge_tables {
+    float *ent;        /* [n_ent, d_e] entity_emb.emb                                        */
+    float *ent_state;  /* [n_ent]      entity_emb.state_sum                                  */
+    float *rel;        /* [n_rel, d_r]                                                       */
+    float *rel_state;  /* [n_rel]                                                            */
+    int64_t n_ent, n_rel;
+} kge_tables;
+
+/* optional outputs of a step (any may be NULL) */
+typedef struct kge_step_out {
+    float *loss4;      /* {pos_loss, neg_loss, loss (without reg), regularization}           */
+    float *loss_accum; /* [4] running sums (+= loss4) for log_interval averaging             */
+    float *pos_score;  /* [B]                                                                */
+    float *neg_score;  /* [C,chunk,N] scores (copied before they are overwritten)            */
+    float *g_pos_ent;  /* [U? no: UE, d_e] trace-0 gradient per union entry (0 if not pos)   */
+    float *g_neg;      /* [C*N, d_e]  trace-1 gradient                                       */
+    float *g_rel;      /* [B, d_r]    relation-trace gradient                                */
+} kge_step_out;
+
+size_t kge_step_workspace_bytes(const kge_hparams *hp, int B, int C, int chunk, int N, int UE,
+                                int UR);
+/* forward + backward + update of one batch, enqueued on `stream`. */
+int kge_step_fused(const kge_hparams *hp, const kge_tables *tb, const kge_batch *b,
+                   const kge_step_out *out, void *ws, size_t ws_bytes, void *stream);
+
+/* ---- range-sharded training (one process per GPU) ----
+ * kge_step_grads: same as kge_step_fused but instead of updating the entity table it EMITS, per
+ * union entry u, the two trace gradients and their Adagrad increments so that the owner rank can
+ * apply them: g0[u,:] (trace 0), gs0[u] = mean(g0^2); g1[u,:] = sum over duplicates (trace 1),
+ * gs1[u] = sum_k mean(g_k^2).  The relation table is still updated locally unless rel_emit. */
+typedef struct kge_emit {
+    float *g0;  float *gs0;  /* [UE,d_e], [UE] */
+    float *g1;  float *gs1;  /* [UE,d_e], [UE] */
+    float *gr;  float *gsr;  /* [UR,d_r], [UR] summed relation gradient (NULL: update locally) */
+} kge_emit;
+int kge_step_grads(const kge_hparams *hp, const kge_tables *tb, const kge_batch *b,
+                   const kge_step_out *out, const kge_emit *emit, void *ws, size_t ws_bytes,
+                   void *stream);
+/* owner side: for k < n: s = state[idx[k]] + gs[k]; state = s; table[idx[k],:] += -lr*g[k,:] /
+ * (sqrt(s)+eps).  idx must be unique within one call (one wavefront owns one row). A row with
+ * gs[k] == 0 and an all-zero gradient is left untouched. */
+int kge_adagrad_apply_rows(float *table, float *state_sum, int64_t n_rows, int dim,
+                           const int64_t *idx, const float *g, const float *gs, int64_t n,
+                           float lr, float eps, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KGE_HIP_H */

@@ -1,0 +1,128 @@
+"""torch-CPU port of one reference training step, used ONLY as bench.py's `cpu_baseline`
+(kind "port") and cross-checked against the golden vectors in tests/.
+
+*** TEST / MEASUREMENT INFRASTRUCTURE - never imported by the product (dgl-ke_amd/). ***
+
+/root/reference is pure Python on torch + DGL and cannot travel to the GPU box, so the CPU
+baseline cannot be the reference itself.  This file restates `KEModel.forward -> loss.backward()
+-> KEModel.update` (models/general_models.py:529-588, train_pytorch.py:141-152) with the SAME
+torch ops the reference uses on its CPU path - advanced-index gather + clone (tensor_models.py:
+292-298), th.baddbmm / th.cdist / th.bmm negative scores (score_fun.py:26-38, 275-284, 359-375,
+526-531), logsigmoid + softmax adversarial weighting (loss.py:87-98), autograd backward, and
+index_add_ Adagrad (tensor_models.py:330-361) - on flat id arrays instead of DGL subgraphs, so its
+wall time is representative of the reference's `--num_proc 1` CPU path without the DGL sampler.
+"""
+import numpy as np
+import torch as th
+import torch.nn.functional as Fn
+
+
+class TorchPort(object):
+    def __init__(self, model, n_ent, n_rel, hidden, gamma, lr, de=False, dr=False, adv=False,
+                 adv_temp=1.0, reg_coef=0.0, reg_norm=3, seed=0):
+        self.model = "TransE_l2" if model == "TransE" else model
+        self.gamma, self.lr = gamma, lr
+        self.adv, self.adv_temp = adv, adv_temp
+        self.reg_coef, self.reg_norm = reg_coef, reg_norm
+        self.emb_init = (gamma + 2.0) / hidden
+        g = th.Generator().manual_seed(seed)
+        d_e = 2 * hidden if de else hidden
+        d_r = 2 * hidden if dr else hidden
+        self.ent = (th.rand(n_ent, d_e, generator=g) * 2 - 1) * self.emb_init
+        self.rel = (th.rand(n_rel, d_r, generator=g) * 2 - 1) * self.emb_init
+        self.ent_state = th.zeros(n_ent)
+        self.rel_state = th.zeros(n_rel)
+
+    # --- score functions (same op sequences as models/pytorch/score_fun.py) -------------------
+    def _pos(self, h, r, t):
+        m = self.model
+        if m == "TransE_l2":
+            return self.gamma - th.norm(h + r - t, p=2, dim=-1)
+        if m == "TransE_l1":
+            return self.gamma - th.norm(h + r - t, p=1, dim=-1)
+        if m == "DistMult":
+            return th.sum(h * r * t, dim=-1)
+        if m == "ComplEx":
+            rh, ih = th.chunk(h, 2, dim=-1)
+            rt, it = th.chunk(t, 2, dim=-1)
+            rr, ir = th.chunk(r, 2, dim=-1)
+            return th.sum(rh * rt * rr + ih * it * rr + rh * it * ir - ih * rt * ir, -1)
+        rh, ih = th.chunk(h, 2, dim=-1)
+        rt, it = th.chunk(t, 2, dim=-1)
+        ph = r / (self.emb_init / np.pi)
+        c, s = th.cos(ph), th.sin(ph)
+        re = rh * c - ih * s - rt
+        im = rh * s + ih * c - it
+        return self.gamma - th.stack([re, im], dim=0).norm(dim=0).sum(-1)
+
+    def _neg(self, x, r, neg, neg_head, C, chunk, N):
+        m = self.model
+        D = x.shape[1]
+        if m in ("TransE_l2", "TransE_l1"):
+            a = (x - r) if neg_head else (x + r)
+            a = a.reshape(C, chunk, D)
+            b = neg.reshape(C, N, D)
+            if m == "TransE_l1":
+                return self.gamma - th.cdist(a, b, p=1)
+            a2 = a.norm(dim=-1).pow(2)
+            b2 = b.norm(dim=-1).pow(2)
+            sq = th.baddbmm(b2.unsqueeze(-2), a, b.transpose(-2, -1), alpha=-2).add_(a2.unsqueeze(-1))
+            return self.gamma - sq.clamp_min_(1e-30).sqrt_()
+        if m == "DistMult":
+            return th.bmm((x * r).reshape(C, chunk, D), neg.reshape(C, N, D).transpose(1, 2))
+        rx, ix = x[..., :D // 2], x[..., D // 2:]
+        if m == "ComplEx":
+            rr, ir = r[..., :D // 2], r[..., D // 2:]
+        else:
+            ph = r / (self.emb_init / np.pi)
+            rr, ir = th.cos(ph), th.sin(ph)
+        if neg_head:
+            real, imag = rx * rr + ix * ir, -rx * ir + ix * rr
+        else:
+            real, imag = rx * rr - ix * ir, rx * ir + ix * rr
+        a = th.cat((real, imag), dim=-1)
+        if m == "ComplEx":
+            return th.bmm(a.reshape(C, chunk, D), neg.reshape(C, N, D).transpose(1, 2))
+        sc = a.reshape(C, chunk, 1, D) - neg.reshape(C, 1, N, D)
+        sc = th.stack([sc[..., :D // 2], sc[..., D // 2:]], dim=-1).norm(dim=-1)
+        return self.gamma - sc.sum(-1)
+
+    def step(self, p):
+        """p: plan dict (nid, h_local, t_local, rel_ids, neg_ids, C, chunk, N, neg_head)."""
+        nid = th.from_numpy(p["nid"])
+        rid = th.from_numpy(p["rel_ids"])
+        gid = th.from_numpy(p["neg_ids"])
+        hl, tl = th.from_numpy(p["h_local"]), th.from_numpy(p["t_local"])
+        C, chunk, N, neg_head = p["C"], p["chunk"], p["N"], bool(p["neg_head"])
+        pos_emb = self.ent[nid].clone().detach().requires_grad_(True)
+        rel = self.rel[rid].clone().detach().requires_grad_(True)
+        neg = self.ent[gid].clone().detach().requires_grad_(True)
+        h, t = pos_emb[hl], pos_emb[tl]
+        pos = self._pos(h, rel, t)
+        ns = self._neg(t if neg_head else h, rel, neg, neg_head, C, chunk, N).reshape(-1, N)
+        pos_loss = -Fn.logsigmoid(pos)
+        neg_loss = -Fn.logsigmoid(-ns)
+        if self.adv:
+            neg_loss = th.sum(th.softmax(ns * self.adv_temp, dim=-1).detach() * neg_loss, dim=-1)
+        else:
+            neg_loss = th.mean(neg_loss, dim=-1)
+        loss = (th.mean(neg_loss) + th.mean(pos_loss)) / 2
+        reg = 0.0
+        if self.reg_coef > 0 and self.reg_norm > 0:
+            q = self.reg_norm
+            regt = self.reg_coef * (th.cat([pos_emb, neg], 0).norm(p=q) ** q + rel.norm(p=q) ** q)
+            reg = regt.item()
+            loss = loss + regt
+        log = (th.mean(pos_loss).item(), th.mean(neg_loss).item(), loss.item() - reg, reg)
+        loss.backward()
+        with th.no_grad():
+            for table, state, idx, g in ((self.ent, self.ent_state, nid, pos_emb.grad),
+                                        (self.ent, self.ent_state, gid, neg.grad),
+                                        (self.rel, self.rel_state, rid, rel.grad)):
+                gs = (g * g).mean(1)
+                state.index_add_(0, idx, gs)
+                std = state[idx].sqrt_().add_(1e-10).unsqueeze(1)
+                table.index_add_(0, idx, -self.lr * g / std)
+        return dict(pos_score=pos.detach().numpy(), neg_score=ns.detach().numpy().reshape(C, chunk, N),
+                    log=log, g_pos_ent=pos_emb.grad.numpy(), g_neg=neg.grad.numpy(),
+                    g_rel=rel.grad.numpy())

@@ -1,0 +1,278 @@
+"""GPU parity tests (run with `-m gpu` on the MI355X box): the HIP path, called through the C ABI
+(ctypes -> libkge_hip.so), against (a) the golden vectors recorded from the unmodified reference
+and (b) the CPU oracle on seeded inputs, including the BASELINE config shapes.
+
+Tolerances (fp32, BASELINE.json north_star: 1e-4 on fp32 scores): scores 1e-4 abs (+1e-4 rel),
+loss 1e-5 rel/abs, gradients 3e-4 of the largest gradient component (fp32 cancellation noise of
+the reference's own |a|^2+|b|^2-2ab formulation, see tests/test_oracle_golden.py), post-update
+rows 5e-3*lr (Adagrad's first steps normalise the gradient).
+"""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import golden_names, load_golden, oracle_config
+from oracle import kge_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _close(a, b, rtol, atol, what):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    assert a.shape == b.shape, "%s: shape %s vs %s" % (what, a.shape, b.shape)
+    assert np.all(np.isfinite(a)), what + ": non-finite values"
+    err = np.abs(a - b)
+    lim = atol + rtol * np.abs(b)
+    bad = err > lim
+    assert not bad.any(), "%s: %d/%d out of tolerance, max err %.3e at %s (got %.6g want %.6g)" % (
+        what, bad.sum(), bad.size, err.max(), np.unravel_index(np.argmax(err), err.shape),
+        a.flat[np.argmax(err)], b.flat[np.argmax(err)])
+
+
+class Args(dict):
+    __getattr__ = dict.get
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def make_args(case):
+    a = Args()
+    a.gpu = [0]
+    a.mix_cpu_gpu = False
+    a.has_edge_importance = bool(case.get("impts", False))
+    a.strict_rel_part = False
+    a.soft_rel_part = False
+    a.lr = case["lr"]
+    a.neg_deg_sample = False
+    a.neg_deg_sample_eval = False
+    a.eval_filter = False
+    a.regularization_coef = case["reg_coef"]
+    a.regularization_norm = case["reg_norm"]
+    a.loss_genre = case.get("loss_genre", "Logsigmoid")
+    a.neg_adversarial_sampling = case["adv"]
+    a.adversarial_temperature = case["adv_temp"]
+    a.pairwise = case.get("pairwise", False)
+    a.margin = case.get("margin", 1.0)
+    return a
+
+
+def build_model(case, z):
+    from dglke_amd.general_models import KEModel
+    m = KEModel(make_args(case), case["model"], case["n_ent"], case["n_rel"], case["hidden"],
+                case["gamma"], double_entity_emb=case["de"], double_relation_emb=case["dr"])
+    m.entity_emb.emb.copy_(torch.from_numpy(z["init_entity"]))
+    m.relation_emb.emb.copy_(torch.from_numpy(z["init_relation"]))
+    m.entity_emb.state_sum.zero_()
+    m.relation_emb.state_sum.zero_()
+    return m
+
+
+def golden_batch(z, case, s):
+    from dglke_amd import plan
+    p = "s%d_" % s
+    w = z[p + "w"] if (p + "w") in z else None
+    return plan.make_batch(z[p + "h"], z[p + "t"], z[p + "r"], z[p + "neg"], case["chunk"],
+                           case["N"], bool(z[p + "neg_head"]), DEV, w)
+
+
+def grad_tol(ref):
+    return 3e-4 * max(float(np.abs(ref).max()), 1e-12)
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_dropin_model_matches_reference(name):
+    """reference loop: model.forward -> loss.backward() -> model.update (train_pytorch.py:141-152)
+    on the HIP-backed KEModel, every op one C-ABI call."""
+    from dglke_amd.dataloader import NegGraph, PosGraph
+    z, case = load_golden(name)
+    m = build_model(case, z)
+    for s in range(1, case["steps"] + 1):
+        p = "s%d_" % s
+        b = golden_batch(z, case, s)
+        pos_g, neg_g = PosGraph(b), NegGraph(b)
+        loss, log = m.forward(pos_g, neg_g, 0)
+        _close(pos_g.edata["score"].detach().cpu(), z[p + "pos_score"], 1e-4, 1e-4, name + " pos_score")
+        ref_log = z[p + "log"]
+        if not case.get("pairwise", False):
+            _close(log["pos_loss"], ref_log[0], 1e-4, 1e-5, name + " pos_loss")
+            _close(log["neg_loss"], ref_log[1], 1e-4, 1e-5, name + " neg_loss")
+        _close(log["loss"], ref_log[2], 1e-4, 1e-5, name + " loss")
+        _close(log.get("regularization", 0.0), ref_log[3], 1e-4, 1e-7, name + " reg")
+        _close(loss.item(), z[p + "loss_total"], 1e-4, 1e-5, name + " total loss")
+        loss.backward()
+        et, rt = m.entity_emb.trace, m.relation_emb.trace
+        assert len(et) == 2 and len(rt) == 1
+        _close(et[0][1].grad.cpu(), z[p + "g_pos_ent"], 3e-4, grad_tol(z[p + "g_pos_ent"]), name + " g_pos_ent")
+        _close(et[1][1].grad.cpu(), z[p + "g_neg"], 3e-4, grad_tol(z[p + "g_neg"]), name + " g_neg")
+        _close(rt[0][1].grad.cpu(), z[p + "g_rel"], 3e-4, grad_tol(z[p + "g_rel"]), name + " g_rel")
+        m.update(0)
+        _close(m.entity_emb.state_sum.cpu(), z[p + "entity_state"], 2e-3, 1e-9, name + " ent state")
+        _close(m.relation_emb.state_sum.cpu(), z[p + "relation_state"], 2e-3, 1e-9, name + " rel state")
+        if (p + "entity") in z:
+            _close(m.entity_emb.emb.cpu(), z[p + "entity"], 1e-4, 5e-3 * case["lr"], name + " entity rows")
+            _close(m.relation_emb.emb.cpu(), z[p + "relation"], 1e-4, 5e-3 * case["lr"], name + " relation rows")
+    _close(m.entity_emb.emb.cpu(), z["final_entity"], 1e-4, 1e-2 * case["lr"], name + " final entity")
+    _close(m.relation_emb.emb.cpu(), z["final_relation"], 1e-4, 1e-2 * case["lr"], name + " final relation")
+
+
+@pytest.mark.parametrize("force_pairwise", [False, True])
+@pytest.mark.parametrize("name", golden_names())
+def test_fused_step_matches_reference(name, force_pairwise):
+    """kge_step_fused (one call per step) vs the reference's recorded scores / gradients / tables;
+    both the matrix-core and the pairwise negative-score kernels."""
+    from dglke_amd import _lib
+    z, case = load_golden(name)
+    m = build_model(case, z)
+    eng = m.engine
+    eng.hp.flags = _lib.FLAG_FORCE_PAIRWISE if force_pairwise else 0
+    for s in range(1, case["steps"] + 1):
+        p = "s%d_" % s
+        b = golden_batch(z, case, s)
+        want = eng.alloc_outputs(b)
+        eng.step(b, want)
+        torch.cuda.synchronize()
+        _close(want["pos_score"].cpu(), z[p + "pos_score"], 1e-4, 1e-4, name + " pos_score")
+        _close(want["neg_score"].cpu(), z[p + "neg_score"], 1e-4, 1e-4, name + " neg_score")
+        l4 = eng.read_loss()
+        ref_log = z[p + "log"]
+        if not case.get("pairwise", False):
+            _close(l4[0], ref_log[0], 1e-4, 1e-5, name + " pos_loss")
+            _close(l4[1], ref_log[1], 1e-4, 1e-5, name + " neg_loss")
+        _close(l4[2], ref_log[2], 1e-4, 1e-5, name + " loss")
+        _close(l4[3], ref_log[3], 1e-4, 1e-7, name + " reg")
+        ue = b.p["ue_id"]
+        sel = np.searchsorted(ue, z[p + "nid"])
+        _close(want["g_pos_ent"].cpu().numpy()[sel], z[p + "g_pos_ent"], 3e-4, grad_tol(z[p + "g_pos_ent"]), name + " g_pos_ent")
+        _close(want["g_neg"].cpu(), z[p + "g_neg"], 3e-4, grad_tol(z[p + "g_neg"]), name + " g_neg")
+        _close(want["g_rel"].cpu(), z[p + "g_rel"], 3e-4, grad_tol(z[p + "g_rel"]), name + " g_rel")
+        _close(eng.ent_state.cpu(), z[p + "entity_state"], 2e-3, 1e-9, name + " ent state")
+        _close(eng.rel_state.cpu(), z[p + "relation_state"], 2e-3, 1e-9, name + " rel state")
+        if (p + "entity") in z:
+            _close(eng.ent.cpu(), z[p + "entity"], 1e-4, 5e-3 * case["lr"], name + " entity rows")
+            _close(eng.rel.cpu(), z[p + "relation"], 1e-4, 5e-3 * case["lr"], name + " relation rows")
+    _close(eng.ent.cpu(), z["final_entity"], 1e-4, 1e-2 * case["lr"], name + " final entity")
+    _close(eng.rel.cpu(), z["final_relation"], 1e-4, 1e-2 * case["lr"], name + " final relation")
+
+
+# ---------------------------------------------------------------------------------------------
+# oracle comparisons on seeded synthetic batches, up to the BASELINE config shapes
+# ---------------------------------------------------------------------------------------------
+SHAPES = [
+    # model, n_ent, n_rel, hidden, de, dr, B, N, chunk, gamma, lr, adv, reg
+    ("TransE_l2", 14951, 1345, 400, False, False, 1000, 200, 200, 19.9, 0.25, True, 1e-9),   # cfg-T
+    ("DistMult", 14951, 1345, 400, False, False, 1000, 200, 200, 143.0, 0.08, True, 2e-6),   # cfg-D
+    ("ComplEx", 50000, 535, 200, True, True, 1024, 256, 256, 143.0, 0.1, True, 2e-6),        # cfg-C shape
+    ("RotatE", 20000, 300, 200, True, False, 512, 128, 128, 12.0, 0.01, True, 1e-7),
+    ("TransE_l1", 14951, 1345, 400, False, False, 400, 200, 200, 16.0, 0.01, True, 1e-7),
+    ("TransE_l2", 300, 10, 36, False, False, 120, 24, 40, 10.0, 0.1, False, 0.0),             # chunk != N, dups
+]
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "%s-B%d-N%d-D%d" % (s[0], s[6], s[7], s[3]))
+def test_fused_step_matches_oracle_at_config_shapes(shape):
+    from dglke_amd import plan
+    from dglke_amd.engine import StepEngine
+    model, n_ent, n_rel, hidden, de, dr, B, N, chunk, gamma, lr, adv, reg = shape
+    cfg = O.Config(model, gamma, hidden, lr, adv=adv, adv_temp=1.0, reg_coef=reg, reg_norm=3,
+                   double_ent=de, double_rel=dr)
+    rng = np.random.RandomState(1234)
+    ent = rng.uniform(-cfg.emb_init, cfg.emb_init, size=(n_ent, cfg.ent_dim)).astype(np.float32)
+    rel = rng.uniform(-cfg.emb_init, cfg.emb_init, size=(n_rel, cfg.rel_dim)).astype(np.float32)
+    eng = StepEngine(model, n_ent, n_rel, hidden, gamma, lr, DEV, de, dr, adv, 1.0, reg, 3)
+    eng.load_tables(ent, rel)
+    for step in (1, 2):
+        # the oracle runs in fp64 from the SAME fp32 tables the GPU step starts from
+        ent64 = eng.ent.cpu().numpy().astype(np.float64)
+        rel64 = eng.rel.cpu().numpy().astype(np.float64)
+        es64 = eng.ent_state.cpu().numpy().astype(np.float64)
+        rs64 = eng.rel_state.cpu().numpy().astype(np.float64)
+        bt = O.synth_batch(rng, n_ent, n_rel, B, N, chunk, step)
+        b = plan.make_batch(bt["h"], bt["t"], bt["r"], bt["neg"], chunk, N, bt["neg_head"], DEV)
+        want = eng.alloc_outputs(b)
+        eng.step(b, want)
+        torch.cuda.synchronize()
+        out = O.train_step(cfg, ent64, es64, rel64, rs64, bt["nid"], bt["h_local"], bt["t_local"],
+                           bt["r"], bt["neg"], bt["neg_head"], chunk, N)
+        tag = "%s step %d" % (model, step)
+        _close(want["pos_score"].cpu(), out["pos_score"], 1e-4, 1e-4, tag + " pos_score")
+        _close(want["neg_score"].cpu(), out["neg_score"], 1e-4, 1e-4, tag + " neg_score")
+        l4 = eng.read_loss()
+        _close(l4[:3], out["log"][:3], 1e-4, 1e-5, tag + " loss")
+        _close(l4[3], out["log"][3], 1e-3, 1e-7, tag + " reg")
+        sel = np.searchsorted(b.p["ue_id"], bt["nid"])
+        _close(want["g_pos_ent"].cpu().numpy()[sel], out["g_pos_ent"], 3e-4, grad_tol(out["g_pos_ent"]), tag + " g_pos_ent")
+        _close(want["g_neg"].cpu(), out["g_neg"], 3e-4, grad_tol(out["g_neg"]), tag + " g_neg")
+        _close(want["g_rel"].cpu(), out["g_rel"], 3e-4, grad_tol(out["g_rel"]), tag + " g_rel")
+        _close(eng.ent_state.cpu(), es64, 2e-3, 1e-9, tag + " ent state")
+        _close(eng.rel_state.cpu(), rs64, 2e-3, 1e-9, tag + " rel state")
+        _close(eng.ent.cpu(), ent64, 1e-4, 5e-3 * lr, tag + " entity rows")
+        _close(eng.rel.cpu(), rel64, 1e-4, 5e-3 * lr, tag + " relation rows")
+
+
+def test_fused_step_is_deterministic_and_graph_replay_matches_eager():
+    """size-independent property at the full cfg-T shape: the owner-computes update has no atomics,
+    so two runs are bit-identical, and a HIP-graph replay equals eager launches."""
+    from dglke_amd import plan
+    from dglke_amd.engine import StepEngine
+    rng = np.random.RandomState(7)
+    n_ent, n_rel, B, N, D = 14951, 1345, 1000, 200, 400
+    plans = []
+    for step in range(1, 5):
+        bt = O.synth_batch(rng, n_ent, n_rel, B, N, N, step)
+        plans.append(plan.build_plan(bt["h"], bt["t"], bt["r"], bt["neg"], N, N, bt["neg_head"]))
+    results = []
+    for mode in ("eager", "eager", "graph"):
+        torch.manual_seed(0)
+        eng = StepEngine("TransE_l2", n_ent, n_rel, D, 19.9, 0.25, DEV, False, False, True, 1.0, 1e-9, 3)
+        batches = plan.upload(plans, DEV)
+        if mode == "eager":
+            for b in batches:
+                eng.step(b)
+        else:
+            # warm-up outside capture so that workspace allocation is not captured
+            eng.workspace_for(batches[0])
+            g = eng.capture(batches)
+            g.replay()
+        torch.cuda.synchronize()
+        results.append((eng.ent.cpu().numpy().copy(), eng.rel.cpu().numpy().copy(),
+                        eng.ent_state.cpu().numpy().copy(), np.array(eng.read_loss())))
+    for k in range(4):
+        assert np.array_equal(results[0][k], results[1][k]), "run-to-run difference in output %d" % k
+        assert np.array_equal(results[0][k], results[2][k]), "graph replay differs in output %d" % k
+    assert np.isfinite(results[0][3]).all()
+
+
+def test_adagrad_scatter_duplicate_semantics():
+    """ExternalEmbedding.update duplicate-index semantics (tensor_models.py:352-361) with the
+    lock-free scatter kernels: a table of 5 rows, 4096 updates."""
+    from dglke_amd import ops
+    rng = np.random.RandomState(3)
+    table = rng.randn(5, 64).astype(np.float32)
+    state = rng.rand(5).astype(np.float32)
+    idx = rng.randint(0, 5, size=4096).astype(np.int64)
+    grad = (rng.randn(4096, 64) * 0.01).astype(np.float32)
+    t_d, s_d = torch.from_numpy(table).to(DEV), torch.from_numpy(state).to(DEV)
+    ops.adagrad_scatter(t_d, s_d, torch.from_numpy(idx).to(DEV), torch.from_numpy(grad).to(DEV), 0.3)
+    t64, s64 = table.astype(np.float64), state.astype(np.float64)
+    O.adagrad_update(t64, s64, idx, grad.astype(np.float64), 0.3)
+    _close(s_d.cpu(), s64, 1e-5, 1e-7, "state")
+    _close(t_d.cpu(), t64, 1e-5, 1e-5, "table")
+
+
+def test_gather_rows_and_errors():
+    from dglke_amd import ops, _lib
+    t = torch.arange(0, 40, dtype=torch.float32, device=DEV).reshape(10, 4)
+    idx = torch.tensor([9, 0, 0, 3], device=DEV)
+    assert torch.equal(ops.gather_rows(t, idx), t[idx])
+    assert ops.gather_rows(t, idx[:0]).shape == (0, 4)
+    t5 = torch.arange(0, 50, dtype=torch.float32, device=DEV).reshape(10, 5)   # unaligned rows
+    assert torch.equal(ops.gather_rows(t5, idx), t5[idx])
+    with pytest.raises(_lib.KgeError):
+        ops.gather_rows(t.cpu(), idx.cpu())      # no CPU fallback
+    with pytest.raises(_lib.KgeError):
+        ops.score_pos("ComplEx", torch.zeros(2, 6, device=DEV), torch.zeros(2, 4, device=DEV),
+                      torch.zeros(2, 6, device=DEV), 1.0)

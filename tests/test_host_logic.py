@@ -1,0 +1,134 @@
+"""CPU tests of the host logic: the batch plan, the C-ABI surface of libkge_hip.so (symbols only -
+no compute without a GPU), the torch-CPU port used as cpu_baseline, the no-CPU-fallback rule."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import golden_names, load_golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__
+    __graft_entry__.build()
+    from dglke_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "kge_hip.h")).read()
+    declared = set(re.findall(r"\b(kge_[a-z_0-9]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    h = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(h, name), "libkge_hip.so does not export " + name
+    assert declared == set(_lib.EXPORTED_SYMBOLS), (declared ^ set(_lib.EXPORTED_SYMBOLS))
+    assert _lib.lib().kge_abi_version() == 1
+
+
+def test_argument_errors_are_reported_without_a_gpu():
+    from dglke_amd import _lib
+    h = _lib.lib()
+    rc = h.kge_gather_rows(None, 0, 4, None, 0, None, None)
+    assert rc == -1 and b"kge_gather_rows" in h.kge_last_error()
+    rc = h.kge_score_pos(3, 1, 1, 1, 2, 6, 4, 1.0, 1.0, 1, None)   # ComplEx with d_r != d_e
+    assert rc == -1 and b"ComplEx" in h.kge_last_error()
+    rc = h.kge_score_pos(9, 1, 1, 1, 2, 4, 4, 1.0, 1.0, 1, None)
+    assert rc == -1 and b"unknown model" in h.kge_last_error()
+
+
+def test_product_has_no_cpu_fallback():
+    from dglke_amd import _lib, ops
+    from dglke_amd.engine import StepEngine
+    with pytest.raises(_lib.KgeError):
+        ops.gather_rows(torch.zeros(4, 4), torch.zeros(2, dtype=torch.int64))
+    with pytest.raises(_lib.KgeError):
+        StepEngine("TransE_l2", 10, 2, 8, 12.0, 0.1, "cpu")
+    # nothing in the product imports the oracle
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "dgl-ke_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def _check_plan(p):
+    B, C, N = p["B"], p["C"], p["N"]
+    ue = p["ue_id"]
+    assert np.all(np.diff(ue) > 0)
+    assert set(ue) == set(p["nid"]) | set(p["neg_ids"])
+    # every edge end appears exactly once, under the right entity
+    seen = np.zeros(2 * B, bool)
+    for u in range(p["UE"]):
+        for k in range(p["ue_pos_ptr"][u], p["ue_pos_ptr"][u + 1]):
+            code = p["ue_pos_adj"][k]
+            e, side = code >> 1, code & 1
+            assert (p["t_gid"][e] if side else p["h_gid"][e]) == ue[u]
+            assert not seen[code]
+            seen[code] = True
+        slots = p["ue_neg_slot"][p["ue_neg_ptr"][u]:p["ue_neg_ptr"][u + 1]]
+        assert np.all(p["neg_ids"][slots] == ue[u]) and np.all(np.diff(slots) > 0)
+    assert seen.all() and p["ue_neg_ptr"][-1] == C * N
+    seen_e = np.zeros(B, bool)
+    for u in range(p["UR"]):
+        es = p["ur_edge"][p["ur_ptr"][u]:p["ur_ptr"][u + 1]]
+        assert np.all(p["rel_ids"][es] == p["ur_id"][u]) and np.all(np.diff(es) > 0)
+        seen_e[es] = True
+    assert seen_e.all()
+    assert np.array_equal(p["nid"][p["h_local"]], p["h_gid"])
+    assert np.array_equal(p["nid"][p["t_local"]], p["t_gid"])
+
+
+@pytest.mark.parametrize("n_ent,n_rel,B,N,chunk", [(50, 3, 16, 4, 4), (5, 1, 12, 3, 6), (14951, 1345, 1000, 200, 200)])
+def test_plan_groups_every_row_once(n_ent, n_rel, B, N, chunk):
+    from dglke_amd import plan
+    rng = np.random.RandomState(0)
+    h, t = rng.randint(0, n_ent, B), rng.randint(0, n_ent, B)
+    r = rng.randint(0, n_rel, B)
+    neg = rng.randint(0, n_ent, (B // chunk) * N)
+    p = plan.build_plan(h, t, r, neg, chunk, N, True)
+    _check_plan(p)
+    with pytest.raises(ValueError):
+        plan.build_plan(h[:-1], t[:-1], r[:-1], neg, chunk, N, True)     # ragged batch is rejected
+    with pytest.raises(ValueError):
+        plan.build_plan(h, t, r, neg[:-1], chunk, N, True)
+
+
+def test_sampler_alternates_corruption_side_and_covers_epochs():
+    """dataloader/sampler.py:853-859: step 1 corrupts tails, step 2 heads, ..."""
+    from dglke_amd.dataloader import UniformChunkedSampler
+    rng = np.random.RandomState(0)
+    n = 100
+    s = UniformChunkedSampler(rng.randint(0, 30, n), rng.randint(0, 4, n), rng.randint(0, 30, n), 30,
+                              batch_size=16, neg_sample_size=4, device="cpu", seed=1)
+    plans = s.next_plans(12)
+    assert [p["neg_head"] for p in plans[:4]] == [0, 1, 0, 1]
+    assert all(p["B"] == 16 and p["C"] == 4 and p["neg_ids"].shape[0] == 16 for p in plans)
+    for p in plans:
+        _check_plan(p)
+
+
+@pytest.mark.parametrize("name", [n for n in golden_names() if not any(
+    k in n for k in ("logistic", "hinge", "bce", "impts"))])
+def test_torch_port_matches_reference(name):
+    """the cpu_baseline port reproduces the reference step (same torch ops)."""
+    from oracle import torch_port
+    z, case = load_golden(name)
+    m = torch_port.TorchPort(case["model"], case["n_ent"], case["n_rel"], case["hidden"], case["gamma"],
+                             case["lr"], case["de"], case["dr"], case["adv"], case["adv_temp"],
+                             case["reg_coef"], case["reg_norm"])
+    m.ent = torch.from_numpy(z["init_entity"].copy())
+    m.rel = torch.from_numpy(z["init_relation"].copy())
+    torch.set_num_threads(1)
+    for s in range(1, case["steps"] + 1):
+        p = "s%d_" % s
+        pl = dict(nid=z[p + "nid"], rel_ids=z[p + "r"], neg_ids=z[p + "neg"], h_local=z[p + "h_local"],
+                  t_local=z[p + "t_local"], C=case["B"] // case["chunk"], chunk=case["chunk"],
+                  N=case["N"], neg_head=int(z[p + "neg_head"]))
+        out = m.step(pl)
+        np.testing.assert_allclose(out["neg_score"], z[p + "neg_score"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(out["g_neg"], z[p + "g_neg"], rtol=1e-4, atol=1e-7)
+        np.testing.assert_allclose(out["log"][2], z[p + "log"][2], rtol=1e-5)
+    np.testing.assert_allclose(m.ent.numpy(), z["final_entity"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(m.rel.numpy(), z["final_relation"], rtol=1e-4, atol=1e-5)
