@@ -74,7 +74,7 @@ const char *kge_last_error(void) { return g_err; }
 
 int kge_gather_rows(const float *table, int64_t n_rows, int dim, const int64_t *idx, int64_t n_idx,
                     float *out, void *stream) {
-    if (!table || !out || (!idx && n_idx) || dim <= 0 || n_rows < 0 || n_idx < 0)
+    if (!table || (!out && n_idx) || (!idx && n_idx) || dim <= 0 || n_rows < 0 || n_idx < 0)
         return fail(KGE_ERR_ARG, "kge_gather_rows: bad argument");
     KGE_TRY(launch_gather_rows(table, dim, idx, n_idx, out, (hipStream_t)stream));
     return KGE_OK;

@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 rocpd sqlite database (`--kernel-trace --stats` output) as a per-kernel
+table: calls, total / average / min / max duration, share of GPU time.  Usage:
+    python tools/rocpd_stats.py gpurun_out/prof/run/NNN_results.db > profiles/xxx_kernel_stats.txt
+"""
+import sqlite3
+import sys
+
+
+def main(path):
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+    name_col = "name" if "name" in cols else [c for c in cols if "name" in c][0]
+    rows = cur.execute("select %s, start, end from kernels" % name_col).fetchall()
+    agg = {}
+    for name, s, e in rows:
+        d = e - s
+        a = agg.setdefault(name, [0, 0, 1 << 62, 0])
+        a[0] += 1
+        a[1] += d
+        a[2] = min(a[2], d)
+        a[3] = max(a[3], d)
+    tot = sum(a[1] for a in agg.values())
+    print("%-72s %8s %12s %10s %10s %10s %6s" % ("kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "pct"))
+    for name, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        short = name if len(name) <= 72 else name[:69] + "..."
+        print("%-72s %8d %12.1f %10.3f %10.3f %10.3f %6.2f" % (short, a[0], a[1] / 1e3, a[1] / a[0] / 1e3,
+                                                             a[2] / 1e3, a[3] / 1e3, 100.0 * a[1] / tot))
+    print("total GPU kernel time: %.1f us over %d dispatches" % (tot / 1e3, len(rows)))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
