@@ -197,7 +197,7 @@ def main():
     wall = time.perf_counter() - t0
     ev_ms = ev0.elapsed_time(ev1)
     K = args.steps
-    accum = eng.loss_accum.tolist()
+    accum = eng.read_loss_sums()
     assert all(np.isfinite(accum[:3])), "non-finite loss: %r" % (accum,)
 
     bytes_step = algorithmic_bytes(plans, eng.d_e, eng.d_r)

@@ -222,7 +222,7 @@ int kge_loss_fwd_bwd(int loss_genre, int adv, float adv_temp, int pairwise, floa
     a.B = (int)B; a.N = N; a.genre = loss_genre; a.adv = adv; a.pairwise = pairwise;
     a.adv_temp = adv_temp; a.margin = margin; a.pos = pos; a.neg = neg; a.w = w;
     a.dpos = dpos; a.dneg = dneg; a.row_pos = row_pos; a.row_neg = row_neg;
-    a.l2_scale = 0; a.gamma = 0.f; a.neg_copy = nullptr;
+    a.l2_scale = 0; a.gamma = 0.f; a.neg_copy = nullptr; a.acc = nullptr;
     KGE_TRY(launch_loss(a, (hipStream_t)stream));
     if (loss3) {
         // finalize writes 4 floats {pos, neg, loss, reg}; loss3 has room for 3 -> stage in ws
@@ -235,6 +235,12 @@ int kge_loss_fwd_bwd(int loss_genre, int adv, float adv_temp, int pairwise, floa
         if (hipMemcpyAsync(loss3, l4, 3 * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
             return fail(KGE_ERR_LAUNCH, "hipMemcpyAsync failed");
     }
+    return KGE_OK;
+}
+
+int kge_reduce_loss(float *loss_accum, float *out4, int zero_after, void *stream) {
+    if (!loss_accum || !out4) return fail(KGE_ERR_ARG, "kge_reduce_loss: null argument");
+    KGE_TRY(launch_reduce_acc(loss_accum, out4, zero_after, (hipStream_t)stream));
     return KGE_OK;
 }
 
@@ -264,6 +270,7 @@ size_t kge_step_workspace_bytes(const kge_hparams *hp, int B, int C, int chunk, 
     size_t n = 0;
     auto add = [&](size_t floats) { n += align_up(floats * sizeof(float)); };
     add(B * d_e);        // A
+    add(CN * d_e);       // Bn (dense copy of the negative rows)
     add(B); add(CN);     // asq, bsq
     add(B); add(B);      // pos score, dpos
     add((size_t)B * N);  // S / W
@@ -297,7 +304,7 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     const bool reg = hp->reg_coef > 0.f && hp->reg_norm > 0;
 
     Carver cv(ws, ws_bytes);
-    float *A = cv.f((size_t)B * d_e), *asq = cv.f(B), *bsq = cv.f(CN);
+    float *A = cv.f((size_t)B * d_e), *Bn = cv.f((size_t)CN * d_e), *asq = cv.f(B), *bsq = cv.f(CN);
     float *P = cv.f(B), *dP = cv.f(B);
     float *S = cv.f((size_t)B * N);
     float *GA = cv.f((size_t)B * d_e), *GN = cv.f((size_t)CN * d_e);
@@ -319,12 +326,13 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     ef.gamma = hp->gamma; ef.rot_div = rot_div;
     ef.pos_score = P; ef.A = A; ef.asq = l2m ? asq : nullptr;
     ef.nbase = tb->ent; ef.nidx = b->neg_ids; ef.n_neg = CN; ef.bsq = l2m ? bsq : nullptr;
+    ef.Bn = Bn;
     KGE_TRY(launch_edge_fwd(ef, s));
 
     // 2. chunked negative scores
     NegArgs na{};
     na.model = hp->model; na.C = C; na.chunk = chunk; na.N = N; na.d_e = d_e; na.gamma = hp->gamma;
-    na.A = A; na.asq = asq; na.nbase = tb->ent; na.nidx = b->neg_ids; na.bsq = bsq; na.S = S;
+    na.A = A; na.asq = asq; na.nbase = Bn; na.nidx = nullptr; na.bsq = bsq; na.S = S;
     if (mfma) KGE_TRY(launch_neg_fwd_mfma(na, s)); else KGE_TRY(launch_neg_fwd_pair(na, s));
 
     // 3. loss and d loss / d score (S is overwritten in place by W)
@@ -332,7 +340,9 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     la.B = B; la.N = N; la.genre = hp->loss_genre; la.adv = hp->adv; la.pairwise = hp->pairwise;
     la.adv_temp = hp->adv_temp; la.margin = hp->margin;
     la.pos = P; la.neg = S; la.w = b->edge_w; la.dpos = dP; la.dneg = S;
-    la.row_pos = row_pos; la.row_neg = row_neg;
+    const bool want4 = out && out->loss4;
+    la.row_pos = want4 ? row_pos : nullptr; la.row_neg = want4 ? row_neg : nullptr;
+    la.acc = out ? out->loss_accum : nullptr;
     la.l2_scale = (l2m || l2p) ? 1 : 0; la.gamma = hp->gamma;
     la.neg_copy = out ? out->neg_score : nullptr;
     KGE_TRY(launch_loss(la, s));
@@ -359,7 +369,8 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     ua.ue_neg_ptr = b->ue_neg_ptr; ua.ue_neg_slot = b->ue_neg_slot;
     ua.ur_id = b->ur_id; ua.ur_ptr = b->ur_ptr; ua.ur_edge = b->ur_edge;
     ua.GH = GH; ua.GT = GT; ua.GN = GN; ua.GR = GR;
-    ua.reg_ent = reg_ent; ua.reg_rel = reg_rel;
+    ua.reg_ent = want4 ? reg_ent : nullptr; ua.reg_rel = want4 ? reg_rel : nullptr;
+    ua.acc = out ? out->loss_accum : nullptr;
     if (emit) {
         ua.g0 = emit->g0; ua.gs0 = emit->gs0; ua.g1 = emit->g1; ua.gs1 = emit->gs1;
         ua.gr = emit->gr; ua.gsr = emit->gsr;
@@ -368,12 +379,13 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     if (out && out->g_pos_ent) ua.g0 = out->g_pos_ent;
     KGE_TRY(launch_update(ua, s));
 
-    // 7. deterministic loss reduction
-    if (out && (out->loss4 || out->loss_accum)) {
+    // 7. deterministic reduction of this step's loss terms (only when the caller wants the
+    //    per-step values; running sums are accumulated by the kernels above without it)
+    if (want4) {
         FinalizeArgs f{};
         f.B = B; f.UE = b->UE; f.UR = b->UR; f.pairwise = hp->pairwise;
         f.row_pos = row_pos; f.row_neg = row_neg; f.reg_ent = reg_ent; f.reg_rel = reg_rel;
-        f.loss4 = out->loss4; f.accum = out->loss_accum;
+        f.loss4 = out->loss4;
         KGE_TRY(launch_finalize(f, s));
     }
     return KGE_OK;

@@ -108,6 +108,7 @@ struct EdgeFwdArgs {
     // extra row jobs folded into the same launch (fused step):
     const float *nbase; const int64_t *nidx; int n_neg;  // negative rows -> bsq
     float *bsq;                      // [n_neg] or null
+    float *Bn;                       // [n_neg,d_e] dense copy of the negative rows or null
 };
 
 struct EdgeBwdArgs {
@@ -141,7 +142,8 @@ struct LossArgs {
     float adv_temp, margin;
     const float *pos, *neg, *w;
     float *dpos, *dneg;              // dneg may alias neg (in place)
-    float *row_pos, *row_neg;        // [B] per-row loss terms (already divided by B)
+    float *row_pos, *row_neg;        // [B] per-row loss terms (already divided by B), or null
+    float *acc;                      // [4][KGE_ACC_SLOTS] running loss sums (slot = row & mask) or null
     int l2_scale; float gamma;       // if set: dneg /= (gamma - n)   (TransE_l2 GEMM backward)
     float *neg_copy;                 // optional copy of the scores before overwrite
 };
@@ -154,16 +156,16 @@ struct UpdateArgs {
     const int64_t *ur_id; const int32_t *ur_ptr, *ur_edge;
     const float *GH, *GT, *GN, *GR;
     float *reg_ent, *reg_rel;        // [UE], [UR] regularisation value partials (or null)
+    float *acc;                      // [4][KGE_ACC_SLOTS] running sums (row 3 = regularisation) or null
     // emit mode (sharded training): write gradients instead of updating the entity table
     float *g0, *gs0, *g1, *gs1, *gr, *gsr;
     int emit_ent, emit_rel;
-    float *out_g_pos;                // optional [UE,d_e] copy of the trace-0 gradient
 };
 
 struct FinalizeArgs {
     int B, UE, UR, pairwise;
     const float *row_pos, *row_neg, *reg_ent, *reg_rel;
-    float *loss4, *accum;
+    float *loss4;
 };
 
 int launch_gather_rows(const float *table, int dim, const int64_t *idx, int64_t n, float *out,
@@ -178,8 +180,7 @@ int launch_adagrad_scatter(float *table, float *state, int dim, const int64_t *i
 int launch_adagrad_apply_rows(float *table, float *state, int dim, const int64_t *idx,
                               const float *g, const float *gs, int64_t n, float lr, float eps,
                               hipStream_t s);
-int launch_add_reg_rows(float *G, const float *base, const int64_t *idx, int64_t n, int dim,
-                        float coef, int q, hipStream_t s);
+int launch_reduce_acc(float *acc, float *out4, int zero_after, hipStream_t s);
 bool neg_mfma_supported(int model, int d_e, int N);
 int launch_neg_fwd_mfma(const NegArgs &a, hipStream_t s);
 int launch_neg_bwd_mfma(const NegArgs &a, hipStream_t s);

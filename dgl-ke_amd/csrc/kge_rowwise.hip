@@ -15,6 +15,16 @@ using namespace kge;
 #define WAVE_ID() ((int64_t)blockIdx.x * KGE_WAVES_PER_BLOCK + (threadIdx.x >> 6))
 #define LANE() (threadIdx.x & 63)
 
+// running-sum slot update: a kernel adds at most once per slot when `unique`, so a plain
+// read-modify-write is race-free (and deterministic); otherwise fall back to a float atomic.
+__device__ __forceinline__ void acc_add(float *p, float v, bool unique) {
+#ifdef KGE_ACC_ATOMIC_ONLY
+    (void)unique; atomicAdd(p, v);
+#else
+    if (unique) *p += v; else atomicAdd(p, v);
+#endif
+}
+
 static inline int blocks_for_waves(int64_t waves) {
     return (int)((waves + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK);
 }
@@ -138,24 +148,30 @@ __global__ __launch_bounds__(KGE_BLOCK) void edge_fwd_kernel(EdgeFwdArgs a) {
             if (lane == 0) a.asq[i] = as;
         }
     } else if (w < (int64_t)a.B + a.n_neg) {
+        // negative row job: dense copy for the GEMM / pairwise kernels and |b|^2
         const int64_t j = w - a.B;
         const float *x = row_ptr(a.nbase, a.nidx, j, a.d_e);
+        float *cp = a.Bn ? a.Bn + j * (int64_t)a.d_e : nullptr;
         float s = 0.f;
         for (int it = lane; it < a.d_e / V; it += 64) {
             const Pack<V> v = ld<V>(x + it * V);
+            if (cp) st<V>(cp + it * V, v);
 #pragma unroll
             for (int e = 0; e < V; ++e) s += v.v[e] * v.v[e];
         }
-        s = wave_sum(s);
-        if (lane == 0) a.bsq[j] = s;
+        if (a.bsq) {
+            s = wave_sum(s);
+            if (lane == 0) a.bsq[j] = s;
+        }
     }
 }
 
 template <int MODEL>
 static int launch_edge_fwd_m(const EdgeFwdArgs &a, hipStream_t s) {
-    const int64_t waves = (int64_t)a.B + (a.bsq ? a.n_neg : 0);
+    const bool negjob = a.bsq || a.Bn;
+    const int64_t waves = (int64_t)a.B + (negjob ? a.n_neg : 0);
     EdgeFwdArgs b = a;
-    if (!a.bsq) b.n_neg = 0;
+    if (!negjob) b.n_neg = 0;
     const int nb = blocks_for_waves(waves);
     const bool cx = is_complex_model(MODEL);
     const bool vec = cx ? ((a.d_e / 2) % 4 == 0 && a.d_r % 4 == 0) : (a.d_e % 4 == 0);
@@ -397,14 +413,20 @@ __global__ __launch_bounds__(KGE_BLOCK) void loss_kernel(LossArgs a) {
         }
         lsum = wave_sum(lsum);
         dsum = wave_sum(dsum);
-        if (lane == 0) { a.dpos[i] = dsum; a.row_pos[i] = 0.f; a.row_neg[i] = lsum; }
+        if (lane == 0) {
+            a.dpos[i] = dsum;
+            if (a.row_pos) { a.row_pos[i] = 0.f; a.row_neg[i] = lsum; }
+            if (a.acc) acc_add(&a.acc[2 * KGE_ACC_SLOTS + (int)(i & (KGE_ACC_SLOTS - 1))], lsum, a.B <= KGE_ACC_SLOTS);
+        }
         return;
     }
+    float plw = 0.f;
     if (lane == 0) {
         float pl, dpl;
         criterion(a.genre, p, 1.f, a.margin, pl, dpl);
         a.dpos[i] = dpl * w * 0.5f * invB;
-        a.row_pos[i] = pl * w * invB;
+        plw = pl * w * invB;
+        if (a.row_pos) a.row_pos[i] = plw;
     }
     const float neg_label = a.genre == KGE_LOSS_BCE ? 0.f : -1.f;
     float mx = -INFINITY, Z = 1.f;
@@ -428,13 +450,122 @@ __global__ __launch_bounds__(KGE_BLOCK) void loss_kernel(LossArgs a) {
         if (a.l2_scale) { const float d = a.gamma - nv; g = d > 1e-15f ? g / d : 0.f; }
         dn[j] = g;
     }
-    acc = wave_sum(acc);
-    if (lane == 0) a.row_neg[i] = acc * invB;
+    acc = wave_sum(acc) * invB;
+    if (lane == 0) {
+        if (a.row_neg) a.row_neg[i] = acc;
+        if (a.acc) {
+            const int slot = (int)(i & (KGE_ACC_SLOTS - 1));
+            const bool uq = a.B <= KGE_ACC_SLOTS;
+            acc_add(&a.acc[0 * KGE_ACC_SLOTS + slot], plw, uq);
+            acc_add(&a.acc[1 * KGE_ACC_SLOTS + slot], acc, uq);
+            acc_add(&a.acc[2 * KGE_ACC_SLOTS + slot], 0.5f * (plw + acc), uq);
+        }
+    }
+}
+
+// register-resident variant: the whole score row (N <= 64*NPER) is loaded once.
+template <int NPER>
+__global__ __launch_bounds__(KGE_BLOCK) void loss_kernel_reg(LossArgs a) {
+    const int64_t i = WAVE_ID();
+    if (i >= a.B) return;
+    const int lane = LANE();
+    const int N = a.N;
+    const float *n = a.neg + i * (int64_t)N;
+    float *dn = a.dneg + i * (int64_t)N;
+    float *cp = a.neg_copy ? a.neg_copy + i * (int64_t)N : nullptr;
+    float nv[NPER];
+#pragma unroll
+    for (int u = 0; u < NPER; ++u) { const int j = lane + 64 * u; nv[u] = j < N ? n[j] : 0.f; }
+    const float w = a.w ? a.w[i] : 1.f;
+    const float p = a.pos[i];
+    const float invB = 1.f / (float)a.B;
+    const int slot = (int)(i & (KGE_ACC_SLOTS - 1));
+    if (a.pairwise) {   // loss.py:76-80
+        const float sc = w / ((float)a.B * (float)N);
+        float lsum = 0.f, dsum = 0.f;
+#pragma unroll
+        for (int u = 0; u < NPER; ++u) {
+            const int j = lane + 64 * u;
+            if (j < N) {
+                float val, dv;
+                criterion(a.genre, p - nv[u], 1.f, a.margin, val, dv);
+                lsum += val * sc;
+                const float dd = dv * sc;
+                dsum += dd;
+                if (cp) cp[j] = nv[u];
+                float g = -dd;
+                if (a.l2_scale) { const float d = a.gamma - nv[u]; g = d > 1e-15f ? g / d : 0.f; }
+                dn[j] = g;
+            }
+        }
+        lsum = wave_sum(lsum);
+        dsum = wave_sum(dsum);
+        if (lane == 0) {
+            a.dpos[i] = dsum;
+            if (a.row_pos) { a.row_pos[i] = 0.f; a.row_neg[i] = lsum; }
+            if (a.acc) acc_add(&a.acc[2 * KGE_ACC_SLOTS + slot], lsum, a.B <= KGE_ACC_SLOTS);
+        }
+        return;
+    }
+    float plw = 0.f;
+    if (lane == 0) {
+        float pl, dpl;
+        criterion(a.genre, p, 1.f, a.margin, pl, dpl);
+        a.dpos[i] = dpl * w * 0.5f * invB;
+        plw = pl * w * invB;
+        if (a.row_pos) a.row_pos[i] = plw;
+    }
+    const float neg_label = a.genre == KGE_LOSS_BCE ? 0.f : -1.f;
+    float mx = -INFINITY, Z = 1.f;
+    float ex[NPER];
+    if (a.adv) {   // softmax(neg * T) over the row, detached (loss.py:87-88)
+#pragma unroll
+        for (int u = 0; u < NPER; ++u) if (lane + 64 * u < N) mx = fmaxf(mx, nv[u] * a.adv_temp);
+        mx = wave_max(mx);
+        float z = 0.f;
+#pragma unroll
+        for (int u = 0; u < NPER; ++u) {
+            ex[u] = (lane + 64 * u < N) ? expf(nv[u] * a.adv_temp - mx) : 0.f;
+            z += ex[u];
+        }
+        Z = wave_sum(z);
+    }
+    const float invZ = 1.f / Z, invN = 1.f / (float)N;
+    float acc = 0.f;
+#pragma unroll
+    for (int u = 0; u < NPER; ++u) {
+        const int j = lane + 64 * u;
+        if (j < N) {
+            float nl, dnl;
+            criterion(a.genre, nv[u], neg_label, a.margin, nl, dnl);
+            const float A = a.adv ? ex[u] * invZ : invN;
+            acc += A * nl * w;
+            float g = dnl * w * A * 0.5f * invB;
+            if (cp) cp[j] = nv[u];
+            if (a.l2_scale) { const float d = a.gamma - nv[u]; g = d > 1e-15f ? g / d : 0.f; }
+            dn[j] = g;
+        }
+    }
+    acc = wave_sum(acc) * invB;
+    if (lane == 0) {
+        if (a.row_neg) a.row_neg[i] = acc;
+        if (a.acc) {
+            const bool uq = a.B <= KGE_ACC_SLOTS;
+            acc_add(&a.acc[0 * KGE_ACC_SLOTS + slot], plw, uq);
+            acc_add(&a.acc[1 * KGE_ACC_SLOTS + slot], acc, uq);
+            acc_add(&a.acc[2 * KGE_ACC_SLOTS + slot], 0.5f * (plw + acc), uq);
+        }
+    }
 }
 
 int launch_loss(const LossArgs &a, hipStream_t s) {
     if (a.B == 0) return KGE_OK;
-    hipLaunchKernelGGL(loss_kernel, dim3(blocks_for_waves(a.B)), dim3(KGE_BLOCK), 0, s, a);
+    const dim3 g(blocks_for_waves(a.B)), b(KGE_BLOCK);
+    if (a.N <= 64) hipLaunchKernelGGL(loss_kernel_reg<1>, g, b, 0, s, a);
+    else if (a.N <= 128) hipLaunchKernelGGL(loss_kernel_reg<2>, g, b, 0, s, a);
+    else if (a.N <= 256) hipLaunchKernelGGL(loss_kernel_reg<4>, g, b, 0, s, a);
+    else if (a.N <= 512) hipLaunchKernelGGL(loss_kernel_reg<8>, g, b, 0, s, a);
+    else hipLaunchKernelGGL(loss_kernel, g, b, 0, s, a);
     return check_launch();
 }
 
@@ -461,8 +592,26 @@ __global__ __launch_bounds__(KGE_BLOCK) void finalize_kernel(FinalizeArgs a) {
         else { o[0] = lp; o[1] = ln; o[2] = 0.5f * (lp + ln); }
         o[3] = re + rr;
         if (a.loss4) for (int k = 0; k < 4; ++k) a.loss4[k] = o[k];
-        if (a.accum) for (int k = 0; k < 4; ++k) a.accum[k] += o[k];
     }
+}
+
+// reduce the running-sum slots to 4 scalars {pos_loss, neg_loss, loss, regularisation} (sums over
+// all steps since the last reset; the host divides by the step count)
+__global__ __launch_bounds__(KGE_BLOCK) void reduce_acc_kernel(float *acc, float *out4, int zero_after) {
+    __shared__ float sh[KGE_WAVES_PER_BLOCK];
+    for (int r = 0; r < 4; ++r) {
+        const float v = block_sum_det(acc + r * KGE_ACC_SLOTS, KGE_ACC_SLOTS, sh);
+        if (threadIdx.x == 0) out4[r] = v;
+    }
+    if (zero_after) {
+        __syncthreads();
+        for (int k = threadIdx.x; k < 4 * KGE_ACC_SLOTS; k += KGE_BLOCK) acc[k] = 0.f;
+    }
+}
+
+int launch_reduce_acc(float *acc, float *out4, int zero_after, hipStream_t s) {
+    hipLaunchKernelGGL(reduce_acc_kernel, dim3(1), dim3(KGE_BLOCK), 0, s, acc, out4, zero_after);
+    return check_launch();
 }
 
 int launch_finalize(const FinalizeArgs &a, hipStream_t s) {
@@ -564,10 +713,14 @@ __global__ __launch_bounds__(KGE_BLOCK) void update_kernel(UpdateArgs a, int nb_
             if (a.gs0) a.gs0[u] = has_pos ? s0 : 0.f;
             if (a.gs1) a.gs1[u] = has_neg ? s1 : 0.f;
         }
-        if (a.reg_ent) {
+        if (reg && (a.reg_ent || a.acc)) {
             rv = wave_sum(rv);
-            if (lane == 0) a.reg_ent[u] = reg ? a.reg_coef * rv * (float)((has_pos ? 1 : 0) + (n1 - n0)) : 0.f;
-        }
+            const float val = a.reg_coef * rv * (float)((has_pos ? 1 : 0) + (n1 - n0));
+            if (lane == 0) {
+                if (a.reg_ent) a.reg_ent[u] = val;
+                if (a.acc) acc_add(&a.acc[3 * KGE_ACC_SLOTS + (int)(u & (KGE_ACC_SLOTS - 1))], val, a.UE + a.UR <= KGE_ACC_SLOTS);
+            }
+        } else if (a.reg_ent && lane == 0) a.reg_ent[u] = 0.f;
     } else {
         const int64_t u = ((int64_t)blockIdx.x - nb_ent) * KGE_WAVES_PER_BLOCK + (threadIdx.x >> 6);
         if (u >= a.UR) return;
@@ -579,7 +732,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void update_kernel(UpdateArgs a, int nb_
         float ss = 0.f, rv = 0.f;
         for (int it = lane; it < nit; it += 64) {
             const int off = it * V;
-            if (reg && a.reg_rel) {
+            if (reg && (a.reg_rel || a.acc)) {
                 const Pack<V> x = ld<V>(row + off);
 #pragma unroll
                 for (int e = 0; e < V; ++e) rv += reg_val(x.v[e], a.reg_norm);
@@ -612,20 +765,203 @@ __global__ __launch_bounds__(KGE_BLOCK) void update_kernel(UpdateArgs a, int nb_
             if (!a.emit_rel) a.rel_state[id] = sN;
             if (a.gsr) a.gsr[u] = ss;
         }
-        if (a.reg_rel) {
+        if (reg && (a.reg_rel || a.acc)) {
             rv = wave_sum(rv);
-            if (lane == 0) a.reg_rel[u] = reg ? a.reg_coef * rv * (float)(e1 - e0) : 0.f;
+            const float val = a.reg_coef * rv * (float)(e1 - e0);
+            if (lane == 0) {
+                if (a.reg_rel) a.reg_rel[u] = val;
+                if (a.acc) acc_add(&a.acc[3 * KGE_ACC_SLOTS + (int)((u + a.UE) & (KGE_ACC_SLOTS - 1))], val, a.UE + a.UR <= KGE_ACC_SLOTS);
+            }
+        } else if (a.reg_rel && lane == 0) a.reg_rel[u] = 0.f;
+    }
+}
+
+// single-pass variant: the row and its gradients stay in registers (row width <= 256*NIT floats),
+// so every table row is read once and written once - the algorithmic minimum.
+template <int NIT>
+__global__ __launch_bounds__(KGE_BLOCK) void update_kernel_reg(UpdateArgs a, int nb_ent) {
+    const int lane = LANE();
+    const bool reg = a.reg_coef > 0.f && a.reg_norm > 0;
+    if ((int)blockIdx.x < nb_ent) {
+        const int64_t u = WAVE_ID();
+        if (u >= a.UE) return;
+        const int d = a.model_d_e;
+        const int64_t id = a.ue_id[u];
+        const int p0 = a.ue_pos_ptr[u], p1 = a.ue_pos_ptr[u + 1];
+        const int n0 = a.ue_neg_ptr[u], n1 = a.ue_neg_ptr[u + 1];
+        float *row = a.ent + id * (int64_t)d;
+        const float st0 = a.ent_state[id];
+        const bool has_pos = p1 > p0, has_neg = n1 > n0;
+        const int nit = d >> 2;
+        Pack<4> x[NIT], g0[NIT], g1[NIT];
+        float rv = 0.f;
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int it = lane + 64 * k;
+            g1[k] = zero_pack<4>();
+            if (it < nit) {
+                x[k] = ld<4>(row + it * 4);
+                if (reg) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        rv += reg_val(x[k].v[e], a.reg_norm);
+                        g0[k].v[e] = reg_grad(x[k].v[e], a.reg_coef, a.reg_norm);
+                    }
+                } else g0[k] = zero_pack<4>();
+            } else { x[k] = zero_pack<4>(); g0[k] = zero_pack<4>(); }
         }
+        float s0 = 0.f, s1 = 0.f;
+        for (int p = p0; p < p1; ++p) {
+            const int adj = a.ue_pos_adj[p];
+            const float *src = ((adj & 1) ? a.GT : a.GH) + (int64_t)(adj >> 1) * d;
+#pragma unroll
+            for (int k = 0; k < NIT; ++k) {
+                const int it = lane + 64 * k;
+                if (it < nit) {
+                    const Pack<4> g = ld<4>(src + it * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) g0[k].v[e] += g.v[e];
+                }
+            }
+        }
+        for (int q = n0; q < n1; ++q) {
+            const float *src = a.GN + (int64_t)a.ue_neg_slot[q] * d;
+#pragma unroll
+            for (int k = 0; k < NIT; ++k) {
+                const int it = lane + 64 * k;
+                if (it < nit) {
+                    const Pack<4> g = ld<4>(src + it * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { s1 += g.v[e] * g.v[e]; g1[k].v[e] += g.v[e]; }
+                }
+            }
+        }
+        if (has_pos) {
+#pragma unroll
+            for (int k = 0; k < NIT; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s0 += g0[k].v[e] * g0[k].v[e];
+        } else {
+#pragma unroll
+            for (int k = 0; k < NIT; ++k) g0[k] = zero_pack<4>();
+        }
+        // two interleaved wave reductions
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64); }
+        s0 /= (float)d; s1 /= (float)d;
+        const float sA = has_pos ? st0 + s0 : st0;
+        const float sB = has_neg ? sA + s1 : sA;
+        const float std0 = sqrtf(sA) + a.eps, std1 = sqrtf(sB) + a.eps;
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int it = lane + 64 * k;
+            if (it < nit) {
+                if (!a.emit_ent) {
+                    Pack<4> y = x[k];
+                    if (has_pos) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) y.v[e] += (-a.lr * g0[k].v[e]) / std0;
+                    }
+                    if (has_neg) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) y.v[e] += (-a.lr * g1[k].v[e]) / std1;
+                    }
+                    st<4>(row + it * 4, y);
+                }
+                if (a.g0) st<4>(a.g0 + u * (int64_t)d + it * 4, g0[k]);
+                if (a.g1) st<4>(a.g1 + u * (int64_t)d + it * 4, g1[k]);
+            }
+        }
+        if (lane == 0) {
+            if (!a.emit_ent) a.ent_state[id] = sB;
+            if (a.gs0) a.gs0[u] = has_pos ? s0 : 0.f;
+            if (a.gs1) a.gs1[u] = has_neg ? s1 : 0.f;
+        }
+        if (reg && (a.reg_ent || a.acc)) {
+            rv = wave_sum(rv);
+            const float val = a.reg_coef * rv * (float)((has_pos ? 1 : 0) + (n1 - n0));
+            if (lane == 0) {
+                if (a.reg_ent) a.reg_ent[u] = val;
+                if (a.acc) acc_add(&a.acc[3 * KGE_ACC_SLOTS + (int)(u & (KGE_ACC_SLOTS - 1))], val, a.UE + a.UR <= KGE_ACC_SLOTS);
+            }
+        } else if (a.reg_ent && lane == 0) a.reg_ent[u] = 0.f;
+    } else {
+        const int64_t u = ((int64_t)blockIdx.x - nb_ent) * KGE_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+        if (u >= a.UR) return;
+        const int d = a.d_r;
+        const int64_t id = a.ur_id[u];
+        const int e0 = a.ur_ptr[u], e1 = a.ur_ptr[u + 1];
+        float *row = a.rel + id * (int64_t)d;
+        const float st0 = a.rel_state[id];
+        const int nit = d >> 2;
+        Pack<4> x[NIT], gsum[NIT];
+        float rv = 0.f, ss = 0.f;
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int it = lane + 64 * k;
+            gsum[k] = zero_pack<4>();
+            if (it < nit) {
+                x[k] = ld<4>(row + it * 4);
+                if (reg) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rv += reg_val(x[k].v[e], a.reg_norm);
+                }
+            } else x[k] = zero_pack<4>();
+        }
+        for (int q = e0; q < e1; ++q) {
+            const float *src = a.GR + (int64_t)a.ur_edge[q] * d;
+#pragma unroll
+            for (int k = 0; k < NIT; ++k) {
+                const int it = lane + 64 * k;
+                if (it < nit) {
+                    const Pack<4> g = ld<4>(src + it * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { ss += g.v[e] * g.v[e]; gsum[k].v[e] += g.v[e]; }
+                }
+            }
+        }
+        ss = wave_sum(ss) / (float)d;
+        const float sN = st0 + ss;
+        const float sd = sqrtf(sN) + a.eps;
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int it = lane + 64 * k;
+            if (it < nit) {
+                if (!a.emit_rel) {
+                    Pack<4> y = x[k];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) y.v[e] += (-a.lr * gsum[k].v[e]) / sd;
+                    st<4>(row + it * 4, y);
+                }
+                if (a.gr) st<4>(a.gr + u * (int64_t)d + it * 4, gsum[k]);
+            }
+        }
+        if (lane == 0) {
+            if (!a.emit_rel) a.rel_state[id] = sN;
+            if (a.gsr) a.gsr[u] = ss;
+        }
+        if (reg && (a.reg_rel || a.acc)) {
+            rv = wave_sum(rv);
+            const float val = a.reg_coef * rv * (float)(e1 - e0);
+            if (lane == 0) {
+                if (a.reg_rel) a.reg_rel[u] = val;
+                if (a.acc) acc_add(&a.acc[3 * KGE_ACC_SLOTS + (int)((u + a.UE) & (KGE_ACC_SLOTS - 1))], val, a.UE + a.UR <= KGE_ACC_SLOTS);
+            }
+        } else if (a.reg_rel && lane == 0) a.reg_rel[u] = 0.f;
     }
 }
 
 int launch_update(const UpdateArgs &a, hipStream_t s) {
     const int nbE = blocks_for_waves(a.UE), nbR = blocks_for_waves(a.UR);
     if (nbE + nbR == 0) return KGE_OK;
-    if (a.model_d_e % 4 == 0 && a.d_r % 4 == 0)
-        hipLaunchKernelGGL(update_kernel<4>, dim3(nbE + nbR), dim3(KGE_BLOCK), 0, s, a, nbE);
-    else
-        hipLaunchKernelGGL(update_kernel<1>, dim3(nbE + nbR), dim3(KGE_BLOCK), 0, s, a, nbE);
+    const dim3 g(nbE + nbR), b(KGE_BLOCK);
+    const int dmax = a.model_d_e > a.d_r ? a.model_d_e : a.d_r;
+    const bool vec = a.model_d_e % 4 == 0 && a.d_r % 4 == 0;
+    if (vec && dmax <= 256) hipLaunchKernelGGL(update_kernel_reg<1>, g, b, 0, s, a, nbE);
+    else if (vec && dmax <= 512) hipLaunchKernelGGL(update_kernel_reg<2>, g, b, 0, s, a, nbE);
+    else if (vec && dmax <= 1024) hipLaunchKernelGGL(update_kernel_reg<4>, g, b, 0, s, a, nbE);
+    else if (vec) hipLaunchKernelGGL(update_kernel<4>, g, b, 0, s, a, nbE);
+    else hipLaunchKernelGGL(update_kernel<1>, g, b, 0, s, a, nbE);
     return check_launch();
 }
 

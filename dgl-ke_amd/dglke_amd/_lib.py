@@ -10,12 +10,13 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkge_hip.so")
+LIB_PATH = os.environ.get("KGE_LIB") or os.path.join(_HERE, "libkge_hip.so")   # KGE_LIB: A/B builds
 
 KGE_ABI_VERSION = 1
 MODEL_IDS = {"TransE_l1": 0, "TransE_l2": 1, "TransE": 1, "DistMult": 2, "ComplEx": 3, "RotatE": 4}
 LOSS_IDS = {"Logsigmoid": 0, "Logistic": 1, "Hinge": 2, "BCE": 3}
 FLAG_FORCE_PAIRWISE = 1
+ACC_SLOTS = 4096
 
 c_f = C.c_float
 c_i = C.c_int
@@ -69,6 +70,7 @@ _SIGNATURES = {
                                 c_f, c_p, c_p, c_p, c_p, c_sz, c_u, c_p]),
     "kge_loss_fwd_bwd": (c_i, [c_i, c_i, c_f, c_i, c_f, c_p, c_p, c_p, c_i64, c_i, c_p, c_p, c_p,
                                c_p, c_sz, c_p]),
+    "kge_reduce_loss": (c_i, [c_p, c_p, c_i, c_p]),
     "kge_adagrad_scatter": (c_i, [c_p, c_p, c_i64, c_i, c_p, c_p, c_i64, c_f, c_f, c_p]),
     "kge_adagrad_apply_rows": (c_i, [c_p, c_p, c_i64, c_i, c_p, c_p, c_p, c_i64, c_f, c_f, c_p]),
     "kge_step_workspace_bytes": (c_sz, [C.POINTER(KgeHParams), c_i, c_i, c_i, c_i, c_i, c_i]),

@@ -54,7 +54,8 @@ class StepEngine(object):
             self.ent, self.ent_state, self.rel, self.rel_state = tables
         self._bind_tables()
         self.loss4 = torch.zeros(4, dtype=torch.float32, device=self.device)
-        self.loss_accum = torch.zeros(4, dtype=torch.float32, device=self.device)
+        self.loss_accum = torch.zeros(4 * _lib.ACC_SLOTS, dtype=torch.float32, device=self.device)
+        self._sum4 = torch.zeros(4, dtype=torch.float32, device=self.device)
         self._ws = None
         self._ws_bytes = 0
         self._graphs = []
@@ -93,12 +94,13 @@ class StepEngine(object):
             self._ws_bytes = self._ws.numel()
         return self._ws
 
-    def step(self, batch, want=None, emit=None):
+    def step(self, batch, want=None, emit=None, per_step_loss=False):
         """enqueue one fused step.  `want`: dict of optional output tensors (pos_score, neg_score,
         g_pos_ent, g_neg, g_rel).  `emit`: KgeEmit for the sharded path."""
         ws = self.workspace_for(batch)
         out = _lib.KgeStepOut()
-        out.loss4 = ptr(self.loss4)
+        if want is not None or per_step_loss:
+            out.loss4 = ptr(self.loss4)
         out.loss_accum = ptr(self.loss_accum)
         if want:
             for k, t in want.items():
@@ -132,5 +134,12 @@ class StepEngine(object):
         return g
 
     def read_loss(self):
-        """one 16-byte D2H copy: [pos_loss, neg_loss, loss, regularization] of the last step."""
+        """[pos_loss, neg_loss, loss, regularization] of the last step run with `want` or
+        `per_step_loss` (one 16-byte D2H copy)."""
         return self.loss4.tolist()
+
+    def read_loss_sums(self, zero=True):
+        """sums of the four loss terms over all steps since the last reset (one reduction
+        kernel + one 16-byte D2H copy); the caller divides by its step count."""
+        check(lib().kge_reduce_loss(ptr(self.loss_accum), ptr(self._sum4), int(zero), stream_ptr()))
+        return self._sum4.tolist()

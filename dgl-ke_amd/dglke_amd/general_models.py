@@ -216,7 +216,7 @@ class KEModel(object):
         batch = pos_g.batch if hasattr(pos_g, 'batch') else pos_g
         if getattr(self.args, 'neg_deg_sample', False):
             raise KgeError("neg_deg_sample is only available on the drop-in path")
-        self.engine.step(batch)
+        self.engine.step(batch, per_step_loss=sync_log)
         if not sync_log:
             return None
         v = self.engine.read_loss()

@@ -165,14 +165,23 @@ typedef struct kge_tables {
 
 /* optional outputs of a step (any may be NULL) */
 typedef struct kge_step_out {
-    float *loss4;      /* {pos_loss, neg_loss, loss (without reg), regularization}           */
-    float *loss_accum; /* [4] running sums (+= loss4) for log_interval averaging             */
+    float *loss4;      /* {pos_loss, neg_loss, loss (without reg), regularization} of THIS   */
+                       /* step (costs one extra single-block reduction kernel)              */
+    float *loss_accum; /* [4][KGE_ACC_SLOTS] running sums over steps of the same four        */
+                       /* quantities, spread over slots so that no per-step reduction is     */
+                       /* needed; reduce with kge_reduce_loss() when the log is wanted       */
+                       /* (replaces the 3-4 .item() host syncs per step of loss.py:95-97)    */
     float *pos_score;  /* [B]                                                                */
     float *neg_score;  /* [C,chunk,N] scores (copied before they are overwritten)            */
-    float *g_pos_ent;  /* [U? no: UE, d_e] trace-0 gradient per union entry (0 if not pos)   */
+    float *g_pos_ent;  /* [UE, d_e] trace-0 gradient per union entry (0 if not a pos node)   */
     float *g_neg;      /* [C*N, d_e]  trace-1 gradient                                       */
     float *g_rel;      /* [B, d_r]    relation-trace gradient                                */
 } kge_step_out;
+
+#define KGE_ACC_SLOTS 4096
+/* out4 = per-quantity sums of the running-sum slots (divide by the number of steps for the
+ * averages the reference prints, train_pytorch.py:165-167); optionally zero the slots. */
+int kge_reduce_loss(float *loss_accum, float *out4, int zero_after, void *stream);
 
 size_t kge_step_workspace_bytes(const kge_hparams *hp, int B, int C, int chunk, int N, int UE,
                                 int UR);

@@ -239,7 +239,7 @@ def test_fused_step_is_deterministic_and_graph_replay_matches_eager():
             g.replay()
         torch.cuda.synchronize()
         results.append((eng.ent.cpu().numpy().copy(), eng.rel.cpu().numpy().copy(),
-                        eng.ent_state.cpu().numpy().copy(), np.array(eng.read_loss())))
+                        eng.ent_state.cpu().numpy().copy(), np.array(eng.read_loss_sums())))
     for k in range(4):
         assert np.array_equal(results[0][k], results[1][k]), "run-to-run difference in output %d" % k
         assert np.array_equal(results[0][k], results[2][k]), "graph replay differs in output %d" % k
