@@ -104,7 +104,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3000)
     ap.add_argument("--warmup", type=int, default=300)
-    ap.add_argument("--workload", default="transe_l2_fb15k", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="transe_l2_fb15k",
+                    choices=sorted(WORKLOADS) + ["transe_l2_freebase", "rotate_freebase"])
     ap.add_argument("--pool", type=int, default=480, help="pre-staged batches (cycled)")
     ap.add_argument("--graph-steps", type=int, default=120, help="steps per captured HIP graph")
     ap.add_argument("--no-graph", action="store_true")
@@ -115,7 +116,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or os.environ.get("KGE_FORCE_DIST"):
         import bench_dist
         return bench_dist.main(args, world, rank, local_rank)
     if args.gpus != 1:

@@ -1,0 +1,121 @@
+"""bench_dist.py - N>1 leg of bench.py: weak-scaled, one process per GPU (torch.distributed, backend
+nccl = RCCL), entity table range-sharded across the ranks (dglke_amd/dist.py).
+
+Per-GPU work is the SAME step as the N=1 bench (TransE_l2, batch 1000, neg 200, dim 400, -adv) but
+on a Freebase-sized synthetic id space (86 054 151 entities, 14 824 relations -
+examples/README.md:11 of the reference), which is what the entity sharding is for: the table is
+137.7 GB, each rank holds 1/N of it in HBM and pulls/pushes the rows of its batch over xGMI
+all-to-all.  `--workload rotate_freebase` selects BASELINE.json configs[4] (RotatE, D_e = 800).
+value = (steps x batch x N) / max-over-ranks wall time.
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+DIST_WORKLOADS = {
+    "transe_l2_freebase": dict(model="TransE_l2", n_ent=86054151, n_rel=14824, hidden=400, de=False,
+                               dr=False, B=1000, N=200, gamma=10.0, lr=0.1, adv=True, adv_temp=1.0,
+                               reg_coef=1e-9, reg_norm=3),
+    "rotate_freebase": dict(model="RotatE", n_ent=86054151, n_rel=14824, hidden=400, de=True, dr=False,
+                            B=1024, N=256, gamma=12.0, lr=0.01, adv=True, adv_temp=1.0,
+                            reg_coef=1e-7, reg_norm=3),
+}
+
+
+def main(args, world, rank, local_rank):
+    import __graft_entry__
+    __graft_entry__.build()      # serialised by a file lock; a no-op when the .so is current
+    from dglke_amd import _lib, plan
+    from dglke_amd import dist as kd
+    from dglke_amd.engine import StepEngine
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if not dist.is_initialized():
+        if "MASTER_ADDR" not in os.environ:
+            os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29533"
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    name = args.workload if args.workload in DIST_WORKLOADS else "transe_l2_freebase"
+    w = dict(DIST_WORKLOADS[name])
+    n_ent = int(os.environ.get("KGE_DIST_ENTITIES", w["n_ent"]))
+    d_e = 2 * w["hidden"] if w["de"] else w["hidden"]
+    spec = kd.ShardSpec(n_ent, world, rank)
+    emb_init = (w["gamma"] + 2.0) / w["hidden"]
+    torch.manual_seed(1234 + rank)
+    ent = torch.empty(spec.n_local, d_e, dtype=torch.float32, device=dev).uniform_(-emb_init, emb_init)
+    ent_state = torch.zeros(spec.n_local, dtype=torch.float32, device=dev)
+    torch.manual_seed(99)          # identical relation replicas on every rank
+    eng = StepEngine(w["model"], 1, w["n_rel"], w["hidden"], w["gamma"], w["lr"], dev, w["de"], w["dr"],
+                     w["adv"], w["adv_temp"], w["reg_coef"], w["reg_norm"])
+    de = kd.DistEngine(eng, spec, ent, ent_state)
+
+    # pre-stage a pool of batches: ids (uniform, like the N=1 bench), plans, routes
+    pool = max(8, min(args.pool, 64))
+    rng = np.random.RandomState(1000 + rank)
+    C = w["B"] // w["N"]
+    plans, ues = [], []
+    for s in range(pool):
+        h = rng.randint(0, n_ent, w["B"]).astype(np.int64)
+        t = rng.randint(0, n_ent, w["B"]).astype(np.int64)
+        r = rng.randint(0, w["n_rel"], w["B"]).astype(np.int64)
+        neg = rng.randint(0, n_ent, C * w["N"]).astype(np.int64)
+        ue, p = kd.localize_plan(h, t, r, neg, w["N"], w["N"], (s + 1) % 2 == 0)
+        plans.append(p)
+        ues.append(ue)
+    batches = plan.upload(plans, dev)
+    routes = [de.prepare_route(ue) for ue in ues]
+    for b in batches:
+        eng.workspace_for(b)
+
+    def run(start, count):
+        for k in range(count):
+            i = (start + k) % pool
+            de.step(batches[i], routes[i])
+
+    run(0, args.warmup)
+    torch.cuda.synchronize()
+    dist.barrier()
+    eng.loss_accum.zero_()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(args.warmup, args.steps)
+    torch.cuda.synchronize()
+    dist.barrier()
+    wall = time.perf_counter() - t0
+    tw = torch.tensor([wall], dtype=torch.float64, device=dev)
+    dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+    wall = float(tw.item())
+    sums = eng.read_loss_sums()
+    K = args.steps
+    if rank == 0:
+        # algorithmic bytes per rank-step (SURVEY 8d formula on the actual batches)
+        bytes_step = float(np.mean([12.0 * (p["UE"] * d_e + p["B"] * eng.d_r) + 16.0 * (p["UE"] + p["B"])
+                                    for p in plans]))
+        xgmi_step = float(np.mean([3.0 * p["UE"] * d_e * 4 * (world - 1) / world for p in plans]))
+        out = {
+            "metric": "positive edges/sec (whole node)",
+            "value": round(K * w["B"] * world / wall, 1), "unit": "edges/s",
+            "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * wall / K, 5),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s synthetic Freebase-sized: n_ent=%d n_rel=%d, per-GPU batch=%d neg=%d "
+                                   "dim=%d, entity table range-sharded over %d GPUs (%.1f GB/GPU), relation "
+                                   "table replicated, RCCL all-to-all pull/push, eager launches"
+                                   % (w["model"], n_ent, w["n_rel"], w["B"], w["N"], w["hidden"], world,
+                                      spec.n_local * d_e * 4 / 1e9),
+                       "global_batch": w["B"] * world, "parallelism": "entity-shard x%d (all-to-all)" % world},
+            "roofline": {"bound": "hbm", "achieved": round(bytes_step * world / (wall / K) / 1e9, 2),
+                         "peak": 8000.0 * world, "unit": "GB/s",
+                         "frac": round(bytes_step / (wall / K) / 1e9 / 8000.0, 5), "traffic": None,
+                         "algorithmic_bytes_per_rank_step": round(bytes_step, 1),
+                         "xgmi_bytes_per_rank_step": round(xgmi_step, 1)},
+            "mean_loss": round(sums[2] / K, 6),
+        }
+        print(json.dumps(out))
+    dist.destroy_process_group()

@@ -1,0 +1,163 @@
+"""world_size-2 gloo test (CPU) of the sharded step's ROUTING (dglke_amd/dist.py): id bucketing by
+owner, row pull, gradient push, owner-side apply order, replicated relation update.  The
+arithmetic is supplied by a stand-in ops object built on the CPU oracle (test infrastructure); the
+product path uses HipOps (libkge_hip) and is covered on the GPU by tests/test_gpu_parity.py."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+N_ENT, N_REL, HID, B, N, CHUNK, LR = 37, 5, 8, 12, 4, 4, 0.1
+MODEL, GAMMA = "TransE_l2", 12.0
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class FakeEngine(object):
+    """what DistEngine needs from a StepEngine: relation table + lr; no HIP."""
+    def __init__(self, rel, rel_state, lr):
+        self.rel, self.rel_state, self.lr = rel, rel_state, lr
+
+
+class OracleOps(object):
+    def __init__(self, cfg):
+        self.cfg = cfg
+
+    def gather(self, table, idx):
+        return table[idx].clone()
+
+    def apply_rows(self, table, state, idx, g, gs, lr):
+        for k in range(idx.shape[0]):
+            i = int(idx[k])
+            if i < 0 or float(gs[k]) == 0.0:
+                continue
+            state[i] += gs[k]
+            table[i] += (-lr * g[k]) / (torch.sqrt(state[i]) + 1e-10)
+
+    def step_grads(self, engine, batch, cache, em):
+        from oracle import kge_oracle as O
+        p = batch.p
+        out = O.forward_backward(self.cfg, cache.numpy().astype(np.float64), engine.rel.numpy().astype(np.float64),
+                                 p["nid"], p["h_local"], p["t_local"], p["rel_ids"], p["neg_ids"],
+                                 bool(p["neg_head"]), p["chunk"], p["N"])
+        for k in ("g0", "gs0", "g1", "gs1"):
+            em[k].zero_()
+        g0 = np.zeros((p["UE"], cache.shape[1]))
+        g0[p["nid"]] = out["g_pos_ent"]
+        gs0 = np.zeros(p["UE"])
+        gs0[p["nid"]] = (out["g_pos_ent"] ** 2).mean(1)
+        g1 = np.zeros_like(g0)
+        gs1 = np.zeros(p["UE"])
+        np.add.at(g1, p["neg_ids"], out["g_neg"])
+        np.add.at(gs1, p["neg_ids"], (out["g_neg"] ** 2).mean(1))
+        em["g0"].copy_(torch.from_numpy(g0)); em["gs0"].copy_(torch.from_numpy(gs0))
+        em["g1"].copy_(torch.from_numpy(g1)); em["gs1"].copy_(torch.from_numpy(gs1))
+        gr = np.zeros((p["B"], engine.rel.shape[1]))
+        gsr = np.zeros(p["B"])
+        ur = p["ur_id"]
+        inv = np.searchsorted(ur, p["rel_ids"])
+        np.add.at(gr, inv, out["g_rel"])
+        np.add.at(gsr, inv, (out["g_rel"] ** 2).mean(1))
+        em["gr"].copy_(torch.from_numpy(gr)); em["gsr"].copy_(torch.from_numpy(gsr))
+
+
+def _batches(world, steps):
+    from oracle import kge_oracle as O
+    rng = np.random.RandomState(5)
+    return [[O.synth_batch(rng, N_ENT, N_REL, B, N, CHUNK, s + 1) for _ in range(world)] for s in range(steps)]
+
+
+def _worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "dgl-ke_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dglke_amd import dist as kd, plan
+        from oracle import kge_oracle as O
+        cfg = O.Config(MODEL, GAMMA, HID, LR, adv=True, reg_coef=1e-3)
+        rng = np.random.RandomState(1)
+        ent = rng.uniform(-1, 1, (N_ENT, HID))
+        rel = rng.uniform(-1, 1, (N_REL, HID))
+        spec = kd.ShardSpec(N_ENT, world, rank)
+        ent_shard = torch.from_numpy(ent[spec.lo:spec.hi].copy())
+        state_shard = torch.zeros(spec.n_local, dtype=torch.float64)
+        eng = FakeEngine(torch.from_numpy(rel.copy()), torch.zeros(N_REL, dtype=torch.float64), LR)
+        de = kd.DistEngine(eng, spec, ent_shard, state_shard, ops=OracleOps(cfg))
+        for step_batches in _batches(world, 3):
+            bt = step_batches[rank]
+            ue, p = kd.localize_plan(bt["h"], bt["t"], bt["r"], bt["neg"], CHUNK, N, bt["neg_head"])
+            b = plan.upload([p], "cpu")[0]
+            route = de.prepare_route(ue)
+            assert sum(route.send_counts) == len(ue)
+            de.step(b, route)
+        # collect the shards on rank 0
+        shards = [None] * world
+        dist.all_gather_object(shards, (ent_shard.numpy(), state_shard.numpy(), eng.rel.numpy(), eng.rel_state.numpy()))
+        if rank == 0:
+            ret["ent"] = np.concatenate([s[0] for s in shards])
+            ret["state"] = np.concatenate([s[1] for s in shards])
+            ret["rels"] = [s[2] for s in shards]
+            ret["rel_states"] = [s[3] for s in shards]
+    finally:
+        dist.destroy_process_group()
+
+
+def _expected(world):
+    """single-process statement of the synchronous sharded step: every rank's gradients are
+    computed from the SAME pre-step tables, then applied owner-side in rank order (trace 0 then
+    trace 1 per rank; relations in rank order)."""
+    from oracle import kge_oracle as O
+    cfg = O.Config(MODEL, GAMMA, HID, LR, adv=True, reg_coef=1e-3)
+    rng = np.random.RandomState(1)
+    ent = rng.uniform(-1, 1, (N_ENT, HID))
+    rel = rng.uniform(-1, 1, (N_REL, HID))
+    es, rs = np.zeros(N_ENT), np.zeros(N_REL)
+    for step_batches in _batches(world, 3):
+        outs = [O.forward_backward(cfg, ent, rel, bt["nid"], bt["h_local"], bt["t_local"], bt["r"],
+                                   bt["neg"], bt["neg_head"], CHUNK, N) for bt in step_batches]
+        for bt, out in zip(step_batches, outs):
+            O.adagrad_update(ent, es, bt["nid"], out["g_pos_ent"], LR)
+            O.adagrad_update(ent, es, bt["neg"], out["g_neg"], LR)
+        for bt, out in zip(step_batches, outs):
+            O.adagrad_update(rel, rs, bt["r"], out["g_rel"], LR)
+    return ent, es, rel, rs
+
+
+def test_shard_spec_covers_all_ids():
+    sys.path.insert(0, os.path.join(ROOT, "dgl-ke_amd"))
+    from dglke_amd.dist import ShardSpec
+    for n, w in ((37, 2), (86054151, 8), (5, 8), (16, 4)):
+        specs = [ShardSpec(n, w, r) for r in range(w)]
+        assert specs[0].lo == 0 and specs[-1].hi == n
+        assert all(specs[i].hi == specs[i + 1].lo for i in range(w - 1))
+        assert sum(s.n_local for s in specs) == n
+
+
+@pytest.mark.timeout(180)
+def test_sharded_step_world2_matches_single_process_statement():
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    ent, es, rel, rs = _expected(world)
+    np.testing.assert_allclose(ret["ent"], ent, rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(ret["state"], es, rtol=1e-9, atol=1e-12)
+    for r_, s_ in zip(ret["rels"], ret["rel_states"]):
+        np.testing.assert_allclose(r_, rel, rtol=1e-9, atol=1e-11)     # replicas identical
+        np.testing.assert_allclose(s_, rs, rtol=1e-9, atol=1e-12)

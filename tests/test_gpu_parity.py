@@ -276,3 +276,40 @@ def test_gather_rows_and_errors():
     with pytest.raises(_lib.KgeError):
         ops.score_pos("ComplEx", torch.zeros(2, 6, device=DEV), torch.zeros(2, 4, device=DEV),
                       torch.zeros(2, 6, device=DEV), 1.0)
+
+
+def test_sharded_engine_world1_equals_fused_step():
+    """dglke_amd.dist.DistEngine (pull -> kge_step_grads -> push -> kge_adagrad_apply_rows) with a
+    single rank must reproduce the fused single-GPU step: same kernels, same trace order."""
+    import os
+    import torch.distributed as dist
+    from dglke_amd import dist as kd, plan
+    from dglke_amd.engine import StepEngine
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        n_ent, n_rel, hidden, B, N = 5000, 40, 64, 128, 32
+        rng = np.random.RandomState(11)
+        for model, de_, dr_ in (("TransE_l2", False, False), ("RotatE", True, False)):
+            a = StepEngine(model, n_ent, n_rel, hidden, 12.0, 0.1, DEV, de_, dr_, True, 1.0, 1e-6, 3)
+            b = StepEngine(model, 1, n_rel, hidden, 12.0, 0.1, DEV, de_, dr_, True, 1.0, 1e-6, 3)
+            b.rel.copy_(a.rel)
+            ent = a.ent.clone()
+            state = torch.zeros(n_ent, device=DEV)
+            deng = kd.DistEngine(b, kd.ShardSpec(n_ent, 1, 0), ent, state)
+            for step in range(1, 4):
+                bt = O.synth_batch(rng, n_ent, n_rel, B, N, N, step)
+                a.step(plan.make_batch(bt["h"], bt["t"], bt["r"], bt["neg"], N, N, bt["neg_head"], DEV))
+                ue, p = kd.localize_plan(bt["h"], bt["t"], bt["r"], bt["neg"], N, N, bt["neg_head"])
+                lb = plan.upload([p], DEV)[0]
+                deng.step(lb, deng.prepare_route(ue))
+            torch.cuda.synchronize()
+            _close(ent.cpu(), a.ent.cpu(), 1e-6, 1e-7, model + " sharded entity table")
+            _close(state.cpu(), a.ent_state.cpu(), 1e-6, 1e-9, model + " sharded entity state")
+            _close(b.rel.cpu(), a.rel.cpu(), 1e-6, 1e-7, model + " relation table")
+            _close(b.rel_state.cpu(), a.rel_state.cpu(), 1e-6, 1e-9, model + " relation state")
+            la, lb_ = a.read_loss_sums(), b.read_loss_sums()
+            _close(lb_, la, 1e-5, 1e-6, model + " loss sums")
+    finally:
+        dist.destroy_process_group()
