@@ -30,5 +30,25 @@ def main(path):
     print("total GPU kernel time: %.1f us over %d dispatches" % (tot / 1e3, len(rows)))
 
 
+def pmc(path):
+    """per-kernel mean of every collected counter (rocprofv3 --pmc ...)."""
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(counters_collection)")]
+    print("# counters_collection columns:", cols)
+    namec = "kernel_name" if "kernel_name" in cols else [c for c in cols if "name" in c and "counter" not in c][0]
+    cname = "counter_name" if "counter_name" in cols else [c for c in cols if "counter" in c and "name" in c][0]
+    val = "value" if "value" in cols else [c for c in cols if "value" in c][0]
+    rows = cur.execute("select %s, %s, count(*), sum(%s) from counters_collection group by %s, %s"
+                       % (namec, cname, val, namec, cname)).fetchall()
+    print("%-64s %-14s %8s %16s %14s" % ("kernel", "counter", "samples", "sum", "mean"))
+    for k, c, n, sm in sorted(rows, key=lambda r: -(r[3] or 0)):
+        short = k if len(k) <= 64 else k[:61] + "..."
+        print("%-64s %-14s %8d %16.1f %14.2f" % (short, c, n, sm, sm / max(n, 1)))
+
+
 if __name__ == "__main__":
-    main(sys.argv[1])
+    if len(sys.argv) > 2 and sys.argv[2] == "--pmc":
+        pmc(sys.argv[1])
+    else:
+        main(sys.argv[1])
