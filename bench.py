@@ -65,6 +65,18 @@ def algorithmic_bytes(plans, d_e, d_r):
     return tot / len(plans)
 
 
+def measured_traffic(workload):
+    """HBM bytes per step from the rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
+    separate passes, tools/pmc_cycle.sh), recorded in profiles/latest_traffic.json for the build that
+    produced it; bench.py cannot collect PMC counters itself."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "latest_traffic.json")) as f:
+            d = json.load(f)
+        return d["hbm_bytes_per_step"] if d.get("workload") == workload else None
+    except Exception:
+        return None
+
+
 def synth_triples(w, seed):
     """FB15k-shaped synthetic triples: h,t ~ U[0,n_ent), r ~ U[0,n_rel)."""
     rng = np.random.RandomState(seed)
@@ -99,6 +111,55 @@ def cpu_baseline(w, plans, budget_s=12.0, max_steps=200):
             "ms_per_step": round(1e3 * dt / max(n, 1), 3)}
 
 
+def hogwild_measure(w, eng, dev, trainers, steps, G, flags):
+    """K concurrent trainers on ONE GPU (K HIP streams, K graph chains) updating the same tables
+    lock-free - the reference's multi-process Hogwild mode (`--num_proc K`, train.py:298-317,
+    docs/source/train.rst:138) with the processes replaced by streams.  Results are
+    order-nondeterministic exactly like the reference's racy index_add_; reported next to the
+    strict single-trainer number, never instead of it."""
+    from dglke_amd import plan
+    from dglke_amd.dataloader import UniformChunkedSampler
+    from dglke_amd.engine import StepEngine
+    tables = (eng.ent, eng.ent_state, eng.rel, eng.rel_state)
+    per = max(G, (steps // trainers // G) * G)
+    engines, graphs, streams = [], [], []
+    for k in range(trainers):
+        h, r, t = synth_triples(w, 100 + k)
+        smp = UniformChunkedSampler(h, r, t, w["n_ent"], w["B"], w["N"], dev, seed=100 + k)
+        batches = plan.upload(smp.next_plans(G * 2), dev)
+        e = StepEngine(w["model"], w["n_ent"], w["n_rel"], w["hidden"], w["gamma"], w["lr"], dev, w["de"],
+                       w["dr"], w["adv"], w["adv_temp"], w["reg_coef"], w["reg_norm"], flags=flags,
+                       tables=tables)
+        for b in batches:
+            e.workspace_for(b)
+        st = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(st):
+            e.step(batches[0])
+        torch.cuda.synchronize()
+        gs = [e.capture(batches[:G], stream=st), e.capture(batches[G:], stream=st)]
+        engines.append(e); graphs.append(gs); streams.append(st)
+    torch.cuda.synchronize()
+
+    def run(nrep):
+        for rep in range(nrep):
+            for k in range(trainers):
+                with torch.cuda.stream(streams[k]):
+                    graphs[k][rep % 2].replay()
+    run(2)
+    torch.cuda.synchronize()
+    nrep = per // G
+    t0 = time.perf_counter()
+    run(nrep)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    total = nrep * G * trainers
+    sums = [e.read_loss_sums() for e in engines]
+    ok = all(np.isfinite(s_[2]) for s_ in sums)
+    return {"trainers": trainers, "steps_total": total, "value": round(total * w["B"] / wall, 1),
+            "unit": "edges/s", "us_per_step_aggregate": round(1e6 * wall / total, 3), "finite_loss": bool(ok),
+            "semantics": "Hogwild: concurrent lock-free trainers on shared tables (reference --num_proc K)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -111,6 +172,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-pairwise", action="store_true")
+    ap.add_argument("--flags", type=int, default=0, help="extra kge_hparams.flags bits (tuning)")
+    ap.add_argument("--no-adv", action="store_true", help="tuning: disable -adv")
+    ap.add_argument("--hogwild", type=int, default=4, help="also measure K concurrent Hogwild trainers (0 = skip)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -128,7 +192,9 @@ def main():
     from dglke_amd.dataloader import UniformChunkedSampler
     from dglke_amd.engine import StepEngine
 
-    w = WORKLOADS[args.workload]
+    w = dict(WORKLOADS[args.workload])
+    if args.no_adv:
+        w["adv"] = False
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     torch.manual_seed(0)
@@ -140,7 +206,7 @@ def main():
     batches = plan.upload(plans, dev)
     eng = StepEngine(w["model"], w["n_ent"], w["n_rel"], w["hidden"], w["gamma"], w["lr"], dev, w["de"],
                      w["dr"], w["adv"], w["adv_temp"], w["reg_coef"], w["reg_norm"],
-                     flags=_lib.FLAG_FORCE_PAIRWISE if args.force_pairwise else 0)
+                     flags=(_lib.FLAG_FORCE_PAIRWISE if args.force_pairwise else 0) | args.flags)
     for b in batches:
         eng.workspace_for(b)
 
@@ -221,13 +287,18 @@ def main():
                    "launch": "hipGraph of %d steps" % G if use_graph else "eager",
                    "neg_kernels": "pairwise" if args.force_pairwise else "auto"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
-                     "frac": round(achieved / 8000.0, 5), "traffic": None,
-                     "kernel": "fused step (7 kernels: edge_fwd, neg_fwd, loss, neg_bwd, edge_bwd, "
-                               "update, finalize)",
+                     "frac": round(achieved / 8000.0, 5), "traffic": measured_traffic(args.workload),
+                     "kernel": "one training step = 5 dependent kernels (edge_fwd, neg_fwd_gemm, loss, "
+                               "neg_bwd_gemm, update); dominant: neg_bwd_gemm_kernel",
                      "algorithmic_bytes_per_step": round(bytes_step, 1),
                      "event_ms_per_step": round(ev_ms / K, 6)},
         "mean_loss": round(accum[2] / K, 6),
     }
+    if args.hogwild > 1:
+        try:
+            out["hogwild"] = hogwild_measure(w, eng, dev, args.hogwild, K, G, eng.hp.flags)
+        except Exception as e:
+            out["hogwild"] = {"error": repr(e)}
     if not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(w, plans)

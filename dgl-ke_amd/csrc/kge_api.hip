@@ -113,32 +113,43 @@ size_t kge_score_neg_workspace_bytes(int model, int C, int chunk, int N, int d_e
     const size_t B = (size_t)C * chunk, CN = (size_t)C * N;
     size_t n = 0;
     n += align_up(B * d_e * sizeof(float));      // A
-    n += align_up(B * sizeof(float));            // asq
-    n += align_up(CN * sizeof(float));           // bsq
+    n += align_up(B * sizeof(float));            // (reserved)
+    n += align_up(CN * sizeof(float));           // (reserved)
     n += align_up(B * (size_t)N * sizeof(float)); // W (L2-scaled dneg)
     n += align_up(B * d_e * sizeof(float));      // GA
     return n;
 }
 
+// pos-side vectors A = T(pos_side, rel) for the modular negative-score entry points
 static int neg_prepare(int model, int neg_head, const float *pos_side, const float *rel,
                        const float *neg, int C, int chunk, int N, int d_e, int d_r, float gamma,
-                       float emb_init, bool mfma, Carver &cv, NegArgs &na, hipStream_t s) {
-    const int B = C * chunk, CN = C * N;
-    float *A = cv.f((size_t)B * d_e), *asq = cv.f(B), *bsq = cv.f(CN);
+                       float emb_init, bool l2g, Carver &cv, float *&A, float *&asq, float *&bsq,
+                       hipStream_t s) {
+    const int B = C * chunk;
+    A = cv.f((size_t)B * d_e);
+    asq = cv.f(B); bsq = cv.f((size_t)C * N);
     if (!cv.ok()) return fail(KGE_ERR_WORKSPACE, "workspace too small");
     EdgeFwdArgs a{};
     a.src = EdgeSrc{pos_side, nullptr, pos_side, nullptr, rel, nullptr};
     a.B = B; a.d_e = d_e; a.d_r = d_r; a.neg_head = neg_head; a.model = model;
     a.gamma = gamma; a.rot_div = rot_div_of(emb_init);
     a.A = A;
-    const bool l2m = mfma && model == KGE_TRANSE_L2;
-    a.asq = l2m ? asq : nullptr;
-    a.nbase = neg; a.nidx = nullptr; a.n_neg = CN; a.bsq = l2m ? bsq : nullptr;
+    if (l2g) { a.asq = asq; a.nbase = neg; a.nidx = nullptr; a.n_neg = C * N; a.bsq = bsq; }
     KGE_TRY(launch_edge_fwd(a, s));
+    return KGE_OK;
+}
+
+static void fill_gemm(GemmArgs &g, int model, int C, int chunk, int N, int d_e, float gamma,
+                      const float *A, const float *nbase, const int64_t *nidx) {
+    g = GemmArgs{};
+    g.model = model; g.C = C; g.chunk = chunk; g.N = N; g.D = d_e; g.gamma = gamma;
+    g.A = A; g.nbase = nbase; g.nidx = nidx; g.B = C * chunk;
+}
+static void fill_pair(NegArgs &na, int model, int C, int chunk, int N, int d_e, float gamma,
+                      const float *A, const float *nbase, const int64_t *nidx) {
     na = NegArgs{};
     na.model = model; na.C = C; na.chunk = chunk; na.N = N; na.d_e = d_e; na.gamma = gamma;
-    na.A = A; na.asq = asq; na.nbase = neg; na.nidx = nullptr; na.bsq = bsq;
-    return KGE_OK;
+    na.A = A; na.nbase = nbase; na.nidx = nidx;
 }
 
 int kge_score_neg_fwd(int model, int neg_head, const float *pos_side, const float *rel,
@@ -150,13 +161,20 @@ int kge_score_neg_fwd(int model, int neg_head, const float *pos_side, const floa
         return fail(KGE_ERR_ARG, "kge_score_neg_fwd: bad argument");
     if (C == 0) return KGE_OK;
     hipStream_t s = (hipStream_t)stream;
-    const bool mfma = use_mfma(model, d_e, N, flags);
     Carver cv(ws, ws_bytes);
-    NegArgs na;
+    float *A, *asq, *bsq;
+    const bool mf = use_mfma(model, d_e, N, flags);
     if (int rc = neg_prepare(model, neg_head, pos_side, rel, neg, C, chunk, N, d_e, d_r, gamma,
-                             emb_init, mfma, cv, na, s)) return rc;
-    na.S = out;
-    if (mfma) KGE_TRY(launch_neg_fwd_mfma(na, s)); else KGE_TRY(launch_neg_fwd_pair(na, s));
+                             emb_init, mf && model == KGE_TRANSE_L2, cv, A, asq, bsq, s)) return rc;
+    if (mf) {
+        GemmArgs g; fill_gemm(g, model, C, chunk, N, d_e, gamma, A, neg, nullptr);
+        g.S = out; g.asq = asq; g.bsq = bsq;
+        KGE_TRY(launch_neg_fwd_gemm(g, s));
+    } else {
+        NegArgs na; fill_pair(na, model, C, chunk, N, d_e, gamma, A, neg, nullptr);
+        na.S = out;
+        KGE_TRY(launch_neg_fwd_pair(na, s));
+    }
     return KGE_OK;
 }
 
@@ -173,25 +191,30 @@ int kge_score_neg_bwd(int model, int neg_head, const float *pos_side, const floa
         return fail(KGE_ERR_ARG, "kge_score_neg_bwd: TransE_l2 needs the forward scores");
     if (C == 0) return KGE_OK;
     hipStream_t s = (hipStream_t)stream;
-    const bool mfma = use_mfma(model, d_e, N, flags);
     const int B = C * chunk;
     Carver cv(ws, ws_bytes);
-    NegArgs na;
+    float *A, *asq, *bsq;
     if (int rc = neg_prepare(model, neg_head, pos_side, rel, neg, C, chunk, N, d_e, d_r, gamma,
-                             emb_init, mfma, cv, na, s)) return rc;
+                             emb_init, false, cv, A, asq, bsq, s)) return rc;
     float *W = cv.f((size_t)B * N), *GA = cv.f((size_t)B * d_e);
     if (!cv.ok()) return fail(KGE_ERR_WORKSPACE, "workspace too small: need %zu bytes",
                               kge_score_neg_workspace_bytes(model, C, chunk, N, d_e));
+    const float *Wuse = dneg;
     if (model == KGE_TRANSE_L2) {
         const int64_t n = (int64_t)B * N;
         hipLaunchKernelGGL(l2_scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dneg,
                            neg_score, gamma, W, n);
-        na.W = W;
-    } else {
-        na.W = dneg;
+        Wuse = W;
     }
-    na.GA = GA; na.GN = g_neg; na.reg_coef = 0.f; na.reg_norm = 0;
-    if (mfma) KGE_TRY(launch_neg_bwd_mfma(na, s)); else KGE_TRY(launch_neg_bwd_pair(na, s));
+    if (use_mfma(model, d_e, N, flags)) {
+        GemmArgs g; fill_gemm(g, model, C, chunk, N, d_e, gamma, A, neg, nullptr);
+        g.W = Wuse; g.GA = GA; g.GN = g_neg;
+        KGE_TRY(launch_neg_bwd_gemm(g, s));
+    } else {
+        NegArgs na; fill_pair(na, model, C, chunk, N, d_e, gamma, A, neg, nullptr);
+        na.W = Wuse; na.GA = GA; na.GN = g_neg;
+        KGE_TRY(launch_neg_bwd_pair(na, s));
+    }
     EdgeBwdArgs e{};
     e.src = EdgeSrc{pos_side, nullptr, pos_side, nullptr, rel, nullptr};
     e.B = B; e.d_e = d_e; e.d_r = d_r; e.neg_head = neg_head; e.model = model;
@@ -266,17 +289,19 @@ int kge_adagrad_apply_rows(float *table, float *state_sum, int64_t n_rows, int d
 // ------------------------------------------------------------------------------------------
 size_t kge_step_workspace_bytes(const kge_hparams *hp, int B, int C, int chunk, int N, int UE, int UR) {
     (void)chunk;
-    const size_t d_e = hp->d_e, d_r = hp->d_r, CN = (size_t)C * N;
+    const size_t d_e = hp->d_e, d_r = hp->d_r, CN = (size_t)C * N, tj16 = (N + 15) / 16;
     size_t n = 0;
     auto add = [&](size_t floats) { n += align_up(floats * sizeof(float)); };
     add(B * d_e);        // A
-    add(CN * d_e);       // Bn (dense copy of the negative rows)
+    add(CN * d_e);       // Bn (pairwise-kernel path only)
     add(B); add(CN);     // asq, bsq
     add(B); add(B);      // pos score, dpos
     add((size_t)B * N);  // S / W
+    add(B * tj16); add(B * tj16);   // partial row max / sum-exp
     add(B * d_e);        // GA
     add(CN * d_e);       // GN
-    add(B * d_e); add(B * d_e); add(B * d_r);   // GH, GT, GR
+    add(B * d_e);        // P (TransE) or GH
+    add(B * d_e); add(B * d_r);   // GT, GR
     add(B); add(B); add(UE); add(UR);           // row_pos, row_neg, reg_ent, reg_rel
     return n;
 }
@@ -288,77 +313,134 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     if (int rc = check_model(hp->model, hp->d_e, hp->d_r)) return rc;
     if (b->B <= 0 || b->C <= 0 || b->chunk <= 0 || b->N <= 0 || (int64_t)b->C * b->chunk != b->B)
         return fail(KGE_ERR_ARG, "kge_step: need C*chunk == B (B=%d C=%d chunk=%d)", b->B, b->C, b->chunk);
+    if (hp->loss_genre < KGE_LOSS_LOGSIGMOID || hp->loss_genre > KGE_LOSS_BCE)
+        return fail(KGE_ERR_ARG, "unknown loss genre %d", hp->loss_genre);
     if (hp->pairwise && hp->adv) return fail(KGE_ERR_ARG, "loss cannot be pairwise and adversarial sampled");
     if (hp->pairwise && hp->loss_genre != KGE_LOSS_LOGISTIC && hp->loss_genre != KGE_LOSS_HINGE)
         return fail(KGE_ERR_ARG, "this loss cannot be applied to pairwise loss function");
     if (!tb->ent || !tb->ent_state || !tb->rel || !tb->rel_state || !b->h_gid || !b->t_gid ||
         !b->rel_ids || !b->neg_ids || !b->ue_id || !b->ue_pos_ptr || !b->ue_pos_adj ||
-        !b->ue_neg_ptr || !b->ue_neg_slot || !b->ur_id || !b->ur_ptr || !b->ur_edge)
+        !b->ue_neg_ptr || !b->ue_neg_slot || !b->ur_id || !b->ur_ptr || !b->ur_edge || !b->ue_rec ||
+        !b->ur_rec)
         return fail(KGE_ERR_ARG, "kge_step: null table / batch pointer");
     hipStream_t s = (hipStream_t)stream;
     const int B = b->B, C = b->C, chunk = b->chunk, N = b->N, CN = C * N;
-    const int d_e = hp->d_e, d_r = hp->d_r;
-    const bool mfma = use_mfma(hp->model, d_e, N, hp->flags);
-    const bool l2m = mfma && hp->model == KGE_TRANSE_L2;      // GEMM form with rank-1 terms
-    const bool l2p = !mfma && hp->model == KGE_TRANSE_L2;     // direct pairwise form
+    const int d_e = hp->d_e, d_r = hp->d_r, tj16 = (N + 15) / 16;
     const bool reg = hp->reg_coef > 0.f && hp->reg_norm > 0;
+    const bool pairwise = hp->pairwise != 0;
+    // which kernels run
+    const bool gemm = use_mfma(hp->model, d_e, N, hp->flags);       // matrix-core negative scoring
+    const bool fused_loss = gemm && !pairwise && (hp->flags & KGE_FLAG_FUSED_LOSS);   // loss gradient inside the bwd GEMM
+    const bool is_l2 = hp->model == KGE_TRANSE_L2;
+    const bool transe = hp->model == KGE_TRANSE_L1 || is_l2;
+    const int dmax = d_e > d_r ? d_e : d_r;
+    const bool transe_fast = transe && !pairwise && d_e % 4 == 0 && d_r % 4 == 0 && dmax <= 1024 &&
+                             !(hp->flags & KGE_FLAG_NO_TRANSE_FAST);
 
     Carver cv(ws, ws_bytes);
-    float *A = cv.f((size_t)B * d_e), *Bn = cv.f((size_t)CN * d_e), *asq = cv.f(B), *bsq = cv.f(CN);
+    float *A = cv.f((size_t)B * d_e), *Bn = cv.f((size_t)CN * d_e);
+    float *asq = cv.f(B), *bsq = cv.f(CN);
     float *P = cv.f(B), *dP = cv.f(B);
     float *S = cv.f((size_t)B * N);
+    float *PM = cv.f((size_t)B * tj16), *PS = cv.f((size_t)B * tj16);
     float *GA = cv.f((size_t)B * d_e), *GN = cv.f((size_t)CN * d_e);
     float *GH = cv.f((size_t)B * d_e), *GT = cv.f((size_t)B * d_e), *GR = cv.f((size_t)B * d_r);
     float *row_pos = cv.f(B), *row_neg = cv.f(B), *reg_ent = cv.f(b->UE), *reg_rel = cv.f(b->UR);
     if (!cv.ok())
         return fail(KGE_ERR_WORKSPACE, "kge_step: workspace too small (%zu < %zu)", ws_bytes,
                     kge_step_workspace_bytes(hp, B, C, chunk, N, b->UE, b->UR));
+    float *Pg = GH;                                   // TransE fast path: P rows reuse the GH buffer
     if (out && out->pos_score) P = out->pos_score;
     if (out && out->g_neg) GN = out->g_neg;
-    if (out && out->g_rel) GR = out->g_rel;
+    if (out && out->g_rel && !transe_fast) GR = out->g_rel;
+    const bool want4 = out && out->loss4;
+    float *acc = out ? out->loss_accum : nullptr;
+    const LossParams lp{hp->loss_genre, hp->adv, hp->pairwise, hp->adv_temp, hp->margin};
 
     const EdgeSrc src{tb->ent, b->h_gid, tb->ent, b->t_gid, tb->rel, b->rel_ids};
     const float rot_div = rot_div_of(hp->emb_init);
 
-    // 1. gather + positive score + pos-side vectors (+ squared norms for the L2 GEMM form)
+    // 1. gather + positive score + pos-side vectors (+ positive-loss part, + P rows for TransE)
     EdgeFwdArgs ef{};
     ef.src = src; ef.B = B; ef.d_e = d_e; ef.d_r = d_r; ef.neg_head = b->neg_head; ef.model = hp->model;
     ef.gamma = hp->gamma; ef.rot_div = rot_div;
-    ef.pos_score = P; ef.A = A; ef.asq = l2m ? asq : nullptr;
-    ef.nbase = tb->ent; ef.nidx = b->neg_ids; ef.n_neg = CN; ef.bsq = l2m ? bsq : nullptr;
-    ef.Bn = Bn;
+    ef.pos_score = P; ef.A = A;
+    ef.nbase = tb->ent; ef.nidx = b->neg_ids; ef.n_neg = CN;
+    const bool dense_neg = !gemm || (hp->flags & KGE_FLAG_DENSE_NEG);
+    ef.Bn = dense_neg ? Bn : nullptr;                 // the pairwise kernels read a dense copy
+    const bool l2g = gemm && is_l2;                   // GEMM form of the L2 distance needs |a|^2, |b|^2
+    ef.asq = l2g ? asq : nullptr; ef.bsq = l2g ? bsq : nullptr;
+    ef.do_pos_loss = pairwise ? 0 : 1; ef.lp = lp; ef.w = b->edge_w;
+    ef.dpos = dP; ef.row_pos = want4 ? row_pos : nullptr; ef.acc = acc;
+    ef.P = transe_fast ? Pg : nullptr;
     KGE_TRY(launch_edge_fwd(ef, s));
 
-    // 2. chunked negative scores
-    NegArgs na{};
-    na.model = hp->model; na.C = C; na.chunk = chunk; na.N = N; na.d_e = d_e; na.gamma = hp->gamma;
-    na.A = A; na.asq = asq; na.nbase = Bn; na.nidx = nullptr; na.bsq = bsq; na.S = S;
-    if (mfma) KGE_TRY(launch_neg_fwd_mfma(na, s)); else KGE_TRY(launch_neg_fwd_pair(na, s));
+    // 2. chunked negative scores (+ per-16-column partial row statistics for the adversarial softmax)
+    GemmArgs g; NegArgs na;
+    if (gemm) {
+        if (dense_neg) fill_gemm(g, hp->model, C, chunk, N, d_e, hp->gamma, A, Bn, nullptr);
+        else fill_gemm(g, hp->model, C, chunk, N, d_e, hp->gamma, A, tb->ent, b->neg_ids);
+        g.S = S; g.adv_temp = hp->adv_temp; g.asq = asq; g.bsq = bsq;
+        if (fused_loss && hp->adv) { g.PM = PM; g.PS = PS; }
+        KGE_TRY(launch_neg_fwd_gemm(g, s));
+    } else {
+        fill_pair(na, hp->model, C, chunk, N, d_e, hp->gamma, A, Bn, nullptr);
+        na.S = S;
+        KGE_TRY(launch_neg_fwd_pair(na, s));
+    }
 
-    // 3. loss and d loss / d score (S is overwritten in place by W)
-    LossArgs la{};
-    la.B = B; la.N = N; la.genre = hp->loss_genre; la.adv = hp->adv; la.pairwise = hp->pairwise;
-    la.adv_temp = hp->adv_temp; la.margin = hp->margin;
-    la.pos = P; la.neg = S; la.w = b->edge_w; la.dpos = dP; la.dneg = S;
-    const bool want4 = out && out->loss4;
-    la.row_pos = want4 ? row_pos : nullptr; la.row_neg = want4 ? row_neg : nullptr;
-    la.acc = out ? out->loss_accum : nullptr;
-    la.l2_scale = (l2m || l2p) ? 1 : 0; la.gamma = hp->gamma;
-    la.neg_copy = out ? out->neg_score : nullptr;
-    KGE_TRY(launch_loss(la, s));
+    // 3. stand-alone loss kernel (only when the loss is not fused into the backward GEMM)
+    if (!fused_loss) {
+        LossArgs la{};
+        la.B = B; la.N = N; la.genre = hp->loss_genre; la.adv = hp->adv; la.pairwise = hp->pairwise;
+        la.adv_temp = hp->adv_temp; la.margin = hp->margin;
+        la.pos = P; la.neg = S; la.w = b->edge_w; la.dpos = dP; la.dneg = S;
+        la.row_pos = want4 ? row_pos : nullptr; la.row_neg = want4 ? row_neg : nullptr;
+        la.acc = acc;
+        la.l2_scale = is_l2 ? 1 : 0; la.gamma = hp->gamma;
+        la.neg_copy = out ? out->neg_score : nullptr;
+        la.skip_pos = pairwise ? 0 : 1;
+        KGE_TRY(launch_loss(la, s));
+    }
 
     // 4. gradients w.r.t. the pos-side vectors and the negative rows
-    na.W = S; na.GA = GA; na.GN = GN;
-    na.reg_coef = reg ? hp->reg_coef : 0.f; na.reg_norm = hp->reg_norm;
-    if (mfma) KGE_TRY(launch_neg_bwd_mfma(na, s)); else KGE_TRY(launch_neg_bwd_pair(na, s));
+    if (gemm) {
+        g.PM = PM; g.PS = PS;
+        g.W = fused_loss ? nullptr : S; g.Sc = S; g.pos = P; g.w = b->edge_w; g.lp = lp;
+        g.GA = GA; g.GN = GN;
+        g.reg_coef = reg ? hp->reg_coef : 0.f; g.reg_norm = hp->reg_norm;
+        g.row_neg = (fused_loss && want4) ? row_neg : nullptr;
+        g.acc = fused_loss ? acc : nullptr;
+        KGE_TRY(launch_neg_bwd_gemm(g, s));
+        if (fused_loss && out && out->neg_score &&
+            hipMemcpyAsync(out->neg_score, S, (size_t)B * N * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
+            return fail(KGE_ERR_LAUNCH, "hipMemcpyAsync failed");
+    } else {
+        na.W = S; na.GA = GA; na.GN = GN;
+        na.reg_coef = reg ? hp->reg_coef : 0.f; na.reg_norm = hp->reg_norm;
+        KGE_TRY(launch_neg_bwd_pair(na, s));
+    }
 
-    // 5. per-edge gradients of head / tail / relation rows
-    EdgeBwdArgs eb{};
-    eb.src = src; eb.B = B; eb.d_e = d_e; eb.d_r = d_r; eb.neg_head = b->neg_head; eb.model = hp->model;
-    eb.gamma = hp->gamma; eb.rot_div = rot_div;
-    eb.dpos = dP; eb.GA = GA; eb.reg_coef = reg ? hp->reg_coef : 0.f; eb.reg_norm = hp->reg_norm;
-    eb.GH = GH; eb.GT = GT; eb.GR = GR;
-    KGE_TRY(launch_edge_bwd(eb, s));
+    // 5. per-edge gradients of head / tail / relation rows (TransE rebuilds them in the update)
+    if (!transe_fast) {
+        EdgeBwdArgs eb{};
+        eb.src = src; eb.B = B; eb.d_e = d_e; eb.d_r = d_r; eb.neg_head = b->neg_head; eb.model = hp->model;
+        eb.gamma = hp->gamma; eb.rot_div = rot_div;
+        eb.dpos = dP; eb.GA = GA; eb.reg_coef = reg ? hp->reg_coef : 0.f; eb.reg_norm = hp->reg_norm;
+        eb.GH = GH; eb.GT = GT; eb.GR = GR;
+        KGE_TRY(launch_edge_bwd(eb, s));
+    }
+
+    if (transe_fast && out && out->g_rel) {
+        // the per-edge relation gradient is not materialised on the fast path; rebuild it for the
+        // caller with the generic kernel BEFORE the tables change (test / debugging output only)
+        EdgeBwdArgs eb{};
+        eb.src = src; eb.B = B; eb.d_e = d_e; eb.d_r = d_r; eb.neg_head = b->neg_head; eb.model = hp->model;
+        eb.gamma = hp->gamma; eb.rot_div = rot_div;
+        eb.dpos = dP; eb.GA = GA; eb.reg_coef = reg ? hp->reg_coef : 0.f; eb.reg_norm = hp->reg_norm;
+        eb.GH = nullptr; eb.GT = nullptr; eb.GR = out->g_rel;
+        KGE_TRY(launch_edge_bwd(eb, s));
+    }
 
     // 6. owner-computes Adagrad on both tables (or gradient emission for sharded training)
     UpdateArgs ua{};
@@ -368,9 +450,11 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     ua.ue_id = b->ue_id; ua.ue_pos_ptr = b->ue_pos_ptr; ua.ue_pos_adj = b->ue_pos_adj;
     ua.ue_neg_ptr = b->ue_neg_ptr; ua.ue_neg_slot = b->ue_neg_slot;
     ua.ur_id = b->ur_id; ua.ur_ptr = b->ur_ptr; ua.ur_edge = b->ur_edge;
+    ua.ue_rec = b->ue_rec; ua.ur_rec = b->ur_rec;
     ua.GH = GH; ua.GT = GT; ua.GN = GN; ua.GR = GR;
+    ua.transe_fast = transe_fast ? 1 : 0; ua.neg_head = b->neg_head; ua.P = Pg; ua.GA = GA;
     ua.reg_ent = want4 ? reg_ent : nullptr; ua.reg_rel = want4 ? reg_rel : nullptr;
-    ua.acc = out ? out->loss_accum : nullptr;
+    ua.acc = acc;
     if (emit) {
         ua.g0 = emit->g0; ua.gs0 = emit->gs0; ua.g1 = emit->g1; ua.gs1 = emit->gs1;
         ua.gr = emit->gr; ua.gsr = emit->gsr;
@@ -378,7 +462,6 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     }
     if (out && out->g_pos_ent) ua.g0 = out->g_pos_ent;
     KGE_TRY(launch_update(ua, s));
-
     // 7. deterministic reduction of this step's loss terms (only when the caller wants the
     //    per-step values; running sums are accumulated by the kernels above without it)
     if (want4) {

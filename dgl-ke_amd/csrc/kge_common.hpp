@@ -87,6 +87,31 @@ __device__ __forceinline__ float neg_logsigmoid(float z) {
 
 constexpr bool is_complex_model(int m) { return m == KGE_COMPLEX || m == KGE_ROTATE; }
 
+// criterion value and derivative w.r.t. the score for label l (models/pytorch/loss.py:10-38)
+__device__ __forceinline__ void criterion(int genre, float s, float label, float margin,
+                                          float &val, float &dval) {
+    if (genre == KGE_LOSS_HINGE) {
+        const float v = margin - label * s;
+        val = v < 0.f ? 0.f : v;
+        dval = v < 0.f ? 0.f : -label;
+    } else if (genre == KGE_LOSS_BCE) {
+        // -(l*log(sig(s)) + (1-l)*log(1-sig(s))), written with softplus for stability
+        val = label * neg_logsigmoid(s) + (1.f - label) * neg_logsigmoid(-s);
+        dval = sigmoidf_(s) - label;
+    } else {   // Logsigmoid / Logistic: -logsigmoid(l*s) == softplus(-l*s)
+        const float z = label * s;
+        val = neg_logsigmoid(z);
+        dval = -label * sigmoidf_(-z);
+    }
+}
+
+// bijective XCD-aware remap: hardware block b runs on XCD b%8; give the blocks of one XCD
+// consecutive logical ids (L2 locality only, never correctness).
+__device__ __forceinline__ int xcd_remap(int b, int nb) {
+    const int q = nb >> 3, r = nb & 7, x = b & 7, k = b >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+}
+
 }  // namespace kge
 
 // ------------------------------------------------------------------------------------------
@@ -96,6 +121,11 @@ struct EdgeSrc {           // where the rows of one positive edge come from
     const float *hbase; const int64_t *hidx;   // head rows  hbase + (hidx? hidx[i] : i)*d_e
     const float *tbase; const int64_t *tidx;   // tail rows
     const float *rbase; const int64_t *ridx;   // relation rows, ld = d_r
+};
+
+struct LossParams {                 // LossGenerator configuration (loss.py:41-61)
+    int genre, adv, pairwise;
+    float adv_temp, margin;
 };
 
 struct EdgeFwdArgs {
@@ -109,6 +139,12 @@ struct EdgeFwdArgs {
     const float *nbase; const int64_t *nidx; int n_neg;  // negative rows -> bsq
     float *bsq;                      // [n_neg] or null
     float *Bn;                       // [n_neg,d_e] dense copy of the negative rows or null
+    // positive-loss part (pointwise losses): dpos_i = dL/dp_i needs only p_i
+    int do_pos_loss; LossParams lp; const float *w;
+    float *dpos;                     // [B] or null
+    float *row_pos;                  // [B] per-row positive loss terms or null
+    float *acc;                      // running sums or null
+    float *P;                        // [B,d_e] TransE only: dpos_i * d|u_i|/du_i (u = h+r-t) or null
 };
 
 struct EdgeBwdArgs {
@@ -146,6 +182,7 @@ struct LossArgs {
     float *acc;                      // [4][KGE_ACC_SLOTS] running loss sums (slot = row & mask) or null
     int l2_scale; float gamma;       // if set: dneg /= (gamma - n)   (TransE_l2 GEMM backward)
     float *neg_copy;                 // optional copy of the scores before overwrite
+    int skip_pos;                    // the positive-loss part was already done by edge_fwd
 };
 
 struct UpdateArgs {
@@ -154,7 +191,12 @@ struct UpdateArgs {
     float *ent, *ent_state, *rel, *rel_state;
     const int64_t *ue_id; const int32_t *ue_pos_ptr, *ue_pos_adj, *ue_neg_ptr, *ue_neg_slot;
     const int64_t *ur_id; const int32_t *ur_ptr, *ur_edge;
+    const int32_t *ue_rec, *ur_rec;  // [UE][8], [UR][8] packed plan records (see kge_batch)
     const float *GH, *GT, *GN, *GR;
+    // TransE fast path: per-edge gradients are rebuilt from P (positive part) and GA (negative
+    // part) instead of reading GH/GT/GR written by edge_bwd:  GH = -P (+GA in tail mode),
+    // GT = +P (+GA in head mode), GR = -P +/- GA + regulariser
+    int transe_fast, neg_head; const float *P, *GA;
     float *reg_ent, *reg_rel;        // [UE], [UR] regularisation value partials (or null)
     float *acc;                      // [4][KGE_ACC_SLOTS] running sums (row 3 = regularisation) or null
     // emit mode (sharded training): write gradients instead of updating the entity table
@@ -181,8 +223,28 @@ int launch_adagrad_apply_rows(float *table, float *state, int dim, const int64_t
                               const float *g, const float *gs, int64_t n, float lr, float eps,
                               hipStream_t s);
 int launch_reduce_acc(float *acc, float *out4, int zero_after, hipStream_t s);
+struct GemmArgs {                   // LDS-staged fp32-MFMA negative scoring (kge_neg_gemm.hip)
+    int model, C, chunk, N, D;
+    float gamma;
+    const float *A;                  // [C*chunk, D] pos-side vectors (dense)
+    const float *nbase; const int64_t *nidx;   // negative rows: nbase + (nidx ? nidx[j] : j)*D
+    const float *asq, *bsq;          // [C*chunk], [C*N] squared norms (TransE_l2)
+    // forward
+    float *S;                        // out [C,chunk,N]
+    float *PM, *PS;                  // [C*chunk, tj16] per-16-column partial max / sum-exp of T*n, or null
+    float adv_temp;
+    // backward
+    const float *W;                  // explicit dL/dn (TransE_l2: already / dist) or null: on the fly
+    const float *Sc;                 // scores (on-the-fly mode)
+    const float *pos, *w;            // [B] positive scores (pairwise) / edge weights or null
+    LossParams lp; int B;
+    float *GA, *GN;                  // out [C*chunk, D], [C*N, D]
+    float reg_coef; int reg_norm;
+    float *row_neg;                  // [B] per-row negative loss terms or null
+    float *acc;                      // running sums or null
+};
 bool neg_mfma_supported(int model, int d_e, int N);
-int launch_neg_fwd_mfma(const NegArgs &a, hipStream_t s);
-int launch_neg_bwd_mfma(const NegArgs &a, hipStream_t s);
+int launch_neg_fwd_gemm(const GemmArgs &a, hipStream_t s);
+int launch_neg_bwd_gemm(const GemmArgs &a, hipStream_t s);
 int launch_neg_fwd_pair(const NegArgs &a, hipStream_t s);
 int launch_neg_bwd_pair(const NegArgs &a, hipStream_t s);

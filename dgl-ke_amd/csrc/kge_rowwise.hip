@@ -133,14 +133,50 @@ __global__ __launch_bounds__(KGE_BLOCK) void edge_fwd_kernel(EdgeFwdArgs a) {
                 if (A) { st<V>(A + off, are); st<V>(A + hd + off, aim); }
             }
         }
-        if (a.pos_score) {
-            ps = wave_sum(ps);
-            if (lane == 0) {
-                float p;
-                if constexpr (MODEL == KGE_TRANSE_L1 || MODEL == KGE_ROTATE) p = a.gamma - ps;
-                else if constexpr (MODEL == KGE_TRANSE_L2) p = a.gamma - sqrtf(ps);
-                else p = ps;
-                a.pos_score[i] = p;
+        if (a.pos_score || a.do_pos_loss) {
+            ps = wave_sum(ps);          // xor butterfly: every lane holds the sum
+            float p;
+            if constexpr (MODEL == KGE_TRANSE_L1 || MODEL == KGE_ROTATE) p = a.gamma - ps;
+            else if constexpr (MODEL == KGE_TRANSE_L2) p = a.gamma - sqrtf(ps);
+            else p = ps;
+            if (lane == 0 && a.pos_score) a.pos_score[i] = p;
+            if (a.do_pos_loss) {
+                // pointwise losses: d loss / d p_i depends on p_i only (loss.py:82-94)
+                const float w = a.w ? a.w[i] : 1.f;
+                const float invB = 1.f / (float)a.B;
+                float pl, dpl;
+                criterion(a.lp.genre, p, 1.f, a.lp.margin, pl, dpl);
+                const float dp = dpl * w * 0.5f * invB;
+                if (lane == 0) {
+                    const float plw = pl * w * invB;
+                    if (a.dpos) a.dpos[i] = dp;
+                    if (a.row_pos) a.row_pos[i] = plw;
+                    if (a.acc) {
+                        const bool uq = a.B <= KGE_ACC_SLOTS;
+                        const int slot = (int)(i & (KGE_ACC_SLOTS - 1));
+                        acc_add(&a.acc[0 * KGE_ACC_SLOTS + slot], plw, uq);
+                        acc_add(&a.acc[2 * KGE_ACC_SLOTS + slot], 0.5f * plw, uq);
+                    }
+                }
+                if constexpr (MODEL == KGE_TRANSE_L1 || MODEL == KGE_TRANSE_L2) {
+                    if (a.P) {
+                        // P_i = dp * d|u|/du, u = h + r - t  (second pass: rows are L1/L2 hot)
+                        float inv = 0.f;
+                        if constexpr (MODEL == KGE_TRANSE_L2) { const float nr = sqrtf(ps); inv = nr > 0.f ? 1.f / nr : 0.f; }
+                        float *P = a.P + i * (int64_t)a.d_e;
+                        for (int it = lane; it < a.d_e / V; it += 64) {
+                            const int off = it * V;
+                            const Pack<V> hv = ld<V>(h + off), rv = ld<V>(r + off), tv = ld<V>(t + off);
+                            Pack<V> pv;
+#pragma unroll
+                            for (int e = 0; e < V; ++e) {
+                                const float u = hv.v[e] + rv.v[e] - tv.v[e];
+                                pv.v[e] = dp * ((MODEL == KGE_TRANSE_L1) ? sgnf(u) : u * inv);
+                            }
+                            st<V>(P + off, pv);
+                        }
+                    }
+                }
             }
         }
         if (a.asq) {
@@ -367,24 +403,6 @@ int launch_edge_bwd(const EdgeBwdArgs &a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------
 // loss + d loss / d score.  One wavefront per positive edge (row of the [B,N] negative scores).
 // ------------------------------------------------------------------------------------------
-// criterion value and derivative w.r.t. the score for label l (loss.py:10-38)
-__device__ __forceinline__ void criterion(int genre, float s, float label, float margin,
-                                          float &val, float &dval) {
-    if (genre == KGE_LOSS_HINGE) {
-        const float v = margin - label * s;
-        val = v < 0.f ? 0.f : v;
-        dval = v < 0.f ? 0.f : -label;
-    } else if (genre == KGE_LOSS_BCE) {
-        // -(l*log(sig(s)) + (1-l)*log(1-sig(s))), written with softplus for stability
-        val = label * neg_logsigmoid(s) + (1.f - label) * neg_logsigmoid(-s);
-        dval = sigmoidf_(s) - label;
-    } else {   // Logsigmoid / Logistic: -logsigmoid(l*s) == softplus(-l*s)
-        const float z = label * s;
-        val = neg_logsigmoid(z);
-        dval = -label * sigmoidf_(-z);
-    }
-}
-
 __global__ __launch_bounds__(KGE_BLOCK) void loss_kernel(LossArgs a) {
     const int64_t i = WAVE_ID();
     if (i >= a.B) return;
@@ -421,7 +439,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void loss_kernel(LossArgs a) {
         return;
     }
     float plw = 0.f;
-    if (lane == 0) {
+    if (lane == 0 && !a.skip_pos) {
         float pl, dpl;
         criterion(a.genre, p, 1.f, a.margin, pl, dpl);
         a.dpos[i] = dpl * w * 0.5f * invB;
@@ -456,7 +474,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void loss_kernel(LossArgs a) {
         if (a.acc) {
             const int slot = (int)(i & (KGE_ACC_SLOTS - 1));
             const bool uq = a.B <= KGE_ACC_SLOTS;
-            acc_add(&a.acc[0 * KGE_ACC_SLOTS + slot], plw, uq);
+            if (!a.skip_pos) acc_add(&a.acc[0 * KGE_ACC_SLOTS + slot], plw, uq);
             acc_add(&a.acc[1 * KGE_ACC_SLOTS + slot], acc, uq);
             acc_add(&a.acc[2 * KGE_ACC_SLOTS + slot], 0.5f * (plw + acc), uq);
         }
@@ -508,7 +526,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void loss_kernel_reg(LossArgs a) {
         return;
     }
     float plw = 0.f;
-    if (lane == 0) {
+    if (lane == 0 && !a.skip_pos) {
         float pl, dpl;
         criterion(a.genre, p, 1.f, a.margin, pl, dpl);
         a.dpos[i] = dpl * w * 0.5f * invB;
@@ -551,7 +569,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void loss_kernel_reg(LossArgs a) {
         if (a.row_neg) a.row_neg[i] = acc;
         if (a.acc) {
             const bool uq = a.B <= KGE_ACC_SLOTS;
-            acc_add(&a.acc[0 * KGE_ACC_SLOTS + slot], plw, uq);
+            if (!a.skip_pos) acc_add(&a.acc[0 * KGE_ACC_SLOTS + slot], plw, uq);
             acc_add(&a.acc[1 * KGE_ACC_SLOTS + slot], acc, uq);
             acc_add(&a.acc[2 * KGE_ACC_SLOTS + slot], 0.5f * (plw + acc), uq);
         }
@@ -777,7 +795,10 @@ __global__ __launch_bounds__(KGE_BLOCK) void update_kernel(UpdateArgs a, int nb_
 }
 
 // single-pass variant: the row and its gradients stay in registers (row width <= 256*NIT floats),
-// so every table row is read once and written once - the algorithmic minimum.
+// so every table row is read once and written once - the algorithmic minimum.  Memory-level
+// parallelism: one 32-byte plan record per row gives the row id, the list bounds AND the first
+// list entries, so that the row itself and its first positive / negative gradient rows are
+// requested together (one dependent round instead of five); longer lists continue in loops.
 template <int NIT>
 __global__ __launch_bounds__(KGE_BLOCK) void update_kernel_reg(UpdateArgs a, int nb_ent) {
     const int lane = LANE();
@@ -786,45 +807,73 @@ __global__ __launch_bounds__(KGE_BLOCK) void update_kernel_reg(UpdateArgs a, int
         const int64_t u = WAVE_ID();
         if (u >= a.UE) return;
         const int d = a.model_d_e;
-        const int64_t id = a.ue_id[u];
-        const int p0 = a.ue_pos_ptr[u], p1 = a.ue_pos_ptr[u + 1];
-        const int n0 = a.ue_neg_ptr[u], n1 = a.ue_neg_ptr[u + 1];
+        const int4 r0 = reinterpret_cast<const int4 *>(a.ue_rec)[2 * u];
+        const int4 r1 = reinterpret_cast<const int4 *>(a.ue_rec)[2 * u + 1];
+        const int64_t id = (int64_t)(uint32_t)r0.x | ((int64_t)r0.y << 32);
+        const int p0 = r0.z, p1 = r0.w, n0 = r1.x, n1 = r1.y, adj0 = r1.z, slot0 = r1.w;
         float *row = a.ent + id * (int64_t)d;
-        const float st0 = a.ent_state[id];
         const bool has_pos = p1 > p0, has_neg = n1 > n0;
         const int nit = d >> 2;
+        // first positive contribution: two source rows (fast path: P and maybe GA; generic: GH|GT)
+        const int64_t e0 = has_pos ? (int64_t)(adj0 >> 1) * d : 0;
+        const int side0 = adj0 & 1;
+        const bool ga0 = a.transe_fast && has_pos && side0 == a.neg_head;
+        const float sg0 = a.transe_fast ? (side0 ? 1.f : -1.f) : 1.f;
+        const float *pA = !has_pos ? row : (a.transe_fast ? a.P + e0 : (side0 ? a.GT : a.GH) + e0);
+        const float *pB = ga0 ? a.GA + e0 : pA;          // aliases pA when unused (same lines, no extra traffic)
+        const float *pC = has_neg ? a.GN + (int64_t)slot0 * d : row;
+        const float st0 = a.ent_state[id];
         Pack<4> x[NIT], g0[NIT], g1[NIT];
-        float rv = 0.f;
+        float rv = 0.f, s0 = 0.f, s1 = 0.f;
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
             const int it = lane + 64 * k;
-            g1[k] = zero_pack<4>();
             if (it < nit) {
                 x[k] = ld<4>(row + it * 4);
-                if (reg) {
+                const Pack<4> va = ld<4>(pA + it * 4), vb = ld<4>(pB + it * 4), vc = ld<4>(pC + it * 4);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        rv += reg_val(x[k].v[e], a.reg_norm);
-                        g0[k].v[e] = reg_grad(x[k].v[e], a.reg_coef, a.reg_norm);
-                    }
-                } else g0[k] = zero_pack<4>();
-            } else { x[k] = zero_pack<4>(); g0[k] = zero_pack<4>(); }
+                for (int e = 0; e < 4; ++e) {
+                    float g = 0.f;
+                    if (reg) { rv += reg_val(x[k].v[e], a.reg_norm); g = reg_grad(x[k].v[e], a.reg_coef, a.reg_norm); }
+                    if (has_pos) g += sg0 * va.v[e] + (ga0 ? vb.v[e] : 0.f);
+                    g0[k].v[e] = g;
+                    const float gn = has_neg ? vc.v[e] : 0.f;
+                    g1[k].v[e] = gn;
+                    s1 += gn * gn;
+                }
+            } else { x[k] = zero_pack<4>(); g0[k] = zero_pack<4>(); g1[k] = zero_pack<4>(); }
         }
-        float s0 = 0.f, s1 = 0.f;
-        for (int p = p0; p < p1; ++p) {
+        for (int p = p0 + 1; p < p1; ++p) {
             const int adj = a.ue_pos_adj[p];
-            const float *src = ((adj & 1) ? a.GT : a.GH) + (int64_t)(adj >> 1) * d;
+            const int64_t eo = (int64_t)(adj >> 1) * d;
+            const int side = adj & 1;
+            if (a.transe_fast) {
+                const float sg = side ? 1.f : -1.f;
+                const bool withGA = side == a.neg_head;
 #pragma unroll
-            for (int k = 0; k < NIT; ++k) {
-                const int it = lane + 64 * k;
-                if (it < nit) {
-                    const Pack<4> g = ld<4>(src + it * 4);
+                for (int k = 0; k < NIT; ++k) {
+                    const int it = lane + 64 * k;
+                    if (it < nit) {
+                        const Pack<4> g = ld<4>(a.P + eo + it * 4);
+                        const Pack<4> g2 = ld<4>((withGA ? a.GA : a.P) + eo + it * 4);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) g0[k].v[e] += g.v[e];
+                        for (int e = 0; e < 4; ++e) g0[k].v[e] += sg * g.v[e] + (withGA ? g2.v[e] : 0.f);
+                    }
+                }
+            } else {
+                const float *src = (side ? a.GT : a.GH) + eo;
+#pragma unroll
+                for (int k = 0; k < NIT; ++k) {
+                    const int it = lane + 64 * k;
+                    if (it < nit) {
+                        const Pack<4> g = ld<4>(src + it * 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) g0[k].v[e] += g.v[e];
+                    }
                 }
             }
         }
-        for (int q = n0; q < n1; ++q) {
+        for (int q = n0 + 1; q < n1; ++q) {
             const float *src = a.GN + (int64_t)a.ue_neg_slot[q] * d;
 #pragma unroll
             for (int k = 0; k < NIT; ++k) {
@@ -889,34 +938,57 @@ __global__ __launch_bounds__(KGE_BLOCK) void update_kernel_reg(UpdateArgs a, int
         const int64_t u = ((int64_t)blockIdx.x - nb_ent) * KGE_WAVES_PER_BLOCK + (threadIdx.x >> 6);
         if (u >= a.UR) return;
         const int d = a.d_r;
-        const int64_t id = a.ur_id[u];
-        const int e0 = a.ur_ptr[u], e1 = a.ur_ptr[u + 1];
+        const int4 r0 = reinterpret_cast<const int4 *>(a.ur_rec)[2 * u];
+        const int4 r1 = reinterpret_cast<const int4 *>(a.ur_rec)[2 * u + 1];
+        const int64_t id = (int64_t)(uint32_t)r0.x | ((int64_t)r0.y << 32);
+        const int e0 = r0.z, e1 = r0.w, edge0 = r1.x;
         float *row = a.rel + id * (int64_t)d;
         const float st0 = a.rel_state[id];
         const int nit = d >> 2;
+        const float sgr = a.neg_head ? -1.f : 1.f;       // TransE fast path: GR = -P +/- GA + regulariser
+        const int64_t eo0 = (int64_t)edge0 * d;
+        const float *pA = a.transe_fast ? a.P + eo0 : a.GR + eo0;
+        const float *pB = a.transe_fast ? a.GA + eo0 : pA;
         Pack<4> x[NIT], gsum[NIT];
         float rv = 0.f, ss = 0.f;
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
             const int it = lane + 64 * k;
-            gsum[k] = zero_pack<4>();
             if (it < nit) {
                 x[k] = ld<4>(row + it * 4);
-                if (reg) {
+                const Pack<4> va = ld<4>(pA + it * 4), vb = ld<4>(pB + it * 4);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) rv += reg_val(x[k].v[e], a.reg_norm);
+                for (int e = 0; e < 4; ++e) {
+                    if (reg) rv += reg_val(x[k].v[e], a.reg_norm);
+                    float g;
+                    if (a.transe_fast) {
+                        g = sgr * vb.v[e] - va.v[e];
+                        if (reg) g += reg_grad(x[k].v[e], a.reg_coef, a.reg_norm);
+                    } else g = va.v[e];
+                    ss += g * g;
+                    gsum[k].v[e] = g;
                 }
-            } else x[k] = zero_pack<4>();
+            } else { x[k] = zero_pack<4>(); gsum[k] = zero_pack<4>(); }
         }
-        for (int q = e0; q < e1; ++q) {
-            const float *src = a.GR + (int64_t)a.ur_edge[q] * d;
+        for (int q = e0 + 1; q < e1; ++q) {
+            const int64_t eo = (int64_t)a.ur_edge[q] * d;
 #pragma unroll
             for (int k = 0; k < NIT; ++k) {
                 const int it = lane + 64 * k;
                 if (it < nit) {
-                    const Pack<4> g = ld<4>(src + it * 4);
+                    if (a.transe_fast) {
+                        const Pack<4> pv = ld<4>(a.P + eo + it * 4), gv = ld<4>(a.GA + eo + it * 4);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { ss += g.v[e] * g.v[e]; gsum[k].v[e] += g.v[e]; }
+                        for (int e = 0; e < 4; ++e) {
+                            float g = sgr * gv.v[e] - pv.v[e];
+                            if (reg) g += reg_grad(x[k].v[e], a.reg_coef, a.reg_norm);
+                            ss += g * g; gsum[k].v[e] += g;
+                        }
+                    } else {
+                        const Pack<4> g = ld<4>(a.GR + eo + it * 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { ss += g.v[e] * g.v[e]; gsum[k].v[e] += g.v[e]; }
+                    }
                 }
             }
         }

@@ -16,6 +16,7 @@ KGE_ABI_VERSION = 1
 MODEL_IDS = {"TransE_l1": 0, "TransE_l2": 1, "TransE": 1, "DistMult": 2, "ComplEx": 3, "RotatE": 4}
 LOSS_IDS = {"Logsigmoid": 0, "Logistic": 1, "Hinge": 2, "BCE": 3}
 FLAG_FORCE_PAIRWISE = 1
+FLAG_NO_TRANSE_FAST = 2
 ACC_SLOTS = 4096
 
 c_f = C.c_float
@@ -32,7 +33,8 @@ class KgeBatch(C.Structure):
                 ("U", c_i32), ("UE", c_i32), ("UR", c_i32),
                 ("h_gid", c_p), ("t_gid", c_p), ("rel_ids", c_p), ("neg_ids", c_p), ("edge_w", c_p),
                 ("ue_id", c_p), ("ue_pos_ptr", c_p), ("ue_pos_adj", c_p), ("ue_neg_ptr", c_p),
-                ("ue_neg_slot", c_p), ("ur_id", c_p), ("ur_ptr", c_p), ("ur_edge", c_p)]
+                ("ue_neg_slot", c_p), ("ur_id", c_p), ("ur_ptr", c_p), ("ur_edge", c_p),
+                ("ue_rec", c_p), ("ur_rec", c_p)]
 
 
 class KgeHParams(C.Structure):

@@ -121,13 +121,14 @@ class StepEngine(object):
                     g_neg=torch.empty(batch.C * batch.N, self.d_e, device=dev),
                     g_rel=torch.empty(batch.B, self.d_r, device=dev))
 
-    def capture(self, batches):
-        """record `len(batches)` consecutive steps into one HIP graph; returns the graph."""
+    def capture(self, batches, stream=None):
+        """record `len(batches)` consecutive steps into one HIP graph (on `stream` if given);
+        returns the graph."""
         for b in batches:
             self.workspace_for(b)
         # warm-up on a side stream is not needed: the library allocates nothing
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, stream=stream):
             for b in batches:
                 self.step(b)
         self._graphs.append((g, batches))

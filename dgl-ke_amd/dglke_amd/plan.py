@@ -16,7 +16,8 @@ import torch
 from . import _lib
 
 _I64_FIELDS = ("h_gid", "t_gid", "rel_ids", "neg_ids", "ue_id", "ur_id", "nid", "h_local", "t_local")
-_I32_FIELDS = ("ue_pos_ptr", "ue_pos_adj", "ue_neg_ptr", "ue_neg_slot", "ur_ptr", "ur_edge")
+_I32_FIELDS = ("ue_pos_ptr", "ue_pos_adj", "ue_neg_ptr", "ue_neg_slot", "ur_ptr", "ur_edge", "ue_rec",
+               "ur_rec")
 
 
 def build_plan(h, t, r, neg, chunk, N, neg_head, edge_w=None):
@@ -54,6 +55,22 @@ def build_plan(h, t, r, neg, chunk, N, neg_head, edge_w=None):
     ur_edge = np.argsort(rinv, kind="stable").astype(np.int32)
     ur_ptr = np.zeros(UR + 1, np.int32)
     np.cumsum(np.bincount(rinv, minlength=UR), out=ur_ptr[1:])
+    # packed 32-byte records (include/kge_hip.h): id, list bounds and the first list entries
+    def _lohi(ids):
+        ids = ids.astype(np.int64)
+        return (ids & 0xFFFFFFFF).astype(np.uint32).view(np.int32), (ids >> 32).astype(np.int32)
+    ue_rec = np.zeros((UE, 8), np.int32)
+    ue_rec[:, 0], ue_rec[:, 1] = _lohi(ue_id)
+    ue_rec[:, 2], ue_rec[:, 3] = ue_pos_ptr[:-1], ue_pos_ptr[1:]
+    ue_rec[:, 4], ue_rec[:, 5] = ue_neg_ptr[:-1], ue_neg_ptr[1:]
+    hp = ue_pos_ptr[1:] > ue_pos_ptr[:-1]
+    hn = ue_neg_ptr[1:] > ue_neg_ptr[:-1]
+    ue_rec[:, 6] = np.where(hp, ue_pos_adj[np.minimum(ue_pos_ptr[:-1], 2 * B - 1)], -1)
+    ue_rec[:, 7] = np.where(hn, ue_neg_slot[np.minimum(ue_neg_ptr[:-1], Cn * N - 1)], -1)
+    ur_rec = np.zeros((UR, 8), np.int32)
+    ur_rec[:, 0], ur_rec[:, 1] = _lohi(ur_id)
+    ur_rec[:, 2], ur_rec[:, 3] = ur_ptr[:-1], ur_ptr[1:]
+    ur_rec[:, 4] = ur_edge[ur_ptr[:-1]]
     out = dict(B=B, C=Cn, chunk=int(chunk), N=int(N), neg_head=int(bool(neg_head)),
                U=int(nid.shape[0]), UE=int(UE), UR=int(UR),
                h_gid=h, t_gid=t, rel_ids=r, neg_ids=neg, ue_id=ue_id.astype(np.int64),
@@ -61,6 +78,7 @@ def build_plan(h, t, r, neg, chunk, N, neg_head, edge_w=None):
                h_local=inv[:B].astype(np.int64), t_local=inv[B:].astype(np.int64),
                ue_pos_ptr=ue_pos_ptr, ue_pos_adj=ue_pos_adj, ue_neg_ptr=ue_neg_ptr,
                ue_neg_slot=ue_neg_slot, ur_ptr=ur_ptr, ur_edge=ur_edge,
+               ue_rec=ue_rec.reshape(-1), ur_rec=ur_rec.reshape(-1),
                edge_w=None if edge_w is None else np.ascontiguousarray(edge_w, np.float32))
     return out
 
@@ -71,7 +89,7 @@ def _pack(plans):
 
     def put(a):
         nonlocal pos
-        pad = (-pos) % 16
+        pad = (-pos) % 32
         if pad:
             chunks.append(np.zeros(pad, np.uint8))
             pos += pad
@@ -106,7 +124,7 @@ class Batch(object):
         for k in ("B", "C", "chunk", "N", "neg_head", "U", "UE", "UR"):
             setattr(kb, k, plan[k])
         for k in ("h_gid", "t_gid", "rel_ids", "neg_ids", "ue_id", "ue_pos_ptr", "ue_pos_adj",
-                  "ue_neg_ptr", "ue_neg_slot", "ur_id", "ur_ptr", "ur_edge"):
+                  "ue_neg_ptr", "ue_neg_slot", "ur_id", "ur_ptr", "ur_edge", "ue_rec", "ur_rec"):
             setattr(kb, k, base + offs[k])
         kb.edge_w = (base + offs["edge_w"]) if "edge_w" in offs else None
         self.c = kb

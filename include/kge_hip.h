@@ -58,6 +58,16 @@ enum kge_status {
  * GEMM kernels for the models that have a GEMM form (validation aid; TransE_l1 / RotatE always
  * use the pairwise kernels). */
 #define KGE_FLAG_FORCE_PAIRWISE 1u
+/* keep the generic edge-gradient kernel for TransE instead of rebuilding the per-edge gradients
+ * inside the update kernel (validation aid) */
+#define KGE_FLAG_NO_TRANSE_FAST 2u
+/* matrix-core path: read the negative rows from a dense per-step copy instead of gathering them
+ * from the entity table through neg_ids (tuning aid) */
+#define KGE_FLAG_DENSE_NEG 4u
+/* matrix-core path: apply the loss gradient on the fly inside the backward GEMM instead of
+ * running the stand-alone loss kernel (one launch fewer; currently slower because the extra VALU
+ * work sits between the MFMAs - kept for tuning) */
+#define KGE_FLAG_FUSED_LOSS 8u
 
 int         kge_abi_version(void);
 const char *kge_last_error(void);
@@ -142,6 +152,11 @@ typedef struct kge_batch {
     const int64_t *ur_id;       /* [UR]   unique relation id                                 */
     const int32_t *ur_ptr;      /* [UR+1] CSR into ur_edge                                   */
     const int32_t *ur_edge;     /* [B]    edges carrying this relation                       */
+    /* packed records, 32-byte aligned, one per unique row: everything the update kernel needs  */
+    /* to request the row and its first gradient rows in ONE dependent round                    */
+    const int32_t *ue_rec;      /* [UE][8] {id_lo, id_hi, pos_begin, pos_end, neg_begin,     */
+                                /*          neg_end, ue_pos_adj[pos_begin]|-1, ue_neg_slot[neg_begin]|-1} */
+    const int32_t *ur_rec;      /* [UR][8] {id_lo, id_hi, edge_begin, edge_end, ur_edge[edge_begin], 0,0,0} */
 } kge_batch;
 
 typedef struct kge_hparams {

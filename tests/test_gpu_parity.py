@@ -119,16 +119,16 @@ def test_dropin_model_matches_reference(name):
     _close(m.relation_emb.emb.cpu(), z["final_relation"], 1e-4, 1e-2 * case["lr"], name + " final relation")
 
 
-@pytest.mark.parametrize("force_pairwise", [False, True])
+@pytest.mark.parametrize("flags", [0, 1, 2], ids=["auto", "force_pairwise", "no_transe_fast"])
 @pytest.mark.parametrize("name", golden_names())
-def test_fused_step_matches_reference(name, force_pairwise):
+def test_fused_step_matches_reference(name, flags):
     """kge_step_fused (one call per step) vs the reference's recorded scores / gradients / tables;
     both the matrix-core and the pairwise negative-score kernels."""
     from dglke_amd import _lib
     z, case = load_golden(name)
     m = build_model(case, z)
     eng = m.engine
-    eng.hp.flags = _lib.FLAG_FORCE_PAIRWISE if force_pairwise else 0
+    eng.hp.flags = flags       # _lib.FLAG_FORCE_PAIRWISE = 1, _lib.FLAG_NO_TRANSE_FAST = 2
     for s in range(1, case["steps"] + 1):
         p = "s%d_" % s
         b = golden_batch(z, case, s)
