@@ -87,6 +87,27 @@ __device__ __forceinline__ float neg_logsigmoid(float z) {
 
 constexpr bool is_complex_model(int m) { return m == KGE_COMPLEX || m == KGE_ROTATE; }
 
+// fast-math variants (hardware exp/log, |rel err| ~1e-6) for the hot kernels
+__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.f + __expf(-x)); }
+__device__ __forceinline__ float fast_neg_logsigmoid(float z) {
+    return fmaxf(-z, 0.f) + __logf(1.f + __expf(-fabsf(z)));
+}
+__device__ __forceinline__ void criterion_fast(int genre, float s, float label, float margin,
+                                               float &val, float &dval) {
+    if (genre == KGE_LOSS_HINGE) {
+        const float v = margin - label * s;
+        val = v < 0.f ? 0.f : v;
+        dval = v < 0.f ? 0.f : -label;
+    } else if (genre == KGE_LOSS_BCE) {
+        val = label * fast_neg_logsigmoid(s) + (1.f - label) * fast_neg_logsigmoid(-s);
+        dval = fast_sigmoid(s) - label;
+    } else {
+        const float z = label * s;
+        val = fast_neg_logsigmoid(z);
+        dval = -label * fast_sigmoid(-z);
+    }
+}
+
 // criterion value and derivative w.r.t. the score for label l (models/pytorch/loss.py:10-38)
 __device__ __forceinline__ void criterion(int genre, float s, float label, float margin,
                                           float &val, float &dval) {

@@ -68,19 +68,19 @@ __global__ __launch_bounds__(KGE_BLOCK) void neg_fwd_gemm_kernel(GemmArgs a, int
     const float *Ap = a.A + ((int64_t)c * a.chunk + ia) * D + q * 4;
     const float *Bp = row_ptr(a.nbase, a.nidx, (int64_t)c * a.N + jb, D) + q * 4;
     const int kq = q * 4;
-    const int ksteps = (D + 15) / 16;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     float4 a0[FU], b0[FU], a1[FU], b1[FU];
 
+    // main loop: only FULL k-steps (all 64 lanes in range) - no per-lane predicates, no exec-mask
+    // branches between the MFMAs; the (KS0)+u < kfull tests are wave-uniform scalar branches
+    const int kfull = D >> 4;
 #define FWD_LOAD(AV, BV, KS0)                                                    \
     _Pragma("unroll") for (int u = 0; u < FU; ++u) {                             \
-        const int k = ((KS0) + u) * 16;                                          \
-        if (k + kq < D) { AV[u] = ldg4(Ap + k); BV[u] = ldg4(Bp + k); }          \
-        else { AV[u] = zero4(); BV[u] = zero4(); }                               \
+        if ((KS0) + u < kfull) { AV[u] = ldg4(Ap + ((KS0) + u) * 16); BV[u] = ldg4(Bp + ((KS0) + u) * 16); } \
     }
 #define FWD_MMA(AV, BV, KS0)                                                     \
     _Pragma("unroll") for (int u = 0; u < FU; ++u) {                             \
-        if ((KS0) + u < ksteps) {                                                \
+        if ((KS0) + u < kfull) {                                                 \
             acc0 = MFMA16(AV[u].x, BV[u].x, acc0);                               \
             acc1 = MFMA16(AV[u].y, BV[u].y, acc1);                               \
             acc0 = MFMA16(AV[u].z, BV[u].z, acc0);                               \
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void neg_fwd_gemm_kernel(GemmArgs a, int
     }
 
     FWD_LOAD(a0, b0, 0);
-    for (int g = 0; g < ksteps; g += 2 * FU) {
+    for (int g = 0; g < kfull; g += 2 * FU) {
         FWD_LOAD(a1, b1, g + FU);
         FWD_MMA(a0, b0, g);
         FWD_LOAD(a0, b0, g + 2 * FU);
@@ -97,6 +97,14 @@ __global__ __launch_bounds__(KGE_BLOCK) void neg_fwd_gemm_kernel(GemmArgs a, int
     }
 #undef FWD_LOAD
 #undef FWD_MMA
+    if (D & 15) {   // tail k-step: lanes whose 4 floats lie beyond D contribute zeros
+        float4 av = zero4(), bv = zero4();
+        if (kfull * 16 + kq < D) { av = ldg4(Ap + kfull * 16); bv = ldg4(Bp + kfull * 16); }
+        acc0 = MFMA16(av.x, bv.x, acc0);
+        acc1 = MFMA16(av.y, bv.y, acc1);
+        acc0 = MFMA16(av.z, bv.z, acc0);
+        acc1 = MFMA16(av.w, bv.w, acc1);
+    }
 
     // NOTE: the MFMA stream above is kept free of VALU work on purpose - accumulating |a|^2,|b|^2
     // from the loaded fragments inside the loop cost +3.5 us (45 %) on MI355X; they come precomputed.

@@ -506,7 +506,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void loss_kernel_reg(LossArgs a) {
             const int j = lane + 64 * u;
             if (j < N) {
                 float val, dv;
-                criterion(a.genre, p - nv[u], 1.f, a.margin, val, dv);
+                criterion_fast(a.genre, p - nv[u], 1.f, a.margin, val, dv);
                 lsum += val * sc;
                 const float dd = dv * sc;
                 dsum += dd;
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void loss_kernel_reg(LossArgs a) {
         float z = 0.f;
 #pragma unroll
         for (int u = 0; u < NPER; ++u) {
-            ex[u] = (lane + 64 * u < N) ? expf(nv[u] * a.adv_temp - mx) : 0.f;
+            ex[u] = (lane + 64 * u < N) ? __expf(nv[u] * a.adv_temp - mx) : 0.f;
             z += ex[u];
         }
         Z = wave_sum(z);
@@ -555,7 +555,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void loss_kernel_reg(LossArgs a) {
         const int j = lane + 64 * u;
         if (j < N) {
             float nl, dnl;
-            criterion(a.genre, nv[u], neg_label, a.margin, nl, dnl);
+            criterion_fast(a.genre, nv[u], neg_label, a.margin, nl, dnl);
             const float A = a.adv ? ex[u] * invZ : invN;
             acc += A * nl * w;
             float g = dnl * w * A * 0.5f * invB;
