@@ -71,11 +71,37 @@ def main(args, world, rank, local_rank):
     routes = [de.prepare_route(ue) for ue in ues]
     for b in batches:
         eng.workspace_for(b)
+    de.max_rows = int(max(max(r.UE for r in routes), max(r.n_recv for r in routes)) * 1.25) + 64
+
+    # one eager step (allocates every persistent buffer), then try to record each pool batch's step
+    # - kernels AND RCCL collectives - into a HIP graph; fall back to eager launches if capture fails
+    de.step(batches[0], routes[0])
+    torch.cuda.synchronize()
+    graphs = None
+    # NOTE: recording the RCCL collectives into a HIP graph hung on the test box (world=1, RCCL
+    # 2.26.6 / ROCm 7.0.2 user-space in torch) - opt-in only until that is understood.
+    if os.environ.get("KGE_DIST_GRAPH") and not args.no_graph:
+        try:
+            side = torch.cuda.Stream(device=dev)
+            graphs = [de.capture(b, r, stream=side) for b, r in zip(batches, routes)]
+            torch.cuda.synchronize()
+        except Exception as e:       # noqa: BLE001 - any capture problem means: run eager
+            if rank == 0:
+                print("graph capture of the sharded step failed (%r): running eager" % (e,), file=sys.stderr)
+            graphs = None
+            de._frozen = False
+    ok = torch.tensor([1 if graphs is not None else 0], device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) == 0:
+        graphs = None
 
     def run(start, count):
         for k in range(count):
             i = (start + k) % pool
-            de.step(batches[i], routes[i])
+            if graphs is not None:
+                graphs[i].replay()
+            else:
+                de.step(batches[i], routes[i])
 
     run(0, args.warmup)
     torch.cuda.synchronize()
@@ -106,9 +132,10 @@ def main(args, world, rank, local_rank):
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s synthetic Freebase-sized: n_ent=%d n_rel=%d, per-GPU batch=%d neg=%d "
                                    "dim=%d, entity table range-sharded over %d GPUs (%.1f GB/GPU), relation "
-                                   "table replicated, RCCL all-to-all pull/push, eager launches"
+                                   "table replicated, RCCL all-to-all pull/push, %s"
                                    % (w["model"], n_ent, w["n_rel"], w["B"], w["N"], w["hidden"], world,
-                                      spec.n_local * d_e * 4 / 1e9),
+                                      spec.n_local * d_e * 4 / 1e9,
+                                      "one hipGraph per step" if graphs is not None else "eager launches"),
                        "global_batch": w["B"] * world, "parallelism": "entity-shard x%d (all-to-all)" % world},
             "roofline": {"bound": "hbm", "achieved": round(bytes_step * world / (wall / K) / 1e9, 2),
                          "peak": 8000.0 * world, "unit": "GB/s",

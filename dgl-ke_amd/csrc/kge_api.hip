@@ -275,6 +275,16 @@ int kge_adagrad_scatter(float *table, float *state_sum, int64_t n_rows, int dim,
     return KGE_OK;
 }
 
+int kge_adagrad_apply_packed(float *table, float *state_sum, int64_t n_rows, int dim,
+                             const int64_t *idx, const float *msg, int ld, int64_t n, int ntraces,
+                             float lr, float eps, void *stream) {
+    if (!table || !state_sum || (n && !msg) || dim <= 0 || n_rows < 0 || ntraces < 1 ||
+        ld < ntraces * dim + ntraces + (idx ? 0 : 2))
+        return fail(KGE_ERR_ARG, "kge_adagrad_apply_packed: bad argument");
+    KGE_TRY(launch_adagrad_apply_packed(table, state_sum, dim, idx, msg, ld, n, ntraces, lr, eps, (hipStream_t)stream));
+    return KGE_OK;
+}
+
 int kge_adagrad_apply_rows(float *table, float *state_sum, int64_t n_rows, int dim,
                            const int64_t *idx, const float *g, const float *gs, int64_t n, float lr,
                            float eps, void *stream) {
@@ -455,12 +465,18 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     ua.transe_fast = transe_fast ? 1 : 0; ua.neg_head = b->neg_head; ua.P = Pg; ua.GA = GA;
     ua.reg_ent = want4 ? reg_ent : nullptr; ua.reg_rel = want4 ? reg_rel : nullptr;
     ua.acc = acc;
+    ua.ld_e = d_e; ua.ld_r = d_r; ua.ld_gs_e = 1; ua.ld_gs_r = 1;
     if (emit) {
         ua.g0 = emit->g0; ua.gs0 = emit->gs0; ua.g1 = emit->g1; ua.gs1 = emit->gs1;
-        ua.gr = emit->gr; ua.gsr = emit->gsr;
+        ua.gr = emit->gr; ua.gsr = emit->gsr; ua.rid = emit->rid;
         ua.emit_ent = 1; ua.emit_rel = emit->gr ? 1 : 0;
+        if (emit->ld_e > 0) { ua.ld_e = emit->ld_e; ua.ld_gs_e = emit->ld_e; }
+        if (emit->ld_r > 0) { ua.ld_r = emit->ld_r; ua.ld_gs_r = emit->ld_r; }
     }
-    if (out && out->g_pos_ent) ua.g0 = out->g_pos_ent;
+    if (out && out->g_pos_ent) {
+        if (emit && emit->ld_e > 0) return fail(KGE_ERR_ARG, "g_pos_ent output cannot be combined with a strided emit");
+        ua.g0 = out->g_pos_ent;
+    }
     KGE_TRY(launch_update(ua, s));
     // 7. deterministic reduction of this step's loss terms (only when the caller wants the
     //    per-step values; running sums are accumulated by the kernels above without it)

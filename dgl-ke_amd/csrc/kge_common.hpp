@@ -223,6 +223,9 @@ struct UpdateArgs {
     // emit mode (sharded training): write gradients instead of updating the entity table
     float *g0, *gs0, *g1, *gs1, *gr, *gsr;
     int emit_ent, emit_rel;
+    int ld_e, ld_r;                  // row strides of the emit buffers (floats)
+    int32_t *rid;                    // optional relation-id words inside the relation message
+    int ld_gs_e, ld_gs_r;            // strides of gs0/gs1 and gsr
 };
 
 struct FinalizeArgs {
@@ -240,6 +243,8 @@ int launch_finalize(const FinalizeArgs &a, hipStream_t s);
 int launch_update(const UpdateArgs &a, hipStream_t s);
 int launch_adagrad_scatter(float *table, float *state, int dim, const int64_t *idx,
                            const float *grad, int64_t n, float lr, float eps, hipStream_t s);
+int launch_adagrad_apply_packed(float *table, float *state, int dim, const int64_t *idx, const float *msg,
+                                int ld, int64_t n, int ntraces, float lr, float eps, hipStream_t s);
 int launch_adagrad_apply_rows(float *table, float *state, int dim, const int64_t *idx,
                               const float *g, const float *gs, int64_t n, float lr, float eps,
                               hipStream_t s);

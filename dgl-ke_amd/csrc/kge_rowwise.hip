@@ -723,13 +723,13 @@ __global__ __launch_bounds__(KGE_BLOCK) void update_kernel(UpdateArgs a, int nb_
                 }
             }
             if (!a.emit_ent) st<V>(row + off, x);
-            if (a.g0) st<V>(a.g0 + u * (int64_t)d + off, g0);
-            if (a.g1) st<V>(a.g1 + u * (int64_t)d + off, g1);
+            if (a.g0) st<V>(a.g0 + u * (int64_t)a.ld_e + off, g0);
+            if (a.g1) st<V>(a.g1 + u * (int64_t)a.ld_e + off, g1);
         }
         if (lane == 0) {
             if (!a.emit_ent) a.ent_state[id] = sB;
-            if (a.gs0) a.gs0[u] = has_pos ? s0 : 0.f;
-            if (a.gs1) a.gs1[u] = has_neg ? s1 : 0.f;
+            if (a.gs0) a.gs0[u * (int64_t)a.ld_gs_e] = has_pos ? s0 : 0.f;
+            if (a.gs1) a.gs1[u * (int64_t)a.ld_gs_e] = has_neg ? s1 : 0.f;
         }
         if (reg && (a.reg_ent || a.acc)) {
             rv = wave_sum(rv);
@@ -777,11 +777,12 @@ __global__ __launch_bounds__(KGE_BLOCK) void update_kernel(UpdateArgs a, int nb_
                 }
             }
             if (!a.emit_rel) st<V>(row + off, x);
-            if (a.gr) st<V>(a.gr + u * (int64_t)d + off, gsum);
+            if (a.gr) st<V>(a.gr + u * (int64_t)a.ld_r + off, gsum);
         }
         if (lane == 0) {
             if (!a.emit_rel) a.rel_state[id] = sN;
-            if (a.gsr) a.gsr[u] = ss;
+            if (a.gsr) a.gsr[u * (int64_t)a.ld_gs_r] = ss;
+            if (a.rid) { a.rid[u * (int64_t)a.ld_r] = (int32_t)(id & 0xFFFFFFFF); a.rid[u * (int64_t)a.ld_r + 1] = (int32_t)(id >> 32); }
         }
         if (reg && (a.reg_rel || a.acc)) {
             rv = wave_sum(rv);
@@ -917,14 +918,14 @@ __global__ __launch_bounds__(KGE_BLOCK) void update_kernel_reg(UpdateArgs a, int
                     }
                     st<4>(row + it * 4, y);
                 }
-                if (a.g0) st<4>(a.g0 + u * (int64_t)d + it * 4, g0[k]);
-                if (a.g1) st<4>(a.g1 + u * (int64_t)d + it * 4, g1[k]);
+                if (a.g0) st<4>(a.g0 + u * (int64_t)a.ld_e + it * 4, g0[k]);
+                if (a.g1) st<4>(a.g1 + u * (int64_t)a.ld_e + it * 4, g1[k]);
             }
         }
         if (lane == 0) {
             if (!a.emit_ent) a.ent_state[id] = sB;
-            if (a.gs0) a.gs0[u] = has_pos ? s0 : 0.f;
-            if (a.gs1) a.gs1[u] = has_neg ? s1 : 0.f;
+            if (a.gs0) a.gs0[u * (int64_t)a.ld_gs_e] = has_pos ? s0 : 0.f;
+            if (a.gs1) a.gs1[u * (int64_t)a.ld_gs_e] = has_neg ? s1 : 0.f;
         }
         if (reg && (a.reg_ent || a.acc)) {
             rv = wave_sum(rv);
@@ -1005,12 +1006,13 @@ __global__ __launch_bounds__(KGE_BLOCK) void update_kernel_reg(UpdateArgs a, int
                     for (int e = 0; e < 4; ++e) y.v[e] += (-a.lr * gsum[k].v[e]) / sd;
                     st<4>(row + it * 4, y);
                 }
-                if (a.gr) st<4>(a.gr + u * (int64_t)d + it * 4, gsum[k]);
+                if (a.gr) st<4>(a.gr + u * (int64_t)a.ld_r + it * 4, gsum[k]);
             }
         }
         if (lane == 0) {
             if (!a.emit_rel) a.rel_state[id] = sN;
-            if (a.gsr) a.gsr[u] = ss;
+            if (a.gsr) a.gsr[u * (int64_t)a.ld_gs_r] = ss;
+            if (a.rid) { a.rid[u * (int64_t)a.ld_r] = (int32_t)(id & 0xFFFFFFFF); a.rid[u * (int64_t)a.ld_r + 1] = (int32_t)(id >> 32); }
         }
         if (reg && (a.reg_rel || a.acc)) {
             rv = wave_sum(rv);
@@ -1101,6 +1103,54 @@ __global__ __launch_bounds__(KGE_BLOCK) void apply_rows_kernel(float *table, flo
         st<V>(row + it * V, x);
     }
     if (lane == 0) state[id] = sN;
+}
+
+// packed messages: T traces per row applied in order by one wavefront (see include/kge_hip.h)
+template <int V>
+__global__ __launch_bounds__(KGE_BLOCK) void apply_packed_kernel(float *table, float *state, int dim,
+                                                                 const int64_t *idx, const float *msg, int mld,
+                                                                 int64_t n, int T, float lr, float eps) {
+    const int64_t k = WAVE_ID();
+    if (k >= n) return;
+    const int lane = LANE();
+    const float *m = msg + k * (int64_t)mld;
+    int64_t id;
+    if (idx) id = idx[k];
+    else {
+        const int32_t *w = reinterpret_cast<const int32_t *>(m + (int64_t)T * dim + T);
+        id = (int64_t)(uint32_t)w[0] | ((int64_t)w[1] << 32);
+    }
+    if (id < 0) return;
+    float *row = table + id * (int64_t)dim;
+    float s = state[id];
+    bool any = false;
+    for (int t = 0; t < T; ++t) {
+        const float inc = m[(int64_t)T * dim + t];
+        if (inc == 0.f) continue;
+        any = true;
+        s += inc;
+        const float sd = sqrtf(s) + eps;
+        const float *g = m + (int64_t)t * dim;
+        for (int it = lane; it < dim / V; it += 64) {
+            Pack<V> x = ld<V>(row + it * V);
+            const Pack<V> gv = ld<V>(g + it * V);
+#pragma unroll
+            for (int e = 0; e < V; ++e) x.v[e] += (-lr * gv.v[e]) / sd;
+            st<V>(row + it * V, x);
+        }
+    }
+    if (any && lane == 0) state[id] = s;
+}
+
+int launch_adagrad_apply_packed(float *table, float *state, int dim, const int64_t *idx, const float *msg,
+                                int ld, int64_t n, int ntraces, float lr, float eps, hipStream_t s) {
+    if (n == 0) return KGE_OK;
+    const int nb = blocks_for_waves(n);
+    if (dim % 4 == 0 && ld % 4 == 0)
+        hipLaunchKernelGGL(apply_packed_kernel<4>, dim3(nb), dim3(KGE_BLOCK), 0, s, table, state, dim, idx, msg, ld, n, ntraces, lr, eps);
+    else
+        hipLaunchKernelGGL(apply_packed_kernel<1>, dim3(nb), dim3(KGE_BLOCK), 0, s, table, state, dim, idx, msg, ld, n, ntraces, lr, eps);
+    return check_launch();
 }
 
 int launch_adagrad_apply_rows(float *table, float *state, int dim, const int64_t *idx,

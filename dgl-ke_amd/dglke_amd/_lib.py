@@ -55,7 +55,8 @@ class KgeStepOut(C.Structure):
 
 
 class KgeEmit(C.Structure):
-    _fields_ = [("g0", c_p), ("gs0", c_p), ("g1", c_p), ("gs1", c_p), ("gr", c_p), ("gsr", c_p)]
+    _fields_ = [("g0", c_p), ("gs0", c_p), ("g1", c_p), ("gs1", c_p), ("gr", c_p), ("gsr", c_p),
+                ("ld_e", c_i32), ("ld_r", c_i32), ("rid", c_p)]
 
 
 _SIGNATURES = {
@@ -74,6 +75,7 @@ _SIGNATURES = {
                                c_p, c_sz, c_p]),
     "kge_reduce_loss": (c_i, [c_p, c_p, c_i, c_p]),
     "kge_adagrad_scatter": (c_i, [c_p, c_p, c_i64, c_i, c_p, c_p, c_i64, c_f, c_f, c_p]),
+    "kge_adagrad_apply_packed": (c_i, [c_p, c_p, c_i64, c_i, c_p, c_p, c_i, c_i64, c_i, c_f, c_f, c_p]),
     "kge_adagrad_apply_rows": (c_i, [c_p, c_p, c_i64, c_i, c_p, c_p, c_p, c_i64, c_f, c_f, c_p]),
     "kge_step_workspace_bytes": (c_sz, [C.POINTER(KgeHParams), c_i, c_i, c_i, c_i, c_i, c_i]),
     "kge_step_fused": (c_i, [C.POINTER(KgeHParams), C.POINTER(KgeTables), C.POINTER(KgeBatch),

@@ -58,21 +58,31 @@ class HipOps(object):
         from . import ops
         return ops.gather_rows(table, idx)
 
-    def apply_rows(self, table, state, idx, g, gs, lr):
-        from . import ops
-        ops.adagrad_apply_rows(table, state, idx, g, gs, lr)
+    def apply_packed(self, table, state, idx, msg, ntraces, lr):
+        """owner-side Adagrad of packed messages (kge_adagrad_apply_packed)."""
+        _lib.check(_lib.lib().kge_adagrad_apply_packed(
+            _lib.ptr(table), _lib.ptr(state), table.shape[0], table.shape[1],
+            _lib.ptr(idx) if idx is not None else None, _lib.ptr(msg), msg.shape[1], msg.shape[0],
+            ntraces, float(lr), 1e-10, _lib.stream_ptr()))
 
-    def step_grads(self, engine, batch, cache, emit_bufs):
-        """run kge_step_grads against the row cache."""
-        dev = cache.device
+    def reset_rel_msg(self, rel_msg, d_r):
+        rel_msg[:, d_r] = 0
+        rel_msg.view(torch.int32)[:, d_r + 1:d_r + 3] = -1
+
+    def step_grads(self, engine, batch, cache, ent_msg, rel_msg, zero_state):
+        """run kge_step_grads against the row cache, emitting packed messages:
+        ent_msg[u] = [g0 | g1 | gs0 gs1 . .],  rel_msg[u] = [gr | gsr | id_lo id_hi .]"""
+        d_e, d_r = cache.shape[1], engine.rel.shape[1]
         tb = _lib.KgeTables()
-        zero_state = emit_bufs["zero_state"]
         tb.ent, tb.ent_state = _lib.ptr(cache), _lib.ptr(zero_state)
         tb.rel, tb.rel_state = _lib.ptr(engine.rel), _lib.ptr(engine.rel_state)
         tb.n_ent, tb.n_rel = cache.shape[0], engine.rel.shape[0]
         em = _lib.KgeEmit()
-        for k in ("g0", "gs0", "g1", "gs1", "gr", "gsr"):
-            setattr(em, k, _lib.ptr(emit_bufs[k]))
+        e0, r0 = ent_msg.data_ptr(), rel_msg.data_ptr()
+        em.g0, em.g1 = e0, e0 + 4 * d_e
+        em.gs0, em.gs1 = e0 + 8 * d_e, e0 + 8 * d_e + 4
+        em.gr, em.gsr, em.rid = r0, r0 + 4 * d_r, r0 + 4 * d_r + 4
+        em.ld_e, em.ld_r = ent_msg.shape[1], rel_msg.shape[1]
         out = _lib.KgeStepOut()
         out.loss_accum = _lib.ptr(engine.loss_accum)
         ws = engine.workspace_for(batch)
@@ -110,6 +120,8 @@ class DistEngine(object):
         self.d_e = ent_shard.shape[1]
         self.d_r = engine.rel.shape[1]
         self._bufs = {}
+        self._frozen = False
+        self.max_rows = 0
 
     # ---- step 1: ids ---------------------------------------------------------------------
     def prepare_route(self, ue_ids_np):
@@ -131,57 +143,54 @@ class DistEngine(object):
         return rt
 
     def _buf(self, name, shape, dtype=None):
+        """persistent scratch: allocated once for the largest row count seen so far, returned as a
+        [rows, ...] view (so that a captured graph never allocates)."""
         dtype = dtype or self.ent.dtype
+        rows = shape[0]
         t = self._bufs.get(name)
-        if t is None or tuple(t.shape) != tuple(shape):
-            t = torch.zeros(shape, dtype=dtype, device=self.dev)
+        if t is None or t.shape[0] < rows or tuple(t.shape[1:]) != tuple(shape[1:]) or t.dtype != dtype:
+            if self._frozen:
+                raise _lib.KgeError("DistEngine buffer %s would be re-allocated after graph capture" % name)
+            cap = max(rows, self.max_rows)
+            t = torch.zeros((cap,) + tuple(shape[1:]), dtype=dtype, device=self.dev)
             self._bufs[name] = t
-        return t
+        return t[:rows]
 
     # ---- steps 2-5 -----------------------------------------------------------------------
     def step(self, batch, route):
         sp, ops = self.spec, self.ops
-        UE, nrecv = route.UE, route.n_recv
-        B = batch.B
-        # 2. pull
+        UE, nrecv, B = route.UE, route.n_recv, batch.B
+        ld_e, ld_r = 2 * self.d_e + 4, self.d_r + 4
+        # 2. pull: owners gather the requested rows, one all-to-all returns them into the row cache
         rows_out = ops.gather(self.ent, route.recv_ids_local)
         cache = self._buf("cache", (UE, self.d_e))
         dist.all_to_all_single(cache, rows_out, route.send_counts, route.recv_counts, group=self.group)
-        # 3. local compute against the cache
-        em = dict(g0=self._buf("g0", (UE, self.d_e)), gs0=self._buf("gs0", (UE,)),
-                  g1=self._buf("g1", (UE, self.d_e)), gs1=self._buf("gs1", (UE,)),
-                  gr=self._buf("gr", (B, self.d_r)), gsr=self._buf("gsr", (B,)),
-                  zero_state=self._buf("zero_state", (UE,)))
-        ops.step_grads(self.engine, batch, cache, em)
-        # 4. push entity gradients to their owners and apply in source-rank order
-        r0 = self._buf("r_g0", (nrecv, self.d_e))
-        r1 = self._buf("r_g1", (nrecv, self.d_e))
-        gs = torch.stack([em["gs0"], em["gs1"]], dim=1).contiguous()
-        rgs = self._buf("r_gs", (nrecv, 2))
-        dist.all_to_all_single(r0, em["g0"], route.recv_counts, route.send_counts, group=self.group)
-        dist.all_to_all_single(r1, em["g1"], route.recv_counts, route.send_counts, group=self.group)
-        dist.all_to_all_single(rgs, gs, route.recv_counts, route.send_counts, group=self.group)
+        # 3. local compute against the cache -> one packed message per unique entity / relation
+        ent_msg = self._buf("ent_msg", (UE, ld_e))
+        rel_msg = self._buf("rel_msg", (B, ld_r))
+        ops.reset_rel_msg(rel_msg, self.d_r)       # padding rows: id = -1, increment = 0
+        ops.step_grads(self.engine, batch, cache, ent_msg, rel_msg, self._buf("zero_state", (UE,)))
+        # 4. push: ONE all-to-all carries both entity traces; owners apply per source rank, in order
+        recv_msg = self._buf("recv_msg", (nrecv, ld_e))
+        dist.all_to_all_single(recv_msg, ent_msg, route.recv_counts, route.send_counts, group=self.group)
         off = 0
         for src in range(sp.world):
             n = route.recv_counts[src]
             if n:
-                sl = slice(off, off + n)
-                ids = route.recv_ids_local[sl]
-                ops.apply_rows(self.ent, self.ent_state, ids, r0[sl], rgs[sl, 0].contiguous(), self.lr)
-                ops.apply_rows(self.ent, self.ent_state, ids, r1[sl], rgs[sl, 1].contiguous(), self.lr)
+                ops.apply_packed(self.ent, self.ent_state, route.recv_ids_local[off:off + n],
+                                 recv_msg[off:off + n], 2, self.lr)
             off += n
-        # 5. relations: all-gather (padded to B rows) and apply everything in rank order
-        ur = self._buf("ur_pad", (B,), torch.int64)
-        ur.fill_(-1)
-        ur[:batch.UR] = batch.view("ur_id")
-        if batch.UR < B:
-            em["gsr"][batch.UR:] = 0
-        all_ur = self._buf("all_ur", (sp.world, B), torch.int64)
-        all_gr = self._buf("all_gr", (sp.world, B, self.d_r))
-        all_gsr = self._buf("all_gsr", (sp.world, B))
-        dist.all_gather_into_tensor(all_ur.view(-1), ur, group=self.group)
-        dist.all_gather_into_tensor(all_gr.view(-1), em["gr"].view(-1), group=self.group)
-        dist.all_gather_into_tensor(all_gsr.view(-1), em["gsr"], group=self.group)
+        # 5. relations: ONE all-gather of the packed messages (ids inside); every rank applies all
+        #    ranks' updates in rank order -> replicas stay bit-identical
+        all_rel = self._buf("all_rel", (sp.world * B, ld_r))
+        dist.all_gather_into_tensor(all_rel.view(-1), rel_msg.reshape(-1), group=self.group)
         for src in range(sp.world):
-            ops.apply_rows(self.engine.rel, self.engine.rel_state, all_ur[src], all_gr[src],
-                           all_gsr[src], self.lr)
+            ops.apply_packed(self.engine.rel, self.engine.rel_state, None, all_rel[src * B:(src + 1) * B], 1, self.lr)
+
+    def capture(self, batch, route, stream=None):
+        """record one sharded step (kernels + RCCL collectives) into a HIP graph."""
+        self._frozen = True
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=stream):
+            self.step(batch, route)
+        return g

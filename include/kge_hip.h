@@ -213,6 +213,13 @@ typedef struct kge_emit {
     float *g0;  float *gs0;  /* [UE,d_e], [UE] */
     float *g1;  float *gs1;  /* [UE,d_e], [UE] */
     float *gr;  float *gsr;  /* [UR,d_r], [UR] summed relation gradient (NULL: update locally) */
+    /* row strides in floats (0 = dense: d_e / 1 / d_r / 1).  With strides the six arrays can be
+     * interleaved into ONE message per row - e.g. [g0 | g1 | gs0 gs1 pad pad] with ld_e = 2*d_e+4 -
+     * so that a single all-to-all pushes both traces (see kge_adagrad_apply_packed). */
+    int32_t ld_e;            /* stride of g0, g1, gs0, gs1 */
+    int32_t ld_r;            /* stride of gr, gsr */
+    int32_t *rid;            /* optional [UR*ld_r] view: relation id written as two int32 words at */
+                             /* rid[u*ld_r], rid[u*ld_r+1] (lo, hi) next to the gradient, or NULL   */
 } kge_emit;
 int kge_step_grads(const kge_hparams *hp, const kge_tables *tb, const kge_batch *b,
                    const kge_step_out *out, const kge_emit *emit, void *ws, size_t ws_bytes,
@@ -223,6 +230,15 @@ int kge_step_grads(const kge_hparams *hp, const kge_tables *tb, const kge_batch 
 int kge_adagrad_apply_rows(float *table, float *state_sum, int64_t n_rows, int dim,
                            const int64_t *idx, const float *g, const float *gs, int64_t n,
                            float lr, float eps, void *stream);
+
+/* owner side, packed messages (one row per message, `ld` floats apart):
+ *   msg = [ g_0 (dim) | ... | g_{T-1} (dim) | gs_0 .. gs_{T-1} | (id_lo id_hi as int32 bits when idx == NULL) ]
+ * applies the T traces of every row in order (trace t: s += gs_t; row += -lr*g_t/(sqrt(s)+eps)).
+ * Row ids come from idx[k] or, when idx is NULL, from the two int32 words stored after the gs
+ * values (a negative id skips the row).  Ids must be unique within one call. */
+int kge_adagrad_apply_packed(float *table, float *state_sum, int64_t n_rows, int dim,
+                             const int64_t *idx, const float *msg, int ld, int64_t n, int ntraces,
+                             float lr, float eps, void *stream);
 
 #ifdef __cplusplus
 }

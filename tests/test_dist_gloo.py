@@ -33,45 +33,50 @@ class FakeEngine(object):
 
 
 class OracleOps(object):
+    """stand-in for dglke_amd.dist.HipOps: same message layout, arithmetic by the CPU oracle."""
     def __init__(self, cfg):
         self.cfg = cfg
 
     def gather(self, table, idx):
         return table[idx].clone()
 
-    def apply_rows(self, table, state, idx, g, gs, lr):
-        for k in range(idx.shape[0]):
-            i = int(idx[k])
-            if i < 0 or float(gs[k]) == 0.0:
-                continue
-            state[i] += gs[k]
-            table[i] += (-lr * g[k]) / (torch.sqrt(state[i]) + 1e-10)
+    def reset_rel_msg(self, rel_msg, d_r):
+        rel_msg[:, d_r] = 0
+        rel_msg[:, d_r + 1] = -1          # id kept as a number in the test double
 
-    def step_grads(self, engine, batch, cache, em):
+    def apply_packed(self, table, state, idx, msg, ntraces, lr):
+        dim = table.shape[1]
+        for k in range(msg.shape[0]):
+            i = int(idx[k]) if idx is not None else int(msg[k, ntraces * dim + ntraces])
+            if i < 0:
+                continue
+            for t in range(ntraces):
+                inc = msg[k, ntraces * dim + t]
+                if float(inc) == 0.0:
+                    continue
+                state[i] += inc
+                table[i] += (-lr * msg[k, t * dim:(t + 1) * dim]) / (torch.sqrt(state[i]) + 1e-10)
+
+    def step_grads(self, engine, batch, cache, ent_msg, rel_msg, zero_state):
         from oracle import kge_oracle as O
         p = batch.p
+        D, dr = cache.shape[1], engine.rel.shape[1]
         out = O.forward_backward(self.cfg, cache.numpy().astype(np.float64), engine.rel.numpy().astype(np.float64),
                                  p["nid"], p["h_local"], p["t_local"], p["rel_ids"], p["neg_ids"],
                                  bool(p["neg_head"]), p["chunk"], p["N"])
-        for k in ("g0", "gs0", "g1", "gs1"):
-            em[k].zero_()
-        g0 = np.zeros((p["UE"], cache.shape[1]))
-        g0[p["nid"]] = out["g_pos_ent"]
-        gs0 = np.zeros(p["UE"])
-        gs0[p["nid"]] = (out["g_pos_ent"] ** 2).mean(1)
-        g1 = np.zeros_like(g0)
-        gs1 = np.zeros(p["UE"])
-        np.add.at(g1, p["neg_ids"], out["g_neg"])
-        np.add.at(gs1, p["neg_ids"], (out["g_neg"] ** 2).mean(1))
-        em["g0"].copy_(torch.from_numpy(g0)); em["gs0"].copy_(torch.from_numpy(gs0))
-        em["g1"].copy_(torch.from_numpy(g1)); em["gs1"].copy_(torch.from_numpy(gs1))
-        gr = np.zeros((p["B"], engine.rel.shape[1]))
-        gsr = np.zeros(p["B"])
+        em = np.zeros((p["UE"], 2 * D + 4))
+        em[p["nid"], :D] = out["g_pos_ent"]
+        em[p["nid"], 2 * D] = (out["g_pos_ent"] ** 2).mean(1)
+        np.add.at(em[:, D:2 * D], p["neg_ids"], out["g_neg"])
+        np.add.at(em[:, 2 * D + 1], p["neg_ids"], (out["g_neg"] ** 2).mean(1))
+        ent_msg.copy_(torch.from_numpy(em))
         ur = p["ur_id"]
         inv = np.searchsorted(ur, p["rel_ids"])
-        np.add.at(gr, inv, out["g_rel"])
-        np.add.at(gsr, inv, (out["g_rel"] ** 2).mean(1))
-        em["gr"].copy_(torch.from_numpy(gr)); em["gsr"].copy_(torch.from_numpy(gsr))
+        rm = rel_msg.numpy()
+        rm[:len(ur), :dr + 1] = 0
+        np.add.at(rm[:, :dr], inv, out["g_rel"])
+        np.add.at(rm[:, dr], inv, (out["g_rel"] ** 2).mean(1))
+        rm[:len(ur), dr + 1] = ur
 
 
 def _batches(world, steps):
