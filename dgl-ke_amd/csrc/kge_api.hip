@@ -460,7 +460,7 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     ua.ue_id = b->ue_id; ua.ue_pos_ptr = b->ue_pos_ptr; ua.ue_pos_adj = b->ue_pos_adj;
     ua.ue_neg_ptr = b->ue_neg_ptr; ua.ue_neg_slot = b->ue_neg_slot;
     ua.ur_id = b->ur_id; ua.ur_ptr = b->ur_ptr; ua.ur_edge = b->ur_edge;
-    ua.ue_rec = b->ue_rec; ua.ur_rec = b->ur_rec;
+    ua.ue_rec = b->ue_rec; ua.ur_rec = b->ur_rec; ua.counts_dev = b->counts_dev;
     ua.GH = GH; ua.GT = GT; ua.GN = GN; ua.GR = GR;
     ua.transe_fast = transe_fast ? 1 : 0; ua.neg_head = b->neg_head; ua.P = Pg; ua.GA = GA;
     ua.reg_ent = want4 ? reg_ent : nullptr; ua.reg_rel = want4 ? reg_rel : nullptr;
@@ -484,6 +484,7 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         FinalizeArgs f{};
         f.B = B; f.UE = b->UE; f.UR = b->UR; f.pairwise = hp->pairwise;
         f.row_pos = row_pos; f.row_neg = row_neg; f.reg_ent = reg_ent; f.reg_rel = reg_rel;
+        f.counts_dev = b->counts_dev;
         f.loss4 = out->loss4;
         KGE_TRY(launch_finalize(f, s));
     }

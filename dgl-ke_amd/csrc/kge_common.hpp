@@ -213,6 +213,7 @@ struct UpdateArgs {
     const int64_t *ue_id; const int32_t *ue_pos_ptr, *ue_pos_adj, *ue_neg_ptr, *ue_neg_slot;
     const int64_t *ur_id; const int32_t *ur_ptr, *ur_edge;
     const int32_t *ue_rec, *ur_rec;  // [UE][8], [UR][8] packed plan records (see kge_batch)
+    const int32_t *counts_dev;       // device {UE, UR} for device-built plans (UE/UR are bounds) or null
     const float *GH, *GT, *GN, *GR;
     // TransE fast path: per-edge gradients are rebuilt from P (positive part) and GA (negative
     // part) instead of reading GH/GT/GR written by edge_bwd:  GH = -P (+GA in tail mode),
@@ -231,6 +232,7 @@ struct UpdateArgs {
 struct FinalizeArgs {
     int B, UE, UR, pairwise;
     const float *row_pos, *row_neg, *reg_ent, *reg_rel;
+    const int32_t *counts_dev;
     float *loss4;
 };
 

@@ -602,8 +602,8 @@ __global__ __launch_bounds__(KGE_BLOCK) void finalize_kernel(FinalizeArgs a) {
     __shared__ float sh[KGE_WAVES_PER_BLOCK];
     const float lp = block_sum_det(a.row_pos, a.B, sh);
     const float ln = block_sum_det(a.row_neg, a.B, sh);
-    const float re = block_sum_det(a.reg_ent, a.UE, sh);
-    const float rr = block_sum_det(a.reg_rel, a.UR, sh);
+    const float re = block_sum_det(a.reg_ent, a.counts_dev ? a.counts_dev[0] : a.UE, sh);
+    const float rr = block_sum_det(a.reg_rel, a.counts_dev ? a.counts_dev[1] : a.UR, sh);
     if (threadIdx.x == 0) {
         float o[4];
         if (a.pairwise) { o[0] = NAN; o[1] = NAN; o[2] = ln; }
@@ -652,7 +652,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void update_kernel(UpdateArgs a, int nb_
     const bool reg = a.reg_coef > 0.f && a.reg_norm > 0;
     if ((int)blockIdx.x < nb_ent) {
         const int64_t u = WAVE_ID();
-        if (u >= a.UE) return;
+        if (u >= (a.counts_dev ? a.counts_dev[0] : a.UE)) return;
         const int d = a.model_d_e;
         const int64_t id = a.ue_id[u];
         float *row = a.ent + id * (int64_t)d;
@@ -741,7 +741,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void update_kernel(UpdateArgs a, int nb_
         } else if (a.reg_ent && lane == 0) a.reg_ent[u] = 0.f;
     } else {
         const int64_t u = ((int64_t)blockIdx.x - nb_ent) * KGE_WAVES_PER_BLOCK + (threadIdx.x >> 6);
-        if (u >= a.UR) return;
+        if (u >= (a.counts_dev ? a.counts_dev[1] : a.UR)) return;
         const int d = a.d_r;
         const int64_t id = a.ur_id[u];
         float *row = a.rel + id * (int64_t)d;
@@ -806,7 +806,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void update_kernel_reg(UpdateArgs a, int
     const bool reg = a.reg_coef > 0.f && a.reg_norm > 0;
     if ((int)blockIdx.x < nb_ent) {
         const int64_t u = WAVE_ID();
-        if (u >= a.UE) return;
+        if (u >= (a.counts_dev ? a.counts_dev[0] : a.UE)) return;
         const int d = a.model_d_e;
         const int4 r0 = reinterpret_cast<const int4 *>(a.ue_rec)[2 * u];
         const int4 r1 = reinterpret_cast<const int4 *>(a.ue_rec)[2 * u + 1];
@@ -937,7 +937,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void update_kernel_reg(UpdateArgs a, int
         } else if (a.reg_ent && lane == 0) a.reg_ent[u] = 0.f;
     } else {
         const int64_t u = ((int64_t)blockIdx.x - nb_ent) * KGE_WAVES_PER_BLOCK + (threadIdx.x >> 6);
-        if (u >= a.UR) return;
+        if (u >= (a.counts_dev ? a.counts_dev[1] : a.UR)) return;
         const int d = a.d_r;
         const int4 r0 = reinterpret_cast<const int4 *>(a.ur_rec)[2 * u];
         const int4 r1 = reinterpret_cast<const int4 *>(a.ur_rec)[2 * u + 1];

@@ -34,7 +34,7 @@ class KgeBatch(C.Structure):
                 ("h_gid", c_p), ("t_gid", c_p), ("rel_ids", c_p), ("neg_ids", c_p), ("edge_w", c_p),
                 ("ue_id", c_p), ("ue_pos_ptr", c_p), ("ue_pos_adj", c_p), ("ue_neg_ptr", c_p),
                 ("ue_neg_slot", c_p), ("ur_id", c_p), ("ur_ptr", c_p), ("ur_edge", c_p),
-                ("ue_rec", c_p), ("ur_rec", c_p)]
+                ("ue_rec", c_p), ("ur_rec", c_p), ("counts_dev", c_p)]
 
 
 class KgeHParams(C.Structure):
@@ -75,6 +75,10 @@ _SIGNATURES = {
                                c_p, c_sz, c_p]),
     "kge_reduce_loss": (c_i, [c_p, c_p, c_i, c_p]),
     "kge_adagrad_scatter": (c_i, [c_p, c_p, c_i64, c_i, c_p, c_p, c_i64, c_f, c_f, c_p]),
+    "kge_sampler_slot_bytes": (c_sz, [c_i, c_i, c_i]),
+    "kge_sample_batches": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i, c_i, c_i, c_i, C.c_uint64, c_p, c_p, c_sz,
+                                 c_i, c_p]),
+    "kge_batch_from_slot": (c_i, [c_p, c_sz, c_i, c_i, c_i, c_i, c_i, c_i, C.POINTER(KgeBatch)]),
     "kge_adagrad_apply_packed": (c_i, [c_p, c_p, c_i64, c_i, c_p, c_p, c_i, c_i64, c_i, c_f, c_f, c_p]),
     "kge_adagrad_apply_rows": (c_i, [c_p, c_p, c_i64, c_i, c_p, c_p, c_p, c_i64, c_f, c_f, c_p]),
     "kge_step_workspace_bytes": (c_sz, [C.POINTER(KgeHParams), c_i, c_i, c_i, c_i, c_i, c_i]),

@@ -113,3 +113,95 @@ class UniformChunkedSampler(object):
             self._queue = self.next_batches(self.prefetch)
         b = self._queue.pop(0)
         return PosGraph(b), NegGraph(b)
+
+
+class DeviceBatch(object):
+    """a batch that lives in a sampler slot in HBM: same duck type as plan.Batch for StepEngine
+    (`.c` = kge_batch, sizes as attributes); UE / UR are upper bounds, the kernels read the actual
+    counts from the slot."""
+
+    def __init__(self, sampler, slot, neg_head):
+        from . import _lib
+        import ctypes as C
+        self.sampler = sampler
+        self.slot = slot
+        self.B, self.C, self.chunk, self.N = sampler.B, sampler.C, sampler.chunk, sampler.N
+        self.neg_head = bool(neg_head)
+        kb = _lib.KgeBatch()
+        _lib.check(_lib.lib().kge_batch_from_slot(_lib.ptr(sampler.slots), sampler.slot_bytes, slot, self.B,
+                                                  self.C, self.chunk, self.N, int(self.neg_head), C.byref(kb)))
+        self.c = kb
+        self.U, self.UE, self.UR = 0, kb.UE, kb.UR
+
+
+class DeviceSampler(object):
+    """On-device sampler + plan builder (libkge_hip `kge_sample_batches`): the training triples, the
+    epoch permutation, the RNG state and the batch slots all live in HBM; `sample()` enqueues ONE
+    kernel that builds `n_slots` consecutive batches (no host work, graph-capturable).  Restates the
+    EdgeSampler wrappers of dataloader/sampler.py:376-419, 823-876 (uniform negatives with
+    replacement over all entities, alternating tail/head corruption, whole batches only)."""
+
+    def __init__(self, heads, rels, tails, n_entities, batch_size, neg_sample_size, device, n_slots=64,
+                 neg_chunk_size=None, seed=0, shuffle=True):
+        from . import _lib
+        self.dev = th.device(device)
+        if self.dev.type != 'cuda':
+            raise _lib.KgeError("DeviceSampler needs a CUDA (HIP) device")
+        self.B, self.N = int(batch_size), int(neg_sample_size)
+        self.chunk = int(neg_chunk_size or neg_sample_size)
+        if self.B % self.chunk:
+            raise ValueError("batch_size should be divisible by the chunk size")
+        self.C = self.B // self.chunk
+        if 2 * self.B + self.C * self.N > 4096:
+            raise _lib.KgeError("DeviceSampler handles 2*batch + chunks*neg <= 4096 elements per step; "
+                                "use UniformChunkedSampler (host plan) for larger batches")
+        self.n_entities = int(n_entities)
+        self.H = th.as_tensor(np.asarray(heads, np.int64)).to(self.dev)
+        self.R = th.as_tensor(np.asarray(rels, np.int64)).to(self.dev)
+        self.T = th.as_tensor(np.asarray(tails, np.int64)).to(self.dev)
+        self.n_train = int(self.H.shape[0])
+        self.seed = int(seed)
+        g = th.Generator(device=self.dev)
+        g.manual_seed(self.seed)
+        self.perm = th.randperm(self.n_train, device=self.dev, generator=g) if shuffle else None
+        self.state = th.tensor([0, 1], dtype=th.int64, device=self.dev)       # {position, step (1-based)}
+        self.n_slots = int(n_slots)
+        self.slot_bytes = int(_lib.lib().kge_sampler_slot_bytes(self.B, self.C, self.N))
+        self.slots = th.zeros(self.n_slots * self.slot_bytes, dtype=th.uint8, device=self.dev)
+        self.host_step = 1                                                     # next step to be sampled
+
+    def sample(self, n=None):
+        """enqueue the construction of the next `n` (default: all slots) batches into slots 0..n-1;
+        returns the DeviceBatch objects (their neg_head flag follows the step parity)."""
+        from . import _lib
+        n = self.n_slots if n is None else int(n)
+        if n > self.n_slots:
+            raise ValueError("more batches than slots")
+        _lib.check(_lib.lib().kge_sample_batches(
+            _lib.ptr(self.H), _lib.ptr(self.R), _lib.ptr(self.T),
+            _lib.ptr(self.perm) if self.perm is not None else None, self.n_train, self.n_entities, self.B,
+            self.C, self.chunk, self.N, self.seed, _lib.ptr(self.state), _lib.ptr(self.slots), self.slot_bytes,
+            n, _lib.stream_ptr()))
+        out = [DeviceBatch(self, k, (self.host_step + k) % 2 == 0) for k in range(n)]
+        self.host_step += n
+        return out
+
+    def slot_arrays(self, slot):
+        """copy one slot back to the host as numpy arrays (tests / debugging)."""
+        B, CN = self.B, self.C * self.N
+        NE = 2 * B + CN
+        raw = self.slots[slot * self.slot_bytes:(slot + 1) * self.slot_bytes].cpu().numpy()
+
+        def al(x):
+            return (x + 31) & ~31
+        o, out = 0, {}
+        for name, n, dt in (("h_gid", B, np.int64), ("t_gid", B, np.int64), ("rel_ids", B, np.int64),
+                            ("neg_ids", CN, np.int64), ("ue_id", NE, np.int64), ("ur_id", B, np.int64),
+                            ("ue_pos_ptr", NE + 1, np.int32), ("ue_pos_adj", 2 * B, np.int32),
+                            ("ue_neg_ptr", NE + 1, np.int32), ("ue_neg_slot", CN, np.int32),
+                            ("ur_ptr", B + 1, np.int32), ("ur_edge", B, np.int32),
+                            ("ue_rec", 8 * NE, np.int32), ("ur_rec", 8 * B, np.int32), ("counts", 4, np.int32)):
+            nb = n * np.dtype(dt).itemsize
+            out[name] = raw[o:o + nb].view(dt).copy()
+            o = al(o + nb)
+        return out

@@ -157,6 +157,9 @@ typedef struct kge_batch {
     const int32_t *ue_rec;      /* [UE][8] {id_lo, id_hi, pos_begin, pos_end, neg_begin,     */
                                 /*          neg_end, ue_pos_adj[pos_begin]|-1, ue_neg_slot[neg_begin]|-1} */
     const int32_t *ur_rec;      /* [UR][8] {id_lo, id_hi, edge_begin, edge_end, ur_edge[edge_begin], 0,0,0} */
+    /* batches built ON THE DEVICE (kge_sample_batches): UE / UR above are upper bounds and the  */
+    /* kernels read the actual counts {UE, UR} from this device array; NULL for host-built plans */
+    const int32_t *counts_dev;
 } kge_batch;
 
 typedef struct kge_hparams {
@@ -230,6 +233,22 @@ int kge_step_grads(const kge_hparams *hp, const kge_tables *tb, const kge_batch 
 int kge_adagrad_apply_rows(float *table, float *state_sum, int64_t n_rows, int dim,
                            const int64_t *idx, const float *g, const float *gs, int64_t n,
                            float lr, float eps, void *stream);
+
+/* ---- on-device sampler + plan builder (replaces the DGL EdgeSampler wrappers of
+ * dataloader/sampler.py:376-419, 823-876 and the host plan of dglke_amd/plan.py) ----
+ * heads/rels/tails: the training triples in HBM; perm: epoch permutation or NULL; state: device
+ * int64[2] = {position in the epoch, step number (1-based)}, advanced by the call; builds n_slots
+ * consecutive batches (batch k = step state[1]+k: odd steps corrupt tails, even steps heads;
+ * C*N uniform negatives with replacement from a counter-based RNG keyed by (seed, step)).
+ * Limits: 2B + C*N <= 4096 (one workgroup sorts a batch in LDS). */
+size_t kge_sampler_slot_bytes(int B, int C, int N);
+int kge_sample_batches(const int64_t *heads, const int64_t *rels, const int64_t *tails,
+                       const int64_t *perm, int64_t n_train, int64_t n_ent, int B, int C, int chunk,
+                       int N, uint64_t seed, int64_t *state, void *slots, size_t slot_bytes,
+                       int n_slots, void *stream);
+/* host-side: point a kge_batch at slot `slot` (pure pointer arithmetic, no device access) */
+int kge_batch_from_slot(void *slots, size_t slot_bytes, int slot, int B, int C, int chunk, int N,
+                        int neg_head, kge_batch *out);
 
 /* owner side, packed messages (one row per message, `ld` floats apart):
  *   msg = [ g_0 (dim) | ... | g_{T-1} (dim) | gs_0 .. gs_{T-1} | (id_lo id_hi as int32 bits when idx == NULL) ]

@@ -1,0 +1,84 @@
+"""On-device sampler + plan builder (kge_sample_batches) vs the host plan (dglke_amd/plan.py) rebuilt
+from the ids the kernel sampled; sampler semantics of dataloader/sampler.py:376-419, 853-859."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("n_ent,n_rel,B,N,chunk", [(14951, 1345, 1000, 200, 200), (9, 2, 16, 4, 4), (86054151, 14824, 1024, 256, 256),
+                                                    (500, 7, 120, 24, 40)])
+def test_device_plan_equals_host_plan(n_ent, n_rel, B, N, chunk):
+    from dglke_amd import plan
+    from dglke_amd.dataloader import DeviceSampler
+    rng = np.random.RandomState(0)
+    n_train = 5 * B + 17
+    h, r, t = rng.randint(0, n_ent, n_train), rng.randint(0, n_rel, n_train), rng.randint(0, n_ent, n_train)
+    s = DeviceSampler(h, r, t, n_ent, B, N, DEV, n_slots=6, neg_chunk_size=chunk, seed=3)
+    batches = s.sample()
+    torch.cuda.synchronize()
+    perm = s.perm.cpu().numpy()
+    C = B // chunk
+    allneg = []
+    for k, b in enumerate(batches):
+        a = s.slot_arrays(k)
+        e = perm[(k * B + np.arange(B)) % n_train]            # consecutive whole batches of the permuted epoch
+        assert np.array_equal(a["h_gid"], h[e]) and np.array_equal(a["t_gid"], t[e]) and np.array_equal(a["rel_ids"], r[e])
+        assert a["neg_ids"].min() >= 0 and a["neg_ids"].max() < n_ent
+        assert b.neg_head == ((k + 1) % 2 == 0)               # step 1 corrupts tails, step 2 heads, ...
+        assert a["counts"][2] == int(b.neg_head)
+        allneg.append(a["neg_ids"])
+        p = plan.build_plan(a["h_gid"], a["t_gid"], a["rel_ids"], a["neg_ids"], chunk, N, b.neg_head)
+        UE, UR = int(a["counts"][0]), int(a["counts"][1])
+        assert UE == p["UE"] and UR == p["UR"]
+        assert np.array_equal(a["ue_id"][:UE], p["ue_id"])
+        assert np.array_equal(a["ue_pos_ptr"][:UE + 1], p["ue_pos_ptr"])
+        assert np.array_equal(a["ue_pos_adj"], p["ue_pos_adj"])
+        assert np.array_equal(a["ue_neg_ptr"][:UE + 1], p["ue_neg_ptr"])
+        assert np.array_equal(a["ue_neg_slot"], p["ue_neg_slot"])
+        assert np.array_equal(a["ur_id"][:UR], p["ur_id"])
+        assert np.array_equal(a["ur_ptr"][:UR + 1], p["ur_ptr"])
+        assert np.array_equal(a["ur_edge"], p["ur_edge"])
+        assert np.array_equal(a["ue_rec"][:8 * UE], p["ue_rec"])
+        assert np.array_equal(a["ur_rec"][:8 * UR].reshape(-1, 8)[:, :5], p["ur_rec"].reshape(-1, 8)[:, :5])
+    # the counter-based RNG: different steps differ, values spread over the id range
+    allneg = np.concatenate(allneg)
+    assert not np.array_equal(allneg[:C * N], allneg[C * N:2 * C * N])
+    if n_ent > 1000:
+        assert 0.35 * n_ent < allneg.mean() < 0.65 * n_ent
+    # a second launch continues the epoch and the step counter
+    more = s.sample(2)
+    torch.cuda.synchronize()
+    a = s.slot_arrays(0)
+    e = perm[(6 * B + np.arange(B)) % n_train]
+    assert np.array_equal(a["h_gid"], h[e]) and more[0].neg_head == (7 % 2 == 0)
+
+
+def test_step_from_device_batch_equals_step_from_host_plan():
+    """the fused step fed by a device-built batch gives bit-identical tables to the step fed by the
+    host plan of the same ids."""
+    from dglke_amd import plan
+    from dglke_amd.dataloader import DeviceSampler
+    from dglke_amd.engine import StepEngine
+    rng = np.random.RandomState(1)
+    n_ent, n_rel, B, N, D = 3000, 40, 256, 64, 64
+    n_train = 4000
+    h, r, t = rng.randint(0, n_ent, n_train), rng.randint(0, n_rel, n_train), rng.randint(0, n_ent, n_train)
+    s = DeviceSampler(h, r, t, n_ent, B, N, DEV, n_slots=4, seed=9)
+    dbs = s.sample()
+    torch.cuda.synchronize()
+    torch.manual_seed(0)
+    e1 = StepEngine("TransE_l2", n_ent, n_rel, D, 12.0, 0.1, DEV, False, False, True, 1.0, 1e-6, 3)
+    e2 = StepEngine("TransE_l2", n_ent, n_rel, D, 12.0, 0.1, DEV, False, False, True, 1.0, 1e-6, 3)
+    e2.load_tables(e1.ent.clone(), e1.rel.clone())
+    for k, db in enumerate(dbs):
+        a = s.slot_arrays(k)
+        hb = plan.make_batch(a["h_gid"], a["t_gid"], a["rel_ids"], a["neg_ids"], N, N, db.neg_head, DEV)
+        e1.step(db)
+        e2.step(hb)
+    torch.cuda.synchronize()
+    assert torch.equal(e1.ent, e2.ent) and torch.equal(e1.rel, e2.rel)
+    assert torch.equal(e1.ent_state, e2.ent_state) and torch.equal(e1.rel_state, e2.rel_state)
+    assert np.allclose(e1.read_loss_sums(), e2.read_loss_sums(), rtol=1e-6)
