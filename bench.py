@@ -89,6 +89,10 @@ def synth_triples(w, seed):
 def cpu_baseline(w, plans, budget_s=12.0, max_steps=200):
     """time the CPU port of the reference step (oracle/torch_port.py) on the host cores."""
     from oracle import torch_port
+    if len(plans) < 32:          # device-sampler mode keeps only a few host plans: make a host sample
+        from dglke_amd.dataloader import UniformChunkedSampler
+        hh, rr, tt = synth_triples(w, 0)
+        plans = UniformChunkedSampler(hh, rr, tt, w["n_ent"], w["B"], w["N"], "cpu", seed=0).next_plans(max_steps + 2)
     th = torch
     nthreads = th.get_num_threads()
     model = torch_port.TorchPort(w["model"], w["n_ent"], w["n_rel"], w["hidden"], w["gamma"], w["lr"],
@@ -174,6 +178,8 @@ def main():
     ap.add_argument("--force-pairwise", action="store_true")
     ap.add_argument("--flags", type=int, default=0, help="extra kge_hparams.flags bits (tuning)")
     ap.add_argument("--no-adv", action="store_true", help="tuning: disable -adv")
+    ap.add_argument("--host-plan", action="store_true",
+                    help="pre-stage host-built batches instead of sampling on the device inside the timed region")
     ap.add_argument("--hogwild", type=int, default=4, help="also measure K concurrent Hogwild trainers (0 = skip)")
     args = ap.parse_args()
 
@@ -199,66 +205,115 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.manual_seed(0)
     h, r, t = synth_triples(w, 0)
-    sampler = UniformChunkedSampler(h, r, t, w["n_ent"], w["B"], w["N"], dev, seed=0)
-    G = args.graph_steps
-    pool = max(G, (args.pool // G) * G)
-    plans = sampler.next_plans(pool)
-    batches = plan.upload(plans, dev)
+    import math
     eng = StepEngine(w["model"], w["n_ent"], w["n_rel"], w["hidden"], w["gamma"], w["lr"], dev, w["de"],
                      w["dr"], w["adv"], w["adv_temp"], w["reg_coef"], w["reg_norm"],
                      flags=(_lib.FLAG_FORCE_PAIRWISE if args.force_pairwise else 0) | args.flags)
-    for b in batches:
-        eng.workspace_for(b)
-
-    # schedule: positions advance cyclically through the pool; full aligned segments replay a
-    # captured graph, partial segments get their own captured graph (outside the timed region)
-    graphs = {}
-
-    def get_graph(start, count):
-        key = (start, count)
-        if key not in graphs:
-            graphs[key] = eng.capture([batches[(start + k) % pool] for k in range(count)])
-        return graphs[key]
-
-    def schedule(pos, count):
-        items = []
-        while count > 0:
-            seg_off = pos % G
-            n = min(G - seg_off, count)
-            items.append((pos % pool, n))
-            pos += n
-            count -= n
-        return items, pos
-
+    C = w["B"] // w["N"]
     use_graph = not args.no_graph
-    warm_items, pos = schedule(0, args.warmup)
-    timed_items, pos = schedule(pos, args.steps)
-    if use_graph:
-        # eager warm-up of every kernel once before any capture
-        eng.step(batches[0])
+    G = args.graph_steps
+    dev_sampler = (not args.host_plan) and 2 * w["B"] + C * w["N"] <= 4096
+    if dev_sampler:
+        g = math.gcd(math.gcd(args.steps, args.warmup if args.warmup else args.steps), G)
+        if g >= 2 and g % 2 == 0:
+            G = g
+        else:
+            dev_sampler = False          # odd / tiny step counts: host-plan mode handles any K, W
+
+    if dev_sampler:
+        # ---- sampling + plan ON THE DEVICE, inside the timed region: one sampler launch per G steps ----
+        from dglke_amd.dataloader import DeviceSampler
+        smp = DeviceSampler(h, r, t, w["n_ent"], w["B"], w["N"], dev, n_slots=G, seed=0)
+        dbs = smp.sample()
+        for b in dbs[:1]:
+            eng.workspace_for(b)
+        torch.cuda.synchronize()
+        plans = []
+        for k in range(min(8, G)):       # host copies of a few batches: only to count traced rows (bytes)
+            a_ = smp.slot_arrays(k)
+            plans.append(plan.build_plan(a_["h_gid"], a_["t_gid"], a_["rel_ids"], a_["neg_ids"], w["N"], w["N"],
+                                         dbs[k].neg_head))
+        for b in dbs:                    # eager warm-up of every kernel before capture
+            eng.step(b)
         torch.cuda.synchronize()
         eng.reset_parameters()
-        for it in warm_items + timed_items:
-            get_graph(*it)
-        torch.cuda.synchronize()
 
-    def run(items):
+        def group():
+            for b in smp.sample():
+                eng.step(b)
         if use_graph:
-            for it in items:
-                graphs[it].replay()
-        else:
-            for start, n in items:
-                for k in range(n):
-                    eng.step(batches[(start + k) % pool])
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                group()
+            torch.cuda.synchronize()
 
-    run(warm_items)
+        def run_steps(count):
+            for _ in range(count // G):
+                if use_graph:
+                    gr.replay()
+                else:
+                    group()
+        run_w = lambda: run_steps(args.warmup)
+        run_t = lambda: run_steps(args.steps)
+        launch_desc = ("hipGraph of [1 sampler launch + %d steps]" % G) if use_graph else "eager"
+        data_desc = "triples in HBM; batch ids, negatives and plan built ON THE DEVICE inside the timed region"
+    else:
+        # ---- host-built batches + plans pre-staged in HBM (sampler outside the timed region) ----
+        sampler = UniformChunkedSampler(h, r, t, w["n_ent"], w["B"], w["N"], dev, seed=0)
+        pool = max(G, (args.pool // G) * G)
+        plans = sampler.next_plans(pool)
+        batches = plan.upload(plans, dev)
+        for b in batches:
+            eng.workspace_for(b)
+        graphs = {}
+
+        def get_graph(start, count):
+            key = (start, count)
+            if key not in graphs:
+                graphs[key] = eng.capture([batches[(start + k) % pool] for k in range(count)])
+            return graphs[key]
+
+        def schedule(pos, count):
+            items = []
+            while count > 0:
+                seg_off = pos % G
+                n = min(G - seg_off, count)
+                items.append((pos % pool, n))
+                pos += n
+                count -= n
+            return items, pos
+
+        warm_items, pos = schedule(0, args.warmup)
+        timed_items, pos = schedule(pos, args.steps)
+        if use_graph:
+            eng.step(batches[0])
+            torch.cuda.synchronize()
+            eng.reset_parameters()
+            for it in warm_items + timed_items:
+                get_graph(*it)
+            torch.cuda.synchronize()
+
+        def run(items):
+            if use_graph:
+                for it in items:
+                    graphs[it].replay()
+            else:
+                for start, n in items:
+                    for k in range(n):
+                        eng.step(batches[(start + k) % pool])
+        run_w = lambda: run(warm_items)
+        run_t = lambda: run(timed_items)
+        launch_desc = "hipGraph of %d steps" % G if use_graph else "eager"
+        data_desc = "id batches + plan built on the host and pre-staged in HBM, sampler excluded"
+
+    run_w()
     torch.cuda.synchronize()
     eng.loss_accum.zero_()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ev0.record()
-    run(timed_items)
+    run_t()
     ev1.record()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
@@ -279,12 +334,11 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s synthetic FB15k-shaped: n_ent=%d n_rel=%d batch=%d neg=%d dim=%d "
-                               "gamma=%g lr=%g adv=%s rc=%g, full tables in HBM, id batches + plan "
-                               "pre-staged in HBM, sampler excluded" % (
+                               "gamma=%g lr=%g adv=%s rc=%g, full tables in HBM, %s" % (
                                    w["model"], w["n_ent"], w["n_rel"], w["B"], w["N"], w["hidden"],
-                                   w["gamma"], w["lr"], w["adv"], w["reg_coef"]),
+                                   w["gamma"], w["lr"], w["adv"], w["reg_coef"], data_desc),
                    "global_batch": w["B"], "parallelism": "1 GPU",
-                   "launch": "hipGraph of %d steps" % G if use_graph else "eager",
+                   "launch": launch_desc,
                    "neg_kernels": "pairwise" if args.force_pairwise else "auto"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                      "frac": round(achieved / 8000.0, 5), "traffic": measured_traffic(args.workload),
@@ -296,7 +350,7 @@ def main():
     }
     if args.hogwild > 1:
         try:
-            out["hogwild"] = hogwild_measure(w, eng, dev, args.hogwild, K, G, eng.hp.flags)
+            out["hogwild"] = hogwild_measure(w, eng, dev, args.hogwild, K, max(G, 60), eng.hp.flags)
         except Exception as e:
             out["hogwild"] = {"error": repr(e)}
     if not args.no_cpu_baseline:
