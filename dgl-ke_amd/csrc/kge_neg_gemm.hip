@@ -164,7 +164,7 @@ int launch_neg_fwd_gemm(const GemmArgs &a, hipStream_t s) {
 #ifndef BU
 #define BU 4    // macro steps per register buffer
 #endif
-#define GB_MAXK 4096                   // rows of a chunk operand whose pointers / statistics fit in LDS
+#define GB_MAXK 2048                   // rows of a chunk operand whose indices / statistics fit in LDS (32 KB)
 
 struct BwdStage { float w[4]; float4 r[4]; };
 
@@ -237,13 +237,16 @@ __global__ __launch_bounds__(KGE_BLOCK) void neg_bwd_gemm_kernel(GemmArgs a, int
     const int K = isGA ? N : chunk;                      // reduction length
     const int R = isGA ? chunk : N;                      // output rows per chunk
 
-    // ---- workgroup-shared tables in LDS: operand row pointers (GA), row statistics (GN) ----
-    const float **rp = reinterpret_cast<const float **>(smem);          // [K] (GA only)
-    float2 *st = reinterpret_cast<float2 *>(smem);                       // [K] (GN only)
-    if (isGA) {
-        if (a.nidx)
-            for (int k = threadIdx.x; k < K; k += KGE_BLOCK) rp[k] = a.nbase + a.nidx[(int64_t)c * N + k] * (int64_t)D;
-    } else if (otf) {
+    // ---- workgroup-shared tables in LDS ----
+    // rix[k]: row index of reduction element k in the streamed operand (GA: negative row, gathered
+    // through neg_ids or dense; GN: positive row of the chunk).  INDICES, not pointers: a pointer read
+    // back from LDS turns the row loads into flat loads, which count on lgkmcnt and serialise behind
+    // every LDS wait (measured: 48 % of the wavefront time parked in s_waitcnt).
+    int64_t *rix = reinterpret_cast<int64_t *>(smem);                     // [K]
+    float2 *st = reinterpret_cast<float2 *>(smem + 2 * GB_MAXK);          // [K] (GN, fused loss only)
+    for (int k = threadIdx.x; k < K; k += KGE_BLOCK)
+        rix[k] = isGA ? (a.nidx ? a.nidx[(int64_t)c * N + k] : (int64_t)c * N + k) : (int64_t)c * chunk + k;
+    if (!isGA && otf) {
         for (int k = threadIdx.x; k < K; k += KGE_BLOCK) {
             float M, coef;
             row_stats(a, (int64_t)c * chunk + k, tj, M, coef);
@@ -264,9 +267,6 @@ __global__ __launch_bounds__(KGE_BLOCK) void neg_bwd_gemm_kernel(GemmArgs a, int
     const bool vecW = isGA && (N % 4 == 0);
     const float *Wrow = isGA ? Wc + (int64_t)rowc * N : Wc + rowc;
     const int64_t wstride = isGA ? 1 : N;
-    const bool gather = isGA && a.nidx != nullptr;
-    const float *Xc = isGA ? a.nbase + (int64_t)c * N * D : Ac;      // dense operand rows [K, D]
-    const int msteps = (K + 15) / 16;
     // GA: this lane's row statistics; loss terms of the row are summed by the d-tile-0 wavefronts
     float rM = 0.f, rcoef = 0.f;
     if (otf && isGA) row_stats(a, (int64_t)c * chunk + rowc, tj, rM, rcoef);
@@ -279,39 +279,54 @@ __global__ __launch_bounds__(KGE_BLOCK) void neg_bwd_gemm_kernel(GemmArgs a, int
     float wsum = 0.f;                                    // partial row (GA) / column (GN) sum of W
     BwdStage s0[BU], s1[BU];
 
+    // Main loop over FULL macro steps: no per-lane predicates (rows / columns are clamped so every
+    // load is in bounds; garbage in clamped rows only reaches outputs that are never stored), row
+    // addresses = kernel-argument base + LDS index (global loads, vmcnt only).  One predicated tail
+    // step handles K % 16.
+    const int msfull = K >> 4;
+    const float *Xb = (isGA ? a.nbase : a.A) + dc;                 // operand base (global address space)
+    const float *Wq = Wrow + (int64_t)(q * 4) * wstride;
+
 #define BWD_LOAD(ST, MS0)                                                                      \
     _Pragma("unroll") for (int u = 0; u < BU; ++u) {                                           \
-        const int kk = ((MS0) + u) * 16 + q * 4;                                               \
-        if (vecW && kk + 3 < K) {                                                              \
-            const float4 t4 = ldg4(Wrow + kk);                                                 \
-            ST[u].w[0] = t4.x; ST[u].w[1] = t4.y; ST[u].w[2] = t4.z; ST[u].w[3] = t4.w;        \
-        } else {                                                                               \
-            _Pragma("unroll") for (int e = 0; e < 4; ++e)                                      \
-                ST[u].w[e] = (kk + e < K) ? Wrow[(int64_t)(kk + e) * wstride] : 0.f;           \
+        if ((MS0) + u < msfull) {                                                              \
+            const int ms = (MS0) + u;                                                          \
+            int64_t ri[4];                                                                     \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) ri[e] = rix[ms * 16 + q * 4 + e];    \
+            if (vecW) {                                                                        \
+                const float4 t4 = ldg4(Wq + ms * 16);                                          \
+                ST[u].w[0] = t4.x; ST[u].w[1] = t4.y; ST[u].w[2] = t4.z; ST[u].w[3] = t4.w;    \
+            } else {                                                                           \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e)                                  \
+                    ST[u].w[e] = Wq[(int64_t)(ms * 16 + e) * wstride];                         \
+            }                                                                                  \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) ST[u].r[e] = ldg4(Xb + ri[e] * D);   \
         }                                                                                      \
-        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                        \
-            if (kk + e < K) ST[u].r[e] = ldg4((gather ? rp[kk + e] : Xc + (int64_t)(kk + e) * D) + dc); \
-            else ST[u].r[e] = zero4();                                                         \
+    }
+#define BWD_XFORM(ST, MS0)                                                                     \
+    if (otf) {                                                                                 \
+        _Pragma("unroll") for (int u = 0; u < BU; ++u) {                                       \
+            if ((MS0) + u < msfull) {                                                          \
+                const int kk = ((MS0) + u) * 16 + q * 4;                                       \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                \
+                    const float n_ = ST[u].w[e];                                               \
+                    float M_ = rM, cf_ = rcoef;                                                \
+                    if (!isGA) { const float2 s2 = st[kk + e]; M_ = s2.x; cf_ = s2.y; }        \
+                    if (do_loss) {                                                             \
+                        float nl, dnl;                                                         \
+                        criterion(a.lp.genre, n_, a.lp.genre == KGE_LOSS_BCE ? 0.f : -1.f, a.lp.margin, nl, dnl); \
+                        lsum += nl * cf_ * (a.lp.adv ? __expf(n_ * a.lp.adv_temp - M_) : 1.f); \
+                    }                                                                          \
+                    ST[u].w[e] = wgrad<L2>(a.lp, a.gamma, n_, M_, cf_);                        \
+                }                                                                              \
+            }                                                                                  \
         }                                                                                      \
     }
 #define BWD_MMA(ST, MS0)                                                                       \
     _Pragma("unroll") for (int u = 0; u < BU; ++u) {                                           \
-        if ((MS0) + u < msteps) {                                                              \
-            const int kk = ((MS0) + u) * 16 + q * 4;                                           \
+        if ((MS0) + u < msfull) {                                                              \
             _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                    \
-                float wgt = ST[u].w[e];                                                        \
-                if (otf) {                                                                     \
-                    const bool kok = kk + e < K;                                               \
-                    float M_ = rM, cf_ = rcoef;                                                \
-                    if (!isGA) { const float2 s2 = st[min(kk + e, K - 1)]; M_ = s2.x; cf_ = s2.y; } \
-                    if (do_loss && kok && rok) {                                               \
-                        float nl, dnl;                                                         \
-                        criterion(a.lp.genre, wgt, a.lp.genre == KGE_LOSS_BCE ? 0.f : -1.f, a.lp.margin, nl, dnl); \
-                        lsum += nl * cf_ * (a.lp.adv ? __expf(wgt * a.lp.adv_temp - M_) : 1.f); \
-                    }                                                                          \
-                    wgt = kok ? wgrad<L2>(a.lp, a.gamma, wgt, M_, cf_) : 0.f;                  \
-                }                                                                              \
-                wgt = rok ? wgt : 0.f;                                                         \
+                const float wgt = ST[u].w[e];                                                  \
                 wsum += wgt;                                                                   \
                 acc[0] = MFMA16(wgt, ST[u].r[e].x, acc[0]);                                    \
                 acc[1] = MFMA16(wgt, ST[u].r[e].y, acc[1]);                                    \
@@ -322,14 +337,43 @@ __global__ __launch_bounds__(KGE_BLOCK) void neg_bwd_gemm_kernel(GemmArgs a, int
     }
 
     BWD_LOAD(s0, 0);
-    for (int g = 0; g < msteps; g += 2 * BU) {
+    for (int g = 0; g < msfull; g += 2 * BU) {
         BWD_LOAD(s1, g + BU);
+        BWD_XFORM(s0, g);
         BWD_MMA(s0, g);
         BWD_LOAD(s0, g + 2 * BU);
+        BWD_XFORM(s1, g + BU);
         BWD_MMA(s1, g + BU);
     }
 #undef BWD_LOAD
+#undef BWD_XFORM
 #undef BWD_MMA
+    if (K & 15) {   // tail macro step: reduction indices beyond K get zero weight
+        const int kk = msfull * 16 + q * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool kok = kk + e < K;
+            const int kc = min(kk + e, K - 1);
+            float wgt = Wrow[(int64_t)kc * wstride];
+            const float4 xv = ldg4(Xb + rix[kc] * D);
+            if (otf) {
+                float M_ = rM, cf_ = rcoef;
+                if (!isGA) { const float2 s2 = st[kc]; M_ = s2.x; cf_ = s2.y; }
+                if (do_loss && kok) {
+                    float nl, dnl;
+                    criterion(a.lp.genre, wgt, a.lp.genre == KGE_LOSS_BCE ? 0.f : -1.f, a.lp.margin, nl, dnl);
+                    lsum += nl * cf_ * (a.lp.adv ? __expf(wgt * a.lp.adv_temp - M_) : 1.f);
+                }
+                wgt = wgrad<L2>(a.lp, a.gamma, wgt, M_, cf_);
+            }
+            wgt = kok ? wgt : 0.f;
+            wsum += wgt;
+            acc[0] = MFMA16(wgt, xv.x, acc[0]);
+            acc[1] = MFMA16(wgt, xv.y, acc[1]);
+            acc[2] = MFMA16(wgt, xv.z, acc[2]);
+            acc[3] = MFMA16(wgt, xv.w, acc[3]);
+        }
+    }
 
     // lanes with equal (lane&15) hold partial sums of the same W row/column: combine the 4 groups
     wsum += __shfl_xor(wsum, 16, 64);
@@ -384,7 +428,7 @@ int launch_neg_bwd_gemm(const GemmArgs &a, hipStream_t s) {
     const int bpA = (ti * td + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK;   // workgroups per chunk, GA
     const int bpN = (tj * td + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK;
     const int nb = a.C * (bpA + bpN);
-    const size_t sm = (size_t)maxK * 8;
+    const size_t sm = (size_t)GB_MAXK * 16;      // row indices [GB_MAXK] int64 + row statistics [GB_MAXK] float2
     const bool l2 = a.model == KGE_TRANSE_L2, otf = a.W == nullptr;
     const dim3 g(nb), b(KGE_BLOCK);
     if (l2 && otf) hipLaunchKernelGGL((neg_bwd_gemm_kernel<true, true>), g, b, sm, s, a, ti, tj, td, bpA, bpN);
