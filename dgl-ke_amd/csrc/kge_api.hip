@@ -318,8 +318,16 @@ size_t kge_step_workspace_bytes(const kge_hparams *hp, int B, int C, int chunk, 
 
 static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batch *b,
                      const kge_step_out *out, const kge_emit *emit, void *ws, size_t ws_bytes,
-                     void *stream) {
+                     void *stream, const kge_shards *sh = nullptr) {
     if (!hp || !tb || !b || !ws) return fail(KGE_ERR_ARG, "kge_step: null argument");
+    kge::ShardMap em{}, rm{};
+    if (sh) {
+        if (sh->n_shards < 1 || sh->ent_rows_per_shard <= 0 || sh->rel_rows_per_shard <= 0 ||
+            !sh->ent_rows || !sh->ent_state || !sh->rel_rows || !sh->rel_state)
+            return fail(KGE_ERR_ARG, "kge_step_sharded: bad shard map");
+        em = kge::ShardMap{sh->ent_rows, sh->ent_state, sh->ent_rows_per_shard, sh->n_shards};
+        rm = kge::ShardMap{sh->rel_rows, sh->rel_state, sh->rel_rows_per_shard, sh->n_shards};
+    }
     if (int rc = check_model(hp->model, hp->d_e, hp->d_r)) return rc;
     if (b->B <= 0 || b->C <= 0 || b->chunk <= 0 || b->N <= 0 || (int64_t)b->C * b->chunk != b->B)
         return fail(KGE_ERR_ARG, "kge_step: need C*chunk == B (B=%d C=%d chunk=%d)", b->B, b->C, b->chunk);
@@ -328,7 +336,7 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     if (hp->pairwise && hp->adv) return fail(KGE_ERR_ARG, "loss cannot be pairwise and adversarial sampled");
     if (hp->pairwise && hp->loss_genre != KGE_LOSS_LOGISTIC && hp->loss_genre != KGE_LOSS_HINGE)
         return fail(KGE_ERR_ARG, "this loss cannot be applied to pairwise loss function");
-    if (!tb->ent || !tb->ent_state || !tb->rel || !tb->rel_state || !b->h_gid || !b->t_gid ||
+    if ((!sh && (!tb->ent || !tb->ent_state || !tb->rel || !tb->rel_state)) || !b->h_gid || !b->t_gid ||
         !b->rel_ids || !b->neg_ids || !b->ue_id || !b->ue_pos_ptr || !b->ue_pos_adj ||
         !b->ue_neg_ptr || !b->ue_neg_slot || !b->ur_id || !b->ur_ptr || !b->ur_edge || !b->ue_rec ||
         !b->ur_rec)
@@ -367,7 +375,7 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     float *acc = out ? out->loss_accum : nullptr;
     const LossParams lp{hp->loss_genre, hp->adv, hp->pairwise, hp->adv_temp, hp->margin};
 
-    const EdgeSrc src{tb->ent, b->h_gid, tb->ent, b->t_gid, tb->rel, b->rel_ids};
+    const EdgeSrc src{tb->ent, b->h_gid, tb->ent, b->t_gid, tb->rel, b->rel_ids, em, rm};
     const float rot_div = rot_div_of(hp->emb_init);
 
     // 1. gather + positive score + pos-side vectors (+ positive-loss part, + P rows for TransE)
@@ -376,7 +384,9 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     ef.gamma = hp->gamma; ef.rot_div = rot_div;
     ef.pos_score = P; ef.A = A;
     ef.nbase = tb->ent; ef.nidx = b->neg_ids; ef.n_neg = CN;
-    const bool dense_neg = !gemm || (hp->flags & KGE_FLAG_DENSE_NEG);
+    // sharded tables: the scoring kernels re-read the negative rows many times - they must come from
+    // the dense local copy edge_fwd makes, never from the (remote, uncached) table rows
+    const bool dense_neg = !gemm || sh || (hp->flags & KGE_FLAG_DENSE_NEG);
     ef.Bn = dense_neg ? Bn : nullptr;                 // the pairwise kernels read a dense copy
     const bool l2g = gemm && is_l2;                   // GEMM form of the L2 distance needs |a|^2, |b|^2
     ef.asq = l2g ? asq : nullptr; ef.bsq = l2g ? bsq : nullptr;
@@ -457,6 +467,7 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     ua.model_d_e = d_e; ua.d_r = d_r; ua.UE = b->UE; ua.UR = b->UR; ua.reg_norm = hp->reg_norm;
     ua.lr = hp->lr; ua.eps = hp->eps; ua.reg_coef = reg ? hp->reg_coef : 0.f;
     ua.ent = tb->ent; ua.ent_state = tb->ent_state; ua.rel = tb->rel; ua.rel_state = tb->rel_state;
+    ua.em = em; ua.rm = rm;
     ua.ue_id = b->ue_id; ua.ue_pos_ptr = b->ue_pos_ptr; ua.ue_pos_adj = b->ue_pos_adj;
     ua.ue_neg_ptr = b->ue_neg_ptr; ua.ue_neg_slot = b->ue_neg_slot;
     ua.ur_id = b->ur_id; ua.ur_ptr = b->ur_ptr; ua.ur_edge = b->ur_edge;
@@ -504,6 +515,54 @@ int kge_step_grads(const kge_hparams *hp, const kge_tables *tb, const kge_batch 
     if ((emit->gr == nullptr) != (emit->gsr == nullptr))
         return fail(KGE_ERR_ARG, "kge_step_grads: gr and gsr must be given together");
     return step_impl(hp, tb, b, out, emit, ws, ws_bytes, stream);
+}
+
+int kge_step_sharded(const kge_hparams *hp, const kge_shards *sh, const kge_batch *b,
+                     const kge_step_out *out, void *ws, size_t ws_bytes, void *stream) {
+    if (!sh) return fail(KGE_ERR_ARG, "kge_step_sharded: null shard map");
+    if (hp && (hp->d_e % 4 || hp->d_r % 4 || hp->d_e > 1024 || hp->d_r > 1024))
+        return fail(KGE_ERR_ARG, "kge_step_sharded: row widths must be multiples of 4 and <= 1024 floats");
+    kge_tables tb{};
+    tb.n_ent = sh->n_ent; tb.n_rel = sh->n_rel;
+    return step_impl(hp, &tb, b, out, nullptr, ws, ws_bytes, stream, sh);
+}
+
+int kge_gather_rows_sharded(float *const *shard_rows, int n_shards, int64_t rows_per_shard, int dim,
+                            const int64_t *idx, int64_t n_idx, float *out, void *stream) {
+    if (!shard_rows || n_shards < 1 || rows_per_shard <= 0 || dim <= 0 || n_idx < 0 || (n_idx && (!idx || !out)))
+        return fail(KGE_ERR_ARG, "kge_gather_rows_sharded: bad argument");
+    KGE_TRY(launch_gather_rows_sharded(shard_rows, n_shards, rows_per_shard, dim, idx, n_idx, out, (hipStream_t)stream));
+    return KGE_OK;
+}
+
+int kge_ipc_export(const void *dev_ptr, void *handle64, int64_t *offset) {
+    static_assert(sizeof(hipIpcMemHandle_t) == KGE_IPC_HANDLE_BYTES, "hipIpcMemHandle_t is 64 bytes");
+    if (!dev_ptr || !handle64 || !offset) return fail(KGE_ERR_ARG, "kge_ipc_export: null argument");
+    hipDeviceptr_t base = nullptr; size_t size = 0;
+    hipError_t e = hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)dev_ptr);
+    if (e != hipSuccess) return fail(KGE_ERR_LAUNCH, "hipMemGetAddressRange: %s", hipGetErrorString(e));
+    hipIpcMemHandle_t h;
+    e = hipIpcGetMemHandle(&h, base);
+    if (e != hipSuccess) return fail(KGE_ERR_LAUNCH, "hipIpcGetMemHandle: %s", hipGetErrorString(e));
+    memcpy(handle64, &h, sizeof(h));
+    *offset = (int64_t)((const char *)dev_ptr - (const char *)base);
+    return KGE_OK;
+}
+
+int kge_ipc_open(const void *handle64, void **base) {
+    if (!handle64 || !base) return fail(KGE_ERR_ARG, "kge_ipc_open: null argument");
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle64, sizeof(h));
+    hipError_t e = hipIpcOpenMemHandle(base, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) return fail(KGE_ERR_LAUNCH, "hipIpcOpenMemHandle: %s", hipGetErrorString(e));
+    return KGE_OK;
+}
+
+int kge_ipc_close(void *base) {
+    if (!base) return KGE_OK;
+    hipError_t e = hipIpcCloseMemHandle(base);
+    if (e != hipSuccess) return fail(KGE_ERR_LAUNCH, "hipIpcCloseMemHandle: %s", hipGetErrorString(e));
+    return KGE_OK;
 }
 
 }  // extern "C"

@@ -32,6 +32,33 @@ __device__ __forceinline__ const float *row_ptr(const float *base, const int64_t
     return base + r * (int64_t)ld;
 }
 
+// Range-sharded table mapped peer-to-peer over xGMI (sharded training, kge_step_sharded): row `id`
+// lives in shard id / per at local row id % per; `rows` / `state` are DEVICE arrays of the n shard
+// bases as mapped into THIS process (own shard: the local allocation, peers: hipIpcOpenMemHandle).
+// n == 0 means "one local table" and every helper degenerates to base + id * ld.
+struct ShardMap {
+    float *const *rows;
+    float *const *state;
+    int64_t per;
+    int n;
+};
+__device__ __forceinline__ float *shard_row(const ShardMap &m, float *base, int64_t id, int ld) {
+    if (m.n == 0) return base + id * (int64_t)ld;
+    const int64_t o = id / m.per;
+    return m.rows[o] + (id - o * m.per) * (int64_t)ld;
+}
+__device__ __forceinline__ float *shard_state(const ShardMap &m, float *base, int64_t id) {
+    if (m.n == 0) return base + id;
+    const int64_t o = id / m.per;
+    return m.state[o] + (id - o * m.per);
+}
+// row pointer through an id list into a (possibly sharded) table
+__device__ __forceinline__ const float *table_row(const ShardMap &m, const float *base, const int64_t *idx,
+                                                  int64_t i, int ld) {
+    const int64_t r = idx ? idx[i] : i;
+    return shard_row(m, const_cast<float *>(base), r, ld);
+}
+
 // V-wide load/store (V = 4: one 16-byte access; V = 1: scalar)
 template <int V> struct Pack { float v[V]; };
 template <int V> __device__ __forceinline__ Pack<V> ld(const float *p);
@@ -142,6 +169,7 @@ struct EdgeSrc {           // where the rows of one positive edge come from
     const float *hbase; const int64_t *hidx;   // head rows  hbase + (hidx? hidx[i] : i)*d_e
     const float *tbase; const int64_t *tidx;   // tail rows
     const float *rbase; const int64_t *ridx;   // relation rows, ld = d_r
+    kge::ShardMap em, rm;                      // entity / relation table sharding (n = 0: local tables)
 };
 
 struct LossParams {                 // LossGenerator configuration (loss.py:41-61)
@@ -210,6 +238,7 @@ struct UpdateArgs {
     int model_d_e, d_r, UE, UR, reg_norm;
     float lr, eps, reg_coef;
     float *ent, *ent_state, *rel, *rel_state;
+    kge::ShardMap em, rm;            // sharded tables (n = 0: ent / rel above are the whole tables)
     const int64_t *ue_id; const int32_t *ue_pos_ptr, *ue_pos_adj, *ue_neg_ptr, *ue_neg_slot;
     const int64_t *ur_id; const int32_t *ur_ptr, *ur_edge;
     const int32_t *ue_rec, *ur_rec;  // [UE][8], [UR][8] packed plan records (see kge_batch)
@@ -238,6 +267,8 @@ struct FinalizeArgs {
 
 int launch_gather_rows(const float *table, int dim, const int64_t *idx, int64_t n, float *out,
                        hipStream_t s);
+int launch_gather_rows_sharded(float *const *shard_rows, int n_shards, int64_t per, int dim,
+                               const int64_t *idx, int64_t n, float *out, hipStream_t s);
 int launch_edge_fwd(const EdgeFwdArgs &a, hipStream_t s);
 int launch_edge_bwd(const EdgeBwdArgs &a, hipStream_t s);
 int launch_loss(const LossArgs &a, hipStream_t s);

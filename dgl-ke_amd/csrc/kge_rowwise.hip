@@ -58,6 +58,30 @@ int launch_gather_rows(const float *table, int dim, const int64_t *idx, int64_t 
     return check_launch();
 }
 
+template <int V>
+__global__ __launch_bounds__(KGE_BLOCK) void gather_sharded_kernel(ShardMap m, int dim,
+                                                                   const int64_t *__restrict__ idx,
+                                                                   int64_t n, float *__restrict__ out) {
+    const int64_t k = WAVE_ID();
+    if (k >= n) return;
+    const int lane = LANE();
+    const float *src = shard_row(m, nullptr, idx[k], dim);
+    float *dst = out + k * (int64_t)dim;
+    for (int it = lane; it < dim / V; it += 64) st<V>(dst + it * V, ld<V>(src + it * V));
+}
+
+int launch_gather_rows_sharded(float *const *shard_rows, int n_shards, int64_t per, int dim,
+                               const int64_t *idx, int64_t n, float *out, hipStream_t s) {
+    if (n == 0) return KGE_OK;
+    const int nb = blocks_for_waves(n);
+    const ShardMap m{shard_rows, nullptr, per, n_shards};
+    if (dim % 4 == 0)
+        hipLaunchKernelGGL(gather_sharded_kernel<4>, dim3(nb), dim3(KGE_BLOCK), 0, s, m, dim, idx, n, out);
+    else
+        hipLaunchKernelGGL(gather_sharded_kernel<1>, dim3(nb), dim3(KGE_BLOCK), 0, s, m, dim, idx, n, out);
+    return check_launch();
+}
+
 // ------------------------------------------------------------------------------------------
 // edge forward: positive score p_i, pos-side vector a_i (and |a_i|^2), |neg_j|^2
 // ------------------------------------------------------------------------------------------
@@ -67,9 +91,9 @@ __global__ __launch_bounds__(KGE_BLOCK) void edge_fwd_kernel(EdgeFwdArgs a) {
     const int lane = LANE();
     if (w < a.B) {
         const int64_t i = w;
-        const float *h = row_ptr(a.src.hbase, a.src.hidx, i, a.d_e);
-        const float *t = row_ptr(a.src.tbase, a.src.tidx, i, a.d_e);
-        const float *r = row_ptr(a.src.rbase, a.src.ridx, i, a.d_r);
+        const float *h = table_row(a.src.em, a.src.hbase, a.src.hidx, i, a.d_e);
+        const float *t = table_row(a.src.em, a.src.tbase, a.src.tidx, i, a.d_e);
+        const float *r = table_row(a.src.rm, a.src.rbase, a.src.ridx, i, a.d_r);
         float *A = a.A ? a.A + i * (int64_t)a.d_e : nullptr;
         float ps = 0.f, as = 0.f;
         if constexpr (!is_complex_model(MODEL)) {
@@ -186,7 +210,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void edge_fwd_kernel(EdgeFwdArgs a) {
     } else if (w < (int64_t)a.B + a.n_neg) {
         // negative row job: dense copy for the GEMM / pairwise kernels and |b|^2
         const int64_t j = w - a.B;
-        const float *x = row_ptr(a.nbase, a.nidx, j, a.d_e);
+        const float *x = table_row(a.src.em, a.nbase, a.nidx, j, a.d_e);
         float *cp = a.Bn ? a.Bn + j * (int64_t)a.d_e : nullptr;
         float s = 0.f;
         for (int it = lane; it < a.d_e / V; it += 64) {
@@ -240,9 +264,9 @@ __global__ __launch_bounds__(KGE_BLOCK) void edge_bwd_kernel(EdgeBwdArgs a) {
     const int64_t i = WAVE_ID();
     if (i >= a.B) return;
     const int lane = LANE();
-    const float *h = row_ptr(a.src.hbase, a.src.hidx, i, a.d_e);
-    const float *t = row_ptr(a.src.tbase, a.src.tidx, i, a.d_e);
-    const float *r = row_ptr(a.src.rbase, a.src.ridx, i, a.d_r);
+    const float *h = table_row(a.src.em, a.src.hbase, a.src.hidx, i, a.d_e);
+    const float *t = table_row(a.src.em, a.src.tbase, a.src.tidx, i, a.d_e);
+    const float *r = table_row(a.src.rm, a.src.rbase, a.src.ridx, i, a.d_r);
     const float dp = a.dpos ? a.dpos[i] : 0.f;
     const float *ga = a.GA ? a.GA + i * (int64_t)a.d_e : nullptr;
     float *GH = a.GH ? a.GH + i * (int64_t)a.d_e : nullptr;
@@ -655,7 +679,8 @@ __global__ __launch_bounds__(KGE_BLOCK) void update_kernel(UpdateArgs a, int nb_
         if (u >= (a.counts_dev ? a.counts_dev[0] : a.UE)) return;
         const int d = a.model_d_e;
         const int64_t id = a.ue_id[u];
-        float *row = a.ent + id * (int64_t)d;
+        float *row = shard_row(a.em, a.ent, id, d);
+        float *srow = shard_state(a.em, a.ent_state, id);
         const int p0 = a.ue_pos_ptr[u], p1 = a.ue_pos_ptr[u + 1];
         const int n0 = a.ue_neg_ptr[u], n1 = a.ue_neg_ptr[u + 1];
         const bool has_pos = p1 > p0, has_neg = n1 > n0;
@@ -691,7 +716,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void update_kernel(UpdateArgs a, int nb_
         }
         s0 = wave_sum(s0) / (float)d;
         s1 = wave_sum(s1) / (float)d;
-        const float st0 = a.ent_state[id];
+        const float st0 = *srow;
         const float sA = has_pos ? st0 + s0 : st0;
         const float sB = has_neg ? sA + s1 : sA;
         const float std0 = sqrtf(sA) + a.eps, std1 = sqrtf(sB) + a.eps;
@@ -727,7 +752,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void update_kernel(UpdateArgs a, int nb_
             if (a.g1) st<V>(a.g1 + u * (int64_t)a.ld_e + off, g1);
         }
         if (lane == 0) {
-            if (!a.emit_ent) a.ent_state[id] = sB;
+            if (!a.emit_ent) *srow = sB;
             if (a.gs0) a.gs0[u * (int64_t)a.ld_gs_e] = has_pos ? s0 : 0.f;
             if (a.gs1) a.gs1[u * (int64_t)a.ld_gs_e] = has_neg ? s1 : 0.f;
         }
@@ -744,7 +769,8 @@ __global__ __launch_bounds__(KGE_BLOCK) void update_kernel(UpdateArgs a, int nb_
         if (u >= (a.counts_dev ? a.counts_dev[1] : a.UR)) return;
         const int d = a.d_r;
         const int64_t id = a.ur_id[u];
-        float *row = a.rel + id * (int64_t)d;
+        float *row = shard_row(a.rm, a.rel, id, d);
+        float *srow = shard_state(a.rm, a.rel_state, id);
         const int e0 = a.ur_ptr[u], e1 = a.ur_ptr[u + 1];
         const int nit = d / V;
         float ss = 0.f, rv = 0.f;
@@ -762,7 +788,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void update_kernel(UpdateArgs a, int nb_
             }
         }
         ss = wave_sum(ss) / (float)d;
-        const float sN = a.rel_state[id] + ss;
+        const float sN = *srow + ss;
         const float sd = sqrtf(sN) + a.eps;
         for (int it = lane; it < nit; it += 64) {
             const int off = it * V;
@@ -780,7 +806,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void update_kernel(UpdateArgs a, int nb_
             if (a.gr) st<V>(a.gr + u * (int64_t)a.ld_r + off, gsum);
         }
         if (lane == 0) {
-            if (!a.emit_rel) a.rel_state[id] = sN;
+            if (!a.emit_rel) *srow = sN;
             if (a.gsr) a.gsr[u * (int64_t)a.ld_gs_r] = ss;
             if (a.rid) { a.rid[u * (int64_t)a.ld_r] = (int32_t)(id & 0xFFFFFFFF); a.rid[u * (int64_t)a.ld_r + 1] = (int32_t)(id >> 32); }
         }
@@ -812,7 +838,8 @@ __global__ __launch_bounds__(KGE_BLOCK) void update_kernel_reg(UpdateArgs a, int
         const int4 r1 = reinterpret_cast<const int4 *>(a.ue_rec)[2 * u + 1];
         const int64_t id = (int64_t)(uint32_t)r0.x | ((int64_t)r0.y << 32);
         const int p0 = r0.z, p1 = r0.w, n0 = r1.x, n1 = r1.y, adj0 = r1.z, slot0 = r1.w;
-        float *row = a.ent + id * (int64_t)d;
+        float *row = shard_row(a.em, a.ent, id, d);
+        float *srow = shard_state(a.em, a.ent_state, id);
         const bool has_pos = p1 > p0, has_neg = n1 > n0;
         const int nit = d >> 2;
         // first positive contribution: two source rows (fast path: P and maybe GA; generic: GH|GT)
@@ -823,7 +850,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void update_kernel_reg(UpdateArgs a, int
         const float *pA = !has_pos ? row : (a.transe_fast ? a.P + e0 : (side0 ? a.GT : a.GH) + e0);
         const float *pB = ga0 ? a.GA + e0 : pA;          // aliases pA when unused (same lines, no extra traffic)
         const float *pC = has_neg ? a.GN + (int64_t)slot0 * d : row;
-        const float st0 = a.ent_state[id];
+        const float st0 = *srow;
         Pack<4> x[NIT], g0[NIT], g1[NIT];
         float rv = 0.f, s0 = 0.f, s1 = 0.f;
 #pragma unroll
@@ -923,7 +950,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void update_kernel_reg(UpdateArgs a, int
             }
         }
         if (lane == 0) {
-            if (!a.emit_ent) a.ent_state[id] = sB;
+            if (!a.emit_ent) *srow = sB;
             if (a.gs0) a.gs0[u * (int64_t)a.ld_gs_e] = has_pos ? s0 : 0.f;
             if (a.gs1) a.gs1[u * (int64_t)a.ld_gs_e] = has_neg ? s1 : 0.f;
         }
@@ -943,8 +970,9 @@ __global__ __launch_bounds__(KGE_BLOCK) void update_kernel_reg(UpdateArgs a, int
         const int4 r1 = reinterpret_cast<const int4 *>(a.ur_rec)[2 * u + 1];
         const int64_t id = (int64_t)(uint32_t)r0.x | ((int64_t)r0.y << 32);
         const int e0 = r0.z, e1 = r0.w, edge0 = r1.x;
-        float *row = a.rel + id * (int64_t)d;
-        const float st0 = a.rel_state[id];
+        float *row = shard_row(a.rm, a.rel, id, d);
+        float *srow = shard_state(a.rm, a.rel_state, id);
+        const float st0 = *srow;
         const int nit = d >> 2;
         const float sgr = a.neg_head ? -1.f : 1.f;       // TransE fast path: GR = -P +/- GA + regulariser
         const int64_t eo0 = (int64_t)edge0 * d;
@@ -1010,7 +1038,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void update_kernel_reg(UpdateArgs a, int
             }
         }
         if (lane == 0) {
-            if (!a.emit_rel) a.rel_state[id] = sN;
+            if (!a.emit_rel) *srow = sN;
             if (a.gsr) a.gsr[u * (int64_t)a.ld_gs_r] = ss;
             if (a.rid) { a.rid[u * (int64_t)a.ld_r] = (int32_t)(id & 0xFFFFFFFF); a.rid[u * (int64_t)a.ld_r + 1] = (int32_t)(id >> 32); }
         }

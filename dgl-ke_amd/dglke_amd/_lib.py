@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KGE_LIB") or os.path.join(_HERE, "libkge_hip.so")   # KGE_LIB: A/B builds
 
-KGE_ABI_VERSION = 1
+KGE_ABI_VERSION = 2
 MODEL_IDS = {"TransE_l1": 0, "TransE_l2": 1, "TransE": 1, "DistMult": 2, "ComplEx": 3, "RotatE": 4}
 LOSS_IDS = {"Logsigmoid": 0, "Logistic": 1, "Hinge": 2, "BCE": 3}
 FLAG_FORCE_PAIRWISE = 1
@@ -59,6 +59,14 @@ class KgeEmit(C.Structure):
                 ("ld_e", c_i32), ("ld_r", c_i32), ("rid", c_p)]
 
 
+class KgeShards(C.Structure):
+    _fields_ = [("n_shards", c_i32), ("reserved", c_i32), ("ent_rows_per_shard", c_i64),
+                ("rel_rows_per_shard", c_i64), ("ent_rows", c_p), ("ent_state", c_p),
+                ("rel_rows", c_p), ("rel_state", c_p), ("n_ent", c_i64), ("n_rel", c_i64)]
+
+
+IPC_HANDLE_BYTES = 64
+
 _SIGNATURES = {
     "kge_abi_version": (c_i, []),
     "kge_last_error": (C.c_char_p, []),
@@ -86,6 +94,12 @@ _SIGNATURES = {
                              C.POINTER(KgeStepOut), c_p, c_sz, c_p]),
     "kge_step_grads": (c_i, [C.POINTER(KgeHParams), C.POINTER(KgeTables), C.POINTER(KgeBatch),
                              C.POINTER(KgeStepOut), C.POINTER(KgeEmit), c_p, c_sz, c_p]),
+    "kge_step_sharded": (c_i, [C.POINTER(KgeHParams), C.POINTER(KgeShards), C.POINTER(KgeBatch),
+                               C.POINTER(KgeStepOut), c_p, c_sz, c_p]),
+    "kge_gather_rows_sharded": (c_i, [c_p, c_i, c_i64, c_i, c_p, c_i64, c_p, c_p]),
+    "kge_ipc_export": (c_i, [c_p, c_p, C.POINTER(c_i64)]),
+    "kge_ipc_open": (c_i, [c_p, C.POINTER(c_p)]),
+    "kge_ipc_close": (c_i, [c_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES.keys())

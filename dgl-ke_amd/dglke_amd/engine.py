@@ -17,7 +17,7 @@ class StepEngine(object):
                  double_entity_emb=False, double_relation_emb=False, neg_adversarial_sampling=False,
                  adversarial_temperature=1.0, regularization_coef=0.0, regularization_norm=3,
                  loss_genre='Logsigmoid', pairwise=False, margin=1.0, flags=0,
-                 tables=None):
+                 tables=None, shards=None):
         self.device = torch.device(device)
         if self.device.type != 'cuda':
             raise _lib.KgeError("StepEngine needs a CUDA (HIP) device; there is no CPU fallback")
@@ -44,7 +44,14 @@ class StepEngine(object):
         hp.reg_coef = float(regularization_coef)
         hp.eps = 1e-10
         self.hp = hp
-        if tables is None:
+        self.shards = shards           # p2p.ShardedTables: the tables live in the peers' HBM
+        if shards is not None:
+            if (shards.d_e, shards.d_r) != (self.d_e, self.d_r):
+                raise _lib.KgeError("sharded tables have row widths (%d, %d), model needs (%d, %d)"
+                                    % (shards.d_e, shards.d_r, self.d_e, self.d_r))
+            self.ent, self.ent_state = shards.ent(0), shards.ent_state(0)
+            self.rel, self.rel_state = shards.rel(0), shards.rel_state(0)
+        elif tables is None:
             self.ent = torch.empty(n_entities, self.d_e, dtype=torch.float32, device=self.device)
             self.ent_state = torch.zeros(n_entities, dtype=torch.float32, device=self.device)
             self.rel = torch.empty(n_relations, self.d_r, dtype=torch.float32, device=self.device)
@@ -105,7 +112,12 @@ class StepEngine(object):
         if want:
             for k, t in want.items():
                 setattr(out, k, ptr(t))
-        if emit is None:
+        if self.shards is not None:
+            if emit is not None:
+                raise _lib.KgeError("gradient emission and peer-to-peer sharding are different multi-GPU modes")
+            check(lib().kge_step_sharded(C.byref(self.hp), C.byref(self.shards.c), C.byref(batch.c),
+                                         C.byref(out), ptr(ws), self._ws_bytes, stream_ptr()))
+        elif emit is None:
             check(lib().kge_step_fused(C.byref(self.hp), C.byref(self.tb), C.byref(batch.c),
                                        C.byref(out), ptr(ws), self._ws_bytes, stream_ptr()))
         else:

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KGE_ABI_VERSION 1
+#define KGE_ABI_VERSION 2
 
 /* score functions (models/general_models.py:248-268 model_name strings) */
 enum kge_model {
@@ -233,6 +233,38 @@ int kge_step_grads(const kge_hparams *hp, const kge_tables *tb, const kge_batch 
 int kge_adagrad_apply_rows(float *table, float *state_sum, int64_t n_rows, int dim,
                            const int64_t *idx, const float *g, const float *gs, int64_t n,
                            float lr, float eps, void *stream);
+
+/* ---- peer-to-peer sharded step (xGMI direct; the Hogwild multi-GPU mode) ----
+ * The reference's multi-GPU trainer keeps ONE entity table in shared host memory and lets every
+ * trainer process gather from it and update it without locks (train.py:298-317 --num_proc,
+ * tensor_models.py:233 share_memory, :304-362 update; relation table likewise unless
+ * --rel_part).  Here the shared table is the union of the 8 GPUs' HBM: rank k owns the rows
+ * [k*rows_per_shard, (k+1)*rows_per_shard) of both tables (+ Adagrad state), every rank maps all
+ * peers' shards into its address space (kge_ipc_export / kge_ipc_open = hipIpc handles) and
+ * kge_step_sharded runs the SAME kernels as kge_step_fused with row addresses resolved through
+ * the shard map: remote rows are read and read-modify-written directly over xGMI, no collective
+ * and no host work in the step.  Within a rank the update is still owner-computes and
+ * deterministic; across ranks it is Hogwild, exactly like the reference's shared table.
+ * The four pointer arrays are DEVICE arrays [n_shards] of bases valid in the calling process. */
+typedef struct kge_shards {
+    int32_t n_shards, reserved;
+    int64_t ent_rows_per_shard, rel_rows_per_shard;
+    float *const *ent_rows;  float *const *ent_state;
+    float *const *rel_rows;  float *const *rel_state;
+    int64_t n_ent, n_rel;    /* global row counts (ids in the batch are global) */
+} kge_shards;
+int kge_step_sharded(const kge_hparams *hp, const kge_shards *sh, const kge_batch *b,
+                     const kge_step_out *out, void *ws, size_t ws_bytes, void *stream);
+/* rows of a sharded table by global id (evaluation / checkpoint helper): out[k,:] = row idx[k] */
+int kge_gather_rows_sharded(float *const *shard_rows, int n_shards, int64_t rows_per_shard, int dim,
+                            const int64_t *idx, int64_t n_idx, float *out, void *stream);
+/* hipIpc plumbing for the shard map.  export: handle64 = 64-byte hipIpcMemHandle_t of the
+ * ALLOCATION that contains dev_ptr, *offset = dev_ptr - allocation base.  open: maps a peer's
+ * allocation into this process (current device) and returns its base; close unmaps it. */
+#define KGE_IPC_HANDLE_BYTES 64
+int kge_ipc_export(const void *dev_ptr, void *handle64, int64_t *offset);
+int kge_ipc_open(const void *handle64, void **base);
+int kge_ipc_close(void *base);
 
 /* ---- on-device sampler + plan builder (replaces the DGL EdgeSampler wrappers of
  * dataloader/sampler.py:376-419, 823-876 and the host plan of dglke_amd/plan.py) ----
