@@ -1,11 +1,20 @@
 """bench_dist.py - N>1 leg of bench.py: weak-scaled, one process per GPU (torch.distributed, backend
-nccl = RCCL), entity table range-sharded across the ranks (dglke_amd/dist.py).
+nccl = RCCL), entity AND relation tables range-sharded over the ranks' HBM.
 
-Per-GPU work is the SAME step as the N=1 bench (TransE_l2, batch 1000, neg 200, dim 400, -adv) but
-on a Freebase-sized synthetic id space (86 054 151 entities, 14 824 relations -
-examples/README.md:11 of the reference), which is what the entity sharding is for: the table is
-137.7 GB, each rank holds 1/N of it in HBM and pulls/pushes the rows of its batch over xGMI
-all-to-all.  `--workload rotate_freebase` selects BASELINE.json configs[4] (RotatE, D_e = 800).
+Per-GPU work is the SAME step as the N=1 bench (TransE_l2, batch 1000, neg 200, dim 400, -adv; batch
+ids, negatives and plan built on the device inside the timed region) but on a Freebase-sized
+synthetic id space (86 054 151 entities, 14 824 relations - examples/README.md:11 of the
+reference), which is what the sharding is for: the entity table is 137.7 GB, each rank holds 1/N.
+`--workload rotate_freebase` selects BASELINE.json configs[4] (RotatE, D_e = 800).
+
+Two multi-GPU modes (KGE_DIST_MODE):
+  p2p (default)  the shared-table Hogwild mode of the reference's multi-GPU trainer with the shared
+                 table living in the union of the GPUs' HBM: every rank maps all peer shards
+                 (hipIpc) and kge_step_sharded reads / updates remote rows directly over xGMI.  No
+                 collective and no host work per step; [1 sampler launch + G steps] per hipGraph.
+  a2a            the parameter-server semantics (pull -> compute -> push, owner applies) as RCCL
+                 all-to-all collectives (dglke_amd/dist.py).  Also the automatic fall-back when the
+                 peer mappings cannot be established.
 value = (steps x batch x N) / max-over-ranks wall time.
 """
 import json
@@ -27,25 +36,73 @@ DIST_WORKLOADS = {
 }
 
 
-def main(args, world, rank, local_rank):
-    import __graft_entry__
-    __graft_entry__.build()      # serialised by a file lock; a no-op when the .so is current
-    from dglke_amd import _lib, plan
+def _p2p_setup(args, world, rank, dev, w, n_ent, d_e, d_r, emb_init):
+    """shared tables over the peers' HBM + on-device sampler + one hipGraph per G steps."""
+    import math
+    from dglke_amd import p2p
+    from dglke_amd.dataloader import DeviceSampler
+    from dglke_amd.engine import StepEngine
+    tabs = p2p.ShardedTables(n_ent, w["n_rel"], d_e, d_r, dev, world, rank)
+    if not tabs.probe():
+        raise RuntimeError("peer mappings do not reach the other GPUs' memory")
+    tabs.init_uniform(emb_init, 1234)
+    eng = StepEngine(w["model"], n_ent, w["n_rel"], w["hidden"], w["gamma"], w["lr"], dev, w["de"], w["dr"],
+                     w["adv"], w["adv_temp"], w["reg_coef"], w["reg_norm"], shards=tabs)
+    # this rank's edge shard (reference: RandomPartition of the training triples, sampler.py:256-290):
+    # synthetic uniform triples over the GLOBAL id space, generated in HBM
+    n_train = int(os.environ.get("KGE_DIST_TRIPLES", min(338586276 // world, 48_000_000)))
+    g = torch.Generator(device=dev)
+    g.manual_seed(777 + rank)
+    H = torch.randint(0, n_ent, (n_train,), device=dev, generator=g)
+    T = torch.randint(0, n_ent, (n_train,), device=dev, generator=g)
+    R = torch.randint(0, w["n_rel"], (n_train,), device=dev, generator=g)
+    G = math.gcd(math.gcd(args.steps, args.warmup if args.warmup else args.steps), 120)
+    if G < 2 or G % 2:
+        G = 2 if (args.steps % 2 == 0 and args.warmup % 2 == 0) else 0
+    if G == 0:
+        raise RuntimeError("odd step counts: the device sampler needs an even group size")
+    smp = DeviceSampler(H, R, T, n_ent, w["B"], w["N"], dev, n_slots=G, seed=rank + 1)
+    dbs = smp.sample()
+    eng.workspace_for(dbs[0])
+    for b in dbs:                       # eager warm-up of every kernel before capture
+        eng.step(b)
+    torch.cuda.synchronize()
+
+    def group():
+        for b in smp.sample():
+            eng.step(b)
+    gr = None
+    if not args.no_graph:
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            group()
+        torch.cuda.synchronize()
+
+    def run(count):
+        for _ in range(count // G):
+            if gr is not None:
+                gr.replay()
+            else:
+                group()
+    C = w["B"] // w["N"]
+    # traced rows per step for the byte accounting: count them on one sampled batch
+    a_ = smp.slot_arrays(0)
+    ue = int(np.unique(np.concatenate([a_["h_gid"], a_["t_gid"], a_["neg_ids"]])).shape[0])
+    u_pos = int(np.unique(np.concatenate([a_["h_gid"], a_["t_gid"]])).shape[0])
+    rows = dict(UE=ue, R_e=u_pos + C * w["N"], B=w["B"])
+    desc = ("tables sharded over the GPUs' HBM and mapped peer-to-peer (hipIpc): remote rows read and "
+            "updated directly over xGMI, Hogwild across ranks (reference --num_proc shared-table semantics), "
+            "no collective in the step; %s; sampling + plan on the device inside the timed region"
+            % (("hipGraph of [1 sampler launch + %d steps]" % G) if gr is not None else "eager launches"))
+    return eng, run, rows, desc, tabs
+
+
+def _a2a_setup(args, world, rank, dev, w, n_ent, d_e, emb_init):
+    """parameter-server semantics over RCCL all-to-all (dglke_amd/dist.py)."""
+    from dglke_amd import plan
     from dglke_amd import dist as kd
     from dglke_amd.engine import StepEngine
-
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if not dist.is_initialized():
-        if "MASTER_ADDR" not in os.environ:
-            os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29533"
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    name = args.workload if args.workload in DIST_WORKLOADS else "transe_l2_freebase"
-    w = dict(DIST_WORKLOADS[name])
-    n_ent = int(os.environ.get("KGE_DIST_ENTITIES", w["n_ent"]))
-    d_e = 2 * w["hidden"] if w["de"] else w["hidden"]
     spec = kd.ShardSpec(n_ent, world, rank)
-    emb_init = (w["gamma"] + 2.0) / w["hidden"]
     torch.manual_seed(1234 + rank)
     ent = torch.empty(spec.n_local, d_e, dtype=torch.float32, device=dev).uniform_(-emb_init, emb_init)
     ent_state = torch.zeros(spec.n_local, dtype=torch.float32, device=dev)
@@ -53,7 +110,6 @@ def main(args, world, rank, local_rank):
     eng = StepEngine(w["model"], 1, w["n_rel"], w["hidden"], w["gamma"], w["lr"], dev, w["de"], w["dr"],
                      w["adv"], w["adv_temp"], w["reg_coef"], w["reg_norm"])
     de = kd.DistEngine(eng, spec, ent, ent_state)
-
     # pre-stage a pool of batches: ids (uniform, like the N=1 bench), plans, routes
     pool = max(8, min(args.pool, 64))
     rng = np.random.RandomState(1000 + rank)
@@ -72,44 +128,65 @@ def main(args, world, rank, local_rank):
     for b in batches:
         eng.workspace_for(b)
     de.max_rows = int(max(max(r.UE for r in routes), max(r.n_recv for r in routes)) * 1.25) + 64
-
-    # one eager step (allocates every persistent buffer), then try to record each pool batch's step
-    # - kernels AND RCCL collectives - into a HIP graph; fall back to eager launches if capture fails
-    de.step(batches[0], routes[0])
+    de.step(batches[0], routes[0])     # allocates every persistent buffer
     torch.cuda.synchronize()
-    graphs = None
-    # NOTE: recording the RCCL collectives into a HIP graph hung on the test box (world=1, RCCL
-    # 2.26.6 / ROCm 7.0.2 user-space in torch) - opt-in only until that is understood.
-    if os.environ.get("KGE_DIST_GRAPH") and not args.no_graph:
+    state = {"pos": 0}
+
+    def run(count):
+        for _ in range(count):
+            i = state["pos"] % pool
+            de.step(batches[i], routes[i])
+            state["pos"] += 1
+    rows = dict(UE=float(np.mean([p["UE"] for p in plans])),
+                R_e=float(np.mean([p["U"] + C * w["N"] for p in plans])), B=w["B"])
+    desc = ("entity table range-sharded, relation table replicated, RCCL all-to-all pull/push with owner-side "
+            "Adagrad (parameter-server semantics), eager launches, host-built batches pre-staged")
+    return eng, run, rows, desc
+
+
+def main(args, world, rank, local_rank):
+    import __graft_entry__
+    __graft_entry__.build()      # serialised by a file lock; a no-op when the .so is current
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if not dist.is_initialized():
+        if "MASTER_ADDR" not in os.environ:
+            os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29533"
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    name = args.workload if args.workload in DIST_WORKLOADS else "transe_l2_freebase"
+    w = dict(DIST_WORKLOADS[name])
+    n_ent = int(os.environ.get("KGE_DIST_ENTITIES", w["n_ent"]))
+    d_e = 2 * w["hidden"] if w["de"] else w["hidden"]
+    d_r = 2 * w["hidden"] if w["dr"] else w["hidden"]
+    emb_init = (w["gamma"] + 2.0) / w["hidden"]
+
+    mode = os.environ.get("KGE_DIST_MODE", "p2p")
+    eng = run = rows = desc = tabs = None
+    why = ""
+    if mode == "p2p":
+        ok = 1
         try:
-            side = torch.cuda.Stream(device=dev)
-            graphs = [de.capture(b, r, stream=side) for b, r in zip(batches, routes)]
-            torch.cuda.synchronize()
-        except Exception as e:       # noqa: BLE001 - any capture problem means: run eager
-            if rank == 0:
-                print("graph capture of the sharded step failed (%r): running eager" % (e,), file=sys.stderr)
-            graphs = None
-            de._frozen = False
-    ok = torch.tensor([1 if graphs is not None else 0], device=dev)
-    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-    if int(ok.item()) == 0:
-        graphs = None
+            eng, run, rows, desc, tabs = _p2p_setup(args, world, rank, dev, w, n_ent, d_e, d_r, emb_init)
+        except Exception as e:           # noqa: BLE001 - any set-up problem means: use the collectives
+            ok, why = 0, repr(e)
+            print("[rank %d] peer-to-peer set-up failed (%s): falling back to all-to-all" % (rank, why),
+                  file=sys.stderr)
+        flag = torch.tensor([ok], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            mode, eng, run, tabs = "a2a", None, None, None
+            torch.cuda.empty_cache()
+    if mode != "p2p":
+        eng, run, rows, desc = _a2a_setup(args, world, rank, dev, w, n_ent, d_e, emb_init)
 
-    def run(start, count):
-        for k in range(count):
-            i = (start + k) % pool
-            if graphs is not None:
-                graphs[i].replay()
-            else:
-                de.step(batches[i], routes[i])
-
-    run(0, args.warmup)
+    run(args.warmup)
     torch.cuda.synchronize()
     dist.barrier()
     eng.loss_accum.zero_()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run(args.warmup, args.steps)
+    run(args.steps)
     torch.cuda.synchronize()
     dist.barrier()
     wall = time.perf_counter() - t0
@@ -119,10 +196,10 @@ def main(args, world, rank, local_rank):
     sums = eng.read_loss_sums()
     K = args.steps
     if rank == 0:
-        # algorithmic bytes per rank-step (SURVEY 8d formula on the actual batches)
-        bytes_step = float(np.mean([12.0 * (p["UE"] * d_e + p["B"] * eng.d_r) + 16.0 * (p["UE"] + p["B"])
-                                    for p in plans]))
-        xgmi_step = float(np.mean([3.0 * p["UE"] * d_e * 4 * (world - 1) / world for p in plans]))
+        # algorithmic bytes per rank-step (SURVEY 8d formula on the sampled batches)
+        bytes_step = 12.0 * (rows["R_e"] * d_e + rows["B"] * eng.d_r) + 16.0 * (rows["R_e"] + rows["B"])
+        # rows crossing xGMI per rank-step: every traced row is read once and read-modify-written once
+        xgmi_step = 3.0 * (rows["R_e"] * d_e + rows["B"] * eng.d_r) * 4 * (world - 1) / world
         out = {
             "metric": "positive edges/sec (whole node)",
             "value": round(K * w["B"] * world / wall, 1), "unit": "edges/s",
@@ -131,12 +208,13 @@ def main(args, world, rank, local_rank):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s synthetic Freebase-sized: n_ent=%d n_rel=%d, per-GPU batch=%d neg=%d "
-                                   "dim=%d, entity table range-sharded over %d GPUs (%.1f GB/GPU), relation "
-                                   "table replicated, RCCL all-to-all pull/push, %s"
+                                   "dim=%d over %d GPUs (%.1f GB of entity rows per GPU); %s"
                                    % (w["model"], n_ent, w["n_rel"], w["B"], w["N"], w["hidden"], world,
-                                      spec.n_local * d_e * 4 / 1e9,
-                                      "one hipGraph per step" if graphs is not None else "eager launches"),
-                       "global_batch": w["B"] * world, "parallelism": "entity-shard x%d (all-to-all)" % world},
+                                      (n_ent + world - 1) // world * d_e * 4 / 1e9, desc),
+                       "global_batch": w["B"] * world,
+                       "parallelism": ("shared tables over %d GPUs' HBM, peer-to-peer xGMI (Hogwild)" % world)
+                       if mode == "p2p" else ("entity-shard x%d (RCCL all-to-all)" % world),
+                       "mode": mode, "fallback_reason": why or None},
             "roofline": {"bound": "hbm", "achieved": round(bytes_step * world / (wall / K) / 1e9, 2),
                          "peak": 8000.0 * world, "unit": "GB/s",
                          "frac": round(bytes_step / (wall / K) / 1e9 / 8000.0, 5), "traffic": None,
@@ -145,4 +223,7 @@ def main(args, world, rank, local_rank):
             "mean_loss": round(sums[2] / K, 6),
         }
         print(json.dumps(out))
+    dist.barrier()
+    if tabs is not None:
+        tabs.close()
     dist.destroy_process_group()

@@ -156,9 +156,11 @@ class DeviceSampler(object):
             raise _lib.KgeError("DeviceSampler handles 2*batch + chunks*neg <= 4096 elements per step; "
                                 "use UniformChunkedSampler (host plan) for larger batches")
         self.n_entities = int(n_entities)
-        self.H = th.as_tensor(np.asarray(heads, np.int64)).to(self.dev)
-        self.R = th.as_tensor(np.asarray(rels, np.int64)).to(self.dev)
-        self.T = th.as_tensor(np.asarray(tails, np.int64)).to(self.dev)
+        def put(x):       # triples may already live in HBM (generated or loaded there)
+            if isinstance(x, th.Tensor):
+                return x.to(self.dev, th.int64).contiguous()
+            return th.as_tensor(np.asarray(x, np.int64)).to(self.dev)
+        self.H, self.R, self.T = put(heads), put(rels), put(tails)
         self.n_train = int(self.H.shape[0])
         self.seed = int(seed)
         g = th.Generator(device=self.dev)
