@@ -517,6 +517,65 @@ int kge_step_grads(const kge_hparams *hp, const kge_tables *tb, const kge_batch 
     return step_impl(hp, tb, b, out, emit, ws, ws_bytes, stream);
 }
 
+size_t kge_rank_workspace_bytes(int Eb, int64_t n_cand, int d_e) {
+    size_t n = 0;
+    n += align_up((size_t)Eb * d_e * sizeof(float));        // A
+    n += 2 * align_up((size_t)Eb * sizeof(float));          // asq, P
+    n += align_up((size_t)n_cand * sizeof(float));          // bsq
+    n += align_up((size_t)Eb * (size_t)n_cand * sizeof(float));   // S
+    return n;
+}
+
+int kge_rank_eval(int model, int neg_head, const float *ent, int64_t n_ent, const float *rel,
+                  int64_t n_rel, const int64_t *h, const int64_t *r, const int64_t *t, int64_t E,
+                  int d_e, int d_r, float gamma, float emb_init, const int64_t *cand, int64_t n_cand,
+                  const int64_t *filt_ptr, const int64_t *filt_ids, int Eb, int32_t *ranks,
+                  float *pos_score_out, void *ws, size_t ws_bytes, unsigned flags, void *stream) {
+    if (int rc = check_model(model, d_e, d_r)) return rc;
+    if (!ent || !rel || n_ent <= 0 || n_rel <= 0 || E < 0 || (E && (!h || !r || !t || !ranks)) || !ws || Eb <= 0)
+        return fail(KGE_ERR_ARG, "kge_rank_eval: bad argument");
+    if ((filt_ptr == nullptr) != (filt_ids == nullptr))
+        return fail(KGE_ERR_ARG, "kge_rank_eval: filt_ptr and filt_ids must be given together");
+    const int64_t N = cand ? n_cand : n_ent;
+    if (N <= 0 || N > 0x7fffffff) return fail(KGE_ERR_ARG, "kge_rank_eval: bad candidate count %lld", (long long)N);
+    if (E == 0) return KGE_OK;
+    hipStream_t s = (hipStream_t)stream;
+    Carver cv(ws, ws_bytes);
+    float *A = cv.f((size_t)Eb * d_e), *asq = cv.f(Eb), *P = cv.f(Eb), *bsq = cv.f((size_t)N);
+    float *S = cv.f((size_t)Eb * (size_t)N);
+    if (!cv.ok()) return fail(KGE_ERR_WORKSPACE, "kge_rank_eval: workspace too small (%zu < %zu)", ws_bytes,
+                              kge_rank_workspace_bytes(Eb, N, d_e));
+    const bool gemm = use_mfma(model, d_e, (int)N, flags);
+    const bool l2g = gemm && model == KGE_TRANSE_L2;
+    const float rot_div = rot_div_of(emb_init);
+    if (l2g) {       // |b|^2 of every candidate row, once
+        EdgeFwdArgs nb{};
+        nb.B = 0; nb.d_e = d_e; nb.d_r = d_r; nb.model = model; nb.nbase = ent; nb.nidx = cand; nb.n_neg = (int)N;
+        nb.bsq = bsq;
+        KGE_TRY(launch_edge_fwd(nb, s));
+    }
+    for (int64_t e0 = 0; e0 < E; e0 += Eb) {
+        const int rows = (int)((E - e0) < Eb ? (E - e0) : Eb);
+        EdgeFwdArgs ef{};
+        ef.src = EdgeSrc{ent, h + e0, ent, t + e0, rel, r + e0};
+        ef.B = rows; ef.d_e = d_e; ef.d_r = d_r; ef.neg_head = neg_head; ef.model = model;
+        ef.gamma = gamma; ef.rot_div = rot_div;
+        ef.pos_score = pos_score_out ? pos_score_out + e0 : P; ef.A = A; ef.asq = l2g ? asq : nullptr;
+        KGE_TRY(launch_edge_fwd(ef, s));
+        if (gemm) {
+            GemmArgs g; fill_gemm(g, model, 1, rows, (int)N, d_e, gamma, A, ent, cand);
+            g.S = S; g.asq = asq; g.bsq = bsq;
+            KGE_TRY(launch_neg_fwd_gemm(g, s));
+        } else {
+            NegArgs na; fill_pair(na, model, 1, rows, (int)N, d_e, gamma, A, ent, cand);
+            na.S = S;
+            KGE_TRY(launch_neg_fwd_pair(na, s));
+        }
+        KGE_TRY(launch_rank_count(S, pos_score_out ? pos_score_out + e0 : P, rows, N, filt_ptr, filt_ids, e0, ranks, s));
+    }
+    return KGE_OK;
+}
+
 int kge_step_sharded(const kge_hparams *hp, const kge_shards *sh, const kge_batch *b,
                      const kge_step_out *out, void *ws, size_t ws_bytes, void *stream) {
     if (!sh) return fail(KGE_ERR_ARG, "kge_step_sharded: null shard map");

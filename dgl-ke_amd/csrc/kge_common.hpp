@@ -282,6 +282,8 @@ int launch_adagrad_apply_rows(float *table, float *state, int dim, const int64_t
                               const float *g, const float *gs, int64_t n, float lr, float eps,
                               hipStream_t s);
 int launch_reduce_acc(float *acc, float *out4, int zero_after, hipStream_t s);
+int launch_rank_count(const float *S, const float *P, int rows, int64_t N, const int64_t *filt_ptr,
+                      const int64_t *filt_ids, int64_t e0, int32_t *ranks, hipStream_t s);
 struct GemmArgs {                   // LDS-staged fp32-MFMA negative scoring (kge_neg_gemm.hip)
     int model, C, chunk, N, D;
     float gamma;

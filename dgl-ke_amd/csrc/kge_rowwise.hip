@@ -243,7 +243,7 @@ static int launch_edge_fwd_m(const EdgeFwdArgs &a, hipStream_t s) {
 }
 
 int launch_edge_fwd(const EdgeFwdArgs &a, hipStream_t s) {
-    if (a.B == 0) return KGE_OK;
+    if (a.B == 0 && !((a.bsq || a.Bn) && a.n_neg > 0)) return KGE_OK;
     switch (a.model) {
         case KGE_TRANSE_L1: return launch_edge_fwd_m<KGE_TRANSE_L1>(a, s);
         case KGE_TRANSE_L2: return launch_edge_fwd_m<KGE_TRANSE_L2>(a, s);

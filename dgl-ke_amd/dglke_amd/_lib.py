@@ -97,6 +97,9 @@ _SIGNATURES = {
     "kge_step_sharded": (c_i, [C.POINTER(KgeHParams), C.POINTER(KgeShards), C.POINTER(KgeBatch),
                                C.POINTER(KgeStepOut), c_p, c_sz, c_p]),
     "kge_gather_rows_sharded": (c_i, [c_p, c_i, c_i64, c_i, c_p, c_i64, c_p, c_p]),
+    "kge_rank_workspace_bytes": (c_sz, [c_i, c_i64, c_i]),
+    "kge_rank_eval": (c_i, [c_i, c_i, c_p, c_i64, c_p, c_i64, c_p, c_p, c_p, c_i64, c_i, c_i, c_f, c_f, c_p, c_i64,
+                            c_p, c_p, c_i, c_p, c_p, c_p, c_sz, c_u, c_p]),
     "kge_ipc_export": (c_i, [c_p, c_p, C.POINTER(c_i64)]),
     "kge_ipc_open": (c_i, [c_p, C.POINTER(c_p)]),
     "kge_ipc_close": (c_i, [c_p]),

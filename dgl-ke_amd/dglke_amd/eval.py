@@ -1,0 +1,107 @@
+"""Ranking evaluation on the device (libkge_hip `kge_rank_eval`): the filtered MRR / MR / HITS@k
+protocol of the reference's `test()` loop (train_pytorch.py:199-253) - every test triple against
+ALL entities as corrupted heads and as corrupted tails (EvalSampler, dataloader/sampler.py:514-597,
+`--neg_sample_size_eval -1`), triples that exist in the graph masked out when `eval_filter`
+(general_models.py:463-475) - without the per-triple Python loop of `forward_test`.
+
+The host part (this file) only builds the filter lists once per dataset; scoring and counting run
+in HIP.  There is no CPU path."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def build_filter(known_h, known_r, known_t, test_h, test_r, test_t, neg_head, n_relations=None):
+    """filter lists for `kge_rank_eval`: for test triple i the entities e such that the triple with
+    its head (neg_head) / tail replaced by e is a KNOWN triple (train + valid + test, like the
+    graph the reference's EvalSampler draws `false_neg` from).  Triples sharing (r,t) / (h,r) share
+    one list.  Returns (rng [E,2] int64, ids [M] int64) numpy arrays."""
+    known_h, known_r, known_t = (np.asarray(x, np.int64) for x in (known_h, known_r, known_t))
+    test_h, test_r, test_t = (np.asarray(x, np.int64) for x in (test_h, test_r, test_t))
+    R = int(n_relations if n_relations is not None else max(known_r.max(initial=0), test_r.max(initial=0)) + 1)
+    if neg_head:
+        key, val = known_t * R + known_r, known_h
+        tkey = test_t * R + test_r
+    else:
+        key, val = known_h * R + known_r, known_t
+        tkey = test_h * R + test_r
+    order = np.lexsort((val, key))
+    key, val = key[order], val[order]
+    if key.shape[0]:
+        keep = np.ones(key.shape[0], bool)
+        keep[1:] = (key[1:] != key[:-1]) | (val[1:] != val[:-1])      # unique (key, entity) pairs
+        key, val = key[keep], val[keep]
+    rng = np.stack([np.searchsorted(key, tkey, "left"), np.searchsorted(key, tkey, "right")], 1).astype(np.int64)
+    return rng, val.astype(np.int64)
+
+
+class Ranker(object):
+    """device-resident evaluation of one (ent, rel) table pair."""
+
+    def __init__(self, model_name, ent, rel, gamma, emb_init, batch=1024, flags=0):
+        if not ent.is_cuda:
+            raise _lib.KgeError("Ranker needs CUDA (HIP) tensors; there is no CPU path")
+        self.model = _lib.model_id(model_name)
+        self.ent, self.rel = ent, rel
+        self.gamma, self.emb_init = float(gamma), float(emb_init)
+        self.batch = int(batch)
+        self.flags = int(flags)
+        self._ws = None
+
+    def ranks(self, h, r, t, neg_head, filt=None, cand=None, want_pos_score=False):
+        """int32 [E] ranks of the true triples among the corruptions of the chosen side."""
+        dev = self.ent.device
+
+        def put(x, dt=torch.int64):
+            if x is None:
+                return None
+            if isinstance(x, torch.Tensor):
+                return x.to(dev, dt).contiguous()
+            return torch.as_tensor(np.ascontiguousarray(x)).to(dev, dt)
+        h, r, t, cand = put(h), put(r), put(t), put(cand)
+        E = int(h.shape[0])
+        n_cand = int(cand.shape[0]) if cand is not None else int(self.ent.shape[0])
+        frng = fids = None
+        if filt is not None:
+            frng, fids = put(filt[0].reshape(-1)), put(filt[1])
+            if fids.shape[0] == 0:
+                fids = torch.zeros(1, dtype=torch.int64, device=dev)
+        Eb = max(1, min(self.batch, E))
+        need = _lib.lib().kge_rank_workspace_bytes(Eb, n_cand, self.ent.shape[1])
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need + 4096, dtype=torch.uint8, device=dev)
+        ranks = torch.zeros(E, dtype=torch.int32, device=dev)
+        pos = torch.empty(E, dtype=torch.float32, device=dev) if want_pos_score else None
+        _lib.check(_lib.lib().kge_rank_eval(
+            self.model, int(bool(neg_head)), _lib.ptr(self.ent), self.ent.shape[0], _lib.ptr(self.rel),
+            self.rel.shape[0], _lib.ptr(h), _lib.ptr(r), _lib.ptr(t), E, self.ent.shape[1], self.rel.shape[1],
+            self.gamma, self.emb_init, _lib.ptr(cand), n_cand, _lib.ptr(frng), _lib.ptr(fids), Eb,
+            _lib.ptr(ranks), _lib.ptr(pos), _lib.ptr(self._ws), self._ws.numel(), self.flags, _lib.stream_ptr()))
+        return (ranks, pos) if want_pos_score else ranks
+
+
+def metrics_from_ranks(ranks):
+    """the averages `test()` prints (train_pytorch.py:236-247): MRR, MR, HITS@1/3/10."""
+    rk = ranks.to(torch.float64)
+    return {"MRR": float((1.0 / rk).mean()), "MR": float(rk.mean()),
+            "HITS@1": float((rk <= 1).double().mean()), "HITS@3": float((rk <= 3).double().mean()),
+            "HITS@10": float((rk <= 10).double().mean())}
+
+
+def evaluate(model_name, ent, rel, gamma, emb_init, test, known=None, batch=1024, modes=("head", "tail")):
+    """filtered (known given) or raw ranking metrics over both corruption modes, averaged over all
+    2E rankings like the reference (logs of the head and the tail sampler are concatenated,
+    train_pytorch.py:221-231).  test / known: (h, r, t) triples of int64 arrays."""
+    rk = Ranker(model_name, ent, rel, gamma, emb_init, batch)
+    th_, tr_, tt_ = test
+    allr = []
+    for mode in modes:
+        neg_head = mode == "head"
+        filt = None
+        if known is not None:
+            filt = build_filter(known[0], known[1], known[2], th_, tr_, tt_, neg_head, rel.shape[0])
+        allr.append(rk.ranks(th_, tr_, tt_, neg_head, filt))
+    return metrics_from_ranks(torch.cat(allr))

@@ -234,6 +234,25 @@ int kge_adagrad_apply_rows(float *table, float *state_sum, int64_t n_rows, int d
                            const int64_t *idx, const float *g, const float *gs, int64_t n,
                            float lr, float eps, void *stream);
 
+/* ---- ranking evaluation: KEModel.forward_test (models/general_models.py:436-485) over the
+ * batches an EvalSampler would produce (dataloader/sampler.py:514-597; test loop
+ * train_pytorch.py:199-253), for E test triples at once ----
+ * For triple i the corrupted side (head if neg_head else tail) is replaced by every candidate
+ * (cand == NULL: all n_ent entities, column j = entity j; else the n_cand ids in cand) and
+ *   ranks[i] = 1 + #{j : score(i,j) >= score(i)} - #{j in filt_i : score(i,j) >= score(i)}
+ * filt_i = filt_ids[filt_ptr[2i] .. filt_ptr[2i+1]) are candidate COLUMNS whose corrupted triple
+ * exists in the graph (the reference's bias == -1 mask, :463-475; unique within a list; filt_ptr
+ * is [E][2] begin/end so that triples with the same (h,r) or (r,t) share one list; NULL =
+ * --no_eval_filter, where the true triple itself counts exactly as in the reference).  Scores are
+ * the training kernels' chunked negative scores (one chunk of Eb triples per pass).
+ * pos_score_out (optional) receives the E true-triple scores. */
+size_t kge_rank_workspace_bytes(int Eb, int64_t n_cand, int d_e);
+int kge_rank_eval(int model, int neg_head, const float *ent, int64_t n_ent, const float *rel,
+                  int64_t n_rel, const int64_t *h, const int64_t *r, const int64_t *t, int64_t E,
+                  int d_e, int d_r, float gamma, float emb_init, const int64_t *cand, int64_t n_cand,
+                  const int64_t *filt_ptr, const int64_t *filt_ids, int Eb, int32_t *ranks,
+                  float *pos_score_out, void *ws, size_t ws_bytes, unsigned flags, void *stream);
+
 /* ---- peer-to-peer sharded step (xGMI direct; the Hogwild multi-GPU mode) ----
  * The reference's multi-GPU trainer keeps ONE entity table in shared host memory and lets every
  * trainer process gather from it and update it without locks (train.py:298-317 --num_proc,

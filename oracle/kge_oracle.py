@@ -420,3 +420,39 @@ def synth_batch(rng, n_ent, n_rel, B, N, chunk, step):
     nid, inv = np.unique(np.concatenate([h, t]), return_inverse=True)
     return dict(h=h, t=t, r=r, neg=neg, neg_head=(step % 2 == 0), nid=nid.astype(np.int64),
                 h_local=inv[:B].astype(np.int64), t_local=inv[B:].astype(np.int64), C=C)
+
+
+# ---------------------------------------------------------------------------------------------
+# ranking evaluation: KEModel.forward_test (general_models.py:436-485) for E test triples scored
+# against ALL entities in one chunk (EvalSampler with neg_sample_size_eval = -1 collapses to one
+# chunk, dataloader/sampler.py:492-495); false negatives = corrupted triples that exist in the
+# graph (`bias == -1`, sampler.py:586-587; general_models.py:463-475)
+# ---------------------------------------------------------------------------------------------
+def false_negative_mask(known, h, r, t, neg_head, n_ent):
+    """[E, n_ent] bool: True where replacing the head (neg_head) / tail of test triple i by entity e
+    gives a known triple."""
+    ks = set(map(tuple, np.asarray(known, np.int64).tolist()))
+    E = len(h)
+    m = np.zeros((E, n_ent), bool)
+    for i in range(E):
+        for e in range(n_ent):
+            c = (e, int(r[i]), int(t[i])) if neg_head else (int(h[i]), int(r[i]), e)
+            m[i, e] = c in ks
+    return m
+
+
+def rank_eval(model, ent, rel, h, r, t, neg_head, gamma, emb_init, false_neg=None, tol=0.0):
+    """returns (ranks [E], pos_score [E], neg_score [E, n_ent]); with tol > 0 `ranks` is a pair
+    (lowest, highest) rank consistent with scores perturbed by at most tol (tie tolerance for fp32
+    implementations whose rounding differs from the reference's)."""
+    E, n_ent = len(h), ent.shape[0]
+    hs, rs, ts = ent[h], rel[r], ent[t]
+    p = score_pos(model, hs, rs, ts, gamma, emb_init)
+    a = pos_side(model, neg_head, ts if neg_head else hs, rs, emb_init)
+    S = score_neg(model, a, ent, 1, E, n_ent, gamma)[0]
+    keep = np.ones_like(S, bool) if false_neg is None else ~false_neg
+    if tol == 0.0:
+        return ((S >= p[:, None]) & keep).sum(1) + 1, p, S
+    lo = ((S >= p[:, None] + tol) & keep).sum(1) + 1
+    hi = ((S >= p[:, None] - tol) & keep).sum(1) + 1
+    return (lo, hi), p, S

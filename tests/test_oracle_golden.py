@@ -3,7 +3,7 @@ reference (tests/golden/gen_golden.py).  CPU-only; runs in seconds."""
 import numpy as np
 import pytest
 
-from golden_util import golden_names, load_golden, oracle_config
+from golden_util import eval_golden_names, golden_names, load_golden, oracle_config
 from oracle import kge_oracle as O
 
 
@@ -76,3 +76,29 @@ def test_duplicate_adagrad_semantics():
     assert np.allclose(state, [0, 10, 4])
     assert np.allclose(table[1], -0.5 * (1 + 3) / (np.sqrt(10) + 1e-10))
     assert np.allclose(table[2], -0.5 * 2 / (2 + 1e-10))
+
+
+# ---- ranking evaluation (forward_test) -------------------------------------------------------
+@pytest.mark.parametrize("name", eval_golden_names())
+def test_oracle_rank_eval_matches_reference(name):
+    """oracle rank_eval vs rankings / scores recorded from the reference's forward_test."""
+    z, case = load_golden(name)
+    ent, rel = z["entity"].astype(np.float64), z["relation"].astype(np.float64)
+    test = z["test"]
+    h, r, t = test[:, 0], test[:, 1], test[:, 2]
+    for mode in ("head", "tail"):
+        neg_head = mode == "head"
+        fn = O.false_negative_mask(z["known"], h, r, t, neg_head, ent.shape[0])
+        assert np.array_equal(fn, z[mode + "_false_neg"] > 0)
+        (lo, hi), p, S = O.rank_eval(case["model"], ent, rel, h, r, t, neg_head, case["gamma"], float(z["emb_init"]),
+                                     fn, tol=2e-5)
+        np.testing.assert_allclose(p, z[mode + "_pos_score"], rtol=1e-5, atol=2e-5)
+        np.testing.assert_allclose(S, z[mode + "_neg_score"], rtol=1e-5, atol=2e-5)
+        want = z[mode + "_ranks_filtered"]
+        assert np.all((lo <= want) & (want <= hi)), (mode, lo, want, hi)
+        (lo, hi), _, _ = O.rank_eval(case["model"], ent, rel, h, r, t, neg_head, case["gamma"], float(z["emb_init"]),
+                                     None, tol=2e-5)
+        want = z[mode + "_ranks_raw"]
+        assert np.all((lo <= want) & (want <= hi)), (mode, lo, want, hi)
+        # the true triple is a known triple: unfiltered it always counts itself
+        assert np.all(z[mode + "_ranks_raw"] >= 2)
