@@ -1,0 +1,290 @@
+"""`dglke_train`-compatible entry point (reference: python/dglke/train.py:40-330 + the common flags of
+python/dglke/utils.py:199-297): same flag names, same dataset formats, same log-line formats, same
+output files (`<save_path>/<model>_<dataset>_<n>/<dataset>_<model>_{entity,relation}.npy` +
+config.json, utils.py:35-49) so that the reference's `dglke_eval` / `dglke_predict` can consume the
+embeddings.
+
+What is different underneath: the per-step loop `sample -> forward -> backward -> update`
+(train_pytorch.py:132-152) is ONE fused HIP step (`kge_step_fused`) fed by the on-device sampler,
+replayed from a hipGraph; validation / test are one `kge_rank_eval` call per corruption mode instead
+of the per-triple Python loop.  There is no CPU training path: `--gpu` must name a GPU.
+
+    python -m dglke_amd.train --model_name TransE_l2 --dataset FB15k --data_path data --gpu 0 \\
+        --batch_size 1000 --neg_sample_size 200 --hidden_dim 400 --gamma 19.9 --lr 0.25 \\
+        --max_step 24000 --log_interval 1000 --batch_size_eval 16 -adv --regularization_coef 1e-9 --test
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch as th
+
+from ._lib import KgeError
+from .kgdataset import get_dataset
+
+
+class ArgParser(argparse.ArgumentParser):
+    """flags of utils.py:199-297 (CommonArgParser) + train.py:40-60 (ArgParser)."""
+
+    def __init__(self):
+        super(ArgParser, self).__init__(prog="dglke_train")
+        a = self.add_argument
+        a('--model_name', default='TransE', choices=['TransE', 'TransE_l1', 'TransE_l2', 'TransR', 'RESCAL',
+                                                     'DistMult', 'ComplEx', 'RotatE', 'SimplE'])
+        a('--data_path', type=str, default='data')
+        a('--dataset', type=str, default='FB15k')
+        a('--format', type=str, default='built_in')
+        a('--data_files', type=str, default=None, nargs='+')
+        a('--delimiter', type=str, default='\t')
+        a('--save_path', type=str, default='ckpts')
+        a('--no_save_emb', action='store_true')
+        a('--max_step', type=int, default=80000)
+        a('--batch_size', type=int, default=1024)
+        a('--batch_size_eval', type=int, default=8)
+        a('--neg_sample_size', type=int, default=256)
+        a('--neg_deg_sample', action='store_true')
+        a('--neg_deg_sample_eval', action='store_true')
+        a('--neg_sample_size_eval', type=int, default=-1)
+        a('--eval_percent', type=float, default=1)
+        a('--no_eval_filter', action='store_true')
+        a('-log', '--log_interval', type=int, default=1000)
+        a('--eval_interval', type=int, default=10000)
+        a('--test', action='store_true')
+        a('--num_proc', type=int, default=1)
+        a('--num_thread', type=int, default=1)
+        a('--force_sync_interval', type=int, default=-1)
+        a('--hidden_dim', type=int, default=400)
+        a('--lr', type=float, default=0.01)
+        a('-g', '--gamma', type=float, default=12.0)
+        a('-de', '--double_ent', action='store_true')
+        a('-dr', '--double_rel', action='store_true')
+        a('-adv', '--neg_adversarial_sampling', action='store_true')
+        a('-a', '--adversarial_temperature', default=1.0, type=float)
+        a('-rc', '--regularization_coef', type=float, default=0.000002)
+        a('-rn', '--regularization_norm', type=int, default=3)
+        a('-pw', '--pairwise', action='store_true')
+        a('--loss_genre', default='Logsigmoid', choices=['Hinge', 'Logistic', 'Logsigmoid', 'BCE'])
+        a('-m', '--margin', type=float, default=1.0)
+        a('--gpu', type=int, default=[-1], nargs='+')
+        a('--mix_cpu_gpu', action='store_true')
+        a('--valid', action='store_true')
+        a('--rel_part', action='store_true')
+        a('--async_update', action='store_true')
+        a('--has_edge_importance', action='store_true')
+        # additions of this build
+        a('--seed', type=int, default=0, help='seed of the table initialisation and of the device sampler')
+        a('--graph_steps', type=int, default=100, help='steps per captured hipGraph (0: eager launches)')
+        a('--target_mrr', type=float, default=None,
+          help='with --valid: stop as soon as the validation MRR reaches this value and report the time')
+
+
+def get_compatible_batch_size(batch_size, neg_sample_size):
+    """utils.py:27-33"""
+    if neg_sample_size < batch_size and batch_size % neg_sample_size != 0:
+        old = batch_size
+        batch_size = int(math.ceil(batch_size / neg_sample_size) * neg_sample_size)
+        print('batch size ({}) is incompatible to the negative sample size ({}). Change the batch size to {}'.format(
+            old, neg_sample_size, batch_size))
+    return batch_size
+
+
+def prepare_save_path(args):
+    """train.py:62-72"""
+    os.makedirs(args.save_path, exist_ok=True)
+    folder = '{}_{}_'.format(args.model_name, args.dataset)
+    n = len([x for x in os.listdir(args.save_path) if x.startswith(folder)])
+    args.save_path = os.path.join(args.save_path, folder + str(n))
+    os.makedirs(args.save_path, exist_ok=True)
+
+
+def save_model(args, model, emap_file=None, rmap_file=None):
+    """utils.py:35-49 (same keys, including the reference's 'emp_file' spelling)"""
+    os.makedirs(args.save_path, exist_ok=True)
+    print('Save model to {}'.format(args.save_path))
+    model.save_emb(args.save_path, args.dataset)
+    conf = dict(vars(args))
+    conf.update({'emp_file': emap_file, 'rmap_file': rmap_file})
+    with open(os.path.join(args.save_path, 'config.json'), 'w') as f:
+        json.dump(conf, f, indent=4)
+
+
+class Trainer(object):
+    """the training loop of train_pytorch.py:105-196 over the fused step."""
+
+    def __init__(self, args, dataset):
+        from .dataloader import DeviceSampler, UniformChunkedSampler
+        from .general_models import KEModel
+        self.args = args
+        self.dataset = dataset
+        if args.gpu[0] < 0:
+            raise KgeError("dglke_amd trains on the GPU only: pass --gpu <id> (there is no CPU fallback)")
+        if len(args.gpu) > 1 or args.num_proc > 1:
+            raise KgeError("multi-GPU training runs one process per GPU under torch.distributed.run "
+                           "(see bench_dist.py / dglke_amd.p2p); this entry point drives one GPU")
+        th.cuda.set_device(args.gpu[0])
+        self.dev = th.device("cuda", args.gpu[0])
+        th.manual_seed(args.seed)
+        self.model = KEModel(args, args.model_name, dataset.n_entities, dataset.n_relations, args.hidden_dim,
+                             args.gamma, double_entity_emb=args.double_ent, double_relation_emb=args.double_rel)
+        tr = dataset.train
+        B, N = args.batch_size, args.neg_sample_size
+        chunk = N if N <= B else B
+        C = B // chunk
+        self.fused = not args.neg_deg_sample
+        self.device_sampler = self.fused and not args.has_edge_importance and 2 * B + C * N <= 4096
+        w = tr[3] if args.has_edge_importance else None
+        if self.device_sampler:
+            self.sampler = DeviceSampler(tr[0], tr[1], tr[2], dataset.n_entities, B, N, self.dev,
+                                         n_slots=max(2, args.graph_steps or 2), neg_chunk_size=chunk, seed=args.seed)
+        else:
+            self.sampler = UniformChunkedSampler(tr[0], tr[1], tr[2], dataset.n_entities, B, N, self.dev,
+                                                 neg_chunk_size=chunk, seed=args.seed, edge_importance=w)
+        self._graph = None
+        self._graph_n = 0
+
+    # ---- n fused steps, as few launches as possible ---------------------------------------
+    def _run(self, n):
+        eng = self.model.engine
+        if not self.fused:
+            for _ in range(n):               # drop-in path (autograd Functions over the modular kernels)
+                pos_g, neg_g = next(self.sampler)
+                loss, log = self.model.forward(pos_g, neg_g, self.args.gpu[0])
+                loss.backward()
+                self.model.update(self.args.gpu[0])
+            return
+        if not self.device_sampler:
+            for b in self.sampler.next_batches(n):
+                eng.step(b)
+            return
+        G = self.args.graph_steps
+        done = 0
+        if G >= 2 and G % 2 == 0 and n >= G and self.sampler.host_step % 2 == 1:
+            if self._graph is None:
+                for b in self.sampler.sample(G):      # eager warm-up (also allocates the workspace)
+                    eng.step(b)
+                done += G
+                if n - done >= G:
+                    g = th.cuda.CUDAGraph()
+                    with th.cuda.graph(g):
+                        for b in self.sampler.sample(G):
+                            eng.step(b)
+                    self._graph, self._graph_n = g, G
+                    self.sampler.host_step -= G       # the capture itself did not run the steps
+            while self._graph is not None and n - done >= G:
+                self._graph.replay()
+                self.sampler.host_step += G
+                done += G
+        while done < n:                               # remainder: eager, any count
+            k = min(self.sampler.n_slots, n - done)
+            for b in self.sampler.sample(k):
+                eng.step(b)
+            done += k
+
+    def evaluate(self, which, mode):
+        from . import eval as kev
+        args, ds = self.args, self.dataset
+        trip = getattr(ds, which)
+        if trip is None:
+            raise KgeError("the dataset has no %s split" % which)
+        h, r, t = (np.asarray(x) for x in trip[:3])
+        if args.eval_percent < 1:
+            rng = np.random.RandomState(args.seed + 17)
+            keep = rng.permutation(len(h))[:max(1, int(len(h) * args.eval_percent))]
+            h, r, t = h[keep], r[keep], t[keep]
+        known = None
+        if args.eval_filter:
+            parts = [p for p in (ds.train, ds.valid, ds.test) if p is not None]
+            known = tuple(np.concatenate([np.asarray(p[k]) for p in parts]) for k in range(3))
+        m = self.model
+        n_cand = m.n_entities
+        Eb = int(max(1, min(max(args.batch_size_eval, 1024), (1 << 31) // (4 * n_cand), len(h))))
+        metrics = kev.evaluate(args.model_name, m.entity_emb.emb, m.relation_emb.emb, args.gamma, m.emb_init,
+                               (h, r, t), known, batch=Eb)
+        for k, v in metrics.items():
+            print('[{}]{} average {}: {}'.format(0, mode, k, v))
+        return metrics
+
+    def train(self):
+        args = self.args
+        eng = self.model.engine
+        keys = ['loss'] if args.pairwise else ['pos_loss', 'neg_loss', 'loss']
+        if args.regularization_coef > 0 and args.regularization_norm > 0:
+            keys.append('regularization')
+        idx = {'pos_loss': 0, 'neg_loss': 1, 'loss': 2, 'regularization': 3}
+        th.cuda.synchronize()
+        train_start = start = time.time()
+        step, t_train, reached = 0, 0.0, None
+        marks = set()
+        for iv in (args.log_interval, args.eval_interval if args.valid else 0):
+            if iv and iv > 0:
+                marks.update(range(iv, args.max_step + 1, iv))
+        marks.add(args.max_step)
+        since_log = 0
+        for nxt in sorted(marks):
+            n = nxt - step
+            if n > 0:
+                t0 = time.time()
+                self._run(n)
+                th.cuda.synchronize()
+                t_train += time.time() - t0
+                step, since_log = nxt, since_log + n
+            if step % args.log_interval == 0 and since_log:
+                if self.fused:
+                    sums = eng.read_loss_sums()
+                    for k in keys:
+                        print('[proc {}][Train]({}/{}) average {}: {}'.format(0, step, args.max_step, k,
+                                                                            sums[idx[k]] / since_log))
+                print('[proc {}][Train] {} steps take {:.3f} seconds'.format(0, since_log, time.time() - start))
+                print('[proc {}]sample+forward+backward+update (fused HIP step): {:.3f}'.format(0, t_train))
+                since_log, start = 0, time.time()
+            if args.valid and step % args.eval_interval == 0 and step > 1 and self.dataset.valid is not None:
+                valid_start = time.time()
+                m = self.evaluate('valid', 'Valid')
+                print('[proc {}]validation take {:.3f} seconds:'.format(0, time.time() - valid_start))
+                if args.target_mrr is not None and reached is None and m['MRR'] >= args.target_mrr:
+                    reached = (step, t_train)
+                    print('[proc 0]validation MRR {:.4f} >= {:.4f} after {} steps, {:.3f} s of training'.format(
+                        m['MRR'], args.target_mrr, step, t_train))
+                    break
+                start = time.time()
+        print('proc {} takes {:.3f} seconds'.format(0, time.time() - train_start))
+        return reached
+
+
+def main(argv=None):
+    args = ArgParser().parse_args(argv)
+    prepare_save_path(args)
+    init_time_start = time.time()
+    dataset = get_dataset(args.data_path, args.dataset, args.format, args.delimiter, args.data_files,
+                          args.has_edge_importance)
+    if args.neg_sample_size_eval < 0:
+        args.neg_sample_size_eval = dataset.n_entities
+    args.batch_size = get_compatible_batch_size(args.batch_size, args.neg_sample_size)
+    args.batch_size_eval = get_compatible_batch_size(args.batch_size_eval, args.neg_sample_size_eval)
+    args.eval_filter = not args.no_eval_filter
+    if args.neg_deg_sample_eval:
+        assert not args.eval_filter, "if negative sampling based on degree, we can't filter positive edges."
+    args.soft_rel_part = args.strict_rel_part = False     # one replicated HBM relation table
+    trainer = Trainer(args, dataset)
+    print('Total initialize time {:.3f} seconds'.format(time.time() - init_time_start))
+    start = time.time()
+    trainer.train()
+    print('training takes {} seconds'.format(time.time() - start))
+    if not args.no_save_emb:
+        save_model(args, trainer.model, emap_file=dataset.emap_fname, rmap_file=dataset.rmap_fname)
+    if args.test:
+        start = time.time()
+        trainer.evaluate('test', 'Test')
+        print('testing takes {:.3f} seconds'.format(time.time() - start))
+    return trainer
+
+
+if __name__ == '__main__':
+    try:
+        main()
+    except KgeError as e:
+        sys.exit("dglke_train: %s" % e)

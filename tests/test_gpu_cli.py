@@ -1,0 +1,80 @@
+"""dglke_train end to end on the GPU: a small planted graph in the reference's udd format -> train with
+the fused step + device sampler (graph replay and eager remainder) -> validation / test through
+kge_rank_eval -> embeddings + config.json in the reference's file layout."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def _planted(path, n_ent=400, n_rel=6, n=9000, seed=3):
+    from planted_kg import make_planted
+    train, test = make_planted(n_ent, n_rel, n, dim=8, seed=seed)
+    valid, test = test[:len(test) // 2], test[len(test) // 2:]
+    os.makedirs(path, exist_ok=True)
+    with open(os.path.join(path, "e.dict"), "w") as f:
+        f.writelines("%d\te%d\n" % (i, i) for i in range(n_ent))
+    with open(os.path.join(path, "r.dict"), "w") as f:
+        f.writelines("%d\tr%d\n" % (i, i) for i in range(n_rel))
+    for name, t in (("train.txt", train), ("valid.txt", valid), ("test.txt", test)):
+        np.savetxt(os.path.join(path, name), t, fmt="%d", delimiter="\t")
+    return train, valid, test
+
+
+@pytest.mark.parametrize("model,extra", [("TransE_l2", []), ("DistMult", ["--loss_genre", "Logistic", "-g", "6"]),
+                                         ("RotatE", ["-de"])])
+def test_train_cli_end_to_end(tmp_path, capsys, model, extra):
+    from dglke_amd import train as T
+    data = str(tmp_path / "kg")
+    _planted(data)
+    argv = ["--model_name", model, "--format", "udd_hrt", "--dataset", "toy", "--data_path", data, "--data_files",
+            "e.dict", "r.dict", "train.txt", "valid.txt", "test.txt", "--save_path", str(tmp_path / "ckpts"),
+            "--gpu", "0", "--batch_size", "256", "--neg_sample_size", "64", "--hidden_dim", "32", "-g", "8",
+            "--lr", "0.25", "-adv", "-rc", "1e-7", "--max_step", "1250", "--log_interval", "500",
+            "--eval_interval", "1000", "--valid", "--test", "--graph_steps", "100"] + extra
+    tr = T.main(argv)
+    out = capsys.readouterr().out
+    # reference log formats (train_pytorch.py:165-172, :236-247)
+    assert "[proc 0][Train](500/1250) average loss:" in out and "[proc 0][Train](1000/1250) average pos_loss:" in out
+    assert "[0]Valid average MRR:" in out and "[0]Test average HITS@10:" in out and "training takes" in out
+    mrr = float([l for l in out.split("\n") if l.startswith("[0]Test average MRR:")][0].split(":")[1])
+    mrr0 = 2.0 / 400
+    assert mrr > 10 * mrr0, "training did not learn the planted graph (test MRR %.4f)" % mrr
+    save = tr.args.save_path
+    assert os.path.basename(save) == "%s_toy_0" % model
+    ent = np.load(os.path.join(save, "toy_%s_entity.npy" % model))
+    rel = np.load(os.path.join(save, "toy_%s_relation.npy" % model))
+    assert ent.shape == (400, 64 if model == "RotatE" else 32) and rel.shape == (6, 32)
+    assert np.array_equal(ent, tr.model.entity_emb.emb.cpu().numpy())
+    conf = json.load(open(os.path.join(save, "config.json")))
+    assert conf["model_name"] == model and conf["emp_file"] == "e.dict" and conf["rmap_file"] == "r.dict"
+    assert conf["hidden_dim"] == 32 and conf["dataset"] == "toy"
+    # losses fell
+    first = float([l for l in out.split("\n") if "(500/1250) average loss:" in l][0].split(":")[1])
+    last = float([l for l in out.split("\n") if "(1000/1250) average loss:" in l][0].split(":")[1])
+    assert last < first
+
+
+def test_train_cli_host_sampler_paths(tmp_path, capsys):
+    """edge importance (host plan) and a batch too large for the device sampler."""
+    from dglke_amd import train as T
+    data = str(tmp_path / "kg")
+    train, _, _ = _planted(data)
+    w = np.random.RandomState(0).uniform(0.5, 1.5, len(train))
+    with open(os.path.join(data, "train_w.txt"), "w") as f:
+        for (h, r, t), x in zip(train.tolist(), w):
+            f.write("%d\t%d\t%d\t%.4f\n" % (h, r, t, x))
+    base = ["--model_name", "TransE_l2", "--format", "udd_hrt", "--dataset", "toy", "--data_path", data,
+            "--save_path", str(tmp_path / "ckpts"), "--gpu", "0", "--hidden_dim", "32", "-g", "8", "--lr", "0.25",
+            "--max_step", "300", "--log_interval", "150", "--no_save_emb"]
+    T.main(base + ["--data_files", "e.dict", "r.dict", "train_w.txt", "--has_edge_importance", "--batch_size", "256",
+                   "--neg_sample_size", "64"])
+    T.main(base + ["--data_files", "e.dict", "r.dict", "train.txt", "--batch_size", "2048", "--neg_sample_size", "128"])
+    out = capsys.readouterr().out
+    assert out.count("(300/300) average loss:") == 2
