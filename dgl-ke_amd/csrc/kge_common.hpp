@@ -309,3 +309,6 @@ int launch_neg_fwd_gemm(const GemmArgs &a, hipStream_t s);
 int launch_neg_bwd_gemm(const GemmArgs &a, hipStream_t s);
 int launch_neg_fwd_pair(const NegArgs &a, hipStream_t s);
 int launch_neg_bwd_pair(const NegArgs &a, hipStream_t s);
+bool neg_bcast_supported(int model, int d_e);          // kge_neg_bcast.hip: lane = row, other operand wave-uniform
+int launch_neg_fwd_bcast(const NegArgs &a, hipStream_t s);
+int launch_neg_bwd_bcast(const NegArgs &a, hipStream_t s);

@@ -124,6 +124,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void neg_fwd_pair_kernel(NegArgs a, int 
 }
 
 int launch_neg_fwd_pair(const NegArgs &a, hipStream_t s) {
+    if (neg_bcast_supported(a.model, a.d_e)) return launch_neg_fwd_bcast(a, s);    // fast path (kge_neg_bcast.hip)
     const int ti = (a.chunk + PT - 1) / PT, tj = (a.N + PT - 1) / PT;
     const int nb = a.C * ti * tj;
     if (nb == 0) return KGE_OK;
@@ -286,6 +287,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void neg_bwd_pair_kernel(NegArgs a, int 
 }
 
 int launch_neg_bwd_pair(const NegArgs &a, hipStream_t s) {
+    if (neg_bcast_supported(a.model, a.d_e)) return launch_neg_bwd_bcast(a, s);
     const int ti = (a.chunk + PT - 1) / PT, tj = (a.N + PT - 1) / PT;
     const int K = (a.model == KGE_ROTATE) ? a.d_e / 2 : a.d_e;
     const int tk = (K + PK - 1) / PK;
