@@ -42,7 +42,7 @@ template <int L> __device__ __forceinline__ float bcast(float v) {
 // contrast, measured ~16 cycles per broadcast on MI355X)
 template <int Q> __device__ __forceinline__ float quad(float v) {
     constexpr int ctrl = Q | (Q << 2) | (Q << 4) | (Q << 6);
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xF, 0xF, false));
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), ctrl, 0xF, 0xF, true));
 }
 // compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N-1>{})
 template <class F, int... I> __device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) {
@@ -280,7 +280,7 @@ __device__ __forceinline__ void bwd_task(const NegArgs &a, int c, int st, int k0
             if constexpr (CPLX) {
                 const float y1 = quad<e & 3>(yi[e >> 2]);
                 const float dr = xr[e] - y0, di = xi[e] - y1;
-                const float m2 = fmaxf(fmaf(di, di, dr * dr), 1e-30f);
+                const float m2 = fmaf(di, di, fmaf(dr, dr, 1e-30f));     // + tiny: zero difference -> zero gradient
                 const float iv = -w * fast_rsq(m2);
                 outr[e] = fmaf(dr, iv, outr[e]);
                 outi[e] = fmaf(di, iv, outi[e]);
