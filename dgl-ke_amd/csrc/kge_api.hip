@@ -40,10 +40,11 @@ struct Carver {
 };
 
 int check_model(int model, int d_e, int d_r) {
-    if (model < KGE_TRANSE_L1 || model > KGE_ROTATE) return fail(KGE_ERR_ARG, "unknown model %d", model);
+    if (model < KGE_TRANSE_L1 || model > KGE_SIMPLE) return fail(KGE_ERR_ARG, "unknown model %d", model);
     if (d_e <= 0 || d_r <= 0) return fail(KGE_ERR_ARG, "bad dims d_e=%d d_r=%d", d_e, d_r);
-    if (model == KGE_COMPLEX) {
-        if (d_e % 2 || d_r != d_e) return fail(KGE_ERR_ARG, "ComplEx needs even d_e and d_r == d_e (got %d, %d)", d_e, d_r);
+    if (model == KGE_COMPLEX || model == KGE_SIMPLE) {
+        if (d_e % 2 || d_r != d_e) return fail(KGE_ERR_ARG, "%s needs even d_e and d_r == d_e (got %d, %d)",
+                                               model == KGE_COMPLEX ? "ComplEx" : "SimplE", d_e, d_r);
     } else if (model == KGE_ROTATE) {
         if (d_e % 2 || d_r != d_e / 2) return fail(KGE_ERR_ARG, "RotatE needs d_r == d_e/2 (got d_e=%d d_r=%d)", d_e, d_r);
     } else if (d_r != d_e) {
@@ -53,9 +54,17 @@ int check_model(int model, int d_e, int d_r) {
 }
 
 inline float rot_div_of(float emb_init) { return (float)((double)emb_init / M_PI); }
+inline float clamp_of(int model) { return model == KGE_SIMPLE ? KGE_SIMPLE_CLAMP : 0.f; }
 
 bool use_mfma(int model, int d_e, int N, unsigned flags) {
     return !(flags & KGE_FLAG_FORCE_PAIRWISE) && neg_mfma_supported(model, d_e, N);
+}
+
+// SimplE, modular backward: no gradient through a saturated clamp
+__global__ void clamp_mask_kernel(const float *dneg, const float *score, float c, float *W, int64_t n) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    W[k] = fabsf(score[k]) >= c ? 0.f : dneg[k];
 }
 
 __global__ void l2_scale_kernel(const float *dneg, const float *score, float gamma, float *W, int64_t n) {
@@ -102,7 +111,7 @@ int kge_score_pos_bwd(int model, const float *h, const float *r, const float *t,
     a.src = EdgeSrc{h, nullptr, t, nullptr, r, nullptr};
     a.B = (int)B; a.d_e = d_e; a.d_r = d_r; a.neg_head = 0; a.model = model;
     a.gamma = gamma; a.rot_div = rot_div_of(emb_init);
-    a.dpos = dpos; a.GA = nullptr; a.reg_coef = 0.f; a.reg_norm = 0;
+    a.dpos = dpos; a.GA = nullptr; a.reg_coef = 0.f; a.reg_norm = 0; a.clamp_pos = 1;
     a.GH = gh; a.GT = gt; a.GR = gr;
     KGE_TRY(launch_edge_bwd(a, (hipStream_t)stream));
     return KGE_OK;
@@ -143,13 +152,13 @@ static void fill_gemm(GemmArgs &g, int model, int C, int chunk, int N, int d_e, 
                       const float *A, const float *nbase, const int64_t *nidx) {
     g = GemmArgs{};
     g.model = model; g.C = C; g.chunk = chunk; g.N = N; g.D = d_e; g.gamma = gamma;
-    g.A = A; g.nbase = nbase; g.nidx = nidx; g.B = C * chunk;
+    g.A = A; g.nbase = nbase; g.nidx = nidx; g.B = C * chunk; g.clampv = clamp_of(model);
 }
 static void fill_pair(NegArgs &na, int model, int C, int chunk, int N, int d_e, float gamma,
                       const float *A, const float *nbase, const int64_t *nidx) {
     na = NegArgs{};
     na.model = model; na.C = C; na.chunk = chunk; na.N = N; na.d_e = d_e; na.gamma = gamma;
-    na.A = A; na.nbase = nbase; na.nidx = nidx;
+    na.A = A; na.nbase = nbase; na.nidx = nidx; na.clampv = clamp_of(model);
 }
 
 int kge_score_neg_fwd(int model, int neg_head, const float *pos_side, const float *rel,
@@ -187,8 +196,8 @@ int kge_score_neg_bwd(int model, int neg_head, const float *pos_side, const floa
     if (!pos_side || !rel || !neg || !dneg || !g_pos_side || !g_rel || !g_neg || !ws || C < 0 ||
         chunk <= 0 || N <= 0)
         return fail(KGE_ERR_ARG, "kge_score_neg_bwd: bad argument");
-    if (model == KGE_TRANSE_L2 && !neg_score)
-        return fail(KGE_ERR_ARG, "kge_score_neg_bwd: TransE_l2 needs the forward scores");
+    if ((model == KGE_TRANSE_L2 || model == KGE_SIMPLE) && !neg_score)
+        return fail(KGE_ERR_ARG, "kge_score_neg_bwd: TransE_l2 / SimplE need the forward scores");
     if (C == 0) return KGE_OK;
     hipStream_t s = (hipStream_t)stream;
     const int B = C * chunk;
@@ -204,6 +213,11 @@ int kge_score_neg_bwd(int model, int neg_head, const float *pos_side, const floa
         const int64_t n = (int64_t)B * N;
         hipLaunchKernelGGL(l2_scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dneg,
                            neg_score, gamma, W, n);
+        Wuse = W;
+    } else if (model == KGE_SIMPLE) {
+        const int64_t n = (int64_t)B * N;
+        hipLaunchKernelGGL(clamp_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dneg,
+                           neg_score, KGE_SIMPLE_CLAMP, W, n);
         Wuse = W;
     }
     if (use_mfma(model, d_e, N, flags)) {
@@ -348,7 +362,7 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     const bool pairwise = hp->pairwise != 0;
     // which kernels run
     const bool gemm = use_mfma(hp->model, d_e, N, hp->flags);       // matrix-core negative scoring
-    const bool fused_loss = gemm && !pairwise && (hp->flags & KGE_FLAG_FUSED_LOSS);   // loss gradient inside the bwd GEMM
+    const bool fused_loss = gemm && !pairwise && (hp->flags & KGE_FLAG_FUSED_LOSS) && hp->model != KGE_SIMPLE;   // loss gradient inside the bwd GEMM
     const bool is_l2 = hp->model == KGE_TRANSE_L2;
     const bool transe = hp->model == KGE_TRANSE_L1 || is_l2;
     const int dmax = d_e > d_r ? d_e : d_r;
@@ -417,7 +431,7 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         la.pos = P; la.neg = S; la.w = b->edge_w; la.dpos = dP; la.dneg = S;
         la.row_pos = want4 ? row_pos : nullptr; la.row_neg = want4 ? row_neg : nullptr;
         la.acc = acc;
-        la.l2_scale = is_l2 ? 1 : 0; la.gamma = hp->gamma;
+        la.l2_scale = is_l2 ? 1 : 0; la.gamma = hp->gamma; la.clampv = clamp_of(hp->model);
         la.neg_copy = out ? out->neg_score : nullptr;
         la.skip_pos = pairwise ? 0 : 1;
         KGE_TRY(launch_loss(la, s));

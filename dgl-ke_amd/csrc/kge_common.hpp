@@ -112,7 +112,9 @@ __device__ __forceinline__ float neg_logsigmoid(float z) {
     return fmaxf(-z, 0.f) + log1pf(expf(-fabsf(z)));
 }
 
-constexpr bool is_complex_model(int m) { return m == KGE_COMPLEX || m == KGE_ROTATE; }
+// models whose rows are two halves ([re | im], SimplE: [x_i | x_j]) processed element-pair-wise
+constexpr bool is_complex_model(int m) { return m == KGE_COMPLEX || m == KGE_ROTATE || m == KGE_SIMPLE; }
+#define KGE_SIMPLE_CLAMP 20.f        // th.clamp(score, -20, 20), score_fun.py:568
 
 // fast-math variants (hardware exp/log, |rel err| ~1e-6) for the hot kernels
 __device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.f + __expf(-x)); }
@@ -203,6 +205,8 @@ struct EdgeBwdArgs {
     const float *dpos;               // [B] dL/dp or null (no positive-score part)
     const float *GA;                 // [B,d_e] dL/da or null (no negative-score part)
     float reg_coef; int reg_norm;    // regularisation gradient added to the relation row grad
+    int clamp_pos;                   // SimplE, modular op: dpos is the gradient w.r.t. the CLAMPED score -> recompute
+                                     // the raw score and drop it where saturated (the fused step masks in edge_fwd)
     float *GH, *GT;                  // [B,d_e] (either may be null)
     float *GR;                       // [B,d_r] or null
 };
@@ -220,6 +224,7 @@ struct NegArgs {                     // chunked negative scoring, forward and ba
     float *GN;                       // bwd out [C*N, d_e]
     float reg_coef; int reg_norm;    // (unused by the GEMM/pair kernels; regularisation is added
                                      //  by the consumers of GN)
+    float clampv;                    // > 0: clamp the scores to [-clampv, clampv] (SimplE)
 };
 
 struct LossArgs {
@@ -230,6 +235,7 @@ struct LossArgs {
     float *row_pos, *row_neg;        // [B] per-row loss terms (already divided by B), or null
     float *acc;                      // [4][KGE_ACC_SLOTS] running loss sums (slot = row & mask) or null
     int l2_scale; float gamma;       // if set: dneg /= (gamma - n)   (TransE_l2 GEMM backward)
+    float clampv;                    // > 0: scores were clamped to [-clampv, clampv] (SimplE): no gradient where saturated
     float *neg_copy;                 // optional copy of the scores before overwrite
     int skip_pos;                    // the positive-loss part was already done by edge_fwd
 };
@@ -292,6 +298,7 @@ struct GemmArgs {                   // LDS-staged fp32-MFMA negative scoring (kg
     const float *asq, *bsq;          // [C*chunk], [C*N] squared norms (TransE_l2)
     // forward
     float *S;                        // out [C,chunk,N]
+    float clampv;                    // > 0: clamp the scores to [-clampv, clampv] (SimplE)
     float *PM, *PS;                  // [C*chunk, tj16] per-16-column partial max / sum-exp of T*n, or null
     float adv_temp;
     // backward

@@ -177,6 +177,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void neg_fwd_bcast_kernel(NegArgs a, int
                 float v = acc[r];
                 if (MODEL == KGE_TRANSE_L1 || CPLX) v = a.gamma - v;
                 else if (MODEL == KGE_TRANSE_L2) v = a.gamma - sqrtf(fmaxf(v, 1e-30f));
+                else if (a.clampv > 0.f) v = fminf(fmaxf(v, -a.clampv), a.clampv);
                 a.S[((int64_t)c * a.chunk + i0 + r) * a.N + j] = v;
             }
         }
@@ -196,7 +197,7 @@ int launch_neg_fwd_bcast(const NegArgs &a, hipStream_t s) {
     switch (a.model) {
         case KGE_TRANSE_L1: return fwd_launch<KGE_TRANSE_L1>(a, s);
         case KGE_TRANSE_L2: return fwd_launch<KGE_TRANSE_L2>(a, s);
-        case KGE_DISTMULT: case KGE_COMPLEX: return fwd_launch<KGE_DISTMULT>(a, s);
+        case KGE_DISTMULT: case KGE_COMPLEX: case KGE_SIMPLE: return fwd_launch<KGE_DISTMULT>(a, s);
         case KGE_ROTATE: return fwd_launch<KGE_ROTATE>(a, s);
     }
     return KGE_ERR_ARG;
@@ -367,7 +368,7 @@ int launch_neg_bwd_bcast(const NegArgs &a, hipStream_t s) {
     switch (a.model) {
         case KGE_TRANSE_L1: return bwd_launch<KGE_TRANSE_L1>(a, s);
         case KGE_TRANSE_L2: return bwd_launch<KGE_TRANSE_L2>(a, s);
-        case KGE_DISTMULT: case KGE_COMPLEX: return bwd_launch<KGE_DISTMULT>(a, s);
+        case KGE_DISTMULT: case KGE_COMPLEX: case KGE_SIMPLE: return bwd_launch<KGE_DISTMULT>(a, s);
         case KGE_ROTATE: return bwd_launch<KGE_ROTATE>(a, s);
     }
     return KGE_ERR_ARG;

@@ -35,7 +35,7 @@ using namespace kge;
 
 bool neg_mfma_supported(int model, int d_e, int N) {
     (void)N;
-    if (model != KGE_TRANSE_L2 && model != KGE_DISTMULT && model != KGE_COMPLEX) return false;
+    if (model != KGE_TRANSE_L2 && model != KGE_DISTMULT && model != KGE_COMPLEX && model != KGE_SIMPLE) return false;
     return d_e % 4 == 0;   // 16-byte aligned rows
 }
 
@@ -118,6 +118,8 @@ __global__ __launch_bounds__(KGE_BLOCK) void neg_fwd_gemm_kernel(GemmArgs a, int
         if (L2) {
             const float ar = a.asq[(int64_t)c * a.chunk + min(i, a.chunk - 1)];
             v = a.gamma - sqrtf(fmaxf(ar + bsq - 2.f * v, 1e-30f));
+        } else if (a.clampv > 0.f) {
+            v = fminf(fmaxf(v, -a.clampv), a.clampv);            // SimplE: th.clamp(tmp, -20, 20)
         }
         const bool ok = jok && i < a.chunk;
         if (ok) a.S[((int64_t)c * a.chunk + i) * a.N + j] = v;

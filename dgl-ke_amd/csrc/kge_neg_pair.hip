@@ -119,7 +119,11 @@ __global__ __launch_bounds__(KGE_BLOCK) void neg_fwd_pair_kernel(NegArgs a, int 
         for (int s = 0; s < 2; ++s) {
             const int i = i0 + 2 * ty + r, j = j0 + 2 * tx + s;
             if (i < a.chunk && j < a.N)
-                a.S[((int64_t)c * a.chunk + i) * a.N + j] = F::fin(acc[r][s], a.gamma);
+            {
+                float v = F::fin(acc[r][s], a.gamma);
+                if (a.clampv > 0.f) v = fminf(fmaxf(v, -a.clampv), a.clampv);
+                a.S[((int64_t)c * a.chunk + i) * a.N + j] = v;
+            }
         }
 }
 
@@ -133,7 +137,7 @@ int launch_neg_fwd_pair(const NegArgs &a, hipStream_t s) {
             hipLaunchKernelGGL(neg_fwd_pair_kernel<KGE_TRANSE_L1>, dim3(nb), dim3(KGE_BLOCK), 0, s, a, ti, tj); break;
         case KGE_TRANSE_L2:
             hipLaunchKernelGGL(neg_fwd_pair_kernel<KGE_TRANSE_L2>, dim3(nb), dim3(KGE_BLOCK), 0, s, a, ti, tj); break;
-        case KGE_DISTMULT: case KGE_COMPLEX:
+        case KGE_DISTMULT: case KGE_COMPLEX: case KGE_SIMPLE:
             hipLaunchKernelGGL(neg_fwd_pair_kernel<KGE_DISTMULT>, dim3(nb), dim3(KGE_BLOCK), 0, s, a, ti, tj); break;
         case KGE_ROTATE:
             hipLaunchKernelGGL(neg_fwd_pair_kernel<KGE_ROTATE>, dim3(nb), dim3(KGE_BLOCK), 0, s, a, ti, tj); break;
@@ -298,7 +302,7 @@ int launch_neg_bwd_pair(const NegArgs &a, hipStream_t s) {
             hipLaunchKernelGGL(neg_bwd_pair_kernel<KGE_TRANSE_L1>, dim3(nb), dim3(KGE_BLOCK), 0, s, a, ti, tj, tk); break;
         case KGE_TRANSE_L2:
             hipLaunchKernelGGL(neg_bwd_pair_kernel<KGE_TRANSE_L2>, dim3(nb), dim3(KGE_BLOCK), 0, s, a, ti, tj, tk); break;
-        case KGE_DISTMULT: case KGE_COMPLEX:
+        case KGE_DISTMULT: case KGE_COMPLEX: case KGE_SIMPLE:
             hipLaunchKernelGGL(neg_bwd_pair_kernel<KGE_DISTMULT>, dim3(nb), dim3(KGE_BLOCK), 0, s, a, ti, tj, tk); break;
         case KGE_ROTATE:
             hipLaunchKernelGGL(neg_bwd_pair_kernel<KGE_ROTATE>, dim3(nb), dim3(KGE_BLOCK), 0, s, a, ti, tj, tk); break;

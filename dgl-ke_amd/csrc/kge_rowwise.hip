@@ -126,8 +126,8 @@ __global__ __launch_bounds__(KGE_BLOCK) void edge_fwd_kernel(EdgeFwdArgs a) {
                 const Pack<V> rh = ld<V>(h + off), ih = ld<V>(h + hd + off);
                 const Pack<V> rt = ld<V>(t + off), it_ = ld<V>(t + hd + off);
                 Pack<V> rr, ir;
-                if constexpr (MODEL == KGE_COMPLEX) {
-                    rr = ld<V>(r + off); ir = ld<V>(r + hd + off);
+                if constexpr (MODEL == KGE_COMPLEX || MODEL == KGE_SIMPLE) {
+                    rr = ld<V>(r + off); ir = ld<V>(r + hd + off);     // SimplE: rel | rel_inv
                 } else {
                     const Pack<V> ph = ld<V>(r + off);
 #pragma unroll
@@ -137,7 +137,15 @@ __global__ __launch_bounds__(KGE_BLOCK) void edge_fwd_kernel(EdgeFwdArgs a) {
 #pragma unroll
                 for (int e = 0; e < V; ++e) {
                     const float c = rr.v[e], s = ir.v[e];
-                    if constexpr (MODEL == KGE_COMPLEX) {
+                    if constexpr (MODEL == KGE_SIMPLE) {
+                        // (h_i, h_j) = (rh, ih), (t_i, t_j) = (rt, it_), (rel, rel_inv) = (c, s); score_fun.py:562-568
+                        ps += 0.5f * (rh.v[e] * c * it_.v[e] + rt.v[e] * s * ih.v[e]);
+                        // pos-side vector, 1/2 folded in, laid out so that a . neg = the chunked score
+                        // (score_fun.py:611-622 head mode, :626-641 tail mode)
+                        if (a.neg_head) { are.v[e] = 0.5f * c * it_.v[e]; aim.v[e] = 0.5f * s * rt.v[e]; }
+                        else            { are.v[e] = 0.5f * s * ih.v[e];  aim.v[e] = 0.5f * rh.v[e] * c; }
+                        continue;
+                    } else if constexpr (MODEL == KGE_COMPLEX) {
                         ps += rh.v[e] * rt.v[e] * c + ih.v[e] * it_.v[e] * c +
                               rh.v[e] * it_.v[e] * s - ih.v[e] * rt.v[e] * s;
                     } else {
@@ -162,6 +170,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void edge_fwd_kernel(EdgeFwdArgs a) {
             float p;
             if constexpr (MODEL == KGE_TRANSE_L1 || MODEL == KGE_ROTATE) p = a.gamma - ps;
             else if constexpr (MODEL == KGE_TRANSE_L2) p = a.gamma - sqrtf(ps);
+            else if constexpr (MODEL == KGE_SIMPLE) p = fminf(fmaxf(ps, -KGE_SIMPLE_CLAMP), KGE_SIMPLE_CLAMP);
             else p = ps;
             if (lane == 0 && a.pos_score) a.pos_score[i] = p;
             if (a.do_pos_loss) {
@@ -170,6 +179,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void edge_fwd_kernel(EdgeFwdArgs a) {
                 const float invB = 1.f / (float)a.B;
                 float pl, dpl;
                 criterion(a.lp.genre, p, 1.f, a.lp.margin, pl, dpl);
+                if constexpr (MODEL == KGE_SIMPLE) { if (fabsf(ps) >= KGE_SIMPLE_CLAMP) dpl = 0.f; }   // saturated clamp
                 const float dp = dpl * w * 0.5f * invB;
                 if (lane == 0) {
                     const float plw = pl * w * invB;
@@ -250,6 +260,7 @@ int launch_edge_fwd(const EdgeFwdArgs &a, hipStream_t s) {
         case KGE_DISTMULT: return launch_edge_fwd_m<KGE_DISTMULT>(a, s);
         case KGE_COMPLEX: return launch_edge_fwd_m<KGE_COMPLEX>(a, s);
         case KGE_ROTATE: return launch_edge_fwd_m<KGE_ROTATE>(a, s);
+        case KGE_SIMPLE: return launch_edge_fwd_m<KGE_SIMPLE>(a, s);
     }
     return KGE_ERR_ARG;
 }
@@ -267,7 +278,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void edge_bwd_kernel(EdgeBwdArgs a) {
     const float *h = table_row(a.src.em, a.src.hbase, a.src.hidx, i, a.d_e);
     const float *t = table_row(a.src.em, a.src.tbase, a.src.tidx, i, a.d_e);
     const float *r = table_row(a.src.rm, a.src.rbase, a.src.ridx, i, a.d_r);
-    const float dp = a.dpos ? a.dpos[i] : 0.f;
+    const float dp_in = a.dpos ? a.dpos[i] : 0.f;
     const float *ga = a.GA ? a.GA + i * (int64_t)a.d_e : nullptr;
     float *GH = a.GH ? a.GH + i * (int64_t)a.d_e : nullptr;
     float *GT = a.GT ? a.GT + i * (int64_t)a.d_e : nullptr;
@@ -276,6 +287,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void edge_bwd_kernel(EdgeBwdArgs a) {
 
     if constexpr (!is_complex_model(MODEL)) {
         const int nit = a.d_e / V;
+        const float dp = dp_in;
         float inv = 0.f;
         if constexpr (MODEL == KGE_TRANSE_L2) {
             if (a.dpos) {   // |h + r - t|_2 for the positive-score gradient
@@ -320,6 +332,20 @@ __global__ __launch_bounds__(KGE_BLOCK) void edge_bwd_kernel(EdgeBwdArgs a) {
     } else {
         const int hd = a.d_e / 2;
         const int nit = hd / V;
+        float dp = dp_in;
+        if constexpr (MODEL == KGE_SIMPLE) {
+            if (a.clamp_pos && a.dpos) {
+                float ps = 0.f;
+                for (int it = lane; it < nit; it += 64) {
+                    const int off = it * V;
+                    const Pack<V> hi = ld<V>(h + off), hj = ld<V>(h + hd + off), ti = ld<V>(t + off), tj = ld<V>(t + hd + off);
+                    const Pack<V> c = ld<V>(r + off), sv = ld<V>(r + hd + off);
+#pragma unroll
+                    for (int e = 0; e < V; ++e) ps += 0.5f * (hi.v[e] * c.v[e] * tj.v[e] + ti.v[e] * sv.v[e] * hj.v[e]);
+                }
+                if (fabsf(wave_sum(ps)) >= KGE_SIMPLE_CLAMP) dp = 0.f;
+            }
+        }
         for (int it = lane; it < nit; it += 64) {
             const int off = it * V;
             const Pack<V> rh = ld<V>(h + off), ih = ld<V>(h + hd + off);
@@ -327,7 +353,28 @@ __global__ __launch_bounds__(KGE_BLOCK) void edge_bwd_kernel(EdgeBwdArgs a) {
             const Pack<V> gre = ga ? ld<V>(ga + off) : zero_pack<V>();
             const Pack<V> gim = ga ? ld<V>(ga + hd + off) : zero_pack<V>();
             Pack<V> o_rh, o_ih, o_rt, o_it;
-            if constexpr (MODEL == KGE_COMPLEX) {
+            if constexpr (MODEL == KGE_SIMPLE) {
+                const Pack<V> rr = ld<V>(r + off), ir = ld<V>(r + hd + off);
+                Pack<V> o_rr, o_ir;
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    // p = 1/2 sum(h_i r t_j + t_i r_inv h_j); a = 1/2 [r_inv h_j | h_i r] (tail mode) or
+                    // 1/2 [r t_j | r_inv t_i] (head mode); (gre, gim) = dL/da halves
+                    const float hi = rh.v[e], hj = ih.v[e], ti = rt.v[e], tj = it_.v[e];
+                    const float c = rr.v[e], s = ir.v[e], g1 = 0.5f * gre.v[e], g2 = 0.5f * gim.v[e], d = 0.5f * dp;
+                    float v_hi = d * c * tj, v_hj = d * ti * s, v_ti = d * s * hj, v_tj = d * hi * c;
+                    float v_r = d * hi * tj, v_ri = d * ti * hj;
+                    if (a.neg_head) { v_tj += g1 * c; v_r += g1 * tj; v_ti += g2 * s; v_ri += g2 * ti; }
+                    else            { v_hj += g1 * s; v_ri += g1 * hj; v_hi += g2 * c; v_r += g2 * hi; }
+                    if (reg) {
+                        v_r += reg_grad(c, a.reg_coef, a.reg_norm);
+                        v_ri += reg_grad(s, a.reg_coef, a.reg_norm);
+                    }
+                    o_rh.v[e] = v_hi; o_ih.v[e] = v_hj; o_rt.v[e] = v_ti; o_it.v[e] = v_tj;
+                    o_rr.v[e] = v_r; o_ir.v[e] = v_ri;
+                }
+                if (GR) { st<V>(GR + off, o_rr); st<V>(GR + hd + off, o_ir); }
+            } else if constexpr (MODEL == KGE_COMPLEX) {
                 const Pack<V> rr = ld<V>(r + off), ir = ld<V>(r + hd + off);
                 Pack<V> o_rr, o_ir;
 #pragma unroll
@@ -420,6 +467,7 @@ int launch_edge_bwd(const EdgeBwdArgs &a, hipStream_t s) {
         case KGE_DISTMULT: return launch_edge_bwd_m<KGE_DISTMULT>(a, s);
         case KGE_COMPLEX: return launch_edge_bwd_m<KGE_COMPLEX>(a, s);
         case KGE_ROTATE: return launch_edge_bwd_m<KGE_ROTATE>(a, s);
+        case KGE_SIMPLE: return launch_edge_bwd_m<KGE_SIMPLE>(a, s);
     }
     return KGE_ERR_ARG;
 }
@@ -451,12 +499,13 @@ __global__ __launch_bounds__(KGE_BLOCK) void loss_kernel(LossArgs a) {
             if (cp) cp[j] = nv;
             float g = -dd;
             if (a.l2_scale) { const float d = a.gamma - nv; g = d > 1e-15f ? g / d : 0.f; }
+            if (a.clampv > 0.f && fabsf(nv) >= a.clampv) g = 0.f;
             dn[j] = g;
         }
         lsum = wave_sum(lsum);
         dsum = wave_sum(dsum);
         if (lane == 0) {
-            a.dpos[i] = dsum;
+            a.dpos[i] = (a.clampv > 0.f && fabsf(p) >= a.clampv) ? 0.f : dsum;
             if (a.row_pos) { a.row_pos[i] = 0.f; a.row_neg[i] = lsum; }
             if (a.acc) acc_add(&a.acc[2 * KGE_ACC_SLOTS + (int)(i & (KGE_ACC_SLOTS - 1))], lsum, a.B <= KGE_ACC_SLOTS);
         }
@@ -466,7 +515,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void loss_kernel(LossArgs a) {
     if (lane == 0 && !a.skip_pos) {
         float pl, dpl;
         criterion(a.genre, p, 1.f, a.margin, pl, dpl);
-        a.dpos[i] = dpl * w * 0.5f * invB;
+        a.dpos[i] = (a.clampv > 0.f && fabsf(p) >= a.clampv) ? 0.f : dpl * w * 0.5f * invB;
         plw = pl * w * invB;
         if (a.row_pos) a.row_pos[i] = plw;
     }
@@ -490,6 +539,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void loss_kernel(LossArgs a) {
         float g = dnl * w * A * 0.5f * invB;
         if (cp) cp[j] = nv;
         if (a.l2_scale) { const float d = a.gamma - nv; g = d > 1e-15f ? g / d : 0.f; }
+        if (a.clampv > 0.f && fabsf(nv) >= a.clampv) g = 0.f;
         dn[j] = g;
     }
     acc = wave_sum(acc) * invB;
@@ -537,13 +587,14 @@ __global__ __launch_bounds__(KGE_BLOCK) void loss_kernel_reg(LossArgs a) {
                 if (cp) cp[j] = nv[u];
                 float g = -dd;
                 if (a.l2_scale) { const float d = a.gamma - nv[u]; g = d > 1e-15f ? g / d : 0.f; }
+                if (a.clampv > 0.f && fabsf(nv[u]) >= a.clampv) g = 0.f;
                 dn[j] = g;
             }
         }
         lsum = wave_sum(lsum);
         dsum = wave_sum(dsum);
         if (lane == 0) {
-            a.dpos[i] = dsum;
+            a.dpos[i] = (a.clampv > 0.f && fabsf(p) >= a.clampv) ? 0.f : dsum;
             if (a.row_pos) { a.row_pos[i] = 0.f; a.row_neg[i] = lsum; }
             if (a.acc) acc_add(&a.acc[2 * KGE_ACC_SLOTS + slot], lsum, a.B <= KGE_ACC_SLOTS);
         }
@@ -553,7 +604,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void loss_kernel_reg(LossArgs a) {
     if (lane == 0 && !a.skip_pos) {
         float pl, dpl;
         criterion(a.genre, p, 1.f, a.margin, pl, dpl);
-        a.dpos[i] = dpl * w * 0.5f * invB;
+        a.dpos[i] = (a.clampv > 0.f && fabsf(p) >= a.clampv) ? 0.f : dpl * w * 0.5f * invB;
         plw = pl * w * invB;
         if (a.row_pos) a.row_pos[i] = plw;
     }
@@ -585,6 +636,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void loss_kernel_reg(LossArgs a) {
             float g = dnl * w * A * 0.5f * invB;
             if (cp) cp[j] = nv[u];
             if (a.l2_scale) { const float d = a.gamma - nv[u]; g = d > 1e-15f ? g / d : 0.f; }
+            if (a.clampv > 0.f && fabsf(nv[u]) >= a.clampv) g = 0.f;
             dn[j] = g;
         }
     }

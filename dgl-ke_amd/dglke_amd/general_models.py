@@ -13,7 +13,7 @@ import torch as th
 from . import ops
 from .engine import StepEngine
 from .loss import LossGenerator
-from .score_fun import ComplExScore, DistMultScore, RotatEScore, TransEScore
+from .score_fun import ComplExScore, DistMultScore, RotatEScore, SimplEScore, TransEScore
 from .tensor_models import (ExternalEmbedding, cuda, get_dev, get_device, get_scalar, norm,
                             reshape)
 from ._lib import KgeError
@@ -66,9 +66,11 @@ class KEModel(object):
             self.score_func = ComplExScore()
         elif model_name == 'RotatE':
             self.score_func = RotatEScore(gamma, self.emb_init)
+        elif model_name == 'SimplE':
+            self.score_func = SimplEScore()
         else:
-            raise KgeError("model %s has no HIP kernel in this build (TransR / RESCAL / SimplE "
-                           "are listed as next in SURVEY.md 8f)" % model_name)
+            raise KgeError("model %s has no HIP kernel in this build (TransR / RESCAL are listed as "
+                           "next in SURVEY.md 8f)" % model_name)
         self.head_neg_score = self.score_func.create_neg(True)
         self.tail_neg_score = self.score_func.create_neg(False)
         self.head_neg_prepare = self.score_func.create_neg_prepare(True)

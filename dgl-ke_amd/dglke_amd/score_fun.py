@@ -3,7 +3,7 @@
 `create_neg`, `update`, `reset_parameters`, `save`, `load`.
 
 In scope (hand-written kernels, forward and analytic backward): TransE_l1 / TransE_l2
-(score_fun.py:40), DistMult (:222), ComplEx (:289), RotatE (:451).
+(score_fun.py:40), DistMult (:222), ComplEx (:289), RotatE (:451), SimplE (:556).
 """
 import torch as th
 
@@ -88,6 +88,24 @@ class DistMultScore(_HipScore):
 class ComplExScore(_HipScore):
     """score_fun.py:289-376"""
     model_name = 'ComplEx'
+
+
+class SimplEScore(_HipScore):
+    """score_fun.py:556-641: rows are [x_i | x_j] halves, relation rows [rel | rel_inv];
+    score = clamp(1/2 (<h_i, rel, t_j> + <t_i, rel_inv, h_j>), -20, 20)."""
+    model_name = 'SimplE'
+
+    def infer(self, head_emb, rel_emb, tail_emb):
+        """the reference's `infer` does NOT clamp (score_fun.py:570-577): run the un-clamped dot-product
+        kernel on the SimplE pos-side vectors 1/2 [rel_inv * h_j | h_i * rel]."""
+        H, R, T = head_emb.shape[0], rel_emb.shape[0], tail_emb.shape[0]
+        hd = head_emb.shape[1] // 2
+        hi, hj = head_emb[:, :hd].unsqueeze(1), head_emb[:, hd:].unsqueeze(1)
+        rel, rinv = rel_emb[:, :hd].unsqueeze(0), rel_emb[:, hd:].unsqueeze(0)
+        a = (0.5 * th.cat([rinv * hj, hi * rel], -1)).reshape(H * R, -1).contiguous()
+        s = ops.score_neg('DistMult', False, a, th.ones_like(a), tail_emb.contiguous(), 1, H * R, T, 0.0, 1.0,
+                          self.flags)
+        return s.reshape(H, R, T)
 
 
 class RotatEScore(_HipScore):

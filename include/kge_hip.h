@@ -36,7 +36,9 @@ enum kge_model {
     KGE_TRANSE_L2 = 1, /* score_fun.py:40  TransEScore(dist_func='l2') */
     KGE_DISTMULT  = 2, /* score_fun.py:222 DistMultScore */
     KGE_COMPLEX   = 3, /* score_fun.py:289 ComplExScore */
-    KGE_ROTATE    = 4  /* score_fun.py:451 RotatEScore */
+    KGE_ROTATE    = 4, /* score_fun.py:451 RotatEScore */
+    KGE_SIMPLE    = 5  /* score_fun.py:556 SimplEScore: rows = [x_i | x_j] halves, relation = [r | r_inv];
+                          scores are clamped to [-20, 20] like the reference (:568, :622, :641) */
 };
 
 /* loss criteria (models/pytorch/loss.py:44-59) */

@@ -19,7 +19,8 @@ All functions take/return numpy arrays; `dtype` selects float32 (reference preci
 """
 import numpy as np
 
-MODELS = ("TransE_l1", "TransE_l2", "DistMult", "ComplEx", "RotatE")
+MODELS = ("TransE_l1", "TransE_l2", "DistMult", "ComplEx", "RotatE", "SimplE")
+SIMPLE_CLAMP = 20.0          # th.clamp(score, -20, 20): score_fun.py:568, 622, 641
 LOSSES = ("Logsigmoid", "Logistic", "Hinge", "BCE")
 
 
@@ -86,6 +87,12 @@ def score_pos(model, h, r, t, gamma, emb_init=None):
         re = rh * c - ih * s - rt
         im = rh * s + ih * c - it
         return gamma - np.sqrt(re * re + im * im).sum(-1)
+    if model == "SimplE":      # score_fun.py:562-569
+        hi, hj = _halves(h)
+        ti, tj = _halves(t)
+        rel, rinv = _halves(r)
+        raw = 0.5 * (hi * rel * tj + ti * rinv * hj).sum(-1)
+        return np.clip(raw, -SIMPLE_CLAMP, SIMPLE_CLAMP)
     raise ValueError(model)
 
 
@@ -128,6 +135,16 @@ def score_pos_bwd(model, h, r, t, dp, gamma, emb_init=None):
         gt = np.concatenate([-gre, -gim], -1)
         gphi = gre * (-rh * s - ih * c) + gim * (rh * c - ih * s)
         return gh, gphi * scale, gt
+    if model == "SimplE":      # th.clamp passes the gradient where -20 <= raw <= 20
+        hi, hj = _halves(h)
+        ti, tj = _halves(t)
+        rel, rinv = _halves(r)
+        raw = 0.5 * (hi * rel * tj + ti * rinv * hj).sum(-1, keepdims=True)
+        d = 0.5 * dp * (np.abs(raw) <= SIMPLE_CLAMP)
+        gh = np.concatenate([d * rel * tj, d * ti * rinv], -1)
+        gt = np.concatenate([d * rinv * hj, d * hi * rel], -1)
+        gr = np.concatenate([d * hi * tj, d * ti * hj], -1)
+        return gh, gr, gt
     raise ValueError(model)
 
 
@@ -144,6 +161,14 @@ def pos_side(model, neg_head, x, r, emb_init=None):
         return x - r if neg_head else x + r
     if model == "DistMult":
         return x * r
+    if model == "SimplE":
+        # a . neg = the un-halved chunked score: head mode (score_fun.py:611-620) pairs rel*t_j with head_i
+        # and rel_inv*t_i with head_j; tail mode (:626-639) pairs rel_inv*h_j with tail_i and h_i*rel with tail_j
+        xi, xj = _halves(x)
+        rel, rinv = _halves(r)
+        if neg_head:
+            return np.concatenate([rel * xj, rinv * xi], -1)
+        return np.concatenate([rinv * xj, xi * rel], -1)
     if model in ("ComplEx", "RotatE"):
         rx, ix = _halves(x)
         if model == "ComplEx":
@@ -174,6 +199,8 @@ def score_neg(model, a, neg, C, chunk, N, gamma):
         return gamma - np.abs(A[:, :, None, :] - Bn[:, None, :, :]).sum(-1)
     if model in ("DistMult", "ComplEx"):
         return np.einsum("cik,cjk->cij", A, Bn)
+    if model == "SimplE":
+        return np.clip(0.5 * np.einsum("cik,cjk->cij", A, Bn), -SIMPLE_CLAMP, SIMPLE_CLAMP)
     if model == "RotatE":
         d = A[:, :, None, :] - Bn[:, None, :, :]
         re, im = _halves(d)
@@ -204,6 +231,11 @@ def score_neg_bwd(model, a, neg, dneg, C, chunk, N, gamma):
     elif model in ("DistMult", "ComplEx"):
         ga = np.einsum("cij,cjk->cik", G, Bn)
         gb = np.einsum("cij,cik->cjk", G, A)
+    elif model == "SimplE":
+        raw = 0.5 * np.einsum("cik,cjk->cij", A, Bn)
+        Gm = 0.5 * G * (np.abs(raw) <= SIMPLE_CLAMP)
+        ga = np.einsum("cij,cjk->cik", Gm, Bn)
+        gb = np.einsum("cij,cik->cjk", Gm, A)
     elif model == "RotatE":
         d = A[:, :, None, :] - Bn[:, None, :, :]
         re, im = _halves(d)
@@ -226,6 +258,13 @@ def pos_side_bwd(model, neg_head, x, r, ga, emb_init=None):
         return ga, (-ga if neg_head else ga)
     if model == "DistMult":
         return ga * r, ga * x
+    if model == "SimplE":
+        xi, xj = _halves(x)
+        rel, rinv = _halves(r)
+        g1, g2 = _halves(ga)
+        if neg_head:          # a = [rel * x_j | rinv * x_i]
+            return np.concatenate([g2 * rinv, g1 * rel], -1), np.concatenate([g1 * xj, g2 * xi], -1)
+        return np.concatenate([g2 * rel, g1 * rinv], -1), np.concatenate([g2 * xi, g1 * xj], -1)   # a = [rinv*x_j | x_i*rel]
     rx, ix = _halves(x)
     gre, gim = _halves(ga)
     if model == "ComplEx":

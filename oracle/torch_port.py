@@ -47,6 +47,11 @@ class TorchPort(object):
             rt, it = th.chunk(t, 2, dim=-1)
             rr, ir = th.chunk(r, 2, dim=-1)
             return th.sum(rh * rt * rr + ih * it * rr + rh * it * ir - ih * rt * ir, -1)
+        if m == "SimplE":
+            hi, hj = th.chunk(h, 2, dim=-1)
+            ti, tj = th.chunk(t, 2, dim=-1)
+            rel, rinv = th.chunk(r, 2, dim=-1)
+            return th.clamp(0.5 * (hi * rel * tj + ti * rinv * hj).sum(-1), -20, 20)
         rh, ih = th.chunk(h, 2, dim=-1)
         rt, it = th.chunk(t, 2, dim=-1)
         ph = r / (self.emb_init / np.pi)
@@ -70,6 +75,17 @@ class TorchPort(object):
             return self.gamma - sq.clamp_min_(1e-30).sqrt_()
         if m == "DistMult":
             return th.bmm((x * r).reshape(C, chunk, D), neg.reshape(C, N, D).transpose(1, 2))
+        if m == "SimplE":
+            xi, xj = x[..., :D // 2], x[..., D // 2:]
+            rel, rinv = r[..., :D // 2], r[..., D // 2:]
+            nt = neg.reshape(C, N, D).transpose(1, 2)
+            if neg_head:       # x = tails, neg = heads
+                fwd, bwd = (rel * xj).reshape(C, chunk, D // 2), (rinv * xi).reshape(C, chunk, D // 2)
+                tmp = 0.5 * (th.bmm(fwd, nt[..., :D // 2, :]) + th.bmm(bwd, nt[..., D // 2:, :]))
+            else:              # x = heads, neg = tails
+                fwd, bwd = (xi * rel).reshape(C, chunk, D // 2), (rinv * xj).reshape(C, chunk, D // 2)
+                tmp = 0.5 * (th.bmm(fwd, nt[..., D // 2:, :]) + th.bmm(bwd, nt[..., :D // 2, :]))
+            return th.clamp(tmp, -20, 20)
         rx, ix = x[..., :D // 2], x[..., D // 2:]
         if m == "ComplEx":
             rr, ir = r[..., :D // 2], r[..., D // 2:]

@@ -235,6 +235,12 @@ CASES = {
     "distmult_small": base("DistMult", gamma=6.0, hidden=16, lr=0.08, seed=9),
     "complex_small": base("ComplEx", gamma=6.0, de=True, dr=True, seed=10),
     "rotate_small": base("RotatE", gamma=12.0, de=True, seed=11),
+    # SimplE (score_fun.py:556): [x_i | x_j] halves, clamp(+-20); the large-scale case saturates the clamp
+    "simple_small": base("SimplE", gamma=6.0, de=True, dr=True, seed=41),
+    "simple_ragged": base("SimplE", hidden=10, de=True, dr=True, B=30, N=7, chunk=10, seed=42),
+    "simple_dups": base("SimplE", n_ent=9, n_rel=2, de=True, dr=True, steps=4, seed=43),
+    "simple_plain": base("SimplE", hidden=16, adv=False, reg_coef=0.0, seed=44),
+    "simple_clamped": base("SimplE", hidden=8, gamma=22.0, de=True, dr=True, lr=0.01, seed=45),
     # no adversarial weighting, no regularisation
     "transe_l2_noadv": base("TransE_l2", adv=False, reg_coef=0.0, seed=12),
     "distmult_noadv": base("DistMult", adv=False, reg_coef=0.0, seed=13),
