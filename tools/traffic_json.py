@@ -15,7 +15,7 @@ f, w = parse(sys.argv[1]), parse(sys.argv[2])
 G = int(sys.argv[5]) if len(sys.argv) > 5 else 120
 ours = lambda d: {k: (v / G if "sample_plan" in k else v) for k, v in d.items()
                   if "at::native" not in k and "rocclr" not in k and "reduce_acc" not in k and "rocprim" not in k
-                  and "randperm" not in k}
+                  and "randperm" not in k and "elementwise" not in k and "anonymous namespace" not in k}
 f, w = ours(f), ours(w)
 tot = sum(2 * v * 1024 for v in f.values()) + sum(v * 1024 for v in w.values())
 json.dump({"build": sys.argv[3], "workload": sys.argv[4], "fetch_kb_per_launch": f, "write_kb_per_launch": w,
