@@ -112,17 +112,79 @@ def save_model(args, model, emap_file=None, rmap_file=None):
         json.dump(conf, f, indent=4)
 
 
+class _Lane(object):
+    """one trainer: a StepEngine (sharing the tables), its sampler over its share of the training triples,
+    its HIP stream and - device sampler - a hipGraph of [1 sampler launch + G steps].  `--num_proc K` on
+    one GPU = K lanes running concurrently, lock-free on the same tables: the reference's multi-process
+    Hogwild training (train.py:298-317, RandomPartition of the edges sampler.py:256-290) with the
+    processes replaced by streams."""
+
+    def __init__(self, trainer, k, engine, triples, weights):
+        from .dataloader import DeviceSampler, UniformChunkedSampler
+        a = trainer.args
+        self.t, self.k, self.engine = trainer, k, engine
+        self.stream = th.cuda.current_stream() if trainer.n_lanes == 1 else th.cuda.Stream(device=trainer.dev)
+        B, N, chunk = a.batch_size, a.neg_sample_size, trainer.chunk
+        n_ent = trainer.dataset.n_entities
+        if trainer.device_sampler:
+            self.sampler = DeviceSampler(triples[0], triples[1], triples[2], n_ent, B, N, trainer.dev,
+                                         n_slots=max(2, a.graph_steps or 2), neg_chunk_size=chunk, seed=a.seed + 1000 * k)
+        else:
+            self.sampler = UniformChunkedSampler(triples[0], triples[1], triples[2], n_ent, B, N, trainer.dev,
+                                                 neg_chunk_size=chunk, seed=a.seed + 1000 * k, edge_importance=weights)
+        self._graph = None
+
+    def enqueue(self, n):
+        """enqueue n steps on this lane's stream (no synchronisation)."""
+        t, eng = self.t, self.engine
+        with th.cuda.stream(self.stream):
+            if not t.fused:
+                for _ in range(n):           # drop-in path (autograd Functions over the modular kernels)
+                    pos_g, neg_g = next(self.sampler)
+                    loss, log = t.model.forward(pos_g, neg_g, t.args.gpu[0])
+                    loss.backward()
+                    t.model.update(t.args.gpu[0])
+                return
+            if not t.device_sampler:
+                for b in self.sampler.next_batches(n):
+                    eng.step(b)
+                return
+            G, smp, done = t.args.graph_steps, self.sampler, 0
+            if G >= 2 and G % 2 == 0 and n >= G and smp.host_step % 2 == 1:
+                if self._graph is None:
+                    for b in smp.sample(G):           # eager warm-up (also allocates the workspace)
+                        eng.step(b)
+                    done += G
+                    if n - done >= G:
+                        self.stream.synchronize()
+                        g = th.cuda.CUDAGraph()
+                        with th.cuda.graph(g, stream=self.stream if t.n_lanes > 1 else None):
+                            for b in smp.sample(G):
+                                eng.step(b)
+                        self._graph = g
+                        smp.host_step -= G            # the capture itself did not run the steps
+                while self._graph is not None and n - done >= G:
+                    self._graph.replay()
+                    smp.host_step += G
+                    done += G
+            while done < n:                           # remainder: eager, any count
+                k = min(smp.n_slots, n - done)
+                for b in smp.sample(k):
+                    eng.step(b)
+                done += k
+
+
 class Trainer(object):
     """the training loop of train_pytorch.py:105-196 over the fused step."""
 
     def __init__(self, args, dataset):
-        from .dataloader import DeviceSampler, UniformChunkedSampler
+        from .engine import StepEngine
         from .general_models import KEModel
         self.args = args
         self.dataset = dataset
         if args.gpu[0] < 0:
             raise KgeError("dglke_amd trains on the GPU only: pass --gpu <id> (there is no CPU fallback)")
-        if len(args.gpu) > 1 or args.num_proc > 1:
+        if len(args.gpu) > 1:
             raise KgeError("multi-GPU training runs one process per GPU under torch.distributed.run "
                            "(see bench_dist.py / dglke_amd.p2p); this entry point drives one GPU")
         th.cuda.set_device(args.gpu[0])
@@ -132,57 +194,33 @@ class Trainer(object):
                              args.gamma, double_entity_emb=args.double_ent, double_relation_emb=args.double_rel)
         tr = dataset.train
         B, N = args.batch_size, args.neg_sample_size
-        chunk = N if N <= B else B
-        C = B // chunk
+        self.chunk = N if N <= B else B
+        C = B // self.chunk
         self.fused = not args.neg_deg_sample
         self.device_sampler = self.fused and not args.has_edge_importance and 2 * B + C * N <= 4096
-        w = tr[3] if args.has_edge_importance else None
-        if self.device_sampler:
-            self.sampler = DeviceSampler(tr[0], tr[1], tr[2], dataset.n_entities, B, N, self.dev,
-                                         n_slots=max(2, args.graph_steps or 2), neg_chunk_size=chunk, seed=args.seed)
-        else:
-            self.sampler = UniformChunkedSampler(tr[0], tr[1], tr[2], dataset.n_entities, B, N, self.dev,
-                                                 neg_chunk_size=chunk, seed=args.seed, edge_importance=w)
-        self._graph = None
-        self._graph_n = 0
+        self.n_lanes = max(1, int(args.num_proc))
+        if self.n_lanes > 1 and not self.fused:
+            raise KgeError("--num_proc > 1 needs the fused step (not available with --neg_deg_sample)")
+        # the lanes share the tables; every lane trains on its own random share of the triples
+        m = self.model
+        tables = (m.entity_emb.emb, m.entity_emb.state_sum, m.relation_emb.emb, m.relation_emb.state_sum)
+        parts = np.array_split(np.random.RandomState(args.seed).permutation(len(tr[0])), self.n_lanes)
+        self.lanes = []
+        for k in range(self.n_lanes):
+            eng = m.engine if k == 0 else StepEngine(
+                args.model_name, dataset.n_entities, dataset.n_relations, args.hidden_dim, args.gamma, args.lr,
+                self.dev, args.double_ent, args.double_rel, args.neg_adversarial_sampling,
+                args.adversarial_temperature, args.regularization_coef, args.regularization_norm, args.loss_genre,
+                args.pairwise, args.margin, tables=tables)
+            sel = parts[k] if self.n_lanes > 1 else slice(None)
+            trip = tuple(np.asarray(x)[sel] for x in tr[:3])
+            w = np.asarray(tr[3])[sel] if args.has_edge_importance else None
+            self.lanes.append(_Lane(self, k, eng, trip, w))
 
-    # ---- n fused steps, as few launches as possible ---------------------------------------
     def _run(self, n):
-        eng = self.model.engine
-        if not self.fused:
-            for _ in range(n):               # drop-in path (autograd Functions over the modular kernels)
-                pos_g, neg_g = next(self.sampler)
-                loss, log = self.model.forward(pos_g, neg_g, self.args.gpu[0])
-                loss.backward()
-                self.model.update(self.args.gpu[0])
-            return
-        if not self.device_sampler:
-            for b in self.sampler.next_batches(n):
-                eng.step(b)
-            return
-        G = self.args.graph_steps
-        done = 0
-        if G >= 2 and G % 2 == 0 and n >= G and self.sampler.host_step % 2 == 1:
-            if self._graph is None:
-                for b in self.sampler.sample(G):      # eager warm-up (also allocates the workspace)
-                    eng.step(b)
-                done += G
-                if n - done >= G:
-                    g = th.cuda.CUDAGraph()
-                    with th.cuda.graph(g):
-                        for b in self.sampler.sample(G):
-                            eng.step(b)
-                    self._graph, self._graph_n = g, G
-                    self.sampler.host_step -= G       # the capture itself did not run the steps
-            while self._graph is not None and n - done >= G:
-                self._graph.replay()
-                self.sampler.host_step += G
-                done += G
-        while done < n:                               # remainder: eager, any count
-            k = min(self.sampler.n_slots, n - done)
-            for b in self.sampler.sample(k):
-                eng.step(b)
-            done += k
+        """n steps on every lane, concurrently (no synchronisation here)."""
+        for lane in self.lanes:
+            lane.enqueue(n)
 
     def evaluate(self, which, mode):
         from . import eval as kev
@@ -233,13 +271,15 @@ class Trainer(object):
                 t_train += time.time() - t0
                 step, since_log = nxt, since_log + n
             if step % args.log_interval == 0 and since_log:
-                if self.fused:
-                    sums = eng.read_loss_sums()
-                    for k in keys:
-                        print('[proc {}][Train]({}/{}) average {}: {}'.format(0, step, args.max_step, k,
-                                                                            sums[idx[k]] / since_log))
-                print('[proc {}][Train] {} steps take {:.3f} seconds'.format(0, since_log, time.time() - start))
-                print('[proc {}]sample+forward+backward+update (fused HIP step): {:.3f}'.format(0, t_train))
+                for lane in self.lanes:
+                    if self.fused:
+                        sums = lane.engine.read_loss_sums()
+                        for k in keys:
+                            print('[proc {}][Train]({}/{}) average {}: {}'.format(lane.k, step, args.max_step, k,
+                                                                                sums[idx[k]] / since_log))
+                    print('[proc {}][Train] {} steps take {:.3f} seconds'.format(lane.k, since_log, time.time() - start))
+                print('[proc {}]sample+forward+backward+update (fused HIP step{}): {:.3f}'.format(
+                    0, '' if self.n_lanes == 1 else ', %d concurrent trainers' % self.n_lanes, t_train))
                 since_log, start = 0, time.time()
             if args.valid and step % args.eval_interval == 0 and step > 1 and self.dataset.valid is not None:
                 valid_start = time.time()

@@ -78,3 +78,23 @@ def test_train_cli_host_sampler_paths(tmp_path, capsys):
     T.main(base + ["--data_files", "e.dict", "r.dict", "train.txt", "--batch_size", "2048", "--neg_sample_size", "128"])
     out = capsys.readouterr().out
     assert out.count("(300/300) average loss:") == 2
+
+
+def test_train_cli_hogwild_lanes(tmp_path, capsys):
+    """--num_proc 3 on one GPU: three concurrent lock-free trainers (streams) on the shared tables, each on
+    its own share of the triples - the reference's multi-process mode; it must still learn."""
+    from dglke_amd import train as T
+    data = str(tmp_path / "kg")
+    _planted(data)
+    tr = T.main(["--model_name", "TransE_l2", "--format", "udd_hrt", "--dataset", "toy", "--data_path", data,
+                 "--data_files", "e.dict", "r.dict", "train.txt", "valid.txt", "test.txt", "--save_path",
+                 str(tmp_path / "ckpts"), "--gpu", "0", "--batch_size", "256", "--neg_sample_size", "64",
+                 "--hidden_dim", "32", "-g", "8", "--lr", "0.25", "-adv", "-rc", "1e-7", "--max_step", "600",
+                 "--log_interval", "300", "--num_proc", "3", "--test", "--no_save_emb", "--graph_steps", "100"])
+    out = capsys.readouterr().out
+    assert len(tr.lanes) == 3 and len({id(l.engine) for l in tr.lanes}) == 3
+    assert tr.lanes[1].engine.ent.data_ptr() == tr.model.entity_emb.emb.data_ptr()     # shared tables
+    for k in range(3):
+        assert "[proc %d][Train](600/600) average loss:" % k in out
+    mrr = float([l for l in out.split("\n") if l.startswith("[0]Test average MRR:")][0].split(":")[1])
+    assert mrr > 10 * 2.0 / 400
