@@ -40,7 +40,12 @@ struct Carver {
 };
 
 int check_model(int model, int d_e, int d_r) {
-    if (model < KGE_TRANSE_L1 || model > KGE_SIMPLE) return fail(KGE_ERR_ARG, "unknown model %d", model);
+    if (model < KGE_TRANSE_L1 || model > KGE_RESCAL) return fail(KGE_ERR_ARG, "unknown model %d", model);
+    if (model == KGE_RESCAL) {
+        if (d_e <= 0 || d_e > 1024 || (int64_t)d_r != (int64_t)d_e * d_e)
+            return fail(KGE_ERR_ARG, "RESCAL needs d_r == d_e*d_e and d_e <= 1024 (got d_e=%d d_r=%d)", d_e, d_r);
+        return KGE_OK;
+    }
     if (d_e <= 0 || d_r <= 0) return fail(KGE_ERR_ARG, "bad dims d_e=%d d_r=%d", d_e, d_r);
     if (model == KGE_COMPLEX || model == KGE_SIMPLE) {
         if (d_e % 2 || d_r != d_e) return fail(KGE_ERR_ARG, "%s needs even d_e and d_r == d_e (got %d, %d)",
@@ -93,6 +98,12 @@ int kge_score_pos(int model, const float *h, const float *r, const float *t, int
                   int d_r, float gamma, float emb_init, float *out, void *stream) {
     if (int rc = check_model(model, d_e, d_r)) return rc;
     if (!h || !r || !t || !out || B < 0) return fail(KGE_ERR_ARG, "kge_score_pos: bad argument");
+    if (model == KGE_RESCAL) {                       // p = h . (M t), one pass over M per edge
+        RescalMatvecArgs m{};
+        m.B = (int)B; m.D = d_e; m.rel = r; m.y1 = t; m.pd = h; m.p = out;
+        KGE_TRY(launch_rescal_matvec(m, (hipStream_t)stream));
+        return KGE_OK;
+    }
     EdgeFwdArgs a{};
     a.src = EdgeSrc{h, nullptr, t, nullptr, r, nullptr};
     a.B = (int)B; a.d_e = d_e; a.d_r = d_r; a.neg_head = 0; a.model = model;
@@ -107,6 +118,19 @@ int kge_score_pos_bwd(int model, const float *h, const float *r, const float *t,
                       float *gt, void *stream) {
     if (int rc = check_model(model, d_e, d_r)) return rc;
     if (!h || !r || !t || !dpos || B < 0) return fail(KGE_ERR_ARG, "kge_score_pos_bwd: bad argument");
+    if (model == KGE_RESCAL) {                       // gh = dp M t, gt = dp M^T h, gr = dp h t^T
+        if (!gh || !gt || !gr) return fail(KGE_ERR_ARG, "kge_score_pos_bwd: RESCAL needs all three outputs");
+        hipStream_t s = (hipStream_t)stream;
+        RescalMatvecArgs m{};
+        m.B = (int)B; m.D = d_e; m.rel = r; m.y1 = t; m.r1 = gh; m.z1 = h; m.c1 = gt;
+        KGE_TRY(launch_rescal_matvec(m, s));
+        KGE_TRY(launch_rescal_axpy(dpos, gh, nullptr, (int)B, d_e, gh, s));
+        KGE_TRY(launch_rescal_axpy(dpos, gt, nullptr, (int)B, d_e, gt, s));
+        RescalOuterArgs o{};
+        o.B = (int)B; o.D = d_e; o.c = dpos; o.u = h; o.v = t; o.G = gr;
+        KGE_TRY(launch_rescal_outer(o, s));
+        return KGE_OK;
+    }
     EdgeBwdArgs a{};
     a.src = EdgeSrc{h, nullptr, t, nullptr, r, nullptr};
     a.B = (int)B; a.d_e = d_e; a.d_r = d_r; a.neg_head = 0; a.model = model;
@@ -138,6 +162,12 @@ static int neg_prepare(int model, int neg_head, const float *pos_side, const flo
     A = cv.f((size_t)B * d_e);
     asq = cv.f(B); bsq = cv.f((size_t)C * N);
     if (!cv.ok()) return fail(KGE_ERR_WORKSPACE, "workspace too small");
+    if (model == KGE_RESCAL) {
+        RescalMatvecArgs m{};
+        m.B = B; m.D = d_e; m.rel = rel; m.y1 = pos_side; m.r1 = A;
+        KGE_TRY(launch_rescal_matvec(m, s));
+        return KGE_OK;
+    }
     EdgeFwdArgs a{};
     a.src = EdgeSrc{pos_side, nullptr, pos_side, nullptr, rel, nullptr};
     a.B = B; a.d_e = d_e; a.d_r = d_r; a.neg_head = neg_head; a.model = model;
@@ -228,6 +258,15 @@ int kge_score_neg_bwd(int model, int neg_head, const float *pos_side, const floa
         NegArgs na; fill_pair(na, model, C, chunk, N, d_e, gamma, A, neg, nullptr);
         na.W = Wuse; na.GA = GA; na.GN = g_neg;
         KGE_TRY(launch_neg_bwd_pair(na, s));
+    }
+    if (model == KGE_RESCAL) {                       // a = M x:  dL/dx = M^T GA,  dL/dM = GA x^T
+        RescalMatvecArgs m{};
+        m.B = B; m.D = d_e; m.rel = rel; m.z1 = GA; m.c1 = g_pos_side;
+        KGE_TRY(launch_rescal_matvec(m, s));
+        RescalOuterArgs o{};
+        o.B = B; o.D = d_e; o.u = GA; o.v = pos_side; o.G = g_rel;
+        KGE_TRY(launch_rescal_outer(o, s));
+        return KGE_OK;
     }
     EdgeBwdArgs e{};
     e.src = EdgeSrc{pos_side, nullptr, pos_side, nullptr, rel, nullptr};
@@ -325,7 +364,9 @@ size_t kge_step_workspace_bytes(const kge_hparams *hp, int B, int C, int chunk, 
     add(B * d_e);        // GA
     add(CN * d_e);       // GN
     add(B * d_e);        // P (TransE) or GH
-    add(B * d_e); add(B * d_r);   // GT, GR
+    add(B * d_e);                 // GT
+    if (hp->model == KGE_RESCAL) { add(B * d_e); add(B * d_e); add(B * d_e); }   // V = M t, M^T h, M^T GA (no [B, d_r] buffer)
+    else add(B * d_r);            // GR
     add(B); add(B); add(UE); add(UR);           // row_pos, row_neg, reg_ent, reg_rel
     return n;
 }
@@ -343,6 +384,8 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         rm = kge::ShardMap{sh->rel_rows, sh->rel_state, sh->rel_rows_per_shard, sh->n_shards};
     }
     if (int rc = check_model(hp->model, hp->d_e, hp->d_r)) return rc;
+    if (hp->model == KGE_RESCAL && (sh || emit))
+        return fail(KGE_ERR_ARG, "RESCAL is not available in the sharded / gradient-emitting steps");
     if (b->B <= 0 || b->C <= 0 || b->chunk <= 0 || b->N <= 0 || (int64_t)b->C * b->chunk != b->B)
         return fail(KGE_ERR_ARG, "kge_step: need C*chunk == B (B=%d C=%d chunk=%d)", b->B, b->C, b->chunk);
     if (hp->loss_genre < KGE_LOSS_LOGSIGMOID || hp->loss_genre > KGE_LOSS_BCE)
@@ -376,7 +419,11 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     float *S = cv.f((size_t)B * N);
     float *PM = cv.f((size_t)B * tj16), *PS = cv.f((size_t)B * tj16);
     float *GA = cv.f((size_t)B * d_e), *GN = cv.f((size_t)CN * d_e);
-    float *GH = cv.f((size_t)B * d_e), *GT = cv.f((size_t)B * d_e), *GR = cv.f((size_t)B * d_r);
+    const bool rescal = hp->model == KGE_RESCAL;
+    float *GH = cv.f((size_t)B * d_e), *GT = cv.f((size_t)B * d_e);
+    float *RV = rescal ? cv.f((size_t)B * d_e) : nullptr, *RC1 = rescal ? cv.f((size_t)B * d_e) : nullptr;
+    float *RC2 = rescal ? cv.f((size_t)B * d_e) : nullptr;
+    float *GR = rescal ? nullptr : cv.f((size_t)B * d_r);
     float *row_pos = cv.f(B), *row_neg = cv.f(B), *reg_ent = cv.f(b->UE), *reg_rel = cv.f(b->UR);
     if (!cv.ok())
         return fail(KGE_ERR_WORKSPACE, "kge_step: workspace too small (%zu < %zu)", ws_bytes,
@@ -407,7 +454,23 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     ef.do_pos_loss = pairwise ? 0 : 1; ef.lp = lp; ef.w = b->edge_w;
     ef.dpos = dP; ef.row_pos = want4 ? row_pos : nullptr; ef.acc = acc;
     ef.P = transe_fast ? Pg : nullptr;
-    KGE_TRY(launch_edge_fwd(ef, s));
+    if (rescal) {
+        // V = M t (always: p = h.V), A = M x with x = h in tail mode (then a second product of the same pass)
+        RescalMatvecArgs m{};
+        m.B = B; m.D = d_e; m.rel = tb->rel; m.ridx = b->rel_ids;
+        m.y1 = tb->ent; m.y1idx = b->t_gid; m.r1 = b->neg_head ? A : RV;
+        if (!b->neg_head) { m.y2 = tb->ent; m.y2idx = b->h_gid; m.r2 = A; }
+        m.pd = tb->ent; m.pdidx = b->h_gid; m.p = P;
+        KGE_TRY(launch_rescal_matvec(m, s));
+        if (dense_neg) {                 // pairwise fallback kernels read a dense copy of the negative rows
+            EdgeFwdArgs nb{};
+            nb.B = 0; nb.d_e = d_e; nb.d_r = d_e; nb.model = KGE_DISTMULT; nb.nbase = tb->ent; nb.nidx = b->neg_ids;
+            nb.n_neg = CN; nb.Bn = Bn;
+            KGE_TRY(launch_edge_fwd(nb, s));
+        }
+    } else {
+        KGE_TRY(launch_edge_fwd(ef, s));
+    }
 
     // 2. chunked negative scores (+ per-16-column partial row statistics for the adversarial softmax)
     GemmArgs g; NegArgs na;
@@ -433,7 +496,7 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         la.acc = acc;
         la.l2_scale = is_l2 ? 1 : 0; la.gamma = hp->gamma; la.clampv = clamp_of(hp->model);
         la.neg_copy = out ? out->neg_score : nullptr;
-        la.skip_pos = pairwise ? 0 : 1;
+        la.skip_pos = (pairwise || rescal) ? 0 : 1;          // RESCAL: no edge_fwd -> positive part here
         KGE_TRY(launch_loss(la, s));
     }
 
@@ -456,7 +519,35 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     }
 
     // 5. per-edge gradients of head / tail / relation rows (TransE rebuilds them in the update)
-    if (!transe_fast) {
+    const float *Vr = rescal ? (b->neg_head ? A : RV) : nullptr;           // RESCAL: M t
+    if (rescal) {
+        // one pass over M per edge: M^T h and M^T GA;  GH = dp M t (+ M^T GA, tail mode),
+        // GT = dp M^T h (+ M^T GA, head mode);  the relation gradient stays factored (update below)
+        RescalMatvecArgs m{};
+        m.B = B; m.D = d_e; m.rel = tb->rel; m.ridx = b->rel_ids;
+        m.z1 = tb->ent; m.z1idx = b->h_gid; m.c1 = RC1;
+        m.z2 = GA; m.c2 = RC2;
+        KGE_TRY(launch_rescal_matvec(m, s));
+        KGE_TRY(launch_rescal_axpy(dP, Vr, b->neg_head ? nullptr : RC2, B, d_e, GH, s));
+        KGE_TRY(launch_rescal_axpy(dP, RC1, b->neg_head ? RC2 : nullptr, B, d_e, GT, s));
+        if (out && out->g_rel) {        // test / debugging output: materialise dp h t^T + GA x^T + regulariser
+            RescalOuterArgs o{};
+            o.B = B; o.D = d_e; o.c = dP; o.u = tb->ent; o.uidx = b->h_gid; o.v = tb->ent; o.vidx = b->t_gid;
+            o.G = out->g_rel;
+            KGE_TRY(launch_rescal_outer(o, s));
+            o.c = nullptr; o.u = GA; o.uidx = nullptr; o.vidx = b->neg_head ? b->t_gid : b->h_gid; o.accumulate = 1;
+            if (reg) { o.rel = tb->rel; o.ridx = b->rel_ids; o.reg_coef = hp->reg_coef; o.reg_norm = hp->reg_norm; }
+            KGE_TRY(launch_rescal_outer(o, s));
+        }
+        // relation matrices first: the entity update below changes the h / t rows this kernel reads
+        RescalUpdateArgs ru{};
+        ru.D = d_e; ru.UE = b->UE; ru.UR = b->UR; ru.neg_head = b->neg_head; ru.reg_norm = hp->reg_norm;
+        ru.lr = hp->lr; ru.eps = hp->eps; ru.reg_coef = reg ? hp->reg_coef : 0.f;
+        ru.rel = tb->rel; ru.rel_state = tb->rel_state; ru.ent = tb->ent; ru.hidx = b->h_gid; ru.tidx = b->t_gid;
+        ru.dpos = dP; ru.GA = GA; ru.ur_id = b->ur_id; ru.ur_ptr = b->ur_ptr; ru.ur_edge = b->ur_edge;
+        ru.counts_dev = b->counts_dev; ru.reg_rel = want4 ? reg_rel : nullptr; ru.acc = acc;
+        KGE_TRY(launch_rescal_update_rel(ru, s));
+    } else if (!transe_fast) {
         EdgeBwdArgs eb{};
         eb.src = src; eb.B = B; eb.d_e = d_e; eb.d_r = d_r; eb.neg_head = b->neg_head; eb.model = hp->model;
         eb.gamma = hp->gamma; eb.rot_div = rot_div;
@@ -478,7 +569,7 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
 
     // 6. owner-computes Adagrad on both tables (or gradient emission for sharded training)
     UpdateArgs ua{};
-    ua.model_d_e = d_e; ua.d_r = d_r; ua.UE = b->UE; ua.UR = b->UR; ua.reg_norm = hp->reg_norm;
+    ua.model_d_e = d_e; ua.d_r = rescal ? d_e : d_r; ua.UE = b->UE; ua.UR = rescal ? 0 : b->UR; ua.reg_norm = hp->reg_norm;
     ua.lr = hp->lr; ua.eps = hp->eps; ua.reg_coef = reg ? hp->reg_coef : 0.f;
     ua.ent = tb->ent; ua.ent_state = tb->ent_state; ua.rel = tb->rel; ua.rel_state = tb->rel_state;
     ua.em = em; ua.rm = rm;
@@ -537,6 +628,7 @@ size_t kge_rank_workspace_bytes(int Eb, int64_t n_cand, int d_e) {
     n += 2 * align_up((size_t)Eb * sizeof(float));          // asq, P
     n += align_up((size_t)n_cand * sizeof(float));          // bsq
     n += align_up((size_t)Eb * (size_t)n_cand * sizeof(float));   // S
+    n += align_up((size_t)Eb * d_e * sizeof(float));        // V = M t (RESCAL)
     return n;
 }
 
@@ -557,6 +649,7 @@ int kge_rank_eval(int model, int neg_head, const float *ent, int64_t n_ent, cons
     Carver cv(ws, ws_bytes);
     float *A = cv.f((size_t)Eb * d_e), *asq = cv.f(Eb), *P = cv.f(Eb), *bsq = cv.f((size_t)N);
     float *S = cv.f((size_t)Eb * (size_t)N);
+    float *RV = cv.f((size_t)Eb * d_e);
     if (!cv.ok()) return fail(KGE_ERR_WORKSPACE, "kge_rank_eval: workspace too small (%zu < %zu)", ws_bytes,
                               kge_rank_workspace_bytes(Eb, N, d_e));
     const bool gemm = use_mfma(model, d_e, (int)N, flags);
@@ -575,7 +668,16 @@ int kge_rank_eval(int model, int neg_head, const float *ent, int64_t n_ent, cons
         ef.B = rows; ef.d_e = d_e; ef.d_r = d_r; ef.neg_head = neg_head; ef.model = model;
         ef.gamma = gamma; ef.rot_div = rot_div;
         ef.pos_score = pos_score_out ? pos_score_out + e0 : P; ef.A = A; ef.asq = l2g ? asq : nullptr;
-        KGE_TRY(launch_edge_fwd(ef, s));
+        if (model == KGE_RESCAL) {
+            RescalMatvecArgs m{};
+            m.B = rows; m.D = d_e; m.rel = rel; m.ridx = r + e0;
+            m.y1 = ent; m.y1idx = t + e0; m.r1 = neg_head ? A : RV;
+            if (!neg_head) { m.y2 = ent; m.y2idx = h + e0; m.r2 = A; }
+            m.pd = ent; m.pdidx = h + e0; m.p = ef.pos_score;
+            KGE_TRY(launch_rescal_matvec(m, s));
+        } else {
+            KGE_TRY(launch_edge_fwd(ef, s));
+        }
         if (gemm) {
             GemmArgs g; fill_gemm(g, model, 1, rows, (int)N, d_e, gamma, A, ent, cand);
             g.S = S; g.asq = asq; g.bsq = bsq;

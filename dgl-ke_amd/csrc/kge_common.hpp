@@ -316,6 +316,38 @@ int launch_neg_fwd_gemm(const GemmArgs &a, hipStream_t s);
 int launch_neg_bwd_gemm(const GemmArgs &a, hipStream_t s);
 int launch_neg_fwd_pair(const NegArgs &a, hipStream_t s);
 int launch_neg_bwd_pair(const NegArgs &a, hipStream_t s);
+// ---- RESCAL (kge_rescal.hip) ----
+struct RescalMatvecArgs {            // one pass over M_i = rel + (ridx ? ridx[i] : i) * D*D per edge i
+    int B, D;
+    const float *rel; const int64_t *ridx;
+    const float *y1; const int64_t *y1idx;   // r1 = M y1   (vectors: base + (idx ? idx[i] : i) * D; null = absent)
+    const float *y2; const int64_t *y2idx;   // r2 = M y2
+    const float *z1; const int64_t *z1idx;   // c1 = M^T z1
+    const float *z2; const int64_t *z2idx;   // c2 = M^T z2
+    const float *pd; const int64_t *pdidx;   // p  = pd . (M y1)
+    float *r1, *r2, *c1, *c2;                // [B,D] outputs or null
+    float *p;                                // [B] or null
+};
+struct RescalOuterArgs {             // G_i = c_i * u_i v_i^T (+ G_i) (+ regulariser gradient of M_i)
+    int B, D;
+    const float *c; const float *u; const int64_t *uidx; const float *v; const int64_t *vidx;
+    const float *rel; const int64_t *ridx; float reg_coef; int reg_norm;
+    int accumulate;
+    float *G;                                // [B, D*D]
+};
+struct RescalUpdateArgs {            // fused Adagrad of the relation matrices (one workgroup per unique relation)
+    int D, UE, UR, neg_head, reg_norm;
+    float lr, eps, reg_coef;
+    float *rel, *rel_state;
+    const float *ent; const int64_t *hidx, *tidx;
+    const float *dpos, *GA;
+    const int64_t *ur_id; const int32_t *ur_ptr, *ur_edge; const int32_t *counts_dev;
+    float *reg_rel, *acc;
+};
+int launch_rescal_matvec(const RescalMatvecArgs &a, hipStream_t s);
+int launch_rescal_axpy(const float *s1, const float *u1, const float *u2, int B, int D, float *out, hipStream_t s);
+int launch_rescal_outer(const RescalOuterArgs &a, hipStream_t s);
+int launch_rescal_update_rel(const RescalUpdateArgs &a, hipStream_t s);
 bool neg_bcast_supported(int model, int d_e);          // kge_neg_bcast.hip: lane = row, other operand wave-uniform
 int launch_neg_fwd_bcast(const NegArgs &a, hipStream_t s);
 int launch_neg_bwd_bcast(const NegArgs &a, hipStream_t s);

@@ -197,7 +197,7 @@ int launch_neg_fwd_bcast(const NegArgs &a, hipStream_t s) {
     switch (a.model) {
         case KGE_TRANSE_L1: return fwd_launch<KGE_TRANSE_L1>(a, s);
         case KGE_TRANSE_L2: return fwd_launch<KGE_TRANSE_L2>(a, s);
-        case KGE_DISTMULT: case KGE_COMPLEX: case KGE_SIMPLE: return fwd_launch<KGE_DISTMULT>(a, s);
+        case KGE_DISTMULT: case KGE_COMPLEX: case KGE_SIMPLE: case KGE_RESCAL: return fwd_launch<KGE_DISTMULT>(a, s);
         case KGE_ROTATE: return fwd_launch<KGE_ROTATE>(a, s);
     }
     return KGE_ERR_ARG;
@@ -368,7 +368,7 @@ int launch_neg_bwd_bcast(const NegArgs &a, hipStream_t s) {
     switch (a.model) {
         case KGE_TRANSE_L1: return bwd_launch<KGE_TRANSE_L1>(a, s);
         case KGE_TRANSE_L2: return bwd_launch<KGE_TRANSE_L2>(a, s);
-        case KGE_DISTMULT: case KGE_COMPLEX: case KGE_SIMPLE: return bwd_launch<KGE_DISTMULT>(a, s);
+        case KGE_DISTMULT: case KGE_COMPLEX: case KGE_SIMPLE: case KGE_RESCAL: return bwd_launch<KGE_DISTMULT>(a, s);
         case KGE_ROTATE: return bwd_launch<KGE_ROTATE>(a, s);
     }
     return KGE_ERR_ARG;

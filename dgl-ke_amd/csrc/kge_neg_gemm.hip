@@ -35,7 +35,8 @@ using namespace kge;
 
 bool neg_mfma_supported(int model, int d_e, int N) {
     (void)N;
-    if (model != KGE_TRANSE_L2 && model != KGE_DISTMULT && model != KGE_COMPLEX && model != KGE_SIMPLE) return false;
+    if (model != KGE_TRANSE_L2 && model != KGE_DISTMULT && model != KGE_COMPLEX && model != KGE_SIMPLE &&
+        model != KGE_RESCAL) return false;
     return d_e % 4 == 0;   // 16-byte aligned rows
 }
 

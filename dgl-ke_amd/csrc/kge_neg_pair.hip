@@ -137,7 +137,7 @@ int launch_neg_fwd_pair(const NegArgs &a, hipStream_t s) {
             hipLaunchKernelGGL(neg_fwd_pair_kernel<KGE_TRANSE_L1>, dim3(nb), dim3(KGE_BLOCK), 0, s, a, ti, tj); break;
         case KGE_TRANSE_L2:
             hipLaunchKernelGGL(neg_fwd_pair_kernel<KGE_TRANSE_L2>, dim3(nb), dim3(KGE_BLOCK), 0, s, a, ti, tj); break;
-        case KGE_DISTMULT: case KGE_COMPLEX: case KGE_SIMPLE:
+        case KGE_DISTMULT: case KGE_COMPLEX: case KGE_SIMPLE: case KGE_RESCAL:
             hipLaunchKernelGGL(neg_fwd_pair_kernel<KGE_DISTMULT>, dim3(nb), dim3(KGE_BLOCK), 0, s, a, ti, tj); break;
         case KGE_ROTATE:
             hipLaunchKernelGGL(neg_fwd_pair_kernel<KGE_ROTATE>, dim3(nb), dim3(KGE_BLOCK), 0, s, a, ti, tj); break;
@@ -302,7 +302,7 @@ int launch_neg_bwd_pair(const NegArgs &a, hipStream_t s) {
             hipLaunchKernelGGL(neg_bwd_pair_kernel<KGE_TRANSE_L1>, dim3(nb), dim3(KGE_BLOCK), 0, s, a, ti, tj, tk); break;
         case KGE_TRANSE_L2:
             hipLaunchKernelGGL(neg_bwd_pair_kernel<KGE_TRANSE_L2>, dim3(nb), dim3(KGE_BLOCK), 0, s, a, ti, tj, tk); break;
-        case KGE_DISTMULT: case KGE_COMPLEX: case KGE_SIMPLE:
+        case KGE_DISTMULT: case KGE_COMPLEX: case KGE_SIMPLE: case KGE_RESCAL:
             hipLaunchKernelGGL(neg_bwd_pair_kernel<KGE_DISTMULT>, dim3(nb), dim3(KGE_BLOCK), 0, s, a, ti, tj, tk); break;
         case KGE_ROTATE:
             hipLaunchKernelGGL(neg_bwd_pair_kernel<KGE_ROTATE>, dim3(nb), dim3(KGE_BLOCK), 0, s, a, ti, tj, tk); break;

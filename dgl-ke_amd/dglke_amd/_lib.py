@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KGE_LIB") or os.path.join(_HERE, "libkge_hip.so")   # KGE_LIB: A/B builds
 
 KGE_ABI_VERSION = 2
-MODEL_IDS = {"TransE_l1": 0, "TransE_l2": 1, "TransE": 1, "DistMult": 2, "ComplEx": 3, "RotatE": 4, "SimplE": 5}
+MODEL_IDS = {"TransE_l1": 0, "TransE_l2": 1, "TransE": 1, "DistMult": 2, "ComplEx": 3, "RotatE": 4, "SimplE": 5, "RESCAL": 6}
 LOSS_IDS = {"Logsigmoid": 0, "Logistic": 1, "Hinge": 2, "BCE": 3}
 FLAG_FORCE_PAIRWISE = 1
 FLAG_NO_TRANSE_FAST = 2

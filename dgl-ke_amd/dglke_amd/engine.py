@@ -28,6 +28,8 @@ class StepEngine(object):
         self.emb_init = (gamma + 2.0) / hidden_dim          # general_models.py:217-218
         self.d_e = 2 * hidden_dim if double_entity_emb else hidden_dim
         self.d_r = 2 * hidden_dim if double_relation_emb else hidden_dim
+        if model_name == 'RESCAL':                          # relation row = [rel_dim x ent_dim] matrix, general_models.py:232-236
+            self.d_r = self.d_r * self.d_e
         hp = _lib.KgeHParams()
         hp.model = model_id(model_name)
         hp.d_e, hp.d_r = self.d_e, self.d_r

@@ -13,7 +13,7 @@ import torch as th
 from . import ops
 from .engine import StepEngine
 from .loss import LossGenerator
-from .score_fun import ComplExScore, DistMultScore, RotatEScore, SimplEScore, TransEScore
+from .score_fun import ComplExScore, DistMultScore, RESCALScore, RotatEScore, SimplEScore, TransEScore
 from .tensor_models import (ExternalEmbedding, cuda, get_dev, get_device, get_scalar, norm,
                             reshape)
 from ._lib import KgeError
@@ -45,8 +45,11 @@ class KEModel(object):
                                       getattr(args, 'adversarial_temperature', None) or 1.0,
                                       bool(getattr(args, 'pairwise', False)))
         self.entity_emb = ExternalEmbedding(args, n_entities, entity_dim, device)
-        if model_name == 'RESCAL':
-            raise KgeError("RESCAL has no HIP kernel in this build")
+        if model_name == 'RESCAL':        # relation_emb = relation_dim * entity_dim (general_models.py:232-236)
+            if relation_dim != entity_dim:
+                raise KgeError("RESCAL needs relation_dim == entity_dim (the reference's edge_func multiplies "
+                               "head [ent_dim] with M tail [rel_dim] element-wise, score_fun.py:387-394)")
+            relation_dim = relation_dim * entity_dim
         self.rel_dim = relation_dim
         self.entity_dim = entity_dim
         self.strict_rel_part = bool(getattr(args, 'strict_rel_part', False))
@@ -68,9 +71,11 @@ class KEModel(object):
             self.score_func = RotatEScore(gamma, self.emb_init)
         elif model_name == 'SimplE':
             self.score_func = SimplEScore()
+        elif model_name == 'RESCAL':
+            self.score_func = RESCALScore(relation_dim // entity_dim, entity_dim)
         else:
-            raise KgeError("model %s has no HIP kernel in this build (TransR / RESCAL are listed as "
-                           "next in SURVEY.md 8f)" % model_name)
+            raise KgeError("model %s has no HIP kernel in this build (TransR is listed as next in "
+                           "SURVEY.md 8f)" % model_name)
         self.head_neg_score = self.score_func.create_neg(True)
         self.tail_neg_score = self.score_func.create_neg(False)
         self.head_neg_prepare = self.score_func.create_neg_prepare(True)

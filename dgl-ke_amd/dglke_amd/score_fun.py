@@ -108,6 +108,25 @@ class SimplEScore(_HipScore):
         return s.reshape(H, R, T)
 
 
+class RESCALScore(_HipScore):
+    """score_fun.py:378-449: relation rows are [relation_dim x entity_dim] matrices M; p = h . (M t); both
+    corruption modes score (M x) . neg with x the uncorrupted entity."""
+    model_name = 'RESCAL'
+
+    def __init__(self, relation_dim, entity_dim):
+        self.relation_dim, self.entity_dim = relation_dim, entity_dim
+
+    def infer(self, head_emb, rel_emb, tail_emb):
+        """score_fun.py:396-401: [H, R, T] = h . (M t): the head-corruption kernel with every (r, t) pair as a
+        'positive' and the heads as candidates, transposed."""
+        H, R, T = head_emb.shape[0], rel_emb.shape[0], tail_emb.shape[0]
+        tails = tail_emb.unsqueeze(0).expand(R, T, tail_emb.shape[1]).reshape(R * T, -1).contiguous()
+        rels = rel_emb.unsqueeze(1).expand(R, T, rel_emb.shape[1]).reshape(R * T, -1).contiguous()
+        s = ops.score_neg(self.model_name, True, tails, rels, head_emb.contiguous(), 1, R * T, H, 0.0, 1.0,
+                          self.flags)
+        return s.reshape(R, T, H).permute(2, 0, 1).contiguous()
+
+
 class RotatEScore(_HipScore):
     """score_fun.py:451-554"""
     model_name = 'RotatE'

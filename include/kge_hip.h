@@ -37,6 +37,8 @@ enum kge_model {
     KGE_DISTMULT  = 2, /* score_fun.py:222 DistMultScore */
     KGE_COMPLEX   = 3, /* score_fun.py:289 ComplExScore */
     KGE_ROTATE    = 4, /* score_fun.py:451 RotatEScore */
+    KGE_RESCAL    = 6, /* score_fun.py:378 RESCALScore: relation row = [d_e x d_e] matrix M (d_r = d_e*d_e),
+                          p = h.(M t); BOTH corruption modes use the pos-side vector M x (:428-447) */
     KGE_SIMPLE    = 5  /* score_fun.py:556 SimplEScore: rows = [x_i | x_j] halves, relation = [r | r_inv];
                           scores are clamped to [-20, 20] like the reference (:568, :622, :641) */
 };

@@ -19,7 +19,7 @@ All functions take/return numpy arrays; `dtype` selects float32 (reference preci
 """
 import numpy as np
 
-MODELS = ("TransE_l1", "TransE_l2", "DistMult", "ComplEx", "RotatE", "SimplE")
+MODELS = ("TransE_l1", "TransE_l2", "DistMult", "ComplEx", "RotatE", "SimplE", "RESCAL")
 SIMPLE_CLAMP = 20.0          # th.clamp(score, -20, 20): score_fun.py:568, 622, 641
 LOSSES = ("Logsigmoid", "Logistic", "Hinge", "BCE")
 
@@ -87,6 +87,9 @@ def score_pos(model, h, r, t, gamma, emb_init=None):
         re = rh * c - ih * s - rt
         im = rh * s + ih * c - it
         return gamma - np.sqrt(re * re + im * im).sum(-1)
+    if model == "RESCAL":      # score_fun.py:387-394: relation row = [rel_dim, ent_dim] matrix, score = h . (M t)
+        M = r.reshape(r.shape[0], h.shape[-1], -1)
+        return (h * np.einsum("bij,bj->bi", M, t)).sum(-1)
     if model == "SimplE":      # score_fun.py:562-569
         hi, hj = _halves(h)
         ti, tj = _halves(t)
@@ -135,6 +138,12 @@ def score_pos_bwd(model, h, r, t, dp, gamma, emb_init=None):
         gt = np.concatenate([-gre, -gim], -1)
         gphi = gre * (-rh * s - ih * c) + gim * (rh * c - ih * s)
         return gh, gphi * scale, gt
+    if model == "RESCAL":
+        M = r.reshape(r.shape[0], h.shape[-1], -1)
+        gh = dp * np.einsum("bij,bj->bi", M, t)
+        gt = dp * np.einsum("bij,bi->bj", M, h)
+        gr = (dp[:, :, None] * h[:, :, None] * t[:, None, :]).reshape(r.shape)
+        return gh, gr, gt
     if model == "SimplE":      # th.clamp passes the gradient where -20 <= raw <= 20
         hi, hj = _halves(h)
         ti, tj = _halves(t)
@@ -161,6 +170,11 @@ def pos_side(model, neg_head, x, r, emb_init=None):
         return x - r if neg_head else x + r
     if model == "DistMult":
         return x * r
+    if model == "RESCAL":
+        # BOTH modes use M x (score_fun.py:428-447): head mode scores h'.(M t) like the positive score, tail
+        # mode scores (M h).t' - NOT h.(M t') - exactly as the reference does
+        M = r.reshape(r.shape[0], x.shape[-1], -1)
+        return np.einsum("bij,bj->bi", M, x)
     if model == "SimplE":
         # a . neg = the un-halved chunked score: head mode (score_fun.py:611-620) pairs rel*t_j with head_i
         # and rel_inv*t_i with head_j; tail mode (:626-639) pairs rel_inv*h_j with tail_i and h_i*rel with tail_j
@@ -197,7 +211,7 @@ def score_neg(model, a, neg, C, chunk, N, gamma):
         return gamma - np.sqrt(np.maximum(sq, a.dtype.type(1e-30)))
     if model == "TransE_l1":
         return gamma - np.abs(A[:, :, None, :] - Bn[:, None, :, :]).sum(-1)
-    if model in ("DistMult", "ComplEx"):
+    if model in ("DistMult", "ComplEx", "RESCAL"):
         return np.einsum("cik,cjk->cij", A, Bn)
     if model == "SimplE":
         return np.clip(0.5 * np.einsum("cik,cjk->cij", A, Bn), -SIMPLE_CLAMP, SIMPLE_CLAMP)
@@ -228,7 +242,7 @@ def score_neg_bwd(model, a, neg, dneg, C, chunk, N, gamma):
         sg = np.sign(A[:, :, None, :] - Bn[:, None, :, :])
         ga = -(G[..., None] * sg).sum(2)
         gb = (G[..., None] * sg).sum(1)
-    elif model in ("DistMult", "ComplEx"):
+    elif model in ("DistMult", "ComplEx", "RESCAL"):
         ga = np.einsum("cij,cjk->cik", G, Bn)
         gb = np.einsum("cij,cik->cjk", G, A)
     elif model == "SimplE":
@@ -258,6 +272,9 @@ def pos_side_bwd(model, neg_head, x, r, ga, emb_init=None):
         return ga, (-ga if neg_head else ga)
     if model == "DistMult":
         return ga * r, ga * x
+    if model == "RESCAL":      # a = M x
+        M = r.reshape(r.shape[0], x.shape[-1], -1)
+        return np.einsum("bij,bi->bj", M, ga), (ga[:, :, None] * x[:, None, :]).reshape(r.shape)
     if model == "SimplE":
         xi, xj = _halves(x)
         rel, rinv = _halves(r)

@@ -28,6 +28,8 @@ class TorchPort(object):
         g = th.Generator().manual_seed(seed)
         d_e = 2 * hidden if de else hidden
         d_r = 2 * hidden if dr else hidden
+        if model == "RESCAL":
+            d_r = d_r * d_e
         self.ent = (th.rand(n_ent, d_e, generator=g) * 2 - 1) * self.emb_init
         self.rel = (th.rand(n_rel, d_r, generator=g) * 2 - 1) * self.emb_init
         self.ent_state = th.zeros(n_ent)
@@ -47,6 +49,9 @@ class TorchPort(object):
             rt, it = th.chunk(t, 2, dim=-1)
             rr, ir = th.chunk(r, 2, dim=-1)
             return th.sum(rh * rt * rr + ih * it * rr + rh * it * ir - ih * rt * ir, -1)
+        if m == "RESCAL":
+            M = r.view(-1, h.shape[1], h.shape[1])
+            return th.sum(h * th.matmul(M, t.unsqueeze(-1)).squeeze(-1), dim=-1)
         if m == "SimplE":
             hi, hj = th.chunk(h, 2, dim=-1)
             ti, tj = th.chunk(t, 2, dim=-1)
@@ -75,6 +80,9 @@ class TorchPort(object):
             return self.gamma - sq.clamp_min_(1e-30).sqrt_()
         if m == "DistMult":
             return th.bmm((x * r).reshape(C, chunk, D), neg.reshape(C, N, D).transpose(1, 2))
+        if m == "RESCAL":
+            tmp = th.matmul(r.view(-1, D, D), x.unsqueeze(-1)).squeeze(-1).reshape(C, chunk, D)
+            return th.bmm(tmp, neg.reshape(C, N, D).transpose(1, 2))
         if m == "SimplE":
             xi, xj = x[..., :D // 2], x[..., D // 2:]
             rel, rinv = r[..., :D // 2], r[..., D // 2:]

@@ -241,6 +241,12 @@ CASES = {
     "simple_dups": base("SimplE", n_ent=9, n_rel=2, de=True, dr=True, steps=4, seed=43),
     "simple_plain": base("SimplE", hidden=16, adv=False, reg_coef=0.0, seed=44),
     "simple_clamped": base("SimplE", hidden=8, gamma=22.0, de=True, dr=True, lr=0.01, seed=45),
+    # RESCAL (score_fun.py:378): relation rows are [rel_dim x ent_dim] matrices
+    "rescal_small": base("RESCAL", gamma=6.0, hidden=8, seed=51),
+    "rescal_ragged": base("RESCAL", gamma=6.0, hidden=6, B=30, N=7, chunk=10, seed=52),
+    "rescal_dups": base("RESCAL", gamma=6.0, hidden=8, n_ent=9, n_rel=2, steps=4, seed=53),
+    "rescal_mid": base("RESCAL", n_ent=200, n_rel=12, hidden=32, gamma=12.0, B=64, N=32, chunk=32, lr=0.05,
+                       reg_coef=1e-6, steps=2, seed=54, save_tables_each_step=False),
     # no adversarial weighting, no regularisation
     "transe_l2_noadv": base("TransE_l2", adv=False, reg_coef=0.0, seed=12),
     "distmult_noadv": base("DistMult", adv=False, reg_coef=0.0, seed=13),

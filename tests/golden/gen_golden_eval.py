@@ -87,6 +87,7 @@ CASES = {
     "eval_complex": base("ComplEx", de=True, dr=True, scale=6.0, seed=34),
     "eval_rotate": base("RotatE", de=True, scale=4.0, seed=35),
     "eval_simple": base("SimplE", de=True, dr=True, scale=6.0, seed=37),
+    "eval_rescal": base("RESCAL", hidden=8, scale=3.0, seed=38),
     # ragged: candidate count / dims that are not tile multiples
     "eval_transe_l2_ragged": base("TransE_l2", n_ent=37, hidden=20, E=9, scale=4.0, seed=36),
 }
