@@ -48,6 +48,13 @@ WORKLOADS = {
     "rotate_fb15k": dict(model="RotatE", n_ent=14951, n_rel=1345, n_train=483142, hidden=200,
                          de=True, dr=False, B=1024, N=256, gamma=12.0, lr=0.009, adv=True,
                          adv_temp=1.0, reg_coef=1e-7, reg_norm=3),
+    # the reference's FB15k recipes for the remaining score functions (examples/fb15k/multi_gpu.sh)
+    "simple_fb15k": dict(model="SimplE", n_ent=14951, n_rel=1345, n_train=483142, hidden=400,
+                         de=True, dr=True, B=1000, N=200, gamma=143.0, lr=0.1, adv=True,
+                         adv_temp=1.0, reg_coef=2e-6, reg_norm=3),
+    "rescal_fb15k": dict(model="RESCAL", n_ent=14951, n_rel=1345, n_train=483142, hidden=500,
+                         de=False, dr=False, B=1024, N=256, gamma=24.0, lr=0.03, adv=True,
+                         adv_temp=1.0, reg_coef=0.0, reg_norm=3),
     "transe_l1_fb15k": dict(model="TransE_l1", n_ent=14951, n_rel=1345, n_train=483142, hidden=400,
                             de=False, dr=False, B=1000, N=200, gamma=16.0, lr=0.01, adv=True,
                             adv_temp=1.0, reg_coef=1e-7, reg_norm=3),

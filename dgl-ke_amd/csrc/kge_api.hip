@@ -365,7 +365,10 @@ size_t kge_step_workspace_bytes(const kge_hparams *hp, int B, int C, int chunk, 
     add(CN * d_e);       // GN
     add(B * d_e);        // P (TransE) or GH
     add(B * d_e);                 // GT
-    if (hp->model == KGE_RESCAL) { add(B * d_e); add(B * d_e); add(B * d_e); }   // V = M t, M^T h, M^T GA (no [B, d_r] buffer)
+    if (hp->model == KGE_RESCAL) {   // V = M t, M^T h, M^T GA (no [B, d_r] buffer) + update scratch
+        add(B * d_e); add(B * d_e); add(B * d_e);
+        add((size_t)B * RESCAL_RB); add(UR); add((size_t)UR * RESCAL_RB);
+    }
     else add(B * d_r);            // GR
     add(B); add(B); add(UE); add(UR);           // row_pos, row_neg, reg_ent, reg_rel
     return n;
@@ -423,6 +426,8 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     float *GH = cv.f((size_t)B * d_e), *GT = cv.f((size_t)B * d_e);
     float *RV = rescal ? cv.f((size_t)B * d_e) : nullptr, *RC1 = rescal ? cv.f((size_t)B * d_e) : nullptr;
     float *RC2 = rescal ? cv.f((size_t)B * d_e) : nullptr;
+    float *Rgs = rescal ? cv.f((size_t)B * RESCAL_RB) : nullptr, *Rstd = rescal ? cv.f(b->UR) : nullptr;
+    float *Rreg = rescal ? cv.f((size_t)b->UR * RESCAL_RB) : nullptr;
     float *GR = rescal ? nullptr : cv.f((size_t)B * d_r);
     float *row_pos = cv.f(B), *row_neg = cv.f(B), *reg_ent = cv.f(b->UE), *reg_rel = cv.f(b->UR);
     if (!cv.ok())
@@ -541,7 +546,8 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         }
         // relation matrices first: the entity update below changes the h / t rows this kernel reads
         RescalUpdateArgs ru{};
-        ru.D = d_e; ru.UE = b->UE; ru.UR = b->UR; ru.neg_head = b->neg_head; ru.reg_norm = hp->reg_norm;
+        ru.B = B; ru.D = d_e; ru.UE = b->UE; ru.UR = b->UR; ru.neg_head = b->neg_head; ru.reg_norm = hp->reg_norm;
+        ru.rel_ids = b->rel_ids; ru.gs = Rgs; ru.inv_std = Rstd; ru.reg_part = (want4 || (reg && acc)) ? Rreg : nullptr;
         ru.lr = hp->lr; ru.eps = hp->eps; ru.reg_coef = reg ? hp->reg_coef : 0.f;
         ru.rel = tb->rel; ru.rel_state = tb->rel_state; ru.ent = tb->ent; ru.hidx = b->h_gid; ru.tidx = b->t_gid;
         ru.dpos = dP; ru.GA = GA; ru.ur_id = b->ur_id; ru.ur_ptr = b->ur_ptr; ru.ur_edge = b->ur_edge;

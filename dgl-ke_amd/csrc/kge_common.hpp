@@ -335,13 +335,17 @@ struct RescalOuterArgs {             // G_i = c_i * u_i v_i^T (+ G_i) (+ regular
     int accumulate;
     float *G;                                // [B, D*D]
 };
-struct RescalUpdateArgs {            // fused Adagrad of the relation matrices (one workgroup per unique relation)
-    int D, UE, UR, neg_head, reg_norm;
+#define RESCAL_RB 8                  // row blocks per relation matrix in the update kernels
+struct RescalUpdateArgs {            // fused Adagrad of the relation matrices (kge_rescal.hip)
+    int B, D, UE, UR, neg_head, reg_norm;
     float lr, eps, reg_coef;
     float *rel, *rel_state;
-    const float *ent; const int64_t *hidx, *tidx;
+    const float *ent; const int64_t *hidx, *tidx, *rel_ids;
     const float *dpos, *GA;
     const int64_t *ur_id; const int32_t *ur_ptr, *ur_edge; const int32_t *counts_dev;
+    float *gs;                       // scratch [B, RESCAL_RB]: mean-square of every traced-row gradient (parts)
+    float *inv_std;                  // scratch [UR]
+    float *reg_part;                 // scratch [UR, RESCAL_RB] or null (no regularisation value wanted)
     float *reg_rel, *acc;
 };
 int launch_rescal_matvec(const RescalMatvecArgs &a, hipStream_t s);

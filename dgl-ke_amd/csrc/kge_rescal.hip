@@ -146,12 +146,16 @@ int launch_rescal_outer(const RescalOuterArgs &a, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// fused relation update: one workgroup per unique relation u with edges E_u (plan lists ur_ptr / ur_edge).
-// Per edge e the traced-row gradient is g_e = dp_e h_e t_e^T + GA_e x_e^T + R  (R = regulariser gradient of
-// the current M, one copy per traced row like the reference, general_models.py:572-576) and Adagrad
-// (tensor_models.py:330-361) needs  S = sum_e mean(g_e^2)  BEFORE the row changes:
-//   pass 1 (per edge, over all D*D elements): sum of squares -> S, deterministic block reduction;
-//   pass 2: M -= lr * sum_e g_e / (sqrt(state + S) + eps).
+// fused relation update.  Per edge e the traced-row gradient is g_e = dp_e h_e t_e^T + GA_e x_e^T + R
+// (R = regulariser gradient of the current M, one copy per traced row like the reference,
+// general_models.py:572-576) and Adagrad (tensor_models.py:330-361) needs S_u = sum_{e in E_u} mean(g_e^2)
+// BEFORE the row changes.  Three launches, all deterministic (fixed summation orders, no atomics):
+//   1. rescal_edge_sq:   mean(g_e^2) per edge.  Without regulariser the rank-2 matrix has the closed form
+//        |g|^2 = dp^2 |h|^2 |t|^2 + |GA|^2 |x|^2 + 2 dp (h.GA)(t.x)      (one wavefront per edge, O(D));
+//      with regulariser: RESCAL_RB row blocks per edge sum (dp h_r t_b + GA_r x_b + R_rb)^2 over the matrix.
+//   2. rescal_rel_state: one thread per unique relation: S_u in plan order, state += S_u, 1/std -> scratch.
+//   3. rescal_apply:     (unique relation, row block) workgroups: M -= lr * (sum_e g_e) / std, the gradient
+//      rebuilt per element from the rank-1 factors (never materialised).
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float block_sum(float v, float *red) {
     v = wave_sum(v);
@@ -164,69 +168,220 @@ __device__ __forceinline__ float block_sum(float v, float *red) {
     return s;
 }
 
-__global__ __launch_bounds__(KGE_BLOCK) void rescal_update_rel_kernel(RescalUpdateArgs a) {
-    __shared__ float red[KGE_WAVES_PER_BLOCK];
-    const int u = blockIdx.x;
-    if (u >= (a.counts_dev ? a.counts_dev[1] : a.UR)) return;
-    const int D = a.D;
-    const int64_t n = (int64_t)D * D;
-    const int64_t id = a.ur_id[u];
-    const int e0 = a.ur_ptr[u], e1 = a.ur_ptr[u + 1];
-    float *M = a.rel + id * n;
-    const bool reg = a.reg_coef > 0.f && a.reg_norm > 0;
-    auto row_of = [&](const int64_t *idx, int e) { return a.ent + idx[e] * (int64_t)D; };
-    // pass 1: S = sum_e mean(g_e^2); regulariser value of the traced copies
-    float S = 0.f, rv = 0.f;
-    for (int q = e0; q < e1; ++q) {
-        const int e = a.ur_edge[q];
+__global__ __launch_bounds__(KGE_BLOCK) void rescal_edge_sq_kernel(RescalUpdateArgs a) {      // no regulariser
+    const int64_t e = (int64_t)blockIdx.x * KGE_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (e >= a.B) return;
+    const int lane = threadIdx.x & 63, D = a.D;
+    const float *h = a.ent + a.hidx[e] * (int64_t)D, *t = a.ent + a.tidx[e] * (int64_t)D, *x = a.neg_head ? t : h;
+    const float *ga = a.GA + e * (int64_t)D;
+    float hh = 0.f, tt = 0.f, gg = 0.f, xx = 0.f, hg = 0.f, tx = 0.f;
+    for (int b = lane; b < D; b += 64) {
+        const float hv = h[b], tv = t[b], gv = ga[b], xv = x[b];
+        hh = fmaf(hv, hv, hh); tt = fmaf(tv, tv, tt); gg = fmaf(gv, gv, gg);
+        xx = fmaf(xv, xv, xx); hg = fmaf(hv, gv, hg); tx = fmaf(tv, xv, tx);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        hh += __shfl_xor(hh, o, 64); tt += __shfl_xor(tt, o, 64); gg += __shfl_xor(gg, o, 64);
+        xx += __shfl_xor(xx, o, 64); hg += __shfl_xor(hg, o, 64); tx += __shfl_xor(tx, o, 64);
+    }
+    if (lane == 0) {
         const float dp = a.dpos[e];
-        const float *h = row_of(a.hidx, e), *t = row_of(a.tidx, e), *x = a.neg_head ? t : h;
-        const float *ga = a.GA + (int64_t)e * D;
-        float ss = 0.f;
-        for (int64_t k = threadIdx.x; k < n; k += KGE_BLOCK) {
-            const int r = (int)(k / D), b = (int)(k - (int64_t)r * D);
-            float g = dp * h[r] * t[b] + ga[r] * x[b];
-            if (reg) {
-                const float m = M[k];
-                g += reg_grad(m, a.reg_coef, a.reg_norm);
-                if (q == e0) rv += reg_val(m, a.reg_norm);
-            }
+        a.gs[e * RESCAL_RB] = fmaxf(dp * dp * hh * tt + gg * xx + 2.f * dp * hg * tx, 0.f) / ((float)D * (float)D);
+    }
+}
+
+__global__ __launch_bounds__(KGE_BLOCK) void rescal_edge_sq_reg_kernel(RescalUpdateArgs a) {  // with regulariser
+    __shared__ float red[KGE_WAVES_PER_BLOCK];
+    const int e = blockIdx.x / RESCAL_RB, rb = blockIdx.x % RESCAL_RB;
+    const int D = a.D;
+    const int rows = (D + RESCAL_RB - 1) / RESCAL_RB, r0 = rb * rows, r1 = min(D, r0 + rows);
+    const float *h = a.ent + a.hidx[e] * (int64_t)D, *t = a.ent + a.tidx[e] * (int64_t)D, *x = a.neg_head ? t : h;
+    const float *ga = a.GA + (int64_t)e * D;
+    const float *M = a.rel + a.rel_ids[e] * (int64_t)D * D;
+    const float dp = a.dpos[e];
+    float ss = 0.f;
+    for (int r = r0; r < r1; ++r) {
+        const float dh = dp * h[r], gr = ga[r];
+        for (int b = threadIdx.x; b < D; b += KGE_BLOCK) {
+            const float g = dh * t[b] + gr * x[b] + reg_grad(M[(int64_t)r * D + b], a.reg_coef, a.reg_norm);
             ss = fmaf(g, g, ss);
         }
-        S += block_sum(ss, red) / (float)n;
+    }
+    ss = block_sum(ss, red);
+    if (threadIdx.x == 0) a.gs[(int64_t)e * RESCAL_RB + rb] = ss / ((float)D * (float)D);
+}
+
+__global__ void rescal_rel_state_kernel(RescalUpdateArgs a, int nparts) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= (a.counts_dev ? a.counts_dev[1] : a.UR)) return;
+    const int64_t id = a.ur_id[u];
+    float S = 0.f;
+    for (int q = a.ur_ptr[u]; q < a.ur_ptr[u + 1]; ++q) {
+        const int64_t e = a.ur_edge[q];
+        float g = 0.f;
+        for (int k = 0; k < nparts; ++k) g += a.gs[e * RESCAL_RB + k];
+        S += g;
     }
     const float sN = a.rel_state[id] + S;
-    const float sd = sqrtf(sN) + a.eps;
-    // pass 2: apply the summed gradient
-    const float cnt = (float)(e1 - e0);
-    for (int64_t k = threadIdx.x; k < n; k += KGE_BLOCK) {
-        const int r = (int)(k / D), b = (int)(k - (int64_t)r * D);
-        const float m = M[k];
-        float g = reg ? cnt * reg_grad(m, a.reg_coef, a.reg_norm) : 0.f;
-        for (int q = e0; q < e1; ++q) {
-            const int e = a.ur_edge[q];
-            const float *h = row_of(a.hidx, e), *t = row_of(a.tidx, e), *x = a.neg_head ? t : h;
-            g += a.dpos[e] * h[r] * t[b] + a.GA[(int64_t)e * D + r] * x[b];
-        }
-        M[k] = m + (-a.lr * g) / sd;
+    a.rel_state[id] = sN;
+    a.inv_std[u] = 1.f / (sqrtf(sN) + a.eps);
+}
+
+// NCOL = ceil(D / 256): every thread owns columns b = tid + 256 j of all rows of the block, so the t / x
+// operands of an edge are loaded once per row from L1 and the per-row factors (dp h_r, GA_r) are uniform
+template <int NCOL>
+__global__ __launch_bounds__(KGE_BLOCK) void rescal_apply_kernel(RescalUpdateArgs a) {
+    __shared__ float red[KGE_WAVES_PER_BLOCK];
+    const int u = blockIdx.x / RESCAL_RB, rb = blockIdx.x % RESCAL_RB;
+    if (u >= (a.counts_dev ? a.counts_dev[1] : a.UR)) return;
+    const int D = a.D;
+    const int rows = (D + RESCAL_RB - 1) / RESCAL_RB, r0 = rb * rows, r1 = min(D, r0 + rows);
+    const int e0 = a.ur_ptr[u], e1 = a.ur_ptr[u + 1];
+    float *M = a.rel + a.ur_id[u] * (int64_t)D * D;
+    const bool reg = a.reg_coef > 0.f && a.reg_norm > 0;
+    const float cnt = (float)(e1 - e0), step = -a.lr * a.inv_std[u];
+    // per-edge metadata does not depend on the row: fetch it once (the chain ur_edge -> ids -> rows would
+    // otherwise be three dependent loads in every row iteration)
+    constexpr int NEC = 32;
+    __shared__ int64_t s_ho[NEC], s_to[NEC], s_go[NEC];
+    __shared__ float s_dp[NEC];
+    const int nec = min(NEC, e1 - e0);
+    if ((int)threadIdx.x < nec) {
+        const int64_t e = a.ur_edge[e0 + threadIdx.x];
+        s_ho[threadIdx.x] = a.hidx[e] * (int64_t)D;
+        s_to[threadIdx.x] = a.tidx[e] * (int64_t)D;
+        s_go[threadIdx.x] = e * (int64_t)D;
+        s_dp[threadIdx.x] = a.dpos[e];
     }
-    if (reg && (a.reg_rel || a.acc)) {
-        const float tot = block_sum(rv, red);
-        if (threadIdx.x == 0) {
-            const float val = a.reg_coef * tot * cnt;
-            if (a.reg_rel) a.reg_rel[u] = val;
-            if (a.acc) {
-                float *slot = &a.acc[3 * KGE_ACC_SLOTS + (int)((u + a.UE) & (KGE_ACC_SLOTS - 1))];
-                if (a.UE + a.UR <= KGE_ACC_SLOTS) *slot += val; else atomicAdd(slot, val);
+    __syncthreads();
+    float rv = 0.f;
+#pragma unroll 2
+    for (int r = r0; r < r1; ++r) {
+        float m[NCOL], g[NCOL];
+#pragma unroll
+        for (int j = 0; j < NCOL; ++j) {
+            const int b = threadIdx.x + KGE_BLOCK * j;
+            m[j] = b < D ? M[(int64_t)r * D + b] : 0.f;
+            g[j] = 0.f;
+            if (reg) { g[j] = cnt * reg_grad(m[j], a.reg_coef, a.reg_norm); rv += reg_val(m[j], a.reg_norm); }
+        }
+        for (int q = 0; q < e1 - e0; ++q) {
+            int64_t ho, to, go; float dp;
+            if (q < NEC) { ho = s_ho[q]; to = s_to[q]; go = s_go[q]; dp = s_dp[q]; }
+            else {
+                const int64_t e = a.ur_edge[e0 + q];
+                ho = a.hidx[e] * (int64_t)D; to = a.tidx[e] * (int64_t)D; go = e * (int64_t)D; dp = a.dpos[e];
+            }
+            const int64_t xo = a.neg_head ? to : ho;
+            const float dh = dp * a.ent[ho + r], gr = a.GA[go + r];
+#pragma unroll
+            for (int j = 0; j < NCOL; ++j) {
+                const int b = threadIdx.x + KGE_BLOCK * j;
+                if (b < D) g[j] = fmaf(dh, a.ent[to + b], fmaf(gr, a.ent[xo + b], g[j]));
             }
         }
-    } else if (a.reg_rel && threadIdx.x == 0) a.reg_rel[u] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCOL; ++j) {
+            const int b = threadIdx.x + KGE_BLOCK * j;
+            if (b < D) M[(int64_t)r * D + b] = fmaf(step, g[j], m[j]);
+        }
+    }
+    if (a.reg_part) {        // regularisation value of the traced copies: cnt * coef * sum |M|^p, per row block
+        const float tot = reg ? block_sum(rv, red) : 0.f;
+        if (threadIdx.x == 0) a.reg_part[(int64_t)u * RESCAL_RB + rb] = a.reg_coef * tot * cnt;
+    }
+}
+
+// 16-byte variant (D % 4 == 0): TPR = power of two >= D/4 threads cover one row with one float4 each, the
+// workgroup walks 256 / TPR rows per iteration; two iterations are in flight (unroll) for memory parallelism
+__global__ __launch_bounds__(KGE_BLOCK) void rescal_apply_vec_kernel(RescalUpdateArgs a, int tpr) {
+    __shared__ float red[KGE_WAVES_PER_BLOCK];
+    const int u = blockIdx.x / RESCAL_RB, rb = blockIdx.x % RESCAL_RB;
+    if (u >= (a.counts_dev ? a.counts_dev[1] : a.UR)) return;
+    const int D = a.D;
+    const int rows = (D + RESCAL_RB - 1) / RESCAL_RB, r0 = rb * rows, r1 = min(D, r0 + rows);
+    const int e0 = a.ur_ptr[u], e1 = a.ur_ptr[u + 1];
+    float *M = a.rel + a.ur_id[u] * (int64_t)D * D;
+    const bool reg = a.reg_coef > 0.f && a.reg_norm > 0;
+    const float cnt = (float)(e1 - e0), step = -a.lr * a.inv_std[u];
+    constexpr int NEC = 32;
+    __shared__ int64_t s_ho[NEC], s_to[NEC], s_go[NEC];
+    __shared__ float s_dp[NEC];
+    const int nec = min(NEC, e1 - e0);
+    if ((int)threadIdx.x < nec) {
+        const int64_t e = a.ur_edge[e0 + threadIdx.x];
+        s_ho[threadIdx.x] = a.hidx[e] * (int64_t)D;
+        s_to[threadIdx.x] = a.tidx[e] * (int64_t)D;
+        s_go[threadIdx.x] = e * (int64_t)D;
+        s_dp[threadIdx.x] = a.dpos[e];
+    }
     __syncthreads();
-    if (threadIdx.x == 0) a.rel_state[id] = sN;
+    const int rpi = KGE_BLOCK / tpr;                       // rows per iteration
+    const int rsub = threadIdx.x / tpr, b = (threadIdx.x % tpr) * 4;
+    const bool colok = b < D;
+    float rv = 0.f;
+#pragma unroll 2
+    for (int rr = r0; rr < r1; rr += rpi) {
+        const int r = rr + rsub;
+        if (r >= r1 || !colok) continue;
+        float4 m = *reinterpret_cast<const float4 *>(M + (int64_t)r * D + b);
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (reg) {
+            g.x = cnt * reg_grad(m.x, a.reg_coef, a.reg_norm); g.y = cnt * reg_grad(m.y, a.reg_coef, a.reg_norm);
+            g.z = cnt * reg_grad(m.z, a.reg_coef, a.reg_norm); g.w = cnt * reg_grad(m.w, a.reg_coef, a.reg_norm);
+            rv += reg_val(m.x, a.reg_norm) + reg_val(m.y, a.reg_norm) + reg_val(m.z, a.reg_norm) + reg_val(m.w, a.reg_norm);
+        }
+        for (int q = 0; q < e1 - e0; ++q) {
+            int64_t ho, to, go; float dp;
+            if (q < NEC) { ho = s_ho[q]; to = s_to[q]; go = s_go[q]; dp = s_dp[q]; }
+            else {
+                const int64_t e = a.ur_edge[e0 + q];
+                ho = a.hidx[e] * (int64_t)D; to = a.tidx[e] * (int64_t)D; go = e * (int64_t)D; dp = a.dpos[e];
+            }
+            const int64_t xo = a.neg_head ? to : ho;
+            const float dh = dp * a.ent[ho + r], gr = a.GA[go + r];
+            const float4 tv = *reinterpret_cast<const float4 *>(a.ent + to + b);
+            const float4 xv = *reinterpret_cast<const float4 *>(a.ent + xo + b);
+            g.x = fmaf(dh, tv.x, fmaf(gr, xv.x, g.x)); g.y = fmaf(dh, tv.y, fmaf(gr, xv.y, g.y));
+            g.z = fmaf(dh, tv.z, fmaf(gr, xv.z, g.z)); g.w = fmaf(dh, tv.w, fmaf(gr, xv.w, g.w));
+        }
+        m.x = fmaf(step, g.x, m.x); m.y = fmaf(step, g.y, m.y); m.z = fmaf(step, g.z, m.z); m.w = fmaf(step, g.w, m.w);
+        *reinterpret_cast<float4 *>(M + (int64_t)r * D + b) = m;
+    }
+    if (a.reg_part) {
+        const float tot = reg ? block_sum(rv, red) : 0.f;
+        if (threadIdx.x == 0) a.reg_part[(int64_t)u * RESCAL_RB + rb] = a.reg_coef * tot * cnt;
+    }
+}
+
+__global__ void rescal_reg_finalize_kernel(RescalUpdateArgs a) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= (a.counts_dev ? a.counts_dev[1] : a.UR)) return;
+    float v = 0.f;
+    for (int k = 0; k < RESCAL_RB; ++k) v += a.reg_part[(int64_t)u * RESCAL_RB + k];
+    if (a.reg_rel) a.reg_rel[u] = v;
+    if (a.acc) {
+        float *slot = &a.acc[3 * KGE_ACC_SLOTS + (int)((u + a.UE) & (KGE_ACC_SLOTS - 1))];
+        if (a.UE + a.UR <= KGE_ACC_SLOTS) *slot += v; else atomicAdd(slot, v);
+    }
 }
 
 int launch_rescal_update_rel(const RescalUpdateArgs &a, hipStream_t s) {
-    if (a.UR == 0) return KGE_OK;
-    hipLaunchKernelGGL(rescal_update_rel_kernel, dim3(a.UR), dim3(KGE_BLOCK), 0, s, a);
+    if (a.UR == 0 || a.B == 0) return KGE_OK;
+    const bool reg = a.reg_coef > 0.f && a.reg_norm > 0;
+    if (reg) hipLaunchKernelGGL(rescal_edge_sq_reg_kernel, dim3(a.B * RESCAL_RB), dim3(KGE_BLOCK), 0, s, a);
+    else hipLaunchKernelGGL(rescal_edge_sq_kernel, dim3((a.B + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK), dim3(KGE_BLOCK), 0, s, a);
+    hipLaunchKernelGGL(rescal_rel_state_kernel, dim3((a.UR + 255) / 256), dim3(256), 0, s, a, reg ? RESCAL_RB : 1);
+    const dim3 ga(a.UR * RESCAL_RB), ba(KGE_BLOCK);
+    if (a.D % 4 == 0) {
+        int tpr = 64;                                      // >= one wavefront per row: the row factors stay uniform
+        while (tpr * 4 < a.D) tpr *= 2;
+        hipLaunchKernelGGL(rescal_apply_vec_kernel, ga, ba, 0, s, a, tpr);
+    } else if (a.D <= 256) hipLaunchKernelGGL(rescal_apply_kernel<1>, ga, ba, 0, s, a);
+    else if (a.D <= 512) hipLaunchKernelGGL(rescal_apply_kernel<2>, ga, ba, 0, s, a);
+    else hipLaunchKernelGGL(rescal_apply_kernel<4>, ga, ba, 0, s, a);
+    if (a.reg_part && (a.reg_rel || a.acc))
+        hipLaunchKernelGGL(rescal_reg_finalize_kernel, dim3((a.UR + 255) / 256), dim3(256), 0, s, a);
     return check_launch_r();
 }
