@@ -185,6 +185,7 @@ def main():
     ap.add_argument("--force-pairwise", action="store_true")
     ap.add_argument("--flags", type=int, default=0, help="extra kge_hparams.flags bits (tuning)")
     ap.add_argument("--no-adv", action="store_true", help="tuning: disable -adv")
+    ap.add_argument("--reg-coef", type=float, default=None, help="tuning: override the regularisation coefficient")
     ap.add_argument("--host-plan", action="store_true",
                     help="pre-stage host-built batches instead of sampling on the device inside the timed region")
     ap.add_argument("--hogwild", type=int, default=4, help="also measure K concurrent Hogwild trainers (0 = skip)")
@@ -208,6 +209,8 @@ def main():
     w = dict(WORKLOADS[args.workload])
     if args.no_adv:
         w["adv"] = False
+    if args.reg_coef is not None:
+        w["reg_coef"] = args.reg_coef
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     torch.manual_seed(0)

@@ -262,6 +262,7 @@ struct UpdateArgs {
     int ld_e, ld_r;                  // row strides of the emit buffers (floats)
     int32_t *rid;                    // optional relation-id words inside the relation message
     int ld_gs_e, ld_gs_r;            // strides of gs0/gs1 and gsr
+    int dry;                         // tuning probe: read everything, write nothing
 };
 
 struct FinalizeArgs {
