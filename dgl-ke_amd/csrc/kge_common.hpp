@@ -83,22 +83,18 @@ template <int V> __device__ __forceinline__ Pack<V> zero_pack() {
 
 __device__ __forceinline__ float sgnf(float x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); }
 
-// d/dx coef*|x|^q  (general_models.py:572-576; norm = x.norm(p)**p, tensor_models.py:54)
+// d/dx coef*|x|^q  (general_models.py:572-576; norm = x.norm(p)**p, tensor_models.py:54).
+// Branch-free on purpose (hardware exp2 / log2, ~1e-6 relative): a chain of `if (q == 3) ... else powf` at every
+// use is unswitched / inlined by the compiler into several copies of every loop and made the update kernel
+// 11 k instructions - larger than the instruction cache (measured 15.6 -> 12.4 us just from removing powf).
 __device__ __forceinline__ float reg_grad(float x, float coef, int q) {
     const float ax = fabsf(x);
-    float pw;
-    if (q == 3) pw = ax * ax;
-    else if (q == 2) pw = ax;
-    else if (q == 1) pw = 1.f;
-    else pw = powf(ax, (float)(q - 1));
-    return coef * (float)q * pw * sgnf(x);
+    const float pw = __builtin_amdgcn_exp2f((float)(q - 1) * __builtin_amdgcn_logf(ax));     // |x|^(q-1)
+    return ax > 0.f ? copysignf(coef * (float)q * pw, x) : 0.f;
 }
 __device__ __forceinline__ float reg_val(float x, int q) {
     const float ax = fabsf(x);
-    if (q == 3) return ax * ax * ax;
-    if (q == 2) return ax * ax;
-    if (q == 1) return ax;
-    return powf(ax, (float)q);
+    return ax > 0.f ? __builtin_amdgcn_exp2f((float)q * __builtin_amdgcn_logf(ax)) : 0.f;    // |x|^q
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) {
@@ -137,22 +133,12 @@ __device__ __forceinline__ void criterion_fast(int genre, float s, float label, 
     }
 }
 
-// criterion value and derivative w.r.t. the score for label l (models/pytorch/loss.py:10-38)
+// criterion value and derivative w.r.t. the score for label l (models/pytorch/loss.py:10-38): the hardware
+// exp/log version everywhere (rel. error ~1e-6, inside the 1e-5 loss tolerance) - the libm expansions of
+// expf / log1pf are hundreds of instructions per call site
 __device__ __forceinline__ void criterion(int genre, float s, float label, float margin,
                                           float &val, float &dval) {
-    if (genre == KGE_LOSS_HINGE) {
-        const float v = margin - label * s;
-        val = v < 0.f ? 0.f : v;
-        dval = v < 0.f ? 0.f : -label;
-    } else if (genre == KGE_LOSS_BCE) {
-        // -(l*log(sig(s)) + (1-l)*log(1-sig(s))), written with softplus for stability
-        val = label * neg_logsigmoid(s) + (1.f - label) * neg_logsigmoid(-s);
-        dval = sigmoidf_(s) - label;
-    } else {   // Logsigmoid / Logistic: -logsigmoid(l*s) == softplus(-l*s)
-        const float z = label * s;
-        val = neg_logsigmoid(z);
-        dval = -label * sigmoidf_(-z);
-    }
+    criterion_fast(genre, s, label, margin, val, dval);
 }
 
 // bijective XCD-aware remap: hardware block b runs on XCD b%8; give the blocks of one XCD

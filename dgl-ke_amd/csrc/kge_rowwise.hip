@@ -15,14 +15,14 @@ using namespace kge;
 #define WAVE_ID() ((int64_t)blockIdx.x * KGE_WAVES_PER_BLOCK + (threadIdx.x >> 6))
 #define LANE() (threadIdx.x & 63)
 
-// running-sum slot update: a kernel adds at most once per slot when `unique`, so a plain
-// read-modify-write is race-free (and deterministic); otherwise fall back to a float atomic.
+// running-sum slot update: a fire-and-forget hardware float atomic (global_atomic_add_f32, no return value).
+// A plain read-modify-write costs a dependent global load - one more ~1.5 us round trip at the end of every
+// wavefront's chain (update kernel 15.7 -> see profiles/r01_microbench_mi355x.txt).  The result is still
+// deterministic whenever `unique` holds (every slot gets at most ONE add per kernel, kernels are stream
+// ordered): a single atomic add performs exactly old + v.
 __device__ __forceinline__ void acc_add(float *p, float v, bool unique) {
-#ifdef KGE_ACC_ATOMIC_ONLY
-    (void)unique; atomicAdd(p, v);
-#else
-    if (unique) *p += v; else atomicAdd(p, v);
-#endif
+    (void)unique;
+    atomicAdd(p, v);
 }
 
 static inline int blocks_for_waves(int64_t waves) {
@@ -878,8 +878,18 @@ __global__ __launch_bounds__(KGE_BLOCK) void update_kernel(UpdateArgs a, int nb_
 // parallelism: one 32-byte plan record per row gives the row id, the list bounds AND the first
 // list entries, so that the row itself and its first positive / negative gradient rows are
 // requested together (one dependent round instead of five); longer lists continue in loops.
-template <int NIT>
-__global__ __launch_bounds__(KGE_BLOCK) void update_kernel_reg(UpdateArgs a, int nb_ent) {
+// SHARDED: rows resolved through the shard map (two 64-bit divisions per wavefront otherwise compiled in);
+// LEAN: the common fused-step case - TransE fast path, tables updated in place, no gradient outputs - with the
+// generic / emitting code removed at compile time.  Code size matters: the five kernels of a step do not fit the
+// instruction cache together, every launch starts cold, and the full-featured kernel was 11 k instructions.
+template <int NIT, bool SHARDED, bool LEAN>
+__global__ __launch_bounds__(KGE_BLOCK) void update_kernel_reg(UpdateArgs a_in, int nb_ent) {
+    UpdateArgs a = a_in;
+    if constexpr (!SHARDED) { a.em.n = 0; a.rm.n = 0; }
+    if constexpr (LEAN) {
+        a.transe_fast = 1; a.emit_ent = 0; a.emit_rel = 0;
+        a.g0 = a.g1 = a.gs0 = a.gs1 = a.gr = a.gsr = nullptr; a.rid = nullptr; a.dry = 0;
+    }
     const int lane = LANE();
     const bool reg = a.reg_coef > 0.f && a.reg_norm > 0;
     // the (fewer) relation workgroups are dispatched FIRST: measured 14.9 vs 16.5 us - a relation wavefront has
@@ -1145,12 +1155,21 @@ int launch_update(const UpdateArgs &a, hipStream_t s) {
     const dim3 g(nbE + nbR), b(KGE_BLOCK);
     const int dmax = a.model_d_e > a.d_r ? a.model_d_e : a.d_r;
     const bool vec = a.model_d_e % 4 == 0 && a.d_r % 4 == 0;
-#ifdef UPD_PROBE_DRY                 // tuning probe: a write-free pass first, so that the real pass finds its rows in L2
-    if (vec && dmax <= 512 && dmax > 256) { UpdateArgs d = a; d.dry = 1; hipLaunchKernelGGL(update_kernel_reg<2>, g, b, 0, s, d, nbE); }
-#endif
-    if (vec && dmax <= 256) hipLaunchKernelGGL(update_kernel_reg<1>, g, b, 0, s, a, nbE);
-    else if (vec && dmax <= 512) hipLaunchKernelGGL(update_kernel_reg<2>, g, b, 0, s, a, nbE);
-    else if (vec && dmax <= 1024) hipLaunchKernelGGL(update_kernel_reg<4>, g, b, 0, s, a, nbE);
+    const bool sharded = a.em.n != 0 || a.rm.n != 0;
+    const bool lean = a.transe_fast && !a.emit_ent && !a.emit_rel && !a.g0 && !a.g1 && !a.gs0 && !a.gs1 && !a.gr &&
+                      !a.gsr && !a.rid && !a.dry;
+    const int nit = dmax <= 256 ? 1 : (dmax <= 512 ? 2 : 4);
+#define KGE_UPD(N, SH, LE) hipLaunchKernelGGL((update_kernel_reg<N, SH, LE>), g, b, 0, s, a, nbE)
+#define KGE_UPD_N(N)                                                             \
+    do {                                                                         \
+        if (sharded) { if (lean) KGE_UPD(N, true, true); else KGE_UPD(N, true, false); } \
+        else { if (lean) KGE_UPD(N, false, true); else KGE_UPD(N, false, false); }       \
+    } while (0)
+    if (vec && dmax <= 1024) {
+        if (nit == 1) KGE_UPD_N(1); else if (nit == 2) KGE_UPD_N(2); else KGE_UPD_N(4);
+    }
+#undef KGE_UPD_N
+#undef KGE_UPD
     else if (vec) hipLaunchKernelGGL(update_kernel<4>, g, b, 0, s, a, nbE);
     else hipLaunchKernelGGL(update_kernel<1>, g, b, 0, s, a, nbE);
     return check_launch();
