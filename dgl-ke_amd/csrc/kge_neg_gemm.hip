@@ -49,7 +49,7 @@ __device__ __forceinline__ float sq4(const float4 &v) { return v.x * v.x + v.y *
 // forward: one wavefront per 16x16 tile of S
 // =============================================================================================
 #ifndef FU
-#define FU 8    // k-steps (of 16) per register buffer
+#define FU 2    // k-steps (of 16) per register buffer (small on purpose: code size)
 #endif
 
 template <bool L2, bool STATS>
@@ -165,7 +165,7 @@ int launch_neg_fwd_gemm(const GemmArgs &a, hipStream_t s) {
 // One "macro step" = 16 values of the reduction index = 4 MFMA k-steps = 16 MFMAs.
 // =============================================================================================
 #ifndef BU
-#define BU 4    // macro steps per register buffer
+#define BU 1    // macro steps per register buffer (small on purpose: code size)
 #endif
 #define GB_MAXK 2048                   // rows of a chunk operand whose indices / statistics fit in LDS (32 KB)
 

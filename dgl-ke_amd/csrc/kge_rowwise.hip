@@ -85,8 +85,12 @@ int launch_gather_rows_sharded(float *const *shard_rows, int n_shards, int64_t p
 // ------------------------------------------------------------------------------------------
 // edge forward: positive score p_i, pos-side vector a_i (and |a_i|^2), |neg_j|^2
 // ------------------------------------------------------------------------------------------
-template <int MODEL, int V>
-__global__ __launch_bounds__(KGE_BLOCK) void edge_fwd_kernel(EdgeFwdArgs a) {
+// LEAN: local (un-sharded) tables and the Logsigmoid criterion fixed at compile time (no 64-bit divisions of
+// the shard map, no three-way loss switch) - the configuration of every single-GPU BASELINE workload
+template <int MODEL, int V, bool LEAN>
+__global__ __launch_bounds__(KGE_BLOCK) void edge_fwd_kernel(EdgeFwdArgs a_in) {
+    EdgeFwdArgs a = a_in;
+    if constexpr (LEAN) { a.src.em.n = 0; a.src.rm.n = 0; a.lp.genre = KGE_LOSS_LOGSIGMOID; a.row_pos = nullptr; }
     const int64_t w = WAVE_ID();
     const int lane = LANE();
     if (w < a.B) {
@@ -245,10 +249,13 @@ static int launch_edge_fwd_m(const EdgeFwdArgs &a, hipStream_t s) {
     const int nb = blocks_for_waves(waves);
     const bool cx = is_complex_model(MODEL);
     const bool vec = cx ? ((a.d_e / 2) % 4 == 0 && a.d_r % 4 == 0) : (a.d_e % 4 == 0);
-    if (vec)
-        hipLaunchKernelGGL((edge_fwd_kernel<MODEL, 4>), dim3(nb), dim3(KGE_BLOCK), 0, s, b);
+    const bool lean = vec && a.src.em.n == 0 && a.src.rm.n == 0 && a.lp.genre == KGE_LOSS_LOGSIGMOID && !a.row_pos;
+    if (lean)
+        hipLaunchKernelGGL((edge_fwd_kernel<MODEL, 4, true>), dim3(nb), dim3(KGE_BLOCK), 0, s, b);
+    else if (vec)
+        hipLaunchKernelGGL((edge_fwd_kernel<MODEL, 4, false>), dim3(nb), dim3(KGE_BLOCK), 0, s, b);
     else
-        hipLaunchKernelGGL((edge_fwd_kernel<MODEL, 1>), dim3(nb), dim3(KGE_BLOCK), 0, s, b);
+        hipLaunchKernelGGL((edge_fwd_kernel<MODEL, 1, false>), dim3(nb), dim3(KGE_BLOCK), 0, s, b);
     return check_launch();
 }
 
@@ -556,8 +563,16 @@ __global__ __launch_bounds__(KGE_BLOCK) void loss_kernel(LossArgs a) {
 }
 
 // register-resident variant: the whole score row (N <= 64*NPER) is loaded once.
-template <int NPER>
-__global__ __launch_bounds__(KGE_BLOCK) void loss_kernel_reg(LossArgs a) {
+// LEAN: the common configuration (Logsigmoid, point-wise, positive part done by edge_fwd, no score clamp) with
+// every other loss genre / option compiled out - the generic instantiation carries NPER copies of a three-way
+// criterion switch, the pairwise variant and the option handling (2.1 k instructions vs ~0.7 k)
+template <int NPER, bool LEAN>
+__global__ __launch_bounds__(KGE_BLOCK) void loss_kernel_reg(LossArgs a_in) {
+    LossArgs a = a_in;
+    if constexpr (LEAN) {
+        a.genre = KGE_LOSS_LOGSIGMOID; a.pairwise = 0; a.skip_pos = 1; a.clampv = 0.f; a.neg_copy = nullptr;
+        a.row_pos = nullptr; a.row_neg = nullptr;
+    }
     const int64_t i = WAVE_ID();
     if (i >= a.B) return;
     const int lane = LANE();
@@ -655,11 +670,16 @@ __global__ __launch_bounds__(KGE_BLOCK) void loss_kernel_reg(LossArgs a) {
 int launch_loss(const LossArgs &a, hipStream_t s) {
     if (a.B == 0) return KGE_OK;
     const dim3 g(blocks_for_waves(a.B)), b(KGE_BLOCK);
-    if (a.N <= 64) hipLaunchKernelGGL(loss_kernel_reg<1>, g, b, 0, s, a);
-    else if (a.N <= 128) hipLaunchKernelGGL(loss_kernel_reg<2>, g, b, 0, s, a);
-    else if (a.N <= 256) hipLaunchKernelGGL(loss_kernel_reg<4>, g, b, 0, s, a);
-    else if (a.N <= 512) hipLaunchKernelGGL(loss_kernel_reg<8>, g, b, 0, s, a);
+    const bool lean = a.genre == KGE_LOSS_LOGSIGMOID && !a.pairwise && a.skip_pos && a.clampv == 0.f && !a.neg_copy &&
+                      !a.row_pos && !a.row_neg;
+#define KGE_LOSS(N) do { if (lean) hipLaunchKernelGGL((loss_kernel_reg<N, true>), g, b, 0, s, a); \
+                         else hipLaunchKernelGGL((loss_kernel_reg<N, false>), g, b, 0, s, a); } while (0)
+    if (a.N <= 64) KGE_LOSS(1);
+    else if (a.N <= 128) KGE_LOSS(2);
+    else if (a.N <= 256) KGE_LOSS(4);
+    else if (a.N <= 512) KGE_LOSS(8);
     else hipLaunchKernelGGL(loss_kernel, g, b, 0, s, a);
+#undef KGE_LOSS
     return check_launch();
 }
 
