@@ -809,13 +809,13 @@ __global__ __launch_bounds__(KGE_BLOCK) void update_kernel(UpdateArgs a, int nb_
                     for (int e = 0; e < V; ++e) g0.v[e] += g.v[e];
                 }
 #pragma unroll
-                for (int e = 0; e < V; ++e) x.v[e] += (-a.lr * g0.v[e]) / std0;
+                for (int e = 0; e < V; ++e) x.v[e] = fmaf(g0.v[e], -a.lr / std0, x.v[e]);
             }
             for (int k = n0; k < n1; ++k) {
                 const Pack<V> g = ld<V>(a.GN + (int64_t)a.ue_neg_slot[k] * d + off);
 #pragma unroll
                 for (int e = 0; e < V; ++e) {
-                    x.v[e] += (-a.lr * g.v[e]) / std1;
+                    x.v[e] = fmaf(g.v[e], -a.lr / std1, x.v[e]);
                     g1.v[e] += g.v[e];
                 }
             }
@@ -870,7 +870,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void update_kernel(UpdateArgs a, int nb_
                 const Pack<V> g = ld<V>(a.GR + (int64_t)a.ur_edge[k] * d + off);
 #pragma unroll
                 for (int e = 0; e < V; ++e) {
-                    x.v[e] += (-a.lr * g.v[e]) / sd;
+                    x.v[e] = fmaf(g.v[e], -a.lr / sd, x.v[e]);
                     gsum.v[e] += g.v[e];
                 }
             }
@@ -972,7 +972,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void update_kernel_reg(UpdateArgs a_in, 
                 }
             } else { x[k] = zero_pack<4>(); g0[k] = zero_pack<4>(); g1[k] = zero_pack<4>(); }
         }
-#pragma unroll 2
+#pragma unroll 1
         for (int i = 0; i < npx; ++i) {
             const int adj = i < 64 ? __builtin_amdgcn_readlane(adjv, i) : a.ue_pos_adj[p0 + 1 + i];
             const int64_t eo = (int64_t)(adj >> 1) * d;
@@ -1003,7 +1003,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void update_kernel_reg(UpdateArgs a_in, 
                 }
             }
         }
-#pragma unroll 2
+#pragma unroll 1
         for (int i = 0; i < nnx; ++i) {
             const int slot = i < 64 ? __builtin_amdgcn_readlane(slotv, i) : a.ue_neg_slot[n0 + 1 + i];
             const float *src = a.GN + (int64_t)slot * d;
@@ -1033,7 +1033,9 @@ __global__ __launch_bounds__(KGE_BLOCK) void update_kernel_reg(UpdateArgs a_in, 
         if (a.dry) return;
         const float sA = has_pos ? st0 + s0 : st0;
         const float sB = has_neg ? sA + s1 : sA;
-        const float std0 = sqrtf(sA) + a.eps, std1 = sqrtf(sB) + a.eps;
+        // one division per row (-lr / std), then multiply-adds: 24 IEEE division sequences per wavefront were
+        // 10 % of this kernel's instructions (<= 1 ulp from the reference's per-element division)
+        const float k0 = -a.lr / (sqrtf(sA) + a.eps), k1 = -a.lr / (sqrtf(sB) + a.eps);
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
             const int it = lane + 64 * k;
@@ -1042,11 +1044,11 @@ __global__ __launch_bounds__(KGE_BLOCK) void update_kernel_reg(UpdateArgs a_in, 
                     Pack<4> y = x[k];
                     if (has_pos) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) y.v[e] += (-a.lr * g0[k].v[e]) / std0;
+                        for (int e = 0; e < 4; ++e) y.v[e] = fmaf(g0[k].v[e], k0, y.v[e]);
                     }
                     if (has_neg) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) y.v[e] += (-a.lr * g1[k].v[e]) / std1;
+                        for (int e = 0; e < 4; ++e) y.v[e] = fmaf(g1[k].v[e], k1, y.v[e]);
                     }
                     st<4>(row + it * 4, y);
                 }
@@ -1113,7 +1115,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void update_kernel_reg(UpdateArgs a_in, 
                 }
             } else { x[k] = zero_pack<4>(); gsum[k] = zero_pack<4>(); }
         }
-#pragma unroll 2
+#pragma unroll 1
         for (int i = 0; i < nex; ++i) {
             const int64_t eo = (int64_t)(i < 64 ? __builtin_amdgcn_readlane(edgev, i) : a.ur_edge[e0 + 1 + i]) * d;
 #pragma unroll
@@ -1139,7 +1141,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void update_kernel_reg(UpdateArgs a_in, 
         ss = wave_sum(ss) / (float)d;
         if (a.dry) return;
         const float sN = st0 + ss;
-        const float sd = sqrtf(sN) + a.eps;
+        const float kr = -a.lr / (sqrtf(sN) + a.eps);
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
             const int it = lane + 64 * k;
@@ -1147,7 +1149,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void update_kernel_reg(UpdateArgs a_in, 
                 if (!a.emit_rel) {
                     Pack<4> y = x[k];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) y.v[e] += (-a.lr * gsum[k].v[e]) / sd;
+                    for (int e = 0; e < 4; ++e) y.v[e] = fmaf(gsum[k].v[e], kr, y.v[e]);
                     st<4>(row + it * 4, y);
                 }
                 if (a.gr) st<4>(a.gr + u * (int64_t)a.ld_r + it * 4, gsum[k]);
@@ -1222,7 +1224,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void adagrad_apply_kernel(float *table, 
     const float sd = sqrtf(state[id]) + eps;
     const float *g = grad + k * (int64_t)dim;
     float *row = table + id * (int64_t)dim;
-    for (int d = lane; d < dim; d += 64) atomicAdd(&row[d], (-lr * g[d]) / sd);
+    for (int d = lane; d < dim; d += 64) atomicAdd(&row[d], g[d] * (-lr / sd));
 }
 
 int launch_adagrad_scatter(float *table, float *state, int dim, const int64_t *idx,
@@ -1255,7 +1257,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void apply_rows_kernel(float *table, flo
         Pack<V> x = ld<V>(row + it * V);
         const Pack<V> gv = ld<V>(gg + it * V);
 #pragma unroll
-        for (int e = 0; e < V; ++e) x.v[e] += (-lr * gv.v[e]) / sd;
+        for (int e = 0; e < V; ++e) x.v[e] = fmaf(gv.v[e], -lr / sd, x.v[e]);
         st<V>(row + it * V, x);
     }
     if (lane == 0) state[id] = sN;
@@ -1291,7 +1293,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void apply_packed_kernel(float *table, f
             Pack<V> x = ld<V>(row + it * V);
             const Pack<V> gv = ld<V>(g + it * V);
 #pragma unroll
-            for (int e = 0; e < V; ++e) x.v[e] += (-lr * gv.v[e]) / sd;
+            for (int e = 0; e < V; ++e) x.v[e] = fmaf(gv.v[e], -lr / sd, x.v[e]);
             st<V>(row + it * V, x);
         }
     }
