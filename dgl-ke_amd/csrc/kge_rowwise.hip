@@ -277,8 +277,10 @@ int launch_edge_fwd(const EdgeFwdArgs &a, hipStream_t s) {
 //   = dpos_i * d p_i/d(h,r,t)  +  chain of GA_i = dL/da_i through a_i = T(x_i, r_i)
 //   (+ regularisation gradient of the relation row copy)
 // ------------------------------------------------------------------------------------------
-template <int MODEL, int V>
-__global__ __launch_bounds__(KGE_BLOCK) void edge_bwd_kernel(EdgeBwdArgs a) {
+template <int MODEL, int V, bool LOCAL>       // LOCAL: un-sharded tables (no shard-map divisions compiled in)
+__global__ __launch_bounds__(KGE_BLOCK) void edge_bwd_kernel(EdgeBwdArgs a_in) {
+    EdgeBwdArgs a = a_in;
+    if constexpr (LOCAL) { a.src.em.n = 0; a.src.rm.n = 0; }
     const int64_t i = WAVE_ID();
     if (i >= a.B) return;
     const int lane = LANE();
@@ -459,10 +461,13 @@ static int launch_edge_bwd_m(const EdgeBwdArgs &a, hipStream_t s) {
     const int nb = blocks_for_waves(a.B);
     const bool cx = is_complex_model(MODEL);
     const bool vec = cx ? ((a.d_e / 2) % 4 == 0 && a.d_r % 4 == 0) : (a.d_e % 4 == 0);
-    if (vec)
-        hipLaunchKernelGGL((edge_bwd_kernel<MODEL, 4>), dim3(nb), dim3(KGE_BLOCK), 0, s, a);
+    const bool local = a.src.em.n == 0 && a.src.rm.n == 0;
+    if (vec && local)
+        hipLaunchKernelGGL((edge_bwd_kernel<MODEL, 4, true>), dim3(nb), dim3(KGE_BLOCK), 0, s, a);
+    else if (vec)
+        hipLaunchKernelGGL((edge_bwd_kernel<MODEL, 4, false>), dim3(nb), dim3(KGE_BLOCK), 0, s, a);
     else
-        hipLaunchKernelGGL((edge_bwd_kernel<MODEL, 1>), dim3(nb), dim3(KGE_BLOCK), 0, s, a);
+        hipLaunchKernelGGL((edge_bwd_kernel<MODEL, 1, false>), dim3(nb), dim3(KGE_BLOCK), 0, s, a);
     return check_launch();
 }
 
@@ -902,12 +907,12 @@ __global__ __launch_bounds__(KGE_BLOCK) void update_kernel(UpdateArgs a, int nb_
 // LEAN: the common fused-step case - TransE fast path, tables updated in place, no gradient outputs - with the
 // generic / emitting code removed at compile time.  Code size matters: the five kernels of a step do not fit the
 // instruction cache together, every launch starts cold, and the full-featured kernel was 11 k instructions.
-template <int NIT, bool SHARDED, bool LEAN>
-__global__ __launch_bounds__(KGE_BLOCK) void update_kernel_reg(UpdateArgs a_in, int nb_ent) {
+template <int NIT, bool SHARDED, int LEAN>      // LEAN: 0 = everything at run time, 1 = in-place + TransE fast path,
+__global__ __launch_bounds__(KGE_BLOCK) void update_kernel_reg(UpdateArgs a_in, int nb_ent) {   // 2 = in-place + per-edge gradients
     UpdateArgs a = a_in;
     if constexpr (!SHARDED) { a.em.n = 0; a.rm.n = 0; }
-    if constexpr (LEAN) {
-        a.transe_fast = 1; a.emit_ent = 0; a.emit_rel = 0;
+    if constexpr (LEAN != 0) {
+        a.transe_fast = LEAN == 1 ? 1 : 0; a.emit_ent = 0; a.emit_rel = 0;
         a.g0 = a.g1 = a.gs0 = a.gs1 = a.gr = a.gsr = nullptr; a.rid = nullptr; a.dry = 0;
     }
     const int lane = LANE();
@@ -1178,14 +1183,15 @@ int launch_update(const UpdateArgs &a, hipStream_t s) {
     const int dmax = a.model_d_e > a.d_r ? a.model_d_e : a.d_r;
     const bool vec = a.model_d_e % 4 == 0 && a.d_r % 4 == 0;
     const bool sharded = a.em.n != 0 || a.rm.n != 0;
-    const bool lean = a.transe_fast && !a.emit_ent && !a.emit_rel && !a.g0 && !a.g1 && !a.gs0 && !a.gs1 && !a.gr &&
-                      !a.gsr && !a.rid && !a.dry;
+    const bool inplace = !a.emit_ent && !a.emit_rel && !a.g0 && !a.g1 && !a.gs0 && !a.gs1 && !a.gr && !a.gsr && !a.rid &&
+                         !a.dry;
+    const int lean = !inplace ? 0 : (a.transe_fast ? 1 : 2);
     const int nit = dmax <= 256 ? 1 : (dmax <= 512 ? 2 : 4);
 #define KGE_UPD(N, SH, LE) hipLaunchKernelGGL((update_kernel_reg<N, SH, LE>), g, b, 0, s, a, nbE)
 #define KGE_UPD_N(N)                                                             \
     do {                                                                         \
-        if (sharded) { if (lean) KGE_UPD(N, true, true); else KGE_UPD(N, true, false); } \
-        else { if (lean) KGE_UPD(N, false, true); else KGE_UPD(N, false, false); }       \
+        if (sharded) { if (lean == 1) KGE_UPD(N, true, 1); else if (lean == 2) KGE_UPD(N, true, 2); else KGE_UPD(N, true, 0); } \
+        else { if (lean == 1) KGE_UPD(N, false, 1); else if (lean == 2) KGE_UPD(N, false, 2); else KGE_UPD(N, false, 0); }       \
     } while (0)
     if (vec && dmax <= 1024) {
         if (nit == 1) KGE_UPD_N(1); else if (nit == 2) KGE_UPD_N(2); else KGE_UPD_N(4);
