@@ -184,9 +184,6 @@ class Trainer(object):
         self.dataset = dataset
         if args.gpu[0] < 0:
             raise KgeError("dglke_amd trains on the GPU only: pass --gpu <id> (there is no CPU fallback)")
-        if len(args.gpu) > 1:
-            raise KgeError("multi-GPU training runs one process per GPU under torch.distributed.run "
-                           "(see bench_dist.py / dglke_amd.p2p); this entry point drives one GPU")
         th.cuda.set_device(args.gpu[0])
         self.dev = th.device("cuda", args.gpu[0])
         th.manual_seed(args.seed)
@@ -295,10 +292,172 @@ class Trainer(object):
         return reached
 
 
+class ShardedTrainer(object):
+    """one of the `--gpu g0 g1 ...` trainer processes (reference: train.py:298-317, one process per GPU on
+    tables in shared host memory).  Here the shared tables are the union of the GPUs' HBM, mapped peer to peer
+    (dglke_amd/p2p.py): every process trains on its random share of the triples with the fused step
+    (`kge_step_sharded`), lock-free across processes like the reference; the process group (gloo) is only
+    used to exchange the hipIpc handles and for barriers."""
+
+    def __init__(self, args, dataset, rank, world):
+        from . import p2p
+        from .engine import StepEngine
+        self.args, self.dataset, self.rank, self.world = args, dataset, rank, world
+        th.cuda.set_device(args.gpu[rank])
+        self.dev = th.device("cuda", args.gpu[rank])
+        B, N = args.batch_size, args.neg_sample_size
+        self.chunk = N if N <= B else B
+        self.fused, self.n_lanes = True, 1
+        self.device_sampler = 2 * B + (B // self.chunk) * N <= 4096
+        if args.neg_deg_sample or args.has_edge_importance or not self.device_sampler:
+            raise KgeError("multi-GPU training uses the on-device sampler: no --neg_deg_sample / "
+                           "--has_edge_importance, and 2*batch + chunks*neg <= 4096")
+        if args.model_name == 'RESCAL':
+            raise KgeError("RESCAL is not available on sharded tables")
+        d_e = args.hidden_dim * (2 if args.double_ent else 1)
+        d_r = args.hidden_dim * (2 if args.double_rel else 1)
+        self.emb_init = (args.gamma + 2.0) / args.hidden_dim
+        self.tabs = p2p.ShardedTables(dataset.n_entities, dataset.n_relations, d_e, d_r, self.dev, world, rank)
+        if not self.tabs.probe():
+            raise KgeError("peer mappings do not reach the other GPUs' memory")
+        self.tabs.init_uniform(self.emb_init, args.seed)
+        self.engine = StepEngine(args.model_name, dataset.n_entities, dataset.n_relations, args.hidden_dim, args.gamma,
+                                 args.lr, self.dev, args.double_ent, args.double_rel, args.neg_adversarial_sampling,
+                                 args.adversarial_temperature, args.regularization_coef, args.regularization_norm,
+                                 args.loss_genre, args.pairwise, args.margin, shards=self.tabs)
+        tr = dataset.train
+        part = np.array_split(np.random.RandomState(args.seed).permutation(len(tr[0])), world)[rank]
+        self.lane = _Lane(self, rank, self.engine, tuple(np.asarray(x)[part] for x in tr[:3]), None)
+
+    def full_tables(self):
+        """the whole entity / relation tables read through the shard map (rank-local copies)."""
+        ds = self.dataset
+        ent = self.tabs.gather("ent", th.arange(ds.n_entities, device=self.dev))
+        rel = self.tabs.gather("rel", th.arange(ds.n_relations, device=self.dev))
+        return ent, rel
+
+    def evaluate(self, which, mode):
+        from . import eval as kev
+        args, ds = self.args, self.dataset
+        trip = getattr(ds, which)
+        h, r, t = (np.asarray(x) for x in trip[:3])
+        if args.eval_percent < 1:
+            keep = np.random.RandomState(args.seed + 17).permutation(len(h))[:max(1, int(len(h) * args.eval_percent))]
+            h, r, t = h[keep], r[keep], t[keep]
+        known = None
+        if args.eval_filter:
+            parts = [p for p in (ds.train, ds.valid, ds.test) if p is not None]
+            known = tuple(np.concatenate([np.asarray(p[k]) for p in parts]) for k in range(3))
+        ent, rel = self.full_tables()
+        Eb = int(max(1, min(max(args.batch_size_eval, 1024), (1 << 31) // (4 * ds.n_entities), len(h))))
+        metrics = kev.evaluate(args.model_name, ent, rel, args.gamma, self.emb_init, (h, r, t), known, batch=Eb)
+        for k, v in metrics.items():
+            print('[{}]{} average {}: {}'.format(self.rank, mode, k, v))
+        return metrics
+
+    def train(self):
+        import torch.distributed as dist
+        args, rank = self.args, self.rank
+        keys = ['loss'] if args.pairwise else ['pos_loss', 'neg_loss', 'loss']
+        if args.regularization_coef > 0 and args.regularization_norm > 0:
+            keys.append('regularization')
+        idx = {'pos_loss': 0, 'neg_loss': 1, 'loss': 2, 'regularization': 3}
+        marks = set()
+        for iv in (args.log_interval, args.eval_interval if args.valid else 0):
+            if iv and iv > 0:
+                marks.update(range(iv, args.max_step + 1, iv))
+        marks.add(args.max_step)
+        th.cuda.synchronize()
+        dist.barrier()
+        train_start = start = time.time()
+        step = since_log = 0
+        for nxt in sorted(marks):
+            n = nxt - step
+            if n > 0:
+                self.lane.enqueue(n)
+                th.cuda.synchronize()
+                step, since_log = nxt, since_log + n
+            if step % args.log_interval == 0 and since_log:
+                sums = self.engine.read_loss_sums()
+                for k in keys:
+                    print('[proc {}][Train]({}/{}) average {}: {}'.format(rank, step, args.max_step, k,
+                                                                        sums[idx[k]] / since_log))
+                print('[proc {}][Train] {} steps take {:.3f} seconds'.format(rank, since_log, time.time() - start))
+                since_log, start = 0, time.time()
+            if args.valid and step % args.eval_interval == 0 and step > 1 and self.dataset.valid is not None:
+                dist.barrier()                   # like the reference: all trainers stop for the validation
+                if rank == 0:
+                    valid_start = time.time()
+                    self.evaluate('valid', 'Valid')
+                    print('[proc {}]validation take {:.3f} seconds:'.format(rank, time.time() - valid_start))
+                dist.barrier()
+                start = time.time()
+        th.cuda.synchronize()
+        print('proc {} takes {:.3f} seconds'.format(rank, time.time() - train_start))
+        dist.barrier()
+
+
+def _mp_worker(rank, args, port):
+    import torch.distributed as dist
+    world = len(args.gpu)
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        init_time_start = time.time()
+        if rank != 0:                            # one copy of the loader messages is enough
+            sys.stdout = open(os.devnull, "w")
+        dataset = get_dataset(args.data_path, args.dataset, args.format, args.delimiter, args.data_files,
+                              args.has_edge_importance)
+        sys.stdout = sys.__stdout__
+        trainer = ShardedTrainer(args, dataset, rank, world)
+        if rank == 0:
+            print('Total initialize time {:.3f} seconds'.format(time.time() - init_time_start))
+        start = time.time()
+        trainer.train()
+        if rank == 0:
+            print('training takes {} seconds'.format(time.time() - start))
+            ent, rel = trainer.full_tables()
+            if not args.no_save_emb:
+                print('Save model to {}'.format(args.save_path))
+                np.save(os.path.join(args.save_path, '%s_%s_entity.npy' % (args.dataset, args.model_name)), ent.cpu().numpy())
+                np.save(os.path.join(args.save_path, '%s_%s_relation.npy' % (args.dataset, args.model_name)), rel.cpu().numpy())
+                conf = dict(vars(args))
+                conf.update({'emp_file': dataset.emap_fname, 'rmap_file': dataset.rmap_fname})
+                with open(os.path.join(args.save_path, 'config.json'), 'w') as f:
+                    json.dump(conf, f, indent=4)
+            if args.test:
+                start = time.time()
+                trainer.evaluate('test', 'Test')
+                print('testing takes {:.3f} seconds'.format(time.time() - start))
+        dist.barrier()
+        trainer.tabs.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def launch_multi_gpu(args):
+    """`--gpu g0 g1 ...`: one trainer process per listed GPU (the same GPU may be listed twice: the processes
+    then share it, which is how the path is tested on a one-GPU box)."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    mp.spawn(_mp_worker, args=(args, port), nprocs=len(args.gpu), join=True)
+
+
 def main(argv=None):
     args = ArgParser().parse_args(argv)
     prepare_save_path(args)
     init_time_start = time.time()
+    if len(args.gpu) > 1:                        # multi-GPU: one process per GPU on peer-to-peer shared tables
+        if min(args.gpu) < 0:
+            raise KgeError("dglke_amd trains on the GPU only: pass --gpu <ids> (there is no CPU fallback)")
+        args.batch_size = get_compatible_batch_size(args.batch_size, args.neg_sample_size)
+        args.eval_filter = not args.no_eval_filter
+        args.soft_rel_part = args.strict_rel_part = False
+        launch_multi_gpu(args)
+        return None
     dataset = get_dataset(args.data_path, args.dataset, args.format, args.delimiter, args.data_files,
                           args.has_edge_importance)
     if args.neg_sample_size_eval < 0:

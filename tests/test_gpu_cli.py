@@ -98,3 +98,32 @@ def test_train_cli_hogwild_lanes(tmp_path, capsys):
         assert "[proc %d][Train](600/600) average loss:" % k in out
     mrr = float([l for l in out.split("\n") if l.startswith("[0]Test average MRR:")][0].split(":")[1])
     assert mrr > 10 * 2.0 / 400
+
+
+def test_train_cli_multi_process_shared_tables(tmp_path):
+    """`--gpu 0 0`: two trainer processes (here on one GPU) on peer-to-peer shared tables - the multi-GPU mode
+    of the CLI; hipIpc mapping, sharded fused step, gather for evaluation and saving."""
+    import subprocess
+    data = str(tmp_path / "kg")
+    _planted(data)
+    cmd = [sys.executable, os.path.join(ROOT, "dgl-ke_amd", "dglke_train"), "--model_name", "TransE_l2", "--format",
+           "udd_hrt", "--dataset", "toy", "--data_path", data, "--data_files", "e.dict", "r.dict", "train.txt",
+           "valid.txt", "test.txt", "--save_path", str(tmp_path / "ckpts"), "--gpu", "0", "0", "--batch_size", "256",
+           "--neg_sample_size", "64", "--hidden_dim", "32", "-g", "8", "--lr", "0.25", "-adv", "-rc", "1e-7",
+           "--max_step", "600", "--log_interval", "300", "--eval_interval", "600", "--valid", "--test",
+           "--graph_steps", "100"]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    out = r.stdout.decode(errors="replace")
+    assert r.returncode == 0, out[-3000:]
+    for k in range(2):
+        assert "[proc %d][Train](600/600) average loss:" % k in out, out[-2000:]
+    assert "[0]Valid average MRR:" in out and "[0]Test average MRR:" in out
+    mrr = float([l for l in out.split("\n") if l.startswith("[0]Test average MRR:")][0].split(":")[1])
+    assert mrr > 10 * 2.0 / 400, out[-1500:]
+    save = os.path.join(str(tmp_path / "ckpts"), "TransE_l2_toy_0")
+    ent = np.load(os.path.join(save, "toy_TransE_l2_entity.npy"))
+    rel = np.load(os.path.join(save, "toy_TransE_l2_relation.npy"))
+    assert ent.shape == (400, 32) and rel.shape == (6, 32) and np.isfinite(ent).all()
+    assert json.load(open(os.path.join(save, "config.json")))["gpu"] == [0, 0]
