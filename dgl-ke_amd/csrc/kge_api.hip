@@ -40,7 +40,11 @@ struct Carver {
 };
 
 int check_model(int model, int d_e, int d_r) {
-    if (model < KGE_TRANSE_L1 || model > KGE_RESCAL) return fail(KGE_ERR_ARG, "unknown model %d", model);
+    if (model < KGE_TRANSE_L1 || model > KGE_TRANSR) return fail(KGE_ERR_ARG, "unknown model %d", model);
+    if (model == KGE_TRANSR) {
+        if (d_e <= 0 || d_r <= 0 || d_r > 1024) return fail(KGE_ERR_ARG, "TransR needs 0 < d_r <= 1024 (got d_e=%d d_r=%d)", d_e, d_r);
+        return KGE_OK;
+    }
     if (model == KGE_RESCAL) {
         if (d_e <= 0 || d_e > 1024 || (int64_t)d_r != (int64_t)d_e * d_e)
             return fail(KGE_ERR_ARG, "RESCAL needs d_r == d_e*d_e and d_e <= 1024 (got d_e=%d d_r=%d)", d_e, d_r);
@@ -98,6 +102,7 @@ int kge_score_pos(int model, const float *h, const float *r, const float *t, int
                   int d_r, float gamma, float emb_init, float *out, void *stream) {
     if (int rc = check_model(model, d_e, d_r)) return rc;
     if (!h || !r || !t || !out || B < 0) return fail(KGE_ERR_ARG, "kge_score_pos: bad argument");
+    if (model == KGE_TRANSR) return fail(KGE_ERR_ARG, "TransR has no modular score ops: use kge_step_fused / kge_rank_eval_ex");
     if (model == KGE_RESCAL) {                       // p = h . (M t), one pass over M per edge
         RescalMatvecArgs m{};
         m.B = (int)B; m.D = d_e; m.rel = r; m.y1 = t; m.pd = h; m.p = out;
@@ -118,6 +123,7 @@ int kge_score_pos_bwd(int model, const float *h, const float *r, const float *t,
                       float *gt, void *stream) {
     if (int rc = check_model(model, d_e, d_r)) return rc;
     if (!h || !r || !t || !dpos || B < 0) return fail(KGE_ERR_ARG, "kge_score_pos_bwd: bad argument");
+    if (model == KGE_TRANSR) return fail(KGE_ERR_ARG, "TransR has no modular score ops: use kge_step_fused / kge_rank_eval_ex");
     if (model == KGE_RESCAL) {                       // gh = dp M t, gt = dp M^T h, gr = dp h t^T
         if (!gh || !gt || !gr) return fail(KGE_ERR_ARG, "kge_score_pos_bwd: RESCAL needs all three outputs");
         hipStream_t s = (hipStream_t)stream;
@@ -198,6 +204,7 @@ int kge_score_neg_fwd(int model, int neg_head, const float *pos_side, const floa
     if (int rc = check_model(model, d_e, d_r)) return rc;
     if (!pos_side || !rel || !neg || !out || !ws || C < 0 || chunk <= 0 || N <= 0)
         return fail(KGE_ERR_ARG, "kge_score_neg_fwd: bad argument");
+    if (model == KGE_TRANSR) return fail(KGE_ERR_ARG, "TransR has no modular score ops: use kge_step_fused / kge_rank_eval_ex");
     if (C == 0) return KGE_OK;
     hipStream_t s = (hipStream_t)stream;
     Carver cv(ws, ws_bytes);
@@ -226,6 +233,7 @@ int kge_score_neg_bwd(int model, int neg_head, const float *pos_side, const floa
     if (!pos_side || !rel || !neg || !dneg || !g_pos_side || !g_rel || !g_neg || !ws || C < 0 ||
         chunk <= 0 || N <= 0)
         return fail(KGE_ERR_ARG, "kge_score_neg_bwd: bad argument");
+    if (model == KGE_TRANSR) return fail(KGE_ERR_ARG, "TransR has no modular score ops: use kge_step_fused / kge_rank_eval_ex");
     if ((model == KGE_TRANSE_L2 || model == KGE_SIMPLE) && !neg_score)
         return fail(KGE_ERR_ARG, "kge_score_neg_bwd: TransE_l2 / SimplE need the forward scores");
     if (C == 0) return KGE_OK;
@@ -365,6 +373,13 @@ size_t kge_step_workspace_bytes(const kge_hparams *hp, int B, int C, int chunk, 
     add(CN * d_e);       // GN
     add(B * d_e);        // P (TransE) or GH
     add(B * d_e);                 // GT
+    if (hp->model == KGE_TRANSR) {   // projections, q, signs, dq, P s, P dq; sign bytes; per-edge projection gradients
+        for (int k = 0; k < 5; ++k) add(B * d_r);
+        add(B * d_e); add(B * d_e);
+        add(((size_t)B * N * d_r + 3) / 4);
+        add((size_t)B * d_e * d_r);
+        add(B); add(B); add(UR); add(UR);
+    }
     if (hp->model == KGE_RESCAL) {   // V = M t, M^T h, M^T GA (no [B, d_r] buffer) + update scratch
         add(B * d_e); add(B * d_e); add(B * d_e);
         add((size_t)B * RESCAL_RB); add(UR); add((size_t)UR * RESCAL_RB);
@@ -429,6 +444,19 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     float *Rgs = rescal ? cv.f((size_t)B * RESCAL_RB) : nullptr, *Rstd = rescal ? cv.f(b->UR) : nullptr;
     float *Rreg = rescal ? cv.f((size_t)b->UR * RESCAL_RB) : nullptr;
     float *GR = rescal ? nullptr : cv.f((size_t)B * d_r);
+    const bool transr = hp->model == KGE_TRANSR;
+    TransRArgs tr{};
+    float *TR1 = nullptr, *TR2 = nullptr;
+    if (transr) {
+        if (sh || emit) return fail(KGE_ERR_ARG, "TransR is not available in the sharded / gradient-emitting steps");
+        if (!tb->proj || !tb->proj_state) return fail(KGE_ERR_ARG, "TransR needs kge_tables.proj / proj_state");
+        tr.HP = cv.f((size_t)B * d_r); tr.TP = cv.f((size_t)B * d_r); tr.Q = cv.f((size_t)B * d_r);
+        tr.SG = cv.f((size_t)B * d_r); tr.DQ = cv.f((size_t)B * d_r);
+        TR1 = cv.f((size_t)B * d_e); TR2 = cv.f((size_t)B * d_e);
+        tr.Z = reinterpret_cast<signed char *>(cv.f(((size_t)B * N * d_r + 3) / 4));
+        tr.GP = cv.f((size_t)B * d_e * d_r);
+        tr.gs0 = cv.f(B); tr.gs1 = cv.f(B); tr.k0 = cv.f(b->UR); tr.k1 = cv.f(b->UR);
+    }
     float *row_pos = cv.f(B), *row_neg = cv.f(B), *reg_ent = cv.f(b->UE), *reg_rel = cv.f(b->UR);
     if (!cv.ok())
         return fail(KGE_ERR_WORKSPACE, "kge_step: workspace too small (%zu < %zu)", ws_bytes,
@@ -442,6 +470,15 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     const LossParams lp{hp->loss_genre, hp->adv, hp->pairwise, hp->adv_temp, hp->margin};
 
     const EdgeSrc src{tb->ent, b->h_gid, tb->ent, b->t_gid, tb->rel, b->rel_ids, em, rm};
+    if (transr) {
+        tr.B = B; tr.C = C; tr.chunk = chunk; tr.N = N; tr.De = d_e; tr.Dr = d_r; tr.neg_head = b->neg_head;
+        tr.UR = b->UR; tr.reg_norm = hp->reg_norm; tr.gamma = hp->gamma; tr.lr = hp->lr; tr.eps = hp->eps;
+        tr.reg_coef = reg ? hp->reg_coef : 0.f;
+        tr.ent = tb->ent; tr.h_gid = b->h_gid; tr.t_gid = b->t_gid; tr.neg_ids = b->neg_ids; tr.rel_ids = b->rel_ids;
+        tr.rel = tb->rel; tr.proj = tb->proj; tr.proj_state = tb->proj_state;
+        tr.P = P; tr.S = S; tr.GN = GN; tr.GR = GR; tr.dpos = dP;
+        tr.ur_id = b->ur_id; tr.ur_ptr = b->ur_ptr; tr.ur_edge = b->ur_edge; tr.counts_dev = b->counts_dev;
+    }
     const float rot_div = rot_div_of(hp->emb_init);
 
     // 1. gather + positive score + pos-side vectors (+ positive-loss part, + P rows for TransE)
@@ -459,7 +496,17 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     ef.do_pos_loss = pairwise ? 0 : 1; ef.lp = lp; ef.w = b->edge_w;
     ef.dpos = dP; ef.row_pos = want4 ? row_pos : nullptr; ef.acc = acc;
     ef.P = transe_fast ? Pg : nullptr;
-    if (rescal) {
+    if (transr) {
+        // hp = h P, tp = t P in one pass over every edge's projection matrix; then p, sign(u), q; then the
+        // batched projection of the chunk's negatives with the L1 epilogue (scores + sign bytes)
+        RescalMatvecArgs m{};
+        m.B = B; m.D = d_e; m.Dc = d_r; m.rel = tb->proj; m.ridx = b->rel_ids;
+        m.z1 = tb->ent; m.z1idx = b->h_gid; m.c1 = tr.HP;
+        m.z2 = tb->ent; m.z2idx = b->t_gid; m.c2 = tr.TP;
+        KGE_TRY(launch_rescal_matvec(m, s));
+        KGE_TRY(launch_transr_pos(tr, s));
+        KGE_TRY(launch_transr_fwd(tr, s));
+    } else if (rescal) {
         // V = M t (always: p = h.V), A = M x with x = h in tail mode (then a second product of the same pass)
         RescalMatvecArgs m{};
         m.B = B; m.D = d_e; m.rel = tb->rel; m.ridx = b->rel_ids;
@@ -479,7 +526,9 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
 
     // 2. chunked negative scores (+ per-16-column partial row statistics for the adversarial softmax)
     GemmArgs g; NegArgs na;
-    if (gemm) {
+    if (transr) {
+        // scores already in S
+    } else if (gemm) {
         if (dense_neg) fill_gemm(g, hp->model, C, chunk, N, d_e, hp->gamma, A, Bn, nullptr);
         else fill_gemm(g, hp->model, C, chunk, N, d_e, hp->gamma, A, tb->ent, b->neg_ids);
         g.S = S; g.adv_temp = hp->adv_temp; g.asq = asq; g.bsq = bsq;
@@ -501,12 +550,14 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         la.acc = acc;
         la.l2_scale = is_l2 ? 1 : 0; la.gamma = hp->gamma; la.clampv = clamp_of(hp->model);
         la.neg_copy = out ? out->neg_score : nullptr;
-        la.skip_pos = (pairwise || rescal) ? 0 : 1;          // RESCAL: no edge_fwd -> positive part here
+        la.skip_pos = (pairwise || rescal || transr) ? 0 : 1;  // RESCAL / TransR: no edge_fwd -> positive part here
         KGE_TRY(launch_loss(la, s));
     }
 
     // 4. gradients w.r.t. the pos-side vectors and the negative rows
-    if (gemm) {
+    if (transr) {
+        KGE_TRY(launch_transr_bwd(tr, s));       // dq, GN, per-edge projection gradients, relation-vector gradients
+    } else if (gemm) {
         g.PM = PM; g.PS = PS;
         g.W = fused_loss ? nullptr : S; g.Sc = S; g.pos = P; g.w = b->edge_w; g.lp = lp;
         g.GA = GA; g.GN = GN;
@@ -525,7 +576,17 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
 
     // 5. per-edge gradients of head / tail / relation rows (TransE rebuilds them in the update)
     const float *Vr = rescal ? (b->neg_head ? A : RV) : nullptr;           // RESCAL: M t
-    if (rescal) {
+    if (transr) {
+        // entity gradients through the projections: GH = P (-dp s) (+ P dq, tail mode), GT = P (+dp s) (+ P dq, head mode)
+        RescalMatvecArgs m{};
+        m.B = B; m.D = d_e; m.Dc = d_r; m.rel = tb->proj; m.ridx = b->rel_ids;
+        m.y1 = tr.SG; m.r1 = TR1; m.y2 = tr.DQ; m.r2 = TR2;
+        KGE_TRY(launch_rescal_matvec(m, s));
+        KGE_TRY(launch_rescal_axpy(dP, TR1, b->neg_head ? nullptr : TR2, B, d_e, GH, s, -1.f));
+        KGE_TRY(launch_rescal_axpy(dP, TR1, b->neg_head ? TR2 : nullptr, B, d_e, GT, s, 1.f));
+        // projection table first: the entity update below changes the h / t rows its rank-1 trace reads
+        KGE_TRY(launch_transr_proj_update(tr, s));
+    } else if (rescal) {
         // one pass over M per edge: M^T h and M^T GA;  GH = dp M t (+ M^T GA, tail mode),
         // GT = dp M^T h (+ M^T GA, head mode);  the relation gradient stays factored (update below)
         RescalMatvecArgs m{};
@@ -635,6 +696,7 @@ size_t kge_rank_workspace_bytes(int Eb, int64_t n_cand, int d_e) {
     n += align_up((size_t)n_cand * sizeof(float));          // bsq
     n += align_up((size_t)Eb * (size_t)n_cand * sizeof(float));   // S
     n += align_up((size_t)Eb * d_e * sizeof(float));        // V = M t (RESCAL)
+    n += 4 * align_up((size_t)Eb * 1024 * sizeof(float));   // TransR: hp, tp, q, sign rows (d_r <= 1024)
     return n;
 }
 
@@ -643,7 +705,18 @@ int kge_rank_eval(int model, int neg_head, const float *ent, int64_t n_ent, cons
                   int d_e, int d_r, float gamma, float emb_init, const int64_t *cand, int64_t n_cand,
                   const int64_t *filt_ptr, const int64_t *filt_ids, int Eb, int32_t *ranks,
                   float *pos_score_out, void *ws, size_t ws_bytes, unsigned flags, void *stream) {
+    return kge_rank_eval_ex(model, neg_head, ent, n_ent, rel, n_rel, nullptr, h, r, t, E, d_e, d_r, gamma, emb_init, cand,
+                            n_cand, filt_ptr, filt_ids, Eb, ranks, pos_score_out, ws, ws_bytes, flags, stream);
+}
+
+int kge_rank_eval_ex(int model, int neg_head, const float *ent, int64_t n_ent, const float *rel,
+                     int64_t n_rel, const float *proj, const int64_t *h, const int64_t *r, const int64_t *t,
+                     int64_t E, int d_e, int d_r, float gamma, float emb_init, const int64_t *cand,
+                     int64_t n_cand, const int64_t *filt_ptr, const int64_t *filt_ids, int Eb, int32_t *ranks,
+                     float *pos_score_out, void *ws, size_t ws_bytes, unsigned flags, void *stream) {
     if (int rc = check_model(model, d_e, d_r)) return rc;
+    if (model == KGE_TRANSR && (!proj || !cand))
+        return fail(KGE_ERR_ARG, "kge_rank_eval_ex: TransR needs the projection table and an explicit candidate list");
     if (!ent || !rel || n_ent <= 0 || n_rel <= 0 || E < 0 || (E && (!h || !r || !t || !ranks)) || !ws || Eb <= 0)
         return fail(KGE_ERR_ARG, "kge_rank_eval: bad argument");
     if ((filt_ptr == nullptr) != (filt_ids == nullptr))
@@ -656,6 +729,7 @@ int kge_rank_eval(int model, int neg_head, const float *ent, int64_t n_ent, cons
     float *A = cv.f((size_t)Eb * d_e), *asq = cv.f(Eb), *P = cv.f(Eb), *bsq = cv.f((size_t)N);
     float *S = cv.f((size_t)Eb * (size_t)N);
     float *RV = cv.f((size_t)Eb * d_e);
+    float *THP = cv.f((size_t)Eb * 1024), *TTP = cv.f((size_t)Eb * 1024), *TQ = cv.f((size_t)Eb * 1024), *TSG = cv.f((size_t)Eb * 1024);
     if (!cv.ok()) return fail(KGE_ERR_WORKSPACE, "kge_rank_eval: workspace too small (%zu < %zu)", ws_bytes,
                               kge_rank_workspace_bytes(Eb, N, d_e));
     const bool gemm = use_mfma(model, d_e, (int)N, flags);
@@ -674,7 +748,20 @@ int kge_rank_eval(int model, int neg_head, const float *ent, int64_t n_ent, cons
         ef.B = rows; ef.d_e = d_e; ef.d_r = d_r; ef.neg_head = neg_head; ef.model = model;
         ef.gamma = gamma; ef.rot_div = rot_div;
         ef.pos_score = pos_score_out ? pos_score_out + e0 : P; ef.A = A; ef.asq = l2g ? asq : nullptr;
-        if (model == KGE_RESCAL) {
+        if (model == KGE_TRANSR) {
+            // the training kernels with one chunk = this batch of test triples and the candidates as negatives
+            RescalMatvecArgs m{};
+            m.B = rows; m.D = d_e; m.Dc = d_r; m.rel = proj; m.ridx = r + e0;
+            m.z1 = ent; m.z1idx = h + e0; m.c1 = THP; m.z2 = ent; m.z2idx = t + e0; m.c2 = TTP;
+            KGE_TRY(launch_rescal_matvec(m, s));
+            TransRArgs tr{};
+            tr.B = rows; tr.C = 1; tr.chunk = rows; tr.N = (int)N; tr.De = d_e; tr.Dr = d_r; tr.neg_head = neg_head;
+            tr.gamma = gamma; tr.ent = ent; tr.h_gid = h + e0; tr.t_gid = t + e0; tr.neg_ids = cand; tr.rel_ids = r + e0;
+            tr.rel = rel; tr.proj = const_cast<float *>(proj);
+            tr.HP = THP; tr.TP = TTP; tr.Q = TQ; tr.SG = TSG; tr.P = ef.pos_score; tr.S = S; tr.Z = nullptr;
+            KGE_TRY(launch_transr_pos(tr, s));
+            KGE_TRY(launch_transr_fwd(tr, s));
+        } else if (model == KGE_RESCAL) {
             RescalMatvecArgs m{};
             m.B = rows; m.D = d_e; m.rel = rel; m.ridx = r + e0;
             m.y1 = ent; m.y1idx = t + e0; m.r1 = neg_head ? A : RV;
@@ -684,7 +771,9 @@ int kge_rank_eval(int model, int neg_head, const float *ent, int64_t n_ent, cons
         } else {
             KGE_TRY(launch_edge_fwd(ef, s));
         }
-        if (gemm) {
+        if (model == KGE_TRANSR) {
+            // scores already in S
+        } else if (gemm) {
             GemmArgs g; fill_gemm(g, model, 1, rows, (int)N, d_e, gamma, A, ent, cand);
             g.S = S; g.asq = asq; g.bsq = bsq;
             KGE_TRY(launch_neg_fwd_gemm(g, s));

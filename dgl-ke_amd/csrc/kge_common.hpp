@@ -304,8 +304,9 @@ int launch_neg_bwd_gemm(const GemmArgs &a, hipStream_t s);
 int launch_neg_fwd_pair(const NegArgs &a, hipStream_t s);
 int launch_neg_bwd_pair(const NegArgs &a, hipStream_t s);
 // ---- RESCAL (kge_rescal.hip) ----
-struct RescalMatvecArgs {            // one pass over M_i = rel + (ridx ? ridx[i] : i) * D*D per edge i
-    int B, D;
+struct RescalMatvecArgs {            // one pass over M_i = rel + (ridx ? ridx[i] : i) * D*Dc per edge i
+    int B, D;                        // D rows; Dc columns (0: square).  y vectors have Dc entries, z / pd vectors D
+    int Dc;
     const float *rel; const int64_t *ridx;
     const float *y1; const int64_t *y1idx;   // r1 = M y1   (vectors: base + (idx ? idx[i] : i) * D; null = absent)
     const float *y2; const int64_t *y2idx;   // r2 = M y2
@@ -336,9 +337,29 @@ struct RescalUpdateArgs {            // fused Adagrad of the relation matrices (
     float *reg_rel, *acc;
 };
 int launch_rescal_matvec(const RescalMatvecArgs &a, hipStream_t s);
-int launch_rescal_axpy(const float *s1, const float *u1, const float *u2, int B, int D, float *out, hipStream_t s);
+int launch_rescal_axpy(const float *s1, const float *u1, const float *u2, int B, int D, float *out, hipStream_t s,
+                       float alpha = 1.f);      // out_i = alpha * s1_i * u1_i + u2_i
 int launch_rescal_outer(const RescalOuterArgs &a, hipStream_t s);
 int launch_rescal_update_rel(const RescalUpdateArgs &a, hipStream_t s);
+// ---- TransR (kge_transr.hip) ----
+struct TransRArgs {
+    int B, C, chunk, N, De, Dr, neg_head, UR, reg_norm;
+    float gamma, lr, eps, reg_coef;
+    const float *ent; const int64_t *h_gid, *t_gid, *neg_ids, *rel_ids;
+    const float *rel; float *proj, *proj_state;
+    float *HP, *TP, *Q, *SG;         // [B, Dr] projected head / tail, q = x P - r, sign(hp + r - tp)
+    float *P;                        // [B] positive scores
+    float *S;                        // [B, N] negative scores, later dL/dn
+    signed char *Z;                  // [B, N, Dr] sign(Y - q) or null (evaluation)
+    float *DQ, *GN, *GP, *GR;        // [B, Dr], [C*N, De], [B, De*Dr], [B, Dr]
+    const float *dpos;
+    const int64_t *ur_id; const int32_t *ur_ptr, *ur_edge, *counts_dev;
+    float *gs0, *gs1, *k0, *k1;      // [B], [B], [UR], [UR] scratch of the projection update
+};
+int launch_transr_pos(const TransRArgs &a, hipStream_t s);
+int launch_transr_fwd(const TransRArgs &a, hipStream_t s);
+int launch_transr_bwd(const TransRArgs &a, hipStream_t s);
+int launch_transr_proj_update(const TransRArgs &a, hipStream_t s);
 bool neg_bcast_supported(int model, int d_e);          // kge_neg_bcast.hip: lane = row, other operand wave-uniform
 int launch_neg_fwd_bcast(const NegArgs &a, hipStream_t s);
 int launch_neg_bwd_bcast(const NegArgs &a, hipStream_t s);

@@ -24,31 +24,32 @@ __global__ __launch_bounds__(KGE_BLOCK) void rescal_matvec_kernel(RescalMatvecAr
     __shared__ float pred[KGE_WAVES_PER_BLOCK];
     const int i = blockIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int D = a.D;
-    const float *M = a.rel + (a.ridx ? a.ridx[i] : (int64_t)i) * (int64_t)D * D;
-    auto vec = [&](const float *base, const int64_t *idx) -> const float * {
-        return base ? base + (idx ? idx[i] : (int64_t)i) * (int64_t)D : nullptr;
+    const int D = a.D;                                // rows of M
+    const int Dc = a.Dc > 0 ? a.Dc : a.D;             // columns of M (RESCAL: square; TransR projections: D_e x D_r)
+    const float *M = a.rel + (a.ridx ? a.ridx[i] : (int64_t)i) * (int64_t)D * Dc;
+    auto vec = [&](const float *base, const int64_t *idx, int len) -> const float * {
+        return base ? base + (idx ? idx[i] : (int64_t)i) * (int64_t)len : nullptr;
     };
-    const float *y1 = vec(a.y1, a.y1idx), *y2 = vec(a.y2, a.y2idx);
-    const float *z1 = vec(a.z1, a.z1idx), *z2 = vec(a.z2, a.z2idx);
-    const float *pd = vec(a.pd, a.pdidx);
+    const float *y1 = vec(a.y1, a.y1idx, Dc), *y2 = vec(a.y2, a.y2idx, Dc);      // column-space vectors
+    const float *z1 = vec(a.z1, a.z1idx, D), *z2 = vec(a.z2, a.z2idx, D);        // row-space vectors
+    const float *pd = vec(a.pd, a.pdidx, D);
     float pacc = 0.f;
     float y1v[NCH], y2v[NCH], c1[NCH], c2[NCH];
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
         const int b = lane + 64 * k;
-        y1v[k] = (y1 && b < D) ? y1[b] : 0.f;
-        y2v[k] = (y2 && b < D) ? y2[b] : 0.f;
+        y1v[k] = (y1 && b < Dc) ? y1[b] : 0.f;
+        y2v[k] = (y2 && b < Dc) ? y2[b] : 0.f;
         c1[k] = 0.f; c2[k] = 0.f;
     }
     for (int r = wave; r < D; r += KGE_WAVES_PER_BLOCK) {
-        const float *row = M + (int64_t)r * D;
+        const float *row = M + (int64_t)r * Dc;
         const float zz1 = z1 ? z1[r] : 0.f, zz2 = z2 ? z2[r] : 0.f;
         float d1 = 0.f, d2 = 0.f;
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
             const int b = lane + 64 * k;
-            const float m = b < D ? row[b] : 0.f;
+            const float m = b < Dc ? row[b] : 0.f;
             d1 = fmaf(m, y1v[k], d1);
             d2 = fmaf(m, y2v[k], d2);
             c1[k] = fmaf(m, zz1, c1[k]);
@@ -81,12 +82,12 @@ __global__ __launch_bounds__(KGE_BLOCK) void rescal_matvec_kernel(RescalMatvecAr
             colsum[1][wave][lane + 64 * k] = c2[k];
         }
         __syncthreads();
-        for (int b = threadIdx.x; b < D; b += KGE_BLOCK) {
+        for (int b = threadIdx.x; b < Dc; b += KGE_BLOCK) {
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int w = 0; w < KGE_WAVES_PER_BLOCK; ++w) { s1 += colsum[0][w][b]; s2 += colsum[1][w][b]; }
-            if (a.c1) a.c1[(int64_t)i * D + b] = s1;
-            if (a.c2) a.c2[(int64_t)i * D + b] = s2;
+            if (a.c1) a.c1[(int64_t)i * Dc + b] = s1;
+            if (a.c2) a.c2[(int64_t)i * Dc + b] = s2;
         }
     }
 }
@@ -94,28 +95,30 @@ __global__ __launch_bounds__(KGE_BLOCK) void rescal_matvec_kernel(RescalMatvecAr
 int launch_rescal_matvec(const RescalMatvecArgs &a, hipStream_t s) {
     if (a.B == 0) return KGE_OK;
     const dim3 g(a.B), b(KGE_BLOCK);
-    if (a.D <= 256) hipLaunchKernelGGL(rescal_matvec_kernel<4>, g, b, 0, s, a);
-    else if (a.D <= 512) hipLaunchKernelGGL(rescal_matvec_kernel<8>, g, b, 0, s, a);
-    else if (a.D <= 1024) hipLaunchKernelGGL(rescal_matvec_kernel<16>, g, b, 0, s, a);
+    const int cols = a.Dc > 0 ? a.Dc : a.D;
+    if (cols <= 256) hipLaunchKernelGGL(rescal_matvec_kernel<4>, g, b, 0, s, a);
+    else if (cols <= 512) hipLaunchKernelGGL(rescal_matvec_kernel<8>, g, b, 0, s, a);
+    else if (cols <= 1024) hipLaunchKernelGGL(rescal_matvec_kernel<16>, g, b, 0, s, a);
     else return KGE_ERR_ARG;
     return check_launch_r();
 }
 
 // out_i = s1_i * u1_i (+ u2_i)   (vector combine: GH = dp * (M t) + M^T GA ...), one wavefront per edge
 __global__ __launch_bounds__(KGE_BLOCK) void rescal_axpy_kernel(const float *s1, const float *u1, const float *u2, int B,
-                                                                int D, float *out) {
+                                                                int D, float *out, float alpha) {
     const int64_t i = (int64_t)blockIdx.x * KGE_WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if (i >= B) return;
     const int lane = threadIdx.x & 63;
-    const float c = s1 ? s1[i] : 1.f;
+    const float c = alpha * (s1 ? s1[i] : 1.f);
     for (int b = lane; b < D; b += 64)
         out[i * (int64_t)D + b] = c * u1[i * (int64_t)D + b] + (u2 ? u2[i * (int64_t)D + b] : 0.f);
 }
 
-int launch_rescal_axpy(const float *s1, const float *u1, const float *u2, int B, int D, float *out, hipStream_t s) {
+int launch_rescal_axpy(const float *s1, const float *u1, const float *u2, int B, int D, float *out, hipStream_t s,
+                       float alpha) {
     if (B == 0) return KGE_OK;
     hipLaunchKernelGGL(rescal_axpy_kernel, dim3((B + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK), dim3(KGE_BLOCK), 0, s,
-                       s1, u1, u2, B, D, out);
+                       s1, u1, u2, B, D, out, alpha);
     return check_launch_r();
 }
 

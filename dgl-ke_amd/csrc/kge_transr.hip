@@ -1,0 +1,333 @@
+// kge_transr.hip - TransR (models/pytorch/score_fun.py:110-220): every relation owns a projection matrix
+// P [ent_dim x rel_dim] (a THIRD table, projection_emb) and
+//     positive score   p    = gamma - |h P + r - t P|_1                                 (edge_func, :122-127)
+//     negative score   n_ij = gamma - |e_j P_i - (x_i P_i - r_i)|_1                     (create_neg, :199-219;
+//                             x = tail in head mode, head in tail mode - BOTH closures subtract r)
+// i.e. every negative of a chunk is projected with every positive's matrix: B batched [N x D_e] x [D_e x D_r]
+// products per step (32 GMAC at the FB15k shape) - real GEMM work, done here by one LDS-tiled fp32-MFMA tile
+// routine (64 x 64 output tile per workgroup, v_mfma_f32_16x16x4_f32) shared by the three products:
+//     forward   Y_i  = Neg_c  P_i              -> L1 epilogue (scores) + sign(Y - q) as int8 for the backward
+//     backward  GN_c = sum_i dY_i P_i^T         (K runs over the chunk's positives x D_r)
+//               GP_i = Neg_c^T dY_i + x_i (x) dq_i   (per-edge gradient of the projection matrix, materialised:
+//                       it is full rank and Adagrad needs its mean square per traced row)
+// with dY_ij = -W_ij sign(Y_ij - q_i), dq_i = -sum_j dY_ij.  The reference materialises Y [B, N, D_r] fp32
+// (320 MB at the FB15k shape); here only the sign byte survives the forward (80 MB).
+#include "kge_common.hpp"
+
+using namespace kge;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#define TR_T 64          // output tile edge
+#define TR_K 16          // reduction slab
+#define TR_LD (TR_T + 4)
+
+static inline int check_launch_t() { return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH; }
+
+// one K sweep of a 64 x 64 tile: acc[ct][r] = C[wave*16 + 4*(lane/16) + r][ct*16 + lane%16].
+// loadA(row, k) / loadB(k, col) return the (zero-padded) operand elements; AKF / BKF say whether consecutive
+// threads should walk the reduction index (operand rows contiguous along k) or the tile row / column.
+template <bool AKF, bool BKF, class LA, class LB>
+__device__ __forceinline__ void tile_sweep(f32x4 (&acc)[4], int Ktot, LA loadA, LB loadB, float (*As)[TR_LD], float (*Bs)[TR_LD]) {
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63, m = lane & 15, q = lane >> 4;
+    for (int k0 = 0; k0 < Ktot; k0 += TR_K) {
+        float av[4], bv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int lin = t + KGE_BLOCK * e;
+            const int ar = AKF ? lin >> 4 : lin & 63, ak = AKF ? lin & 15 : lin >> 6;
+            const int bc = BKF ? lin >> 4 : lin & 63, bk = BKF ? lin & 15 : lin >> 6;
+            av[e] = loadA(ar, k0 + ak);
+            bv[e] = loadB(k0 + bk, bc);
+        }
+        __syncthreads();                       // previous slab fully consumed
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int lin = t + KGE_BLOCK * e;
+            const int ar = AKF ? lin >> 4 : lin & 63, ak = AKF ? lin & 15 : lin >> 6;
+            const int bc = BKF ? lin >> 4 : lin & 63, bk = BKF ? lin & 15 : lin >> 6;
+            As[ak][ar] = av[e];
+            Bs[bk][bc] = bv[e];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const float a = As[4 * s4 + q][wave * 16 + m];
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc[ct] = MFMA16(a, Bs[4 * s4 + q][ct * 16 + m], acc[ct]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// positive score, sign vector, q = x P - r   (one wavefront per edge; hp / tp from the projection pass)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(KGE_BLOCK) void transr_pos_kernel(TransRArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * KGE_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (i >= a.B) return;
+    const int lane = threadIdx.x & 63, Dr = a.Dr;
+    const float *hp = a.HP + i * Dr, *tp = a.TP + i * Dr, *r = a.rel + a.rel_ids[i] * (int64_t)Dr;
+    float s = 0.f;
+    for (int d = lane; d < Dr; d += 64) {
+        const float u = hp[d] + r[d] - tp[d];
+        s += fabsf(u);
+        a.SG[i * Dr + d] = (u > 0.f) ? 1.f : ((u < 0.f) ? -1.f : 0.f);
+        a.Q[i * Dr + d] = (a.neg_head ? tp[d] : hp[d]) - r[d];
+    }
+    s = wave_sum(s);
+    if (lane == 0) a.P[i] = a.gamma - s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward: workgroup = (positive i, block of 64 negatives); loops the D_r column tiles
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(KGE_BLOCK) void transr_fwd_kernel(TransRArgs a, int nJB) {
+    __shared__ float As[TR_K][TR_LD], Bs[TR_K][TR_LD];
+    __shared__ int64_t rowoff[TR_T];
+    const int i = blockIdx.x / nJB, j0 = (blockIdx.x % nJB) * TR_T;
+    const int c = i / a.chunk, De = a.De, Dr = a.Dr, N = a.N;
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63, m = lane & 15, q = lane >> 4;
+    if (t < TR_T) rowoff[t] = (j0 + t < N) ? a.neg_ids[(int64_t)c * N + j0 + t] * (int64_t)De : -1;
+    __syncthreads();
+    const float *Pi = a.proj + a.rel_ids[i] * (int64_t)De * Dr;
+    const float *Qi = a.Q + (int64_t)i * Dr;
+    float d[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int dr0 = 0; dr0 < Dr; dr0 += TR_T) {
+        f32x4 acc[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        tile_sweep<true, false>(acc, De,
+            [&](int row, int k) { const int64_t o = rowoff[row]; return (o >= 0 && k < De) ? a.ent[o + k] : 0.f; },
+            [&](int k, int col) { return (k < De && dr0 + col < Dr) ? Pi[(int64_t)k * Dr + dr0 + col] : 0.f; }, As, Bs);
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            const int col = dr0 + ct * 16 + m;
+            const float qv = col < Dr ? Qi[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = j0 + wave * 16 + 4 * q + r;
+                const float v = acc[ct][r] - qv;
+                if (col < Dr && j < N) {
+                    d[r] += fabsf(v);
+                    if (a.Z) a.Z[((int64_t)i * N + j) * Dr + col] = (signed char)((v > 0.f) - (v < 0.f));
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) d[r] += __shfl_xor(d[r], o, 64);
+        const int j = j0 + wave * 16 + 4 * q + r;
+        if (m == 0 && j < N) a.S[(int64_t)i * N + j] = a.gamma - d[r];
+    }
+}
+
+// dq_i = -sum_j dY_ij = sum_j W_ij sign(Y_ij - q_i)      (one wavefront per positive)
+__global__ __launch_bounds__(KGE_BLOCK) void transr_dq_kernel(TransRArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * KGE_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (i >= a.B) return;
+    const int lane = threadIdx.x & 63, Dr = a.Dr, N = a.N;
+    for (int d0 = 0; d0 < Dr; d0 += 64) {
+        const int d = d0 + lane;
+        float s = 0.f;
+        if (d < Dr)
+            for (int j = 0; j < N; ++j) s = fmaf(a.S[i * N + j], (float)a.Z[(i * N + j) * Dr + d], s);
+        if (d < Dr) a.DQ[i * Dr + d] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// GN_c[j][de] = sum_{i in chunk} sum_dr dY_i[j][dr] P_i[de][dr]    workgroup = (chunk, 64 negatives, 64 de)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(KGE_BLOCK) void transr_gn_kernel(TransRArgs a, int nJB, int nEB) {
+    __shared__ float As[TR_K][TR_LD], Bs[TR_K][TR_LD];
+    const int eb = blockIdx.x % nEB, jb = (blockIdx.x / nEB) % nJB, c = blockIdx.x / (nEB * nJB);
+    const int j0 = jb * TR_T, de0 = eb * TR_T, De = a.De, Dr = a.Dr, N = a.N, chunk = a.chunk;
+    const int DrP = (Dr + TR_K - 1) / TR_K * TR_K;              // every positive contributes whole slabs
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63, m = lane & 15, q = lane >> 4;
+    f32x4 acc[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    tile_sweep<true, true>(acc, chunk * DrP,
+        [&](int row, int k) {
+            const int il = k / DrP, dr = k - il * DrP, j = j0 + row;
+            if (j >= N || dr >= Dr) return 0.f;
+            const int64_t ij = ((int64_t)c * chunk + il) * N + j;
+            return -a.S[ij] * (float)a.Z[ij * Dr + dr];
+        },
+        [&](int k, int col) {
+            const int il = k / DrP, dr = k - il * DrP, de = de0 + col;
+            if (de >= De || dr >= Dr) return 0.f;
+            return a.proj[a.rel_ids[(int64_t)c * chunk + il] * (int64_t)De * Dr + (int64_t)de * Dr + dr];
+        }, As, Bs);
+    const bool reg = a.reg_coef > 0.f && a.reg_norm > 0;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        const int de = de0 + ct * 16 + m;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = j0 + wave * 16 + 4 * q + r;
+            if (de < De && j < N) {
+                float v = acc[ct][r];
+                if (reg) v += reg_grad(a.ent[a.neg_ids[(int64_t)c * N + j] * (int64_t)De + de], a.reg_coef, a.reg_norm);
+                a.GN[((int64_t)c * N + j) * De + de] = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// GP_i[de][dr] = sum_j Neg_j[de] dY_ij[dr] + x_i[de] dq_i[dr]     workgroup = (positive, 64 de, 64 dr)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(KGE_BLOCK) void transr_gp_kernel(TransRArgs a, int nEB, int nRB) {
+    __shared__ float As[TR_K][TR_LD], Bs[TR_K][TR_LD];
+    const int rb = blockIdx.x % nRB, eb = (blockIdx.x / nRB) % nEB, i = blockIdx.x / (nRB * nEB);
+    const int de0 = eb * TR_T, dr0 = rb * TR_T, De = a.De, Dr = a.Dr, N = a.N;
+    const int c = i / a.chunk;
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63, m = lane & 15, q = lane >> 4;
+    f32x4 acc[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    tile_sweep<false, false>(acc, N,
+        [&](int row, int k) {
+            return (k < N && de0 + row < De) ? a.ent[a.neg_ids[(int64_t)c * N + k] * (int64_t)De + de0 + row] : 0.f;
+        },
+        [&](int k, int col) {
+            if (k >= N || dr0 + col >= Dr) return 0.f;
+            const int64_t ij = (int64_t)i * N + k;
+            return -a.S[ij] * (float)a.Z[ij * Dr + dr0 + col];
+        }, As, Bs);
+    const float *x = a.ent + (a.neg_head ? a.t_gid[i] : a.h_gid[i]) * (int64_t)De;
+    const float *dq = a.DQ + (int64_t)i * Dr;
+    float *G = a.GP + (int64_t)i * De * Dr;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        const int dr = dr0 + ct * 16 + m;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int de = de0 + wave * 16 + 4 * q + r;
+            if (de < De && dr < Dr) G[(int64_t)de * Dr + dr] = acc[ct][r] + x[de] * dq[dr];
+        }
+    }
+}
+
+// relation-vector gradient per edge: GR_i = -dp_i s_i - dq_i (+ regulariser of the traced copy)
+__global__ __launch_bounds__(KGE_BLOCK) void transr_gr_kernel(TransRArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * KGE_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (i >= a.B) return;
+    const int lane = threadIdx.x & 63, Dr = a.Dr;
+    const float dp = a.dpos[i];
+    const float *r = a.rel + a.rel_ids[i] * (int64_t)Dr;
+    const bool reg = a.reg_coef > 0.f && a.reg_norm > 0;
+    for (int d = lane; d < Dr; d += 64) {
+        float g = -dp * a.SG[i * Dr + d] - a.DQ[i * Dr + d];
+        if (reg) g += reg_grad(r[d], a.reg_coef, a.reg_norm);
+        a.GR[i * Dr + d] = g;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// projection-table Adagrad (score_func.update -> projection_emb.update, score_fun.py:173-174): two traces per
+// step over the same relation ids - trace 0 from prepare() (G0_e = dp_e (t_e - h_e) (x) s_e, rank 1), trace 1
+// from the neg-prepare closure (G1_e = GP_e above).  Like tensor_models.py:330-361 per trace:
+//   st0 = st + sum_e mean(G0_e^2), P -= lr sum_e G0_e / (sqrt(st0) + eps);  st1 = st0 + sum_e mean(G1_e^2), ...
+// both gradients were taken before any update, so one pass applies both.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum_t(float v, float *red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < KGE_WAVES_PER_BLOCK; ++w) s += red[w];
+    return s;
+}
+
+__global__ __launch_bounds__(KGE_BLOCK) void transr_proj_sq_kernel(TransRArgs a) {      // one workgroup per edge
+    __shared__ float red[KGE_WAVES_PER_BLOCK];
+    const int e = blockIdx.x, De = a.De, Dr = a.Dr;
+    const int64_t n = (int64_t)De * Dr;
+    const float *G = a.GP + (int64_t)e * n;
+    float ss = 0.f;
+    for (int64_t k = threadIdx.x; k < n; k += KGE_BLOCK) ss = fmaf(G[k], G[k], ss);
+    const float s1 = block_sum_t(ss, red);
+    const float *h = a.ent + a.h_gid[e] * (int64_t)De, *t = a.ent + a.t_gid[e] * (int64_t)De;
+    float dd = 0.f, sg = 0.f;
+    for (int k = threadIdx.x; k < De; k += KGE_BLOCK) { const float u = t[k] - h[k]; dd = fmaf(u, u, dd); }
+    for (int k = threadIdx.x; k < Dr; k += KGE_BLOCK) { const float v = a.SG[(int64_t)e * Dr + k]; sg = fmaf(v, v, sg); }
+    const float d2 = block_sum_t(dd, red), s2 = block_sum_t(sg, red);
+    if (threadIdx.x == 0) {
+        const float dp = a.dpos[e];
+        a.gs0[e] = dp * dp * d2 * s2 / (float)n;
+        a.gs1[e] = s1 / (float)n;
+    }
+}
+
+__global__ void transr_proj_state_kernel(TransRArgs a) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= (a.counts_dev ? a.counts_dev[1] : a.UR)) return;
+    const int64_t id = a.ur_id[u];
+    float S0 = 0.f, S1 = 0.f;
+    for (int q = a.ur_ptr[u]; q < a.ur_ptr[u + 1]; ++q) { const int e = a.ur_edge[q]; S0 += a.gs0[e]; S1 += a.gs1[e]; }
+    const float st0 = a.proj_state[id] + S0, st1 = st0 + S1;
+    a.proj_state[id] = st1;
+    a.k0[u] = -a.lr / (sqrtf(st0) + a.eps);
+    a.k1[u] = -a.lr / (sqrtf(st1) + a.eps);
+}
+
+#define TR_RB 8      // row blocks per projection matrix in the apply kernel
+__global__ __launch_bounds__(KGE_BLOCK) void transr_proj_apply_kernel(TransRArgs a) {
+    const int u = blockIdx.x / TR_RB, rb = blockIdx.x % TR_RB;
+    if (u >= (a.counts_dev ? a.counts_dev[1] : a.UR)) return;
+    const int De = a.De, Dr = a.Dr;
+    const int rows = (De + TR_RB - 1) / TR_RB, r0 = rb * rows, r1 = min(De, r0 + rows);
+    const int e0 = a.ur_ptr[u], e1 = a.ur_ptr[u + 1];
+    float *Pm = a.proj + a.ur_id[u] * (int64_t)De * Dr;
+    const float k0 = a.k0[u], k1 = a.k1[u];
+    for (int r = r0; r < r1; ++r) {
+        for (int b = threadIdx.x; b < Dr; b += KGE_BLOCK) {
+            float g0 = 0.f, g1 = 0.f;
+            for (int q = e0; q < e1; ++q) {
+                const int64_t e = a.ur_edge[q];
+                const float th = a.ent[a.t_gid[e] * (int64_t)De + r] - a.ent[a.h_gid[e] * (int64_t)De + r];
+                g0 = fmaf(a.dpos[e] * th, a.SG[e * Dr + b], g0);
+                g1 += a.GP[e * De * Dr + (int64_t)r * Dr + b];
+            }
+            Pm[(int64_t)r * Dr + b] += k0 * g0 + k1 * g1;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side launchers
+// ---------------------------------------------------------------------------------------------
+int launch_transr_pos(const TransRArgs &a, hipStream_t s) {
+    if (a.B == 0) return KGE_OK;
+    hipLaunchKernelGGL(transr_pos_kernel, dim3((a.B + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK), dim3(KGE_BLOCK), 0, s, a);
+    return check_launch_t();
+}
+int launch_transr_fwd(const TransRArgs &a, hipStream_t s) {
+    if (a.B == 0) return KGE_OK;
+    const int nJB = (a.N + TR_T - 1) / TR_T;
+    hipLaunchKernelGGL(transr_fwd_kernel, dim3(a.B * nJB), dim3(KGE_BLOCK), 0, s, a, nJB);
+    return check_launch_t();
+}
+int launch_transr_bwd(const TransRArgs &a, hipStream_t s) {
+    if (a.B == 0) return KGE_OK;
+    const int nJB = (a.N + TR_T - 1) / TR_T, nEB = (a.De + TR_T - 1) / TR_T, nRB = (a.Dr + TR_T - 1) / TR_T;
+    const dim3 gw((a.B + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK), b(KGE_BLOCK);
+    hipLaunchKernelGGL(transr_dq_kernel, gw, b, 0, s, a);
+    hipLaunchKernelGGL(transr_gn_kernel, dim3(a.C * nJB * nEB), b, 0, s, a, nJB, nEB);
+    hipLaunchKernelGGL(transr_gp_kernel, dim3(a.B * nEB * nRB), b, 0, s, a, nEB, nRB);
+    hipLaunchKernelGGL(transr_gr_kernel, gw, b, 0, s, a);
+    return check_launch_t();
+}
+int launch_transr_proj_update(const TransRArgs &a, hipStream_t s) {
+    if (a.B == 0 || a.UR == 0) return KGE_OK;
+    hipLaunchKernelGGL(transr_proj_sq_kernel, dim3(a.B), dim3(KGE_BLOCK), 0, s, a);
+    hipLaunchKernelGGL(transr_proj_state_kernel, dim3((a.UR + 255) / 256), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(transr_proj_apply_kernel, dim3(a.UR * TR_RB), dim3(KGE_BLOCK), 0, s, a);
+    return check_launch_t();
+}

@@ -12,8 +12,8 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KGE_LIB") or os.path.join(_HERE, "libkge_hip.so")   # KGE_LIB: A/B builds
 
-KGE_ABI_VERSION = 2
-MODEL_IDS = {"TransE_l1": 0, "TransE_l2": 1, "TransE": 1, "DistMult": 2, "ComplEx": 3, "RotatE": 4, "SimplE": 5, "RESCAL": 6}
+KGE_ABI_VERSION = 3
+MODEL_IDS = {"TransE_l1": 0, "TransE_l2": 1, "TransE": 1, "DistMult": 2, "ComplEx": 3, "RotatE": 4, "SimplE": 5, "RESCAL": 6, "TransR": 7}
 LOSS_IDS = {"Logsigmoid": 0, "Logistic": 1, "Hinge": 2, "BCE": 3}
 FLAG_FORCE_PAIRWISE = 1
 FLAG_NO_TRANSE_FAST = 2
@@ -46,7 +46,7 @@ class KgeHParams(C.Structure):
 
 class KgeTables(C.Structure):
     _fields_ = [("ent", c_p), ("ent_state", c_p), ("rel", c_p), ("rel_state", c_p),
-                ("n_ent", c_i64), ("n_rel", c_i64)]
+                ("n_ent", c_i64), ("n_rel", c_i64), ("proj", c_p), ("proj_state", c_p)]
 
 
 class KgeStepOut(C.Structure):
@@ -100,6 +100,8 @@ _SIGNATURES = {
     "kge_rank_workspace_bytes": (c_sz, [c_i, c_i64, c_i]),
     "kge_rank_eval": (c_i, [c_i, c_i, c_p, c_i64, c_p, c_i64, c_p, c_p, c_p, c_i64, c_i, c_i, c_f, c_f, c_p, c_i64,
                             c_p, c_p, c_i, c_p, c_p, c_p, c_sz, c_u, c_p]),
+    "kge_rank_eval_ex": (c_i, [c_i, c_i, c_p, c_i64, c_p, c_i64, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_f, c_f, c_p, c_i64,
+                               c_p, c_p, c_i, c_p, c_p, c_p, c_sz, c_u, c_p]),
     "kge_ipc_export": (c_i, [c_p, c_p, C.POINTER(c_i64)]),
     "kge_ipc_open": (c_i, [c_p, C.POINTER(c_p)]),
     "kge_ipc_close": (c_i, [c_p]),

@@ -53,14 +53,26 @@ class StepEngine(object):
                                     % (shards.d_e, shards.d_r, self.d_e, self.d_r))
             self.ent, self.ent_state = shards.ent(0), shards.ent_state(0)
             self.rel, self.rel_state = shards.rel(0), shards.rel_state(0)
+        self.proj = self.proj_state = None      # TransR: projection_emb of the score function (score_fun.py:114-118)
+        if model_name == 'TransR' and (shards is not None):
+            raise _lib.KgeError("TransR is not available on sharded tables")
+        if shards is not None:
+            pass
         elif tables is None:
+            if model_name == 'TransR':
+                self.proj = torch.empty(n_relations, self.d_e * self.d_r, dtype=torch.float32, device=self.device)
+                self.proj_state = torch.zeros(n_relations, dtype=torch.float32, device=self.device)
             self.ent = torch.empty(n_entities, self.d_e, dtype=torch.float32, device=self.device)
             self.ent_state = torch.zeros(n_entities, dtype=torch.float32, device=self.device)
             self.rel = torch.empty(n_relations, self.d_r, dtype=torch.float32, device=self.device)
             self.rel_state = torch.zeros(n_relations, dtype=torch.float32, device=self.device)
             self.reset_parameters()
         else:
-            self.ent, self.ent_state, self.rel, self.rel_state = tables
+            self.ent, self.ent_state, self.rel, self.rel_state = tables[:4]
+            if model_name == 'TransR':
+                if len(tables) < 6:
+                    raise _lib.KgeError("TransR needs tables = (ent, ent_state, rel, rel_state, proj, proj_state)")
+                self.proj, self.proj_state = tables[4], tables[5]
         self._bind_tables()
         self.loss4 = torch.zeros(4, dtype=torch.float32, device=self.device)
         self.loss_accum = torch.zeros(4 * _lib.ACC_SLOTS, dtype=torch.float32, device=self.device)
@@ -74,6 +86,7 @@ class StepEngine(object):
         tb.ent, tb.ent_state = ptr(self.ent), ptr(self.ent_state)
         tb.rel, tb.rel_state = ptr(self.rel), ptr(self.rel_state)
         tb.n_ent, tb.n_rel = self.ent.shape[0], self.rel.shape[0]
+        tb.proj, tb.proj_state = ptr(self.proj), ptr(self.proj_state)
         self.tb = tb
 
     def reset_parameters(self):
@@ -81,6 +94,9 @@ class StepEngine(object):
         torch.nn.init.uniform_(self.rel, -self.emb_init, self.emb_init)
         self.ent_state.zero_()
         self.rel_state.zero_()
+        if self.proj is not None:                 # TransRScore.reset_parameters: projection_emb.init(1.0)
+            torch.nn.init.uniform_(self.proj, -1.0, 1.0)
+            self.proj_state.zero_()
 
     def load_tables(self, ent, rel, ent_state=None, rel_state=None):
         self.ent.copy_(torch.as_tensor(ent))

@@ -41,7 +41,7 @@ def build_filter(known_h, known_r, known_t, test_h, test_r, test_t, neg_head, n_
 class Ranker(object):
     """device-resident evaluation of one (ent, rel) table pair."""
 
-    def __init__(self, model_name, ent, rel, gamma, emb_init, batch=1024, flags=0):
+    def __init__(self, model_name, ent, rel, gamma, emb_init, batch=1024, flags=0, proj=None):
         if not ent.is_cuda:
             raise _lib.KgeError("Ranker needs CUDA (HIP) tensors; there is no CPU path")
         self.model = _lib.model_id(model_name)
@@ -49,7 +49,11 @@ class Ranker(object):
         self.gamma, self.emb_init = float(gamma), float(emb_init)
         self.batch = int(batch)
         self.flags = int(flags)
+        self.proj = proj                   # TransR: projection table [n_rel, d_e * d_r]
+        if model_name == 'TransR' and proj is None:
+            raise _lib.KgeError("TransR ranking needs the projection table (proj=...)")
         self._ws = None
+        self._all = None
 
     def ranks(self, h, r, t, neg_head, filt=None, cand=None, want_pos_score=False):
         """int32 [E] ranks of the true triples among the corruptions of the chosen side."""
@@ -63,6 +67,10 @@ class Ranker(object):
             return torch.as_tensor(np.ascontiguousarray(x)).to(dev, dt)
         h, r, t, cand = put(h), put(r), put(t), put(cand)
         E = int(h.shape[0])
+        if cand is None and self.proj is not None:         # TransR kernels walk an explicit candidate list
+            if self._all is None:
+                self._all = torch.arange(self.ent.shape[0], dtype=torch.int64, device=dev)
+            cand = self._all
         n_cand = int(cand.shape[0]) if cand is not None else int(self.ent.shape[0])
         frng = fids = None
         if filt is not None:
@@ -75,9 +83,10 @@ class Ranker(object):
             self._ws = torch.empty(need + 4096, dtype=torch.uint8, device=dev)
         ranks = torch.zeros(E, dtype=torch.int32, device=dev)
         pos = torch.empty(E, dtype=torch.float32, device=dev) if want_pos_score else None
-        _lib.check(_lib.lib().kge_rank_eval(
+        _lib.check(_lib.lib().kge_rank_eval_ex(
             self.model, int(bool(neg_head)), _lib.ptr(self.ent), self.ent.shape[0], _lib.ptr(self.rel),
-            self.rel.shape[0], _lib.ptr(h), _lib.ptr(r), _lib.ptr(t), E, self.ent.shape[1], self.rel.shape[1],
+            self.rel.shape[0], _lib.ptr(self.proj), _lib.ptr(h), _lib.ptr(r), _lib.ptr(t), E, self.ent.shape[1],
+            self.rel.shape[1],
             self.gamma, self.emb_init, _lib.ptr(cand), n_cand, _lib.ptr(frng), _lib.ptr(fids), Eb,
             _lib.ptr(ranks), _lib.ptr(pos), _lib.ptr(self._ws), self._ws.numel(), self.flags, _lib.stream_ptr()))
         return (ranks, pos) if want_pos_score else ranks
@@ -91,11 +100,11 @@ def metrics_from_ranks(ranks):
             "HITS@10": float((rk <= 10).double().mean())}
 
 
-def evaluate(model_name, ent, rel, gamma, emb_init, test, known=None, batch=1024, modes=("head", "tail")):
+def evaluate(model_name, ent, rel, gamma, emb_init, test, known=None, batch=1024, modes=("head", "tail"), proj=None):
     """filtered (known given) or raw ranking metrics over both corruption modes, averaged over all
     2E rankings like the reference (logs of the head and the tail sampler are concatenated,
     train_pytorch.py:221-231).  test / known: (h, r, t) triples of int64 arrays."""
-    rk = Ranker(model_name, ent, rel, gamma, emb_init, batch)
+    rk = Ranker(model_name, ent, rel, gamma, emb_init, batch, proj=proj)
     th_, tr_, tt_ = test
     allr = []
     for mode in modes:

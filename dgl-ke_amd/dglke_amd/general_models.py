@@ -13,7 +13,8 @@ import torch as th
 from . import ops
 from .engine import StepEngine
 from .loss import LossGenerator
-from .score_fun import ComplExScore, DistMultScore, RESCALScore, RotatEScore, SimplEScore, TransEScore
+from .score_fun import (ComplExScore, DistMultScore, RESCALScore, RotatEScore, SimplEScore, TransEScore,
+                        TransRScore)
 from .tensor_models import (ExternalEmbedding, cuda, get_dev, get_device, get_scalar, norm,
                             reshape)
 from ._lib import KgeError
@@ -73,9 +74,11 @@ class KEModel(object):
             self.score_func = SimplEScore()
         elif model_name == 'RESCAL':
             self.score_func = RESCALScore(relation_dim // entity_dim, entity_dim)
+        elif model_name == 'TransR':
+            projection_emb = ExternalEmbedding(args, n_relations, entity_dim * relation_dim, device)
+            self.score_func = TransRScore(gamma, projection_emb, relation_dim, entity_dim)
         else:
-            raise KgeError("model %s has no HIP kernel in this build (TransR is listed as next in "
-                           "SURVEY.md 8f)" % model_name)
+            raise KgeError("unknown model %s" % model_name)
         self.head_neg_score = self.score_func.create_neg(True)
         self.tail_neg_score = self.score_func.create_neg(False)
         self.head_neg_prepare = self.score_func.create_neg_prepare(True)
@@ -91,7 +94,9 @@ class KEModel(object):
             getattr(args, 'loss_genre', None) or 'Logsigmoid',
             bool(getattr(args, 'pairwise', False)), getattr(args, 'margin', 1.0),
             tables=(self.entity_emb.emb, self.entity_emb.state_sum, self.relation_emb.emb,
-                    self.relation_emb.state_sum))
+                    self.relation_emb.state_sum) + ((self.score_func.projection_emb.emb,
+                                                     self.score_func.projection_emb.state_sum)
+                                                    if model_name == 'TransR' else ()))
 
     # ---- bookkeeping (general_models.py:278-330) ----------------------------------------
     def share_memory(self):
@@ -113,6 +118,8 @@ class KEModel(object):
         e = self.engine
         e.ent, e.ent_state = self.entity_emb.emb, self.entity_emb.state_sum
         e.rel, e.rel_state = self.relation_emb.emb, self.relation_emb.state_sum
+        if self.model_name == 'TransR':
+            e.proj, e.proj_state = self.score_func.projection_emb.emb, self.score_func.projection_emb.state_sum
         e._bind_tables()
 
     def reset_parameters(self):

@@ -108,6 +108,46 @@ class SimplEScore(_HipScore):
         return s.reshape(H, R, T)
 
 
+class TransRScore(_HipScore):
+    """score_fun.py:110-220: owns the third table, projection_emb [n_rel, entity_dim * relation_dim].  The HIP
+    build runs TransR through the fused step (`KEModel.train_step` / `dglke_train`) and `kge_rank_eval_ex`; the
+    per-op autograd route of the other score functions (edge_func / create_neg closures) is not provided."""
+    model_name = 'TransR'
+
+    def __init__(self, gamma, projection_emb, relation_dim, entity_dim):
+        self.gamma = gamma
+        self.projection_emb = projection_emb
+        self.relation_dim, self.entity_dim = relation_dim, entity_dim
+
+    def _no_modular(self, *a, **k):
+        from ._lib import KgeError
+        raise KgeError("TransR runs through the fused step (KEModel.train_step / dglke_train) and kge_rank_eval_ex; "
+                       "the per-op drop-in route is not built for it")
+
+    edge_func = infer = prepare = _no_modular
+
+    def create_neg(self, neg_head):
+        return self._no_modular
+
+    def create_neg_prepare(self, neg_head):
+        return self._no_modular
+
+    def reset_parameters(self):
+        self.projection_emb.init(1.0)                     # score_fun.py:170-171
+
+    def update(self, gpu_id=-1):
+        self.projection_emb.update(gpu_id)
+
+    def save(self, path, name):
+        self.projection_emb.save(path, name + 'projection')
+
+    def load(self, path, name):
+        self.projection_emb.load(path, name + 'projection')
+
+    def share_memory(self):
+        self.projection_emb.share_memory()
+
+
 class RESCALScore(_HipScore):
     """score_fun.py:378-449: relation rows are [relation_dim x entity_dim] matrices M; p = h . (M t); both
     corruption modes score (M x) . neg with x the uncorrupted entity."""

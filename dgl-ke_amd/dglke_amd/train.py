@@ -237,8 +237,11 @@ class Trainer(object):
         m = self.model
         n_cand = m.n_entities
         Eb = int(max(1, min(max(args.batch_size_eval, 1024), (1 << 31) // (4 * n_cand), len(h))))
+        proj = m.score_func.projection_emb.emb if args.model_name == 'TransR' else None
+        if proj is not None:
+            Eb = min(Eb, 64)                  # TransR projects every candidate with every test triple's matrix
         metrics = kev.evaluate(args.model_name, m.entity_emb.emb, m.relation_emb.emb, args.gamma, m.emb_init,
-                               (h, r, t), known, batch=Eb)
+                               (h, r, t), known, batch=Eb, proj=proj)
         for k, v in metrics.items():
             print('[{}]{} average {}: {}'.format(0, mode, k, v))
         return metrics

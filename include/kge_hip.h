@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define KGE_ABI_VERSION 2
+#define KGE_ABI_VERSION 3
 
 /* score functions (models/general_models.py:248-268 model_name strings) */
 enum kge_model {
@@ -37,6 +37,8 @@ enum kge_model {
     KGE_DISTMULT  = 2, /* score_fun.py:222 DistMultScore */
     KGE_COMPLEX   = 3, /* score_fun.py:289 ComplExScore */
     KGE_ROTATE    = 4, /* score_fun.py:451 RotatEScore */
+    KGE_TRANSR    = 7, /* score_fun.py:110 TransRScore: third table of per-relation projection matrices
+                          [d_e x d_r] (kge_tables.proj); fused step and ranking only (no modular autograd ops) */
     KGE_RESCAL    = 6, /* score_fun.py:378 RESCALScore: relation row = [d_e x d_e] matrix M (d_r = d_e*d_e),
                           p = h.(M t); BOTH corruption modes use the pos-side vector M x (:428-447) */
     KGE_SIMPLE    = 5  /* score_fun.py:556 SimplEScore: rows = [x_i | x_j] halves, relation = [r | r_inv];
@@ -183,6 +185,8 @@ typedef struct kge_tables {
     float *rel;        /* [n_rel, d_r]                                                       */
     float *rel_state;  /* [n_rel]                                                            */
     int64_t n_ent, n_rel;
+    float *proj;       /* TransR only: [n_rel, d_e*d_r] projection_emb.emb (score_fun.py:114-118), else NULL */
+    float *proj_state; /* TransR only: [n_rel] projection_emb.state_sum                      */
 } kge_tables;
 
 /* optional outputs of a step (any may be NULL) */
@@ -256,6 +260,14 @@ int kge_rank_eval(int model, int neg_head, const float *ent, int64_t n_ent, cons
                   int d_e, int d_r, float gamma, float emb_init, const int64_t *cand, int64_t n_cand,
                   const int64_t *filt_ptr, const int64_t *filt_ids, int Eb, int32_t *ranks,
                   float *pos_score_out, void *ws, size_t ws_bytes, unsigned flags, void *stream);
+
+/* same with the TransR projection table (proj = NULL for every other model); for TransR `cand` must be given
+ * (pass the identity list for "all entities") */
+int kge_rank_eval_ex(int model, int neg_head, const float *ent, int64_t n_ent, const float *rel,
+                     int64_t n_rel, const float *proj, const int64_t *h, const int64_t *r, const int64_t *t,
+                     int64_t E, int d_e, int d_r, float gamma, float emb_init, const int64_t *cand,
+                     int64_t n_cand, const int64_t *filt_ptr, const int64_t *filt_ids, int Eb, int32_t *ranks,
+                     float *pos_score_out, void *ws, size_t ws_bytes, unsigned flags, void *stream);
 
 /* ---- peer-to-peer sharded step (xGMI direct; the Hogwild multi-GPU mode) ----
  * The reference's multi-GPU trainer keeps ONE entity table in shared host memory and lets every

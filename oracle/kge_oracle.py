@@ -19,7 +19,7 @@ All functions take/return numpy arrays; `dtype` selects float32 (reference preci
 """
 import numpy as np
 
-MODELS = ("TransE_l1", "TransE_l2", "DistMult", "ComplEx", "RotatE", "SimplE", "RESCAL")
+MODELS = ("TransE_l1", "TransE_l2", "DistMult", "ComplEx", "RotatE", "SimplE", "RESCAL", "TransR")
 SIMPLE_CLAMP = 20.0          # th.clamp(score, -20, 20): score_fun.py:568, 622, 641
 LOSSES = ("Logsigmoid", "Logistic", "Hinge", "BCE")
 
@@ -463,6 +463,82 @@ def train_step(cfg, ent, ent_state, rel, rel_state, nid, h_local, t_local, rel_i
     return out
 
 
+# ---------------------------------------------------------------------------------------------
+# TransR (score_fun.py:110-220): a THIRD table, projection_emb [n_rel, ent_dim * rel_dim], owned by the score
+# function.  prepare() (:131-136) projects head and tail of every positive edge with its relation's matrix
+# (projection trace 0); the neg-prepare closure (:138-166) gathers the matrices AGAIN (trace 1), projects the
+# uncorrupted entity and projects EVERY negative of the chunk with EVERY positive's matrix; scores are L1
+# distances in relation space (:122-127, :199-219).  The regulariser covers entity and relation traces only
+# (general_models.py:572-576); projection_emb is initialised U(-1, 1) (:171).
+# ---------------------------------------------------------------------------------------------
+def transr_forward_backward(cfg, ent, rel, proj, nid, h_local, t_local, rel_ids, neg_ids, neg_head, chunk, N, w=None):
+    dt = ent.dtype
+    B, C = h_local.shape[0], h_local.shape[0] // chunk
+    De, Dr = ent.shape[1], rel.shape[1]
+    pos_emb, r, neg = gather_rows(ent, nid), gather_rows(rel, rel_ids), gather_rows(ent, neg_ids)
+    P = gather_rows(proj, rel_ids).reshape(B, De, Dr)
+    h, t = pos_emb[h_local], pos_emb[t_local]
+    gamma = dt.type(cfg.gamma)
+    hp, tp = np.einsum("ab,abc->ac", h, P), np.einsum("ab,abc->ac", t, P)
+    u = hp + r - tp
+    p = gamma - np.abs(u).sum(-1)
+    x = t if neg_head else h
+    xp = np.einsum("ab,abc->ac", x, P)
+    # NOTE: BOTH closures subtract the relation (score_fun.py:203-204 head mode: tails - relations; :212-213
+    # tail mode: heads - relations - not heads + relations); kept as the reference computes it
+    q = xp - r                                                           # [B, Dr]
+    Y = np.einsum("cjd,cide->cije", neg.reshape(C, N, De), P.reshape(C, chunk, De, Dr))   # [C, chunk, N, Dr]
+    D = Y - q.reshape(C, chunk, 1, Dr)                                   # head mode: heads - tails; tail mode: its negative
+    n = gamma - np.abs(D).sum(-1)
+    (pl, nl, loss), dpos, dneg = loss_fwd_bwd(p, n.reshape(B, N), w, cfg.loss_genre, cfg.adv, cfg.adv_temp,
+                                              cfg.pairwise, cfg.margin)
+    reg = 0.0
+    use_reg = cfg.reg_coef > 0.0 and cfg.reg_norm > 0
+    if use_reg:
+        reg = reg_value([pos_emb, neg], cfg.reg_coef, cfg.reg_norm) + reg_value([r], cfg.reg_coef, cfg.reg_norm)
+    # positive score: p = gamma - |hp + r - tp|_1
+    s = np.sign(u)
+    ghp, gtp = -dpos[:, None] * s, dpos[:, None] * s
+    gr = -dpos[:, None] * s
+    g_proj0 = h[:, :, None] * ghp[:, None, :] + t[:, :, None] * gtp[:, None, :]
+    gh, gt = np.einsum("abc,ac->ab", P, ghp), np.einsum("abc,ac->ab", P, gtp)
+    # negative scores: n = gamma - sum |Y - q|  (either sign convention): dY = -W sign(Y - q), dq = -sum_j dY
+    dY = -dneg.reshape(C, chunk, N, 1) * np.sign(D)
+    dq = -dY.sum(2).reshape(B, Dr)
+    g_neg = np.einsum("cije,cide->cjd", dY, P.reshape(C, chunk, De, Dr)).reshape(C * N, De)
+    g_proj1 = np.einsum("cjd,cije->cide", neg.reshape(C, N, De), dY).reshape(B, De, Dr) + x[:, :, None] * dq[:, None, :]
+    gx = np.einsum("abc,ac->ab", P, dq)
+    gr = gr - dq
+    if neg_head:
+        gt = gt + gx
+    else:
+        gh = gh + gx
+    g_pos = np.zeros_like(pos_emb)
+    np.add.at(g_pos, h_local, gh)
+    np.add.at(g_pos, t_local, gt)
+    g_neg = g_neg.astype(dt)
+    if use_reg:
+        g_pos += reg_grad(pos_emb, cfg.reg_coef, cfg.reg_norm)
+        g_neg = g_neg + reg_grad(neg, cfg.reg_coef, cfg.reg_norm)
+        gr = gr + reg_grad(r, cfg.reg_coef, cfg.reg_norm)
+    return dict(pos_score=p, neg_score=n, log=(pl, nl, loss, reg), loss_total=loss + reg,
+                g_pos_ent=g_pos.astype(dt), g_rel=gr.astype(dt), g_neg=g_neg.astype(dt),
+                g_proj0=g_proj0.reshape(B, De * Dr).astype(dt), g_proj1=g_proj1.reshape(B, De * Dr).astype(dt))
+
+
+def transr_train_step(cfg, ent, ent_state, rel, rel_state, proj, proj_state, nid, h_local, t_local, rel_ids, neg_ids,
+                      neg_head, chunk, N, w=None):
+    """update order: entity traces, relation trace (KEModel.update, general_models.py:580-588), then
+    score_func.update() = projection trace 0 (prepare) and trace 1 (neg-prepare), score_fun.py:173-174."""
+    out = transr_forward_backward(cfg, ent, rel, proj, nid, h_local, t_local, rel_ids, neg_ids, neg_head, chunk, N, w)
+    adagrad_update(ent, ent_state, nid, out["g_pos_ent"], cfg.lr)
+    adagrad_update(ent, ent_state, neg_ids, out["g_neg"], cfg.lr)
+    adagrad_update(rel, rel_state, rel_ids, out["g_rel"], cfg.lr)
+    adagrad_update(proj, proj_state, rel_ids, out["g_proj0"], cfg.lr)
+    adagrad_update(proj, proj_state, rel_ids, out["g_proj1"], cfg.lr)
+    return out
+
+
 def synth_batch(rng, n_ent, n_rel, B, N, chunk, step):
     """Seeded synthetic id batch (same generator as tests/golden/gen_golden.py:make_batch):
     uniform h,t,r; C*N uniform negatives with replacement, positives not excluded
@@ -497,15 +573,22 @@ def false_negative_mask(known, h, r, t, neg_head, n_ent):
     return m
 
 
-def rank_eval(model, ent, rel, h, r, t, neg_head, gamma, emb_init, false_neg=None, tol=0.0):
+def rank_eval(model, ent, rel, h, r, t, neg_head, gamma, emb_init, false_neg=None, tol=0.0, proj=None):
     """returns (ranks [E], pos_score [E], neg_score [E, n_ent]); with tol > 0 `ranks` is a pair
     (lowest, highest) rank consistent with scores perturbed by at most tol (tie tolerance for fp32
     implementations whose rounding differs from the reference's)."""
     E, n_ent = len(h), ent.shape[0]
     hs, rs, ts = ent[h], rel[r], ent[t]
-    p = score_pos(model, hs, rs, ts, gamma, emb_init)
-    a = pos_side(model, neg_head, ts if neg_head else hs, rs, emb_init)
-    S = score_neg(model, a, ent, 1, E, n_ent, gamma)[0]
+    if _canon(model) == "TransR":          # projections of both ends and of every candidate (score_fun.py:131-166)
+        P = proj[r].reshape(E, ent.shape[1], rel.shape[1])
+        hp, tp = np.einsum("ab,abc->ac", hs, P), np.einsum("ab,abc->ac", ts, P)
+        p = gamma - np.abs(hp + rs - tp).sum(-1)
+        q = (tp if neg_head else hp) - rs
+        S = gamma - np.abs(np.einsum("jd,ide->ije", ent, P) - q[:, None, :]).sum(-1)
+    else:
+        p = score_pos(model, hs, rs, ts, gamma, emb_init)
+        a = pos_side(model, neg_head, ts if neg_head else hs, rs, emb_init)
+        S = score_neg(model, a, ent, 1, E, n_ent, gamma)[0]
     keep = np.ones_like(S, bool) if false_neg is None else ~false_neg
     if tol == 0.0:
         return ((S >= p[:, None]) & keep).sum(1) + 1, p, S

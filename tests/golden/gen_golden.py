@@ -176,6 +176,9 @@ def run_case(name, case):
     out["init_entity"] = model.entity_emb.emb.numpy().copy()
     out["init_relation"] = model.relation_emb.emb.numpy().copy()
     out["emb_init"] = np.float64(model.emb_init)
+    transr = case["model"] == "TransR"
+    if transr:      # third table: per-relation projection matrices owned by the score function (score_fun.py:114-118)
+        out["init_projection"] = model.score_func.projection_emb.emb.numpy().copy()
     for s in range(1, case["steps"] + 1):
         b = make_batch(rng, case, s)
         pos_g = PosG(th.from_numpy(b["nid"]), th.from_numpy(b["h_local"]),
@@ -201,12 +204,20 @@ def run_case(name, case):
         et = model.entity_emb.trace
         rt = model.relation_emb.trace
         assert len(et) == 2 and len(rt) == 1
+        if transr:  # two traces: prepare() (positive projections) then the neg-prepare closure
+            pt = model.score_func.projection_emb.trace
+            assert len(pt) == 2
+            out[p + "g_proj0"] = pt[0][1].grad.numpy().copy()
+            out[p + "g_proj1"] = pt[1][1].grad.numpy().copy()
         out[p + "g_pos_ent"] = et[0][1].grad.numpy().copy()
         out[p + "g_neg"] = et[1][1].grad.numpy().copy()
         out[p + "g_rel"] = rt[0][1].grad.numpy().copy()
         model.update(-1)
         out[p + "entity_state"] = model.entity_emb.state_sum.numpy().copy()
         out[p + "relation_state"] = model.relation_emb.state_sum.numpy().copy()
+        if transr:
+            out[p + "projection_state"] = model.score_func.projection_emb.state_sum.numpy().copy()
+            out[p + "projection"] = model.score_func.projection_emb.emb.numpy().copy()
         if case.get("save_tables_each_step", True):
             out[p + "entity"] = model.entity_emb.emb.numpy().copy()
             out[p + "relation"] = model.relation_emb.emb.numpy().copy()
@@ -241,6 +252,12 @@ CASES = {
     "simple_dups": base("SimplE", n_ent=9, n_rel=2, de=True, dr=True, steps=4, seed=43),
     "simple_plain": base("SimplE", hidden=16, adv=False, reg_coef=0.0, seed=44),
     "simple_clamped": base("SimplE", hidden=8, gamma=22.0, de=True, dr=True, lr=0.01, seed=45),
+    # TransR (score_fun.py:110): per-relation projection matrices [ent_dim x rel_dim], L1 distance in relation space
+    "transr_small": base("TransR", gamma=8.0, hidden=8, seed=61),
+    "transr_ragged": base("TransR", gamma=8.0, hidden=6, B=30, N=7, chunk=10, seed=62),
+    "transr_dups": base("TransR", gamma=8.0, hidden=8, n_ent=9, n_rel=2, steps=4, seed=63),
+    "transr_mid": base("TransR", n_ent=200, n_rel=12, hidden=32, gamma=12.0, B=64, N=32, chunk=32, lr=0.05,
+                       reg_coef=1e-6, steps=2, seed=64, save_tables_each_step=False),
     # RESCAL (score_fun.py:378): relation rows are [rel_dim x ent_dim] matrices
     "rescal_small": base("RESCAL", gamma=6.0, hidden=8, seed=51),
     "rescal_ragged": base("RESCAL", gamma=6.0, hidden=6, B=30, N=7, chunk=10, seed=52),

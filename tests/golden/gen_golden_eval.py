@@ -40,6 +40,8 @@ def run_case(name, case):
             model.entity_emb.emb.mul_(case["scale"])
             model.relation_emb.emb.mul_(case["scale"])
     out = {"entity": model.entity_emb.emb.numpy().copy(), "relation": model.relation_emb.emb.numpy().copy(),
+           "projection": (model.score_func.projection_emb.emb.numpy().copy() if case["model"] == "TransR"
+                          else np.zeros(0, np.float32)),
            "emb_init": np.float64(model.emb_init), "known": trip, "test": test,
            "case_json": np.array(json.dumps(case))}
     known = set(map(tuple, trip.tolist()))
@@ -67,6 +69,7 @@ def run_case(name, case):
         with th.no_grad():
             pos_g.ndata["emb"] = model.entity_emb(pos_g.ndata["id"], -1, False)
             pos_g.edata["emb"] = model.relation_emb(pos_g.edata["id"], -1, False)
+            model.score_func.prepare(pos_g, -1, False)
             out[mode + "_pos_score"] = model.predict_score(pos_g).numpy().copy()
             out[mode + "_neg_score"] = model.predict_neg_score(pos_g, neg_g, trace=False).numpy().reshape(E, n_ent).copy()
         out[mode + "_false_neg"] = false_neg
@@ -88,6 +91,7 @@ CASES = {
     "eval_rotate": base("RotatE", de=True, scale=4.0, seed=35),
     "eval_simple": base("SimplE", de=True, dr=True, scale=6.0, seed=37),
     "eval_rescal": base("RESCAL", hidden=8, scale=3.0, seed=38),
+    "eval_transr": base("TransR", hidden=8, scale=3.0, seed=39),
     # ragged: candidate count / dims that are not tile multiples
     "eval_transe_l2_ragged": base("TransE_l2", n_ent=37, hidden=20, E=9, scale=4.0, seed=36),
 }

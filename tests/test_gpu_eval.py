@@ -36,7 +36,9 @@ def test_rank_eval_matches_reference_rankings(name, flags):
     rel = torch.from_numpy(z["relation"]).to(DEV)
     test, known = z["test"], z["known"]
     h, r, t = test[:, 0], test[:, 1], test[:, 2]
-    rk = E.Ranker(case["model"], ent, rel, case["gamma"], float(z["emb_init"]), batch=5, flags=flags)
+    proj = torch.from_numpy(z["projection"]).to(DEV) if case["model"] == "TransR" else None
+    proj64 = z["projection"].astype(np.float64) if case["model"] == "TransR" else None
+    rk = E.Ranker(case["model"], ent, rel, case["gamma"], float(z["emb_init"]), batch=5, flags=flags, proj=proj)
     for mode in ("head", "tail"):
         neg_head = mode == "head"
         filt = E.build_filter(known[:, 0], known[:, 1], known[:, 2], h, r, t, neg_head, rel.shape[0])
@@ -50,7 +52,7 @@ def test_rank_eval_matches_reference_rankings(name, flags):
         for f, key in ((filt, "filtered"), (None, "raw")):
             got = rk.ranks(h, r, t, neg_head, f).cpu().numpy()
             (lo, hi), _, _ = O.rank_eval(case["model"], ent64, rel64, h, r, t, neg_head, case["gamma"],
-                                         float(z["emb_init"]), mask if f is not None else None, tol=TOL)
+                                         float(z["emb_init"]), mask if f is not None else None, tol=TOL, proj=proj64)
             want = z["%s_ranks_%s" % (mode, key)]
             assert np.all((lo <= got) & (got <= hi)), (mode, key, lo, got, hi)
             exact = lo == hi

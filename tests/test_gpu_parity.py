@@ -83,7 +83,7 @@ def grad_tol(ref):
     return 3e-4 * max(float(np.abs(ref).max()), 1e-12)
 
 
-@pytest.mark.parametrize("name", golden_names())
+@pytest.mark.parametrize("name", golden_names(transr=False))
 def test_dropin_model_matches_reference(name):
     """reference loop: model.forward -> loss.backward() -> model.update (train_pytorch.py:141-152)
     on the HIP-backed KEModel, every op one C-ABI call."""
@@ -120,7 +120,7 @@ def test_dropin_model_matches_reference(name):
 
 
 @pytest.mark.parametrize("flags", [0, 1, 2], ids=["auto", "force_pairwise", "no_transe_fast"])
-@pytest.mark.parametrize("name", golden_names())
+@pytest.mark.parametrize("name", golden_names(transr=False))
 def test_fused_step_matches_reference(name, flags):
     """kge_step_fused (one call per step) vs the reference's recorded scores / gradients / tables;
     both the matrix-core and the pairwise negative-score kernels."""

@@ -1,0 +1,83 @@
+"""TransR on the HIP path (kge_transr.hip): the fused step against the goldens recorded from the reference -
+scores, loss terms, the three trace gradients, Adagrad state and rows of the entity, relation AND projection
+tables (two projection traces per step, score_fun.py:131-166, :173-174)."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import golden_names, load_golden
+from test_gpu_parity import DEV, _close, build_model, golden_batch, grad_tol
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", golden_names(transr=True))
+def test_transr_fused_step_matches_reference(name):
+    z, case = load_golden(name)
+    m = build_model(case, z)
+    pe = m.score_func.projection_emb
+    pe.emb.copy_(torch.from_numpy(z["init_projection"]))
+    pe.state_sum.zero_()
+    eng = m.engine
+    assert eng.proj.data_ptr() == pe.emb.data_ptr()
+    for s in range(1, case["steps"] + 1):
+        p = "s%d_" % s
+        b = golden_batch(z, case, s)
+        want = eng.alloc_outputs(b)
+        eng.step(b, want)
+        torch.cuda.synchronize()
+        _close(want["pos_score"].cpu(), z[p + "pos_score"], 1e-4, 1e-4, name + " pos_score")
+        _close(want["neg_score"].cpu(), z[p + "neg_score"], 1e-4, 1e-4, name + " neg_score")
+        l4 = eng.read_loss()
+        ref_log = z[p + "log"]
+        _close(l4[0], ref_log[0], 1e-4, 1e-5, name + " pos_loss")
+        _close(l4[1], ref_log[1], 1e-4, 1e-5, name + " neg_loss")
+        _close(l4[2], ref_log[2], 1e-4, 1e-5, name + " loss")
+        _close(l4[3], ref_log[3], 1e-4, 1e-7, name + " reg")
+        ue = b.p["ue_id"]
+        sel = np.searchsorted(ue, z[p + "nid"])
+        _close(want["g_pos_ent"].cpu().numpy()[sel], z[p + "g_pos_ent"], 3e-4, grad_tol(z[p + "g_pos_ent"]), name + " g_pos_ent")
+        _close(want["g_neg"].cpu(), z[p + "g_neg"], 3e-4, grad_tol(z[p + "g_neg"]), name + " g_neg")
+        _close(want["g_rel"].cpu(), z[p + "g_rel"], 3e-4, grad_tol(z[p + "g_rel"]), name + " g_rel")
+        _close(eng.ent_state.cpu(), z[p + "entity_state"], 2e-3, 1e-9, name + " ent state")
+        _close(eng.rel_state.cpu(), z[p + "relation_state"], 2e-3, 1e-9, name + " rel state")
+        _close(eng.proj_state.cpu(), z[p + "projection_state"], 2e-3, 1e-9, name + " projection state")
+        _close(eng.proj.cpu(), z[p + "projection"], 1e-4, 5e-3 * case["lr"], name + " projection rows")
+        if (p + "entity") in z:
+            _close(eng.ent.cpu(), z[p + "entity"], 1e-4, 5e-3 * case["lr"], name + " entity rows")
+            _close(eng.rel.cpu(), z[p + "relation"], 1e-4, 5e-3 * case["lr"], name + " relation rows")
+    _close(eng.ent.cpu(), z["final_entity"], 1e-4, 1e-2 * case["lr"], name + " final entity")
+    _close(eng.rel.cpu(), z["final_relation"], 1e-4, 1e-2 * case["lr"], name + " final relation")
+
+
+def test_transr_fused_step_matches_oracle_at_tile_shapes():
+    """dims that span several 64 x 64 tiles and do not divide them: De = 72, Dr = 144, N = 70, chunk = 35."""
+    from dglke_amd import plan
+    from dglke_amd.engine import StepEngine
+    from oracle import kge_oracle as O
+    n_ent, n_rel, hidden, B, N, chunk = 500, 9, 72, 70, 70, 35
+    rng = np.random.RandomState(4)
+    # -dr: relation_dim = 144 != entity_dim = 72 (rectangular projection matrices, 3 column tiles, the last partial)
+    eng = StepEngine("TransR", n_ent, n_rel, hidden, 10.0, 0.05, DEV, False, True, True, 1.0, 1e-6, 3)
+    assert eng.proj.shape == (n_rel, 72 * 144)
+    cfg = O.Config("TransR", 10.0, hidden, 0.05, adv=True, adv_temp=1.0, reg_coef=1e-6, reg_norm=3, double_rel=True)
+    ent, rel, proj = (x.cpu().numpy().astype(np.float64) for x in (eng.ent, eng.rel, eng.proj))
+    es, rs, ps = np.zeros(n_ent), np.zeros(n_rel), np.zeros(n_rel)
+    for step in range(1, 3):
+        bt = O.synth_batch(rng, n_ent, n_rel, B, N, chunk, step)
+        b = plan.make_batch(bt["h"], bt["t"], bt["r"], bt["neg"], chunk, N, bt["neg_head"], DEV)
+        want = eng.alloc_outputs(b)
+        eng.step(b, want)
+        out = O.transr_train_step(cfg, ent, es, rel, rs, proj, ps, bt["nid"], bt["h_local"], bt["t_local"], bt["r"],
+                                  bt["neg"], bt["neg_head"], chunk, N)
+        torch.cuda.synchronize()
+        _close(want["pos_score"].cpu(), out["pos_score"], 1e-4, 1e-4, "pos")
+        _close(want["neg_score"].cpu(), out["neg_score"], 1e-4, 2e-4, "neg")
+        _close(want["g_neg"].cpu(), out["g_neg"], 3e-4, grad_tol(out["g_neg"]), "g_neg")
+        _close(want["g_rel"].cpu(), out["g_rel"], 3e-4, grad_tol(out["g_rel"]), "g_rel")
+        _close(eng.proj_state.cpu(), ps, 2e-3, 1e-9, "projection state")
+        _close(eng.proj.cpu(), proj, 1e-4, 5e-3 * 0.05, "projection rows")
+        _close(eng.ent.cpu(), ent, 1e-4, 5e-3 * 0.05, "entity rows")
+        # re-synchronise the fp64 oracle on the fp32 tables so that drift does not accumulate
+        ent, rel, proj = (x.cpu().numpy().astype(np.float64) for x in (eng.ent, eng.rel, eng.proj))
+        es, rs, ps = (x.cpu().numpy().astype(np.float64) for x in (eng.ent_state, eng.rel_state, eng.proj_state))

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(h, name), "libkge_hip.so does not export " + name
     assert declared == set(_lib.EXPORTED_SYMBOLS), (declared ^ set(_lib.EXPORTED_SYMBOLS))
-    assert _lib.lib().kge_abi_version() == _lib.KGE_ABI_VERSION == 2
+    assert _lib.lib().kge_abi_version() == _lib.KGE_ABI_VERSION == 3
 
 
 def test_argument_errors_are_reported_without_a_gpu():
@@ -109,7 +109,7 @@ def test_sampler_alternates_corruption_side_and_covers_epochs():
         _check_plan(p)
 
 
-@pytest.mark.parametrize("name", [n for n in golden_names() if not any(
+@pytest.mark.parametrize("name", [n for n in golden_names(transr=False) if not any(
     k in n for k in ("logistic", "hinge", "bce", "impts"))])
 def test_torch_port_matches_reference(name):
     """the cpu_baseline port reproduces the reference step (same torch ops)."""

@@ -26,6 +26,9 @@ def test_step_matches_reference(name, dtype):
     assert abs(cfg.emb_init - float(z["emb_init"])) < 1e-12
     ent_state = np.zeros(ent.shape[0], dtype)
     rel_state = np.zeros(rel.shape[0], dtype)
+    transr = case["model"] == "TransR"
+    proj = z["init_projection"].astype(dtype) if transr else None
+    proj_state = np.zeros(rel.shape[0], dtype) if transr else None
     # fp64 oracle vs the fp32 reference: differences are the reference's own fp32 rounding
     tol = dict(rtol=2e-4, atol=2e-5)
     # Post-update rows: Adagrad's first steps normalise the gradient (delta = -lr*g/sqrt(mean g^2)),
@@ -38,9 +41,20 @@ def test_step_matches_reference(name, dtype):
             ent = z["s%d_entity" % (s - 1)].astype(dtype) if ("s%d_entity" % (s - 1)) in z else ent
             rel = z["s%d_relation" % (s - 1)].astype(dtype) if ("s%d_relation" % (s - 1)) in z else rel
         w = z[p + "w"].astype(dtype) if (p + "w") in z else None
-        out = O.train_step(cfg, ent, ent_state, rel, rel_state, z[p + "nid"], z[p + "h_local"],
-                           z[p + "t_local"], z[p + "r"], z[p + "neg"], bool(z[p + "neg_head"]),
-                           case["chunk"], case["N"], w)
+        if transr:
+            if dtype == np.float64 and s > 1 and ("s%d_projection" % (s - 1)) in z:
+                proj = z["s%d_projection" % (s - 1)].astype(dtype)
+            out = O.transr_train_step(cfg, ent, ent_state, rel, rel_state, proj, proj_state, z[p + "nid"],
+                                      z[p + "h_local"], z[p + "t_local"], z[p + "r"], z[p + "neg"],
+                                      bool(z[p + "neg_head"]), case["chunk"], case["N"], w)
+            for k in ("g_proj0", "g_proj1"):
+                _close(out[k], z[p + k], 2e-4, 3e-4 * max(np.abs(z[p + k]).max(), 1e-12), name + " " + k)
+            _close(proj_state, z[p + "projection_state"], 1e-3, 1e-9, name + " projection state")
+            _close(proj, z[p + "projection"], 1e-4, 5e-3 * case["lr"], name + " projection table step %d" % s)
+        else:
+            out = O.train_step(cfg, ent, ent_state, rel, rel_state, z[p + "nid"], z[p + "h_local"],
+                               z[p + "t_local"], z[p + "r"], z[p + "neg"], bool(z[p + "neg_head"]),
+                               case["chunk"], case["N"], w)
         _close(out["pos_score"], z[p + "pos_score"], what=name + " pos_score", **tol)
         _close(out["neg_score"], z[p + "neg_score"], what=name + " neg_score", **tol)
         log = z[p + "log"]
@@ -90,14 +104,15 @@ def test_oracle_rank_eval_matches_reference(name):
         neg_head = mode == "head"
         fn = O.false_negative_mask(z["known"], h, r, t, neg_head, ent.shape[0])
         assert np.array_equal(fn, z[mode + "_false_neg"] > 0)
+        proj = z["projection"].astype(np.float64) if case["model"] == "TransR" else None
         (lo, hi), p, S = O.rank_eval(case["model"], ent, rel, h, r, t, neg_head, case["gamma"], float(z["emb_init"]),
-                                     fn, tol=2e-5)
+                                     fn, tol=2e-5, proj=proj)
         np.testing.assert_allclose(p, z[mode + "_pos_score"], rtol=1e-5, atol=2e-5)
         np.testing.assert_allclose(S, z[mode + "_neg_score"], rtol=1e-5, atol=2e-5)
         want = z[mode + "_ranks_filtered"]
         assert np.all((lo <= want) & (want <= hi)), (mode, lo, want, hi)
         (lo, hi), _, _ = O.rank_eval(case["model"], ent, rel, h, r, t, neg_head, case["gamma"], float(z["emb_init"]),
-                                     None, tol=2e-5)
+                                     None, tol=2e-5, proj=proj)
         want = z[mode + "_ranks_raw"]
         assert np.all((lo <= want) & (want <= hi)), (mode, lo, want, hi)
         # the true triple is a known triple: unfiltered it always counts itself
