@@ -55,6 +55,9 @@ WORKLOADS = {
     "rescal_fb15k": dict(model="RESCAL", n_ent=14951, n_rel=1345, n_train=483142, hidden=500,
                          de=False, dr=False, B=1024, N=256, gamma=24.0, lr=0.03, adv=True,
                          adv_temp=1.0, reg_coef=0.0, reg_norm=3),
+    "transr_fb15k": dict(model="TransR", n_ent=14951, n_rel=1345, n_train=483142, hidden=200,
+                         de=False, dr=False, B=1024, N=256, gamma=8.0, lr=0.015, adv=True,
+                         adv_temp=1.0, reg_coef=5e-8, reg_norm=3),
     "transe_l1_fb15k": dict(model="TransE_l1", n_ent=14951, n_rel=1345, n_train=483142, hidden=400,
                             de=False, dr=False, B=1000, N=200, gamma=16.0, lr=0.01, adv=True,
                             adv_temp=1.0, reg_coef=1e-7, reg_norm=3),

@@ -379,6 +379,7 @@ size_t kge_step_workspace_bytes(const kge_hparams *hp, int B, int C, int chunk, 
         add(((size_t)B * N * d_r + 3) / 4);
         add((size_t)B * d_e * d_r);
         add(B); add(B); add(UR); add(UR);
+        add((size_t)TRANSR_GN_GROUPS * CN * d_e);
     }
     if (hp->model == KGE_RESCAL) {   // V = M t, M^T h, M^T GA (no [B, d_r] buffer) + update scratch
         add(B * d_e); add(B * d_e); add(B * d_e);
@@ -456,6 +457,8 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         tr.Z = reinterpret_cast<signed char *>(cv.f(((size_t)B * N * d_r + 3) / 4));
         tr.GP = cv.f((size_t)B * d_e * d_r);
         tr.gs0 = cv.f(B); tr.gs1 = cv.f(B); tr.k0 = cv.f(b->UR); tr.k1 = cv.f(b->UR);
+        tr.nG = chunk < TRANSR_GN_GROUPS ? chunk : TRANSR_GN_GROUPS;
+        tr.GNp = cv.f((size_t)TRANSR_GN_GROUPS * CN * d_e);
     }
     float *row_pos = cv.f(B), *row_neg = cv.f(B), *reg_ent = cv.f(b->UE), *reg_rel = cv.f(b->UR);
     if (!cv.ok())

@@ -355,7 +355,9 @@ struct TransRArgs {
     const float *dpos;
     const int64_t *ur_id; const int32_t *ur_ptr, *ur_edge, *counts_dev;
     float *gs0, *gs1, *k0, *k1;      // [B], [B], [UR], [UR] scratch of the projection update
+    int nG; float *GNp;              // split-K groups of the negative-row gradient and their partial tiles [nG, C*N, De]
 };
+#define TRANSR_GN_GROUPS 16
 int launch_transr_pos(const TransRArgs &a, hipStream_t s);
 int launch_transr_fwd(const TransRArgs &a, hipStream_t s);
 int launch_transr_bwd(const TransRArgs &a, hipStream_t s);

@@ -123,57 +123,104 @@ __global__ __launch_bounds__(KGE_BLOCK) void transr_fwd_kernel(TransRArgs a, int
     }
 }
 
-// dq_i = -sum_j dY_ij = sum_j W_ij sign(Y_ij - q_i)      (one wavefront per positive)
+// dq_i = -sum_j dY_ij = sum_j W_ij sign(Y_ij - q_i).  One workgroup per positive: the wavefronts split the
+// negatives, every lane owns 4 consecutive columns (one 32-bit load = 4 sign bytes), partial sums are added in
+// a fixed order through LDS.
 __global__ __launch_bounds__(KGE_BLOCK) void transr_dq_kernel(TransRArgs a) {
-    const int64_t i = (int64_t)blockIdx.x * KGE_WAVES_PER_BLOCK + (threadIdx.x >> 6);
-    if (i >= a.B) return;
-    const int lane = threadIdx.x & 63, Dr = a.Dr, N = a.N;
-    for (int d0 = 0; d0 < Dr; d0 += 64) {
-        const int d = d0 + lane;
-        float s = 0.f;
-        if (d < Dr)
-            for (int j = 0; j < N; ++j) s = fmaf(a.S[i * N + j], (float)a.Z[(i * N + j) * Dr + d], s);
-        if (d < Dr) a.DQ[i * Dr + d] = s;
+    __shared__ float part[KGE_WAVES_PER_BLOCK][1024];
+    const int64_t i = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, Dr = a.Dr, N = a.N;
+    const bool vec = (Dr & 3) == 0;
+    for (int d0 = 0; d0 < Dr; d0 += 256) {
+        const int d = d0 + lane * 4;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        if (d < Dr) {
+#pragma unroll 4
+            for (int j = wave; j < N; j += KGE_WAVES_PER_BLOCK) {
+                const float w = a.S[i * N + j];
+                const signed char *z = a.Z + (i * N + j) * Dr + d;
+                if (vec) {
+                    const int pk = *reinterpret_cast<const int *>(z);
+                    s0 = fmaf(w, (float)(signed char)(pk & 0xff), s0);
+                    s1 = fmaf(w, (float)(signed char)((pk >> 8) & 0xff), s1);
+                    s2 = fmaf(w, (float)(signed char)((pk >> 16) & 0xff), s2);
+                    s3 = fmaf(w, (float)(signed char)((pk >> 24) & 0xff), s3);
+                } else {
+                    s0 = fmaf(w, (float)z[0], s0);
+                    if (d + 1 < Dr) s1 = fmaf(w, (float)z[1], s1);
+                    if (d + 2 < Dr) s2 = fmaf(w, (float)z[2], s2);
+                    if (d + 3 < Dr) s3 = fmaf(w, (float)z[3], s3);
+                }
+            }
+        }
+        __syncthreads();
+        if (d < Dr) { part[wave][d] = s0; if (d + 1 < 1024) part[wave][d + 1] = s1; if (d + 2 < 1024) part[wave][d + 2] = s2;
+                      if (d + 3 < 1024) part[wave][d + 3] = s3; }
+        __syncthreads();
+        for (int k = threadIdx.x; k < 256 && d0 + k < Dr; k += KGE_BLOCK) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < KGE_WAVES_PER_BLOCK; ++w) v += part[w][d0 + k];
+            a.DQ[i * Dr + d0 + k] = v;
+        }
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 // GN_c[j][de] = sum_{i in chunk} sum_dr dY_i[j][dr] P_i[de][dr]    workgroup = (chunk, 64 negatives, 64 de)
 // ---------------------------------------------------------------------------------------------
+// The chunk's positives are split into a.nG groups (split-K): with 4-5 chunks there are only ~64 output tiles,
+// far too few workgroups; every group writes its own partial tile and transr_gn_reduce_kernel adds the groups
+// in a fixed order (deterministic, no atomics).
 __global__ __launch_bounds__(KGE_BLOCK) void transr_gn_kernel(TransRArgs a, int nJB, int nEB) {
     __shared__ float As[TR_K][TR_LD], Bs[TR_K][TR_LD];
-    const int eb = blockIdx.x % nEB, jb = (blockIdx.x / nEB) % nJB, c = blockIdx.x / (nEB * nJB);
+    const int g = blockIdx.x % a.nG;
+    const int blk = blockIdx.x / a.nG;
+    const int eb = blk % nEB, jb = (blk / nEB) % nJB, c = blk / (nEB * nJB);
     const int j0 = jb * TR_T, de0 = eb * TR_T, De = a.De, Dr = a.Dr, N = a.N, chunk = a.chunk;
     const int DrP = (Dr + TR_K - 1) / TR_K * TR_K;              // every positive contributes whole slabs
+    const int ipg = (chunk + a.nG - 1) / a.nG, i0 = g * ipg, i1 = min(chunk, i0 + ipg);
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63, m = lane & 15, q = lane >> 4;
     f32x4 acc[4];
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    tile_sweep<true, true>(acc, chunk * DrP,
+    tile_sweep<true, true>(acc, max(0, i1 - i0) * DrP,
         [&](int row, int k) {
-            const int il = k / DrP, dr = k - il * DrP, j = j0 + row;
+            const int il = i0 + k / DrP, dr = k % DrP, j = j0 + row;
             if (j >= N || dr >= Dr) return 0.f;
             const int64_t ij = ((int64_t)c * chunk + il) * N + j;
             return -a.S[ij] * (float)a.Z[ij * Dr + dr];
         },
         [&](int k, int col) {
-            const int il = k / DrP, dr = k - il * DrP, de = de0 + col;
+            const int il = i0 + k / DrP, dr = k % DrP, de = de0 + col;
             if (de >= De || dr >= Dr) return 0.f;
             return a.proj[a.rel_ids[(int64_t)c * chunk + il] * (int64_t)De * Dr + (int64_t)de * Dr + dr];
         }, As, Bs);
-    const bool reg = a.reg_coef > 0.f && a.reg_norm > 0;
+    float *out = a.GNp + (int64_t)g * a.C * N * De;
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
         const int de = de0 + ct * 16 + m;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int j = j0 + wave * 16 + 4 * q + r;
-            if (de < De && j < N) {
-                float v = acc[ct][r];
-                if (reg) v += reg_grad(a.ent[a.neg_ids[(int64_t)c * N + j] * (int64_t)De + de], a.reg_coef, a.reg_norm);
-                a.GN[((int64_t)c * N + j) * De + de] = v;
-            }
+            if (de < De && j < N) out[((int64_t)c * N + j) * De + de] = acc[ct][r];
         }
+    }
+}
+
+// GN = sum over the groups (fixed order) + regulariser of the negative row copy
+__global__ __launch_bounds__(KGE_BLOCK) void transr_gn_reduce_kernel(TransRArgs a) {
+    const int64_t row = (int64_t)blockIdx.x * KGE_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    const int64_t rows = (int64_t)a.C * a.N;
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63, De = a.De;
+    const bool reg = a.reg_coef > 0.f && a.reg_norm > 0;
+    const float *x = a.ent + a.neg_ids[row] * (int64_t)De;
+    for (int d = lane; d < De; d += 64) {
+        float v = 0.f;
+        for (int g = 0; g < a.nG; ++g) v += a.GNp[((int64_t)g * rows + row) * De + d];
+        if (reg) v += reg_grad(x[d], a.reg_coef, a.reg_norm);
+        a.GN[row * De + d] = v;
     }
 }
 
@@ -318,8 +365,9 @@ int launch_transr_bwd(const TransRArgs &a, hipStream_t s) {
     if (a.B == 0) return KGE_OK;
     const int nJB = (a.N + TR_T - 1) / TR_T, nEB = (a.De + TR_T - 1) / TR_T, nRB = (a.Dr + TR_T - 1) / TR_T;
     const dim3 gw((a.B + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK), b(KGE_BLOCK);
-    hipLaunchKernelGGL(transr_dq_kernel, gw, b, 0, s, a);
-    hipLaunchKernelGGL(transr_gn_kernel, dim3(a.C * nJB * nEB), b, 0, s, a, nJB, nEB);
+    hipLaunchKernelGGL(transr_dq_kernel, dim3(a.B), b, 0, s, a);
+    hipLaunchKernelGGL(transr_gn_kernel, dim3(a.C * nJB * nEB * a.nG), b, 0, s, a, nJB, nEB);
+    hipLaunchKernelGGL(transr_gn_reduce_kernel, dim3(((int64_t)a.C * a.N + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK), b, 0, s, a);
     hipLaunchKernelGGL(transr_gp_kernel, dim3(a.B * nEB * nRB), b, 0, s, a, nEB, nRB);
     hipLaunchKernelGGL(transr_gr_kernel, gw, b, 0, s, a);
     return check_launch_t();

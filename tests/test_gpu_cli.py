@@ -28,7 +28,7 @@ def _planted(path, n_ent=400, n_rel=6, n=9000, seed=3):
 
 
 @pytest.mark.parametrize("model,extra", [("TransE_l2", []), ("DistMult", ["--loss_genre", "Logistic", "-g", "6"]),
-                                         ("RotatE", ["-de"])])
+                                         ("RotatE", ["-de"]), ("TransR", ["--lr", "0.05"]), ("RESCAL", ["--lr", "0.05", "-g", "6"])])
 def test_train_cli_end_to_end(tmp_path, capsys, model, extra):
     from dglke_amd import train as T
     data = str(tmp_path / "kg")
@@ -50,7 +50,9 @@ def test_train_cli_end_to_end(tmp_path, capsys, model, extra):
     assert os.path.basename(save) == "%s_toy_0" % model
     ent = np.load(os.path.join(save, "toy_%s_entity.npy" % model))
     rel = np.load(os.path.join(save, "toy_%s_relation.npy" % model))
-    assert ent.shape == (400, 64 if model == "RotatE" else 32) and rel.shape == (6, 32)
+    assert ent.shape == (400, 64 if model == "RotatE" else 32) and rel.shape == (6, 32 * 32 if model == "RESCAL" else 32)
+    if model == "TransR":
+        assert np.load(os.path.join(save, "toy_TransRprojection.npy")).shape == (6, 32 * 32)
     assert np.array_equal(ent, tr.model.entity_emb.emb.cpu().numpy())
     conf = json.load(open(os.path.join(save, "config.json")))
     assert conf["model_name"] == model and conf["emp_file"] == "e.dict" and conf["rmap_file"] == "r.dict"
