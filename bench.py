@@ -243,12 +243,7 @@ def main():
     G = args.graph_steps
     dev_sampler = (not args.host_plan) and 2 * w["B"] + C * w["N"] <= 4096
     if dev_sampler:
-        g = math.gcd(math.gcd(args.steps, args.warmup if args.warmup else args.steps), G)
-        if g >= 2 and g % 2 == 0:
-            G = g
-        else:
-            dev_sampler = False          # odd / tiny step counts: host-plan mode handles any K, W
-
+        G = max(2, G - G % 2)            # even group: slot parity = head / tail corruption (sampler.py:853-859)
     if dev_sampler:
         # ---- sampling + plan ON THE DEVICE, inside the timed region: one sampler launch per G steps ----
         from dglke_amd.dataloader import DeviceSampler
@@ -276,12 +271,30 @@ def main():
                 group()
             torch.cuda.synchronize()
 
-        def run_steps(count):
+        rem_graphs = {}
+
+        def partial(n):                  # one sampler launch + the first n < G steps of the group
+            dbs_ = smp.sample()
+            for b in dbs_[:n]:
+                eng.step(b)
+        if use_graph:
+            for n in {args.warmup % G, args.steps % G} - {0}:
+                rem_graphs[n] = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(rem_graphs[n]):
+                    partial(n)
+            torch.cuda.synchronize()
+
+        def run_steps(count):            # EXACTLY count steps: full groups, then one partial group
             for _ in range(count // G):
                 if use_graph:
                     gr.replay()
                 else:
                     group()
+            if count % G:
+                if use_graph:
+                    rem_graphs[count % G].replay()
+                else:
+                    partial(count % G)
         run_w = lambda: run_steps(args.warmup)
         run_t = lambda: run_steps(args.steps)
         launch_desc = ("hipGraph of [1 sampler launch + %d steps]" % G) if use_graph else "eager"

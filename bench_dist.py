@@ -56,11 +56,7 @@ def _p2p_setup(args, world, rank, dev, w, n_ent, d_e, d_r, emb_init):
     H = torch.randint(0, n_ent, (n_train,), device=dev, generator=g)
     T = torch.randint(0, n_ent, (n_train,), device=dev, generator=g)
     R = torch.randint(0, w["n_rel"], (n_train,), device=dev, generator=g)
-    G = math.gcd(math.gcd(args.steps, args.warmup if args.warmup else args.steps), 120)
-    if G < 2 or G % 2:
-        G = 2 if (args.steps % 2 == 0 and args.warmup % 2 == 0) else 0
-    if G == 0:
-        raise RuntimeError("odd step counts: the device sampler needs an even group size")
+    G = max(2, min(120, args.graph_steps) // 2 * 2)      # even group: slot parity = head / tail corruption
     smp = DeviceSampler(H, R, T, n_ent, w["B"], w["N"], dev, n_slots=G, seed=rank + 1)
     dbs = smp.sample()
     eng.workspace_for(dbs[0])
@@ -78,12 +74,28 @@ def _p2p_setup(args, world, rank, dev, w, n_ent, d_e, d_r, emb_init):
             group()
         torch.cuda.synchronize()
 
-    def run(count):
+    def partial(n):                     # one sampler launch + the first n < G steps of the group
+        for b in smp.sample()[:n]:
+            eng.step(b)
+    rem_graphs = {}
+    if gr is not None:
+        for n in {args.warmup % G, args.steps % G} - {0}:
+            rem_graphs[n] = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(rem_graphs[n]):
+                partial(n)
+        torch.cuda.synchronize()
+
+    def run(count):                     # EXACTLY count steps: full groups, then one partial group
         for _ in range(count // G):
             if gr is not None:
                 gr.replay()
             else:
                 group()
+        if count % G:
+            if gr is not None:
+                rem_graphs[count % G].replay()
+            else:
+                partial(count % G)
     C = w["B"] // w["N"]
     # traced rows per step for the byte accounting: count them on one sampled batch
     a_ = smp.slot_arrays(0)
