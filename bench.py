@@ -390,6 +390,15 @@ def main():
                      "event_ms_per_step": round(ev_ms / K, 6)},
         "mean_loss": round(accum[2] / K, 6),
     }
+    if w["model"] in ("TransE_l2", "DistMult", "ComplEx", "SimplE") and not args.force_pairwise:
+        # second bound of SURVEY 8(d): the chunked negative score and its two gradient products on the
+        # fp32 matrix cores, 2·B·N·D forward + 4·B·N·D backward, against the dense fp32 MFMA peak
+        d_row = w["hidden"] * (2 if w["de"] else 1)
+        flops = 6.0 * w["B"] * w["N"] * d_row
+        tf = flops / (ev_ms / K * 1e-3) / 1e12
+        out["roofline"]["mfma"] = {"flops_per_step": flops, "achieved": round(tf, 3), "peak": 157.3,
+                                   "unit": "TFLOP/s", "frac": round(tf / 157.3, 5),
+                                   "note": "whole step; the two GEMM kernels alone: see profiles/*kernel_stats*"}
     if args.hogwild > 1:
         try:
             out["hogwild"] = hogwild_measure(w, eng, dev, args.hogwild, K, max(G, 60), eng.hp.flags)
