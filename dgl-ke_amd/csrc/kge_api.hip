@@ -148,7 +148,6 @@ int kge_score_pos_bwd(int model, const float *h, const float *r, const float *t,
 }
 
 size_t kge_score_neg_workspace_bytes(int model, int C, int chunk, int N, int d_e) {
-    (void)model;
     const size_t B = (size_t)C * chunk, CN = (size_t)C * N;
     size_t n = 0;
     n += align_up(B * d_e * sizeof(float));      // A
@@ -156,6 +155,7 @@ size_t kge_score_neg_workspace_bytes(int model, int C, int chunk, int N, int d_e
     n += align_up(CN * sizeof(float));           // (reserved)
     n += align_up(B * (size_t)N * sizeof(float)); // W (L2-scaled dneg)
     n += align_up(B * d_e * sizeof(float));      // GA
+    if (neg_bwd_lc_supported(model, d_e)) n += align_up(neg_bwd_lc_partial_floats(model, C, chunk, N, d_e) * sizeof(float));
     return n;
 }
 
@@ -244,6 +244,8 @@ int kge_score_neg_bwd(int model, int neg_head, const float *pos_side, const floa
     if (int rc = neg_prepare(model, neg_head, pos_side, rel, neg, C, chunk, N, d_e, d_r, gamma,
                              emb_init, false, cv, A, asq, bsq, s)) return rc;
     float *W = cv.f((size_t)B * N), *GA = cv.f((size_t)B * d_e);
+    float *GNp = (neg_bwd_lc_supported(model, d_e) && !(flags & KGE_FLAG_TWO_PASS_PAIR))
+                     ? cv.f(neg_bwd_lc_partial_floats(model, C, chunk, N, d_e)) : nullptr;
     if (!cv.ok()) return fail(KGE_ERR_WORKSPACE, "workspace too small: need %zu bytes",
                               kge_score_neg_workspace_bytes(model, C, chunk, N, d_e));
     const float *Wuse = dneg;
@@ -264,7 +266,7 @@ int kge_score_neg_bwd(int model, int neg_head, const float *pos_side, const floa
         KGE_TRY(launch_neg_bwd_gemm(g, s));
     } else {
         NegArgs na; fill_pair(na, model, C, chunk, N, d_e, gamma, A, neg, nullptr);
-        na.W = Wuse; na.GA = GA; na.GN = g_neg;
+        na.W = Wuse; na.GA = GA; na.GN = g_neg; na.GNp = GNp;
         KGE_TRY(launch_neg_bwd_pair(na, s));
     }
     if (model == KGE_RESCAL) {                       // a = M x:  dL/dx = M^T GA,  dL/dM = GA x^T
@@ -359,7 +361,6 @@ int kge_adagrad_apply_rows(float *table, float *state_sum, int64_t n_rows, int d
 // fused step
 // ------------------------------------------------------------------------------------------
 size_t kge_step_workspace_bytes(const kge_hparams *hp, int B, int C, int chunk, int N, int UE, int UR) {
-    (void)chunk;
     const size_t d_e = hp->d_e, d_r = hp->d_r, CN = (size_t)C * N, tj16 = (N + 15) / 16;
     size_t n = 0;
     auto add = [&](size_t floats) { n += align_up(floats * sizeof(float)); };
@@ -387,6 +388,8 @@ size_t kge_step_workspace_bytes(const kge_hparams *hp, int B, int C, int chunk, 
     }
     else add(B * d_r);            // GR
     add(B); add(B); add(UE); add(UR);           // row_pos, row_neg, reg_ent, reg_rel
+    if (neg_bwd_lc_supported(hp->model, hp->d_e))   // TransE_l1 / RotatE: GN partials of the shared-pair backward
+        add(neg_bwd_lc_partial_floats(hp->model, C, chunk, N, hp->d_e));
     return n;
 }
 
@@ -461,6 +464,8 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         tr.GNp = cv.f((size_t)TRANSR_GN_GROUPS * CN * d_e);
     }
     float *row_pos = cv.f(B), *row_neg = cv.f(B), *reg_ent = cv.f(b->UE), *reg_rel = cv.f(b->UR);
+    float *GNp = (neg_bwd_lc_supported(hp->model, d_e) && !(hp->flags & KGE_FLAG_TWO_PASS_PAIR))
+                     ? cv.f(neg_bwd_lc_partial_floats(hp->model, C, chunk, N, d_e)) : nullptr;
     if (!cv.ok())
         return fail(KGE_ERR_WORKSPACE, "kge_step: workspace too small (%zu < %zu)", ws_bytes,
                     kge_step_workspace_bytes(hp, B, C, chunk, N, b->UE, b->UR));
@@ -574,6 +579,7 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     } else {
         na.W = S; na.GA = GA; na.GN = GN;
         na.reg_coef = reg ? hp->reg_coef : 0.f; na.reg_norm = hp->reg_norm;
+        na.GNp = gemm ? nullptr : GNp;
         KGE_TRY(launch_neg_bwd_pair(na, s));
     }
 

@@ -211,6 +211,8 @@ struct NegArgs {                     // chunked negative scoring, forward and ba
     float reg_coef; int reg_norm;    // (unused by the GEMM/pair kernels; regularisation is added
                                      //  by the consumers of GN)
     float clampv;                    // > 0: clamp the scores to [-clampv, clampv] (SimplE)
+    float *GNp;                      // bwd, TransE_l1 / RotatE: room for the per-row-group GN partials
+                                     // (neg_bwd_lc_partial_floats) or null: two-pass kernels
 };
 
 struct LossArgs {
@@ -365,3 +367,5 @@ int launch_transr_proj_update(const TransRArgs &a, hipStream_t s);
 bool neg_bcast_supported(int model, int d_e);          // kge_neg_bcast.hip: lane = row, other operand wave-uniform
 int launch_neg_fwd_bcast(const NegArgs &a, hipStream_t s);
 int launch_neg_bwd_bcast(const NegArgs &a, hipStream_t s);
+bool neg_bwd_lc_supported(int model, int d_e);         // kge_neg_bcast.hip: lane = column, one pair evaluation feeds GA and GN
+size_t neg_bwd_lc_partial_floats(int model, int C, int chunk, int N, int d_e);

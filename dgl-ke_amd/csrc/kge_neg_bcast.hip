@@ -62,32 +62,50 @@ bool neg_bcast_supported(int model, int d_e) {
 // uniform rows whose operands sit in lanes [lb, lb+NE) of yr / yi.  LB >= 0: compile-time lane
 // indices (main loop); LB < 0: the lane base is the run-time (wave-uniform) value lbr (tail).
 // ---------------------------------------------------------------------------------------------
+typedef float v2f __attribute__((ext_vector_type(2)));   // two fp32 in an even-aligned VGPR pair: v_pk_add/mul/fma_f32
+
 template <int MODEL, int RW, int NE, int LB>
 __device__ __forceinline__ void fwd_step(const float (&xc)[16], const float (&yr)[RW], const float (&yi)[RW],
-                                         float (&acc)[RW], int lbr) {
+                                         v2f (&acc)[RW], int lbr) {
     constexpr bool CPLX = MODEL == KGE_ROTATE;
-    static_for<NE>([&](auto ec) {
-        constexpr int e = decltype(ec)::value;
+    // two reduction elements (e, e+1) per step in packed fp32 math: the uniform operands are read into an SGPR
+    // pair, the lane's own operands are adjacent VGPRs of the float4 loads, the accumulator is a pair as well
+    // (even / odd elements, summed at the end) - half the VALU issue slots of the scalar form
+    static_for<NE / 2>([&](auto ec) {
+        constexpr int e = 2 * decltype(ec)::value;
 #pragma unroll
         for (int r = 0; r < RW; ++r) {
-            float y0, y1 = 0.f;
+            v2f y0, y1 = {0.f, 0.f};
             if constexpr (LB >= 0) {
-                y0 = bcast<(LB >= 0 ? LB : 0) + e>(yr[r]);
-                if constexpr (CPLX) y1 = bcast<(LB >= 0 ? LB : 0) + e>(yi[r]);
+                y0 = (v2f){bcast<(LB >= 0 ? LB : 0) + e>(yr[r]), bcast<(LB >= 0 ? LB : 0) + e + 1>(yr[r])};
+                if constexpr (CPLX)
+                    y1 = (v2f){bcast<(LB >= 0 ? LB : 0) + e>(yi[r]), bcast<(LB >= 0 ? LB : 0) + e + 1>(yi[r])};
             } else {
-                y0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(yr[r]), lbr + e));
-                if constexpr (CPLX) y1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(yi[r]), lbr + e));
+                y0 = (v2f){__int_as_float(__builtin_amdgcn_readlane(__float_as_int(yr[r]), lbr + e)),
+                           __int_as_float(__builtin_amdgcn_readlane(__float_as_int(yr[r]), lbr + e + 1))};
+                if constexpr (CPLX)
+                    y1 = (v2f){__int_as_float(__builtin_amdgcn_readlane(__float_as_int(yi[r]), lbr + e)),
+                               __int_as_float(__builtin_amdgcn_readlane(__float_as_int(yi[r]), lbr + e + 1))};
             }
+            const v2f x0 = {xc[e], xc[e + 1]};
             if constexpr (CPLX) {
-                const float dr = y0 - xc[e], di = y1 - xc[8 + e];
-                acc[r] += fast_sqrt(fmaf(di, di, dr * dr));
+                const v2f x1 = {xc[8 + e], xc[9 + e]};
+                const v2f dr = y0 - x0, di = y1 - x1;
+                const v2f m2 = __builtin_elementwise_fma(di, di, dr * dr);
+                acc[r] += (v2f){fast_sqrt(m2.x), fast_sqrt(m2.y)};
             } else if constexpr (MODEL == KGE_TRANSE_L1) {
-                acc[r] += fabsf(y0 - xc[e]);
+                // one packed subtraction, then |.| as the free source modifier of two scalar additions (written
+                // as asm: the vectoriser otherwise re-packs the additions and pays two v_and for the |.|)
+                const v2f u = y0 - x0;
+                float ax = acc[r].x, ay = acc[r].y;
+                asm("v_add_f32 %0, |%1|, %0" : "+v"(ax) : "v"(u.x));
+                asm("v_add_f32 %0, |%1|, %0" : "+v"(ay) : "v"(u.y));
+                acc[r] = (v2f){ax, ay};
             } else if constexpr (MODEL == KGE_TRANSE_L2) {
-                const float u = y0 - xc[e];
-                acc[r] = fmaf(u, u, acc[r]);
+                const v2f u = y0 - x0;
+                acc[r] = __builtin_elementwise_fma(u, u, acc[r]);
             } else {
-                acc[r] = fmaf(y0, xc[e], acc[r]);
+                acc[r] = __builtin_elementwise_fma(y0, x0, acc[r]);
             }
         }
     });
@@ -125,9 +143,9 @@ __global__ __launch_bounds__(KGE_BLOCK) void neg_fwd_bcast_kernel(NegArgs a, int
     const float *y[RW];
 #pragma unroll
     for (int r = 0; r < RW; ++r) y[r] = a.A + ((int64_t)c * a.chunk + min(i0 + r, a.chunk - 1)) * D;
-    float acc[RW];
+    v2f acc[RW];
 #pragma unroll
-    for (int r = 0; r < RW; ++r) acc[r] = 0.f;
+    for (int r = 0; r < RW; ++r) acc[r] = (v2f){0.f, 0.f};
 
     auto loady = [&](float (&yr)[RW], float (&yi)[RW], int kb) {     // block of 64 elements: lane = element
         const int k = min(kb + lane, K - 1);
@@ -174,7 +192,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void neg_fwd_bcast_kernel(NegArgs a, int
 #pragma unroll
         for (int r = 0; r < RW; ++r) {
             if (i0 + r < a.chunk) {
-                float v = acc[r];
+                float v = acc[r].x + acc[r].y;
                 if (MODEL == KGE_TRANSE_L1 || CPLX) v = a.gamma - v;
                 else if (MODEL == KGE_TRANSE_L2) v = a.gamma - sqrtf(fmaxf(v, 1e-30f));
                 else if (a.clampv > 0.f) v = fminf(fmaxf(v, -a.clampv), a.clampv);
@@ -351,6 +369,257 @@ __global__ __launch_bounds__(KGE_BLOCK) void neg_bwd_bcast_kernel(NegArgs a, int
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// backward, "lane = column" layout (TransE_l1 and RotatE): ONE evaluation of every pair (i, j) feeds BOTH
+// products.  The kernels above compute GA and GN in separate passes because a lane owns an output row and the
+// other operand is broadcast - every pair difference, modulus and reciprocal root is evaluated twice.  Here a
+// lane owns two adjacent (complex) columns instead:
+//     lane = (sg, kk):  columns k0 + 2 kk, k0 + 2 kk + 1  (packed fp32 pairs: v_pk_add/mul/fma_f32),
+//                       sg = lane / 16 selects one of the 4 negatives of a quad  s = 4 q + sg.
+// A wavefront keeps RT positive rows x_n (and their GA accumulators) in VGPRs and streams the quads of
+// negatives: y = b_s[cols] is one 8-byte load per lane, W(r0 + n, s) comes from ONE register per quad
+// (lane (sg, kk) holds W(r0 + kk, 4 q + sg)) through the DPP row_newbcast:n modifier (lane n of every row of
+// 16 lanes).  Per pair and per two columns:  d = x - y, m2 = |d|^2, rsq, iv = w rsq, GA_n -= iv d, GN_s += iv d.
+// GA needs the sum over the 4 lane rows at the very end (two cross-row shuffles per value); GN is complete
+// over the wavefront's RT rows after every quad and is summed over the 4 wavefronts of the workgroup (= 4 row
+// blocks of the same chunk and column slab) in LDS, in fixed order, every LC_GQ quads; what remains is one
+// partial per workgroup row group (chunk / (4 RT), 3 for chunk = 200), added up - with the regulariser of the
+// negative rows - by gn_reduce_kernel.  Deterministic (no atomics).
+// ---------------------------------------------------------------------------------------------
+#define LC_CW 32                                 // (complex) columns per wavefront: 16 lanes x 2
+#define LC_GQ 8                                  // quads of negatives per group (staging + LDS reduction round)
+#define LC_SG (4 * LC_GQ)                         // negatives per group
+#define LC_RTMAX 20                              // most positive rows a wavefront keeps in registers (RotatE: 16)
+
+__device__ __forceinline__ float4 zero4b() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+template <int L> __device__ __forceinline__ float rowb(float v) {    // lane L of every row of 16 lanes
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x150 + L, 0xF, 0xF, true));
+}
+
+// workgroups per (chunk, slab) and rows per wavefront: at least as many workgroups as keep every wavefront at
+// <= LC_RTMAX rows; more (down to 8 rows per wavefront) while the launch still fits one workgroup per CU
+static inline void lc_shape(int model, int C, int chunk, int d_e, int &nslab, int &nrw, int &rpw) {
+    const int K = model == KGE_ROTATE ? d_e / 2 : d_e;
+    nslab = (K + LC_CW - 1) / LC_CW;
+    const int rtmax = model == KGE_ROTATE ? 16 : LC_RTMAX;
+    nrw = 1;
+    while ((chunk + 4 * nrw - 1) / (4 * nrw) > rtmax) ++nrw;
+    while ((int64_t)C * nslab * (nrw + 1) <= 256 && (chunk + 4 * (nrw + 1) - 1) / (4 * (nrw + 1)) >= 8) ++nrw;
+    rpw = (chunk + 4 * nrw - 1) / (4 * nrw);
+}
+bool neg_bwd_lc_supported(int model, int d_e) {
+    if (model == KGE_ROTATE) return d_e % 4 == 0 && neg_bcast_supported(model, d_e);
+    return model == KGE_TRANSE_L1 && d_e % 2 == 0 && neg_bcast_supported(model, d_e);
+}
+size_t neg_bwd_lc_partial_floats(int model, int C, int chunk, int N, int d_e) {
+    int nslab, nrw, rpw;
+    lc_shape(model, C, chunk, d_e, nslab, nrw, rpw);
+    return (size_t)nrw * C * N * d_e;
+}
+
+template <int MODEL, int RT>
+__global__ __launch_bounds__(KGE_BLOCK) void neg_bwd_lc_kernel(NegArgs a, int nslab, int nrw, int rpw) {
+    constexpr bool CPLX = MODEL == KGE_ROTATE;
+    constexpr int NV = CPLX ? 4 : 2;                             // floats per lane in a GN partial
+    __shared__ __attribute__((aligned(16))) float red[2 * LC_GQ * KGE_WAVES_PER_BLOCK * 64 * NV];   // GN partials, two alternating buffers
+    __shared__ __attribute__((aligned(16))) float stage[2 * LC_SG * LC_CW * (CPLX ? 2 : 1) + 2 * KGE_WAVES_PER_BLOCK * LC_SG * (RT > 16 ? 32 : 16)];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63, sg = lane >> 4, kk = lane & 15;
+    const int blk = blockIdx.x;
+    const int rw = blk % nrw, slab = (blk / nrw) % nslab, c = blk / (nrw * nslab);
+    const int D = a.d_e, K = CPLX ? D / 2 : D, N = a.N, chunk = a.chunk;
+    const int col = slab * LC_CW + 2 * kk;
+    const bool colok = col < K;                                  // K is even: both columns or none
+    const int colc = colok ? col : 0;
+    const int r0 = (rw * KGE_WAVES_PER_BLOCK + wave) * rpw;      // first positive row of this wavefront
+    const int rend = min(r0 + rpw, chunk);                       // rows [r0, rend)
+
+    v2f xr[RT], xi[RT], gr[RT], gi[RT];
+#pragma unroll
+    for (int n = 0; n < RT; ++n) {
+        const float *xp = a.A + ((int64_t)c * chunk + min(r0 + n, chunk - 1)) * D + colc;
+        xr[n] = *reinterpret_cast<const v2f *>(xp);
+        xi[n] = CPLX ? *reinterpret_cast<const v2f *>(xp + K) : (v2f){0.f, 0.f};
+        gr[n] = (v2f){0.f, 0.f};
+        gi[n] = (v2f){0.f, 0.f};
+    }
+    const float *Wc = a.W + (int64_t)c * chunk * N;
+    const int nq = (N + 3) >> 2;
+    // ---- operand staging through LDS, one group of LC_GQ quads (= LC_SG negatives) at a time ----------------
+    // The 4 wavefronts of the workgroup need the SAME negative rows (their slab columns) and each its own block
+    // of W.  The global loads of group i+1 are issued BEFORE the arithmetic of group i and written to the other
+    // LDS buffer after it: their latency (an L2 miss is ~1.5 k cycles, a quad only ~0.3-0.6 k cycles of
+    // arithmetic, one wavefront per SIMD) is covered by a whole group of work; inside a group the operands of a
+    // quad come from LDS, requested one quad ahead.  (Register slots filled straight from global memory either
+    // stall - the compiler drains every outstanding load at the loop head - or, unrolled far enough to avoid
+    // that, blow up the register allocation.)
+    constexpr int YF = LC_CW * (CPLX ? 2 : 1);                   // floats per negative in the y buffer
+    constexpr int RTW = RT > 16 ? 32 : 16;                       // W rows per wavefront in LDS
+    float *ybuf = stage;                                         // [2][LC_SG][YF]
+    float *wbuf = stage + 2 * LC_SG * YF;                        // [2][4 wavefronts][LC_SG][RTW]  (negative-major)
+    const int tid = threadIdx.x;
+    const int ys = tid >> 3, yp4 = (tid & 7) * 4;                // y staging: negative ys, 4 columns from yp4
+    const int ycol = slab * LC_CW + yp4;
+    const int ycolc = ycol < K ? ycol : 0;
+    const int wrow = lane >> 3, wp4 = (lane & 7) * 4;            // W staging: rows wrow (+8, ...), 4 negatives from wp4
+    float4 sy0, sy1 = zero4b(), sw[RTW / 8];
+    auto gload = [&](int qb) {                                   // global -> registers (group starting at quad qb)
+        const int s = min(4 * qb + ys, N - 1);
+        const float *yp = a.nbase + ((int64_t)c * N + s) * D + ycolc;
+        sy0 = *reinterpret_cast<const float4 *>(yp);
+        if constexpr (CPLX) sy1 = *reinterpret_cast<const float4 *>(yp + K);
+        const int s4 = min(4 * qb + wp4, N - 4);                 // N % 4 == 0: whole float4 or (masked later) a re-read
+#pragma unroll
+        for (int t = 0; t < RTW / 8; ++t)
+            sw[t] = *reinterpret_cast<const float4 *>(Wc + (int64_t)min(r0 + wrow + 8 * t, chunk - 1) * N + s4);
+    };
+    auto lstore = [&](int bf) {                                  // registers -> LDS buffer bf
+        float *yb = ybuf + (bf * LC_SG + ys) * YF;
+        *reinterpret_cast<float4 *>(yb + yp4) = sy0;
+        if constexpr (CPLX) *reinterpret_cast<float4 *>(yb + LC_CW + yp4) = sy1;
+        float *wb = wbuf + ((bf * KGE_WAVES_PER_BLOCK + wave) * LC_SG + wp4) * RTW + wrow;
+#pragma unroll
+        for (int t = 0; t < RTW / 8; ++t) {
+            wb[8 * t] = sw[t].x; wb[RTW + 8 * t] = sw[t].y; wb[2 * RTW + 8 * t] = sw[t].z; wb[3 * RTW + 8 * t] = sw[t].w;
+        }
+    };
+    const bool rok0 = r0 + kk < rend, rok1 = RT > 16 && kk < RT - 16 && r0 + 16 + kk < rend;
+    // operands of one quad out of LDS buffer bf: y = b_s[cols] (s = quad g, lane row sg), raw W values
+    auto lread = [&](int bf, int g, v2f &yr_, v2f &yi_, float &w0_, float &w1_) {
+        const float *yb = ybuf + (bf * LC_SG + 4 * g + sg) * YF + 2 * kk;
+        yr_ = *reinterpret_cast<const v2f *>(yb);
+        yi_ = CPLX ? *reinterpret_cast<const v2f *>(yb + LC_CW) : (v2f){0.f, 0.f};
+        const float *wb = wbuf + ((bf * KGE_WAVES_PER_BLOCK + wave) * LC_SG + 4 * g + sg) * RTW + kk;
+        w0_ = wb[0];
+        w1_ = RT > 16 ? wb[16] : 0.f;
+    };
+    // one quad: RT rows of this wavefront against the 4 negatives of the quad; GN partial -> LDS
+    auto quad = [&](int q, int g, float *redb, const v2f &yr_, const v2f &yi_, float w0_, float w1_) {
+        v2f nr = {0.f, 0.f}, ni = {0.f, 0.f};
+        const bool sok = q < nq && 4 * q + sg < N;
+        const float wa = (rok0 && sok) ? w0_ : 0.f, wb = (rok1 && sok) ? w1_ : 0.f;
+        static_for<RT>([&](auto nc) {
+            constexpr int n = decltype(nc)::value;
+            const float w = n < 16 ? rowb<(n & 15)>(wa) : rowb<(n & 15)>(wb);
+            if constexpr (CPLX) {
+                const v2f dr = xr[n] - yr_, di = xi[n] - yi_;
+                const v2f m2 = __builtin_elementwise_fma(di, di, __builtin_elementwise_fma(dr, dr, (v2f){1e-30f, 1e-30f}));
+                const v2f iv = (v2f){fast_rsq(m2.x), fast_rsq(m2.y)} * w;   // + tiny: zero difference -> zero gradient
+                gr[n] = __builtin_elementwise_fma(dr, -iv, gr[n]);
+                gi[n] = __builtin_elementwise_fma(di, -iv, gi[n]);
+                nr = __builtin_elementwise_fma(dr, iv, nr);
+                ni = __builtin_elementwise_fma(di, iv, ni);
+            } else {
+                const v2f d = xr[n] - yr_;
+                // sign(d) = med3(d * 2^126, -1, 1): exact for every normal d, 0 at d == 0
+                const v2f sgn = {__builtin_amdgcn_fmed3f(__builtin_amdgcn_ldexpf(d.x, 126), -1.f, 1.f),
+                                 __builtin_amdgcn_fmed3f(__builtin_amdgcn_ldexpf(d.y, 126), -1.f, 1.f)};
+                const v2f wv = {w, w};
+                gr[n] = __builtin_elementwise_fma(sgn, -wv, gr[n]);
+                nr = __builtin_elementwise_fma(sgn, wv, nr);
+            }
+        });
+        float *slot = redb + ((g * KGE_WAVES_PER_BLOCK + wave) * 64 + lane) * NV;
+        if constexpr (CPLX) *reinterpret_cast<float4 *>(slot) = make_float4(nr.x, nr.y, ni.x, ni.y);
+        else *reinterpret_cast<v2f *>(slot) = nr;
+    };
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    int buf = 0;
+    for (int qb = 0; qb < nq; qb += LC_GQ) {
+        float *redb = red + buf * (LC_GQ * KGE_WAVES_PER_BLOCK * 64 * NV);
+        gload(min(qb + LC_GQ, nq - 1));                          // next group (past the end: a harmless re-read)
+        v2f ya, yia, yb_, yib;
+        float wa0, wa1, wb0, wb1;
+        lread(buf, 0, ya, yia, wa0, wa1);
+#pragma unroll 1
+        for (int g = 0; g < LC_GQ; g += 2) {                     // two quads per trip: LDS operands one quad ahead
+            lread(buf, g + 1, yb_, yib, wb0, wb1);
+            quad(qb + g, g, redb, ya, yia, wa0, wa1);
+            lread(buf, min(g + 2, LC_GQ - 1), ya, yia, wa0, wa1);
+            quad(qb + g + 1, g + 1, redb, yb_, yib, wb0, wb1);
+        }
+        lstore(buf ^ 1);
+        __syncthreads();
+        // fixed-order sum over the 4 wavefronts: one partial per (workgroup row group, negative, column).  The
+        // LDS buffers alternate, so the next group needs no second barrier.
+        for (int e = tid; e < LC_GQ * 64; e += KGE_BLOCK) {
+            const int g = e >> 6, l = e & 63;
+            const float *p = redb + (g * KGE_WAVES_PER_BLOCK * 64 + l) * NV;
+            const int sN = 4 * (qb + g) + (l >> 4);
+            const int cl = slab * LC_CW + 2 * (l & 15);
+            float *o = a.GNp + (((int64_t)rw * a.C + c) * N + sN) * D + cl;
+            if constexpr (CPLX) {
+                const float4 v0 = *reinterpret_cast<const float4 *>(p), v1 = *reinterpret_cast<const float4 *>(p + 64 * NV);
+                const float4 v2 = *reinterpret_cast<const float4 *>(p + 2 * 64 * NV), v3 = *reinterpret_cast<const float4 *>(p + 3 * 64 * NV);
+                if (sN < N && cl < K) {
+                    *reinterpret_cast<v2f *>(o) = (v2f){((v0.x + v1.x) + v2.x) + v3.x, ((v0.y + v1.y) + v2.y) + v3.y};
+                    *reinterpret_cast<v2f *>(o + K) = (v2f){((v0.z + v1.z) + v2.z) + v3.z, ((v0.w + v1.w) + v2.w) + v3.w};
+                }
+            } else {
+                const v2f v0 = *reinterpret_cast<const v2f *>(p), v1 = *reinterpret_cast<const v2f *>(p + 64 * NV);
+                const v2f v2 = *reinterpret_cast<const v2f *>(p + 2 * 64 * NV), v3 = *reinterpret_cast<const v2f *>(p + 3 * 64 * NV);
+                if (sN < N && cl < K) *reinterpret_cast<v2f *>(o) = ((v0 + v1) + v2) + v3;
+            }
+        }
+        buf ^= 1;
+    }
+    // GA: sum over the 4 lane rows (different negatives), then lane row 0 stores
+#pragma unroll
+    for (int n = 0; n < RT; ++n) {
+        gr[n].x += __shfl_xor(gr[n].x, 16, 64); gr[n].y += __shfl_xor(gr[n].y, 16, 64);
+        gr[n].x += __shfl_xor(gr[n].x, 32, 64); gr[n].y += __shfl_xor(gr[n].y, 32, 64);
+        if constexpr (CPLX) {
+            gi[n].x += __shfl_xor(gi[n].x, 16, 64); gi[n].y += __shfl_xor(gi[n].y, 16, 64);
+            gi[n].x += __shfl_xor(gi[n].x, 32, 64); gi[n].y += __shfl_xor(gi[n].y, 32, 64);
+        }
+        if (sg == 0 && colok && r0 + n < rend) {
+            float *o = a.GA + ((int64_t)c * chunk + r0 + n) * D + col;
+            *reinterpret_cast<v2f *>(o) = gr[n];
+            if constexpr (CPLX) *reinterpret_cast<v2f *>(o + K) = gi[n];
+        }
+    }
+}
+
+// GN[j, :] = sum over the workgroup row groups of the partials (fixed order) + regulariser of the negative row
+__global__ __launch_bounds__(KGE_BLOCK) void gn_reduce_kernel(NegArgs a, int nrw) {
+    const int64_t n4 = (int64_t)a.C * a.N * a.d_e / 4;
+    const int64_t t = (int64_t)blockIdx.x * KGE_BLOCK + threadIdx.x;
+    if (t >= n4) return;
+    const int64_t stride = (int64_t)a.C * a.N * a.d_e;
+    float4 acc = *reinterpret_cast<const float4 *>(a.GNp + 4 * t);
+    for (int r = 1; r < nrw; ++r) {
+        const float4 v = *reinterpret_cast<const float4 *>(a.GNp + r * stride + 4 * t);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    if (a.reg_coef > 0.f && a.reg_norm > 0) {
+        const int64_t j = (4 * t) / a.d_e;
+        const int k = (int)((4 * t) % a.d_e);
+        const float4 x = *reinterpret_cast<const float4 *>(row_ptr(a.nbase, a.nidx, j, a.d_e) + k);
+        acc.x += reg_grad(x.x, a.reg_coef, a.reg_norm); acc.y += reg_grad(x.y, a.reg_coef, a.reg_norm);
+        acc.z += reg_grad(x.z, a.reg_coef, a.reg_norm); acc.w += reg_grad(x.w, a.reg_coef, a.reg_norm);
+    }
+    *reinterpret_cast<float4 *>(a.GN + 4 * t) = acc;
+}
+
+template <int MODEL> static int lc_launch(const NegArgs &a, hipStream_t s) {
+    int nslab, nrw, rpw;
+    lc_shape(MODEL, a.C, a.chunk, a.d_e, nslab, nrw, rpw);
+    const int64_t nb = (int64_t)a.C * nslab * nrw;
+    if (nb == 0) return KGE_OK;
+    const dim3 g((unsigned)nb), b(KGE_BLOCK);
+    // rows per wavefront rounded up to the next instantiation (the padding rows carry W = 0)
+    if (rpw <= 8) hipLaunchKernelGGL((neg_bwd_lc_kernel<MODEL, 8>), g, b, 0, s, a, nslab, nrw, rpw);
+    else if (rpw <= 12) hipLaunchKernelGGL((neg_bwd_lc_kernel<MODEL, 12>), g, b, 0, s, a, nslab, nrw, rpw);
+    else if (rpw <= 16) hipLaunchKernelGGL((neg_bwd_lc_kernel<MODEL, 16>), g, b, 0, s, a, nslab, nrw, rpw);
+    else if constexpr (MODEL != KGE_ROTATE) hipLaunchKernelGGL((neg_bwd_lc_kernel<MODEL, LC_RTMAX>), g, b, 0, s, a, nslab, nrw, rpw);
+    if (int rc = check_launch_b()) return rc;
+    const int64_t n4 = (int64_t)a.C * a.N * a.d_e / 4;
+    hipLaunchKernelGGL(gn_reduce_kernel, dim3((unsigned)((n4 + KGE_BLOCK - 1) / KGE_BLOCK)), dim3(KGE_BLOCK), 0, s, a, nrw);
+    return check_launch_b();
+}
+
 template <int MODEL> static int bwd_launch(const NegArgs &a, hipStream_t s) {
     constexpr int KW = MODEL == KGE_ROTATE ? SB_KC : SB_KWR;
     constexpr int GS = 4;
@@ -365,6 +634,8 @@ template <int MODEL> static int bwd_launch(const NegArgs &a, hipStream_t s) {
 }
 
 int launch_neg_bwd_bcast(const NegArgs &a, hipStream_t s) {
+    if (a.GNp && !a.nidx && a.N % 4 == 0 && neg_bwd_lc_supported(a.model, a.d_e))   // shared-pair kernel when the caller gave it room
+        return a.model == KGE_ROTATE ? lc_launch<KGE_ROTATE>(a, s) : lc_launch<KGE_TRANSE_L1>(a, s);
     switch (a.model) {
         case KGE_TRANSE_L1: return bwd_launch<KGE_TRANSE_L1>(a, s);
         case KGE_TRANSE_L2: return bwd_launch<KGE_TRANSE_L2>(a, s);

@@ -17,6 +17,9 @@ MODEL_IDS = {"TransE_l1": 0, "TransE_l2": 1, "TransE": 1, "DistMult": 2, "ComplE
 LOSS_IDS = {"Logsigmoid": 0, "Logistic": 1, "Hinge": 2, "BCE": 3}
 FLAG_FORCE_PAIRWISE = 1
 FLAG_NO_TRANSE_FAST = 2
+FLAG_DENSE_NEG = 4
+FLAG_FUSED_LOSS = 8
+FLAG_TWO_PASS_PAIR = 16
 ACC_SLOTS = 4096
 
 c_f = C.c_float

@@ -74,6 +74,9 @@ enum kge_status {
  * running the stand-alone loss kernel (one launch fewer; currently slower because the extra VALU
  * work sits between the MFMAs - kept for tuning) */
 #define KGE_FLAG_FUSED_LOSS 8u
+/* TransE_l1 / RotatE: keep the two-pass pairwise backward (GA and GN evaluated separately) instead
+ * of the kernel that evaluates every (positive, negative) pair once for both products (validation aid) */
+#define KGE_FLAG_TWO_PASS_PAIR 16u
 
 int         kge_abi_version(void);
 const char *kge_last_error(void);

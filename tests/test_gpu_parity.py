@@ -317,3 +317,60 @@ def test_sharded_engine_world1_equals_fused_step():
             _close(lb_, la, 1e-5, 1e-6, model + " loss sums")
     finally:
         dist.destroy_process_group()
+
+
+def _pair_neg_reference(model, neg_head, a, b, W, C, chunk, N, gamma):
+    """fp64 torch autograd of the reference's pairwise create_neg forms (score_fun.py:36-38 cdist p=1;
+    :526-531, 548-552 RotatE modulus of the broadcast difference) given the pos-side vectors a."""
+    a = torch.tensor(a, dtype=torch.float64, requires_grad=True)
+    b = torch.tensor(b, dtype=torch.float64, requires_grad=True)
+    A = a.view(C, chunk, 1, -1)
+    Bn = b.view(C, 1, N, -1)
+    if model == "TransE_l1":
+        s = gamma - (A - Bn).abs().sum(-1)
+    else:
+        K = a.shape[1] // 2
+        dr = A[..., :K] - Bn[..., :K]
+        di = A[..., K:] - Bn[..., K:]
+        s = gamma - torch.sqrt(dr * dr + di * di).sum(-1)
+    (s * torch.tensor(W, dtype=torch.float64)).sum().backward()
+    return s.detach().numpy(), a.grad.numpy(), b.grad.numpy()
+
+
+@pytest.mark.parametrize("model", ["TransE_l1", "RotatE"])
+@pytest.mark.parametrize("shape", [(5, 200, 200, 400), (3, 37, 44, 48), (2, 16, 4, 16), (1, 129, 260, 112)])
+def test_shared_pair_backward_matches_two_pass_and_fp64(model, shape):
+    """TransE_l1 / RotatE negative-score backward: the kernel that evaluates every (positive, negative) pair once
+    for both products (lane = column, LDS-staged) against the two-pass kernels (KGE_FLAG_TWO_PASS_PAIR) and an
+    fp64 autograd reference - ragged row blocks, partial column slabs and a partial last group of negatives."""
+    from dglke_amd import _lib, ops
+    C, chunk, N, D = shape
+    rng = np.random.RandomState(7)
+    B = C * chunk
+    de = D
+    dr = D // 2 if model == "RotatE" else D
+    x = rng.uniform(-1, 1, (B, de)).astype(np.float32)
+    r = rng.uniform(-1, 1, (B, dr)).astype(np.float32)
+    nb = rng.uniform(-1, 1, (C * N, de)).astype(np.float32)
+    W = rng.uniform(-1, 1, (C, chunk, N)).astype(np.float32)
+    outs = {}
+    for name, fl in (("shared", 0), ("two_pass", _lib.FLAG_TWO_PASS_PAIR)):
+        xt = torch.tensor(x, device=DEV, requires_grad=True)
+        rt = torch.tensor(r, device=DEV, requires_grad=True)
+        nt = torch.tensor(nb, device=DEV, requires_grad=True)
+        s = ops.score_neg(model, False, xt, rt, nt, C, chunk, N, 12.0, emb_init=0.07, flags=fl)
+        (s * torch.tensor(W, device=DEV)).sum().backward()
+        outs[name] = (s.detach().cpu().numpy(), xt.grad.cpu().numpy(), rt.grad.cpu().numpy(), nt.grad.cpu().numpy())
+    gscale = max(np.abs(outs["two_pass"][3]).max(), np.abs(outs["two_pass"][1]).max())
+    for k, what in ((1, "g_pos_side"), (2, "g_rel"), (3, "g_neg")):
+        _close(outs["shared"][k], outs["two_pass"][k], 0, 2e-5 * np.abs(outs["two_pass"][k]).max(),
+               "%s shared vs two-pass %s" % (model, what))
+    if model == "TransE_l1":       # a = h + r: compare the negative-row gradient with fp64 directly
+        a = x.astype(np.float64) + r.astype(np.float64)
+        s64, ga64, gn64 = _pair_neg_reference(model, False, a, nb, W, C, chunk, N, 12.0)
+        _close(outs["shared"][0], s64, 1e-4, 1e-4, "TransE_l1 scores vs fp64")
+        # sign() is discontinuous: an fp32 a_k - b_k of the other sign than fp64 flips one W_ij term
+        bad = np.abs(outs["shared"][3] - gn64) > 3e-4 * gscale
+        assert bad.mean() < 2e-3, "TransE_l1 g_neg vs fp64: %.4f of the entries differ" % bad.mean()
+        bad = np.abs(outs["shared"][1] - ga64) > 3e-4 * gscale
+        assert bad.mean() < 2e-3, "TransE_l1 g_pos_side vs fp64: %.4f of the entries differ" % bad.mean()
