@@ -377,18 +377,22 @@ __global__ __launch_bounds__(KGE_BLOCK) void neg_bwd_bcast_kernel(NegArgs a, int
 //     lane = (sg, kk):  columns k0 + 2 kk, k0 + 2 kk + 1  (packed fp32 pairs: v_pk_add/mul/fma_f32),
 //                       sg = lane / 16 selects one of the 4 negatives of a quad  s = 4 q + sg.
 // A wavefront keeps RT positive rows x_n (and their GA accumulators) in VGPRs and streams the quads of
-// negatives: y = b_s[cols] is one 8-byte load per lane, W(r0 + n, s) comes from ONE register per quad
+// negatives (operands staged through LDS, see the kernel): y = b_s[cols], W(r0 + n, s) comes from ONE register per quad
 // (lane (sg, kk) holds W(r0 + kk, 4 q + sg)) through the DPP row_newbcast:n modifier (lane n of every row of
 // 16 lanes).  Per pair and per two columns:  d = x - y, m2 = |d|^2, rsq, iv = w rsq, GA_n -= iv d, GN_s += iv d.
 // GA needs the sum over the 4 lane rows at the very end (two cross-row shuffles per value); GN is complete
 // over the wavefront's RT rows after every quad and is summed over the 4 wavefronts of the workgroup (= 4 row
 // blocks of the same chunk and column slab) in LDS, in fixed order, every LC_GQ quads; what remains is one
-// partial per workgroup row group (chunk / (4 RT), 3 for chunk = 200), added up - with the regulariser of the
+// partial per workgroup row group (chunk / (4 RT), 7 for chunk = 200), added up - with the regulariser of the
 // negative rows - by gn_reduce_kernel.  Deterministic (no atomics).
+// MI355X, per launch (profiles/r01_microbench_mi355x.txt): TransE_l1 cfg-T 40.0 -> 24.3 + 5.1 us (reduce),
+// RotatE (B 1024, N 256, 200 complex columns) 58.8 -> 27.9 + 5.4 us; arithmetic alone (no loads, no LDS) 13 / 10 us.
 // ---------------------------------------------------------------------------------------------
 #define LC_CW 32                                 // (complex) columns per wavefront: 16 lanes x 2
-#define LC_GQ 8                                  // quads of negatives per group (staging + LDS reduction round)
-#define LC_SG (4 * LC_GQ)                         // negatives per group
+#ifndef LC_GQ_CPLX
+#define LC_GQ_CPLX 4                             // quads of negatives per group (staging + LDS reduction round), RotatE
+#endif
+#define LC_GQ_REAL 8                             // ... TransE_l1; both sized so that TWO workgroups fit the LDS of a CU
 #define LC_RTMAX 20                              // most positive rows a wavefront keeps in registers (RotatE: 16)
 
 __device__ __forceinline__ float4 zero4b() { return make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -397,14 +401,15 @@ template <int L> __device__ __forceinline__ float rowb(float v) {    // lane L o
 }
 
 // workgroups per (chunk, slab) and rows per wavefront: at least as many workgroups as keep every wavefront at
-// <= LC_RTMAX rows; more (down to 8 rows per wavefront) while the launch still fits one workgroup per CU
+// <= LC_RTMAX rows; more (down to 8 rows per wavefront) while the launch still fits TWO workgroups per CU (the
+// kernel is bound by the instruction issue of its wavefronts: measured 31 -> 24 us for TransE_l1 at cfg-T)
 static inline void lc_shape(int model, int C, int chunk, int d_e, int &nslab, int &nrw, int &rpw) {
     const int K = model == KGE_ROTATE ? d_e / 2 : d_e;
     nslab = (K + LC_CW - 1) / LC_CW;
     const int rtmax = model == KGE_ROTATE ? 16 : LC_RTMAX;
     nrw = 1;
     while ((chunk + 4 * nrw - 1) / (4 * nrw) > rtmax) ++nrw;
-    while ((int64_t)C * nslab * (nrw + 1) <= 256 && (chunk + 4 * (nrw + 1) - 1) / (4 * (nrw + 1)) >= 8) ++nrw;
+    while ((int64_t)C * nslab * (nrw + 1) <= 512 && (chunk + 4 * (nrw + 1) - 1) / (4 * (nrw + 1)) >= 8) ++nrw;
     rpw = (chunk + 4 * nrw - 1) / (4 * nrw);
 }
 bool neg_bwd_lc_supported(int model, int d_e) {
@@ -421,6 +426,7 @@ template <int MODEL, int RT>
 __global__ __launch_bounds__(KGE_BLOCK) void neg_bwd_lc_kernel(NegArgs a, int nslab, int nrw, int rpw) {
     constexpr bool CPLX = MODEL == KGE_ROTATE;
     constexpr int NV = CPLX ? 4 : 2;                             // floats per lane in a GN partial
+    constexpr int LC_GQ = CPLX ? LC_GQ_CPLX : LC_GQ_REAL, LC_SG = 4 * LC_GQ;   // quads / negatives per group
     __shared__ __attribute__((aligned(16))) float red[2 * LC_GQ * KGE_WAVES_PER_BLOCK * 64 * NV];   // GN partials, two alternating buffers
     __shared__ __attribute__((aligned(16))) float stage[2 * LC_SG * LC_CW * (CPLX ? 2 : 1) + 2 * KGE_WAVES_PER_BLOCK * LC_SG * (RT > 16 ? 32 : 16)];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -458,32 +464,43 @@ __global__ __launch_bounds__(KGE_BLOCK) void neg_bwd_lc_kernel(NegArgs a, int ns
     float *ybuf = stage;                                         // [2][LC_SG][YF]
     float *wbuf = stage + 2 * LC_SG * YF;                        // [2][4 wavefronts][LC_SG][RTW]  (negative-major)
     const int tid = threadIdx.x;
-    const int ys = tid >> 3, yp4 = (tid & 7) * 4;                // y staging: negative ys, 4 columns from yp4
+    const int ys = tid >> 3, yp4 = (tid & 7) * 4;                // y staging: negative ys (< LC_SG), 4 columns from yp4
+    const bool ystg = ys < LC_SG;
     const int ycol = slab * LC_CW + yp4;
     const int ycolc = ycol < K ? ycol : 0;
-    const int wrow = lane >> 3, wp4 = (lane & 7) * 4;            // W staging: rows wrow (+8, ...), 4 negatives from wp4
-    float4 sy0, sy1 = zero4b(), sw[RTW / 8];
+    constexpr int NP = LC_SG / 4, RPP = 64 / NP, NPASS = RTW / RPP;   // W staging: float4 parts per row, rows per pass
+    const int wrow = lane / NP, wp4 = (lane % NP) * 4;           // rows wrow (+RPP, ...), 4 negatives from wp4
+    float4 sy0 = zero4b(), sy1 = zero4b(), sw[NPASS];
     auto gload = [&](int qb) {                                   // global -> registers (group starting at quad qb)
-        const int s = min(4 * qb + ys, N - 1);
-        const float *yp = a.nbase + ((int64_t)c * N + s) * D + ycolc;
-        sy0 = *reinterpret_cast<const float4 *>(yp);
-        if constexpr (CPLX) sy1 = *reinterpret_cast<const float4 *>(yp + K);
+        if (ystg) {
+            const int s = min(4 * qb + ys, N - 1);
+            const float *yp = a.nbase + ((int64_t)c * N + s) * D + ycolc;
+            sy0 = *reinterpret_cast<const float4 *>(yp);
+            if constexpr (CPLX) sy1 = *reinterpret_cast<const float4 *>(yp + K);
+        }
         const int s4 = min(4 * qb + wp4, N - 4);                 // N % 4 == 0: whole float4 or (masked later) a re-read
 #pragma unroll
-        for (int t = 0; t < RTW / 8; ++t)
-            sw[t] = *reinterpret_cast<const float4 *>(Wc + (int64_t)min(r0 + wrow + 8 * t, chunk - 1) * N + s4);
+        for (int t = 0; t < NPASS; ++t)
+            sw[t] = *reinterpret_cast<const float4 *>(Wc + (int64_t)min(r0 + wrow + RPP * t, chunk - 1) * N + s4);
     };
-    auto lstore = [&](int bf) {                                  // registers -> LDS buffer bf
-        float *yb = ybuf + (bf * LC_SG + ys) * YF;
-        *reinterpret_cast<float4 *>(yb + yp4) = sy0;
-        if constexpr (CPLX) *reinterpret_cast<float4 *>(yb + LC_CW + yp4) = sy1;
+    // registers -> LDS buffer bf.  W is zeroed HERE for rows outside this wavefront's block and negatives beyond
+    // N (the values arrived a whole group ago, the selects cost nothing): the arithmetic needs no masks at all.
+    auto lstore = [&](int bf, int qb) {
+        if (ystg) {
+            float *yb = ybuf + (bf * LC_SG + ys) * YF;
+            *reinterpret_cast<float4 *>(yb + yp4) = sy0;
+            if constexpr (CPLX) *reinterpret_cast<float4 *>(yb + LC_CW + yp4) = sy1;
+        }
         float *wb = wbuf + ((bf * KGE_WAVES_PER_BLOCK + wave) * LC_SG + wp4) * RTW + wrow;
+        const int s4 = 4 * qb + wp4;
+        const bool sval = qb < nq && s4 + 3 < N;                 // N % 4 == 0: a float4 of negatives is all in or all out
 #pragma unroll
-        for (int t = 0; t < RTW / 8; ++t) {
-            wb[8 * t] = sw[t].x; wb[RTW + 8 * t] = sw[t].y; wb[2 * RTW + 8 * t] = sw[t].z; wb[3 * RTW + 8 * t] = sw[t].w;
+        for (int t = 0; t < NPASS; ++t) {
+            const bool ok = sval && wrow + RPP * t < RT && r0 + wrow + RPP * t < rend;
+            wb[RPP * t] = ok ? sw[t].x : 0.f; wb[RTW + RPP * t] = ok ? sw[t].y : 0.f;
+            wb[2 * RTW + RPP * t] = ok ? sw[t].z : 0.f; wb[3 * RTW + RPP * t] = ok ? sw[t].w : 0.f;
         }
     };
-    const bool rok0 = r0 + kk < rend, rok1 = RT > 16 && kk < RT - 16 && r0 + 16 + kk < rend;
     // operands of one quad out of LDS buffer bf: y = b_s[cols] (s = quad g, lane row sg), raw W values
     auto lread = [&](int bf, int g, v2f &yr_, v2f &yi_, float &w0_, float &w1_) {
         const float *yb = ybuf + (bf * LC_SG + 4 * g + sg) * YF + 2 * kk;
@@ -494,10 +511,8 @@ __global__ __launch_bounds__(KGE_BLOCK) void neg_bwd_lc_kernel(NegArgs a, int ns
         w1_ = RT > 16 ? wb[16] : 0.f;
     };
     // one quad: RT rows of this wavefront against the 4 negatives of the quad; GN partial -> LDS
-    auto quad = [&](int q, int g, float *redb, const v2f &yr_, const v2f &yi_, float w0_, float w1_) {
+    auto quad = [&](int g, float *redb, const v2f &yr_, const v2f &yi_, float wa, float wb) {
         v2f nr = {0.f, 0.f}, ni = {0.f, 0.f};
-        const bool sok = q < nq && 4 * q + sg < N;
-        const float wa = (rok0 && sok) ? w0_ : 0.f, wb = (rok1 && sok) ? w1_ : 0.f;
         static_for<RT>([&](auto nc) {
             constexpr int n = decltype(nc)::value;
             const float w = n < 16 ? rowb<(n & 15)>(wa) : rowb<(n & 15)>(wb);
@@ -524,7 +539,11 @@ __global__ __launch_bounds__(KGE_BLOCK) void neg_bwd_lc_kernel(NegArgs a, int ns
         else *reinterpret_cast<v2f *>(slot) = nr;
     };
     gload(0);
-    lstore(0);
+    lstore(0, 0);
+    // every load of the prologue (x rows included) has landed before the loop: otherwise the compiler keeps
+    // "x may still be in flight" alive around the back edge and makes the first quad of every group wait for the
+    // previous group's partial-sum stores
+    __builtin_amdgcn_s_waitcnt(0x0F70);                          // vmcnt(0)
     __syncthreads();
     int buf = 0;
     for (int qb = 0; qb < nq; qb += LC_GQ) {
@@ -533,14 +552,16 @@ __global__ __launch_bounds__(KGE_BLOCK) void neg_bwd_lc_kernel(NegArgs a, int ns
         v2f ya, yia, yb_, yib;
         float wa0, wa1, wb0, wb1;
         lread(buf, 0, ya, yia, wa0, wa1);
+        // two quads per trip, LDS operands one quad ahead.  NOT unrolled further: with the whole group in one basic
+        // block the register allocation explodes (512 VGPRs + spills)
 #pragma unroll 1
-        for (int g = 0; g < LC_GQ; g += 2) {                     // two quads per trip: LDS operands one quad ahead
+        for (int g = 0; g < LC_GQ; g += 2) {
             lread(buf, g + 1, yb_, yib, wb0, wb1);
-            quad(qb + g, g, redb, ya, yia, wa0, wa1);
-            lread(buf, min(g + 2, LC_GQ - 1), ya, yia, wa0, wa1);
-            quad(qb + g + 1, g + 1, redb, yb_, yib, wb0, wb1);
+            quad(g, redb, ya, yia, wa0, wa1);
+            lread(buf, g + 2 < LC_GQ ? g + 2 : LC_GQ - 1, ya, yia, wa0, wa1);
+            quad(g + 1, redb, yb_, yib, wb0, wb1);
         }
-        lstore(buf ^ 1);
+        lstore(buf ^ 1, qb + LC_GQ);
         __syncthreads();
         // fixed-order sum over the 4 wavefronts: one partial per (workgroup row group, negative, column).  The
         // LDS buffers alternate, so the next group needs no second barrier.
