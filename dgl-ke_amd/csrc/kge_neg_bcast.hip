@@ -9,8 +9,9 @@
 // vector loads and broadcast inside the wavefront: the backward kernel lays them out "lane & 3 = element"
 // (one VGPR = four operands replicated in every quad of lanes, picked by a DPP quad_perm modifier that
 // is folded into the consuming VALU instruction or costs one v_mov_dpp), the forward kernel "lane =
-// element" (one VGPR = 64 operands, v_readlane_b32).  No LDS, no barriers, no scalar-cache latency,
-// prefetch one row / sub-slab ahead, branch-free main loops.
+// element" (one coalesced load = 64 operands, broadcast back out of wavefront-private LDS rows).  No
+// barriers, no scalar-cache latency, prefetch one row / sub-slab ahead, branch-free main loops.
+// The default backward is the shared-pair kernel further down (lane = column).
 // Measured alternatives on MI355X (profiles/r01_microbench_mi355x.txt): s_load_dwordx8 for the uniform
 // rows (SGPR double buffers spill; scalar loads can only be waited for with lgkmcnt(0)): 3x slower for
 // TransE_l1; "one VGPR = 64 operands" + v_readlane_b32 broadcasts: ~16 cycles per broadcast.
@@ -65,28 +66,20 @@ bool neg_bcast_supported(int model, int d_e) {
 typedef float v2f __attribute__((ext_vector_type(2)));   // two fp32 in an even-aligned VGPR pair: v_pk_add/mul/fma_f32
 
 template <int MODEL, int RW, int NE, int LB>
-__device__ __forceinline__ void fwd_step(const float (&xc)[16], const float (&yr)[RW], const float (&yi)[RW],
-                                         v2f (&acc)[RW], int lbr) {
+__device__ __forceinline__ void fwd_step(const float (&xc)[16], const float *ly, v2f (&acc)[RW], int lbr) {
     constexpr bool CPLX = MODEL == KGE_ROTATE;
-    // two reduction elements (e, e+1) per step in packed fp32 math: the uniform operands are read into an SGPR
-    // pair, the lane's own operands are adjacent VGPRs of the float4 loads, the accumulator is a pair as well
-    // (even / odd elements, summed at the end) - half the VALU issue slots of the scalar form
+    // two reduction elements (e, e+1) per step in packed fp32 math.  The uniform operands are read back from the
+    // wavefront's LDS rows with ONE address for all lanes (a broadcast read: ds_read_b64, no VALU slot, unlike the
+    // two v_readlane_b32 + hazard nops it replaces), the lane's own operands are adjacent VGPRs of the float4
+    // loads, the accumulator is a pair as well (even / odd elements, summed at the end)
     static_for<NE / 2>([&](auto ec) {
         constexpr int e = 2 * decltype(ec)::value;
 #pragma unroll
         for (int r = 0; r < RW; ++r) {
-            v2f y0, y1 = {0.f, 0.f};
-            if constexpr (LB >= 0) {
-                y0 = (v2f){bcast<(LB >= 0 ? LB : 0) + e>(yr[r]), bcast<(LB >= 0 ? LB : 0) + e + 1>(yr[r])};
-                if constexpr (CPLX)
-                    y1 = (v2f){bcast<(LB >= 0 ? LB : 0) + e>(yi[r]), bcast<(LB >= 0 ? LB : 0) + e + 1>(yi[r])};
-            } else {
-                y0 = (v2f){__int_as_float(__builtin_amdgcn_readlane(__float_as_int(yr[r]), lbr + e)),
-                           __int_as_float(__builtin_amdgcn_readlane(__float_as_int(yr[r]), lbr + e + 1))};
-                if constexpr (CPLX)
-                    y1 = (v2f){__int_as_float(__builtin_amdgcn_readlane(__float_as_int(yi[r]), lbr + e)),
-                               __int_as_float(__builtin_amdgcn_readlane(__float_as_int(yi[r]), lbr + e + 1))};
-            }
+            const float *yp = ly + r * 64 + (LB >= 0 ? LB : lbr) + e;
+            const v2f y0 = *reinterpret_cast<const v2f *>(yp);
+            v2f y1 = {0.f, 0.f};
+            if constexpr (CPLX) y1 = *reinterpret_cast<const v2f *>(yp + RW * 64);
             const v2f x0 = {xc[e], xc[e + 1]};
             if constexpr (CPLX) {
                 const v2f x1 = {xc[8 + e], xc[9 + e]};
@@ -114,12 +107,17 @@ __device__ __forceinline__ void fwd_step(const float (&xc)[16], const float (&yr
 // ---------------------------------------------------------------------------------------------
 // forward: lanes = negatives j (score rows are then written coalesced), uniform = pos-side rows a_i.
 // One task (= one wavefront) = (chunk, strip of 64 negatives, RW positives).  The uniform rows are
-// fetched "lane = element" - yr[r] = a_{i0+r}[64*t + lane], ONE VGPR = 64 operands - and broadcast with
-// v_readlane_b32 (measured: fewer, wider loads beat the quad layout of the backward kernel here, 14.8
-// vs 21.8 us for TransE_l1); inside a 64-element block, sub-slabs of 16 (real) / 8 complex elements of
-// the lane's own row are double-buffered in VGPRs.  The main loop has NO conditionals (loads inside
-// branches make the compiler wait for everything at the joins): prefetch addresses are clamped
+// fetched "lane = element" - yr[r] = a_{i0+r}[64*t + lane], ONE coalesced load = 64 operands - parked in the
+// wavefront's own LDS rows and read back with one address for all lanes (broadcast ds_read, 4 operands per
+// instruction); v_readlane_b32 broadcasts out of the register measured the same (13.4 vs 13.3 us TransE_l1,
+// 19.5 vs 19.4 us RotatE) at twice the issue slots.  Inside a 64-element block, sub-slabs of 16 (real) /
+// 8 complex elements of the lane's own row are double-buffered in VGPRs.  The main loop has NO conditionals
+// (loads inside branches make the compiler wait for everything at the joins): prefetch addresses are clamped
 // instead, and the partial last block runs in a separate tail loop.
+// PMC (TransE_l1, cfg-T, per wavefront): 2 659 VALU + 414 LDS + 176 VMEM instructions; 29 % of the wave
+// cycles issue VALU, 35 % wait on memory counters, 26 % wait for instruction issue.  The per-lane row loads
+// (64 cache lines per instruction) are the RotatE bound (probe with one line per instruction: 19.5 -> 12.2 us)
+// but not the TransE_l1 one (13.4 -> 13.0 us).
 // ---------------------------------------------------------------------------------------------
 template <int MODEL>
 __global__ __launch_bounds__(KGE_BLOCK) void neg_fwd_bcast_kernel(NegArgs a, int ns, int ng) {
@@ -168,24 +166,41 @@ __global__ __launch_bounds__(KGE_BLOCK) void neg_fwd_bcast_kernel(NegArgs a, int
             }
         }
     };
+    // the uniform rows of the current 64-element block, wavefront-private in LDS: [RW][64] (+ [RW][64] imaginary).
+    // Written "lane = element" straight from the coalesced loads, read back as broadcasts.  One wavefront's LDS
+    // instructions execute in order: no barrier between its writes and its reads.
+    __shared__ __attribute__((aligned(16))) float ylds[KGE_WAVES_PER_BLOCK][2 * RW * 64];
+    float *ly = ylds[wave];
+    auto puty = [&](const float (&yr_)[RW], const float (&yi_)[RW]) {
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            ly[r * 64 + lane] = yr_[r];
+            if constexpr (CPLX) ly[(RW + r) * 64 + lane] = yi_[r];
+        }
+    };
+    // the lane's own row: sub-slabs double-buffered in VGPRs, one ahead.  (A ring of four buffers requested three
+    // sub-slabs ahead was SLOWER, 13.3 -> 17.9 us for TransE_l1: these per-lane row loads touch 64 cache lines per
+    // instruction and more of them in flight only lengthen the queue in front of the texture addresser.)
     float yr[RW], yi[RW], ynr[RW], yni[RW], xa[16], xb[16];
     loady(yr, yi, 0);
     loadx(xa, 0);
     int kb = 0;
     for (; kb + 64 <= K; kb += 64) {                             // full blocks, branch-free
         loady(ynr, yni, kb + 64);                                // next block, one block ahead
+        puty(yr, yi);
         static_for<NSUB>([&](auto subc) {
             constexpr int SUB = decltype(subc)::value;
             float(&xc)[16] = (SUB & 1) ? xb : xa;
             float(&xn)[16] = (SUB & 1) ? xa : xb;
             loadx(xn, kb + (SUB + 1) * NE);                      // next sub-slab, one ahead
-            fwd_step<MODEL, RW, NE, SUB * NE>(xc, yr, yi, acc, 0);
+            fwd_step<MODEL, RW, NE, SUB * NE>(xc, ly, acc, 0);
         });
 #pragma unroll
         for (int r = 0; r < RW; ++r) { yr[r] = ynr[r]; yi[r] = yni[r]; }
     }
+    if (kb < K) puty(yr, yi);
     for (int k0 = kb; k0 < K; k0 += NE) {                        // partial last block (K % 64 elements)
-        fwd_step<MODEL, RW, NE, -1>(xa, yr, yi, acc, k0 - kb);
+        fwd_step<MODEL, RW, NE, -1>(xa, ly, acc, k0 - kb);
         loadx(xa, k0 + NE);
     }
     if (j < a.N) {
