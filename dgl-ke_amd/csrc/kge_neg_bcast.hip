@@ -29,6 +29,9 @@ using namespace kge;
 #ifndef SB_RWR
 #define SB_RWR 4                                 // forward, real models: uniform rows per wavefront
 #endif
+#ifndef SB_RWC
+#define SB_RWC 4                                 // forward, RotatE: uniform rows per wavefront (2: 19.4 us, 4: 16.4 us)
+#endif
 
 static inline int check_launch_b() { return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH; }
 
@@ -122,7 +125,7 @@ __device__ __forceinline__ void fwd_step(const float (&xc)[16], const float *ly,
 template <int MODEL>
 __global__ __launch_bounds__(KGE_BLOCK) void neg_fwd_bcast_kernel(NegArgs a, int ns, int ng) {
     constexpr bool CPLX = MODEL == KGE_ROTATE;
-    constexpr int RW = CPLX ? 2 : SB_RWR;                        // uniform rows per wavefront
+    constexpr int RW = CPLX ? SB_RWC : SB_RWR;                        // uniform rows per wavefront
     constexpr int NE = CPLX ? SB_KC : SB_KB;                     // (complex) elements per sub-slab
     constexpr int NSUB = 64 / NE;                                // sub-slabs per 64-element block
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void neg_fwd_bcast_kernel(NegArgs a, int
 }
 
 template <int MODEL> static int fwd_launch(const NegArgs &a, hipStream_t s) {
-    constexpr int RW = MODEL == KGE_ROTATE ? 2 : SB_RWR;
+    constexpr int RW = MODEL == KGE_ROTATE ? SB_RWC : SB_RWR;
     const int ns = (a.N + 63) / 64, ng = (a.chunk + RW - 1) / RW;
     const int64_t nb = ((int64_t)a.C * ns * ng + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK;
     if (nb == 0) return KGE_OK;
