@@ -102,7 +102,7 @@ def cpu_baseline(w, plans, budget_s=12.0, max_steps=200):
     if len(plans) < 32:          # device-sampler mode keeps only a few host plans: make a host sample
         from dglke_amd.dataloader import UniformChunkedSampler
         hh, rr, tt = synth_triples(w, 0)
-        plans = UniformChunkedSampler(hh, rr, tt, w["n_ent"], w["B"], w["N"], "cpu", seed=0).next_plans(max_steps + 6)
+        plans = UniformChunkedSampler(hh, rr, tt, w["n_ent"], w["B"], w["N"], "cpu", seed=0).next_plans(max_steps + 15)
     th = torch
     nthreads = th.get_num_threads()
     model = torch_port.TorchPort(w["model"], w["n_ent"], w["n_rel"], w["hidden"], w["gamma"], w["lr"],
@@ -111,7 +111,7 @@ def cpu_baseline(w, plans, budget_s=12.0, max_steps=200):
     for p in plans[:2]:
         model.step(p)
     # the intra-op thread count that is fastest on THIS host (all cores oversubscribe a step this
-    # small): probe a few counts on 3 steps each, then time the sample with the best one
+    # small): probe a few counts on 12 steps each, then time the sample with the best one
     tried = {}
     for nt in sorted({1, 4, 8, 16, 32, 64, nthreads}):
         if nt > nthreads:
@@ -119,14 +119,14 @@ def cpu_baseline(w, plans, budget_s=12.0, max_steps=200):
         th.set_num_threads(nt)
         model.step(plans[2])
         t0 = time.perf_counter()
-        for p in plans[3:6]:
+        for p in plans[3:15]:
             model.step(p)
-        tried[nt] = round(3 * w["B"] / (time.perf_counter() - t0), 1)
+        tried[nt] = round(12 * w["B"] / (time.perf_counter() - t0), 1)
     best = max(tried, key=tried.get)
     th.set_num_threads(best)
     t0 = time.perf_counter()
     n = 0
-    for p in plans[6:6 + max_steps]:
+    for p in plans[15:15 + max_steps]:
         model.step(p)
         n += 1
         if time.perf_counter() - t0 > budget_s:
