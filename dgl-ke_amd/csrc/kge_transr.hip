@@ -27,11 +27,15 @@ static inline int check_launch_t() { return hipGetLastError() == hipSuccess ? KG
 // one K sweep of a 64 x 64 tile: acc[ct][r] = C[wave*16 + 4*(lane/16) + r][ct*16 + lane%16].
 // loadA(row, k) / loadB(k, col) return the (zero-padded) operand elements; AKF / BKF say whether consecutive
 // threads should walk the reduction index (operand rows contiguous along k) or the tile row / column.
+// Software pipeline: the global loads of slab s+1 are issued BEFORE the MFMAs of slab s and land in the other LDS
+// buffer after them - one barrier per slab, load latency under the matrix work (the single-buffered version
+// exposed a full global-load round trip per 16-deep slab: 50 TFLOP/s).
 template <bool AKF, bool BKF, class LA, class LB>
-__device__ __forceinline__ void tile_sweep(f32x4 (&acc)[4], int Ktot, LA loadA, LB loadB, float (*As)[TR_LD], float (*Bs)[TR_LD]) {
+__device__ __forceinline__ void tile_sweep(f32x4 (&acc)[4], int Ktot, LA loadA, LB loadB, float (*As)[TR_K][TR_LD],
+                                           float (*Bs)[TR_K][TR_LD]) {
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63, m = lane & 15, q = lane >> 4;
-    for (int k0 = 0; k0 < Ktot; k0 += TR_K) {
-        float av[4], bv[4];
+    float av[4], bv[4];
+    auto gload = [&](int k0) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int lin = t + KGE_BLOCK * e;
@@ -40,21 +44,26 @@ __device__ __forceinline__ void tile_sweep(f32x4 (&acc)[4], int Ktot, LA loadA, 
             av[e] = loadA(ar, k0 + ak);
             bv[e] = loadB(k0 + bk, bc);
         }
-        __syncthreads();                       // previous slab fully consumed
+    };
+    if (Ktot > 0) gload(0);                    // (an empty reduction must not touch the operands at all)
+    int buf = 0;
+    __syncthreads();                           // the caller's previous sweep has left the LDS buffers
+    for (int k0 = 0; k0 < Ktot; k0 += TR_K, buf ^= 1) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int lin = t + KGE_BLOCK * e;
             const int ar = AKF ? lin >> 4 : lin & 63, ak = AKF ? lin & 15 : lin >> 6;
             const int bc = BKF ? lin >> 4 : lin & 63, bk = BKF ? lin & 15 : lin >> 6;
-            As[ak][ar] = av[e];
-            Bs[bk][bc] = bv[e];
+            As[buf][ak][ar] = av[e];
+            Bs[buf][bk][bc] = bv[e];
         }
         __syncthreads();
+        if (k0 + TR_K < Ktot) gload(k0 + TR_K);
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
-            const float a = As[4 * s4 + q][wave * 16 + m];
+            const float a = As[buf][4 * s4 + q][wave * 16 + m];
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) acc[ct] = MFMA16(a, Bs[4 * s4 + q][ct * 16 + m], acc[ct]);
+            for (int ct = 0; ct < 4; ++ct) acc[ct] = MFMA16(a, Bs[buf][4 * s4 + q][ct * 16 + m], acc[ct]);
         }
     }
 }
@@ -82,7 +91,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void transr_pos_kernel(TransRArgs a) {
 // forward: workgroup = (positive i, block of 64 negatives); loops the D_r column tiles
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(KGE_BLOCK) void transr_fwd_kernel(TransRArgs a, int nJB) {
-    __shared__ float As[TR_K][TR_LD], Bs[TR_K][TR_LD];
+    __shared__ float As[2][TR_K][TR_LD], Bs[2][TR_K][TR_LD];
     __shared__ int64_t rowoff[TR_T];
     const int i = blockIdx.x / nJB, j0 = (blockIdx.x % nJB) * TR_T;
     const int c = i / a.chunk, De = a.De, Dr = a.Dr, N = a.N;
@@ -173,7 +182,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void transr_dq_kernel(TransRArgs a) {
 // far too few workgroups; every group writes its own partial tile and transr_gn_reduce_kernel adds the groups
 // in a fixed order (deterministic, no atomics).
 __global__ __launch_bounds__(KGE_BLOCK) void transr_gn_kernel(TransRArgs a, int nJB, int nEB) {
-    __shared__ float As[TR_K][TR_LD], Bs[TR_K][TR_LD];
+    __shared__ float As[2][TR_K][TR_LD], Bs[2][TR_K][TR_LD];
     const int g = blockIdx.x % a.nG;
     const int blk = blockIdx.x / a.nG;
     const int eb = blk % nEB, jb = (blk / nEB) % nJB, c = blk / (nEB * nJB);
@@ -228,7 +237,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void transr_gn_reduce_kernel(TransRArgs 
 // GP_i[de][dr] = sum_j Neg_j[de] dY_ij[dr] + x_i[de] dq_i[dr]     workgroup = (positive, 64 de, 64 dr)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(KGE_BLOCK) void transr_gp_kernel(TransRArgs a, int nEB, int nRB) {
-    __shared__ float As[TR_K][TR_LD], Bs[TR_K][TR_LD];
+    __shared__ float As[2][TR_K][TR_LD], Bs[2][TR_K][TR_LD];
     const int rb = blockIdx.x % nRB, eb = (blockIdx.x / nRB) % nEB, i = blockIdx.x / (nRB * nEB);
     const int de0 = eb * TR_T, dr0 = rb * TR_T, De = a.De, Dr = a.Dr, N = a.N;
     const int c = i / a.chunk;
