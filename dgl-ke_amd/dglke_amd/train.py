@@ -133,6 +133,7 @@ class _Lane(object):
             self.sampler = UniformChunkedSampler(triples[0], triples[1], triples[2], n_ent, B, N, trainer.dev,
                                                  neg_chunk_size=chunk, seed=a.seed + 1000 * k, edge_importance=weights)
         self._graph = None
+        self._rem_graphs = {}
 
     def enqueue(self, n):
         """enqueue n steps on this lane's stream (no synchronisation)."""
@@ -167,10 +168,26 @@ class _Lane(object):
                     self._graph.replay()
                     smp.host_step += G
                     done += G
-            while done < n:                           # remainder: eager, any count
+            while done < n:                           # remainder (< G steps, or the parity of a full group is off)
                 k = min(smp.n_slots, n - done)
-                for b in smp.sample(k):
-                    eng.step(b)
+                key = (k, smp.host_step % 2)          # neg_head of slot j is baked into the graph: same parity only
+                g = self._rem_graphs.get(key)
+                if g is None and self._graph is not None and len(self._rem_graphs) < 8:
+                    # the log / eval marks repeat: record [1 sampler launch + k steps] once instead of paying
+                    # ~6 eager launches per step every time (56 -> 44 us/step at log_interval 1000, eval 500)
+                    self.stream.synchronize()
+                    g = th.cuda.CUDAGraph()
+                    with th.cuda.graph(g, stream=self.stream if t.n_lanes > 1 else None):
+                        for b in smp.sample(k):
+                            eng.step(b)
+                    smp.host_step -= k                # the capture itself did not run the steps
+                    self._rem_graphs[key] = g
+                if g is not None:
+                    g.replay()
+                    smp.host_step += k
+                else:
+                    for b in smp.sample(k):
+                        eng.step(b)
                 done += k
 
 
