@@ -394,8 +394,9 @@ def adagrad_update(table, state, idx, grad, lr, eps=1e-10):
 class Config(object):
     def __init__(self, model, gamma, hidden, lr, adv=False, adv_temp=1.0, reg_coef=0.0,
                  reg_norm=3, loss_genre="Logsigmoid", pairwise=False, margin=1.0,
-                 double_ent=False, double_rel=False):
+                 double_ent=False, double_rel=False, neg_deg=False):
         self.model = _canon(model)
+        self.neg_deg = bool(neg_deg)                  # --neg_deg_sample (general_models.py:396-402, 424-432)
         self.gamma = gamma
         self.hidden = hidden
         self.emb_init = (gamma + 2.0) / hidden        # general_models.py:217-218, EMB_INIT_EPS=2
@@ -423,7 +424,20 @@ def forward_backward(cfg, ent, rel, nid, h_local, t_local, rel_ids, neg_ids, neg
     p = score_pos(cfg.model, h, r, t, gamma, cfg.emb_init)
     x = t if neg_head else h
     a = pos_side(cfg.model, neg_head, x, r, cfg.emb_init)
-    n = score_neg(cfg.model, a, neg, C, chunk, N, gamma)
+    nd = getattr(cfg, "neg_deg", False)
+    if nd:
+        # neg_deg_sample: the corrupted-side entities of the chunk's OWN positives are prepended to the chunk's
+        # negatives (general_models.py:396-400 heads, :424-427 tails); the chunk x chunk diagonal - the positive
+        # edge itself - is multiplied by 0 (mask[:, 0::(N'+1)] = 0, :401, :429-432): its SCORE becomes 0 and stays
+        # in the loss, its gradient vanishes.  These rows come out of pos_g.ndata['emb'] (no new trace): their
+        # gradients join the positive trace.
+        y = (h if neg_head else t).reshape(C, chunk, -1)
+        Np = chunk + N
+        neg_all = np.concatenate([y, neg.reshape(C, N, -1)], axis=1).reshape(C * Np, -1)
+        mask = np.ones((C, chunk, Np), dtype=dt)
+        mask[:, np.arange(chunk), np.arange(chunk)] = 0
+        n = score_neg(cfg.model, a, neg_all, C, chunk, Np, gamma) * mask
+        N_sampled, N = N, Np
     (pl, nl, loss), dpos, dneg = loss_fwd_bwd(p, n.reshape(B, N), w, cfg.loss_genre, cfg.adv,
                                               cfg.adv_temp, cfg.pairwise, cfg.margin)
     reg = 0.0
@@ -432,13 +446,23 @@ def forward_backward(cfg, ent, rel, nid, h_local, t_local, rel_ids, neg_ids, neg
         reg = reg_value([pos_emb, neg], cfg.reg_coef, cfg.reg_norm) + \
             reg_value([r], cfg.reg_coef, cfg.reg_norm)
     gh, gr, gt = score_pos_bwd(cfg.model, h, r, t, dpos, gamma, cfg.emb_init)
-    ga, g_neg = score_neg_bwd(cfg.model, a, neg, dneg.reshape(C, chunk, N), C, chunk, N, gamma)
+    if nd:
+        ga, g_all = score_neg_bwd(cfg.model, a, neg_all, dneg.reshape(C, chunk, N) * mask, C, chunk, N, gamma)
+        g_all = g_all.reshape(C, N, -1)
+        g_inb = g_all[:, :chunk].reshape(B, -1)          # gradient w.r.t. the in-batch negative rows
+        g_neg = g_all[:, chunk:].reshape(C * N_sampled, -1)
+    else:
+        ga, g_neg = score_neg_bwd(cfg.model, a, neg, dneg.reshape(C, chunk, N), C, chunk, N, gamma)
     gx, gr2 = pos_side_bwd(cfg.model, neg_head, x, r, ga, cfg.emb_init)
     gr = gr + gr2
     if neg_head:
         gt = gt + gx
+        if nd:
+            gh = gh + g_inb
     else:
         gh = gh + gx
+        if nd:
+            gt = gt + g_inb
     g_pos = np.zeros_like(pos_emb)
     np.add.at(g_pos, h_local, gh.astype(dt))
     np.add.at(g_pos, t_local, gt.astype(dt))

@@ -133,7 +133,7 @@ def make_args(case):
     a.strict_rel_part = False
     a.soft_rel_part = False
     a.lr = case["lr"]
-    a.neg_deg_sample = False
+    a.neg_deg_sample = bool(case.get("neg_deg", False))      # general_models.py:396-402, 424-432
     a.neg_deg_sample_eval = False
     a.eval_filter = False
     a.regularization_coef = case["reg_coef"]
@@ -196,7 +196,11 @@ def run_case(name, case):
         out[p + "pos_score"] = pos_g.edata["score"].detach().numpy().copy()
         # neg score recomputed without trace for recording (same tensors, no side effect)
         with th.no_grad():
-            ns = model.predict_neg_score(pos_g, neg_g, trace=False)
+            if case.get("neg_deg", False):    # predict_neg_score mutates neg_g.neg_sample_size in this mode: fresh object
+                ng2 = NegG(th.from_numpy(b["neg"]), b["C"], case["chunk"], case["N"], b["neg_head"])
+                ns = model.predict_neg_score(pos_g, ng2, trace=False, neg_deg_sample=True)
+            else:
+                ns = model.predict_neg_score(pos_g, neg_g, trace=False)
         out[p + "neg_score"] = ns.detach().numpy().copy()
         out[p + "log"] = np.array([log.get("pos_loss", np.nan), log.get("neg_loss", np.nan),
                                    log["loss"], log.get("regularization", 0.0)], dtype=np.float64)
@@ -304,6 +308,26 @@ CASES = {
                                      pairwise=True, seed=31),
     "distmult_logistic_pairwise": base("DistMult", loss_genre="Logistic", adv=False,
                                        pairwise=True, seed=32),
+    # --neg_deg_sample (general_models.py:396-402, 424-432): the chunk's own positives join the negatives, the
+    # diagonal is masked to score 0; their gradients land in the POSITIVE trace
+    "nd_transe_l2_small": base("TransE_l2", neg_deg=True, seed=71),
+    "nd_transe_l1_small": base("TransE_l1", neg_deg=True, seed=72),
+    "nd_distmult_small": base("DistMult", gamma=6.0, lr=0.08, neg_deg=True, seed=73),
+    "nd_complex_small": base("ComplEx", gamma=6.0, de=True, dr=True, neg_deg=True, seed=74),
+    "nd_rotate_small": base("RotatE", gamma=12.0, de=True, neg_deg=True, seed=75),
+    "nd_simple_small": base("SimplE", gamma=6.0, de=True, dr=True, neg_deg=True, seed=76),
+    "nd_transe_l2_dups": base("TransE_l2", n_ent=9, n_rel=2, steps=4, neg_deg=True, seed=77),
+    "nd_rotate_ragged": base("RotatE", hidden=10, de=True, B=30, N=7, chunk=10, neg_deg=True, seed=78),
+    "nd_distmult_noadv": base("DistMult", adv=False, reg_coef=0.0, neg_deg=True, seed=79),
+    "nd_transe_l2_mid": base("TransE_l2", n_ent=400, n_rel=30, hidden=64, gamma=19.9, B=96, N=32,
+                             chunk=32, lr=0.25, reg_coef=1e-9, steps=2, neg_deg=True, seed=80,
+                             save_tables_each_step=False),
+    "nd_rotate_mid": base("RotatE", n_ent=400, n_rel=30, hidden=32, gamma=12.0, de=True,
+                          B=96, N=32, chunk=32, lr=0.01, reg_coef=1e-7, steps=2, neg_deg=True, seed=81,
+                          save_tables_each_step=False),
+    "nd_transe_l1_mid": base("TransE_l1", n_ent=400, n_rel=30, hidden=64, gamma=16.0, B=96, N=32,
+                             chunk=32, lr=0.01, reg_coef=1e-7, steps=2, neg_deg=True, seed=82,
+                             save_tables_each_step=False),
 }
 
 

@@ -35,4 +35,4 @@ def oracle_config(case):
                     adv_temp=case["adv_temp"], reg_coef=case["reg_coef"],
                     reg_norm=case["reg_norm"], loss_genre=case.get("loss_genre", "Logsigmoid"),
                     pairwise=case.get("pairwise", False), margin=case.get("margin", 1.0),
-                    double_ent=case["de"], double_rel=case["dr"])
+                    double_ent=case["de"], double_rel=case["dr"], neg_deg=case.get("neg_deg", False))
