@@ -224,6 +224,14 @@ int kge_score_neg_fwd(int model, int neg_head, const float *pos_side, const floa
     return KGE_OK;
 }
 
+// neg_deg_sample: ids of the rows scored as negatives, per chunk [the chunk's own corrupted-side entities | sampled ids]
+__global__ void nd_ids_kernel(const int64_t *own, const int64_t *sampled, int chunk, int Ns, int total, int64_t *out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= total) return;
+    const int Np = chunk + Ns, c = j / Np, jj = j % Np;
+    out[j] = jj < chunk ? own[(int64_t)c * chunk + jj] : sampled[(int64_t)c * Ns + jj - chunk];
+}
+
 int kge_score_neg_bwd(int model, int neg_head, const float *pos_side, const float *rel,
                       const float *neg, const float *neg_score, const float *dneg, int C,
                       int chunk, int N, int d_e, int d_r, float gamma, float emb_init,
@@ -361,6 +369,8 @@ int kge_adagrad_apply_rows(float *table, float *state_sum, int64_t n_rows, int d
 // fused step
 // ------------------------------------------------------------------------------------------
 size_t kge_step_workspace_bytes(const kge_hparams *hp, int B, int C, int chunk, int N, int UE, int UR) {
+    const bool nd = (hp->flags & KGE_FLAG_NEG_DEG_SAMPLE) != 0;
+    if (nd) N += chunk;                                   // neg_deg_sample: the chunk's own positives join its negatives
     const size_t d_e = hp->d_e, d_r = hp->d_r, CN = (size_t)C * N, tj16 = (N + 15) / 16;
     size_t n = 0;
     auto add = [&](size_t floats) { n += align_up(floats * sizeof(float)); };
@@ -390,6 +400,7 @@ size_t kge_step_workspace_bytes(const kge_hparams *hp, int B, int C, int chunk, 
     add(B); add(B); add(UE); add(UR);           // row_pos, row_neg, reg_ent, reg_rel
     if (neg_bwd_lc_supported(hp->model, hp->d_e))   // TransE_l1 / RotatE: GN partials of the shared-pair backward
         add(neg_bwd_lc_partial_floats(hp->model, C, chunk, N, hp->d_e));
+    if (nd) add(2 * CN);                                  // combined id list (int64)
     return n;
 }
 
@@ -421,17 +432,22 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         !b->ur_rec)
         return fail(KGE_ERR_ARG, "kge_step: null table / batch pointer");
     hipStream_t s = (hipStream_t)stream;
-    const int B = b->B, C = b->C, chunk = b->chunk, N = b->N, CN = C * N;
+    // neg_deg_sample: the scoring / loss / gradient kernels see N = chunk + (sampled negatives) rows per chunk; the
+    // plan of the batch keeps indexing the sampled ones (b->N)
+    const bool nd = (hp->flags & KGE_FLAG_NEG_DEG_SAMPLE) != 0;
+    if (nd && (hp->model == KGE_RESCAL || hp->model == KGE_TRANSR || emit))
+        return fail(KGE_ERR_ARG, "neg_deg_sample is not available for RESCAL / TransR and in the gradient-emitting step");
+    const int B = b->B, C = b->C, chunk = b->chunk, N = nd ? b->chunk + b->N : b->N, CN = C * N;
     const int d_e = hp->d_e, d_r = hp->d_r, tj16 = (N + 15) / 16;
     const bool reg = hp->reg_coef > 0.f && hp->reg_norm > 0;
     const bool pairwise = hp->pairwise != 0;
     // which kernels run
     const bool gemm = use_mfma(hp->model, d_e, N, hp->flags);       // matrix-core negative scoring
-    const bool fused_loss = gemm && !pairwise && (hp->flags & KGE_FLAG_FUSED_LOSS) && hp->model != KGE_SIMPLE;   // loss gradient inside the bwd GEMM
+    const bool fused_loss = gemm && !pairwise && !nd && (hp->flags & KGE_FLAG_FUSED_LOSS) && hp->model != KGE_SIMPLE;   // loss gradient inside the bwd GEMM
     const bool is_l2 = hp->model == KGE_TRANSE_L2;
     const bool transe = hp->model == KGE_TRANSE_L1 || is_l2;
     const int dmax = d_e > d_r ? d_e : d_r;
-    const bool transe_fast = transe && !pairwise && d_e % 4 == 0 && d_r % 4 == 0 && dmax <= 1024 &&
+    const bool transe_fast = transe && !pairwise && !nd && d_e % 4 == 0 && d_r % 4 == 0 && dmax <= 1024 &&
                              !(hp->flags & KGE_FLAG_NO_TRANSE_FAST);
 
     Carver cv(ws, ws_bytes);
@@ -466,9 +482,10 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     float *row_pos = cv.f(B), *row_neg = cv.f(B), *reg_ent = cv.f(b->UE), *reg_rel = cv.f(b->UR);
     float *GNp = (neg_bwd_lc_supported(hp->model, d_e) && !(hp->flags & KGE_FLAG_TWO_PASS_PAIR))
                      ? cv.f(neg_bwd_lc_partial_floats(hp->model, C, chunk, N, d_e)) : nullptr;
+    int64_t *nd_ids = nd ? reinterpret_cast<int64_t *>(cv.f(2 * (size_t)CN)) : nullptr;
     if (!cv.ok())
         return fail(KGE_ERR_WORKSPACE, "kge_step: workspace too small (%zu < %zu)", ws_bytes,
-                    kge_step_workspace_bytes(hp, B, C, chunk, N, b->UE, b->UR));
+                    kge_step_workspace_bytes(hp, B, C, chunk, b->N, b->UE, b->UR));
     float *Pg = GH;                                   // TransE fast path: P rows reuse the GH buffer
     if (out && out->pos_score) P = out->pos_score;
     if (out && out->g_neg) GN = out->g_neg;
@@ -478,6 +495,13 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     const LossParams lp{hp->loss_genre, hp->adv, hp->pairwise, hp->adv_temp, hp->margin};
 
     const EdgeSrc src{tb->ent, b->h_gid, tb->ent, b->t_gid, tb->rel, b->rel_ids, em, rm};
+    const int64_t *nids = b->neg_ids;                 // ids of the rows the scoring kernels treat as negatives
+    if (nd) {
+        hipLaunchKernelGGL(nd_ids_kernel, dim3((unsigned)((CN + 255) / 256)), dim3(256), 0, s,
+                           b->neg_head ? b->h_gid : b->t_gid, b->neg_ids, chunk, b->N, CN, nd_ids);
+        if (hipGetLastError() != hipSuccess) return fail(KGE_ERR_LAUNCH, "nd_ids_kernel launch failed");
+        nids = nd_ids;
+    }
     if (transr) {
         tr.B = B; tr.C = C; tr.chunk = chunk; tr.N = N; tr.De = d_e; tr.Dr = d_r; tr.neg_head = b->neg_head;
         tr.UR = b->UR; tr.reg_norm = hp->reg_norm; tr.gamma = hp->gamma; tr.lr = hp->lr; tr.eps = hp->eps;
@@ -494,7 +518,7 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     ef.src = src; ef.B = B; ef.d_e = d_e; ef.d_r = d_r; ef.neg_head = b->neg_head; ef.model = hp->model;
     ef.gamma = hp->gamma; ef.rot_div = rot_div;
     ef.pos_score = P; ef.A = A;
-    ef.nbase = tb->ent; ef.nidx = b->neg_ids; ef.n_neg = CN;
+    ef.nbase = tb->ent; ef.nidx = nids; ef.n_neg = CN;
     // sharded tables: the scoring kernels re-read the negative rows many times - they must come from
     // the dense local copy edge_fwd makes, never from the (remote, uncached) table rows
     const bool dense_neg = !gemm || sh || (hp->flags & KGE_FLAG_DENSE_NEG);
@@ -524,7 +548,7 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         KGE_TRY(launch_rescal_matvec(m, s));
         if (dense_neg) {                 // pairwise fallback kernels read a dense copy of the negative rows
             EdgeFwdArgs nb{};
-            nb.B = 0; nb.d_e = d_e; nb.d_r = d_e; nb.model = KGE_DISTMULT; nb.nbase = tb->ent; nb.nidx = b->neg_ids;
+            nb.B = 0; nb.d_e = d_e; nb.d_r = d_e; nb.model = KGE_DISTMULT; nb.nbase = tb->ent; nb.nidx = nids;
             nb.n_neg = CN; nb.Bn = Bn;
             KGE_TRY(launch_edge_fwd(nb, s));
         }
@@ -538,7 +562,7 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         // scores already in S
     } else if (gemm) {
         if (dense_neg) fill_gemm(g, hp->model, C, chunk, N, d_e, hp->gamma, A, Bn, nullptr);
-        else fill_gemm(g, hp->model, C, chunk, N, d_e, hp->gamma, A, tb->ent, b->neg_ids);
+        else fill_gemm(g, hp->model, C, chunk, N, d_e, hp->gamma, A, tb->ent, nids);
         g.S = S; g.adv_temp = hp->adv_temp; g.asq = asq; g.bsq = bsq;
         if (fused_loss && hp->adv) { g.PM = PM; g.PS = PS; }
         KGE_TRY(launch_neg_fwd_gemm(g, s));
@@ -559,6 +583,7 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         la.l2_scale = is_l2 ? 1 : 0; la.gamma = hp->gamma; la.clampv = clamp_of(hp->model);
         la.neg_copy = out ? out->neg_score : nullptr;
         la.skip_pos = (pairwise || rescal || transr) ? 0 : 1;  // RESCAL / TransR: no edge_fwd -> positive part here
+        la.diag_chunk = nd ? chunk : 0;
         KGE_TRY(launch_loss(la, s));
     }
 
@@ -569,7 +594,7 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         g.PM = PM; g.PS = PS;
         g.W = fused_loss ? nullptr : S; g.Sc = S; g.pos = P; g.w = b->edge_w; g.lp = lp;
         g.GA = GA; g.GN = GN;
-        g.reg_coef = reg ? hp->reg_coef : 0.f; g.reg_norm = hp->reg_norm;
+        g.reg_coef = (reg && !nd) ? hp->reg_coef : 0.f; g.reg_norm = hp->reg_norm;   // nd: the update adds it (sampled rows only)
         g.row_neg = (fused_loss && want4) ? row_neg : nullptr;
         g.acc = fused_loss ? acc : nullptr;
         KGE_TRY(launch_neg_bwd_gemm(g, s));
@@ -578,7 +603,7 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
             return fail(KGE_ERR_LAUNCH, "hipMemcpyAsync failed");
     } else {
         na.W = S; na.GA = GA; na.GN = GN;
-        na.reg_coef = reg ? hp->reg_coef : 0.f; na.reg_norm = hp->reg_norm;
+        na.reg_coef = (reg && !nd) ? hp->reg_coef : 0.f; na.reg_norm = hp->reg_norm;
         na.GNp = gemm ? nullptr : GNp;
         KGE_TRY(launch_neg_bwd_pair(na, s));
     }
@@ -629,6 +654,7 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         eb.gamma = hp->gamma; eb.rot_div = rot_div;
         eb.dpos = dP; eb.GA = GA; eb.reg_coef = reg ? hp->reg_coef : 0.f; eb.reg_norm = hp->reg_norm;
         eb.GH = GH; eb.GT = GT; eb.GR = GR;
+        if (nd) { eb.GNd = GN; eb.nd_chunk = chunk; eb.nd_Np = N; }   // in-batch negative rows -> positive trace
         KGE_TRY(launch_edge_bwd(eb, s));
     }
 
@@ -658,6 +684,7 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     ua.reg_ent = want4 ? reg_ent : nullptr; ua.reg_rel = want4 ? reg_rel : nullptr;
     ua.acc = acc;
     ua.ld_e = d_e; ua.ld_r = d_r; ua.ld_gs_e = 1; ua.ld_gs_r = 1;
+    if (nd) { ua.nd_chunk = chunk; ua.nd_Ns = b->N; ua.nd_Np = N; }
     if (emit) {
         ua.g0 = emit->g0; ua.gs0 = emit->gs0; ua.g1 = emit->g1; ua.gs1 = emit->gs1;
         ua.gr = emit->gr; ua.gsr = emit->gsr; ua.rid = emit->rid;

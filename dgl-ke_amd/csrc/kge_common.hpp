@@ -195,6 +195,9 @@ struct EdgeBwdArgs {
                                      // the raw score and drop it where saturated (the fused step masks in edge_fwd)
     float *GH, *GT;                  // [B,d_e] (either may be null)
     float *GR;                       // [B,d_r] or null
+    // neg_deg_sample: gradient of the in-batch negative row of edge i, GNd[((i / nd_chunk) * nd_Np + i % nd_chunk) * d_e],
+    // is added to the corrupted side's gradient (positive trace of that entity); null = off
+    const float *GNd; int nd_chunk, nd_Np;
 };
 
 struct NegArgs {                     // chunked negative scoring, forward and backward
@@ -226,6 +229,7 @@ struct LossArgs {
     float clampv;                    // > 0: scores were clamped to [-clampv, clampv] (SimplE): no gradient where saturated
     float *neg_copy;                 // optional copy of the scores before overwrite
     int skip_pos;                    // the positive-loss part was already done by edge_fwd
+    int diag_chunk;                  // > 0 (neg_deg_sample): column i % diag_chunk of row i is masked - score 0, no gradient
 };
 
 struct UpdateArgs {
@@ -251,7 +255,13 @@ struct UpdateArgs {
     int32_t *rid;                    // optional relation-id words inside the relation message
     int ld_gs_e, ld_gs_r;            // strides of gs0/gs1 and gsr
     int dry;                         // tuning probe: read everything, write nothing
+    // neg_deg_sample (nd_chunk > 0): GN has nd_Np = nd_chunk + nd_Ns rows per chunk, plan slot k (sampled negative)
+    // is row (k / nd_Ns) * nd_Np + nd_chunk + k % nd_Ns, and the regulariser of the negative rows is added here
+    int nd_chunk, nd_Ns, nd_Np;
 };
+__device__ __forceinline__ int64_t gn_row(const UpdateArgs &a, int slot) {
+    return a.nd_chunk ? (int64_t)(slot / a.nd_Ns) * a.nd_Np + a.nd_chunk + slot % a.nd_Ns : (int64_t)slot;
+}
 
 struct FinalizeArgs {
     int B, UE, UR, pairwise;

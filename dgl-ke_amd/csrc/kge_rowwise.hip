@@ -293,6 +293,8 @@ __global__ __launch_bounds__(KGE_BLOCK) void edge_bwd_kernel(EdgeBwdArgs a_in) {
     float *GT = a.GT ? a.GT + i * (int64_t)a.d_e : nullptr;
     float *GR = a.GR ? a.GR + i * (int64_t)a.d_r : nullptr;
     const bool reg = a.reg_coef > 0.f && a.reg_norm > 0;
+    // neg_deg_sample: the in-batch negative row of this edge feeds the corrupted side (general_models.py:396-402)
+    const float *gnd = a.GNd ? a.GNd + ((i / a.nd_chunk) * a.nd_Np + i % a.nd_chunk) * (int64_t)a.d_e : nullptr;
 
     if constexpr (!is_complex_model(MODEL)) {
         const int nit = a.d_e / V;
@@ -333,6 +335,11 @@ __global__ __launch_bounds__(KGE_BLOCK) void edge_bwd_kernel(EdgeBwdArgs a_in) {
                 }
                 if (reg) o_r += reg_grad(rr, a.reg_coef, a.reg_norm);
                 gh.v[e] = o_h; gt.v[e] = o_t; gr.v[e] = o_r;
+            }
+            if (gnd) {
+                const Pack<V> gv = ld<V>(gnd + off);
+#pragma unroll
+                for (int e = 0; e < V; ++e) { if (a.neg_head) gh.v[e] += gv.v[e]; else gt.v[e] += gv.v[e]; }
             }
             if (GH) st<V>(GH + off, gh);
             if (GT) st<V>(GT + off, gt);
@@ -450,6 +457,14 @@ __global__ __launch_bounds__(KGE_BLOCK) void edge_bwd_kernel(EdgeBwdArgs a_in) {
                 }
                 if (GR) st<V>(GR + off, o_r);
             }
+            if (gnd) {
+                const Pack<V> gv0 = ld<V>(gnd + off), gv1 = ld<V>(gnd + hd + off);
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    if (a.neg_head) { o_rh.v[e] += gv0.v[e]; o_ih.v[e] += gv1.v[e]; }
+                    else { o_rt.v[e] += gv0.v[e]; o_it.v[e] += gv1.v[e]; }
+                }
+            }
             if (GH) { st<V>(GH + off, o_rh); st<V>(GH + hd + off, o_ih); }
             if (GT) { st<V>(GT + off, o_rt); st<V>(GT + hd + off, o_it); }
         }
@@ -498,11 +513,13 @@ __global__ __launch_bounds__(KGE_BLOCK) void loss_kernel(LossArgs a) {
     const float w = a.w ? a.w[i] : 1.f;
     const float p = a.pos[i];
     const float invB = 1.f / (float)a.B;
+    // neg_deg_sample: the positive edge itself sits in column i % chunk - score 0, no gradient (general_models.py:401, 429-432)
+    const int jd = a.diag_chunk > 0 ? (int)(i % a.diag_chunk) : -1;
     if (a.pairwise) {   // loss.py:76-80
         const float sc = w / ((float)a.B * (float)N);
         float lsum = 0.f, dsum = 0.f;
         for (int j = lane; j < N; j += 64) {
-            const float nv = n[j];
+            const float nv = j == jd ? 0.f : n[j];
             float val, dv;
             criterion(a.genre, p - nv, 1.f, a.margin, val, dv);
             lsum += val * sc;
@@ -512,7 +529,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void loss_kernel(LossArgs a) {
             float g = -dd;
             if (a.l2_scale) { const float d = a.gamma - nv; g = d > 1e-15f ? g / d : 0.f; }
             if (a.clampv > 0.f && fabsf(nv) >= a.clampv) g = 0.f;
-            dn[j] = g;
+            dn[j] = j == jd ? 0.f : g;
         }
         lsum = wave_sum(lsum);
         dsum = wave_sum(dsum);
@@ -534,16 +551,16 @@ __global__ __launch_bounds__(KGE_BLOCK) void loss_kernel(LossArgs a) {
     const float neg_label = a.genre == KGE_LOSS_BCE ? 0.f : -1.f;
     float mx = -INFINITY, Z = 1.f;
     if (a.adv) {   // softmax(neg * T) over the row, detached (loss.py:87-88)
-        for (int j = lane; j < N; j += 64) mx = fmaxf(mx, n[j] * a.adv_temp);
+        for (int j = lane; j < N; j += 64) mx = fmaxf(mx, (j == jd ? 0.f : n[j]) * a.adv_temp);
         mx = wave_max(mx);
         float z = 0.f;
-        for (int j = lane; j < N; j += 64) z += expf(n[j] * a.adv_temp - mx);
+        for (int j = lane; j < N; j += 64) z += expf((j == jd ? 0.f : n[j]) * a.adv_temp - mx);
         Z = wave_sum(z);
     }
     const float invZ = 1.f / Z, invN = 1.f / (float)N;
     float acc = 0.f;
     for (int j = lane; j < N; j += 64) {
-        const float nv = n[j];
+        const float nv = j == jd ? 0.f : n[j];
         float nl, dnl;
         criterion(a.genre, nv, neg_label, a.margin, nl, dnl);
         const float A = a.adv ? expf(nv * a.adv_temp - mx) * invZ : invN;
@@ -552,7 +569,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void loss_kernel(LossArgs a) {
         if (cp) cp[j] = nv;
         if (a.l2_scale) { const float d = a.gamma - nv; g = d > 1e-15f ? g / d : 0.f; }
         if (a.clampv > 0.f && fabsf(nv) >= a.clampv) g = 0.f;
-        dn[j] = g;
+        dn[j] = j == jd ? 0.f : g;
     }
     acc = wave_sum(acc) * invB;
     if (lane == 0) {
@@ -576,7 +593,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void loss_kernel_reg(LossArgs a_in) {
     LossArgs a = a_in;
     if constexpr (LEAN) {
         a.genre = KGE_LOSS_LOGSIGMOID; a.pairwise = 0; a.skip_pos = 1; a.clampv = 0.f; a.neg_copy = nullptr;
-        a.row_pos = nullptr; a.row_neg = nullptr;
+        a.row_pos = nullptr; a.row_neg = nullptr; a.diag_chunk = 0;
     }
     const int64_t i = WAVE_ID();
     if (i >= a.B) return;
@@ -586,8 +603,10 @@ __global__ __launch_bounds__(KGE_BLOCK) void loss_kernel_reg(LossArgs a_in) {
     float *dn = a.dneg + i * (int64_t)N;
     float *cp = a.neg_copy ? a.neg_copy + i * (int64_t)N : nullptr;
     float nv[NPER];
+    // neg_deg_sample: the positive edge itself sits in column i % chunk - score 0, no gradient
+    const int jd = a.diag_chunk > 0 ? (int)(i % a.diag_chunk) : -1;
 #pragma unroll
-    for (int u = 0; u < NPER; ++u) { const int j = lane + 64 * u; nv[u] = j < N ? n[j] : 0.f; }
+    for (int u = 0; u < NPER; ++u) { const int j = lane + 64 * u; nv[u] = (j < N && j != jd) ? n[j] : 0.f; }
     const float w = a.w ? a.w[i] : 1.f;
     const float p = a.pos[i];
     const float invB = 1.f / (float)a.B;
@@ -608,7 +627,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void loss_kernel_reg(LossArgs a_in) {
                 float g = -dd;
                 if (a.l2_scale) { const float d = a.gamma - nv[u]; g = d > 1e-15f ? g / d : 0.f; }
                 if (a.clampv > 0.f && fabsf(nv[u]) >= a.clampv) g = 0.f;
-                dn[j] = g;
+                dn[j] = j == jd ? 0.f : g;
             }
         }
         lsum = wave_sum(lsum);
@@ -657,7 +676,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void loss_kernel_reg(LossArgs a_in) {
             if (cp) cp[j] = nv[u];
             if (a.l2_scale) { const float d = a.gamma - nv[u]; g = d > 1e-15f ? g / d : 0.f; }
             if (a.clampv > 0.f && fabsf(nv[u]) >= a.clampv) g = 0.f;
-            dn[j] = g;
+            dn[j] = j == jd ? 0.f : g;
         }
     }
     acc = wave_sum(acc) * invB;
@@ -676,7 +695,7 @@ int launch_loss(const LossArgs &a, hipStream_t s) {
     if (a.B == 0) return KGE_OK;
     const dim3 g(blocks_for_waves(a.B)), b(KGE_BLOCK);
     const bool lean = a.genre == KGE_LOSS_LOGSIGMOID && !a.pairwise && a.skip_pos && a.clampv == 0.f && !a.neg_copy &&
-                      !a.row_pos && !a.row_neg;
+                      !a.row_pos && !a.row_neg && a.diag_chunk <= 0;
 #define KGE_LOSS(N) do { if (lean) hipLaunchKernelGGL((loss_kernel_reg<N, true>), g, b, 0, s, a); \
                          else hipLaunchKernelGGL((loss_kernel_reg<N, false>), g, b, 0, s, a); } while (0)
     if (a.N <= 64) KGE_LOSS(1);
@@ -786,7 +805,11 @@ __global__ __launch_bounds__(KGE_BLOCK) void update_kernel(UpdateArgs a, int nb_
                 for (int e = 0; e < V; ++e) s0 += g0.v[e] * g0.v[e];
             }
             for (int k = n0; k < n1; ++k) {
-                const Pack<V> g = ld<V>(a.GN + (int64_t)a.ue_neg_slot[k] * d + off);
+                Pack<V> g = ld<V>(a.GN + gn_row(a, a.ue_neg_slot[k]) * d + off);
+                if (a.nd_chunk && reg) {      // neg_deg_sample: the scoring kernels leave the regulariser to this kernel
+#pragma unroll
+                    for (int e = 0; e < V; ++e) g.v[e] += reg_grad(x.v[e], a.reg_coef, a.reg_norm);
+                }
 #pragma unroll
                 for (int e = 0; e < V; ++e) s1 += g.v[e] * g.v[e];
             }
@@ -800,6 +823,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void update_kernel(UpdateArgs a, int nb_
         for (int it = lane; it < nit; it += 64) {
             const int off = it * V;
             Pack<V> x = ld<V>(row + off);
+            const Pack<V> x0 = x;             // the row as it was gathered (regulariser of the negative rows, nd mode)
             Pack<V> g0 = zero_pack<V>(), g1 = zero_pack<V>();
             if (has_pos) {
                 if (reg) {
@@ -817,7 +841,11 @@ __global__ __launch_bounds__(KGE_BLOCK) void update_kernel(UpdateArgs a, int nb_
                 for (int e = 0; e < V; ++e) x.v[e] = fmaf(g0.v[e], -a.lr / std0, x.v[e]);
             }
             for (int k = n0; k < n1; ++k) {
-                const Pack<V> g = ld<V>(a.GN + (int64_t)a.ue_neg_slot[k] * d + off);
+                Pack<V> g = ld<V>(a.GN + gn_row(a, a.ue_neg_slot[k]) * d + off);
+                if (a.nd_chunk && reg) {
+#pragma unroll
+                    for (int e = 0; e < V; ++e) g.v[e] += reg_grad(x0.v[e], a.reg_coef, a.reg_norm);
+                }
 #pragma unroll
                 for (int e = 0; e < V; ++e) {
                     x.v[e] = fmaf(g.v[e], -a.lr / std1, x.v[e]);
@@ -913,7 +941,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void update_kernel_reg(UpdateArgs a_in, 
     if constexpr (!SHARDED) { a.em.n = 0; a.rm.n = 0; }
     if constexpr (LEAN != 0) {
         a.transe_fast = LEAN == 1 ? 1 : 0; a.emit_ent = 0; a.emit_rel = 0;
-        a.g0 = a.g1 = a.gs0 = a.gs1 = a.gr = a.gsr = nullptr; a.rid = nullptr; a.dry = 0;
+        a.g0 = a.g1 = a.gs0 = a.gs1 = a.gr = a.gsr = nullptr; a.rid = nullptr; a.dry = 0; a.nd_chunk = 0;
     }
     const int lane = LANE();
     const bool reg = a.reg_coef > 0.f && a.reg_norm > 0;
@@ -949,7 +977,8 @@ __global__ __launch_bounds__(KGE_BLOCK) void update_kernel_reg(UpdateArgs a_in, 
         const float sg0 = a.transe_fast ? (side0 ? 1.f : -1.f) : 1.f;
         const float *pA = !has_pos ? row : (a.transe_fast ? a.P + e0 : (side0 ? a.GT : a.GH) + e0);
         const float *pB = ga0 ? a.GA + e0 : pA;          // aliases pA when unused (same lines, no extra traffic)
-        const float *pC = has_neg ? a.GN + (int64_t)slot0 * d : row;
+        const float *pC = has_neg ? a.GN + gn_row(a, slot0) * d : row;
+        const bool ndreg = a.nd_chunk && reg;       // neg_deg_sample: regulariser of the negative rows added here
         const float st0 = *srow;
         // the rest of the two lists (entries 1..) is requested NOW, one entry per lane, together with the
         // rows above: a serial "load index -> load row" chain per extra entry made the longest list set the
@@ -971,7 +1000,8 @@ __global__ __launch_bounds__(KGE_BLOCK) void update_kernel_reg(UpdateArgs a_in, 
                     if (reg) { rv += reg_val(x[k].v[e], a.reg_norm); g = reg_grad(x[k].v[e], a.reg_coef, a.reg_norm); }
                     if (has_pos) g += sg0 * va.v[e] + (ga0 ? vb.v[e] : 0.f);
                     g0[k].v[e] = g;
-                    const float gn = has_neg ? vc.v[e] : 0.f;
+                    float gn = has_neg ? vc.v[e] : 0.f;
+                    if (ndreg && has_neg) gn += reg_grad(x[k].v[e], a.reg_coef, a.reg_norm);
                     g1[k].v[e] = gn;
                     s1 += gn * gn;
                 }
@@ -1011,12 +1041,16 @@ __global__ __launch_bounds__(KGE_BLOCK) void update_kernel_reg(UpdateArgs a_in, 
 #pragma unroll 1
         for (int i = 0; i < nnx; ++i) {
             const int slot = i < 64 ? __builtin_amdgcn_readlane(slotv, i) : a.ue_neg_slot[n0 + 1 + i];
-            const float *src = a.GN + (int64_t)slot * d;
+            const float *src = a.GN + gn_row(a, slot) * d;
 #pragma unroll
             for (int k = 0; k < NIT; ++k) {
                 const int it = lane + 64 * k;
                 if (it < nit) {
-                    const Pack<4> g = ld<4>(src + it * 4);
+                    Pack<4> g = ld<4>(src + it * 4);
+                    if (ndreg) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) g.v[e] += reg_grad(x[k].v[e], a.reg_coef, a.reg_norm);
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { s1 += g.v[e] * g.v[e]; g1[k].v[e] += g.v[e]; }
                 }
@@ -1185,7 +1219,7 @@ int launch_update(const UpdateArgs &a, hipStream_t s) {
     const bool sharded = a.em.n != 0 || a.rm.n != 0;
     const bool inplace = !a.emit_ent && !a.emit_rel && !a.g0 && !a.g1 && !a.gs0 && !a.gs1 && !a.gr && !a.gsr && !a.rid &&
                          !a.dry;
-    const int lean = !inplace ? 0 : (a.transe_fast ? 1 : 2);
+    const int lean = (!inplace || a.nd_chunk) ? 0 : (a.transe_fast ? 1 : 2);
     const int nit = dmax <= 256 ? 1 : (dmax <= 512 ? 2 : 4);
 #define KGE_UPD(N, SH, LE) hipLaunchKernelGGL((update_kernel_reg<N, SH, LE>), g, b, 0, s, a, nbE)
 #define KGE_UPD_N(N)                                                             \

@@ -20,6 +20,7 @@ FLAG_NO_TRANSE_FAST = 2
 FLAG_DENSE_NEG = 4
 FLAG_FUSED_LOSS = 8
 FLAG_TWO_PASS_PAIR = 16
+FLAG_NEG_DEG_SAMPLE = 32
 ACC_SLOTS = 4096
 
 c_f = C.c_float

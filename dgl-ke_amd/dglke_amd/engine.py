@@ -145,10 +145,12 @@ class StepEngine(object):
 
     def alloc_outputs(self, batch):
         dev = self.device
+        # neg_deg_sample: every chunk is scored against its own positives too (N' = chunk + N rows)
+        Np = batch.N + (batch.chunk if self.hp.flags & _lib.FLAG_NEG_DEG_SAMPLE else 0)
         return dict(pos_score=torch.empty(batch.B, device=dev),
-                    neg_score=torch.empty(batch.C, batch.chunk, batch.N, device=dev),
+                    neg_score=torch.empty(batch.C, batch.chunk, Np, device=dev),
                     g_pos_ent=torch.empty(batch.UE, self.d_e, device=dev),
-                    g_neg=torch.empty(batch.C * batch.N, self.d_e, device=dev),
+                    g_neg=torch.empty(batch.C * Np, self.d_e, device=dev),
                     g_rel=torch.empty(batch.B, self.d_r, device=dev))
 
     def capture(self, batches, stream=None):

@@ -11,6 +11,7 @@ libkge_hip.  Two ways to run a training step:
 import torch as th
 
 from . import ops
+from . import _lib
 from .engine import StepEngine
 from .loss import LossGenerator
 from .score_fun import (ComplExScore, DistMultScore, RESCALScore, RotatEScore, SimplEScore, TransEScore,
@@ -96,7 +97,9 @@ class KEModel(object):
             tables=(self.entity_emb.emb, self.entity_emb.state_sum, self.relation_emb.emb,
                     self.relation_emb.state_sum) + ((self.score_func.projection_emb.emb,
                                                      self.score_func.projection_emb.state_sum)
-                                                    if model_name == 'TransR' else ()))
+                                                    if model_name == 'TransR' else ()),
+            flags=_lib.FLAG_NEG_DEG_SAMPLE if getattr(args, 'neg_deg_sample', False) and
+            model_name not in ('TransR', 'RESCAL') else 0)
 
     # ---- bookkeeping (general_models.py:278-330) ----------------------------------------
     def share_memory(self):
@@ -228,8 +231,6 @@ class KEModel(object):
         sync_log (one 16-byte D2H copy) else None; running sums are kept in
         self.engine.loss_accum."""
         batch = pos_g.batch if hasattr(pos_g, 'batch') else pos_g
-        if getattr(self.args, 'neg_deg_sample', False):
-            raise KgeError("neg_deg_sample is only available on the drop-in path")
         self.engine.step(batch, per_step_loss=sync_log)
         if not sync_log:
             return None

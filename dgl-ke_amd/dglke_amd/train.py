@@ -23,6 +23,7 @@ import time
 import numpy as np
 import torch as th
 
+from . import _lib
 from ._lib import KgeError
 from .kgdataset import get_dataset
 
@@ -210,7 +211,9 @@ class Trainer(object):
         B, N = args.batch_size, args.neg_sample_size
         self.chunk = N if N <= B else B
         C = B // self.chunk
-        self.fused = not args.neg_deg_sample
+        # --neg_deg_sample runs on the fused step too (KGE_FLAG_NEG_DEG_SAMPLE); TransR / RESCAL keep the drop-in path for it
+        self.fused = not (args.neg_deg_sample and args.model_name in ('TransR', 'RESCAL'))
+        self.step_flags = _lib.FLAG_NEG_DEG_SAMPLE if (args.neg_deg_sample and self.fused) else 0
         self.device_sampler = self.fused and not args.has_edge_importance and 2 * B + C * N <= 4096
         self.n_lanes = max(1, int(args.num_proc))
         if self.n_lanes > 1 and not self.fused:
@@ -225,7 +228,7 @@ class Trainer(object):
                 args.model_name, dataset.n_entities, dataset.n_relations, args.hidden_dim, args.gamma, args.lr,
                 self.dev, args.double_ent, args.double_rel, args.neg_adversarial_sampling,
                 args.adversarial_temperature, args.regularization_coef, args.regularization_norm, args.loss_genre,
-                args.pairwise, args.margin, tables=tables)
+                args.pairwise, args.margin, flags=self.step_flags, tables=tables)
             sel = parts[k] if self.n_lanes > 1 else slice(None)
             trip = tuple(np.asarray(x)[sel] for x in tr[:3])
             w = np.asarray(tr[3])[sel] if args.has_edge_importance else None
@@ -329,11 +332,13 @@ class ShardedTrainer(object):
         self.chunk = N if N <= B else B
         self.fused, self.n_lanes = True, 1
         self.device_sampler = 2 * B + (B // self.chunk) * N <= 4096
-        if args.neg_deg_sample or args.has_edge_importance or not self.device_sampler:
-            raise KgeError("multi-GPU training uses the on-device sampler: no --neg_deg_sample / "
-                           "--has_edge_importance, and 2*batch + chunks*neg <= 4096")
+        if args.has_edge_importance or not self.device_sampler:
+            raise KgeError("multi-GPU training uses the on-device sampler: no --has_edge_importance, "
+                           "and 2*batch + chunks*neg <= 4096")
         if args.model_name == 'RESCAL':
             raise KgeError("RESCAL is not available on sharded tables")
+        if args.neg_deg_sample and args.model_name == 'TransR':
+            raise KgeError("--neg_deg_sample is not available for TransR on sharded tables")
         d_e = args.hidden_dim * (2 if args.double_ent else 1)
         d_r = args.hidden_dim * (2 if args.double_rel else 1)
         self.emb_init = (args.gamma + 2.0) / args.hidden_dim
@@ -344,7 +349,8 @@ class ShardedTrainer(object):
         self.engine = StepEngine(args.model_name, dataset.n_entities, dataset.n_relations, args.hidden_dim, args.gamma,
                                  args.lr, self.dev, args.double_ent, args.double_rel, args.neg_adversarial_sampling,
                                  args.adversarial_temperature, args.regularization_coef, args.regularization_norm,
-                                 args.loss_genre, args.pairwise, args.margin, shards=self.tabs)
+                                 args.loss_genre, args.pairwise, args.margin,
+                                 flags=_lib.FLAG_NEG_DEG_SAMPLE if args.neg_deg_sample else 0, shards=self.tabs)
         tr = dataset.train
         part = np.array_split(np.random.RandomState(args.seed).permutation(len(tr[0])), world)[rank]
         self.lane = _Lane(self, rank, self.engine, tuple(np.asarray(x)[part] for x in tr[:3]), None)

@@ -77,6 +77,15 @@ enum kge_status {
 /* TransE_l1 / RotatE: keep the two-pass pairwise backward (GA and GN evaluated separately) instead
  * of the kernel that evaluates every (positive, negative) pair once for both products (validation aid) */
 #define KGE_FLAG_TWO_PASS_PAIR 16u
+/* kge_step_fused / kge_step_sharded: --neg_deg_sample of the reference (general_models.py:396-402,
+ * 424-432).  The corrupted-side entities of a chunk's OWN positives are prepended to the chunk's
+ * negatives: every positive is scored against N' = chunk + N rows, the chunk x chunk diagonal (the
+ * positive edge itself) is masked to score 0 (it stays in the loss, its gradient vanishes) and the
+ * gradients of the in-batch rows join the POSITIVE trace of their entity.  kge_batch is unchanged
+ * (N and the plan describe the SAMPLED negatives); kge_step_workspace_bytes accounts for N';
+ * kge_step_out.neg_score is [B, N'], g_neg [C*N', d_e] (rows c*N' + chunk.. are the sampled ones).
+ * Not available for RESCAL / TransR and in kge_step_grads. */
+#define KGE_FLAG_NEG_DEG_SAMPLE 32u
 
 int         kge_abi_version(void);
 const char *kge_last_error(void);

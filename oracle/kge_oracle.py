@@ -438,6 +438,8 @@ def forward_backward(cfg, ent, rel, nid, h_local, t_local, rel_ids, neg_ids, neg
         mask[:, np.arange(chunk), np.arange(chunk)] = 0
         n = score_neg(cfg.model, a, neg_all, C, chunk, Np, gamma) * mask
         N_sampled, N = N, Np
+    else:
+        n = score_neg(cfg.model, a, neg, C, chunk, N, gamma)
     (pl, nl, loss), dpos, dneg = loss_fwd_bwd(p, n.reshape(B, N), w, cfg.loss_genre, cfg.adv,
                                               cfg.adv_temp, cfg.pairwise, cfg.margin)
     reg = 0.0

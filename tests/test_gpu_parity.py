@@ -374,3 +374,51 @@ def test_shared_pair_backward_matches_two_pass_and_fp64(model, shape):
         assert bad.mean() < 2e-3, "TransE_l1 g_neg vs fp64: %.4f of the entries differ" % bad.mean()
         bad = np.abs(outs["shared"][1] - ga64) > 3e-4 * gscale
         assert bad.mean() < 2e-3, "TransE_l1 g_pos_side vs fp64: %.4f of the entries differ" % bad.mean()
+
+
+@pytest.mark.parametrize("flags", [32, 33], ids=["auto", "force_pairwise"])
+@pytest.mark.parametrize("name", golden_names(nd=True))
+def test_fused_step_neg_deg_sample_matches_reference(name, flags):
+    """--neg_deg_sample on the fused step (KGE_FLAG_NEG_DEG_SAMPLE = 32): the chunk's own positives join the
+    negatives, masked diagonal, their gradients in the positive trace - against scores / gradients / tables
+    recorded from the reference running with args.neg_deg_sample = True (general_models.py:396-402, 424-432)."""
+    z, case = load_golden(name)
+    m = build_model(case, z)
+    eng = m.engine
+    eng.hp.flags = flags
+    chunk, N = case["chunk"], case["N"]
+    Np = chunk + N
+    for s in range(1, case["steps"] + 1):
+        p = "s%d_" % s
+        b = golden_batch(z, case, s)
+        want = eng.alloc_outputs(b)
+        eng.step(b, want)
+        torch.cuda.synchronize()
+        _close(want["pos_score"].cpu(), z[p + "pos_score"], 1e-4, 1e-4, name + " pos_score")
+        assert tuple(want["neg_score"].shape) == z[p + "neg_score"].shape
+        _close(want["neg_score"].cpu(), z[p + "neg_score"], 1e-4, 1e-4, name + " neg_score")
+        l4 = eng.read_loss()
+        ref_log = z[p + "log"]
+        _close(l4[0], ref_log[0], 1e-4, 1e-5, name + " pos_loss")
+        _close(l4[1], ref_log[1], 1e-4, 1e-5, name + " neg_loss")
+        _close(l4[2], ref_log[2], 1e-4, 1e-5, name + " loss")
+        _close(l4[3], ref_log[3], 1e-4, 1e-7, name + " reg")
+        sel = np.searchsorted(b.p["ue_id"], z[p + "nid"])
+        _close(want["g_pos_ent"].cpu().numpy()[sel], z[p + "g_pos_ent"], 3e-4, grad_tol(z[p + "g_pos_ent"]), name + " g_pos_ent")
+        # the sampled negatives are rows chunk.. of every chunk's N' block; the regulariser of those rows is added by
+        # the update kernel in this mode (the reference's trace gradient includes it)
+        gneg = want["g_neg"].cpu().numpy().reshape(-1, Np, want["g_neg"].shape[1])[:, chunk:].reshape(-1, want["g_neg"].shape[1])
+        ref_gneg = z[p + "g_neg"]
+        if case["reg_coef"] > 0:
+            negrows = (z["init_entity"] if s == 1 else prev_ent)[z[p + "neg"]]
+            ref_gneg = ref_gneg - O.reg_grad(negrows.astype(np.float64), case["reg_coef"], case["reg_norm"])
+        _close(gneg, ref_gneg, 3e-4, grad_tol(z[p + "g_neg"]), name + " g_neg")
+        _close(want["g_rel"].cpu(), z[p + "g_rel"], 3e-4, grad_tol(z[p + "g_rel"]), name + " g_rel")
+        _close(eng.ent_state.cpu(), z[p + "entity_state"], 2e-3, 1e-9, name + " ent state")
+        _close(eng.rel_state.cpu(), z[p + "relation_state"], 2e-3, 1e-9, name + " rel state")
+        if (p + "entity") in z:
+            _close(eng.ent.cpu(), z[p + "entity"], 1e-4, 5e-3 * case["lr"], name + " entity rows")
+            _close(eng.rel.cpu(), z[p + "relation"], 1e-4, 5e-3 * case["lr"], name + " relation rows")
+        prev_ent = eng.ent.cpu().numpy()
+    _close(eng.ent.cpu(), z["final_entity"], 1e-4, 1e-2 * case["lr"], name + " final entity")
+    _close(eng.rel.cpu(), z["final_relation"], 1e-4, 1e-2 * case["lr"], name + " final relation")

@@ -16,7 +16,7 @@ def _close(a, b, rtol, atol, what):
         what, err.max(), lim.flat[np.argmax(err - lim)], np.unravel_index(np.argmax(err - lim), err.shape))
 
 
-@pytest.mark.parametrize("name", golden_names())
+@pytest.mark.parametrize("name", golden_names(nd=None))
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_step_matches_reference(name, dtype):
     z, case = load_golden(name)
