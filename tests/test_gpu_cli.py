@@ -28,7 +28,9 @@ def _planted(path, n_ent=400, n_rel=6, n=9000, seed=3):
 
 
 @pytest.mark.parametrize("model,extra", [("TransE_l2", []), ("DistMult", ["--loss_genre", "Logistic", "-g", "6"]),
-                                         ("RotatE", ["-de"]), ("TransR", ["--lr", "0.05"]), ("RESCAL", ["--lr", "0.05", "-g", "6"])])
+                                         ("RotatE", ["-de"]), ("TransR", ["--lr", "0.05"]), ("RESCAL", ["--lr", "0.05", "-g", "6"]),
+                                         # the reference's FB15k RotatE recipe uses --neg_deg_sample (examples/fb15k/multi_gpu.sh:318)
+                                         ("RotatE", ["-de", "--neg_deg_sample"]), ("TransE_l1", ["--neg_deg_sample", "-g", "12"])])
 def test_train_cli_end_to_end(tmp_path, capsys, model, extra):
     from dglke_amd import train as T
     data = str(tmp_path / "kg")
@@ -40,6 +42,9 @@ def test_train_cli_end_to_end(tmp_path, capsys, model, extra):
             "--eval_interval", "1000", "--valid", "--test", "--graph_steps", "100"] + extra
     tr = T.main(argv)
     out = capsys.readouterr().out
+    if "--neg_deg_sample" in extra:      # it runs on the fused step, not on the per-op drop-in path
+        from dglke_amd import _lib
+        assert tr.fused and tr.model.engine.hp.flags & _lib.FLAG_NEG_DEG_SAMPLE
     # reference log formats (train_pytorch.py:165-172, :236-247)
     assert "[proc 0][Train](500/1250) average loss:" in out and "[proc 0][Train](1000/1250) average pos_loss:" in out
     assert "[0]Valid average MRR:" in out and "[0]Test average HITS@10:" in out and "training takes" in out
