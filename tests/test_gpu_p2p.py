@@ -20,17 +20,17 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 @pytest.mark.parametrize("model,de_,dr_,hidden", [("TransE_l2", False, False, 64), ("TransE_l1", False, False, 32),
                                                   ("DistMult", False, False, 64), ("ComplEx", True, True, 32),
                                                   ("RotatE", True, False, 32)])
-@pytest.mark.parametrize("n_shards", [1, 3])
-def test_emulated_shards_equal_single_table(model, de_, dr_, hidden, n_shards):
+@pytest.mark.parametrize("n_shards,flags", [(1, 0), (3, 0), (3, 32)], ids=["1shard", "3shards", "3shards_neg_deg_sample"])
+def test_emulated_shards_equal_single_table(model, de_, dr_, hidden, n_shards, flags):
     from dglke_amd import p2p, plan
     from dglke_amd.engine import StepEngine
     n_ent, n_rel, B, N = 1000, 23, 96, 32           # 1000 / 3 and 23 / 3 leave ragged last shards
     d_e = 2 * hidden if de_ else hidden
     d_r = 2 * hidden if dr_ else hidden
-    ref = StepEngine(model, n_ent, n_rel, hidden, 10.0, 0.1, DEV, de_, dr_, True, 1.0, 1e-5, 3)
+    ref = StepEngine(model, n_ent, n_rel, hidden, 10.0, 0.1, DEV, de_, dr_, True, 1.0, 1e-5, 3, flags=flags)
     tabs = p2p.ShardedTables(n_ent, n_rel, d_e, d_r, DEV, emulate=n_shards)
     tabs.load_full(ref.ent, ref.rel)
-    eng = StepEngine(model, n_ent, n_rel, hidden, 10.0, 0.1, DEV, de_, dr_, True, 1.0, 1e-5, 3, shards=tabs)
+    eng = StepEngine(model, n_ent, n_rel, hidden, 10.0, 0.1, DEV, de_, dr_, True, 1.0, 1e-5, 3, flags=flags, shards=tabs)
     rng = np.random.RandomState(7)
     for step in range(1, 6):
         bt = O.synth_batch(rng, n_ent, n_rel, B, N, N, step)
