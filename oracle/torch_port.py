@@ -150,3 +150,57 @@ class TorchPort(object):
         return dict(pos_score=pos.detach().numpy(), neg_score=ns.detach().numpy().reshape(C, chunk, N),
                     log=log, g_pos_ent=pos_emb.grad.numpy(), g_neg=neg.grad.numpy(),
                     g_rel=rel.grad.numpy())
+
+
+# ---------------------------------------------------------------------------------------------
+# the reference's multi-process CPU mode (`--num_proc P`, train.py:298-317): P trainer processes, one
+# thread each, lock-free on ONE table in shared memory (ExternalEmbedding.share_memory, tensor_models.py:
+# 233-236).  Used only by bench.py's cpu_baseline leg.
+# ---------------------------------------------------------------------------------------------
+def _hogwild_worker(rank, tables, w, seconds, ready, go, out):
+    import time
+    from oracle import kge_oracle as O
+    th.set_num_threads(1)
+    port = TorchPort(w["model"], 1, 1, w["hidden"], w["gamma"], w["lr"], w["de"], w["dr"], w["adv"], w["adv_temp"],
+                     w["reg_coef"], w["reg_norm"])
+    port.ent, port.ent_state, port.rel, port.rel_state = tables
+    rng = np.random.RandomState(1000 + rank)
+    plans = []
+    for s in range(1, 13):
+        bt = O.synth_batch(rng, w["n_ent"], w["n_rel"], w["B"], w["N"], w["N"], s)
+        plans.append(dict(nid=bt["nid"], h_local=bt["h_local"], t_local=bt["t_local"], rel_ids=bt["r"], neg_ids=bt["neg"],
+                          C=w["B"] // w["N"], chunk=w["N"], N=w["N"], neg_head=bt["neg_head"]))
+    port.step(plans[0])
+    ready.put(rank)
+    go.wait()
+    t0, n = time.perf_counter(), 0
+    while time.perf_counter() - t0 < seconds:
+        port.step(plans[n % len(plans)])
+        n += 1
+    out.put((rank, n, time.perf_counter() - t0))
+
+
+def hogwild_cpu(w, procs, seconds=5.0, timeout=120.0):
+    """aggregate edges/s of `procs` single-thread trainer processes sharing the tables; returns (edges/s, steps)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    base = TorchPort(w["model"], w["n_ent"], w["n_rel"], w["hidden"], w["gamma"], w["lr"], w["de"], w["dr"], w["adv"],
+                     w["adv_temp"], w["reg_coef"], w["reg_norm"])
+    tables = tuple(t.share_memory_() for t in (base.ent, base.ent_state, base.rel, base.rel_state))
+    ready, out, go = ctx.Queue(), ctx.Queue(), ctx.Event()
+    ps = [ctx.Process(target=_hogwild_worker, args=(r, tables, w, seconds, ready, go, out), daemon=True) for r in range(procs)]
+    for p in ps:
+        p.start()
+    try:
+        for _ in range(procs):
+            ready.get(timeout=timeout)
+        go.set()
+        res = [out.get(timeout=seconds + timeout) for _ in range(procs)]
+    finally:
+        for p in ps:
+            p.join(timeout=5)
+            if p.is_alive():
+                p.kill()          # our own children, by handle
+    steps = sum(n for _, n, _ in res)
+    wall = max(dt for _, _, dt in res)
+    return steps * w["B"] / wall, steps
