@@ -117,3 +117,13 @@ def test_oracle_rank_eval_matches_reference(name):
         assert np.all((lo <= want) & (want <= hi)), (mode, lo, want, hi)
         # the true triple is a known triple: unfiltered it always counts itself
         assert np.all(z[mode + "_ranks_raw"] >= 2)
+
+
+def test_torch_port_num_proc_mode_runs():
+    """bench.py's cpu_baseline leg: the reference's --num_proc mode restated (single-thread processes, Hogwild on
+    shared-memory tables) makes progress in every process and leaves finite tables."""
+    from oracle import torch_port
+    w = dict(model="TransE_l2", n_ent=300, n_rel=7, hidden=16, de=False, dr=False, B=64, N=16, gamma=10.0, lr=0.1,
+             adv=True, adv_temp=1.0, reg_coef=1e-6, reg_norm=3)
+    rate, steps = torch_port.hogwild_cpu(w, 2, seconds=0.5, timeout=120.0)
+    assert steps >= 2 and rate > 0
