@@ -68,6 +68,42 @@ __device__ __forceinline__ void tile_sweep(f32x4 (&acc)[4], int Ktot, LA loadA, 
     }
 }
 
+// Same sweep with 16-byte operand loads (D_e % 4 == 0 and D_r % 4 == 0): every thread fetches ONE float4 (or four
+// sign bytes as one 32-bit word) per operand and slab instead of four scalars.  AROW / BROW: the four elements are
+// consecutive tile rows (columns) at one k - a float4 store into LDS; otherwise they are consecutive k of one row.
+template <bool AROW, bool BROW, class LA, class LB>
+__device__ __forceinline__ void tile_sweep4(f32x4 (&acc)[4], int Ktot, LA loadA4, LB loadB4, float (*As)[TR_K][TR_LD],
+                                            float (*Bs)[TR_K][TR_LD]) {
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63, m = lane & 15, q = lane >> 4;
+    const int ai = AROW ? (t & 15) * 4 : t >> 2, ak = AROW ? t >> 4 : (t & 3) * 4;
+    const int bi = BROW ? (t & 15) * 4 : t >> 2, bk = BROW ? t >> 4 : (t & 3) * 4;
+    float4 av, bv;
+    if (Ktot > 0) { av = loadA4(ai, ak); bv = loadB4(bk, bi); }
+    int buf = 0;
+    __syncthreads();
+    for (int k0 = 0; k0 < Ktot; k0 += TR_K, buf ^= 1) {
+        if constexpr (AROW) *reinterpret_cast<float4 *>(&As[buf][ak][ai]) = av;
+        else { As[buf][ak][ai] = av.x; As[buf][ak + 1][ai] = av.y; As[buf][ak + 2][ai] = av.z; As[buf][ak + 3][ai] = av.w; }
+        if constexpr (BROW) *reinterpret_cast<float4 *>(&Bs[buf][bk][bi]) = bv;
+        else { Bs[buf][bk][bi] = bv.x; Bs[buf][bk + 1][bi] = bv.y; Bs[buf][bk + 2][bi] = bv.z; Bs[buf][bk + 3][bi] = bv.w; }
+        __syncthreads();
+        if (k0 + TR_K < Ktot) { av = loadA4(ai, k0 + TR_K + ak); bv = loadB4(k0 + TR_K + bk, bi); }
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const float a = As[buf][4 * s4 + q][wave * 16 + m];
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc[ct] = MFMA16(a, Bs[buf][4 * s4 + q][ct * 16 + m], acc[ct]);
+        }
+    }
+}
+__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+// four sign bytes (one aligned 32-bit word) times a scale
+__device__ __forceinline__ float4 sign4(const signed char *z, float scale) {
+    const int w = *reinterpret_cast<const int *>(z);
+    return make_float4(scale * (float)(signed char)(w & 0xff), scale * (float)(signed char)((w >> 8) & 0xff),
+                       scale * (float)(signed char)((w >> 16) & 0xff), scale * (float)(signed char)(w >> 24));
+}
+
 // ---------------------------------------------------------------------------------------------
 // positive score, sign vector, q = x P - r   (one wavefront per edge; hp / tp from the projection pass)
 // ---------------------------------------------------------------------------------------------
@@ -90,6 +126,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void transr_pos_kernel(TransRArgs a) {
 // ---------------------------------------------------------------------------------------------
 // forward: workgroup = (positive i, block of 64 negatives); loops the D_r column tiles
 // ---------------------------------------------------------------------------------------------
+template <bool VEC>
 __global__ __launch_bounds__(KGE_BLOCK) void transr_fwd_kernel(TransRArgs a, int nJB) {
     __shared__ float As[2][TR_K][TR_LD], Bs[2][TR_K][TR_LD];
     __shared__ int64_t rowoff[TR_T];
@@ -105,6 +142,13 @@ __global__ __launch_bounds__(KGE_BLOCK) void transr_fwd_kernel(TransRArgs a, int
         f32x4 acc[4];
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if constexpr (VEC)
+            tile_sweep4<false, true>(acc, De,
+                [&](int row, int k) { const int64_t o = rowoff[row];
+                                      return (o >= 0 && k < De) ? *reinterpret_cast<const float4 *>(a.ent + o + k) : f4zero(); },
+                [&](int k, int col) { return (k < De && dr0 + col < Dr) ? *reinterpret_cast<const float4 *>(Pi + (int64_t)k * Dr + dr0 + col)
+                                                                        : f4zero(); }, As, Bs);
+        else
         tile_sweep<true, false>(acc, De,
             [&](int row, int k) { const int64_t o = rowoff[row]; return (o >= 0 && k < De) ? a.ent[o + k] : 0.f; },
             [&](int k, int col) { return (k < De && dr0 + col < Dr) ? Pi[(int64_t)k * Dr + dr0 + col] : 0.f; }, As, Bs);
@@ -181,6 +225,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void transr_dq_kernel(TransRArgs a) {
 // The chunk's positives are split into a.nG groups (split-K): with 4-5 chunks there are only ~64 output tiles,
 // far too few workgroups; every group writes its own partial tile and transr_gn_reduce_kernel adds the groups
 // in a fixed order (deterministic, no atomics).
+template <bool VEC>
 __global__ __launch_bounds__(KGE_BLOCK) void transr_gn_kernel(TransRArgs a, int nJB, int nEB) {
     __shared__ float As[2][TR_K][TR_LD], Bs[2][TR_K][TR_LD];
     const int g = blockIdx.x % a.nG;
@@ -193,6 +238,20 @@ __global__ __launch_bounds__(KGE_BLOCK) void transr_gn_kernel(TransRArgs a, int 
     f32x4 acc[4];
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (VEC)
+        tile_sweep4<false, false>(acc, max(0, i1 - i0) * DrP,
+            [&](int row, int k) {          // 4 consecutive d_r of one (positive, negative): one word of sign bytes
+                const int il = i0 + k / DrP, dr = k % DrP, j = j0 + row;
+                if (j >= N || dr >= Dr) return f4zero();
+                const int64_t ij = ((int64_t)c * chunk + il) * N + j;
+                return sign4(a.Z + ij * Dr + dr, -a.S[ij]);
+            },
+            [&](int k, int col) {          // P_i[de][dr .. dr+3]
+                const int il = i0 + k / DrP, dr = k % DrP, de = de0 + col;
+                if (de >= De || dr >= Dr) return f4zero();
+                return *reinterpret_cast<const float4 *>(a.proj + a.rel_ids[(int64_t)c * chunk + il] * (int64_t)De * Dr + (int64_t)de * Dr + dr);
+            }, As, Bs);
+    else
     tile_sweep<true, true>(acc, max(0, i1 - i0) * DrP,
         [&](int row, int k) {
             const int il = i0 + k / DrP, dr = k % DrP, j = j0 + row;
@@ -236,6 +295,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void transr_gn_reduce_kernel(TransRArgs 
 // ---------------------------------------------------------------------------------------------
 // GP_i[de][dr] = sum_j Neg_j[de] dY_ij[dr] + x_i[de] dq_i[dr]     workgroup = (positive, 64 de, 64 dr)
 // ---------------------------------------------------------------------------------------------
+template <bool VEC>
 __global__ __launch_bounds__(KGE_BLOCK) void transr_gp_kernel(TransRArgs a, int nEB, int nRB) {
     __shared__ float As[2][TR_K][TR_LD], Bs[2][TR_K][TR_LD];
     const int rb = blockIdx.x % nRB, eb = (blockIdx.x / nRB) % nEB, i = blockIdx.x / (nRB * nEB);
@@ -245,6 +305,18 @@ __global__ __launch_bounds__(KGE_BLOCK) void transr_gp_kernel(TransRArgs a, int 
     f32x4 acc[4];
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (VEC)
+        tile_sweep4<true, true>(acc, N,
+            [&](int row, int k) {          // Neg_k[de0 + row .. +3]
+                return (k < N && de0 + row < De) ? *reinterpret_cast<const float4 *>(a.ent + a.neg_ids[(int64_t)c * N + k] * (int64_t)De + de0 + row)
+                                                 : f4zero();
+            },
+            [&](int k, int col) {          // dY_ik[dr0 + col .. +3]: one word of sign bytes
+                if (k >= N || dr0 + col >= Dr) return f4zero();
+                const int64_t ij = (int64_t)i * N + k;
+                return sign4(a.Z + ij * Dr + dr0 + col, -a.S[ij]);
+            }, As, Bs);
+    else
     tile_sweep<false, false>(acc, N,
         [&](int row, int k) {
             return (k < N && de0 + row < De) ? a.ent[a.neg_ids[(int64_t)c * N + k] * (int64_t)De + de0 + row] : 0.f;
@@ -367,7 +439,8 @@ int launch_transr_pos(const TransRArgs &a, hipStream_t s) {
 int launch_transr_fwd(const TransRArgs &a, hipStream_t s) {
     if (a.B == 0) return KGE_OK;
     const int nJB = (a.N + TR_T - 1) / TR_T;
-    hipLaunchKernelGGL(transr_fwd_kernel, dim3(a.B * nJB), dim3(KGE_BLOCK), 0, s, a, nJB);
+    if (a.De % 4 == 0 && a.Dr % 4 == 0) hipLaunchKernelGGL(transr_fwd_kernel<true>, dim3(a.B * nJB), dim3(KGE_BLOCK), 0, s, a, nJB);
+    else hipLaunchKernelGGL(transr_fwd_kernel<false>, dim3(a.B * nJB), dim3(KGE_BLOCK), 0, s, a, nJB);
     return check_launch_t();
 }
 int launch_transr_bwd(const TransRArgs &a, hipStream_t s) {
@@ -375,9 +448,12 @@ int launch_transr_bwd(const TransRArgs &a, hipStream_t s) {
     const int nJB = (a.N + TR_T - 1) / TR_T, nEB = (a.De + TR_T - 1) / TR_T, nRB = (a.Dr + TR_T - 1) / TR_T;
     const dim3 gw((a.B + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK), b(KGE_BLOCK);
     hipLaunchKernelGGL(transr_dq_kernel, dim3(a.B), b, 0, s, a);
-    hipLaunchKernelGGL(transr_gn_kernel, dim3(a.C * nJB * nEB * a.nG), b, 0, s, a, nJB, nEB);
+    const bool vec = a.De % 4 == 0 && a.Dr % 4 == 0;      // 16-byte operand loads (4 sign bytes per word)
+    if (vec) hipLaunchKernelGGL(transr_gn_kernel<true>, dim3(a.C * nJB * nEB * a.nG), b, 0, s, a, nJB, nEB);
+    else hipLaunchKernelGGL(transr_gn_kernel<false>, dim3(a.C * nJB * nEB * a.nG), b, 0, s, a, nJB, nEB);
     hipLaunchKernelGGL(transr_gn_reduce_kernel, dim3(((int64_t)a.C * a.N + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK), b, 0, s, a);
-    hipLaunchKernelGGL(transr_gp_kernel, dim3(a.B * nEB * nRB), b, 0, s, a, nEB, nRB);
+    if (vec) hipLaunchKernelGGL(transr_gp_kernel<true>, dim3(a.B * nEB * nRB), b, 0, s, a, nEB, nRB);
+    else hipLaunchKernelGGL(transr_gp_kernel<false>, dim3(a.B * nEB * nRB), b, 0, s, a, nEB, nRB);
     hipLaunchKernelGGL(transr_gr_kernel, gw, b, 0, s, a);
     return check_launch_t();
 }
