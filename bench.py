@@ -96,6 +96,24 @@ def synth_triples(w, seed):
             rng.randint(0, w["n_ent"], n).astype(np.int64))
 
 
+def step_kernels(model, force_pairwise=False):
+    """the launches of one strict training step per model family and the dominant one."""
+    if model == "TransR":
+        return ("one training step = projections (matvec), transr_pos, transr_fwd, loss, transr_dq / gn / gp / gr, "
+                "projection Adagrad, update; dominant: transr_gp_kernel / transr_gn_kernel (fp32 MFMA)")
+    if model == "RESCAL":
+        return ("one training step = rescal_matvec x2, neg_fwd_gemm, loss, neg_bwd_gemm, relation-matrix Adagrad, update; "
+                "dominant: rescal_apply / rescal_matvec (HBM streaming of the relation matrices)")
+    if model in ("TransE_l1", "RotatE") or force_pairwise:
+        return ("one training step = edge_fwd, neg_fwd_bcast, loss, neg_bwd_lc + gn_reduce, (edge_bwd,) update; "
+                "dominant: neg_bwd_lc_kernel (VALU, packed fp32)")
+    if model == "TransE_l2":
+        return ("one training step = 5 dependent kernels (edge_fwd, neg_fwd_gemm, loss, neg_bwd_gemm, update); "
+                "dominant: neg_bwd_gemm_kernel")
+    return ("one training step = 6 dependent kernels (edge_fwd, neg_fwd_gemm, loss, neg_bwd_gemm, edge_bwd, update); "
+            "dominant: neg_bwd_gemm_kernel")
+
+
 def cpu_baseline(w, plans, budget_s=12.0, max_steps=200):
     """time the CPU port of the reference step (oracle/torch_port.py) on the host cores."""
     from oracle import torch_port
@@ -403,8 +421,7 @@ def main():
                    "neg_kernels": "pairwise" if args.force_pairwise else "auto"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                      "frac": round(achieved / 8000.0, 5), "traffic": measured_traffic(args.workload),
-                     "kernel": "one training step = 5 dependent kernels (edge_fwd, neg_fwd_gemm, loss, "
-                               "neg_bwd_gemm, update); dominant: neg_bwd_gemm_kernel",
+                     "kernel": step_kernels(w["model"], args.force_pairwise),
                      "algorithmic_bytes_per_step": round(bytes_step, 1),
                      "event_ms_per_step": round(ev_ms / K, 6)},
         "mean_loss": round(accum[2] / K, 6),
