@@ -71,12 +71,22 @@ class ShardedTables(object):
         handle = (C.c_ubyte * _lib.IPC_HANDLE_BYTES)()
         off = C.c_int64(0)
         _lib.check(lib.kge_ipc_export(arena.data_ptr(), handle, C.byref(off)))
-        mine = (bytes(handle), int(off.value))
+        my_dev = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
+        mine = (bytes(handle), int(off.value), int(my_dev))
         world = dist.get_world_size(self.group)
         everyone = [None] * world
         dist.all_gather_object(everyone, mine, group=self.group)
+        # refuse BEFORE any kernel touches a peer mapping: a load from memory this GPU cannot reach is a GPU fault
+        # (the process dies), not an exception a caller could turn into the all-to-all fall-back
+        bad = [d for r, (_, _, d) in enumerate(everyone)
+               if r != self.rank and d != my_dev and not torch.cuda.can_device_access_peer(my_dev, d)]
+        verdicts = [None] * world                      # decided TOGETHER: every rank raises or none does
+        dist.all_gather_object(verdicts, bad, group=self.group)
+        if any(verdicts):
+            raise _lib.KgeError("no peer-to-peer access between some GPUs: %s" % (
+                "; ".join("rank %d -> GPUs %s" % (r, v) for r, v in enumerate(verdicts) if v)))
         bases = []
-        for r, (h, o) in enumerate(everyone):
+        for r, (h, o, _) in enumerate(everyone):
             if r == self.rank:
                 bases.append(arena.data_ptr())
                 continue
