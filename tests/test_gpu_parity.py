@@ -422,3 +422,75 @@ def test_fused_step_neg_deg_sample_matches_reference(name, flags):
         prev_ent = eng.ent.cpu().numpy()
     _close(eng.ent.cpu(), z["final_entity"], 1e-4, 1e-2 * case["lr"], name + " final entity")
     _close(eng.rel.cpu(), z["final_relation"], 1e-4, 1e-2 * case["lr"], name + " final relation")
+
+
+def _random_step_case(seed):
+    """one random small configuration: model, shapes (ragged on purpose), loss options, kernel-path flags"""
+    rng = np.random.RandomState(seed)
+    model = ["TransE_l1", "TransE_l2", "DistMult", "ComplEx", "RotatE", "SimplE"][seed % 6]
+    de = model in ("ComplEx", "RotatE", "SimplE")
+    dr = model in ("ComplEx", "SimplE")
+    hidden = int(rng.choice([8, 12, 16, 20, 24, 32, 40, 48, 64]))
+    chunk = int(rng.choice([1, 3, 4, 7, 8, 16, 17, 24, 32, 40]))
+    C = int(rng.randint(1, 5))
+    N = int(rng.choice([1, 2, 4, 5, 8, 12, 16, 20, 32, 36, 64]))
+    flags = int(rng.choice([0, 0, 1, 2, 16, 32, 33]))
+    return dict(model=model, de=de, dr=dr, hidden=hidden, chunk=chunk, C=C, N=N, flags=flags,
+                n_ent=int(rng.choice([30, 200, 2000])), n_rel=int(rng.choice([3, 17])),
+                adv=bool(rng.randint(2)), reg=float(rng.choice([0.0, 1e-4])), gamma=float(rng.choice([6.0, 12.0])),
+                lr=float(rng.choice([0.05, 0.2])))
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_fused_step_random_shapes_match_oracle(seed):
+    """fuzz: 48 random (model, chunk, N, width, options, kernel-path flag) combinations - two fused steps (tail then head
+    corruption) against the fp64 oracle started from the same tables: scores, loss, the three trace gradients, Adagrad
+    states and rows.  Exercises ragged tiles of every negative-score kernel (matrix-core, pairwise, shared-pair), the
+    TransE fast path on and off, and --neg_deg_sample."""
+    from dglke_amd import plan
+    from dglke_amd.engine import StepEngine
+    k = _random_step_case(seed)
+    nd = bool(k["flags"] & 32)
+    cfg = O.Config(k["model"], k["gamma"], k["hidden"], k["lr"], adv=k["adv"], adv_temp=1.0, reg_coef=k["reg"], reg_norm=3,
+                   double_ent=k["de"], double_rel=k["dr"], neg_deg=nd)
+    rng = np.random.RandomState(1000 + seed)
+    ent = rng.uniform(-cfg.emb_init, cfg.emb_init, size=(k["n_ent"], cfg.ent_dim)).astype(np.float32)
+    rel = rng.uniform(-cfg.emb_init, cfg.emb_init, size=(k["n_rel"], cfg.rel_dim)).astype(np.float32)
+    eng = StepEngine(k["model"], k["n_ent"], k["n_rel"], k["hidden"], k["gamma"], k["lr"], DEV, k["de"], k["dr"], k["adv"], 1.0,
+                     k["reg"], 3, flags=k["flags"])
+    eng.load_tables(ent, rel)
+    B, chunk, N = k["C"] * k["chunk"], k["chunk"], k["N"]
+    Np = chunk + N if nd else N
+    tag0 = "seed %d %s" % (seed, k)
+    for step in (1, 2):
+        ent64 = eng.ent.cpu().numpy().astype(np.float64)
+        rel64 = eng.rel.cpu().numpy().astype(np.float64)
+        es64 = eng.ent_state.cpu().numpy().astype(np.float64)
+        rs64 = eng.rel_state.cpu().numpy().astype(np.float64)
+        bt = O.synth_batch(rng, k["n_ent"], k["n_rel"], B, N, chunk, step)
+        b = plan.make_batch(bt["h"], bt["t"], bt["r"], bt["neg"], chunk, N, bt["neg_head"], DEV)
+        want = eng.alloc_outputs(b)
+        eng.step(b, want)
+        torch.cuda.synchronize()
+        negrows = ent64[bt["neg"]]
+        out = O.train_step(cfg, ent64, es64, rel64, rs64, bt["nid"], bt["h_local"], bt["t_local"],
+                           bt["r"], bt["neg"], bt["neg_head"], chunk, N)
+        tag = "%s step %d" % (tag0, step)
+        _close(want["pos_score"].cpu(), out["pos_score"], 1e-4, 1e-4, tag + " pos_score")
+        _close(want["neg_score"].cpu(), out["neg_score"], 1e-4, 1e-4, tag + " neg_score")
+        l4 = eng.read_loss()
+        _close(l4[:3], out["log"][:3], 1e-4, 1e-5, tag + " loss")
+        sel = np.searchsorted(b.p["ue_id"], bt["nid"])
+        _close(want["g_pos_ent"].cpu().numpy()[sel], out["g_pos_ent"], 3e-4, grad_tol(out["g_pos_ent"]), tag + " g_pos_ent")
+        gneg = want["g_neg"].cpu().numpy()
+        ref_gneg = out["g_neg"]
+        if nd:      # sampled rows only; the regulariser of those rows is added by the update kernel in this mode
+            gneg = gneg.reshape(-1, Np, gneg.shape[1])[:, chunk:].reshape(-1, gneg.shape[1])
+            if k["reg"] > 0:
+                ref_gneg = ref_gneg - O.reg_grad(negrows, k["reg"], 3)
+        _close(gneg, ref_gneg, 3e-4, grad_tol(out["g_neg"]), tag + " g_neg")
+        _close(want["g_rel"].cpu(), out["g_rel"], 3e-4, grad_tol(out["g_rel"]), tag + " g_rel")
+        _close(eng.ent_state.cpu(), es64, 2e-3, 1e-9, tag + " ent state")
+        _close(eng.rel_state.cpu(), rs64, 2e-3, 1e-9, tag + " rel state")
+        _close(eng.ent.cpu(), ent64, 1e-4, 5e-3 * k["lr"], tag + " entity rows")
+        _close(eng.rel.cpu(), rel64, 1e-4, 5e-3 * k["lr"], tag + " relation rows")
