@@ -62,6 +62,14 @@ def test_train_cli_end_to_end(tmp_path, capsys, model, extra):
     conf = json.load(open(os.path.join(save, "config.json")))
     assert conf["model_name"] == model and conf["emp_file"] == "e.dict" and conf["rmap_file"] == "r.dict"
     assert conf["hidden_dim"] == 32 and conf["dataset"] == "toy"
+    # dglke_eval on the saved files reproduces the test metrics of the training run
+    from dglke_amd import eval_cli
+    gamma = extra[extra.index("-g") + 1] if "-g" in extra else "8"          # argparse: the last -g wins
+    ev = eval_cli.main(["--model_name", model, "--format", "udd_hrt", "--dataset", "toy", "--data_path", data, "--data_files",
+                        "e.dict", "r.dict", "train.txt", "valid.txt", "test.txt", "--model_path", save, "--gpu", "0",
+                        "--hidden_dim", "32", "-g", gamma] + (["-de"] if "-de" in extra else []))
+    capsys.readouterr()
+    assert abs(ev["MRR"] - mrr) < 1e-6, (ev["MRR"], mrr)
     # losses fell
     first = float([l for l in out.split("\n") if "(500/1250) average loss:" in l][0].split(":")[1])
     last = float([l for l in out.split("\n") if "(1000/1250) average loss:" in l][0].split(":")[1])
