@@ -95,3 +95,15 @@ def test_cpu_run_is_refused_loudly(tmp_path):
     with pytest.raises(KgeError):
         T.main(["--format", "udd_hrt", "--dataset", "toy", "--data_path", str(tmp_path), "--data_files", "e.txt",
                 "r.txt", "tr.txt", "--save_path", str(tmp_path / "ck"), "--max_step", "2"])     # --gpu defaults to -1
+
+
+def test_dglke_eval_flags_and_gpu_only():
+    """dglke_eval takes the reference's flags (eval.py:39-110) with its defaults, and refuses to run without a GPU."""
+    from dglke_amd import eval_cli
+    from dglke_amd._lib import KgeError
+    a = eval_cli.ArgParser().parse_args([])
+    assert (a.model_name, a.dataset, a.format, a.model_path) == ("TransE", "FB15k", "built_in", "ckpts")
+    assert (a.batch_size_eval, a.neg_sample_size_eval, a.hidden_dim, a.gamma, a.eval_percent) == (8, -1, 256, 12.0, 1)
+    assert a.gpu == [-1] and not a.double_ent and not a.no_eval_filter and a.num_proc == 1
+    with pytest.raises(KgeError):
+        eval_cli.main(["--gpu", "-1"])
