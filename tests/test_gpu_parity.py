@@ -441,7 +441,7 @@ def _random_step_case(seed):
                 lr=float(rng.choice([0.05, 0.2])))
 
 
-@pytest.mark.parametrize("seed", range(48))
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("KGE_FUZZ_N", "48"))))   # KGE_FUZZ_N=500 for a longer hunt
 def test_fused_step_random_shapes_match_oracle(seed):
     """fuzz: 48 random (model, chunk, N, width, options, kernel-path flag) combinations - two fused steps (tail then head
     corruption) against the fp64 oracle started from the same tables: scores, loss, the three trace gradients, Adagrad
