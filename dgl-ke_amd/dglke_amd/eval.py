@@ -100,17 +100,59 @@ def metrics_from_ranks(ranks):
             "HITS@10": float((rk <= 10).double().mean())}
 
 
-def evaluate(model_name, ent, rel, gamma, emb_init, test, known=None, batch=1024, modes=("head", "tail"), proj=None):
+def sampled_ranks(rk, h, r, t, neg_head, filt, n_entities, n_cand, chunk, rng, cand_of_chunk=None):
+    """`--neg_sample_size_eval n_cand` (EvalSampler with a negative sample size below the entity count,
+    dataloader/sampler.py:514-597): every chunk of `chunk` test triples is ranked against ITS OWN n_cand candidates
+    drawn uniformly with replacement from all entities; with a filter, candidates that make a known triple do not
+    count (the sampler's false-negative bias, general_models.py:463-475).  rank = 1 + #{unfiltered candidates scoring
+    >= the true triple}.  cand_of_chunk(k): override of the draw (tests)."""
+    h, r, t = (np.asarray(x, np.int64) for x in (h, r, t))
+    E = h.shape[0]
+    out = []
+    for k, e0 in enumerate(range(0, E, chunk)):
+        e1 = min(E, e0 + chunk)
+        cand = cand_of_chunk(k) if cand_of_chunk is not None else rng.randint(0, n_entities, size=n_cand)
+        cand = np.asarray(cand, np.int64)
+        f = None
+        if filt is not None:
+            # columns of this chunk's candidate list that hold a filtered entity, per triple (duplicates in the draw
+            # are separate columns): sorted candidates + two binary searches per filtered id
+            order = np.argsort(cand, kind="stable")
+            sc = cand[order]
+            frng, fids = filt
+            ptr, cols = [0], []
+            for i in range(e0, e1):
+                ids = fids[frng[i, 0]:frng[i, 1]]
+                lo, hi = np.searchsorted(sc, ids, "left"), np.searchsorted(sc, ids, "right")
+                hit = [order[a:b] for a, b in zip(lo, hi) if b > a]
+                c = np.concatenate(hit) if hit else np.zeros(0, np.int64)
+                cols.append(c)
+                ptr.append(ptr[-1] + c.shape[0])
+            ptr = np.asarray(ptr, np.int64)
+            f = (np.stack([ptr[:-1], ptr[1:]], 1), np.concatenate(cols) if cols else np.zeros(0, np.int64))
+        out.append(rk.ranks(h[e0:e1], r[e0:e1], t[e0:e1], neg_head, f, cand=cand))
+    return torch.cat(out)
+
+
+def evaluate(model_name, ent, rel, gamma, emb_init, test, known=None, batch=1024, modes=("head", "tail"), proj=None,
+             n_cand=None, chunk=None, seed=0):
     """filtered (known given) or raw ranking metrics over both corruption modes, averaged over all
     2E rankings like the reference (logs of the head and the tail sampler are concatenated,
-    train_pytorch.py:221-231).  test / known: (h, r, t) triples of int64 arrays."""
+    train_pytorch.py:221-231).  test / known: (h, r, t) triples of int64 arrays.  n_cand (< number of entities):
+    rank against n_cand sampled candidates per chunk of `chunk` triples instead of all entities."""
     rk = Ranker(model_name, ent, rel, gamma, emb_init, batch, proj=proj)
     th_, tr_, tt_ = test
+    n_ent = int(ent.shape[0])
+    sampled = n_cand is not None and 0 < n_cand < n_ent
+    rng = np.random.RandomState(seed)
     allr = []
     for mode in modes:
         neg_head = mode == "head"
         filt = None
         if known is not None:
             filt = build_filter(known[0], known[1], known[2], th_, tr_, tt_, neg_head, rel.shape[0])
-        allr.append(rk.ranks(th_, tr_, tt_, neg_head, filt))
+        if sampled:
+            allr.append(sampled_ranks(rk, th_, tr_, tt_, neg_head, filt, n_ent, int(n_cand), int(chunk or batch), rng))
+        else:
+            allr.append(rk.ranks(th_, tr_, tt_, neg_head, filt))
     return metrics_from_ranks(torch.cat(allr))

@@ -48,9 +48,7 @@ def main(argv=None):
     args = ArgParser().parse_args(argv)
     args.eval_filter = not args.no_eval_filter
     if args.neg_deg_sample_eval:
-        raise KgeError("--neg_deg_sample_eval is not available: the ranking runs against all entities")
-    if 0 <= args.neg_sample_size_eval:
-        raise KgeError("--neg_sample_size_eval is not available: the ranking runs against all entities")
+        raise KgeError("--neg_deg_sample_eval is not available (uniform --neg_sample_size_eval or all entities)")
     if args.gpu[0] < 0:
         raise KgeError("dglke_eval ranks on the GPU only: pass --gpu <id> (there is no CPU fallback)")
     if not os.path.isdir(args.model_path):
@@ -86,7 +84,9 @@ def main(argv=None):
     if proj is not None:
         Eb = min(Eb, 64)
     start = time.time()
-    metrics = kev.evaluate(model, ent, rel, args.gamma, emb_init, (h, r, t), known, batch=Eb, proj=proj)
+    metrics = kev.evaluate(model, ent, rel, args.gamma, emb_init, (h, r, t), known, batch=Eb, proj=proj,
+                           n_cand=args.neg_sample_size_eval if args.neg_sample_size_eval > 0 else None,
+                           chunk=args.batch_size_eval, seed=args.seed + 29)
     for k, v in metrics.items():
         print('[{}]{} average {}: {}'.format(0, 'Test', k, v))          # train_pytorch.py:236-247 format
     print('Test takes {:.3f} seconds'.format(time.time() - start))

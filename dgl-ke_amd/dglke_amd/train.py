@@ -261,7 +261,8 @@ class Trainer(object):
         if proj is not None:
             Eb = min(Eb, 64)                  # TransR projects every candidate with every test triple's matrix
         metrics = kev.evaluate(args.model_name, m.entity_emb.emb, m.relation_emb.emb, args.gamma, m.emb_init,
-                               (h, r, t), known, batch=Eb, proj=proj)
+                               (h, r, t), known, batch=Eb, proj=proj, n_cand=args.neg_sample_size_eval,
+                               chunk=args.batch_size_eval, seed=args.seed + 29)   # sampled candidates if < n_entities
         for k, v in metrics.items():
             print('[{}]{} average {}: {}'.format(0, mode, k, v))
         return metrics
@@ -376,7 +377,8 @@ class ShardedTrainer(object):
             known = tuple(np.concatenate([np.asarray(p[k]) for p in parts]) for k in range(3))
         ent, rel = self.full_tables()
         Eb = int(max(1, min(max(args.batch_size_eval, 1024), (1 << 31) // (4 * ds.n_entities), len(h))))
-        metrics = kev.evaluate(args.model_name, ent, rel, args.gamma, self.emb_init, (h, r, t), known, batch=Eb)
+        metrics = kev.evaluate(args.model_name, ent, rel, args.gamma, self.emb_init, (h, r, t), known, batch=Eb,
+                               n_cand=args.neg_sample_size_eval, chunk=args.batch_size_eval, seed=args.seed + 29)
         for k, v in metrics.items():
             print('[{}]{} average {}: {}'.format(self.rank, mode, k, v))
         return metrics

@@ -76,6 +76,21 @@ def test_train_cli_end_to_end(tmp_path, capsys, model, extra):
     assert last < first
 
 
+def test_train_cli_sampled_evaluation(tmp_path, capsys):
+    """--neg_sample_size_eval: validation / test against sampled candidates (the Freebase recipe of the reference)."""
+    from dglke_amd import train as T
+    data = str(tmp_path / "kg")
+    _planted(data)
+    T.main(["--model_name", "TransE_l2", "--format", "udd_hrt", "--dataset", "toy", "--data_path", data, "--data_files",
+            "e.dict", "r.dict", "train.txt", "valid.txt", "test.txt", "--save_path", str(tmp_path / "ckpts"), "--gpu", "0",
+            "--batch_size", "256", "--neg_sample_size", "64", "--hidden_dim", "32", "-g", "8", "--lr", "0.25", "-adv",
+            "--max_step", "600", "--log_interval", "300", "--test", "--neg_sample_size_eval", "50", "--batch_size_eval", "50",
+            "--no_save_emb"])
+    out = capsys.readouterr().out
+    mrr = float([l for l in out.split("\n") if l.startswith("[0]Test average MRR:")][0].split(":")[1])
+    assert mrr > 0.3, "sampled-candidate test MRR %.3f" % mrr          # 50 candidates: chance level is ~0.09
+
+
 def test_train_cli_host_sampler_paths(tmp_path, capsys):
     """edge importance (host plan) and a batch too large for the device sampler."""
     from dglke_amd import train as T

@@ -113,3 +113,38 @@ def test_rank_eval_argument_errors():
         rk.ranks(np.array([0]), np.array([0]), np.array([1]), False)
     rk = E.Ranker("TransE_l2", ent, rel, 1.0, 1.0)
     assert rk.ranks(np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(0, np.int64), False).shape == (0,)
+
+
+def test_sampled_candidate_ranking_is_consistent_with_full_ranking():
+    """--neg_sample_size_eval: (a) with every chunk's candidates = a permutation of ALL entities the sampled path
+    (candidate list + per-chunk filter columns) reproduces the full filtered ranking exactly; (b) with fewer
+    candidates the rank is 1 + the number of unfiltered candidates that score >= the true triple (brute force)."""
+    from dglke_amd import eval as kev
+    rng = np.random.RandomState(5)
+    n_ent, n_rel, D, E = 300, 7, 32, 90
+    ent = torch.tensor(rng.uniform(-1, 1, (n_ent, D)).astype(np.float32), device=DEV)
+    rel = torch.tensor(rng.uniform(-1, 1, (n_rel, D)).astype(np.float32), device=DEV)
+    kh, kr, kt = rng.randint(0, n_ent, 4000), rng.randint(0, n_rel, 4000), rng.randint(0, n_ent, 4000)
+    h, r, t = kh[:E].copy(), kr[:E].copy(), kt[:E].copy()
+    rk = kev.Ranker("TransE_l2", ent, rel, 8.0, 0.3, batch=32)
+    for neg_head in (False, True):
+        filt = kev.build_filter(kh, kr, kt, h, r, t, neg_head, n_rel)
+        full = rk.ranks(h, r, t, neg_head, filt).cpu().numpy()
+        perms = [rng.permutation(n_ent) for _ in range(8)]
+        got = kev.sampled_ranks(rk, h, r, t, neg_head, filt, n_ent, n_ent, 16, rng, cand_of_chunk=lambda k: perms[k]).cpu().numpy()
+        assert np.array_equal(got, full)
+        # (b) 40 candidates with replacement per chunk of 16
+        draws = [rng.randint(0, n_ent, 40) for _ in range(8)]
+        got = kev.sampled_ranks(rk, h, r, t, neg_head, filt, n_ent, 40, 16, rng, cand_of_chunk=lambda k: draws[k]).cpu().numpy()
+        _, pos = rk.ranks(h, r, t, neg_head, None, want_pos_score=True)
+        pos = pos.cpu().numpy()
+        e64, r64 = ent.cpu().numpy().astype(np.float64), rel.cpu().numpy().astype(np.float64)
+        for i in range(E):
+            cand = draws[i // 16]
+            x = e64[cand]
+            sc = 8.0 - (np.linalg.norm(x + r64[r[i]] - e64[t[i]], axis=1) if neg_head else np.linalg.norm(e64[h[i]] + r64[r[i]] - x, axis=1))
+            known = set(filt[1][filt[0][i, 0]:filt[0][i, 1]].tolist())
+            keep = np.array([c not in known for c in cand])
+            lo = 1 + int(((sc >= pos[i] + 1e-4) & keep).sum())
+            hi = 1 + int(((sc >= pos[i] - 1e-4) & keep).sum())
+            assert lo <= got[i] <= hi, (i, got[i], lo, hi)
