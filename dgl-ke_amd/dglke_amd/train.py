@@ -481,6 +481,10 @@ def main(argv=None):
     if len(args.gpu) > 1:                        # multi-GPU: one process per GPU on peer-to-peer shared tables
         if min(args.gpu) < 0:
             raise KgeError("dglke_amd trains on the GPU only: pass --gpu <ids> (there is no CPU fallback)")
+        if args.num_proc > len(args.gpu):            # reference: several trainer processes per GPU (train.py:94-100, 115-119)
+            if args.num_proc % len(args.gpu):
+                raise KgeError("--num_proc should be a multiple of the number of GPUs")
+            args.gpu = [g for g in args.gpu for _ in range(args.num_proc // len(args.gpu))]
         args.batch_size = get_compatible_batch_size(args.batch_size, args.neg_sample_size)
         args.eval_filter = not args.no_eval_filter
         args.soft_rel_part = args.strict_rel_part = False

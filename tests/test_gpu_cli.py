@@ -130,9 +130,11 @@ def test_train_cli_hogwild_lanes(tmp_path, capsys):
     assert mrr > 10 * 2.0 / 400
 
 
-def test_train_cli_multi_process_shared_tables(tmp_path):
+@pytest.mark.parametrize("extra,nproc", [([], 2), (["--num_proc", "4"], 4)], ids=["one_per_gpu", "num_proc_4"])
+def test_train_cli_multi_process_shared_tables(tmp_path, extra, nproc):
     """`--gpu 0 0`: two trainer processes (here on one GPU) on peer-to-peer shared tables - the multi-GPU mode
-    of the CLI; hipIpc mapping, sharded fused step, gather for evaluation and saving."""
+    of the CLI; hipIpc mapping, sharded fused step, gather for evaluation and saving.  `--num_proc 4` on two listed
+    GPUs = two processes per GPU like the reference (train.py:94-100, 115-119)."""
     import subprocess
     data = str(tmp_path / "kg")
     _planted(data)
@@ -141,13 +143,13 @@ def test_train_cli_multi_process_shared_tables(tmp_path):
            "valid.txt", "test.txt", "--save_path", str(tmp_path / "ckpts"), "--gpu", "0", "0", "--batch_size", "256",
            "--neg_sample_size", "64", "--hidden_dim", "32", "-g", "8", "--lr", "0.25", "-adv", "-rc", "1e-7",
            "--max_step", "600", "--log_interval", "300", "--eval_interval", "600", "--valid", "--test",
-           "--graph_steps", "100"]
+           "--graph_steps", "100"] + extra
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     out = r.stdout.decode(errors="replace")
     assert r.returncode == 0, out[-3000:]
-    for k in range(2):
+    for k in range(nproc):
         assert "[proc %d][Train](600/600) average loss:" % k in out, out[-2000:]
     assert "[0]Valid average MRR:" in out and "[0]Test average MRR:" in out
     mrr = float([l for l in out.split("\n") if l.startswith("[0]Test average MRR:")][0].split(":")[1])
@@ -156,4 +158,4 @@ def test_train_cli_multi_process_shared_tables(tmp_path):
     ent = np.load(os.path.join(save, "toy_TransE_l2_entity.npy"))
     rel = np.load(os.path.join(save, "toy_TransE_l2_relation.npy"))
     assert ent.shape == (400, 32) and rel.shape == (6, 32) and np.isfinite(ent).all()
-    assert json.load(open(os.path.join(save, "config.json")))["gpu"] == [0, 0]
+    assert json.load(open(os.path.join(save, "config.json")))["gpu"] == [0] * nproc
