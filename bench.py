@@ -311,8 +311,7 @@ def main():
         rem_graphs = {}
 
         def partial(n):                  # one sampler launch + the first n < G steps of the group
-            dbs_ = smp.sample()
-            for b in dbs_[:n]:
+            for b in smp.sample(n):       # n slots only: a 20-step run is not charged a 120-slot sampler launch
                 eng.step(b)
         if use_graph:
             for n in {args.warmup % G, args.steps % G} - {0}:

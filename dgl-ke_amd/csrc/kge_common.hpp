@@ -12,6 +12,38 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+
+// ---- developer timeline (build with -DKGE_TIMELINE; tools/timeline.py): every wavefront of the step's kernels
+// records {kernel id | hardware id, start, end} (100 MHz wall clock) into a per-translation-unit device buffer
+// at slot kid * KGE_TL_PER_KERNEL + its wavefront number.  Compiled out of the product library.
+#ifdef KGE_TIMELINE
+#define KGE_TL_PER_KERNEL 8192
+static __device__ unsigned long long *kge_tl_buf = nullptr;
+struct KgeTlScope {
+    unsigned long long t0; int kid; int wid;
+    __device__ __forceinline__ KgeTlScope(int kid_, int wid_) : kid(kid_), wid(wid_) { t0 = wall_clock64(); }
+    __device__ __forceinline__ ~KgeTlScope() {
+        if ((threadIdx.x & 63) == 0 && kge_tl_buf && wid < KGE_TL_PER_KERNEL) {
+            unsigned hw;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            unsigned long long *r = kge_tl_buf + ((size_t)kid * KGE_TL_PER_KERNEL + wid) * 4;
+            r[0] = ((unsigned long long)(xcc & 0xf) << 32) | hw;
+            r[1] = t0;
+            r[2] = wall_clock64();
+            r[3] = (unsigned long long)kid + 1;
+        }
+    }
+};
+#define KGE_TL(kid) KgeTlScope kge_tl_scope_((kid), (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)))
+#define KGE_TL_DEFINE(name) extern "C" int kge_tl_set_##name(void *p) { \
+        return hipMemcpyToSymbol(HIP_SYMBOL(kge_tl_buf), &p, sizeof(p)) == hipSuccess ? 0 : -1; }
+#else
+#define KGE_TL(kid)
+#define KGE_TL_DEFINE(name)
+#endif
+
 namespace kge {
 
 __device__ __forceinline__ float wave_sum(float v) {

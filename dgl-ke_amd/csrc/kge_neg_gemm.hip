@@ -30,6 +30,7 @@
 #include "kge_common.hpp"
 
 using namespace kge;
+KGE_TL_DEFINE(gemm)
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
@@ -54,6 +55,7 @@ __device__ __forceinline__ float sq4(const float4 &v) { return v.x * v.x + v.y *
 
 template <bool L2, bool STATS>
 __global__ __launch_bounds__(KGE_BLOCK) void neg_fwd_gemm_kernel(GemmArgs a, int ti, int tj) {
+    KGE_TL(1);
     const int lane = threadIdx.x & 63;
     const int64_t tile = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * KGE_WAVES_PER_BLOCK + (threadIdx.x >> 6);
     const int64_t ntiles = (int64_t)a.C * ti * tj;
@@ -231,6 +233,7 @@ __device__ __forceinline__ void row_stats(const GemmArgs &a, int64_t gi, int tj,
 template <bool L2, bool OTF>
 __global__ __launch_bounds__(KGE_BLOCK) void neg_bwd_gemm_kernel(GemmArgs a, int ti, int tj, int td,
                                                                  int bpA, int bpN) {
+    KGE_TL(3);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     // workgroup -> (chunk, product, 4 consecutive tiles)

@@ -11,6 +11,7 @@
 #include "kge_common.hpp"
 
 using namespace kge;
+KGE_TL_DEFINE(rowwise)
 
 #define WAVE_ID() ((int64_t)blockIdx.x * KGE_WAVES_PER_BLOCK + (threadIdx.x >> 6))
 #define LANE() (threadIdx.x & 63)
@@ -89,6 +90,7 @@ int launch_gather_rows_sharded(float *const *shard_rows, int n_shards, int64_t p
 // the shard map, no three-way loss switch) - the configuration of every single-GPU BASELINE workload
 template <int MODEL, int V, bool LEAN>
 __global__ __launch_bounds__(KGE_BLOCK) void edge_fwd_kernel(EdgeFwdArgs a_in) {
+    KGE_TL(0);
     EdgeFwdArgs a = a_in;
     if constexpr (LEAN) { a.src.em.n = 0; a.src.rm.n = 0; a.lp.genre = KGE_LOSS_LOGSIGMOID; a.row_pos = nullptr; }
     const int64_t w = WAVE_ID();
@@ -279,6 +281,7 @@ int launch_edge_fwd(const EdgeFwdArgs &a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------
 template <int MODEL, int V, bool LOCAL>       // LOCAL: un-sharded tables (no shard-map divisions compiled in)
 __global__ __launch_bounds__(KGE_BLOCK) void edge_bwd_kernel(EdgeBwdArgs a_in) {
+    KGE_TL(5);
     EdgeBwdArgs a = a_in;
     if constexpr (LOCAL) { a.src.em.n = 0; a.src.rm.n = 0; }
     const int64_t i = WAVE_ID();
@@ -590,6 +593,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void loss_kernel(LossArgs a) {
 // criterion switch, the pairwise variant and the option handling (2.1 k instructions vs ~0.7 k)
 template <int NPER, bool LEAN>
 __global__ __launch_bounds__(KGE_BLOCK) void loss_kernel_reg(LossArgs a_in) {
+    KGE_TL(2);
     LossArgs a = a_in;
     if constexpr (LEAN) {
         a.genre = KGE_LOSS_LOGSIGMOID; a.pairwise = 0; a.skip_pos = 1; a.clampv = 0.f; a.neg_copy = nullptr;
@@ -937,6 +941,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void update_kernel(UpdateArgs a, int nb_
 // instruction cache together, every launch starts cold, and the full-featured kernel was 11 k instructions.
 template <int NIT, bool SHARDED, int LEAN>      // LEAN: 0 = everything at run time, 1 = in-place + TransE fast path,
 __global__ __launch_bounds__(KGE_BLOCK) void update_kernel_reg(UpdateArgs a_in, int nb_ent) {   // 2 = in-place + per-edge gradients
+    KGE_TL(4);
     UpdateArgs a = a_in;
     if constexpr (!SHARDED) { a.em.n = 0; a.rm.n = 0; }
     if constexpr (LEAN != 0) {

@@ -494,3 +494,140 @@ def test_fused_step_random_shapes_match_oracle(seed):
         _close(eng.rel_state.cpu(), rs64, 2e-3, 1e-9, tag + " rel state")
         _close(eng.ent.cpu(), ent64, 1e-4, 5e-3 * k["lr"], tag + " entity rows")
         _close(eng.rel.cpu(), rel64, 1e-4, 5e-3 * k["lr"], tag + " relation rows")
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE configs at their REAL table sizes (cfg-C: 2.5 M entities = 4 GB, beyond Infinity Cache; cfg-R: the
+# per-GPU step of the Freebase RotatE config, D_e = 800 / D_r = 400 over >= 1 M entities).  The oracle works on
+# the compacted sub-table of the rows the step touches (same ids through a relabelling - the arithmetic does not
+# depend on the id values); the untouched part of the 3-4 GB table must stay bit-identical.
+# ---------------------------------------------------------------------------------------------
+BIG = [
+    # model, n_ent, n_rel, hidden, de, dr, B, N, gamma, lr, reg
+    ("ComplEx", 2500604, 535, 200, True, True, 1024, 256, 143.0, 0.1, 2e-6),        # cfg-C, real table size
+    ("RotatE", 1000003, 14824, 400, True, False, 1024, 256, 12.0, 0.01, 1e-7),      # cfg-R per-GPU step, D_e = 800
+    ("TransE_l2", 1000003, 1345, 400, True, True, 1000, 200, 19.9, 0.25, 1e-9),     # D_e = D_r = 800 through the GEMM path
+]
+
+
+@pytest.mark.parametrize("shape", BIG, ids=lambda s: "%s-ent%d-D%d" % (s[0], s[1], s[3] * (2 if s[4] else 1)))
+def test_fused_step_matches_oracle_at_real_table_sizes(shape):
+    from dglke_amd import plan
+    from dglke_amd.engine import StepEngine
+    model, n_ent, n_rel, hidden, de, dr, B, N, gamma, lr, reg = shape
+    cfg = O.Config(model, gamma, hidden, lr, adv=True, adv_temp=1.0, reg_coef=reg, reg_norm=3, double_ent=de, double_rel=dr)
+    torch.manual_seed(5)
+    eng = StepEngine(model, n_ent, n_rel, hidden, gamma, lr, DEV, de, dr, True, 1.0, reg, 3)
+    rng = np.random.RandomState(99)
+    for step in (1, 2):
+        bt = O.synth_batch(rng, n_ent, n_rel, B, N, N, step)
+        if step == 2:           # make the second step revisit rows the first one updated (state + row carried over)
+            bt["h"][:64] = prev["h"][:64]
+            bt["neg"][:64] = prev["neg"][:64]
+            nid, inv = np.unique(np.concatenate([bt["h"], bt["t"]]), return_inverse=True)
+            bt.update(nid=nid.astype(np.int64), h_local=inv[:B].astype(np.int64), t_local=inv[B:].astype(np.int64))
+        prev = bt
+        touched = np.unique(np.concatenate([bt["h"], bt["t"], bt["neg"]]))
+        tix = torch.from_numpy(touched).to(DEV)
+        before_ent, before_state = eng.ent.clone(), eng.ent_state.clone()
+        ent_sub = eng.ent[tix].cpu().numpy().astype(np.float64)
+        es_sub = eng.ent_state[tix].cpu().numpy().astype(np.float64)
+        rel64 = eng.rel.cpu().numpy().astype(np.float64)
+        rs64 = eng.rel_state.cpu().numpy().astype(np.float64)
+        b = plan.make_batch(bt["h"], bt["t"], bt["r"], bt["neg"], N, N, bt["neg_head"], DEV)
+        want = eng.alloc_outputs(b)
+        eng.step(b, want)
+        torch.cuda.synchronize()
+        loc = lambda x: np.searchsorted(touched, x).astype(np.int64)
+        out = O.train_step(cfg, ent_sub, es_sub, rel64, rs64, loc(bt["nid"]), bt["h_local"], bt["t_local"],
+                           bt["r"], loc(bt["neg"]), bt["neg_head"], N, N)
+        tag = "%s n_ent=%d step %d" % (model, n_ent, step)
+        _close(want["pos_score"].cpu(), out["pos_score"], 1e-4, 1e-4, tag + " pos_score")
+        _close(want["neg_score"].cpu(), out["neg_score"], 1e-4, 1e-4, tag + " neg_score")
+        l4 = eng.read_loss()
+        _close(l4[:3], out["log"][:3], 1e-4, 1e-5, tag + " loss")
+        sel = np.searchsorted(b.p["ue_id"], bt["nid"])
+        _close(want["g_pos_ent"].cpu().numpy()[sel], out["g_pos_ent"], 3e-4, grad_tol(out["g_pos_ent"]), tag + " g_pos_ent")
+        _close(want["g_neg"].cpu(), out["g_neg"], 3e-4, grad_tol(out["g_neg"]), tag + " g_neg")
+        _close(want["g_rel"].cpu(), out["g_rel"], 3e-4, grad_tol(out["g_rel"]), tag + " g_rel")
+        _close(eng.ent_state[tix].cpu(), es_sub, 2e-3, 1e-9, tag + " ent state")
+        _close(eng.rel_state.cpu(), rs64, 2e-3, 1e-9, tag + " rel state")
+        _close(eng.ent[tix].cpu(), ent_sub, 1e-4, 5e-3 * lr, tag + " entity rows")
+        _close(eng.rel.cpu(), rel64, 1e-4, 5e-3 * lr, tag + " relation rows")
+        # every row the step did not name is bit-identical
+        keep = torch.ones(n_ent, dtype=torch.bool, device=DEV)
+        keep[tix] = False
+        assert torch.equal(eng.ent[keep], before_ent[keep]), tag + ": an untouched entity row changed"
+        assert torch.equal(eng.ent_state[keep], before_state[keep]), tag + ": an untouched Adagrad state changed"
+        del before_ent, before_state, keep
+
+
+def _wide_step_case(seed):
+    """random configuration at the BASELINE row widths: hidden in {100, 200, 400}, doubled rows where the recipes double them"""
+    rng = np.random.RandomState(5000 + seed)
+    model = ["TransE_l1", "TransE_l2", "DistMult", "ComplEx", "RotatE", "SimplE"][seed % 6]
+    de = model in ("ComplEx", "RotatE", "SimplE") or bool(rng.randint(2))
+    dr = de if model != "RotatE" else False
+    hidden = int(rng.choice([100, 200, 400]))
+    chunk = int(rng.choice([8, 16, 24, 40, 64]))
+    C = int(rng.randint(1, 4))
+    N = int(rng.choice([8, 16, 20, 32, 64, 72]))
+    flags = int(rng.choice([0, 0, 0, 1, 2, 16, 32]))
+    return dict(model=model, de=de, dr=dr, hidden=hidden, chunk=chunk, C=C, N=N, flags=flags,
+                n_ent=int(rng.choice([100, 3000])), n_rel=int(rng.choice([5, 40])),
+                adv=bool(rng.randint(2)), reg=float(rng.choice([0.0, 1e-6])), gamma=float(rng.choice([12.0, 19.9])),
+                lr=float(rng.choice([0.05, 0.25])))
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("KGE_FUZZ_WIDE_N", "24"))))
+def test_fused_step_wide_rows_match_oracle(seed):
+    """fuzz at the BASELINE row widths (hidden 100 / 200 / 400, with -de [-dr]: rows of 100 .. 800 floats): selects the
+    NIT = 1 / 2 / 4 instantiations of the update kernel, the multi-slab paths of the shared-pair backward and every
+    d-tile count of the backward GEMM - two fused steps against the fp64 oracle from the same tables."""
+    from dglke_amd import plan
+    from dglke_amd.engine import StepEngine
+    k = _wide_step_case(seed)
+    nd = bool(k["flags"] & 32)
+    cfg = O.Config(k["model"], k["gamma"], k["hidden"], k["lr"], adv=k["adv"], adv_temp=1.0, reg_coef=k["reg"], reg_norm=3,
+                   double_ent=k["de"], double_rel=k["dr"], neg_deg=nd)
+    rng = np.random.RandomState(7000 + seed)
+    ent = rng.uniform(-cfg.emb_init, cfg.emb_init, size=(k["n_ent"], cfg.ent_dim)).astype(np.float32)
+    rel = rng.uniform(-cfg.emb_init, cfg.emb_init, size=(k["n_rel"], cfg.rel_dim)).astype(np.float32)
+    eng = StepEngine(k["model"], k["n_ent"], k["n_rel"], k["hidden"], k["gamma"], k["lr"], DEV, k["de"], k["dr"], k["adv"], 1.0,
+                     k["reg"], 3, flags=k["flags"])
+    eng.load_tables(ent, rel)
+    B, chunk, N = k["C"] * k["chunk"], k["chunk"], k["N"]
+    Np = chunk + N if nd else N
+    tag0 = "wide seed %d %s" % (seed, k)
+    for step in (1, 2):
+        ent64 = eng.ent.cpu().numpy().astype(np.float64)
+        rel64 = eng.rel.cpu().numpy().astype(np.float64)
+        es64 = eng.ent_state.cpu().numpy().astype(np.float64)
+        rs64 = eng.rel_state.cpu().numpy().astype(np.float64)
+        bt = O.synth_batch(rng, k["n_ent"], k["n_rel"], B, N, chunk, step)
+        b = plan.make_batch(bt["h"], bt["t"], bt["r"], bt["neg"], chunk, N, bt["neg_head"], DEV)
+        want = eng.alloc_outputs(b)
+        eng.step(b, want)
+        torch.cuda.synchronize()
+        negrows = ent64[bt["neg"]]
+        out = O.train_step(cfg, ent64, es64, rel64, rs64, bt["nid"], bt["h_local"], bt["t_local"],
+                           bt["r"], bt["neg"], bt["neg_head"], chunk, N)
+        tag = "%s step %d" % (tag0, step)
+        _close(want["pos_score"].cpu(), out["pos_score"], 1e-4, 1e-4, tag + " pos_score")
+        _close(want["neg_score"].cpu(), out["neg_score"], 1e-4, 1e-4, tag + " neg_score")
+        l4 = eng.read_loss()
+        _close(l4[:3], out["log"][:3], 1e-4, 1e-5, tag + " loss")
+        sel = np.searchsorted(b.p["ue_id"], bt["nid"])
+        _close(want["g_pos_ent"].cpu().numpy()[sel], out["g_pos_ent"], 3e-4, grad_tol(out["g_pos_ent"]), tag + " g_pos_ent")
+        gneg = want["g_neg"].cpu().numpy()
+        ref_gneg = out["g_neg"]
+        if nd:
+            gneg = gneg.reshape(-1, Np, gneg.shape[1])[:, chunk:].reshape(-1, gneg.shape[1])
+            if k["reg"] > 0:
+                ref_gneg = ref_gneg - O.reg_grad(negrows, k["reg"], 3)
+        _close(gneg, ref_gneg, 3e-4, grad_tol(out["g_neg"]), tag + " g_neg")
+        _close(want["g_rel"].cpu(), out["g_rel"], 3e-4, grad_tol(out["g_rel"]), tag + " g_rel")
+        _close(eng.ent_state.cpu(), es64, 2e-3, 1e-9, tag + " ent state")
+        _close(eng.rel_state.cpu(), rs64, 2e-3, 1e-9, tag + " rel state")
+        _close(eng.ent.cpu(), ent64, 1e-4, 5e-3 * k["lr"], tag + " entity rows")
+        _close(eng.rel.cpu(), rel64, 1e-4, 5e-3 * k["lr"], tag + " relation rows")

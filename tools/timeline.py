@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""tools/timeline.py - per-wavefront timeline of ONE strict training step (developer tool).
+
+Needs the library variant built with -DKGE_TIMELINE (tools/build_variant.sh tl -DKGE_TIMELINE) selected through
+KGE_LIB.  Every wavefront of the step's kernels writes {hardware id, start, end} on the 100 MHz wall clock; the
+buffers are read after a hipGraph replay of G steps (later steps overwrite earlier ones, so the records show the
+LAST step of the group) and summarised: when each kernel's first / median / last wavefront started and ended,
+how long the wavefronts lived, and the gaps between the kernels.
+
+    KGE_LIB=dgl-ke_amd/variants/libkge_tl.so python tools/timeline.py [--workload transe_l2_fb15k] [--flags F]
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "dgl-ke_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+import numpy as np
+import torch
+
+NAMES = {0: "edge_fwd", 1: "neg_fwd_gemm", 2: "loss", 3: "neg_bwd_gemm", 4: "update", 5: "edge_bwd", 6: "fwd_fused", 7: "aux"}
+PER = 8192
+NK = 8
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="transe_l2_fb15k")
+    ap.add_argument("--flags", type=int, default=0)
+    ap.add_argument("--graph-steps", type=int, default=20)
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--async-update", action="store_true")
+    args = ap.parse_args()
+    import bench
+    from dglke_amd import _lib
+    from dglke_amd.dataloader import DeviceSampler
+    from dglke_amd.engine import StepEngine
+    w = dict(bench.WORKLOADS[args.workload])
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    h, r, t = bench.synth_triples(w, 0)
+    eng = StepEngine(w["model"], w["n_ent"], w["n_rel"], w["hidden"], w["gamma"], w["lr"], dev, w["de"], w["dr"],
+                     w["adv"], w["adv_temp"], w["reg_coef"], w["reg_norm"], flags=args.flags)
+    lib = _lib.lib()
+    bufs = {}
+    for tu in ("rowwise", "gemm"):
+        fn = getattr(lib, "kge_tl_set_" + tu, None)
+        if fn is None:
+            raise SystemExit("library has no timeline hooks: build with -DKGE_TIMELINE and set KGE_LIB")
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p]
+        bufs[tu] = torch.zeros(NK * PER * 4, dtype=torch.int64, device=dev)
+        assert fn(bufs[tu].data_ptr()) == 0
+    G = args.graph_steps
+    smp = DeviceSampler(h, r, t, w["n_ent"], w["B"], w["N"], dev, n_slots=G, seed=0)
+    for b in smp.sample():
+        eng.step(b)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for b in smp.sample():
+            eng.step(b)
+    for _ in range(args.reps):
+        g.replay()
+    torch.cuda.synchronize()
+    rec = []
+    for tu, bf in bufs.items():
+        a = bf.cpu().numpy().reshape(NK * PER, 4)
+        a = a[a[:, 3] > 0]
+        rec.append(a)
+    a = np.concatenate(rec, 0)
+    kid = a[:, 3] - 1
+    t0 = a[:, 1].astype(np.float64) * 0.01      # us
+    t1 = a[:, 2].astype(np.float64) * 0.01
+    xcc = (a[:, 0] >> 32) & 0xf
+    order = sorted(set(kid.tolist()), key=lambda k: t0[kid == k].min())
+    # only the records of the LAST step: a kernel that did not run in the last step keeps stale records - drop
+    # everything that ended before the first kernel's earliest start
+    base = t0[kid == order[0]].min() if order else 0.0
+    print("# %s flags=%d  (times in us relative to the first wavefront of the step's first kernel; 10 ns clock)" % (args.workload, args.flags))
+    print("%-14s %6s | %7s %7s %7s | %7s %7s %7s | %6s %6s %6s | waves per XCD" % (
+        "kernel", "waves", "start0", "start50", "start99", "end1", "end50", "end100", "dur50", "dur90", "durmax"))
+    prev_end = None
+    for k in order:
+        m = kid == k
+        s, e = t0[m] - base, t1[m] - base
+        d = e - s
+        per = np.bincount(xcc[m].astype(int), minlength=8)
+        gap = "" if prev_end is None else "  gap_after_prev_end %.2f" % (s.min() - prev_end)
+        print("%-14s %6d | %7.2f %7.2f %7.2f | %7.2f %7.2f %7.2f | %6.2f %6.2f %6.2f | %s%s" % (
+            NAMES.get(int(k), str(k)), m.sum(), s.min(), np.percentile(s, 50), np.percentile(s, 99),
+            np.percentile(e, 1), np.percentile(e, 50), e.max(), np.percentile(d, 50), np.percentile(d, 90), d.max(),
+            " ".join(str(x) for x in per), gap))
+        prev_end = e.max()
+    if order:
+        print("step span (first start -> last end): %.2f us" % (t1.max() - base))
+
+
+if __name__ == "__main__":
+    main()
