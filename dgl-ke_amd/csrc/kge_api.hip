@@ -379,7 +379,7 @@ size_t kge_step_workspace_bytes(const kge_hparams *hp, int B, int C, int chunk, 
     add(B); add(CN);     // asq, bsq
     add(B); add(B);      // pos score, dpos
     add((size_t)B * N);  // S / W
-    add(B * tj16); add(B * tj16);   // partial row max / sum-exp
+    add(B * tj16); add(B * tj16); add(B * tj16);   // per-(row, 16-column tile) partials: max / sum-exp / loss
     add(B * d_e);        // GA
     add(CN * d_e);       // GN
     add(B * d_e);        // P (TransE) or GH
@@ -443,7 +443,12 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     const bool pairwise = hp->pairwise != 0;
     // which kernels run
     const bool gemm = use_mfma(hp->model, d_e, N, hp->flags);       // matrix-core negative scoring
-    const bool fused_loss = gemm && !pairwise && !nd && (hp->flags & KGE_FLAG_FUSED_LOSS) && hp->model != KGE_SIMPLE;   // loss gradient inside the bwd GEMM
+    // KGE_FLAG_FUSED_LOSS (matrix-core path, pointwise criteria): no loss kernel - the forward tiles emit the
+    // factorised gradient (kge_neg_gemm.hip).  4 launches per step instead of 5, 1.6 MB less traffic, but measured
+    // 41.7 vs 41.1 us per step at cfg-T (profiles/r02_fused_loss_experiment.txt), so it is opt-in.
+    // (RESCAL has no edge_fwd: its positive-loss part lives in the loss kernel)
+    const bool fused_loss = gemm && !pairwise && !nd && hp->model != KGE_RESCAL && (hp->flags & KGE_FLAG_FUSED_LOSS) &&
+                            neg_gemm_fused_loss_supported(chunk, N);
     const bool is_l2 = hp->model == KGE_TRANSE_L2;
     const bool transe = hp->model == KGE_TRANSE_L1 || is_l2;
     const int dmax = d_e > d_r ? d_e : d_r;
@@ -455,7 +460,7 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     float *asq = cv.f(B), *bsq = cv.f(CN);
     float *P = cv.f(B), *dP = cv.f(B);
     float *S = cv.f((size_t)B * N);
-    float *PM = cv.f((size_t)B * tj16), *PS = cv.f((size_t)B * tj16);
+    float *PM = cv.f((size_t)B * tj16), *PS = cv.f((size_t)B * tj16), *PL = cv.f((size_t)B * tj16);
     float *GA = cv.f((size_t)B * d_e), *GN = cv.f((size_t)CN * d_e);
     const bool rescal = hp->model == KGE_RESCAL;
     float *GH = cv.f((size_t)B * d_e), *GT = cv.f((size_t)B * d_e);
@@ -564,7 +569,8 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         if (dense_neg) fill_gemm(g, hp->model, C, chunk, N, d_e, hp->gamma, A, Bn, nullptr);
         else fill_gemm(g, hp->model, C, chunk, N, d_e, hp->gamma, A, tb->ent, nids);
         g.S = S; g.adv_temp = hp->adv_temp; g.asq = asq; g.bsq = bsq;
-        if (fused_loss && hp->adv) { g.PM = PM; g.PS = PS; }
+        g.lp = lp; g.w = b->edge_w;
+        if (fused_loss) { g.PM = PM; g.PS = PS; g.PL = PL; g.Sraw = out ? out->neg_score : nullptr; }
         KGE_TRY(launch_neg_fwd_gemm(g, s));
     } else {
         fill_pair(na, hp->model, C, chunk, N, d_e, hp->gamma, A, Bn, nullptr);
@@ -591,16 +597,12 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     if (transr) {
         KGE_TRY(launch_transr_bwd(tr, s));       // dq, GN, per-edge projection gradients, relation-vector gradients
     } else if (gemm) {
-        g.PM = PM; g.PS = PS;
-        g.W = fused_loss ? nullptr : S; g.Sc = S; g.pos = P; g.w = b->edge_w; g.lp = lp;
+        g.W = S; g.w = b->edge_w; g.lp = lp;      // fused loss: S holds u_ij and PM/PS/PL (set above) the partials
         g.GA = GA; g.GN = GN;
         g.reg_coef = (reg && !nd) ? hp->reg_coef : 0.f; g.reg_norm = hp->reg_norm;   // nd: the update adds it (sampled rows only)
         g.row_neg = (fused_loss && want4) ? row_neg : nullptr;
         g.acc = fused_loss ? acc : nullptr;
         KGE_TRY(launch_neg_bwd_gemm(g, s));
-        if (fused_loss && out && out->neg_score &&
-            hipMemcpyAsync(out->neg_score, S, (size_t)B * N * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
-            return fail(KGE_ERR_LAUNCH, "hipMemcpyAsync failed");
     } else {
         na.W = S; na.GA = GA; na.GN = GN;
         na.reg_coef = (reg && !nd) ? hp->reg_coef : 0.f; na.reg_norm = hp->reg_norm;

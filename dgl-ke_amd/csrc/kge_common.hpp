@@ -21,40 +21,78 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 static __device__ unsigned long long *kge_tl_buf = nullptr;
 struct KgeTlScope {
     unsigned long long t0; int kid; int wid;
-    __device__ __forceinline__ KgeTlScope(int kid_, int wid_) : kid(kid_), wid(wid_) { t0 = wall_clock64(); }
+    unsigned long long mk[4];
+    __device__ __forceinline__ KgeTlScope(int kid_, int wid_) : kid(kid_), wid(wid_) {
+        mk[0] = mk[1] = mk[2] = mk[3] = 0; t0 = wall_clock64(); }
+    // phase mark: drains the memory counters first, so the time since the previous mark is the latency of
+    // whatever was outstanding (changes the overlap - use for attribution, not for the headline time)
+    __device__ __forceinline__ void mark(int n) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        mk[n] = wall_clock64();
+    }
     __device__ __forceinline__ ~KgeTlScope() {
         if ((threadIdx.x & 63) == 0 && kge_tl_buf && wid < KGE_TL_PER_KERNEL) {
             unsigned hw;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
             unsigned xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            unsigned long long *r = kge_tl_buf + ((size_t)kid * KGE_TL_PER_KERNEL + wid) * 4;
+            unsigned long long *r = kge_tl_buf + ((size_t)kid * KGE_TL_PER_KERNEL + wid) * 8;
             r[0] = ((unsigned long long)(xcc & 0xf) << 32) | hw;
             r[1] = t0;
             r[2] = wall_clock64();
             r[3] = (unsigned long long)kid + 1;
+            r[4] = mk[0]; r[5] = mk[1]; r[6] = mk[2]; r[7] = mk[3];
         }
     }
 };
 #define KGE_TL(kid) KgeTlScope kge_tl_scope_((kid), (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)))
+#define KGE_TL_MARK(n) kge_tl_scope_.mark(n)
 #define KGE_TL_DEFINE(name) extern "C" int kge_tl_set_##name(void *p) { \
         return hipMemcpyToSymbol(HIP_SYMBOL(kge_tl_buf), &p, sizeof(p)) == hipSuccess ? 0 : -1; }
 #else
 #define KGE_TL(kid)
+#define KGE_TL_MARK(n)
 #define KGE_TL_DEFINE(name)
 #endif
 
 namespace kge {
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Wavefront reductions on DPP (data-parallel primitives: the cross-lane operand is part of the VALU
+// instruction) + v_readlane, instead of __shfl_xor butterflies: a shuffle compiles to ds_bpermute_b32 - an
+// LDS-crossbar round trip of >100 cycles - and a 64-lane butterfly is a dependent chain of six of them; with
+// one wavefront per SIMD nothing hides it (measured: 18-30 ds_bpermute per row-wise kernel, ~0.3 us per
+// reduction).  Steps: xor 1, xor 2 (quad_perm), 8-group (row_half_mirror), 16-lane row (row_mirror): every
+// lane of a row then holds the row's result; the four rows are combined through SGPRs in a fixed order.
+// Every lane returns the same value; the summation order is fixed (bit-reproducible).
+#define KGE_DPP_F(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xf, 0xf, true))
+#define KGE_DPP_QUAD_X1 0xB1      // quad_perm [1,0,3,2]
+#define KGE_DPP_QUAD_X2 0x4E      // quad_perm [2,3,0,1]
+#define KGE_DPP_HALF_MIRROR 0x141
+#define KGE_DPP_MIRROR 0x140
+__device__ __forceinline__ float readlane_f(float v, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+__device__ __forceinline__ float row_sum16(float v) {       // sum over the 16 lanes of each DPP row, in every lane
+    v += KGE_DPP_F(v, KGE_DPP_QUAD_X1);
+    v += KGE_DPP_F(v, KGE_DPP_QUAD_X2);
+    v += KGE_DPP_F(v, KGE_DPP_HALF_MIRROR);
+    v += KGE_DPP_F(v, KGE_DPP_MIRROR);
     return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+__device__ __forceinline__ float row_max16(float v) {
+    v = fmaxf(v, KGE_DPP_F(v, KGE_DPP_QUAD_X1));
+    v = fmaxf(v, KGE_DPP_F(v, KGE_DPP_QUAD_X2));
+    v = fmaxf(v, KGE_DPP_F(v, KGE_DPP_HALF_MIRROR));
+    v = fmaxf(v, KGE_DPP_F(v, KGE_DPP_MIRROR));
     return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v = row_sum16(v);
+    return (readlane_f(v, 0) + readlane_f(v, 16)) + (readlane_f(v, 32) + readlane_f(v, 48));
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = row_max16(v);
+    return fmaxf(fmaxf(readlane_f(v, 0), readlane_f(v, 16)), fmaxf(readlane_f(v, 32), readlane_f(v, 48)));
 }
 
 // row pointer with optional one-level indirection: base + (idx ? idx[i] : i) * ld
@@ -330,12 +368,15 @@ struct GemmArgs {                   // LDS-staged fp32-MFMA negative scoring (kg
     // forward
     float *S;                        // out [C,chunk,N]
     float clampv;                    // > 0: clamp the scores to [-clampv, clampv] (SimplE)
-    float *PM, *PS;                  // [C*chunk, tj16] per-16-column partial max / sum-exp of T*n, or null
+    // fused loss (PM != null; pointwise criteria): S receives u_ij = crit'(n_ij) * exp(T n_ij - m_it) (/ dist for
+    // TransE_l2) instead of the scores, and per (row, 16-column tile): PM = m_it = max_j T*n_ij (0 without -adv),
+    // PS = sum_j exp(T n_ij - m_it), PL = sum_j exp(T n_ij - m_it) * criterion(n_ij)
+    float *PM, *PS, *PL;             // [C*chunk, tj] or null
+    float *Sraw;                     // fused loss: optional copy of the raw scores [C,chunk,N] or null
     float adv_temp;
     // backward
-    const float *W;                  // explicit dL/dn (TransE_l2: already / dist) or null: on the fly
-    const float *Sc;                 // scores (on-the-fly mode)
-    const float *pos, *w;            // [B] positive scores (pairwise) / edge weights or null
+    const float *W;                  // dL/dn (TransE_l2: already / dist); with PM != null: u_ij, scaled per (row, tile) here
+    const float *w;                  // [B] edge weights or null
     LossParams lp; int B;
     float *GA, *GN;                  // out [C*chunk, D], [C*N, D]
     float reg_coef; int reg_norm;
@@ -343,6 +384,7 @@ struct GemmArgs {                   // LDS-staged fp32-MFMA negative scoring (kg
     float *acc;                      // running sums or null
 };
 bool neg_mfma_supported(int model, int d_e, int N);
+bool neg_gemm_fused_loss_supported(int chunk, int N);   // fused loss of the matrix-core path (else: stand-alone loss kernel)
 int launch_neg_fwd_gemm(const GemmArgs &a, hipStream_t s);
 int launch_neg_bwd_gemm(const GemmArgs &a, hipStream_t s);
 int launch_neg_fwd_pair(const NegArgs &a, hipStream_t s);

@@ -18,11 +18,20 @@
 // workgroup tiles (whose load -> barrier -> compute phases cannot overlap at <= 1 workgroup per
 // CU).  So: one wavefront per 16x16 (forward) / 16x64 (backward) output tile, <= 1 wavefront per
 // SIMD, register double buffering so that loads of the next group fly under the MFMAs of the
-// current one, v_mfma_f32_16x16x4_f32 (fp32 in / fp32 accumulate = exact FMA chain).  There are
-// only TWO grid-wide phases: the forward tiles also emit, per 16 columns, the partial max /
-// sum-exp of every score row; the backward wavefronts combine those partials into the softmax
-// statistics and apply the loss gradient ON THE FLY to the score fragment they load as MFMA
-// operand - the separate loss kernel, its launch boundary and the W round trip disappear.
+// current one, v_mfma_f32_16x16x4_f32 (fp32 in / fp32 accumulate = exact FMA chain).
+//
+// Fused loss (pointwise criteria; round 2): there are only TWO grid-wide phases and no loss kernel.
+// The loss gradient factorises per (row i, 16-column tile t):
+//     dL/dn_ij = crit'(n_ij) * softmax_j(T n_ij) * w_i / 2B
+//              = [ crit'(n_ij) * exp(T n_ij - m_it) ]  *  [ exp(m_it - M_i) * w_i / (2B Z_i) ]
+//              =              u_ij                     *            f_it
+// with m_it the maximum of T*n over the tile's 16 columns, M_i = max_t m_it, Z_i = sum_t s_it exp(m_it - M_i),
+// s_it = sum_{j in t} exp(T n_ij - m_it).  The forward tile knows everything in u_ij (it also folds the
+// 1/dist of the TransE_l2 chain rule in) and emits u instead of the scores, plus the partials (m, s, and
+// l_it = sum_j exp(.) * criterion(n_ij) for the loss value); the backward wavefronts combine the <= tj partials
+// of a row (a handful of exps per wavefront) and multiply the u fragment they load as MFMA operand by ONE
+// factor per (row, macro step) - no transcendental work between the MFMAs (the first fused version applied the
+// whole gradient there and was 2.5x slower), no atomics, no completion counters, bit-reproducible.
 // Negative rows are gathered straight from the entity table through neg_ids (no dense copy).
 // Fragment layout of the 16x16x4 f32 MFMA (wave64): A: lane l = A[m=l&15][k=l>>4],
 // B: lane l = B[k=l>>4][n=l&15], C/D: lane l, reg r = D[4*(l>>4)+r][l&15].  A lane loads 4
@@ -41,6 +50,9 @@ bool neg_mfma_supported(int model, int d_e, int N) {
     return d_e % 4 == 0;   // 16-byte aligned rows
 }
 
+// the fused loss keeps a [chunk][tiles] factor table in LDS and combines <= 16 partials per row in registers
+bool neg_gemm_fused_loss_supported(int chunk, int N) { return N <= 256 && chunk <= 768; }
+
 static inline int check_launch_g() { return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH; }
 __device__ __forceinline__ float4 ldg4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -53,7 +65,7 @@ __device__ __forceinline__ float sq4(const float4 &v) { return v.x * v.x + v.y *
 #define FU 2    // k-steps (of 16) per register buffer (small on purpose: code size)
 #endif
 
-template <bool L2, bool STATS>
+template <bool L2, bool FUSE>     // FUSE: emit the factorised loss gradient + per-tile partials instead of the scores
 __global__ __launch_bounds__(KGE_BLOCK) void neg_fwd_gemm_kernel(GemmArgs a, int ti, int tj) {
     KGE_TL(1);
     const int lane = threadIdx.x & 63;
@@ -100,6 +112,9 @@ __global__ __launch_bounds__(KGE_BLOCK) void neg_fwd_gemm_kernel(GemmArgs a, int
     }
 
     FWD_LOAD(a0, b0, 0);
+#ifdef KGE_TL_MARKS
+    KGE_TL_MARK(0);              // first operand fragments (and the epilogue operands) have arrived
+#endif
     for (int g = 0; g < kfull; g += 2 * FU) {
         FWD_LOAD(a1, b1, g + FU);
         FWD_MMA(a0, b0, g);
@@ -108,6 +123,9 @@ __global__ __launch_bounds__(KGE_BLOCK) void neg_fwd_gemm_kernel(GemmArgs a, int
     }
 #undef FWD_LOAD
 #undef FWD_MMA
+#ifdef KGE_TL_MARKS
+    KGE_TL_MARK(1);              // main loop done
+#endif
     if (D & 15) {   // tail k-step: lanes whose 4 floats lie beyond D contribute zeros
         float4 av = zero4(), bv = zero4();
         if (kfull * 16 + kq < D) { av = ldg4(Ap + kfull * 16); bv = ldg4(Bp + kfull * 16); }
@@ -122,31 +140,67 @@ __global__ __launch_bounds__(KGE_BLOCK) void neg_fwd_gemm_kernel(GemmArgs a, int
     const int j = jt * 16 + m;
     const bool jok = j < a.N;
     const float bsq = bsq_pre;
+    const float neg_label = a.lp.genre == KGE_LOSS_BCE ? 0.f : -1.f;
+    // The four rows of a lane are independent: every stage below runs over all four before the next stage starts,
+    // so that the dependent chains (DPP reductions, exp / log / rcp) of the rows interleave - one wavefront per
+    // SIMD has nothing else to hide a dependent VALU instruction's latency with.
+    float v[4]; bool ok[4]; int64_t so[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int i = it * 16 + q * 4 + r;
-        float v = acc0[r] + acc1[r];
-        if (L2) {
-            const float ar = asq_pre[r];
-            v = a.gamma - sqrtf(fmaxf(ar + bsq - 2.f * v, 1e-30f));
-        } else if (a.clampv > 0.f) {
-            v = fminf(fmaxf(v, -a.clampv), a.clampv);            // SimplE: th.clamp(tmp, -20, 20)
-        }
-        const bool ok = jok && i < a.chunk;
-        if (ok) a.S[((int64_t)c * a.chunk + i) * a.N + j] = v;
-        if (STATS) {
-            // max and sum-exp of T*n over this tile's 16 columns (the 16 lanes with the same q)
-            const float tn = ok ? v * a.adv_temp : -INFINITY;
-            float mx = tn;
+        float x = acc0[r] + acc1[r];
+        if (L2) x = a.gamma - sqrtf(fmaxf(asq_pre[r] + bsq - 2.f * x, 1e-30f));
+        else if (a.clampv > 0.f) x = fminf(fmaxf(x, -a.clampv), a.clampv);            // SimplE: th.clamp(tmp, -20, 20)
+        v[r] = x;
+        ok[r] = jok && i < a.chunk;
+        so[r] = ((int64_t)c * a.chunk + i) * a.N + j;
+    }
+    if (!FUSE) {
 #pragma unroll
-            for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-            float e = ok ? __expf(tn - mx) : 0.f;
+        for (int r = 0; r < 4; ++r) if (ok[r]) a.S[so[r]] = v[r];
+        return;
+    }
+    // loss.py:82-94 on this tile's 16 columns of each row (the 16 lanes with the same q are one DPP row)
+    if (a.Sraw) {
 #pragma unroll
-            for (int o = 8; o > 0; o >>= 1) e += __shfl_xor(e, o, 64);
-            if (m == 0 && i < a.chunk) {
+        for (int r = 0; r < 4; ++r) if (ok[r]) a.Sraw[so[r]] = v[r];
+    }
+    float mx[4], ex[4], nl[4], u[4], ps[4], pl[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mx[r] = (a.lp.adv && ok[r]) ? v[r] * a.adv_temp : (a.lp.adv ? -INFINITY : 0.f);
+    if (a.lp.adv) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx[r] = fmaxf(mx[r], KGE_DPP_F(mx[r], KGE_DPP_QUAD_X1));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx[r] = fmaxf(mx[r], KGE_DPP_F(mx[r], KGE_DPP_QUAD_X2));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx[r] = fmaxf(mx[r], KGE_DPP_F(mx[r], KGE_DPP_HALF_MIRROR));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx[r] = fmaxf(mx[r], KGE_DPP_F(mx[r], KGE_DPP_MIRROR));
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        ex[r] = ok[r] ? (a.lp.adv ? __expf(v[r] * a.adv_temp - mx[r]) : 1.f) : 0.f;
+        float dnl;
+        criterion_fast(a.lp.genre, v[r], neg_label, a.lp.margin, nl[r], dnl);
+        float t = dnl * ex[r];
+        if (L2) { const float d = a.gamma - v[r]; t = d > 1e-15f ? t * __frcp_rn(d) : 0.f; }   // dn/d(a-b) = -(a-b)/dist
+        else if (a.clampv > 0.f && fabsf(v[r]) >= a.clampv) t = 0.f;                            // saturated clamp: no gradient
+        u[r] = t;
+        ps[r] = ex[r]; pl[r] = ex[r] * nl[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) if (ok[r]) a.S[so[r]] = u[r];
+#define KGE_ROWSTEP(CTRL) _Pragma("unroll") for (int r = 0; r < 4; ++r) { ps[r] += KGE_DPP_F(ps[r], CTRL); pl[r] += KGE_DPP_F(pl[r], CTRL); }
+    KGE_ROWSTEP(KGE_DPP_QUAD_X1) KGE_ROWSTEP(KGE_DPP_QUAD_X2) KGE_ROWSTEP(KGE_DPP_HALF_MIRROR) KGE_ROWSTEP(KGE_DPP_MIRROR)
+#undef KGE_ROWSTEP
+    if (m == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = it * 16 + q * 4 + r;
+            if (i < a.chunk) {
                 const int64_t o = ((int64_t)c * a.chunk + i) * tj + jt;
-                a.PM[o] = mx;
-                a.PS[o] = e;
+                a.PM[o] = mx[r]; a.PS[o] = ps[r]; a.PL[o] = pl[r];
             }
         }
     }
@@ -157,7 +211,7 @@ int launch_neg_fwd_gemm(const GemmArgs &a, hipStream_t s) {
     const int64_t ntiles = (int64_t)a.C * ti * tj;
     if (ntiles == 0) return KGE_OK;
     const int nb = (int)((ntiles + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK);
-    const bool l2 = a.model == KGE_TRANSE_L2, st = a.PM != nullptr;
+    const bool l2 = a.model == KGE_TRANSE_L2, st = a.PM != nullptr;       // PM/PS/PL given: fused loss
     const dim3 g(nb), b(KGE_BLOCK);
     if (l2 && st) hipLaunchKernelGGL((neg_fwd_gemm_kernel<true, true>), g, b, 0, s, a, ti, tj);
     else if (l2) hipLaunchKernelGGL((neg_fwd_gemm_kernel<true, false>), g, b, 0, s, a, ti, tj);
@@ -179,60 +233,57 @@ int launch_neg_fwd_gemm(const GemmArgs &a, hipStream_t s) {
 #endif
 #define GB_MAXK 2048                   // rows of a chunk operand whose indices / statistics fit in LDS (32 KB)
 
-struct BwdStage { float w[4]; float4 r[4]; };
+struct BwdStage { float w[4]; float4 r[4]; float pm; };
 
-// fast logistic: 1/(1+e^-x) with the hardware exp (|rel err| ~1e-6)
-__device__ __forceinline__ float fsigmoid(float x) { return __frcp_rn(1.f + __expf(-x)); }
-
-// d criterion / d score only (fast-math version of kge::criterion)
-__device__ __forceinline__ float crit_grad(int genre, float s, float label, float margin) {
-    if (genre == KGE_LOSS_HINGE) return (margin - label * s) < 0.f ? 0.f : -label;
-    if (genre == KGE_LOSS_BCE) return fsigmoid(s) - label;
-    return -label * fsigmoid(-label * s);
-}
-
-// d loss / d n_ij of a pointwise loss (loss.py:82-94) given the row's softmax statistics:
-//   M = max_j T*n_ij,  coef = w_i / (2B) * (adv ? 1/sum_j exp(T*n_ij - M) : 1/N)
-template <bool L2>
-__device__ __forceinline__ float wgrad(const LossParams &lp, float gamma, float n, float M, float coef) {
-    const float label = lp.genre == KGE_LOSS_BCE ? 0.f : -1.f;
-    float g = crit_grad(lp.genre, n, label, lp.margin) * coef;
-    if (lp.adv) g *= __expf(n * lp.adv_temp - M);            // detached softmax weight, loss.py:88
-    if (L2) { const float d = gamma - n; g = d > 1e-15f ? g * __frcp_rn(d) : 0.f; }
-    return g;
-}
-
-// combine the per-16-column partials of one score row.  All partial loads are issued before the
-// first use (independent registers) so that they overlap instead of forming a latency chain.
+// combine the per-16-column partials of one score row (tj <= 16 tiles, i.e. N <= 256; longer rows use the stand-alone
+// loss kernel): M = max_t m_t, coef = w_i / (2B) / (adv ? Z : N).  All partial loads are issued before the first use
+// (independent registers) so that they overlap instead of forming a latency chain.
+//   LOSS: also the row's negative loss term (loss.py:87-94) from the l_t partials;
+//   fac != null: the factor f_t = exp(m_t - M) * coef of every tile is written to fac[t] (LDS, GN workgroups).
 #define GB_TJ 16
-__device__ __forceinline__ void row_stats(const GemmArgs &a, int64_t gi, int tj, float &M, float &coef) {
+template <bool LOSS>
+__device__ __forceinline__ void row_stats(const GemmArgs &a, int64_t gi, int tj, float &M, float &coef, float &lrow,
+                                          float *fac = nullptr) {
     const float w = a.w ? a.w[gi] : 1.f;
     const float base = w * 0.5f / (float)a.B;
-    if (!a.lp.adv) { M = 0.f; coef = base / (float)a.N; return; }
-    const float *pm = a.PM + gi * tj, *ps = a.PS + gi * tj;
-    float mx = -INFINITY, z = 0.f;
-    for (int k0 = 0; k0 < tj; k0 += GB_TJ) {       // one pass for N <= 256
-        float vm[GB_TJ], vs[GB_TJ];
+    const float *pm = a.PM + gi * tj, *ps = a.PS + gi * tj, *pl = a.PL + gi * tj;
+    float vm[GB_TJ], vs[GB_TJ], vl[GB_TJ];
 #pragma unroll
-        for (int k = 0; k < GB_TJ; ++k) {
-            const bool ok = k0 + k < tj;
-            vm[k] = ok ? pm[k0 + k] : -INFINITY;
-            vs[k] = ok ? ps[k0 + k] : 0.f;
-        }
-        float m2 = mx;
-#pragma unroll
-        for (int k = 0; k < GB_TJ; ++k) m2 = fmaxf(m2, vm[k]);
-        z *= __expf(mx - m2);                       // rescale the running sum (exp(-inf) = 0 on the first pass)
-#pragma unroll
-        for (int k = 0; k < GB_TJ; ++k) z += vs[k] * __expf(vm[k] - m2);
-        mx = m2;
+    for (int k = 0; k < GB_TJ; ++k) {
+        const bool ok = k < tj;
+        vm[k] = (ok && a.lp.adv) ? pm[k] : -INFINITY;
+        vs[k] = (ok && a.lp.adv) ? ps[k] : 0.f;
+        vl[k] = (LOSS && ok) ? pl[k] : 0.f;
     }
+    if (!a.lp.adv) {
+        M = 0.f; coef = base / (float)a.N;
+        if (LOSS) {
+            float l = 0.f;
+#pragma unroll
+            for (int k = 0; k < GB_TJ; ++k) l += vl[k];
+            lrow = 2.f * coef * l;
+        }
+        if (fac) for (int k = 0; k < tj; ++k) fac[k] = coef;
+        return;
+    }
+    float mx = vm[0];
+#pragma unroll
+    for (int k = 1; k < GB_TJ; ++k) mx = fmaxf(mx, vm[k]);
+    float z = 0.f, l = 0.f, e[GB_TJ];
+#pragma unroll
+    for (int k = 0; k < GB_TJ; ++k) { e[k] = __expf(vm[k] - mx); z += vs[k] * e[k]; if (LOSS) l += vl[k] * e[k]; }
     M = mx; coef = base / z;
+    if (LOSS) lrow = 2.f * coef * l;                // sum_j softmax_ij * nl_ij * w_i / B
+    if (fac) {
+#pragma unroll
+        for (int k = 0; k < GB_TJ; ++k) if (k < tj) fac[k] = e[k] * coef;
+    }
 }
+#define GB_TJP 17                      // row stride of the LDS factor table (odd: conflict-free column reads)
 
-template <bool L2, bool OTF>
+template <bool L2, bool FACT>          // FACT: the streamed weights are u_ij and get the per-(row, tile) factor here
 __global__ __launch_bounds__(KGE_BLOCK) void neg_bwd_gemm_kernel(GemmArgs a, int ti, int tj, int td,
-                                                                 int bpA, int bpN) {
+                                                                 int bpA, int bpN, int maxK) {
     KGE_TL(3);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -247,7 +298,6 @@ __global__ __launch_bounds__(KGE_BLOCK) void neg_bwd_gemm_kernel(GemmArgs a, int
     const int dt = tl % td, rt = tl / td;
     const int D = a.D, N = a.N, chunk = a.chunk;
     const int m = lane & 15, q = lane >> 4;
-    constexpr bool otf = OTF;                            // loss gradient applied on the fly to S
     const int K = isGA ? N : chunk;                      // reduction length
     const int R = isGA ? chunk : N;                      // output rows per chunk
 
@@ -256,24 +306,51 @@ __global__ __launch_bounds__(KGE_BLOCK) void neg_bwd_gemm_kernel(GemmArgs a, int
     // through neg_ids or dense; GN: positive row of the chunk).  INDICES, not pointers: a pointer read
     // back from LDS turns the row loads into flat loads, which count on lgkmcnt and serialise behind
     // every LDS wait (measured: 48 % of the wavefront time parked in s_waitcnt).
-    int64_t *rix = reinterpret_cast<int64_t *>(smem);                     // [K]
-    float2 *st = reinterpret_cast<float2 *>(smem + 2 * GB_MAXK);          // [K] (GN, fused loss only)
+    // FACT, GN: ftab[k][t] = factor f(k, t) of every positive row k of the chunk and every column tile t, computed by
+    // thread k in the same pass as the row's statistics (one dependent round; the wavefront whose output rows are
+    // column tile rt reads column rt).
+    int64_t *rix = reinterpret_cast<int64_t *>(smem);                     // [maxK]
+    float *ftab = smem + 2 * maxK;                                        // [maxK][GB_TJP]
     for (int k = threadIdx.x; k < K; k += KGE_BLOCK)
         rix[k] = isGA ? (a.nidx ? a.nidx[(int64_t)c * N + k] : (int64_t)c * N + k) : (int64_t)c * chunk + k;
-    if (!isGA && otf) {
+    if (FACT && !isGA) {
         for (int k = threadIdx.x; k < K; k += KGE_BLOCK) {
-            float M, coef;
-            row_stats(a, (int64_t)c * chunk + k, tj, M, coef);
-            st[k] = make_float2(M, coef);
+            float M, coef, lr;
+            row_stats<false>(a, (int64_t)c * chunk + k, tj, M, coef, lr, ftab + k * GB_TJP);
+        }
+    }
+    // FACT, GA: this lane's row statistics (lane m <-> output row rt*16 + m), requested BEFORE the barrier so that the
+    // partial loads fly together with the index loads above; the d-tile-0 wavefronts also reduce the row's loss term
+    float rM = 0.f, rcoef = 0.f;
+    const float *PMrow = nullptr;
+    if (FACT && isGA) {
+        const int rowg = min(rt * 16 + m, chunk - 1);
+        const int64_t gi = (int64_t)c * chunk + rowg;
+        const bool do_loss = dt == 0 && (a.row_neg || a.acc);
+        float lrow = 0.f;
+        if (do_loss) row_stats<true>(a, gi, tj, rM, rcoef, lrow);
+        else row_stats<false>(a, gi, tj, rM, rcoef, lrow);
+        PMrow = a.PM + gi * tj;
+        if (do_loss && q == 0 && tile_ok && rt * 16 + m < chunk) {
+            if (a.row_neg) a.row_neg[gi] = lrow;
+            if (a.acc) {
+                const int slot = (int)(gi & (KGE_ACC_SLOTS - 1));
+                atomicAdd(a.acc + 1 * KGE_ACC_SLOTS + slot, lrow);          // fire-and-forget; one add per slot and
+                atomicAdd(a.acc + 2 * KGE_ACC_SLOTS + slot, 0.5f * lrow);   // kernel when B <= slots: deterministic
+            }
         }
     }
     __syncthreads();
+#ifdef KGE_TL_MARKS
+    KGE_TL_MARK(0);              // index table / factor table / row statistics ready
+#endif
     if (!tile_ok) return;
+    const float *ft = ftab + rt;                         // GN: factor of reduction row k = ft[k * GB_TJP]
 
     const int d = dt * 64 + m * 4;                       // this lane's 4 output columns
     const bool dok = d < D;                              // D % 4 == 0: all-or-nothing
     const int dc = dok ? d : 0;
-    const float *Wc = (otf ? a.Sc : a.W) + (int64_t)c * chunk * N;
+    const float *Wc = a.W + (int64_t)c * chunk * N;
     const float *Ac = a.A + (int64_t)c * chunk * D;
     const int row = rt * 16 + m;
     const bool rok = row < R;
@@ -281,12 +358,6 @@ __global__ __launch_bounds__(KGE_BLOCK) void neg_bwd_gemm_kernel(GemmArgs a, int
     const bool vecW = isGA && (N % 4 == 0);
     const float *Wrow = isGA ? Wc + (int64_t)rowc * N : Wc + rowc;
     const int64_t wstride = isGA ? 1 : N;
-    // GA: this lane's row statistics; loss terms of the row are summed by the d-tile-0 wavefronts
-    float rM = 0.f, rcoef = 0.f;
-    if (otf && isGA) row_stats(a, (int64_t)c * chunk + rowc, tj, rM, rcoef);
-    const bool do_loss = otf && isGA && dt == 0 && (a.row_neg || a.acc);
-    float lsum = 0.f;
-
     f32x4 acc[4];
 #pragma unroll
     for (int s_ = 0; s_ < 4; ++s_) acc[s_] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -327,24 +398,21 @@ __global__ __launch_bounds__(KGE_BLOCK) void neg_bwd_gemm_kernel(GemmArgs a, int
                 _Pragma("unroll") for (int e = 0; e < 4; ++e)                                  \
                     ST[u].w[e] = Wq[(int64_t)(ms * 16 + e) * wstride];                         \
             }                                                                                  \
+            if (FACT && isGA) ST[u].pm = PMrow[ms];   /* macro step ms = column tile ms */     \
             _Pragma("unroll") for (int e = 0; e < 4; ++e) ST[u].r[e] = ldg4(Xb + ri[e] * D);   \
         }                                                                                      \
     }
+    // u_ij -> dL/dn_ij: one factor per (row, macro step) for GA, one LDS read of four per-row factors for GN
 #define BWD_XFORM(ST, MS0)                                                                     \
-    if (otf) {                                                                                 \
+    if (FACT) {                                                                                \
         _Pragma("unroll") for (int u = 0; u < BU; ++u) {                                       \
             if ((MS0) + u < msfull) {                                                          \
-                const int kk = ((MS0) + u) * 16 + q * 4;                                       \
-                _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                \
-                    const float n_ = ST[u].w[e];                                               \
-                    float M_ = rM, cf_ = rcoef;                                                \
-                    if (!isGA) { const float2 s2 = st[kk + e]; M_ = s2.x; cf_ = s2.y; }        \
-                    if (do_loss) {                                                             \
-                        float nl, dnl;                                                         \
-                        criterion(a.lp.genre, n_, a.lp.genre == KGE_LOSS_BCE ? 0.f : -1.f, a.lp.margin, nl, dnl); \
-                        lsum += nl * cf_ * (a.lp.adv ? __expf(n_ * a.lp.adv_temp - M_) : 1.f); \
-                    }                                                                          \
-                    ST[u].w[e] = wgrad<L2>(a.lp, a.gamma, n_, M_, cf_);                        \
+                if (isGA) {                                                                    \
+                    const float f_ = a.lp.adv ? __expf(ST[u].pm - rM) * rcoef : rcoef;         \
+                    _Pragma("unroll") for (int e = 0; e < 4; ++e) ST[u].w[e] *= f_;           \
+                } else {                                                                       \
+                    _Pragma("unroll") for (int e = 0; e < 4; ++e)                              \
+                        ST[u].w[e] *= ft[(((MS0) + u) * 16 + q * 4 + e) * GB_TJP];             \
                 }                                                                              \
             }                                                                                  \
         }                                                                                      \
@@ -364,6 +432,9 @@ __global__ __launch_bounds__(KGE_BLOCK) void neg_bwd_gemm_kernel(GemmArgs a, int
     }
 
     BWD_LOAD(s0, 0);
+#ifdef KGE_TL_MARKS
+    KGE_TL_MARK(1);              // first macro step's operands have arrived
+#endif
     for (int g = 0; g < msfull; g += 2 * BU) {
         BWD_LOAD(s1, g + BU);
         BWD_XFORM(s0, g);
@@ -375,24 +446,20 @@ __global__ __launch_bounds__(KGE_BLOCK) void neg_bwd_gemm_kernel(GemmArgs a, int
 #undef BWD_LOAD
 #undef BWD_XFORM
 #undef BWD_MMA
+#ifdef KGE_TL_MARKS
+    KGE_TL_MARK(2);              // main loop done
+#endif
     if (K & 15) {   // tail macro step: reduction indices beyond K get zero weight
         const int kk = msfull * 16 + q * 4;
+        float ftail = 1.f;
+        if (FACT && isGA) ftail = a.lp.adv ? __expf(PMrow[msfull] - rM) * rcoef : rcoef;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const bool kok = kk + e < K;
             const int kc = min(kk + e, K - 1);
             float wgt = Wrow[(int64_t)kc * wstride];
             const float4 xv = ldg4(Xb + rix[kc] * D);
-            if (otf) {
-                float M_ = rM, cf_ = rcoef;
-                if (!isGA) { const float2 s2 = st[kc]; M_ = s2.x; cf_ = s2.y; }
-                if (do_loss && kok) {
-                    float nl, dnl;
-                    criterion(a.lp.genre, wgt, a.lp.genre == KGE_LOSS_BCE ? 0.f : -1.f, a.lp.margin, nl, dnl);
-                    lsum += nl * cf_ * (a.lp.adv ? __expf(wgt * a.lp.adv_temp - M_) : 1.f);
-                }
-                wgt = wgrad<L2>(a.lp, a.gamma, wgt, M_, cf_);
-            }
+            if (FACT) wgt *= isGA ? ftail : ft[kc * GB_TJP];
             wgt = kok ? wgt : 0.f;
             wsum += wgt;
             acc[0] = MFMA16(wgt, xv.x, acc[0]);
@@ -405,22 +472,6 @@ __global__ __launch_bounds__(KGE_BLOCK) void neg_bwd_gemm_kernel(GemmArgs a, int
     // lanes with equal (lane&15) hold partial sums of the same W row/column: combine the 4 groups
     wsum += __shfl_xor(wsum, 16, 64);
     wsum += __shfl_xor(wsum, 32, 64);
-    if (do_loss) {
-        // negative loss term of the row: sum_j A_ij * nl_ij * w_i / B = 2 * sum_j nl * coef * e_ij
-        lsum += __shfl_xor(lsum, 16, 64);
-        lsum += __shfl_xor(lsum, 32, 64);
-        if (q == 0 && rok) {
-            const int64_t gi = (int64_t)c * chunk + row;
-            const float v = 2.f * lsum;
-            if (a.row_neg) a.row_neg[gi] = v;
-            if (a.acc) {
-                const bool uq = a.B <= KGE_ACC_SLOTS;
-                const int slot = (int)(gi & (KGE_ACC_SLOTS - 1));
-                float *p1 = a.acc + 1 * KGE_ACC_SLOTS + slot, *p2 = a.acc + 2 * KGE_ACC_SLOTS + slot;
-                if (uq) { *p1 += v; *p2 += 0.5f * v; } else { atomicAdd(p1, v); atomicAdd(p2, 0.5f * v); }
-            }
-        }
-    }
     const bool reg = (!isGA) && a.reg_coef > 0.f && a.reg_norm > 0;
     float *O = isGA ? a.GA : a.GN;
 #pragma unroll
@@ -447,19 +498,24 @@ __global__ __launch_bounds__(KGE_BLOCK) void neg_bwd_gemm_kernel(GemmArgs a, int
 
 int launch_neg_bwd_gemm(const GemmArgs &a, hipStream_t s) {
     if (a.C == 0) return KGE_OK;
-    if (a.W == nullptr && a.lp.pairwise) return KGE_ERR_ARG;     // on-the-fly gradient: pointwise losses
+    if (!a.W) return KGE_ERR_ARG;
+    const bool fact = a.PM != nullptr;                           // W holds u_ij: factorised fused loss
+    if (fact && (a.lp.pairwise || !a.PS || !a.PL)) return KGE_ERR_ARG;
     const int maxK = a.chunk > a.N ? a.chunk : a.N;
     if (maxK > GB_MAXK) return KGE_ERR_ARG;
     const int ti = (a.chunk + 15) / 16, tj = (a.N + 15) / 16, td = (a.D + 63) / 64;
     const int bpA = (ti * td + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK;   // workgroups per chunk, GA
     const int bpN = (tj * td + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK;
     const int nb = a.C * (bpA + bpN);
-    const size_t sm = (size_t)GB_MAXK * 16;      // row indices [GB_MAXK] int64 + row statistics [GB_MAXK] float2
-    const bool l2 = a.model == KGE_TRANSE_L2, otf = a.W == nullptr;
+    const int mk = (maxK + 3) & ~3;
+    if (fact && !neg_gemm_fused_loss_supported(a.chunk, a.N)) return KGE_ERR_ARG;
+    // row indices [mk] int64 (+ factorised: the factor table [mk][GB_TJP])
+    const size_t sm = (size_t)mk * 8 + (fact ? (size_t)mk * GB_TJP * 4 : 0);
+    const bool l2 = a.model == KGE_TRANSE_L2;
     const dim3 g(nb), b(KGE_BLOCK);
-    if (l2 && otf) hipLaunchKernelGGL((neg_bwd_gemm_kernel<true, true>), g, b, sm, s, a, ti, tj, td, bpA, bpN);
-    else if (l2) hipLaunchKernelGGL((neg_bwd_gemm_kernel<true, false>), g, b, sm, s, a, ti, tj, td, bpA, bpN);
-    else if (otf) hipLaunchKernelGGL((neg_bwd_gemm_kernel<false, true>), g, b, sm, s, a, ti, tj, td, bpA, bpN);
-    else hipLaunchKernelGGL((neg_bwd_gemm_kernel<false, false>), g, b, sm, s, a, ti, tj, td, bpA, bpN);
+    if (l2 && fact) hipLaunchKernelGGL((neg_bwd_gemm_kernel<true, true>), g, b, sm, s, a, ti, tj, td, bpA, bpN, mk);
+    else if (l2) hipLaunchKernelGGL((neg_bwd_gemm_kernel<true, false>), g, b, sm, s, a, ti, tj, td, bpA, bpN, mk);
+    else if (fact) hipLaunchKernelGGL((neg_bwd_gemm_kernel<false, true>), g, b, sm, s, a, ti, tj, td, bpA, bpN, mk);
+    else hipLaunchKernelGGL((neg_bwd_gemm_kernel<false, false>), g, b, sm, s, a, ti, tj, td, bpA, bpN, mk);
     return check_launch_g();
 }

@@ -101,6 +101,9 @@ __global__ __launch_bounds__(KGE_BLOCK) void edge_fwd_kernel(EdgeFwdArgs a_in) {
         const float *t = table_row(a.src.em, a.src.tbase, a.src.tidx, i, a.d_e);
         const float *r = table_row(a.src.rm, a.src.rbase, a.src.ridx, i, a.d_r);
         float *A = a.A ? a.A + i * (int64_t)a.d_e : nullptr;
+#ifdef KGE_TL_MARKS
+        KGE_TL_MARK(0);          // ids have arrived
+#endif
         float ps = 0.f, as = 0.f;
         if constexpr (!is_complex_model(MODEL)) {
             const int nit = a.d_e / V;
@@ -171,6 +174,9 @@ __global__ __launch_bounds__(KGE_BLOCK) void edge_fwd_kernel(EdgeFwdArgs a_in) {
                 if (A) { st<V>(A + off, are); st<V>(A + hd + off, aim); }
             }
         }
+#ifdef KGE_TL_MARKS
+        KGE_TL_MARK(1);          // rows read, pos-side vector stored
+#endif
         if (a.pos_score || a.do_pos_loss) {
             ps = wave_sum(ps);          // xor butterfly: every lane holds the sum
             float p;
@@ -613,6 +619,9 @@ __global__ __launch_bounds__(KGE_BLOCK) void loss_kernel_reg(LossArgs a_in) {
     for (int u = 0; u < NPER; ++u) { const int j = lane + 64 * u; nv[u] = (j < N && j != jd) ? n[j] : 0.f; }
     const float w = a.w ? a.w[i] : 1.f;
     const float p = a.pos[i];
+#ifdef KGE_TL_MARKS
+    KGE_TL_MARK(0);              // score row, positive score, weight have arrived
+#endif
     const float invB = 1.f / (float)a.B;
     const int slot = (int)(i & (KGE_ACC_SLOTS - 1));
     if (a.pairwise) {   // loss.py:76-80
@@ -684,6 +693,9 @@ __global__ __launch_bounds__(KGE_BLOCK) void loss_kernel_reg(LossArgs a_in) {
         }
     }
     acc = wave_sum(acc) * invB;
+#ifdef KGE_TL_MARKS
+    KGE_TL_MARK(1);              // softmax, criterion, reductions done; gradient stores acknowledged
+#endif
     if (lane == 0) {
         if (a.row_neg) a.row_neg[i] = acc;
         if (a.acc) {
@@ -973,6 +985,9 @@ __global__ __launch_bounds__(KGE_BLOCK) void update_kernel_reg(UpdateArgs a_in, 
 #endif
         float *row = shard_row(a.em, a.ent, id, d);
         float *srow = shard_state(a.em, a.ent_state, id);
+#ifdef KGE_TL_MARKS
+        KGE_TL_MARK(0);          // plan record has arrived
+#endif
         const bool has_pos = p1 > p0, has_neg = n1 > n0;
         const int nit = d >> 2;
         // first positive contribution: two source rows (fast path: P and maybe GA; generic: GH|GT)
@@ -1070,9 +1085,14 @@ __global__ __launch_bounds__(KGE_BLOCK) void update_kernel_reg(UpdateArgs a_in, 
 #pragma unroll
             for (int k = 0; k < NIT; ++k) g0[k] = zero_pack<4>();
         }
-        // two interleaved wave reductions
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64); }
+#ifdef KGE_TL_MARKS
+        KGE_TL_MARK(1);          // row + every gradient row have arrived
+#endif
+        // two wave reductions (DPP + readlane, see kge_common.hpp)
+        s0 = wave_sum(s0); s1 = wave_sum(s1);
+#ifdef KGE_TL_MARKS
+        KGE_TL_MARK(2);          // reductions done
+#endif
         s0 /= (float)d; s1 /= (float)d;
         if (a.dry) return;
         const float sA = has_pos ? st0 + s0 : st0;

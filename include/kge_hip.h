@@ -70,9 +70,11 @@ enum kge_status {
 /* matrix-core path: read the negative rows from a dense per-step copy instead of gathering them
  * from the entity table through neg_ids (tuning aid) */
 #define KGE_FLAG_DENSE_NEG 4u
-/* matrix-core path: apply the loss gradient on the fly inside the backward GEMM instead of
- * running the stand-alone loss kernel (one launch fewer; currently slower because the extra VALU
- * work sits between the MFMAs - kept for tuning) */
+/* matrix-core path, pointwise criteria, N <= 256: no stand-alone loss kernel - the forward tiles emit the
+ * factorised loss gradient u_ij + per-(row, 16-column tile) softmax partials and the backward wavefronts
+ * combine them (4 launches per TransE step instead of 5; same results within rounding).  Opt-in: on MI355X
+ * the work it moves into the two GEMM kernels costs what the loss launch cost
+ * (profiles/r02_fused_loss_experiment.txt). */
 #define KGE_FLAG_FUSED_LOSS 8u
 /* TransE_l1 / RotatE: keep the two-pass pairwise backward (GA and GN evaluated separately) instead
  * of the kernel that evaluates every (positive, negative) pair once for both products (validation aid) */

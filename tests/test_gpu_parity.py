@@ -119,7 +119,7 @@ def test_dropin_model_matches_reference(name):
     _close(m.relation_emb.emb.cpu(), z["final_relation"], 1e-4, 1e-2 * case["lr"], name + " final relation")
 
 
-@pytest.mark.parametrize("flags", [0, 1, 2], ids=["auto", "force_pairwise", "no_transe_fast"])
+@pytest.mark.parametrize("flags", [0, 1, 2, 8], ids=["auto", "force_pairwise", "no_transe_fast", "fused_loss"])
 @pytest.mark.parametrize("name", golden_names(transr=False))
 def test_fused_step_matches_reference(name, flags):
     """kge_step_fused (one call per step) vs the reference's recorded scores / gradients / tables;
@@ -128,7 +128,7 @@ def test_fused_step_matches_reference(name, flags):
     z, case = load_golden(name)
     m = build_model(case, z)
     eng = m.engine
-    eng.hp.flags = flags       # _lib.FLAG_FORCE_PAIRWISE = 1, _lib.FLAG_NO_TRANSE_FAST = 2
+    eng.hp.flags = flags       # _lib.FLAG_FORCE_PAIRWISE = 1, _lib.FLAG_NO_TRANSE_FAST = 2, _lib.FLAG_FUSED_LOSS = 8
     for s in range(1, case["steps"] + 1):
         p = "s%d_" % s
         b = golden_batch(z, case, s)
@@ -169,11 +169,14 @@ SHAPES = [
     ("RotatE", 20000, 300, 200, True, False, 512, 128, 128, 12.0, 0.01, True, 1e-7),
     ("TransE_l1", 14951, 1345, 400, False, False, 400, 200, 200, 16.0, 0.01, True, 1e-7),
     ("TransE_l2", 300, 10, 36, False, False, 120, 24, 40, 10.0, 0.1, False, 0.0),             # chunk != N, dups
+    ("DistMult", 5000, 50, 64, False, False, 128, 288, 64, 143.0, 0.08, True, 1e-6),          # N > 256: stand-alone loss kernel
+    ("TransE_l2", 5000, 50, 64, False, False, 96, 250, 48, 12.0, 0.1, True, 1e-6),            # ragged last column tile, fused loss
 ]
 
 
+@pytest.mark.parametrize("flags", [0, 8], ids=["loss_kernel", "fused_loss"])
 @pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "%s-B%d-N%d-D%d" % (s[0], s[6], s[7], s[3]))
-def test_fused_step_matches_oracle_at_config_shapes(shape):
+def test_fused_step_matches_oracle_at_config_shapes(shape, flags):
     from dglke_amd import plan
     from dglke_amd.engine import StepEngine
     model, n_ent, n_rel, hidden, de, dr, B, N, chunk, gamma, lr, adv, reg = shape
@@ -182,7 +185,7 @@ def test_fused_step_matches_oracle_at_config_shapes(shape):
     rng = np.random.RandomState(1234)
     ent = rng.uniform(-cfg.emb_init, cfg.emb_init, size=(n_ent, cfg.ent_dim)).astype(np.float32)
     rel = rng.uniform(-cfg.emb_init, cfg.emb_init, size=(n_rel, cfg.rel_dim)).astype(np.float32)
-    eng = StepEngine(model, n_ent, n_rel, hidden, gamma, lr, DEV, de, dr, adv, 1.0, reg, 3)
+    eng = StepEngine(model, n_ent, n_rel, hidden, gamma, lr, DEV, de, dr, adv, 1.0, reg, 3, flags=flags)
     eng.load_tables(ent, rel)
     for step in (1, 2):
         # the oracle runs in fp64 from the SAME fp32 tables the GPU step starts from
@@ -434,7 +437,7 @@ def _random_step_case(seed):
     chunk = int(rng.choice([1, 3, 4, 7, 8, 16, 17, 24, 32, 40]))
     C = int(rng.randint(1, 5))
     N = int(rng.choice([1, 2, 4, 5, 8, 12, 16, 20, 32, 36, 64]))
-    flags = int(rng.choice([0, 0, 1, 2, 16, 32, 33]))
+    flags = int(rng.choice([0, 0, 1, 2, 8, 10, 16, 32, 33]))
     return dict(model=model, de=de, dr=dr, hidden=hidden, chunk=chunk, C=C, N=N, flags=flags,
                 n_ent=int(rng.choice([30, 200, 2000])), n_rel=int(rng.choice([3, 17])),
                 adv=bool(rng.randint(2)), reg=float(rng.choice([0.0, 1e-4])), gamma=float(rng.choice([6.0, 12.0])),
@@ -572,7 +575,7 @@ def _wide_step_case(seed):
     chunk = int(rng.choice([8, 16, 24, 40, 64]))
     C = int(rng.randint(1, 4))
     N = int(rng.choice([8, 16, 20, 32, 64, 72]))
-    flags = int(rng.choice([0, 0, 0, 1, 2, 16, 32]))
+    flags = int(rng.choice([0, 0, 8, 8, 1, 2, 16, 32]))
     return dict(model=model, de=de, dr=dr, hidden=hidden, chunk=chunk, C=C, N=N, flags=flags,
                 n_ent=int(rng.choice([100, 3000])), n_rel=int(rng.choice([5, 40])),
                 adv=bool(rng.randint(2)), reg=float(rng.choice([0.0, 1e-6])), gamma=float(rng.choice([12.0, 19.9])),

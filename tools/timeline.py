@@ -52,7 +52,7 @@ def main():
             raise SystemExit("library has no timeline hooks: build with -DKGE_TIMELINE and set KGE_LIB")
         fn.restype = C.c_int
         fn.argtypes = [C.c_void_p]
-        bufs[tu] = torch.zeros(NK * PER * 4, dtype=torch.int64, device=dev)
+        bufs[tu] = torch.zeros(NK * PER * 8, dtype=torch.int64, device=dev)
         assert fn(bufs[tu].data_ptr()) == 0
     G = args.graph_steps
     smp = DeviceSampler(h, r, t, w["n_ent"], w["B"], w["N"], dev, n_slots=G, seed=0)
@@ -68,7 +68,7 @@ def main():
     torch.cuda.synchronize()
     rec = []
     for tu, bf in bufs.items():
-        a = bf.cpu().numpy().reshape(NK * PER, 4)
+        a = bf.cpu().numpy().reshape(NK * PER, 8)
         a = a[a[:, 3] > 0]
         rec.append(a)
     a = np.concatenate(rec, 0)
@@ -95,6 +95,15 @@ def main():
             np.percentile(e, 1), np.percentile(e, 50), e.max(), np.percentile(d, 50), np.percentile(d, 90), d.max(),
             " ".join(str(x) for x in per), gap))
         prev_end = e.max()
+        mk = a[m][:, 4:8].astype(np.float64) * 0.01
+        if (mk > 0).any():          # phase marks (KGE_TL_MARKS build): median time of each mark since the wave start
+            parts = []
+            for j in range(4):
+                ok = mk[:, j] > 0
+                if ok.any():
+                    rel = mk[ok, j] - t0[m][ok]
+                    parts.append("mark%d p50 %.2f p90 %.2f" % (j, np.percentile(rel, 50), np.percentile(rel, 90)))
+            print("               marks since wave start: " + " | ".join(parts))
     if order:
         print("step span (first start -> last end): %.2f us" % (t1.max() - base))
 
