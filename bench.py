@@ -227,6 +227,44 @@ def hogwild_measure(w, eng, dev, trainers, steps, G, flags):
             "semantics": "Hogwild: concurrent lock-free trainers on shared tables (reference --num_proc K)"}
 
 
+def async_measure(w, dev, steps, G, flags, seed=0):
+    """the --async_update pipeline (kge_step_async: the entity update of step s-1 runs on a side stream under the
+    scoring of step s; exact one-step staleness inside a group of G steps, flushed at the group's end) on its own
+    tables, same workload, sampler inside the timed region.  Reported next to the strict number, never as `value`."""
+    from dglke_amd.dataloader import DeviceSampler
+    from dglke_amd.engine import StepEngine
+    h, r, t = synth_triples(w, seed)
+    eng = StepEngine(w["model"], w["n_ent"], w["n_rel"], w["hidden"], w["gamma"], w["lr"], dev, w["de"], w["dr"], w["adv"],
+                     w["adv_temp"], w["reg_coef"], w["reg_norm"], flags=flags)
+    smp = DeviceSampler(h, r, t, w["n_ent"], w["B"], w["N"], dev, n_slots=G, seed=seed)
+    for b in smp.sample():
+        eng.step_async(b)
+    eng.flush_async()
+    torch.cuda.synchronize()
+    eng.reset_parameters()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for b in smp.sample():
+            eng.step_async(b)
+        eng.flush_async()
+    nrep = max(1, steps // G)
+    for _ in range(2):
+        g.replay()
+    torch.cuda.synchronize()
+    eng.loss_accum.zero_()
+    t0 = time.perf_counter()
+    for _ in range(nrep):
+        g.replay()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    sums = eng.read_loss_sums()
+    return {"value": round(nrep * G * w["B"] / wall, 1), "unit": "edges/s", "steps": nrep * G,
+            "us_per_step": round(1e6 * wall / (nrep * G), 3), "group": G, "mean_loss": round(sums[2] / (nrep * G), 6),
+            "relation_trace": "deferred too" if flags & 64 else "synchronous (reference: entity table only)",
+            "semantics": "--async_update: step s gathers rows that hold every update up to s-2 (exact one-step staleness, "
+                         "bit-reproducible); groups of %d steps, flushed at the end of each group" % G}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -245,6 +283,8 @@ def main():
     ap.add_argument("--host-plan", action="store_true",
                     help="pre-stage host-built batches instead of sampling on the device inside the timed region")
     ap.add_argument("--hogwild", type=int, default=4, help="also measure K concurrent Hogwild trainers (0 = skip)")
+    ap.add_argument("--no-async-update", dest="async_update", action="store_false",
+                    help="skip the --async_update pipeline measurement (reported as its own object)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -439,6 +479,12 @@ def main():
             out["hogwild"] = hogwild_measure(w, eng, dev, args.hogwild, K, max(G, 60), eng.hp.flags)
         except Exception as e:
             out["hogwild"] = {"error": repr(e)}
+    if args.async_update and dev_sampler and w["model"] not in ("RESCAL", "TransR"):
+        try:
+            out["async_update"] = async_measure(w, dev, K, G, eng.hp.flags)
+            out["async_update_rel"] = async_measure(w, dev, K, G, eng.hp.flags | 64)
+        except Exception as e:
+            out["async_update"] = {"error": repr(e)}
     if not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(w, plans)

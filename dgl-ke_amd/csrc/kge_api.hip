@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <new>
 #include "kge_common.hpp"
 
 namespace {
@@ -404,9 +405,15 @@ size_t kge_step_workspace_bytes(const kge_hparams *hp, int B, int C, int chunk, 
     return n;
 }
 
+// phases of one step.  The strict step runs all three back to back on one stream; the --async_update pipeline
+// (kge_step_async) runs PREP(s) | SCORE(s) on the caller's stream and UPDATE(s-1) on its side stream in between.
+enum { PH_PREP = 1, PH_SCORE = 2, PH_UPD_ENT = 4, PH_UPD_REL = 8, PH_UPDATE = 12, PH_ALL = 15 };
+
 static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batch *b,
                      const kge_step_out *out, const kge_emit *emit, void *ws, size_t ws_bytes,
-                     void *stream, const kge_shards *sh = nullptr) {
+                     void *stream, const kge_shards *sh = nullptr, int phases = PH_ALL,
+                     UpdateArgs *build_update = nullptr,      // PH_UPD_*: fill the launch arguments instead of launching
+                     const UpdateArgs *co_update = nullptr) { // PH_SCORE: another step's update to run alongside the backward
     if (!hp || !tb || !b || !ws) return fail(KGE_ERR_ARG, "kge_step: null argument");
     kge::ShardMap em{}, rm{};
     if (sh) {
@@ -488,6 +495,11 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     float *GNp = (neg_bwd_lc_supported(hp->model, d_e) && !(hp->flags & KGE_FLAG_TWO_PASS_PAIR))
                      ? cv.f(neg_bwd_lc_partial_floats(hp->model, C, chunk, N, d_e)) : nullptr;
     int64_t *nd_ids = nd ? reinterpret_cast<int64_t *>(cv.f(2 * (size_t)CN)) : nullptr;
+    // --async_update pipeline (phases != PH_ALL): dense copies of the h / t / r rows as PREP gathered them, for the
+    // kernels that read them again after the previous step's update has started (edge_bwd)
+    const bool need_cp = phases != PH_ALL && (!transe_fast || reg || (out && out->g_rel));
+    float *Hc = need_cp ? cv.f((size_t)B * d_e) : nullptr, *Tc = need_cp ? cv.f((size_t)B * d_e) : nullptr;
+    float *Rc = need_cp ? cv.f((size_t)B * d_r) : nullptr;
     if (!cv.ok())
         return fail(KGE_ERR_WORKSPACE, "kge_step: workspace too small (%zu < %zu)", ws_bytes,
                     kge_step_workspace_bytes(hp, B, C, chunk, b->N, b->UE, b->UR));
@@ -502,9 +514,11 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     const EdgeSrc src{tb->ent, b->h_gid, tb->ent, b->t_gid, tb->rel, b->rel_ids, em, rm};
     const int64_t *nids = b->neg_ids;                 // ids of the rows the scoring kernels treat as negatives
     if (nd) {
-        hipLaunchKernelGGL(nd_ids_kernel, dim3((unsigned)((CN + 255) / 256)), dim3(256), 0, s,
-                           b->neg_head ? b->h_gid : b->t_gid, b->neg_ids, chunk, b->N, CN, nd_ids);
-        if (hipGetLastError() != hipSuccess) return fail(KGE_ERR_LAUNCH, "nd_ids_kernel launch failed");
+        if (phases & PH_PREP) {
+            hipLaunchKernelGGL(nd_ids_kernel, dim3((unsigned)((CN + 255) / 256)), dim3(256), 0, s,
+                               b->neg_head ? b->h_gid : b->t_gid, b->neg_ids, chunk, b->N, CN, nd_ids);
+            if (hipGetLastError() != hipSuccess) return fail(KGE_ERR_LAUNCH, "nd_ids_kernel launch failed");
+        }
         nids = nd_ids;
     }
     if (transr) {
@@ -517,7 +531,18 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         tr.ur_id = b->ur_id; tr.ur_ptr = b->ur_ptr; tr.ur_edge = b->ur_edge; tr.counts_dev = b->counts_dev;
     }
     const float rot_div = rot_div_of(hp->emb_init);
+    // --async_update pipeline: everything after PREP must read the rows as PREP gathered them (the previous step's
+    // update is changing the tables meanwhile): negatives from the dense copy Bn, h / t / r from dense copies too
+    const bool async = phases != PH_ALL;
+    if (async && (sh || emit || transr || rescal))
+        return fail(KGE_ERR_ARG, "kge_step_async: not available for RESCAL / TransR and the sharded / gradient-emitting steps");
 
+    const bool dense_neg = !gemm || sh || async || (hp->flags & KGE_FLAG_DENSE_NEG);
+    const bool l2g = gemm && is_l2;                   // GEMM form of the L2 distance needs |a|^2, |b|^2
+    // rows as the scoring / gradient kernels of THIS step see them: the tables, or PREP's dense copies (async)
+    const EdgeSrc src_bwd = need_cp ? EdgeSrc{Hc, nullptr, Tc, nullptr, Rc, nullptr, kge::ShardMap{}, kge::ShardMap{}} : src;
+
+    if (phases & PH_PREP) {
     // 1. gather + positive score + pos-side vectors (+ positive-loss part, + P rows for TransE)
     EdgeFwdArgs ef{};
     ef.src = src; ef.B = B; ef.d_e = d_e; ef.d_r = d_r; ef.neg_head = b->neg_head; ef.model = hp->model;
@@ -526,9 +551,8 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     ef.nbase = tb->ent; ef.nidx = nids; ef.n_neg = CN;
     // sharded tables: the scoring kernels re-read the negative rows many times - they must come from
     // the dense local copy edge_fwd makes, never from the (remote, uncached) table rows
-    const bool dense_neg = !gemm || sh || (hp->flags & KGE_FLAG_DENSE_NEG);
     ef.Bn = dense_neg ? Bn : nullptr;                 // the pairwise kernels read a dense copy
-    const bool l2g = gemm && is_l2;                   // GEMM form of the L2 distance needs |a|^2, |b|^2
+    ef.Hc = Hc; ef.Tc = Tc; ef.Rc = Rc;
     ef.asq = l2g ? asq : nullptr; ef.bsq = l2g ? bsq : nullptr;
     ef.do_pos_loss = pairwise ? 0 : 1; ef.lp = lp; ef.w = b->edge_w;
     ef.dpos = dP; ef.row_pos = want4 ? row_pos : nullptr; ef.acc = acc;
@@ -560,7 +584,9 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     } else {
         KGE_TRY(launch_edge_fwd(ef, s));
     }
+    }   // PH_PREP
 
+    if (phases & PH_SCORE) {
     // 2. chunked negative scores (+ per-16-column partial row statistics for the adversarial softmax)
     GemmArgs g; NegArgs na;
     if (transr) {
@@ -602,8 +628,16 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         g.reg_coef = (reg && !nd) ? hp->reg_coef : 0.f; g.reg_norm = hp->reg_norm;   // nd: the update adds it (sampled rows only)
         g.row_neg = (fused_loss && want4) ? row_neg : nullptr;
         g.acc = fused_loss ? acc : nullptr;
-        KGE_TRY(launch_neg_bwd_gemm(g, s));
+        bool fused_launch = false;
+        if (co_update) {                      // async pipeline: backward GEMM(s) + update(s-1) in ONE launch
+            const int rc = launch_neg_bwd_gemm_with_update(g, *co_update, s);
+            if (rc == KGE_OK) fused_launch = true;
+            else if (rc != KGE_ERR_ARG) return fail(rc, "launch_neg_bwd_gemm_with_update failed (%d)", rc);
+            else KGE_TRY(launch_update(*co_update, s));          // no fused instantiation: one after the other
+        }
+        if (!fused_launch) KGE_TRY(launch_neg_bwd_gemm(g, s));
     } else {
+        if (co_update) KGE_TRY(launch_update(*co_update, s));
         na.W = S; na.GA = GA; na.GN = GN;
         na.reg_coef = (reg && !nd) ? hp->reg_coef : 0.f; na.reg_norm = hp->reg_norm;
         na.GNp = gemm ? nullptr : GNp;
@@ -652,7 +686,7 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         KGE_TRY(launch_rescal_update_rel(ru, s));
     } else if (!transe_fast) {
         EdgeBwdArgs eb{};
-        eb.src = src; eb.B = B; eb.d_e = d_e; eb.d_r = d_r; eb.neg_head = b->neg_head; eb.model = hp->model;
+        eb.src = src_bwd; eb.B = B; eb.d_e = d_e; eb.d_r = d_r; eb.neg_head = b->neg_head; eb.model = hp->model;
         eb.gamma = hp->gamma; eb.rot_div = rot_div;
         eb.dpos = dP; eb.GA = GA; eb.reg_coef = reg ? hp->reg_coef : 0.f; eb.reg_norm = hp->reg_norm;
         eb.GH = GH; eb.GT = GT; eb.GR = GR;
@@ -664,16 +698,21 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         // the per-edge relation gradient is not materialised on the fast path; rebuild it for the
         // caller with the generic kernel BEFORE the tables change (test / debugging output only)
         EdgeBwdArgs eb{};
-        eb.src = src; eb.B = B; eb.d_e = d_e; eb.d_r = d_r; eb.neg_head = b->neg_head; eb.model = hp->model;
+        eb.src = src_bwd; eb.B = B; eb.d_e = d_e; eb.d_r = d_r; eb.neg_head = b->neg_head; eb.model = hp->model;
         eb.gamma = hp->gamma; eb.rot_div = rot_div;
         eb.dpos = dP; eb.GA = GA; eb.reg_coef = reg ? hp->reg_coef : 0.f; eb.reg_norm = hp->reg_norm;
         eb.GH = nullptr; eb.GT = nullptr; eb.GR = out->g_rel;
         KGE_TRY(launch_edge_bwd(eb, s));
     }
+    }   // PH_SCORE
+
+    if (phases & PH_UPDATE) {
 
     // 6. owner-computes Adagrad on both tables (or gradient emission for sharded training)
     UpdateArgs ua{};
-    ua.model_d_e = d_e; ua.d_r = rescal ? d_e : d_r; ua.UE = b->UE; ua.UR = rescal ? 0 : b->UR; ua.reg_norm = hp->reg_norm;
+    ua.model_d_e = d_e; ua.d_r = rescal ? d_e : d_r; ua.reg_norm = hp->reg_norm;
+    ua.UE = (phases & PH_UPD_ENT) ? b->UE : 0;            // the async pipeline applies the two tables' traces separately
+    ua.UR = (rescal || !(phases & PH_UPD_REL)) ? 0 : b->UR;
     ua.lr = hp->lr; ua.eps = hp->eps; ua.reg_coef = reg ? hp->reg_coef : 0.f;
     ua.ent = tb->ent; ua.ent_state = tb->ent_state; ua.rel = tb->rel; ua.rel_state = tb->rel_state;
     ua.em = em; ua.rm = rm;
@@ -687,6 +726,14 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     ua.acc = acc;
     ua.ld_e = d_e; ua.ld_r = d_r; ua.ld_gs_e = 1; ua.ld_gs_r = 1;
     if (nd) { ua.nd_chunk = chunk; ua.nd_Ns = b->N; ua.nd_Np = N; }
+    if (async && reg) {
+        // the regulariser of the positive-trace rows is part of the gradient the reference computes in forward, from the
+        // rows as gathered: evaluate it on PREP's copies.  (The relation trace is only deferred with KGE_FLAG_ASYNC_REL;
+        // otherwise it lands before anything else touches the relation table and the current row IS the gathered row.)
+        if (nd) return fail(KGE_ERR_ARG, "kge_step_async: neg_deg_sample with a regulariser is not available");
+        ua.Hs = Hc; ua.Ts = Tc;
+        ua.Rs = ((hp->flags & KGE_FLAG_ASYNC_REL) && transe_fast) ? Rc : nullptr;
+    }
     if (emit) {
         ua.g0 = emit->g0; ua.gs0 = emit->gs0; ua.g1 = emit->g1; ua.gs1 = emit->gs1;
         ua.gr = emit->gr; ua.gsr = emit->gsr; ua.rid = emit->rid;
@@ -698,10 +745,11 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         if (emit && emit->ld_e > 0) return fail(KGE_ERR_ARG, "g_pos_ent output cannot be combined with a strided emit");
         ua.g0 = out->g_pos_ent;
     }
+    if (build_update) { *build_update = ua; return KGE_OK; }
     KGE_TRY(launch_update(ua, s));
     // 7. deterministic reduction of this step's loss terms (only when the caller wants the
     //    per-step values; running sums are accumulated by the kernels above without it)
-    if (want4) {
+    if (want4 && (phases & PH_UPD_ENT)) {
         FinalizeArgs f{};
         f.B = B; f.UE = b->UE; f.UR = b->UR; f.pairwise = hp->pairwise;
         f.row_pos = row_pos; f.row_neg = row_neg; f.reg_ent = reg_ent; f.reg_rel = reg_rel;
@@ -709,12 +757,90 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         f.loss4 = out->loss4;
         KGE_TRY(launch_finalize(f, s));
     }
+    }   // PH_UPDATE
     return KGE_OK;
 }
 
 int kge_step_fused(const kge_hparams *hp, const kge_tables *tb, const kge_batch *b,
                    const kge_step_out *out, void *ws, size_t ws_bytes, void *stream) {
     return step_impl(hp, tb, b, out, nullptr, ws, ws_bytes, stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// --async_update: the update of step s-1 overlaps the scoring of step s (two HIP streams)
+// ------------------------------------------------------------------------------------------
+struct kge_pipe {
+    bool pending;        // a step has been scored but its (entity) update is not enqueued yet
+    int parity;          // workspace half of the NEXT step
+    int upd_phases;      // what the pending update covers (entity trace, or entity + relation with KGE_FLAG_ASYNC_REL)
+    kge_hparams hp; kge_tables tb; kge_batch b; kge_step_out out; bool has_out;
+    void *ws; size_t ws_bytes;     // workspace half of the pending step
+};
+
+int kge_pipe_create(kge_pipe **pipe) {
+    if (!pipe) return fail(KGE_ERR_ARG, "kge_pipe_create: null argument");
+    kge_pipe *p = new (std::nothrow) kge_pipe();
+    if (!p) return fail(KGE_ERR_LAUNCH, "kge_pipe_create: out of host memory");
+    *pipe = p;
+    return KGE_OK;
+}
+
+int kge_pipe_destroy(kge_pipe *p) {
+    delete p;
+    return KGE_OK;
+}
+
+size_t kge_step_async_workspace_bytes(const kge_hparams *hp, int B, int C, int chunk, int N, int UE, int UR) {
+    // two halves (the update of step s-1 reads its gradients while step s fills the other half), each with room
+    // for the dense h / t / r copies
+    const size_t one = kge_step_workspace_bytes(hp, B, C, chunk, N, UE, UR) +
+                       2 * align_up((size_t)B * hp->d_e * sizeof(float)) + align_up((size_t)B * hp->d_r * sizeof(float));
+    return 2 * align_up(one);
+}
+
+int kge_step_async(kge_pipe *p, const kge_hparams *hp, const kge_tables *tb, const kge_batch *b,
+                   const kge_step_out *out, void *ws, size_t ws_bytes, void *stream) {
+    if (!p || !hp || !tb || !b || !ws) return fail(KGE_ERR_ARG, "kge_step_async: null argument");
+    const size_t half = (ws_bytes / 2) & ~(size_t)255;
+    void *wsp = (char *)ws + (size_t)p->parity * half;
+    // PREP(s): gathers the rows (update s-2 has landed: stream order) and makes the dense copies SCORE(s) reads
+    if (int rc = step_impl(hp, tb, b, out, nullptr, wsp, half, stream, nullptr, PH_PREP)) return rc;
+    // UPDATE(s-1) lands now, under SCORE(s): same launch as the backward GEMM where a fused instantiation exists
+    UpdateArgs co{};
+    bool have_co = false;
+    if (p->pending) {
+        p->pending = false;
+        const kge_step_out *po = p->has_out ? &p->out : nullptr;
+        if (po && po->loss4) {         // per-step loss wanted: the reduction kernel follows the update - keep them together
+            if (int rc = step_impl(&p->hp, &p->tb, &p->b, po, nullptr, p->ws, p->ws_bytes, stream, nullptr, p->upd_phases)) return rc;
+        } else {
+            if (int rc = step_impl(&p->hp, &p->tb, &p->b, po, nullptr, p->ws, p->ws_bytes, stream, nullptr, p->upd_phases, &co)) return rc;
+            have_co = true;
+        }
+    }
+    if (int rc = step_impl(hp, tb, b, out, nullptr, wsp, half, stream, nullptr, PH_SCORE, nullptr, have_co ? &co : nullptr)) return rc;
+    // the reference defers the ENTITY table only (general_models.py:639-647: create_async_update on entity_emb;
+    // relation_emb.update stays in the training loop): relation trace now
+    const bool defer_rel = (hp->flags & KGE_FLAG_ASYNC_REL) != 0;
+    if (!defer_rel)
+        if (int rc = step_impl(hp, tb, b, out, nullptr, wsp, half, stream, nullptr, PH_UPD_REL)) return rc;
+    p->upd_phases = defer_rel ? PH_UPDATE : PH_UPD_ENT;
+    p->hp = *hp; p->tb = *tb; p->b = *b; p->has_out = out != nullptr;
+    if (out) p->out = *out;
+    p->ws = wsp; p->ws_bytes = half;
+    p->pending = true;
+    p->parity ^= 1;
+    return KGE_OK;
+}
+
+int kge_step_async_flush(kge_pipe *p, void *stream) {
+    if (!p) return fail(KGE_ERR_ARG, "kge_step_async_flush: null argument");
+    if (p->pending) {
+        p->pending = false;
+        if (int rc = step_impl(&p->hp, &p->tb, &p->b, p->has_out ? &p->out : nullptr, nullptr, p->ws, p->ws_bytes, stream, nullptr,
+                               p->upd_phases)) return rc;
+    }
+    return KGE_OK;
 }
 
 int kge_step_grads(const kge_hparams *hp, const kge_tables *tb, const kge_batch *b,

@@ -252,6 +252,8 @@ struct EdgeFwdArgs {
     float *row_pos;                  // [B] per-row positive loss terms or null
     float *acc;                      // running sums or null
     float *P;                        // [B,d_e] TransE only: dpos_i * d|u_i|/du_i (u = h+r-t) or null
+    float *Hc, *Tc, *Rc;             // [B,d_e], [B,d_e], [B,d_r] dense copies of the gathered h / t / r rows or null
+                                     // (--async_update pipeline: later kernels of the step must not re-read the tables)
 };
 
 struct EdgeBwdArgs {
@@ -325,6 +327,10 @@ struct UpdateArgs {
     int32_t *rid;                    // optional relation-id words inside the relation message
     int ld_gs_e, ld_gs_r;            // strides of gs0/gs1 and gsr
     int dry;                         // tuning probe: read everything, write nothing
+    // --async_update pipeline: per-edge dense copies of the h / t / r rows AS GATHERED ([B,d_e], [B,d_e], [B,d_r]);
+    // the regulariser gradient / value of a positive-trace row is evaluated on that copy (the reference computes it in
+    // forward, from the gathered rows), not on the row as it is when the deferred update lands.  null: current rows.
+    const float *Hs, *Ts, *Rs;
     // neg_deg_sample (nd_chunk > 0): GN has nd_Np = nd_chunk + nd_Ns rows per chunk, plan slot k (sampled negative)
     // is row (k / nd_Ns) * nd_Np + nd_chunk + k % nd_Ns, and the regulariser of the negative rows is added here
     int nd_chunk, nd_Ns, nd_Np;
@@ -387,6 +393,8 @@ bool neg_mfma_supported(int model, int d_e, int N);
 bool neg_gemm_fused_loss_supported(int chunk, int N);   // fused loss of the matrix-core path (else: stand-alone loss kernel)
 int launch_neg_fwd_gemm(const GemmArgs &a, hipStream_t s);
 int launch_neg_bwd_gemm(const GemmArgs &a, hipStream_t s);
+struct UpdateArgs;
+int launch_neg_bwd_gemm_with_update(const GemmArgs &a, const UpdateArgs &u, hipStream_t s);   // KGE_ERR_ARG: no fused instantiation
 int launch_neg_fwd_pair(const NegArgs &a, hipStream_t s);
 int launch_neg_bwd_pair(const NegArgs &a, hipStream_t s);
 // ---- RESCAL (kge_rescal.hip) ----

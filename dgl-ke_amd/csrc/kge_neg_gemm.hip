@@ -37,6 +37,7 @@
 // B: lane l = B[k=l>>4][n=l&15], C/D: lane l, reg r = D[4*(l>>4)+r][l&15].  A lane loads 4
 // consecutive k (one float4) and feeds element e to MFMA step e.
 #include "kge_common.hpp"
+#include "kge_update_body.hpp"
 
 using namespace kge;
 KGE_TL_DEFINE(gemm)
@@ -281,14 +282,14 @@ __device__ __forceinline__ void row_stats(const GemmArgs &a, int64_t gi, int tj,
 }
 #define GB_TJP 17                      // row stride of the LDS factor table (odd: conflict-free column reads)
 
+// `bid` / `nblk`: this workgroup's index and the number of workgroups doing GEMM work (the body is also one half of the
+// horizontally fused launch below)
 template <bool L2, bool FACT>          // FACT: the streamed weights are u_ij and get the per-(row, tile) factor here
-__global__ __launch_bounds__(KGE_BLOCK) void neg_bwd_gemm_kernel(GemmArgs a, int ti, int tj, int td,
-                                                                 int bpA, int bpN, int maxK) {
-    KGE_TL(3);
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+__device__ __forceinline__ void neg_bwd_gemm_body(const GemmArgs &a, int ti, int tj, int td, int bpA, int bpN, int maxK,
+                                                  int bid, int nblk, float *smem) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     // workgroup -> (chunk, product, 4 consecutive tiles)
-    const int blk = xcd_remap(blockIdx.x, gridDim.x);
+    const int blk = xcd_remap(bid, nblk);
     const int c = blk / (bpA + bpN);
     const int bc = blk % (bpA + bpN);
     const bool isGA = bc < bpA;
@@ -341,9 +342,6 @@ __global__ __launch_bounds__(KGE_BLOCK) void neg_bwd_gemm_kernel(GemmArgs a, int
         }
     }
     __syncthreads();
-#ifdef KGE_TL_MARKS
-    KGE_TL_MARK(0);              // index table / factor table / row statistics ready
-#endif
     if (!tile_ok) return;
     const float *ft = ftab + rt;                         // GN: factor of reduction row k = ft[k * GB_TJP]
 
@@ -432,9 +430,6 @@ __global__ __launch_bounds__(KGE_BLOCK) void neg_bwd_gemm_kernel(GemmArgs a, int
     }
 
     BWD_LOAD(s0, 0);
-#ifdef KGE_TL_MARKS
-    KGE_TL_MARK(1);              // first macro step's operands have arrived
-#endif
     for (int g = 0; g < msfull; g += 2 * BU) {
         BWD_LOAD(s1, g + BU);
         BWD_XFORM(s0, g);
@@ -446,9 +441,6 @@ __global__ __launch_bounds__(KGE_BLOCK) void neg_bwd_gemm_kernel(GemmArgs a, int
 #undef BWD_LOAD
 #undef BWD_XFORM
 #undef BWD_MMA
-#ifdef KGE_TL_MARKS
-    KGE_TL_MARK(2);              // main loop done
-#endif
     if (K & 15) {   // tail macro step: reduction indices beyond K get zero weight
         const int kk = msfull * 16 + q * 4;
         float ftail = 1.f;
@@ -496,6 +488,33 @@ __global__ __launch_bounds__(KGE_BLOCK) void neg_bwd_gemm_kernel(GemmArgs a, int
     }
 }
 
+template <bool L2, bool FACT>
+__global__ __launch_bounds__(KGE_BLOCK) void neg_bwd_gemm_kernel(GemmArgs a, int ti, int tj, int td,
+                                                                 int bpA, int bpN, int maxK) {
+    KGE_TL(3);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    neg_bwd_gemm_body<L2, FACT>(a, ti, tj, td, bpA, bpN, maxK, (int)blockIdx.x, (int)gridDim.x, smem);
+}
+
+// --async_update pipeline, horizontal fusion: ONE launch whose first nbG workgroups are the backward GEMM tiles of step s
+// and whose remaining workgroups apply the Adagrad update of step s-1 (different workspace half, different work: the
+// update is row read-modify-write traffic, the GEMM tiles sit on the matrix pipe and on L2 operand delivery).  The two
+// halves share nothing; stream order gives the pipeline its dependencies (PREP(s) before, PREP(s+1) after), so no second
+// stream and no events are needed - cross-stream dependencies inside a hipGraph cost 9-15 us of dispatch gaps per step on
+// this stack (profiles/r02_async_pipeline.txt), more than the update they were meant to hide.
+template <bool L2, int NIT, int LEAN>
+__global__ __launch_bounds__(KGE_BLOCK) void neg_bwd_update_kernel(GemmArgs a, int ti, int tj, int td, int bpA, int bpN,
+                                                                   int maxK, int nbG, UpdateArgs u, int nb_ent) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    if ((int)blockIdx.x < nbG) {
+        KGE_TL(3);
+        neg_bwd_gemm_body<L2, false>(a, ti, tj, td, bpA, bpN, maxK, (int)blockIdx.x, nbG, smem);
+    } else {
+        KGE_TL(4);
+        update_reg_body<NIT, false, LEAN>(u, nb_ent, (int)blockIdx.x - nbG, (int)gridDim.x - nbG);
+    }
+}
+
 int launch_neg_bwd_gemm(const GemmArgs &a, hipStream_t s) {
     if (a.C == 0) return KGE_OK;
     if (!a.W) return KGE_ERR_ARG;
@@ -517,5 +536,36 @@ int launch_neg_bwd_gemm(const GemmArgs &a, hipStream_t s) {
     else if (l2) hipLaunchKernelGGL((neg_bwd_gemm_kernel<true, false>), g, b, sm, s, a, ti, tj, td, bpA, bpN, mk);
     else if (fact) hipLaunchKernelGGL((neg_bwd_gemm_kernel<false, true>), g, b, sm, s, a, ti, tj, td, bpA, bpN, mk);
     else hipLaunchKernelGGL((neg_bwd_gemm_kernel<false, false>), g, b, sm, s, a, ti, tj, td, bpA, bpN, mk);
+    return check_launch_g();
+}
+
+// backward GEMM of one step + Adagrad update of ANOTHER step in one launch (see neg_bwd_update_kernel).
+// Returns KGE_ERR_ARG when the combination has no fused instantiation (the caller then launches the two kernels apart).
+int launch_neg_bwd_gemm_with_update(const GemmArgs &a, const UpdateArgs &u, hipStream_t s) {
+    if (a.C == 0 || !a.W || a.PM) return KGE_ERR_ARG;
+    const int maxK = a.chunk > a.N ? a.chunk : a.N;
+    if (maxK > GB_MAXK) return KGE_ERR_ARG;
+    const int dmax = u.model_d_e > u.d_r ? u.model_d_e : u.d_r;
+    const bool inplace = !u.emit_ent && !u.emit_rel && !u.g0 && !u.g1 && !u.gs0 && !u.gs1 && !u.gr && !u.gsr && !u.rid &&
+                         !u.dry && !u.nd_chunk && u.em.n == 0 && u.rm.n == 0;
+    if (!inplace || u.model_d_e % 4 || u.d_r % 4 || dmax > 1024) return KGE_ERR_ARG;
+    const int nbE = (u.UE + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK, nbR = (u.UR + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK;
+    if (nbE + nbR == 0) return KGE_ERR_ARG;
+    const int ti = (a.chunk + 15) / 16, tj = (a.N + 15) / 16, td = (a.D + 63) / 64;
+    const int bpA = (ti * td + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK;
+    const int bpN = (tj * td + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK;
+    const int nbG = a.C * (bpA + bpN);
+    const int mk = (maxK + 3) & ~3;
+    const size_t sm = (size_t)mk * 8;
+    const bool l2 = a.model == KGE_TRANSE_L2;
+    const int nit = dmax <= 256 ? 1 : (dmax <= 512 ? 2 : 4);
+    const int lean = u.transe_fast ? 1 : 2;
+    const dim3 g(nbG + nbE + nbR), b(KGE_BLOCK);
+#define KGE_BU(L2_, N_, LE_) hipLaunchKernelGGL((neg_bwd_update_kernel<L2_, N_, LE_>), g, b, sm, s, a, ti, tj, td, bpA, bpN, mk, nbG, u, nbE)
+#define KGE_BU_N(N_) do { if (l2) { if (lean == 1) KGE_BU(true, N_, 1); else KGE_BU(true, N_, 2); }           \
+                          else { if (lean == 1) KGE_BU(false, N_, 1); else KGE_BU(false, N_, 2); } } while (0)
+    if (nit == 1) KGE_BU_N(1); else if (nit == 2) KGE_BU_N(2); else KGE_BU_N(4);
+#undef KGE_BU_N
+#undef KGE_BU
     return check_launch_g();
 }

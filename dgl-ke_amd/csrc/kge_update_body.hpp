@@ -1,0 +1,311 @@
+// kge_update_body.hpp - device body of the register-resident owner-computes Adagrad kernel (ExternalEmbedding.update,
+// models/pytorch/tensor_models.py:304-362), shared by the stand-alone update kernel (kge_rowwise.hip) and the
+// horizontally fused "backward GEMM of step s + entity update of step s-1" launch of the --async_update pipeline
+// (kge_neg_gemm.hip).
+#pragma once
+#include "kge_common.hpp"
+
+#ifndef LANE
+#define LANE() (threadIdx.x & 63)
+#endif
+// running-sum slot update: a fire-and-forget hardware float atomic (global_atomic_add_f32, no return value).
+// A plain read-modify-write costs a dependent global load - one more ~1.5 us round trip at the end of every
+// wavefront's chain (update kernel 15.7 -> see profiles/r01_microbench_mi355x.txt).  The result is still
+// deterministic whenever `unique` holds (every slot gets at most ONE add per kernel, kernels are stream
+// ordered): a single atomic add performs exactly old + v.
+__device__ __forceinline__ void acc_add(float *p, float v, bool unique) {
+    (void)unique;
+    atomicAdd(p, v);
+}
+
+// single-pass variant: the row and its gradients stay in registers (row width <= 256*NIT floats),
+// so every table row is read once and written once - the algorithmic minimum.  Memory-level
+// parallelism: one 32-byte plan record per row gives the row id, the list bounds AND the first
+// list entries, so that the row itself and its first positive / negative gradient rows are
+// requested together (one dependent round instead of five); longer lists continue in loops.
+// SHARDED: rows resolved through the shard map (two 64-bit divisions per wavefront otherwise compiled in);
+// LEAN: the common fused-step case - TransE fast path, tables updated in place, no gradient outputs - with the
+// generic / emitting code removed at compile time.  Code size matters: the five kernels of a step do not fit the
+// instruction cache together, every launch starts cold, and the full-featured kernel was 11 k instructions.
+// `bid` / `nblk`: this workgroup's index and the number of workgroups doing update work (the body also runs as one
+// half of a horizontally fused launch, see neg_bwd_update_kernel in kge_neg_gemm.hip).
+template <int NIT, bool SHARDED, int LEAN>      // LEAN: 0 = everything at run time, 1 = in-place + TransE fast path,
+__device__ __forceinline__ void update_reg_body(const UpdateArgs &a_in, int nb_ent, int bid, int nblk) {   // 2 = in-place + per-edge gradients
+    using namespace kge;
+    UpdateArgs a = a_in;
+    if constexpr (!SHARDED) { a.em.n = 0; a.rm.n = 0; }
+    if constexpr (LEAN != 0) {
+        a.transe_fast = LEAN == 1 ? 1 : 0; a.emit_ent = 0; a.emit_rel = 0;
+        a.g0 = a.g1 = a.gs0 = a.gs1 = a.gr = a.gsr = nullptr; a.rid = nullptr; a.dry = 0; a.nd_chunk = 0;
+    }
+    const int lane = LANE();
+    const bool reg = a.reg_coef > 0.f && a.reg_norm > 0;
+    // the (fewer) relation workgroups are dispatched FIRST: measured 14.9 vs 16.5 us - a relation wavefront has
+    // the same dependent-load chain as an entity wavefront and must not start after all entity workgroups
+    const int nb_rel = nblk - nb_ent;
+    const int bx = bid < nb_rel ? bid + nb_ent : bid - nb_rel;
+    if (bx < nb_ent) {
+#ifdef UPD_PROBE_NOENT
+        return;
+#endif
+        const int64_t u = (int64_t)bx * KGE_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+        if (u >= (a.counts_dev ? a.counts_dev[0] : a.UE)) return;
+        const int d = a.model_d_e;
+        const int4 r0 = reinterpret_cast<const int4 *>(a.ue_rec)[2 * u];
+        const int4 r1 = reinterpret_cast<const int4 *>(a.ue_rec)[2 * u + 1];
+        const int64_t id = (int64_t)(uint32_t)r0.x | ((int64_t)r0.y << 32);
+#if defined(UPD_PROBE_NOGRAD)      // tuning probe: table read-modify-write only (no gradient rows)
+        const int p0 = 0, p1 = 0, n0 = 0, n1 = 0, adj0 = 0, slot0 = 0; (void)r1;
+#elif defined(UPD_PROBE_NONEG)     // tuning probe: no negative-gradient rows
+        const int p0 = r0.z, p1 = r0.w, n0 = 0, n1 = 0, adj0 = r1.z, slot0 = 0;
+#else
+        const int p0 = r0.z, p1 = r0.w, n0 = r1.x, n1 = r1.y, adj0 = r1.z, slot0 = r1.w;
+#endif
+        float *row = shard_row(a.em, a.ent, id, d);
+        float *srow = shard_state(a.em, a.ent_state, id);
+        const bool has_pos = p1 > p0, has_neg = n1 > n0;
+        const int nit = d >> 2;
+        // first positive contribution: two source rows (fast path: P and maybe GA; generic: GH|GT)
+        const int64_t e0 = has_pos ? (int64_t)(adj0 >> 1) * d : 0;
+        const int side0 = adj0 & 1;
+        const bool ga0 = a.transe_fast && has_pos && side0 == a.neg_head;
+        const float sg0 = a.transe_fast ? (side0 ? 1.f : -1.f) : 1.f;
+        const float *pA = !has_pos ? row : (a.transe_fast ? a.P + e0 : (side0 ? a.GT : a.GH) + e0);
+        const float *pB = ga0 ? a.GA + e0 : pA;          // aliases pA when unused (same lines, no extra traffic)
+        const float *pC = has_neg ? a.GN + gn_row(a, slot0) * d : row;
+        // row the regulariser is evaluated on: as gathered by this step (async pipeline) or as it is now
+        const float *pX = (a.Hs && has_pos) ? (side0 ? a.Ts : a.Hs) + e0 : row;
+        const bool ndreg = a.nd_chunk && reg;       // neg_deg_sample: regulariser of the negative rows added here
+        const float st0 = *srow;
+        // the rest of the two lists (entries 1..) is requested NOW, one entry per lane, together with the
+        // rows above: a serial "load index -> load row" chain per extra entry made the longest list set the
+        // kernel time (8 of 16 us came from the few rows with 3-5 contributions)
+        const int npx = p1 - p0 - 1, nnx = n1 - n0 - 1;
+        const int adjv = lane < npx ? a.ue_pos_adj[p0 + 1 + lane] : 0;
+        const int slotv = lane < nnx ? a.ue_neg_slot[n0 + 1 + lane] : 0;
+        Pack<4> x[NIT], g0[NIT], g1[NIT];
+        float rv = 0.f, s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int it = lane + 64 * k;
+            if (it < nit) {
+                x[k] = ld<4>(row + it * 4);
+                const Pack<4> va = ld<4>(pA + it * 4), vb = ld<4>(pB + it * 4), vc = ld<4>(pC + it * 4);
+                const Pack<4> xr = ld<4>(pX + it * 4);      // aliases the row itself outside the async pipeline
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float g = 0.f;
+                    if (reg) { rv += reg_val(xr.v[e], a.reg_norm); g = reg_grad(xr.v[e], a.reg_coef, a.reg_norm); }
+                    if (has_pos) g += sg0 * va.v[e] + (ga0 ? vb.v[e] : 0.f);
+                    g0[k].v[e] = g;
+                    float gn = has_neg ? vc.v[e] : 0.f;
+                    if (ndreg && has_neg) gn += reg_grad(x[k].v[e], a.reg_coef, a.reg_norm);
+                    g1[k].v[e] = gn;
+                    s1 += gn * gn;
+                }
+            } else { x[k] = zero_pack<4>(); g0[k] = zero_pack<4>(); g1[k] = zero_pack<4>(); }
+        }
+#pragma unroll 1
+        for (int i = 0; i < npx; ++i) {
+            const int adj = i < 64 ? __builtin_amdgcn_readlane(adjv, i) : a.ue_pos_adj[p0 + 1 + i];
+            const int64_t eo = (int64_t)(adj >> 1) * d;
+            const int side = adj & 1;
+            if (a.transe_fast) {
+                const float sg = side ? 1.f : -1.f;
+                const bool withGA = side == a.neg_head;
+#pragma unroll
+                for (int k = 0; k < NIT; ++k) {
+                    const int it = lane + 64 * k;
+                    if (it < nit) {
+                        const Pack<4> g = ld<4>(a.P + eo + it * 4);
+                        const Pack<4> g2 = ld<4>((withGA ? a.GA : a.P) + eo + it * 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) g0[k].v[e] += sg * g.v[e] + (withGA ? g2.v[e] : 0.f);
+                    }
+                }
+            } else {
+                const float *src = (side ? a.GT : a.GH) + eo;
+#pragma unroll
+                for (int k = 0; k < NIT; ++k) {
+                    const int it = lane + 64 * k;
+                    if (it < nit) {
+                        const Pack<4> g = ld<4>(src + it * 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) g0[k].v[e] += g.v[e];
+                    }
+                }
+            }
+        }
+#pragma unroll 1
+        for (int i = 0; i < nnx; ++i) {
+            const int slot = i < 64 ? __builtin_amdgcn_readlane(slotv, i) : a.ue_neg_slot[n0 + 1 + i];
+            const float *src = a.GN + gn_row(a, slot) * d;
+#pragma unroll
+            for (int k = 0; k < NIT; ++k) {
+                const int it = lane + 64 * k;
+                if (it < nit) {
+                    Pack<4> g = ld<4>(src + it * 4);
+                    if (ndreg) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) g.v[e] += reg_grad(x[k].v[e], a.reg_coef, a.reg_norm);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { s1 += g.v[e] * g.v[e]; g1[k].v[e] += g.v[e]; }
+                }
+            }
+        }
+        if (has_pos) {
+#pragma unroll
+            for (int k = 0; k < NIT; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s0 += g0[k].v[e] * g0[k].v[e];
+        } else {
+#pragma unroll
+            for (int k = 0; k < NIT; ++k) g0[k] = zero_pack<4>();
+        }
+        // two wave reductions (DPP + readlane, see kge_common.hpp)
+        s0 = wave_sum(s0); s1 = wave_sum(s1);
+        s0 /= (float)d; s1 /= (float)d;
+        if (a.dry) return;
+        const float sA = has_pos ? st0 + s0 : st0;
+        const float sB = has_neg ? sA + s1 : sA;
+        // one division per row (-lr / std), then multiply-adds: 24 IEEE division sequences per wavefront were
+        // 10 % of this kernel's instructions (<= 1 ulp from the reference's per-element division)
+        const float k0 = -a.lr / (sqrtf(sA) + a.eps), k1 = -a.lr / (sqrtf(sB) + a.eps);
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int it = lane + 64 * k;
+            if (it < nit) {
+                if (!a.emit_ent) {
+                    Pack<4> y = x[k];
+                    if (has_pos) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) y.v[e] = fmaf(g0[k].v[e], k0, y.v[e]);
+                    }
+                    if (has_neg) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) y.v[e] = fmaf(g1[k].v[e], k1, y.v[e]);
+                    }
+                    st<4>(row + it * 4, y);
+                }
+                if (a.g0) st<4>(a.g0 + u * (int64_t)a.ld_e + it * 4, g0[k]);
+                if (a.g1) st<4>(a.g1 + u * (int64_t)a.ld_e + it * 4, g1[k]);
+            }
+        }
+        if (lane == 0) {
+            if (!a.emit_ent) *srow = sB;
+            if (a.gs0) a.gs0[u * (int64_t)a.ld_gs_e] = has_pos ? s0 : 0.f;
+            if (a.gs1) a.gs1[u * (int64_t)a.ld_gs_e] = has_neg ? s1 : 0.f;
+        }
+#ifdef UPD_PROBE_NOACC
+        if (false) {
+#else
+        if (reg && (a.reg_ent || a.acc)) {
+#endif
+            rv = wave_sum(rv);
+            const float val = a.reg_coef * rv * (float)((has_pos ? 1 : 0) + (n1 - n0));
+            if (lane == 0) {
+                if (a.reg_ent) a.reg_ent[u] = val;
+                if (a.acc) acc_add(&a.acc[3 * KGE_ACC_SLOTS + (int)(u & (KGE_ACC_SLOTS - 1))], val, a.UE + a.UR <= KGE_ACC_SLOTS);
+            }
+        } else if (a.reg_ent && lane == 0) a.reg_ent[u] = 0.f;
+    } else {
+#ifdef UPD_PROBE_NOREL
+        return;
+#endif
+        const int64_t u = ((int64_t)bx - nb_ent) * KGE_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+        if (u >= (a.counts_dev ? a.counts_dev[1] : a.UR)) return;
+        const int d = a.d_r;
+        const int4 r0 = reinterpret_cast<const int4 *>(a.ur_rec)[2 * u];
+        const int4 r1 = reinterpret_cast<const int4 *>(a.ur_rec)[2 * u + 1];
+        const int64_t id = (int64_t)(uint32_t)r0.x | ((int64_t)r0.y << 32);
+        const int e0 = r0.z, e1 = r0.w, edge0 = r1.x;
+        float *row = shard_row(a.rm, a.rel, id, d);
+        float *srow = shard_state(a.rm, a.rel_state, id);
+        const float st0 = *srow;
+        const int nex = e1 - e0 - 1;
+        const int edgev = lane < nex ? a.ur_edge[e0 + 1 + lane] : 0;     // rest of the edge list, one entry per lane
+        const int nit = d >> 2;
+        const float sgr = a.neg_head ? -1.f : 1.f;       // TransE fast path: GR = -P +/- GA + regulariser
+        const int64_t eo0 = (int64_t)edge0 * d;
+        const float *pA = a.transe_fast ? a.P + eo0 : a.GR + eo0;
+        const float *pB = a.transe_fast ? a.GA + eo0 : pA;
+        const float *pX = a.Rs ? a.Rs + eo0 : row;        // row the regulariser is evaluated on (see the entity part)
+        Pack<4> x[NIT], gsum[NIT], xr[NIT];
+        float rv = 0.f, ss = 0.f;
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int it = lane + 64 * k;
+            if (it < nit) {
+                x[k] = ld<4>(row + it * 4);
+                const Pack<4> va = ld<4>(pA + it * 4), vb = ld<4>(pB + it * 4);
+                xr[k] = ld<4>(pX + it * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (reg) rv += reg_val(xr[k].v[e], a.reg_norm);
+                    float g;
+                    if (a.transe_fast) {
+                        g = sgr * vb.v[e] - va.v[e];
+                        if (reg) g += reg_grad(xr[k].v[e], a.reg_coef, a.reg_norm);
+                    } else g = va.v[e];
+                    ss += g * g;
+                    gsum[k].v[e] = g;
+                }
+            } else { x[k] = zero_pack<4>(); gsum[k] = zero_pack<4>(); xr[k] = zero_pack<4>(); }
+        }
+#pragma unroll 1
+        for (int i = 0; i < nex; ++i) {
+            const int64_t eo = (int64_t)(i < 64 ? __builtin_amdgcn_readlane(edgev, i) : a.ur_edge[e0 + 1 + i]) * d;
+#pragma unroll
+            for (int k = 0; k < NIT; ++k) {
+                const int it = lane + 64 * k;
+                if (it < nit) {
+                    if (a.transe_fast) {
+                        const Pack<4> pv = ld<4>(a.P + eo + it * 4), gv = ld<4>(a.GA + eo + it * 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float g = sgr * gv.v[e] - pv.v[e];
+                            if (reg) g += reg_grad(xr[k].v[e], a.reg_coef, a.reg_norm);
+                            ss += g * g; gsum[k].v[e] += g;
+                        }
+                    } else {
+                        const Pack<4> g = ld<4>(a.GR + eo + it * 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { ss += g.v[e] * g.v[e]; gsum[k].v[e] += g.v[e]; }
+                    }
+                }
+            }
+        }
+        ss = wave_sum(ss) / (float)d;
+        if (a.dry) return;
+        const float sN = st0 + ss;
+        const float kr = -a.lr / (sqrtf(sN) + a.eps);
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int it = lane + 64 * k;
+            if (it < nit) {
+                if (!a.emit_rel) {
+                    Pack<4> y = x[k];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) y.v[e] = fmaf(gsum[k].v[e], kr, y.v[e]);
+                    st<4>(row + it * 4, y);
+                }
+                if (a.gr) st<4>(a.gr + u * (int64_t)a.ld_r + it * 4, gsum[k]);
+            }
+        }
+        if (lane == 0) {
+            if (!a.emit_rel) *srow = sN;
+            if (a.gsr) a.gsr[u * (int64_t)a.ld_gs_r] = ss;
+            if (a.rid) { a.rid[u * (int64_t)a.ld_r] = (int32_t)(id & 0xFFFFFFFF); a.rid[u * (int64_t)a.ld_r + 1] = (int32_t)(id >> 32); }
+        }
+        if (reg && (a.reg_rel || a.acc)) {
+            rv = wave_sum(rv);
+            const float val = a.reg_coef * rv * (float)(e1 - e0);
+            if (lane == 0) {
+                if (a.reg_rel) a.reg_rel[u] = val;
+                if (a.acc) acc_add(&a.acc[3 * KGE_ACC_SLOTS + (int)((u + a.UE) & (KGE_ACC_SLOTS - 1))], val, a.UE + a.UR <= KGE_ACC_SLOTS);
+            }
+        } else if (a.reg_rel && lane == 0) a.reg_rel[u] = 0.f;
+    }
+}
+

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KGE_LIB") or os.path.join(_HERE, "libkge_hip.so")   # KGE_LIB: A/B builds
 
-KGE_ABI_VERSION = 3
+KGE_ABI_VERSION = 4
 MODEL_IDS = {"TransE_l1": 0, "TransE_l2": 1, "TransE": 1, "DistMult": 2, "ComplEx": 3, "RotatE": 4, "SimplE": 5, "RESCAL": 6, "TransR": 7}
 LOSS_IDS = {"Logsigmoid": 0, "Logistic": 1, "Hinge": 2, "BCE": 3}
 FLAG_FORCE_PAIRWISE = 1
@@ -21,6 +21,7 @@ FLAG_DENSE_NEG = 4
 FLAG_FUSED_LOSS = 8
 FLAG_TWO_PASS_PAIR = 16
 FLAG_NEG_DEG_SAMPLE = 32
+FLAG_ASYNC_REL = 64
 ACC_SLOTS = 4096
 
 c_f = C.c_float
@@ -96,6 +97,12 @@ _SIGNATURES = {
     "kge_step_workspace_bytes": (c_sz, [C.POINTER(KgeHParams), c_i, c_i, c_i, c_i, c_i, c_i]),
     "kge_step_fused": (c_i, [C.POINTER(KgeHParams), C.POINTER(KgeTables), C.POINTER(KgeBatch),
                              C.POINTER(KgeStepOut), c_p, c_sz, c_p]),
+    "kge_pipe_create": (c_i, [C.POINTER(c_p)]),
+    "kge_pipe_destroy": (c_i, [c_p]),
+    "kge_step_async_workspace_bytes": (c_sz, [C.POINTER(KgeHParams), c_i, c_i, c_i, c_i, c_i, c_i]),
+    "kge_step_async": (c_i, [c_p, C.POINTER(KgeHParams), C.POINTER(KgeTables), C.POINTER(KgeBatch),
+                             C.POINTER(KgeStepOut), c_p, c_sz, c_p]),
+    "kge_step_async_flush": (c_i, [c_p, c_p]),
     "kge_step_grads": (c_i, [C.POINTER(KgeHParams), C.POINTER(KgeTables), C.POINTER(KgeBatch),
                              C.POINTER(KgeStepOut), C.POINTER(KgeEmit), c_p, c_sz, c_p]),
     "kge_step_sharded": (c_i, [C.POINTER(KgeHParams), C.POINTER(KgeShards), C.POINTER(KgeBatch),

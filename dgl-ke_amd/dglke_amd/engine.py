@@ -80,6 +80,9 @@ class StepEngine(object):
         self._ws = None
         self._ws_bytes = 0
         self._graphs = []
+        self._pipe = None              # kge_pipe of the --async_update pipeline (side stream + events)
+        self._aws = None
+        self._aws_bytes = 0
 
     def _bind_tables(self):
         tb = _lib.KgeTables()
@@ -143,6 +146,50 @@ class StepEngine(object):
                                        C.byref(out), C.byref(emit), ptr(ws), self._ws_bytes,
                                        stream_ptr()))
 
+    # ---- --async_update: UPDATE(s-1) on a side stream under SCORE(s) (include/kge_hip.h, kge_step_async) ----
+    def async_workspace_for(self, b):
+        need = lib().kge_step_async_workspace_bytes(C.byref(self.hp), b.B, b.C, b.chunk, b.N, b.UE, b.UR)
+        if need > self._aws_bytes:
+            if self._graphs:
+                raise _lib.KgeError("workspace would be re-allocated after graph capture")
+            self._aws = torch.empty(int(need * 1.25) + 8192, dtype=torch.uint8, device=self.device)
+            self._aws_bytes = self._aws.numel()
+        return self._aws
+
+    def step_async(self, batch, want=None, per_step_loss=False):
+        """enqueue one step of the --async_update pipeline: gathers rows that contain every update up to step s-2's
+        (inside one flush-to-flush group), applies step s-1's update concurrently with this step's scoring.
+        `flush_async()` must follow the last step (before the tables are read / before a stream capture ends)."""
+        if self.shards is not None:
+            raise _lib.KgeError("--async_update is not available on peer-to-peer sharded tables")
+        if self._pipe is None:
+            h = C.c_void_p()
+            check(lib().kge_pipe_create(C.byref(h)))
+            self._pipe = h
+        ws = self.async_workspace_for(batch)
+        out = _lib.KgeStepOut()
+        if want is not None or per_step_loss:
+            out.loss4 = ptr(self.loss4)
+        out.loss_accum = ptr(self.loss_accum)
+        if want:
+            for k, t in want.items():
+                setattr(out, k, ptr(t))
+        check(lib().kge_step_async(self._pipe, C.byref(self.hp), C.byref(self.tb), C.byref(batch.c), C.byref(out),
+                                   ptr(ws), self._aws_bytes, stream_ptr()))
+        self._async_keep = batch       # the pending update reads the batch's plan arrays
+
+    def flush_async(self):
+        if self._pipe is not None:
+            check(lib().kge_step_async_flush(self._pipe, stream_ptr()))
+
+    def __del__(self):
+        try:
+            if self._pipe is not None:
+                lib().kge_pipe_destroy(self._pipe)
+                self._pipe = None
+        except Exception:
+            pass
+
     def alloc_outputs(self, batch):
         dev = self.device
         # neg_deg_sample: every chunk is scored against its own positives too (N' = chunk + N rows)
@@ -153,16 +200,21 @@ class StepEngine(object):
                     g_neg=torch.empty(batch.C * Np, self.d_e, device=dev),
                     g_rel=torch.empty(batch.B, self.d_r, device=dev))
 
-    def capture(self, batches, stream=None):
+    def capture(self, batches, stream=None, async_update=False):
         """record `len(batches)` consecutive steps into one HIP graph (on `stream` if given);
-        returns the graph."""
+        returns the graph.  async_update: the --async_update pipeline, flushed at the end of the group."""
         for b in batches:
-            self.workspace_for(b)
+            (self.async_workspace_for if async_update else self.workspace_for)(b)
         # warm-up on a side stream is not needed: the library allocates nothing
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=stream):
             for b in batches:
-                self.step(b)
+                if async_update:
+                    self.step_async(b)
+                else:
+                    self.step(b)
+            if async_update:
+                self.flush_async()
         self._graphs.append((g, batches))
         return g
 

@@ -13,7 +13,8 @@
  *    (the reference's dtypes), int32 for the batch-plan CSR arrays this library defines;
  *  - no allocation, no host synchronisation and no global mutable state inside; every call takes
  *    an explicit stream (hipStream_t passed as void*) and only enqueues kernels on it, so calls
- *    can be captured into a hipGraph;
+ *    can be captured into a hipGraph (the one object the library creates is the kge_pipe of the
+ *    --async_update pipeline: a small host-side struct, explicitly created / destroyed by the caller);
  *  - return value 0 = success, negative = kge_status; kge_last_error() returns the message of
  *    the last failure on the calling thread;
  *  - embedding rows of ComplEx / RotatE are [re | im] halves (models/pytorch/score_fun.py:298-300).
@@ -28,7 +29,7 @@
 extern "C" {
 #endif
 
-#define KGE_ABI_VERSION 3
+#define KGE_ABI_VERSION 4
 
 /* score functions (models/general_models.py:248-268 model_name strings) */
 enum kge_model {
@@ -88,6 +89,9 @@ enum kge_status {
  * kge_step_out.neg_score is [B, N'], g_neg [C*N', d_e] (rows c*N' + chunk.. are the sampled ones).
  * Not available for RESCAL / TransR and in kge_step_grads. */
 #define KGE_FLAG_NEG_DEG_SAMPLE 32u
+/* kge_step_async: defer the relation-table update by one step as well (the reference's --async_update defers the
+ * entity table only, general_models.py:639-647; with this flag no update at all sits between two steps' scoring) */
+#define KGE_FLAG_ASYNC_REL 64u
 
 int         kge_abi_version(void);
 const char *kge_last_error(void);
@@ -228,6 +232,35 @@ size_t kge_step_workspace_bytes(const kge_hparams *hp, int B, int C, int chunk, 
 /* forward + backward + update of one batch, enqueued on `stream`. */
 int kge_step_fused(const kge_hparams *hp, const kge_tables *tb, const kge_batch *b,
                    const kge_step_out *out, void *ws, size_t ws_bytes, void *stream);
+
+/* ---- --async_update (models/pytorch/tensor_models.py:136-175 async_update, :364-375 create/finish_async_update;
+ * models/general_models.py:639-647; train_pytorch.py:120-121, 194-195; docs/source/train.rst:217-259) ----
+ * The reference hands the entity gradients of step s to a helper PROCESS and starts step s+1 while they are
+ * applied: the gather of step s+1 may miss the update of step s (<= 1 step of staleness), racily.  Here the
+ * staleness is exact and race-free, and the "helper" is the other half of a horizontally fused launch:
+ *
+ *     PREP(s) | forward(s) | loss(s) | [ backward(s) || UPDATE(s-1) ] | relation trace(s) | PREP(s+1) | ...
+ *
+ *   PREP(s)   = gather + positive scores + pos-side vectors + DENSE COPIES of every row the step reads again
+ *               (negative rows; h / t / r rows for the per-edge gradient kernel and the regulariser);
+ *   forward / loss / backward(s) read only PREP's copies;
+ *   UPDATE(s-1) = row-sparse Adagrad of the ENTITY table (both traces) with the gradients of step s-1, applied to
+ *               the rows as they are then - in the SAME launch as the backward matrix-core tiles of step s
+ *               (different workspace half; the update is row read-modify-write traffic, the tiles matrix work).
+ *               The relation trace of step s is applied right after backward(s), like the reference, which defers
+ *               entity_emb only (general_models.py:639-647); KGE_FLAG_ASYNC_REL defers it too.
+ * Step s+1 therefore gathers entity rows that contain every update up to s-1 and not the update of s -
+ * bit-reproducible, one stream, no events.  kge_step_async_flush() applies the last pending update (call it
+ * before reading the tables and at the end of a captured group of steps).  Gradients, including the regulariser,
+ * are those of the rows as gathered.  Not available for RESCAL / TransR, nor --neg_deg_sample with a regulariser.
+ * The workspace holds two halves (kge_step_async_workspace_bytes).  kge_pipe is host-side state only. */
+typedef struct kge_pipe kge_pipe;
+int kge_pipe_create(kge_pipe **pipe);
+int kge_pipe_destroy(kge_pipe *pipe);
+size_t kge_step_async_workspace_bytes(const kge_hparams *hp, int B, int C, int chunk, int N, int UE, int UR);
+int kge_step_async(kge_pipe *pipe, const kge_hparams *hp, const kge_tables *tb, const kge_batch *b,
+                   const kge_step_out *out, void *ws, size_t ws_bytes, void *stream);
+int kge_step_async_flush(kge_pipe *pipe, void *stream);
 
 /* ---- range-sharded training (one process per GPU) ----
  * kge_step_grads: same as kge_step_fused but instead of updating the entity table it EMITS, per

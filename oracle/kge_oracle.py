@@ -489,6 +489,41 @@ def train_step(cfg, ent, ent_state, rel, rel_state, nid, h_local, t_local, rel_i
     return out
 
 
+def train_steps_async(cfg, ent, ent_state, rel, rel_state, batches, defer_rel=False):
+    """--async_update (tensor_models.py:136-175 async_update process, :325-328 queue hand-off, :364-375;
+    general_models.py:639-647; train_pytorch.py:120-121, 194-195) for a GROUP of consecutive steps, restated
+    deterministically: the reference hands the entity gradients of step s to a helper process through a
+    1-slot queue and starts step s+1 at once, so the gather of step s+1 may or may not see update s (racy,
+    <= 1 step of staleness).  This restatement fixes the race at its bound: step s gathers rows that contain
+    every update up to s-2 and never update s-1, which lands while step s is being scored; the last update
+    is applied at the end of the group (finish_async_update).  Gradients (including the regulariser) are
+    those of the rows as gathered, applied to the rows as they are when the update lands, exactly like the
+    helper process does.  Only the ENTITY table is deferred (create_async_update is called on entity_emb
+    only); defer_rel=True defers the relation trace too (KGE_FLAG_ASYNC_REL).
+    `batches`: dicts with nid, h_local, t_local, r, neg, neg_head, chunk, N.  Tables modified in place."""
+    outs, pending = [], None
+
+    def land(p):
+        adagrad_update(ent, ent_state, p["nid"], p["g_pos_ent"], cfg.lr)
+        adagrad_update(ent, ent_state, p["neg"], p["g_neg"], cfg.lr)
+        if defer_rel:
+            adagrad_update(rel, rel_state, p["r"], p["g_rel"], cfg.lr)
+
+    for bt in batches:
+        out = forward_backward(cfg, ent, rel, bt["nid"], bt["h_local"], bt["t_local"], bt["r"], bt["neg"],
+                               bt["neg_head"], bt["chunk"], bt["N"], bt.get("w"))
+        if pending is not None:
+            land(pending)
+        if not defer_rel:
+            adagrad_update(rel, rel_state, bt["r"], out["g_rel"], cfg.lr)
+        pending = dict(nid=bt["nid"], neg=bt["neg"], r=bt["r"], g_pos_ent=out["g_pos_ent"], g_neg=out["g_neg"],
+                       g_rel=out["g_rel"])
+        outs.append(out)
+    if pending is not None:
+        land(pending)
+    return outs
+
+
 # ---------------------------------------------------------------------------------------------
 # TransR (score_fun.py:110-220): a THIRD table, projection_emb [n_rel, ent_dim * rel_dim], owned by the score
 # function.  prepare() (:131-136) projects head and tail of every positive edge with its relation's matrix

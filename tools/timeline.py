@@ -56,13 +56,19 @@ def main():
         assert fn(bufs[tu].data_ptr()) == 0
     G = args.graph_steps
     smp = DeviceSampler(h, r, t, w["n_ent"], w["B"], w["N"], dev, n_slots=G, seed=0)
-    for b in smp.sample():
-        eng.step(b)
+    def run_group():
+        for b in smp.sample():
+            if args.async_update:
+                eng.step_async(b)
+            else:
+                eng.step(b)
+        if args.async_update:
+            eng.flush_async()
+    run_group()
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
-        for b in smp.sample():
-            eng.step(b)
+        run_group()
     for _ in range(args.reps):
         g.replay()
     torch.cuda.synchronize()
