@@ -290,7 +290,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 or os.environ.get("KGE_FORCE_DIST"):
+    if world > 1 or os.environ.get("KGE_FORCE_DIST") or args.workload in ("transe_l2_freebase", "rotate_freebase"):
         import bench_dist
         return bench_dist.main(args, world, rank, local_rank)
     if args.gpus != 1:

@@ -1,11 +1,14 @@
 """bench_dist.py - N>1 leg of bench.py: weak-scaled, one process per GPU (torch.distributed, backend
 nccl = RCCL), entity AND relation tables range-sharded over the ranks' HBM.
 
-Per-GPU work is the SAME step as the N=1 bench (TransE_l2, batch 1000, neg 200, dim 400, -adv; batch
-ids, negatives and plan built on the device inside the timed region) but on a Freebase-sized
-synthetic id space (86 054 151 entities, 14 824 relations - examples/README.md:11 of the
-reference), which is what the sharding is for: the entity table is 137.7 GB, each rank holds 1/N.
-`--workload rotate_freebase` selects BASELINE.json configs[4] (RotatE, D_e = 800).
+Default workload = BASELINE.json configs[4]: RotatE on a synthetic Freebase-sized graph (hidden 400 -de: D_e = 800,
+D_r = 400; per-GPU batch 1024, neg 256; 86 054 151 entities / 14 824 relations at 8 GPUs - examples/README.md:11 of
+the reference), WEAK-scaled in both dimensions: every GPU runs the same step and holds the same 1/8 of the Freebase
+entity table (10 756 769 rows = 34.4 GB), so N GPUs train a graph of N/8 x Freebase and N = 8 is configs[4]
+itself.  The SAME workload runs at N = 1 (`python bench.py --gpus 1 --workload rotate_freebase`: one shard,
+kge_step_sharded through a 1-entry shard map), so 1 / 2 / 4 / 8 is one curve; the N = 1 DEFAULT of bench.py stays
+configs[1] (the configuration BASELINE.json's metric is quoted on).  `--workload transe_l2_freebase`: the N=1
+bench's step on the same tables.
 
 Two multi-GPU modes (KGE_DIST_MODE):
   p2p (default)  the shared-table Hogwild mode of the reference's multi-GPU trainer with the shared
@@ -166,9 +169,10 @@ def main(args, world, rank, local_rank):
         if "MASTER_ADDR" not in os.environ:
             os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29533"
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    name = args.workload if args.workload in DIST_WORKLOADS else "transe_l2_freebase"
+    name = args.workload if args.workload in DIST_WORKLOADS else "rotate_freebase"
     w = dict(DIST_WORKLOADS[name])
-    n_ent = int(os.environ.get("KGE_DIST_ENTITIES", w["n_ent"]))
+    # weak scaling of the table as well: every GPU holds 1/8 of the Freebase entity table, N = 8 is the full graph
+    n_ent = int(os.environ.get("KGE_DIST_ENTITIES", (w["n_ent"] + 7) // 8 * world))
     d_e = 2 * w["hidden"] if w["de"] else w["hidden"]
     d_r = 2 * w["hidden"] if w["dr"] else w["hidden"]
     emb_init = (w["gamma"] + 2.0) / w["hidden"]
@@ -207,11 +211,58 @@ def main(args, world, rank, local_rank):
     wall = float(tw.item())
     sums = eng.read_loss_sums()
     K = args.steps
-    if rank == 0:
+    # secondary leg at N > 1: the parameter-server semantics over RCCL all-to-all (the partitioning north_star names:
+    # entity table range-sharded, relation table replicated, pull / push collectives), eager launches, a bounded
+    # number of steps, under a watchdog - a hung collective must never cost the headline line
+    a2a_leg = {"result": None}
+    want_a2a = mode == "p2p" and world > 1 and os.environ.get("KGE_DIST_A2A_LEG", "1") != "0"
+
+    def emit(a2a):
+        if rank != 0:
+            return
+        line = _result_line(args, w, n_ent, world, wall, K, rows, d_e, eng.d_r, desc, mode, why, sums, a2a)
+        print(json.dumps(line), flush=True)
+
+    if want_a2a:
+        import threading
+        done = threading.Event()
+
+        def watchdog():
+            if not done.wait(float(os.environ.get("KGE_DIST_A2A_TIMEOUT", "90"))):
+                emit({"error": "all-to-all leg did not finish in time (watchdog)"})
+                os._exit(0)
+        th = threading.Thread(target=watchdog, daemon=True)
+        th.start()
+        try:
+            a_steps = max(20, min(K, 200))
+            aeng, arun, arows, adesc = _a2a_setup(args, world, rank, dev, w, n_ent, d_e, emb_init)
+            arun(min(20, a_steps))
+            torch.cuda.synchronize(); dist.barrier()
+            t0 = time.perf_counter()
+            arun(a_steps)
+            torch.cuda.synchronize(); dist.barrier()
+            aw = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            dist.all_reduce(aw, op=dist.ReduceOp.MAX)
+            a2a_leg["result"] = {"value": round(a_steps * w["B"] * world / float(aw.item()), 1), "unit": "edges/s",
+                                 "steps": a_steps, "us_per_step": round(1e6 * float(aw.item()) / a_steps, 2),
+                                 "collectives_per_step": "2 all_to_all_single (rows, packed gradients) + 1 all_gather (relation "
+                                                         "gradients); ids routed ahead", "launch": "eager", "desc": adesc}
+        except Exception as e:          # noqa: BLE001
+            a2a_leg["result"] = {"error": repr(e)}
+        done.set()
+    emit(a2a_leg["result"])
+    dist.barrier()
+    if tabs is not None:
+        tabs.close()
+    dist.destroy_process_group()
+
+
+def _result_line(args, w, n_ent, world, wall, K, rows, d_e, d_r, desc, mode, why, sums, a2a):
+    if True:
         # algorithmic bytes per rank-step (SURVEY 8d formula on the sampled batches)
-        bytes_step = 12.0 * (rows["R_e"] * d_e + rows["B"] * eng.d_r) + 16.0 * (rows["R_e"] + rows["B"])
+        bytes_step = 12.0 * (rows["R_e"] * d_e + rows["B"] * d_r) + 16.0 * (rows["R_e"] + rows["B"])
         # rows crossing xGMI per rank-step: every traced row is read once and read-modify-written once
-        xgmi_step = 3.0 * (rows["R_e"] * d_e + rows["B"] * eng.d_r) * 4 * (world - 1) / world
+        xgmi_step = 3.0 * (rows["R_e"] * d_e + rows["B"] * d_r) * 4 * (world - 1) / world
         out = {
             "metric": "positive edges/sec (whole node)",
             "value": round(K * w["B"] * world / wall, 1), "unit": "edges/s",
@@ -219,10 +270,11 @@ def main(args, world, rank, local_rank):
             "ms_per_step": round(1e3 * wall / K, 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s synthetic Freebase-sized: n_ent=%d n_rel=%d, per-GPU batch=%d neg=%d "
-                                   "dim=%d over %d GPUs (%.1f GB of entity rows per GPU); %s"
-                                   % (w["model"], n_ent, w["n_rel"], w["B"], w["N"], w["hidden"], world,
-                                      (n_ent + world - 1) // world * d_e * 4 / 1e9, desc),
+            "config": {"workload": "%s synthetic Freebase-scale (BASELINE configs[4], weak-scaled: %d/8 of the 86 054 151-entity "
+                                   "graph): n_ent=%d n_rel=%d, per-GPU batch=%d neg=%d hidden=%d (D_e=%d) over %d GPU%s "
+                                   "(%.1f GB of entity rows per GPU); %s"
+                                   % (w["model"], world, n_ent, w["n_rel"], w["B"], w["N"], w["hidden"], d_e, world,
+                                      "" if world == 1 else "s", (n_ent + world - 1) // world * d_e * 4 / 1e9, desc),
                        "global_batch": w["B"] * world,
                        "parallelism": ("shared tables over %d GPUs' HBM, peer-to-peer xGMI (Hogwild)" % world)
                        if mode == "p2p" else ("entity-shard x%d (RCCL all-to-all)" % world),
@@ -231,11 +283,13 @@ def main(args, world, rank, local_rank):
                          "peak": 8000.0 * world, "unit": "GB/s",
                          "frac": round(bytes_step / (wall / K) / 1e9 / 8000.0, 5), "traffic": None,
                          "algorithmic_bytes_per_rank_step": round(bytes_step, 1),
-                         "xgmi_bytes_per_rank_step": round(xgmi_step, 1)},
+                         "xgmi_bytes_per_rank_step": round(xgmi_step, 1),
+                         "xgmi_GBps_per_gpu": round(xgmi_step / (wall / K) / 1e9, 2),
+                         "xgmi_peak_GBps_per_gpu": 1071.0},
             "mean_loss": round(sums[2] / K, 6),
+            "n1_same_workload": "python bench.py --gpus 1 --workload %s" % args.workload if args.workload in DIST_WORKLOADS
+                                else "python bench.py --gpus 1 --workload rotate_freebase",
         }
-        print(json.dumps(out))
-    dist.barrier()
-    if tabs is not None:
-        tabs.close()
-    dist.destroy_process_group()
+        if a2a is not None:
+            out["a2a"] = a2a
+        return out

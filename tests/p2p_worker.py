@@ -1,7 +1,8 @@
 """worker of tests/test_gpu_p2p.py::test_two_processes_share_tables_over_ipc - one of two processes
 on the SAME GPU; they map each other's shard through hipIpc handles and train alternately (barrier
 between the turns) so that the outcome is deterministic and must equal one engine processing the
-same batches in the same order on un-sharded tables.  argv: rank world port out_dir"""
+same batches in the same order on un-sharded tables.  argv: rank world port out_dir [device ids, comma separated:
+rank k runs on device ids[k] - two DIFFERENT GPUs exercise the real xGMI path]"""
 import os
 import sys
 
@@ -21,8 +22,9 @@ def main():
     from dglke_amd import p2p, plan
     from dglke_amd.engine import StepEngine
     from oracle import kge_oracle as O      # batch generator only (test infrastructure)
-    dev = "cuda:0"
-    torch.cuda.set_device(0)
+    devs = [int(x) for x in sys.argv[5].split(",")] if len(sys.argv) > 5 else [0] * world
+    dev = "cuda:%d" % devs[rank]
+    torch.cuda.set_device(devs[rank])
     n_ent, n_rel, hidden, B, N = 3001, 37, 64, 128, 32
     res = {}
     for model, de_, dr_ in (("TransE_l2", False, False), ("ComplEx", True, True), ("RotatE", True, False)):

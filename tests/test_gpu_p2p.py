@@ -58,13 +58,18 @@ def test_sharded_step_argument_errors():
         StepEngine("DistMult", 100, 5, 8, 10.0, 0.1, DEV, shards=tabs)   # width mismatch
 
 
-def test_two_processes_share_tables_over_ipc(tmp_path):
-    """two trainer processes on this GPU, each owning half of every table, mapped into each other
-    through hipIpc handles; alternate turns -> deterministic -> must equal the un-sharded engine."""
-    port = str(29600 + os.getpid() % 300)
+@pytest.mark.parametrize("devices", ["0,0", "0,1"], ids=["one_gpu", "two_gpus"])
+def test_two_processes_share_tables_over_ipc(tmp_path, devices):
+    """two trainer processes, each owning half of every table, mapped into each other through hipIpc handles;
+    alternate turns -> deterministic -> must equal the un-sharded engine.  "one_gpu": both processes on this GPU
+    (what a one-GPU box can run); "two_gpus": ranks on DIFFERENT devices - remote rows really cross xGMI, and after
+    every barrier each rank must observe the other's read-modify-writes (skipped with fewer than two GPUs)."""
+    if devices == "0,1" and torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    port = str(29600 + os.getpid() % 300 + (1 if devices == "0,1" else 0))
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "p2p_worker.py"), str(r), "2", port, str(tmp_path)],
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "p2p_worker.py"), str(r), "2", port, str(tmp_path), devices],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
     outs = []
     for p in procs:
