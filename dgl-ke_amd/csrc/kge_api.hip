@@ -407,7 +407,9 @@ size_t kge_step_workspace_bytes(const kge_hparams *hp, int B, int C, int chunk, 
 
 // phases of one step.  The strict step runs all three back to back on one stream; the --async_update pipeline
 // (kge_step_async) runs PREP(s) | SCORE(s) on the caller's stream and UPDATE(s-1) on its side stream in between.
-enum { PH_PREP = 1, PH_SCORE = 2, PH_UPD_ENT = 4, PH_UPD_REL = 8, PH_UPDATE = 12, PH_ALL = 15 };
+enum { PH_PREP = 1, PH_FWD = 2, PH_BWD = 16, PH_SCORE = 18, PH_UPD_ENT = 4, PH_UPD_REL = 8, PH_UPDATE = 12, PH_ALL = 31,
+       PH_STRICT = 32 };   // PH_STRICT: the phases belong to a strict step issued in pieces (kge_step_phase): table reads stay
+                           // table reads (no dense copies), exactly the kernels of PH_ALL
 
 static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batch *b,
                      const kge_step_out *out, const kge_emit *emit, void *ws, size_t ws_bytes,
@@ -497,7 +499,8 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     int64_t *nd_ids = nd ? reinterpret_cast<int64_t *>(cv.f(2 * (size_t)CN)) : nullptr;
     // --async_update pipeline (phases != PH_ALL): dense copies of the h / t / r rows as PREP gathered them, for the
     // kernels that read them again after the previous step's update has started (edge_bwd)
-    const bool need_cp = phases != PH_ALL && (!transe_fast || reg || (out && out->g_rel));
+    const bool pipelined = phases != PH_ALL && !(phases & PH_STRICT);      // the async pipeline (kge_step_async)
+    const bool need_cp = pipelined && (!transe_fast || reg || (out && out->g_rel));
     float *Hc = need_cp ? cv.f((size_t)B * d_e) : nullptr, *Tc = need_cp ? cv.f((size_t)B * d_e) : nullptr;
     float *Rc = need_cp ? cv.f((size_t)B * d_r) : nullptr;
     if (!cv.ok())
@@ -533,7 +536,7 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     const float rot_div = rot_div_of(hp->emb_init);
     // --async_update pipeline: everything after PREP must read the rows as PREP gathered them (the previous step's
     // update is changing the tables meanwhile): negatives from the dense copy Bn, h / t / r from dense copies too
-    const bool async = phases != PH_ALL;
+    const bool async = pipelined;
     if (async && (sh || emit || transr || rescal))
         return fail(KGE_ERR_ARG, "kge_step_async: not available for RESCAL / TransR and the sharded / gradient-emitting steps");
 
@@ -597,15 +600,15 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         g.S = S; g.adv_temp = hp->adv_temp; g.asq = asq; g.bsq = bsq;
         g.lp = lp; g.w = b->edge_w;
         if (fused_loss) { g.PM = PM; g.PS = PS; g.PL = PL; g.Sraw = out ? out->neg_score : nullptr; }
-        KGE_TRY(launch_neg_fwd_gemm(g, s));
+        if (phases & PH_FWD) KGE_TRY(launch_neg_fwd_gemm(g, s));
     } else {
         fill_pair(na, hp->model, C, chunk, N, d_e, hp->gamma, A, Bn, nullptr);
         na.S = S;
-        KGE_TRY(launch_neg_fwd_pair(na, s));
+        if (phases & PH_FWD) KGE_TRY(launch_neg_fwd_pair(na, s));
     }
 
     // 3. stand-alone loss kernel (only when the loss is not fused into the backward GEMM)
-    if (!fused_loss) {
+    if (!fused_loss && (phases & PH_FWD)) {
         LossArgs la{};
         la.B = B; la.N = N; la.genre = hp->loss_genre; la.adv = hp->adv; la.pairwise = hp->pairwise;
         la.adv_temp = hp->adv_temp; la.margin = hp->margin;
@@ -619,6 +622,7 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         KGE_TRY(launch_loss(la, s));
     }
 
+    if (phases & PH_BWD) {
     // 4. gradients w.r.t. the pos-side vectors and the negative rows
     if (transr) {
         KGE_TRY(launch_transr_bwd(tr, s));       // dq, GN, per-edge projection gradients, relation-vector gradients
@@ -704,6 +708,7 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         eb.GH = nullptr; eb.GT = nullptr; eb.GR = out->g_rel;
         KGE_TRY(launch_edge_bwd(eb, s));
     }
+    }   // PH_BWD
     }   // PH_SCORE
 
     if (phases & PH_UPDATE) {
@@ -841,6 +846,20 @@ int kge_step_async_flush(kge_pipe *p, void *stream) {
                                p->upd_phases)) return rc;
     }
     return KGE_OK;
+}
+
+int kge_step_phase(const kge_hparams *hp, const kge_tables *tb, const kge_batch *b, const kge_step_out *out,
+                   void *ws, size_t ws_bytes, int phases, void *stream) {
+    // the strict step, one phase group at a time (same kernels, same order: calling the four groups in sequence IS
+    // kge_step_fused); exists so that the caller can put events between the groups (the reference's per-phase timers)
+    if (phases <= 0 || phases > (KGE_PHASE_GATHER | KGE_PHASE_FORWARD | KGE_PHASE_BACKWARD | KGE_PHASE_UPDATE))
+        return fail(KGE_ERR_ARG, "kge_step_phase: bad phase mask %d", phases);
+    int ph = 0;
+    if (phases & KGE_PHASE_GATHER) ph |= PH_PREP;
+    if (phases & KGE_PHASE_FORWARD) ph |= PH_FWD;
+    if (phases & KGE_PHASE_BACKWARD) ph |= PH_BWD;
+    if (phases & KGE_PHASE_UPDATE) ph |= PH_UPDATE;
+    return step_impl(hp, tb, b, out, nullptr, ws, ws_bytes, stream, nullptr, ph | PH_STRICT);
 }
 
 int kge_step_grads(const kge_hparams *hp, const kge_tables *tb, const kge_batch *b,

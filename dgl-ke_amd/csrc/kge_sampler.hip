@@ -9,7 +9,7 @@
 // host from the ids the kernel sampled and compare every array.
 //
 // One workgroup (1024 threads) builds one batch entirely in LDS:
-//   1. positives: edge e = perm[(pos + i) mod n_train] -> (h, r, t);  negatives: counter-based hash
+//   1. positives: whole batches of the epoch's edge order (base permutation re-keyed per epoch) -> (h, r, t);  negatives: counter-based hash
 //      RNG keyed by (seed, step, j) -> uniform id in [0, n_ent)
 //   2. bitonic sort of <= 4096 64-bit keys  (entity id << 12 | element code), code = edge*2+side
 //      for positive edge ends, 2B + slot for negatives  -> elements grouped by entity, ascending
@@ -114,6 +114,11 @@ __device__ uint32_t block_exclusive_scan(uint32_t *v, int n, uint32_t *wsum /*[S
     return total;
 }
 
+__device__ __forceinline__ uint64_t gcd_u64(uint64_t x, uint64_t y) {
+    while (y) { const uint64_t r = x % y; x = y; y = r; }
+    return x;
+}
+
 __global__ __launch_bounds__(SP_THREADS) void sample_plan_kernel(SamplerArgs a) {
     __shared__ uint64_t keys[SP_MAXE];         // 32 KB
     __shared__ uint32_t scan[SP_MAXE];         // 16 KB
@@ -135,8 +140,25 @@ __global__ __launch_bounds__(SP_THREADS) void sample_plan_kernel(SamplerArgs a) 
     int32_t *counts = (int32_t *)(sb + L.counts);
 
     // ---- 1. sample ----
+    // Whole batches only (the reference drops the trailing partial batch of an epoch, dataloader/sampler.py:503-504)
+    // and a NEW edge order every epoch (shuffle=True): batch k of the run is batch k % nb of epoch k / nb, whose
+    // order is the base permutation composed with an affine bijection of [0, n_train) keyed by (seed, epoch) -
+    // a fresh permutation without regenerating n_train indices; epoch 0 uses the base permutation as it is.
+    const int64_t nb = a.n_train / B;
+    const int64_t gk = step - 1, ep = gk / nb, pos1 = (gk % nb) * B;
+    static const uint64_t MULT[8] = {2654435761ull, 2246822519ull, 3266489917ull, 668265263ull, 374761393ull,
+                                     2870177450ull + 13ull, 1597334677ull, 1181783497ull};
+    uint64_t mul = 1, add = 0;
+    if (a.perm && ep > 0) {
+        add = mix64(a.seed ^ (0xD6E8FEB86659FD93ULL * (uint64_t)ep)) % (uint64_t)a.n_train;
+        if (a.n_train < (1ll << 31)) {         // pos * mul must not overflow 64 bits
+            mul = MULT[ep & 7];
+            while (gcd_u64(mul, (uint64_t)a.n_train) != 1) mul += 2;     // bijection needs gcd(mul, n_train) = 1
+        }
+    }
+    (void)pos0;
     for (int i = t; i < B; i += SP_THREADS) {
-        int64_t e = (pos0 + i) % a.n_train;
+        int64_t e = (int64_t)(((uint64_t)(pos1 + i) * mul + add) % (uint64_t)a.n_train);
         if (a.perm) e = a.perm[e];
         const int64_t h = a.H[e], r = a.R[e], tl = a.T[e];
         h_gid[i] = h; t_gid[i] = tl; rel_ids[i] = r;
@@ -242,6 +264,7 @@ size_t kge_sampler_slot_bytes(int B, int C, int N) {
 int kge_sample_batches(const int64_t *heads, const int64_t *rels, const int64_t *tails, const int64_t *perm,
                        int64_t n_train, int64_t n_ent, int B, int C, int chunk, int N, uint64_t seed,
                        int64_t *state, void *slots, size_t slot_bytes, int n_slots, void *stream) {
+    if (n_train < B) return KGE_ERR_ARG;       // fewer training triples than one batch
     if (!heads || !rels || !tails || !state || !slots || n_train <= 0 || n_ent <= 0 || B <= 0 || C <= 0 ||
         chunk <= 0 || N <= 0 || C * chunk != B)
         return KGE_ERR_ARG;

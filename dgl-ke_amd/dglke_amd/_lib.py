@@ -22,6 +22,7 @@ FLAG_FUSED_LOSS = 8
 FLAG_TWO_PASS_PAIR = 16
 FLAG_NEG_DEG_SAMPLE = 32
 FLAG_ASYNC_REL = 64
+PHASE_GATHER, PHASE_FORWARD, PHASE_BACKWARD, PHASE_UPDATE = 1, 2, 4, 8
 ACC_SLOTS = 4096
 
 c_f = C.c_float
@@ -103,6 +104,8 @@ _SIGNATURES = {
     "kge_step_async": (c_i, [c_p, C.POINTER(KgeHParams), C.POINTER(KgeTables), C.POINTER(KgeBatch),
                              C.POINTER(KgeStepOut), c_p, c_sz, c_p]),
     "kge_step_async_flush": (c_i, [c_p, c_p]),
+    "kge_step_phase": (c_i, [C.POINTER(KgeHParams), C.POINTER(KgeTables), C.POINTER(KgeBatch), C.POINTER(KgeStepOut), c_p,
+                             c_sz, c_i, c_p]),
     "kge_step_grads": (c_i, [C.POINTER(KgeHParams), C.POINTER(KgeTables), C.POINTER(KgeBatch),
                              C.POINTER(KgeStepOut), C.POINTER(KgeEmit), c_p, c_sz, c_p]),
     "kge_step_sharded": (c_i, [C.POINTER(KgeHParams), C.POINTER(KgeShards), C.POINTER(KgeBatch),

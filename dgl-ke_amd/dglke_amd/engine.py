@@ -146,7 +146,27 @@ class StepEngine(object):
                                        C.byref(out), C.byref(emit), ptr(ws), self._ws_bytes,
                                        stream_ptr()))
 
-    # ---- --async_update: UPDATE(s-1) on a side stream under SCORE(s) (include/kge_hip.h, kge_step_async) ----
+    def step_timed(self, batch):
+        """ONE strict step issued as its four phase groups (kge_step_phase: gather+positive / negative scores+loss /
+        gradients / Adagrad - together exactly kge_step_fused) with HIP events in between; returns the four durations in
+        seconds (forward = gather + scores + loss, like the reference's timer around model.forward).  Synchronises."""
+        if self.shards is not None:
+            self.step(batch)
+            return None
+        ws = self.workspace_for(batch)
+        out = _lib.KgeStepOut()
+        out.loss_accum = ptr(self.loss_accum)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        ev[0].record()
+        for k, ph in enumerate((_lib.PHASE_GATHER, _lib.PHASE_FORWARD, _lib.PHASE_BACKWARD, _lib.PHASE_UPDATE)):
+            check(lib().kge_step_phase(C.byref(self.hp), C.byref(self.tb), C.byref(batch.c), C.byref(out), ptr(ws),
+                                       self._ws_bytes, ph, stream_ptr()))
+            ev[k + 1].record()
+        ev[4].synchronize()
+        t = [ev[k].elapsed_time(ev[k + 1]) * 1e-3 for k in range(4)]
+        return dict(forward=t[0] + t[1], backward=t[2], update=t[3])
+
+    # ---- --async_update: UPDATE(s-1) in the same launch as backward(s) (include/kge_hip.h, kge_step_async) ----
     def async_workspace_for(self, b):
         need = lib().kge_step_async_workspace_bytes(C.byref(self.hp), b.B, b.C, b.chunk, b.N, b.UE, b.UR)
         if need > self._aws_bytes:

@@ -6,6 +6,7 @@ Differences: there is no network here, so a built-in dataset must already be unp
 `<data_path>/<name>/` (the reference downloads it); files are parsed with pandas instead of
 per-line Python loops (FB15k loads in well under a second)."""
 import os
+import re
 
 import numpy as np
 import pandas as pd
@@ -22,7 +23,10 @@ def _order(fmt):
 
 
 def _read_table(path, delimiter, ncols=None):
-    df = pd.read_csv(path, sep=delimiter, header=None, dtype=str, keep_default_na=False, quoting=3,
+    # a multi-character separator goes to the python engine, which treats it as a REGEX: escape it so that
+    # '||' or '.'-style delimiters split literally (like str.split in the reference's readers)
+    sep = delimiter if len(delimiter) == 1 else re.escape(delimiter)
+    df = pd.read_csv(path, sep=sep, header=None, dtype=str, keep_default_na=False, quoting=3,
                      engine="c" if len(delimiter) == 1 else "python")
     if ncols is not None and df.shape[1] < ncols:
         raise ValueError("%s: expected at least %d columns separated by %r" % (path, ncols, delimiter))

@@ -70,9 +70,11 @@ class ExternalEmbedding(object):
         return idx[mask.to(idx.device)]
 
     def share_memory(self):
-        """tensor_models.py:264-268: the reference shares a CPU table between trainer processes.
-        Here each process owns its HBM shard, so there is nothing to share."""
-        return None
+        """tensor_models.py:264-268: the reference moves the CPU table into shared memory so that the trainer
+        processes see one table.  The HBM-resident table is already visible to every trainer of this process
+        (streams / lanes) and, across processes, through the hipIpc shard map (dglke_amd.p2p): nothing to move.
+        Returns self (the reference's tensors return themselves from share_memory_())."""
+        return self
 
     def __call__(self, idx, gpu_id=-1, trace=True):
         """row gather (tensor_models.py:270-302)."""
@@ -85,24 +87,34 @@ class ExternalEmbedding(object):
             data = s
         return data
 
-    def update(self, gpu_id=-1):
-        """row-sparse Adagrad per trace, in trace order (tensor_models.py:304-362)."""
-        self.state_step += 1
+    def _apply(self, traces):
         with th.no_grad():
-            for idx, data in self.trace:
-                if data.grad is None:
-                    continue
-                ops.adagrad_scatter(self.emb, self.state_sum, idx, data.grad, self.args.lr, 1e-10)
+            for idx, grad in traces:
+                ops.adagrad_scatter(self.emb, self.state_sum, idx, grad, self.args.lr, 1e-10)
+
+    def update(self, gpu_id=-1):
+        """row-sparse Adagrad per trace, in trace order (tensor_models.py:304-362).  After create_async_update():
+        the traces of THIS step are parked and the traces of the PREVIOUS step land now - the next forward gathers
+        rows that contain every update but this step's, the deterministic form of the reference's helper-process
+        update (tensor_models.py:136-175, :325-328): one step of staleness, no race."""
+        self.state_step += 1
+        traces = [(idx, data.grad.detach()) for idx, data in self.trace if data.grad is not None]
         self.trace = []
+        if self.async_q is None:
+            self._apply(traces)
+        else:
+            pending, self.async_q = self.async_q, traces
+            self._apply(pending)
 
     def create_async_update(self):
-        """tensor_models.py:364-369: the reference overlaps a CPU update process with GPU compute.
-        Kernels on a HIP stream are already asynchronous w.r.t. the host, so this is a no-op."""
-        self.async_q = None
+        """tensor_models.py:364-369 (starts the helper process there): from now on `update` defers by one step."""
+        self.async_q = []
 
     def finish_async_update(self):
-        if th.cuda.is_available():
-            th.cuda.current_stream().synchronize()
+        """tensor_models.py:371-375: land what is still parked and return to synchronous updates."""
+        if self.async_q is not None:
+            self._apply(self.async_q)
+        self.async_q = None
 
     def curr_emb(self):
         return th.cat([data for _, data in self.trace], 0)
@@ -111,6 +123,12 @@ class ExternalEmbedding(object):
         np.save(os.path.join(path, name + '.npy'), self.emb.detach().cpu().numpy())
 
     def load(self, path, name):
+        """tensor_models.py:399-407.  The table keeps its storage when the shape matches (engines and graphs hold its
+        address); a file of another shape replaces table AND state (a fresh, zero Adagrad state of the new row count)."""
         arr = np.load(os.path.join(path, name + '.npy'))
-        self.emb = th.tensor(arr, dtype=th.float32, device=self.emb.device)
-        self.num, self.dim = self.emb.shape
+        if tuple(arr.shape) == tuple(self.emb.shape):
+            self.emb.copy_(th.as_tensor(arr, dtype=th.float32))
+        else:
+            self.emb = th.tensor(arr, dtype=th.float32, device=self.emb.device)
+            self.num, self.dim = self.emb.shape
+            self.state_sum = th.zeros(self.num, dtype=th.float32, device=self.emb.device)

@@ -135,6 +135,41 @@ class _Lane(object):
                                                  neg_chunk_size=chunk, seed=a.seed + 1000 * k, edge_importance=weights)
         self._graph = None
         self._rem_graphs = {}
+        self.dropin_logs = {}
+        # --async_update (reference: tensor_models.py:136-175, general_models.py:639-647): the one-step-stale pipeline of
+        # kge_step_async - the entity update of step s-1 shares a launch with the backward of step s; every captured /
+        # enqueued group of steps ends with a flush
+        self.async_update = bool(getattr(a, 'async_update', False)) and trainer.async_ok
+
+    def _steps(self, batches):
+        eng = self.engine
+        if self.async_update:
+            for b in batches:
+                eng.step_async(b)
+            eng.flush_async()
+        else:
+            for b in batches:
+                eng.step(b)
+
+    def timed_step(self):
+        """one strict step with the reference's four timers (train_pytorch.py:132-152): returns seconds per phase"""
+        import time as _t
+        with th.cuda.stream(self.stream):
+            t0 = _t.time()
+            if self.t.device_sampler:
+                e0, e1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
+                e0.record()
+                b = self.sampler.sample(1)[0]
+                e1.record()
+                d = self.engine.step_timed(b)
+                smp = e0.elapsed_time(e1) * 1e-3
+            else:
+                b = self.sampler.next_batches(1)[0]
+                smp = _t.time() - t0
+                d = self.engine.step_timed(b)
+        if d is not None:
+            d['sample'] = smp
+        return d
 
     def enqueue(self, n):
         """enqueue n steps on this lane's stream (no synchronisation)."""
@@ -146,23 +181,22 @@ class _Lane(object):
                     loss, log = t.model.forward(pos_g, neg_g, t.args.gpu[0])
                     loss.backward()
                     t.model.update(t.args.gpu[0])
+                    for k_, v_ in log.items():          # reference: logs.append(log), averaged at the log marks
+                        self.dropin_logs[k_] = self.dropin_logs.get(k_, 0.0) + float(v_)
                 return
             if not t.device_sampler:
-                for b in self.sampler.next_batches(n):
-                    eng.step(b)
+                self._steps(self.sampler.next_batches(n))
                 return
             G, smp, done = t.args.graph_steps, self.sampler, 0
             if G >= 2 and G % 2 == 0 and n >= G and smp.host_step % 2 == 1:
                 if self._graph is None:
-                    for b in smp.sample(G):           # eager warm-up (also allocates the workspace)
-                        eng.step(b)
+                    self._steps(smp.sample(G))        # eager warm-up (also allocates the workspace)
                     done += G
                     if n - done >= G:
                         self.stream.synchronize()
                         g = th.cuda.CUDAGraph()
                         with th.cuda.graph(g, stream=self.stream if t.n_lanes > 1 else None):
-                            for b in smp.sample(G):
-                                eng.step(b)
+                            self._steps(smp.sample(G))
                         self._graph = g
                         smp.host_step -= G            # the capture itself did not run the steps
                 while self._graph is not None and n - done >= G:
@@ -179,16 +213,14 @@ class _Lane(object):
                     self.stream.synchronize()
                     g = th.cuda.CUDAGraph()
                     with th.cuda.graph(g, stream=self.stream if t.n_lanes > 1 else None):
-                        for b in smp.sample(k):
-                            eng.step(b)
+                        self._steps(smp.sample(k))
                     smp.host_step -= k                # the capture itself did not run the steps
                     self._rem_graphs[key] = g
                 if g is not None:
                     g.replay()
                     smp.host_step += k
                 else:
-                    for b in smp.sample(k):
-                        eng.step(b)
+                    self._steps(smp.sample(k))
                 done += k
 
 
@@ -212,15 +244,25 @@ class Trainer(object):
         self.chunk = N if N <= B else B
         C = B // self.chunk
         # --neg_deg_sample runs on the fused step too (KGE_FLAG_NEG_DEG_SAMPLE); TransR / RESCAL keep the drop-in path for it
-        self.fused = not (args.neg_deg_sample and args.model_name in ('TransR', 'RESCAL'))
+        if args.neg_deg_sample and args.model_name == 'TransR':
+            # TransRScore has no per-op route (its prepare / create_neg closures raise) and the fused step has no
+            # --neg_deg_sample for TransR: refuse before any table is allocated
+            raise KgeError("--neg_deg_sample is not available for TransR")
+        self.fused = not (args.neg_deg_sample and args.model_name == 'RESCAL')
         self.step_flags = _lib.FLAG_NEG_DEG_SAMPLE if (args.neg_deg_sample and self.fused) else 0
         self.device_sampler = self.fused and not args.has_edge_importance and 2 * B + C * N <= 4096
         self.n_lanes = max(1, int(args.num_proc))
+        reg = args.regularization_coef > 0 and args.regularization_norm > 0
+        self.async_ok = self.fused and args.model_name not in ('TransR', 'RESCAL') and not (args.neg_deg_sample and reg)
+        if getattr(args, 'async_update', False) and not self.async_ok:
+            print('--async_update: not available for this model / option combination; running the strict step')
         if self.n_lanes > 1 and not self.fused:
             raise KgeError("--num_proc > 1 needs the fused step (not available with --neg_deg_sample)")
         # the lanes share the tables; every lane trains on its own random share of the triples
         m = self.model
         tables = (m.entity_emb.emb, m.entity_emb.state_sum, m.relation_emb.emb, m.relation_emb.state_sum)
+        if args.model_name == 'TransR':       # the lanes share the projection table too (general_models.py:97-100)
+            tables += (m.score_func.projection_emb.emb, m.score_func.projection_emb.state_sum)
         parts = np.array_split(np.random.RandomState(args.seed).permutation(len(tr[0])), self.n_lanes)
         self.lanes = []
         for k in range(self.n_lanes):
@@ -283,24 +325,43 @@ class Trainer(object):
                 marks.update(range(iv, args.max_step + 1, iv))
         marks.add(args.max_step)
         since_log = 0
+        timed = None
         for nxt in sorted(marks):
             n = nxt - step
+            at_log = args.log_interval > 0 and nxt % args.log_interval == 0
             if n > 0:
                 t0 = time.time()
-                self._run(n)
+                # the reference's four timers (train_pytorch.py:127-177): the LAST step before a log mark runs as four
+                # phase groups with HIP events in between (same kernels, same result); the printed totals are that
+                # step's phase times x the steps of the interval
+                want_timers = at_log and self.fused and self.n_lanes == 1 and not self.lanes[0].async_update
+                self._run(n - 1 if want_timers else n)
+                if want_timers:
+                    th.cuda.synchronize()
+                    timed = self.lanes[0].timed_step()
                 th.cuda.synchronize()
                 t_train += time.time() - t0
                 step, since_log = nxt, since_log + n
-            if step % args.log_interval == 0 and since_log:
+            if at_log and since_log:
                 for lane in self.lanes:
                     if self.fused:
                         sums = lane.engine.read_loss_sums()
                         for k in keys:
                             print('[proc {}][Train]({}/{}) average {}: {}'.format(lane.k, step, args.max_step, k,
                                                                                 sums[idx[k]] / since_log))
+                    else:
+                        for k, v in lane.dropin_logs.items():
+                            print('[proc {}][Train]({}/{}) average {}: {}'.format(lane.k, step, args.max_step, k, v / since_log))
+                        lane.dropin_logs = {}
                     print('[proc {}][Train] {} steps take {:.3f} seconds'.format(lane.k, since_log, time.time() - start))
-                print('[proc {}]sample+forward+backward+update (fused HIP step{}): {:.3f}'.format(
-                    0, '' if self.n_lanes == 1 else ', %d concurrent trainers' % self.n_lanes, t_train))
+                if timed is not None:
+                    print('[proc {}]sample: {:.3f}, forward: {:.3f}, backward: {:.3f}, update: {:.3f}'.format(
+                        0, timed['sample'] * since_log, timed['forward'] * since_log, timed['backward'] * since_log,
+                        timed['update'] * since_log))
+                    timed = None
+                print('[proc {}]sample+forward+backward+update (fused HIP step{}{}): {:.3f}'.format(
+                    0, ', --async_update pipeline' if self.lanes[0].async_update else '',
+                    '' if self.n_lanes == 1 else ', %d concurrent trainers' % self.n_lanes, t_train))
                 since_log, start = 0, time.time()
             if args.valid and step % args.eval_interval == 0 and step > 1 and self.dataset.valid is not None:
                 valid_start = time.time()
@@ -331,7 +392,7 @@ class ShardedTrainer(object):
         self.dev = th.device("cuda", args.gpu[rank])
         B, N = args.batch_size, args.neg_sample_size
         self.chunk = N if N <= B else B
-        self.fused, self.n_lanes = True, 1
+        self.fused, self.n_lanes, self.async_ok = True, 1, False
         self.device_sampler = 2 * B + (B // self.chunk) * N <= 4096
         if args.has_edge_importance or not self.device_sampler:
             raise KgeError("multi-GPU training uses the on-device sampler: no --has_edge_importance, "
@@ -367,6 +428,8 @@ class ShardedTrainer(object):
         from . import eval as kev
         args, ds = self.args, self.dataset
         trip = getattr(ds, which)
+        if trip is None:
+            raise KgeError("the dataset has no %s split" % which)
         h, r, t = (np.asarray(x) for x in trip[:3])
         if args.eval_percent < 1:
             keep = np.random.RandomState(args.seed + 17).permutation(len(h))[:max(1, int(len(h) * args.eval_percent))]
@@ -405,7 +468,7 @@ class ShardedTrainer(object):
                 self.lane.enqueue(n)
                 th.cuda.synchronize()
                 step, since_log = nxt, since_log + n
-            if step % args.log_interval == 0 and since_log:
+            if args.log_interval > 0 and step % args.log_interval == 0 and since_log:
                 sums = self.engine.read_loss_sums()
                 for k in keys:
                     print('[proc {}][Train]({}/{}) average {}: {}'.format(rank, step, args.max_step, k,
@@ -441,23 +504,31 @@ def _mp_worker(rank, args, port):
             print('Total initialize time {:.3f} seconds'.format(time.time() - init_time_start))
         start = time.time()
         trainer.train()
+        failure = None
         if rank == 0:
-            print('training takes {} seconds'.format(time.time() - start))
-            ent, rel = trainer.full_tables()
-            if not args.no_save_emb:
-                print('Save model to {}'.format(args.save_path))
-                np.save(os.path.join(args.save_path, '%s_%s_entity.npy' % (args.dataset, args.model_name)), ent.cpu().numpy())
-                np.save(os.path.join(args.save_path, '%s_%s_relation.npy' % (args.dataset, args.model_name)), rel.cpu().numpy())
-                conf = dict(vars(args))
-                conf.update({'emp_file': dataset.emap_fname, 'rmap_file': dataset.rmap_fname})
-                with open(os.path.join(args.save_path, 'config.json'), 'w') as f:
-                    json.dump(conf, f, indent=4)
-            if args.test:
-                start = time.time()
-                trainer.evaluate('test', 'Test')
-                print('testing takes {:.3f} seconds'.format(time.time() - start))
+            # whatever happens in rank 0's save / test section, every rank must still reach the barrier below
+            # (a rank-0-only exception used to leave the others waiting for the gloo timeout)
+            try:
+                print('training takes {} seconds'.format(time.time() - start))
+                ent, rel = trainer.full_tables()
+                if not args.no_save_emb:
+                    print('Save model to {}'.format(args.save_path))
+                    np.save(os.path.join(args.save_path, '%s_%s_entity.npy' % (args.dataset, args.model_name)), ent.cpu().numpy())
+                    np.save(os.path.join(args.save_path, '%s_%s_relation.npy' % (args.dataset, args.model_name)), rel.cpu().numpy())
+                    conf = dict(vars(args))
+                    conf.update({'emp_file': dataset.emap_fname, 'rmap_file': dataset.rmap_fname})
+                    with open(os.path.join(args.save_path, 'config.json'), 'w') as f:
+                        json.dump(conf, f, indent=4)
+                if args.test:
+                    start = time.time()
+                    trainer.evaluate('test', 'Test')
+                    print('testing takes {:.3f} seconds'.format(time.time() - start))
+            except Exception as e:      # noqa: BLE001 - re-raised after the barrier
+                failure = e
         dist.barrier()
         trainer.tabs.close()
+        if failure is not None:
+            raise failure
     finally:
         dist.destroy_process_group()
 
@@ -481,6 +552,12 @@ def main(argv=None):
     if len(args.gpu) > 1:                        # multi-GPU: one process per GPU on peer-to-peer shared tables
         if min(args.gpu) < 0:
             raise KgeError("dglke_amd trains on the GPU only: pass --gpu <ids> (there is no CPU fallback)")
+        if args.model_name in ('RESCAL', 'TransR'):
+            raise KgeError("%s is not available on the multi-GPU sharded tables: train it on one GPU" % args.model_name)
+        if args.has_edge_importance:
+            raise KgeError("multi-GPU training uses the on-device sampler: no --has_edge_importance")
+        if args.log_interval <= 0:
+            raise KgeError("--log_interval must be positive")
         if args.num_proc > len(args.gpu):            # reference: several trainer processes per GPU (train.py:94-100, 115-119)
             if args.num_proc % len(args.gpu):
                 raise KgeError("--num_proc should be a multiple of the number of GPUs")
@@ -490,8 +567,12 @@ def main(argv=None):
         args.soft_rel_part = args.strict_rel_part = False
         launch_multi_gpu(args)
         return None
+    if args.log_interval <= 0:
+        raise KgeError("--log_interval must be positive")
     dataset = get_dataset(args.data_path, args.dataset, args.format, args.delimiter, args.data_files,
                           args.has_edge_importance)
+    if args.test and dataset.test is None:
+        raise KgeError("--test: the dataset has no test split")
     if args.neg_sample_size_eval < 0:
         args.neg_sample_size_eval = dataset.n_entities
     args.batch_size = get_compatible_batch_size(args.batch_size, args.neg_sample_size)

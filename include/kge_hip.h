@@ -262,6 +262,16 @@ int kge_step_async(kge_pipe *pipe, const kge_hparams *hp, const kge_tables *tb, 
                    const kge_step_out *out, void *ws, size_t ws_bytes, void *stream);
 int kge_step_async_flush(kge_pipe *pipe, void *stream);
 
+/* ---- the strict step in four pieces (the reference's per-phase timers, train_pytorch.py:127-177: sample / forward /
+ * backward / update): calling the four phase groups in this order on one stream IS kge_step_fused - same kernels,
+ * same workspace; the caller puts events between them.  TransR's forward projections sit in GATHER. */
+#define KGE_PHASE_GATHER   1   /* ids -> rows, positive scores, pos-side vectors, positive-loss part */
+#define KGE_PHASE_FORWARD  2   /* chunked negative scores + loss */
+#define KGE_PHASE_BACKWARD 4   /* gradients w.r.t. the pos-side vectors, the negative rows and the per-edge rows */
+#define KGE_PHASE_UPDATE   8   /* row-sparse Adagrad on both tables */
+int kge_step_phase(const kge_hparams *hp, const kge_tables *tb, const kge_batch *b, const kge_step_out *out,
+                   void *ws, size_t ws_bytes, int phases, void *stream);
+
 /* ---- range-sharded training (one process per GPU) ----
  * kge_step_grads: same as kge_step_fused but instead of updating the entity table it EMITS, per
  * union entry u, the two trace gradients and their Adagrad increments so that the owner rank can
@@ -350,10 +360,13 @@ int kge_ipc_close(void *base);
 
 /* ---- on-device sampler + plan builder (replaces the DGL EdgeSampler wrappers of
  * dataloader/sampler.py:376-419, 823-876 and the host plan of dglke_amd/plan.py) ----
- * heads/rels/tails: the training triples in HBM; perm: epoch permutation or NULL; state: device
- * int64[2] = {position in the epoch, step number (1-based)}, advanced by the call; builds n_slots
+ * heads/rels/tails: the training triples in HBM; perm: base edge permutation or NULL (sequential order);
+ * state: device int64[2] = {(legacy) position, step number (1-based)}, advanced by the call; builds n_slots
  * consecutive batches (batch k = step state[1]+k: odd steps corrupt tails, even steps heads;
- * C*N uniform negatives with replacement from a counter-based RNG keyed by (seed, step)).
+ * C*N uniform negatives with replacement from a counter-based RNG keyed by (seed, step)).  Epochs consist of
+ * floor(n_train / B) WHOLE batches (the trailing partial batch is dropped, dataloader/sampler.py:503-504) and
+ * every epoch has its own edge order (shuffle=True): epoch 0 = perm, epoch e > 0 = perm composed with an affine
+ * bijection of [0, n_train) keyed by (seed, e).  n_train >= B.
  * Limits: 2B + C*N <= 4096 (one workgroup sorts a batch in LDS). */
 size_t kge_sampler_slot_bytes(int B, int C, int N);
 int kge_sample_batches(const int64_t *heads, const int64_t *rels, const int64_t *tails,

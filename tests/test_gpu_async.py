@@ -128,3 +128,43 @@ def test_async_at_cfg_t_shape_is_deterministic_and_close_to_oracle():
     _close(outs[0][1], es, 2e-3, 1e-9, "entity state")
     _close(outs[0][0], e64, 1e-4, 1e-2 * 0.25, "entity table")
     _close(outs[0][2], r64, 1e-4, 1e-2 * 0.25, "relation table")
+
+
+def test_dropin_model_async_update_matches_the_stale_oracle():
+    """the reference loop with --async_update on the drop-in classes (train_pytorch.py:120-121, 141-152, 194-195):
+    KEModel.create_async_update() -> [forward, backward, update] x n -> finish_async_update(); the entity updates land
+    one step late, the relation updates at once - against oracle.train_steps_async."""
+    from test_gpu_parity import make_args
+    from dglke_amd import plan
+    from dglke_amd.dataloader import NegGraph, PosGraph
+    from dglke_amd.general_models import KEModel
+    case = dict(model="DistMult", n_ent=70, n_rel=6, hidden=32, gamma=12.0, lr=0.1, reg_coef=1e-5, reg_norm=3, adv=True,
+                adv_temp=1.0, de=False, dr=False)
+    chunk, N, C = 16, 16, 2
+    cfg = O.Config(case["model"], case["gamma"], case["hidden"], case["lr"], adv=True, adv_temp=1.0, reg_coef=case["reg_coef"],
+                   reg_norm=3)
+    rng = np.random.RandomState(2)
+    ent = rng.uniform(-cfg.emb_init, cfg.emb_init, size=(case["n_ent"], cfg.ent_dim)).astype(np.float32)
+    rel = rng.uniform(-cfg.emb_init, cfg.emb_init, size=(case["n_rel"], cfg.rel_dim)).astype(np.float32)
+    bts = []
+    for s in range(1, 6):
+        bt = O.synth_batch(rng, case["n_ent"], case["n_rel"], C * chunk, N, chunk, s)
+        bt.update(chunk=chunk, N=N)
+        bts.append(bt)
+    e64, r64 = ent.astype(np.float64), rel.astype(np.float64)
+    es, rs = np.zeros(len(ent)), np.zeros(len(rel))
+    O.train_steps_async(cfg, e64, es, r64, rs, bts)
+    m = KEModel(make_args(case), case["model"], case["n_ent"], case["n_rel"], case["hidden"], case["gamma"])
+    m.entity_emb.emb.copy_(torch.from_numpy(ent)); m.relation_emb.emb.copy_(torch.from_numpy(rel))
+    m.entity_emb.state_sum.zero_(); m.relation_emb.state_sum.zero_()
+    m.create_async_update()
+    for bt in bts:
+        b = plan.make_batch(bt["h"], bt["t"], bt["r"], bt["neg"], chunk, N, bt["neg_head"], DEV)
+        loss, log = m.forward(PosGraph(b), NegGraph(b), 0)
+        loss.backward()
+        m.update(0)
+    m.finish_async_update()
+    torch.cuda.synchronize()
+    _close(m.entity_emb.state_sum.cpu(), es, 2e-3, 1e-9, "entity state")
+    _close(m.entity_emb.emb.cpu(), e64, 1e-4, 1e-2 * case["lr"], "entity table")
+    _close(m.relation_emb.emb.cpu(), r64, 1e-4, 1e-2 * case["lr"], "relation table")

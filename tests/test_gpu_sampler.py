@@ -16,8 +16,8 @@ def test_device_plan_equals_host_plan(n_ent, n_rel, B, N, chunk):
     rng = np.random.RandomState(0)
     n_train = 5 * B + 17
     h, r, t = rng.randint(0, n_ent, n_train), rng.randint(0, n_rel, n_train), rng.randint(0, n_ent, n_train)
-    s = DeviceSampler(h, r, t, n_ent, B, N, DEV, n_slots=6, neg_chunk_size=chunk, seed=3)
-    batches = s.sample()
+    s = DeviceSampler(h, r, t, n_ent, B, N, DEV, n_slots=5, neg_chunk_size=chunk, seed=3)
+    batches = s.sample()                                       # the 5 whole batches of epoch 0
     torch.cuda.synchronize()
     perm = s.perm.cpu().numpy()
     C = B // chunk
@@ -48,12 +48,32 @@ def test_device_plan_equals_host_plan(n_ent, n_rel, B, N, chunk):
     assert not np.array_equal(allneg[:C * N], allneg[C * N:2 * C * N])
     if n_ent > 1000:
         assert 0.35 * n_ent < allneg.mean() < 0.65 * n_ent
-    # a second launch continues the epoch and the step counter
+    # a second launch continues the step counter: epoch 1 (the 17 trailing triples of epoch 0 are dropped), new order
     more = s.sample(2)
     torch.cuda.synchronize()
     a = s.slot_arrays(0)
-    e = perm[(6 * B + np.arange(B)) % n_train]
-    assert np.array_equal(a["h_gid"], h[e]) and more[0].neg_head == (7 % 2 == 0)
+    assert more[0].neg_head == (6 % 2 == 0)
+    assert not np.array_equal(a["h_gid"], h[perm[np.arange(B)]]), "epoch 1 repeats epoch 0's first batch"
+
+
+def test_epochs_are_whole_batches_in_a_new_order():
+    """reference: EdgeSampler(shuffle=True) reshuffles every epoch and the trailing partial batch is dropped
+    (dataloader/sampler.py:408-419, 503-504).  Heads are the edge index here, so the sampled ids ARE the edges."""
+    from dglke_amd.dataloader import DeviceSampler
+    B, N, n_train, n_ent = 64, 16, 64 * 7 + 23, 10000
+    h = np.arange(n_train)
+    z = np.zeros(n_train, np.int64)
+    s = DeviceSampler(h, z, z, n_ent, B, N, DEV, n_slots=21, seed=5)      # 3 epochs of 7 whole batches
+    s.sample()
+    torch.cuda.synchronize()
+    epochs = [np.concatenate([s.slot_arrays(7 * e + k)["h_gid"] for k in range(7)]) for e in range(3)]
+    for e, ids in enumerate(epochs):
+        assert len(np.unique(ids)) == 7 * B, "epoch %d repeats an edge" % e     # a bijection: no edge twice in an epoch
+        assert ids.min() >= 0 and ids.max() < n_train
+    assert not np.array_equal(epochs[0], epochs[1]) and not np.array_equal(epochs[1], epochs[2])
+    # batches are not just the same sets in another order: epoch 1's first batch mixes edges of many epoch-0 batches
+    where0 = {int(x): k // B for k, x in enumerate(epochs[0])}
+    assert len({where0.get(int(x), -1) for x in epochs[1][:B]}) > 3
 
 
 def test_step_from_device_batch_equals_step_from_host_plan():
