@@ -130,6 +130,59 @@ def test_train_cli_hogwild_lanes(tmp_path, capsys):
     assert mrr > 10 * 2.0 / 400
 
 
+def _base(tmp_path, model="TransE_l2"):
+    data = str(tmp_path / "kg")
+    _planted(data)
+    return ["--model_name", model, "--format", "udd_hrt", "--dataset", "toy", "--data_path", data, "--data_files",
+            "e.dict", "r.dict", "train.txt", "valid.txt", "test.txt", "--save_path", str(tmp_path / "ckpts"), "--gpu", "0",
+            "--batch_size", "256", "--neg_sample_size", "64", "--hidden_dim", "32", "-g", "8", "--lr", "0.25", "-adv",
+            "-rc", "1e-7", "--log_interval", "300", "--test", "--no_save_emb", "--graph_steps", "100"]
+
+
+def test_train_cli_prints_the_reference_timers(tmp_path, capsys):
+    """train_pytorch.py:170-172: '[proc 0]sample: ..., forward: ..., backward: ..., update: ...' at every log mark"""
+    from dglke_amd import train as T
+    T.main(_base(tmp_path) + ["--max_step", "600"])
+    out = capsys.readouterr().out
+    lines = [l for l in out.split("\n") if l.startswith("[proc 0]sample: ")]
+    assert len(lines) == 2, out
+    vals = [float(x.split(": ")[1]) for x in lines[0].replace("[proc 0]", "").split(", ")]
+    assert len(vals) == 4 and all(v > 0 for v in vals) and sum(vals) < 5.0
+
+
+@pytest.mark.parametrize("model", ["TransE_l2", "RotatE"])
+def test_train_cli_async_update(tmp_path, capsys, model):
+    """--async_update: the one-step-stale pipeline (kge_step_async) behind the reference's flag; it still learns, and
+    the run is reproducible bit for bit"""
+    from dglke_amd import train as T
+    argv = _base(tmp_path, model) + ["--max_step", "1200", "--async_update"] + (["-de"] if model == "RotatE" else [])
+    tr = T.main(argv)
+    out = capsys.readouterr().out
+    assert tr.lanes[0].async_update and "--async_update pipeline" in out
+    assert "[proc 0][Train](1200/1200) average loss:" in out
+    mrr = float([l for l in out.split("\n") if l.startswith("[0]Test average MRR:")][0].split(":")[1])
+    assert mrr > 10 * 2.0 / 400
+    tr2 = T.main(argv)
+    capsys.readouterr()
+    import torch
+    assert torch.equal(tr.model.entity_emb.emb, tr2.model.entity_emb.emb)
+
+
+def test_train_cli_transr_lanes_and_rejected_flags(tmp_path, capsys):
+    """--num_proc 2 with TransR: every lane shares the projection table too; TransR + --neg_deg_sample is refused
+    before anything is allocated; a non-positive --log_interval is refused"""
+    from dglke_amd import train as T
+    from dglke_amd._lib import KgeError
+    tr = T.main(_base(tmp_path, "TransR") + ["--max_step", "300", "--num_proc", "2", "--lr", "0.05"])
+    out = capsys.readouterr().out
+    assert len(tr.lanes) == 2 and tr.lanes[1].engine.proj.data_ptr() == tr.model.score_func.projection_emb.emb.data_ptr()
+    assert "[proc 1][Train](300/300) average loss:" in out
+    with pytest.raises(KgeError):
+        T.main(_base(tmp_path, "TransR") + ["--max_step", "10", "--neg_deg_sample"])
+    with pytest.raises(KgeError):
+        T.main(_base(tmp_path) + ["--max_step", "10", "--log_interval", "0"])
+
+
 @pytest.mark.parametrize("extra,nproc", [([], 2), (["--num_proc", "4"], 4)], ids=["one_per_gpu", "num_proc_4"])
 def test_train_cli_multi_process_shared_tables(tmp_path, extra, nproc):
     """`--gpu 0 0`: two trainer processes (here on one GPU) on peer-to-peer shared tables - the multi-GPU mode
