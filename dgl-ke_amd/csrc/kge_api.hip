@@ -347,6 +347,37 @@ int kge_adagrad_scatter(float *table, float *state_sum, int64_t n_rows, int dim,
     return KGE_OK;
 }
 
+int kge_scatter_add_rows(float *out, int64_t n_rows, int dim, const int64_t *idx, const float *src, int64_t n_idx, void *stream) {
+    if ((n_idx && (!out || !idx || !src)) || dim <= 0 || n_rows < 0 || n_idx < 0) return fail(KGE_ERR_ARG, "kge_scatter_add_rows: bad argument");
+    KGE_TRY(launch_scatter_add_rows(out, dim, idx, src, n_idx, (hipStream_t)stream));
+    return KGE_OK;
+}
+
+int kge_pnorm_pow(const float *x, int64_t n, int dim, int p, float *out, void *ws, size_t ws_bytes, void *stream) {
+    if (!out || (n && !x) || n < 0 || dim <= 0 || p <= 0 || !ws || ws_bytes < (size_t)(n > 0 ? n : 1) * sizeof(float))
+        return fail(KGE_ERR_ARG, "kge_pnorm_pow: bad argument (workspace: n floats)");
+    KGE_TRY(launch_pnorm(x, n, dim, p, (float *)ws, out, (hipStream_t)stream));
+    return KGE_OK;
+}
+
+int kge_pnorm_pow_bwd(const float *x, int64_t n, int dim, int p, const float *gout, float *gx, void *stream) {
+    if ((n && (!x || !gx)) || !gout || n < 0 || dim <= 0 || p <= 0) return fail(KGE_ERR_ARG, "kge_pnorm_pow_bwd: bad argument");
+    KGE_TRY(launch_pnorm_bwd(x, n * (int64_t)dim, p, gout, gx, (hipStream_t)stream));
+    return KGE_OK;
+}
+
+int kge_mask_diag(float *x, int C, int chunk, int Np, void *stream) {
+    if (!x || C < 0 || chunk < 0 || Np <= 0) return fail(KGE_ERR_ARG, "kge_mask_diag: bad argument");
+    KGE_TRY(launch_mask_diag(x, C, chunk, Np, (hipStream_t)stream));
+    return KGE_OK;
+}
+
+int kge_rank_from_scores(const float *neg, const float *pos, const float *bias, int64_t E, int64_t N, int64_t *ranks, void *stream) {
+    if ((E && (!neg || !pos || !ranks)) || E < 0 || N < 0 || N >= (1 << 24)) return fail(KGE_ERR_ARG, "kge_rank_from_scores: bad argument");
+    KGE_TRY(launch_rank_mask(neg, pos, bias, E, N, ranks, (hipStream_t)stream));
+    return KGE_OK;
+}
+
 int kge_adagrad_apply_packed(float *table, float *state_sum, int64_t n_rows, int dim,
                              const int64_t *idx, const float *msg, int ld, int64_t n, int ntraces,
                              float lr, float eps, void *stream) {

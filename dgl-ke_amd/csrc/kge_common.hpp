@@ -363,6 +363,11 @@ int launch_adagrad_apply_rows(float *table, float *state, int dim, const int64_t
                               const float *g, const float *gs, int64_t n, float lr, float eps,
                               hipStream_t s);
 int launch_reduce_acc(float *acc, float *out4, int zero_after, hipStream_t s);
+int launch_scatter_add_rows(float *out, int dim, const int64_t *idx, const float *src, int64_t n, hipStream_t s);
+int launch_pnorm(const float *x, int64_t n, int dim, int p, float *part, float *out, hipStream_t s);
+int launch_pnorm_bwd(const float *x, int64_t total, int p, const float *gout, float *gx, hipStream_t s);
+int launch_mask_diag(float *x, int C, int chunk, int Np, hipStream_t s);
+int launch_rank_mask(const float *neg, const float *pos, const float *bias, int64_t E, int64_t N, int64_t *ranks, hipStream_t s);
 int launch_rank_count(const float *S, const float *P, int rows, int64_t N, const int64_t *filt_ptr,
                       const int64_t *filt_ids, int64_t e0, int32_t *ranks, hipStream_t s);
 struct GemmArgs {                   // LDS-staged fp32-MFMA negative scoring (kge_neg_gemm.hip)

@@ -1100,3 +1100,91 @@ int launch_adagrad_apply_rows(float *table, float *state, int dim, const int64_t
         hipLaunchKernelGGL(apply_rows_kernel<1>, dim3(nb), dim3(KGE_BLOCK), 0, s, table, state, dim, idx, g, gs, n, lr, eps);
     return check_launch();
 }
+
+// ------------------------------------------------------------------------------------------
+// small ops of the drop-in (per-op autograd) route that used to be torch glue
+// ------------------------------------------------------------------------------------------
+// out[idx[k], :] += src[k, :]  - the backward of gathering rows through LOCAL ids (pos_g.ndata['emb'][head_ids],
+// general_models.py:384-388, 410-414; autograd of advanced indexing = index_add): float atomics like the reference's.
+__global__ __launch_bounds__(KGE_BLOCK) void scatter_add_rows_kernel(float *out, int dim, const int64_t *idx, const float *src,
+                                                                     int64_t n) {
+    const int64_t k = WAVE_ID();
+    if (k >= n) return;
+    float *o = out + idx[k] * (int64_t)dim;
+    const float *g = src + k * (int64_t)dim;
+    for (int d = LANE(); d < dim; d += 64) atomicAdd(o + d, g[d]);
+}
+int launch_scatter_add_rows(float *out, int dim, const int64_t *idx, const float *src, int64_t n, hipStream_t s) {
+    if (n == 0) return KGE_OK;
+    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(blocks_for_waves(n)), dim3(KGE_BLOCK), 0, s, out, dim, idx, src, n);
+    return check_launch();
+}
+
+// x.norm(p) ** p over a [n, dim] block (tensor_models.py:54 `norm`; general_models.py:572-576): per-row partials, then a
+// fixed-order single-block sum (deterministic); and its gradient gout * p * |x|^(p-1) * sign(x)
+__global__ __launch_bounds__(KGE_BLOCK) void pnorm_rows_kernel(const float *x, int64_t n, int dim, int p, float *part) {
+    const int64_t k = WAVE_ID();
+    if (k >= n) return;
+    const float *r = x + k * (int64_t)dim;
+    float v = 0.f;
+    for (int d = LANE(); d < dim; d += 64) v += reg_val(r[d], p);
+    v = wave_sum(v);
+    if (LANE() == 0) part[k] = v;
+}
+__global__ __launch_bounds__(KGE_BLOCK) void pnorm_final_kernel(const float *part, int64_t n, float *out) {
+    __shared__ float sh[KGE_WAVES_PER_BLOCK];
+    float v = 0.f;
+    for (int64_t k = threadIdx.x; k < n; k += KGE_BLOCK) v += part[k];
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+__global__ void pnorm_bwd_kernel(const float *x, int64_t total, int p, const float *gout, float *gx) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < total) gx[k] = reg_grad(x[k], *gout, p);
+}
+int launch_pnorm(const float *x, int64_t n, int dim, int p, float *part, float *out, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(pnorm_rows_kernel, dim3(blocks_for_waves(n)), dim3(KGE_BLOCK), 0, s, x, n, dim, p, part);
+    hipLaunchKernelGGL(pnorm_final_kernel, dim3(1), dim3(KGE_BLOCK), 0, s, part, n, out);
+    return check_launch();
+}
+int launch_pnorm_bwd(const float *x, int64_t total, int p, const float *gout, float *gx, hipStream_t s) {
+    if (total == 0) return KGE_OK;
+    hipLaunchKernelGGL(pnorm_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, total, p, gout, gx);
+    return check_launch();
+}
+
+// x[c, i, i] = 0 for i < chunk on a [C, chunk, Np] block, in place: the diagonal mask of --neg_deg_sample
+// (general_models.py:401-402, 429-432: mask[:, 0::(neg_sample_size + 1)] = 0)
+__global__ void mask_diag_kernel(float *x, int C, int chunk, int Np) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= C * chunk) return;
+    const int i = k % chunk;
+    if (i < Np) x[(int64_t)k * Np + i] = 0.f;
+}
+int launch_mask_diag(float *x, int C, int chunk, int Np, hipStream_t s) {
+    if (C * chunk == 0) return KGE_OK;
+    hipLaunchKernelGGL(mask_diag_kernel, dim3((C * chunk + 255) / 256), dim3(256), 0, s, x, C, chunk, Np);
+    return check_launch();
+}
+
+// ranks[i] = 1 + #{j : neg[i, j] >= pos[i] and bias[i, j] != -1}   (KEModel.forward_test, general_models.py:463-478)
+__global__ __launch_bounds__(KGE_BLOCK) void rank_mask_kernel(const float *neg, const float *pos, const float *bias, int64_t E,
+                                                              int64_t N, int64_t *ranks) {
+    const int64_t i = WAVE_ID();
+    if (i >= E) return;
+    const float p = pos[i];
+    const float *r = neg + i * N;
+    const float *b = bias ? bias + i * N : nullptr;
+    float c = 0.f;                                   // < 2^24 candidates per row: exact in fp32
+    for (int64_t j = LANE(); j < N; j += 64) c += (r[j] >= p && (!b || b[j] != -1.f)) ? 1.f : 0.f;
+    c = wave_sum(c);
+    if (LANE() == 0) ranks[i] = 1 + (int64_t)c;
+}
+int launch_rank_mask(const float *neg, const float *pos, const float *bias, int64_t E, int64_t N, int64_t *ranks, hipStream_t s) {
+    if (E == 0) return KGE_OK;
+    hipLaunchKernelGGL(rank_mask_kernel, dim3(blocks_for_waves(E)), dim3(KGE_BLOCK), 0, s, neg, pos, bias, E, N, ranks);
+    return check_launch();
+}
+

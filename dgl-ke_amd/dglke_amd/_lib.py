@@ -89,6 +89,11 @@ _SIGNATURES = {
                                c_p, c_sz, c_p]),
     "kge_reduce_loss": (c_i, [c_p, c_p, c_i, c_p]),
     "kge_adagrad_scatter": (c_i, [c_p, c_p, c_i64, c_i, c_p, c_p, c_i64, c_f, c_f, c_p]),
+    "kge_scatter_add_rows": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_i64, c_p]),
+    "kge_pnorm_pow": (c_i, [c_p, c_i64, c_i, c_i, c_p, c_p, c_sz, c_p]),
+    "kge_pnorm_pow_bwd": (c_i, [c_p, c_i64, c_i, c_i, c_p, c_p, c_p]),
+    "kge_mask_diag": (c_i, [c_p, c_i, c_i, c_i, c_p]),
+    "kge_rank_from_scores": (c_i, [c_p, c_p, c_p, c_i64, c_i64, c_p, c_p]),
     "kge_sampler_slot_bytes": (c_sz, [c_i, c_i, c_i]),
     "kge_sample_batches": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i, c_i, c_i, c_i, C.c_uint64, c_p, c_p, c_sz,
                                  c_i, c_p]),

@@ -34,8 +34,10 @@ class PosGraph(object):
         return self.batch.B
 
     def apply_edges(self, fn):
+        from . import ops
         emb = self.ndata['emb']
-        self.edata.update(fn(_Edges({'emb': emb[self._h]}, {'emb': emb[self._t]}, self.edata)))
+        self.edata.update(fn(_Edges({'emb': ops.gather_local(emb, self._h)}, {'emb': ops.gather_local(emb, self._t)},
+                                    self.edata)))
 
 
 class NegGraph(object):

@@ -142,26 +142,22 @@ class KEModel(object):
         neg_sample_size = neg_g.neg_sample_size
         head_ids, tail_ids = pos_g.all_edges(order='eid')
         rel = pos_g.edata['emb']
-        mask = None
         if neg_g.neg_head:
             neg_ids = neg_g.ndata['id'][neg_g.head_nid]
             neg = self.entity_emb(neg_ids, gpu_id, trace)
-            pos_side = pos_g.ndata['emb'][tail_ids]
+            pos_side = ops.gather_local(pos_g.ndata['emb'], tail_ids)
             other = head_ids
         else:
             neg_ids = neg_g.ndata['id'][neg_g.tail_nid]
             neg = self.entity_emb(neg_ids, gpu_id, trace)
-            pos_side = pos_g.ndata['emb'][head_ids]
+            pos_side = ops.gather_local(pos_g.ndata['emb'], head_ids)
             other = tail_ids
         if neg_deg_sample:
             # in-batch positives of the corrupted side are used as extra negatives, the true
             # edge is masked out (general_models.py:396-402, 417-423, 429-432)
-            extra = pos_g.ndata['emb'][other].reshape(num_chunks, chunk_size, -1)
+            extra = ops.gather_local(pos_g.ndata['emb'], other).reshape(num_chunks, chunk_size, -1)
             neg = th.cat([extra, neg.reshape(num_chunks, neg_sample_size, -1)], 1)
             neg_sample_size = chunk_size + neg_sample_size
-            mask = th.ones((num_chunks, chunk_size * neg_sample_size), dtype=th.float32,
-                           device=pos_side.device)
-            mask[:, 0::(neg_sample_size + 1)] = 0
             neg = neg.reshape(num_chunks * neg_sample_size, -1)
         if neg_g.neg_head:
             neg, pos_side = self.head_neg_prepare(pos_g.edata['id'], num_chunks, neg, pos_side,
@@ -175,7 +171,7 @@ class KEModel(object):
                                             neg_sample_size)
         if neg_deg_sample:
             neg_g.neg_sample_size = neg_sample_size
-            return neg_score * mask.reshape(num_chunks, chunk_size, neg_sample_size)
+            return ops.mask_diag(neg_score, num_chunks, chunk_size, neg_sample_size)     # mask[:, 0::(N'+1)] = 0
         return neg_score
 
     # ---- evaluation (general_models.py:436-485), rank computed on the GPU --------------
@@ -190,11 +186,10 @@ class KEModel(object):
                 pos_g, neg_g, to_device=cuda, gpu_id=gpu_id, trace=False,
                 neg_deg_sample=getattr(self.args, 'neg_deg_sample_eval', False))
             neg_scores = reshape(neg_scores, batch_size, -1)
-            ge = neg_scores >= pos_scores
+            bias = None
             if getattr(self.args, 'eval_filter', False):
-                bias = reshape(neg_g.edata['bias'], batch_size, -1).to(ge.device)
-                ge = ge & (bias != -1)
-            rankings = (ge.sum(dim=1) + 1).tolist()
+                bias = reshape(neg_g.edata['bias'], batch_size, -1)
+            rankings = ops.rank_from_scores(neg_scores, pos_scores, bias).tolist()
         for ranking in rankings:
             logs.append({'MRR': 1.0 / ranking, 'MR': float(ranking),
                          'HITS@1': 1.0 if ranking <= 1 else 0.0,
@@ -215,7 +210,9 @@ class KEModel(object):
         coef = getattr(self.args, 'regularization_coef', 0.0) or 0.0
         nm = getattr(self.args, 'regularization_norm', 0) or 0
         if coef > 0.0 and nm > 0:
-            reg = coef * (norm(self.entity_emb.curr_emb(), nm) + norm(self.relation_emb.curr_emb(), nm))
+            # x.norm(p) ** p of the concatenated traces = the sum over the traces (no th.cat copy)
+            terms = [ops.pnorm_pow(data, nm) for _, data in self.entity_emb.trace + self.relation_emb.trace]
+            reg = coef * sum(terms[1:], terms[0])
             log['regularization'] = get_scalar(reg)
             loss = loss + reg
         return loss, log

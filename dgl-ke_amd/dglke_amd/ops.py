@@ -142,3 +142,90 @@ def loss_fwd_bwd(pos, neg, w, genre, adv, adv_temp, pairwise, margin):
     loss3 = [pos_loss, neg_loss, loss])."""
     return _Loss.apply(pos, neg, w, _lib.LOSS_IDS[genre], bool(adv), float(adv_temp),
                        bool(pairwise), float(margin))
+
+
+class _GatherLocal(torch.autograd.Function):
+    """rows of a [U, D] block through LOCAL ids (pos_g.ndata['emb'][head_ids], general_models.py:384-388, 410-414):
+    forward = kge_gather_rows, backward = kge_scatter_add_rows (index_add with duplicates, like torch's autograd)."""
+    @staticmethod
+    def forward(ctx, block, idx):
+        block, idx = _f32(block), _i64(idx)
+        out = torch.empty((idx.shape[0], block.shape[1]), dtype=torch.float32, device=block.device)
+        check(lib().kge_gather_rows(ptr(block), block.shape[0], block.shape[1], ptr(idx), idx.shape[0], ptr(out),
+                                    stream_ptr()))
+        ctx.save_for_backward(idx)
+        ctx.shape = tuple(block.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        g = _f32(g)
+        out = torch.zeros(ctx.shape, dtype=torch.float32, device=g.device)
+        check(lib().kge_scatter_add_rows(ptr(out), out.shape[0], out.shape[1], ptr(idx), ptr(g), idx.shape[0],
+                                         stream_ptr()))
+        return out, None
+
+
+def gather_local(block, idx):
+    return _GatherLocal.apply(block, idx)
+
+
+class _PnormPow(torch.autograd.Function):
+    """x.norm(p) ** p (tensor_models.py:54 `norm`), value and gradient in libkge_hip."""
+    @staticmethod
+    def forward(ctx, x, p):
+        x = _f32(x)
+        x2 = x.reshape(-1, x.shape[-1]) if x.dim() > 1 else x.reshape(1, -1)
+        out = torch.empty((), dtype=torch.float32, device=x.device)
+        ws = torch.empty(max(x2.shape[0], 1), dtype=torch.float32, device=x.device)
+        check(lib().kge_pnorm_pow(ptr(x2), x2.shape[0], x2.shape[1], int(p), ptr(out), ptr(ws), ws.numel() * 4,
+                                  stream_ptr()))
+        ctx.save_for_backward(x2)
+        ctx.meta = (int(p), tuple(x.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (x2,) = ctx.saved_tensors
+        p, shape = ctx.meta
+        gx = torch.empty_like(x2)
+        check(lib().kge_pnorm_pow_bwd(ptr(x2), x2.shape[0], x2.shape[1], p, ptr(_f32(gout).reshape(1)), ptr(gx),
+                                      stream_ptr()))
+        return gx.reshape(shape), None
+
+
+def pnorm_pow(x, p):
+    return _PnormPow.apply(x, p)
+
+
+class _MaskDiag(torch.autograd.Function):
+    """--neg_deg_sample: the chunk x chunk diagonal of the [C, chunk, Np] score block is the positive edge itself -
+    its score becomes 0 and carries no gradient (general_models.py:401-402, 429-432)."""
+    @staticmethod
+    def forward(ctx, x, C, chunk, Np):
+        y = _f32(x).clone()
+        check(lib().kge_mask_diag(ptr(y), C, chunk, Np, stream_ptr()))
+        ctx.meta = (C, chunk, Np)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        C, chunk, Np = ctx.meta
+        g = _f32(g).clone()
+        check(lib().kge_mask_diag(ptr(g), C, chunk, Np, stream_ptr()))
+        return g, None, None, None
+
+
+def mask_diag(x, C, chunk, Np):
+    return _MaskDiag.apply(x, int(C), int(chunk), int(Np))
+
+
+def rank_from_scores(neg, pos, bias=None):
+    """rankings of KEModel.forward_test (general_models.py:463-478): 1 + #{j: neg[i,j] >= pos[i], bias[i,j] != -1}"""
+    neg, pos = _f32(neg), _f32(pos).reshape(-1)
+    E, N = neg.shape
+    ranks = torch.empty(E, dtype=torch.int64, device=neg.device)
+    b = _f32(bias.to(neg.device).float()) if bias is not None else None
+    check(lib().kge_rank_from_scores(ptr(neg), ptr(pos), ptr(b) if b is not None else None, E, N, ptr(ranks), stream_ptr()))
+    return ranks

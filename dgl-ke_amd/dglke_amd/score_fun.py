@@ -2,8 +2,9 @@
 (models/pytorch/score_fun.py): `edge_func`, `infer`, `prepare`, `create_neg_prepare`, `forward`,
 `create_neg`, `update`, `reset_parameters`, `save`, `load`.
 
-In scope (hand-written kernels, forward and analytic backward): TransE_l1 / TransE_l2
-(score_fun.py:40), DistMult (:222), ComplEx (:289), RotatE (:451), SimplE (:556).
+Hand-written kernels, forward and analytic backward: TransE_l1 / TransE_l2 (score_fun.py:40), DistMult (:222),
+ComplEx (:289), RotatE (:451), SimplE (:556), RESCAL (:378); TransR (:110) per-op = library GEMM projections +
+the TransE_l1 kernels in relation space (its fast path is the fused step).
 """
 import torch as th
 
@@ -109,9 +110,15 @@ class SimplEScore(_HipScore):
 
 
 class TransRScore(_HipScore):
-    """score_fun.py:110-220: owns the third table, projection_emb [n_rel, entity_dim * relation_dim].  The HIP
-    build runs TransR through the fused step (`KEModel.train_step` / `dglke_train`) and `kge_rank_eval_ex`; the
-    per-op autograd route of the other score functions (edge_func / create_neg closures) is not provided."""
+    """score_fun.py:110-220: owns the third table, projection_emb [n_rel, entity_dim * relation_dim].
+
+    Per-op route (the reference's own decomposition): `prepare` projects head and tail of every positive edge with its
+    relation's matrix (projection trace 0), the `create_neg_prepare` closures gather the matrices AGAIN (trace 1), project
+    the uncorrupted side and EVERY negative of the chunk with EVERY positive's matrix - plain batched matrix products,
+    run by the library GEMM behind torch.matmul with its autograd - and `edge_func` / `create_neg` are L1 distances in
+    relation space: the TransE_l1 HIP kernels on the projected rows (one 'chunk' per positive for the negatives, whose
+    projections differ per positive).  The fast path for TransR is the fused step (`KEModel.train_step`, kge_transr.hip),
+    which never materialises the [C, chunk, N, relation_dim] tensor this route passes around like the reference."""
     model_name = 'TransR'
 
     def __init__(self, gamma, projection_emb, relation_dim, entity_dim):
@@ -119,18 +126,57 @@ class TransRScore(_HipScore):
         self.projection_emb = projection_emb
         self.relation_dim, self.entity_dim = relation_dim, entity_dim
 
-    def _no_modular(self, *a, **k):
-        from ._lib import KgeError
-        raise KgeError("TransR runs through the fused step (KEModel.train_step / dglke_train) and kge_rank_eval_ex; "
-                       "the per-op drop-in route is not built for it")
+    def edge_func(self, edges):
+        # gamma - ||head_emb + emb - tail_emb||_1 (score_fun.py:121-126) = the TransE_l1 edge score on projected rows
+        return {'score': ops.score_pos('TransE_l1', edges.data['head_emb'], edges.data['emb'], edges.data['tail_emb'],
+                                       self.gamma, 1.0)}
 
-    edge_func = infer = prepare = _no_modular
+    def infer(self, head_emb, rel_emb, tail_emb):
+        pass                                              # like the reference (score_fun.py:128-129)
 
-    def create_neg(self, neg_head):
-        return self._no_modular
+    def prepare(self, g, gpu_id, trace=False):
+        head_ids, tail_ids = g.all_edges(order='eid')
+        projection = self.projection_emb(g.edata['id'], gpu_id, trace).reshape(-1, self.entity_dim, self.relation_dim)
+        emb = g.ndata['emb']
+        g.edata['head_emb'] = th.matmul(ops.gather_local(emb, head_ids).unsqueeze(1), projection).squeeze(1)
+        g.edata['tail_emb'] = th.matmul(ops.gather_local(emb, tail_ids).unsqueeze(1), projection).squeeze(1)
 
     def create_neg_prepare(self, neg_head):
-        return self._no_modular
+        def project(rel_id, num_chunks, pos, neg, gpu_id, trace):
+            projection = self.projection_emb(rel_id, gpu_id, trace)
+            projection = projection.reshape(num_chunks, -1, self.entity_dim, self.relation_dim)
+            pos = th.matmul(pos.reshape(num_chunks, -1, 1, self.entity_dim), projection)
+            pos = pos.reshape(num_chunks, -1, self.relation_dim)
+            # (num_chunks, num_rel, num_neg_nodes, rel_dim): every negative through every positive's matrix
+            neg = th.matmul(neg.reshape(num_chunks, 1, -1, self.entity_dim), projection)
+            return pos, neg
+        if neg_head:
+            def fn(rel_id, num_chunks, head, tail, gpu_id, trace=False):
+                tail, head = project(rel_id, num_chunks, tail, head, gpu_id, trace)
+                return head, tail
+        else:
+            def fn(rel_id, num_chunks, head, tail, gpu_id, trace=False):
+                head, tail = project(rel_id, num_chunks, head, tail, gpu_id, trace)
+                return head, tail
+        return fn
+
+    def create_neg(self, neg_head):
+        gamma = self.gamma
+
+        def fn(heads, relations, tails, num_chunks, chunk_size, neg_sample_size):
+            # BOTH closures of the reference subtract the relation (score_fun.py:203-204, 212-213):
+            #   head mode: gamma - ||heads' - (tails - r)||_1      tail mode: gamma - ||(heads - r) - tails'||_1
+            # = TransE_l1 negative scores with B 'chunks' of one positive each (the projected negatives differ per
+            #   positive); tail mode feeds -r so that the kernel's pos-side vector h + (-r) is h - r
+            B = num_chunks * chunk_size
+            if neg_head:
+                s = ops.score_neg('TransE_l1', True, tails.reshape(B, -1), relations.reshape(B, -1),
+                                  heads.reshape(B * neg_sample_size, -1), B, 1, neg_sample_size, gamma, 1.0, self.flags)
+            else:
+                s = ops.score_neg('TransE_l1', False, heads.reshape(B, -1), -relations.reshape(B, -1),
+                                  tails.reshape(B * neg_sample_size, -1), B, 1, neg_sample_size, gamma, 1.0, self.flags)
+            return s.reshape(num_chunks, chunk_size, neg_sample_size)
+        return fn
 
     def reset_parameters(self):
         self.projection_emb.init(1.0)                     # score_fun.py:170-171

@@ -145,6 +145,23 @@ int kge_adagrad_scatter(float *table, float *state_sum, int64_t n_rows, int dim,
                         const int64_t *idx, const float *grad, int64_t n_idx, float lr, float eps,
                         void *stream);
 
+/* ---- small ops of the drop-in route (KEModel.forward / forward_test with per-op autograd) ----
+ * kge_scatter_add_rows: out[idx[k],:] += src[k,:] - autograd of the LOCAL-id gathers pos_g.ndata['emb'][head_ids]
+ *   (general_models.py:384-388, 410-414), i.e. index_add; float atomics, out is accumulated into (caller zeroes).
+ * kge_pnorm_pow(_bwd): x.norm(p)**p of a [n, dim] block (tensor_models.py:54, used by the regulariser
+ *   general_models.py:572-576) - deterministic two-stage sum, ws = n floats - and its gradient
+ *   gx = gout[0] * p * |x|^(p-1) * sign(x).
+ * kge_mask_diag: x[c,i,i] = 0 in place on [C, chunk, Np] - the --neg_deg_sample mask (general_models.py:401-402).
+ * kge_rank_from_scores: ranks[i] = 1 + #{j: neg[i,j] >= pos[i] and bias[i,j] != -1} (bias NULL: no filter) -
+ *   the ranking of KEModel.forward_test (general_models.py:463-478). */
+int kge_scatter_add_rows(float *out, int64_t n_rows, int dim, const int64_t *idx, const float *src, int64_t n_idx,
+                         void *stream);
+int kge_pnorm_pow(const float *x, int64_t n, int dim, int p, float *out, void *ws, size_t ws_bytes, void *stream);
+int kge_pnorm_pow_bwd(const float *x, int64_t n, int dim, int p, const float *gout, float *gx, void *stream);
+int kge_mask_diag(float *x, int C, int chunk, int Np, void *stream);
+int kge_rank_from_scores(const float *neg, const float *pos, const float *bias, int64_t E, int64_t N, int64_t *ranks,
+                         void *stream);
+
 /* ---- fused step: KEModel.forward + loss.backward() + KEModel.update
  * (train_pytorch.py:141-152; general_models.py:529-588) for one batch ----
  *

@@ -47,7 +47,7 @@ def make_args(case):
     a.strict_rel_part = False
     a.soft_rel_part = False
     a.lr = case["lr"]
-    a.neg_deg_sample = False
+    a.neg_deg_sample = bool(case.get("neg_deg", False))
     a.neg_deg_sample_eval = False
     a.eval_filter = False
     a.regularization_coef = case["reg_coef"]
@@ -68,6 +68,9 @@ def build_model(case, z):
     m.relation_emb.emb.copy_(torch.from_numpy(z["init_relation"]))
     m.entity_emb.state_sum.zero_()
     m.relation_emb.state_sum.zero_()
+    if "init_projection" in z:           # TransR: third table (score_fun.py:114-118)
+        m.score_func.projection_emb.emb.copy_(torch.from_numpy(z["init_projection"]))
+        m.score_func.projection_emb.state_sum.zero_()
     return m
 
 
@@ -83,10 +86,11 @@ def grad_tol(ref):
     return 3e-4 * max(float(np.abs(ref).max()), 1e-12)
 
 
-@pytest.mark.parametrize("name", golden_names(transr=False))
+@pytest.mark.parametrize("name", golden_names(transr=None, nd=None))
 def test_dropin_model_matches_reference(name):
     """reference loop: model.forward -> loss.backward() -> model.update (train_pytorch.py:141-152)
-    on the HIP-backed KEModel, every op one C-ABI call."""
+    on the HIP-backed KEModel, every op one C-ABI call (TransR: its projections are library GEMMs, the two
+    projection traces are checked too)."""
     from dglke_amd.dataloader import NegGraph, PosGraph
     z, case = load_golden(name)
     m = build_model(case, z)
@@ -109,9 +113,15 @@ def test_dropin_model_matches_reference(name):
         _close(et[0][1].grad.cpu(), z[p + "g_pos_ent"], 3e-4, grad_tol(z[p + "g_pos_ent"]), name + " g_pos_ent")
         _close(et[1][1].grad.cpu(), z[p + "g_neg"], 3e-4, grad_tol(z[p + "g_neg"]), name + " g_neg")
         _close(rt[0][1].grad.cpu(), z[p + "g_rel"], 3e-4, grad_tol(z[p + "g_rel"]), name + " g_rel")
+        if case["model"] == "TransR":
+            assert len(m.score_func.projection_emb.trace) == 2          # prepare + neg-prepare (score_fun.py:131-166)
         m.update(0)
         _close(m.entity_emb.state_sum.cpu(), z[p + "entity_state"], 2e-3, 1e-9, name + " ent state")
         _close(m.relation_emb.state_sum.cpu(), z[p + "relation_state"], 2e-3, 1e-9, name + " rel state")
+        if (p + "projection_state") in z:
+            pe = m.score_func.projection_emb
+            _close(pe.state_sum.cpu(), z[p + "projection_state"], 2e-3, 1e-9, name + " projection state")
+            _close(pe.emb.cpu(), z[p + "projection"], 1e-4, 5e-3 * case["lr"], name + " projection rows")
         if (p + "entity") in z:
             _close(m.entity_emb.emb.cpu(), z[p + "entity"], 1e-4, 5e-3 * case["lr"], name + " entity rows")
             _close(m.relation_emb.emb.cpu(), z[p + "relation"], 1e-4, 5e-3 * case["lr"], name + " relation rows")
