@@ -144,6 +144,14 @@ template <> __device__ __forceinline__ void st<4>(float *p, const Pack<4> &x) {
     *reinterpret_cast<float4 *>(p) = make_float4(x.v[0], x.v[1], x.v[2], x.v[3]);
 }
 template <> __device__ __forceinline__ void st<1>(float *p, const Pack<1> &x) { *p = x.v[0]; }
+// streaming store: the line is not kept dirty in this XCD's L2 (the consumer is another kernel, usually on another XCD,
+// and every dirty line must be written back before the next kernel of the stream may start)
+template <int V> __device__ __forceinline__ void st_nt(float *p, const Pack<V> &x);
+template <> __device__ __forceinline__ void st_nt<4>(float *p, const Pack<4> &x) {
+    f32x4 v = {x.v[0], x.v[1], x.v[2], x.v[3]};
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(p));
+}
+template <> __device__ __forceinline__ void st_nt<1>(float *p, const Pack<1> &x) { __builtin_nontemporal_store(x.v[0], p); }
 template <int V> __device__ __forceinline__ Pack<V> zero_pack() {
     Pack<V> r;
 #pragma unroll

@@ -13,6 +13,7 @@
 
 using namespace kge;
 KGE_TL_DEFINE(rowwise)
+#define KGE_ST_OUT st_nt      // P rows: consumed two kernels later by the update (any XCD) - streaming store
 
 #define WAVE_ID() ((int64_t)blockIdx.x * KGE_WAVES_PER_BLOCK + (threadIdx.x >> 6))
 #define LANE() (threadIdx.x & 63)
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void edge_fwd_kernel(EdgeFwdArgs a_in) {
                                 const float u = hv.v[e] + rv.v[e] - tv.v[e];
                                 pv.v[e] = dp * ((MODEL == KGE_TRANSE_L1) ? sgnf(u) : u * inv);
                             }
-                            st<V>(P + off, pv);
+                            KGE_ST_OUT<V>(P + off, pv);
                         }
                     }
                 }

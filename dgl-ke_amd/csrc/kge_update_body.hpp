@@ -5,6 +5,7 @@
 #pragma once
 #include "kge_common.hpp"
 
+#define KGE_ST_ROW kge::st_nt      // updated table rows: read next by another kernel on any XCD - streaming store
 #ifndef LANE
 #define LANE() (threadIdx.x & 63)
 #endif
@@ -186,7 +187,7 @@ __device__ __forceinline__ void update_reg_body(const UpdateArgs &a_in, int nb_e
 #pragma unroll
                         for (int e = 0; e < 4; ++e) y.v[e] = fmaf(g1[k].v[e], k1, y.v[e]);
                     }
-                    st<4>(row + it * 4, y);
+                    KGE_ST_ROW<4>(row + it * 4, y);
                 }
                 if (a.g0) st<4>(a.g0 + u * (int64_t)a.ld_e + it * 4, g0[k]);
                 if (a.g1) st<4>(a.g1 + u * (int64_t)a.ld_e + it * 4, g1[k]);
@@ -288,7 +289,7 @@ __device__ __forceinline__ void update_reg_body(const UpdateArgs &a_in, int nb_e
                     Pack<4> y = x[k];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) y.v[e] = fmaf(gsum[k].v[e], kr, y.v[e]);
-                    st<4>(row + it * 4, y);
+                    KGE_ST_ROW<4>(row + it * 4, y);
                 }
                 if (a.gr) st<4>(a.gr + u * (int64_t)a.ld_r + it * 4, gsum[k]);
             }
