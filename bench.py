@@ -87,6 +87,17 @@ def measured_traffic(workload):
         return None
 
 
+def profiled_kernels(workload):
+    """per-kernel average launch durations of the committed rocprofv3 --kernel-trace --stats summary of this workload
+    (profiles/latest_kernel_stats.json, written by tools/kernel_stats_json.py); None when the profile is of another one."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "latest_kernel_stats.json")) as f:
+            d = json.load(f)
+        return d if d.get("workload") == workload else None
+    except Exception:
+        return None
+
+
 def synth_triples(w, seed):
     """FB15k-shaped synthetic triples: h,t ~ U[0,n_ent), r ~ U[0,n_rel)."""
     rng = np.random.RandomState(seed)
@@ -237,16 +248,12 @@ def async_measure(w, dev, steps, G, flags, seed=0):
     eng = StepEngine(w["model"], w["n_ent"], w["n_rel"], w["hidden"], w["gamma"], w["lr"], dev, w["de"], w["dr"], w["adv"],
                      w["adv_temp"], w["reg_coef"], w["reg_norm"], flags=flags)
     smp = DeviceSampler(h, r, t, w["n_ent"], w["B"], w["N"], dev, n_slots=G, seed=seed)
-    for b in smp.sample():
-        eng.step_async(b)
-    eng.flush_async()
+    eng.steps_async(smp.sample())
     torch.cuda.synchronize()
     eng.reset_parameters()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
-        for b in smp.sample():
-            eng.step_async(b)
-        eng.flush_async()
+        eng.steps_async(smp.sample())
     nrep = max(1, steps // G)
     for _ in range(2):
         g.replay()
@@ -465,6 +472,19 @@ def main():
                      "event_ms_per_step": round(ev_ms / K, 6)},
         "mean_loss": round(accum[2] / K, 6),
     }
+    prof = profiled_kernels(args.workload)
+    if prof:
+        # self-check: the dominant kernel of the committed profile, its share of the step and its own roofline fraction
+        ks = {k: v for k, v in prof["kernels"].items() if "sample" not in k and "reduce_acc" not in k}
+        dom = max(ks, key=lambda k: ks[k]["avg_us"])
+        out["roofline"]["dominant_kernel"] = dom.split("(")[0].replace("void ", "")
+        out["roofline"]["dominant_kernel_us"] = ks[dom]["avg_us"]
+        out["roofline"]["profiled_step_us"] = round(sum(v["avg_us"] for v in ks.values()), 3)
+        out["roofline"]["profile_build"] = prof.get("build")
+        if "neg_bwd_gemm" in dom:
+            d_row = w["hidden"] * (2 if w["de"] else 1)
+            tf = 4.0 * w["B"] * w["N"] * d_row / (ks[dom]["avg_us"] * 1e-6) / 1e12
+            out["roofline"]["mfma_dominant_frac"] = round(tf / 157.3, 5)
     if w["model"] in ("TransE_l2", "DistMult", "ComplEx", "SimplE") and not args.force_pairwise:
         # second bound of SURVEY 8(d): the chunked negative score and its two gradient products on the
         # fp32 matrix cores, 2·B·N·D forward + 4·B·N·D backward, against the dense fp32 MFMA peak

@@ -446,7 +446,9 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
                      const kge_step_out *out, const kge_emit *emit, void *ws, size_t ws_bytes,
                      void *stream, const kge_shards *sh = nullptr, int phases = PH_ALL,
                      UpdateArgs *build_update = nullptr,      // PH_UPD_*: fill the launch arguments instead of launching
-                     const UpdateArgs *co_update = nullptr) { // PH_SCORE: another step's update to run alongside the backward
+                     const UpdateArgs *co_update = nullptr,   // PH_FWD: another step's update to run alongside the forward
+                     EdgeFwdArgs *build_prep = nullptr,       // PH_PREP: fill the launch arguments instead of launching
+                     const EdgeFwdArgs *co_prep = nullptr) {  // PH_BWD: the NEXT step's PREP to run alongside the backward
     if (!hp || !tb || !b || !ws) return fail(KGE_ERR_ARG, "kge_step: null argument");
     kge::ShardMap em{}, rm{};
     if (sh) {
@@ -616,6 +618,7 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
             KGE_TRY(launch_edge_fwd(nb, s));
         }
     } else {
+        if (build_prep) { *build_prep = ef; return KGE_OK; }
         KGE_TRY(launch_edge_fwd(ef, s));
     }
     }   // PH_PREP
@@ -631,11 +634,23 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         g.S = S; g.adv_temp = hp->adv_temp; g.asq = asq; g.bsq = bsq;
         g.lp = lp; g.w = b->edge_w;
         if (fused_loss) { g.PM = PM; g.PS = PS; g.PL = PL; g.Sraw = out ? out->neg_score : nullptr; }
-        if (phases & PH_FWD) KGE_TRY(launch_neg_fwd_gemm(g, s));
+        if (phases & PH_FWD) {
+            bool fused_launch = false;
+            if (co_update) {                  // async pipeline: forward GEMM(s) + update(s-1) in ONE launch
+                const int rc = launch_neg_fwd_gemm_with_update(g, *co_update, s);
+                if (rc == KGE_OK) fused_launch = true;
+                else if (rc != KGE_ERR_ARG) return fail(rc, "launch_neg_fwd_gemm_with_update failed (%d)", rc);
+                else KGE_TRY(launch_update(*co_update, s));      // no fused instantiation: one after the other
+            }
+            if (!fused_launch) KGE_TRY(launch_neg_fwd_gemm(g, s));
+        }
     } else {
         fill_pair(na, hp->model, C, chunk, N, d_e, hp->gamma, A, Bn, nullptr);
         na.S = S;
-        if (phases & PH_FWD) KGE_TRY(launch_neg_fwd_pair(na, s));
+        if (phases & PH_FWD) {
+            if (co_update) KGE_TRY(launch_update(*co_update, s));
+            KGE_TRY(launch_neg_fwd_pair(na, s));
+        }
     }
 
     // 3. stand-alone loss kernel (only when the loss is not fused into the backward GEMM)
@@ -664,19 +679,21 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         g.row_neg = (fused_loss && want4) ? row_neg : nullptr;
         g.acc = fused_loss ? acc : nullptr;
         bool fused_launch = false;
-        if (co_update) {                      // async pipeline: backward GEMM(s) + update(s-1) in ONE launch
-            const int rc = launch_neg_bwd_gemm_with_update(g, *co_update, s);
+        if (co_prep) {                        // async pipeline: backward GEMM(s) + PREP(s+1) in ONE launch
+            const int rc = launch_neg_bwd_gemm_with_prep(g, *co_prep, s);
             if (rc == KGE_OK) fused_launch = true;
-            else if (rc != KGE_ERR_ARG) return fail(rc, "launch_neg_bwd_gemm_with_update failed (%d)", rc);
-            else KGE_TRY(launch_update(*co_update, s));          // no fused instantiation: one after the other
+            else if (rc != KGE_ERR_ARG) return fail(rc, "launch_neg_bwd_gemm_with_prep failed (%d)", rc);
         }
-        if (!fused_launch) KGE_TRY(launch_neg_bwd_gemm(g, s));
+        if (!fused_launch) {
+            KGE_TRY(launch_neg_bwd_gemm(g, s));
+            if (co_prep) KGE_TRY(launch_edge_fwd(*co_prep, s));  // no fused instantiation: one after the other
+        }
     } else {
-        if (co_update) KGE_TRY(launch_update(*co_update, s));
         na.W = S; na.GA = GA; na.GN = GN;
         na.reg_coef = (reg && !nd) ? hp->reg_coef : 0.f; na.reg_norm = hp->reg_norm;
         na.GNp = gemm ? nullptr : GNp;
         KGE_TRY(launch_neg_bwd_pair(na, s));
+        if (co_prep) KGE_TRY(launch_edge_fwd(*co_prep, s));
     }
 
     // 5. per-edge gradients of head / tail / relation rows (TransE rebuilds them in the update)
@@ -811,6 +828,8 @@ struct kge_pipe {
     int upd_phases;      // what the pending update covers (entity trace, or entity + relation with KGE_FLAG_ASYNC_REL)
     kge_hparams hp; kge_tables tb; kge_batch b; kge_step_out out; bool has_out;
     void *ws; size_t ws_bytes;     // workspace half of the pending step
+    bool prepped;        // PREP of the next step already ran (inside the previous call's backward launch) ...
+    const void *prep_key;          // ... for the batch whose h_gid array is this
 };
 
 int kge_pipe_create(kge_pipe **pipe) {
@@ -834,14 +853,19 @@ size_t kge_step_async_workspace_bytes(const kge_hparams *hp, int B, int C, int c
     return 2 * align_up(one);
 }
 
-int kge_step_async(kge_pipe *p, const kge_hparams *hp, const kge_tables *tb, const kge_batch *b,
+int kge_step_async(kge_pipe *p, const kge_hparams *hp, const kge_tables *tb, const kge_batch *b, const kge_batch *b_next,
                    const kge_step_out *out, void *ws, size_t ws_bytes, void *stream) {
     if (!p || !hp || !tb || !b || !ws) return fail(KGE_ERR_ARG, "kge_step_async: null argument");
     const size_t half = (ws_bytes / 2) & ~(size_t)255;
     void *wsp = (char *)ws + (size_t)p->parity * half;
-    // PREP(s): gathers the rows (update s-2 has landed: stream order) and makes the dense copies SCORE(s) reads
-    if (int rc = step_impl(hp, tb, b, out, nullptr, wsp, half, stream, nullptr, PH_PREP)) return rc;
-    // UPDATE(s-1) lands now, under SCORE(s): same launch as the backward GEMM where a fused instantiation exists
+    void *wsn = (char *)ws + (size_t)(p->parity ^ 1) * half;
+    const bool defer_rel = (hp->flags & KGE_FLAG_ASYNC_REL) != 0;
+    // PREP(s): gathers the rows (update s-2 has landed: stream order) and makes the dense copies the rest of the step
+    // reads - unless the previous call already ran it inside its backward launch
+    if (!(p->prepped && p->prep_key == (const void *)b->h_gid))
+        if (int rc = step_impl(hp, tb, b, out, nullptr, wsp, half, stream, nullptr, PH_PREP)) return rc;
+    p->prepped = false;
+    // launch A: forward(s) || UPDATE(s-1)
     UpdateArgs co{};
     bool have_co = false;
     if (p->pending) {
@@ -854,10 +878,21 @@ int kge_step_async(kge_pipe *p, const kge_hparams *hp, const kge_tables *tb, con
             have_co = true;
         }
     }
-    if (int rc = step_impl(hp, tb, b, out, nullptr, wsp, half, stream, nullptr, PH_SCORE, nullptr, have_co ? &co : nullptr)) return rc;
+    if (int rc = step_impl(hp, tb, b, out, nullptr, wsp, half, stream, nullptr, PH_FWD, nullptr, have_co ? &co : nullptr)) return rc;
+    // launch C: backward(s) || PREP(s+1).  Only when nothing touches the tables between this backward and the next PREP
+    // (relation trace deferred too), for the plain step (no per-step outputs, no --neg_deg_sample id kernel)
+    EdgeFwdArgs ef{};
+    bool have_prep = false;
+    const bool plain_out = !out || (!out->loss4 && !out->pos_score && !out->neg_score && !out->g_pos_ent && !out->g_neg && !out->g_rel);
+    if (b_next && defer_rel && plain_out && !(hp->flags & KGE_FLAG_NEG_DEG_SAMPLE)) {
+        if (int rc = step_impl(hp, tb, b_next, out, nullptr, wsn, half, stream, nullptr, PH_PREP, nullptr, nullptr, &ef)) return rc;
+        have_prep = true;
+    }
+    if (int rc = step_impl(hp, tb, b, out, nullptr, wsp, half, stream, nullptr, PH_BWD, nullptr, nullptr, nullptr,
+                           have_prep ? &ef : nullptr)) return rc;
+    if (have_prep) { p->prepped = true; p->prep_key = (const void *)b_next->h_gid; }
     // the reference defers the ENTITY table only (general_models.py:639-647: create_async_update on entity_emb;
     // relation_emb.update stays in the training loop): relation trace now
-    const bool defer_rel = (hp->flags & KGE_FLAG_ASYNC_REL) != 0;
     if (!defer_rel)
         if (int rc = step_impl(hp, tb, b, out, nullptr, wsp, half, stream, nullptr, PH_UPD_REL)) return rc;
     p->upd_phases = defer_rel ? PH_UPDATE : PH_UPD_ENT;
@@ -876,6 +911,7 @@ int kge_step_async_flush(kge_pipe *p, void *stream) {
         if (int rc = step_impl(&p->hp, &p->tb, &p->b, p->has_out ? &p->out : nullptr, nullptr, p->ws, p->ws_bytes, stream, nullptr,
                                p->upd_phases)) return rc;
     }
+    p->prepped = false;         // a PREP that ran ahead gathered rows without this update: it must not be reused
     return KGE_OK;
 }
 

@@ -407,7 +407,9 @@ bool neg_gemm_fused_loss_supported(int chunk, int N);   // fused loss of the mat
 int launch_neg_fwd_gemm(const GemmArgs &a, hipStream_t s);
 int launch_neg_bwd_gemm(const GemmArgs &a, hipStream_t s);
 struct UpdateArgs;
-int launch_neg_bwd_gemm_with_update(const GemmArgs &a, const UpdateArgs &u, hipStream_t s);   // KGE_ERR_ARG: no fused instantiation
+// horizontally fused launches of the --async_update pipeline (KGE_ERR_ARG: no fused instantiation for the combination)
+int launch_neg_fwd_gemm_with_update(const GemmArgs &a, const UpdateArgs &u, hipStream_t s);
+int launch_neg_bwd_gemm_with_prep(const GemmArgs &a, const EdgeFwdArgs &e, hipStream_t s);
 int launch_neg_fwd_pair(const NegArgs &a, hipStream_t s);
 int launch_neg_bwd_pair(const NegArgs &a, hipStream_t s);
 // ---- RESCAL (kge_rescal.hip) ----

@@ -38,6 +38,7 @@
 // consecutive k (one float4) and feeds element e to MFMA step e.
 #include "kge_common.hpp"
 #include "kge_update_body.hpp"
+#include "kge_edge_fwd_body.hpp"
 
 using namespace kge;
 KGE_TL_DEFINE(gemm)
@@ -66,11 +67,12 @@ __device__ __forceinline__ float sq4(const float4 &v) { return v.x * v.x + v.y *
 #define FU 2    // k-steps (of 16) per register buffer (small on purpose: code size)
 #endif
 
+// `bid` / `nblk`: this workgroup's index and the number of workgroups doing forward-GEMM work (the body is also one half of
+// the horizontally fused "forward GEMM of step s + update of step s-1" launch of the --async_update pipeline)
 template <bool L2, bool FUSE>     // FUSE: emit the factorised loss gradient + per-tile partials instead of the scores
-__global__ __launch_bounds__(KGE_BLOCK) void neg_fwd_gemm_kernel(GemmArgs a, int ti, int tj) {
-    KGE_TL(1);
+__device__ __forceinline__ void neg_fwd_gemm_body(const GemmArgs &a, int ti, int tj, int bid, int nblk) {
     const int lane = threadIdx.x & 63;
-    const int64_t tile = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * KGE_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    const int64_t tile = (int64_t)xcd_remap(bid, nblk) * KGE_WAVES_PER_BLOCK + (threadIdx.x >> 6);
     const int64_t ntiles = (int64_t)a.C * ti * tj;
     if (tile >= ntiles) return;
     const int jt = (int)(tile % tj);
@@ -113,9 +115,6 @@ __global__ __launch_bounds__(KGE_BLOCK) void neg_fwd_gemm_kernel(GemmArgs a, int
     }
 
     FWD_LOAD(a0, b0, 0);
-#ifdef KGE_TL_MARKS
-    KGE_TL_MARK(0);              // first operand fragments (and the epilogue operands) have arrived
-#endif
     for (int g = 0; g < kfull; g += 2 * FU) {
         FWD_LOAD(a1, b1, g + FU);
         FWD_MMA(a0, b0, g);
@@ -124,9 +123,6 @@ __global__ __launch_bounds__(KGE_BLOCK) void neg_fwd_gemm_kernel(GemmArgs a, int
     }
 #undef FWD_LOAD
 #undef FWD_MMA
-#ifdef KGE_TL_MARKS
-    KGE_TL_MARK(1);              // main loop done
-#endif
     if (D & 15) {   // tail k-step: lanes whose 4 floats lie beyond D contribute zeros
         float4 av = zero4(), bv = zero4();
         if (kfull * 16 + kq < D) { av = ldg4(Ap + kfull * 16); bv = ldg4(Bp + kfull * 16); }
@@ -204,6 +200,25 @@ __global__ __launch_bounds__(KGE_BLOCK) void neg_fwd_gemm_kernel(GemmArgs a, int
                 a.PM[o] = mx[r]; a.PS[o] = ps[r]; a.PL[o] = pl[r];
             }
         }
+    }
+}
+
+template <bool L2, bool FUSE>
+__global__ __launch_bounds__(KGE_BLOCK) void neg_fwd_gemm_kernel(GemmArgs a, int ti, int tj) {
+    KGE_TL(1);
+    neg_fwd_gemm_body<L2, FUSE>(a, ti, tj, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// --async_update pipeline, horizontal fusion #1: forward GEMM tiles of step s (first nbG workgroups) + Adagrad update of
+// step s-1 (the rest).  See neg_bwd_prep_kernel below for the other half of the schedule.
+template <bool L2, int NIT, int LEAN>
+__global__ __launch_bounds__(KGE_BLOCK) void neg_fwd_update_kernel(GemmArgs a, int ti, int tj, int nbG, UpdateArgs u, int nb_ent) {
+    if ((int)blockIdx.x < nbG) {
+        KGE_TL(1);
+        neg_fwd_gemm_body<L2, false>(a, ti, tj, (int)blockIdx.x, nbG);
+    } else {
+        KGE_TL(4);
+        update_reg_body<NIT, false, LEAN>(u, nb_ent, (int)blockIdx.x - nbG, (int)gridDim.x - nbG);
     }
 }
 
@@ -512,22 +527,24 @@ __global__ __launch_bounds__(KGE_BLOCK) void neg_bwd_gemm_kernel(GemmArgs a, int
     neg_bwd_gemm_body<L2, FACT>(a, ti, tj, td, bpA, bpN, maxK, (int)blockIdx.x, (int)gridDim.x, smem);
 }
 
-// --async_update pipeline, horizontal fusion: ONE launch whose first nbG workgroups are the backward GEMM tiles of step s
-// and whose remaining workgroups apply the Adagrad update of step s-1 (different workspace half, different work: the
-// update is row read-modify-write traffic, the GEMM tiles sit on the matrix pipe and on L2 operand delivery).  The two
-// halves share nothing; stream order gives the pipeline its dependencies (PREP(s) before, PREP(s+1) after), so no second
-// stream and no events are needed - cross-stream dependencies inside a hipGraph cost 9-15 us of dispatch gaps per step on
-// this stack (profiles/r02_async_pipeline.txt), more than the update they were meant to hide.
-template <bool L2, int NIT, int LEAN>
-__global__ __launch_bounds__(KGE_BLOCK) void neg_bwd_update_kernel(GemmArgs a, int ti, int tj, int td, int bpA, int bpN,
-                                                                   int maxK, int nbG, UpdateArgs u, int nb_ent) {
+// --async_update pipeline, horizontal fusion.  The pipeline (kge_step_async) keeps the exact one-step staleness of the
+// reference's --async_update while only THREE launches per step sit on the critical path:
+//     [ forward GEMM(s) || UPDATE(s-1) ]  ->  loss(s)  ->  [ backward GEMM(s) || PREP(s+1) ]
+// Each fused launch = one grid whose first nbG workgroups run the GEMM tiles and whose remaining workgroups run the other
+// job (different workspace halves / the tables; the two halves share nothing).  Stream order gives every dependency:
+// UPDATE(s-1) after PREP(s) (previous launch) and before PREP(s+1) (next fused launch); PREP(s+1) therefore gathers rows
+// with every update up to s-1 and without update s.  No second stream, no events - cross-stream dependencies inside a
+// hipGraph cost 9-15 us of dispatch gaps per step on this stack (profiles/r02_async_pipeline.txt).
+template <bool L2, int MODEL>
+__global__ __launch_bounds__(KGE_BLOCK) void neg_bwd_prep_kernel(GemmArgs a, int ti, int tj, int td, int bpA, int bpN,
+                                                                 int maxK, int nbG, EdgeFwdArgs e) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     if ((int)blockIdx.x < nbG) {
         KGE_TL(3);
         neg_bwd_gemm_body<L2, false>(a, ti, tj, td, bpA, bpN, maxK, (int)blockIdx.x, nbG, smem);
     } else {
-        KGE_TL(4);
-        update_reg_body<NIT, false, LEAN>(u, nb_ent, (int)blockIdx.x - nbG, (int)gridDim.x - nbG);
+        KGE_TL(0);
+        edge_fwd_body<MODEL, 4, false>(e, (int)blockIdx.x - nbG);
     }
 }
 
@@ -555,33 +572,60 @@ int launch_neg_bwd_gemm(const GemmArgs &a, hipStream_t s) {
     return check_launch_g();
 }
 
-// backward GEMM of one step + Adagrad update of ANOTHER step in one launch (see neg_bwd_update_kernel).
+// forward GEMM of one step + Adagrad update of ANOTHER step in one launch (neg_fwd_update_kernel).
 // Returns KGE_ERR_ARG when the combination has no fused instantiation (the caller then launches the two kernels apart).
-int launch_neg_bwd_gemm_with_update(const GemmArgs &a, const UpdateArgs &u, hipStream_t s) {
-    if (a.C == 0 || !a.W || a.PM) return KGE_ERR_ARG;
-    const int maxK = a.chunk > a.N ? a.chunk : a.N;
-    if (maxK > GB_MAXK) return KGE_ERR_ARG;
+int launch_neg_fwd_gemm_with_update(const GemmArgs &a, const UpdateArgs &u, hipStream_t s) {
+    if (a.C == 0 || a.PM) return KGE_ERR_ARG;
     const int dmax = u.model_d_e > u.d_r ? u.model_d_e : u.d_r;
     const bool inplace = !u.emit_ent && !u.emit_rel && !u.g0 && !u.g1 && !u.gs0 && !u.gs1 && !u.gr && !u.gsr && !u.rid &&
                          !u.dry && !u.nd_chunk && u.em.n == 0 && u.rm.n == 0;
     if (!inplace || u.model_d_e % 4 || u.d_r % 4 || dmax > 1024) return KGE_ERR_ARG;
     const int nbE = (u.UE + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK, nbR = (u.UR + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK;
     if (nbE + nbR == 0) return KGE_ERR_ARG;
+    const int ti = (a.chunk + 15) / 16, tj = (a.N + 15) / 16;
+    const int64_t ntiles = (int64_t)a.C * ti * tj;
+    const int nbG = (int)((ntiles + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK);
+    const bool l2 = a.model == KGE_TRANSE_L2;
+    const int nit = dmax <= 256 ? 1 : (dmax <= 512 ? 2 : 4);
+    const int lean = u.transe_fast ? 1 : 2;
+    const dim3 g(nbG + nbE + nbR), b(KGE_BLOCK);
+#define KGE_FU(L2_, N_, LE_) hipLaunchKernelGGL((neg_fwd_update_kernel<L2_, N_, LE_>), g, b, 0, s, a, ti, tj, nbG, u, nbE)
+#define KGE_FU_N(N_) do { if (l2) { if (lean == 1) KGE_FU(true, N_, 1); else KGE_FU(true, N_, 2); }           \
+                          else { if (lean == 1) KGE_FU(false, N_, 1); else KGE_FU(false, N_, 2); } } while (0)
+    if (nit == 1) KGE_FU_N(1); else if (nit == 2) KGE_FU_N(2); else KGE_FU_N(4);
+#undef KGE_FU_N
+#undef KGE_FU
+    return check_launch_g();
+}
+
+// backward GEMM of one step + PREP (edge forward) of the NEXT step in one launch (neg_bwd_prep_kernel).
+// Returns KGE_ERR_ARG when the combination has no fused instantiation.
+int launch_neg_bwd_gemm_with_prep(const GemmArgs &a, const EdgeFwdArgs &e, hipStream_t s) {
+    if (a.C == 0 || !a.W || a.PM) return KGE_ERR_ARG;
+    const int maxK = a.chunk > a.N ? a.chunk : a.N;
+    if (maxK > GB_MAXK) return KGE_ERR_ARG;
+    const bool cx = kge::is_complex_model(e.model);
+    const bool vec = cx ? ((e.d_e / 2) % 4 == 0 && e.d_r % 4 == 0) : (e.d_e % 4 == 0);
+    if (!vec || e.src.em.n || e.src.rm.n) return KGE_ERR_ARG;
+    const bool negjob = e.bsq || e.Bn;
+    const int64_t waves = (int64_t)e.B + (negjob ? e.n_neg : 0);
+    EdgeFwdArgs ee = e;
+    if (!negjob) ee.n_neg = 0;
+    const int nbP = (int)((waves + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK);
+    if (nbP == 0) return KGE_ERR_ARG;
     const int ti = (a.chunk + 15) / 16, tj = (a.N + 15) / 16, td = (a.D + 63) / 64;
     const int bpA = (ti * td + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK;
     const int bpN = (tj * td + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK;
     const int nbG = a.C * (bpA + bpN);
     const int mk = (maxK + 3) & ~3;
     const size_t sm = (size_t)mk * 8;
-    const bool l2 = a.model == KGE_TRANSE_L2;
-    const int nit = dmax <= 256 ? 1 : (dmax <= 512 ? 2 : 4);
-    const int lean = u.transe_fast ? 1 : 2;
-    const dim3 g(nbG + nbE + nbR), b(KGE_BLOCK);
-#define KGE_BU(L2_, N_, LE_) hipLaunchKernelGGL((neg_bwd_update_kernel<L2_, N_, LE_>), g, b, sm, s, a, ti, tj, td, bpA, bpN, mk, nbG, u, nbE)
-#define KGE_BU_N(N_) do { if (l2) { if (lean == 1) KGE_BU(true, N_, 1); else KGE_BU(true, N_, 2); }           \
-                          else { if (lean == 1) KGE_BU(false, N_, 1); else KGE_BU(false, N_, 2); } } while (0)
-    if (nit == 1) KGE_BU_N(1); else if (nit == 2) KGE_BU_N(2); else KGE_BU_N(4);
-#undef KGE_BU_N
-#undef KGE_BU
+    const dim3 g(nbG + nbP), b(KGE_BLOCK);
+#define KGE_BP(L2_, M_) hipLaunchKernelGGL((neg_bwd_prep_kernel<L2_, M_>), g, b, sm, s, a, ti, tj, td, bpA, bpN, mk, nbG, ee)
+    if (a.model == KGE_TRANSE_L2 && e.model == KGE_TRANSE_L2) KGE_BP(true, KGE_TRANSE_L2);
+    else if (a.model == KGE_DISTMULT && e.model == KGE_DISTMULT) KGE_BP(false, KGE_DISTMULT);
+    else if (a.model == KGE_COMPLEX && e.model == KGE_COMPLEX) KGE_BP(false, KGE_COMPLEX);
+    else if (a.model == KGE_SIMPLE && e.model == KGE_SIMPLE) KGE_BP(false, KGE_SIMPLE);
+    else return KGE_ERR_ARG;
+#undef KGE_BP
     return check_launch_g();
 }

@@ -10,10 +10,10 @@
 // reductions by cross-lane shuffles, no LDS, no atomics on the fused path.
 #include "kge_common.hpp"
 #include "kge_update_body.hpp"
+#include "kge_edge_fwd_body.hpp"
 
 using namespace kge;
 KGE_TL_DEFINE(rowwise)
-#define KGE_ST_OUT st_nt      // P rows: consumed two kernels later by the update (any XCD) - streaming store
 
 #define WAVE_ID() ((int64_t)blockIdx.x * KGE_WAVES_PER_BLOCK + (threadIdx.x >> 6))
 #define LANE() (threadIdx.x & 63)
@@ -78,173 +78,11 @@ int launch_gather_rows_sharded(float *const *shard_rows, int n_shards, int64_t p
 // ------------------------------------------------------------------------------------------
 // edge forward: positive score p_i, pos-side vector a_i (and |a_i|^2), |neg_j|^2
 // ------------------------------------------------------------------------------------------
-// LEAN: local (un-sharded) tables and the Logsigmoid criterion fixed at compile time (no 64-bit divisions of
-// the shard map, no three-way loss switch) - the configuration of every single-GPU BASELINE workload
+// edge forward: body in kge_edge_fwd_body.hpp
 template <int MODEL, int V, bool LEAN>
-__global__ __launch_bounds__(KGE_BLOCK) void edge_fwd_kernel(EdgeFwdArgs a_in) {
+__global__ __launch_bounds__(KGE_BLOCK) void edge_fwd_kernel(EdgeFwdArgs a) {
     KGE_TL(0);
-    EdgeFwdArgs a = a_in;
-    if constexpr (LEAN) { a.src.em.n = 0; a.src.rm.n = 0; a.lp.genre = KGE_LOSS_LOGSIGMOID; a.row_pos = nullptr; a.Hc = nullptr; }
-    const int64_t w = WAVE_ID();
-    const int lane = LANE();
-    if (w < a.B) {
-        const int64_t i = w;
-        const float *h = table_row(a.src.em, a.src.hbase, a.src.hidx, i, a.d_e);
-        const float *t = table_row(a.src.em, a.src.tbase, a.src.tidx, i, a.d_e);
-        const float *r = table_row(a.src.rm, a.src.rbase, a.src.ridx, i, a.d_r);
-        float *A = a.A ? a.A + i * (int64_t)a.d_e : nullptr;
-#ifdef KGE_TL_MARKS
-        KGE_TL_MARK(0);          // ids have arrived
-#endif
-        float ps = 0.f, as = 0.f;
-        if constexpr (!is_complex_model(MODEL)) {
-            const int nit = a.d_e / V;
-            for (int it = lane; it < nit; it += 64) {
-                const int off = it * V;
-                const Pack<V> hv = ld<V>(h + off), rv = ld<V>(r + off), tv = ld<V>(t + off);
-                Pack<V> av;
-#pragma unroll
-                for (int e = 0; e < V; ++e) {
-                    const float hh = hv.v[e], rr = rv.v[e], tt = tv.v[e];
-                    const float x = a.neg_head ? tt : hh;
-                    if constexpr (MODEL == KGE_DISTMULT) {
-                        ps += hh * rr * tt;
-                        av.v[e] = x * rr;
-                    } else {
-                        const float u = hh + rr - tt;
-                        if constexpr (MODEL == KGE_TRANSE_L1) ps += fabsf(u); else ps += u * u;
-                        av.v[e] = a.neg_head ? (x - rr) : (x + rr);
-                    }
-                    as += av.v[e] * av.v[e];
-                }
-                if (A) st<V>(A + off, av);
-            }
-        } else {
-            const int hd = a.d_e / 2;
-            const int nit = hd / V;
-            for (int it = lane; it < nit; it += 64) {
-                const int off = it * V;
-                const Pack<V> rh = ld<V>(h + off), ih = ld<V>(h + hd + off);
-                const Pack<V> rt = ld<V>(t + off), it_ = ld<V>(t + hd + off);
-                Pack<V> rr, ir;
-                if constexpr (MODEL == KGE_COMPLEX || MODEL == KGE_SIMPLE) {
-                    rr = ld<V>(r + off); ir = ld<V>(r + hd + off);     // SimplE: rel | rel_inv
-                } else {
-                    const Pack<V> ph = ld<V>(r + off);
-#pragma unroll
-                    for (int e = 0; e < V; ++e) sincosf(ph.v[e] / a.rot_div, &ir.v[e], &rr.v[e]);
-                }
-                Pack<V> are, aim;
-#pragma unroll
-                for (int e = 0; e < V; ++e) {
-                    const float c = rr.v[e], s = ir.v[e];
-                    if constexpr (MODEL == KGE_SIMPLE) {
-                        // (h_i, h_j) = (rh, ih), (t_i, t_j) = (rt, it_), (rel, rel_inv) = (c, s); score_fun.py:562-568
-                        ps += 0.5f * (rh.v[e] * c * it_.v[e] + rt.v[e] * s * ih.v[e]);
-                        // pos-side vector, 1/2 folded in, laid out so that a . neg = the chunked score
-                        // (score_fun.py:611-622 head mode, :626-641 tail mode)
-                        if (a.neg_head) { are.v[e] = 0.5f * c * it_.v[e]; aim.v[e] = 0.5f * s * rt.v[e]; }
-                        else            { are.v[e] = 0.5f * s * ih.v[e];  aim.v[e] = 0.5f * rh.v[e] * c; }
-                        continue;
-                    } else if constexpr (MODEL == KGE_COMPLEX) {
-                        ps += rh.v[e] * rt.v[e] * c + ih.v[e] * it_.v[e] * c +
-                              rh.v[e] * it_.v[e] * s - ih.v[e] * rt.v[e] * s;
-                    } else {
-                        const float re = rh.v[e] * c - ih.v[e] * s - rt.v[e];
-                        const float im = rh.v[e] * s + ih.v[e] * c - it_.v[e];
-                        ps += sqrtf(re * re + im * im);
-                    }
-                    if (a.neg_head) {   // a = t o conj(r)
-                        are.v[e] = rt.v[e] * c + it_.v[e] * s;
-                        aim.v[e] = -rt.v[e] * s + it_.v[e] * c;
-                    } else {            // a = h o r
-                        are.v[e] = rh.v[e] * c - ih.v[e] * s;
-                        aim.v[e] = rh.v[e] * s + ih.v[e] * c;
-                    }
-                    as += are.v[e] * are.v[e] + aim.v[e] * aim.v[e];
-                }
-                if (A) { st<V>(A + off, are); st<V>(A + hd + off, aim); }
-            }
-        }
-#ifdef KGE_TL_MARKS
-        KGE_TL_MARK(1);          // rows read, pos-side vector stored
-#endif
-        if (a.pos_score || a.do_pos_loss) {
-            ps = wave_sum(ps);          // xor butterfly: every lane holds the sum
-            float p;
-            if constexpr (MODEL == KGE_TRANSE_L1 || MODEL == KGE_ROTATE) p = a.gamma - ps;
-            else if constexpr (MODEL == KGE_TRANSE_L2) p = a.gamma - sqrtf(ps);
-            else if constexpr (MODEL == KGE_SIMPLE) p = fminf(fmaxf(ps, -KGE_SIMPLE_CLAMP), KGE_SIMPLE_CLAMP);
-            else p = ps;
-            if (lane == 0 && a.pos_score) a.pos_score[i] = p;
-            if (a.do_pos_loss) {
-                // pointwise losses: d loss / d p_i depends on p_i only (loss.py:82-94)
-                const float w = a.w ? a.w[i] : 1.f;
-                const float invB = 1.f / (float)a.B;
-                float pl, dpl;
-                criterion(a.lp.genre, p, 1.f, a.lp.margin, pl, dpl);
-                if constexpr (MODEL == KGE_SIMPLE) { if (fabsf(ps) >= KGE_SIMPLE_CLAMP) dpl = 0.f; }   // saturated clamp
-                const float dp = dpl * w * 0.5f * invB;
-                if (lane == 0) {
-                    const float plw = pl * w * invB;
-                    if (a.dpos) a.dpos[i] = dp;
-                    if (a.row_pos) a.row_pos[i] = plw;
-                    if (a.acc) {
-                        const bool uq = a.B <= KGE_ACC_SLOTS;
-                        const int slot = (int)(i & (KGE_ACC_SLOTS - 1));
-                        acc_add(&a.acc[0 * KGE_ACC_SLOTS + slot], plw, uq);
-                        acc_add(&a.acc[2 * KGE_ACC_SLOTS + slot], 0.5f * plw, uq);
-                    }
-                }
-                if constexpr (MODEL == KGE_TRANSE_L1 || MODEL == KGE_TRANSE_L2) {
-                    if (a.P) {
-                        // P_i = dp * d|u|/du, u = h + r - t  (second pass: rows are L1/L2 hot)
-                        float inv = 0.f;
-                        if constexpr (MODEL == KGE_TRANSE_L2) { const float nr = sqrtf(ps); inv = nr > 0.f ? 1.f / nr : 0.f; }
-                        float *P = a.P + i * (int64_t)a.d_e;
-                        for (int it = lane; it < a.d_e / V; it += 64) {
-                            const int off = it * V;
-                            const Pack<V> hv = ld<V>(h + off), rv = ld<V>(r + off), tv = ld<V>(t + off);
-                            Pack<V> pv;
-#pragma unroll
-                            for (int e = 0; e < V; ++e) {
-                                const float u = hv.v[e] + rv.v[e] - tv.v[e];
-                                pv.v[e] = dp * ((MODEL == KGE_TRANSE_L1) ? sgnf(u) : u * inv);
-                            }
-                            KGE_ST_OUT<V>(P + off, pv);
-                        }
-                    }
-                }
-            }
-        }
-        if (a.asq) {
-            as = wave_sum(as);
-            if (lane == 0) a.asq[i] = as;
-        }
-        if (a.Hc) {      // dense copies of the gathered rows (second pass: the rows are L1 / L2 hot)
-            for (int it = lane; it < a.d_e / V; it += 64) {
-                st<V>(a.Hc + i * (int64_t)a.d_e + it * V, ld<V>(h + it * V));
-                st<V>(a.Tc + i * (int64_t)a.d_e + it * V, ld<V>(t + it * V));
-            }
-            for (int it = lane; it < a.d_r / V; it += 64) st<V>(a.Rc + i * (int64_t)a.d_r + it * V, ld<V>(r + it * V));
-        }
-    } else if (w < (int64_t)a.B + a.n_neg) {
-        // negative row job: dense copy for the GEMM / pairwise kernels and |b|^2
-        const int64_t j = w - a.B;
-        const float *x = table_row(a.src.em, a.nbase, a.nidx, j, a.d_e);
-        float *cp = a.Bn ? a.Bn + j * (int64_t)a.d_e : nullptr;
-        float s = 0.f;
-        for (int it = lane; it < a.d_e / V; it += 64) {
-            const Pack<V> v = ld<V>(x + it * V);
-            if (cp) st<V>(cp + it * V, v);
-#pragma unroll
-            for (int e = 0; e < V; ++e) s += v.v[e] * v.v[e];
-        }
-        if (a.bsq) {
-            s = wave_sum(s);
-            if (lane == 0) a.bsq[j] = s;
-        }
-    }
+    edge_fwd_body<MODEL, V, LEAN>(a, (int)blockIdx.x);
 }
 
 template <int MODEL>

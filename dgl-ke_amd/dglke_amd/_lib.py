@@ -106,7 +106,7 @@ _SIGNATURES = {
     "kge_pipe_create": (c_i, [C.POINTER(c_p)]),
     "kge_pipe_destroy": (c_i, [c_p]),
     "kge_step_async_workspace_bytes": (c_sz, [C.POINTER(KgeHParams), c_i, c_i, c_i, c_i, c_i, c_i]),
-    "kge_step_async": (c_i, [c_p, C.POINTER(KgeHParams), C.POINTER(KgeTables), C.POINTER(KgeBatch),
+    "kge_step_async": (c_i, [c_p, C.POINTER(KgeHParams), C.POINTER(KgeTables), C.POINTER(KgeBatch), C.POINTER(KgeBatch),
                              C.POINTER(KgeStepOut), c_p, c_sz, c_p]),
     "kge_step_async_flush": (c_i, [c_p, c_p]),
     "kge_step_phase": (c_i, [C.POINTER(KgeHParams), C.POINTER(KgeTables), C.POINTER(KgeBatch), C.POINTER(KgeStepOut), c_p,

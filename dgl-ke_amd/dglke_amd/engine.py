@@ -176,10 +176,12 @@ class StepEngine(object):
             self._aws_bytes = self._aws.numel()
         return self._aws
 
-    def step_async(self, batch, want=None, per_step_loss=False):
+    def step_async(self, batch, want=None, per_step_loss=False, next_batch=None):
         """enqueue one step of the --async_update pipeline: gathers rows that contain every update up to step s-2's
-        (inside one flush-to-flush group), applies step s-1's update concurrently with this step's scoring.
-        `flush_async()` must follow the last step (before the tables are read / before a stream capture ends)."""
+        (inside one flush-to-flush group), applies step s-1's update in the same launch as this step's forward tiles.
+        `next_batch`: the batch of the following step_async call (optional): with KGE_FLAG_ASYNC_REL its PREP shares
+        this step's backward launch.  `flush_async()` must follow the last step (before the tables are read / before a
+        stream capture ends)."""
         if self.shards is not None:
             raise _lib.KgeError("--async_update is not available on peer-to-peer sharded tables")
         if self._pipe is None:
@@ -194,9 +196,16 @@ class StepEngine(object):
         if want:
             for k, t in want.items():
                 setattr(out, k, ptr(t))
-        check(lib().kge_step_async(self._pipe, C.byref(self.hp), C.byref(self.tb), C.byref(batch.c), C.byref(out),
+        check(lib().kge_step_async(self._pipe, C.byref(self.hp), C.byref(self.tb), C.byref(batch.c),
+                                   C.byref(next_batch.c) if next_batch is not None else None, C.byref(out),
                                    ptr(ws), self._aws_bytes, stream_ptr()))
-        self._async_keep = batch       # the pending update reads the batch's plan arrays
+        self._async_keep = (batch, next_batch)       # the pending update / the prefetched PREP read their plan arrays
+
+    def steps_async(self, batches):
+        """a group of steps of the pipeline, every step naming its successor, flushed at the end"""
+        for k, b in enumerate(batches):
+            self.step_async(b, next_batch=batches[k + 1] if k + 1 < len(batches) else None)
+        self.flush_async()
 
     def flush_async(self):
         if self._pipe is not None:
@@ -228,13 +237,11 @@ class StepEngine(object):
         # warm-up on a side stream is not needed: the library allocates nothing
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=stream):
-            for b in batches:
-                if async_update:
-                    self.step_async(b)
-                else:
-                    self.step(b)
             if async_update:
-                self.flush_async()
+                self.steps_async(batches)
+            else:
+                for b in batches:
+                    self.step(b)
         self._graphs.append((g, batches))
         return g
 

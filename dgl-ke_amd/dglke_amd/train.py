@@ -77,6 +77,9 @@ class ArgParser(argparse.ArgumentParser):
         a('--async_update', action='store_true')
         a('--has_edge_importance', action='store_true')
         # additions of this build
+        a('--async_update_rel', action='store_true',
+          help='with --async_update: defer the relation-table update by one step as well (the reference defers the entity '
+               'table only); the next step\'s gather then shares a launch with this step\'s backward (fastest mode)')
         a('--seed', type=int, default=0, help='seed of the table initialisation and of the device sampler')
         a('--graph_steps', type=int, default=100, help='steps per captured hipGraph (0: eager launches)')
         a('--target_mrr', type=float, default=None,
@@ -144,9 +147,7 @@ class _Lane(object):
     def _steps(self, batches):
         eng = self.engine
         if self.async_update:
-            for b in batches:
-                eng.step_async(b)
-            eng.flush_async()
+            eng.steps_async(batches)
         else:
             for b in batches:
                 eng.step(b)
@@ -250,6 +251,9 @@ class Trainer(object):
             raise KgeError("--neg_deg_sample is not available for TransR")
         self.fused = not (args.neg_deg_sample and args.model_name == 'RESCAL')
         self.step_flags = _lib.FLAG_NEG_DEG_SAMPLE if (args.neg_deg_sample and self.fused) else 0
+        if getattr(args, 'async_update', False) and getattr(args, 'async_update_rel', False):
+            self.step_flags |= _lib.FLAG_ASYNC_REL
+            self.model.engine.hp.flags |= _lib.FLAG_ASYNC_REL
         self.device_sampler = self.fused and not args.has_edge_importance and 2 * B + C * N <= 4096
         self.n_lanes = max(1, int(args.num_proc))
         reg = args.regularization_coef > 0 and args.regularization_norm > 0

@@ -256,27 +256,30 @@ int kge_step_fused(const kge_hparams *hp, const kge_tables *tb, const kge_batch 
  * applied: the gather of step s+1 may miss the update of step s (<= 1 step of staleness), racily.  Here the
  * staleness is exact and race-free, and the "helper" is the other half of a horizontally fused launch:
  *
- *     PREP(s) | forward(s) | loss(s) | [ backward(s) || UPDATE(s-1) ] | relation trace(s) | PREP(s+1) | ...
+ *     [ forward(s) || UPDATE(s-1) ]  ->  loss(s)  ->  [ backward(s) || PREP(s+1) ]  ->  [ forward(s+1) || UPDATE(s) ] ...
  *
  *   PREP(s)   = gather + positive scores + pos-side vectors + DENSE COPIES of every row the step reads again
  *               (negative rows; h / t / r rows for the per-edge gradient kernel and the regulariser);
  *   forward / loss / backward(s) read only PREP's copies;
- *   UPDATE(s-1) = row-sparse Adagrad of the ENTITY table (both traces) with the gradients of step s-1, applied to
- *               the rows as they are then - in the SAME launch as the backward matrix-core tiles of step s
- *               (different workspace half; the update is row read-modify-write traffic, the tiles matrix work).
- *               The relation trace of step s is applied right after backward(s), like the reference, which defers
- *               entity_emb only (general_models.py:639-647); KGE_FLAG_ASYNC_REL defers it too.
- * Step s+1 therefore gathers entity rows that contain every update up to s-1 and not the update of s -
- * bit-reproducible, one stream, no events.  kge_step_async_flush() applies the last pending update (call it
- * before reading the tables and at the end of a captured group of steps).  Gradients, including the regulariser,
- * are those of the rows as gathered.  Not available for RESCAL / TransR, nor --neg_deg_sample with a regulariser.
- * The workspace holds two halves (kge_step_async_workspace_bytes).  kge_pipe is host-side state only. */
+ *   UPDATE(s-1) = row-sparse Adagrad with the gradients of step s-1, applied to the rows as they are then, in the
+ *               SAME launch as the forward matrix-core tiles of step s (different workspace half).
+ * UPDATE(s-1) is launched after PREP(s) and completes before PREP(s+1): step s+1 gathers entity rows that contain
+ * every update up to s-1 and not the update of s - bit-reproducible, one stream, no events.
+ * By default only the ENTITY table is deferred, like the reference (general_models.py:639-647 defers entity_emb
+ * only): the relation trace of step s is applied right after backward(s) and PREP(s+1) is its own launch.
+ * KGE_FLAG_ASYNC_REL defers the relation trace too; then nothing touches the tables between backward(s) and
+ * PREP(s+1), and - when the caller names the next batch (b_next) - PREP(s+1) shares the backward launch of step s
+ * (three launches per step on the critical path).  b_next may be NULL (PREP runs at the start of the next call).
+ * kge_step_async_flush() applies the last pending update (call it before reading the tables and at the end of a
+ * captured group of steps; the step after a flush gathers fully updated rows).  Gradients, including the
+ * regulariser, are those of the rows as gathered.  Not available for RESCAL / TransR, nor --neg_deg_sample with a
+ * regulariser.  The workspace holds two halves (kge_step_async_workspace_bytes).  kge_pipe is host-side state only. */
 typedef struct kge_pipe kge_pipe;
 int kge_pipe_create(kge_pipe **pipe);
 int kge_pipe_destroy(kge_pipe *pipe);
 size_t kge_step_async_workspace_bytes(const kge_hparams *hp, int B, int C, int chunk, int N, int UE, int UR);
 int kge_step_async(kge_pipe *pipe, const kge_hparams *hp, const kge_tables *tb, const kge_batch *b,
-                   const kge_step_out *out, void *ws, size_t ws_bytes, void *stream);
+                   const kge_batch *b_next, const kge_step_out *out, void *ws, size_t ws_bytes, void *stream);
 int kge_step_async_flush(kge_pipe *pipe, void *stream);
 
 /* ---- the strict step in four pieces (the reference's per-phase timers, train_pytorch.py:127-177: sample / forward /

@@ -77,9 +77,7 @@ def test_async_pipeline_matches_the_stale_oracle(case):
     for mode in ("eager", "eager", "graph"):
         eng = engine()
         if mode == "eager":
-            for b in batches:
-                eng.step_async(b)
-            eng.flush_async()
+            eng.steps_async(batches)
         else:
             g = eng.capture(batches, async_update=True)
             g.replay()

@@ -1,6 +1,7 @@
 #!/bin/bash
 # one GPU round-trip: parity tests, bench, rocprof kernel stats.  usage: tools/gpu_cycle.sh TAG [bench args]
 TAG=$1; shift
+[ -z "$GRAFT_REPO_ROOT" ] && export GRAFT_REPO_ROOT=$(pwd)
 mkdir -p gpurun_out
 timeout 700 python -m pytest tests -m gpu -q --timeout=120 -x 2>&1 | tail -15 > gpurun_out/${TAG}_pytest.log; tail -3 gpurun_out/${TAG}_pytest.log
 timeout 300 python bench.py "$@" > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; cat gpurun_out/${TAG}_bench.json; tail -3 gpurun_out/${TAG}_bench.err | grep -v amdgpu.ids

@@ -57,13 +57,11 @@ def main():
     G = args.graph_steps
     smp = DeviceSampler(h, r, t, w["n_ent"], w["B"], w["N"], dev, n_slots=G, seed=0)
     def run_group():
-        for b in smp.sample():
-            if args.async_update:
-                eng.step_async(b)
-            else:
-                eng.step(b)
         if args.async_update:
-            eng.flush_async()
+            eng.steps_async(smp.sample())
+        else:
+            for b in smp.sample():
+                eng.step(b)
     run_group()
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
