@@ -9,9 +9,11 @@ import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
         d = json.loads(l); r = d['roofline']
-        print('edges/s %.1f  ms/step %.5f  hbm frac %.4f  mfma %s' % (d['value'], d['ms_per_step'], r['frac'], r.get('mfma', {}).get('achieved')))
+        au, ar = d.get('async_update', {}), d.get('async_update_rel', {})
+        print('edges/s %.1f  ms/step %.5f  hbm frac %.4f  mfma %s  | --async_update us/step: entity-only %s, relation deferred %s' % (
+            d['value'], d['ms_per_step'], r['frac'], r.get('mfma', {}).get('achieved'), au.get('us_per_step'), ar.get('us_per_step')))
 " >> $O
-  cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_w && timeout 200 rocprofv3 --kernel-trace --stats -d /tmp/prof_w -- python $R/bench.py --no-cpu-baseline --hogwild 0 --steps 600 --warmup 120 --workload $W > /tmp/prof_w.log 2>&1
+  cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_w && timeout 200 rocprofv3 --kernel-trace --stats -d /tmp/prof_w -- python $R/bench.py --no-cpu-baseline --hogwild 0 --no-async-update --steps 600 --warmup 120 --workload $W > /tmp/prof_w.log 2>&1
   python $R/tools/rocpd_stats.py $(ls /tmp/prof_w/*/*_results.db | head -1) | head -9 | cut -c1-64,73-118 >> $O
   cd $R
 done
