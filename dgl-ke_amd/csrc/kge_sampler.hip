@@ -73,8 +73,9 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {   // splitmix64 finalise
     return x;
 }
 
-// in-LDS bitonic sort of n2 (power of two) 64-bit keys by all SP_THREADS threads
-__device__ void bitonic_sort(uint64_t *keys, int n2) {
+// in-LDS bitonic sort of n2 (power of two) 64-bit keys by all SP_THREADS threads - generic version: one
+// compare-exchange stage per barrier
+__device__ void bitonic_sort_lds(uint64_t *keys, int n2) {
     for (int k = 2; k <= n2; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int i = threadIdx.x; i < n2; i += SP_THREADS) {
@@ -88,6 +89,67 @@ __device__ void bitonic_sort(uint64_t *keys, int n2) {
             __syncthreads();
         }
     }
+}
+
+// Register-resident bitonic sort: thread t owns the E consecutive keys [E*t, E*t + E).  A stage with partner distance
+// j < E exchanges inside the thread, j < 64*E inside the wavefront (cross-lane shuffles, no barrier), only j >= 64*E
+// goes through LDS - 10 of the 78 stages for 4096 keys, 6 of 55 for 1024 (each __syncthreads of 16 wavefronts costs
+// ~0.4 us: the barriers were most of the sampler kernel's 91 us).  Keys are distinct, so the result is THE sorted order.
+template <int E>
+__device__ void bitonic_sort_regs(uint64_t *keys, int n2) {
+    const int t = threadIdx.x, lane = t & 63;
+    (void)lane;
+    uint64_t v[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) v[e] = keys[E * t + e];
+    for (int k = 2; k <= n2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j < E) {                                   // partner in this thread
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int p = e ^ j;
+                    if (p > e) {
+                        const bool up = (((E * t + e) & k) == 0);
+                        const uint64_t a = v[e], b = v[p];
+                        if ((a > b) == up) { v[e] = b; v[p] = a; }
+                    }
+                }
+            } else if (j < 64 * E) {                       // partner in this wavefront: lane ^ (j / E), same slot
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int i = E * t + e;
+                    const uint64_t o = __shfl_xor(v[e], j / E, 64);
+                    const bool lower = (i & j) == 0, up = (i & k) == 0;
+                    const bool want_min = lower == up;
+                    v[e] = want_min ? (v[e] < o ? v[e] : o) : (v[e] > o ? v[e] : o);
+                }
+            } else {                                       // partner in another wavefront: through LDS
+                __syncthreads();                           // everybody has read what an earlier LDS stage wrote
+#pragma unroll
+                for (int e = 0; e < E; ++e) keys[E * t + e] = v[e];
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int i = E * t + e;
+                    const uint64_t o = keys[i ^ j];
+                    const bool lower = (i & j) == 0, up = (i & k) == 0;
+                    const bool want_min = lower == up;
+                    v[e] = want_min ? (v[e] < o ? v[e] : o) : (v[e] > o ? v[e] : o);
+                }
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < E; ++e) keys[E * t + e] = v[e];
+    __syncthreads();
+}
+
+__device__ void bitonic_sort(uint64_t *keys, int n2) {
+    if (n2 == 4 * SP_THREADS) bitonic_sort_regs<4>(keys, n2);
+    else if (n2 == 2 * SP_THREADS) bitonic_sort_regs<2>(keys, n2);
+    else if (n2 == SP_THREADS) bitonic_sort_regs<1>(keys, n2);
+    else bitonic_sort_lds(keys, n2);
 }
 
 // block-wide exclusive scan of n (<= SP_MAXE) uint32 values in `v` (in place); returns the total.

@@ -174,19 +174,21 @@ class DeviceSampler(object):
         self.slots = th.zeros(self.n_slots * self.slot_bytes, dtype=th.uint8, device=self.dev)
         self.host_step = 1                                                     # next step to be sampled
 
-    def sample(self, n=None):
-        """enqueue the construction of the next `n` (default: all slots) batches into slots 0..n-1;
-        returns the DeviceBatch objects (their neg_head flag follows the step parity)."""
+    def sample(self, n=None, slot0=0):
+        """enqueue the construction of the next `n` (default: all slots) batches into slots slot0..slot0+n-1;
+        returns the DeviceBatch objects (their neg_head flag follows the step parity).  `slot0` lets a caller
+        double-buffer: sample the next group of batches (on another stream) while the current group trains."""
         from . import _lib
         n = self.n_slots if n is None else int(n)
-        if n > self.n_slots:
+        slot0 = int(slot0)
+        if slot0 < 0 or slot0 + n > self.n_slots:
             raise ValueError("more batches than slots")
         _lib.check(_lib.lib().kge_sample_batches(
             _lib.ptr(self.H), _lib.ptr(self.R), _lib.ptr(self.T),
             _lib.ptr(self.perm) if self.perm is not None else None, self.n_train, self.n_entities, self.B,
-            self.C, self.chunk, self.N, self.seed, _lib.ptr(self.state), _lib.ptr(self.slots), self.slot_bytes,
-            n, _lib.stream_ptr()))
-        out = [DeviceBatch(self, k, (self.host_step + k) % 2 == 0) for k in range(n)]
+            self.C, self.chunk, self.N, self.seed, _lib.ptr(self.state),
+            self.slots.data_ptr() + slot0 * self.slot_bytes, self.slot_bytes, n, _lib.stream_ptr()))
+        out = [DeviceBatch(self, slot0 + k, (self.host_step + k) % 2 == 0) for k in range(n)]
         self.host_step += n
         return out
 
