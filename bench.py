@@ -475,7 +475,8 @@ def main():
     prof = profiled_kernels(args.workload)
     if prof:
         # self-check: the dominant kernel of the committed profile, its share of the step and its own roofline fraction
-        ks = {k: v for k, v in prof["kernels"].items() if "sample" not in k and "reduce_acc" not in k}
+        top = max(v["calls"] for v in prof["kernels"].values())
+        ks = {k: v for k, v in prof["kernels"].items() if v["calls"] * 2 >= top}       # the once-per-step kernels
         dom = max(ks, key=lambda k: ks[k]["avg_us"])
         out["roofline"]["dominant_kernel"] = dom.split("(")[0].replace("void ", "")
         out["roofline"]["dominant_kernel_us"] = ks[dom]["avg_us"]

@@ -782,7 +782,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void update_kernel(UpdateArgs a, int nb_
 // single-pass register-resident variant: body in kge_update_body.hpp
 template <int NIT, bool SHARDED, int LEAN>
 __global__ __launch_bounds__(KGE_BLOCK) void update_kernel_reg(UpdateArgs a, int nb_ent) {
-    KGE_TL(4);
+    KGE_TL(((int)blockIdx.x < (int)gridDim.x - nb_ent) ? 7 : 4);      // timeline: relation workgroups come first (id 7)
     update_reg_body<NIT, SHARDED, LEAN>(a, nb_ent, (int)blockIdx.x, (int)gridDim.x);
 }
 
