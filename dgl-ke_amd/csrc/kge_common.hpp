@@ -152,6 +152,16 @@ template <> __device__ __forceinline__ void st_nt<4>(float *p, const Pack<4> &x)
     __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(p));
 }
 template <> __device__ __forceinline__ void st_nt<1>(float *p, const Pack<1> &x) { __builtin_nontemporal_store(x.v[0], p); }
+// write-through store (system-coherent cache policy, no streaming hint): the line goes to the memory side (Infinity Cache)
+// at once instead of staying dirty in this XCD's L2 until the end-of-kernel write-back
+template <int V> __device__ __forceinline__ void st_wt(float *p, const Pack<V> &x);
+template <> __device__ __forceinline__ void st_wt<4>(float *p, const Pack<4> &x) {
+    f32x4 v = {x.v[0], x.v[1], x.v[2], x.v[3]};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+}
+template <> __device__ __forceinline__ void st_wt<1>(float *p, const Pack<1> &x) {
+    asm volatile("global_store_dword %0, %1, off sc0 sc1" : : "v"(p), "v"(x.v[0]) : "memory");
+}
 template <int V> __device__ __forceinline__ Pack<V> zero_pack() {
     Pack<V> r;
 #pragma unroll

@@ -7,7 +7,12 @@
 #include "kge_common.hpp"
 #include "kge_update_body.hpp"      // LANE(), acc_add
 
-#define KGE_ST_OUT kge::st_nt      // P rows: consumed two kernels later by the update (any XCD) - streaming store
+// Store policies (A/B measured on MI355X, profiles/r02_store_policy.txt): lines left dirty in the producer XCD's L2 are written
+// back before the next launch may start, and their consumers run on any XCD.  A (read by the very next kernel): write-through to the
+// memory side; P (read two kernels later, by the update): streaming store.
+#define KGE_ST_A kge::st_wt
+#define KGE_ST_OUT kge::st_nt
+//      // P rows: consumed two kernels later by the update (any XCD) - streaming store
 
 // LEAN: local (un-sharded) tables and the Logsigmoid criterion fixed at compile time (no 64-bit divisions of
 // the shard map, no three-way loss switch) - the configuration of every single-GPU BASELINE workload
@@ -47,7 +52,7 @@ __device__ __forceinline__ void edge_fwd_body(const EdgeFwdArgs &a_in, int bid) 
                     }
                     as += av.v[e] * av.v[e];
                 }
-                if (A) st<V>(A + off, av);
+                if (A) KGE_ST_A<V>(A + off, av);
             }
         } else {
             const int hd = a.d_e / 2;
@@ -93,7 +98,7 @@ __device__ __forceinline__ void edge_fwd_body(const EdgeFwdArgs &a_in, int bid) 
                     }
                     as += are.v[e] * are.v[e] + aim.v[e] * aim.v[e];
                 }
-                if (A) { st<V>(A + off, are); st<V>(A + hd + off, aim); }
+                if (A) { KGE_ST_A<V>(A + off, are); KGE_ST_A<V>(A + hd + off, aim); }
             }
         }
         if (a.pos_score || a.do_pos_loss) {

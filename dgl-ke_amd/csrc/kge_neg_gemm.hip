@@ -512,9 +512,9 @@ __device__ __forceinline__ void neg_bwd_gemm_body(const GemmArgs &a, int ti, int
                     o.w += reg_grad(sv.w, a.reg_coef, a.reg_norm);
                 }
             }
-            // streaming store: GA / GN are consumed by the update kernel (any XCD); lines left dirty in this XCD's L2 only
-            // lengthen the write-back before the next launch (measured -0.3 us on the gap after this kernel)
-            { f32x4 ov = {o.x, o.y, o.z, o.w}; __builtin_nontemporal_store(ov, reinterpret_cast<f32x4 *>(O + ((int64_t)c * R + ro) * D + d)); }
+            // write-through store: GA / GN are consumed by the update kernel (any XCD); lines left dirty in this XCD's L2 only
+            // lengthen the write-back before the next launch (profiles/r02_store_policy.txt)
+            { Pack<4> ov; ov.v[0] = o.x; ov.v[1] = o.y; ov.v[2] = o.z; ov.v[3] = o.w; st_wt<4>(O + ((int64_t)c * R + ro) * D + d, ov); }
         }
     }
 }

@@ -187,9 +187,9 @@ __global__ __launch_bounds__(KGE_BLOCK) void edge_bwd_kernel(EdgeBwdArgs a_in) {
 #pragma unroll
                 for (int e = 0; e < V; ++e) { if (a.neg_head) gh.v[e] += gv.v[e]; else gt.v[e] += gv.v[e]; }
             }
-            if (GH) st<V>(GH + off, gh);
-            if (GT) st<V>(GT + off, gt);
-            if (GR) st<V>(GR + off, gr);
+            if (GH) st_wt<V>(GH + off, gh);
+            if (GT) st_wt<V>(GT + off, gt);
+            if (GR) st_wt<V>(GR + off, gr);
         }
     } else {
         const int hd = a.d_e / 2;
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void edge_bwd_kernel(EdgeBwdArgs a_in) {
                     o_rh.v[e] = v_hi; o_ih.v[e] = v_hj; o_rt.v[e] = v_ti; o_it.v[e] = v_tj;
                     o_rr.v[e] = v_r; o_ir.v[e] = v_ri;
                 }
-                if (GR) { st<V>(GR + off, o_rr); st<V>(GR + hd + off, o_ir); }
+                if (GR) { st_wt<V>(GR + off, o_rr); st_wt<V>(GR + hd + off, o_ir); }
             } else if constexpr (MODEL == KGE_COMPLEX) {
                 const Pack<V> rr = ld<V>(r + off), ir = ld<V>(r + hd + off);
                 Pack<V> o_rr, o_ir;
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void edge_bwd_kernel(EdgeBwdArgs a_in) {
                     o_rh.v[e] = v_rh; o_ih.v[e] = v_ih; o_rt.v[e] = v_rt; o_it.v[e] = v_it;
                     o_rr.v[e] = v_rr; o_ir.v[e] = v_ir;
                 }
-                if (GR) { st<V>(GR + off, o_rr); st<V>(GR + hd + off, o_ir); }
+                if (GR) { st_wt<V>(GR + off, o_rr); st_wt<V>(GR + hd + off, o_ir); }
             } else {   // RotatE
                 const Pack<V> ph = ld<V>(r + off);
                 Pack<V> o_r;
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void edge_bwd_kernel(EdgeBwdArgs a_in) {
                     o_rh.v[e] = v_rh; o_ih.v[e] = v_ih; o_rt.v[e] = v_rt; o_it.v[e] = v_it;
                     o_r.v[e] = v_r;
                 }
-                if (GR) st<V>(GR + off, o_r);
+                if (GR) st_wt<V>(GR + off, o_r);
             }
             if (gnd) {
                 const Pack<V> gv0 = ld<V>(gnd + off), gv1 = ld<V>(gnd + hd + off);
@@ -311,8 +311,8 @@ __global__ __launch_bounds__(KGE_BLOCK) void edge_bwd_kernel(EdgeBwdArgs a_in) {
                     else { o_rt.v[e] += gv0.v[e]; o_it.v[e] += gv1.v[e]; }
                 }
             }
-            if (GH) { st<V>(GH + off, o_rh); st<V>(GH + hd + off, o_ih); }
-            if (GT) { st<V>(GT + off, o_rt); st<V>(GT + hd + off, o_it); }
+            if (GH) { st_wt<V>(GH + off, o_rh); st_wt<V>(GH + hd + off, o_ih); }
+            if (GT) { st_wt<V>(GT + off, o_rt); st_wt<V>(GT + hd + off, o_it); }
         }
     }
 }

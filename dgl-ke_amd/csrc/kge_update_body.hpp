@@ -5,7 +5,7 @@
 #pragma once
 #include "kge_common.hpp"
 
-#define KGE_ST_ROW kge::st_nt      // updated table rows: read next by another kernel on any XCD - streaming store
+#define KGE_ST_ROW kge::st_wt      // updated table rows: read next by another kernel on any XCD - write-through store
 #ifndef LANE
 #define LANE() (threadIdx.x & 63)
 #endif
