@@ -311,7 +311,7 @@ __device__ __forceinline__ void neg_bwd_gemm_body(const GemmArgs &a, int ti, int
     const int tl = (isGA ? bc : bc - bpA) * KGE_WAVES_PER_BLOCK + wv;
     const int tr = isGA ? ti : tj;                       // row tiles of this product
     const bool tile_ok = tl < tr * td;
-    const int dt = tl % td, rt = tl / td;
+    const int dt = tl % td, rt = tl / td;                // (row tile fastest - 4 wavefronts sharing a column slab - measured the same)
     const int D = a.D, N = a.N, chunk = a.chunk;
     const int m = lane & 15, q = lane >> 4;
     const int K = isGA ? N : chunk;                      // reduction length
