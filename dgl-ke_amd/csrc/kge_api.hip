@@ -783,8 +783,8 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         // the regulariser of the positive-trace rows is part of the gradient the reference computes in forward, from the
         // rows as gathered: evaluate it on PREP's copies.  (The relation trace is only deferred with KGE_FLAG_ASYNC_REL;
         // otherwise it lands before anything else touches the relation table and the current row IS the gathered row.)
-        if (nd) return fail(KGE_ERR_ARG, "kge_step_async: neg_deg_sample with a regulariser is not available");
         ua.Hs = Hc; ua.Ts = Tc;
+        if (nd) ua.Ns = Bn;            // the update adds the regulariser of the sampled negative rows in this mode
         ua.Rs = ((hp->flags & KGE_FLAG_ASYNC_REL) && transe_fast) ? Rc : nullptr;
     }
     if (emit) {

@@ -349,6 +349,8 @@ struct UpdateArgs {
     // the regulariser gradient / value of a positive-trace row is evaluated on that copy (the reference computes it in
     // forward, from the gathered rows), not on the row as it is when the deferred update lands.  null: current rows.
     const float *Hs, *Ts, *Rs;
+    const float *Ns;                 // same for the --neg_deg_sample regulariser of the sampled negative rows: PREP's dense copy
+                                     // of the negative rows, indexed like GN (gn_row); null: current rows
     // neg_deg_sample (nd_chunk > 0): GN has nd_Np = nd_chunk + nd_Ns rows per chunk, plan slot k (sampled negative)
     // is row (k / nd_Ns) * nd_Np + nd_chunk + k % nd_Ns, and the regulariser of the negative rows is added here
     int nd_chunk, nd_Ns, nd_Np;

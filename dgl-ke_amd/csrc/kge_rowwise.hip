@@ -795,7 +795,7 @@ int launch_update(const UpdateArgs &a, hipStream_t s) {
     const bool sharded = a.em.n != 0 || a.rm.n != 0;
     const bool inplace = !a.emit_ent && !a.emit_rel && !a.g0 && !a.g1 && !a.gs0 && !a.gs1 && !a.gr && !a.gsr && !a.rid &&
                          !a.dry;
-    if ((a.Hs || a.Rs) && !(vec && dmax <= 1024)) return KGE_ERR_ARG;      // stale-row regulariser: register-resident kernel only
+    if ((a.Hs || a.Rs || a.Ns) && !(vec && dmax <= 1024)) return KGE_ERR_ARG;      // stale-row regulariser: register-resident kernel only
     const int lean = (!inplace || a.nd_chunk) ? 0 : (a.transe_fast ? 1 : 2);
     const int nit = dmax <= 256 ? 1 : (dmax <= 512 ? 2 : 4);
 #define KGE_UPD(N, SH, LE) hipLaunchKernelGGL((update_kernel_reg<N, SH, LE>), g, b, 0, s, a, nbE)

@@ -77,6 +77,8 @@ __device__ __forceinline__ void update_reg_body(const UpdateArgs &a_in, int nb_e
         // row the regulariser is evaluated on: as gathered by this step (async pipeline) or as it is now
         const float *pX = (a.Hs && has_pos) ? (side0 ? a.Ts : a.Hs) + e0 : row;
         const bool ndreg = a.nd_chunk && reg;       // neg_deg_sample: regulariser of the negative rows added here
+        // ... evaluated on the negative row as gathered (async pipeline: PREP's dense copy of the sampled rows)
+        const float *pXn = (a.Ns && has_neg) ? a.Ns + gn_row(a, slot0) * d : row;
         const float st0 = *srow;
         // the rest of the two lists (entries 1..) is requested NOW, one entry per lane, together with the
         // rows above: a serial "load index -> load row" chain per extra entry made the longest list set the
@@ -84,7 +86,7 @@ __device__ __forceinline__ void update_reg_body(const UpdateArgs &a_in, int nb_e
         const int npx = p1 - p0 - 1, nnx = n1 - n0 - 1;
         const int adjv = lane < npx ? a.ue_pos_adj[p0 + 1 + lane] : 0;
         const int slotv = lane < nnx ? a.ue_neg_slot[n0 + 1 + lane] : 0;
-        Pack<4> x[NIT], g0[NIT], g1[NIT];
+        Pack<4> x[NIT], g0[NIT], g1[NIT], xn[NIT];
         float rv = 0.f, s0 = 0.f, s1 = 0.f;
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
@@ -93,6 +95,7 @@ __device__ __forceinline__ void update_reg_body(const UpdateArgs &a_in, int nb_e
                 x[k] = ld<4>(row + it * 4);
                 const Pack<4> va = ld<4>(pA + it * 4), vb = ld<4>(pB + it * 4), vc = ld<4>(pC + it * 4);
                 const Pack<4> xr = ld<4>(pX + it * 4);      // aliases the row itself outside the async pipeline
+                xn[k] = ndreg ? ld<4>(pXn + it * 4) : x[k];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float g = 0.f;
@@ -100,11 +103,11 @@ __device__ __forceinline__ void update_reg_body(const UpdateArgs &a_in, int nb_e
                     if (has_pos) g += sg0 * va.v[e] + (ga0 ? vb.v[e] : 0.f);
                     g0[k].v[e] = g;
                     float gn = has_neg ? vc.v[e] : 0.f;
-                    if (ndreg && has_neg) gn += reg_grad(x[k].v[e], a.reg_coef, a.reg_norm);
+                    if (ndreg && has_neg) gn += reg_grad(xn[k].v[e], a.reg_coef, a.reg_norm);
                     g1[k].v[e] = gn;
                     s1 += gn * gn;
                 }
-            } else { x[k] = zero_pack<4>(); g0[k] = zero_pack<4>(); g1[k] = zero_pack<4>(); }
+            } else { x[k] = zero_pack<4>(); g0[k] = zero_pack<4>(); g1[k] = zero_pack<4>(); xn[k] = zero_pack<4>(); }
         }
 #pragma unroll 1
         for (int i = 0; i < npx; ++i) {
@@ -148,7 +151,7 @@ __device__ __forceinline__ void update_reg_body(const UpdateArgs &a_in, int nb_e
                     Pack<4> g = ld<4>(src + it * 4);
                     if (ndreg) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) g.v[e] += reg_grad(x[k].v[e], a.reg_coef, a.reg_norm);
+                        for (int e = 0; e < 4; ++e) g.v[e] += reg_grad(xn[k].v[e], a.reg_coef, a.reg_norm);
                     }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { s1 += g.v[e] * g.v[e]; g1[k].v[e] += g.v[e]; }

@@ -256,8 +256,7 @@ class Trainer(object):
             self.model.engine.hp.flags |= _lib.FLAG_ASYNC_REL
         self.device_sampler = self.fused and not args.has_edge_importance and 2 * B + C * N <= 4096
         self.n_lanes = max(1, int(args.num_proc))
-        reg = args.regularization_coef > 0 and args.regularization_norm > 0
-        self.async_ok = self.fused and args.model_name not in ('TransR', 'RESCAL') and not (args.neg_deg_sample and reg)
+        self.async_ok = self.fused and args.model_name not in ('TransR', 'RESCAL')
         if getattr(args, 'async_update', False) and not self.async_ok:
             print('--async_update: not available for this model / option combination; running the strict step')
         if self.n_lanes > 1 and not self.fused:

@@ -272,8 +272,7 @@ int kge_step_fused(const kge_hparams *hp, const kge_tables *tb, const kge_batch 
  * (three launches per step on the critical path).  b_next may be NULL (PREP runs at the start of the next call).
  * kge_step_async_flush() applies the last pending update (call it before reading the tables and at the end of a
  * captured group of steps; the step after a flush gathers fully updated rows).  Gradients, including the
- * regulariser, are those of the rows as gathered.  Not available for RESCAL / TransR, nor --neg_deg_sample with a
- * regulariser.  The workspace holds two halves (kge_step_async_workspace_bytes).  kge_pipe is host-side state only. */
+ * regulariser, are those of the rows as gathered.  Not available for RESCAL / TransR.  The workspace holds two halves (kge_step_async_workspace_bytes).  kge_pipe is host-side state only. */
 typedef struct kge_pipe kge_pipe;
 int kge_pipe_create(kge_pipe **pipe);
 int kge_pipe_destroy(kge_pipe *pipe);

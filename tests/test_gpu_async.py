@@ -31,6 +31,9 @@ CASES = [
     ("SimplE", 80, 5, 16, True, True, 16, 1, 16, 12.0, 0.1, 0.0, 0),
     ("TransE_l2", 80, 5, 32, False, False, 16, 2, 16, 10.0, 0.1, 0.0, 8),        # with the fused loss
     ("DistMult", 80, 5, 32, False, False, 16, 2, 16, 12.0, 0.1, 0.0, 32),        # --neg_deg_sample
+    ("RotatE", 80, 5, 16, True, False, 16, 2, 20, 10.0, 0.05, 1e-4, 32),         # --neg_deg_sample + regulariser (FB15k RotatE recipe)
+    ("TransE_l2", 80, 5, 32, False, False, 16, 2, 16, 10.0, 0.1, 1e-4, 32),
+    ("ComplEx", 80, 5, 16, True, True, 16, 2, 16, 12.0, 0.1, 1e-4, 64),          # regulariser on the copies, relation deferred
 ]
 
 
