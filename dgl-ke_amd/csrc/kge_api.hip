@@ -225,14 +225,6 @@ int kge_score_neg_fwd(int model, int neg_head, const float *pos_side, const floa
     return KGE_OK;
 }
 
-// neg_deg_sample: ids of the rows scored as negatives, per chunk [the chunk's own corrupted-side entities | sampled ids]
-__global__ void nd_ids_kernel(const int64_t *own, const int64_t *sampled, int chunk, int Ns, int total, int64_t *out) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= total) return;
-    const int Np = chunk + Ns, c = j / Np, jj = j % Np;
-    out[j] = jj < chunk ? own[(int64_t)c * chunk + jj] : sampled[(int64_t)c * Ns + jj - chunk];
-}
-
 int kge_score_neg_bwd(int model, int neg_head, const float *pos_side, const float *rel,
                       const float *neg, const float *neg_score, const float *dneg, int C,
                       int chunk, int N, int d_e, int d_r, float gamma, float emb_init,
@@ -432,7 +424,6 @@ size_t kge_step_workspace_bytes(const kge_hparams *hp, int B, int C, int chunk, 
     add(B); add(B); add(UE); add(UR);           // row_pos, row_neg, reg_ent, reg_rel
     if (neg_bwd_lc_supported(hp->model, hp->d_e))   // TransE_l1 / RotatE: GN partials of the shared-pair backward
         add(neg_bwd_lc_partial_floats(hp->model, C, chunk, N, hp->d_e));
-    if (nd) add(2 * CN);                                  // combined id list (int64)
     return n;
 }
 
@@ -529,7 +520,6 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     float *row_pos = cv.f(B), *row_neg = cv.f(B), *reg_ent = cv.f(b->UE), *reg_rel = cv.f(b->UR);
     float *GNp = (neg_bwd_lc_supported(hp->model, d_e) && !(hp->flags & KGE_FLAG_TWO_PASS_PAIR))
                      ? cv.f(neg_bwd_lc_partial_floats(hp->model, C, chunk, N, d_e)) : nullptr;
-    int64_t *nd_ids = nd ? reinterpret_cast<int64_t *>(cv.f(2 * (size_t)CN)) : nullptr;
     // --async_update pipeline (phases != PH_ALL): dense copies of the h / t / r rows as PREP gathered them, for the
     // kernels that read them again after the previous step's update has started (edge_bwd)
     const bool pipelined = phases != PH_ALL && !(phases & PH_STRICT);      // the async pipeline (kge_step_async)
@@ -548,15 +538,9 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     const LossParams lp{hp->loss_genre, hp->adv, hp->pairwise, hp->adv_temp, hp->margin};
 
     const EdgeSrc src{tb->ent, b->h_gid, tb->ent, b->t_gid, tb->rel, b->rel_ids, em, rm};
-    const int64_t *nids = b->neg_ids;                 // ids of the rows the scoring kernels treat as negatives
-    if (nd) {
-        if (phases & PH_PREP) {
-            hipLaunchKernelGGL(nd_ids_kernel, dim3((unsigned)((CN + 255) / 256)), dim3(256), 0, s,
-                               b->neg_head ? b->h_gid : b->t_gid, b->neg_ids, chunk, b->N, CN, nd_ids);
-            if (hipGetLastError() != hipSuccess) return fail(KGE_ERR_LAUNCH, "nd_ids_kernel launch failed");
-        }
-        nids = nd_ids;
-    }
+    // ids of the rows the scoring kernels treat as negatives.  neg_deg_sample: [the chunk's own corrupted-side entities |
+    // the sampled ids] per chunk - edge_fwd resolves that on the fly and writes the dense copy Bn every later kernel reads
+    const int64_t *nids = b->neg_ids;
     if (transr) {
         tr.B = B; tr.C = C; tr.chunk = chunk; tr.N = N; tr.De = d_e; tr.Dr = d_r; tr.neg_head = b->neg_head;
         tr.UR = b->UR; tr.reg_norm = hp->reg_norm; tr.gamma = hp->gamma; tr.lr = hp->lr; tr.eps = hp->eps;
@@ -573,7 +557,7 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     if (async && (sh || emit || transr || rescal))
         return fail(KGE_ERR_ARG, "kge_step_async: not available for RESCAL / TransR and the sharded / gradient-emitting steps");
 
-    const bool dense_neg = !gemm || sh || async || (hp->flags & KGE_FLAG_DENSE_NEG);
+    const bool dense_neg = !gemm || sh || async || nd || (hp->flags & KGE_FLAG_DENSE_NEG);
     const bool l2g = gemm && is_l2;                   // GEMM form of the L2 distance needs |a|^2, |b|^2
     // rows as the scoring / gradient kernels of THIS step see them: the tables, or PREP's dense copies (async)
     const EdgeSrc src_bwd = need_cp ? EdgeSrc{Hc, nullptr, Tc, nullptr, Rc, nullptr, kge::ShardMap{}, kge::ShardMap{}} : src;
@@ -585,6 +569,7 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     ef.gamma = hp->gamma; ef.rot_div = rot_div;
     ef.pos_score = P; ef.A = A;
     ef.nbase = tb->ent; ef.nidx = nids; ef.n_neg = CN;
+    if (nd) { ef.nd_own = b->neg_head ? b->h_gid : b->t_gid; ef.nd_chunk = chunk; ef.nd_Ns = b->N; }
     // sharded tables: the scoring kernels re-read the negative rows many times - they must come from
     // the dense local copy edge_fwd makes, never from the (remote, uncached) table rows
     ef.Bn = dense_neg ? Bn : nullptr;                 // the pairwise kernels read a dense copy
@@ -880,11 +865,11 @@ int kge_step_async(kge_pipe *p, const kge_hparams *hp, const kge_tables *tb, con
     }
     if (int rc = step_impl(hp, tb, b, out, nullptr, wsp, half, stream, nullptr, PH_FWD, nullptr, have_co ? &co : nullptr)) return rc;
     // launch C: backward(s) || PREP(s+1).  Only when nothing touches the tables between this backward and the next PREP
-    // (relation trace deferred too), for the plain step (no per-step outputs, no --neg_deg_sample id kernel)
+    // (relation trace deferred too), for the plain step (no per-step outputs)
     EdgeFwdArgs ef{};
     bool have_prep = false;
     const bool plain_out = !out || (!out->loss4 && !out->pos_score && !out->neg_score && !out->g_pos_ent && !out->g_neg && !out->g_rel);
-    if (b_next && defer_rel && plain_out && !(hp->flags & KGE_FLAG_NEG_DEG_SAMPLE)) {
+    if (b_next && defer_rel && plain_out) {
         if (int rc = step_impl(hp, tb, b_next, out, nullptr, wsn, half, stream, nullptr, PH_PREP, nullptr, nullptr, &ef)) return rc;
         have_prep = true;
     }

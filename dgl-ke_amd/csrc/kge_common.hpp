@@ -270,6 +270,10 @@ struct EdgeFwdArgs {
     float *row_pos;                  // [B] per-row positive loss terms or null
     float *acc;                      // running sums or null
     float *P;                        // [B,d_e] TransE only: dpos_i * d|u_i|/du_i (u = h+r-t) or null
+    // --neg_deg_sample: the negative rows of chunk c are [the chunk's own corrupted-side entities | the sampled ids]
+    // (general_models.py:396-400, 424-427): nd_own != null -> negative job j reads id nd_own[c*nd_chunk + jj] for
+    // jj = j % (nd_chunk + nd_Ns) < nd_chunk, else nidx[c*nd_Ns + jj - nd_chunk] (no combined id list is materialised)
+    const int64_t *nd_own; int nd_chunk, nd_Ns;
     float *Hc, *Tc, *Rc;             // [B,d_e], [B,d_e], [B,d_r] dense copies of the gathered h / t / r rows or null
                                      // (--async_update pipeline: later kernels of the step must not re-read the tables)
 };

@@ -22,7 +22,7 @@ template <int MODEL, int V, bool LEAN>
 __device__ __forceinline__ void edge_fwd_body(const EdgeFwdArgs &a_in, int bid) {
     using namespace kge;
     EdgeFwdArgs a = a_in;
-    if constexpr (LEAN) { a.src.em.n = 0; a.src.rm.n = 0; a.lp.genre = KGE_LOSS_LOGSIGMOID; a.row_pos = nullptr; a.Hc = nullptr; }
+    if constexpr (LEAN) { a.src.em.n = 0; a.src.rm.n = 0; a.lp.genre = KGE_LOSS_LOGSIGMOID; a.row_pos = nullptr; a.Hc = nullptr; a.nd_own = nullptr; }
     const int64_t w = (int64_t)bid * KGE_WAVES_PER_BLOCK + (threadIdx.x >> 6);
     const int lane = LANE();
     if (w < a.B) {
@@ -163,7 +163,14 @@ __device__ __forceinline__ void edge_fwd_body(const EdgeFwdArgs &a_in, int bid) 
     } else if (w < (int64_t)a.B + a.n_neg) {
         // negative row job: dense copy for the GEMM / pairwise kernels and |b|^2
         const int64_t j = w - a.B;
-        const float *x = table_row(a.src.em, a.nbase, a.nidx, j, a.d_e);
+        int64_t jx = j;
+        const int64_t *jidx = a.nidx;
+        if (!LEAN && a.nd_own) {         // neg_deg_sample: in-batch rows first, then the sampled ones
+            const int Np = a.nd_chunk + a.nd_Ns, c = (int)(j / Np), jj = (int)(j % Np);
+            if (jj < a.nd_chunk) { jidx = a.nd_own; jx = (int64_t)c * a.nd_chunk + jj; }
+            else jx = (int64_t)c * a.nd_Ns + jj - a.nd_chunk;
+        }
+        const float *x = table_row(a.src.em, a.nbase, jidx, jx, a.d_e);
         float *cp = a.Bn ? a.Bn + j * (int64_t)a.d_e : nullptr;
         float s = 0.f;
         for (int it = lane; it < a.d_e / V; it += 64) {

@@ -94,7 +94,8 @@ static int launch_edge_fwd_m(const EdgeFwdArgs &a, hipStream_t s) {
     const int nb = blocks_for_waves(waves);
     const bool cx = is_complex_model(MODEL);
     const bool vec = cx ? ((a.d_e / 2) % 4 == 0 && a.d_r % 4 == 0) : (a.d_e % 4 == 0);
-    const bool lean = vec && a.src.em.n == 0 && a.src.rm.n == 0 && a.lp.genre == KGE_LOSS_LOGSIGMOID && !a.row_pos && !a.Hc;
+    const bool lean = vec && a.src.em.n == 0 && a.src.rm.n == 0 && a.lp.genre == KGE_LOSS_LOGSIGMOID && !a.row_pos && !a.Hc &&
+                      !a.nd_own;
     if (lean)
         hipLaunchKernelGGL((edge_fwd_kernel<MODEL, 4, true>), dim3(nb), dim3(KGE_BLOCK), 0, s, b);
     else if (vec)
