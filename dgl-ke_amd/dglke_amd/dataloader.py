@@ -168,7 +168,7 @@ class DeviceSampler(object):
         g = th.Generator(device=self.dev)
         g.manual_seed(self.seed)
         self.perm = th.randperm(self.n_train, device=self.dev, generator=g) if shuffle else None
-        self.state = th.tensor([0, 1], dtype=th.int64, device=self.dev)       # {position, step (1-based)}
+        self.state = th.tensor([0, 1, 0, 0], dtype=th.int64, device=self.dev)   # {position, step (1-based), ticket, -}
         self.n_slots = int(n_slots)
         self.slot_bytes = int(_lib.lib().kge_sampler_slot_bytes(self.B, self.C, self.N))
         self.slots = th.zeros(self.n_slots * self.slot_bytes, dtype=th.uint8, device=self.dev)

@@ -380,7 +380,8 @@ int kge_ipc_close(void *base);
 /* ---- on-device sampler + plan builder (replaces the DGL EdgeSampler wrappers of
  * dataloader/sampler.py:376-419, 823-876 and the host plan of dglke_amd/plan.py) ----
  * heads/rels/tails: the training triples in HBM; perm: base edge permutation or NULL (sequential order);
- * state: device int64[2] = {(legacy) position, step number (1-based)}, advanced by the call; builds n_slots
+ * state: device int64[4] = {(legacy) position, step number (1-based), ticket counter (0 between launches), unused}, advanced
+ * by the launch itself (its last workgroup); builds n_slots
  * consecutive batches (batch k = step state[1]+k: odd steps corrupt tails, even steps heads;
  * C*N uniform negatives with replacement from a counter-based RNG keyed by (seed, step)).  Epochs consist of
  * floor(n_train / B) WHOLE batches (the trailing partial batch is dropped, dataloader/sampler.py:503-504) and
