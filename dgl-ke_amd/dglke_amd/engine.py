@@ -79,7 +79,7 @@ class StepEngine(object):
         self._sum4 = torch.zeros(4, dtype=torch.float32, device=self.device)
         self._ws = None
         self._ws_bytes = 0
-        self._graphs = []
+        self._graphs = 0               # graphs captured with this engine's workspace baked in (the workspace may not move then)
         self._pipe = None              # kge_pipe of the --async_update pipeline (side stream + events)
         self._aws = None
         self._aws_bytes = 0
@@ -242,7 +242,8 @@ class StepEngine(object):
             else:
                 for b in batches:
                     self.step(b)
-        self._graphs.append((g, batches))
+        g._kge_batches = batches       # the graph reads the batches' arrays: they live as long as the graph does
+        self._graphs += 1
         return g
 
     def read_loss(self):
