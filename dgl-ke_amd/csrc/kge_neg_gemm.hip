@@ -44,6 +44,11 @@ using namespace kge;
 KGE_TL_DEFINE(gemm)
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+// program order is kept across this point: loads by the compiler-level memory barrier, everything else by the scheduling barrier
+// MFMAs are pure values without a place in program order: the accumulators go through an empty volatile asm (AGPR operands, no
+// instruction) so that the MFMAs producing them stay BEFORE this point
+#define KGE_PIN_ACC(x, y) do { asm volatile("" : "+a"(x), "+a"(y) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define KGE_ORDER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 
 bool neg_mfma_supported(int model, int d_e, int N) {
     (void)N;
@@ -97,32 +102,50 @@ __device__ __forceinline__ void neg_fwd_gemm_body(const GemmArgs &a, int ti, int
         for (int r = 0; r < 4; ++r) asq_pre[r] = a.asq[(int64_t)c * a.chunk + min(it * 16 + q * 4 + r, a.chunk - 1)];
     }
 
-    // main loop: only FULL k-steps (all 64 lanes in range) - no per-lane predicates, no exec-mask
-    // branches between the MFMAs; the (KS0)+u < kfull tests are wave-uniform scalar branches
+    // main loop: only FULL k-steps (all 64 lanes in range) - no per-lane predicates, no exec-mask branches between the
+    // MFMAs.  The loads are UNCONDITIONAL (k-step index clamped to the last full one, a redundant in-bounds load at the end):
+    // a load under a branch - even a wave-uniform scalar one - makes the compiler's s_waitcnt pass assume at the join that it
+    // was NOT issued, so the wait before the MFMAs of the older buffer became vmcnt(0) and also waited for the buffer just
+    // requested: the double buffering was there in the source and absent in the ISA (profiles/r02_waitcnt_fix.txt).
     const int kfull = D >> 4;
+    // (the k-step index goes through an empty volatile asm: these loads have no other tie to program order - read-only
+    //  kernel-argument pointers - and were otherwise hoisted above the MFMAs that still read the buffer they refill)
 #define FWD_LOAD(AV, BV, KS0)                                                    \
-    _Pragma("unroll") for (int u = 0; u < FU; ++u) {                             \
-        if ((KS0) + u < kfull) { AV[u] = ldg4(Ap + ((KS0) + u) * 16); BV[u] = ldg4(Bp + ((KS0) + u) * 16); } \
-    }
-#define FWD_MMA(AV, BV, KS0)                                                     \
-    _Pragma("unroll") for (int u = 0; u < FU; ++u) {                             \
-        if ((KS0) + u < kfull) {                                                 \
-            acc0 = MFMA16(AV[u].x, BV[u].x, acc0);                               \
-            acc1 = MFMA16(AV[u].y, BV[u].y, acc1);                               \
-            acc0 = MFMA16(AV[u].z, BV[u].z, acc0);                               \
-            acc1 = MFMA16(AV[u].w, BV[u].w, acc1);                               \
-        }                                                                        \
-    }
-
-    FWD_LOAD(a0, b0, 0);
-    for (int g = 0; g < kfull; g += 2 * FU) {
-        FWD_LOAD(a1, b1, g + FU);
-        FWD_MMA(a0, b0, g);
-        FWD_LOAD(a0, b0, g + 2 * FU);
-        FWD_MMA(a1, b1, g + FU);
+    { int k0_ = (KS0); asm volatile("" : "+s"(k0_));                             \
+      _Pragma("unroll") for (int u = 0; u < FU; ++u) {                           \
+        const int ks_ = min(k0_ + u, kfull - 1);                                 \
+        AV[u] = ldg4(Ap + ks_ * 16); BV[u] = ldg4(Bp + ks_ * 16);                \
+    } }
+#define FWD_MMA1(AV, BV, u)                                                      \
+    { acc0 = MFMA16(AV[u].x, BV[u].x, acc0);                                     \
+      acc1 = MFMA16(AV[u].y, BV[u].y, acc1);                                     \
+      acc0 = MFMA16(AV[u].z, BV[u].z, acc0);                                     \
+      acc1 = MFMA16(AV[u].w, BV[u].w, acc1); }
+#define FWD_MMA(AV, BV) _Pragma("unroll") for (int u = 0; u < FU; ++u) FWD_MMA1(AV, BV, u)
+#define FWD_MMA_G(AV, BV, KS0) _Pragma("unroll") for (int u = 0; u < FU; ++u) { if ((KS0) + u < kfull) FWD_MMA1(AV, BV, u) }
+    if (kfull > 0) {
+        FWD_LOAD(a0, b0, 0);
+        int g = 0;
+        for (; g + 2 * FU <= kfull; g += 2 * FU) {
+            FWD_LOAD(a1, b1, g + FU);
+            KGE_ORDER();                                // the requests go out BEFORE the MFMAs on the other buffer, as written
+            FWD_MMA(a0, b0);
+            KGE_PIN_ACC(acc0, acc1);                    // ... and a buffer is refilled only AFTER its MFMAs were issued
+            FWD_LOAD(a0, b0, g + 2 * FU);
+            KGE_ORDER();
+            FWD_MMA(a1, b1);
+            KGE_PIN_ACC(acc0, acc1);
+        }
+        if (g < kfull) {                     // fewer than 2 * FU k-steps left; a0 / b0 hold the first FU of them
+            FWD_LOAD(a1, b1, g + FU);
+            FWD_MMA_G(a0, b0, g);
+            FWD_MMA_G(a1, b1, g + FU);
+        }
     }
 #undef FWD_LOAD
+#undef FWD_MMA1
 #undef FWD_MMA
+#undef FWD_MMA_G
     if (D & 15) {   // tail k-step: lanes whose 4 floats lie beyond D contribute zeros
         float4 av = zero4(), bv = zero4();
         if (kfull * 16 + kq < D) { av = ldg4(Ap + kfull * 16); bv = ldg4(Bp + kfull * 16); }
@@ -338,7 +361,7 @@ __device__ __forceinline__ void neg_bwd_gemm_body(const GemmArgs &a, int ti, int
     // FACT, GA: this lane's row statistics (lane m <-> output row rt*16 + m), requested BEFORE the barrier so that the
     // partial loads fly together with the index loads above; the d-tile-0 wavefronts also reduce the row's loss term
     float rM = 0.f, rcoef = 0.f;
-    const float *PMrow = nullptr;
+    const float *PMrow = FACT ? a.PM : nullptr;      // GN workgroups: any valid address (their loop loads it unconditionally, unused)
     if (FACT && isGA) {
         const int rowg = min(rt * 16 + m, chunk - 1);
         const int64_t gi = (int64_t)c * chunk + rowg;
@@ -398,49 +421,70 @@ __device__ __forceinline__ void neg_bwd_gemm_body(const GemmArgs &a, int ti, int
     const float *Xb = (isGA ? a.nbase : a.A) + dc;                 // operand base (global address space)
     const float *Wq = Wrow + (int64_t)(q * 4) * wstride;
 
-#define BWD_LOAD(ST, MS0)                                                                      \
+    // loads are UNCONDITIONAL (macro step clamped; see the forward kernel: a load under a branch defeats the double buffering),
+    // the W-layout choice is a compile-time constant of the loop instance (VECW), not a branch per load
+#define BWD_LOAD(ST, MS0, VECW)                                                                \
     _Pragma("unroll") for (int u = 0; u < BU; ++u) {                                           \
-        if ((MS0) + u < msfull) {                                                              \
-            const int ms = (MS0) + u;                                                          \
-            int64_t ri[4];                                                                     \
-            _Pragma("unroll") for (int e = 0; e < 4; ++e) ri[e] = rix[ms * 16 + q * 4 + e];    \
-            if (vecW) {                                                                        \
-                const float4 t4 = ldg4(Wq + ms * 16);                                          \
-                ST[u].w[0] = t4.x; ST[u].w[1] = t4.y; ST[u].w[2] = t4.z; ST[u].w[3] = t4.w;    \
-            } else {                                                                           \
-                _Pragma("unroll") for (int e = 0; e < 4; ++e)                                  \
-                    ST[u].w[e] = Wq[(int64_t)(ms * 16 + e) * wstride];                         \
-            }                                                                                  \
-            if (FACT && isGA) ST[u].pm = PMrow[ms];   /* macro step ms = column tile ms */     \
-            _Pragma("unroll") for (int e = 0; e < 4; ++e) ST[u].r[e] = ldg4(Xb + ri[e] * D);   \
+        const int ms = min((MS0) + u, msfull - 1);                                             \
+        int64_t ri[4];                                                                         \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) ri[e] = rix[ms * 16 + q * 4 + e];        \
+        if (VECW) {                                                                            \
+            const float4 t4 = ldg4(Wq + ms * 16);                                              \
+            ST[u].w[0] = t4.x; ST[u].w[1] = t4.y; ST[u].w[2] = t4.z; ST[u].w[3] = t4.w;        \
+        } else {                                                                               \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e)                                      \
+                ST[u].w[e] = Wq[(int64_t)(ms * 16 + e) * wstride];                             \
         }                                                                                      \
+        if (FACT) ST[u].pm = PMrow[isGA ? ms : 0];    /* macro step ms = column tile ms */     \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) ST[u].r[e] = ldg4(Xb + ri[e] * D);       \
     }
     // u_ij -> dL/dn_ij: one factor per (row, macro step) for GA, one LDS read of four per-row factors for GN
 #define BWD_XFORM(ST, MS0)                                                                     \
     if (FACT) {                                                                                \
         _Pragma("unroll") for (int u = 0; u < BU; ++u) {                                       \
-            if ((MS0) + u < msfull) {                                                          \
-                if (isGA) {                                                                    \
-                    const float f_ = a.lp.adv ? __expf(ST[u].pm - rM) * rcoef : rcoef;         \
-                    _Pragma("unroll") for (int e = 0; e < 4; ++e) ST[u].w[e] *= f_;           \
-                } else {                                                                       \
-                    _Pragma("unroll") for (int e = 0; e < 4; ++e)                              \
-                        ST[u].w[e] *= ft[(((MS0) + u) * 16 + q * 4 + e) * GB_TJP];             \
-                }                                                                              \
+            const int ms = min((MS0) + u, msfull - 1);                                         \
+            if (isGA) {                                                                        \
+                const float f_ = a.lp.adv ? __expf(ST[u].pm - rM) * rcoef : rcoef;             \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) ST[u].w[e] *= f_;               \
+            } else {                                                                           \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e)                                  \
+                    ST[u].w[e] *= ft[(ms * 16 + q * 4 + e) * GB_TJP];                          \
             }                                                                                  \
         }                                                                                      \
     }
-#define BWD_MMA(ST, MS0)                                                                       \
-    _Pragma("unroll") for (int u = 0; u < BU; ++u) {                                           \
-        if ((MS0) + u < msfull) {                                                              \
-            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                    \
-                const float wgt = ST[u].w[e];                                                  \
-                wsum += wgt;                                                                   \
-                acc[0] = MFMA16(wgt, ST[u].r[e].x, acc[0]);                                    \
-                acc[1] = MFMA16(wgt, ST[u].r[e].y, acc[1]);                                    \
-                acc[2] = MFMA16(wgt, ST[u].r[e].z, acc[2]);                                    \
-                acc[3] = MFMA16(wgt, ST[u].r[e].w, acc[3]);                                    \
-            }                                                                                  \
+#define BWD_MMA1(ST, u)                                                                        \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                            \
+        const float wgt = ST[u].w[e];                                                          \
+        wsum += wgt;                                                                           \
+        acc[0] = MFMA16(wgt, ST[u].r[e].x, acc[0]);                                            \
+        acc[1] = MFMA16(wgt, ST[u].r[e].y, acc[1]);                                            \
+        acc[2] = MFMA16(wgt, ST[u].r[e].z, acc[2]);                                            \
+        acc[3] = MFMA16(wgt, ST[u].r[e].w, acc[3]);                                            \
+    }
+#define BWD_MMA(ST) _Pragma("unroll") for (int u = 0; u < BU; ++u) { BWD_MMA1(ST, u) }
+#define BWD_MMA_G(ST, MS0) _Pragma("unroll") for (int u = 0; u < BU; ++u) { if ((MS0) + u < msfull) { BWD_MMA1(ST, u) } }
+#define BWD_PIPE(VECW)                                                                         \
+    {                                                                                          \
+        BWD_LOAD(s0, 0, VECW);                                                                 \
+        int g = 0;                                                                             \
+        for (; g + 2 * BU <= msfull; g += 2 * BU) {                                            \
+            BWD_LOAD(s1, g + BU, VECW);                                                        \
+            KGE_ORDER();                           /* requests first, then the MFMAs on the other buffer */ \
+            BWD_XFORM(s0, g);                                                                  \
+            BWD_MMA(s0);                                                                       \
+            KGE_ORDER();                                                                       \
+            BWD_LOAD(s0, g + 2 * BU, VECW);                                                    \
+            KGE_ORDER();                                                                       \
+            BWD_XFORM(s1, g + BU);                                                             \
+            BWD_MMA(s1);                                                                       \
+            KGE_ORDER();                                                                       \
+        }                                                                                      \
+        if (g < msfull) {                    /* fewer than 2 * BU macro steps left */          \
+            BWD_LOAD(s1, g + BU, VECW);                                                        \
+            BWD_XFORM(s0, g);                                                                  \
+            BWD_MMA_G(s0, g);                                                                  \
+            BWD_XFORM(s1, g + BU);                                                             \
+            BWD_MMA_G(s1, g + BU);                                                             \
         }                                                                                      \
     }
 
@@ -461,18 +505,15 @@ __device__ __forceinline__ void neg_bwd_gemm_body(const GemmArgs &a, int ti, int
         }
         if (FACT && isGA) tpm = PMrow[msfull];
     }
-    BWD_LOAD(s0, 0);
-    for (int g = 0; g < msfull; g += 2 * BU) {
-        BWD_LOAD(s1, g + BU);
-        BWD_XFORM(s0, g);
-        BWD_MMA(s0, g);
-        BWD_LOAD(s0, g + 2 * BU);
-        BWD_XFORM(s1, g + BU);
-        BWD_MMA(s1, g + BU);
+    if (msfull > 0) {
+        if (vecW) BWD_PIPE(true) else BWD_PIPE(false)
     }
 #undef BWD_LOAD
 #undef BWD_XFORM
+#undef BWD_MMA1
 #undef BWD_MMA
+#undef BWD_MMA_G
+#undef BWD_PIPE
     if (has_tail) {
         const int kk = msfull * 16 + q * 4;
         float ftail = 1.f;
