@@ -487,6 +487,9 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     const int dmax = d_e > d_r ? d_e : d_r;
     const bool transe_fast = transe && !pairwise && !nd && d_e % 4 == 0 && d_r % 4 == 0 && dmax <= 1024 &&
                              !(hp->flags & KGE_FLAG_NO_TRANSE_FAST);
+    // ... behind the matrix-core backward: its GA epilogue also writes Q = GA +/- P (into the GT buffer, unused on this path)
+    // and the update reads one gradient row per list entry (GemmArgs::Q)
+    const bool qfuse = transe_fast && gemm;
 
     Carver cv(ws, ws_bytes);
     float *A = cv.f((size_t)B * d_e), *Bn = cv.f((size_t)CN * d_e);
@@ -660,6 +663,10 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     } else if (gemm) {
         g.W = S; g.w = b->edge_w; g.lp = lp;      // fused loss: S holds u_ij and PM/PS/PL (set above) the partials
         g.GA = GA; g.GN = GN;
+        if (qfuse) {                              // TransE: the update reads Q = GA +/- P, GA itself only on request (g_rel output)
+            g.Q = GT; g.QP = Pg; g.qc = b->neg_head ? 1.f : -1.f;
+            if (!(out && out->g_rel)) g.GA = nullptr;
+        }
         g.reg_coef = (reg && !nd) ? hp->reg_coef : 0.f; g.reg_norm = hp->reg_norm;   // nd: the update adds it (sampled rows only)
         g.row_neg = (fused_loss && want4) ? row_neg : nullptr;
         g.acc = fused_loss ? acc : nullptr;
@@ -760,6 +767,7 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     ua.ue_rec = b->ue_rec; ua.ur_rec = b->ur_rec; ua.counts_dev = b->counts_dev;
     ua.GH = GH; ua.GT = GT; ua.GN = GN; ua.GR = GR;
     ua.transe_fast = transe_fast ? 1 : 0; ua.neg_head = b->neg_head; ua.P = Pg; ua.GA = GA;
+    ua.Q = qfuse ? GT : nullptr;
     ua.reg_ent = want4 ? reg_ent : nullptr; ua.reg_rel = want4 ? reg_rel : nullptr;
     ua.acc = acc;
     ua.ld_e = d_e; ua.ld_r = d_r; ua.ld_gs_e = 1; ua.ld_gs_r = 1;

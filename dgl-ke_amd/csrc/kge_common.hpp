@@ -340,6 +340,8 @@ struct UpdateArgs {
     // part) instead of reading GH/GT/GR written by edge_bwd:  GH = -P (+GA in tail mode),
     // GT = +P (+GA in head mode), GR = -P +/- GA + regulariser
     int transe_fast, neg_head; const float *P, *GA;
+    const float *Q;                  // TransE fast path, matrix-core backward: Q = GA +/- P (GemmArgs::Q) - when set, the corrupted-side
+                                     // entity gradient is Q, the relation gradient +/-Q (+ regulariser), GA is not read
     float *reg_ent, *reg_rel;        // [UE], [UR] regularisation value partials (or null)
     float *acc;                      // [4][KGE_ACC_SLOTS] running sums (row 3 = regularisation) or null
     // emit mode (sharded training): write gradients instead of updating the entity table
@@ -413,7 +415,11 @@ struct GemmArgs {                   // LDS-staged fp32-MFMA negative scoring (kg
     const float *W;                  // dL/dn (TransE_l2: already / dist); with PM != null: u_ij, scaled per (row, tile) here
     const float *w;                  // [B] edge weights or null
     LossParams lp; int B;
-    float *GA, *GN;                  // out [C*chunk, D], [C*N, D]
+    float *GA, *GN;                  // out [C*chunk, D] (or null when only Q is wanted), [C*N, D]
+    // TransE: Q = GA + qc * QP with QP = the per-edge positive-part gradient rows P and qc = +1 (head-corrupted) / -1 -
+    // exactly the gradient of the corrupted-side entity row and, up to the sign, of the relation row, so that the update
+    // reads ONE row per list entry instead of two (P and GA).  null: not emitted.
+    float *Q; const float *QP; float qc;
     float reg_coef; int reg_norm;
     float *row_neg;                  // [B] per-row negative loss terms or null
     float *acc;                      // running sums or null

@@ -402,13 +402,30 @@ __device__ __forceinline__ void neg_bwd_gemm_body(const GemmArgs &a, int ti, int
     const bool need_self = L2 || ((!isGA) && a.reg_coef > 0.f && a.reg_norm > 0);
     float4 selfv[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        selfv[r] = zero4();
-        if (need_self) {
-            const int roc = min(rt * 16 + q * 4 + r, R - 1);
-            const float *self = isGA ? Ac + (int64_t)roc * D : row_ptr(a.nbase, a.nidx, (int64_t)c * N + roc, D);
-            selfv[r] = ldg4(self + dc);
+    for (int r = 0; r < 4; ++r) selfv[r] = zero4();
+    if (need_self) {
+        // row numbers first (GN, gathered negatives: FOUR index loads in one round), then the four row loads back to back.
+        // One `row_ptr()` per row put an index load, a branch join and therefore a vmcnt(0) in front of every row load:
+        // eight serialised memory rounds at the start of every GN wavefront (profiles/r02_waitcnt_fix.txt).
+        int64_t srow[4];
+        if (!isGA && a.nidx) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) srow[r] = a.nidx[(int64_t)c * N + min(rt * 16 + q * 4 + r, R - 1)];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) srow[r] = (int64_t)c * R + min(rt * 16 + q * 4 + r, R - 1);
         }
+        const float *sb = (isGA ? a.A : a.nbase) + dc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) selfv[r] = ldg4(sb + srow[r] * D);
+    }
+    // Q = GA + qc * P (see GemmArgs): the P rows of this tile, requested now as well
+    const bool wantQ = isGA && a.Q != nullptr;
+    float4 pq[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        pq[r] = zero4();
+        if (wantQ) pq[r] = ldg4(a.QP + ((int64_t)c * chunk + min(rt * 16 + q * 4 + r, R - 1)) * D + dc);
     }
     float wsum = 0.f;                                    // partial row (GA) / column (GN) sum of W
     BwdStage s0[BU], s1[BU];
@@ -555,7 +572,13 @@ __device__ __forceinline__ void neg_bwd_gemm_body(const GemmArgs &a, int ti, int
             }
             // write-through store: GA / GN are consumed by the update kernel (any XCD); lines left dirty in this XCD's L2 only
             // lengthen the write-back before the next launch (profiles/r02_store_policy.txt)
-            { Pack<4> ov; ov.v[0] = o.x; ov.v[1] = o.y; ov.v[2] = o.z; ov.v[3] = o.w; st_wt<4>(O + ((int64_t)c * R + ro) * D + d, ov); }
+            if (O) { Pack<4> ov; ov.v[0] = o.x; ov.v[1] = o.y; ov.v[2] = o.z; ov.v[3] = o.w; st_wt<4>(O + ((int64_t)c * R + ro) * D + d, ov); }
+            if (wantQ) {
+                Pack<4> qv;
+                qv.v[0] = o.x + a.qc * pq[r].x; qv.v[1] = o.y + a.qc * pq[r].y;
+                qv.v[2] = o.z + a.qc * pq[r].z; qv.v[3] = o.w + a.qc * pq[r].w;
+                st_wt<4>(a.Q + ((int64_t)c * R + ro) * D + d, qv);
+            }
         }
     }
 }
@@ -628,11 +651,13 @@ int launch_neg_fwd_gemm_with_update(const GemmArgs &a, const UpdateArgs &u, hipS
     const int nbG = (int)((ntiles + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK);
     const bool l2 = a.model == KGE_TRANSE_L2;
     const int nit = dmax <= 256 ? 1 : (dmax <= 512 ? 2 : 4);
-    const int lean = u.transe_fast ? 1 : 2;
+    // (the TransE fast path behind this GEMM always comes with Q: update variants 3 = TransE with Q, 2 = per-edge gradients)
+    if (u.transe_fast && !u.Q) return KGE_ERR_ARG;
+    const int lean = u.transe_fast ? 3 : 2;
     const dim3 g(nbG + nbE + nbR), b(KGE_BLOCK);
 #define KGE_FU(L2_, N_, LE_) hipLaunchKernelGGL((neg_fwd_update_kernel<L2_, N_, LE_>), g, b, 0, s, a, ti, tj, nbG, u, nbE)
-#define KGE_FU_N(N_) do { if (l2) { if (lean == 1) KGE_FU(true, N_, 1); else KGE_FU(true, N_, 2); }           \
-                          else { if (lean == 1) KGE_FU(false, N_, 1); else KGE_FU(false, N_, 2); } } while (0)
+#define KGE_FU_N(N_) do { if (l2) { if (lean == 3) KGE_FU(true, N_, 3); else KGE_FU(true, N_, 2); }           \
+                          else { if (lean == 3) return KGE_ERR_ARG; KGE_FU(false, N_, 2); } } while (0)
     if (nit == 1) KGE_FU_N(1); else if (nit == 2) KGE_FU_N(2); else KGE_FU_N(4);
 #undef KGE_FU_N
 #undef KGE_FU

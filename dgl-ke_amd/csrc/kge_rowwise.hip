@@ -797,18 +797,19 @@ int launch_update(const UpdateArgs &a, hipStream_t s) {
     const bool inplace = !a.emit_ent && !a.emit_rel && !a.g0 && !a.g1 && !a.gs0 && !a.gs1 && !a.gr && !a.gsr && !a.rid &&
                          !a.dry;
     if ((a.Hs || a.Rs || a.Ns) && !(vec && dmax <= 1024)) return KGE_ERR_ARG;      // stale-row regulariser: register-resident kernel only
-    const int lean = (!inplace || a.nd_chunk) ? 0 : (a.transe_fast ? 1 : 2);
+    if (a.Q && !a.transe_fast) return KGE_ERR_ARG;
+    const int lean = (!inplace || a.nd_chunk) ? 0 : (a.transe_fast ? (a.Q ? 3 : 1) : 2);
     const int nit = dmax <= 256 ? 1 : (dmax <= 512 ? 2 : 4);
 #define KGE_UPD(N, SH, LE) hipLaunchKernelGGL((update_kernel_reg<N, SH, LE>), g, b, 0, s, a, nbE)
-#define KGE_UPD_N(N)                                                             \
-    do {                                                                         \
-        if (sharded) { if (lean == 1) KGE_UPD(N, true, 1); else if (lean == 2) KGE_UPD(N, true, 2); else KGE_UPD(N, true, 0); } \
-        else { if (lean == 1) KGE_UPD(N, false, 1); else if (lean == 2) KGE_UPD(N, false, 2); else KGE_UPD(N, false, 0); }       \
-    } while (0)
+#define KGE_UPD_L(N, SH)                                                         \
+    do { if (lean == 1) KGE_UPD(N, SH, 1); else if (lean == 2) KGE_UPD(N, SH, 2); else if (lean == 3) KGE_UPD(N, SH, 3); \
+         else KGE_UPD(N, SH, 0); } while (0)
+#define KGE_UPD_N(N) do { if (sharded) KGE_UPD_L(N, true); else KGE_UPD_L(N, false); } while (0)
     if (vec && dmax <= 1024) {
         if (nit == 1) KGE_UPD_N(1); else if (nit == 2) KGE_UPD_N(2); else KGE_UPD_N(4);
     }
 #undef KGE_UPD_N
+#undef KGE_UPD_L
 #undef KGE_UPD
     else if (vec) hipLaunchKernelGGL(update_kernel<4>, g, b, 0, s, a, nbE);
     else hipLaunchKernelGGL(update_kernel<1>, g, b, 0, s, a, nbE);

@@ -36,11 +36,19 @@ __device__ __forceinline__ void update_reg_body(const UpdateArgs &a_in, int nb_e
     UpdateArgs a = a_in;
     if constexpr (!SHARDED) { a.em.n = 0; a.rm.n = 0; }
     if constexpr (LEAN != 0) {
-        a.transe_fast = LEAN == 1 ? 1 : 0; a.emit_ent = 0; a.emit_rel = 0;
+        a.transe_fast = (LEAN == 1 || LEAN == 3) ? 1 : 0; a.emit_ent = 0; a.emit_rel = 0;
+        if (LEAN != 3) a.Q = nullptr;
         a.g0 = a.g1 = a.gs0 = a.gs1 = a.gr = a.gsr = nullptr; a.rid = nullptr; a.dry = 0; a.nd_chunk = 0;
     }
     const int lane = LANE();
     const bool reg = a.reg_coef > 0.f && a.reg_norm > 0;
+    // Q mode (TransE fast path behind the matrix-core backward): one gradient row per list entry, see UpdateArgs::Q
+    const bool qm = LEAN == 3 ? true : (LEAN == 0 ? (a.transe_fast && a.Q != nullptr) : false);
+    // list entries in flight per wavefront: every entry is a dependent index -> row round (~0.8 us from L2 / MALL), taken one
+    // at a time the longest list set the kernel time (FB15k's hub entity / most frequent relation: 20 - 40 entries per batch,
+    // 15 - 30 us; profiles/r02_heavy_lists.txt).  Bounded by registers: 4 * NIT per entry and source row.
+    constexpr int LB1 = NIT <= 2 ? 4 : 2;       // entries with one source row
+    constexpr int LB2 = NIT <= 2 ? 2 : 1;       // entries with two (TransE fast path without Q: P and GA)
     // the (fewer) relation workgroups are dispatched FIRST: measured 14.9 vs 16.5 us - a relation wavefront has
     // the same dependent-load chain as an entity wavefront and must not start after all entity workgroups
     const int nb_rel = nblk - nb_ent;
@@ -71,8 +79,8 @@ __device__ __forceinline__ void update_reg_body(const UpdateArgs &a_in, int nb_e
         const int side0 = adj0 & 1;
         const bool ga0 = a.transe_fast && has_pos && side0 == a.neg_head;
         const float sg0 = a.transe_fast ? (side0 ? 1.f : -1.f) : 1.f;
-        const float *pA = !has_pos ? row : (a.transe_fast ? a.P + e0 : (side0 ? a.GT : a.GH) + e0);
-        const float *pB = ga0 ? a.GA + e0 : pA;          // aliases pA when unused (same lines, no extra traffic)
+        const float *pA = !has_pos ? row : (a.transe_fast ? ((qm && ga0) ? a.Q : a.P) + e0 : (side0 ? a.GT : a.GH) + e0);
+        const float *pB = (ga0 && !qm) ? a.GA + e0 : pA;  // aliases pA when unused (same lines, no extra traffic)
         const float *pC = has_neg ? a.GN + gn_row(a, slot0) * d : row;
         // row the regulariser is evaluated on: as gathered by this step (async pipeline) or as it is now
         const float *pX = (a.Hs && has_pos) ? (side0 ? a.Ts : a.Hs) + e0 : row;
@@ -100,7 +108,7 @@ __device__ __forceinline__ void update_reg_body(const UpdateArgs &a_in, int nb_e
                 for (int e = 0; e < 4; ++e) {
                     float g = 0.f;
                     if (reg) { rv += reg_val(xr.v[e], a.reg_norm); g = reg_grad(xr.v[e], a.reg_coef, a.reg_norm); }
-                    if (has_pos) g += sg0 * va.v[e] + (ga0 ? vb.v[e] : 0.f);
+                    if (has_pos) g += (qm && ga0) ? va.v[e] : sg0 * va.v[e] + (ga0 ? vb.v[e] : 0.f);
                     g0[k].v[e] = g;
                     float gn = has_neg ? vc.v[e] : 0.f;
                     if (ndreg && has_neg) gn += reg_grad(xn[k].v[e], a.reg_coef, a.reg_norm);
@@ -109,60 +117,136 @@ __device__ __forceinline__ void update_reg_body(const UpdateArgs &a_in, int nb_e
                 }
             } else { x[k] = zero_pack<4>(); g0[k] = zero_pack<4>(); g1[k] = zero_pack<4>(); xn[k] = zero_pack<4>(); }
         }
+        // ---- rest of the positive list: LB entries requested together (loads unconditional - lane offsets clamped, list index
+        // clamped - and consumed in list order: the sums are the same, bit for bit, as one entry at a time) ----
+        const int npx64 = npx < 64 ? npx : 64;               // the first 64 extra entries sit in adjv (one per lane)
+        int itc[NIT];
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) itc[k] = min(lane + 64 * k, nit - 1) * 4;
+        if (a.transe_fast && !qm) {
 #pragma unroll 1
-        for (int i = 0; i < npx; ++i) {
-            const int adj = i < 64 ? __builtin_amdgcn_readlane(adjv, i) : a.ue_pos_adj[p0 + 1 + i];
-            const int64_t eo = (int64_t)(adj >> 1) * d;
-            const int side = adj & 1;
-            if (a.transe_fast) {
-                const float sg = side ? 1.f : -1.f;
-                const bool withGA = side == a.neg_head;
+            for (int i0 = 0; i0 < npx64; i0 += LB2) {
+                Pack<4> vp[LB2][NIT], vg[LB2][NIT]; float sgj[LB2]; bool wg[LB2];
 #pragma unroll
-                for (int k = 0; k < NIT; ++k) {
-                    const int it = lane + 64 * k;
-                    if (it < nit) {
-                        const Pack<4> g = ld<4>(a.P + eo + it * 4);
-                        const Pack<4> g2 = ld<4>((withGA ? a.GA : a.P) + eo + it * 4);
+                for (int j = 0; j < LB2; ++j) {
+                    const int adj = __builtin_amdgcn_readlane(adjv, min(i0 + j, npx64 - 1));
+                    const int64_t eo = (int64_t)(adj >> 1) * d;
+                    const int side = adj & 1;
+                    sgj[j] = side ? 1.f : -1.f; wg[j] = side == a.neg_head;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) g0[k].v[e] += sg * g.v[e] + (withGA ? g2.v[e] : 0.f);
+                    for (int k = 0; k < NIT; ++k) {
+                        vp[j][k] = ld<4>(a.P + eo + itc[k]);
+                        vg[j][k] = ld<4>((wg[j] ? a.GA : a.P) + eo + itc[k]);
                     }
                 }
-            } else {
-                const float *src = (side ? a.GT : a.GH) + eo;
 #pragma unroll
-                for (int k = 0; k < NIT; ++k) {
-                    const int it = lane + 64 * k;
-                    if (it < nit) {
-                        const Pack<4> g = ld<4>(src + it * 4);
+                for (int j = 0; j < LB2; ++j) {
+                    if (i0 + j < npx64) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) g0[k].v[e] += g.v[e];
+                        for (int k = 0; k < NIT; ++k)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) g0[k].v[e] += sgj[j] * vp[j][k].v[e] + (wg[j] ? vg[j][k].v[e] : 0.f);
+                    }
+                }
+            }
+        } else {
+#pragma unroll 1
+            for (int i0 = 0; i0 < npx64; i0 += LB1) {
+                Pack<4> vv[LB1][NIT]; float sgj[LB1];
+#pragma unroll
+                for (int j = 0; j < LB1; ++j) {
+                    const int adj = __builtin_amdgcn_readlane(adjv, min(i0 + j, npx64 - 1));
+                    const int64_t eo = (int64_t)(adj >> 1) * d;
+                    const int side = adj & 1;
+                    const bool isq = a.transe_fast && side == a.neg_head;            // corrupted side: the row of Q
+                    const float *src = (a.transe_fast ? (isq ? a.Q : a.P) : (side ? a.GT : a.GH)) + eo;
+                    sgj[j] = (a.transe_fast && !isq) ? (side ? 1.f : -1.f) : 1.f;
+#pragma unroll
+                    for (int k = 0; k < NIT; ++k) vv[j][k] = ld<4>(src + itc[k]);
+                }
+#pragma unroll
+                for (int j = 0; j < LB1; ++j) {
+                    if (i0 + j < npx64) {
+#pragma unroll
+                        for (int k = 0; k < NIT; ++k)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) g0[k].v[e] += sgj[j] * vv[j][k].v[e];
                     }
                 }
             }
         }
 #pragma unroll 1
-        for (int i = 0; i < nnx; ++i) {
-            const int slot = i < 64 ? __builtin_amdgcn_readlane(slotv, i) : a.ue_neg_slot[n0 + 1 + i];
-            const float *src = a.GN + gn_row(a, slot) * d;
+        for (int i = 64; i < npx; ++i) {                      // lists longer than 65 entries: one entry at a time
+            const int adj = a.ue_pos_adj[p0 + 1 + i];
+            const int64_t eo = (int64_t)(adj >> 1) * d;
+            const int side = adj & 1;
+            const bool wga = a.transe_fast && side == a.neg_head;
+            const float sg = a.transe_fast ? ((qm && wga) ? 1.f : (side ? 1.f : -1.f)) : 1.f;
+            const float *src = (a.transe_fast ? ((qm && wga) ? a.Q : a.P) : (side ? a.GT : a.GH)) + eo;
+            const float *src2 = (wga && !qm) ? a.GA + eo : src;
 #pragma unroll
             for (int k = 0; k < NIT; ++k) {
-                const int it = lane + 64 * k;
-                if (it < nit) {
-                    Pack<4> g = ld<4>(src + it * 4);
-                    if (ndreg) {
+                const Pack<4> g = ld<4>(src + itc[k]), g2 = ld<4>(src2 + itc[k]);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) g.v[e] += reg_grad(xn[k].v[e], a.reg_coef, a.reg_norm);
+                for (int e = 0; e < 4; ++e) g0[k].v[e] += sg * g.v[e] + ((wga && !qm) ? g2.v[e] : 0.f);
+            }
+        }
+        // ---- rest of the negative list (rows of GN) ----
+        const int nnx64 = nnx < 64 ? nnx : 64;
+#pragma unroll 1
+        for (int i0 = 0; i0 < nnx64; i0 += LB1) {
+            Pack<4> vv[LB1][NIT];
+#pragma unroll
+            for (int j = 0; j < LB1; ++j) {
+                const int slot = __builtin_amdgcn_readlane(slotv, min(i0 + j, nnx64 - 1));
+                const float *src = a.GN + gn_row(a, slot) * d;
+#pragma unroll
+                for (int k = 0; k < NIT; ++k) vv[j][k] = ld<4>(src + itc[k]);
+            }
+#pragma unroll
+            for (int j = 0; j < LB1; ++j) {
+                if (i0 + j < nnx64) {
+#pragma unroll
+                    for (int k = 0; k < NIT; ++k) {
+                        Pack<4> g = vv[j][k];
+                        if (ndreg) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) g.v[e] += reg_grad(xn[k].v[e], a.reg_coef, a.reg_norm);
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (lane + 64 * k < nit) s1 += g.v[e] * g.v[e];
+                            g1[k].v[e] += g.v[e];
+                        }
                     }
+                }
+            }
+        }
+#pragma unroll 1
+        for (int i = 64; i < nnx; ++i) {
+            const float *src = a.GN + gn_row(a, a.ue_neg_slot[n0 + 1 + i]) * d;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { s1 += g.v[e] * g.v[e]; g1[k].v[e] += g.v[e]; }
+            for (int k = 0; k < NIT; ++k) {
+                Pack<4> g = ld<4>(src + itc[k]);
+                if (ndreg) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) g.v[e] += reg_grad(xn[k].v[e], a.reg_coef, a.reg_norm);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (lane + 64 * k < nit) s1 += g.v[e] * g.v[e];
+                    g1[k].v[e] += g.v[e];
                 }
             }
         }
         if (has_pos) {
 #pragma unroll
-            for (int k = 0; k < NIT; ++k)
+            for (int k = 0; k < NIT; ++k) {
+                if (lane + 64 * k < nit) {        // (lanes beyond the row hold clamped duplicates from the list loops)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) s0 += g0[k].v[e] * g0[k].v[e];
+                    for (int e = 0; e < 4; ++e) s0 += g0[k].v[e] * g0[k].v[e];
+                }
+            }
         } else {
 #pragma unroll
             for (int k = 0; k < NIT; ++k) g0[k] = zero_pack<4>();
@@ -232,8 +316,8 @@ __device__ __forceinline__ void update_reg_body(const UpdateArgs &a_in, int nb_e
         const int nit = d >> 2;
         const float sgr = a.neg_head ? -1.f : 1.f;       // TransE fast path: GR = -P +/- GA + regulariser
         const int64_t eo0 = (int64_t)edge0 * d;
-        const float *pA = a.transe_fast ? a.P + eo0 : a.GR + eo0;
-        const float *pB = a.transe_fast ? a.GA + eo0 : pA;
+        const float *pA = a.transe_fast ? (qm ? a.Q : a.P) + eo0 : a.GR + eo0;
+        const float *pB = (a.transe_fast && !qm) ? a.GA + eo0 : pA;
         const float *pX = a.Rs ? a.Rs + eo0 : row;        // row the regulariser is evaluated on (see the entity part)
         Pack<4> x[NIT], gsum[NIT], xr[NIT];
         float rv = 0.f, ss = 0.f;
@@ -249,7 +333,7 @@ __device__ __forceinline__ void update_reg_body(const UpdateArgs &a_in, int nb_e
                     if (reg) rv += reg_val(xr[k].v[e], a.reg_norm);
                     float g;
                     if (a.transe_fast) {
-                        g = sgr * vb.v[e] - va.v[e];
+                        g = qm ? sgr * va.v[e] : sgr * vb.v[e] - va.v[e];
                         if (reg) g += reg_grad(xr[k].v[e], a.reg_coef, a.reg_norm);
                     } else g = va.v[e];
                     ss += g * g;
@@ -257,23 +341,86 @@ __device__ __forceinline__ void update_reg_body(const UpdateArgs &a_in, int nb_e
                 }
             } else { x[k] = zero_pack<4>(); gsum[k] = zero_pack<4>(); xr[k] = zero_pack<4>(); }
         }
+        // ---- rest of the edge list, LB entries in flight (see the entity part) ----
+        const int nex64 = nex < 64 ? nex : 64;
+        int itc[NIT];
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) itc[k] = min(lane + 64 * k, nit - 1) * 4;
+        if (a.transe_fast && !qm) {
 #pragma unroll 1
-        for (int i = 0; i < nex; ++i) {
-            const int64_t eo = (int64_t)(i < 64 ? __builtin_amdgcn_readlane(edgev, i) : a.ur_edge[e0 + 1 + i]) * d;
+            for (int i0 = 0; i0 < nex64; i0 += LB2) {
+                Pack<4> vp[LB2][NIT], vg[LB2][NIT];
+#pragma unroll
+                for (int j = 0; j < LB2; ++j) {
+                    const int64_t eo = (int64_t)__builtin_amdgcn_readlane(edgev, min(i0 + j, nex64 - 1)) * d;
+#pragma unroll
+                    for (int k = 0; k < NIT; ++k) { vp[j][k] = ld<4>(a.P + eo + itc[k]); vg[j][k] = ld<4>(a.GA + eo + itc[k]); }
+                }
+#pragma unroll
+                for (int j = 0; j < LB2; ++j) {
+                    if (i0 + j < nex64) {
+#pragma unroll
+                        for (int k = 0; k < NIT; ++k) {
+                            if (lane + 64 * k < nit) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    float g = sgr * vg[j][k].v[e] - vp[j][k].v[e];
+                                    if (reg) g += reg_grad(xr[k].v[e], a.reg_coef, a.reg_norm);
+                                    ss += g * g; gsum[k].v[e] += g;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        } else {
+            const float *gbase = a.transe_fast ? a.Q : a.GR;
+#pragma unroll 1
+            for (int i0 = 0; i0 < nex64; i0 += LB1) {
+                Pack<4> vv[LB1][NIT];
+#pragma unroll
+                for (int j = 0; j < LB1; ++j) {
+                    const int64_t eo = (int64_t)__builtin_amdgcn_readlane(edgev, min(i0 + j, nex64 - 1)) * d;
+#pragma unroll
+                    for (int k = 0; k < NIT; ++k) vv[j][k] = ld<4>(gbase + eo + itc[k]);
+                }
+#pragma unroll
+                for (int j = 0; j < LB1; ++j) {
+                    if (i0 + j < nex64) {
+#pragma unroll
+                        for (int k = 0; k < NIT; ++k) {
+                            if (lane + 64 * k < nit) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    float g = vv[j][k].v[e];
+                                    if (a.transe_fast) {
+                                        g = sgr * g;
+                                        if (reg) g += reg_grad(xr[k].v[e], a.reg_coef, a.reg_norm);
+                                    }
+                                    ss += g * g; gsum[k].v[e] += g;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll 1
+        for (int i = 64; i < nex; ++i) {                      // lists longer than 65 entries: one entry at a time
+            const int64_t eo = (int64_t)a.ur_edge[e0 + 1 + i] * d;
 #pragma unroll
             for (int k = 0; k < NIT; ++k) {
-                const int it = lane + 64 * k;
-                if (it < nit) {
+                if (lane + 64 * k < nit) {
                     if (a.transe_fast) {
-                        const Pack<4> pv = ld<4>(a.P + eo + it * 4), gv = ld<4>(a.GA + eo + it * 4);
+                        const Pack<4> pv = ld<4>((qm ? a.Q : a.P) + eo + itc[k]), gv = ld<4>((qm ? a.Q : a.GA) + eo + itc[k]);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            float g = sgr * gv.v[e] - pv.v[e];
+                            float g = qm ? sgr * pv.v[e] : sgr * gv.v[e] - pv.v[e];
                             if (reg) g += reg_grad(xr[k].v[e], a.reg_coef, a.reg_norm);
                             ss += g * g; gsum[k].v[e] += g;
                         }
                     } else {
-                        const Pack<4> g = ld<4>(a.GR + eo + it * 4);
+                        const Pack<4> g = ld<4>(a.GR + eo + itc[k]);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { ss += g.v[e] * g.v[e]; gsum[k].v[e] += g.v[e]; }
                     }

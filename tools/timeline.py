@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--graph-steps", type=int, default=20)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--async-update", action="store_true")
+    ap.add_argument("--skew", action="store_true", help="heavy-tailed ids (bench.py --skew)")
     args = ap.parse_args()
     import bench
     from dglke_amd import _lib
@@ -41,7 +42,7 @@ def main():
     w = dict(bench.WORKLOADS[args.workload])
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
-    h, r, t = bench.synth_triples(w, 0)
+    h, r, t = bench.synth_triples(w, 0, args.skew)
     eng = StepEngine(w["model"], w["n_ent"], w["n_rel"], w["hidden"], w["gamma"], w["lr"], dev, w["de"], w["dr"],
                      w["adv"], w["adv_temp"], w["reg_coef"], w["reg_norm"], flags=args.flags)
     lib = _lib.lib()
