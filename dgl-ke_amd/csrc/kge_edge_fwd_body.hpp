@@ -32,8 +32,44 @@ __device__ __forceinline__ void edge_fwd_body(const EdgeFwdArgs &a_in, int bid) 
         const float *r = table_row(a.src.rm, a.src.rbase, a.src.ridx, i, a.d_r);
         float *A = a.A ? a.A + i * (int64_t)a.d_e : nullptr;
         float ps = 0.f, as = 0.f;
+        // rows of <= 128 packs (d <= 512 floats) stay in registers: ONE round of row loads (all requested before the first use,
+        // lane offsets clamped instead of predicated) serves the score, the pos-side vector, the P rows and the dense copies -
+        // the loop below took one dependent round per 64 packs and the later passes re-read the rows
+        constexpr int EK = 2;
+        Pack<V> hreg[EK], rreg[EK], treg[EK];
+        bool regres = false;
+        if constexpr (!is_complex_model(MODEL)) regres = a.d_e / V <= 64 * EK && a.d_r == a.d_e;
         if constexpr (!is_complex_model(MODEL)) {
             const int nit = a.d_e / V;
+            if (regres) {
+#pragma unroll
+                for (int k = 0; k < EK; ++k) {
+                    const int off = min(lane + 64 * k, nit - 1) * V;
+                    hreg[k] = ld<V>(h + off); rreg[k] = ld<V>(r + off); treg[k] = ld<V>(t + off);
+                }
+#pragma unroll
+                for (int k = 0; k < EK; ++k) {
+                    if (lane + 64 * k < nit) {
+                        const int off = (lane + 64 * k) * V;
+                        Pack<V> av;
+#pragma unroll
+                        for (int e = 0; e < V; ++e) {
+                            const float hh = hreg[k].v[e], rr = rreg[k].v[e], tt = treg[k].v[e];
+                            const float x = a.neg_head ? tt : hh;
+                            if constexpr (MODEL == KGE_DISTMULT) {
+                                ps += hh * rr * tt;
+                                av.v[e] = x * rr;
+                            } else {
+                                const float u = hh + rr - tt;
+                                if constexpr (MODEL == KGE_TRANSE_L1) ps += fabsf(u); else ps += u * u;
+                                av.v[e] = a.neg_head ? (x - rr) : (x + rr);
+                            }
+                            as += av.v[e] * av.v[e];
+                        }
+                        if (A) KGE_ST_A<V>(A + off, av);
+                    }
+                }
+            } else
             for (int it = lane; it < nit; it += 64) {
                 const int off = it * V;
                 const Pack<V> hv = ld<V>(h + off), rv = ld<V>(r + off), tv = ld<V>(t + off);
@@ -134,6 +170,20 @@ __device__ __forceinline__ void edge_fwd_body(const EdgeFwdArgs &a_in, int bid) 
                         float inv = 0.f;
                         if constexpr (MODEL == KGE_TRANSE_L2) { const float nr = sqrtf(ps); inv = nr > 0.f ? 1.f / nr : 0.f; }
                         float *P = a.P + i * (int64_t)a.d_e;
+                        if (regres) {
+#pragma unroll
+                            for (int k = 0; k < EK; ++k) {
+                                if (lane + 64 * k < a.d_e / V) {
+                                    Pack<V> pv;
+#pragma unroll
+                                    for (int e = 0; e < V; ++e) {
+                                        const float u = hreg[k].v[e] + rreg[k].v[e] - treg[k].v[e];
+                                        pv.v[e] = dp * ((MODEL == KGE_TRANSE_L1) ? sgnf(u) : u * inv);
+                                    }
+                                    KGE_ST_OUT<V>(P + (lane + 64 * k) * V, pv);
+                                }
+                            }
+                        } else
                         for (int it = lane; it < a.d_e / V; it += 64) {
                             const int off = it * V;
                             const Pack<V> hv = ld<V>(h + off), rv = ld<V>(r + off), tv = ld<V>(t + off);
@@ -153,7 +203,15 @@ __device__ __forceinline__ void edge_fwd_body(const EdgeFwdArgs &a_in, int bid) 
             as = wave_sum(as);
             if (lane == 0) a.asq[i] = as;
         }
-        if (a.Hc) {      // dense copies of the gathered rows (second pass: the rows are L1 / L2 hot)
+        if (a.Hc && regres) {
+#pragma unroll
+            for (int k = 0; k < EK; ++k) {
+                if (lane + 64 * k < a.d_e / V) {
+                    const int64_t o = i * (int64_t)a.d_e + (lane + 64 * k) * V;
+                    st<V>(a.Hc + o, hreg[k]); st<V>(a.Tc + o, treg[k]); st<V>(a.Rc + o, rreg[k]);
+                }
+            }
+        } else if (a.Hc) {      // dense copies of the gathered rows (second pass: the rows are L1 / L2 hot)
             for (int it = lane; it < a.d_e / V; it += 64) {
                 st<V>(a.Hc + i * (int64_t)a.d_e + it * V, ld<V>(h + it * V));
                 st<V>(a.Tc + i * (int64_t)a.d_e + it * V, ld<V>(t + it * V));
@@ -173,7 +231,21 @@ __device__ __forceinline__ void edge_fwd_body(const EdgeFwdArgs &a_in, int bid) 
         const float *x = table_row(a.src.em, a.nbase, jidx, jx, a.d_e);
         float *cp = a.Bn ? a.Bn + j * (int64_t)a.d_e : nullptr;
         float s = 0.f;
-        for (int it = lane; it < a.d_e / V; it += 64) {
+        const int nitn = a.d_e / V;
+        if (nitn <= 128) {               // both packs of the row requested together (see the edge job)
+            Pack<V> v2[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) v2[k] = ld<V>(x + min(lane + 64 * k, nitn - 1) * V);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                if (lane + 64 * k < nitn) {
+                    if (cp) st<V>(cp + (lane + 64 * k) * V, v2[k]);
+#pragma unroll
+                    for (int e = 0; e < V; ++e) s += v2[k].v[e] * v2[k].v[e];
+                }
+            }
+        } else
+        for (int it = lane; it < nitn; it += 64) {
             const Pack<V> v = ld<V>(x + it * V);
             if (cp) st<V>(cp + it * V, v);
 #pragma unroll

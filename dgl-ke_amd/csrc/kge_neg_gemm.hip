@@ -107,7 +107,11 @@ __device__ __forceinline__ void neg_fwd_gemm_body(const GemmArgs &a, int ti, int
     // a load under a branch - even a wave-uniform scalar one - makes the compiler's s_waitcnt pass assume at the join that it
     // was NOT issued, so the wait before the MFMAs of the older buffer became vmcnt(0) and also waited for the buffer just
     // requested: the double buffering was there in the source and absent in the ISA (profiles/r02_waitcnt_fix.txt).
+#ifdef FWD_PROBE_NOLOOP            // tuning probe (wrong results): wavefront time without the main loop
+    const int kfull = 0;
+#else
     const int kfull = D >> 4;
+#endif
     // (the k-step index goes through an empty volatile asm: these loads have no other tie to program order - read-only
     //  kernel-argument pointers - and were otherwise hoisted above the MFMAs that still read the buffer they refill)
 #define FWD_LOAD(AV, BV, KS0)                                                    \
@@ -320,18 +324,15 @@ __device__ __forceinline__ void row_stats(const GemmArgs &a, int64_t gi, int tj,
 }
 #define GB_TJP 17                      // row stride of the LDS factor table (odd: conflict-free column reads)
 
-// `bid` / `nblk`: this workgroup's index and the number of workgroups doing GEMM work (the body is also one half of the
-// horizontally fused launch below)
-template <bool L2, bool FACT>          // FACT: the streamed weights are u_ij and get the per-(row, tile) factor here
-__device__ __forceinline__ void neg_bwd_gemm_body(const GemmArgs &a, int ti, int tj, int td, int bpA, int bpN, int maxK,
-                                                  int bid, int nblk, float *smem) {
+// ISGA: the product is a compile-time constant of the instance (the workgroup picks it below): the prologue of each is
+// straight-line code - with `isGA` a run-time value every request sat behind a branch join, and a join in front of a wait
+// makes the wait cover everything requested so far (profiles/r02_waitcnt_fix.txt)
+template <bool L2, bool FACT, bool ISGA>   // FACT: the streamed weights are u_ij and get the per-(row, tile) factor here
+__device__ __forceinline__ void neg_bwd_gemm_tile(const GemmArgs &a, int ti, int tj, int td, int c, int bcl, int maxK,
+                                                  float *smem) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    // workgroup -> (chunk, product, 4 consecutive tiles)
-    const int blk = xcd_remap(bid, nblk);
-    const int c = blk / (bpA + bpN);
-    const int bc = blk % (bpA + bpN);
-    const bool isGA = bc < bpA;
-    const int tl = (isGA ? bc : bc - bpA) * KGE_WAVES_PER_BLOCK + wv;
+    constexpr bool isGA = ISGA;
+    const int tl = bcl * KGE_WAVES_PER_BLOCK + wv;       // 4 consecutive tiles of the same (chunk, product) per workgroup
     const int tr = isGA ? ti : tj;                       // row tiles of this product
     const bool tile_ok = tl < tr * td;
     const int dt = tl % td, rt = tl / td;                // (row tile fastest - 4 wavefronts sharing a column slab - measured the same)
@@ -340,17 +341,49 @@ __device__ __forceinline__ void neg_bwd_gemm_body(const GemmArgs &a, int ti, int
     const int K = isGA ? N : chunk;                      // reduction length
     const int R = isGA ? chunk : N;                      // output rows per chunk
 
-    // ---- workgroup-shared tables in LDS ----
-    // rix[k]: row index of reduction element k in the streamed operand (GA: negative row, gathered
-    // through neg_ids or dense; GN: positive row of the chunk).  INDICES, not pointers: a pointer read
-    // back from LDS turns the row loads into flat loads, which count on lgkmcnt and serialise behind
-    // every LDS wait (measured: 48 % of the wavefront time parked in s_waitcnt).
+    // ---- prologue: every request is issued as early as its address is known, oldest first where something waits for it ----
+    const int d = dt * 64 + m * 4;                       // this lane's 4 output columns
+    const bool dok = d < D;                              // D % 4 == 0: all-or-nothing
+    const int dc = dok ? d : 0;
+    // workgroup-shared table in LDS: rix[k] = row index of reduction element k in the streamed operand (GA: negative row,
+    // gathered through neg_ids or dense; GN: positive row of the chunk).  INDICES, not pointers: a pointer read back from
+    // LDS turns the row loads into flat loads, which count on lgkmcnt and serialise behind every LDS wait (measured: 48 %
+    // of the wavefront time parked in s_waitcnt).
     // FACT, GN: ftab[k][t] = factor f(k, t) of every positive row k of the chunk and every column tile t, computed by
     // thread k in the same pass as the row's statistics (one dependent round; the wavefront whose output rows are
     // column tile rt reads column rt).
     int64_t *rix = reinterpret_cast<int64_t *>(smem);                     // [maxK]
     float *ftab = smem + 2 * maxK;                                        // [maxK][GB_TJP]
-    for (int k = threadIdx.x; k < K; k += KGE_BLOCK)
+    // (1) the index this thread contributes to rix (GA, gathered negatives: a global load - the OLDEST request, the LDS
+    //     write below waits for it alone)
+    const int k0 = threadIdx.x;
+    int64_t rix0;
+    if (isGA) rix0 = a.nidx ? a.nidx[(int64_t)c * N + min(k0, K - 1)] : (int64_t)c * N + k0;
+    else rix0 = (int64_t)c * chunk + k0;
+    // (2) the output rows' own vectors (rank-1 term of the L2 expansion / regulariser; at the end they would be one more
+    //     dependent round) and the P rows of the Q epilogue.  GA: addresses are arithmetic - requested now, unconditionally
+    //     (no Q wanted: a valid dummy address).  GN: the row numbers are gathered - index loads now, rows after the barrier.
+    const bool need_self = L2 || ((!isGA) && a.reg_coef > 0.f && a.reg_norm > 0);
+    const bool wantQ = isGA && a.Q != nullptr;
+    float4 selfv[4], pq[4];
+    int64_t srow[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { selfv[r] = zero4(); pq[r] = zero4(); srow[r] = (int64_t)c * R + min(rt * 16 + q * 4 + r, R - 1); }
+    if (isGA) {
+        if (L2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) selfv[r] = ldg4(a.A + srow[r] * D + dc);
+        }
+        const float *qp = (wantQ ? a.QP : a.A) + dc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pq[r] = ldg4(qp + srow[r] * D);
+    } else if (need_self && a.nidx) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) srow[r] = a.nidx[srow[r]];
+    }
+    // (3) the index table
+    if (k0 < K) rix[k0] = rix0;
+    for (int k = k0 + KGE_BLOCK; k < K; k += KGE_BLOCK)                   // K > 256
         rix[k] = isGA ? (a.nidx ? a.nidx[(int64_t)c * N + k] : (int64_t)c * N + k) : (int64_t)c * chunk + k;
     if (FACT && !isGA) {
         for (int k = threadIdx.x; k < K; k += KGE_BLOCK) {
@@ -383,9 +416,6 @@ __device__ __forceinline__ void neg_bwd_gemm_body(const GemmArgs &a, int ti, int
     if (!tile_ok) return;
     const float *ft = ftab + rt;                         // GN: factor of reduction row k = ft[k * GB_TJP]
 
-    const int d = dt * 64 + m * 4;                       // this lane's 4 output columns
-    const bool dok = d < D;                              // D % 4 == 0: all-or-nothing
-    const int dc = dok ? d : 0;
     const float *Wc = a.W + (int64_t)c * chunk * N;
     const float *Ac = a.A + (int64_t)c * chunk * D;
     const int row = rt * 16 + m;
@@ -397,36 +427,6 @@ __device__ __forceinline__ void neg_bwd_gemm_body(const GemmArgs &a, int ti, int
     f32x4 acc[4];
 #pragma unroll
     for (int s_ = 0; s_ < 4; ++s_) acc[s_] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // the output rows' own vectors (rank-1 term of the L2 expansion / regulariser) are requested NOW: they do
-    // not depend on the loop, and at the end they would be one more dependent round (index -> row)
-    const bool need_self = L2 || ((!isGA) && a.reg_coef > 0.f && a.reg_norm > 0);
-    float4 selfv[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) selfv[r] = zero4();
-    if (need_self) {
-        // row numbers first (GN, gathered negatives: FOUR index loads in one round), then the four row loads back to back.
-        // One `row_ptr()` per row put an index load, a branch join and therefore a vmcnt(0) in front of every row load:
-        // eight serialised memory rounds at the start of every GN wavefront (profiles/r02_waitcnt_fix.txt).
-        int64_t srow[4];
-        if (!isGA && a.nidx) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) srow[r] = a.nidx[(int64_t)c * N + min(rt * 16 + q * 4 + r, R - 1)];
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) srow[r] = (int64_t)c * R + min(rt * 16 + q * 4 + r, R - 1);
-        }
-        const float *sb = (isGA ? a.A : a.nbase) + dc;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) selfv[r] = ldg4(sb + srow[r] * D);
-    }
-    // Q = GA + qc * P (see GemmArgs): the P rows of this tile, requested now as well
-    const bool wantQ = isGA && a.Q != nullptr;
-    float4 pq[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        pq[r] = zero4();
-        if (wantQ) pq[r] = ldg4(a.QP + ((int64_t)c * chunk + min(rt * 16 + q * 4 + r, R - 1)) * D + dc);
-    }
     float wsum = 0.f;                                    // partial row (GA) / column (GN) sum of W
     BwdStage s0[BU], s1[BU];
 
@@ -434,7 +434,11 @@ __device__ __forceinline__ void neg_bwd_gemm_body(const GemmArgs &a, int ti, int
     // load is in bounds; garbage in clamped rows only reaches outputs that are never stored), row
     // addresses = kernel-argument base + LDS index (global loads, vmcnt only).  One predicated tail
     // step handles K % 16.
+#ifdef BWD_PROBE_NOLOOP            // tuning probe (wrong results): wavefront time without the main loop
+    const int msfull = 0;
+#else
     const int msfull = K >> 4;
+#endif
     const float *Xb = (isGA ? a.nbase : a.A) + dc;                 // operand base (global address space)
     const float *Wq = Wrow + (int64_t)(q * 4) * wstride;
 
@@ -509,10 +513,10 @@ __device__ __forceinline__ void neg_bwd_gemm_body(const GemmArgs &a, int ti, int
     // main loop, so that they arrive under it - fetched after the loop they were one more dependent load round (~1 us) at
     // the end of every wavefront.  Reduction indices beyond K get zero weight (clamped, in-bounds loads).
     const bool has_tail = (K & 15) != 0;
-    float tw[4] = {0.f, 0.f, 0.f, 0.f};
+    float tw[4];
     float4 tx[4];
     float tpm = 0.f;
-    if (has_tail) {
+    {   // (requested unconditionally - indices clamped, zero weight beyond K - so that the waits after this point count exactly)
         const int kk = msfull * 16 + q * 4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -520,10 +524,15 @@ __device__ __forceinline__ void neg_bwd_gemm_body(const GemmArgs &a, int ti, int
             tw[e] = Wrow[(int64_t)kc * wstride];
             tx[e] = ldg4(Xb + rix[kc] * D);
         }
-        if (FACT && isGA) tpm = PMrow[msfull];
+        if (FACT && isGA) tpm = PMrow[min(msfull, tj - 1)];
+    }
+    // GN: the own rows, now that their (gathered) numbers have arrived under the barrier
+    if (!isGA && need_self) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) selfv[r] = ldg4(a.nbase + srow[r] * D + dc);
     }
     if (msfull > 0) {
-        if (vecW) BWD_PIPE(true) else BWD_PIPE(false)
+        if (isGA && vecW) BWD_PIPE(true) else BWD_PIPE(false)
     }
 #undef BWD_LOAD
 #undef BWD_XFORM
@@ -581,6 +590,18 @@ __device__ __forceinline__ void neg_bwd_gemm_body(const GemmArgs &a, int ti, int
             }
         }
     }
+}
+
+// `bid` / `nblk`: this workgroup's index and the number of workgroups doing GEMM work (the body is also one half of the
+// horizontally fused launch below); workgroup -> (chunk, product, 4 consecutive tiles)
+template <bool L2, bool FACT>
+__device__ __forceinline__ void neg_bwd_gemm_body(const GemmArgs &a, int ti, int tj, int td, int bpA, int bpN, int maxK,
+                                                  int bid, int nblk, float *smem) {
+    const int blk = xcd_remap(bid, nblk);
+    const int c = blk / (bpA + bpN);
+    const int bc = blk % (bpA + bpN);
+    if (bc < bpA) neg_bwd_gemm_tile<L2, FACT, true>(a, ti, tj, td, c, bc, maxK, smem);
+    else neg_bwd_gemm_tile<L2, FACT, false>(a, ti, tj, td, c, bc - bpA, maxK, smem);
 }
 
 template <bool L2, bool FACT>
