@@ -58,10 +58,15 @@ __device__ __forceinline__ void update_reg_body(const UpdateArgs &a_in, int nb_e
         return;
 #endif
         const int64_t u = (int64_t)bx * KGE_WAVES_PER_BLOCK + (threadIdx.x >> 6);
-        if (u >= (a.counts_dev ? a.counts_dev[0] : a.UE)) return;
+        if (u >= a.UE) return;                 // UE: the bound the grid and the record array were sized for
         const int d = a.model_d_e;
-        const int4 r0 = reinterpret_cast<const int4 *>(a.ue_rec)[2 * u];
+        // the device-side row count and this wavefront's plan record are requested TOGETHER (the record of a row beyond the
+        // count is allocated, just unused): count -> record -> rows was one dependent round more in every wavefront
+        int4 r0 = reinterpret_cast<const int4 *>(a.ue_rec)[2 * u];
         const int4 r1 = reinterpret_cast<const int4 *>(a.ue_rec)[2 * u + 1];
+        const int cnt_e = a.counts_dev ? a.counts_dev[0] : a.UE;
+        asm volatile("" : "+v"(r0.x));         // (keeps the record loads above the early exit)
+        if (u >= cnt_e) return;
         const int64_t id = (int64_t)(uint32_t)r0.x | ((int64_t)r0.y << 32);
 #if defined(UPD_PROBE_NOGRAD)      // tuning probe: table read-modify-write only (no gradient rows)
         const int p0 = 0, p1 = 0, n0 = 0, n1 = 0, adj0 = 0, slot0 = 0; (void)r1;
@@ -96,14 +101,23 @@ __device__ __forceinline__ void update_reg_body(const UpdateArgs &a_in, int nb_e
         const int slotv = lane < nnx ? a.ue_neg_slot[n0 + 1 + lane] : 0;
         Pack<4> x[NIT], g0[NIT], g1[NIT], xn[NIT];
         float rv = 0.f, s0 = 0.f, s1 = 0.f;
+        // all packs of the row and of its first contributions are requested before the first use (lane offsets clamped, not
+        // predicated): with the loads inside `if (it < nit)` every 64 packs were a dependent round of their own
+        int itc[NIT];
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) itc[k] = min(lane + 64 * k, nit - 1) * 4;
+        Pack<4> fva[NIT], fvb[NIT], fvc[NIT], fxr[NIT];
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
-            const int it = lane + 64 * k;
-            if (it < nit) {
-                x[k] = ld<4>(row + it * 4);
-                const Pack<4> va = ld<4>(pA + it * 4), vb = ld<4>(pB + it * 4), vc = ld<4>(pC + it * 4);
-                const Pack<4> xr = ld<4>(pX + it * 4);      // aliases the row itself outside the async pipeline
-                xn[k] = ndreg ? ld<4>(pXn + it * 4) : x[k];
+            x[k] = ld<4>(row + itc[k]);
+            fva[k] = ld<4>(pA + itc[k]); fvb[k] = ld<4>(pB + itc[k]); fvc[k] = ld<4>(pC + itc[k]);
+            fxr[k] = ld<4>(pX + itc[k]);                    // aliases the row itself outside the async pipeline
+            xn[k] = ndreg ? ld<4>(pXn + itc[k]) : x[k];
+        }
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            if (lane + 64 * k < nit) {
+                const Pack<4> va = fva[k], vb = fvb[k], vc = fvc[k], xr = fxr[k];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float g = 0.f;
@@ -120,9 +134,6 @@ __device__ __forceinline__ void update_reg_body(const UpdateArgs &a_in, int nb_e
         // ---- rest of the positive list: LB entries requested together (loads unconditional - lane offsets clamped, list index
         // clamped - and consumed in list order: the sums are the same, bit for bit, as one entry at a time) ----
         const int npx64 = npx < 64 ? npx : 64;               // the first 64 extra entries sit in adjv (one per lane)
-        int itc[NIT];
-#pragma unroll
-        for (int k = 0; k < NIT; ++k) itc[k] = min(lane + 64 * k, nit - 1) * 4;
         if (a.transe_fast && !qm) {
 #pragma unroll 1
             for (int i0 = 0; i0 < npx64; i0 += LB2) {
@@ -302,10 +313,13 @@ __device__ __forceinline__ void update_reg_body(const UpdateArgs &a_in, int nb_e
         return;
 #endif
         const int64_t u = ((int64_t)bx - nb_ent) * KGE_WAVES_PER_BLOCK + (threadIdx.x >> 6);
-        if (u >= (a.counts_dev ? a.counts_dev[1] : a.UR)) return;
+        if (u >= a.UR) return;
         const int d = a.d_r;
-        const int4 r0 = reinterpret_cast<const int4 *>(a.ur_rec)[2 * u];
+        int4 r0 = reinterpret_cast<const int4 *>(a.ur_rec)[2 * u];            // count and record together (see the entity part)
         const int4 r1 = reinterpret_cast<const int4 *>(a.ur_rec)[2 * u + 1];
+        const int cnt_r = a.counts_dev ? a.counts_dev[1] : a.UR;
+        asm volatile("" : "+v"(r0.x));
+        if (u >= cnt_r) return;
         const int64_t id = (int64_t)(uint32_t)r0.x | ((int64_t)r0.y << 32);
         const int e0 = r0.z, e1 = r0.w, edge0 = r1.x;
         float *row = shard_row(a.rm, a.rel, id, d);
@@ -321,13 +335,20 @@ __device__ __forceinline__ void update_reg_body(const UpdateArgs &a_in, int nb_e
         const float *pX = a.Rs ? a.Rs + eo0 : row;        // row the regulariser is evaluated on (see the entity part)
         Pack<4> x[NIT], gsum[NIT], xr[NIT];
         float rv = 0.f, ss = 0.f;
+        int itc[NIT];
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) itc[k] = min(lane + 64 * k, nit - 1) * 4;
+        Pack<4> fva[NIT], fvb[NIT];
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {                         // every pack requested before the first use
+            x[k] = ld<4>(row + itc[k]);
+            fva[k] = ld<4>(pA + itc[k]); fvb[k] = ld<4>(pB + itc[k]);
+            xr[k] = ld<4>(pX + itc[k]);
+        }
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
-            const int it = lane + 64 * k;
-            if (it < nit) {
-                x[k] = ld<4>(row + it * 4);
-                const Pack<4> va = ld<4>(pA + it * 4), vb = ld<4>(pB + it * 4);
-                xr[k] = ld<4>(pX + it * 4);
+            if (lane + 64 * k < nit) {
+                const Pack<4> va = fva[k], vb = fvb[k];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     if (reg) rv += reg_val(xr[k].v[e], a.reg_norm);
@@ -343,9 +364,6 @@ __device__ __forceinline__ void update_reg_body(const UpdateArgs &a_in, int nb_e
         }
         // ---- rest of the edge list, LB entries in flight (see the entity part) ----
         const int nex64 = nex < 64 ? nex : 64;
-        int itc[NIT];
-#pragma unroll
-        for (int k = 0; k < NIT; ++k) itc[k] = min(lane + 64 * k, nit - 1) * 4;
         if (a.transe_fast && !qm) {
 #pragma unroll 1
             for (int i0 = 0; i0 < nex64; i0 += LB2) {
