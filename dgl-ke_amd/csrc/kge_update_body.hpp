@@ -47,8 +47,9 @@ __device__ __forceinline__ void update_reg_body(const UpdateArgs &a_in, int nb_e
     // list entries in flight per wavefront: every entry is a dependent index -> row round (~0.8 us from L2 / MALL), taken one
     // at a time the longest list set the kernel time (FB15k's hub entity / most frequent relation: 20 - 40 entries per batch,
     // 15 - 30 us; profiles/r02_heavy_lists.txt).  Bounded by registers: 4 * NIT per entry and source row.
-    constexpr int LB1 = NIT <= 2 ? 4 : 2;       // entries with one source row
+    constexpr int LB1 = NIT <= 2 ? 4 : 2;       // entity lists: entries with one source row
     constexpr int LB2 = NIT <= 2 ? 2 : 1;       // entries with two (TransE fast path without Q: P and GA)
+    constexpr int LBR = NIT <= 2 ? 6 : 2;       // relation lists (one source row; the relation part holds less other state)
     // the (fewer) relation workgroups are dispatched FIRST: measured 14.9 vs 16.5 us - a relation wavefront has
     // the same dependent-load chain as an entity wavefront and must not start after all entity workgroups
     const int nb_rel = nblk - nb_ent;
@@ -394,16 +395,16 @@ __device__ __forceinline__ void update_reg_body(const UpdateArgs &a_in, int nb_e
         } else {
             const float *gbase = a.transe_fast ? a.Q : a.GR;
 #pragma unroll 1
-            for (int i0 = 0; i0 < nex64; i0 += LB1) {
-                Pack<4> vv[LB1][NIT];
+            for (int i0 = 0; i0 < nex64; i0 += LBR) {
+                Pack<4> vv[LBR][NIT];
 #pragma unroll
-                for (int j = 0; j < LB1; ++j) {
+                for (int j = 0; j < LBR; ++j) {
                     const int64_t eo = (int64_t)__builtin_amdgcn_readlane(edgev, min(i0 + j, nex64 - 1)) * d;
 #pragma unroll
                     for (int k = 0; k < NIT; ++k) vv[j][k] = ld<4>(gbase + eo + itc[k]);
                 }
 #pragma unroll
-                for (int j = 0; j < LB1; ++j) {
+                for (int j = 0; j < LBR; ++j) {
                     if (i0 + j < nex64) {
 #pragma unroll
                         for (int k = 0; k < NIT; ++k) {
