@@ -199,7 +199,7 @@ def cpu_baseline(w, plans, budget_s=12.0, max_steps=200):
     return out
 
 
-def hogwild_measure(w, eng, dev, trainers, steps, G, flags):
+def hogwild_measure(w, eng, dev, trainers, steps, G, flags, skew=False):
     """K concurrent trainers on ONE GPU (K HIP streams, K graph chains) updating the same tables
     lock-free - the reference's multi-process Hogwild mode (`--num_proc K`, train.py:298-317,
     docs/source/train.rst:138) with the processes replaced by streams.  Results are
@@ -212,7 +212,7 @@ def hogwild_measure(w, eng, dev, trainers, steps, G, flags):
     per = max(G, (steps // trainers // G) * G)
     engines, graphs, streams = [], [], []
     for k in range(trainers):
-        h, r, t = synth_triples(w, 100 + k)
+        h, r, t = synth_triples(w, 100 + k, skew)
         smp = UniformChunkedSampler(h, r, t, w["n_ent"], w["B"], w["N"], dev, seed=100 + k)
         batches = plan.upload(smp.next_plans(G * 2), dev)
         e = StepEngine(w["model"], w["n_ent"], w["n_rel"], w["hidden"], w["gamma"], w["lr"], dev, w["de"],
@@ -248,13 +248,13 @@ def hogwild_measure(w, eng, dev, trainers, steps, G, flags):
             "semantics": "Hogwild: concurrent lock-free trainers on shared tables (reference --num_proc K)"}
 
 
-def async_measure(w, dev, steps, G, flags, seed=0):
+def async_measure(w, dev, steps, G, flags, seed=0, skew=False):
     """the --async_update pipeline (kge_step_async: the entity update of step s-1 runs on a side stream under the
     scoring of step s; exact one-step staleness inside a group of G steps, flushed at the group's end) on its own
     tables, same workload, sampler inside the timed region.  Reported next to the strict number, never as `value`."""
     from dglke_amd.dataloader import DeviceSampler
     from dglke_amd.engine import StepEngine
-    h, r, t = synth_triples(w, seed)
+    h, r, t = synth_triples(w, seed, skew)
     eng = StepEngine(w["model"], w["n_ent"], w["n_rel"], w["hidden"], w["gamma"], w["lr"], dev, w["de"], w["dr"], w["adv"],
                      w["adv_temp"], w["reg_coef"], w["reg_norm"], flags=flags)
     smp = DeviceSampler(h, r, t, w["n_ent"], w["B"], w["N"], dev, n_slots=G, seed=seed)
@@ -508,13 +508,13 @@ def main():
                                    "note": "whole step; the two GEMM kernels alone: see profiles/*kernel_stats*"}
     if args.hogwild > 1:
         try:
-            out["hogwild"] = hogwild_measure(w, eng, dev, args.hogwild, K, max(G, 60), eng.hp.flags)
+            out["hogwild"] = hogwild_measure(w, eng, dev, args.hogwild, K, max(G, 60), eng.hp.flags, args.skew)
         except Exception as e:
             out["hogwild"] = {"error": repr(e)}
     if args.async_update and dev_sampler and w["model"] not in ("RESCAL", "TransR"):
         try:
-            out["async_update"] = async_measure(w, dev, K, G, eng.hp.flags)
-            out["async_update_rel"] = async_measure(w, dev, K, G, eng.hp.flags | 64)
+            out["async_update"] = async_measure(w, dev, K, G, eng.hp.flags, skew=args.skew)
+            out["async_update_rel"] = async_measure(w, dev, K, G, eng.hp.flags | 64, skew=args.skew)
         except Exception as e:
             out["async_update"] = {"error": repr(e)}
     if not args.no_cpu_baseline:
