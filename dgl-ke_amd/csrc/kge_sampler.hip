@@ -21,6 +21,7 @@
 // sampler is off the critical path exactly like the reference's prefetching sampler threads.
 #include <cstring>
 #include "kge_common.hpp"
+KGE_TL_DEFINE(sampler)
 
 #define SP_THREADS 1024
 #define SP_MAXE 4096                 // max elements (2B + C*N) and max B handled on the device
@@ -73,15 +74,16 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {   // splitmix64 finalise
     return x;
 }
 
-// in-LDS bitonic sort of n2 (power of two) 64-bit keys by all SP_THREADS threads - generic version: one
+// in-LDS bitonic sort of n2 (power of two) keys by all SP_THREADS threads - generic version: one
 // compare-exchange stage per barrier
-__device__ void bitonic_sort_lds(uint64_t *keys, int n2) {
+template <typename K>
+__device__ void bitonic_sort_lds(K *keys, int n2) {
     for (int k = 2; k <= n2; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int i = threadIdx.x; i < n2; i += SP_THREADS) {
                 const int ixj = i ^ j;
                 if (ixj > i) {
-                    const uint64_t a = keys[i], b = keys[ixj];
+                    const K a = keys[i], b = keys[ixj];
                     const bool up = (i & k) == 0;
                     if ((a > b) == up) { keys[i] = b; keys[ixj] = a; }
                 }
@@ -95,11 +97,14 @@ __device__ void bitonic_sort_lds(uint64_t *keys, int n2) {
 // j < E exchanges inside the thread, j < 64*E inside the wavefront (cross-lane shuffles, no barrier), only j >= 64*E
 // goes through LDS - 10 of the 78 stages for 4096 keys, 6 of 55 for 1024 (each __syncthreads of 16 wavefronts costs
 // ~0.4 us: the barriers were most of the sampler kernel's 91 us).  Keys are distinct, so the result is THE sorted order.
-template <int E>
-__device__ void bitonic_sort_regs(uint64_t *keys, int n2) {
+// K: key type.  32-bit keys (entity id < 2^20, see launch_sample_batches) halve the cross-lane traffic of a stage (one
+// ds_bpermute instead of two per key) and turn the 64-bit compare + two selects into v_min_u32 / v_max_u32: the sort is
+// VALU- and LDS-crossbar-bound on ONE CU (16 wavefronts), 37 of the 52 us of an entity-plan workgroup with 64-bit keys.
+template <int E, typename K>
+__device__ void bitonic_sort_regs(K *keys, int n2) {
     const int t = threadIdx.x, lane = t & 63;
     (void)lane;
-    uint64_t v[E];
+    K v[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) v[e] = keys[E * t + e];
     for (int k = 2; k <= n2; k <<= 1) {
@@ -110,18 +115,20 @@ __device__ void bitonic_sort_regs(uint64_t *keys, int n2) {
                     const int p = e ^ j;
                     if (p > e) {
                         const bool up = (((E * t + e) & k) == 0);
-                        const uint64_t a = v[e], b = v[p];
-                        if ((a > b) == up) { v[e] = b; v[p] = a; }
+                        const K a = v[e], b = v[p];
+                        const K lo = a < b ? a : b, hi = a < b ? b : a;
+                        v[e] = up ? lo : hi; v[p] = up ? hi : lo;
                     }
                 }
             } else if (j < 64 * E) {                       // partner in this wavefront: lane ^ (j / E), same slot
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
                     const int i = E * t + e;
-                    const uint64_t o = __shfl_xor(v[e], j / E, 64);
+                    const K o = __shfl_xor(v[e], j / E, 64);
                     const bool lower = (i & j) == 0, up = (i & k) == 0;
                     const bool want_min = lower == up;
-                    v[e] = want_min ? (v[e] < o ? v[e] : o) : (v[e] > o ? v[e] : o);
+                    const K lo = v[e] < o ? v[e] : o, hi = v[e] < o ? o : v[e];
+                    v[e] = want_min ? lo : hi;
                 }
             } else {                                       // partner in another wavefront: through LDS
                 __syncthreads();                           // everybody has read what an earlier LDS stage wrote
@@ -131,10 +138,11 @@ __device__ void bitonic_sort_regs(uint64_t *keys, int n2) {
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
                     const int i = E * t + e;
-                    const uint64_t o = keys[i ^ j];
+                    const K o = keys[i ^ j];
                     const bool lower = (i & j) == 0, up = (i & k) == 0;
                     const bool want_min = lower == up;
-                    v[e] = want_min ? (v[e] < o ? v[e] : o) : (v[e] > o ? v[e] : o);
+                    const K lo = v[e] < o ? v[e] : o, hi = v[e] < o ? o : v[e];
+                    v[e] = want_min ? lo : hi;
                 }
             }
         }
@@ -145,11 +153,12 @@ __device__ void bitonic_sort_regs(uint64_t *keys, int n2) {
     __syncthreads();
 }
 
-__device__ void bitonic_sort(uint64_t *keys, int n2) {
-    if (n2 == 4 * SP_THREADS) bitonic_sort_regs<4>(keys, n2);
-    else if (n2 == 2 * SP_THREADS) bitonic_sort_regs<2>(keys, n2);
-    else if (n2 == SP_THREADS) bitonic_sort_regs<1>(keys, n2);
-    else bitonic_sort_lds(keys, n2);
+template <typename K>
+__device__ void bitonic_sort(K *keys, int n2) {
+    if (n2 == 4 * SP_THREADS) bitonic_sort_regs<4, K>(keys, n2);
+    else if (n2 == 2 * SP_THREADS) bitonic_sort_regs<2, K>(keys, n2);
+    else if (n2 == SP_THREADS) bitonic_sort_regs<1, K>(keys, n2);
+    else bitonic_sort_lds<K>(keys, n2);
 }
 
 // block-wide exclusive scan of n (<= SP_MAXE) uint32 values in `v` (in place); returns the total.
@@ -181,11 +190,13 @@ __device__ __forceinline__ uint64_t gcd_u64(uint64_t x, uint64_t y) {
     return x;
 }
 
+template <typename K>             // key type of the entity plan: uint32_t when (id << SP_CODE_BITS) fits, else uint64_t
 __global__ __launch_bounds__(SP_THREADS) void sample_plan_kernel(SamplerArgs a) {
-    __shared__ uint64_t keys[SP_MAXE];         // 32 KB
+    __shared__ uint64_t keys[SP_MAXE];         // 32 KB (the entity plan with 32-bit keys uses half of it)
     __shared__ uint32_t scan[SP_MAXE];         // 16 KB
     __shared__ uint32_t wsum[SP_THREADS / 64];
     const int t = threadIdx.x;
+    KGE_TL((int)(blockIdx.x & 1));             // developer timeline: kid 0 = entity-plan workgroups, 1 = relation-plan workgroups
     // two workgroups per batch: part 0 samples the edge ends + negatives and builds the entity plan, part 1 samples the
     // relations of the SAME edges and builds the relation plan - independent work (91 -> 72 -> ~50 us per launch)
     const int slot = blockIdx.x >> 1, part = blockIdx.x & 1;
@@ -254,7 +265,7 @@ __global__ __launch_bounds__(SP_THREADS) void sample_plan_kernel(SamplerArgs a) 
             keys[i] = key;
         }
         __syncthreads();
-        bitonic_sort(keys, b2);
+        bitonic_sort<uint64_t>(keys, b2);
         for (int k = t; k < B; k += SP_THREADS) {
             const uint64_t id = keys[k] >> SP_CODE_BITS;
             scan[k] = (k == 0 || (keys[k - 1] >> SP_CODE_BITS) != id) ? 1u : 0u;
@@ -279,39 +290,46 @@ __global__ __launch_bounds__(SP_THREADS) void sample_plan_kernel(SamplerArgs a) 
         }
         return;
     }
+    K *ek = reinterpret_cast<K *>(keys);        // the entity plan's keys
     for (int i = t; i < B; i += SP_THREADS) {
         int64_t e = (int64_t)(((uint64_t)(pos1 + i) * mul + add) % (uint64_t)a.n_train);
         if (a.perm) e = a.perm[e];
         const int64_t h = a.H[e], tl = a.T[e];
         h_gid[i] = h; t_gid[i] = tl;
-        keys[2 * i] = ((uint64_t)h << SP_CODE_BITS) | (uint64_t)(2 * i);
-        keys[2 * i + 1] = ((uint64_t)tl << SP_CODE_BITS) | (uint64_t)(2 * i + 1);
+        ek[2 * i] = ((K)h << SP_CODE_BITS) | (K)(2 * i);
+        ek[2 * i + 1] = ((K)tl << SP_CODE_BITS) | (K)(2 * i + 1);
     }
     for (int j = t; j < CN; j += SP_THREADS) {
         const uint64_t x = mix64(mix64(a.seed ^ (uint64_t)step * 0x9E3779B97F4A7C15ULL) + (uint64_t)j);
         const int64_t id = (int64_t)__umul64hi(x, (uint64_t)a.n_ent);      // uniform in [0, n_ent)
         neg_ids[j] = id;
-        keys[2 * B + j] = ((uint64_t)id << SP_CODE_BITS) | (uint64_t)(2 * B + j);
+        ek[2 * B + j] = ((K)id << SP_CODE_BITS) | (K)(2 * B + j);
     }
     int n2 = 1;
     while (n2 < NE) n2 <<= 1;
-    for (int i = NE + t; i < n2; i += SP_THREADS) keys[i] = ~0ULL;
+    for (int i = NE + t; i < n2; i += SP_THREADS) ek[i] = ~(K)0;
     __syncthreads();
+#ifdef KGE_TL_MARKS
+    KGE_TL_MARK(0);              // ids sampled, keys in LDS
+#endif
     // ---- 2. sort by (entity, code) ----
-    bitonic_sort(keys, n2);
+    bitonic_sort<K>(ek, n2);
+#ifdef KGE_TL_MARKS
+    KGE_TL_MARK(1);              // sorted
+#endif
     // ---- 3. packed flags: bit fields {unique: 0..15, positive: 16..31}; negative rank = k - positive rank ----
     for (int k = t; k < NE; k += SP_THREADS) {
-        const uint64_t id = keys[k] >> SP_CODE_BITS, code = keys[k] & ((1u << SP_CODE_BITS) - 1);
-        const bool uniq = k == 0 || (keys[k - 1] >> SP_CODE_BITS) != id;
+        const uint64_t id = ek[k] >> SP_CODE_BITS, code = ek[k] & ((1u << SP_CODE_BITS) - 1);
+        const bool uniq = k == 0 || ((uint64_t)(ek[k - 1] >> SP_CODE_BITS)) != id;
         scan[k] = (uniq ? 1u : 0u) | (code < (uint64_t)(2 * B) ? (1u << 16) : 0u);
     }
     __syncthreads();
     const uint32_t tot = block_exclusive_scan(scan, NE, wsum);
     const int UE = (int)(tot & 0xFFFF);
     for (int k = t; k < NE; k += SP_THREADS) {
-        const uint64_t id = keys[k] >> SP_CODE_BITS;
-        const int code = (int)(keys[k] & ((1u << SP_CODE_BITS) - 1));
-        const bool uniq = k == 0 || (keys[k - 1] >> SP_CODE_BITS) != id;
+        const uint64_t id = ek[k] >> SP_CODE_BITS;
+        const int code = (int)(ek[k] & ((1u << SP_CODE_BITS) - 1));
+        const bool uniq = k == 0 || ((uint64_t)(ek[k - 1] >> SP_CODE_BITS)) != id;
         const uint32_t ex = scan[k];
         const int u = (int)(ex & 0xFFFF), pp = (int)(ex >> 16), pn = k - pp;
         if (uniq) { ue_id[u] = (int64_t)id; ue_pos_ptr[u] = pp; ue_neg_ptr[u] = pn; }
@@ -320,6 +338,9 @@ __global__ __launch_bounds__(SP_THREADS) void sample_plan_kernel(SamplerArgs a) 
     if (t == 0) { ue_pos_ptr[UE] = 2 * B; ue_neg_ptr[UE] = CN; counts[0] = UE; }
     __syncthreads();
     __threadfence_block();
+#ifdef KGE_TL_MARKS
+    KGE_TL_MARK(2);              // lists written
+#endif
     for (int u = t; u < UE; u += SP_THREADS) {
         const int64_t id = ue_id[u];
         const int p0 = ue_pos_ptr[u], p1 = ue_pos_ptr[u + 1], n0 = ue_neg_ptr[u], n1 = ue_neg_ptr[u + 1];
@@ -333,7 +354,8 @@ __global__ __launch_bounds__(SP_THREADS) void sample_plan_kernel(SamplerArgs a) 
 
 int launch_sample_batches(const SamplerArgs &a, int n_slots, hipStream_t s) {
     if (n_slots <= 0) return KGE_OK;
-    hipLaunchKernelGGL(sample_plan_kernel, dim3(2 * n_slots), dim3(SP_THREADS), 0, s, a);
+    if (a.n_ent <= (1ll << (32 - SP_CODE_BITS))) hipLaunchKernelGGL(sample_plan_kernel<uint32_t>, dim3(2 * n_slots), dim3(SP_THREADS), 0, s, a);
+    else hipLaunchKernelGGL(sample_plan_kernel<uint64_t>, dim3(2 * n_slots), dim3(SP_THREADS), 0, s, a);
     return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
 }
 
