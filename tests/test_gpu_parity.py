@@ -509,6 +509,73 @@ def test_fused_step_random_shapes_match_oracle(seed):
         _close(eng.rel.cpu(), rel64, 1e-4, 5e-3 * k["lr"], tag + " relation rows")
 
 
+def _skewed_batch(rng, n_ent, n_rel, B, N, chunk, step, hub_frac, rel_frac):
+    """ids with hubs: entity 7 on `hub_frac` of the heads and tails and among the negatives, relation 1 on `rel_frac` of the
+    edges - contribution lists of hundreds of entries (real graphs are heavy-tailed; uniform ids never produce them)."""
+    C = B // chunk
+    h = rng.randint(0, n_ent, size=B).astype(np.int64)
+    t = rng.randint(0, n_ent, size=B).astype(np.int64)
+    r = rng.randint(0, n_rel, size=B).astype(np.int64)
+    neg = rng.randint(0, n_ent, size=C * N).astype(np.int64)
+    h[rng.rand(B) < hub_frac] = 7
+    t[rng.rand(B) < hub_frac] = 7
+    r[rng.rand(B) < rel_frac] = 1
+    neg[rng.rand(C * N) < hub_frac] = 7
+    nid, inv = np.unique(np.concatenate([h, t]), return_inverse=True)
+    return dict(h=h, t=t, r=r, neg=neg, neg_head=(step % 2 == 0), nid=nid.astype(np.int64),
+                h_local=inv[:B].astype(np.int64), t_local=inv[B:].astype(np.int64), C=C)
+
+
+HEAVY = [
+    # model, hidden, de, dr, B, chunk, N, hub_frac, rel_frac, flags
+    ("TransE_l2", 400, False, False, 1000, 200, 200, 0.02, 0.04, 0),     # FB15k's proportions: lists of 20 - 40 entries
+    ("TransE_l2", 400, False, False, 1000, 200, 200, 0.15, 0.50, 0),     # lists longer than 64 entries (the serial remainder loops)
+    ("TransE_l2", 100, False, False, 600, 100, 50, 0.15, 0.50, 0),       # one pack per lane
+    ("TransE_l2", 400, False, False, 1000, 200, 200, 0.15, 0.50, 2),     # per-edge gradients instead of the TransE fast path
+    ("TransE_l1", 400, False, False, 600, 100, 64, 0.15, 0.50, 0),       # TransE fast path with two source rows (P and GA)
+    ("DistMult", 400, False, False, 600, 100, 64, 0.15, 0.50, 0),
+    ("RotatE", 400, True, False, 512, 128, 64, 0.15, 0.50, 0),           # D_e = 800: four packs per lane
+    ("ComplEx", 100, True, True, 600, 100, 50, 0.15, 0.50, 0),
+]
+
+
+@pytest.mark.parametrize("case", HEAVY, ids=lambda c: "%s-D%d-B%d-hub%g-rel%g-f%d" % (c[0], c[1], c[4], c[7], c[8], c[9]))
+def test_fused_step_heavy_lists_match_oracle(case):
+    """hub entities / a dominant relation: the update kernel's contribution lists (requested several entries at a time, the first
+    64 from a register-resident index vector, the rest one by one) against the fp64 oracle - two steps, tail then head
+    corruption, with and without the regulariser."""
+    from dglke_amd import plan
+    from dglke_amd.engine import StepEngine
+    model, hidden, de, dr, B, chunk, N, hub, relf, flags = case
+    n_ent, n_rel = 3000, 11
+    for reg in (0.0, 1e-5):
+        cfg = O.Config(model, 12.0, hidden, 0.1, adv=True, adv_temp=1.0, reg_coef=reg, reg_norm=3, double_ent=de, double_rel=dr)
+        rng = np.random.RandomState(77)
+        ent = rng.uniform(-cfg.emb_init, cfg.emb_init, size=(n_ent, cfg.ent_dim)).astype(np.float32)
+        rel = rng.uniform(-cfg.emb_init, cfg.emb_init, size=(n_rel, cfg.rel_dim)).astype(np.float32)
+        eng = StepEngine(model, n_ent, n_rel, hidden, 12.0, 0.1, DEV, de, dr, True, 1.0, reg, 3, flags=flags)
+        eng.load_tables(ent, rel)
+        for step in (1, 2):
+            ent64 = eng.ent.cpu().numpy().astype(np.float64)
+            rel64 = eng.rel.cpu().numpy().astype(np.float64)
+            es64 = eng.ent_state.cpu().numpy().astype(np.float64)
+            rs64 = eng.rel_state.cpu().numpy().astype(np.float64)
+            bt = _skewed_batch(rng, n_ent, n_rel, B, N, chunk, step, hub, relf)
+            b = plan.make_batch(bt["h"], bt["t"], bt["r"], bt["neg"], chunk, N, bt["neg_head"], DEV)
+            want = eng.alloc_outputs(b)
+            eng.step(b, want)
+            torch.cuda.synchronize()
+            out = O.train_step(cfg, ent64, es64, rel64, rs64, bt["nid"], bt["h_local"], bt["t_local"],
+                               bt["r"], bt["neg"], bt["neg_head"], chunk, N)
+            tag = "%s reg %g step %d" % (case, reg, step)
+            _close(want["neg_score"].cpu(), out["neg_score"], 1e-4, 1e-4, tag + " neg_score")
+            _close(eng.read_loss()[:3], out["log"][:3], 1e-4, 1e-5, tag + " loss")
+            _close(eng.ent_state.cpu(), es64, 2e-3, 1e-9, tag + " ent state")
+            _close(eng.rel_state.cpu(), rs64, 2e-3, 1e-9, tag + " rel state")
+            _close(eng.ent.cpu(), ent64, 1e-4, 5e-3 * 0.1, tag + " entity rows")
+            _close(eng.rel.cpu(), rel64, 1e-4, 5e-3 * 0.1, tag + " relation rows")
+
+
 # ---------------------------------------------------------------------------------------------
 # BASELINE configs at their REAL table sizes (cfg-C: 2.5 M entities = 4 GB, beyond Infinity Cache; cfg-R: the
 # per-GPU step of the Freebase RotatE config, D_e = 800 / D_r = 400 over >= 1 M entities).  The oracle works on
