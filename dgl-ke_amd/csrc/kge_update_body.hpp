@@ -58,7 +58,9 @@ __device__ __forceinline__ void update_reg_body(const UpdateArgs &a_in, int nb_e
 #ifdef UPD_PROBE_NOENT
         return;
 #endif
-        const int64_t u = (int64_t)bx * KGE_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+        // (the wavefront number through readfirstlane: the compiler then knows that the record / count addresses are wave-uniform
+        //  and fetches them with scalar loads)
+        const int64_t u = (int64_t)bx * KGE_WAVES_PER_BLOCK + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
         if (u >= a.UE) return;                 // UE: the bound the grid and the record array were sized for
         const int d = a.model_d_e;
         // the device-side row count and this wavefront's plan record are requested TOGETHER (the record of a row beyond the
@@ -313,7 +315,7 @@ __device__ __forceinline__ void update_reg_body(const UpdateArgs &a_in, int nb_e
 #ifdef UPD_PROBE_NOREL
         return;
 #endif
-        const int64_t u = ((int64_t)bx - nb_ent) * KGE_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+        const int64_t u = ((int64_t)bx - nb_ent) * KGE_WAVES_PER_BLOCK + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
         if (u >= a.UR) return;
         const int d = a.d_r;
         int4 r0 = reinterpret_cast<const int4 *>(a.ur_rec)[2 * u];            // count and record together (see the entity part)
