@@ -279,15 +279,23 @@ __global__ __launch_bounds__(SP_THREADS) void sample_plan_kernel(SamplerArgs a) 
             ur_edge[k] = (int)(keys[k] & ((1u << SP_CODE_BITS) - 1));
             if (uniq) { ur_id[u] = (int64_t)id; ur_ptr[u] = k; }
         }
-        if (t == 0) { ur_ptr[UR] = B; counts[1] = UR; counts[2] = (int)(step & 1 ? 0 : 1); counts[3] = 0; }
+        __shared__ int maxlen_sh;
+        if (t == 0) { ur_ptr[UR] = B; counts[1] = UR; counts[2] = (int)(step & 1 ? 0 : 1); maxlen_sh = 0; }
         __syncthreads();
         __threadfence_block();
+        int mylen = 0;
         for (int u = t; u < UR; u += SP_THREADS) {
             const int64_t id = ur_id[u];
             int32_t *rec = ur_rec + 8 * u;
             rec[0] = (int32_t)(id & 0xFFFFFFFF); rec[1] = (int32_t)(id >> 32);
             rec[2] = ur_ptr[u]; rec[3] = ur_ptr[u + 1]; rec[4] = ur_edge[ur_ptr[u]]; rec[5] = 0; rec[6] = 0; rec[7] = 0;
+            mylen = max(mylen, rec[3] - rec[2]);
         }
+        // counts[3] = edges of the batch's most frequent relation: the update kernel shares lists of that length between the
+        // wavefronts of a workgroup - and skips the workgroup barrier that decision needs when no list of the batch is long
+        if (mylen > 8) atomicMax(&maxlen_sh, mylen);
+        __syncthreads();
+        if (t == 0) counts[3] = maxlen_sh;
         return;
     }
     K *ek = reinterpret_cast<K *>(keys);        // the entity plan's keys

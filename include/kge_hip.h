@@ -199,7 +199,8 @@ typedef struct kge_batch {
                                 /*          neg_end, ue_pos_adj[pos_begin]|-1, ue_neg_slot[neg_begin]|-1} */
     const int32_t *ur_rec;      /* [UR][8] {id_lo, id_hi, edge_begin, edge_end, ur_edge[edge_begin], 0,0,0} */
     /* batches built ON THE DEVICE (kge_sample_batches): UE / UR above are upper bounds and the  */
-    /* kernels read the actual counts {UE, UR} from this device array; NULL for host-built plans */
+    /* kernels read the actual counts from this device array of FOUR int32 {UE, UR, corrupt-head */
+    /* flag of the step, edges of the batch's most frequent relation}; NULL for host-built plans */
     const int32_t *counts_dev;
 } kge_batch;
 

@@ -1,0 +1,31 @@
+import sys, os, numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "dgl-ke_amd")]
+from oracle import kge_oracle as O
+from dglke_amd import p2p, plan
+from dglke_amd.engine import StepEngine
+DEV = "cuda:0"
+model, de_, dr_, hidden, n_shards, flags = "TransE_l2", False, False, 64, 3, 32
+n_ent, n_rel, B, N = 1000, 23, 96, 32
+out = {}
+for rep in range(3):
+    torch.manual_seed(0)
+    ref = StepEngine(model, n_ent, n_rel, hidden, 10.0, 0.1, DEV, de_, dr_, True, 1.0, 1e-5, 3, flags=flags)
+    torch.manual_seed(0)
+    tabs = p2p.ShardedTables(n_ent, n_rel, hidden, hidden, DEV, emulate=n_shards)
+    tabs.load_full(ref.ent, ref.rel)
+    eng = StepEngine(model, n_ent, n_rel, hidden, 10.0, 0.1, DEV, de_, dr_, True, 1.0, 1e-5, 3, flags=flags, shards=tabs)
+    rng = np.random.RandomState(7)
+    for step in range(1, 6):
+        bt = O.synth_batch(rng, n_ent, n_rel, B, N, N, step)
+        b = plan.make_batch(bt["h"], bt["t"], bt["r"], bt["neg"], N, N, bt["neg_head"], DEV)
+        ref.step(b); eng.step(b)
+        torch.cuda.synchronize()
+        for which, want in (("ent", ref.ent), ("ent_state", ref.ent_state), ("rel", ref.rel), ("rel_state", ref.rel_state)):
+            d = (tabs.full(which) - want).abs()
+            if d.max() > 0:
+                print("rep", rep, "step", step, which, "max diff", float(d.max()), "rows differing", int((d.reshape(d.shape[0], -1).max(1)[0] > 0).sum()) if d.dim() > 1 else int((d > 0).sum()))
+    out[rep] = (ref.ent.cpu().numpy().copy(), ref.rel.cpu().numpy().copy(), tabs.full("ent").cpu().numpy().copy(), tabs.full("rel").cpu().numpy().copy())
+for k in range(4):
+    print("run-to-run equal", ["ref.ent", "ref.rel", "shard.ent", "shard.rel"][k], all(np.array_equal(out[0][k], out[r][k]) for r in (1, 2)))
+np.savez(sys.argv[1], *out[0])
