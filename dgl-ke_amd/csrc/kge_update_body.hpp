@@ -19,6 +19,272 @@ __device__ __forceinline__ void acc_add(float *p, float v, bool unique) {
     atomicAdd(p, v);
 }
 
+// one relation row per wavefront (second half of update_reg_body).  COOP: the instance for batches with a long relation list.
+template <int NIT, bool SHARDED, int LEAN, bool COOP>
+__device__ __forceinline__ void update_rel_row(const UpdateArgs &a, int bx, int nb_ent, int lane, bool reg, bool qm) {
+    using namespace kge;
+    constexpr int LB2 = NIT <= 2 ? 2 : 1;
+    constexpr int LBR = NIT <= 2 ? 6 : 2;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t u = ((int64_t)bx - nb_ent) * KGE_WAVES_PER_BLOCK + wv;
+    // COOP (long lists shared by the workgroup, see below): no early exit - the four wavefronts meet at barriers, a wavefront
+    // without a row takes part with an empty record.  Otherwise wavefronts without a row leave at once.
+    if (!COOP && u >= a.UR) return;
+    const int d = a.d_r;
+    const int64_t uc = u < a.UR ? u : (int64_t)a.UR - 1;                   // a.UR >= 1: this workgroup exists
+    int4 r0 = reinterpret_cast<const int4 *>(a.ur_rec)[2 * uc];           // count and record together (see the entity part)
+    const int4 r1 = reinterpret_cast<const int4 *>(a.ur_rec)[2 * uc + 1];
+    const int cnt_r = a.counts_dev ? a.counts_dev[1] : a.UR;
+    const bool valid = u < a.UR && u < cnt_r;
+    if (!COOP && !valid) return;
+    const int64_t id = valid ? ((int64_t)(uint32_t)r0.x | ((int64_t)r0.y << 32)) : 0;
+    const int e0 = valid ? r0.z : 0, e1 = valid ? r0.w : 1, edge0 = valid ? r1.x : 0;
+    float *row = shard_row(a.rm, a.rel, id, d);
+    float *srow = shard_state(a.rm, a.rel_state, id);
+    const int nex = e1 - e0 - 1;
+    const int nit = d >> 2;
+    const float sgr = a.neg_head ? -1.f : 1.f;       // TransE fast path: GR = -P +/- GA + regulariser
+    const int64_t eo0 = (int64_t)edge0 * d;
+    const float *pA = a.transe_fast ? (qm ? a.Q : a.P) + eo0 : a.GR + eo0;
+    const float *pB = (a.transe_fast && !qm) ? a.GA + eo0 : pA;
+    const float *pX = a.Rs ? a.Rs + eo0 : row;        // row the regulariser is evaluated on (see the entity part)
+    // ---- long lists are shared by the four wavefronts of the workgroup (single-source modes): every entry is a dependent
+    // index -> row round and one wavefront keeps LBR of them in flight - FB15k's most frequent relation has 30 - 40 edges
+    // per batch and its wavefront alone set the end of the update kernel (profiles/r02_heavy_lists.txt).  Wavefront w takes
+    // the entries w, w + 4, ... of every long list, partial sums meet in LDS and are added by the owner in wavefront order
+    // (deterministic; the order differs from the serial one only for such rows). ----
+    constexpr int COOP_MIN = 2 * LBR + 1;            // a list is "long" from here
+    constexpr bool coop_mode = COOP;
+    constexpr int CO_W = COOP ? KGE_WAVES_PER_BLOCK : 1, CO_F = COOP ? NIT * 256 + 64 : 1;
+    __shared__ int co_nex[CO_W], co_e0[CO_W];
+    __shared__ const float *co_px[CO_W];
+    __shared__ float co_part[CO_W][CO_F];                  // per helper: the partial row + one ss partial per lane
+    if constexpr (COOP) { if (lane == 0) { co_nex[wv] = valid ? nex : -1; co_e0[wv] = e0; co_px[wv] = pX; } }
+    // the workgroup decides HERE, right behind the record (nothing else is in flight yet, the four records arrive together):
+    // a barrier after the own rows made every wavefront wait for the slowest row of its workgroup (relation wavefronts p50
+    // 2.6 -> 4.7 us on uniform ids)
+    bool any_long = false;
+    if constexpr (COOP) {                            // (this instance runs when the batch has a long list: kernel-uniform)
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < KGE_WAVES_PER_BLOCK; ++j) any_long = any_long || co_nex[j] >= COOP_MIN;
+    }
+    const bool own_long = valid && coop_mode && nex >= COOP_MIN;
+    const float st0 = *srow;
+    const int nown = own_long ? 0 : nex;             // entries this wavefront adds on its own
+    const int edgev = lane < nown ? a.ur_edge[e0 + 1 + lane] : 0;     // rest of the edge list, one entry per lane
+    Pack<4> x[NIT], gsum[NIT], xr[NIT];
+    float rv = 0.f, ss = 0.f;
+    int itc[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) itc[k] = min(lane + 64 * k, nit - 1) * 4;
+    Pack<4> fva[NIT], fvb[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {                         // every pack requested before the first use
+        x[k] = ld<4>(row + itc[k]);
+        fva[k] = ld<4>(pA + itc[k]); fvb[k] = ld<4>(pB + itc[k]);
+        xr[k] = ld<4>(pX + itc[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        if (lane + 64 * k < nit) {
+            const Pack<4> va = fva[k], vb = fvb[k];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (reg) rv += reg_val(xr[k].v[e], a.reg_norm);
+                float g;
+                if (a.transe_fast) {
+                    g = qm ? sgr * va.v[e] : sgr * vb.v[e] - va.v[e];
+                    if (reg) g += reg_grad(xr[k].v[e], a.reg_coef, a.reg_norm);
+                } else g = va.v[e];
+                ss += g * g;
+                gsum[k].v[e] = g;
+            }
+        } else { x[k] = zero_pack<4>(); gsum[k] = zero_pack<4>(); xr[k] = zero_pack<4>(); }
+    }
+    // ---- rest of the edge list, LB entries in flight (see the entity part) ----
+    const int nex64 = nown < 64 ? nown : 64;
+    if (a.transe_fast && !qm) {
+#pragma unroll 1
+        for (int i0 = 0; i0 < nex64; i0 += LB2) {
+            Pack<4> vp[LB2][NIT], vg[LB2][NIT];
+#pragma unroll
+            for (int j = 0; j < LB2; ++j) {
+                const int64_t eo = (int64_t)__builtin_amdgcn_readlane(edgev, min(i0 + j, nex64 - 1)) * d;
+#pragma unroll
+                for (int k = 0; k < NIT; ++k) { vp[j][k] = ld<4>(a.P + eo + itc[k]); vg[j][k] = ld<4>(a.GA + eo + itc[k]); }
+            }
+#pragma unroll
+            for (int j = 0; j < LB2; ++j) {
+                if (i0 + j < nex64) {
+#pragma unroll
+                    for (int k = 0; k < NIT; ++k) {
+                        if (lane + 64 * k < nit) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                float g = sgr * vg[j][k].v[e] - vp[j][k].v[e];
+                                if (reg) g += reg_grad(xr[k].v[e], a.reg_coef, a.reg_norm);
+                                ss += g * g; gsum[k].v[e] += g;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    } else {
+        const float *gbase = a.transe_fast ? a.Q : a.GR;
+#pragma unroll 1
+        for (int i0 = 0; i0 < nex64; i0 += LBR) {
+            Pack<4> vv[LBR][NIT];
+#pragma unroll
+            for (int j = 0; j < LBR; ++j) {
+                const int64_t eo = (int64_t)__builtin_amdgcn_readlane(edgev, min(i0 + j, nex64 - 1)) * d;
+#pragma unroll
+                for (int k = 0; k < NIT; ++k) vv[j][k] = ld<4>(gbase + eo + itc[k]);
+            }
+#pragma unroll
+            for (int j = 0; j < LBR; ++j) {
+                if (i0 + j < nex64) {
+#pragma unroll
+                    for (int k = 0; k < NIT; ++k) {
+                        if (lane + 64 * k < nit) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                float g = vv[j][k].v[e];
+                                if (a.transe_fast) {
+                                    g = sgr * g;
+                                    if (reg) g += reg_grad(xr[k].v[e], a.reg_coef, a.reg_norm);
+                                }
+                                ss += g * g; gsum[k].v[e] += g;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll 1
+    for (int i = 64; i < nown; ++i) {                      // lists longer than 65 entries: one entry at a time
+        const int64_t eo = (int64_t)a.ur_edge[e0 + 1 + i] * d;
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            if (lane + 64 * k < nit) {
+                if (a.transe_fast) {
+                    const Pack<4> pv = ld<4>((qm ? a.Q : a.P) + eo + itc[k]), gv = ld<4>((qm ? a.Q : a.GA) + eo + itc[k]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float g = qm ? sgr * pv.v[e] : sgr * gv.v[e] - pv.v[e];
+                        if (reg) g += reg_grad(xr[k].v[e], a.reg_coef, a.reg_norm);
+                        ss += g * g; gsum[k].v[e] += g;
+                    }
+                } else {
+                    const Pack<4> g = ld<4>(a.GR + eo + itc[k]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { ss += g.v[e] * g.v[e]; gsum[k].v[e] += g.v[e]; }
+                }
+            }
+        }
+    }
+    // ---- the shared part ----
+    if (COOP && any_long) {                          // workgroup-uniform
+#pragma unroll 1
+        for (int j = 0; j < KGE_WAVES_PER_BLOCK; ++j) {
+            const int nj = co_nex[j];
+            if (nj < COOP_MIN) continue;
+            const int ej = co_e0[j];
+            const float *pxj = co_px[j];
+            const float *gbase = a.transe_fast ? a.Q : a.GR;
+            const int mine = (nj - wv + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK;      // entries wv, wv + 4, ... < nj
+            Pack<4> gp[NIT], xj[NIT];
+            float pss = 0.f;
+#pragma unroll
+            for (int k = 0; k < NIT; ++k) { gp[k] = zero_pack<4>(); xj[k] = (reg && a.transe_fast) ? ld<4>(pxj + itc[k]) : zero_pack<4>(); }
+#pragma unroll 1
+            for (int base = 0; base < mine; base += 64) {
+                const int cntb = min(mine - base, 64);
+                const int ev = lane < cntb ? a.ur_edge[ej + 1 + wv + KGE_WAVES_PER_BLOCK * (base + lane)] : 0;
+#pragma unroll 1
+                for (int i0 = 0; i0 < cntb; i0 += LBR) {
+                    Pack<4> vv[LBR][NIT];
+#pragma unroll
+                    for (int jj = 0; jj < LBR; ++jj) {
+                        const int64_t eo = (int64_t)__builtin_amdgcn_readlane(ev, min(i0 + jj, cntb - 1)) * d;
+#pragma unroll
+                        for (int k = 0; k < NIT; ++k) vv[jj][k] = ld<4>(gbase + eo + itc[k]);
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < LBR; ++jj) {
+                        if (i0 + jj < cntb) {
+#pragma unroll
+                            for (int k = 0; k < NIT; ++k) {
+                                if (lane + 64 * k < nit) {
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        float g = vv[jj][k].v[e];
+                                        if (a.transe_fast) {
+                                            g = sgr * g;
+                                            if (reg) g += reg_grad(xj[k].v[e], a.reg_coef, a.reg_norm);
+                                        }
+                                        pss += g * g; gp[k].v[e] += g;
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NIT; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) co_part[wv][(lane + 64 * k) * 4 + e] = gp[k].v[e];
+            co_part[wv][NIT * 256 + lane] = pss;
+            __syncthreads();
+            if (wv == j) {                           // the owner adds the partials, wavefront 0 first
+#pragma unroll 1
+                for (int w2 = 0; w2 < KGE_WAVES_PER_BLOCK; ++w2) {
+#pragma unroll
+                    for (int k = 0; k < NIT; ++k)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) gsum[k].v[e] += co_part[w2][(lane + 64 * k) * 4 + e];
+                    ss += co_part[w2][NIT * 256 + lane];
+                }
+            }
+            __syncthreads();                         // before the next long row overwrites the partials
+        }
+    }
+    if (!valid) return;
+    ss = wave_sum(ss) / (float)d;
+    if (a.dry) return;
+    const float sN = st0 + ss;
+    const float kr = -a.lr / (sqrtf(sN) + a.eps);
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        const int it = lane + 64 * k;
+        if (it < nit) {
+            if (!a.emit_rel) {
+                Pack<4> y = x[k];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y.v[e] = fmaf(gsum[k].v[e], kr, y.v[e]);
+                KGE_ST_ROW<4>(row + it * 4, y);
+            }
+            if (a.gr) st<4>(a.gr + u * (int64_t)a.ld_r + it * 4, gsum[k]);
+        }
+    }
+    if (lane == 0) {
+        if (!a.emit_rel) *srow = sN;
+        if (a.gsr) a.gsr[u * (int64_t)a.ld_gs_r] = ss;
+        if (a.rid) { a.rid[u * (int64_t)a.ld_r] = (int32_t)(id & 0xFFFFFFFF); a.rid[u * (int64_t)a.ld_r + 1] = (int32_t)(id >> 32); }
+    }
+    if (reg && (a.reg_rel || a.acc)) {
+        rv = wave_sum(rv);
+        const float val = a.reg_coef * rv * (float)(e1 - e0);
+        if (lane == 0) {
+            if (a.reg_rel) a.reg_rel[u] = val;
+            if (a.acc) acc_add(&a.acc[3 * KGE_ACC_SLOTS + (int)((u + a.UE) & (KGE_ACC_SLOTS - 1))], val, a.UE + a.UR <= KGE_ACC_SLOTS);
+        }
+    } else if (a.reg_rel && lane == 0) a.reg_rel[u] = 0.f;
+}
+
 // single-pass variant: the row and its gradients stay in registers (row width <= 256*NIT floats),
 // so every table row is read once and written once - the algorithmic minimum.  Memory-level
 // parallelism: one 32-byte plan record per row gives the row id, the list bounds AND the first
@@ -315,262 +581,14 @@ __device__ __forceinline__ void update_reg_body(const UpdateArgs &a_in, int nb_e
 #ifdef UPD_PROBE_NOREL
         return;
 #endif
-        const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-        const int64_t u = ((int64_t)bx - nb_ent) * KGE_WAVES_PER_BLOCK + wv;
-        // (no early exit in this branch: the four wavefronts of a relation workgroup meet at barriers when one of them owns a long
-        //  list - a wavefront without a row takes part with an empty record)
-        const int d = a.d_r;
-        const int64_t uc = u < a.UR ? u : (int64_t)a.UR - 1;                   // a.UR >= 1: this workgroup exists
-        int4 r0 = reinterpret_cast<const int4 *>(a.ur_rec)[2 * uc];           // count and record together (see the entity part)
-        const int4 r1 = reinterpret_cast<const int4 *>(a.ur_rec)[2 * uc + 1];
-        const int cnt_r = a.counts_dev ? a.counts_dev[1] : a.UR;
-        const bool valid = u < a.UR && u < cnt_r;
-        const int64_t id = valid ? ((int64_t)(uint32_t)r0.x | ((int64_t)r0.y << 32)) : 0;
-        const int e0 = valid ? r0.z : 0, e1 = valid ? r0.w : 1, edge0 = valid ? r1.x : 0;
-        float *row = shard_row(a.rm, a.rel, id, d);
-        float *srow = shard_state(a.rm, a.rel_state, id);
-        const int nex = e1 - e0 - 1;
-        const int nit = d >> 2;
-        const float sgr = a.neg_head ? -1.f : 1.f;       // TransE fast path: GR = -P +/- GA + regulariser
-        const int64_t eo0 = (int64_t)edge0 * d;
-        const float *pA = a.transe_fast ? (qm ? a.Q : a.P) + eo0 : a.GR + eo0;
-        const float *pB = (a.transe_fast && !qm) ? a.GA + eo0 : pA;
-        const float *pX = a.Rs ? a.Rs + eo0 : row;        // row the regulariser is evaluated on (see the entity part)
-        // ---- long lists are shared by the four wavefronts of the workgroup (single-source modes): every entry is a dependent
-        // index -> row round and one wavefront keeps LBR of them in flight - FB15k's most frequent relation has 30 - 40 edges
-        // per batch and its wavefront alone set the end of the update kernel (profiles/r02_heavy_lists.txt).  Wavefront w takes
-        // the entries w, w + 4, ... of every long list, partial sums meet in LDS and are added by the owner in wavefront order
-        // (deterministic; the order differs from the serial one only for such rows). ----
-        constexpr int COOP_MIN = 2 * LBR + 1;            // a list is "long" from here
-        // (device-built plans carry the length of the batch's longest relation list in counts[3]: no long list, no barrier)
-        const bool coop_mode = !(a.transe_fast && !qm) && (!a.counts_dev || a.counts_dev[3] - 1 >= COOP_MIN);
-        __shared__ int co_nex[KGE_WAVES_PER_BLOCK], co_e0[KGE_WAVES_PER_BLOCK];
-        __shared__ const float *co_px[KGE_WAVES_PER_BLOCK];
-        __shared__ float co_part[KGE_WAVES_PER_BLOCK][NIT * 256 + 64];      // per helper: the partial row + one ss partial per lane
-        if (coop_mode && lane == 0) { co_nex[wv] = valid ? nex : -1; co_e0[wv] = e0; co_px[wv] = pX; }
-        // the workgroup decides HERE, right behind the record (nothing else is in flight yet, the four records arrive together):
-        // a barrier after the own rows made every wavefront wait for the slowest row of its workgroup (relation wavefronts p50
-        // 2.6 -> 4.7 us on uniform ids)
-        bool any_long = false;
-        if (coop_mode) {                                 // kernel-uniform
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < KGE_WAVES_PER_BLOCK; ++j) any_long = any_long || co_nex[j] >= COOP_MIN;
-        }
-        const bool own_long = valid && coop_mode && nex >= COOP_MIN;
-        const float st0 = *srow;
-        const int nown = own_long ? 0 : nex;             // entries this wavefront adds on its own
-        const int edgev = lane < nown ? a.ur_edge[e0 + 1 + lane] : 0;     // rest of the edge list, one entry per lane
-        Pack<4> x[NIT], gsum[NIT], xr[NIT];
-        float rv = 0.f, ss = 0.f;
-        int itc[NIT];
-#pragma unroll
-        for (int k = 0; k < NIT; ++k) itc[k] = min(lane + 64 * k, nit - 1) * 4;
-        Pack<4> fva[NIT], fvb[NIT];
-#pragma unroll
-        for (int k = 0; k < NIT; ++k) {                         // every pack requested before the first use
-            x[k] = ld<4>(row + itc[k]);
-            fva[k] = ld<4>(pA + itc[k]); fvb[k] = ld<4>(pB + itc[k]);
-            xr[k] = ld<4>(pX + itc[k]);
-        }
-#pragma unroll
-        for (int k = 0; k < NIT; ++k) {
-            if (lane + 64 * k < nit) {
-                const Pack<4> va = fva[k], vb = fvb[k];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (reg) rv += reg_val(xr[k].v[e], a.reg_norm);
-                    float g;
-                    if (a.transe_fast) {
-                        g = qm ? sgr * va.v[e] : sgr * vb.v[e] - va.v[e];
-                        if (reg) g += reg_grad(xr[k].v[e], a.reg_coef, a.reg_norm);
-                    } else g = va.v[e];
-                    ss += g * g;
-                    gsum[k].v[e] = g;
-                }
-            } else { x[k] = zero_pack<4>(); gsum[k] = zero_pack<4>(); xr[k] = zero_pack<4>(); }
-        }
-        // ---- rest of the edge list, LB entries in flight (see the entity part) ----
-        const int nex64 = nown < 64 ? nown : 64;
-        if (a.transe_fast && !qm) {
-#pragma unroll 1
-            for (int i0 = 0; i0 < nex64; i0 += LB2) {
-                Pack<4> vp[LB2][NIT], vg[LB2][NIT];
-#pragma unroll
-                for (int j = 0; j < LB2; ++j) {
-                    const int64_t eo = (int64_t)__builtin_amdgcn_readlane(edgev, min(i0 + j, nex64 - 1)) * d;
-#pragma unroll
-                    for (int k = 0; k < NIT; ++k) { vp[j][k] = ld<4>(a.P + eo + itc[k]); vg[j][k] = ld<4>(a.GA + eo + itc[k]); }
-                }
-#pragma unroll
-                for (int j = 0; j < LB2; ++j) {
-                    if (i0 + j < nex64) {
-#pragma unroll
-                        for (int k = 0; k < NIT; ++k) {
-                            if (lane + 64 * k < nit) {
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) {
-                                    float g = sgr * vg[j][k].v[e] - vp[j][k].v[e];
-                                    if (reg) g += reg_grad(xr[k].v[e], a.reg_coef, a.reg_norm);
-                                    ss += g * g; gsum[k].v[e] += g;
-                                }
-                            }
-                        }
-                    }
-                }
-            }
-        } else {
-            const float *gbase = a.transe_fast ? a.Q : a.GR;
-#pragma unroll 1
-            for (int i0 = 0; i0 < nex64; i0 += LBR) {
-                Pack<4> vv[LBR][NIT];
-#pragma unroll
-                for (int j = 0; j < LBR; ++j) {
-                    const int64_t eo = (int64_t)__builtin_amdgcn_readlane(edgev, min(i0 + j, nex64 - 1)) * d;
-#pragma unroll
-                    for (int k = 0; k < NIT; ++k) vv[j][k] = ld<4>(gbase + eo + itc[k]);
-                }
-#pragma unroll
-                for (int j = 0; j < LBR; ++j) {
-                    if (i0 + j < nex64) {
-#pragma unroll
-                        for (int k = 0; k < NIT; ++k) {
-                            if (lane + 64 * k < nit) {
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) {
-                                    float g = vv[j][k].v[e];
-                                    if (a.transe_fast) {
-                                        g = sgr * g;
-                                        if (reg) g += reg_grad(xr[k].v[e], a.reg_coef, a.reg_norm);
-                                    }
-                                    ss += g * g; gsum[k].v[e] += g;
-                                }
-                            }
-                        }
-                    }
-                }
-            }
-        }
-#pragma unroll 1
-        for (int i = 64; i < nown; ++i) {                      // lists longer than 65 entries: one entry at a time
-            const int64_t eo = (int64_t)a.ur_edge[e0 + 1 + i] * d;
-#pragma unroll
-            for (int k = 0; k < NIT; ++k) {
-                if (lane + 64 * k < nit) {
-                    if (a.transe_fast) {
-                        const Pack<4> pv = ld<4>((qm ? a.Q : a.P) + eo + itc[k]), gv = ld<4>((qm ? a.Q : a.GA) + eo + itc[k]);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float g = qm ? sgr * pv.v[e] : sgr * gv.v[e] - pv.v[e];
-                            if (reg) g += reg_grad(xr[k].v[e], a.reg_coef, a.reg_norm);
-                            ss += g * g; gsum[k].v[e] += g;
-                        }
-                    } else {
-                        const Pack<4> g = ld<4>(a.GR + eo + itc[k]);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { ss += g.v[e] * g.v[e]; gsum[k].v[e] += g.v[e]; }
-                    }
-                }
-            }
-        }
-        // ---- the shared part ----
-        if (any_long) {                                  // workgroup-uniform
-#pragma unroll 1
-            for (int j = 0; j < KGE_WAVES_PER_BLOCK; ++j) {
-                const int nj = co_nex[j];
-                if (nj < COOP_MIN) continue;
-                const int ej = co_e0[j];
-                const float *pxj = co_px[j];
-                const float *gbase = a.transe_fast ? a.Q : a.GR;
-                const int mine = (nj - wv + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK;      // entries wv, wv + 4, ... < nj
-                Pack<4> gp[NIT], xj[NIT];
-                float pss = 0.f;
-#pragma unroll
-                for (int k = 0; k < NIT; ++k) { gp[k] = zero_pack<4>(); xj[k] = (reg && a.transe_fast) ? ld<4>(pxj + itc[k]) : zero_pack<4>(); }
-#pragma unroll 1
-                for (int base = 0; base < mine; base += 64) {
-                    const int cntb = min(mine - base, 64);
-                    const int ev = lane < cntb ? a.ur_edge[ej + 1 + wv + KGE_WAVES_PER_BLOCK * (base + lane)] : 0;
-#pragma unroll 1
-                    for (int i0 = 0; i0 < cntb; i0 += LBR) {
-                        Pack<4> vv[LBR][NIT];
-#pragma unroll
-                        for (int jj = 0; jj < LBR; ++jj) {
-                            const int64_t eo = (int64_t)__builtin_amdgcn_readlane(ev, min(i0 + jj, cntb - 1)) * d;
-#pragma unroll
-                            for (int k = 0; k < NIT; ++k) vv[jj][k] = ld<4>(gbase + eo + itc[k]);
-                        }
-#pragma unroll
-                        for (int jj = 0; jj < LBR; ++jj) {
-                            if (i0 + jj < cntb) {
-#pragma unroll
-                                for (int k = 0; k < NIT; ++k) {
-                                    if (lane + 64 * k < nit) {
-#pragma unroll
-                                        for (int e = 0; e < 4; ++e) {
-                                            float g = vv[jj][k].v[e];
-                                            if (a.transe_fast) {
-                                                g = sgr * g;
-                                                if (reg) g += reg_grad(xj[k].v[e], a.reg_coef, a.reg_norm);
-                                            }
-                                            pss += g * g; gp[k].v[e] += g;
-                                        }
-                                    }
-                                }
-                            }
-                        }
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < NIT; ++k)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) co_part[wv][(lane + 64 * k) * 4 + e] = gp[k].v[e];
-                co_part[wv][NIT * 256 + lane] = pss;
-                __syncthreads();
-                if (wv == j) {                           // the owner adds the partials, wavefront 0 first
-#pragma unroll 1
-                    for (int w2 = 0; w2 < KGE_WAVES_PER_BLOCK; ++w2) {
-#pragma unroll
-                        for (int k = 0; k < NIT; ++k)
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) gsum[k].v[e] += co_part[w2][(lane + 64 * k) * 4 + e];
-                        ss += co_part[w2][NIT * 256 + lane];
-                    }
-                }
-                __syncthreads();                         // before the next long row overwrites the partials
-            }
-        }
-        if (!valid) return;
-        ss = wave_sum(ss) / (float)d;
-        if (a.dry) return;
-        const float sN = st0 + ss;
-        const float kr = -a.lr / (sqrtf(sN) + a.eps);
-#pragma unroll
-        for (int k = 0; k < NIT; ++k) {
-            const int it = lane + 64 * k;
-            if (it < nit) {
-                if (!a.emit_rel) {
-                    Pack<4> y = x[k];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) y.v[e] = fmaf(gsum[k].v[e], kr, y.v[e]);
-                    KGE_ST_ROW<4>(row + it * 4, y);
-                }
-                if (a.gr) st<4>(a.gr + u * (int64_t)a.ld_r + it * 4, gsum[k]);
-            }
-        }
-        if (lane == 0) {
-            if (!a.emit_rel) *srow = sN;
-            if (a.gsr) a.gsr[u * (int64_t)a.ld_gs_r] = ss;
-            if (a.rid) { a.rid[u * (int64_t)a.ld_r] = (int32_t)(id & 0xFFFFFFFF); a.rid[u * (int64_t)a.ld_r + 1] = (int32_t)(id >> 32); }
-        }
-        if (reg && (a.reg_rel || a.acc)) {
-            rv = wave_sum(rv);
-            const float val = a.reg_coef * rv * (float)(e1 - e0);
-            if (lane == 0) {
-                if (a.reg_rel) a.reg_rel[u] = val;
-                if (a.acc) acc_add(&a.acc[3 * KGE_ACC_SLOTS + (int)((u + a.UE) & (KGE_ACC_SLOTS - 1))], val, a.UE + a.UR <= KGE_ACC_SLOTS);
-            }
-        } else if (a.reg_rel && lane == 0) a.reg_rel[u] = 0.f;
+        // two instances of the relation part: long relation lists are shared by the four wavefronts of a workgroup (barriers, LDS);
+        // device-built plans carry the length of the batch's longest relation list in counts[3], and a batch without a long one
+        // (kernel-uniform) runs the plain instance - the shared-list code costs 0.25 us per step on uniform ids just by being
+        // there (registers, code layout; profiles/r02_heavy_lists.txt)
+        constexpr int COOP_MIN_R = 2 * (NIT <= 2 ? 6 : 2) + 1;
+        const bool coop = !(a.transe_fast && !qm) && (!a.counts_dev || a.counts_dev[3] - 1 >= COOP_MIN_R);
+        if (coop) update_rel_row<NIT, SHARDED, LEAN, true>(a, bx, nb_ent, lane, reg, qm);
+        else update_rel_row<NIT, SHARDED, LEAN, false>(a, bx, nb_ent, lane, reg, qm);
     }
 }
 
