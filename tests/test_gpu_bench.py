@@ -1,0 +1,50 @@
+"""bench.py contract (the driver runs `python bench.py --gpus 1 --steps K --warmup W` and reads ONE JSON line)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_skewed_triples_have_fb15k_like_hubs():
+    """bench.synth_triples(skew=True): heavy-tailed ids - the most frequent relation ~3.6 % of the edges, the hub entity ~1 % of
+    the heads and of the tails (what uniform ids never produce: rows with 20 - 40 contributions per 1000-edge batch)."""
+    import bench
+    w = bench.WORKLOADS["transe_l2_fb15k"]
+    h, r, t = bench.synth_triples(w, 0, skew=True)
+    n = len(h)
+    top_r = np.bincount(r, minlength=w["n_rel"]).max() / n
+    top_h = np.bincount(h, minlength=w["n_ent"]).max() / n
+    top_t = np.bincount(t, minlength=w["n_ent"]).max() / n
+    assert 0.025 < top_r < 0.05 and 0.006 < top_h < 0.015 and 0.006 < top_t < 0.015, (top_r, top_h, top_t)
+    h2, r2, t2 = bench.synth_triples(w, 0, skew=True)
+    assert np.array_equal(h, h2) and np.array_equal(r, r2) and np.array_equal(t, t2)
+    hu, ru, tu = bench.synth_triples(w, 0)
+    assert np.bincount(ru, minlength=w["n_rel"]).max() / n < 0.002
+
+
+@pytest.mark.gpu
+def test_bench_line_has_the_contract_fields():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
+                          "--no-cpu-baseline", "--hogwild", "0", "--no-async-update"],
+                         stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode == 0
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line"
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["steps"] == 20 and d["warmup"] == 5 and d["n_gpus"] == 1 and d["unit"] == "edges/s" and d["dtype"] == "f32"
+    assert d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    assert 5e6 < d["value"] < 1e9 and abs(d["value"] - 1000 * 1e3 / d["ms_per_step"]) / d["value"] < 0.02
