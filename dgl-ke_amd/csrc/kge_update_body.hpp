@@ -20,6 +20,8 @@ __device__ __forceinline__ void acc_add(float *p, float v, bool unique) {
 }
 
 // one relation row per wavefront (second half of update_reg_body).  COOP: the instance for batches with a long relation list.
+// (Sums of squares are written as explicit fmaf: left to the compiler, the two instances contracted `ss += g * g` differently and
+//  a row without any shared list came out 1 ulp apart - device-built batches pick the instance per batch, host plans always COOP.)
 template <int NIT, bool SHARDED, int LEAN, bool COOP>
 __device__ __forceinline__ void update_rel_row(const UpdateArgs &a, int bx, int nb_ent, int lane, bool reg, bool qm) {
     using namespace kge;
@@ -97,7 +99,7 @@ __device__ __forceinline__ void update_rel_row(const UpdateArgs &a, int bx, int 
                     g = qm ? sgr * va.v[e] : sgr * vb.v[e] - va.v[e];
                     if (reg) g += reg_grad(xr[k].v[e], a.reg_coef, a.reg_norm);
                 } else g = va.v[e];
-                ss += g * g;
+                ss = fmaf(g, g, ss);
                 gsum[k].v[e] = g;
             }
         } else { x[k] = zero_pack<4>(); gsum[k] = zero_pack<4>(); xr[k] = zero_pack<4>(); }
@@ -124,7 +126,7 @@ __device__ __forceinline__ void update_rel_row(const UpdateArgs &a, int bx, int 
                             for (int e = 0; e < 4; ++e) {
                                 float g = sgr * vg[j][k].v[e] - vp[j][k].v[e];
                                 if (reg) g += reg_grad(xr[k].v[e], a.reg_coef, a.reg_norm);
-                                ss += g * g; gsum[k].v[e] += g;
+                                ss = fmaf(g, g, ss); gsum[k].v[e] += g;
                             }
                         }
                     }
@@ -155,7 +157,7 @@ __device__ __forceinline__ void update_rel_row(const UpdateArgs &a, int bx, int 
                                     g = sgr * g;
                                     if (reg) g += reg_grad(xr[k].v[e], a.reg_coef, a.reg_norm);
                                 }
-                                ss += g * g; gsum[k].v[e] += g;
+                                ss = fmaf(g, g, ss); gsum[k].v[e] += g;
                             }
                         }
                     }
@@ -175,12 +177,12 @@ __device__ __forceinline__ void update_rel_row(const UpdateArgs &a, int bx, int 
                     for (int e = 0; e < 4; ++e) {
                         float g = qm ? sgr * pv.v[e] : sgr * gv.v[e] - pv.v[e];
                         if (reg) g += reg_grad(xr[k].v[e], a.reg_coef, a.reg_norm);
-                        ss += g * g; gsum[k].v[e] += g;
+                        ss = fmaf(g, g, ss); gsum[k].v[e] += g;
                     }
                 } else {
                     const Pack<4> g = ld<4>(a.GR + eo + itc[k]);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { ss += g.v[e] * g.v[e]; gsum[k].v[e] += g.v[e]; }
+                    for (int e = 0; e < 4; ++e) { ss = fmaf(g.v[e], g.v[e], ss); gsum[k].v[e] += g.v[e]; }
                 }
             }
         }
@@ -225,7 +227,7 @@ __device__ __forceinline__ void update_rel_row(const UpdateArgs &a, int bx, int 
                                             g = sgr * g;
                                             if (reg) g += reg_grad(xj[k].v[e], a.reg_coef, a.reg_norm);
                                         }
-                                        pss += g * g; gp[k].v[e] += g;
+                                        pss = fmaf(g, g, pss); gp[k].v[e] += g;
                                     }
                                 }
                             }
@@ -396,7 +398,7 @@ __device__ __forceinline__ void update_reg_body(const UpdateArgs &a_in, int nb_e
                     float gn = has_neg ? vc.v[e] : 0.f;
                     if (ndreg && has_neg) gn += reg_grad(xn[k].v[e], a.reg_coef, a.reg_norm);
                     g1[k].v[e] = gn;
-                    s1 += gn * gn;
+                    s1 = fmaf(gn, gn, s1);
                 }
             } else { x[k] = zero_pack<4>(); g0[k] = zero_pack<4>(); g1[k] = zero_pack<4>(); xn[k] = zero_pack<4>(); }
         }
@@ -495,7 +497,7 @@ __device__ __forceinline__ void update_reg_body(const UpdateArgs &a_in, int nb_e
                         }
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            if (lane + 64 * k < nit) s1 += g.v[e] * g.v[e];
+                            if (lane + 64 * k < nit) s1 = fmaf(g.v[e], g.v[e], s1);
                             g1[k].v[e] += g.v[e];
                         }
                     }
@@ -514,7 +516,7 @@ __device__ __forceinline__ void update_reg_body(const UpdateArgs &a_in, int nb_e
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    if (lane + 64 * k < nit) s1 += g.v[e] * g.v[e];
+                    if (lane + 64 * k < nit) s1 = fmaf(g.v[e], g.v[e], s1);
                     g1[k].v[e] += g.v[e];
                 }
             }
@@ -524,7 +526,7 @@ __device__ __forceinline__ void update_reg_body(const UpdateArgs &a_in, int nb_e
             for (int k = 0; k < NIT; ++k) {
                 if (lane + 64 * k < nit) {        // (lanes beyond the row hold clamped duplicates from the list loops)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) s0 += g0[k].v[e] * g0[k].v[e];
+                    for (int e = 0; e < 4; ++e) s0 = fmaf(g0[k].v[e], g0[k].v[e], s0);
                 }
             }
         } else {

@@ -76,9 +76,12 @@ def test_epochs_are_whole_batches_in_a_new_order():
     assert len({where0.get(int(x), -1) for x in epochs[1][:B]}) > 3
 
 
-def test_step_from_device_batch_equals_step_from_host_plan():
+@pytest.mark.parametrize("rel_hub", [0.0, 0.4], ids=["uniform", "dominant_relation"])
+def test_step_from_device_batch_equals_step_from_host_plan(rel_hub):
     """the fused step fed by a device-built batch gives bit-identical tables to the step fed by the
-    host plan of the same ids."""
+    host plan of the same ids.  (Device-built batches carry the length of their longest relation list and run the plain
+    relation instance of the update kernel when no list is long; host plans always run the list-sharing instance: both
+    must give the same bits - with a dominant relation both share the list.)"""
     from dglke_amd import plan
     from dglke_amd.dataloader import DeviceSampler
     from dglke_amd.engine import StepEngine
@@ -86,6 +89,7 @@ def test_step_from_device_batch_equals_step_from_host_plan():
     n_ent, n_rel, B, N, D = 3000, 40, 256, 64, 64
     n_train = 4000
     h, r, t = rng.randint(0, n_ent, n_train), rng.randint(0, n_rel, n_train), rng.randint(0, n_ent, n_train)
+    r[rng.rand(n_train) < rel_hub] = 3
     s = DeviceSampler(h, r, t, n_ent, B, N, DEV, n_slots=4, seed=9)
     dbs = s.sample()
     torch.cuda.synchronize()
