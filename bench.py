@@ -129,8 +129,11 @@ def step_kernels(model, force_pairwise=False):
         return ("one training step = edge_fwd, neg_fwd_bcast, loss, neg_bwd_lc + gn_reduce, (edge_bwd,) update; "
                 "dominant: neg_bwd_lc_kernel (VALU, packed fp32)")
     if model == "TransE_l2":
-        return ("one training step = 5 dependent kernels (edge_fwd, neg_fwd_gemm, loss, neg_bwd_gemm, update); "
-                "dominant: neg_bwd_gemm_kernel")
+        return ("one training step = 4 dependent launches ([forward GEMM tiles || edge-forward rows], loss, neg_bwd_gemm, "
+                "update); dominant: neg_bwd_gemm_kernel")
+    if model == "DistMult":
+        return ("one training step = 5 dependent launches ([forward GEMM tiles || edge-forward rows], loss, neg_bwd_gemm, "
+                "edge_bwd, update); dominant: neg_bwd_gemm_kernel")
     return ("one training step = 6 dependent kernels (edge_fwd, neg_fwd_gemm, loss, neg_bwd_gemm, edge_bwd, update); "
             "dominant: neg_bwd_gemm_kernel")
 
@@ -375,10 +378,13 @@ def main():
     if dev_sampler:
         G = max(2, G - G % 2)            # even group: slot parity = head / tail corruption (sampler.py:853-859)
     if dev_sampler:
-        # ---- sampling + plan ON THE DEVICE, inside the timed region: one sampler launch per G steps ----
-        from dglke_amd.dataloader import DeviceSampler
-        smp = DeviceSampler(h, r, t, w["n_ent"], w["B"], w["N"], dev, n_slots=G, seed=0)
-        dbs = smp.sample()
+        # ---- sampling + plan ON THE DEVICE, inside the timed region: one sampler launch per group of <= G steps, running on a
+        # forked branch of the group's hipGraph NEXT TO the steps of the previous group (double-buffered slots,
+        # dataloader.PrefetchedGroups): every timed group trains on batches built during the group before it and builds the
+        # batches of the group after it - the timed region contains exactly K steps and the sampling of K batches ----
+        from dglke_amd.dataloader import DeviceSampler, PrefetchedGroups
+        smp = DeviceSampler(h, r, t, w["n_ent"], w["B"], w["N"], dev, n_slots=2 * G, seed=0)
+        dbs = smp.sample(G)
         for b in dbs[:1]:
             eng.workspace_for(b)
         torch.cuda.synchronize()
@@ -390,44 +396,33 @@ def main():
         for b in dbs:                    # eager warm-up of every kernel before capture
             eng.step(b)
         torch.cuda.synchronize()
+
+        def sizes(count):
+            return [G] * (count // G) + ([count % G] if count % G else [])
+        seq_w, seq_t = sizes(args.warmup), sizes(args.steps)
+        seq = seq_w + seq_t
+        pg = PrefetchedGroups(smp, eng.step, group_max=G)
+
+        def run_groups(lo, hi):          # groups seq[lo:hi]; group i builds the batches of group i + 1 (the last one: of a
+            for i in range(lo, hi):      # group like the first timed one, so that K batches are sampled per K timed steps)
+                pg.run(seq[i + 1] if i + 1 < len(seq) else seq_t[0], graph=use_graph)
+
+        def start():
+            pg.buf, pg.ready = 0, None
+            pg.prefill(seq[0])
+        if use_graph:                    # dry run of the whole schedule: captures one graph per distinct
+            start()                      # (group size, next size, buffer half); then start again from fresh parameters
+            run_groups(0, len(seq))
+            torch.cuda.synchronize()
         eng.reset_parameters()
-
-        def group():
-            for b in smp.sample():
-                eng.step(b)
-        if use_graph:
-            gr = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gr):
-                group()
-            torch.cuda.synchronize()
-
-        rem_graphs = {}
-
-        def partial(n):                  # one sampler launch + the first n < G steps of the group
-            for b in smp.sample(n):       # n slots only: a 20-step run is not charged a 120-slot sampler launch
-                eng.step(b)
-        if use_graph:
-            for n in {args.warmup % G, args.steps % G} - {0}:
-                rem_graphs[n] = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(rem_graphs[n]):
-                    partial(n)
-            torch.cuda.synchronize()
-
-        def run_steps(count):            # EXACTLY count steps: full groups, then one partial group
-            for _ in range(count // G):
-                if use_graph:
-                    gr.replay()
-                else:
-                    group()
-            if count % G:
-                if use_graph:
-                    rem_graphs[count % G].replay()
-                else:
-                    partial(count % G)
-        run_w = lambda: run_steps(args.warmup)
-        run_t = lambda: run_steps(args.steps)
-        launch_desc = ("hipGraph of [1 sampler launch + %d steps]" % G) if use_graph else "eager"
-        data_desc = "triples in HBM; batch ids, negatives and plan built ON THE DEVICE inside the timed region"
+        start()
+        torch.cuda.synchronize()
+        run_w = lambda: run_groups(0, len(seq_w))
+        run_t = lambda: run_groups(len(seq_w), len(seq))
+        launch_desc = (("hipGraph of [%d steps || sampler launch for the next group on a forked branch]" % G)
+                       if use_graph else "eager, sampler prefetch on a side stream")
+        data_desc = ("triples in HBM; batch ids, negatives and plan built ON THE DEVICE inside the timed region "
+                     "(double-buffered: group g+1 is sampled while group g trains)")
     else:
         # ---- host-built batches + plans pre-staged in HBM (sampler outside the timed region) ----
         sampler = UniformChunkedSampler(h, r, t, w["n_ent"], w["B"], w["N"], dev, seed=0)

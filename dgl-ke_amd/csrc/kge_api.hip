@@ -565,9 +565,16 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     // rows as the scoring / gradient kernels of THIS step see them: the tables, or PREP's dense copies (async)
     const EdgeSrc src_bwd = need_cp ? EdgeSrc{Hc, nullptr, Tc, nullptr, Rc, nullptr, kge::ShardMap{}, kge::ShardMap{}} : src;
 
+    // round 3: edge-forward and the forward GEMM of the strict step share ONE launch (kge_neg_gemm.hip, neg_fwd_edge_kernel): the
+    // tiles build their pos-side fragments from the table rows themselves and emit raw products, the loss kernel applies the
+    // TransE_l2 distance transform.  4 launches per TransE_l2 step instead of 5.  Not for the async pipeline (its forward shares
+    // a launch with the previous update already), dense-negative modes (sharded / neg_deg_sample) and the fused-loss variant.
+    const bool merged_fwd = gemm && !dense_neg && !fused_loss && !pipelined && !pairwise &&
+                            (phases & (PH_PREP | PH_FWD)) == (PH_PREP | PH_FWD) && !build_prep && !co_update &&
+                            !(hp->flags & KGE_FLAG_SPLIT_FWD) && neg_fwd_gemm_with_edge_supported(hp->model, d_e, d_r);
+    EdgeFwdArgs ef{};
     if (phases & PH_PREP) {
     // 1. gather + positive score + pos-side vectors (+ positive-loss part, + P rows for TransE)
-    EdgeFwdArgs ef{};
     ef.src = src; ef.B = B; ef.d_e = d_e; ef.d_r = d_r; ef.neg_head = b->neg_head; ef.model = hp->model;
     ef.gamma = hp->gamma; ef.rot_div = rot_div;
     ef.pos_score = P; ef.A = A;
@@ -607,7 +614,7 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         }
     } else {
         if (build_prep) { *build_prep = ef; return KGE_OK; }
-        KGE_TRY(launch_edge_fwd(ef, s));
+        if (!merged_fwd) KGE_TRY(launch_edge_fwd(ef, s));     // merged: launched together with the forward tiles below
     }
     }   // PH_PREP
 
@@ -630,7 +637,11 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
                 else if (rc != KGE_ERR_ARG) return fail(rc, "launch_neg_fwd_gemm_with_update failed (%d)", rc);
                 else KGE_TRY(launch_update(*co_update, s));      // no fused instantiation: one after the other
             }
-            if (!fused_launch) KGE_TRY(launch_neg_fwd_gemm(g, s));
+            if (merged_fwd) {
+                g.xbase = tb->ent; g.xidx = b->neg_head ? b->t_gid : b->h_gid; g.rbase = tb->rel; g.ridx = b->rel_ids;
+                g.asign = b->neg_head ? -1.f : 1.f;
+                KGE_TRY(launch_neg_fwd_gemm_with_edge(g, ef, s));
+            } else if (!fused_launch) KGE_TRY(launch_neg_fwd_gemm(g, s));
         }
     } else {
         fill_pair(na, hp->model, C, chunk, N, d_e, hp->gamma, A, Bn, nullptr);
@@ -650,6 +661,7 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         la.row_pos = want4 ? row_pos : nullptr; la.row_neg = want4 ? row_neg : nullptr;
         la.acc = acc;
         la.l2_scale = is_l2 ? 1 : 0; la.gamma = hp->gamma; la.clampv = clamp_of(hp->model);
+        if (merged_fwd && is_l2) { la.l2_raw = 1; la.l2_chunk = chunk; la.asq = asq; la.bsq = bsq; }
         la.neg_copy = out ? out->neg_score : nullptr;
         la.skip_pos = (pairwise || rescal || transr) ? 0 : 1;  // RESCAL / TransR: no edge_fwd -> positive part here
         la.diag_chunk = nd ? chunk : 0;

@@ -320,6 +320,9 @@ struct LossArgs {
     float *row_pos, *row_neg;        // [B] per-row loss terms (already divided by B), or null
     float *acc;                      // [4][KGE_ACC_SLOTS] running loss sums (slot = row & mask) or null
     int l2_scale; float gamma;       // if set: dneg /= (gamma - n)   (TransE_l2 GEMM backward)
+    // l2_raw: `neg` holds the raw products a_i . b_j of the merged forward launch; the score is rebuilt here as
+    // gamma - sqrt(max(asq[i] + bsq[(i / l2_chunk) * N + j] - 2 neg[i][j], 1e-30))   (score_fun.py:26-34)
+    int l2_raw, l2_chunk; const float *asq, *bsq;
     float clampv;                    // > 0: scores were clamped to [-clampv, clampv] (SimplE): no gradient where saturated
     float *neg_copy;                 // optional copy of the scores before overwrite
     int skip_pos;                    // the positive-loss part was already done by edge_fwd
@@ -402,6 +405,12 @@ struct GemmArgs {                   // LDS-staged fp32-MFMA negative scoring (kg
     const float *A;                  // [C*chunk, D] pos-side vectors (dense)
     const float *nbase; const int64_t *nidx;   // negative rows: nbase + (nidx ? nidx[j] : j)*D
     const float *asq, *bsq;          // [C*chunk], [C*N] squared norms (TransE_l2)
+    // forward, merged launch (launch_neg_fwd_gemm_with_edge): the pos-side fragments are built ON THE FLY from the table rows
+    // the edge-forward half of the same launch is reading - a_i = x_i + asign * r_i (TransE) or x_i * r_i (DistMult), x = head
+    // (tail-corrupted step) or tail rows through xidx, r through ridx; A / asq / bsq above are NOT read by the forward tiles
+    // then (the other half of the launch is still writing them) and S receives the RAW products a_i . b_j (TransE_l2: the loss
+    // kernel applies gamma - sqrt(|a|^2 + |b|^2 - 2 S), LossArgs::l2_raw)
+    const float *xbase; const int64_t *xidx; const float *rbase; const int64_t *ridx; float asign;
     // forward
     float *S;                        // out [C,chunk,N]
     float clampv;                    // > 0: clamp the scores to [-clampv, clampv] (SimplE)
@@ -431,6 +440,10 @@ int launch_neg_bwd_gemm(const GemmArgs &a, hipStream_t s);
 struct UpdateArgs;
 // horizontally fused launches of the --async_update pipeline (KGE_ERR_ARG: no fused instantiation for the combination)
 int launch_neg_fwd_gemm_with_update(const GemmArgs &a, const UpdateArgs &u, hipStream_t s);
+// the strict step's first launch: forward GEMM tiles with on-the-fly pos-side fragments + the edge-forward rows of the SAME step
+// (KGE_ERR_ARG: no fused instantiation for the combination)
+bool neg_fwd_gemm_with_edge_supported(int model, int d_e, int d_r);
+int launch_neg_fwd_gemm_with_edge(const GemmArgs &a, const EdgeFwdArgs &e, hipStream_t s);
 int launch_neg_bwd_gemm_with_prep(const GemmArgs &a, const EdgeFwdArgs &e, hipStream_t s);
 int launch_neg_fwd_pair(const NegArgs &a, hipStream_t s);
 int launch_neg_bwd_pair(const NegArgs &a, hipStream_t s);

@@ -74,7 +74,10 @@ __device__ __forceinline__ float sq4(const float4 &v) { return v.x * v.x + v.y *
 
 // `bid` / `nblk`: this workgroup's index and the number of workgroups doing forward-GEMM work (the body is also one half of
 // the horizontally fused "forward GEMM of step s + update of step s-1" launch of the --async_update pipeline)
-template <bool L2, bool FUSE>     // FUSE: emit the factorised loss gradient + per-tile partials instead of the scores
+// AM: where the pos-side fragments come from - 0: the dense A buffer; 1 / 2 (merged launch, launch_neg_fwd_gemm_with_edge): built on
+// the fly from the gathered table rows, a = x + asign * r (TransE) / a = x * r (DistMult) - then L2 means "emit the raw products"
+// (|a|^2, |b|^2 are being written by the other half of the launch; the loss kernel applies the distance transform)
+template <bool L2, bool FUSE, int AM = 0>     // FUSE: emit the factorised loss gradient + per-tile partials instead of the scores
 __device__ __forceinline__ void neg_fwd_gemm_body(const GemmArgs &a, int ti, int tj, int bid, int nblk) {
     const int lane = threadIdx.x & 63;
     const int64_t tile = (int64_t)xcd_remap(bid, nblk) * KGE_WAVES_PER_BLOCK + (threadIdx.x >> 6);
@@ -88,15 +91,20 @@ __device__ __forceinline__ void neg_fwd_gemm_body(const GemmArgs &a, int ti, int
     // operand rows of this lane (clamped so that loads stay in bounds; masked at the store)
     const int ia = min(it * 16 + m, a.chunk - 1);
     const int jb = min(jt * 16 + m, a.N - 1);
-    const float *Ap = a.A + ((int64_t)c * a.chunk + ia) * D + q * 4;
+    // (AM: the three id loads - x row, r row, negative row - are one round; the rows follow in the loop)
+    const float *Ap = AM ? row_ptr(a.xbase, a.xidx, (int64_t)c * a.chunk + ia, D) + q * 4
+                         : a.A + ((int64_t)c * a.chunk + ia) * D + q * 4;
+    const float *Rp = AM ? row_ptr(a.rbase, a.ridx, (int64_t)c * a.chunk + ia, D) + q * 4 : Ap;
     const float *Bp = row_ptr(a.nbase, a.nidx, (int64_t)c * a.N + jb, D) + q * 4;
     const int kq = q * 4;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     float4 a0[FU], b0[FU], a1[FU], b1[FU];
+    float4 r0[AM ? FU : 1], r1[AM ? FU : 1];
+    const float asg = a.asign;
     // epilogue operands are requested NOW (they do not depend on the loop): one dependent ~1.5 us round less
     // at the end of every wavefront
     float bsq_pre = 0.f, asq_pre[4] = {0.f, 0.f, 0.f, 0.f};
-    if (L2) {
+    if (L2 && !AM) {
         bsq_pre = a.bsq[(int64_t)c * a.N + jb];
 #pragma unroll
         for (int r = 0; r < 4; ++r) asq_pre[r] = a.asq[(int64_t)c * a.chunk + min(it * 16 + q * 4 + r, a.chunk - 1)];
@@ -114,36 +122,43 @@ __device__ __forceinline__ void neg_fwd_gemm_body(const GemmArgs &a, int ti, int
 #endif
     // (the k-step index goes through an empty volatile asm: these loads have no other tie to program order - read-only
     //  kernel-argument pointers - and were otherwise hoisted above the MFMAs that still read the buffer they refill)
-#define FWD_LOAD(AV, BV, KS0)                                                    \
+#define FWD_LOAD(AV, RV, BV, KS0)                                                \
     { int k0_ = (KS0); asm volatile("" : "+s"(k0_));                             \
       _Pragma("unroll") for (int u = 0; u < FU; ++u) {                           \
         const int ks_ = min(k0_ + u, kfull - 1);                                 \
         AV[u] = ldg4(Ap + ks_ * 16); BV[u] = ldg4(Bp + ks_ * 16);                \
+        if (AM) RV[u] = ldg4(Rp + ks_ * 16);                                     \
     } }
-#define FWD_MMA1(AV, BV, u)                                                      \
-    { acc0 = MFMA16(AV[u].x, BV[u].x, acc0);                                     \
+    // pos-side fragment from the gathered rows: four VALU operations per k-step, issued under the previous MFMAs
+#define FWD_AFRAG(AV, RV, u)                                                     \
+    { if (AM == 1) { AV[u].x = fmaf(asg, RV[u].x, AV[u].x); AV[u].y = fmaf(asg, RV[u].y, AV[u].y);    \
+                     AV[u].z = fmaf(asg, RV[u].z, AV[u].z); AV[u].w = fmaf(asg, RV[u].w, AV[u].w); }  \
+      else if (AM == 2) { AV[u].x *= RV[u].x; AV[u].y *= RV[u].y; AV[u].z *= RV[u].z; AV[u].w *= RV[u].w; } }
+#define FWD_MMA1(AV, RV, BV, u)                                                  \
+    { FWD_AFRAG(AV, RV, u)                                                       \
+      acc0 = MFMA16(AV[u].x, BV[u].x, acc0);                                     \
       acc1 = MFMA16(AV[u].y, BV[u].y, acc1);                                     \
       acc0 = MFMA16(AV[u].z, BV[u].z, acc0);                                     \
       acc1 = MFMA16(AV[u].w, BV[u].w, acc1); }
-#define FWD_MMA(AV, BV) _Pragma("unroll") for (int u = 0; u < FU; ++u) FWD_MMA1(AV, BV, u)
-#define FWD_MMA_G(AV, BV, KS0) _Pragma("unroll") for (int u = 0; u < FU; ++u) { if ((KS0) + u < kfull) FWD_MMA1(AV, BV, u) }
+#define FWD_MMA(AV, RV, BV) _Pragma("unroll") for (int u = 0; u < FU; ++u) FWD_MMA1(AV, RV, BV, u)
+#define FWD_MMA_G(AV, RV, BV, KS0) _Pragma("unroll") for (int u = 0; u < FU; ++u) { if ((KS0) + u < kfull) FWD_MMA1(AV, RV, BV, u) }
     if (kfull > 0) {
-        FWD_LOAD(a0, b0, 0);
+        FWD_LOAD(a0, r0, b0, 0);
         int g = 0;
         for (; g + 2 * FU <= kfull; g += 2 * FU) {
-            FWD_LOAD(a1, b1, g + FU);
+            FWD_LOAD(a1, r1, b1, g + FU);
             KGE_ORDER();                                // the requests go out BEFORE the MFMAs on the other buffer, as written
-            FWD_MMA(a0, b0);
+            FWD_MMA(a0, r0, b0);
             KGE_PIN_ACC(acc0, acc1);                    // ... and a buffer is refilled only AFTER its MFMAs were issued
-            FWD_LOAD(a0, b0, g + 2 * FU);
+            FWD_LOAD(a0, r0, b0, g + 2 * FU);
             KGE_ORDER();
-            FWD_MMA(a1, b1);
+            FWD_MMA(a1, r1, b1);
             KGE_PIN_ACC(acc0, acc1);
         }
         if (g < kfull) {                     // fewer than 2 * FU k-steps left; a0 / b0 hold the first FU of them
-            FWD_LOAD(a1, b1, g + FU);
-            FWD_MMA_G(a0, b0, g);
-            FWD_MMA_G(a1, b1, g + FU);
+            FWD_LOAD(a1, r1, b1, g + FU);
+            FWD_MMA_G(a0, r0, b0, g);
+            FWD_MMA_G(a1, r1, b1, g + FU);
         }
     }
 #undef FWD_LOAD
@@ -152,12 +167,21 @@ __device__ __forceinline__ void neg_fwd_gemm_body(const GemmArgs &a, int ti, int
 #undef FWD_MMA_G
     if (D & 15) {   // tail k-step: lanes whose 4 floats lie beyond D contribute zeros
         float4 av = zero4(), bv = zero4();
-        if (kfull * 16 + kq < D) { av = ldg4(Ap + kfull * 16); bv = ldg4(Bp + kfull * 16); }
+        if (kfull * 16 + kq < D) {
+            av = ldg4(Ap + kfull * 16); bv = ldg4(Bp + kfull * 16);
+            if (AM) {
+                float4 rv[1]; rv[0] = ldg4(Rp + kfull * 16);
+                float4 av1[1]; av1[0] = av;
+                FWD_AFRAG(av1, rv, 0)
+                av = av1[0];
+            }
+        }
         acc0 = MFMA16(av.x, bv.x, acc0);
         acc1 = MFMA16(av.y, bv.y, acc1);
         acc0 = MFMA16(av.z, bv.z, acc0);
         acc1 = MFMA16(av.w, bv.w, acc1);
     }
+#undef FWD_AFRAG
 
     // NOTE: the MFMA stream above is kept free of VALU work on purpose - accumulating |a|^2,|b|^2
     // from the loaded fragments inside the loop cost +3.5 us (45 %) on MI355X; they come precomputed.
@@ -173,8 +197,8 @@ __device__ __forceinline__ void neg_fwd_gemm_body(const GemmArgs &a, int ti, int
     for (int r = 0; r < 4; ++r) {
         const int i = it * 16 + q * 4 + r;
         float x = acc0[r] + acc1[r];
-        if (L2) x = a.gamma - sqrtf(fmaxf(asq_pre[r] + bsq - 2.f * x, 1e-30f));
-        else if (a.clampv > 0.f) x = fminf(fmaxf(x, -a.clampv), a.clampv);            // SimplE: th.clamp(tmp, -20, 20)
+        if (L2 && !AM) x = a.gamma - sqrtf(fmaxf(fmaf(-2.f, x, asq_pre[r] + bsq), 1e-30f));   // (explicit fma: same bits as the loss kernel's RAW transform)
+        else if (!L2 && a.clampv > 0.f) x = fminf(fmaxf(x, -a.clampv), a.clampv);    // SimplE: th.clamp(tmp, -20, 20)
         v[r] = x;
         ok[r] = jok && i < a.chunk;
         so[r] = ((int64_t)c * a.chunk + i) * a.N + j;
@@ -247,6 +271,49 @@ __global__ __launch_bounds__(KGE_BLOCK) void neg_fwd_update_kernel(GemmArgs a, i
         KGE_TL(4);
         update_reg_body<NIT, false, LEAN>(u, nb_ent, (int)blockIdx.x - nbG, (int)gridDim.x - nbG);
     }
+}
+
+// the strict step's FIRST launch (round 3): forward GEMM tiles (first nbG workgroups) + the edge-forward rows of the SAME step
+// (the rest).  The tiles do not wait for the pos-side vectors a_i: they rebuild their fragments from the table rows the edge
+// half is reading (one packed add / multiply per fragment), emit raw products, and the row-wise results of the edge half
+// (positive scores, |a|^2, |b|^2, dL/dp, P rows, the dense A the backward reads) are consumed one launch later, by the loss
+// kernel (distance transform) and the backward GEMM.  One launch boundary and the whole edge-forward kernel (4.2 + 1.7 us at
+// cfg-T, profiles/r02_v7_timeline.txt) leave the step's critical path.
+template <bool L2, int AM, int MODEL, bool LEAN>
+__global__ __launch_bounds__(KGE_BLOCK) void neg_fwd_edge_kernel(GemmArgs a, int ti, int tj, int nbG, EdgeFwdArgs e) {
+    if ((int)blockIdx.x < nbG) {
+        KGE_TL(1);
+        neg_fwd_gemm_body<L2, false, AM>(a, ti, tj, (int)blockIdx.x, nbG);
+    } else {
+        KGE_TL(0);
+        edge_fwd_body<MODEL, 4, LEAN>(e, (int)blockIdx.x - nbG);
+    }
+}
+
+bool neg_fwd_gemm_with_edge_supported(int model, int d_e, int d_r) {
+    return (model == KGE_TRANSE_L2 || model == KGE_DISTMULT) && d_e % 4 == 0 && d_r == d_e;
+}
+
+int launch_neg_fwd_gemm_with_edge(const GemmArgs &a, const EdgeFwdArgs &e, hipStream_t s) {
+    if (a.C == 0 || a.PM || !a.xbase || !a.rbase || !a.xidx || !a.ridx) return KGE_ERR_ARG;
+    if (!neg_fwd_gemm_with_edge_supported(a.model, a.D, e.d_r) || e.model != a.model || e.d_e != a.D) return KGE_ERR_ARG;
+    if (e.src.em.n || e.src.rm.n || e.nd_own) return KGE_ERR_ARG;
+    const bool negjob = e.bsq || e.Bn;
+    const int64_t waves = (int64_t)e.B + (negjob ? e.n_neg : 0);
+    EdgeFwdArgs ee = e;
+    if (!negjob) ee.n_neg = 0;
+    const int nbP = (int)((waves + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK);
+    const int ti = (a.chunk + 15) / 16, tj = (a.N + 15) / 16;
+    const int64_t ntiles = (int64_t)a.C * ti * tj;
+    const int nbG = (int)((ntiles + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK);
+    const bool lean = e.lp.genre == KGE_LOSS_LOGSIGMOID && !e.row_pos && !e.Hc;
+    const dim3 g(nbG + nbP), b(KGE_BLOCK);
+#define KGE_FE(L2_, AM_, M_) do { if (lean) hipLaunchKernelGGL((neg_fwd_edge_kernel<L2_, AM_, M_, true>), g, b, 0, s, a, ti, tj, nbG, ee); \
+                                  else hipLaunchKernelGGL((neg_fwd_edge_kernel<L2_, AM_, M_, false>), g, b, 0, s, a, ti, tj, nbG, ee); } while (0)
+    if (a.model == KGE_TRANSE_L2) KGE_FE(true, 1, KGE_TRANSE_L2);
+    else KGE_FE(false, 2, KGE_DISTMULT);
+#undef KGE_FE
+    return check_launch_g();
 }
 
 int launch_neg_fwd_gemm(const GemmArgs &a, hipStream_t s) {

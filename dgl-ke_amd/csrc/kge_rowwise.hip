@@ -362,6 +362,13 @@ __global__ __launch_bounds__(KGE_BLOCK) void loss_kernel(LossArgs a) {
     const float invB = 1.f / (float)a.B;
     // neg_deg_sample: the positive edge itself sits in column i % chunk - score 0, no gradient (general_models.py:401, 429-432)
     const int jd = a.diag_chunk > 0 ? (int)(i % a.diag_chunk) : -1;
+    if (a.l2_raw) {     // merged forward launch: the row holds raw products - rebuild the scores in place first (score_fun.py:26-34)
+        const float as = a.asq[i];
+        const float *bq = a.bsq + (i / a.l2_chunk) * (int64_t)N;
+        float *nw = const_cast<float *>(n);
+        for (int j = lane; j < N; j += 64) nw[j] = a.gamma - sqrtf(fmaxf(fmaf(-2.f, n[j], as + bq[j]), 1e-30f));
+        // (a lane re-reads only what it wrote itself: columns j = lane mod 64)
+    }
     if (a.pairwise) {   // loss.py:76-80
         const float sc = w / ((float)a.B * (float)N);
         float lsum = 0.f, dsum = 0.f;
@@ -435,7 +442,9 @@ __global__ __launch_bounds__(KGE_BLOCK) void loss_kernel(LossArgs a) {
 // LEAN: the common configuration (Logsigmoid, point-wise, positive part done by edge_fwd, no score clamp) with
 // every other loss genre / option compiled out - the generic instantiation carries NPER copies of a three-way
 // criterion switch, the pairwise variant and the option handling (2.1 k instructions vs ~0.7 k)
-template <int NPER, bool LEAN>
+// RAW: the row holds the raw products a_i . b_j of the merged forward launch (LossArgs::l2_raw): the TransE_l2 score
+// gamma - sqrt(|a_i|^2 + |b_j|^2 - 2 a_i.b_j) is rebuilt here, from one more coalesced row of |b|^2 requested with the scores
+template <int NPER, bool LEAN, bool RAW>
 __global__ __launch_bounds__(KGE_BLOCK) void loss_kernel_reg(LossArgs a_in) {
     KGE_TL(2);
     LossArgs a = a_in;
@@ -455,8 +464,22 @@ __global__ __launch_bounds__(KGE_BLOCK) void loss_kernel_reg(LossArgs a_in) {
     const int jd = a.diag_chunk > 0 ? (int)(i % a.diag_chunk) : -1;
 #pragma unroll
     for (int u = 0; u < NPER; ++u) { const int j = lane + 64 * u; nv[u] = (j < N && j != jd) ? n[j] : 0.f; }
+    float bq[RAW ? NPER : 1], asq_i = 0.f;
+    if constexpr (RAW) {
+        const float *bqp = a.bsq + (i / a.l2_chunk) * (int64_t)N;
+#pragma unroll
+        for (int u = 0; u < NPER; ++u) { const int j = lane + 64 * u; bq[u] = j < N ? bqp[j] : 0.f; }
+        asq_i = a.asq[i];
+    }
     const float w = a.w ? a.w[i] : 1.f;
     const float p = a.pos[i];
+    if constexpr (RAW) {
+#pragma unroll
+        for (int u = 0; u < NPER; ++u) {
+            const int j = lane + 64 * u;
+            nv[u] = (j < N && j != jd) ? a.gamma - sqrtf(fmaxf(fmaf(-2.f, nv[u], asq_i + bq[u]), 1e-30f)) : 0.f;
+        }
+    }
 #ifdef KGE_TL_MARKS
     KGE_TL_MARK(0);              // score row, positive score, weight have arrived
 #endif
@@ -550,8 +573,11 @@ int launch_loss(const LossArgs &a, hipStream_t s) {
     const dim3 g(blocks_for_waves(a.B)), b(KGE_BLOCK);
     const bool lean = a.genre == KGE_LOSS_LOGSIGMOID && !a.pairwise && a.skip_pos && a.clampv == 0.f && !a.neg_copy &&
                       !a.row_pos && !a.row_neg && a.diag_chunk <= 0;
-#define KGE_LOSS(N) do { if (lean) hipLaunchKernelGGL((loss_kernel_reg<N, true>), g, b, 0, s, a); \
-                         else hipLaunchKernelGGL((loss_kernel_reg<N, false>), g, b, 0, s, a); } while (0)
+    if (a.l2_raw && (!a.asq || !a.bsq || a.l2_chunk <= 0)) return KGE_ERR_ARG;
+#define KGE_LOSS(N) do { if (a.l2_raw) { if (lean) hipLaunchKernelGGL((loss_kernel_reg<N, true, true>), g, b, 0, s, a); \
+                                         else hipLaunchKernelGGL((loss_kernel_reg<N, false, true>), g, b, 0, s, a); } \
+                         else if (lean) hipLaunchKernelGGL((loss_kernel_reg<N, true, false>), g, b, 0, s, a); \
+                         else hipLaunchKernelGGL((loss_kernel_reg<N, false, false>), g, b, 0, s, a); } while (0)
     if (a.N <= 64) KGE_LOSS(1);
     else if (a.N <= 128) KGE_LOSS(2);
     else if (a.N <= 256) KGE_LOSS(4);

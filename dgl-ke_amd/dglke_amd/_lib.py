@@ -22,6 +22,7 @@ FLAG_FUSED_LOSS = 8
 FLAG_TWO_PASS_PAIR = 16
 FLAG_NEG_DEG_SAMPLE = 32
 FLAG_ASYNC_REL = 64
+FLAG_SPLIT_FWD = 128        # strict step: edge-forward and forward GEMM as two launches (validation / A-B aid)
 PHASE_GATHER, PHASE_FORWARD, PHASE_BACKWARD, PHASE_UPDATE = 1, 2, 4, 8
 ACC_SLOTS = 4096
 

@@ -211,3 +211,63 @@ class DeviceSampler(object):
             out[name] = raw[o:o + nb].view(dt).copy()
             o = al(o + nb)
         return out
+
+
+class PrefetchedGroups(object):
+    """Groups of training steps whose batches were built while the PREVIOUS group trained: the sampler launch of group g+1
+    runs on a forked stream (a second branch of the captured hipGraph) next to the steps of group g, over the other half of
+    a double-buffered slot array, and joins at the end of the group - the ~45 us sampler launch leaves the critical path of
+    short runs (a 20-step run paid it serially: 2.4 us per step) while every group still samples exactly the batches of a
+    following group inside the same timed region.  Restates the prefetching of the reference's sampler threads
+    (dataloader/sampler.py:823-876: `NewBidirectionalOneShotIterator` over `num_workers` sampler workers).
+
+    sampler: a DeviceSampler with n_slots >= 2 * the largest group; step_fn(batch): enqueues one training step."""
+
+    def __init__(self, sampler, step_fn, group_max=None):
+        self.smp, self.step_fn = sampler, step_fn
+        self.half = sampler.n_slots // 2 if group_max is None else int(group_max)
+        if 2 * self.half > sampler.n_slots:
+            raise ValueError("the sampler needs 2 x group_max slots")
+        self.side = th.cuda.Stream(device=sampler.dev)
+        self.buf = 0                  # half holding the batches of the NEXT group to train
+        self.ready = None             # DeviceBatch objects in that half
+        self.graphs = {}
+
+    def prefill(self, n):
+        """build the first group's batches on the current stream (outside any graph)."""
+        self.ready = self.smp.sample(n, slot0=self.buf * self.half)
+
+    def _enqueue(self, n_next):
+        cur = th.cuda.current_stream(self.smp.dev)
+        batches, nxt = self.ready, None
+        if n_next:
+            self.side.wait_stream(cur)                                  # fork
+            with th.cuda.stream(self.side):
+                nxt = self.smp.sample(n_next, slot0=(self.buf ^ 1) * self.half)
+        for b in batches:
+            self.step_fn(b)
+        if n_next:
+            cur.wait_stream(self.side)                                  # join
+        return nxt
+
+    def run(self, n_next, graph=True):
+        """train the ready group and (concurrently) build the next one of n_next batches.  graph=True: replay a hipGraph of
+        exactly that, captured on first use per (group size, next size, buffer half)."""
+        n_cur = len(self.ready)
+        if n_next > self.half:
+            raise ValueError("group larger than half of the slots")
+        key = (n_cur, n_next, self.buf)
+        if not graph:
+            nxt = self._enqueue(n_next)
+        elif key in self.graphs:
+            g, nxt = self.graphs[key]
+            self.smp.host_step += n_next
+            g.replay()
+        else:
+            g = th.cuda.CUDAGraph()
+            with th.cuda.graph(g):
+                nxt = self._enqueue(n_next)
+            self.graphs[key] = (g, nxt)
+            g.replay()
+        self.ready = nxt
+        self.buf ^= 1

@@ -93,6 +93,11 @@ enum kge_status {
  * entity table only, general_models.py:639-647; with this flag no update at all sits between two steps' scoring) */
 #define KGE_FLAG_ASYNC_REL 64u
 
+/* strict step, TransE_l2 / DistMult on the matrix-core path: keep edge-forward and the forward GEMM as two launches
+ * (5 launches per TransE_l2 step) instead of the merged first launch of round 3 whose tiles build the pos-side
+ * fragments from the table rows themselves (4 launches).  Validation / A-B aid: same results within rounding. */
+#define KGE_FLAG_SPLIT_FWD 128u
+
 int         kge_abi_version(void);
 const char *kge_last_error(void);
 

@@ -129,7 +129,7 @@ def test_dropin_model_matches_reference(name):
     _close(m.relation_emb.emb.cpu(), z["final_relation"], 1e-4, 1e-2 * case["lr"], name + " final relation")
 
 
-@pytest.mark.parametrize("flags", [0, 1, 2, 8], ids=["auto", "force_pairwise", "no_transe_fast", "fused_loss"])
+@pytest.mark.parametrize("flags", [0, 1, 2, 8, 128], ids=["auto", "force_pairwise", "no_transe_fast", "fused_loss", "split_fwd"])
 @pytest.mark.parametrize("name", golden_names(transr=False))
 def test_fused_step_matches_reference(name, flags):
     """kge_step_fused (one call per step) vs the reference's recorded scores / gradients / tables;
@@ -184,7 +184,7 @@ SHAPES = [
 ]
 
 
-@pytest.mark.parametrize("flags", [0, 8], ids=["loss_kernel", "fused_loss"])
+@pytest.mark.parametrize("flags", [0, 8, 128], ids=["loss_kernel", "fused_loss", "split_fwd"])
 @pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "%s-B%d-N%d-D%d" % (s[0], s[6], s[7], s[3]))
 def test_fused_step_matches_oracle_at_config_shapes(shape, flags):
     from dglke_amd import plan
@@ -257,6 +257,38 @@ def test_fused_step_is_deterministic_and_graph_replay_matches_eager():
         assert np.array_equal(results[0][k], results[1][k]), "run-to-run difference in output %d" % k
         assert np.array_equal(results[0][k], results[2][k]), "graph replay differs in output %d" % k
     assert np.isfinite(results[0][3]).all()
+
+
+@pytest.mark.parametrize("model,gamma", [("TransE_l2", 19.9), ("DistMult", 143.0)])
+def test_merged_forward_launch_equals_split_launches_bit_for_bit(model, gamma):
+    """round 3: the strict step's first launch runs the forward GEMM tiles (pos-side fragments built from the table rows, raw
+    products; the loss kernel applies the TransE_l2 distance) next to the edge-forward rows.  Same arithmetic as the two
+    separate launches (KGE_FLAG_SPLIT_FWD): tables, states and loss sums must be bit-identical - cfg-T / cfg-D shape,
+    both corruption modes (4 steps)."""
+    from dglke_amd import plan, _lib
+    from dglke_amd.engine import StepEngine
+    rng = np.random.RandomState(11)
+    n_ent, n_rel, B, N, D = 14951, 1345, 1000, 200, 400
+    plans = []
+    for step in range(1, 5):
+        bt = O.synth_batch(rng, n_ent, n_rel, B, N, N, step)
+        plans.append(plan.build_plan(bt["h"], bt["t"], bt["r"], bt["neg"], N, N, bt["neg_head"]))
+    results = []
+    for flags in (0, _lib.FLAG_SPLIT_FWD):
+        torch.manual_seed(0)
+        eng = StepEngine(model, n_ent, n_rel, D, gamma, 0.25, DEV, False, False, True, 1.0, 1e-9, 3, flags=flags)
+        batches = plan.upload(plans, DEV)
+        scores = []
+        for b in batches:
+            want = dict(neg_score=torch.empty(b.C, b.chunk, b.N, device=DEV))
+            eng.step(b, want)
+            scores.append(want["neg_score"].cpu().numpy().copy())
+        torch.cuda.synchronize()
+        results.append((eng.ent.cpu().numpy().copy(), eng.rel.cpu().numpy().copy(), eng.ent_state.cpu().numpy().copy(),
+                        eng.rel_state.cpu().numpy().copy(), np.array(eng.read_loss_sums()), np.stack(scores)))
+    for k in range(6):
+        assert np.array_equal(results[0][k], results[1][k]), "merged vs split forward: output %d differs" % k
+    assert np.isfinite(results[0][4]).all()
 
 
 def test_adagrad_scatter_duplicate_semantics():
@@ -447,7 +479,7 @@ def _random_step_case(seed):
     chunk = int(rng.choice([1, 3, 4, 7, 8, 16, 17, 24, 32, 40]))
     C = int(rng.randint(1, 5))
     N = int(rng.choice([1, 2, 4, 5, 8, 12, 16, 20, 32, 36, 64]))
-    flags = int(rng.choice([0, 0, 1, 2, 8, 10, 16, 32, 33]))
+    flags = int(rng.choice([0, 0, 0, 1, 2, 8, 10, 16, 32, 33, 128, 130]))
     return dict(model=model, de=de, dr=dr, hidden=hidden, chunk=chunk, C=C, N=N, flags=flags,
                 n_ent=int(rng.choice([30, 200, 2000])), n_rel=int(rng.choice([3, 17])),
                 adv=bool(rng.randint(2)), reg=float(rng.choice([0.0, 1e-4])), gamma=float(rng.choice([6.0, 12.0])),
@@ -652,7 +684,7 @@ def _wide_step_case(seed):
     chunk = int(rng.choice([8, 16, 24, 40, 64]))
     C = int(rng.randint(1, 4))
     N = int(rng.choice([8, 16, 20, 32, 64, 72]))
-    flags = int(rng.choice([0, 0, 8, 8, 1, 2, 16, 32]))
+    flags = int(rng.choice([0, 0, 0, 8, 8, 1, 2, 16, 32, 128]))
     return dict(model=model, de=de, dr=dr, hidden=hidden, chunk=chunk, C=C, N=N, flags=flags,
                 n_ent=int(rng.choice([100, 3000])), n_rel=int(rng.choice([5, 40])),
                 adv=bool(rng.randint(2)), reg=float(rng.choice([0.0, 1e-6])), gamma=float(rng.choice([12.0, 19.9])),
