@@ -338,6 +338,9 @@ def main():
     ap.add_argument("--reg-coef", type=float, default=None, help="tuning: override the regularisation coefficient")
     ap.add_argument("--host-plan", action="store_true",
                     help="pre-stage host-built batches instead of sampling on the device inside the timed region")
+    ap.add_argument("--sampler-mode", default="streams", choices=["streams", "fork", "serial"],
+                    help="device sampler: next group's batches built on a second stream (default), on a forked graph branch, "
+                         "or serially in front of every group")
     ap.add_argument("--hogwild", type=int, default=4, help="also measure K concurrent Hogwild trainers (0 = skip)")
     ap.add_argument("--no-async-update", dest="async_update", action="store_false",
                     help="skip the --async_update pipeline measurement (reported as its own object)")
@@ -401,7 +404,7 @@ def main():
             return [G] * (count // G) + ([count % G] if count % G else [])
         seq_w, seq_t = sizes(args.warmup), sizes(args.steps)
         seq = seq_w + seq_t
-        pg = PrefetchedGroups(smp, eng.step, group_max=G)
+        pg = PrefetchedGroups(smp, eng.step, group_max=G, mode=args.sampler_mode)
 
         def run_groups(lo, hi):          # groups seq[lo:hi]; group i builds the batches of group i + 1 (the last one: of a
             for i in range(lo, hi):      # group like the first timed one, so that K batches are sampled per K timed steps)
@@ -419,8 +422,9 @@ def main():
         torch.cuda.synchronize()
         run_w = lambda: run_groups(0, len(seq_w))
         run_t = lambda: run_groups(len(seq_w), len(seq))
-        launch_desc = (("hipGraph of [%d steps || sampler launch for the next group on a forked branch]" % G)
-                       if use_graph else "eager, sampler prefetch on a side stream")
+        launch_desc = (("hipGraph of %d steps; sampler launch for the next group: %s" % (G, {
+            "streams": "concurrently on a second stream", "fork": "on a forked branch of the graph",
+            "serial": "serially in front of the group"}[args.sampler_mode])) if use_graph else "eager, sampler mode " + args.sampler_mode)
         data_desc = ("triples in HBM; batch ids, negatives and plan built ON THE DEVICE inside the timed region "
                      "(double-buffered: group g+1 is sampled while group g trains)")
     else:

@@ -582,7 +582,10 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     if (nd) { ef.nd_own = b->neg_head ? b->h_gid : b->t_gid; ef.nd_chunk = chunk; ef.nd_Ns = b->N; }
     // sharded tables: the scoring kernels re-read the negative rows many times - they must come from
     // the dense local copy edge_fwd makes, never from the (remote, uncached) table rows
-    ef.Bn = dense_neg ? Bn : nullptr;                 // the pairwise kernels read a dense copy
+    // merged first launch: its edge half also writes the dense copy of the negative rows - the backward GEMM then needs no id
+    // round, no index table and no barrier (neg_bwd_gemm_tile DENSE); KGE_FLAG_GATHER_BWD keeps the gathering instance (A/B)
+    const bool dense_bwd = merged_fwd && !(hp->flags & KGE_FLAG_GATHER_BWD);
+    ef.Bn = (dense_neg || dense_bwd) ? Bn : nullptr;  // the pairwise kernels read a dense copy
     ef.Hc = Hc; ef.Tc = Tc; ef.Rc = Rc;
     ef.asq = l2g ? asq : nullptr; ef.bsq = l2g ? bsq : nullptr;
     ef.do_pos_loss = pairwise ? 0 : 1; ef.lp = lp; ef.w = b->edge_w;
@@ -639,7 +642,7 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
             }
             if (merged_fwd) {
                 g.xbase = tb->ent; g.xidx = b->neg_head ? b->t_gid : b->h_gid; g.rbase = tb->rel; g.ridx = b->rel_ids;
-                g.asign = b->neg_head ? -1.f : 1.f;
+                g.asign = b->neg_head ? -1.f : 1.f; g.lds_off = (hp->flags & KGE_FLAG_FWD_DIRECT) ? 1 : 0;
                 KGE_TRY(launch_neg_fwd_gemm_with_edge(g, ef, s));
             } else if (!fused_launch) KGE_TRY(launch_neg_fwd_gemm(g, s));
         }
@@ -674,6 +677,7 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         KGE_TRY(launch_transr_bwd(tr, s));       // dq, GN, per-edge projection gradients, relation-vector gradients
     } else if (gemm) {
         g.W = S; g.w = b->edge_w; g.lp = lp;      // fused loss: S holds u_ij and PM/PS/PL (set above) the partials
+        if (merged_fwd && !(hp->flags & KGE_FLAG_GATHER_BWD)) { g.nbase = Bn; g.nidx = nullptr; }   // dense_bwd (see PH_PREP)
         g.GA = GA; g.GN = GN;
         if (qfuse) {                              // TransE: the update reads Q = GA +/- P, GA itself only on request (g_rel output)
             g.Q = GT; g.QP = Pg; g.qc = b->neg_head ? 1.f : -1.f;

@@ -411,6 +411,7 @@ struct GemmArgs {                   // LDS-staged fp32-MFMA negative scoring (kg
     // then (the other half of the launch is still writing them) and S receives the RAW products a_i . b_j (TransE_l2: the loss
     // kernel applies gamma - sqrt(|a|^2 + |b|^2 - 2 S), LossArgs::l2_raw)
     const float *xbase; const int64_t *xidx; const float *rbase; const int64_t *ridx; float asign;
+    int lds_off;                     // merged launch: keep the direct-load tiles instead of the pos-side tile through LDS (A/B aid)
     // forward
     float *S;                        // out [C,chunk,N]
     float clampv;                    // > 0: clamp the scores to [-clampv, clampv] (SimplE)

@@ -273,17 +273,239 @@ __global__ __launch_bounds__(KGE_BLOCK) void neg_fwd_update_kernel(GemmArgs a, i
     }
 }
 
+// ---- wide forward tiles for the merged launch: one wavefront = 16 positives x (NB x 16) negatives.  Building the pos-side
+// fragment on the fly costs a second gathered load per k-step (x and r rows); with ONE negative fragment per wavefront that is
+// 3 fragment loads per 4 MFMAs and the tiles - bound by the texture addresser (a fragment load touches 16 rows x 64 B) - lived
+// 9.3 us instead of 5.6 (profiles/r03_merged_fwd.txt).  NB = 2 shares the (x, r) pair between two negative fragments: 4 loads
+// per 8 MFMAs, the ratio of the dense-A kernel, in half as many wavefronts.  Raw products out (see neg_fwd_edge_kernel).
+template <int AM, int NB>
+__device__ __forceinline__ void neg_fwd_gemm_wide_body(const GemmArgs &a, int ti, int tjg, int bid, int nblk) {
+    const int lane = threadIdx.x & 63;
+    const int64_t tile = (int64_t)xcd_remap(bid, nblk) * KGE_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    const int64_t ntiles = (int64_t)a.C * ti * tjg;
+    if (tile >= ntiles) return;
+    const int jg = (int)(tile % tjg);
+    const int it = (int)((tile / tjg) % ti);
+    const int c = (int)(tile / ((int64_t)tjg * ti));
+    const int D = a.D;
+    const int m = lane & 15, q = lane >> 4;
+    const int ia = min(it * 16 + m, a.chunk - 1);
+    const float *Ap = AM ? row_ptr(a.xbase, a.xidx, (int64_t)c * a.chunk + ia, D) + q * 4
+                         : a.A + ((int64_t)c * a.chunk + ia) * D + q * 4;
+    const float *Rp = AM ? row_ptr(a.rbase, a.ridx, (int64_t)c * a.chunk + ia, D) + q * 4 : Ap;
+    const float *Bp[NB];
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+        Bp[n] = row_ptr(a.nbase, a.nidx, (int64_t)c * a.N + min((jg * NB + n) * 16 + m, a.N - 1), D) + q * 4;
+    f32x4 acc[NB][2];
+#pragma unroll
+    for (int n = 0; n < NB; ++n) { acc[n][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[n][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    float4 a0[FU], a1[FU], r0[AM ? FU : 1], r1[AM ? FU : 1], b0[NB][FU], b1[NB][FU];
+    const float asg = a.asign;
+    const int kfull = D >> 4;
+#define WF_LOAD(AV, RV, BV, KS0)                                                 \
+    { int k0_ = (KS0); asm volatile("" : "+s"(k0_));                             \
+      _Pragma("unroll") for (int u = 0; u < FU; ++u) {                           \
+        const int ks_ = min(k0_ + u, kfull - 1);                                 \
+        AV[u] = ldg4(Ap + ks_ * 16);                                             \
+        if (AM) RV[u] = ldg4(Rp + ks_ * 16);                                     \
+        _Pragma("unroll") for (int n = 0; n < NB; ++n) BV[n][u] = ldg4(Bp[n] + ks_ * 16); \
+    } }
+#define WF_AFRAG(AV, RV, u)                                                      \
+    { if (AM == 1) { AV[u].x = fmaf(asg, RV[u].x, AV[u].x); AV[u].y = fmaf(asg, RV[u].y, AV[u].y);    \
+                     AV[u].z = fmaf(asg, RV[u].z, AV[u].z); AV[u].w = fmaf(asg, RV[u].w, AV[u].w); }  \
+      else if (AM == 2) { AV[u].x *= RV[u].x; AV[u].y *= RV[u].y; AV[u].z *= RV[u].z; AV[u].w *= RV[u].w; } }
+#define WF_MMA1(AV, RV, BV, u)                                                   \
+    { WF_AFRAG(AV, RV, u)                                                        \
+      _Pragma("unroll") for (int n = 0; n < NB; ++n) {                           \
+        acc[n][0] = MFMA16(AV[u].x, BV[n][u].x, acc[n][0]);                      \
+        acc[n][1] = MFMA16(AV[u].y, BV[n][u].y, acc[n][1]); }                    \
+      _Pragma("unroll") for (int n = 0; n < NB; ++n) {                           \
+        acc[n][0] = MFMA16(AV[u].z, BV[n][u].z, acc[n][0]);                      \
+        acc[n][1] = MFMA16(AV[u].w, BV[n][u].w, acc[n][1]); } }
+#define WF_MMA(AV, RV, BV) _Pragma("unroll") for (int u = 0; u < FU; ++u) WF_MMA1(AV, RV, BV, u)
+#define WF_MMA_G(AV, RV, BV, KS0) _Pragma("unroll") for (int u = 0; u < FU; ++u) { if ((KS0) + u < kfull) WF_MMA1(AV, RV, BV, u) }
+#define WF_PIN() do { _Pragma("unroll") for (int n = 0; n < NB; ++n) asm volatile("" : "+a"(acc[n][0]), "+a"(acc[n][1]) :: "memory"); \
+                      __builtin_amdgcn_sched_barrier(0); } while (0)
+    if (kfull > 0) {
+        WF_LOAD(a0, r0, b0, 0);
+        int g = 0;
+        for (; g + 2 * FU <= kfull; g += 2 * FU) {
+            WF_LOAD(a1, r1, b1, g + FU);
+            KGE_ORDER();
+            WF_MMA(a0, r0, b0);
+            WF_PIN();
+            WF_LOAD(a0, r0, b0, g + 2 * FU);
+            KGE_ORDER();
+            WF_MMA(a1, r1, b1);
+            WF_PIN();
+        }
+        if (g < kfull) {
+            WF_LOAD(a1, r1, b1, g + FU);
+            WF_MMA_G(a0, r0, b0, g);
+            WF_MMA_G(a1, r1, b1, g + FU);
+        }
+    }
+    if (D & 15) {   // tail k-step: lanes whose 4 floats lie beyond D contribute zeros
+        float4 av[1], rv[1], bv[NB][1];
+        av[0] = zero4(); rv[0] = zero4();
+#pragma unroll
+        for (int n = 0; n < NB; ++n) bv[n][0] = zero4();
+        if (kfull * 16 + q * 4 < D) {
+            av[0] = ldg4(Ap + kfull * 16);
+            if (AM) rv[0] = ldg4(Rp + kfull * 16);
+#pragma unroll
+            for (int n = 0; n < NB; ++n) bv[n][0] = ldg4(Bp[n] + kfull * 16);
+        }
+        WF_MMA1(av, rv, bv, 0)
+    }
+#undef WF_LOAD
+#undef WF_AFRAG
+#undef WF_MMA1
+#undef WF_MMA
+#undef WF_MMA_G
+#undef WF_PIN
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+        const int j = (jg * NB + n) * 16 + m;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = it * 16 + q * 4 + r;
+            if (j < a.N && i < a.chunk) a.S[((int64_t)c * a.chunk + i) * a.N + j] = acc[n][0][r] + acc[n][1][r];
+        }
+    }
+}
+
+// ---- merged launch, pos-side tile through LDS: a workgroup = one row tile (16 positives) x 4 consecutive column tiles.  The 16
+// pos-side vectors a_i = x_i + asign * r_i (TransE) / x_i * r_i (DistMult) are built ONCE per workgroup from coalesced row loads
+// (16 threads per row, 256 contiguous bytes per pass) and parked in LDS; the wavefronts take their A fragments from there and only
+// the B fragments (gathered negative rows) are direct global loads - one gathered fragment load per k-step instead of three
+// (x, r, b: the tiles of the first merged version lived 9.3 us, ~0.1 us per fragment load; profiles/r03_merged_fwd.txt).
+// Row stride of the tile: whole k-steps + 4 floats (the 16-byte fragment reads of a quarter wavefront fall on different banks).
+static inline int fwd_lds_stride(int D) { return ((D + 15) & ~15) + 4; }
+static inline size_t fwd_lds_bytes(int D) { return (size_t)16 * fwd_lds_stride(D) * sizeof(float); }
+
+template <int AM>
+__device__ __forceinline__ void neg_fwd_gemm_ldsa_body(const GemmArgs &a, int ti, int tj, int bid, int nblk, float *As) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int tjg = (tj + 3) >> 2;
+    const int L = xcd_remap(bid, nblk);
+    const int jg = L % tjg, it = (L / tjg) % ti, c = L / (tjg * ti);
+    const int jt = min(jg * 4 + wv, tj - 1);             // (a wavefront beyond the last column tile helps building A, then leaves)
+    const bool tile_ok = jg * 4 + wv < tj;
+    const int D = a.D, KP = ((D + 15) & ~15) + 4, n4 = D >> 2;
+    const int m = lane & 15, q = lane >> 4;
+    // ids first (one round): this thread's row of the A tile (x and r) and this lane's negative row
+    const int arow = threadIdx.x >> 4, ac = threadIdx.x & 15;
+    const int64_t ie = (int64_t)c * a.chunk + min(it * 16 + arow, a.chunk - 1);
+    const int64_t jl = (int64_t)c * a.N + min(jt * 16 + m, a.N - 1);
+    const int64_t xid = a.xidx[ie], rid = a.ridx[ie];
+    const int64_t jraw = *(a.nidx ? a.nidx + jl : a.xidx);            // (unconditional load: no branch join in front of the waits)
+    const float *Xs = a.xbase + xid * D, *Rs = a.rbase + rid * D;
+    const float *Bp = a.nbase + (a.nidx ? jraw : jl) * D + q * 4;
+    float *Adst = As + arow * KP;
+    const float *Ap = As + m * KP + q * 4;               // this lane's fragment of k-step ks: Ap + ks * 16 (LDS)
+    const float asg = a.asign;
+    const int kfull = D >> 4;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    float4 a0[FU], b0[FU], a1[FU], b1[FU];
+    // the A tile: 8 passes of 16 x 16 bytes per row and source (512 floats per row) requested together, then the first B fragments
+    float4 xv[8], rv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const int o = min(j * 16 + ac, n4 - 1) * 4; xv[j] = ldg4(Xs + o); rv[j] = ldg4(Rs + o); }
+#pragma unroll
+    for (int u = 0; u < FU; ++u) b0[u] = ldg4(Bp + (kfull > 0 ? min(u, kfull - 1) * 16 : -(q * 4)));
+#define LA_COMB(X, R) (AM == 1 ? make_float4(fmaf(asg, R.x, X.x), fmaf(asg, R.y, X.y), fmaf(asg, R.z, X.z), fmaf(asg, R.w, X.w)) \
+                               : make_float4(X.x * R.x, X.y * R.y, X.z * R.z, X.w * R.w))
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c4 = j * 16 + ac;
+        if (c4 < n4) *reinterpret_cast<float4 *>(Adst + c4 * 4) = LA_COMB(xv[j], rv[j]);
+    }
+    for (int c0 = 16 * 8; c0 < n4; c0 += 16 * 8) {       // rows longer than 512 floats
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int o = min(c0 + j * 16 + ac, n4 - 1) * 4; xv[j] = ldg4(Xs + o); rv[j] = ldg4(Rs + o); }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c4 = c0 + j * 16 + ac;
+            if (c4 < n4) *reinterpret_cast<float4 *>(Adst + c4 * 4) = LA_COMB(xv[j], rv[j]);
+        }
+    }
+#undef LA_COMB
+    if (ac < (KP - D) / 4) *reinterpret_cast<float4 *>(Adst + D + ac * 4) = zero4();   // columns D .. KP-1 (D % 4 == 0): zeros
+    __syncthreads();
+    if (!tile_ok) return;
+#define LA_LOAD(AV, BV, KS0)                                                     \
+    { int k0_ = (KS0); asm volatile("" : "+s"(k0_));                             \
+      _Pragma("unroll") for (int u = 0; u < FU; ++u) {                           \
+        const int ks_ = min(k0_ + u, kfull - 1);                                 \
+        AV[u] = *reinterpret_cast<const float4 *>(Ap + ks_ * 16); BV[u] = ldg4(Bp + ks_ * 16); \
+    } }
+#define LA_MMA1(AV, BV, u)                                                       \
+    { acc0 = MFMA16(AV[u].x, BV[u].x, acc0);                                     \
+      acc1 = MFMA16(AV[u].y, BV[u].y, acc1);                                     \
+      acc0 = MFMA16(AV[u].z, BV[u].z, acc0);                                     \
+      acc1 = MFMA16(AV[u].w, BV[u].w, acc1); }
+#define LA_MMA(AV, BV) _Pragma("unroll") for (int u = 0; u < FU; ++u) LA_MMA1(AV, BV, u)
+#define LA_MMA_G(AV, BV, KS0) _Pragma("unroll") for (int u = 0; u < FU; ++u) { if ((KS0) + u < kfull) LA_MMA1(AV, BV, u) }
+    if (kfull > 0) {
+#pragma unroll
+        for (int u = 0; u < FU; ++u) a0[u] = *reinterpret_cast<const float4 *>(Ap + min(u, kfull - 1) * 16);
+        int g = 0;
+        for (; g + 2 * FU <= kfull; g += 2 * FU) {
+            LA_LOAD(a1, b1, g + FU);
+            KGE_ORDER();
+            LA_MMA(a0, b0);
+            KGE_PIN_ACC(acc0, acc1);
+            LA_LOAD(a0, b0, g + 2 * FU);
+            KGE_ORDER();
+            LA_MMA(a1, b1);
+            KGE_PIN_ACC(acc0, acc1);
+        }
+        if (g < kfull) {
+            LA_LOAD(a1, b1, g + FU);
+            LA_MMA_G(a0, b0, g);
+            LA_MMA_G(a1, b1, g + FU);
+        }
+    }
+#undef LA_LOAD
+#undef LA_MMA1
+#undef LA_MMA
+#undef LA_MMA_G
+    if (D & 15) {   // tail k-step: the tile is zero-padded in LDS; B lanes beyond D contribute zeros
+        float4 bv = zero4();
+        const float4 av = *reinterpret_cast<const float4 *>(Ap + kfull * 16);
+        if (kfull * 16 + q * 4 < D) bv = ldg4(Bp + kfull * 16);
+        acc0 = MFMA16(av.x, bv.x, acc0);
+        acc1 = MFMA16(av.y, bv.y, acc1);
+        acc0 = MFMA16(av.z, bv.z, acc0);
+        acc1 = MFMA16(av.w, bv.w, acc1);
+    }
+    const int j = jt * 16 + m;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = it * 16 + q * 4 + r;
+        if (j < a.N && i < a.chunk) a.S[((int64_t)c * a.chunk + i) * a.N + j] = acc0[r] + acc1[r];
+    }
+}
+
 // the strict step's FIRST launch (round 3): forward GEMM tiles (first nbG workgroups) + the edge-forward rows of the SAME step
 // (the rest).  The tiles do not wait for the pos-side vectors a_i: they rebuild their fragments from the table rows the edge
 // half is reading (one packed add / multiply per fragment), emit raw products, and the row-wise results of the edge half
 // (positive scores, |a|^2, |b|^2, dL/dp, P rows, the dense A the backward reads) are consumed one launch later, by the loss
 // kernel (distance transform) and the backward GEMM.  One launch boundary and the whole edge-forward kernel (4.2 + 1.7 us at
 // cfg-T, profiles/r02_v7_timeline.txt) leave the step's critical path.
-template <bool L2, int AM, int MODEL, bool LEAN>
+#ifndef KGE_FWD_NB
+#define KGE_FWD_NB 1               // direct-load instance: negative fragments per forward wavefront (tuning: 1, 2, 3; measured:
+#endif                             // wider is SLOWER - 9.3 / 11.7 / 14 us wave life, the time follows the loads per wavefront)
+template <bool L2, int AM, int MODEL, bool LEAN, bool LDSA>
 __global__ __launch_bounds__(KGE_BLOCK) void neg_fwd_edge_kernel(GemmArgs a, int ti, int tj, int nbG, EdgeFwdArgs e) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     if ((int)blockIdx.x < nbG) {
         KGE_TL(1);
-        neg_fwd_gemm_body<L2, false, AM>(a, ti, tj, (int)blockIdx.x, nbG);
+        if constexpr (LDSA) neg_fwd_gemm_ldsa_body<AM>(a, ti, tj, (int)blockIdx.x, nbG, smem);
+        else if constexpr (KGE_FWD_NB == 1) neg_fwd_gemm_body<L2, false, AM>(a, ti, tj, (int)blockIdx.x, nbG);
+        else neg_fwd_gemm_wide_body<AM, KGE_FWD_NB>(a, ti, (tj + KGE_FWD_NB - 1) / KGE_FWD_NB, (int)blockIdx.x, nbG);
     } else {
         KGE_TL(0);
         edge_fwd_body<MODEL, 4, LEAN>(e, (int)blockIdx.x - nbG);
@@ -304,15 +526,20 @@ int launch_neg_fwd_gemm_with_edge(const GemmArgs &a, const EdgeFwdArgs &e, hipSt
     if (!negjob) ee.n_neg = 0;
     const int nbP = (int)((waves + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK);
     const int ti = (a.chunk + 15) / 16, tj = (a.N + 15) / 16;
-    const int64_t ntiles = (int64_t)a.C * ti * tj;
-    const int nbG = (int)((ntiles + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK);
+    // pos-side tile through LDS (one workgroup = 16 positives x 4 column tiles) whenever the tile fits the default 64 KB
+    const size_t lds = fwd_lds_bytes(a.D);
+    const bool ldsa = lds <= 64 * 1024 && !a.lds_off;
+    const int64_t ntiles = (int64_t)a.C * ti * ((tj + KGE_FWD_NB - 1) / KGE_FWD_NB);
+    const int nbG = ldsa ? a.C * ti * ((tj + 3) / 4) : (int)((ntiles + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK);
     const bool lean = e.lp.genre == KGE_LOSS_LOGSIGMOID && !e.row_pos && !e.Hc;
     const dim3 g(nbG + nbP), b(KGE_BLOCK);
-#define KGE_FE(L2_, AM_, M_) do { if (lean) hipLaunchKernelGGL((neg_fwd_edge_kernel<L2_, AM_, M_, true>), g, b, 0, s, a, ti, tj, nbG, ee); \
-                                  else hipLaunchKernelGGL((neg_fwd_edge_kernel<L2_, AM_, M_, false>), g, b, 0, s, a, ti, tj, nbG, ee); } while (0)
+#define KGE_FE2(L2_, AM_, M_, LE_) do { if (ldsa) hipLaunchKernelGGL((neg_fwd_edge_kernel<L2_, AM_, M_, LE_, true>), g, b, lds, s, a, ti, tj, nbG, ee); \
+                                        else hipLaunchKernelGGL((neg_fwd_edge_kernel<L2_, AM_, M_, LE_, false>), g, b, 0, s, a, ti, tj, nbG, ee); } while (0)
+#define KGE_FE(L2_, AM_, M_) do { if (lean) KGE_FE2(L2_, AM_, M_, true); else KGE_FE2(L2_, AM_, M_, false); } while (0)
     if (a.model == KGE_TRANSE_L2) KGE_FE(true, 1, KGE_TRANSE_L2);
     else KGE_FE(false, 2, KGE_DISTMULT);
 #undef KGE_FE
+#undef KGE_FE2
     return check_launch_g();
 }
 
@@ -394,7 +621,10 @@ __device__ __forceinline__ void row_stats(const GemmArgs &a, int64_t gi, int tj,
 // ISGA: the product is a compile-time constant of the instance (the workgroup picks it below): the prologue of each is
 // straight-line code - with `isGA` a run-time value every request sat behind a branch join, and a join in front of a wait
 // makes the wait cover everything requested so far (profiles/r02_waitcnt_fix.txt)
-template <bool L2, bool FACT, bool ISGA>   // FACT: the streamed weights are u_ij and get the per-(row, tile) factor here
+// DENSE (round 3): both operands are dense arrays (negative rows: the per-step copy Bn written by the edge-forward half of the
+// first launch) - row numbers are arithmetic, so there is no index table, no LDS and NO BARRIER: the first operand requests leave
+// with the wavefront's first instructions instead of after an id round + LDS round (never with FACT: its factor table lives in LDS)
+template <bool L2, bool FACT, bool ISGA, bool DENSE = false>   // FACT: the streamed weights are u_ij and get the per-(row, tile) factor here
 __device__ __forceinline__ void neg_bwd_gemm_tile(const GemmArgs &a, int ti, int tj, int td, int c, int bcl, int maxK,
                                                   float *smem) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -424,9 +654,12 @@ __device__ __forceinline__ void neg_bwd_gemm_tile(const GemmArgs &a, int ti, int
     // (1) the index this thread contributes to rix (GA, gathered negatives: a global load - the OLDEST request, the LDS
     //     write below waits for it alone)
     const int k0 = threadIdx.x;
-    int64_t rix0;
-    if (isGA) rix0 = a.nidx ? a.nidx[(int64_t)c * N + min(k0, K - 1)] : (int64_t)c * N + k0;
-    else rix0 = (int64_t)c * chunk + k0;
+    const int64_t rbase = isGA ? (int64_t)c * N : (int64_t)c * chunk;     // DENSE: reduction element k is row rbase + k
+    int64_t rix0 = 0;
+    if (!DENSE) {
+        if (isGA) rix0 = a.nidx ? a.nidx[(int64_t)c * N + min(k0, K - 1)] : (int64_t)c * N + k0;
+        else rix0 = (int64_t)c * chunk + k0;
+    }
     // (2) the output rows' own vectors (rank-1 term of the L2 expansion / regulariser; at the end they would be one more
     //     dependent round) and the P rows of the Q epilogue.  GA: addresses are arithmetic - requested now, unconditionally
     //     (no Q wanted: a valid dummy address).  GN: the row numbers are gathered - index loads now, rows after the barrier.
@@ -444,14 +677,16 @@ __device__ __forceinline__ void neg_bwd_gemm_tile(const GemmArgs &a, int ti, int
         const float *qp = (wantQ ? a.QP : a.A) + dc;
 #pragma unroll
         for (int r = 0; r < 4; ++r) pq[r] = ldg4(qp + srow[r] * D);
-    } else if (need_self && a.nidx) {
+    } else if (!DENSE && need_self && a.nidx) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) srow[r] = a.nidx[srow[r]];
     }
     // (3) the index table
-    if (k0 < K) rix[k0] = rix0;
-    for (int k = k0 + KGE_BLOCK; k < K; k += KGE_BLOCK)                   // K > 256
-        rix[k] = isGA ? (a.nidx ? a.nidx[(int64_t)c * N + k] : (int64_t)c * N + k) : (int64_t)c * chunk + k;
+    if (!DENSE) {
+        if (k0 < K) rix[k0] = rix0;
+        for (int k = k0 + KGE_BLOCK; k < K; k += KGE_BLOCK)                   // K > 256
+            rix[k] = isGA ? (a.nidx ? a.nidx[(int64_t)c * N + k] : (int64_t)c * N + k) : (int64_t)c * chunk + k;
+    }
     if (FACT && !isGA) {
         for (int k = threadIdx.x; k < K; k += KGE_BLOCK) {
             float M, coef, lr;
@@ -479,7 +714,7 @@ __device__ __forceinline__ void neg_bwd_gemm_tile(const GemmArgs &a, int ti, int
             }
         }
     }
-    __syncthreads();
+    if (!DENSE) __syncthreads();
     if (!tile_ok) return;
     const float *ft = ftab + rt;                         // GN: factor of reduction row k = ft[k * GB_TJP]
 
@@ -515,7 +750,8 @@ __device__ __forceinline__ void neg_bwd_gemm_tile(const GemmArgs &a, int ti, int
     _Pragma("unroll") for (int u = 0; u < BU; ++u) {                                           \
         const int ms = min((MS0) + u, msfull - 1);                                             \
         int64_t ri[4];                                                                         \
-        _Pragma("unroll") for (int e = 0; e < 4; ++e) ri[e] = rix[ms * 16 + q * 4 + e];        \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e)                                          \
+            ri[e] = DENSE ? rbase + (ms * 16 + q * 4 + e) : rix[ms * 16 + q * 4 + e];          \
         if (VECW) {                                                                            \
             const float4 t4 = ldg4(Wq + ms * 16);                                              \
             ST[u].w[0] = t4.x; ST[u].w[1] = t4.y; ST[u].w[2] = t4.z; ST[u].w[3] = t4.w;        \
@@ -589,7 +825,7 @@ __device__ __forceinline__ void neg_bwd_gemm_tile(const GemmArgs &a, int ti, int
         for (int e = 0; e < 4; ++e) {
             const int kc = min(kk + e, K - 1);
             tw[e] = Wrow[(int64_t)kc * wstride];
-            tx[e] = ldg4(Xb + rix[kc] * D);
+            tx[e] = ldg4(Xb + (DENSE ? rbase + kc : rix[kc]) * D);
         }
         if (FACT && isGA) tpm = PMrow[min(msfull, tj - 1)];
     }
@@ -661,22 +897,22 @@ __device__ __forceinline__ void neg_bwd_gemm_tile(const GemmArgs &a, int ti, int
 
 // `bid` / `nblk`: this workgroup's index and the number of workgroups doing GEMM work (the body is also one half of the
 // horizontally fused launch below); workgroup -> (chunk, product, 4 consecutive tiles)
-template <bool L2, bool FACT>
+template <bool L2, bool FACT, bool DENSE = false>
 __device__ __forceinline__ void neg_bwd_gemm_body(const GemmArgs &a, int ti, int tj, int td, int bpA, int bpN, int maxK,
                                                   int bid, int nblk, float *smem) {
     const int blk = xcd_remap(bid, nblk);
     const int c = blk / (bpA + bpN);
     const int bc = blk % (bpA + bpN);
-    if (bc < bpA) neg_bwd_gemm_tile<L2, FACT, true>(a, ti, tj, td, c, bc, maxK, smem);
-    else neg_bwd_gemm_tile<L2, FACT, false>(a, ti, tj, td, c, bc - bpA, maxK, smem);
+    if (bc < bpA) neg_bwd_gemm_tile<L2, FACT, true, DENSE>(a, ti, tj, td, c, bc, maxK, smem);
+    else neg_bwd_gemm_tile<L2, FACT, false, DENSE>(a, ti, tj, td, c, bc - bpA, maxK, smem);
 }
 
-template <bool L2, bool FACT>
+template <bool L2, bool FACT, bool DENSE = false>
 __global__ __launch_bounds__(KGE_BLOCK) void neg_bwd_gemm_kernel(GemmArgs a, int ti, int tj, int td,
                                                                  int bpA, int bpN, int maxK) {
     KGE_TL(3);
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    neg_bwd_gemm_body<L2, FACT>(a, ti, tj, td, bpA, bpN, maxK, (int)blockIdx.x, (int)gridDim.x, smem);
+    neg_bwd_gemm_body<L2, FACT, DENSE>(a, ti, tj, td, bpA, bpN, maxK, (int)blockIdx.x, (int)gridDim.x, smem);
 }
 
 // --async_update pipeline, horizontal fusion.  The pipeline (kge_step_async) keeps the exact one-step staleness of the
@@ -693,7 +929,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void neg_bwd_prep_kernel(GemmArgs a, int
     extern __shared__ __attribute__((aligned(16))) float smem[];
     if ((int)blockIdx.x < nbG) {
         KGE_TL(3);
-        neg_bwd_gemm_body<L2, false>(a, ti, tj, td, bpA, bpN, maxK, (int)blockIdx.x, nbG, smem);
+        neg_bwd_gemm_body<L2, false, true>(a, ti, tj, td, bpA, bpN, maxK, (int)blockIdx.x, nbG, smem);   // the pipeline's operands are dense
     } else {
         KGE_TL(0);
         edge_fwd_body<MODEL, 4, false>(e, (int)blockIdx.x - nbG);
@@ -717,6 +953,11 @@ int launch_neg_bwd_gemm(const GemmArgs &a, hipStream_t s) {
     const size_t sm = (size_t)mk * 8 + (fact ? (size_t)mk * GB_TJP * 4 : 0);
     const bool l2 = a.model == KGE_TRANSE_L2;
     const dim3 g(nb), b(KGE_BLOCK);
+    if (!fact && !a.nidx) {                                      // dense operands: the instance without index table / LDS / barrier
+        if (l2) hipLaunchKernelGGL((neg_bwd_gemm_kernel<true, false, true>), g, b, 0, s, a, ti, tj, td, bpA, bpN, mk);
+        else hipLaunchKernelGGL((neg_bwd_gemm_kernel<false, false, true>), g, b, 0, s, a, ti, tj, td, bpA, bpN, mk);
+        return check_launch_g();
+    }
     if (l2 && fact) hipLaunchKernelGGL((neg_bwd_gemm_kernel<true, true>), g, b, sm, s, a, ti, tj, td, bpA, bpN, mk);
     else if (l2) hipLaunchKernelGGL((neg_bwd_gemm_kernel<true, false>), g, b, sm, s, a, ti, tj, td, bpA, bpN, mk);
     else if (fact) hipLaunchKernelGGL((neg_bwd_gemm_kernel<false, true>), g, b, sm, s, a, ti, tj, td, bpA, bpN, mk);
@@ -755,7 +996,7 @@ int launch_neg_fwd_gemm_with_update(const GemmArgs &a, const UpdateArgs &u, hipS
 // backward GEMM of one step + PREP (edge forward) of the NEXT step in one launch (neg_bwd_prep_kernel).
 // Returns KGE_ERR_ARG when the combination has no fused instantiation.
 int launch_neg_bwd_gemm_with_prep(const GemmArgs &a, const EdgeFwdArgs &e, hipStream_t s) {
-    if (a.C == 0 || !a.W || a.PM) return KGE_ERR_ARG;
+    if (a.C == 0 || !a.W || a.PM || a.nidx) return KGE_ERR_ARG;       // (dense negative rows: PREP's copy)
     const int maxK = a.chunk > a.N ? a.chunk : a.N;
     if (maxK > GB_MAXK) return KGE_ERR_ARG;
     const bool cx = kge::is_complex_model(e.model);
@@ -772,7 +1013,7 @@ int launch_neg_bwd_gemm_with_prep(const GemmArgs &a, const EdgeFwdArgs &e, hipSt
     const int bpN = (tj * td + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK;
     const int nbG = a.C * (bpA + bpN);
     const int mk = (maxK + 3) & ~3;
-    const size_t sm = (size_t)mk * 8;
+    const size_t sm = 0;
     const dim3 g(nbG + nbP), b(KGE_BLOCK);
 #define KGE_BP(L2_, M_) hipLaunchKernelGGL((neg_bwd_prep_kernel<L2_, M_>), g, b, sm, s, a, ti, tj, td, bpA, bpN, mk, nbG, ee)
     if (a.model == KGE_TRANSE_L2 && e.model == KGE_TRANSE_L2) KGE_BP(true, KGE_TRANSE_L2);

@@ -215,19 +215,25 @@ class DeviceSampler(object):
 
 class PrefetchedGroups(object):
     """Groups of training steps whose batches were built while the PREVIOUS group trained: the sampler launch of group g+1
-    runs on a forked stream (a second branch of the captured hipGraph) next to the steps of group g, over the other half of
-    a double-buffered slot array, and joins at the end of the group - the ~45 us sampler launch leaves the critical path of
-    short runs (a 20-step run paid it serially: 2.4 us per step) while every group still samples exactly the batches of a
-    following group inside the same timed region.  Restates the prefetching of the reference's sampler threads
-    (dataloader/sampler.py:823-876: `NewBidirectionalOneShotIterator` over `num_workers` sampler workers).
+    runs on a second stream next to the steps of group g, over the other half of a double-buffered slot array, and is joined
+    by an event at the end of the group - the ~45 us sampler launch leaves the critical path of short runs (a 20-step run
+    paid it serially: 2.4 us per step) while every group still samples exactly the batches of a following group inside the
+    same timed region.  Restates the prefetching of the reference's sampler workers (dataloader/sampler.py:823-876:
+    `NewBidirectionalOneShotIterator` over `num_workers` sampler threads).
+    The steps of a group replay from a SINGLE-BRANCH hipGraph; the sampler launch is a plain launch on the side stream.
+    (mode 'fork' puts the sampler on a second branch INSIDE the graph instead: measured +5 us per step on ROCm 7.0 -
+    multi-branch graphs leave the runtime's fast single-stream submission path; kept for the record, profiles/r03_*.)
 
     sampler: a DeviceSampler with n_slots >= 2 * the largest group; step_fn(batch): enqueues one training step."""
 
-    def __init__(self, sampler, step_fn, group_max=None):
+    def __init__(self, sampler, step_fn, group_max=None, mode="streams"):
         self.smp, self.step_fn = sampler, step_fn
         self.half = sampler.n_slots // 2 if group_max is None else int(group_max)
         if 2 * self.half > sampler.n_slots:
             raise ValueError("the sampler needs 2 x group_max slots")
+        if mode not in ("streams", "fork", "serial"):
+            raise ValueError("mode: streams | fork | serial")
+        self.mode = mode
         self.side = th.cuda.Stream(device=sampler.dev)
         self.buf = 0                  # half holding the batches of the NEXT group to train
         self.ready = None             # DeviceBatch objects in that half
@@ -237,13 +243,16 @@ class PrefetchedGroups(object):
         """build the first group's batches on the current stream (outside any graph)."""
         self.ready = self.smp.sample(n, slot0=self.buf * self.half)
 
-    def _enqueue(self, n_next):
+    def _sample_next(self, n_next):
+        return self.smp.sample(n_next, slot0=(self.buf ^ 1) * self.half)
+
+    def _enqueue_fork(self, n_next):
         cur = th.cuda.current_stream(self.smp.dev)
         batches, nxt = self.ready, None
         if n_next:
             self.side.wait_stream(cur)                                  # fork
             with th.cuda.stream(self.side):
-                nxt = self.smp.sample(n_next, slot0=(self.buf ^ 1) * self.half)
+                nxt = self._sample_next(n_next)
         for b in batches:
             self.step_fn(b)
         if n_next:
@@ -251,23 +260,49 @@ class PrefetchedGroups(object):
         return nxt
 
     def run(self, n_next, graph=True):
-        """train the ready group and (concurrently) build the next one of n_next batches.  graph=True: replay a hipGraph of
-        exactly that, captured on first use per (group size, next size, buffer half)."""
+        """train the ready group and (concurrently) build the next one of n_next batches.  graph=True: the steps replay
+        from a hipGraph captured on first use per (group size, buffer half)."""
         n_cur = len(self.ready)
         if n_next > self.half:
             raise ValueError("group larger than half of the slots")
-        key = (n_cur, n_next, self.buf)
+        if self.mode == "fork":
+            key = (n_cur, n_next, self.buf)
+            if not graph:
+                nxt = self._enqueue_fork(n_next)
+            elif key in self.graphs:
+                g, nxt = self.graphs[key]
+                self.smp.host_step += n_next
+                g.replay()
+            else:
+                g = th.cuda.CUDAGraph()
+                with th.cuda.graph(g):
+                    nxt = self._enqueue_fork(n_next)
+                self.graphs[key] = (g, nxt)
+                g.replay()
+            self.ready = nxt
+            self.buf ^= 1
+            return
+        cur = th.cuda.current_stream(self.smp.dev)
+        nxt = None
+        if n_next and self.mode == "streams":
+            self.side.wait_stream(cur)          # the half it overwrites was read by the group before this one
+            with th.cuda.stream(self.side):
+                nxt = self._sample_next(n_next)
+        elif n_next:                            # 'serial': the sampler launch in front of the group, same stream
+            nxt = self._sample_next(n_next)
         if not graph:
-            nxt = self._enqueue(n_next)
-        elif key in self.graphs:
-            g, nxt = self.graphs[key]
-            self.smp.host_step += n_next
-            g.replay()
+            for b in self.ready:
+                self.step_fn(b)
         else:
-            g = th.cuda.CUDAGraph()
-            with th.cuda.graph(g):
-                nxt = self._enqueue(n_next)
-            self.graphs[key] = (g, nxt)
-            g.replay()
+            key = (n_cur, self.buf)
+            if key not in self.graphs:
+                g = th.cuda.CUDAGraph()
+                with th.cuda.graph(g):
+                    for b in self.ready:
+                        self.step_fn(b)
+                self.graphs[key] = g
+            self.graphs[key].replay()
+        if n_next and self.mode == "streams":
+            cur.wait_stream(self.side)          # join: the next group's batches are complete
         self.ready = nxt
         self.buf ^= 1
