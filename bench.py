@@ -338,9 +338,10 @@ def main():
     ap.add_argument("--reg-coef", type=float, default=None, help="tuning: override the regularisation coefficient")
     ap.add_argument("--host-plan", action="store_true",
                     help="pre-stage host-built batches instead of sampling on the device inside the timed region")
-    ap.add_argument("--sampler-mode", default="streams", choices=["streams", "fork", "serial"],
-                    help="device sampler: next group's batches built on a second stream (default), on a forked graph branch, "
-                         "or serially in front of every group")
+    ap.add_argument("--sampler-mode", default="serial", choices=["streams", "fork", "serial"],
+                    help="device sampler: the next group's batches are built by one sampler launch in front of every group on the "
+                         "same stream (default), concurrently on a second stream, or on a forked branch of the group's hipGraph - the "
+                         "concurrent modes make the steps 3.5 us slower each on ROCm 7.0 (profiles/r03_merged_fwd.txt)")
     ap.add_argument("--hogwild", type=int, default=4, help="also measure K concurrent Hogwild trainers (0 = skip)")
     ap.add_argument("--no-async-update", dest="async_update", action="store_false",
                     help="skip the --async_update pipeline measurement (reported as its own object)")
@@ -381,10 +382,10 @@ def main():
     if dev_sampler:
         G = max(2, G - G % 2)            # even group: slot parity = head / tail corruption (sampler.py:853-859)
     if dev_sampler:
-        # ---- sampling + plan ON THE DEVICE, inside the timed region: one sampler launch per group of <= G steps, running on a
-        # forked branch of the group's hipGraph NEXT TO the steps of the previous group (double-buffered slots,
-        # dataloader.PrefetchedGroups): every timed group trains on batches built during the group before it and builds the
-        # batches of the group after it - the timed region contains exactly K steps and the sampling of K batches ----
+        # ---- sampling + plan ON THE DEVICE, inside the timed region: one sampler launch per group of <= G steps over
+        # double-buffered slots (dataloader.PrefetchedGroups): every timed group trains on batches built during the group before
+        # it and builds the batches of the group after it - the timed region contains exactly K steps and the sampling of K
+        # batches.  --sampler-mode serial (default): the launch sits in front of the group's steps on the same stream ----
         from dglke_amd.dataloader import DeviceSampler, PrefetchedGroups
         smp = DeviceSampler(h, r, t, w["n_ent"], w["B"], w["N"], dev, n_slots=2 * G, seed=0)
         dbs = smp.sample(G)

@@ -582,9 +582,9 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     if (nd) { ef.nd_own = b->neg_head ? b->h_gid : b->t_gid; ef.nd_chunk = chunk; ef.nd_Ns = b->N; }
     // sharded tables: the scoring kernels re-read the negative rows many times - they must come from
     // the dense local copy edge_fwd makes, never from the (remote, uncached) table rows
-    // merged first launch: its edge half also writes the dense copy of the negative rows - the backward GEMM then needs no id
-    // round, no index table and no barrier (neg_bwd_gemm_tile DENSE); KGE_FLAG_GATHER_BWD keeps the gathering instance (A/B)
-    const bool dense_bwd = merged_fwd && !(hp->flags & KGE_FLAG_GATHER_BWD);
+    // merged first launch, KGE_FLAG_DENSE_BWD: its edge half also writes the dense copy of the negative rows and the backward GEMM
+    // reads that (no id round).  Measured equal to gathering through neg_ids (profiles/r03_merged_fwd.txt) at +1.6 MB of writes: opt-in
+    const bool dense_bwd = merged_fwd && (hp->flags & KGE_FLAG_DENSE_BWD);
     ef.Bn = (dense_neg || dense_bwd) ? Bn : nullptr;  // the pairwise kernels read a dense copy
     ef.Hc = Hc; ef.Tc = Tc; ef.Rc = Rc;
     ef.asq = l2g ? asq : nullptr; ef.bsq = l2g ? bsq : nullptr;
@@ -677,7 +677,7 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         KGE_TRY(launch_transr_bwd(tr, s));       // dq, GN, per-edge projection gradients, relation-vector gradients
     } else if (gemm) {
         g.W = S; g.w = b->edge_w; g.lp = lp;      // fused loss: S holds u_ij and PM/PS/PL (set above) the partials
-        if (merged_fwd && !(hp->flags & KGE_FLAG_GATHER_BWD)) { g.nbase = Bn; g.nidx = nullptr; }   // dense_bwd (see PH_PREP)
+        if (merged_fwd && (hp->flags & KGE_FLAG_DENSE_BWD)) { g.nbase = Bn; g.nidx = nullptr; }   // dense_bwd (see PH_PREP)
         g.GA = GA; g.GN = GN;
         if (qfuse) {                              // TransE: the update reads Q = GA +/- P, GA itself only on request (g_rel output)
             g.Q = GT; g.QP = Pg; g.qc = b->neg_head ? 1.f : -1.f;

@@ -19,17 +19,19 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifdef KGE_TIMELINE
 #define KGE_TL_PER_KERNEL 8192
 static __device__ unsigned long long *kge_tl_buf = nullptr;
+// phase mark: drains the memory counters first, so the time since the previous mark is the latency of whatever was
+// outstanding (changes the overlap - use for attribution, not for the headline time); written straight into the wavefront's
+// record, so that device functions below the kernel can set marks too
+__device__ __forceinline__ void kge_tl_mark(int kid, int n) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const int wid = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    if ((threadIdx.x & 63) == 0 && kge_tl_buf && wid < KGE_TL_PER_KERNEL)
+        kge_tl_buf[((size_t)kid * KGE_TL_PER_KERNEL + wid) * 8 + 4 + n] = wall_clock64();
+}
 struct KgeTlScope {
     unsigned long long t0; int kid; int wid;
-    unsigned long long mk[4];
-    __device__ __forceinline__ KgeTlScope(int kid_, int wid_) : kid(kid_), wid(wid_) {
-        mk[0] = mk[1] = mk[2] = mk[3] = 0; t0 = wall_clock64(); }
-    // phase mark: drains the memory counters first, so the time since the previous mark is the latency of
-    // whatever was outstanding (changes the overlap - use for attribution, not for the headline time)
-    __device__ __forceinline__ void mark(int n) {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        mk[n] = wall_clock64();
-    }
+    __device__ __forceinline__ KgeTlScope(int kid_, int wid_) : kid(kid_), wid(wid_) { t0 = wall_clock64(); }
+    __device__ __forceinline__ void mark(int n) { kge_tl_mark(kid, n); }
     __device__ __forceinline__ ~KgeTlScope() {
         if ((threadIdx.x & 63) == 0 && kge_tl_buf && wid < KGE_TL_PER_KERNEL) {
             unsigned hw;
@@ -41,17 +43,18 @@ struct KgeTlScope {
             r[1] = t0;
             r[2] = wall_clock64();
             r[3] = (unsigned long long)kid + 1;
-            r[4] = mk[0]; r[5] = mk[1]; r[6] = mk[2]; r[7] = mk[3];
         }
     }
 };
 #define KGE_TL(kid) KgeTlScope kge_tl_scope_((kid), (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)))
 #define KGE_TL_MARK(n) kge_tl_scope_.mark(n)
+#define KGE_TL_MARK_K(kid, n) kge_tl_mark((kid), (n))
 #define KGE_TL_DEFINE(name) extern "C" int kge_tl_set_##name(void *p) { \
         return hipMemcpyToSymbol(HIP_SYMBOL(kge_tl_buf), &p, sizeof(p)) == hipSuccess ? 0 : -1; }
 #else
 #define KGE_TL(kid)
 #define KGE_TL_MARK(n)
+#define KGE_TL_MARK_K(kid, n)
 #define KGE_TL_DEFINE(name)
 #endif
 

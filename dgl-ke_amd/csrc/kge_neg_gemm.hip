@@ -834,9 +834,15 @@ __device__ __forceinline__ void neg_bwd_gemm_tile(const GemmArgs &a, int ti, int
 #pragma unroll
         for (int r = 0; r < 4; ++r) selfv[r] = ldg4(a.nbase + srow[r] * D + dc);
     }
+#ifdef KGE_TL_MARKS
+    KGE_TL_MARK_K(3, 0);           // prologue done: ids, own rows, first operands and the tail operands have arrived
+#endif
     if (msfull > 0) {
         if (isGA && vecW) BWD_PIPE(true) else BWD_PIPE(false)
     }
+#ifdef KGE_TL_MARKS
+    KGE_TL_MARK_K(3, 1);           // main loop done
+#endif
 #undef BWD_LOAD
 #undef BWD_XFORM
 #undef BWD_MMA1
@@ -860,6 +866,9 @@ __device__ __forceinline__ void neg_bwd_gemm_tile(const GemmArgs &a, int ti, int
         }
     }
 
+#ifdef KGE_TL_MARKS
+    KGE_TL_MARK_K(3, 2);           // tail macro step issued
+#endif
     // lanes with equal (lane&15) hold partial sums of the same W row/column: combine the 4 groups
     wsum += __shfl_xor(wsum, 16, 64);
     wsum += __shfl_xor(wsum, 32, 64);

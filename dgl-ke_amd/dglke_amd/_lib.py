@@ -22,7 +22,7 @@ FLAG_FUSED_LOSS = 8
 FLAG_TWO_PASS_PAIR = 16
 FLAG_NEG_DEG_SAMPLE = 32
 FLAG_ASYNC_REL = 64
-FLAG_GATHER_BWD = 256       # merged first launch: backward GEMM gathers the negative rows through neg_ids (A-B aid)
+FLAG_DENSE_BWD = 256        # merged first launch: backward GEMM reads a dense copy of the negative rows (A-B aid)
 FLAG_FWD_DIRECT = 512       # merged first launch: direct fragment loads instead of the LDS pos-side tile (A-B aid)
 FLAG_SPLIT_FWD = 128        # strict step: edge-forward and forward GEMM as two launches (validation / A-B aid)
 PHASE_GATHER, PHASE_FORWARD, PHASE_BACKWARD, PHASE_UPDATE = 1, 2, 4, 8

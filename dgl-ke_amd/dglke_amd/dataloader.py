@@ -214,19 +214,18 @@ class DeviceSampler(object):
 
 
 class PrefetchedGroups(object):
-    """Groups of training steps whose batches were built while the PREVIOUS group trained: the sampler launch of group g+1
-    runs on a second stream next to the steps of group g, over the other half of a double-buffered slot array, and is joined
-    by an event at the end of the group - the ~45 us sampler launch leaves the critical path of short runs (a 20-step run
-    paid it serially: 2.4 us per step) while every group still samples exactly the batches of a following group inside the
-    same timed region.  Restates the prefetching of the reference's sampler workers (dataloader/sampler.py:823-876:
-    `NewBidirectionalOneShotIterator` over `num_workers` sampler threads).
-    The steps of a group replay from a SINGLE-BRANCH hipGraph; the sampler launch is a plain launch on the side stream.
-    (mode 'fork' puts the sampler on a second branch INSIDE the graph instead: measured +5 us per step on ROCm 7.0 -
-    multi-branch graphs leave the runtime's fast single-stream submission path; kept for the record, profiles/r03_*.)
+    """Groups of training steps over a double-buffered slot array: while group g trains, the batches of group g+1 are built
+    into the other half (the prefetching of the reference's sampler workers, dataloader/sampler.py:823-876:
+    `NewBidirectionalOneShotIterator` over `num_workers` sampler threads).  Where the sampler launch of group g+1 runs:
+      'serial'  - in front of group g's steps, on the same stream (one launch per group; the steps replay from a hipGraph);
+      'streams' - on a second stream next to the steps, joined by an event at the end of the group;
+      'fork'    - on a second branch inside the group's hipGraph.
+    Measured on MI355X / ROCm 7.0 (profiles/r03_merged_fwd.txt): the two concurrent modes hide the ~45 us launch but make every
+    STEP ~3.5 us slower (a second active queue next to the graph's), so 'serial' is what bench.py uses.
 
     sampler: a DeviceSampler with n_slots >= 2 * the largest group; step_fn(batch): enqueues one training step."""
 
-    def __init__(self, sampler, step_fn, group_max=None, mode="streams"):
+    def __init__(self, sampler, step_fn, group_max=None, mode="serial"):
         self.smp, self.step_fn = sampler, step_fn
         self.half = sampler.n_slots // 2 if group_max is None else int(group_max)
         if 2 * self.half > sampler.n_slots:

@@ -98,9 +98,9 @@ enum kge_status {
  * fragments from the table rows themselves (4 launches).  Validation / A-B aid: same results within rounding. */
 #define KGE_FLAG_SPLIT_FWD 128u
 
-/* merged first launch: let the backward GEMM gather the negative rows from the entity table through neg_ids (index table in
- * LDS + barrier) instead of reading the dense copy the edge-forward half writes (tuning / A-B aid) */
-#define KGE_FLAG_GATHER_BWD 256u
+/* merged first launch: the edge-forward half also writes a dense copy of the negative rows and the backward GEMM reads it
+ * instead of gathering the rows from the entity table through neg_ids (tuning / A-B aid: same speed, +1.6 MB of writes) */
+#define KGE_FLAG_DENSE_BWD 256u
 
 /* merged first launch: forward tiles with direct fragment loads of x, r and b (three gathered loads per k-step) instead of the
  * pos-side tile built once per workgroup in LDS (tuning / A-B aid) */

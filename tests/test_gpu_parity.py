@@ -129,7 +129,7 @@ def test_dropin_model_matches_reference(name):
     _close(m.relation_emb.emb.cpu(), z["final_relation"], 1e-4, 1e-2 * case["lr"], name + " final relation")
 
 
-@pytest.mark.parametrize("flags", [0, 1, 2, 8, 128], ids=["auto", "force_pairwise", "no_transe_fast", "fused_loss", "split_fwd"])
+@pytest.mark.parametrize("flags", [0, 1, 2, 8, 128, 512], ids=["auto", "force_pairwise", "no_transe_fast", "fused_loss", "split_fwd", "direct_tiles"])
 @pytest.mark.parametrize("name", golden_names(transr=False))
 def test_fused_step_matches_reference(name, flags):
     """kge_step_fused (one call per step) vs the reference's recorded scores / gradients / tables;
@@ -184,7 +184,7 @@ SHAPES = [
 ]
 
 
-@pytest.mark.parametrize("flags", [0, 8, 128], ids=["loss_kernel", "fused_loss", "split_fwd"])
+@pytest.mark.parametrize("flags", [0, 8, 128, 512 + 256], ids=["loss_kernel", "fused_loss", "split_fwd", "direct_tiles_dense_bwd"])
 @pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "%s-B%d-N%d-D%d" % (s[0], s[6], s[7], s[3]))
 def test_fused_step_matches_oracle_at_config_shapes(shape, flags):
     from dglke_amd import plan
@@ -274,7 +274,9 @@ def test_merged_forward_launch_equals_split_launches_bit_for_bit(model, gamma):
         bt = O.synth_batch(rng, n_ent, n_rel, B, N, N, step)
         plans.append(plan.build_plan(bt["h"], bt["t"], bt["r"], bt["neg"], N, N, bt["neg_head"]))
     results = []
-    for flags in (0, _lib.FLAG_SPLIT_FWD):
+    # ... and the other launch variants of round 3 (direct-load forward tiles, dense copy of the negative rows for the backward):
+    # the same products in the same order
+    for flags in (0, _lib.FLAG_SPLIT_FWD, _lib.FLAG_FWD_DIRECT, _lib.FLAG_DENSE_BWD, _lib.FLAG_FWD_DIRECT | _lib.FLAG_DENSE_BWD):
         torch.manual_seed(0)
         eng = StepEngine(model, n_ent, n_rel, D, gamma, 0.25, DEV, False, False, True, 1.0, 1e-9, 3, flags=flags)
         batches = plan.upload(plans, DEV)
@@ -286,8 +288,9 @@ def test_merged_forward_launch_equals_split_launches_bit_for_bit(model, gamma):
         torch.cuda.synchronize()
         results.append((eng.ent.cpu().numpy().copy(), eng.rel.cpu().numpy().copy(), eng.ent_state.cpu().numpy().copy(),
                         eng.rel_state.cpu().numpy().copy(), np.array(eng.read_loss_sums()), np.stack(scores)))
-    for k in range(6):
-        assert np.array_equal(results[0][k], results[1][k]), "merged vs split forward: output %d differs" % k
+    for v in range(1, len(results)):
+        for k in range(6):
+            assert np.array_equal(results[0][k], results[v][k]), "launch variant %d: output %d differs from the default" % (v, k)
     assert np.isfinite(results[0][4]).all()
 
 
@@ -479,7 +482,7 @@ def _random_step_case(seed):
     chunk = int(rng.choice([1, 3, 4, 7, 8, 16, 17, 24, 32, 40]))
     C = int(rng.randint(1, 5))
     N = int(rng.choice([1, 2, 4, 5, 8, 12, 16, 20, 32, 36, 64]))
-    flags = int(rng.choice([0, 0, 0, 1, 2, 8, 10, 16, 32, 33, 128, 130]))
+    flags = int(rng.choice([0, 0, 0, 1, 2, 8, 10, 16, 32, 33, 128, 130, 512, 256, 768]))
     return dict(model=model, de=de, dr=dr, hidden=hidden, chunk=chunk, C=C, N=N, flags=flags,
                 n_ent=int(rng.choice([30, 200, 2000])), n_rel=int(rng.choice([3, 17])),
                 adv=bool(rng.randint(2)), reg=float(rng.choice([0.0, 1e-4])), gamma=float(rng.choice([6.0, 12.0])),
@@ -684,7 +687,7 @@ def _wide_step_case(seed):
     chunk = int(rng.choice([8, 16, 24, 40, 64]))
     C = int(rng.randint(1, 4))
     N = int(rng.choice([8, 16, 20, 32, 64, 72]))
-    flags = int(rng.choice([0, 0, 0, 8, 8, 1, 2, 16, 32, 128]))
+    flags = int(rng.choice([0, 0, 0, 8, 8, 1, 2, 16, 32, 128, 512, 256]))
     return dict(model=model, de=de, dr=dr, hidden=hidden, chunk=chunk, C=C, N=N, flags=flags,
                 n_ent=int(rng.choice([100, 3000])), n_rel=int(rng.choice([5, 40])),
                 adv=bool(rng.randint(2)), reg=float(rng.choice([0.0, 1e-6])), gamma=float(rng.choice([12.0, 19.9])),
