@@ -1,23 +1,25 @@
 """bench_dist.py - N>1 leg of bench.py: weak-scaled, one process per GPU (torch.distributed, backend
-nccl = RCCL), entity AND relation tables range-sharded over the ranks' HBM.
+nccl = RCCL), the entity table range-sharded over the ranks' HBM.
 
 Default workload = BASELINE.json configs[4]: RotatE on a synthetic Freebase-sized graph (hidden 400 -de: D_e = 800,
 D_r = 400; per-GPU batch 1024, neg 256; 86 054 151 entities / 14 824 relations at 8 GPUs - examples/README.md:11 of
 the reference), WEAK-scaled in both dimensions: every GPU runs the same step and holds the same 1/8 of the Freebase
 entity table (10 756 769 rows = 34.4 GB), so N GPUs train a graph of N/8 x Freebase and N = 8 is configs[4]
-itself.  The SAME workload runs at N = 1 (`python bench.py --gpus 1 --workload rotate_freebase`: one shard,
-kge_step_sharded through a 1-entry shard map), so 1 / 2 / 4 / 8 is one curve; the N = 1 DEFAULT of bench.py stays
+itself.  The SAME workload runs at N = 1 (`python bench.py --gpus 1 --workload rotate_freebase`: one shard, the same
+route -> pull -> step -> push -> apply schedule without collectives), so 1 / 2 / 4 / 8 is one curve; the N = 1 DEFAULT of bench.py stays
 configs[1] (the configuration BASELINE.json's metric is quoted on).  `--workload transe_l2_freebase`: the N=1
 bench's step on the same tables.
 
-Two multi-GPU modes (KGE_DIST_MODE):
-  p2p (default)  the shared-table Hogwild mode of the reference's multi-GPU trainer with the shared
-                 table living in the union of the GPUs' HBM: every rank maps all peer shards
-                 (hipIpc) and kge_step_sharded reads / updates remote rows directly over xGMI.  No
-                 collective and no host work per step; [1 sampler launch + G steps] per hipGraph.
-  a2a            the parameter-server semantics (pull -> compute -> push, owner applies) as RCCL
-                 all-to-all collectives (dglke_amd/dist.py).  Also the automatic fall-back when the
-                 peer mappings cannot be established.
+Two multi-GPU modes (KGE_DIST_MODE), one is the headline, the other a bounded secondary leg on the same line:
+  a2a (default)  BASELINE.json's north_star partitioning: entity table range-sharded, relation table replicated, the
+                 parameter-server semantics (pull -> compute -> push, owner applies) as RCCL all-to-all collectives
+                 (dglke_amd/dist.py): routing on the device, fixed-size messages, no host work in the step; the pull of
+                 step s+1 overlaps step s (one-step-stale rows, the reference's --async_update licence).  Eager launches
+                 (RCCL collectives do not replay reliably from hipGraphs on this stack); at N = 1 there is no collective
+                 and [1 sampler launch + G steps] replay from a hipGraph.
+  p2p            the shared-table Hogwild mode of the reference's multi-GPU trainer with the shared table living in the
+                 union of the GPUs' HBM: every rank maps all peer shards (hipIpc) and kge_step_sharded reads / updates
+                 remote rows directly over xGMI (BOTH tables sharded).  No collective and no host work per step.
 value = (steps x batch x N) / max-over-ranks wall time.
 """
 import json
@@ -113,9 +115,10 @@ def _p2p_setup(args, world, rank, dev, w, n_ent, d_e, d_r, emb_init):
 
 
 def _a2a_setup(args, world, rank, dev, w, n_ent, d_e, emb_init):
-    """parameter-server semantics over RCCL all-to-all (dglke_amd/dist.py)."""
-    from dglke_amd import plan
+    """parameter-server semantics over RCCL all-to-all (dglke_amd/dist.py): entity table range-sharded, relation table
+    replicated, device-side routing, fixed-size messages, on-device sampler inside the timed region."""
     from dglke_amd import dist as kd
+    from dglke_amd.dataloader import DeviceSampler
     from dglke_amd.engine import StepEngine
     spec = kd.ShardSpec(n_ent, world, rank)
     torch.manual_seed(1234 + rank)
@@ -124,39 +127,63 @@ def _a2a_setup(args, world, rank, dev, w, n_ent, d_e, emb_init):
     torch.manual_seed(99)          # identical relation replicas on every rank
     eng = StepEngine(w["model"], 1, w["n_rel"], w["hidden"], w["gamma"], w["lr"], dev, w["de"], w["dr"],
                      w["adv"], w["adv_temp"], w["reg_coef"], w["reg_norm"])
-    de = kd.DistEngine(eng, spec, ent, ent_state)
-    # pre-stage a pool of batches: ids (uniform, like the N=1 bench), plans, routes
-    pool = max(8, min(args.pool, 64))
-    rng = np.random.RandomState(1000 + rank)
-    C = w["B"] // w["N"]
-    plans, ues = [], []
-    for s in range(pool):
-        h = rng.randint(0, n_ent, w["B"]).astype(np.int64)
-        t = rng.randint(0, n_ent, w["B"]).astype(np.int64)
-        r = rng.randint(0, w["n_rel"], w["B"]).astype(np.int64)
-        neg = rng.randint(0, n_ent, C * w["N"]).astype(np.int64)
-        ue, p = kd.localize_plan(h, t, r, neg, w["N"], w["N"], (s + 1) % 2 == 0)
-        plans.append(p)
-        ues.append(ue)
-    batches = plan.upload(plans, dev)
-    routes = [de.prepare_route(ue) for ue in ues]
-    for b in batches:
-        eng.workspace_for(b)
-    de.max_rows = int(max(max(r.UE for r in routes), max(r.n_recv for r in routes)) * 1.25) + 64
-    de.step(batches[0], routes[0])     # allocates every persistent buffer
-    torch.cuda.synchronize()
-    state = {"pos": 0}
+    de = kd.DistEngine(eng, spec, ent, ent_state, slack=float(os.environ.get("KGE_DIST_SLACK", "1.5")))
+    # this rank's edge shard: synthetic uniform triples over the GLOBAL id space, generated in HBM
+    n_train = int(os.environ.get("KGE_DIST_TRIPLES", min(338586276 // world, 48_000_000)))
+    g = torch.Generator(device=dev)
+    g.manual_seed(777 + rank)
+    H = torch.randint(0, n_ent, (n_train,), device=dev, generator=g)
+    T = torch.randint(0, n_ent, (n_train,), device=dev, generator=g)
+    R = torch.randint(0, w["n_rel"], (n_train,), device=dev, generator=g)
+    G = max(2, min(120, args.graph_steps) // 2 * 2)
+    smp = DeviceSampler(H, R, T, n_ent, w["B"], w["N"], dev, n_slots=G, seed=rank + 1)
+    pipelined = world > 1 and os.environ.get("KGE_DIST_PIPELINE", "1") != "0"
 
-    def run(count):
-        for _ in range(count):
-            i = state["pos"] % pool
-            de.step(batches[i], routes[i])
-            state["pos"] += 1
-    rows = dict(UE=float(np.mean([p["UE"] for p in plans])),
-                R_e=float(np.mean([p["U"] + C * w["N"] for p in plans])), B=w["B"])
-    desc = ("entity table range-sharded, relation table replicated, RCCL all-to-all pull/push with owner-side "
-            "Adagrad (parameter-server semantics), eager launches, host-built batches pre-staged")
-    return eng, run, rows, desc
+    def steps(dbs):
+        for k, b in enumerate(dbs):
+            if pipelined:
+                de.step_pipelined(b, dbs[k + 1] if k + 1 < len(dbs) else None)
+            else:
+                de.step(b)
+    dbs = smp.sample()
+    eng.workspace_for(dbs[0])
+    steps(dbs[:4])                      # eager warm-up: allocates every persistent buffer
+    torch.cuda.synchronize()
+    graphs = {}
+    use_graph = world == 1 and not args.no_graph      # no collective at world 1: the whole group replays from a hipGraph
+
+    def run(count):                     # EXACTLY count steps: groups of G, then one partial group (one sampler launch each)
+        left = count
+        while left > 0:
+            n = min(G, left)
+            if use_graph:
+                if n not in graphs:
+                    graphs[n] = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graphs[n]):
+                        steps(smp.sample(n))
+                graphs[n].replay()
+            else:
+                steps(smp.sample(n))
+            left -= n
+    if use_graph:                       # capture outside the timed region
+        for n in {G, args.warmup % G, args.steps % G} - {0}:
+            graphs[n] = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graphs[n]):
+                steps(smp.sample(n))
+        torch.cuda.synchronize()
+    C = w["B"] // w["N"]
+    a_ = smp.slot_arrays(0)
+    u_pos = int(np.unique(np.concatenate([a_["h_gid"], a_["t_gid"]])).shape[0])
+    ue = int(np.unique(np.concatenate([a_["h_gid"], a_["t_gid"], a_["neg_ids"]])).shape[0])
+    rows = dict(UE=ue, R_e=u_pos + C * w["N"], B=w["B"], cap=de.cap)
+    desc = ("entity table range-sharded, relation table replicated; per step: device-side routing into %d-row owner buckets, "
+            "all-to-all pull of the unique rows, the single-GPU kernels against the row cache, all-to-all push of one packed "
+            "gradient message per row, owner-side Adagrad in rank order (one merged launch), relation gradients all-gathered "
+            "(parameter-server semantics, RCCL); %s; sampling + plan on the device inside the timed region"
+            % (de.cap, "hipGraph of [1 sampler launch + %d steps]" % G if use_graph else
+               ("eager launches, pull of step s+1 overlapped with step s (one-step-stale rows, --async_update licence)"
+                if pipelined else "eager launches")))
+    return eng, run, rows, desc, de
 
 
 def main(args, world, rank, local_rank):
@@ -177,7 +204,10 @@ def main(args, world, rank, local_rank):
     d_r = 2 * w["hidden"] if w["dr"] else w["hidden"]
     emb_init = (w["gamma"] + 2.0) / w["hidden"]
 
-    mode = os.environ.get("KGE_DIST_MODE", "p2p")
+    # headline mode = the partitioning BASELINE.json's north_star names (entity range-shard + RCCL all-to-all, relations
+    # replicated); KGE_DIST_MODE=p2p makes the peer-to-peer shared-table mode the headline instead.  The other mode is timed as
+    # a secondary leg (bounded, under a watchdog) and reported next to the headline, never instead of it.
+    mode = os.environ.get("KGE_DIST_MODE", "a2a")
     eng = run = rows = desc = tabs = None
     why = ""
     if mode == "p2p":
@@ -194,7 +224,7 @@ def main(args, world, rank, local_rank):
             mode, eng, run, tabs = "a2a", None, None, None
             torch.cuda.empty_cache()
     if mode != "p2p":
-        eng, run, rows, desc = _a2a_setup(args, world, rank, dev, w, n_ent, d_e, emb_init)
+        eng, run, rows, desc, _de = _a2a_setup(args, world, rank, dev, w, n_ent, d_e, emb_init)
 
     run(args.warmup)
     torch.cuda.synchronize()
@@ -211,58 +241,86 @@ def main(args, world, rank, local_rank):
     wall = float(tw.item())
     sums = eng.read_loss_sums()
     K = args.steps
-    # secondary leg at N > 1: the parameter-server semantics over RCCL all-to-all (the partitioning north_star names:
-    # entity table range-sharded, relation table replicated, pull / push collectives), eager launches, a bounded
-    # number of steps, under a watchdog - a hung collective must never cost the headline line
-    a2a_leg = {"result": None}
-    want_a2a = mode == "p2p" and world > 1 and os.environ.get("KGE_DIST_A2A_LEG", "1") != "0"
+    overflow = _de.check_overflow() if mode != "p2p" else 0
+    other = "p2p" if mode == "a2a" else "a2a"
+    want_other = world > 1 and os.environ.get("KGE_DIST_OTHER_LEG", "1") != "0"
+    import threading
+    lock = threading.Lock()
+    state = {"emitted": False}
 
-    def emit(a2a):
+    def emit(leg, now=True):
+        with lock:                       # the watchdog and the main thread may both get here: ONE line
+            if state["emitted"]:
+                return None
+            state["emitted"] = True
         if rank != 0:
-            return
-        line = _result_line(args, w, n_ent, world, wall, K, rows, d_e, eng.d_r, desc, mode, why, sums, a2a)
-        print(json.dumps(line), flush=True)
+            return None
+        line = json.dumps(_result_line(args, w, n_ent, world, wall, K, rows, d_e, eng.d_r, desc, mode, why, sums, other, leg,
+                                       overflow))
+        if now:
+            print(line, flush=True)
+        return line
 
-    if want_a2a:
-        import threading
+    leg = None
+    if want_other:
         done = threading.Event()
 
         def watchdog():
-            if not done.wait(float(os.environ.get("KGE_DIST_A2A_TIMEOUT", "90"))):
-                emit({"error": "all-to-all leg did not finish in time (watchdog)"})
+            if not done.wait(float(os.environ.get("KGE_DIST_LEG_TIMEOUT", "120"))):
+                emit({"error": "the %s leg did not finish in time (watchdog)" % other})
                 os._exit(0)
         th = threading.Thread(target=watchdog, daemon=True)
         th.start()
         try:
-            a_steps = max(20, min(K, 200))
-            aeng, arun, arows, adesc = _a2a_setup(args, world, rank, dev, w, n_ent, d_e, emb_init)
-            arun(min(20, a_steps))
+            l_steps = max(20, min(K, 240))
+            if other == "p2p":
+                leng, lrun, lrows, ldesc, ltabs = _p2p_setup(args, world, rank, dev, w, n_ent, d_e, d_r, emb_init)
+            else:
+                leng, lrun, lrows, ldesc, _ = _a2a_setup(args, world, rank, dev, w, n_ent, d_e, emb_init)
+                ltabs = None
+            lrun(min(20, l_steps))
             torch.cuda.synchronize(); dist.barrier()
             t0 = time.perf_counter()
-            arun(a_steps)
+            lrun(l_steps)
             torch.cuda.synchronize(); dist.barrier()
             aw = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
             dist.all_reduce(aw, op=dist.ReduceOp.MAX)
-            a2a_leg["result"] = {"value": round(a_steps * w["B"] * world / float(aw.item()), 1), "unit": "edges/s",
-                                 "steps": a_steps, "us_per_step": round(1e6 * float(aw.item()) / a_steps, 2),
-                                 "collectives_per_step": "2 all_to_all_single (rows, packed gradients) + 1 all_gather (relation "
-                                                         "gradients); ids routed ahead", "launch": "eager", "desc": adesc}
+            leg = {"value": round(l_steps * w["B"] * world / float(aw.item()), 1), "unit": "edges/s", "steps": l_steps,
+                   "us_per_step": round(1e6 * float(aw.item()) / l_steps, 2), "desc": ldesc}
+            if ltabs is not None:
+                tabs = ltabs
         except Exception as e:          # noqa: BLE001
-            a2a_leg["result"] = {"error": repr(e)}
+            leg = {"error": repr(e)}
         done.set()
-    emit(a2a_leg["result"])
-    dist.barrier()
-    if tabs is not None:
-        tabs.close()
-    dist.destroy_process_group()
+    line = emit(leg, now=False)
+    try:
+        dist.barrier()
+        if tabs is not None:
+            tabs.close()
+    finally:
+        dist.destroy_process_group()
+    if line is not None:
+        # RCCL prints its version banner through C stdio, which is flushed at exit when stdout is a file: push it out first so
+        # that the JSON line is the LAST line of stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:       # noqa: BLE001
+            pass
+        print(line, flush=True)
 
 
-def _result_line(args, w, n_ent, world, wall, K, rows, d_e, d_r, desc, mode, why, sums, a2a):
+def _result_line(args, w, n_ent, world, wall, K, rows, d_e, d_r, desc, mode, why, sums, other, leg, overflow):
     if True:
         # algorithmic bytes per rank-step (SURVEY 8d formula on the sampled batches)
         bytes_step = 12.0 * (rows["R_e"] * d_e + rows["B"] * d_r) + 16.0 * (rows["R_e"] + rows["B"])
-        # rows crossing xGMI per rank-step: every traced row is read once and read-modify-written once
-        xgmi_step = 3.0 * (rows["R_e"] * d_e + rows["B"] * d_r) * 4 * (world - 1) / world
+        # bytes crossing xGMI per rank-step.  p2p: every traced row is read once and read-modify-written once.  a2a: fixed-size
+        # buckets - ids (8 B), rows (4 D_e) and packed gradient messages (4 (2 D_e + 4)) per bucket row, + the relation all-gather
+        if mode == "p2p":
+            xgmi_step = 3.0 * (rows["R_e"] * d_e + rows["B"] * d_r) * 4 * (world - 1) / world
+        else:
+            cap = rows.get("cap") or rows["UE"]
+            xgmi_step = ((world - 1) * cap * (8 + 4 * d_e + 4 * (2 * d_e + 4)) + (world - 1) * rows["B"] * 4 * (d_r + 4)) * 1.0
         out = {
             "metric": "positive edges/sec (whole node)",
             "value": round(K * w["B"] * world / wall, 1), "unit": "edges/s",
@@ -277,7 +335,7 @@ def _result_line(args, w, n_ent, world, wall, K, rows, d_e, d_r, desc, mode, why
                                       "" if world == 1 else "s", (n_ent + world - 1) // world * d_e * 4 / 1e9, desc),
                        "global_batch": w["B"] * world,
                        "parallelism": ("shared tables over %d GPUs' HBM, peer-to-peer xGMI (Hogwild)" % world)
-                       if mode == "p2p" else ("entity-shard x%d (RCCL all-to-all)" % world),
+                       if mode == "p2p" else ("entity-shard x%d, relations replicated (RCCL all-to-all)" % world),
                        "mode": mode, "fallback_reason": why or None},
             "roofline": {"bound": "hbm", "achieved": round(bytes_step * world / (wall / K) / 1e9, 2),
                          "peak": 8000.0 * world, "unit": "GB/s",
@@ -290,6 +348,9 @@ def _result_line(args, w, n_ent, world, wall, K, rows, d_e, d_r, desc, mode, why
             "n1_same_workload": "python bench.py --gpus 1 --workload %s" % args.workload if args.workload in DIST_WORKLOADS
                                 else "python bench.py --gpus 1 --workload rotate_freebase",
         }
-        if a2a is not None:
-            out["a2a"] = a2a
+        if mode == "a2a":
+            out["config"]["bucket_rows"] = rows.get("cap")
+            out["config"]["bucket_overflows"] = overflow
+        if leg is not None:
+            out[other] = leg
         return out

@@ -800,6 +800,7 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         ua.g0 = emit->g0; ua.gs0 = emit->gs0; ua.g1 = emit->g1; ua.gs1 = emit->gs1;
         ua.gr = emit->gr; ua.gsr = emit->gsr; ua.rid = emit->rid;
         ua.emit_ent = 1; ua.emit_rel = emit->gr ? 1 : 0;
+        ua.emit_by_id = emit->ent_by_id ? 1 : 0;
         if (emit->ld_e > 0) { ua.ld_e = emit->ld_e; ua.ld_gs_e = emit->ld_e; }
         if (emit->ld_r > 0) { ua.ld_r = emit->ld_r; ua.ld_gs_r = emit->ld_r; }
     }

@@ -353,6 +353,7 @@ struct UpdateArgs {
     // emit mode (sharded training): write gradients instead of updating the entity table
     float *g0, *gs0, *g1, *gs1, *gr, *gsr;
     int emit_ent, emit_rel;
+    int emit_by_id;                  // entity messages are written at row `id` (the cache row of dist.py) instead of union entry u
     int ld_e, ld_r;                  // row strides of the emit buffers (floats)
     int32_t *rid;                    // optional relation-id words inside the relation message
     int ld_gs_e, ld_gs_r;            // strides of gs0/gs1 and gsr

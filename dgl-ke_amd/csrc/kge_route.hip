@@ -1,0 +1,255 @@
+// kge_route.hip - device side of the range-sharded multi-GPU step (dglke_amd/dist.py): everything the
+// parameter-server semantics of the reference (KEModel.pull_model / push_gradient, models/general_models.py:650-680; server-side
+// Adagrad, kvserver.py:41-51) needs around the collectives, with NO host round trip:
+//   route_build   the sorted unique entity ids of a batch (the plan of kge_sample_batches / dglke_amd/plan.py) are cut into owner
+//                 buckets of FIXED capacity -> request ids per owner (-1 padded), and the batch re-addressed to "cache rows"
+//                 (owner * cap + position in that owner's bucket), so that the fixed-size all-to-all results ARE the row cache;
+//   gather_req    owner side of the pull: rows of the requested ids (global id - shard offset), pads skipped;
+//   apply_merged  owner side of the push: the messages of all source ranks are applied by the wavefront that owns the FIRST
+//                 occurrence of a row, in source-rank order (a k-ary search finds the same row in the other ranks' sorted
+//                 buckets) - one launch, no atomics, bit-reproducible, the order of ExternalEmbedding.update per trace.
+#include "kge_common.hpp"
+
+using namespace kge;
+
+static inline int check_launch_r() { return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH; }
+
+#define RT_THREADS 256
+#define RT_MAX_WORLD 64
+
+struct RouteArgs {
+    int UEmax, B, CN, world, cap;
+    int64_t per;                               // entity rows per shard (owner = id / per)
+    const int64_t *ue_id; const int32_t *ue_rec; const int32_t *ue_pos_adj, *ue_neg_slot; const int32_t *counts_dev;
+    int64_t *req_ids;                          // [world * cap] global ids requested from each owner, -1 padded
+    int64_t *h_loc, *t_loc, *neg_loc;          // [B], [B], [C*N] cache rows of the edge ends / negative slots
+    int64_t *ue_loc;                           // [UEmax] cache row of union entry u
+    int32_t *ue_rec_loc;                       // [UEmax][8] plan records with the id words replaced by the cache row
+    int32_t *overflow;                         // += entries that did not fit their owner's bucket (must stay 0)
+};
+
+// grid: enough workgroups of RT_THREADS threads for max(UEmax, world * cap) items.  Every workgroup finds the bucket boundaries
+// itself (a scan of the <= 4096 sorted ids: independent loads, ~1 us) instead of waiting for one workgroup to publish them.
+__global__ __launch_bounds__(RT_THREADS) void route_build_kernel(RouteArgs a) {
+    __shared__ int start[RT_MAX_WORLD + 1];
+    const int t = threadIdx.x;
+    const int cnt = a.counts_dev ? min(a.counts_dev[0], a.UEmax) : a.UEmax;
+    const bool small = a.per < 0x7fffffffLL && (a.per * a.world) < 0x7fffffffLL;     // 32-bit owner arithmetic when the ids fit
+    auto owner_of = [&](int64_t id) -> int {
+        return small ? (int)((uint32_t)id / (uint32_t)a.per) : (int)(id / a.per);
+    };
+    for (int o = t; o <= a.world; o += RT_THREADS) start[o] = cnt;
+    __syncthreads();
+    // bucket boundaries: ue_id is sorted, so owner o's entries are one contiguous run; entry u opens the runs of all owners in
+    // (owner(u-1), owner(u)]
+    for (int u = t; u < cnt; u += RT_THREADS) {
+        const int o = owner_of(a.ue_id[u]);
+        const int op = u ? owner_of(a.ue_id[u - 1]) : -1;
+        for (int k = op + 1; k <= o && k < a.world; ++k) start[k] = u;
+    }
+    __syncthreads();
+    const int u = (int)blockIdx.x * RT_THREADS + t;
+    if (u < cnt) {
+        const int64_t id = a.ue_id[u];
+        const int o = min(owner_of(id), a.world - 1);
+        const int pos = u - start[o];
+        const int4 r0 = reinterpret_cast<const int4 *>(a.ue_rec)[2 * u];
+        const int4 r1 = reinterpret_cast<const int4 *>(a.ue_rec)[2 * u + 1];
+        if (pos >= a.cap) {                    // does not fit: counted; the entry trains against the dump row world * cap this step
+            atomicAdd(a.overflow, 1);
+        } else {
+            a.req_ids[(int64_t)o * a.cap + pos] = id;
+        }
+        const int64_t cr = pos < a.cap ? (int64_t)o * a.cap + pos : (int64_t)a.world * a.cap;
+        a.ue_loc[u] = cr;
+        int4 q0 = r0;
+        q0.x = (int)(cr & 0xffffffff); q0.y = (int)(cr >> 32);
+        reinterpret_cast<int4 *>(a.ue_rec_loc)[2 * u] = q0;
+        reinterpret_cast<int4 *>(a.ue_rec_loc)[2 * u + 1] = r1;
+        // first entries of the two lists sit in the record itself; the (rare) rest is read from the list arrays
+        if (r0.w > r0.z) {
+            ((r1.z & 1) ? a.t_loc : a.h_loc)[r1.z >> 1] = cr;
+            for (int p = r0.z + 1; p < r0.w; ++p) {
+                const int adj = a.ue_pos_adj[p];
+                ((adj & 1) ? a.t_loc : a.h_loc)[adj >> 1] = cr;
+            }
+        }
+        if (r1.y > r1.x) {
+            a.neg_loc[r1.w] = cr;
+            for (int p = r1.x + 1; p < r1.y; ++p) a.neg_loc[a.ue_neg_slot[p]] = cr;
+        }
+    }
+    // pads of the request buckets
+    const int k = (int)blockIdx.x * RT_THREADS + t;
+    if (k < a.world * a.cap) {
+        const int o = k / a.cap, pos = k % a.cap;
+        const int n = min(start[o + 1], cnt) - min(start[o], cnt);
+        if (pos >= n) a.req_ids[k] = -1;
+    }
+}
+
+template <int V>
+__global__ __launch_bounds__(KGE_BLOCK) void gather_req_kernel(const float *__restrict__ table, int dim, const int64_t *__restrict__ ids,
+                                                               int64_t id_offset, int64_t n_rows, int64_t n, float *__restrict__ out) {
+    const int64_t k = (int64_t)blockIdx.x * KGE_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (k >= n) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t id = ids[k] - id_offset;
+    if (ids[k] < 0 || id < 0 || id >= n_rows) return;          // pad (or an id this shard does not own): row left as it is
+    const float *src = table + id * (int64_t)dim;
+    float *dst = out + k * (int64_t)dim;
+    for (int it = lane; it < dim / V; it += 64) st<V>(dst + it * V, ld<V>(src + it * V));
+}
+
+// ---- merged owner-side apply -----------------------------------------------------------------------------------------
+struct MergeArgs {
+    float *table, *state;
+    int64_t n_rows, id_offset;
+    int dim, nsrc, cap, ld, ntraces;
+    const int32_t *idw; int64_t id_stride;     // id of message k: words idw[k * id_stride], idw[k * id_stride + 1] (lo, hi)
+    const float *msg;                          // [nsrc * cap][ld]: [g_0 | .. | g_{T-1} | gs_0 .. gs_{T-1} | ...]
+    float lr, eps;
+};
+__device__ __forceinline__ int64_t merge_id(const MergeArgs &a, int64_t k) {
+    const int32_t *w = a.idw + k * a.id_stride;
+    return (int64_t)(uint32_t)w[0] | ((int64_t)w[1] << 32);
+}
+__device__ __forceinline__ uint64_t merge_key(int64_t id) { return id < 0 ? ~0ull : (uint64_t)id; }    // pads sort last
+
+template <int NIT>      // row width <= 256 * NIT floats, dim % 4 == 0
+__global__ __launch_bounds__(KGE_BLOCK) void apply_merged_kernel(MergeArgs a) {
+    const int64_t k = (int64_t)blockIdx.x * KGE_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (k >= (int64_t)a.nsrc * a.cap) return;
+    const int lane = threadIdx.x & 63;
+    const int src = (int)(k / a.cap);
+    const int64_t gid = merge_id(a, k);
+    if (gid < 0) return;
+    const int64_t id = gid - a.id_offset;
+    if (id < 0 || id >= a.n_rows) return;
+    // ---- the same id in the other sources' sorted buckets: a k-ary search per source, Lg lanes probing together ----
+    int lgs = 1;
+    while (lgs * 2 * a.nsrc <= 64) lgs *= 2;            // lanes per source (power of two), nsrc <= 64
+    const int g = lane / lgs, j = lane % lgs;
+    const bool active = g < a.nsrc && g != src;
+    int lo = 0, hi = active ? a.cap : 0, found = -1;
+    const uint64_t X = (uint64_t)gid;
+    const uint64_t gmask = lgs == 64 ? ~0ull : ((1ull << lgs) - 1ull);
+    while (__any(hi > lo)) {
+        const int n = hi - lo;
+        const bool fin = n <= lgs;
+        const int p = fin ? lo + j : lo + (int)(((int64_t)(j + 1) * n) / (lgs + 1));
+        const bool valid = hi > lo && (!fin || j < n);
+        const uint64_t v = valid ? merge_key(merge_id(a, (int64_t)g * a.cap + p)) : ~0ull;
+        const uint64_t beq = __ballot(valid && v == X), blt = __ballot(valid && v < X);
+        const uint64_t geq = (beq >> (g * lgs)) & gmask, glt = (blt >> (g * lgs)) & gmask;
+        if (hi > lo) {
+            if (geq) {
+                const int jj = __builtin_ctzll(geq);
+                found = fin ? lo + jj : lo + (int)(((int64_t)(jj + 1) * n) / (lgs + 1));
+                lo = hi;
+            } else if (fin) {
+                lo = hi;
+            } else {
+                const int c = __builtin_popcountll(glt);      // probes are ascending: the first c are < X
+                const int nlo = c > 0 ? lo + (int)(((int64_t)c * n) / (lgs + 1)) + 1 : lo;
+                const int nhi = c < lgs ? lo + (int)(((int64_t)(c + 1) * n) / (lgs + 1)) : hi;
+                lo = nlo; hi = nhi;
+            }
+        }
+    }
+    // a lower source holds the row too: its wavefront applies every occurrence
+    const uint64_t bf = __ballot(found >= 0 && j == 0);
+    for (int s = 0; s < src; ++s) if ((bf >> (s * lgs)) & 1ull) return;
+    // ---- apply: own message, then the higher sources' in rank order; the row stays in registers ----
+    const int d = a.dim, nit = d >> 2;
+    float *row = a.table + id * (int64_t)d;
+    Pack<4> x[NIT];
+#pragma unroll
+    for (int q = 0; q < NIT; ++q) x[q] = ld<4>(row + min(lane + 64 * q, nit - 1) * 4);
+    float st = a.state[id];
+    bool any = false;
+    for (int s = src; s < a.nsrc; ++s) {
+        int pos;
+        if (s == src) pos = (int)(k % a.cap);
+        else {
+            if (!((bf >> (s * lgs)) & 1ull)) continue;
+            pos = __builtin_amdgcn_readlane(found, s * lgs);
+        }
+        const float *m = a.msg + ((int64_t)s * a.cap + pos) * a.ld;
+        for (int t = 0; t < a.ntraces; ++t) {
+            const float inc = m[(int64_t)a.ntraces * d + t];
+            if (inc == 0.f) continue;
+            any = true;
+            st += inc;
+            const float kf = -a.lr / (sqrtf(st) + a.eps);
+            const float *gp = m + (int64_t)t * d;
+#pragma unroll
+            for (int q = 0; q < NIT; ++q) {
+                const Pack<4> gv = ld<4>(gp + min(lane + 64 * q, nit - 1) * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[q].v[e] = fmaf(gv.v[e], kf, x[q].v[e]);
+            }
+        }
+    }
+    if (!any) return;
+#pragma unroll
+    for (int q = 0; q < NIT; ++q) if (lane + 64 * q < nit) st_wt<4>(row + (lane + 64 * q) * 4, x[q]);
+    if (lane == 0) a.state[id] = st;
+}
+
+extern "C" {
+
+int kge_route_build(const kge_batch *b, int world, int64_t rows_per_shard, int cap, int64_t *req_ids, int64_t *h_loc,
+                    int64_t *t_loc, int64_t *neg_loc, int64_t *ue_loc, int32_t *ue_rec_loc, int32_t *overflow, void *stream) {
+    if (!b || !req_ids || !h_loc || !t_loc || !neg_loc || !ue_loc || !ue_rec_loc || !overflow || world < 1 ||
+        world > RT_MAX_WORLD || rows_per_shard <= 0 || cap <= 0 || !b->ue_id || !b->ue_rec || !b->ue_pos_adj || !b->ue_neg_slot)
+        return KGE_ERR_ARG;
+    RouteArgs a{};
+    a.UEmax = b->UE; a.B = b->B; a.CN = b->C * b->N; a.world = world; a.cap = cap; a.per = rows_per_shard;
+    a.ue_id = b->ue_id; a.ue_rec = b->ue_rec; a.ue_pos_adj = b->ue_pos_adj; a.ue_neg_slot = b->ue_neg_slot;
+    a.counts_dev = b->counts_dev;
+    a.req_ids = req_ids; a.h_loc = h_loc; a.t_loc = t_loc; a.neg_loc = neg_loc; a.ue_loc = ue_loc; a.ue_rec_loc = ue_rec_loc;
+    a.overflow = overflow;
+    const int items = a.UEmax > world * cap ? a.UEmax : world * cap;
+    hipLaunchKernelGGL(route_build_kernel, dim3((items + RT_THREADS - 1) / RT_THREADS), dim3(RT_THREADS), 0, (hipStream_t)stream, a);
+    return check_launch_r();
+}
+
+int kge_batch_localized(const kge_batch *b, const int64_t *h_loc, const int64_t *t_loc, const int64_t *neg_loc,
+                        const int64_t *ue_loc, const int32_t *ue_rec_loc, kge_batch *out) {
+    if (!b || !h_loc || !t_loc || !neg_loc || !ue_loc || !ue_rec_loc || !out) return KGE_ERR_ARG;
+    *out = *b;
+    out->h_gid = h_loc; out->t_gid = t_loc; out->neg_ids = neg_loc; out->ue_id = ue_loc; out->ue_rec = ue_rec_loc;
+    return KGE_OK;
+}
+
+int kge_gather_rows_req(const float *table, int64_t n_rows, int dim, const int64_t *ids, int64_t id_offset, int64_t n_ids,
+                        float *out, void *stream) {
+    if (!table || n_rows < 0 || dim <= 0 || n_ids < 0 || (n_ids && (!ids || !out))) return KGE_ERR_ARG;
+    if (n_ids == 0) return KGE_OK;
+    const int nb = (int)((n_ids + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK);
+    if (dim % 4 == 0)
+        hipLaunchKernelGGL(gather_req_kernel<4>, dim3(nb), dim3(KGE_BLOCK), 0, (hipStream_t)stream, table, dim, ids, id_offset, n_rows, n_ids, out);
+    else
+        hipLaunchKernelGGL(gather_req_kernel<1>, dim3(nb), dim3(KGE_BLOCK), 0, (hipStream_t)stream, table, dim, ids, id_offset, n_rows, n_ids, out);
+    return check_launch_r();
+}
+
+int kge_adagrad_apply_merged(float *table, float *state_sum, int64_t n_rows, int dim, int nsrc, int cap, const int32_t *id_words,
+                             int64_t id_stride_words, int64_t id_offset, const float *msg, int ld, int ntraces, float lr, float eps,
+                             void *stream) {
+    if (!table || !state_sum || n_rows < 0 || dim <= 0 || dim % 4 || dim > 1024 || nsrc < 1 || nsrc > RT_MAX_WORLD || cap <= 0 ||
+        !id_words || id_stride_words < 2 || !msg || ld < ntraces * dim + ntraces || ld % 4 || ntraces < 1)
+        return KGE_ERR_ARG;
+    MergeArgs a{};
+    a.table = table; a.state = state_sum; a.n_rows = n_rows; a.id_offset = id_offset; a.dim = dim; a.nsrc = nsrc; a.cap = cap;
+    a.ld = ld; a.ntraces = ntraces; a.idw = id_words; a.id_stride = id_stride_words; a.msg = msg; a.lr = lr; a.eps = eps;
+    const int64_t n = (int64_t)nsrc * cap;
+    const dim3 g((unsigned)((n + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK)), bl(KGE_BLOCK);
+    if (dim <= 256) hipLaunchKernelGGL(apply_merged_kernel<1>, g, bl, 0, (hipStream_t)stream, a);
+    else if (dim <= 512) hipLaunchKernelGGL(apply_merged_kernel<2>, g, bl, 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(apply_merged_kernel<4>, g, bl, 0, (hipStream_t)stream, a);
+    return check_launch_r();
+}
+
+}  // extern "C"

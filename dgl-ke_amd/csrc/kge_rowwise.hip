@@ -700,6 +700,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void update_kernel(UpdateArgs a, int nb_
         const float sA = has_pos ? st0 + s0 : st0;
         const float sB = has_neg ? sA + s1 : sA;
         const float std0 = sqrtf(sA) + a.eps, std1 = sqrtf(sB) + a.eps;
+        const int64_t mu = a.emit_by_id ? id : u;       // message row: union entry, or the row id itself (cache rows, dist.py)
         for (int it = lane; it < nit; it += 64) {
             const int off = it * V;
             Pack<V> x = ld<V>(row + off);
@@ -733,13 +734,13 @@ __global__ __launch_bounds__(KGE_BLOCK) void update_kernel(UpdateArgs a, int nb_
                 }
             }
             if (!a.emit_ent) st<V>(row + off, x);
-            if (a.g0) st<V>(a.g0 + u * (int64_t)a.ld_e + off, g0);
-            if (a.g1) st<V>(a.g1 + u * (int64_t)a.ld_e + off, g1);
+            if (a.g0) st<V>(a.g0 + mu * (int64_t)a.ld_e + off, g0);
+            if (a.g1) st<V>(a.g1 + mu * (int64_t)a.ld_e + off, g1);
         }
         if (lane == 0) {
             if (!a.emit_ent) *srow = sB;
-            if (a.gs0) a.gs0[u * (int64_t)a.ld_gs_e] = has_pos ? s0 : 0.f;
-            if (a.gs1) a.gs1[u * (int64_t)a.ld_gs_e] = has_neg ? s1 : 0.f;
+            if (a.gs0) a.gs0[mu * (int64_t)a.ld_gs_e] = has_pos ? s0 : 0.f;
+            if (a.gs1) a.gs1[mu * (int64_t)a.ld_gs_e] = has_neg ? s1 : 0.f;
         }
         if (reg && (a.reg_ent || a.acc)) {
             rv = wave_sum(rv);
@@ -751,7 +752,10 @@ __global__ __launch_bounds__(KGE_BLOCK) void update_kernel(UpdateArgs a, int nb_
         } else if (a.reg_ent && lane == 0) a.reg_ent[u] = 0.f;
     } else {
         const int64_t u = ((int64_t)blockIdx.x - nb_ent) * KGE_WAVES_PER_BLOCK + (threadIdx.x >> 6);
-        if (u >= (a.counts_dev ? a.counts_dev[1] : a.UR)) return;
+        if (u >= (a.counts_dev ? a.counts_dev[1] : a.UR)) {
+            if (a.rid && u < a.UR && lane == 0) { a.rid[u * (int64_t)a.ld_r] = -1; a.rid[u * (int64_t)a.ld_r + 1] = -1; }   // pad message
+            return;
+        }
         const int d = a.d_r;
         const int64_t id = a.ur_id[u];
         float *row = shard_row(a.rm, a.rel, id, d);

@@ -38,6 +38,8 @@ __device__ __forceinline__ void update_rel_row(const UpdateArgs &a, int bx, int 
     const int4 r1 = reinterpret_cast<const int4 *>(a.ur_rec)[2 * uc + 1];
     const int cnt_r = a.counts_dev ? a.counts_dev[1] : a.UR;
     const bool valid = u < a.UR && u < cnt_r;
+    // gradient-emitting step on a device-built plan: message rows beyond the batch's relation count are pads (id -1)
+    if (!valid && a.rid && u < a.UR && lane == 0) { a.rid[u * (int64_t)a.ld_r] = -1; a.rid[u * (int64_t)a.ld_r + 1] = -1; }
     if (!COOP && !valid) return;
     const int64_t id = valid ? ((int64_t)(uint32_t)r0.x | ((int64_t)r0.y << 32)) : 0;
     const int e0 = valid ? r0.z : 0, e1 = valid ? r0.w : 1, edge0 = valid ? r1.x : 0;
@@ -306,7 +308,7 @@ __device__ __forceinline__ void update_reg_body(const UpdateArgs &a_in, int nb_e
     if constexpr (LEAN != 0) {
         a.transe_fast = (LEAN == 1 || LEAN == 3) ? 1 : 0; a.emit_ent = 0; a.emit_rel = 0;
         if (LEAN != 3) a.Q = nullptr;
-        a.g0 = a.g1 = a.gs0 = a.gs1 = a.gr = a.gsr = nullptr; a.rid = nullptr; a.dry = 0; a.nd_chunk = 0;
+        a.g0 = a.g1 = a.gs0 = a.gs1 = a.gr = a.gsr = nullptr; a.rid = nullptr; a.dry = 0; a.nd_chunk = 0; a.emit_by_id = 0;
     }
     const int lane = LANE();
     const bool reg = a.reg_coef > 0.f && a.reg_norm > 0;
@@ -539,6 +541,7 @@ __device__ __forceinline__ void update_reg_body(const UpdateArgs &a_in, int nb_e
         if (a.dry) return;
         const float sA = has_pos ? st0 + s0 : st0;
         const float sB = has_neg ? sA + s1 : sA;
+        const int64_t mu = a.emit_by_id ? id : u;       // message row: union entry, or the row id itself (cache rows, dist.py)
         // one division per row (-lr / std), then multiply-adds: 24 IEEE division sequences per wavefront were
         // 10 % of this kernel's instructions (<= 1 ulp from the reference's per-element division)
         const float k0 = -a.lr / (sqrtf(sA) + a.eps), k1 = -a.lr / (sqrtf(sB) + a.eps);
@@ -558,14 +561,14 @@ __device__ __forceinline__ void update_reg_body(const UpdateArgs &a_in, int nb_e
                     }
                     KGE_ST_ROW<4>(row + it * 4, y);
                 }
-                if (a.g0) st<4>(a.g0 + u * (int64_t)a.ld_e + it * 4, g0[k]);
-                if (a.g1) st<4>(a.g1 + u * (int64_t)a.ld_e + it * 4, g1[k]);
+                if (a.g0) st<4>(a.g0 + mu * (int64_t)a.ld_e + it * 4, g0[k]);
+                if (a.g1) st<4>(a.g1 + mu * (int64_t)a.ld_e + it * 4, g1[k]);
             }
         }
         if (lane == 0) {
             if (!a.emit_ent) *srow = sB;
-            if (a.gs0) a.gs0[u * (int64_t)a.ld_gs_e] = has_pos ? s0 : 0.f;
-            if (a.gs1) a.gs1[u * (int64_t)a.ld_gs_e] = has_neg ? s1 : 0.f;
+            if (a.gs0) a.gs0[mu * (int64_t)a.ld_gs_e] = has_pos ? s0 : 0.f;
+            if (a.gs1) a.gs1[mu * (int64_t)a.ld_gs_e] = has_neg ? s1 : 0.f;
         }
 #ifdef UPD_PROBE_NOACC
         if (false) {

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KGE_LIB") or os.path.join(_HERE, "libkge_hip.so")   # KGE_LIB: A/B builds
 
-KGE_ABI_VERSION = 4
+KGE_ABI_VERSION = 5
 MODEL_IDS = {"TransE_l1": 0, "TransE_l2": 1, "TransE": 1, "DistMult": 2, "ComplEx": 3, "RotatE": 4, "SimplE": 5, "RESCAL": 6, "TransR": 7}
 LOSS_IDS = {"Logsigmoid": 0, "Logistic": 1, "Hinge": 2, "BCE": 3}
 FLAG_FORCE_PAIRWISE = 1
@@ -65,7 +65,7 @@ class KgeStepOut(C.Structure):
 
 class KgeEmit(C.Structure):
     _fields_ = [("g0", c_p), ("gs0", c_p), ("g1", c_p), ("gs1", c_p), ("gr", c_p), ("gsr", c_p),
-                ("ld_e", c_i32), ("ld_r", c_i32), ("rid", c_p)]
+                ("ld_e", c_i32), ("ld_r", c_i32), ("rid", c_p), ("ent_by_id", c_i32), ("reserved", c_i32)]
 
 
 class KgeShards(C.Structure):
@@ -102,6 +102,10 @@ _SIGNATURES = {
                                  c_i, c_p]),
     "kge_batch_from_slot": (c_i, [c_p, c_sz, c_i, c_i, c_i, c_i, c_i, c_i, C.POINTER(KgeBatch)]),
     "kge_adagrad_apply_packed": (c_i, [c_p, c_p, c_i64, c_i, c_p, c_p, c_i, c_i64, c_i, c_f, c_f, c_p]),
+    "kge_route_build": (c_i, [c_p, c_i, c_i64, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "kge_batch_localized": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "kge_gather_rows_req": (c_i, [c_p, c_i64, c_i, c_p, c_i64, c_i64, c_p, c_p]),
+    "kge_adagrad_apply_merged": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_i, c_p, c_i64, c_i64, c_p, c_i, c_i, c_f, c_f, c_p]),
     "kge_adagrad_apply_rows": (c_i, [c_p, c_p, c_i64, c_i, c_p, c_p, c_p, c_i64, c_f, c_f, c_p]),
     "kge_step_workspace_bytes": (c_sz, [C.POINTER(KgeHParams), c_i, c_i, c_i, c_i, c_i, c_i]),
     "kge_step_fused": (c_i, [C.POINTER(KgeHParams), C.POINTER(KgeTables), C.POINTER(KgeBatch),

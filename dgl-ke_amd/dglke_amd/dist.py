@@ -8,21 +8,27 @@ unique rows of the batch, compute locally, push per-row gradients, the OWNER app
 with collectives instead of DGL's TCP KVStore.  The reference has no collective to translate; the
 all-to-all is chosen because xGMI is point-to-point (a ring would be bound by one link).
 
-Per step and rank:
-  1. ids:   the sorted unique entity ids of the batch are split by owner (contiguous slices);
-            counts + ids travel by `all_to_all_single` (`prepare_route`, can run steps ahead);
-  2. pull:  owners gather the requested rows (kge_gather_rows) -> all-to-all -> row cache [UE, D];
-  3. step:  `kge_step_grads` = the SAME kernels as the single-GPU step, run against the cache
-            (batch ids remapped to cache rows); emits per-row trace-0 / trace-1 gradients and
-            Adagrad increments instead of updating the entity table;
-  4. push:  reverse all-to-all of the gradients; owners apply them in source-rank order with
-            kge_adagrad_apply_rows (trace 0 then trace 1, like tensor_models.py:316);
-  5. rels:  summed relation gradients are all-gathered and EVERY rank applies all of them in rank
-            order, so the replicated relation tables stay bit-identical.
+Round 3: the routing lives ON THE DEVICE and every message has a FIXED size, so a step never touches the
+host (no `.cpu()`, no numpy, no count exchange) and all collectives are equal-split:
 
-The routing (this file) is device-agnostic torch + torch.distributed code; the arithmetic is in
-`HipOps` (libkge_hip).  CPU tests exercise the routing under gloo with a stand-in ops object
-(tests/test_dist_gloo.py); the product path always uses HipOps and refuses host tensors.
+  route   `kge_route_build` cuts the batch's sorted unique entity ids (the plan the sampler kernel wrote) into one
+          bucket of `cap` ids per owner (-1 padded) and re-addresses the batch to CACHE ROWS (owner * cap + position);
+  pull    all-to-all of the request ids -> owners gather (`kge_gather_rows_req`) -> all-to-all of the rows: the
+          result IS the row cache, laid out [world][cap][D];
+  step    `kge_step_grads` = the kernels of the single-GPU step against the cache; the update kernel emits ONE packed
+          message per unique row at the row's cache position ([g0 | g1 | gs0 gs1 . .]);
+  push    reverse all-to-all of the messages; `kge_adagrad_apply_merged` applies them on the owner: the messages of all
+          source ranks in ONE launch, every row by the wavefront of its first source, in source-rank order;
+  rels    packed relation gradients (ids inside) are all-gathered and EVERY rank applies all of them with the same
+          merged kernel, so the replicated relation tables stay bit-identical.
+
+`step_pipelined` overlaps the pull of step s+1 (side stream) with the compute of step s under the staleness the
+reference's `--async_update` licenses (tensor_models.py:136-175): the rows of step s+1 are gathered after update
+s-1 and before update s has landed - exact one-step staleness, deterministic.
+
+The routing arithmetic is in `HipOps` (libkge_hip); the collectives in `TorchComm` (torch.distributed: backend nccl = RCCL).
+CPU tests run the same `DistEngine` under gloo with numpy stand-ins (tests/test_dist_gloo.py); GPU tests run HipOps at
+world 2 with two processes on one device (tests/test_gpu_dist.py).  The product path uses HipOps and refuses host tensors.
 """
 import ctypes as C
 
@@ -45,33 +51,78 @@ class ShardSpec(object):
         return np.minimum(np.arange(self.world + 1, dtype=np.int64) * self.shard, self.n_entities)
 
 
-class Route(object):
-    """who sends what for one batch: send = what this rank requests from each owner,
-    recv = what this rank owns and the others request."""
-    __slots__ = ("send_counts", "recv_counts", "recv_ids_local", "UE", "n_recv")
+def default_cap(ue_max, world, slack=1.5):
+    """rows per (rank, owner) bucket: the mean share of a batch's unique entities plus slack, a multiple of 64.  Uniform ids
+    put ~ue_max/world +- sqrt(ue_max/world) ids into a bucket; heavy-tailed graphs need more slack (the overflow counter of
+    kge_route_build tells)."""
+    if world == 1:
+        return int(ue_max)
+    return int(min(ue_max, (int(ue_max / world * slack) + 64 + 63) // 64 * 64))
+
+
+class TorchComm(object):
+    """equal-split collectives on device tensors (backend nccl = RCCL over xGMI)."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+
+    def all_to_all(self, out, inp):
+        dist.all_to_all_single(out, inp, group=self.group)
+
+    def all_gather(self, out, inp):
+        dist.all_gather_into_tensor(out, inp, group=self.group)
+
+
+class LocalBatch(object):
+    """a batch re-addressed to cache rows (duck type of plan.Batch / DeviceBatch for StepEngine)."""
+
+    def __init__(self, batch, c, keep):
+        self.B, self.C, self.chunk, self.N = batch.B, batch.C, batch.chunk, batch.N
+        self.U, self.UE, self.UR = batch.U, batch.UE, batch.UR
+        self.neg_head = batch.neg_head
+        self.c = c
+        self._keep = (batch, keep)
 
 
 class HipOps(object):
-    """the arithmetic of the sharded step, all in libkge_hip."""
+    """the device arithmetic of the sharded step, all in libkge_hip."""
 
-    def gather(self, table, idx):
-        from . import ops
-        return ops.gather_rows(table, idx)
+    def route(self, batch, world, per, cap, bf):
+        """fill bf.req_ids and the cache-row id arrays; return the re-addressed batch."""
+        L = _lib.lib()
+        _lib.check(L.kge_route_build(C.byref(batch.c), world, per, cap, _lib.ptr(bf.req_ids), _lib.ptr(bf.h_loc),
+                                     _lib.ptr(bf.t_loc), _lib.ptr(bf.neg_loc), _lib.ptr(bf.ue_loc), _lib.ptr(bf.ue_rec_loc),
+                                     _lib.ptr(bf.overflow), _lib.stream_ptr()))
+        kb = _lib.KgeBatch()
+        _lib.check(L.kge_batch_localized(C.byref(batch.c), _lib.ptr(bf.h_loc), _lib.ptr(bf.t_loc), _lib.ptr(bf.neg_loc),
+                                         _lib.ptr(bf.ue_loc), _lib.ptr(bf.ue_rec_loc), C.byref(kb)))
+        return LocalBatch(batch, kb, bf)
 
-    def apply_packed(self, table, state, idx, msg, ntraces, lr):
-        """owner-side Adagrad of packed messages (kge_adagrad_apply_packed)."""
-        _lib.check(_lib.lib().kge_adagrad_apply_packed(
-            _lib.ptr(table), _lib.ptr(state), table.shape[0], table.shape[1],
-            _lib.ptr(idx) if idx is not None else None, _lib.ptr(msg), msg.shape[1], msg.shape[0],
-            ntraces, float(lr), 1e-10, _lib.stream_ptr()))
+    def gather_req(self, table, ids, lo, out):
+        _lib.check(_lib.lib().kge_gather_rows_req(_lib.ptr(table), table.shape[0], table.shape[1], _lib.ptr(ids), int(lo),
+                                                  ids.shape[0], _lib.ptr(out), _lib.stream_ptr()))
 
-    def reset_rel_msg(self, rel_msg, d_r):
-        rel_msg[:, d_r] = 0
-        rel_msg.view(torch.int32)[:, d_r + 1:d_r + 3] = -1
+    def apply_merged(self, table, state, nsrc, cap, ids, lo, msg, ntraces, lr):
+        """ids: int64 [nsrc * cap] (global ids, -1 pads) or None: the ids sit inside the messages behind the increments"""
+        dim, ld = table.shape[1], msg.shape[1]
+        if ids is not None:
+            idw, stride = ids.data_ptr(), 2
+        else:
+            idw, stride = msg.data_ptr() + 4 * (ntraces * dim + ntraces), ld
+        _lib.check(_lib.lib().kge_adagrad_apply_merged(_lib.ptr(table), _lib.ptr(state), table.shape[0], dim, nsrc, cap, idw,
+                                                       stride, int(lo), _lib.ptr(msg), ld, ntraces, float(lr), 1e-10,
+                                                       _lib.stream_ptr()))
 
-    def step_grads(self, engine, batch, cache, ent_msg, rel_msg, zero_state):
-        """run kge_step_grads against the row cache, emitting packed messages:
-        ent_msg[u] = [g0 | g1 | gs0 gs1 . .],  rel_msg[u] = [gr | gsr | id_lo id_hi .]"""
+    def reset_rel_pads(self, rel_msg, d_r, first):
+        """host-built plans: message rows >= the batch's unique-relation count are pads (device-built plans: the kernel writes them)"""
+        if first < rel_msg.shape[0]:
+            rel_msg.view(torch.int32)[first:, d_r + 1:d_r + 3] = -1
+
+    def step_grads(self, engine, lb, cache, ent_msg, rel_msg, zero_state):
+        """run kge_step_grads against the row cache, emitting packed messages at the rows' cache positions:
+        ent_msg[row] = [g0 | g1 | gs0 gs1 . .],  rel_msg[u] = [gr | gsr | id_lo id_hi .]"""
         d_e, d_r = cache.shape[1], engine.rel.shape[1]
         tb = _lib.KgeTables()
         tb.ent, tb.ent_state = _lib.ptr(cache), _lib.ptr(zero_state)
@@ -83,16 +134,164 @@ class HipOps(object):
         em.gs0, em.gs1 = e0 + 8 * d_e, e0 + 8 * d_e + 4
         em.gr, em.gsr, em.rid = r0, r0 + 4 * d_r, r0 + 4 * d_r + 4
         em.ld_e, em.ld_r = ent_msg.shape[1], rel_msg.shape[1]
+        em.ent_by_id = 1
         out = _lib.KgeStepOut()
         out.loss_accum = _lib.ptr(engine.loss_accum)
-        ws = engine.workspace_for(batch)
-        _lib.check(_lib.lib().kge_step_grads(C.byref(engine.hp), C.byref(tb), C.byref(batch.c),
+        ws = engine.workspace_for(lb)
+        _lib.check(_lib.lib().kge_step_grads(C.byref(engine.hp), C.byref(tb), C.byref(lb.c),
                                              C.byref(out), C.byref(em), _lib.ptr(ws),
                                              engine._ws_bytes, _lib.stream_ptr()))
 
 
+class _Slot(object):
+    """the buffers one in-flight pull needs (two slots: the pull of step s+1 runs while step s computes)."""
+    pass
+
+
+class DistEngine(object):
+    """sharded counterpart of StepEngine.  `engine` is a StepEngine-like object that owns the
+    hyper-parameters, the replicated relation table and the workspace; `ent`/`ent_state` are this
+    rank's shard.  Batches carry GLOBAL entity ids and their plan (DeviceSampler slots or plan.upload)."""
+
+    def __init__(self, engine, spec, ent_shard, ent_state_shard, ops=None, comm=None, cap=None, slack=1.5):
+        self.engine = engine
+        self.spec = spec
+        self.ent = ent_shard
+        self.ent_state = ent_state_shard
+        self.ops = ops or HipOps()
+        self.comm = comm or TorchComm()
+        if self.comm.world != spec.world:
+            raise ValueError("communicator of %d ranks, shard spec of %d" % (self.comm.world, spec.world))
+        self.dev = ent_shard.device
+        self.lr = float(engine.hp.lr) if hasattr(engine, "hp") else float(engine.lr)
+        self.d_e = ent_shard.shape[1]
+        self.d_r = engine.rel.shape[1]
+        self.cap, self.slack = cap, slack
+        self.slots = None
+        self._pre = None              # (batch, LocalBatch, slot index, event) of a pull that ran ahead
+        self._side = None
+        self._parity = 0
+
+    # ---- buffers (allocated once, for the geometry of the first batch) -----------------------------------------------
+    def _setup(self, b):
+        W = self.spec.world
+        if self.cap is None:
+            self.cap = default_cap(b.UE, W, self.slack)
+        cap, dt, dev = self.cap, self.ent.dtype, self.dev
+        self.geom = (b.B, b.C * b.N, b.UE)
+        ld_e, ld_r = 2 * self.d_e + 4, self.d_r + 4
+
+        def z(shape, dtype):
+            return torch.zeros(shape, dtype=dtype, device=dev)
+        self.slots = []
+        self.overflow = z(1, torch.int32)
+        for _ in range(2):
+            s = _Slot()
+            s.req_ids = z(W * cap, torch.int64)
+            s.recv_ids = s.req_ids if W == 1 else z(W * cap, torch.int64)
+            s.h_loc, s.t_loc, s.neg_loc = z(b.B, torch.int64), z(b.B, torch.int64), z(b.C * b.N, torch.int64)
+            s.ue_loc, s.ue_rec_loc = z(b.UE, torch.int64), z(b.UE * 8, torch.int32)
+            s.cache = z((W * cap + 1, self.d_e), dt)              # + the dump row of overflowing entries
+            s.rows_out = s.cache[:W * cap] if W == 1 else z((W * cap, self.d_e), dt)
+            s.overflow = self.overflow
+            self.slots.append(s)
+        self.ent_msg = z((W * cap + 1, ld_e), dt)
+        self.recv_msg = self.ent_msg[:W * cap] if W == 1 else z((W * cap, ld_e), dt)
+        self.rel_msg = z((b.B, ld_r), dt)
+        self.all_rel = self.rel_msg if W == 1 else z((W * b.B, ld_r), dt)
+        self.zero_state = z(W * cap + 1, dt)
+
+    def check_overflow(self):
+        """entries that did not fit their owner bucket since the last call (one 4-byte D2H read: call at the log interval)."""
+        if self.slots is None:
+            return 0
+        n = int(self.overflow.item())
+        if n:
+            self.overflow.zero_()
+        return n
+
+    # ---- pull: route -> ids all-to-all -> owner gather -> rows all-to-all -----------------------------------------------
+    def pull(self, batch, slot):
+        if self.slots is None:
+            self._setup(batch)
+        if (batch.B, batch.C * batch.N, batch.UE) != self.geom:
+            raise _lib.KgeError("DistEngine: batch geometry changed (B, C*N, UE bound) %r -> %r" % (self.geom, (batch.B, batch.C * batch.N, batch.UE)))
+        sp, s, W = self.spec, self.slots[slot], self.spec.world
+        lb = self.ops.route(batch, W, sp.shard, self.cap, s)
+        if W > 1:
+            self.comm.all_to_all(s.recv_ids, s.req_ids)
+        self.ops.gather_req(self.ent, s.recv_ids, sp.lo, s.rows_out)
+        if W > 1:
+            self.comm.all_to_all(s.cache[:W * self.cap], s.rows_out)
+        lb.slot = slot
+        return lb
+
+    # ---- compute + push + owner-side apply -----------------------------------------------------------------------------
+    def _compute(self, lb):
+        s = self.slots[lb.slot]
+        if not lb.c.counts_dev:
+            self.ops.reset_rel_pads(self.rel_msg, self.d_r, lb.UR)      # host-built plan: UR is exact, the rows behind it are pads
+        self.ops.step_grads(self.engine, lb, s.cache, self.ent_msg, self.rel_msg, self.zero_state)
+
+    def _push_apply(self, lb, before_apply=None):
+        sp, s, W = self.spec, self.slots[lb.slot], self.spec.world
+        if W > 1:
+            self.comm.all_to_all(self.recv_msg, self.ent_msg[:W * self.cap])
+        if before_apply is not None:
+            before_apply()
+        self.ops.apply_merged(self.ent, self.ent_state, W, self.cap, s.recv_ids, sp.lo, self.recv_msg, 2, self.lr)
+        if W > 1:
+            self.comm.all_gather(self.all_rel.view(-1), self.rel_msg.view(-1))
+        self.ops.apply_merged(self.engine.rel, self.engine.rel_state, W, lb.B, None, 0, self.all_rel, 1, self.lr)
+
+    def step(self, batch):
+        """one synchronous sharded step (pull, compute, push, apply), all enqueued on the current stream."""
+        lb = self.pull(batch, 0)
+        self._compute(lb)
+        self._push_apply(lb)
+
+    def step_pipelined(self, batch, next_batch=None):
+        """one step with the pull of `next_batch` (the batch of the following call) overlapped: its rows are gathered on a
+        side stream after update s-1 and before update s lands (exact one-step staleness: the reference's --async_update
+        licence, tensor_models.py:136-175), while this step computes."""
+        main = torch.cuda.current_stream(self.dev)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.dev)
+        if self._pre is not None and self._pre[0] is batch:
+            _, lb, ev_rows = self._pre
+            main.wait_event(ev_rows)
+        else:
+            lb = self.pull(batch, self._parity)
+        self._pre = None
+        ev_gather = None
+        if next_batch is not None:
+            self._side.wait_stream(main)              # behind everything enqueued so far: the apply of step s-1
+            with torch.cuda.stream(self._side):
+                nslot = lb.slot ^ 1
+                if self.slots is None:
+                    self._setup(next_batch)
+                sp, s, W = self.spec, self.slots[nslot], self.spec.world
+                nlb = self.ops.route(next_batch, W, sp.shard, self.cap, s)
+                nlb.slot = nslot
+                if W > 1:
+                    self.comm.all_to_all(s.recv_ids, s.req_ids)
+                self.ops.gather_req(self.ent, s.recv_ids, sp.lo, s.rows_out)
+                ev_gather = torch.cuda.Event()
+                ev_gather.record(self._side)
+                if W > 1:
+                    self.comm.all_to_all(s.cache[:W * self.cap], s.rows_out)
+                ev_rows = torch.cuda.Event()
+                ev_rows.record(self._side)
+            self._pre = (next_batch, nlb, ev_rows)
+        self._compute(lb)
+        # the apply of step s must not start before the gather of step s+1 has read the shard (else the staleness is a race)
+        self._push_apply(lb, (lambda: main.wait_event(ev_gather)) if ev_gather is not None else None)
+        self._parity = lb.slot ^ 1
+
+
 def localize_plan(h, t, r, neg, chunk, N, neg_head, edge_w=None):
-    """global-id batch -> (sorted unique entity ids, plan over cache-local row indices)."""
+    """(kept for callers that build cache-local plans on the host) global-id batch -> (sorted unique entity ids, plan over
+    row indices into that sorted list)."""
     h = np.asarray(h, np.int64)
     t = np.asarray(t, np.int64)
     neg = np.asarray(neg, np.int64)
@@ -101,96 +300,3 @@ def localize_plan(h, t, r, neg, chunk, N, neg_head, edge_w=None):
                          np.searchsorted(ue, neg), chunk, N, neg_head, edge_w)
     assert p["UE"] == ue.shape[0]
     return ue, p
-
-
-class DistEngine(object):
-    """sharded counterpart of StepEngine.  `engine` is a StepEngine-like object that owns the
-    hyper-parameters, the replicated relation table and the workspace; `ent`/`ent_state` are this
-    rank's shard."""
-
-    def __init__(self, engine, spec, ent_shard, ent_state_shard, ops=None, group=None):
-        self.engine = engine
-        self.spec = spec
-        self.ent = ent_shard
-        self.ent_state = ent_state_shard
-        self.ops = ops or HipOps()
-        self.group = group
-        self.dev = ent_shard.device
-        self.lr = float(engine.hp.lr) if hasattr(engine, "hp") else float(engine.lr)
-        self.d_e = ent_shard.shape[1]
-        self.d_r = engine.rel.shape[1]
-        self._bufs = {}
-        self._frozen = False
-        self.max_rows = 0
-
-    # ---- step 1: ids ---------------------------------------------------------------------
-    def prepare_route(self, ue_ids_np):
-        """exchange counts and ids for one batch (host-known sorted unique ids)."""
-        sp = self.spec
-        cuts = np.searchsorted(ue_ids_np, sp.bounds())
-        send_counts = np.diff(cuts).astype(np.int64)
-        sc = torch.from_numpy(send_counts).to(self.dev)
-        rc = torch.empty_like(sc)
-        dist.all_to_all_single(rc, sc, group=self.group)
-        recv_counts = rc.cpu().numpy()
-        ids = torch.from_numpy(np.ascontiguousarray(ue_ids_np)).to(self.dev)
-        recv = torch.empty(int(recv_counts.sum()), dtype=torch.int64, device=self.dev)
-        dist.all_to_all_single(recv, ids, recv_counts.tolist(), send_counts.tolist(), group=self.group)
-        rt = Route()
-        rt.send_counts, rt.recv_counts = send_counts.tolist(), recv_counts.tolist()
-        rt.recv_ids_local = recv - sp.lo
-        rt.UE, rt.n_recv = int(ue_ids_np.shape[0]), int(recv.shape[0])
-        return rt
-
-    def _buf(self, name, shape, dtype=None):
-        """persistent scratch: allocated once for the largest row count seen so far, returned as a
-        [rows, ...] view (so that a captured graph never allocates)."""
-        dtype = dtype or self.ent.dtype
-        rows = shape[0]
-        t = self._bufs.get(name)
-        if t is None or t.shape[0] < rows or tuple(t.shape[1:]) != tuple(shape[1:]) or t.dtype != dtype:
-            if self._frozen:
-                raise _lib.KgeError("DistEngine buffer %s would be re-allocated after graph capture" % name)
-            cap = max(rows, self.max_rows)
-            t = torch.zeros((cap,) + tuple(shape[1:]), dtype=dtype, device=self.dev)
-            self._bufs[name] = t
-        return t[:rows]
-
-    # ---- steps 2-5 -----------------------------------------------------------------------
-    def step(self, batch, route):
-        sp, ops = self.spec, self.ops
-        UE, nrecv, B = route.UE, route.n_recv, batch.B
-        ld_e, ld_r = 2 * self.d_e + 4, self.d_r + 4
-        # 2. pull: owners gather the requested rows, one all-to-all returns them into the row cache
-        rows_out = ops.gather(self.ent, route.recv_ids_local)
-        cache = self._buf("cache", (UE, self.d_e))
-        dist.all_to_all_single(cache, rows_out, route.send_counts, route.recv_counts, group=self.group)
-        # 3. local compute against the cache -> one packed message per unique entity / relation
-        ent_msg = self._buf("ent_msg", (UE, ld_e))
-        rel_msg = self._buf("rel_msg", (B, ld_r))
-        ops.reset_rel_msg(rel_msg, self.d_r)       # padding rows: id = -1, increment = 0
-        ops.step_grads(self.engine, batch, cache, ent_msg, rel_msg, self._buf("zero_state", (UE,)))
-        # 4. push: ONE all-to-all carries both entity traces; owners apply per source rank, in order
-        recv_msg = self._buf("recv_msg", (nrecv, ld_e))
-        dist.all_to_all_single(recv_msg, ent_msg, route.recv_counts, route.send_counts, group=self.group)
-        off = 0
-        for src in range(sp.world):
-            n = route.recv_counts[src]
-            if n:
-                ops.apply_packed(self.ent, self.ent_state, route.recv_ids_local[off:off + n],
-                                 recv_msg[off:off + n], 2, self.lr)
-            off += n
-        # 5. relations: ONE all-gather of the packed messages (ids inside); every rank applies all
-        #    ranks' updates in rank order -> replicas stay bit-identical
-        all_rel = self._buf("all_rel", (sp.world * B, ld_r))
-        dist.all_gather_into_tensor(all_rel.view(-1), rel_msg.reshape(-1), group=self.group)
-        for src in range(sp.world):
-            ops.apply_packed(self.engine.rel, self.engine.rel_state, None, all_rel[src * B:(src + 1) * B], 1, self.lr)
-
-    def capture(self, batch, route, stream=None):
-        """record one sharded step (kernels + RCCL collectives) into a HIP graph."""
-        self._frozen = True
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=stream):
-            self.step(batch, route)
-        return g

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define KGE_ABI_VERSION 4
+#define KGE_ABI_VERSION 5
 
 /* score functions (models/general_models.py:248-268 model_name strings) */
 enum kge_model {
@@ -320,7 +320,12 @@ typedef struct kge_emit {
     int32_t ld_e;            /* stride of g0, g1, gs0, gs1 */
     int32_t ld_r;            /* stride of gr, gsr */
     int32_t *rid;            /* optional [UR*ld_r] view: relation id written as two int32 words at */
-                             /* rid[u*ld_r], rid[u*ld_r+1] (lo, hi) next to the gradient, or NULL   */
+                             /* rid[u*ld_r], rid[u*ld_r+1] (lo, hi) next to the gradient, or NULL;  */
+                             /* on device-built plans rows u in [unique relations, UR) get id -1    */
+    int32_t ent_by_id;       /* != 0: the entity messages of union entry u are written at row       */
+                             /* ue_id[u] instead of row u (batches re-addressed to cache rows by     */
+                             /* kge_route_build: the message array is then laid out like the cache) */
+    int32_t reserved;
 } kge_emit;
 int kge_step_grads(const kge_hparams *hp, const kge_tables *tb, const kge_batch *b,
                    const kge_step_out *out, const kge_emit *emit, void *ws, size_t ws_bytes,
@@ -419,6 +424,35 @@ int kge_batch_from_slot(void *slots, size_t slot_bytes, int slot, int B, int C, 
 int kge_adagrad_apply_packed(float *table, float *state_sum, int64_t n_rows, int dim,
                              const int64_t *idx, const float *msg, int ld, int64_t n, int ntraces,
                              float lr, float eps, void *stream);
+
+/* ---- device-side routing of the range-sharded step (entity table sharded by id range over the ranks,
+ * pull -> compute -> push with owner-side Adagrad, KEModel.pull_model / push_gradient, models/general_models.py:650-680,
+ * kvserver.py:41-51) - no host round trip, fixed-size messages, so that the collectives between these calls are plain
+ * equal-split all-to-alls (dglke_amd/dist.py) ----
+ * kge_route_build: the batch's sorted unique entity ids (b->ue_id, count in b->counts_dev[0] or b->UE) are cut into `world` owner
+ *   buckets (owner = id / rows_per_shard) of capacity `cap`:
+ *     req_ids[o*cap + p]  = p-th id requested from owner o, -1 beyond the bucket's fill;
+ *     cache row of an entity = o*cap + p - the position its row will have in the concatenated replies;
+ *     h_loc / t_loc / neg_loc = the batch's edge ends and negative slots as cache rows, ue_loc / ue_rec_loc = the plan's id
+ *     array and packed records with cache rows as ids: kge_batch_localized() points a kge_batch at them.
+ *   Entries that do not fit their bucket are counted in *overflow (must be checked by the caller at its log interval: the
+ *   step treats them as row world*cap, a dump row of the cache that is never sent); one workgroup, ~3 us.
+ * kge_gather_rows_req: owner side of the pull - out[k,:] = table[ids[k] - id_offset,:], entries with ids[k] < 0 (pads) or
+ *   outside [id_offset, id_offset + n_rows) are skipped.
+ * kge_adagrad_apply_merged: owner side of the push for nsrc sources x cap messages (layout [g_0 | .. | g_{T-1} | gs_0 ..
+ *   gs_{T-1} | ..], ld floats apart); the id of message k is the int32 pair id_words[k*id_stride_words], [.. + 1] (a separate
+ *   int64 array: stride 2; ids inside the messages: stride ld) minus id_offset; negative ids are pads.  Within a source the
+ *   ids are ascending with the pads at the end and unique; the same row may come from several sources: the wavefront of its
+ *   first source applies every occurrence in source order (trace order inside a message) - deterministic, one launch. */
+int kge_route_build(const kge_batch *b, int world, int64_t rows_per_shard, int cap, int64_t *req_ids, int64_t *h_loc,
+                    int64_t *t_loc, int64_t *neg_loc, int64_t *ue_loc, int32_t *ue_rec_loc, int32_t *overflow, void *stream);
+int kge_batch_localized(const kge_batch *b, const int64_t *h_loc, const int64_t *t_loc, const int64_t *neg_loc,
+                        const int64_t *ue_loc, const int32_t *ue_rec_loc, kge_batch *out);
+int kge_gather_rows_req(const float *table, int64_t n_rows, int dim, const int64_t *ids, int64_t id_offset, int64_t n_ids,
+                        float *out, void *stream);
+int kge_adagrad_apply_merged(float *table, float *state_sum, int64_t n_rows, int dim, int nsrc, int cap, const int32_t *id_words,
+                             int64_t id_stride_words, int64_t id_offset, const float *msg, int ld, int ntraces, float lr, float eps,
+                             void *stream);
 
 #ifdef __cplusplus
 }

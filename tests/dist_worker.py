@@ -1,0 +1,120 @@
+"""worker of tests/test_gpu_dist.py: one of `world` processes sharing ONE GPU; the device arithmetic of the range-sharded step
+(dglke_amd.dist.HipOps: kge_route_build, kge_gather_rows_req, kge_step_grads, kge_adagrad_apply_merged) runs for real, the
+fixed-size messages travel through gloo (staged through the host: RCCL refuses two ranks on one device).
+argv: rank world port out_dir mode"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", "dgl-ke_amd"))
+sys.path.insert(0, os.path.join(HERE, ".."))
+
+N_ENT, N_REL, HID, B, N, LR, STEPS = 2003, 31, 64, 128, 32, 0.1, 4
+MODELS = (("TransE_l2", False, False), ("DistMult", False, False), ("RotatE", True, False))
+
+
+class GlooStagedComm(object):
+    """test double of dglke_amd.dist.TorchComm: same equal-split collectives, carried by gloo on host copies."""
+    def __init__(self):
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+
+    def all_to_all(self, out, inp):
+        torch.cuda.current_stream().synchronize()
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(o, inp.cpu().contiguous())
+        out.copy_(o)
+
+    def all_gather(self, out, inp):
+        torch.cuda.current_stream().synchronize()
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(o, inp.cpu().contiguous())
+        out.copy_(o)
+
+
+def batches(world, steps, mode, seed=5):
+    """per step and rank one batch of GLOBAL ids.  mode 'disjoint': rank k draws entities / relations from its own slice, so the
+    synchronous step equals processing the ranks' batches one after the other on ONE table."""
+    from oracle import kge_oracle as O
+    rng = np.random.RandomState(seed)
+    out = []
+    for s in range(steps):
+        row = []
+        for k in range(world):
+            if mode == "disjoint":
+                ne, nr = N_ENT // world, N_REL // world
+                bt = O.synth_batch(rng, ne, nr, B, N, N, s + 1)
+                for key in ("h", "t", "neg", "nid"):
+                    bt[key] = bt[key] + k * ne
+                bt["r"] = bt["r"] + k * nr
+            else:
+                bt = O.synth_batch(rng, N_ENT, N_REL, B, N, N, s + 1)
+            row.append(bt)
+        out.append(row)
+    return out
+
+
+def main():
+    rank, world, port, out_dir, mode = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5]
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", port
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dglke_amd import dist as kd, plan
+    from dglke_amd.engine import StepEngine
+    dev = "cuda:0"
+    torch.cuda.set_device(0)
+    res = {}
+    for model, de_, dr_ in MODELS:
+        d_e = 2 * HID if de_ else HID
+        g = torch.Generator().manual_seed(5)
+        ent0 = ((torch.rand(N_ENT, d_e, generator=g) - 0.5) * 0.4)
+        eng = StepEngine(model, 1, N_REL, HID, 12.0, LR, dev, de_, dr_, True, 1.0, 1e-6, 3)
+        rel0 = ((torch.rand(N_REL, eng.d_r, generator=g) - 0.5) * 0.4)
+        eng.rel.copy_(rel0)
+        spec = kd.ShardSpec(N_ENT, world, rank)
+        ent = ent0[spec.lo:spec.hi].to(dev).contiguous()
+        state = torch.zeros(spec.n_local, device=dev)
+        de = kd.DistEngine(eng, spec, ent, state, comm=GlooStagedComm(), cap=None, slack=1.6)
+        bts = batches(world, STEPS, "disjoint" if mode == "disjoint" else "random")
+        ue_bound = 2 * B + (B // N) * N
+        devb = []
+        for row in bts:
+            bt = row[rank]
+            b = plan.make_batch(bt["h"], bt["t"], bt["r"], bt["neg"], N, N, bt["neg_head"], dev)
+            b.UE = ue_bound                  # buffers are sized once for the bound (like the device sampler's slots)
+            devb.append(b)
+        for s, b in enumerate(devb):
+            if mode == "pipelined":
+                de.step_pipelined(b, devb[s + 1] if s + 1 < len(devb) else None)
+            else:
+                de.step(b)
+        torch.cuda.synchronize()
+        assert de.check_overflow() == 0
+        shards = [None] * world
+        dist.all_gather_object(shards, (ent.cpu().numpy(), state.cpu().numpy(), eng.rel.cpu().numpy(), eng.rel_state.cpu().numpy()))
+        if rank == 0:
+            res[model] = dict(ent=np.concatenate([s_[0] for s_ in shards]), state=np.concatenate([s_[1] for s_ in shards]),
+                              rels=[s_[2] for s_ in shards], rel_states=[s_[3] for s_ in shards],
+                              init_ent=ent0.numpy(), init_rel=rel0.numpy())
+            if mode == "disjoint":           # the same batches, rank after rank, on ONE table through the fused single-GPU step
+                ref = StepEngine(model, N_ENT, N_REL, HID, 12.0, LR, dev, de_, dr_, True, 1.0, 1e-6, 3)
+                ref.load_tables(ent0.to(dev), rel0.to(dev))
+                for row in bts:
+                    for bt in row:
+                        ref.step(plan.make_batch(bt["h"], bt["t"], bt["r"], bt["neg"], N, N, bt["neg_head"], dev))
+                torch.cuda.synchronize()
+                res[model].update(ref_ent=ref.ent.cpu().numpy(), ref_state=ref.ent_state.cpu().numpy(),
+                                  ref_rel=ref.rel.cpu().numpy(), ref_rel_state=ref.rel_state.cpu().numpy())
+        dist.barrier()
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "result.npz"), **{m + "_" + k: v for m, d in res.items() for k, v in d.items()
+                                                         if not isinstance(v, list)},
+                 **{m + "_rel%d" % i: r for m, d in res.items() for i, r in enumerate(d["rels"])},
+                 **{m + "_relstate%d" % i: r for m, d in res.items() for i, r in enumerate(d["rel_states"])})
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

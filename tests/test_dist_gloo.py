@@ -1,7 +1,8 @@
-"""world_size-2 gloo test (CPU) of the sharded step's ROUTING (dglke_amd/dist.py): id bucketing by
-owner, row pull, gradient push, owner-side apply order, replicated relation update.  The
-arithmetic is supplied by a stand-in ops object built on the CPU oracle (test infrastructure); the
-product path uses HipOps (libkge_hip) and is covered on the GPU by tests/test_gpu_parity.py."""
+"""world_size-2 gloo test (CPU) of the sharded step's schedule (dglke_amd/dist.py DistEngine): fixed-capacity owner
+buckets, equal-split all-to-alls for ids / rows / packed gradients, owner-side apply order, replicated relation
+update.  The device calls are supplied by a stand-in ops object (numpy routing + the CPU oracle: test
+infrastructure); the product path uses HipOps (libkge_hip) and is covered on the GPU by tests/test_gpu_dist.py
+(two processes on one device) and tests/test_gpu_parity.py (world 1)."""
 import os
 import socket
 import sys
@@ -15,6 +16,8 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 N_ENT, N_REL, HID, B, N, CHUNK, LR = 37, 5, 8, 12, 4, 4, 0.1
+UE_BOUND = 2 * B + (B // CHUNK) * N      # unique entities of a batch never exceed this
+CAP = 24                                 # ids per (rank, owner) bucket: more than any owner's share at this size
 MODEL, GAMMA = "TransE_l2", 12.0
 
 
@@ -32,24 +35,50 @@ class FakeEngine(object):
         self.rel, self.rel_state, self.lr = rel, rel_state, lr
 
 
+class OracleLocalBatch(object):
+    def __init__(self, batch, lp):
+        self.B, self.C, self.chunk, self.N = batch.B, batch.C, batch.chunk, batch.N
+        self.U, self.UE, self.UR = batch.U, batch.UE, batch.UR
+        self.neg_head, self.c, self.lp, self.p = batch.neg_head, batch.c, lp, batch.p
+
+
 class OracleOps(object):
-    """stand-in for dglke_amd.dist.HipOps: same message layout, arithmetic by the CPU oracle."""
+    """stand-in for dglke_amd.dist.HipOps (same calls, same message layout): the routing restated in numpy, the arithmetic
+    by the CPU oracle."""
     def __init__(self, cfg):
         self.cfg = cfg
 
-    def gather(self, table, idx):
-        return table[idx].clone()
+    def route(self, batch, world, per, cap, bf):
+        p = batch.p
+        ue = p["ue_id"]
+        owner = ue // per
+        start = np.searchsorted(owner, np.arange(world + 1))
+        pos = np.arange(len(ue)) - start[owner]
+        assert (pos < cap).all(), "bucket overflow in the test"
+        cr = owner * cap + pos
+        req = np.full(world * cap, -1, np.int64)
+        req[cr] = ue
+        bf.req_ids.copy_(torch.from_numpy(req))
+        row_of = dict(zip(ue.tolist(), cr.tolist()))
+        lp = dict(nid=np.array([row_of[x] for x in p["nid"].tolist()], np.int64),
+                  neg=np.array([row_of[x] for x in p["neg_ids"].tolist()], np.int64))
+        return OracleLocalBatch(batch, lp)
 
-    def reset_rel_msg(self, rel_msg, d_r):
-        rel_msg[:, d_r] = 0
-        rel_msg[:, d_r + 1] = -1          # id kept as a number in the test double
+    def gather_req(self, table, ids, lo, out):
+        for k, i in enumerate(ids.tolist()):
+            if i >= 0:
+                out[k] = table[i - lo]
 
-    def apply_packed(self, table, state, idx, msg, ntraces, lr):
+    def reset_rel_pads(self, rel_msg, d_r, first):
+        rel_msg[first:, d_r + 1] = -1          # id kept as a number in the test double
+
+    def apply_merged(self, table, state, nsrc, cap, ids, lo, msg, ntraces, lr):
         dim = table.shape[1]
-        for k in range(msg.shape[0]):
-            i = int(idx[k]) if idx is not None else int(msg[k, ntraces * dim + ntraces])
+        for k in range(nsrc * cap):            # source-major order = per row: sources in rank order, traces in order
+            i = int(ids[k]) if ids is not None else int(msg[k, ntraces * dim + ntraces])
             if i < 0:
                 continue
+            i -= lo
             for t in range(ntraces):
                 inc = msg[k, ntraces * dim + t]
                 if float(inc) == 0.0:
@@ -57,18 +86,18 @@ class OracleOps(object):
                 state[i] += inc
                 table[i] += (-lr * msg[k, t * dim:(t + 1) * dim]) / (torch.sqrt(state[i]) + 1e-10)
 
-    def step_grads(self, engine, batch, cache, ent_msg, rel_msg, zero_state):
+    def step_grads(self, engine, lb, cache, ent_msg, rel_msg, zero_state):
         from oracle import kge_oracle as O
-        p = batch.p
+        p, lp = lb.p, lb.lp
         D, dr = cache.shape[1], engine.rel.shape[1]
         out = O.forward_backward(self.cfg, cache.numpy().astype(np.float64), engine.rel.numpy().astype(np.float64),
-                                 p["nid"], p["h_local"], p["t_local"], p["rel_ids"], p["neg_ids"],
+                                 lp["nid"], p["h_local"], p["t_local"], p["rel_ids"], lp["neg"],
                                  bool(p["neg_head"]), p["chunk"], p["N"])
-        em = np.zeros((p["UE"], 2 * D + 4))
-        em[p["nid"], :D] = out["g_pos_ent"]
-        em[p["nid"], 2 * D] = (out["g_pos_ent"] ** 2).mean(1)
-        np.add.at(em[:, D:2 * D], p["neg_ids"], out["g_neg"])
-        np.add.at(em[:, 2 * D + 1], p["neg_ids"], (out["g_neg"] ** 2).mean(1))
+        em = np.zeros((ent_msg.shape[0], 2 * D + 4))        # one message per unique row, AT THE ROW'S CACHE POSITION
+        em[lp["nid"], :D] = out["g_pos_ent"]
+        em[lp["nid"], 2 * D] = (out["g_pos_ent"] ** 2).mean(1)
+        np.add.at(em[:, D:2 * D], lp["neg"], out["g_neg"])
+        np.add.at(em[:, 2 * D + 1], lp["neg"], (out["g_neg"] ** 2).mean(1))
         ent_msg.copy_(torch.from_numpy(em))
         ur = p["ur_id"]
         inv = np.searchsorted(ur, p["rel_ids"])
@@ -102,14 +131,15 @@ def _worker(rank, world, port, ret):
         ent_shard = torch.from_numpy(ent[spec.lo:spec.hi].copy())
         state_shard = torch.zeros(spec.n_local, dtype=torch.float64)
         eng = FakeEngine(torch.from_numpy(rel.copy()), torch.zeros(N_REL, dtype=torch.float64), LR)
-        de = kd.DistEngine(eng, spec, ent_shard, state_shard, ops=OracleOps(cfg))
+        de = kd.DistEngine(eng, spec, ent_shard, state_shard, ops=OracleOps(cfg), cap=CAP)
         for step_batches in _batches(world, 3):
             bt = step_batches[rank]
-            ue, p = kd.localize_plan(bt["h"], bt["t"], bt["r"], bt["neg"], CHUNK, N, bt["neg_head"])
+            p = plan.build_plan(bt["h"], bt["t"], bt["r"], bt["neg"], CHUNK, N, bt["neg_head"])     # GLOBAL ids
+            p["UE_exact"] = p["UE"]
             b = plan.upload([p], "cpu")[0]
-            route = de.prepare_route(ue)
-            assert sum(route.send_counts) == len(ue)
-            de.step(b, route)
+            b.UE = UE_BOUND                       # the engine's buffers are sized once, for the bound
+            de.step(b)
+            assert de.check_overflow() == 0
         # collect the shards on rank 0
         shards = [None] * world
         dist.all_gather_object(shards, (ent_shard.numpy(), state_shard.numpy(), eng.rel.numpy(), eng.rel_state.numpy()))

@@ -1,0 +1,191 @@
+"""The range-sharded multi-GPU step (dglke_amd/dist.py) with its DEVICE arithmetic running for real:
+  * unit tests of the routing kernels (kge_route_build, kge_gather_rows_req, kge_adagrad_apply_merged) against numpy;
+  * DistEngine + HipOps at world = 2: two processes on one GPU, the fixed-size messages carried by gloo
+    (tests/dist_worker.py) - against the fp64 oracle's statement of the synchronous sharded step, against the fused
+    single-table step (batches on disjoint supports), and the pipelined step against the one-step-stale statement."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import kge_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+
+def test_route_build_matches_numpy():
+    """owner buckets of fixed capacity, cache rows, re-addressed batch - host plan and device-built plan."""
+    import ctypes as C
+    from dglke_amd import _lib, plan
+    from dglke_amd import dist as kd
+    rng = np.random.RandomState(3)
+    for world, n_ent, B, N, cap in ((1, 500, 64, 16, None), (2, 501, 64, 16, 96), (3, 1000, 96, 32, 80), (8, 5000, 128, 32, 48),
+                                    (4, 400, 128, 32, 20)):            # the last one overflows its buckets on purpose
+        bt = O.synth_batch(rng, n_ent, 7, B, N, N, 1)
+        b = plan.make_batch(bt["h"], bt["t"], bt["r"], bt["neg"], N, N, bt["neg_head"], DEV)
+        per = (n_ent + world - 1) // world
+        cap = cap or b.UE
+        eng_like = type("S", (), {})()
+        z = lambda n, dt: torch.zeros(n, dtype=dt, device=DEV)
+        eng_like.req_ids, eng_like.h_loc, eng_like.t_loc, eng_like.neg_loc = z(world * cap, torch.int64), z(B, torch.int64), z(B, torch.int64), z(b.C * N, torch.int64)
+        eng_like.ue_loc, eng_like.ue_rec_loc, eng_like.overflow = z(b.UE, torch.int64), z(b.UE * 8, torch.int32), z(1, torch.int32)
+        eng_like.req_ids.fill_(12345)                              # pads must be WRITTEN
+        lb = kd.HipOps().route(b, world, per, cap, eng_like)
+        torch.cuda.synchronize()
+        ue = b.p["ue_id"]
+        owner = ue // per
+        start = np.searchsorted(owner, np.arange(world + 1))
+        pos = np.arange(len(ue)) - start[owner]
+        fits = pos < cap
+        cr = np.where(fits, owner * cap + pos, world * cap)
+        req = np.full(world * cap, -1, np.int64)
+        req[cr[fits]] = ue[fits]
+        assert int(eng_like.overflow.item()) == int((~fits).sum())
+        assert np.array_equal(eng_like.req_ids.cpu().numpy(), req)
+        assert np.array_equal(eng_like.ue_loc.cpu().numpy()[:len(ue)], cr)
+        row_of = dict(zip(ue.tolist(), cr.tolist()))
+        assert np.array_equal(eng_like.h_loc.cpu().numpy(), [row_of[x] for x in b.p["h_gid"].tolist()])
+        assert np.array_equal(eng_like.t_loc.cpu().numpy(), [row_of[x] for x in b.p["t_gid"].tolist()])
+        assert np.array_equal(eng_like.neg_loc.cpu().numpy(), [row_of[x] for x in b.p["neg_ids"].tolist()])
+        rec = eng_like.ue_rec_loc.cpu().numpy().reshape(-1, 8)[:len(ue)]
+        want = b.p["ue_rec"].reshape(-1, 8).copy()
+        want[:, 0], want[:, 1] = (cr & 0xffffffff).astype(np.uint32).view(np.int32), (cr >> 32).astype(np.int32)
+        assert np.array_equal(rec, want)
+        assert lb.c.B == B and lb.c.UE == b.UE
+
+
+def test_gather_rows_req_skips_pads_and_foreign_ids():
+    from dglke_amd import dist as kd
+    t = torch.arange(0, 80, dtype=torch.float32, device=DEV).reshape(10, 8)
+    ids = torch.tensor([105, -1, 100, 109, 99, 110], device=DEV)          # shard holds ids 100..109
+    out = torch.full((6, 8), -7.0, device=DEV)
+    kd.HipOps().gather_req(t, ids, 100, out)
+    torch.cuda.synchronize()
+    want = torch.full((6, 8), -7.0)
+    want[0], want[2], want[3] = t[5].cpu(), t[0].cpu(), t[9].cpu()
+    assert torch.equal(out.cpu(), want)
+
+
+@pytest.mark.parametrize("nsrc,cap,dim,n_rows", [(1, 40, 8, 64), (2, 33, 8, 40), (3, 100, 64, 120), (8, 257, 400, 600),
+                                                 (5, 7, 1024, 12), (16, 64, 16, 200), (64, 9, 8, 30)])
+def test_apply_merged_equals_sequential_apply(nsrc, cap, dim, n_rows):
+    """rows that arrive from several sources are applied once, in source order, by the first source's wavefront: compare with a
+    sequential numpy statement (kvserver.py:41-51 per pushed row, tensor_models.py:316 trace order)."""
+    from dglke_amd import dist as kd
+    rng = np.random.RandomState(nsrc * 1000 + cap)
+    lo, T, lr = 1000, 2, 0.1
+    ld = T * dim + 4
+    table = rng.randn(n_rows, dim).astype(np.float32)
+    state = rng.rand(n_rows).astype(np.float32)
+    ids = np.full((nsrc, cap), -1, np.int64)
+    msg = rng.randn(nsrc * cap, ld).astype(np.float32) * 0.05
+    msg[:, T * dim:T * dim + T] = rng.rand(nsrc * cap, T).astype(np.float32) * 0.01
+    for s in range(nsrc):
+        k = rng.randint(0, min(cap, n_rows) + 1)
+        ids[s, :k] = np.sort(rng.choice(n_rows, k, replace=False)) + lo
+    # a few messages with one silent trace (increment 0: that trace is skipped)
+    sil = rng.rand(nsrc * cap) < 0.2
+    msg[sil, T * dim] = 0.0
+    t_d, s_d = torch.from_numpy(table).to(DEV), torch.from_numpy(state).to(DEV)
+    kd.HipOps().apply_merged(t_d, s_d, nsrc, cap, torch.from_numpy(ids.reshape(-1)).to(DEV), lo, torch.from_numpy(msg).to(DEV), T, lr)
+    torch.cuda.synchronize()
+    t64, s64 = table.astype(np.float64), state.astype(np.float64)
+    for s in range(nsrc):
+        for p in range(cap):
+            i = ids[s, p]
+            if i < 0:
+                continue
+            m = msg[s * cap + p].astype(np.float64)
+            for t in range(T):
+                inc = m[T * dim + t]
+                if inc == 0.0:
+                    continue
+                s64[i - lo] += inc
+                t64[i - lo] += -lr * m[t * dim:(t + 1) * dim] / (np.sqrt(s64[i - lo]) + 1e-10)
+    np.testing.assert_allclose(s_d.cpu().numpy(), s64, rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(t_d.cpu().numpy(), t64, rtol=1e-5, atol=2e-6)
+    # ids inside the messages (the relation all-gather's format)
+    t2, s2 = torch.from_numpy(table).to(DEV), torch.from_numpy(state).to(DEV)
+    m2 = msg.copy()
+    m2.view(np.int32)[:, T * dim + T] = ((ids.reshape(-1)) & 0xffffffff).astype(np.uint32).view(np.int32)
+    m2.view(np.int32)[:, T * dim + T + 1] = (ids.reshape(-1) >> 32).astype(np.int32)
+    kd.HipOps().apply_merged(t2, s2, nsrc, cap, None, lo, torch.from_numpy(m2).to(DEV), T, lr)
+    torch.cuda.synchronize()
+    assert torch.equal(t2, t_d) and torch.equal(s2, s_d)
+
+
+def _run_workers(tmp_path, mode, world=2):
+    port = str(29700 + os.getpid() % 250 + {"random": 0, "disjoint": 1, "pipelined": 2}[mode])
+    env = dict(os.environ)
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), str(r), str(world), port, str(tmp_path), mode],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(o.decode(errors="replace"))
+    assert all(p.returncode == 0 for p in procs), "worker failed:\n" + "\n----\n".join(outs)
+    return np.load(os.path.join(str(tmp_path), "result.npz"))
+
+
+def _oracle_statement(model, de_, dr_, z, world, mode):
+    """fp64 statement of the sharded step: every rank's gradients from the SAME tables, applied owner-side in rank order (trace 0
+    then trace 1 per rank), relations in rank order.  mode 'pipelined': the ENTITY rows of step s were pulled before update s-1
+    landed (exact one-step staleness); the replicated relation table is always current."""
+    import dist_worker as W
+    cfg = O.Config(model, 12.0, W.HID, W.LR, adv=True, adv_temp=1.0, reg_coef=1e-6, reg_norm=3, double_ent=de_, double_rel=dr_)
+    ent, rel = z[model + "_init_ent"].astype(np.float64), z[model + "_init_rel"].astype(np.float64)
+    es, rs = np.zeros(W.N_ENT), np.zeros(W.N_REL)
+    bts = W.batches(world, W.STEPS, "random")
+    pulled = ent.copy()                    # what the pull of the current step saw
+    for s, row in enumerate(bts):
+        src = pulled if mode == "pipelined" else ent
+        outs = [O.forward_backward(cfg, src, rel, bt["nid"], bt["h_local"], bt["t_local"], bt["r"], bt["neg"], bt["neg_head"],
+                                   W.N, W.N) for bt in row]
+        pulled = ent.copy()                # the pull of step s+1 runs now: after update s-1, before update s
+        for bt, out in zip(row, outs):
+            O.adagrad_update(ent, es, bt["nid"], out["g_pos_ent"], W.LR)
+            O.adagrad_update(ent, es, bt["neg"], out["g_neg"], W.LR)
+        for bt, out in zip(row, outs):
+            O.adagrad_update(rel, rs, bt["r"], out["g_rel"], W.LR)
+    return ent, es, rel, rs
+
+
+@pytest.mark.parametrize("mode", ["random", "pipelined"])
+def test_world2_hip_ops_match_the_oracle_statement(tmp_path, mode):
+    import dist_worker as W
+    z = _run_workers(tmp_path, mode)
+    for model, de_, dr_ in W.MODELS:
+        ent, es, rel, rs = _oracle_statement(model, de_, dr_, z, 2, mode)
+        lr = W.LR
+        assert np.abs(z[model + "_ent"] - z[model + "_init_ent"]).max() > 1e-3, "training did not move the table"
+        np.testing.assert_allclose(z[model + "_state"], es, rtol=2e-3, atol=1e-9, err_msg=model + " entity state")
+        np.testing.assert_allclose(z[model + "_ent"], ent, rtol=1e-4, atol=5e-3 * lr, err_msg=model + " entity rows")
+        for r in range(2):
+            np.testing.assert_allclose(z[model + "_relstate%d" % r], rs, rtol=2e-3, atol=1e-9, err_msg=model + " relation state")
+            np.testing.assert_allclose(z[model + "_rel%d" % r], rel, rtol=1e-4, atol=5e-3 * lr, err_msg=model + " relation rows")
+        assert np.array_equal(z[model + "_rel0"], z[model + "_rel1"]), "relation replicas differ"
+        assert np.array_equal(z[model + "_relstate0"], z[model + "_relstate1"])
+
+
+def test_world2_equals_single_table_step_on_disjoint_batches(tmp_path):
+    """rank k's batches only touch rank-k entities / relations: the synchronous sharded step is then the fused single-GPU step
+    applied rank after rank on one table (same kernels; the gradient-emitting update + owner-side apply is a different
+    instantiation of the update code, hence a few ulp, see test_sharded_engine_world1_equals_fused_step)."""
+    import dist_worker as W
+    z = _run_workers(tmp_path, "disjoint")
+    for model, _, _ in W.MODELS:
+        np.testing.assert_allclose(z[model + "_ent"], z[model + "_ref_ent"], rtol=1e-5, atol=5e-6, err_msg=model)
+        np.testing.assert_allclose(z[model + "_state"], z[model + "_ref_state"], rtol=1e-5, atol=1e-8, err_msg=model)
+        np.testing.assert_allclose(z[model + "_rel0"], z[model + "_ref_rel"], rtol=1e-5, atol=5e-6, err_msg=model)
+        np.testing.assert_allclose(z[model + "_relstate0"], z[model + "_ref_rel_state"], rtol=1e-5, atol=1e-8, err_msg=model)

@@ -327,7 +327,7 @@ def test_gather_rows_and_errors():
 
 
 def test_sharded_engine_world1_equals_fused_step():
-    """dglke_amd.dist.DistEngine (pull -> kge_step_grads -> push -> kge_adagrad_apply_rows) with a
+    """dglke_amd.dist.DistEngine (kge_route_build -> pull -> kge_step_grads -> push -> kge_adagrad_apply_merged) with a
     single rank must reproduce the fused single-GPU step: same kernels, same trace order."""
     import os
     import torch.distributed as dist
@@ -349,9 +349,10 @@ def test_sharded_engine_world1_equals_fused_step():
             for step in range(1, 4):
                 bt = O.synth_batch(rng, n_ent, n_rel, B, N, N, step)
                 a.step(plan.make_batch(bt["h"], bt["t"], bt["r"], bt["neg"], N, N, bt["neg_head"], DEV))
-                ue, p = kd.localize_plan(bt["h"], bt["t"], bt["r"], bt["neg"], N, N, bt["neg_head"])
-                lb = plan.upload([p], DEV)[0]
-                deng.step(lb, deng.prepare_route(ue))
+                gb = plan.make_batch(bt["h"], bt["t"], bt["r"], bt["neg"], N, N, bt["neg_head"], DEV)      # GLOBAL ids
+                gb.UE = 2 * B + (B // N) * N         # the engine sizes its buffers once, for the bound
+                deng.step(gb)                        # route on the device -> (world 1: no collective) -> grads -> merged apply
+            assert deng.check_overflow() == 0
             torch.cuda.synchronize()
             # the two paths run different instantiations of the update code (in-place vs gradient-emitting +
             # owner-side apply): same formulas, fp32 contraction may differ, and Adagrad's first steps divide
