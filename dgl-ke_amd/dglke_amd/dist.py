@@ -153,7 +153,8 @@ class DistEngine(object):
     hyper-parameters, the replicated relation table and the workspace; `ent`/`ent_state` are this
     rank's shard.  Batches carry GLOBAL entity ids and their plan (DeviceSampler slots or plan.upload)."""
 
-    def __init__(self, engine, spec, ent_shard, ent_state_shard, ops=None, comm=None, cap=None, slack=1.5):
+    def __init__(self, engine, spec, ent_shard, ent_state_shard, ops=None, comm=None, cap=None, slack=1.5,
+                 always_collective=False):
         self.engine = engine
         self.spec = spec
         self.ent = ent_shard
@@ -167,6 +168,8 @@ class DistEngine(object):
         self.d_e = ent_shard.shape[1]
         self.d_r = engine.rel.shape[1]
         self.cap, self.slack = cap, slack
+        # a single rank needs no collective (the buffers alias); always_collective keeps the calls (tests: the RCCL path at world 1)
+        self.coll = spec.world > 1 or bool(always_collective)
         self.slots = None
         self._pre = None              # (batch, LocalBatch, slot index, event) of a pull that ran ahead
         self._side = None
@@ -188,17 +191,17 @@ class DistEngine(object):
         for _ in range(2):
             s = _Slot()
             s.req_ids = z(W * cap, torch.int64)
-            s.recv_ids = s.req_ids if W == 1 else z(W * cap, torch.int64)
+            s.recv_ids = s.req_ids if not self.coll else z(W * cap, torch.int64)
             s.h_loc, s.t_loc, s.neg_loc = z(b.B, torch.int64), z(b.B, torch.int64), z(b.C * b.N, torch.int64)
             s.ue_loc, s.ue_rec_loc = z(b.UE, torch.int64), z(b.UE * 8, torch.int32)
             s.cache = z((W * cap + 1, self.d_e), dt)              # + the dump row of overflowing entries
-            s.rows_out = s.cache[:W * cap] if W == 1 else z((W * cap, self.d_e), dt)
+            s.rows_out = s.cache[:W * cap] if not self.coll else z((W * cap, self.d_e), dt)
             s.overflow = self.overflow
             self.slots.append(s)
         self.ent_msg = z((W * cap + 1, ld_e), dt)
-        self.recv_msg = self.ent_msg[:W * cap] if W == 1 else z((W * cap, ld_e), dt)
+        self.recv_msg = self.ent_msg[:W * cap] if not self.coll else z((W * cap, ld_e), dt)
         self.rel_msg = z((b.B, ld_r), dt)
-        self.all_rel = self.rel_msg if W == 1 else z((W * b.B, ld_r), dt)
+        self.all_rel = self.rel_msg if not self.coll else z((W * b.B, ld_r), dt)
         self.zero_state = z(W * cap + 1, dt)
 
     def check_overflow(self):
@@ -218,10 +221,10 @@ class DistEngine(object):
             raise _lib.KgeError("DistEngine: batch geometry changed (B, C*N, UE bound) %r -> %r" % (self.geom, (batch.B, batch.C * batch.N, batch.UE)))
         sp, s, W = self.spec, self.slots[slot], self.spec.world
         lb = self.ops.route(batch, W, sp.shard, self.cap, s)
-        if W > 1:
+        if self.coll:
             self.comm.all_to_all(s.recv_ids, s.req_ids)
         self.ops.gather_req(self.ent, s.recv_ids, sp.lo, s.rows_out)
-        if W > 1:
+        if self.coll:
             self.comm.all_to_all(s.cache[:W * self.cap], s.rows_out)
         lb.slot = slot
         return lb
@@ -235,12 +238,12 @@ class DistEngine(object):
 
     def _push_apply(self, lb, before_apply=None):
         sp, s, W = self.spec, self.slots[lb.slot], self.spec.world
-        if W > 1:
+        if self.coll:
             self.comm.all_to_all(self.recv_msg, self.ent_msg[:W * self.cap])
         if before_apply is not None:
             before_apply()
         self.ops.apply_merged(self.ent, self.ent_state, W, self.cap, s.recv_ids, sp.lo, self.recv_msg, 2, self.lr)
-        if W > 1:
+        if self.coll:
             self.comm.all_gather(self.all_rel.view(-1), self.rel_msg.view(-1))
         self.ops.apply_merged(self.engine.rel, self.engine.rel_state, W, lb.B, None, 0, self.all_rel, 1, self.lr)
 
@@ -273,12 +276,12 @@ class DistEngine(object):
                 sp, s, W = self.spec, self.slots[nslot], self.spec.world
                 nlb = self.ops.route(next_batch, W, sp.shard, self.cap, s)
                 nlb.slot = nslot
-                if W > 1:
+                if self.coll:
                     self.comm.all_to_all(s.recv_ids, s.req_ids)
                 self.ops.gather_req(self.ent, s.recv_ids, sp.lo, s.rows_out)
                 ev_gather = torch.cuda.Event()
                 ev_gather.record(self._side)
-                if W > 1:
+                if self.coll:
                     self.comm.all_to_all(s.cache[:W * self.cap], s.rows_out)
                 ev_rows = torch.cuda.Event()
                 ev_rows.record(self._side)

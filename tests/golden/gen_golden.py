@@ -165,6 +165,35 @@ def make_batch(rng, case, step):
                 h_local=h_local, t_local=t_local, C=C, w=w)
 
 
+class HeldQueue(object):
+    """stands in for the `mp.Queue(1)` that `ExternalEmbedding.create_async_update` makes (tensor_models.py:364-368): `put` parks
+    the item; nothing is applied until `land()` hands the parked items to the reference's own, unmodified `async_update` loop
+    (tensor_models.py:136-175) - with the helper PROCESS the moment is a race (<= 1 step late), here it is fixed at its bound."""
+
+    def __init__(self):
+        self.items = []
+
+    def put(self, item):
+        self.items.append(item)
+
+
+class _DrainQueue(object):
+    def __init__(self, items):
+        self.items = list(items) + [(None, None, None)]      # ... then the sentinel of finish_async_update (:370-375)
+
+    def get(self):
+        return self.items.pop(0)
+
+
+def land(model, args):
+    """run the reference's async_update body on everything parked in the entity table's queue"""
+    from dglke.models.pytorch.tensor_models import async_update
+    q = model.entity_emb.async_q
+    if q.items:
+        async_update(args, model.entity_emb, _DrainQueue(q.items))
+        q.items = []
+
+
 def run_case(name, case):
     from dglke.models import KEModel
     th.manual_seed(case["seed"])
@@ -179,6 +208,11 @@ def run_case(name, case):
     transr = case["model"] == "TransR"
     if transr:      # third table: per-relation projection matrices owned by the score function (score_fun.py:114-118)
         out["init_projection"] = model.score_func.projection_emb.emb.numpy().copy()
+    use_async = bool(case.get("async", False))
+    if use_async:
+        # --async_update (train_pytorch.py:120-121 -> KEModel.create_async_update, general_models.py:639-647: the ENTITY table
+        # only): ExternalEmbedding.update then hands its traces to the queue (tensor_models.py:325-328) instead of applying them
+        model.entity_emb.async_q = HeldQueue()
     for s in range(1, case["steps"] + 1):
         b = make_batch(rng, case, s)
         pos_g = PosG(th.from_numpy(b["nid"]), th.from_numpy(b["h_local"]),
@@ -216,6 +250,8 @@ def run_case(name, case):
         out[p + "g_pos_ent"] = et[0][1].grad.numpy().copy()
         out[p + "g_neg"] = et[1][1].grad.numpy().copy()
         out[p + "g_rel"] = rt[0][1].grad.numpy().copy()
+        if use_async:
+            land(model, args)        # the helper finished step s-1's entity update while step s was being scored
         model.update(-1)
         out[p + "entity_state"] = model.entity_emb.state_sum.numpy().copy()
         out[p + "relation_state"] = model.relation_emb.state_sum.numpy().copy()
@@ -225,6 +261,8 @@ def run_case(name, case):
         if case.get("save_tables_each_step", True):
             out[p + "entity"] = model.entity_emb.emb.numpy().copy()
             out[p + "relation"] = model.relation_emb.emb.numpy().copy()
+    if use_async:
+        land(model, args)            # finish_async_update: the last pending update lands
     out["final_entity"] = model.entity_emb.emb.numpy().copy()
     out["final_relation"] = model.relation_emb.emb.numpy().copy()
     out["final_entity_state"] = model.entity_emb.state_sum.numpy().copy()
@@ -328,6 +366,16 @@ CASES = {
     "nd_transe_l1_mid": base("TransE_l1", n_ent=400, n_rel=30, hidden=64, gamma=16.0, B=96, N=32,
                              chunk=32, lr=0.01, reg_coef=1e-7, steps=2, neg_deg=True, seed=82,
                              save_tables_each_step=False),
+    # --async_update: the reference's own async_update body applies the entity traces one step late (HeldQueue above); the
+    # duplicate-heavy cases make the staleness visible in every row
+    "async_transe_l2_small": base("TransE_l2", steps=4, seed=91, **{"async": True}),
+    "async_transe_l2_dups": base("TransE_l2", n_ent=9, n_rel=2, steps=5, seed=92, **{"async": True}),
+    "async_distmult_dups": base("DistMult", gamma=6.0, lr=0.08, n_ent=9, n_rel=2, steps=5, seed=93, **{"async": True}),
+    "async_complex_small": base("ComplEx", gamma=6.0, de=True, dr=True, steps=4, seed=94, **{"async": True}),
+    "async_rotate_dups": base("RotatE", n_ent=9, n_rel=2, de=True, steps=5, seed=95, **{"async": True}),
+    "async_transe_l1_ragged": base("TransE_l1", hidden=20, B=30, N=7, chunk=10, steps=4, seed=96, **{"async": True}),
+    "async_transe_l2_mid": base("TransE_l2", n_ent=400, n_rel=30, hidden=64, gamma=19.9, B=96, N=32, chunk=32, lr=0.25,
+                                reg_coef=1e-9, steps=4, seed=97, save_tables_each_step=False, **{"async": True}),
 }
 
 

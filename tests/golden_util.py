@@ -8,12 +8,17 @@ import numpy as np
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
+def async_golden_names():
+    """--async_update goldens (gen_golden.py cases with async=True: the reference's own async_update body, one step late)"""
+    return sorted(n for n in (os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "async_*.npz"))))
+
+
 def golden_names(transr=None, nd=False):
     """training-step goldens (gen_golden.py).  transr: None = all, False = without the TransR cases (three
     tables: the generic two-table harnesses skip them), True = only TransR.  nd: False = without the
-    --neg_deg_sample cases (nd_*), True = only those, None = both."""
+    --neg_deg_sample cases (nd_*), True = only those, None = both.  (The async_* goldens have their own list.)"""
     names = sorted(n for n in (os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
-                   if not n.startswith("eval_"))
+                   if not n.startswith("eval_") and not n.startswith("async_"))
     if nd is not None:
         names = [n for n in names if n.startswith("nd_") == bool(nd)]
     if transr is None:

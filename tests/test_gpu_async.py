@@ -169,3 +169,35 @@ def test_dropin_model_async_update_matches_the_stale_oracle():
     _close(m.entity_emb.state_sum.cpu(), es, 2e-3, 1e-9, "entity state")
     _close(m.entity_emb.emb.cpu(), e64, 1e-4, 1e-2 * case["lr"], "entity table")
     _close(m.relation_emb.emb.cpu(), r64, 1e-4, 1e-2 * case["lr"], "relation table")
+
+
+def _async_goldens():
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from golden_util import async_golden_names
+    return async_golden_names()
+
+
+@pytest.mark.parametrize("name", _async_goldens())
+def test_async_pipeline_matches_the_reference_async_update(name):
+    """kge_step_async against goldens recorded from the REFERENCE's own --async_update code path (the unmodified async_update
+    loop body applying every step's entity traces one step late; tests/golden/gen_golden.py): final tables and states."""
+    from golden_util import load_golden
+    from dglke_amd import plan
+    from dglke_amd.engine import StepEngine
+    z, case = load_golden(name)
+    eng = StepEngine(case["model"], case["n_ent"], case["n_rel"], case["hidden"], case["gamma"], case["lr"], DEV, case["de"],
+                     case["dr"], case["adv"], case["adv_temp"], case["reg_coef"], case["reg_norm"])
+    eng.load_tables(z["init_entity"], z["init_relation"])
+    batches = []
+    for s in range(1, case["steps"] + 1):
+        p = "s%d_" % s
+        batches.append(plan.make_batch(z[p + "h"], z[p + "t"], z[p + "r"], z[p + "neg"], case["chunk"], case["N"],
+                                       bool(z[p + "neg_head"]), DEV))
+    eng.steps_async(batches)
+    torch.cuda.synchronize()
+    lr = case["lr"]
+    _close(eng.ent_state.cpu().numpy(), z["final_entity_state"], 2e-3, 1e-9, name + " entity state")
+    _close(eng.rel_state.cpu().numpy(), z["final_relation_state"], 2e-3, 1e-9, name + " relation state")
+    _close(eng.ent.cpu().numpy(), z["final_entity"], 1e-4, 1e-2 * lr, name + " entity table")
+    _close(eng.rel.cpu().numpy(), z["final_relation"], 1e-4, 1e-2 * lr, name + " relation table")

@@ -222,8 +222,8 @@ def test_fused_step_matches_oracle_at_config_shapes(shape, flags):
         _close(want["g_rel"].cpu(), out["g_rel"], 3e-4, grad_tol(out["g_rel"]), tag + " g_rel")
         _close(eng.ent_state.cpu(), es64, 2e-3, 1e-9, tag + " ent state")
         _close(eng.rel_state.cpu(), rs64, 2e-3, 1e-9, tag + " rel state")
-        _close(eng.ent.cpu(), ent64, 1e-4, 5e-3 * lr, tag + " entity rows")
-        _close(eng.rel.cpu(), rel64, 1e-4, 5e-3 * lr, tag + " relation rows")
+        _close(eng.ent.cpu(), ent64, 1e-4, 1e-3 * lr, tag + " entity rows")       # (fp64 oracle from the SAME fp32 tables: the
+        _close(eng.rel.cpu(), rel64, 1e-4, 1e-3 * lr, tag + " relation rows")     #  per-step error, profiles/r03_row_error_trajectory.txt)
 
 
 def test_fused_step_is_deterministic_and_graph_replay_matches_eager():
@@ -294,6 +294,64 @@ def test_merged_forward_launch_equals_split_launches_bit_for_bit(model, gamma):
     assert np.isfinite(results[0][4]).all()
 
 
+def test_row_error_trajectory_over_24_steps():
+    """How far do the post-update rows drift from exact arithmetic, step after step, at the cfg-T shape?  Every step restarts the
+    fp64 statement from the GPU's own fp32 tables, so the numbers are PER-STEP errors (they cannot accumulate):
+      update:  fp64 Adagrad (trace order, oracle.adagrad_update) fed the GPU's OWN fp32 gradients - isolates the update kernel;
+      full:    the whole fp64 oracle step - adds the gradient kernels' rounding, amplified by Adagrad's normalisation
+               (delta = -lr * g / sqrt(state): with state ~ 0 in the first steps a relative error of the gradient IS a relative
+               error of a step of size ~lr).
+    The trajectory is written next to the test (gpurun_out/) and bounded: at this shape the rows of EVERY step agree with exact
+    arithmetic to < 1e-4 * lr (update kernel alone: < 2e-6 * lr).  The 5e-3 * lr of the golden comparisons is a bound on the
+    fp32 REFERENCE's own rounding at toy sizes (D = 16, 9 - 60 entities, duplicate-heavy batches), not on these kernels."""
+    from dglke_amd import plan
+    from dglke_amd.engine import StepEngine
+    rng = np.random.RandomState(21)
+    n_ent, n_rel, B, N, D, lr = 14951, 1345, 1000, 200, 400, 0.25
+    cfg = O.Config("TransE_l2", 19.9, D, lr, adv=True, adv_temp=1.0, reg_coef=1e-9, reg_norm=3)
+    torch.manual_seed(0)
+    eng = StepEngine("TransE_l2", n_ent, n_rel, D, 19.9, lr, DEV, False, False, True, 1.0, 1e-9, 3)
+    lines = ["step  update-only max|err|/lr   full-step max|err|/lr (entity rows)   relation rows full   rows touched"]
+    upd_err, full_err = [], []
+    for step in range(1, 25):
+        ent64, rel64 = eng.ent.cpu().numpy().astype(np.float64), eng.rel.cpu().numpy().astype(np.float64)
+        es64, rs64 = eng.ent_state.cpu().numpy().astype(np.float64), eng.rel_state.cpu().numpy().astype(np.float64)
+        bt = O.synth_batch(rng, n_ent, n_rel, B, N, N, step)
+        b = plan.make_batch(bt["h"], bt["t"], bt["r"], bt["neg"], N, N, bt["neg_head"], DEV)
+        want = eng.alloc_outputs(b)
+        eng.step(b, want)
+        torch.cuda.synchronize()
+        got_e, got_r = eng.ent.cpu().numpy().astype(np.float64), eng.rel.cpu().numpy().astype(np.float64)
+        # (i) fp64 update from the GPU's own gradients
+        ue, ur = ent64.copy(), rel64.copy()
+        ues, urs = es64.copy(), rs64.copy()
+        sel = np.searchsorted(b.p["ue_id"], bt["nid"])
+        O.adagrad_update(ue, ues, bt["nid"], want["g_pos_ent"].cpu().numpy().astype(np.float64)[sel], lr)
+        O.adagrad_update(ue, ues, bt["neg"], want["g_neg"].cpu().numpy().astype(np.float64), lr)
+        O.adagrad_update(ur, urs, bt["r"], want["g_rel"].cpu().numpy().astype(np.float64), lr)
+        # (ii) the whole step in fp64
+        fe, fr, fes, frs = ent64.copy(), rel64.copy(), es64.copy(), rs64.copy()
+        O.train_step(cfg, fe, fes, fr, frs, bt["nid"], bt["h_local"], bt["t_local"], bt["r"], bt["neg"], bt["neg_head"], N, N)
+        touched = np.unique(np.concatenate([bt["nid"], bt["neg"]]))
+        e_u = np.abs(got_e - ue).max() / lr
+        e_f = np.abs(got_e - fe).max() / lr
+        r_f = np.abs(got_r - fr).max() / lr
+        upd_err.append(max(e_u, np.abs(got_r - ur).max() / lr))
+        full_err.append(max(e_f, r_f))
+        lines.append("%4d  %12.3e              %12.3e                         %12.3e        %d" % (step, e_u, e_f, r_f, len(touched)))
+    try:
+        import os
+        out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        open(os.path.join(out, "row_error_trajectory.txt"), "w").write("\n".join(lines) + "\n")
+    except OSError:
+        pass
+    print("\n".join(lines))
+    # measured on MI355X (profiles/r03_row_error_trajectory.txt): update-only 4.0e-7 .. 7.1e-7, full step 6.6e-7 .. 3.7e-5 (x lr)
+    assert max(upd_err) < 2e-6, "update kernel vs fp64 Adagrad on its own gradients: %.3e * lr" % max(upd_err)
+    assert max(full_err) < 1e-4, "per-step row error: %r" % (full_err,)
+
+
 def test_adagrad_scatter_duplicate_semantics():
     """ExternalEmbedding.update duplicate-index semantics (tensor_models.py:352-361) with the
     lock-free scatter kernels: a table of 5 rows, 4096 updates."""
@@ -345,13 +403,19 @@ def test_sharded_engine_world1_equals_fused_step():
             b.rel.copy_(a.rel)
             ent = a.ent.clone()
             state = torch.zeros(n_ent, device=DEV)
-            deng = kd.DistEngine(b, kd.ShardSpec(n_ent, 1, 0), ent, state)
+            # RotatE: through the RCCL calls too (equal-split all_to_all_single / all_gather_into_tensor with one rank) and the
+            # one-step pull pipeline's streams and events - with a single batch in flight the pipeline is the synchronous step
+            coll = model == "RotatE"
+            deng = kd.DistEngine(b, kd.ShardSpec(n_ent, 1, 0), ent, state, always_collective=coll)
             for step in range(1, 4):
                 bt = O.synth_batch(rng, n_ent, n_rel, B, N, N, step)
                 a.step(plan.make_batch(bt["h"], bt["t"], bt["r"], bt["neg"], N, N, bt["neg_head"], DEV))
                 gb = plan.make_batch(bt["h"], bt["t"], bt["r"], bt["neg"], N, N, bt["neg_head"], DEV)      # GLOBAL ids
                 gb.UE = 2 * B + (B // N) * N         # the engine sizes its buffers once, for the bound
-                deng.step(gb)                        # route on the device -> (world 1: no collective) -> grads -> merged apply
+                if coll:
+                    deng.step_pipelined(gb, None)
+                else:
+                    deng.step(gb)                    # route on the device -> (world 1: no collective) -> grads -> merged apply
             assert deng.check_overflow() == 0
             torch.cuda.synchronize()
             # the two paths run different instantiations of the update code (in-place vs gradient-emitting +

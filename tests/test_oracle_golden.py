@@ -3,7 +3,7 @@ reference (tests/golden/gen_golden.py).  CPU-only; runs in seconds."""
 import numpy as np
 import pytest
 
-from golden_util import eval_golden_names, golden_names, load_golden, oracle_config
+from golden_util import async_golden_names, eval_golden_names, golden_names, load_golden, oracle_config
 from oracle import kge_oracle as O
 
 
@@ -127,6 +127,50 @@ def test_torch_port_num_proc_mode_runs():
              adv=True, adv_temp=1.0, reg_coef=1e-6, reg_norm=3)
     rate, steps = torch_port.hogwild_cpu(w, 2, seconds=0.5, timeout=120.0)
     assert steps >= 2 and rate > 0
+
+
+def _golden_batches(z, case):
+    bts = []
+    for s in range(1, case["steps"] + 1):
+        p = "s%d_" % s
+        bts.append(dict(nid=z[p + "nid"], h_local=z[p + "h_local"], t_local=z[p + "t_local"], r=z[p + "r"], neg=z[p + "neg"],
+                        neg_head=bool(z[p + "neg_head"]), chunk=case["chunk"], N=case["N"], h=z[p + "h"], t=z[p + "t"]))
+    return bts
+
+
+@pytest.mark.parametrize("name", async_golden_names())
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_train_steps_async_matches_the_reference_async_update(name, dtype):
+    """--async_update pinned to the REFERENCE: the goldens were recorded by running the unmodified KEModel with
+    entity_emb.async_q set and the reference's own async_update loop body (tensor_models.py:136-175) applying every step's
+    entity traces one step late (tests/golden/gen_golden.py HeldQueue / land).  oracle.train_steps_async must reproduce the
+    scores and gradients of every (stale) step and the final tables and states."""
+    z, case = load_golden(name)
+    assert case.get("async")
+    cfg = oracle_config(case)
+    ent, rel = z["init_entity"].astype(dtype), z["init_relation"].astype(dtype)
+    es, rs = np.zeros(ent.shape[0], dtype), np.zeros(rel.shape[0], dtype)
+    outs = O.train_steps_async(cfg, ent, es, rel, rs, _golden_batches(z, case))
+    for s, out in enumerate(outs, 1):
+        p = "s%d_" % s
+        # from step 3 on the scores depend on updates that went through fp32 Adagrad in the reference: a little more room
+        tol = dict(rtol=2e-4, atol=2e-5 if s <= 2 else 2e-4)
+        _close(out["pos_score"], z[p + "pos_score"], what=name + " pos_score step %d" % s, **tol)
+        _close(out["neg_score"], z[p + "neg_score"], what=name + " neg_score step %d" % s, **tol)
+        if s <= 2:
+            for k in ("g_pos_ent", "g_rel", "g_neg"):
+                _close(out[k], z[p + k], 2e-4, 3e-4 * max(np.abs(z[p + k]).max(), 1e-12), name + " " + k + " step %d" % s)
+    _close(es, z["final_entity_state"], 2e-3, 1e-9, name + " entity state")
+    _close(rs, z["final_relation_state"], 2e-3, 1e-9, name + " relation state")
+    _close(ent, z["final_entity"], 1e-4, 1e-2 * case["lr"], name + " final entity")
+    _close(rel, z["final_relation"], 1e-4, 1e-2 * case["lr"], name + " final relation")
+    # not vacuous: the strict step from the same start ends somewhere else
+    e2, r2 = z["init_entity"].astype(np.float64), z["init_relation"].astype(np.float64)
+    es2, rs2 = np.zeros(e2.shape[0]), np.zeros(r2.shape[0])
+    for bt in _golden_batches(z, case):
+        O.train_step(cfg, e2, es2, r2, rs2, bt["nid"], bt["h_local"], bt["t_local"], bt["r"], bt["neg"], bt["neg_head"],
+                     bt["chunk"], bt["N"])
+    assert np.abs(e2 - z["final_entity"]).max() > 1e-3 * case["lr"]
 
 
 def test_async_oracle_reduces_to_the_strict_step():
