@@ -464,3 +464,213 @@ int launch_transr_proj_update(const TransRArgs &a, hipStream_t s) {
     hipLaunchKernelGGL(transr_proj_apply_kernel, dim3(a.UR * TR_RB), dim3(KGE_BLOCK), 0, s, a);
     return check_launch_t();
 }
+
+// =============================================================================================
+// per-op (drop-in) route: the projections of TransRScore.prepare / create_neg_prepare (score_fun.py:131-166) and their
+// autograd as stand-alone operators on DENSE gathered operands - the same tile routine as the fused kernels above, plain
+// fp32 operands and plain epilogues (the reference's decomposition materialises Y [C, chunk, N, D_r]; so does this route)
+// =============================================================================================
+struct PnArgs {
+    int B, C, chunk, N, De, Dr, accumulate;
+    const float *proj;             // [B, De * Dr] gathered projection rows (one per positive edge)
+    const float *neg;              // [C * N, De]
+    const float *x;                // [B, De]
+    const float *gy;               // [B, Dr]
+    float *Y;                      // fwd out / bwd in [B, N, Dr]
+    float *gneg, *gproj, *gx;
+};
+
+// Y_i = Neg_c P_i        workgroup = (positive i, 64 negatives, 64 columns of D_r)
+template <bool VEC>
+__global__ __launch_bounds__(KGE_BLOCK) void transr_pn_fwd_kernel(PnArgs a, int nJB, int nRB) {
+    __shared__ float As[2][TR_K][TR_LD], Bs[2][TR_K][TR_LD];
+    const int rb = blockIdx.x % nRB, jb = (blockIdx.x / nRB) % nJB, i = blockIdx.x / (nRB * nJB);
+    const int c = i / a.chunk, De = a.De, Dr = a.Dr, N = a.N, j0 = jb * TR_T, dr0 = rb * TR_T;
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63, m = lane & 15, q = lane >> 4;
+    const float *Pi = a.proj + (int64_t)i * De * Dr, *Nc = a.neg + (int64_t)c * N * De;
+    f32x4 acc[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (VEC)
+        tile_sweep4<false, true>(acc, De,
+            [&](int row, int k) { return (j0 + row < N && k < De) ? *reinterpret_cast<const float4 *>(Nc + (int64_t)(j0 + row) * De + k) : f4zero(); },
+            [&](int k, int col) { return (k < De && dr0 + col < Dr) ? *reinterpret_cast<const float4 *>(Pi + (int64_t)k * Dr + dr0 + col) : f4zero(); },
+            As, Bs);
+    else
+        tile_sweep<true, false>(acc, De,
+            [&](int row, int k) { return (j0 + row < N && k < De) ? Nc[(int64_t)(j0 + row) * De + k] : 0.f; },
+            [&](int k, int col) { return (k < De && dr0 + col < Dr) ? Pi[(int64_t)k * Dr + dr0 + col] : 0.f; }, As, Bs);
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        const int col = dr0 + ct * 16 + m;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = j0 + wave * 16 + 4 * q + r;
+            if (col < Dr && j < N) a.Y[((int64_t)i * N + j) * Dr + col] = acc[ct][r];
+        }
+    }
+}
+
+// gNeg_c[j][de] = sum_{i in chunk} sum_dr gY_i[j][dr] P_i[de][dr]     workgroup = (chunk, 64 negatives, 64 de)
+template <bool VEC>
+__global__ __launch_bounds__(KGE_BLOCK) void transr_pn_bwd_neg_kernel(PnArgs a, int nJB, int nEB) {
+    __shared__ float As[2][TR_K][TR_LD], Bs[2][TR_K][TR_LD];
+    const int eb = blockIdx.x % nEB, jb = (blockIdx.x / nEB) % nJB, c = blockIdx.x / (nEB * nJB);
+    const int j0 = jb * TR_T, de0 = eb * TR_T, De = a.De, Dr = a.Dr, N = a.N, chunk = a.chunk;
+    const int DrP = (Dr + TR_K - 1) / TR_K * TR_K;
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63, m = lane & 15, q = lane >> 4;
+    f32x4 acc[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (VEC)
+        tile_sweep4<false, false>(acc, chunk * DrP,
+            [&](int row, int k) {
+                const int il = k / DrP, dr = k % DrP, j = j0 + row;
+                if (j >= N || dr >= Dr) return f4zero();
+                return *reinterpret_cast<const float4 *>(a.Y + (((int64_t)c * chunk + il) * N + j) * Dr + dr);
+            },
+            [&](int k, int col) {
+                const int il = k / DrP, dr = k % DrP, de = de0 + col;
+                if (de >= De || dr >= Dr) return f4zero();
+                return *reinterpret_cast<const float4 *>(a.proj + ((int64_t)c * chunk + il) * De * Dr + (int64_t)de * Dr + dr);
+            }, As, Bs);
+    else
+        tile_sweep<true, true>(acc, chunk * DrP,
+            [&](int row, int k) {
+                const int il = k / DrP, dr = k % DrP, j = j0 + row;
+                return (j >= N || dr >= Dr) ? 0.f : a.Y[(((int64_t)c * chunk + il) * N + j) * Dr + dr];
+            },
+            [&](int k, int col) {
+                const int il = k / DrP, dr = k % DrP, de = de0 + col;
+                return (de >= De || dr >= Dr) ? 0.f : a.proj[((int64_t)c * chunk + il) * De * Dr + (int64_t)de * Dr + dr];
+            }, As, Bs);
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        const int de = de0 + ct * 16 + m;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = j0 + wave * 16 + 4 * q + r;
+            if (de < De && j < N) a.gneg[((int64_t)c * N + j) * De + de] = acc[ct][r];
+        }
+    }
+}
+
+// gP_i[de][dr] (+)= sum_j Neg_j[de] gY_ij[dr]     workgroup = (positive, 64 de, 64 dr)
+template <bool VEC>
+__global__ __launch_bounds__(KGE_BLOCK) void transr_pn_bwd_proj_kernel(PnArgs a, int nEB, int nRB) {
+    __shared__ float As[2][TR_K][TR_LD], Bs[2][TR_K][TR_LD];
+    const int rb = blockIdx.x % nRB, eb = (blockIdx.x / nRB) % nEB, i = blockIdx.x / (nRB * nEB);
+    const int de0 = eb * TR_T, dr0 = rb * TR_T, De = a.De, Dr = a.Dr, N = a.N, c = i / a.chunk;
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63, m = lane & 15, q = lane >> 4;
+    const float *Nc = a.neg + (int64_t)c * N * De, *Yi = a.Y + (int64_t)i * N * Dr;
+    f32x4 acc[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (VEC)
+        tile_sweep4<true, true>(acc, N,
+            [&](int row, int k) { return (k < N && de0 + row < De) ? *reinterpret_cast<const float4 *>(Nc + (int64_t)k * De + de0 + row) : f4zero(); },
+            [&](int k, int col) { return (k < N && dr0 + col < Dr) ? *reinterpret_cast<const float4 *>(Yi + (int64_t)k * Dr + dr0 + col) : f4zero(); },
+            As, Bs);
+    else
+        tile_sweep<false, false>(acc, N,
+            [&](int row, int k) { return (k < N && de0 + row < De) ? Nc[(int64_t)k * De + de0 + row] : 0.f; },
+            [&](int k, int col) { return (k < N && dr0 + col < Dr) ? Yi[(int64_t)k * Dr + dr0 + col] : 0.f; }, As, Bs);
+    float *G = a.gproj + (int64_t)i * De * Dr;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        const int dr = dr0 + ct * 16 + m;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int de = de0 + wave * 16 + 4 * q + r;
+            if (de < De && dr < Dr) {
+                const int64_t o = (int64_t)de * Dr + dr;
+                G[o] = a.accumulate ? G[o] + acc[ct][r] : acc[ct][r];
+            }
+        }
+    }
+}
+
+// one workgroup per edge: y_i = x_i P_i (fwd) / gx_i = P_i gy_i and gP_i (+)= x_i (x) gy_i (bwd)
+__global__ __launch_bounds__(KGE_BLOCK) void transr_pv_fwd_kernel(PnArgs a) {
+    const int i = blockIdx.x, De = a.De, Dr = a.Dr;
+    const float *P = a.proj + (int64_t)i * De * Dr, *x = a.x + (int64_t)i * De;
+    for (int dr = threadIdx.x; dr < Dr; dr += KGE_BLOCK) {
+        float s = 0.f;
+        for (int de = 0; de < De; ++de) s = fmaf(x[de], P[(int64_t)de * Dr + dr], s);
+        a.Y[(int64_t)i * Dr + dr] = s;
+    }
+}
+__global__ __launch_bounds__(KGE_BLOCK) void transr_pv_bwd_kernel(PnArgs a) {
+    const int i = blockIdx.x, De = a.De, Dr = a.Dr;
+    const float *P = a.proj + (int64_t)i * De * Dr, *x = a.x + (int64_t)i * De, *gy = a.gy + (int64_t)i * Dr;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (a.gx) {
+        for (int de = wave; de < De; de += KGE_WAVES_PER_BLOCK) {       // one wavefront per row of P: coalesced along d_r
+            float s = 0.f;
+            for (int dr = lane; dr < Dr; dr += 64) s = fmaf(P[(int64_t)de * Dr + dr], gy[dr], s);
+            s = wave_sum(s);
+            if (lane == 0) a.gx[(int64_t)i * De + de] = s;
+        }
+    }
+    if (a.gproj) {
+        float *G = a.gproj + (int64_t)i * De * Dr;
+        for (int o = threadIdx.x; o < De * Dr; o += KGE_BLOCK) {
+            const float v = x[o / Dr] * gy[o % Dr];
+            G[o] = a.accumulate ? G[o] + v : v;
+        }
+    }
+}
+
+extern "C" {
+
+int kge_transr_project(const float *proj, const float *x, int64_t B, int d_e, int d_r, float *out, void *stream) {
+    if (B < 0 || d_e <= 0 || d_r <= 0 || (B && (!proj || !x || !out))) return KGE_ERR_ARG;
+    if (B == 0) return KGE_OK;
+    PnArgs a{}; a.B = (int)B; a.De = d_e; a.Dr = d_r; a.proj = proj; a.x = x; a.Y = out;
+    hipLaunchKernelGGL(transr_pv_fwd_kernel, dim3((unsigned)B), dim3(KGE_BLOCK), 0, (hipStream_t)stream, a);
+    return check_launch_t();
+}
+
+int kge_transr_project_bwd(const float *proj, const float *x, const float *gy, int64_t B, int d_e, int d_r, float *gx,
+                           float *gproj, int accumulate, void *stream) {
+    if (B < 0 || d_e <= 0 || d_r <= 0 || (B && (!proj || !x || !gy))) return KGE_ERR_ARG;
+    if (B == 0 || (!gx && !gproj)) return KGE_OK;
+    PnArgs a{}; a.B = (int)B; a.De = d_e; a.Dr = d_r; a.proj = proj; a.x = x; a.gy = gy; a.gx = gx; a.gproj = gproj;
+    a.accumulate = accumulate;
+    hipLaunchKernelGGL(transr_pv_bwd_kernel, dim3((unsigned)B), dim3(KGE_BLOCK), 0, (hipStream_t)stream, a);
+    return check_launch_t();
+}
+
+int kge_transr_project_neg(const float *proj, const float *neg, int C, int chunk, int N, int d_e, int d_r, float *Y, void *stream) {
+    if (C < 0 || chunk <= 0 || N <= 0 || d_e <= 0 || d_r <= 0 || (C && (!proj || !neg || !Y))) return KGE_ERR_ARG;
+    if (C == 0) return KGE_OK;
+    PnArgs a{}; a.B = C * chunk; a.C = C; a.chunk = chunk; a.N = N; a.De = d_e; a.Dr = d_r; a.proj = proj; a.neg = neg; a.Y = Y;
+    const int nJB = (N + TR_T - 1) / TR_T, nRB = (d_r + TR_T - 1) / TR_T;
+    const dim3 g((unsigned)(a.B * nJB * nRB)), b(KGE_BLOCK);
+    if (d_e % 4 == 0 && d_r % 4 == 0) hipLaunchKernelGGL(transr_pn_fwd_kernel<true>, g, b, 0, (hipStream_t)stream, a, nJB, nRB);
+    else hipLaunchKernelGGL(transr_pn_fwd_kernel<false>, g, b, 0, (hipStream_t)stream, a, nJB, nRB);
+    return check_launch_t();
+}
+
+int kge_transr_project_neg_bwd(const float *proj, const float *neg, const float *gY, int C, int chunk, int N, int d_e, int d_r,
+                               float *gneg, float *gproj, int accumulate, void *stream) {
+    if (C < 0 || chunk <= 0 || N <= 0 || d_e <= 0 || d_r <= 0 || (C && (!proj || !neg || !gY))) return KGE_ERR_ARG;
+    if (C == 0) return KGE_OK;
+    PnArgs a{}; a.B = C * chunk; a.C = C; a.chunk = chunk; a.N = N; a.De = d_e; a.Dr = d_r; a.proj = proj; a.neg = neg;
+    a.Y = const_cast<float *>(gY); a.gneg = gneg; a.gproj = gproj; a.accumulate = accumulate;
+    const int nJB = (N + TR_T - 1) / TR_T, nEB = (d_e + TR_T - 1) / TR_T, nRB = (d_r + TR_T - 1) / TR_T;
+    const bool vec = d_e % 4 == 0 && d_r % 4 == 0;
+    const dim3 b(KGE_BLOCK);
+    hipStream_t s = (hipStream_t)stream;
+    if (gneg) {
+        if (vec) hipLaunchKernelGGL(transr_pn_bwd_neg_kernel<true>, dim3((unsigned)(C * nJB * nEB)), b, 0, s, a, nJB, nEB);
+        else hipLaunchKernelGGL(transr_pn_bwd_neg_kernel<false>, dim3((unsigned)(C * nJB * nEB)), b, 0, s, a, nJB, nEB);
+    }
+    if (gproj) {
+        if (vec) hipLaunchKernelGGL(transr_pn_bwd_proj_kernel<true>, dim3((unsigned)(a.B * nEB * nRB)), b, 0, s, a, nEB, nRB);
+        else hipLaunchKernelGGL(transr_pn_bwd_proj_kernel<false>, dim3((unsigned)(a.B * nEB * nRB)), b, 0, s, a, nEB, nRB);
+    }
+    return check_launch_t();
+}
+
+}  // extern "C"

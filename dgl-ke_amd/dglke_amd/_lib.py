@@ -102,6 +102,10 @@ _SIGNATURES = {
                                  c_i, c_p]),
     "kge_batch_from_slot": (c_i, [c_p, c_sz, c_i, c_i, c_i, c_i, c_i, c_i, C.POINTER(KgeBatch)]),
     "kge_adagrad_apply_packed": (c_i, [c_p, c_p, c_i64, c_i, c_p, c_p, c_i, c_i64, c_i, c_f, c_f, c_p]),
+    "kge_transr_project": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_p, c_p]),
+    "kge_transr_project_bwd": (c_i, [c_p, c_p, c_p, c_i64, c_i, c_i, c_p, c_p, c_i, c_p]),
+    "kge_transr_project_neg": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
+    "kge_transr_project_neg_bwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p]),
     "kge_route_build": (c_i, [c_p, c_i, c_i64, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "kge_batch_localized": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "kge_gather_rows_req": (c_i, [c_p, c_i64, c_i, c_p, c_i64, c_i64, c_p, c_p]),

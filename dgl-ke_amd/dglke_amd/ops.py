@@ -115,6 +115,62 @@ def score_neg(model_name, neg_head, pos_side, rel, neg, num_chunks, chunk_size, 
                            float(emb_init), int(flags))
 
 
+class _TransRProject(torch.autograd.Function):
+    """y_i = x_i P_i for B edges (TransRScore.prepare, score_fun.py:131-136; the reference: th.matmul)."""
+    @staticmethod
+    def forward(ctx, x, proj, d_e, d_r):
+        x, proj = _f32(x), _f32(proj)
+        if x.shape[1] != d_e or proj.shape != (x.shape[0], d_e * d_r):
+            raise _lib.KgeError("transr_project: x [B, d_e], proj [B, d_e * d_r] expected")
+        out = torch.empty((x.shape[0], d_r), dtype=torch.float32, device=x.device)
+        check(lib().kge_transr_project(ptr(proj), ptr(x), x.shape[0], d_e, d_r, ptr(out), stream_ptr()))
+        ctx.save_for_backward(x, proj)
+        ctx.meta = (d_e, d_r)
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, proj = ctx.saved_tensors
+        d_e, d_r = ctx.meta
+        gy = _f32(gy)
+        gx, gp = torch.empty_like(x), torch.empty_like(proj)
+        check(lib().kge_transr_project_bwd(ptr(proj), ptr(x), ptr(gy), x.shape[0], d_e, d_r, ptr(gx), ptr(gp), 0, stream_ptr()))
+        return gx, gp, None, None
+
+
+def transr_project(x, proj, d_e, d_r):
+    return _TransRProject.apply(x, proj, int(d_e), int(d_r))
+
+
+class _TransRProjectNeg(torch.autograd.Function):
+    """Y[c,i,j,:] = neg[c,j,:] P_{c,i}: every negative of a chunk through every positive's matrix (the neg-prepare closure,
+    score_fun.py:138-166) - B batched [N x d_e] x [d_e x d_r] products on the fp32-MFMA tile routine of kge_transr.hip."""
+    @staticmethod
+    def forward(ctx, neg, proj, C, chunk, N, d_e, d_r):
+        neg, proj = _f32(neg), _f32(proj)
+        if neg.shape != (C * N, d_e) or proj.shape != (C * chunk, d_e * d_r):
+            raise _lib.KgeError("transr_project_neg: neg [C*N, d_e], proj [C*chunk, d_e * d_r] expected")
+        Y = torch.empty((C, chunk, N, d_r), dtype=torch.float32, device=neg.device)
+        check(lib().kge_transr_project_neg(ptr(proj), ptr(neg), C, chunk, N, d_e, d_r, ptr(Y), stream_ptr()))
+        ctx.save_for_backward(neg, proj)
+        ctx.meta = (C, chunk, N, d_e, d_r)
+        return Y
+
+    @staticmethod
+    def backward(ctx, gY):
+        neg, proj = ctx.saved_tensors
+        C, chunk, N, d_e, d_r = ctx.meta
+        gY = _f32(gY)
+        gn, gp = torch.empty_like(neg), torch.empty_like(proj)
+        check(lib().kge_transr_project_neg_bwd(ptr(proj), ptr(neg), ptr(gY), C, chunk, N, d_e, d_r, ptr(gn), ptr(gp), 0,
+                                               stream_ptr()))
+        return gn, gp, None, None, None, None, None
+
+
+def transr_project_neg(neg, proj, num_chunks, chunk_size, neg_sample_size, d_e, d_r):
+    return _TransRProjectNeg.apply(neg, proj, int(num_chunks), int(chunk_size), int(neg_sample_size), int(d_e), int(d_r))
+
+
 class _Loss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pos, neg, w, genre, adv, adv_temp, pairwise, margin):

@@ -114,8 +114,9 @@ class TransRScore(_HipScore):
 
     Per-op route (the reference's own decomposition): `prepare` projects head and tail of every positive edge with its
     relation's matrix (projection trace 0), the `create_neg_prepare` closures gather the matrices AGAIN (trace 1), project
-    the uncorrupted side and EVERY negative of the chunk with EVERY positive's matrix - plain batched matrix products,
-    run by the library GEMM behind torch.matmul with its autograd - and `edge_func` / `create_neg` are L1 distances in
+    the uncorrupted side and EVERY negative of the chunk with EVERY positive's matrix - batched matrix products on the
+    fp32-MFMA tile routine of kge_transr.hip (`kge_transr_project*`, analytic backward; the reference: th.matmul + autograd)
+    - and `edge_func` / `create_neg` are L1 distances in
     relation space: the TransE_l1 HIP kernels on the projected rows (one 'chunk' per positive for the negatives, whose
     projections differ per positive).  The fast path for TransR is the fused step (`KEModel.train_step`, kge_transr.hip),
     which never materialises the [C, chunk, N, relation_dim] tensor this route passes around like the reference."""
@@ -136,19 +137,21 @@ class TransRScore(_HipScore):
 
     def prepare(self, g, gpu_id, trace=False):
         head_ids, tail_ids = g.all_edges(order='eid')
-        projection = self.projection_emb(g.edata['id'], gpu_id, trace).reshape(-1, self.entity_dim, self.relation_dim)
+        projection = self.projection_emb(g.edata['id'], gpu_id, trace)        # [B, entity_dim * relation_dim]
         emb = g.ndata['emb']
-        g.edata['head_emb'] = th.matmul(ops.gather_local(emb, head_ids).unsqueeze(1), projection).squeeze(1)
-        g.edata['tail_emb'] = th.matmul(ops.gather_local(emb, tail_ids).unsqueeze(1), projection).squeeze(1)
+        De, Dr = self.entity_dim, self.relation_dim
+        g.edata['head_emb'] = ops.transr_project(ops.gather_local(emb, head_ids), projection, De, Dr)
+        g.edata['tail_emb'] = ops.transr_project(ops.gather_local(emb, tail_ids), projection, De, Dr)
 
     def create_neg_prepare(self, neg_head):
         def project(rel_id, num_chunks, pos, neg, gpu_id, trace):
-            projection = self.projection_emb(rel_id, gpu_id, trace)
-            projection = projection.reshape(num_chunks, -1, self.entity_dim, self.relation_dim)
-            pos = th.matmul(pos.reshape(num_chunks, -1, 1, self.entity_dim), projection)
-            pos = pos.reshape(num_chunks, -1, self.relation_dim)
+            projection = self.projection_emb(rel_id, gpu_id, trace)           # gathered AGAIN: the second trace entry
+            De, Dr = self.entity_dim, self.relation_dim
+            pos = ops.transr_project(pos.reshape(-1, De), projection, De, Dr).reshape(num_chunks, -1, Dr)
+            chunk = pos.shape[1]
+            neg = neg.reshape(-1, De)
             # (num_chunks, num_rel, num_neg_nodes, rel_dim): every negative through every positive's matrix
-            neg = th.matmul(neg.reshape(num_chunks, 1, -1, self.entity_dim), projection)
+            neg = ops.transr_project_neg(neg, projection, num_chunks, chunk, neg.shape[0] // num_chunks, De, Dr)
             return pos, neg
         if neg_head:
             def fn(rel_id, num_chunks, head, tail, gpu_id, trace=False):

@@ -425,6 +425,23 @@ int kge_adagrad_apply_packed(float *table, float *state_sum, int64_t n_rows, int
                              const int64_t *idx, const float *msg, int ld, int64_t n, int ntraces,
                              float lr, float eps, void *stream);
 
+/* ---- TransR, per-op (drop-in) route: the projections of TransRScore.prepare / create_neg_prepare
+ * (models/pytorch/score_fun.py:131-166, th.matmul in the reference) and their autograd, on DENSE gathered operands ----
+ * proj: [B, d_e * d_r] gathered projection rows, row i viewed as P_i [d_e, d_r] (projection_emb(rel_id), :133, :142)
+ * kge_transr_project:          out[i,:] = x[i,:] P_i                                   (:135-136, :144-145)
+ * kge_transr_project_bwd:      gx[i,:] = P_i gy[i,:];  gproj[i] (+)= x[i,:] (x) gy[i,:]  (either output may be NULL)
+ * kge_transr_project_neg:      Y[c,i,j,:] = neg[c,j,:] P_{c,i}   [C, chunk, N, d_r]     (:147-148: every negative of a chunk
+ *                              through every positive's matrix)
+ * kge_transr_project_neg_bwd:  gneg[c,j,:] = sum_i gY[c,i,j,:] P_{c,i}^T;  gproj[c,i] (+)= neg_c^T gY[c,i]
+ * fp32-MFMA tile routine of kge_transr.hip (64 x 64 tiles through LDS); accumulate != 0 adds into gproj. */
+int kge_transr_project(const float *proj, const float *x, int64_t B, int d_e, int d_r, float *out, void *stream);
+int kge_transr_project_bwd(const float *proj, const float *x, const float *gy, int64_t B, int d_e, int d_r, float *gx,
+                           float *gproj, int accumulate, void *stream);
+int kge_transr_project_neg(const float *proj, const float *neg, int C, int chunk, int N, int d_e, int d_r, float *Y,
+                           void *stream);
+int kge_transr_project_neg_bwd(const float *proj, const float *neg, const float *gY, int C, int chunk, int N, int d_e, int d_r,
+                               float *gneg, float *gproj, int accumulate, void *stream);
+
 /* ---- device-side routing of the range-sharded step (entity table sharded by id range over the ranks,
  * pull -> compute -> push with owner-side Adagrad, KEModel.pull_model / push_gradient, models/general_models.py:650-680,
  * kvserver.py:41-51) - no host round trip, fixed-size messages, so that the collectives between these calls are plain

@@ -81,3 +81,33 @@ def test_transr_fused_step_matches_oracle_at_tile_shapes():
         # re-synchronise the fp64 oracle on the fp32 tables so that drift does not accumulate
         ent, rel, proj = (x.cpu().numpy().astype(np.float64) for x in (eng.ent, eng.rel, eng.proj))
         es, rs, ps = (x.cpu().numpy().astype(np.float64) for x in (eng.ent_state, eng.rel_state, eng.proj_state))
+
+
+@pytest.mark.parametrize("C,chunk,N,De,Dr", [(2, 8, 12, 16, 16), (1, 5, 7, 10, 6), (3, 33, 70, 64, 40), (2, 64, 64, 128, 72)])
+def test_transr_projection_ops_match_torch_autograd(C, chunk, N, De, Dr):
+    """the per-op route's HIP projections (kge_transr_project / _neg and their analytic backward) against the reference's
+    th.matmul formulation (score_fun.py:131-166) in fp64 with torch autograd."""
+    from dglke_amd import ops
+    g = torch.Generator().manual_seed(C * 100 + N)
+    B = C * chunk
+    x = torch.randn(B, De, generator=g)
+    proj = torch.randn(B, De * Dr, generator=g) * 0.3
+    neg = torch.randn(C * N, De, generator=g)
+    wy = torch.randn(B, Dr, generator=g)
+    wY = torch.randn(C, chunk, N, Dr, generator=g)
+    # reference formulation, fp64
+    x64, p64, n64 = (t.double().requires_grad_(True) for t in (x, proj, neg))
+    P = p64.reshape(C, chunk, De, Dr)
+    y_ref = torch.matmul(x64.reshape(C, chunk, 1, De), P).reshape(B, Dr)
+    Y_ref = torch.matmul(n64.reshape(C, 1, N, De), P)
+    ((y_ref * wy.double()).sum() + (Y_ref * wY.double()).sum()).backward()
+    xd, pd, nd = (t.to(DEV).requires_grad_(True) for t in (x, proj, neg))
+    y = ops.transr_project(xd, pd, De, Dr)
+    Y = ops.transr_project_neg(nd, pd, C, chunk, N, De, Dr)
+    ((y * wy.to(DEV)).sum() + (Y * wY.to(DEV)).sum()).backward()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(y.detach().cpu().numpy(), y_ref.detach().numpy(), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(Y.detach().cpu().numpy(), Y_ref.detach().numpy(), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(xd.grad.cpu().numpy(), x64.grad.numpy(), rtol=2e-5, atol=3e-5)
+    np.testing.assert_allclose(nd.grad.cpu().numpy(), n64.grad.numpy(), rtol=2e-5, atol=2e-4)
+    np.testing.assert_allclose(pd.grad.cpu().numpy(), p64.grad.numpy(), rtol=2e-5, atol=2e-4)
