@@ -671,6 +671,7 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         KGE_TRY(launch_loss(la, s));
     }
 
+    bool fuse_gnred = false;
     if (phases & PH_BWD) {
     // 4. gradients w.r.t. the pos-side vectors and the negative rows
     if (transr) {
@@ -700,6 +701,12 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         na.W = S; na.GA = GA; na.GN = GN;
         na.reg_coef = (reg && !nd) ? hp->reg_coef : 0.f; na.reg_norm = hp->reg_norm;
         na.GNp = gemm ? nullptr : GNp;
+        // shared-pair backward followed by edge_bwd: the sum of its GN partials shares the edge_bwd launch (same inputs' producer,
+        // independent jobs).  Not with neg_deg_sample (edge_bwd reads GN) and not on the TransE fast path (no edge_bwd)
+        fuse_gnred = na.GNp && !nd && !transe_fast && !rescal && !transr && !sh && d_e % 4 == 0 && na.N % 4 == 0 &&
+                     (hp->model == KGE_ROTATE || hp->model == KGE_TRANSE_L1) && !(hp->flags & KGE_FLAG_TWO_PASS_PAIR) &&
+                     !(hp->flags & KGE_FLAG_SPLIT_FWD);
+        na.defer_reduce = fuse_gnred ? 1 : 0;
         KGE_TRY(launch_neg_bwd_pair(na, s));
         if (co_prep) KGE_TRY(launch_edge_fwd(*co_prep, s));
     }
@@ -751,7 +758,10 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         eb.dpos = dP; eb.GA = GA; eb.reg_coef = reg ? hp->reg_coef : 0.f; eb.reg_norm = hp->reg_norm;
         eb.GH = GH; eb.GT = GT; eb.GR = GR;
         if (nd) { eb.GNd = GN; eb.nd_chunk = chunk; eb.nd_Np = N; }   // in-batch negative rows -> positive trace
-        KGE_TRY(launch_edge_bwd(eb, s));
+        if (fuse_gnred) {
+            const int rc = launch_edge_bwd_with_gn_reduce(eb, na, neg_bwd_lc_nrw(hp->model, C, chunk, d_e), s);
+            if (rc != KGE_OK) return fail(rc, "launch_edge_bwd_with_gn_reduce failed (%d)", rc);
+        } else KGE_TRY(launch_edge_bwd(eb, s));
     }
 
     if (transe_fast && out && out->g_rel) {

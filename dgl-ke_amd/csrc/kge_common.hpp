@@ -313,7 +313,28 @@ struct NegArgs {                     // chunked negative scoring, forward and ba
     float clampv;                    // > 0: clamp the scores to [-clampv, clampv] (SimplE)
     float *GNp;                      // bwd, TransE_l1 / RotatE: room for the per-row-group GN partials
                                      // (neg_bwd_lc_partial_floats) or null: two-pass kernels
+    int defer_reduce;                // shared-pair backward: leave the partials unsummed (the caller's next launch sums them)
 };
+// GN[j, :] = sum over the nrw row groups of the shared-pair backward's partials (fixed order) + regulariser of the negative row;
+// t = float4 index into GN
+__device__ __forceinline__ void gn_reduce_body(const NegArgs &a, int nrw, int64_t t) {
+    const int64_t n4 = (int64_t)a.C * a.N * a.d_e / 4;
+    if (t >= n4) return;
+    const int64_t stride = (int64_t)a.C * a.N * a.d_e;
+    float4 acc = *reinterpret_cast<const float4 *>(a.GNp + 4 * t);
+    for (int r = 1; r < nrw; ++r) {
+        const float4 v = *reinterpret_cast<const float4 *>(a.GNp + r * stride + 4 * t);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    if (a.reg_coef > 0.f && a.reg_norm > 0) {
+        const int64_t j = (4 * t) / a.d_e;
+        const int k = (int)((4 * t) % a.d_e);
+        const float4 x = *reinterpret_cast<const float4 *>(kge::row_ptr(a.nbase, a.nidx, j, a.d_e) + k);
+        acc.x += kge::reg_grad(x.x, a.reg_coef, a.reg_norm); acc.y += kge::reg_grad(x.y, a.reg_coef, a.reg_norm);
+        acc.z += kge::reg_grad(x.z, a.reg_coef, a.reg_norm); acc.w += kge::reg_grad(x.w, a.reg_coef, a.reg_norm);
+    }
+    *reinterpret_cast<float4 *>(a.GN + 4 * t) = acc;
+}
 
 struct LossArgs {
     int B, N, genre, adv, pairwise;
@@ -516,3 +537,6 @@ int launch_neg_fwd_bcast(const NegArgs &a, hipStream_t s);
 int launch_neg_bwd_bcast(const NegArgs &a, hipStream_t s);
 bool neg_bwd_lc_supported(int model, int d_e);         // kge_neg_bcast.hip: lane = column, one pair evaluation feeds GA and GN
 size_t neg_bwd_lc_partial_floats(int model, int C, int chunk, int N, int d_e);
+int neg_bwd_lc_nrw(int model, int C, int chunk, int d_e);      // row groups whose partials gn_reduce sums
+struct EdgeBwdArgs;
+int launch_edge_bwd_with_gn_reduce(const EdgeBwdArgs &a, const NegArgs &n, int nrw, hipStream_t s);

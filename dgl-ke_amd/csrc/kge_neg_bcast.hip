@@ -622,24 +622,15 @@ __global__ __launch_bounds__(KGE_BLOCK) void neg_bwd_lc_kernel(NegArgs a, int ns
 }
 
 // GN[j, :] = sum over the workgroup row groups of the partials (fixed order) + regulariser of the negative row
+// (body in kge_common.hpp: the fused step runs it as the second half of the edge_bwd launch, kge_rowwise.hip)
 __global__ __launch_bounds__(KGE_BLOCK) void gn_reduce_kernel(NegArgs a, int nrw) {
-    const int64_t n4 = (int64_t)a.C * a.N * a.d_e / 4;
-    const int64_t t = (int64_t)blockIdx.x * KGE_BLOCK + threadIdx.x;
-    if (t >= n4) return;
-    const int64_t stride = (int64_t)a.C * a.N * a.d_e;
-    float4 acc = *reinterpret_cast<const float4 *>(a.GNp + 4 * t);
-    for (int r = 1; r < nrw; ++r) {
-        const float4 v = *reinterpret_cast<const float4 *>(a.GNp + r * stride + 4 * t);
-        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-    }
-    if (a.reg_coef > 0.f && a.reg_norm > 0) {
-        const int64_t j = (4 * t) / a.d_e;
-        const int k = (int)((4 * t) % a.d_e);
-        const float4 x = *reinterpret_cast<const float4 *>(row_ptr(a.nbase, a.nidx, j, a.d_e) + k);
-        acc.x += reg_grad(x.x, a.reg_coef, a.reg_norm); acc.y += reg_grad(x.y, a.reg_coef, a.reg_norm);
-        acc.z += reg_grad(x.z, a.reg_coef, a.reg_norm); acc.w += reg_grad(x.w, a.reg_coef, a.reg_norm);
-    }
-    *reinterpret_cast<float4 *>(a.GN + 4 * t) = acc;
+    gn_reduce_body(a, nrw, (int64_t)blockIdx.x * KGE_BLOCK + threadIdx.x);
+}
+
+int neg_bwd_lc_nrw(int model, int C, int chunk, int d_e) {
+    int nslab, nrw, rpw;
+    lc_shape(model, C, chunk, d_e, nslab, nrw, rpw);
+    return nrw;
 }
 
 template <int MODEL> static int lc_launch(const NegArgs &a, hipStream_t s) {
@@ -654,6 +645,7 @@ template <int MODEL> static int lc_launch(const NegArgs &a, hipStream_t s) {
     else if (rpw <= 16) hipLaunchKernelGGL((neg_bwd_lc_kernel<MODEL, 16>), g, b, 0, s, a, nslab, nrw, rpw);
     else if constexpr (MODEL != KGE_ROTATE) hipLaunchKernelGGL((neg_bwd_lc_kernel<MODEL, LC_RTMAX>), g, b, 0, s, a, nslab, nrw, rpw);
     if (int rc = check_launch_b()) return rc;
+    if (a.defer_reduce) return KGE_OK;           // the caller sums the partials in its next launch (launch_edge_bwd_with_gn_reduce)
     const int64_t n4 = (int64_t)a.C * a.N * a.d_e / 4;
     hipLaunchKernelGGL(gn_reduce_kernel, dim3((unsigned)((n4 + KGE_BLOCK - 1) / KGE_BLOCK)), dim3(KGE_BLOCK), 0, s, a, nrw);
     return check_launch_b();

@@ -124,11 +124,9 @@ int launch_edge_fwd(const EdgeFwdArgs &a, hipStream_t s) {
 //   (+ regularisation gradient of the relation row copy)
 // ------------------------------------------------------------------------------------------
 template <int MODEL, int V, bool LOCAL>       // LOCAL: un-sharded tables (no shard-map divisions compiled in)
-__global__ __launch_bounds__(KGE_BLOCK) void edge_bwd_kernel(EdgeBwdArgs a_in) {
-    KGE_TL(5);
+__device__ __forceinline__ void edge_bwd_body(const EdgeBwdArgs &a_in, int64_t i) {
     EdgeBwdArgs a = a_in;
     if constexpr (LOCAL) { a.src.em.n = 0; a.src.rm.n = 0; }
-    const int64_t i = WAVE_ID();
     if (i >= a.B) return;
     const int lane = LANE();
     const float *h = table_row(a.src.em, a.src.hbase, a.src.hidx, i, a.d_e);
@@ -316,6 +314,47 @@ __global__ __launch_bounds__(KGE_BLOCK) void edge_bwd_kernel(EdgeBwdArgs a_in) {
             if (GT) { st_wt<V>(GT + off, o_rt); st_wt<V>(GT + hd + off, o_it); }
         }
     }
+}
+
+template <int MODEL, int V, bool LOCAL>
+__global__ __launch_bounds__(KGE_BLOCK) void edge_bwd_kernel(EdgeBwdArgs a) {
+    KGE_TL(5);
+    edge_bwd_body<MODEL, V, LOCAL>(a, WAVE_ID());
+}
+
+// RotatE / TransE_l1 pairwise path: the per-edge gradient rows and the sum of the shared-pair backward's GN partials
+// (kge_neg_bcast.hip) depend on the same launch and not on each other: ONE launch, the first nbE workgroups run edge_bwd, the
+// rest the reduction (round 2: two launches, 6.0 + 5.4 us + a boundary at the RotatE FB15k shape)
+template <int MODEL, int V, bool LOCAL>
+__global__ __launch_bounds__(KGE_BLOCK) void edge_bwd_gnred_kernel(EdgeBwdArgs a, NegArgs n, int nrw, int nbE) {
+    if ((int)blockIdx.x < nbE) {
+        KGE_TL(5);
+        edge_bwd_body<MODEL, V, LOCAL>(a, WAVE_ID());
+    } else {
+        gn_reduce_body(n, nrw, ((int64_t)blockIdx.x - nbE) * KGE_BLOCK + threadIdx.x);
+    }
+}
+
+template <int MODEL>
+static int launch_edge_bwd_gnred_m(const EdgeBwdArgs &a, const NegArgs &n, int nrw, hipStream_t s) {
+    const int nbE = blocks_for_waves(a.B);
+    const int64_t n4 = (int64_t)n.C * n.N * n.d_e / 4;
+    const int nbR = (int)((n4 + KGE_BLOCK - 1) / KGE_BLOCK);
+    const bool cx = is_complex_model(MODEL);
+    const bool vec = cx ? ((a.d_e / 2) % 4 == 0 && a.d_r % 4 == 0) : (a.d_e % 4 == 0);
+    const bool local = a.src.em.n == 0 && a.src.rm.n == 0;
+    if (!vec || !local) return KGE_ERR_ARG;
+    hipLaunchKernelGGL((edge_bwd_gnred_kernel<MODEL, 4, true>), dim3(nbE + nbR), dim3(KGE_BLOCK), 0, s, a, n, nrw, nbE);
+    return check_launch();
+}
+
+int launch_edge_bwd_with_gn_reduce(const EdgeBwdArgs &a, const NegArgs &n, int nrw, hipStream_t s) {
+    if (a.B == 0 || !n.GNp || !n.GN || nrw < 1 || n.d_e % 4) return KGE_ERR_ARG;
+    switch (a.model) {
+        case KGE_ROTATE: return launch_edge_bwd_gnred_m<KGE_ROTATE>(a, n, nrw, s);
+        case KGE_TRANSE_L1: return launch_edge_bwd_gnred_m<KGE_TRANSE_L1>(a, n, nrw, s);
+    }
+    return KGE_ERR_ARG;
 }
 
 template <int MODEL>

@@ -294,6 +294,32 @@ def test_merged_forward_launch_equals_split_launches_bit_for_bit(model, gamma):
     assert np.isfinite(results[0][4]).all()
 
 
+def test_rotate_fused_gn_reduce_equals_separate_launches_bit_for_bit():
+    """RotatE strict step: the sum of the shared-pair backward's GN partials runs as the second half of the edge_bwd launch
+    (round 3) - the same reduction code as the stand-alone gn_reduce launch (KGE_FLAG_SPLIT_FWD keeps round 2's launches):
+    bit-identical tables at the FB15k recipe's shape."""
+    from dglke_amd import plan, _lib
+    from dglke_amd.engine import StepEngine
+    rng = np.random.RandomState(13)
+    n_ent, n_rel, B, N, hidden = 14951, 1345, 1024, 256, 200
+    plans = []
+    for step in range(1, 4):
+        bt = O.synth_batch(rng, n_ent, n_rel, B, N, N, step)
+        plans.append(plan.build_plan(bt["h"], bt["t"], bt["r"], bt["neg"], N, N, bt["neg_head"]))
+    results = []
+    for flags in (0, _lib.FLAG_SPLIT_FWD):
+        torch.manual_seed(0)
+        eng = StepEngine("RotatE", n_ent, n_rel, hidden, 12.0, 0.009, DEV, True, False, True, 1.0, 1e-7, 3, flags=flags)
+        for b in plan.upload(plans, DEV):
+            eng.step(b)
+        torch.cuda.synchronize()
+        results.append((eng.ent.cpu().numpy().copy(), eng.rel.cpu().numpy().copy(), eng.ent_state.cpu().numpy().copy(),
+                        eng.rel_state.cpu().numpy().copy(), np.array(eng.read_loss_sums())))
+    for k in range(5):
+        assert np.array_equal(results[0][k], results[1][k]), "fused vs separate gn_reduce: output %d differs" % k
+    assert np.abs(results[0][0]).max() > 0 and np.isfinite(results[0][4]).all()
+
+
 def test_row_error_trajectory_over_24_steps():
     """How far do the post-update rows drift from exact arithmetic, step after step, at the cfg-T shape?  Every step restarts the
     fp64 statement from the GPU's own fp32 tables, so the numbers are PER-STEP errors (they cannot accumulate):
