@@ -86,6 +86,8 @@ __global__ void l2_scale_kernel(const float *dneg, const float *score, float gam
 
 }  // namespace
 
+int kge_fail(int code, const char *msg) { return fail(code, "%s", msg); }
+
 extern "C" {
 
 int kge_abi_version(void) { return KGE_ABI_VERSION; }
@@ -849,7 +851,8 @@ struct kge_pipe {
     kge_hparams hp; kge_tables tb; kge_batch b; kge_step_out out; bool has_out;
     void *ws; size_t ws_bytes;     // workspace half of the pending step
     bool prepped;        // PREP of the next step already ran (inside the previous call's backward launch) ...
-    const void *prep_key;          // ... for the batch whose h_gid array is this
+    const void *prep_key;          // ... for the batch whose h_gid array is this,
+    kge_hparams prep_hp;           // ... with these hyper-parameters (it is reused only by a call that asks for the same plain step)
 };
 
 int kge_pipe_create(kge_pipe **pipe) {
@@ -882,7 +885,12 @@ int kge_step_async(kge_pipe *p, const kge_hparams *hp, const kge_tables *tb, con
     const bool defer_rel = (hp->flags & KGE_FLAG_ASYNC_REL) != 0;
     // PREP(s): gathers the rows (update s-2 has landed: stream order) and makes the dense copies the rest of the step
     // reads - unless the previous call already ran it inside its backward launch
-    if (!(p->prepped && p->prep_key == (const void *)b->h_gid))
+    // (a PREP that ran ahead was built for a plain step - no per-step outputs - with the previous call's hyper-parameters: it
+    //  serves this call only if this call wants exactly that; otherwise PREP runs again)
+    const bool plain_now = !out || (!out->loss4 && !out->pos_score && !out->neg_score && !out->g_pos_ent && !out->g_neg && !out->g_rel);
+    const bool reuse = p->prepped && p->prep_key == (const void *)b->h_gid && plain_now &&
+                       memcmp(&p->prep_hp, hp, sizeof(kge_hparams)) == 0;
+    if (!reuse)
         if (int rc = step_impl(hp, tb, b, out, nullptr, wsp, half, stream, nullptr, PH_PREP)) return rc;
     p->prepped = false;
     // launch A: forward(s) || UPDATE(s-1)
@@ -910,7 +918,7 @@ int kge_step_async(kge_pipe *p, const kge_hparams *hp, const kge_tables *tb, con
     }
     if (int rc = step_impl(hp, tb, b, out, nullptr, wsp, half, stream, nullptr, PH_BWD, nullptr, nullptr, nullptr,
                            have_prep ? &ef : nullptr)) return rc;
-    if (have_prep) { p->prepped = true; p->prep_key = (const void *)b_next->h_gid; }
+    if (have_prep) { p->prepped = true; p->prep_key = (const void *)b_next->h_gid; p->prep_hp = *hp; }
     // the reference defers the ENTITY table only (general_models.py:639-647: create_async_update on entity_emb;
     // relation_emb.update stays in the training loop): relation trace now
     if (!defer_rel)

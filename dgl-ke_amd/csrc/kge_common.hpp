@@ -400,6 +400,7 @@ struct FinalizeArgs {
     float *loss4;
 };
 
+int kge_fail(int code, const char *msg);      // records the message kge_last_error() returns (kge_api.hip); returns code
 int launch_gather_rows(const float *table, int dim, const int64_t *idx, int64_t n, float *out,
                        hipStream_t s);
 int launch_gather_rows_sharded(float *const *shard_rows, int n_shards, int64_t per, int dim,

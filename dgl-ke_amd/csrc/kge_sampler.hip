@@ -185,6 +185,18 @@ __device__ uint32_t block_exclusive_scan(uint32_t *v, int n, uint32_t *wsum /*[S
     return total;
 }
 
+// (pos * mul + add) mod n for pos, add < n: 64-bit arithmetic when n < 2^32 (then mul < 2^32 too), else a shift-and-add
+// product modulo n (graphs beyond 4 G triples: 64 iterations per index, once per sampled edge)
+__device__ __forceinline__ uint64_t epoch_index(uint64_t pos, uint64_t mul, uint64_t add, uint64_t n) {
+    if (n < (1ull << 32)) return (pos * mul + add) % n;
+    uint64_t acc = add % n, x = pos % n, m = mul;
+    while (m) {
+        if (m & 1ull) { acc += x; if (acc >= n) acc -= n; }
+        x += x; if (x >= n) x -= n;
+        m >>= 1;
+    }
+    return acc;
+}
 __device__ __forceinline__ uint64_t gcd_u64(uint64_t x, uint64_t y) {
     while (y) { const uint64_t r = x % y; x = y; y = r; }
     return x;
@@ -238,15 +250,18 @@ __global__ __launch_bounds__(SP_THREADS) void sample_plan_kernel(SamplerArgs a) 
     // a fresh permutation without regenerating n_train indices; epoch 0 uses the base permutation as it is.
     const int64_t nb = a.n_train / B;
     const int64_t gk = step - 1, ep = gk / nb, pos1 = (gk % nb) * B;
-    static const uint64_t MULT[8] = {2654435761ull, 2246822519ull, 3266489917ull, 668265263ull, 374761393ull,
-                                     2870177450ull + 13ull, 1597334677ull, 1181783497ull};
+    // (multiplier AND offset are hashed from (seed, epoch): a table of eight multipliers made epochs e and e + 8 walk the same
+    //  cyclic sequence, and graphs of >= 2^31 triples got mul = 1 - every epoch a rotation of epoch 0)
     uint64_t mul = 1, add = 0;
     if (a.perm && ep > 0) {
-        add = mix64(a.seed ^ (0xD6E8FEB86659FD93ULL * (uint64_t)ep)) % (uint64_t)a.n_train;
-        if (a.n_train < (1ll << 31)) {         // pos * mul must not overflow 64 bits
-            mul = MULT[ep & 7];
-            while (gcd_u64(mul, (uint64_t)a.n_train) != 1) mul += 2;     // bijection needs gcd(mul, n_train) = 1
-        }
+        const uint64_t n = (uint64_t)a.n_train;
+        add = mix64(a.seed ^ (0xD6E8FEB86659FD93ULL * (uint64_t)ep)) % n;
+        uint64_t m = mix64(a.seed ^ (0xA0761D6478BD642FULL * (uint64_t)(ep + 1)));
+        m = (n < (1ull << 32)) ? (m & 0xffffffffull) : (m % n);          // (keeps pos * mul inside what epoch_index multiplies)
+        m |= 1ull;
+        if (m < 3) m = 3;
+        while (gcd_u64(m, n) != 1) m += 2;                               // bijection needs gcd(mul, n_train) = 1
+        mul = m;
     }
     (void)pos0;
     if (part == 1) {
@@ -256,7 +271,7 @@ __global__ __launch_bounds__(SP_THREADS) void sample_plan_kernel(SamplerArgs a) 
         for (int i = t; i < b2; i += SP_THREADS) {
             uint64_t key = ~0ULL;
             if (i < B) {
-                int64_t e = (int64_t)(((uint64_t)(pos1 + i) * mul + add) % (uint64_t)a.n_train);
+                int64_t e = (int64_t)epoch_index((uint64_t)(pos1 + i), mul, add, (uint64_t)a.n_train);
                 if (a.perm) e = a.perm[e];
                 const int64_t r = a.R[e];
                 rel_ids[i] = r;
@@ -300,7 +315,7 @@ __global__ __launch_bounds__(SP_THREADS) void sample_plan_kernel(SamplerArgs a) 
     }
     K *ek = reinterpret_cast<K *>(keys);        // the entity plan's keys
     for (int i = t; i < B; i += SP_THREADS) {
-        int64_t e = (int64_t)(((uint64_t)(pos1 + i) * mul + add) % (uint64_t)a.n_train);
+        int64_t e = (int64_t)epoch_index((uint64_t)(pos1 + i), mul, add, (uint64_t)a.n_train);
         if (a.perm) e = a.perm[e];
         const int64_t h = a.H[e], tl = a.T[e];
         h_gid[i] = h; t_gid[i] = tl;
@@ -379,7 +394,7 @@ size_t kge_sampler_slot_bytes(int B, int C, int N) {
 int kge_sample_batches(const int64_t *heads, const int64_t *rels, const int64_t *tails, const int64_t *perm,
                        int64_t n_train, int64_t n_ent, int B, int C, int chunk, int N, uint64_t seed,
                        int64_t *state, void *slots, size_t slot_bytes, int n_slots, void *stream) {
-    if (n_train < B) return KGE_ERR_ARG;       // fewer training triples than one batch
+    if (n_train < B) return kge_fail(KGE_ERR_ARG, "kge_sample_batches: fewer training triples than one batch (n_train < batch)");
     if (!heads || !rels || !tails || !state || !slots || n_train <= 0 || n_ent <= 0 || B <= 0 || C <= 0 ||
         chunk <= 0 || N <= 0 || C * chunk != B)
         return KGE_ERR_ARG;

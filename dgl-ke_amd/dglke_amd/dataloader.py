@@ -233,7 +233,7 @@ class PrefetchedGroups(object):
         if mode not in ("streams", "fork", "serial"):
             raise ValueError("mode: streams | fork | serial")
         self.mode = mode
-        self.side = th.cuda.Stream(device=sampler.dev)
+        self.side = th.cuda.Stream(device=sampler.dev)      # (its priority makes no difference: profiles/r03_merged_fwd.txt)
         self.buf = 0                  # half holding the batches of the NEXT group to train
         self.ready = None             # DeviceBatch objects in that half
         self.graphs = {}

@@ -267,6 +267,11 @@ class Trainer(object):
         if args.model_name == 'TransR':       # the lanes share the projection table too (general_models.py:97-100)
             tables += (m.score_func.projection_emb.emb, m.score_func.projection_emb.state_sum)
         parts = np.array_split(np.random.RandomState(args.seed).permutation(len(tr[0])), self.n_lanes)
+        if min(len(p) for p in parts) < B:
+            # both samplers work on whole batches (the reference drops partial ones, dataloader/sampler.py:503-504): a trainer
+            # whose share of the triples is smaller than one batch could never step
+            raise KgeError("every trainer needs at least batch_size training triples: %d triples over %d trainer(s) < batch_size %d "
+                           "- lower --batch_size or --num_proc" % (len(tr[0]), self.n_lanes, B))
         self.lanes = []
         for k in range(self.n_lanes):
             eng = m.engine if k == 0 else StepEngine(
@@ -329,14 +334,16 @@ class Trainer(object):
         marks.add(args.max_step)
         since_log = 0
         timed = None
+        t_interval = 0.0
         for nxt in sorted(marks):
             n = nxt - step
             at_log = args.log_interval > 0 and nxt % args.log_interval == 0
             if n > 0:
                 t0 = time.time()
                 # the reference's four timers (train_pytorch.py:127-177): the LAST step before a log mark runs as four
-                # phase groups with HIP events in between (same kernels, same result); the printed totals are that
-                # step's phase times x the steps of the interval
+                # phase groups with HIP events in between (same kernels, same result).  That one step is launched eagerly and
+                # synchronised, so its absolute times are not those of the graph-replayed steps: only the SPLIT is taken from
+                # it - the printed totals are the interval's measured training time divided in that step's proportions
                 want_timers = at_log and self.fused and self.n_lanes == 1 and not self.lanes[0].async_update
                 self._run(n - 1 if want_timers else n)
                 if want_timers:
@@ -344,6 +351,7 @@ class Trainer(object):
                     timed = self.lanes[0].timed_step()
                 th.cuda.synchronize()
                 t_train += time.time() - t0
+                t_interval += time.time() - t0
                 step, since_log = nxt, since_log + n
             if at_log and since_log:
                 for lane in self.lanes:
@@ -358,10 +366,14 @@ class Trainer(object):
                         lane.dropin_logs = {}
                     print('[proc {}][Train] {} steps take {:.3f} seconds'.format(lane.k, since_log, time.time() - start))
                 if timed is not None:
+                    tot = sum(timed[k] for k in ('sample', 'forward', 'backward', 'update')) or 1.0
+                    sc = t_interval / tot
                     print('[proc {}]sample: {:.3f}, forward: {:.3f}, backward: {:.3f}, update: {:.3f}'.format(
-                        0, timed['sample'] * since_log, timed['forward'] * since_log, timed['backward'] * since_log,
-                        timed['update'] * since_log))
+                        0, timed['sample'] * sc, timed['forward'] * sc, timed['backward'] * sc, timed['update'] * sc))
+                    print('[proc {}](split of {:.3f} s over {} steps in the proportions of one phase-timed step)'.format(
+                        0, t_interval, since_log))
                     timed = None
+                t_interval = 0.0
                 print('[proc {}]sample+forward+backward+update (fused HIP step{}{}): {:.3f}'.format(
                     0, ', --async_update pipeline' if self.lanes[0].async_update else '',
                     '' if self.n_lanes == 1 else ', %d concurrent trainers' % self.n_lanes, t_train))

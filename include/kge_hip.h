@@ -284,6 +284,9 @@ int kge_step_fused(const kge_hparams *hp, const kge_tables *tb, const kge_batch 
  * KGE_FLAG_ASYNC_REL defers the relation trace too; then nothing touches the tables between backward(s) and
  * PREP(s+1), and - when the caller names the next batch (b_next) - PREP(s+1) shares the backward launch of step s
  * (three launches per step on the critical path).  b_next may be NULL (PREP runs at the start of the next call).
+ * The PREP that ran ahead is used by the next call only if that call passes the same batch arrays (b->h_gid), the same
+ * hyper-parameters and asks for no per-step outputs; the arrays of b_next must not be rebuilt in between (a sampler slot
+ * is re-sampled only after kge_step_async_flush).
  * kge_step_async_flush() applies the last pending update (call it before reading the tables and at the end of a
  * captured group of steps; the step after a flush gathers fully updated rows).  Gradients, including the
  * regulariser, are those of the rows as gathered.  Not available for RESCAL / TransR.  The workspace holds two halves (kge_step_async_workspace_bytes).  kge_pipe is host-side state only. */

@@ -320,6 +320,49 @@ def test_rotate_fused_gn_reduce_equals_separate_launches_bit_for_bit():
     assert np.abs(results[0][0]).max() > 0 and np.isfinite(results[0][4]).all()
 
 
+@pytest.mark.parametrize("model,de_,dr_,hidden,flags", [("TransE_l2", False, False, 64, 0), ("RotatE", True, False, 32, 0),
+                                                        ("DistMult", False, False, 64, 0), ("TransR", False, False, 16, 0),
+                                                        ("RESCAL", False, False, 16, 0), ("TransE_l2", False, False, 64, 32),
+                                                        ("RotatE", True, False, 32, 32)],
+                         ids=["TransE_l2", "RotatE", "DistMult", "TransR", "RESCAL", "TransE_l2-neg_deg", "RotatE-neg_deg"])
+def test_four_phase_calls_equal_the_fused_step_bit_for_bit(model, de_, dr_, hidden, flags):
+    """kge_step_phase (the reference's sample / forward / backward / update timers, train_pytorch.py:127-177; runs once per
+    log interval in every dglke_train run): the four phase groups issued one after the other ARE kge_step_fused - same
+    tables, states and loss sums, bit for bit, although the fused call merges launches that the phase calls keep apart."""
+    import ctypes as C
+    from dglke_amd import _lib, plan
+    from dglke_amd.engine import StepEngine
+    n_ent, n_rel, B, N = 800, 11, 96, 32
+    rng = np.random.RandomState(17)
+    plans = []
+    for step in range(1, 4):
+        bt = O.synth_batch(rng, n_ent, n_rel, B, N, N, step)
+        plans.append(plan.build_plan(bt["h"], bt["t"], bt["r"], bt["neg"], N, N, bt["neg_head"]))
+    results = []
+    for phased in (False, True):
+        torch.manual_seed(0)
+        eng = StepEngine(model, n_ent, n_rel, hidden, 10.0, 0.1, DEV, de_, dr_, True, 1.0, 1e-5, 3, flags=flags)
+        for b in plan.upload(plans, DEV):
+            if not phased:
+                eng.step(b)
+                continue
+            ws = eng.workspace_for(b)
+            out = _lib.KgeStepOut()
+            out.loss_accum = _lib.ptr(eng.loss_accum)
+            for ph in (_lib.PHASE_GATHER, _lib.PHASE_FORWARD, _lib.PHASE_BACKWARD, _lib.PHASE_UPDATE):
+                _lib.check(_lib.lib().kge_step_phase(C.byref(eng.hp), C.byref(eng.tb), C.byref(b.c), C.byref(out), _lib.ptr(ws),
+                                                     eng._ws_bytes, ph, _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        res = [eng.ent.cpu().numpy().copy(), eng.rel.cpu().numpy().copy(), eng.ent_state.cpu().numpy().copy(),
+               eng.rel_state.cpu().numpy().copy(), np.array(eng.read_loss_sums())]
+        if eng.proj is not None:
+            res.append(eng.proj.cpu().numpy().copy())
+        results.append(res)
+    for k in range(len(results[0])):
+        assert np.array_equal(results[0][k], results[1][k]), "%s: output %d of the phase calls differs from the fused step" % (model, k)
+    assert np.isfinite(results[0][4]).all() and np.abs(results[0][4]).sum() > 0
+
+
 def test_row_error_trajectory_over_24_steps():
     """How far do the post-update rows drift from exact arithmetic, step after step, at the cfg-T shape?  Every step restarts the
     fp64 statement from the GPU's own fp32 tables, so the numbers are PER-STEP errors (they cannot accumulate):

@@ -76,6 +76,40 @@ def test_epochs_are_whole_batches_in_a_new_order():
     assert len({where0.get(int(x), -1) for x in epochs[1][:B]}) > 3
 
 
+def test_epoch_orders_do_not_repeat_with_period_eight():
+    """the per-epoch order is perm o (i * mul + add mod n) with BOTH constants hashed from (seed, epoch) - a table of eight
+    multipliers made epochs e and e + 8 the same cyclic sequence (same successor of every edge), i.e. nearly identical
+    batches.  Twelve epochs: no two of them share the successor relation."""
+    from dglke_amd.dataloader import DeviceSampler
+    B, N, nb, n_ent = 32, 8, 9, 10000
+    n_train = B * nb
+    h = np.arange(n_train)
+    z = np.zeros(n_train, np.int64)
+    s = DeviceSampler(h, z, z, n_ent, B, N, DEV, n_slots=12 * nb, seed=11)
+    s.sample()
+    torch.cuda.synchronize()
+    succ = []
+    for e in range(12):
+        ids = np.concatenate([s.slot_arrays(nb * e + k)["h_gid"] for k in range(nb)])
+        assert len(np.unique(ids)) == n_train
+        nxt = np.empty(n_train, np.int64)
+        nxt[ids] = np.roll(ids, -1)            # cyclic successor of every edge in this epoch's order
+        succ.append(nxt)
+    for a in range(12):
+        for b in range(a + 1, 12):
+            same = (succ[a] == succ[b]).mean()
+            assert same < 0.2, "epochs %d and %d walk (almost) the same sequence: %.0f %% equal successors" % (a, b, 100 * same)
+
+
+def test_sampler_refuses_fewer_triples_than_a_batch_with_a_message():
+    from dglke_amd import _lib
+    from dglke_amd.dataloader import DeviceSampler
+    z = np.zeros(10, np.int64)
+    s = DeviceSampler(z, z, z, 100, 16, 4, DEV, n_slots=2, seed=1)
+    with pytest.raises(_lib.KgeError, match="fewer training triples than one batch"):
+        s.sample()
+
+
 @pytest.mark.parametrize("rel_hub", [0.0, 0.4], ids=["uniform", "dominant_relation"])
 def test_step_from_device_batch_equals_step_from_host_plan(rel_hub):
     """the fused step fed by a device-built batch gives bit-identical tables to the step fed by the
