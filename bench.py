@@ -126,14 +126,14 @@ def step_kernels(model, force_pairwise=False):
         return ("one training step = rescal_matvec x2, neg_fwd_gemm, loss, neg_bwd_gemm, relation-matrix Adagrad, update; "
                 "dominant: rescal_apply / rescal_matvec (HBM streaming of the relation matrices)")
     if model in ("TransE_l1", "RotatE") or force_pairwise:
-        return ("one training step = edge_fwd, neg_fwd_bcast, loss, neg_bwd_lc + gn_reduce, (edge_bwd,) update; "
-                "dominant: neg_bwd_lc_kernel (VALU, packed fp32)")
+        return ("one training step = edge_fwd, neg_fwd_bcast, loss, neg_bwd_lc, [edge_bwd || gn_reduce] (TransE_l1: gn_reduce alone), "
+                "update; dominant: neg_bwd_lc_kernel (VALU, packed fp32)")
     if model == "TransE_l2":
         return ("one training step = 4 dependent launches ([forward GEMM tiles || edge-forward rows], loss, neg_bwd_gemm, "
-                "update); dominant: neg_bwd_gemm_kernel")
+                "update); the first and the third take ~9 us each (roofline.dominant_kernel: the committed profile's)")
     if model == "DistMult":
         return ("one training step = 5 dependent launches ([forward GEMM tiles || edge-forward rows], loss, neg_bwd_gemm, "
-                "edge_bwd, update); dominant: neg_bwd_gemm_kernel")
+                "edge_bwd, update); dominant: the first launch / neg_bwd_gemm_kernel")
     return ("one training step = 6 dependent kernels (edge_fwd, neg_fwd_gemm, loss, neg_bwd_gemm, edge_bwd, update); "
             "dominant: neg_bwd_gemm_kernel")
 
