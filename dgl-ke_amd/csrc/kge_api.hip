@@ -573,7 +573,8 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     // a launch with the previous update already), dense-negative modes (sharded / neg_deg_sample) and the fused-loss variant.
     const bool merged_fwd = gemm && !dense_neg && !fused_loss && !pipelined && !pairwise &&
                             (phases & (PH_PREP | PH_FWD)) == (PH_PREP | PH_FWD) && !build_prep && !co_update &&
-                            !(hp->flags & KGE_FLAG_SPLIT_FWD) && neg_fwd_gemm_with_edge_supported(hp->model, d_e, d_r);
+                            !(hp->flags & KGE_FLAG_SPLIT_FWD) && neg_fwd_gemm_with_edge_supported(hp->model, d_e, d_r) &&
+                            !(hp->model == KGE_COMPLEX && (hp->flags & KGE_FLAG_FWD_DIRECT));
     EdgeFwdArgs ef{};
     if (phases & PH_PREP) {
     // 1. gather + positive score + pos-side vectors (+ positive-loss part, + P rows for TransE)

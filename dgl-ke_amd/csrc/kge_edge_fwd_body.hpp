@@ -125,12 +125,13 @@ __device__ __forceinline__ void edge_fwd_body(const EdgeFwdArgs &a_in, int bid) 
                         const float im = rh.v[e] * s + ih.v[e] * c - it_.v[e];
                         ps += sqrtf(re * re + im * im);
                     }
+                    // (explicit fmaf forms: the forward tiles of the merged first launch build the same vector, bit for bit)
                     if (a.neg_head) {   // a = t o conj(r)
-                        are.v[e] = rt.v[e] * c + it_.v[e] * s;
-                        aim.v[e] = -rt.v[e] * s + it_.v[e] * c;
+                        are.v[e] = fmaf(it_.v[e], s, rt.v[e] * c);
+                        aim.v[e] = fmaf(-rt.v[e], s, it_.v[e] * c);
                     } else {            // a = h o r
-                        are.v[e] = rh.v[e] * c - ih.v[e] * s;
-                        aim.v[e] = rh.v[e] * s + ih.v[e] * c;
+                        are.v[e] = fmaf(-ih.v[e], s, rh.v[e] * c);
+                        aim.v[e] = fmaf(rh.v[e], s, ih.v[e] * c);
                     }
                     as += are.v[e] * are.v[e] + aim.v[e] * aim.v[e];
                 }

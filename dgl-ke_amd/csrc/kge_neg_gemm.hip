@@ -411,6 +411,36 @@ __device__ __forceinline__ void neg_fwd_gemm_ldsa_body(const GemmArgs &a, int ti
     float4 a0[FU], b0[FU], a1[FU], b1[FU];
     // the A tile: 8 passes of 16 x 16 bytes per row and source (512 floats per row) requested together, then the first B fragments
     float4 xv[8], rv[8];
+    if constexpr (AM == 3) {
+        // ComplEx: rows are [re | im] halves; a = x o r (tail-corrupted step) / x o conj(r) (head-corrupted, x = tail):
+        //   a_re = x_re c -/+ x_im s,  a_im = +/- x_re s + x_im c   (score_fun.py:347-371; same fmaf forms as edge_fwd_body)
+        // a thread takes the SAME 16-byte piece of both halves: 4 passes x (x_re, x_im, r_re, r_im)
+        const int hd = D >> 1, h4 = hd >> 2;
+        for (int c0 = 0; c0 < h4; c0 += 16 * 4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int o = min(c0 + j * 16 + ac, h4 - 1) * 4;
+                xv[j] = ldg4(Xs + o); xv[4 + j] = ldg4(Xs + hd + o); rv[j] = ldg4(Rs + o); rv[4 + j] = ldg4(Rs + hd + o);
+            }
+            if (c0 == 0) {
+#pragma unroll
+                for (int u = 0; u < FU; ++u) b0[u] = ldg4(Bp + (kfull > 0 ? min(u, kfull - 1) * 16 : -(q * 4)));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c4 = c0 + j * 16 + ac;
+                if (c4 < h4) {
+                    const float4 xr = xv[j], xi = xv[4 + j], cc = rv[j], ss = rv[4 + j];
+                    float4 re, im;
+#define LA_CX(E) re.E = fmaf(-asg * xi.E, ss.E, xr.E * cc.E); im.E = fmaf(asg * xr.E, ss.E, xi.E * cc.E);
+                    LA_CX(x) LA_CX(y) LA_CX(z) LA_CX(w)
+#undef LA_CX
+                    *reinterpret_cast<float4 *>(Adst + c4 * 4) = re;
+                    *reinterpret_cast<float4 *>(Adst + hd + c4 * 4) = im;
+                }
+            }
+        }
+    } else {
 #pragma unroll
     for (int j = 0; j < 8; ++j) { const int o = min(j * 16 + ac, n4 - 1) * 4; xv[j] = ldg4(Xs + o); rv[j] = ldg4(Rs + o); }
 #pragma unroll
@@ -432,6 +462,7 @@ __device__ __forceinline__ void neg_fwd_gemm_ldsa_body(const GemmArgs &a, int ti
         }
     }
 #undef LA_COMB
+    }
     if (ac < (KP - D) / 4) *reinterpret_cast<float4 *>(Adst + D + ac * 4) = zero4();   // columns D .. KP-1 (D % 4 == 0): zeros
     __syncthreads();
     if (!tile_ok) return;
@@ -513,6 +544,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void neg_fwd_edge_kernel(GemmArgs a, int
 }
 
 bool neg_fwd_gemm_with_edge_supported(int model, int d_e, int d_r) {
+    if (model == KGE_COMPLEX) return d_e % 8 == 0 && d_r == d_e && fwd_lds_bytes(d_e) <= 64 * 1024;   // (LDS tile instance only)
     return (model == KGE_TRANSE_L2 || model == KGE_DISTMULT) && d_e % 4 == 0 && d_r == d_e;
 }
 
@@ -536,7 +568,11 @@ int launch_neg_fwd_gemm_with_edge(const GemmArgs &a, const EdgeFwdArgs &e, hipSt
 #define KGE_FE2(L2_, AM_, M_, LE_) do { if (ldsa) hipLaunchKernelGGL((neg_fwd_edge_kernel<L2_, AM_, M_, LE_, true>), g, b, lds, s, a, ti, tj, nbG, ee); \
                                         else hipLaunchKernelGGL((neg_fwd_edge_kernel<L2_, AM_, M_, LE_, false>), g, b, 0, s, a, ti, tj, nbG, ee); } while (0)
 #define KGE_FE(L2_, AM_, M_) do { if (lean) KGE_FE2(L2_, AM_, M_, true); else KGE_FE2(L2_, AM_, M_, false); } while (0)
-    if (a.model == KGE_TRANSE_L2) KGE_FE(true, 1, KGE_TRANSE_L2);
+    if (a.model == KGE_COMPLEX) {
+        if (!ldsa) return KGE_ERR_ARG;
+        if (lean) hipLaunchKernelGGL((neg_fwd_edge_kernel<false, 3, KGE_COMPLEX, true, true>), g, b, lds, s, a, ti, tj, nbG, ee);
+        else hipLaunchKernelGGL((neg_fwd_edge_kernel<false, 3, KGE_COMPLEX, false, true>), g, b, lds, s, a, ti, tj, nbG, ee);
+    } else if (a.model == KGE_TRANSE_L2) KGE_FE(true, 1, KGE_TRANSE_L2);
     else KGE_FE(false, 2, KGE_DISTMULT);
 #undef KGE_FE
 #undef KGE_FE2

@@ -259,8 +259,9 @@ def test_fused_step_is_deterministic_and_graph_replay_matches_eager():
     assert np.isfinite(results[0][3]).all()
 
 
-@pytest.mark.parametrize("model,gamma", [("TransE_l2", 19.9), ("DistMult", 143.0)])
-def test_merged_forward_launch_equals_split_launches_bit_for_bit(model, gamma):
+@pytest.mark.parametrize("model,gamma,dbl,D", [("TransE_l2", 19.9, False, 400), ("DistMult", 143.0, False, 400),
+                                               ("ComplEx", 143.0, True, 200)])
+def test_merged_forward_launch_equals_split_launches_bit_for_bit(model, gamma, dbl, D):
     """round 3: the strict step's first launch runs the forward GEMM tiles (pos-side fragments built from the table rows, raw
     products; the loss kernel applies the TransE_l2 distance) next to the edge-forward rows.  Same arithmetic as the two
     separate launches (KGE_FLAG_SPLIT_FWD): tables, states and loss sums must be bit-identical - cfg-T / cfg-D shape,
@@ -268,7 +269,7 @@ def test_merged_forward_launch_equals_split_launches_bit_for_bit(model, gamma):
     from dglke_amd import plan, _lib
     from dglke_amd.engine import StepEngine
     rng = np.random.RandomState(11)
-    n_ent, n_rel, B, N, D = 14951, 1345, 1000, 200, 400
+    n_ent, n_rel, B, N = 14951, 1345, 1000, 200
     plans = []
     for step in range(1, 5):
         bt = O.synth_batch(rng, n_ent, n_rel, B, N, N, step)
@@ -278,7 +279,7 @@ def test_merged_forward_launch_equals_split_launches_bit_for_bit(model, gamma):
     # the same products in the same order
     for flags in (0, _lib.FLAG_SPLIT_FWD, _lib.FLAG_FWD_DIRECT, _lib.FLAG_DENSE_BWD, _lib.FLAG_FWD_DIRECT | _lib.FLAG_DENSE_BWD):
         torch.manual_seed(0)
-        eng = StepEngine(model, n_ent, n_rel, D, gamma, 0.25, DEV, False, False, True, 1.0, 1e-9, 3, flags=flags)
+        eng = StepEngine(model, n_ent, n_rel, D, gamma, 0.25, DEV, dbl, dbl, True, 1.0, 1e-9, 3, flags=flags)
         batches = plan.upload(plans, DEV)
         scores = []
         for b in batches:
