@@ -163,7 +163,9 @@ class _Lane(object):
                 b = self.sampler.sample(1)[0]
                 e1.record()
                 d = self.engine.step_timed(b)
-                smp = e0.elapsed_time(e1) * 1e-3
+                # one sampler launch builds a whole group of batches in the training loop (its latency does not depend on the
+                # count): this step's share of a launch is 1 / group
+                smp = e0.elapsed_time(e1) * 1e-3 / max(1, int(getattr(self.t.args, 'graph_steps', 1) or 1))
             else:
                 b = self.sampler.next_batches(1)[0]
                 smp = _t.time() - t0
