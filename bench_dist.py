@@ -127,7 +127,9 @@ def _a2a_setup(args, world, rank, dev, w, n_ent, d_e, emb_init):
     torch.manual_seed(99)          # identical relation replicas on every rank
     eng = StepEngine(w["model"], 1, w["n_rel"], w["hidden"], w["gamma"], w["lr"], dev, w["de"], w["dr"],
                      w["adv"], w["adv_temp"], w["reg_coef"], w["reg_norm"])
-    de = kd.DistEngine(eng, spec, ent, ent_state, slack=float(os.environ.get("KGE_DIST_SLACK", "1.5")))
+    # KGE_DIST_FORCE_COLL=1: keep the RCCL calls and the pull pipeline at world 1 too (smoke test of the N > 1 code path on one GPU)
+    force_coll = os.environ.get("KGE_DIST_FORCE_COLL", "0") == "1"
+    de = kd.DistEngine(eng, spec, ent, ent_state, slack=float(os.environ.get("KGE_DIST_SLACK", "1.5")), always_collective=force_coll)
     # this rank's edge shard: synthetic uniform triples over the GLOBAL id space, generated in HBM
     n_train = int(os.environ.get("KGE_DIST_TRIPLES", min(338586276 // world, 48_000_000)))
     g = torch.Generator(device=dev)
@@ -137,7 +139,7 @@ def _a2a_setup(args, world, rank, dev, w, n_ent, d_e, emb_init):
     R = torch.randint(0, w["n_rel"], (n_train,), device=dev, generator=g)
     G = max(2, min(120, args.graph_steps) // 2 * 2)
     smp = DeviceSampler(H, R, T, n_ent, w["B"], w["N"], dev, n_slots=G, seed=rank + 1)
-    pipelined = world > 1 and os.environ.get("KGE_DIST_PIPELINE", "1") != "0"
+    pipelined = (world > 1 or force_coll) and os.environ.get("KGE_DIST_PIPELINE", "1") != "0"
 
     def steps(dbs):
         for k, b in enumerate(dbs):
@@ -150,7 +152,7 @@ def _a2a_setup(args, world, rank, dev, w, n_ent, d_e, emb_init):
     steps(dbs[:4])                      # eager warm-up: allocates every persistent buffer
     torch.cuda.synchronize()
     graphs = {}
-    use_graph = world == 1 and not args.no_graph      # no collective at world 1: the whole group replays from a hipGraph
+    use_graph = world == 1 and not force_coll and not args.no_graph      # no collective at world 1: the group replays from a hipGraph
 
     def run(count):                     # EXACTLY count steps: groups of G, then one partial group (one sampler launch each)
         left = count
@@ -171,11 +173,35 @@ def _a2a_setup(args, world, rank, dev, w, n_ent, d_e, emb_init):
             with torch.cuda.graph(graphs[n]):
                 steps(smp.sample(n))
         torch.cuda.synchronize()
+    def graph_runner():
+        """the same step with the RCCL collectives RECORDED into hipGraphs (synchronous schedule, groups of <= 20 steps, the host
+        synchronises after every replay: a long chain of unsynchronised replays of captured collectives hangs on this stack,
+        tools/dbg/rccl_capture_probe2.py).  Returns run(count)."""
+        Gd = max(2, min(20, G) // 2 * 2)
+        gg = {}
+
+        def cap(n):
+            gg[n] = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gg[n]):
+                for b in smp.sample(n):
+                    de.step(b)
+        for n in {Gd, args.warmup % Gd, args.steps % Gd} - {0}:
+            cap(n)
+        torch.cuda.synchronize()
+
+        def run_g(count):
+            left = count
+            while left > 0:
+                n = min(Gd, left)
+                gg[n].replay()
+                torch.cuda.current_stream().synchronize()
+                left -= n
+        return run_g, Gd
     C = w["B"] // w["N"]
     a_ = smp.slot_arrays(0)
     u_pos = int(np.unique(np.concatenate([a_["h_gid"], a_["t_gid"]])).shape[0])
     ue = int(np.unique(np.concatenate([a_["h_gid"], a_["t_gid"], a_["neg_ids"]])).shape[0])
-    rows = dict(UE=ue, R_e=u_pos + C * w["N"], B=w["B"], cap=de.cap)
+    rows = dict(UE=ue, R_e=u_pos + C * w["N"], B=w["B"], cap=de.cap, graph_runner=None if use_graph else graph_runner)
     desc = ("entity table range-sharded, relation table replicated; per step: device-side routing into %d-row owner buckets, "
             "all-to-all pull of the unique rows, the single-GPU kernels against the row cache, all-to-all push of one packed "
             "gradient message per row, owner-side Adagrad in rank order (one merged launch), relation gradients all-gathered "
@@ -242,6 +268,7 @@ def main(args, world, rank, local_rank):
     sums = eng.read_loss_sums()
     K = args.steps
     overflow = _de.check_overflow() if mode != "p2p" else 0
+    eager = None
     other = "p2p" if mode == "a2a" else "a2a"
     want_other = world > 1 and os.environ.get("KGE_DIST_OTHER_LEG", "1") != "0"
     import threading
@@ -255,13 +282,53 @@ def main(args, world, rank, local_rank):
             state["emitted"] = True
         if rank != 0:
             return None
-        line = json.dumps(_result_line(args, w, n_ent, world, wall, K, rows, d_e, eng.d_r, desc, mode, why, sums, other, leg,
-                                       overflow))
+        res = _result_line(args, w, n_ent, world, wall, K, rows, d_e, eng.d_r, desc, mode, why, sums, other, leg, overflow)
+        if eager is not None:
+            res["a2a_eager"] = eager
+        line = json.dumps(res)
         if now:
             print(line, flush=True)
         return line
 
     leg = None
+    # a2a with collectives (N > 1): the SAME K steps once more with the collectives recorded into hipGraphs - no host work between
+    # the kernels of a step.  Under a watchdog: if the replay hangs, the eager measurement above is the line.  When it completes
+    # it is the headline (same step, same K, same tables continuing) and the eager run is reported beside it.
+    gr_fn = rows.pop("graph_runner", None) if mode == "a2a" else None
+    # OPT-IN (KGE_DIST_GRAPH=1): on ROCm 7.0 / RCCL 2.26 the replay of this step's graphs hangs until the process-group watchdog
+    # aborts the process - with a host synchronise after every replay too, although a probe with small messages replays fine
+    # that way (tools/dbg/rccl_capture_probe2.py; profiles/r03_merged_fwd.txt)
+    if gr_fn is not None and not args.no_graph and os.environ.get("KGE_DIST_GRAPH", "0") == "1":
+        done_g = threading.Event()
+
+        def watchdog_g():
+            if not done_g.wait(float(os.environ.get("KGE_DIST_GRAPH_TIMEOUT", "90"))):
+                emit({"error": "skipped: the graph-replay leg did not finish in time (watchdog)"})
+                os._exit(0)
+        threading.Thread(target=watchdog_g, daemon=True).start()
+        try:
+            run_g, Gd = gr_fn()
+            run_g(args.warmup)
+            torch.cuda.synchronize(); dist.barrier()
+            eng.loss_accum.zero_()
+            t0 = time.perf_counter()
+            run_g(args.steps)
+            torch.cuda.synchronize(); dist.barrier()
+            tg = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+            sums_g = eng.read_loss_sums()
+            if all(np.isfinite(sums_g[:3])):
+                eager = {"value": round(K * w["B"] * world / wall, 1), "unit": "edges/s", "us_per_step": round(1e6 * wall / K, 2),
+                         "launch": "eager launches, pull of step s+1 overlapped with step s"}
+                wall, sums = float(tg.item()), sums_g
+                desc = desc.split("(parameter-server semantics, RCCL);")[0] + (
+                    "(parameter-server semantics, RCCL); kernels AND collectives of <= %d steps replay from one hipGraph "
+                    "(synchronous schedule, host synchronises per replay); sampling + plan on the device inside the timed region" % Gd)
+                overflow += _de.check_overflow()
+        except Exception as e:          # noqa: BLE001 - the eager measurement stands
+            eager = {"graph_leg_error": repr(e)}
+        done_g.set()
+    rows.pop("graph_runner", None)
     if want_other:
         done = threading.Event()
 
