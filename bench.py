@@ -125,8 +125,11 @@ def step_kernels(model, force_pairwise=False):
     if model == "RESCAL":
         return ("one training step = rescal_matvec x2, neg_fwd_gemm, loss, neg_bwd_gemm, relation-matrix Adagrad, update; "
                 "dominant: rescal_apply / rescal_matvec (HBM streaming of the relation matrices)")
+    if model == "TransE_l1" and not force_pairwise:
+        return ("one training step = [neg_fwd_bcast tasks || edge-forward rows], loss, neg_bwd_lc, gn_reduce, update; "
+                "dominant: neg_bwd_lc_kernel (VALU, packed fp32)")
     if model in ("TransE_l1", "RotatE") or force_pairwise:
-        return ("one training step = edge_fwd, neg_fwd_bcast, loss, neg_bwd_lc, [edge_bwd || gn_reduce] (TransE_l1: gn_reduce alone), "
+        return ("one training step = edge_fwd, neg_fwd_bcast, loss, neg_bwd_lc, [edge_bwd || gn_reduce], "
                 "update; dominant: neg_bwd_lc_kernel (VALU, packed fp32)")
     if model == "TransE_l2":
         return ("one training step = 4 dependent launches ([forward GEMM tiles || edge-forward rows], loss, neg_bwd_gemm, "

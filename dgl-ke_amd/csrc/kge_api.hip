@@ -575,6 +575,11 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
                             (phases & (PH_PREP | PH_FWD)) == (PH_PREP | PH_FWD) && !build_prep && !co_update &&
                             !(hp->flags & KGE_FLAG_SPLIT_FWD) && neg_fwd_gemm_with_edge_supported(hp->model, d_e, d_r) &&
                             !(hp->model == KGE_COMPLEX && (hp->flags & KGE_FLAG_FWD_DIRECT));
+    // ... and the pairwise family's TransE_l1: its forward tasks build the uniform rows x +/- r themselves and gather the negative
+    // rows through neg_ids; the edge half writes the dense copies (A, Bn) the backward kernels read
+    const bool merged_pair = !gemm && !pipelined && !pairwise && !nd && !sh && !rescal && !transr &&
+                             (phases & (PH_PREP | PH_FWD)) == (PH_PREP | PH_FWD) && !build_prep && !co_update &&
+                             !(hp->flags & KGE_FLAG_SPLIT_FWD) && neg_fwd_bcast_with_edge_supported(hp->model, d_e, d_r);
     EdgeFwdArgs ef{};
     if (phases & PH_PREP) {
     // 1. gather + positive score + pos-side vectors (+ positive-loss part, + P rows for TransE)
@@ -620,7 +625,7 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         }
     } else {
         if (build_prep) { *build_prep = ef; return KGE_OK; }
-        if (!merged_fwd) KGE_TRY(launch_edge_fwd(ef, s));     // merged: launched together with the forward tiles below
+        if (!merged_fwd && !merged_pair) KGE_TRY(launch_edge_fwd(ef, s));     // merged: launched together with the forward tiles below
     }
     }   // PH_PREP
 
@@ -654,7 +659,13 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         na.S = S;
         if (phases & PH_FWD) {
             if (co_update) KGE_TRY(launch_update(*co_update, s));
-            KGE_TRY(launch_neg_fwd_pair(na, s));
+            if (merged_pair) {
+                NegArgs nf = na;                  // the forward gathers the negatives from the table (Bn is written by this launch)
+                nf.nbase = tb->ent; nf.nidx = nids;
+                nf.xbase = tb->ent; nf.xidx = b->neg_head ? b->t_gid : b->h_gid; nf.rbase = tb->rel; nf.ridx = b->rel_ids;
+                nf.asign = b->neg_head ? -1.f : 1.f;
+                KGE_TRY(launch_neg_fwd_bcast_with_edge(nf, ef, s));
+            } else KGE_TRY(launch_neg_fwd_pair(na, s));
         }
     }
 

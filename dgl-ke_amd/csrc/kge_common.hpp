@@ -314,6 +314,8 @@ struct NegArgs {                     // chunked negative scoring, forward and ba
     float *GNp;                      // bwd, TransE_l1 / RotatE: room for the per-row-group GN partials
                                      // (neg_bwd_lc_partial_floats) or null: two-pass kernels
     int defer_reduce;                // shared-pair backward: leave the partials unsummed (the caller's next launch sums them)
+    // forward, merged launch (launch_neg_fwd_bcast_with_edge, TransE_l1): pos-side vectors built on the fly, a = x + asign * r
+    const float *xbase; const int64_t *xidx; const float *rbase; const int64_t *ridx; float asign;
 };
 // GN[j, :] = sum over the nrw row groups of the shared-pair backward's partials (fixed order) + regulariser of the negative row;
 // t = float4 index into GN
@@ -535,6 +537,8 @@ int launch_transr_bwd(const TransRArgs &a, hipStream_t s);
 int launch_transr_proj_update(const TransRArgs &a, hipStream_t s);
 bool neg_bcast_supported(int model, int d_e);          // kge_neg_bcast.hip: lane = row, other operand wave-uniform
 int launch_neg_fwd_bcast(const NegArgs &a, hipStream_t s);
+bool neg_fwd_bcast_with_edge_supported(int model, int d_e, int d_r);
+int launch_neg_fwd_bcast_with_edge(const NegArgs &a, const EdgeFwdArgs &e, hipStream_t s);   // TransE_l1: forward tasks || edge-forward rows
 int launch_neg_bwd_bcast(const NegArgs &a, hipStream_t s);
 bool neg_bwd_lc_supported(int model, int d_e);         // kge_neg_bcast.hip: lane = column, one pair evaluation feeds GA and GN
 size_t neg_bwd_lc_partial_floats(int model, int C, int chunk, int N, int d_e);

@@ -18,6 +18,7 @@
 // The LDS-tiled kernels of kge_neg_pair.hip stay as the generic fallback for other row widths.
 #include <utility>
 #include "kge_common.hpp"
+#include "kge_edge_fwd_body.hpp"
 
 using namespace kge;
 
@@ -122,8 +123,11 @@ __device__ __forceinline__ void fwd_step(const float (&xc)[16], const float *ly,
 // (64 cache lines per instruction) are the RotatE bound (probe with one line per instruction: 19.5 -> 12.2 us)
 // but not the TransE_l1 one (13.4 -> 13.0 us).
 // ---------------------------------------------------------------------------------------------
-template <int MODEL>
-__global__ __launch_bounds__(KGE_BLOCK) void neg_fwd_bcast_kernel(NegArgs a, int ns, int ng) {
+// OTF (round 3, TransE_l1 in the merged first launch): the uniform rows are the pos-side vectors a_i = x_i + asign * r_i built on
+// the fly from the table rows (x = head / tail through xidx, r through ridx: two coalesced loads and one fma per 64 elements of
+// a uniform row instead of one load) - the kernel then does not wait for edge_fwd, which runs as the other half of the launch
+template <int MODEL, bool OTF>
+__device__ __forceinline__ void neg_fwd_bcast_body(const NegArgs &a, int ns, int ng, int bid) {
     constexpr bool CPLX = MODEL == KGE_ROTATE;
     constexpr int RW = CPLX ? SB_RWC : SB_RWR;                        // uniform rows per wavefront
     constexpr int NE = CPLX ? SB_KC : SB_KB;                     // (complex) elements per sub-slab
@@ -134,16 +138,26 @@ __global__ __launch_bounds__(KGE_BLOCK) void neg_fwd_bcast_kernel(NegArgs a, int
     // its wavefronts (almost always) share the strip - the x rows then hit in L1 - while the number of
     // workgroups carries no padding: with ~1 workgroup per CU a few extra workgroups double the
     // makespan (260 instead of 250 at cfg-T).
-    const int task = blockIdx.x * KGE_WAVES_PER_BLOCK + wave;
+    const int task = bid * KGE_WAVES_PER_BLOCK + wave;
     if (task >= a.C * ns * ng) return;                           // wave-uniform
     const int g = task % ng, st = (task / ng) % ns, c = task / (ng * ns);
     const int D = a.d_e, K = CPLX ? D / 2 : D;
     const int i0 = g * RW;
     const int j = st * 64 + lane;
     const float *x = row_ptr(a.nbase, a.nidx, (int64_t)c * a.N + min(j, a.N - 1), D);
-    const float *y[RW];
+    const float *y[RW], *yrel[RW];
 #pragma unroll
-    for (int r = 0; r < RW; ++r) y[r] = a.A + ((int64_t)c * a.chunk + min(i0 + r, a.chunk - 1)) * D;
+    for (int r = 0; r < RW; ++r) {
+        const int64_t ie = (int64_t)c * a.chunk + min(i0 + r, a.chunk - 1);
+        if constexpr (OTF) {
+            y[r] = a.xbase + a.xidx[ie] * (int64_t)D;           // (wave-uniform ids: scalar loads)
+            yrel[r] = a.rbase + a.ridx[ie] * (int64_t)D;
+        } else {
+            y[r] = a.A + ie * D;
+            yrel[r] = y[r];
+        }
+    }
+    const float asg = a.asign;
     v2f acc[RW];
 #pragma unroll
     for (int r = 0; r < RW; ++r) acc[r] = (v2f){0.f, 0.f};
@@ -152,7 +166,8 @@ __global__ __launch_bounds__(KGE_BLOCK) void neg_fwd_bcast_kernel(NegArgs a, int
         const int k = min(kb + lane, K - 1);
 #pragma unroll
         for (int r = 0; r < RW; ++r) {
-            yr[r] = y[r][k];
+            if constexpr (OTF) yr[r] = fmaf(asg, yrel[r][k], y[r][k]);      // = edge_fwd's x +/- r, bit for bit
+            else yr[r] = y[r][k];
             yi[r] = CPLX ? y[r][K + k] : 0.f;
         }
     };
@@ -218,6 +233,41 @@ __global__ __launch_bounds__(KGE_BLOCK) void neg_fwd_bcast_kernel(NegArgs a, int
             }
         }
     }
+}
+
+template <int MODEL>
+__global__ __launch_bounds__(KGE_BLOCK) void neg_fwd_bcast_kernel(NegArgs a, int ns, int ng) {
+    neg_fwd_bcast_body<MODEL, false>(a, ns, ng, (int)blockIdx.x);
+}
+
+// TransE_l1, strict step: forward pairwise tasks (first nbF workgroups) + the edge-forward rows of the SAME step (the rest)
+template <bool LEAN>
+__global__ __launch_bounds__(KGE_BLOCK) void neg_fwd_bcast_edge_kernel(NegArgs a, int ns, int ng, int nbF, EdgeFwdArgs e) {
+    if ((int)blockIdx.x < nbF) neg_fwd_bcast_body<KGE_TRANSE_L1, true>(a, ns, ng, (int)blockIdx.x);
+    else edge_fwd_body<KGE_TRANSE_L1, 4, LEAN>(e, (int)blockIdx.x - nbF);
+}
+
+bool neg_fwd_bcast_with_edge_supported(int model, int d_e, int d_r) {
+    return model == KGE_TRANSE_L1 && d_r == d_e && d_e % 4 == 0 && neg_bcast_supported(model, d_e);
+}
+
+int launch_neg_fwd_bcast_with_edge(const NegArgs &a, const EdgeFwdArgs &e, hipStream_t s) {
+    if (!neg_fwd_bcast_with_edge_supported(a.model, a.d_e, e.d_r) || e.model != a.model || !a.xbase || !a.xidx || !a.rbase ||
+        !a.ridx || e.src.em.n || e.src.rm.n || e.nd_own)
+        return KGE_ERR_ARG;
+    constexpr int RW = SB_RWR;
+    const int ns = (a.N + 63) / 64, ng = (a.chunk + RW - 1) / RW;
+    const int nbF = (int)(((int64_t)a.C * ns * ng + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK);
+    const bool negjob = e.bsq || e.Bn;
+    const int64_t waves = (int64_t)e.B + (negjob ? e.n_neg : 0);
+    EdgeFwdArgs ee = e;
+    if (!negjob) ee.n_neg = 0;
+    const int nbP = (int)((waves + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK);
+    if (nbF == 0) return KGE_ERR_ARG;
+    const bool lean = e.lp.genre == KGE_LOSS_LOGSIGMOID && !e.row_pos && !e.Hc;
+    if (lean) hipLaunchKernelGGL(neg_fwd_bcast_edge_kernel<true>, dim3(nbF + nbP), dim3(KGE_BLOCK), 0, s, a, ns, ng, nbF, ee);
+    else hipLaunchKernelGGL(neg_fwd_bcast_edge_kernel<false>, dim3(nbF + nbP), dim3(KGE_BLOCK), 0, s, a, ns, ng, nbF, ee);
+    return check_launch_b();
 }
 
 template <int MODEL> static int fwd_launch(const NegArgs &a, hipStream_t s) {

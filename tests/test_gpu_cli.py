@@ -147,7 +147,9 @@ def test_train_cli_prints_the_reference_timers(tmp_path, capsys):
     lines = [l for l in out.split("\n") if l.startswith("[proc 0]sample: ")]
     assert len(lines) == 2, out
     vals = [float(x.split(": ")[1]) for x in lines[0].replace("[proc 0]", "").split(", ")]
-    assert len(vals) == 4 and all(v > 0 for v in vals) and sum(vals) < 5.0
+    # (the sampling share of a step is 1 / graph_steps of one sampler launch: it may round to 0.000 on a short interval)
+    assert len(vals) == 4 and all(v >= 0 for v in vals) and all(v > 0 for v in vals[1:]) and sum(vals) < 5.0
+    assert any("in the proportions of one phase-timed step" in l for l in out.split("\n"))
 
 
 @pytest.mark.parametrize("model", ["TransE_l2", "RotatE"])

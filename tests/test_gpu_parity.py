@@ -295,14 +295,17 @@ def test_merged_forward_launch_equals_split_launches_bit_for_bit(model, gamma, d
     assert np.isfinite(results[0][4]).all()
 
 
-def test_rotate_fused_gn_reduce_equals_separate_launches_bit_for_bit():
-    """RotatE strict step: the sum of the shared-pair backward's GN partials runs as the second half of the edge_bwd launch
-    (round 3) - the same reduction code as the stand-alone gn_reduce launch (KGE_FLAG_SPLIT_FWD keeps round 2's launches):
-    bit-identical tables at the FB15k recipe's shape."""
+@pytest.mark.parametrize("model,de_,B,N,hidden,gamma,lr", [("RotatE", True, 1024, 256, 200, 12.0, 0.009),
+                                                           ("TransE_l1", False, 1000, 200, 400, 16.0, 0.01)])
+def test_pairwise_fused_launches_equal_separate_launches_bit_for_bit(model, de_, B, N, hidden, gamma, lr):
+    """the pairwise family's fused launches of round 3 against round 2's launch sequence (KGE_FLAG_SPLIT_FWD), bit for bit at the
+    FB15k recipes' shapes.  RotatE: the sum of the shared-pair backward's GN partials runs as the second half of the edge_bwd
+    launch.  TransE_l1: the forward tasks build their uniform rows x +/- r from the table rows and share the launch with the
+    edge-forward rows (5 launches instead of 6)."""
     from dglke_amd import plan, _lib
     from dglke_amd.engine import StepEngine
     rng = np.random.RandomState(13)
-    n_ent, n_rel, B, N, hidden = 14951, 1345, 1024, 256, 200
+    n_ent, n_rel = 14951, 1345
     plans = []
     for step in range(1, 4):
         bt = O.synth_batch(rng, n_ent, n_rel, B, N, N, step)
@@ -310,14 +313,14 @@ def test_rotate_fused_gn_reduce_equals_separate_launches_bit_for_bit():
     results = []
     for flags in (0, _lib.FLAG_SPLIT_FWD):
         torch.manual_seed(0)
-        eng = StepEngine("RotatE", n_ent, n_rel, hidden, 12.0, 0.009, DEV, True, False, True, 1.0, 1e-7, 3, flags=flags)
+        eng = StepEngine(model, n_ent, n_rel, hidden, gamma, lr, DEV, de_, False, True, 1.0, 1e-7, 3, flags=flags)
         for b in plan.upload(plans, DEV):
             eng.step(b)
         torch.cuda.synchronize()
         results.append((eng.ent.cpu().numpy().copy(), eng.rel.cpu().numpy().copy(), eng.ent_state.cpu().numpy().copy(),
                         eng.rel_state.cpu().numpy().copy(), np.array(eng.read_loss_sums())))
     for k in range(5):
-        assert np.array_equal(results[0][k], results[1][k]), "fused vs separate gn_reduce: output %d differs" % k
+        assert np.array_equal(results[0][k], results[1][k]), "%s fused vs separate launches: output %d differs" % (model, k)
     assert np.abs(results[0][0]).max() > 0 and np.isfinite(results[0][4]).all()
 
 
