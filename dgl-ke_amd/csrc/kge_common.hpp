@@ -295,6 +295,9 @@ struct EdgeBwdArgs {
     // neg_deg_sample: gradient of the in-batch negative row of edge i, GNd[((i / nd_chunk) * nd_Np + i % nd_chunk) * d_e],
     // is added to the corrupted side's gradient (positive trace of that entity); null = off
     const float *GNd; int nd_chunk, nd_Np;
+    // GA arrives as ga_parts (> 1) partial sums, ga_stride floats apart (shared-pair backward with the negatives split over
+    // workgroups, neg_bwd_lc_splits): summed in part order while the row is read
+    int ga_parts; int64_t ga_stride;
 };
 
 struct NegArgs {                     // chunked negative scoring, forward and backward
@@ -314,6 +317,9 @@ struct NegArgs {                     // chunked negative scoring, forward and ba
     float *GNp;                      // bwd, TransE_l1 / RotatE: room for the per-row-group GN partials
                                      // (neg_bwd_lc_partial_floats) or null: two-pass kernels
     int defer_reduce;                // shared-pair backward: leave the partials unsummed (the caller's next launch sums them)
+    // shared-pair backward, RotatE: the negatives of a chunk split over ga_parts (> 1) workgroups per (chunk, slab, row group) -
+    // GA then leaves as ga_parts partial sums ga_stride floats apart and the CONSUMER adds them (edge_bwd: EdgeBwdArgs.ga_parts)
+    int ga_parts; int64_t ga_stride;
     // forward, merged launch (launch_neg_fwd_bcast_with_edge, TransE_l1): pos-side vectors built on the fly, a = x + asign * r
     const float *xbase; const int64_t *xidx; const float *rbase; const int64_t *ridx; float asign;
 };
@@ -542,6 +548,7 @@ int launch_neg_fwd_bcast_with_edge(const NegArgs &a, const EdgeFwdArgs &e, hipSt
 int launch_neg_bwd_bcast(const NegArgs &a, hipStream_t s);
 bool neg_bwd_lc_supported(int model, int d_e);         // kge_neg_bcast.hip: lane = column, one pair evaluation feeds GA and GN
 size_t neg_bwd_lc_partial_floats(int model, int C, int chunk, int N, int d_e);
+int neg_bwd_lc_splits(int model, int C, int chunk, int N, int d_e);   // ga_parts that fills the chip (1: not worth it / not supported)
 int neg_bwd_lc_nrw(int model, int C, int chunk, int d_e);      // row groups whose partials gn_reduce sums
 struct EdgeBwdArgs;
 int launch_edge_bwd_with_gn_reduce(const EdgeBwdArgs &a, const NegArgs &n, int nrw, hipStream_t s);

@@ -126,22 +126,53 @@ __device__ __forceinline__ void fwd_step(const float (&xc)[16], const float *ly,
 // OTF (round 3, TransE_l1 in the merged first launch): the uniform rows are the pos-side vectors a_i = x_i + asign * r_i built on
 // the fly from the table rows (x = head / tail through xidx, r through ridx: two coalesced loads and one fma per 64 elements of
 // a uniform row instead of one load) - the kernel then does not wait for edge_fwd, which runs as the other half of the launch
+// Round 3, occupancy: the kernel is bound by the instruction issue of its wavefronts (tools/valu_rate_probe.hip: one wavefront
+// issues one VALU instruction per ~5.2 cycles whatever the kind, a SIMD with four resident wavefronts one per 2.2 (plain fp32) /
+// 3.2 (packed) / 6.3 (v_sqrt) cycles - the RotatE mix costs 21.6 cycles per complex element and SIMD with one wavefront, 14.6 with
+// four) and a task per wavefront left ONE wavefront per SIMD at the recipes' shapes (1 000 tasks on 1 024 SIMDs).  A task (chunk,
+// strip of 64 negatives, RW positives) is therefore split over SB_KS wavefronts along the reduction (contiguous runs of
+// sub-slabs); a workgroup = SB_TPB tasks x SB_KS runs = 16 wavefronts, four per SIMD (<= 128 VGPRs), the partial sums meet in
+// LDS in fixed order (run 0 + run 1 + ...): deterministic, one barrier per workgroup.
+// RotatE (arithmetic-heavy: a square root per complex element) gains from it; the real-valued models do not (TransE_l1: the
+// per-lane row loads bound the kernel whatever the occupancy) and keep one wavefront per task.
+#ifndef SB_KS_C
+#define SB_KS_C 4                                // RotatE: wavefronts per task (runs of the reduction)
+#endif
+#ifndef SB_TPB_C
+#define SB_TPB_C 4                               // RotatE: tasks per workgroup (consecutive: same strip, the x rows hit in L1)
+#endif
+#ifndef SB_KS_R
+#define SB_KS_R 1                                // real-valued models
+#endif
+#ifndef SB_TPB_R
+#define SB_TPB_R 4
+#endif
+template <int MODEL> struct FwdShape {
+    static constexpr bool CPLX = MODEL == KGE_ROTATE;
+    static constexpr int RW = CPLX ? SB_RWC : SB_RWR, KS = CPLX ? SB_KS_C : SB_KS_R, TPB = CPLX ? SB_TPB_C : SB_TPB_R;
+    static constexpr int WAVES = KS * TPB, BLOCK = 64 * WAVES;
+};
+
 template <int MODEL, bool OTF>
 __device__ __forceinline__ void neg_fwd_bcast_body(const NegArgs &a, int ns, int ng, int bid) {
     constexpr bool CPLX = MODEL == KGE_ROTATE;
-    constexpr int RW = CPLX ? SB_RWC : SB_RWR;                        // uniform rows per wavefront
+    constexpr int RW = FwdShape<MODEL>::RW;                      // uniform rows per wavefront
+    constexpr int SB_KS = FwdShape<MODEL>::KS, SB_TPB = FwdShape<MODEL>::TPB;
+    constexpr int SB_FWD_WAVES = FwdShape<MODEL>::WAVES, SB_FWD_BLOCK = FwdShape<MODEL>::BLOCK;
     constexpr int NE = CPLX ? SB_KC : SB_KB;                     // (complex) elements per sub-slab
     constexpr int NSUB = 64 / NE;                                // sub-slabs per 64-element block
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
-    // tasks are numbered with the row group fastest and a workgroup takes 4 consecutive ones, so that
+    // tasks are numbered with the row group fastest and a workgroup takes SB_TPB consecutive ones, so that
     // its wavefronts (almost always) share the strip - the x rows then hit in L1 - while the number of
-    // workgroups carries no padding: with ~1 workgroup per CU a few extra workgroups double the
-    // makespan (260 instead of 250 at cfg-T).
-    const int task = bid * KGE_WAVES_PER_BLOCK + wave;
-    if (task >= a.C * ns * ng) return;                           // wave-uniform
+    // workgroups carries no padding.  Wavefront = (run kw of the reduction, task tw): the SB_TPB wavefronts of a run are adjacent.
+    const int tw = wave % SB_TPB, kw = wave / SB_TPB;
+    const int ntask = a.C * ns * ng;
+    const int task = min(bid * SB_TPB + tw, ntask - 1);          // (a padding wavefront repeats the last task and stores nothing)
     const int g = task % ng, st = (task / ng) % ns, c = task / (ng * ns);
     const int D = a.d_e, K = CPLX ? D / 2 : D;
+    const int nsl = K / NE;                                      // sub-slabs of a row (K % NE == 0: neg_bcast_supported)
+    const int k_lo = (kw * nsl / SB_KS) * NE, k_hi = ((kw + 1) * nsl / SB_KS) * NE;   // this wavefront's run [k_lo, k_hi)
     const int i0 = g * RW;
     const int j = st * 64 + lane;
     const float *x = row_ptr(a.nbase, a.nidx, (int64_t)c * a.N + min(j, a.N - 1), D);
@@ -187,7 +218,8 @@ __device__ __forceinline__ void neg_fwd_bcast_body(const NegArgs &a, int ns, int
     // the uniform rows of the current 64-element block, wavefront-private in LDS: [RW][64] (+ [RW][64] imaginary).
     // Written "lane = element" straight from the coalesced loads, read back as broadcasts.  One wavefront's LDS
     // instructions execute in order: no barrier between its writes and its reads.
-    __shared__ __attribute__((aligned(16))) float ylds[KGE_WAVES_PER_BLOCK][2 * RW * 64];
+    __shared__ __attribute__((aligned(16))) float ylds[SB_FWD_WAVES][2 * RW * 64];
+    __shared__ float part[SB_FWD_WAVES][RW][64];                 // partial sums of the runs
     float *ly = ylds[wave];
     auto puty = [&](const float (&yr_)[RW], const float (&yi_)[RW]) {
 #pragma unroll
@@ -200,51 +232,98 @@ __device__ __forceinline__ void neg_fwd_bcast_body(const NegArgs &a, int ns, int
     // sub-slabs ahead was SLOWER, 13.3 -> 17.9 us for TransE_l1: these per-lane row loads touch 64 cache lines per
     // instruction and more of them in flight only lengthen the queue in front of the texture addresser.)
     float yr[RW], yi[RW], ynr[RW], yni[RW], xa[16], xb[16];
-    loady(yr, yi, 0);
-    loadx(xa, 0);
-    int kb = 0;
-    for (; kb + 64 <= K; kb += 64) {                             // full blocks, branch-free
+    loady(yr, yi, k_lo);
+    loadx(xa, k_lo);
+    if constexpr (SB_KS == 1) {
+        // one wavefront per task (real-valued models): full blocks unrolled with compile-time lane bases, branch-free (round 2's
+        // loop: at one wavefront per SIMD the rolled form below costs TransE_l1 6 us per launch)
+        int kb = 0;
+        for (; kb + 64 <= K; kb += 64) {
+            loady(ynr, yni, kb + 64);                            // next block, one block ahead
+            puty(yr, yi);
+            static_for<NSUB>([&](auto subc) {
+                constexpr int SUB = decltype(subc)::value;
+                float(&xc)[16] = (SUB & 1) ? xb : xa;
+                float(&xn)[16] = (SUB & 1) ? xa : xb;
+                loadx(xn, kb + (SUB + 1) * NE);                  // next sub-slab, one ahead
+                fwd_step<MODEL, RW, NE, SUB * NE>(xc, ly, acc, 0);
+            });
+#pragma unroll
+            for (int r = 0; r < RW; ++r) { yr[r] = ynr[r]; yi[r] = yni[r]; }
+        }
+        if (kb < K) puty(yr, yi);
+        for (int k0 = kb; k0 < K; k0 += NE) {                    // partial last block (K % 64 elements)
+            fwd_step<MODEL, RW, NE, -1>(xa, ly, acc, k0 - kb);
+            loadx(xa, k0 + NE);
+        }
+    } else {
+    // blocks of 64 elements (the last one of a run partial), sub-slabs with a run-time lane base in a ROLLED loop (the unrolled
+    // block body above needs 180 VGPRs for RotatE; four wavefronts per SIMD have 128), the two register buffers alternating,
+    // every load unconditional (clamped) and ahead of the arithmetic that precedes its use
+    for (int kb = k_lo; kb < k_hi; kb += 64) {
+        const int kend = min(kb + 64, k_hi);
         loady(ynr, yni, kb + 64);                                // next block, one block ahead
         puty(yr, yi);
-        static_for<NSUB>([&](auto subc) {
-            constexpr int SUB = decltype(subc)::value;
-            float(&xc)[16] = (SUB & 1) ? xb : xa;
-            float(&xn)[16] = (SUB & 1) ? xa : xb;
-            loadx(xn, kb + (SUB + 1) * NE);                      // next sub-slab, one ahead
-            fwd_step<MODEL, RW, NE, SUB * NE>(xc, ly, acc, 0);
-        });
+#pragma unroll 1
+        for (int k0 = kb; k0 < kend; k0 += 2 * NE) {
+            const bool two = k0 + NE < kend;                     // (only the last block of a run can hold an odd number)
+            loadx(xb, k0 + NE);
+            fwd_step<MODEL, RW, NE, -1>(xa, ly, acc, k0 - kb);
+            loadx(xa, two ? k0 + 2 * NE : k0 + NE);
+            if (two) fwd_step<MODEL, RW, NE, -1>(xb, ly, acc, k0 + NE - kb);
+        }
 #pragma unroll
         for (int r = 0; r < RW; ++r) { yr[r] = ynr[r]; yi[r] = yni[r]; }
     }
-    if (kb < K) puty(yr, yi);
-    for (int k0 = kb; k0 < K; k0 += NE) {                        // partial last block (K % 64 elements)
-        fwd_step<MODEL, RW, NE, -1>(xa, ly, acc, k0 - kb);
-        loadx(xa, k0 + NE);
     }
-    if (j < a.N) {
+    if constexpr (SB_KS == 1) {                                 // one wavefront per task: its sums are final
+        if (bid * SB_TPB + tw < ntask && j < a.N) {
 #pragma unroll
-        for (int r = 0; r < RW; ++r) {
-            if (i0 + r < a.chunk) {
-                float v = acc[r].x + acc[r].y;
-                if (MODEL == KGE_TRANSE_L1 || CPLX) v = a.gamma - v;
-                else if (MODEL == KGE_TRANSE_L2) v = a.gamma - sqrtf(fmaxf(v, 1e-30f));
-                else if (a.clampv > 0.f) v = fminf(fmaxf(v, -a.clampv), a.clampv);
-                a.S[((int64_t)c * a.chunk + i0 + r) * a.N + j] = v;
+            for (int r = 0; r < RW; ++r) {
+                if (i0 + r < a.chunk) {
+                    float v = acc[r].x + acc[r].y;
+                    if (MODEL == KGE_TRANSE_L1 || CPLX) v = a.gamma - v;
+                    else if (MODEL == KGE_TRANSE_L2) v = a.gamma - sqrtf(fmaxf(v, 1e-30f));
+                    else if (a.clampv > 0.f) v = fminf(fmaxf(v, -a.clampv), a.clampv);
+                    a.S[((int64_t)c * a.chunk + i0 + r) * a.N + j] = v;
+                }
             }
         }
+        return;
+    }
+#pragma unroll
+    for (int r = 0; r < RW; ++r) part[wave][r][lane] = acc[r].x + acc[r].y;
+    __syncthreads();
+    // one output per thread and pass: (task tw2, row r, negative l); the runs are added in run order
+    for (int o = threadIdx.x; o < SB_TPB * RW * 64; o += SB_FWD_BLOCK) {
+        const int l = o & 63, r = (o >> 6) % RW, tw2 = (o >> 6) / RW;
+        const int t2 = bid * SB_TPB + tw2;
+        if (t2 >= ntask) continue;
+        const int g2 = t2 % ng, st2 = (t2 / ng) % ns, c2 = t2 / (ng * ns);
+        const int i2 = g2 * RW + r, j2 = st2 * 64 + l;
+        if (j2 >= a.N || i2 >= a.chunk) continue;
+        float v = part[tw2][r][l];
+#pragma unroll
+        for (int q = 1; q < SB_KS; ++q) v += part[q * SB_TPB + tw2][r][l];
+        if (MODEL == KGE_TRANSE_L1 || CPLX) v = a.gamma - v;
+        else if (MODEL == KGE_TRANSE_L2) v = a.gamma - sqrtf(fmaxf(v, 1e-30f));
+        else if (a.clampv > 0.f) v = fminf(fmaxf(v, -a.clampv), a.clampv);
+        a.S[((int64_t)c2 * a.chunk + i2) * a.N + j2] = v;
     }
 }
 
 template <int MODEL>
-__global__ __launch_bounds__(KGE_BLOCK) void neg_fwd_bcast_kernel(NegArgs a, int ns, int ng) {
+__global__ __launch_bounds__(FwdShape<MODEL>::BLOCK) void neg_fwd_bcast_kernel(NegArgs a, int ns, int ng) {
     neg_fwd_bcast_body<MODEL, false>(a, ns, ng, (int)blockIdx.x);
 }
 
-// TransE_l1, strict step: forward pairwise tasks (first nbF workgroups) + the edge-forward rows of the SAME step (the rest)
+// TransE_l1, strict step: forward pairwise tasks (first nbF workgroups) + the edge-forward rows of the SAME step (the rest: one
+// wavefront per row, SB_FWD_WAVES rows per workgroup - edge_fwd_body counts in workgroups of KGE_WAVES_PER_BLOCK wavefronts)
 template <bool LEAN>
-__global__ __launch_bounds__(KGE_BLOCK) void neg_fwd_bcast_edge_kernel(NegArgs a, int ns, int ng, int nbF, EdgeFwdArgs e) {
+__global__ __launch_bounds__(FwdShape<KGE_TRANSE_L1>::BLOCK) void neg_fwd_bcast_edge_kernel(NegArgs a, int ns, int ng, int nbF, EdgeFwdArgs e) {
+    static_assert(FwdShape<KGE_TRANSE_L1>::WAVES % KGE_WAVES_PER_BLOCK == 0, "edge_fwd_body counts workgroups of KGE_WAVES_PER_BLOCK wavefronts");
     if ((int)blockIdx.x < nbF) neg_fwd_bcast_body<KGE_TRANSE_L1, true>(a, ns, ng, (int)blockIdx.x);
-    else edge_fwd_body<KGE_TRANSE_L1, 4, LEAN>(e, (int)blockIdx.x - nbF);
+    else edge_fwd_body<KGE_TRANSE_L1, 4, LEAN>(e, ((int)blockIdx.x - nbF) * (FwdShape<KGE_TRANSE_L1>::WAVES / KGE_WAVES_PER_BLOCK));
 }
 
 bool neg_fwd_bcast_with_edge_supported(int model, int d_e, int d_r) {
@@ -255,27 +334,28 @@ int launch_neg_fwd_bcast_with_edge(const NegArgs &a, const EdgeFwdArgs &e, hipSt
     if (!neg_fwd_bcast_with_edge_supported(a.model, a.d_e, e.d_r) || e.model != a.model || !a.xbase || !a.xidx || !a.rbase ||
         !a.ridx || e.src.em.n || e.src.rm.n || e.nd_own)
         return KGE_ERR_ARG;
-    constexpr int RW = SB_RWR;
+    typedef FwdShape<KGE_TRANSE_L1> FS;
+    constexpr int RW = FS::RW, SB_TPB = FS::TPB, SB_FWD_WAVES = FS::WAVES, SB_FWD_BLOCK = FS::BLOCK;
     const int ns = (a.N + 63) / 64, ng = (a.chunk + RW - 1) / RW;
-    const int nbF = (int)(((int64_t)a.C * ns * ng + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK);
+    const int nbF = (int)(((int64_t)a.C * ns * ng + SB_TPB - 1) / SB_TPB);
     const bool negjob = e.bsq || e.Bn;
     const int64_t waves = (int64_t)e.B + (negjob ? e.n_neg : 0);
     EdgeFwdArgs ee = e;
     if (!negjob) ee.n_neg = 0;
-    const int nbP = (int)((waves + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK);
+    const int nbP = (int)((waves + SB_FWD_WAVES - 1) / SB_FWD_WAVES);
     if (nbF == 0) return KGE_ERR_ARG;
     const bool lean = e.lp.genre == KGE_LOSS_LOGSIGMOID && !e.row_pos && !e.Hc;
-    if (lean) hipLaunchKernelGGL(neg_fwd_bcast_edge_kernel<true>, dim3(nbF + nbP), dim3(KGE_BLOCK), 0, s, a, ns, ng, nbF, ee);
-    else hipLaunchKernelGGL(neg_fwd_bcast_edge_kernel<false>, dim3(nbF + nbP), dim3(KGE_BLOCK), 0, s, a, ns, ng, nbF, ee);
+    if (lean) hipLaunchKernelGGL(neg_fwd_bcast_edge_kernel<true>, dim3(nbF + nbP), dim3(SB_FWD_BLOCK), 0, s, a, ns, ng, nbF, ee);
+    else hipLaunchKernelGGL(neg_fwd_bcast_edge_kernel<false>, dim3(nbF + nbP), dim3(SB_FWD_BLOCK), 0, s, a, ns, ng, nbF, ee);
     return check_launch_b();
 }
 
 template <int MODEL> static int fwd_launch(const NegArgs &a, hipStream_t s) {
-    constexpr int RW = MODEL == KGE_ROTATE ? SB_RWC : SB_RWR;
+    constexpr int RW = FwdShape<MODEL>::RW, SB_TPB = FwdShape<MODEL>::TPB, SB_FWD_BLOCK = FwdShape<MODEL>::BLOCK;
     const int ns = (a.N + 63) / 64, ng = (a.chunk + RW - 1) / RW;
-    const int64_t nb = ((int64_t)a.C * ns * ng + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK;
+    const int64_t nb = ((int64_t)a.C * ns * ng + SB_TPB - 1) / SB_TPB;
     if (nb == 0) return KGE_OK;
-    hipLaunchKernelGGL(neg_fwd_bcast_kernel<MODEL>, dim3((unsigned)nb), dim3(KGE_BLOCK), 0, s, a, ns, ng);
+    hipLaunchKernelGGL(neg_fwd_bcast_kernel<MODEL>, dim3((unsigned)nb), dim3(SB_FWD_BLOCK), 0, s, a, ns, ng);
     return check_launch_b();
 }
 
@@ -490,8 +570,16 @@ size_t neg_bwd_lc_partial_floats(int model, int C, int chunk, int N, int d_e) {
     return (size_t)nrw * C * N * d_e;
 }
 
+#ifdef LC_WPE
+#define LC_OCC __attribute__((amdgpu_waves_per_eu(LC_WPE, LC_WPE)))
+#else
+#define LC_OCC
+#endif
+#ifndef LC_WG_CAP
+#define LC_WG_CAP 1024                           // negatives are split while the launch stays within this many workgroups
+#endif
 template <int MODEL, int RT>
-__global__ __launch_bounds__(KGE_BLOCK) void neg_bwd_lc_kernel(NegArgs a, int nslab, int nrw, int rpw) {
+__global__ __launch_bounds__(KGE_BLOCK) LC_OCC void neg_bwd_lc_kernel(NegArgs a, int nslab, int nrw, int rpw) {
     constexpr bool CPLX = MODEL == KGE_ROTATE;
     constexpr int NV = CPLX ? 4 : 2;                             // floats per lane in a GN partial
     constexpr int LC_GQ = CPLX ? LC_GQ_CPLX : LC_GQ_REAL, LC_SG = 4 * LC_GQ;   // quads / negatives per group
@@ -499,7 +587,12 @@ __global__ __launch_bounds__(KGE_BLOCK) void neg_bwd_lc_kernel(NegArgs a, int ns
     __shared__ __attribute__((aligned(16))) float stage[2 * LC_SG * LC_CW * (CPLX ? 2 : 1) + 2 * KGE_WAVES_PER_BLOCK * LC_SG * (RT > 16 ? 32 : 16)];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63, sg = lane >> 4, kk = lane & 15;
-    const int blk = blockIdx.x;
+    // a.ga_parts > 1: the quads of the chunk's negatives are split over that many workgroups per (chunk, slab, row group) - three
+    // or four wavefronts per SIMD instead of one (the kernel is bound by the instruction issue of its wavefronts,
+    // tools/valu_rate_probe.hip); every negative still has ONE workgroup per row group (GN partials unchanged), GA leaves as
+    // ga_parts partial sums that the consumer adds
+    const int nsp = max(a.ga_parts, 1);
+    const int sp = (int)blockIdx.x % nsp, blk = (int)blockIdx.x / nsp;
     const int rw = blk % nrw, slab = (blk / nrw) % nslab, c = blk / (nrw * nslab);
     const int D = a.d_e, K = CPLX ? D / 2 : D, N = a.N, chunk = a.chunk;
     const int col = slab * LC_CW + 2 * kk;
@@ -519,6 +612,8 @@ __global__ __launch_bounds__(KGE_BLOCK) void neg_bwd_lc_kernel(NegArgs a, int ns
     }
     const float *Wc = a.W + (int64_t)c * chunk * N;
     const int nq = (N + 3) >> 2;
+    const int ngr = (nq + LC_GQ - 1) / LC_GQ;                    // groups of quads; this workgroup: groups [sp, sp + 1) * ngr / nsp
+    const int q_lo = (sp * ngr / nsp) * LC_GQ, q_hi = min(((sp + 1) * ngr / nsp) * LC_GQ, nq);
     // ---- operand staging through LDS, one group of LC_GQ quads (= LC_SG negatives) at a time ----------------
     // The 4 wavefronts of the workgroup need the SAME negative rows (their slab columns) and each its own block
     // of W.  The global loads of group i+1 are issued BEFORE the arithmetic of group i and written to the other
@@ -606,15 +701,15 @@ __global__ __launch_bounds__(KGE_BLOCK) void neg_bwd_lc_kernel(NegArgs a, int ns
         if constexpr (CPLX) *reinterpret_cast<float4 *>(slot) = make_float4(nr.x, nr.y, ni.x, ni.y);
         else *reinterpret_cast<v2f *>(slot) = nr;
     };
-    gload(0);
-    lstore(0, 0);
+    gload(min(q_lo, nq - 1));
+    lstore(0, q_lo);
     // every load of the prologue (x rows included) has landed before the loop: otherwise the compiler keeps
     // "x may still be in flight" alive around the back edge and makes the first quad of every group wait for the
     // previous group's partial-sum stores
     __builtin_amdgcn_s_waitcnt(0x0F70);                          // vmcnt(0)
     __syncthreads();
     int buf = 0;
-    for (int qb = 0; qb < nq; qb += LC_GQ) {
+    for (int qb = q_lo; qb < q_hi; qb += LC_GQ) {
         float *redb = red + buf * (LC_GQ * KGE_WAVES_PER_BLOCK * 64 * NV);
         gload(min(qb + LC_GQ, nq - 1));                          // next group (past the end: a harmless re-read)
         v2f ya, yia, yb_, yib;
@@ -664,7 +759,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void neg_bwd_lc_kernel(NegArgs a, int ns
             gi[n].x += __shfl_xor(gi[n].x, 32, 64); gi[n].y += __shfl_xor(gi[n].y, 32, 64);
         }
         if (sg == 0 && colok && r0 + n < rend) {
-            float *o = a.GA + ((int64_t)c * chunk + r0 + n) * D + col;
+            float *o = a.GA + sp * a.ga_stride + ((int64_t)c * chunk + r0 + n) * D + col;
             *reinterpret_cast<v2f *>(o) = gr[n];
             if constexpr (CPLX) *reinterpret_cast<v2f *>(o + K) = gi[n];
         }
@@ -677,6 +772,16 @@ __global__ __launch_bounds__(KGE_BLOCK) void gn_reduce_kernel(NegArgs a, int nrw
     gn_reduce_body(a, nrw, (int64_t)blockIdx.x * KGE_BLOCK + threadIdx.x);
 }
 
+// RotatE: split the negatives while the launch stays within ~4 workgroups per CU and a workgroup keeps >= 2 groups of quads
+int neg_bwd_lc_splits(int model, int C, int chunk, int N, int d_e) {
+    if (model != KGE_ROTATE || !neg_bwd_lc_supported(model, d_e) || N % 4) return 1;
+    int nslab, nrw, rpw;
+    lc_shape(model, C, chunk, d_e, nslab, nrw, rpw);
+    const int ngr = ((N + 3) / 4 + LC_GQ_CPLX - 1) / LC_GQ_CPLX;
+    int nsp = 1;
+    while (nsp < 8 && (int64_t)C * nslab * nrw * (nsp + 1) <= LC_WG_CAP && ngr / (nsp + 1) >= 2) ++nsp;
+    return nsp;
+}
 int neg_bwd_lc_nrw(int model, int C, int chunk, int d_e) {
     int nslab, nrw, rpw;
     lc_shape(model, C, chunk, d_e, nslab, nrw, rpw);
@@ -686,7 +791,8 @@ int neg_bwd_lc_nrw(int model, int C, int chunk, int d_e) {
 template <int MODEL> static int lc_launch(const NegArgs &a, hipStream_t s) {
     int nslab, nrw, rpw;
     lc_shape(MODEL, a.C, a.chunk, a.d_e, nslab, nrw, rpw);
-    const int64_t nb = (int64_t)a.C * nslab * nrw;
+    if (a.ga_parts > 1 && MODEL != KGE_ROTATE) return KGE_ERR_ARG;
+    const int64_t nb = (int64_t)a.C * nslab * nrw * max(a.ga_parts, 1);
     if (nb == 0) return KGE_OK;
     const dim3 g((unsigned)nb), b(KGE_BLOCK);
     // rows per wavefront rounded up to the next instantiation (the padding rows carry W = 0)

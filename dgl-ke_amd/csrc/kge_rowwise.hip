@@ -134,6 +134,16 @@ __device__ __forceinline__ void edge_bwd_body(const EdgeBwdArgs &a_in, int64_t i
     const float *r = table_row(a.src.rm, a.src.rbase, a.src.ridx, i, a.d_r);
     const float dp_in = a.dpos ? a.dpos[i] : 0.f;
     const float *ga = a.GA ? a.GA + i * (int64_t)a.d_e : nullptr;
+    // GA in parts (shared-pair backward with split negatives): added in part order
+    auto ld_ga = [&](const float *p) {
+        Pack<V> v = ld<V>(p);
+        for (int q = 1; q < a.ga_parts; ++q) {
+            const Pack<V> u = ld<V>(p + q * a.ga_stride);
+#pragma unroll
+            for (int e = 0; e < V; ++e) v.v[e] += u.v[e];
+        }
+        return v;
+    };
     float *GH = a.GH ? a.GH + i * (int64_t)a.d_e : nullptr;
     float *GT = a.GT ? a.GT + i * (int64_t)a.d_e : nullptr;
     float *GR = a.GR ? a.GR + i * (int64_t)a.d_r : nullptr;
@@ -161,7 +171,7 @@ __device__ __forceinline__ void edge_bwd_body(const EdgeBwdArgs &a_in, int64_t i
         for (int it = lane; it < nit; it += 64) {
             const int off = it * V;
             const Pack<V> hv = ld<V>(h + off), rv = ld<V>(r + off), tv = ld<V>(t + off);
-            const Pack<V> gav = ga ? ld<V>(ga + off) : zero_pack<V>();
+            const Pack<V> gav = ga ? ld_ga(ga + off) : zero_pack<V>();
             Pack<V> gh, gt, gr;
 #pragma unroll
             for (int e = 0; e < V; ++e) {
@@ -211,8 +221,8 @@ __device__ __forceinline__ void edge_bwd_body(const EdgeBwdArgs &a_in, int64_t i
             const int off = it * V;
             const Pack<V> rh = ld<V>(h + off), ih = ld<V>(h + hd + off);
             const Pack<V> rt = ld<V>(t + off), it_ = ld<V>(t + hd + off);
-            const Pack<V> gre = ga ? ld<V>(ga + off) : zero_pack<V>();
-            const Pack<V> gim = ga ? ld<V>(ga + hd + off) : zero_pack<V>();
+            const Pack<V> gre = ga ? ld_ga(ga + off) : zero_pack<V>();
+            const Pack<V> gim = ga ? ld_ga(ga + hd + off) : zero_pack<V>();
             Pack<V> o_rh, o_ih, o_rt, o_it;
             if constexpr (MODEL == KGE_SIMPLE) {
                 const Pack<V> rr = ld<V>(r + off), ir = ld<V>(r + hd + off);
