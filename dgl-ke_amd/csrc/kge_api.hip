@@ -406,7 +406,7 @@ size_t kge_step_workspace_bytes(const kge_hparams *hp, int B, int C, int chunk, 
     add(B); add(B);      // pos score, dpos
     add((size_t)B * N);  // S / W
     add(B * tj16); add(B * tj16); add(B * tj16);   // per-(row, 16-column tile) partials: max / sum-exp / loss
-    add(B * d_e * (size_t)((hp->model == KGE_ROTATE && !(hp->flags & KGE_FLAG_TWO_PASS_PAIR)) ? neg_bwd_lc_splits(hp->model, C, chunk, N, hp->d_e) : 1));   // GA (RotatE: in parts)
+    add(B * d_e * (size_t)(!(hp->flags & KGE_FLAG_TWO_PASS_PAIR) ? neg_bwd_lc_splits(hp->model, C, chunk, N, hp->d_e) : 1));   // GA (shared-pair backward: in parts)
     add(CN * d_e);       // GN
     add(B * d_e);        // P (TransE) or GH
     add(B * d_e);                 // GT
@@ -499,8 +499,8 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     float *P = cv.f(B), *dP = cv.f(B);
     float *S = cv.f((size_t)B * N);
     float *PM = cv.f((size_t)B * tj16), *PS = cv.f((size_t)B * tj16), *PL = cv.f((size_t)B * tj16);
-    // (RotatE's shared-pair backward leaves GA in up to 8 parts, neg_bwd_lc_splits)
-    const int ga_parts = (hp->model == KGE_ROTATE && !(hp->flags & KGE_FLAG_TWO_PASS_PAIR)) ? neg_bwd_lc_splits(hp->model, C, chunk, N, d_e) : 1;
+    // (the shared-pair backward of RotatE / TransE_l1 leaves GA in up to 8 parts, neg_bwd_lc_splits)
+    const int ga_parts = (!gemm && !(hp->flags & KGE_FLAG_TWO_PASS_PAIR)) ? neg_bwd_lc_splits(hp->model, C, chunk, N, d_e) : 1;
     float *GA = cv.f((size_t)B * d_e * ga_parts), *GN = cv.f((size_t)CN * d_e);
     const bool rescal = hp->model == KGE_RESCAL;
     float *GH = cv.f((size_t)B * d_e), *GT = cv.f((size_t)B * d_e);
@@ -723,8 +723,10 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
                      (hp->model == KGE_ROTATE || hp->model == KGE_TRANSE_L1) && !(hp->flags & KGE_FLAG_TWO_PASS_PAIR) &&
                      !(hp->flags & KGE_FLAG_SPLIT_FWD);
         na.defer_reduce = fuse_gnred ? 1 : 0;
-        // GA in parts only where the shared-pair kernel runs and edge_bwd (which adds the parts) consumes it
-        const bool ga_split = ga_parts > 1 && na.GNp && !na.nidx && na.N % 4 == 0 && !transe_fast && !rescal && !transr;
+        // GA in parts only where the shared-pair kernel runs: its stand-alone partial reduction adds them up in place, the
+        // edge_bwd launch that carries the reduction (fuse_gnred) adds them while it reads the row
+        const bool ga_split = ga_parts > 1 && na.GNp && !na.nidx && na.N % 4 == 0 && !rescal && !transr &&
+                              neg_bwd_lc_supported(hp->model, d_e);
         na.ga_parts = ga_split ? ga_parts : 1; na.ga_stride = (int64_t)B * d_e;
         KGE_TRY(launch_neg_bwd_pair(na, s));
         if (co_prep) KGE_TRY(launch_edge_fwd(*co_prep, s));
@@ -776,7 +778,7 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         eb.gamma = hp->gamma; eb.rot_div = rot_div;
         eb.dpos = dP; eb.GA = GA; eb.reg_coef = reg ? hp->reg_coef : 0.f; eb.reg_norm = hp->reg_norm;
         eb.GH = GH; eb.GT = GT; eb.GR = GR;
-        eb.ga_parts = na.ga_parts; eb.ga_stride = na.ga_stride;
+        eb.ga_parts = fuse_gnred ? na.ga_parts : 1; eb.ga_stride = na.ga_stride;
         if (nd) { eb.GNd = GN; eb.nd_chunk = chunk; eb.nd_Np = N; }   // in-batch negative rows -> positive trace
         if (fuse_gnred) {
             const int rc = launch_edge_bwd_with_gn_reduce(eb, na, neg_bwd_lc_nrw(hp->model, C, chunk, d_e), s);

@@ -21,6 +21,7 @@
 #include "kge_edge_fwd_body.hpp"
 
 using namespace kge;
+KGE_TL_DEFINE(bcast)
 
 #define SB_KB 16                                 // real models: reduction elements per forward sub-slab
 #define SB_KC 8                                  // RotatE: complex columns per sub-slab
@@ -234,6 +235,9 @@ __device__ __forceinline__ void neg_fwd_bcast_body(const NegArgs &a, int ns, int
     float yr[RW], yi[RW], ynr[RW], yni[RW], xa[16], xb[16];
     loady(yr, yi, k_lo);
     loadx(xa, k_lo);
+#ifdef KGE_TL_MARKS
+    KGE_TL_MARK_K(1, 0);           // ids, row pointers and the first operands have arrived
+#endif
     if constexpr (SB_KS == 1) {
         // one wavefront per task (real-valued models): full blocks unrolled with compile-time lane bases, branch-free (round 2's
         // loop: at one wavefront per SIMD the rolled form below costs TransE_l1 6 us per launch)
@@ -291,9 +295,15 @@ __device__ __forceinline__ void neg_fwd_bcast_body(const NegArgs &a, int ns, int
         }
         return;
     }
+#ifdef KGE_TL_MARKS
+    KGE_TL_MARK_K(1, 1);           // this wavefront's run is done
+#endif
 #pragma unroll
     for (int r = 0; r < RW; ++r) part[wave][r][lane] = acc[r].x + acc[r].y;
     __syncthreads();
+#ifdef KGE_TL_MARKS
+    KGE_TL_MARK_K(1, 2);           // every run of the workgroup is done
+#endif
     // one output per thread and pass: (task tw2, row r, negative l); the runs are added in run order
     for (int o = threadIdx.x; o < SB_TPB * RW * 64; o += SB_FWD_BLOCK) {
         const int l = o & 63, r = (o >> 6) % RW, tw2 = (o >> 6) / RW;
@@ -314,6 +324,7 @@ __device__ __forceinline__ void neg_fwd_bcast_body(const NegArgs &a, int ns, int
 
 template <int MODEL>
 __global__ __launch_bounds__(FwdShape<MODEL>::BLOCK) void neg_fwd_bcast_kernel(NegArgs a, int ns, int ng) {
+    KGE_TL(1);
     neg_fwd_bcast_body<MODEL, false>(a, ns, ng, (int)blockIdx.x);
 }
 
@@ -570,8 +581,15 @@ size_t neg_bwd_lc_partial_floats(int model, int C, int chunk, int N, int d_e) {
     return (size_t)nrw * C * N * d_e;
 }
 
+// LC_WPE: wavefronts per SIMD the register allocation aims at where the instantiation fits without spilling (RotatE: 8 rows per
+// wavefront, TransE_l1: up to 16); LC_RED_SINGLE: one buffer of GN partials and a second barrier per group (32 instead of 48 KB
+// of LDS).  Together: four workgroups per CU - every workgroup of the split RotatE launch resident at once (60.9 vs 61.7 us/step)
+#ifndef LC_NO_OCC4
+#define LC_WPE 4
+#define LC_RED_SINGLE 1
+#endif
 #ifdef LC_WPE
-#define LC_OCC __attribute__((amdgpu_waves_per_eu(LC_WPE, LC_WPE)))
+#define LC_OCC __attribute__((amdgpu_waves_per_eu((RT <= (MODEL == KGE_ROTATE ? 8 : 16)) ? LC_WPE : 1, (RT <= (MODEL == KGE_ROTATE ? 8 : 16)) ? LC_WPE : 8)))
 #else
 #define LC_OCC
 #endif
@@ -580,10 +598,16 @@ size_t neg_bwd_lc_partial_floats(int model, int C, int chunk, int N, int d_e) {
 #endif
 template <int MODEL, int RT>
 __global__ __launch_bounds__(KGE_BLOCK) LC_OCC void neg_bwd_lc_kernel(NegArgs a, int nslab, int nrw, int rpw) {
+    KGE_TL(3);
     constexpr bool CPLX = MODEL == KGE_ROTATE;
     constexpr int NV = CPLX ? 4 : 2;                             // floats per lane in a GN partial
     constexpr int LC_GQ = CPLX ? LC_GQ_CPLX : LC_GQ_REAL, LC_SG = 4 * LC_GQ;   // quads / negatives per group
-    __shared__ __attribute__((aligned(16))) float red[2 * LC_GQ * KGE_WAVES_PER_BLOCK * 64 * NV];   // GN partials, two alternating buffers
+#ifdef LC_RED_SINGLE
+    constexpr int NRED = 1;                                      // one buffer of GN partials + a second barrier per group: 32 KB of LDS, 4 workgroups per CU
+#else
+    constexpr int NRED = 2;                                      // two alternating buffers
+#endif
+    __shared__ __attribute__((aligned(16))) float red[NRED * LC_GQ * KGE_WAVES_PER_BLOCK * 64 * NV];   // GN partials
     __shared__ __attribute__((aligned(16))) float stage[2 * LC_SG * LC_CW * (CPLX ? 2 : 1) + 2 * KGE_WAVES_PER_BLOCK * LC_SG * (RT > 16 ? 32 : 16)];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63, sg = lane >> 4, kk = lane & 15;
@@ -708,9 +732,12 @@ __global__ __launch_bounds__(KGE_BLOCK) LC_OCC void neg_bwd_lc_kernel(NegArgs a,
     // previous group's partial-sum stores
     __builtin_amdgcn_s_waitcnt(0x0F70);                          // vmcnt(0)
     __syncthreads();
+#ifdef KGE_TL_MARKS
+    KGE_TL_MARK_K(3, 0);           // own rows and the first group of operands are staged
+#endif
     int buf = 0;
     for (int qb = q_lo; qb < q_hi; qb += LC_GQ) {
-        float *redb = red + buf * (LC_GQ * KGE_WAVES_PER_BLOCK * 64 * NV);
+        float *redb = red + (NRED == 2 ? buf : 0) * (LC_GQ * KGE_WAVES_PER_BLOCK * 64 * NV);
         gload(min(qb + LC_GQ, nq - 1));                          // next group (past the end: a harmless re-read)
         v2f ya, yia, yb_, yib;
         float wa0, wa1, wb0, wb1;
@@ -748,7 +775,11 @@ __global__ __launch_bounds__(KGE_BLOCK) LC_OCC void neg_bwd_lc_kernel(NegArgs a,
             }
         }
         buf ^= 1;
+        if constexpr (NRED == 1) __syncthreads();                // the partials are read before the next group overwrites them
     }
+#ifdef KGE_TL_MARKS
+    KGE_TL_MARK_K(3, 1);           // groups done
+#endif
     // GA: sum over the 4 lane rows (different negatives), then lane row 0 stores
 #pragma unroll
     for (int n = 0; n < RT; ++n) {
@@ -768,16 +799,31 @@ __global__ __launch_bounds__(KGE_BLOCK) LC_OCC void neg_bwd_lc_kernel(NegArgs a,
 
 // GN[j, :] = sum over the workgroup row groups of the partials (fixed order) + regulariser of the negative row
 // (body in kge_common.hpp: the fused step runs it as the second half of the edge_bwd launch, kge_rowwise.hip)
+// + (ga_parts > 1, stand-alone reduction only) GA = sum of its parts, in place, in part order
 __global__ __launch_bounds__(KGE_BLOCK) void gn_reduce_kernel(NegArgs a, int nrw) {
-    gn_reduce_body(a, nrw, (int64_t)blockIdx.x * KGE_BLOCK + threadIdx.x);
+    const int64_t t = (int64_t)blockIdx.x * KGE_BLOCK + threadIdx.x;
+    const int64_t n4 = (int64_t)a.C * a.N * a.d_e / 4;
+    if (t < n4) { gn_reduce_body(a, nrw, t); return; }
+    const int64_t u = t - n4;
+    if (a.ga_parts > 1 && u < (int64_t)a.C * a.chunk * a.d_e / 4) {
+        float4 acc = *reinterpret_cast<const float4 *>(a.GA + 4 * u);
+        for (int q = 1; q < a.ga_parts; ++q) {
+            const float4 v = *reinterpret_cast<const float4 *>(a.GA + q * a.ga_stride + 4 * u);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        *reinterpret_cast<float4 *>(a.GA + 4 * u) = acc;
+    }
 }
 
-// RotatE: split the negatives while the launch stays within ~4 workgroups per CU and a workgroup keeps >= 2 groups of quads
+// split the negatives while the launch stays within ~4 workgroups per CU and a workgroup keeps >= 2 groups of quads
 int neg_bwd_lc_splits(int model, int C, int chunk, int N, int d_e) {
-    if (model != KGE_ROTATE || !neg_bwd_lc_supported(model, d_e) || N % 4) return 1;
+    // (TransE_l1: measured no gain - 58.6 vs 58.3 us/step with 2 x 455 workgroups at four per CU, its backward is not bound by
+    // the instruction issue of its wavefronts)
+    if (model != KGE_ROTATE || !neg_bwd_lc_supported(model, d_e) || N % 4 || d_e % 4) return 1;
     int nslab, nrw, rpw;
     lc_shape(model, C, chunk, d_e, nslab, nrw, rpw);
-    const int ngr = ((N + 3) / 4 + LC_GQ_CPLX - 1) / LC_GQ_CPLX;
+    const int gq = model == KGE_ROTATE ? LC_GQ_CPLX : LC_GQ_REAL;
+    const int ngr = ((N + 3) / 4 + gq - 1) / gq;
     int nsp = 1;
     while (nsp < 8 && (int64_t)C * nslab * nrw * (nsp + 1) <= LC_WG_CAP && ngr / (nsp + 1) >= 2) ++nsp;
     return nsp;
@@ -791,7 +837,7 @@ int neg_bwd_lc_nrw(int model, int C, int chunk, int d_e) {
 template <int MODEL> static int lc_launch(const NegArgs &a, hipStream_t s) {
     int nslab, nrw, rpw;
     lc_shape(MODEL, a.C, a.chunk, a.d_e, nslab, nrw, rpw);
-    if (a.ga_parts > 1 && MODEL != KGE_ROTATE) return KGE_ERR_ARG;
+    if (a.ga_parts > 1 && a.d_e % 4) return KGE_ERR_ARG;
     const int64_t nb = (int64_t)a.C * nslab * nrw * max(a.ga_parts, 1);
     if (nb == 0) return KGE_OK;
     const dim3 g((unsigned)nb), b(KGE_BLOCK);
@@ -802,7 +848,7 @@ template <int MODEL> static int lc_launch(const NegArgs &a, hipStream_t s) {
     else if constexpr (MODEL != KGE_ROTATE) hipLaunchKernelGGL((neg_bwd_lc_kernel<MODEL, LC_RTMAX>), g, b, 0, s, a, nslab, nrw, rpw);
     if (int rc = check_launch_b()) return rc;
     if (a.defer_reduce) return KGE_OK;           // the caller sums the partials in its next launch (launch_edge_bwd_with_gn_reduce)
-    const int64_t n4 = (int64_t)a.C * a.N * a.d_e / 4;
+    const int64_t n4 = (int64_t)a.C * a.N * a.d_e / 4 + (a.ga_parts > 1 ? (int64_t)a.C * a.chunk * a.d_e / 4 : 0);
     hipLaunchKernelGGL(gn_reduce_kernel, dim3((unsigned)((n4 + KGE_BLOCK - 1) / KGE_BLOCK)), dim3(KGE_BLOCK), 0, s, a, nrw);
     return check_launch_b();
 }

@@ -47,7 +47,7 @@ def main():
                      w["adv"], w["adv_temp"], w["reg_coef"], w["reg_norm"], flags=args.flags)
     lib = _lib.lib()
     bufs = {}
-    for tu in ("rowwise", "gemm"):
+    for tu in ("rowwise", "gemm", "bcast"):
         fn = getattr(lib, "kge_tl_set_" + tu, None)
         if fn is None:
             raise SystemExit("library has no timeline hooks: build with -DKGE_TIMELINE and set KGE_LIB")
