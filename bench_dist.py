@@ -98,6 +98,10 @@ def _p2p_setup(args, world, rank, dev, w, n_ent, d_e, d_r, emb_init):
                 group()
         if count % G:
             if gr is not None:
+                if count % G not in rem_graphs:         # (a size nobody announced: captured on first use)
+                    rem_graphs[count % G] = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(rem_graphs[count % G]):
+                        partial(count % G)
                 rem_graphs[count % G].replay()
             else:
                 partial(count % G)
@@ -114,7 +118,7 @@ def _p2p_setup(args, world, rank, dev, w, n_ent, d_e, d_r, emb_init):
     return eng, run, rows, desc, tabs
 
 
-def _a2a_setup(args, world, rank, dev, w, n_ent, d_e, emb_init):
+def _a2a_setup(args, world, rank, dev, w, n_ent, d_e, emb_init, allow_force_coll=True):
     """parameter-server semantics over RCCL all-to-all (dglke_amd/dist.py): entity table range-sharded, relation table
     replicated, device-side routing, fixed-size messages, on-device sampler inside the timed region."""
     from dglke_amd import dist as kd
@@ -128,8 +132,11 @@ def _a2a_setup(args, world, rank, dev, w, n_ent, d_e, emb_init):
     eng = StepEngine(w["model"], 1, w["n_rel"], w["hidden"], w["gamma"], w["lr"], dev, w["de"], w["dr"],
                      w["adv"], w["adv_temp"], w["reg_coef"], w["reg_norm"])
     # KGE_DIST_FORCE_COLL=1: keep the RCCL calls and the pull pipeline at world 1 too (smoke test of the N > 1 code path on one GPU)
-    force_coll = os.environ.get("KGE_DIST_FORCE_COLL", "0") == "1"
-    de = kd.DistEngine(eng, spec, ent, ent_state, slack=float(os.environ.get("KGE_DIST_SLACK", "1.5")), always_collective=force_coll)
+    force_coll = allow_force_coll and os.environ.get("KGE_DIST_FORCE_COLL", "0") == "1"
+    # collectives: librccl called directly on the step's streams (dist.RcclComm; KGE_DIST_COMM=torch: the c10d wrappers)
+    comm = kd.make_comm() if (world > 1 or force_coll) else None
+    de = kd.DistEngine(eng, spec, ent, ent_state, comm=comm, slack=float(os.environ.get("KGE_DIST_SLACK", "1.5")),
+                       always_collective=force_coll)
     # this rank's edge shard: synthetic uniform triples over the GLOBAL id space, generated in HBM
     n_train = int(os.environ.get("KGE_DIST_TRIPLES", min(338586276 // world, 48_000_000)))
     g = torch.Generator(device=dev)
@@ -205,8 +212,9 @@ def _a2a_setup(args, world, rank, dev, w, n_ent, d_e, emb_init):
     desc = ("entity table range-sharded, relation table replicated; per step: device-side routing into %d-row owner buckets, "
             "all-to-all pull of the unique rows, the single-GPU kernels against the row cache, all-to-all push of one packed "
             "gradient message per row, owner-side Adagrad in rank order (one merged launch), relation gradients all-gathered "
-            "(parameter-server semantics, RCCL); %s; sampling + plan on the device inside the timed region"
-            % (de.cap, "hipGraph of [1 sampler launch + %d steps]" % G if use_graph else
+            "(parameter-server semantics, RCCL%s); %s; sampling + plan on the device inside the timed region"
+            % (de.cap, (": librccl called directly, push + relation exchange grouped" if type(de.comm).__name__ == "RcclComm" else
+                        ": torch.distributed wrappers") if de.coll else "", "hipGraph of [1 sampler launch + %d steps]" % G if use_graph else
                ("eager launches, pull of step s+1 overlapped with step s (one-step-stale rows, --async_update licence)"
                 if pipelined else "eager launches")))
     return eng, run, rows, desc, de
@@ -270,7 +278,8 @@ def main(args, world, rank, local_rank):
     overflow = _de.check_overflow() if mode != "p2p" else 0
     eager = None
     other = "p2p" if mode == "a2a" else "a2a"
-    want_other = world > 1 and os.environ.get("KGE_DIST_OTHER_LEG", "1") != "0"
+    # (KGE_DIST_OTHER_LEG=force: run the secondary legs at N = 1 too - a smoke test of this code path on one GPU)
+    want_other = (world > 1 and os.environ.get("KGE_DIST_OTHER_LEG", "1") != "0") or os.environ.get("KGE_DIST_OTHER_LEG") == "force"
     import threading
     lock = threading.Lock()
     state = {"emitted": False}
@@ -285,12 +294,15 @@ def main(args, world, rank, local_rank):
         res = _result_line(args, w, n_ent, world, wall, K, rows, d_e, eng.d_r, desc, mode, why, sums, other, leg, overflow)
         if eager is not None:
             res["a2a_eager"] = eager
+        if local_leg is not None:
+            res["per_gpu_step_without_exchange"] = local_leg
         line = json.dumps(res)
         if now:
             print(line, flush=True)
         return line
 
     leg = None
+    local_leg = None
     # a2a with collectives (N > 1): the SAME K steps once more with the collectives recorded into hipGraphs - no host work between
     # the kernels of a step.  Under a watchdog: if the replay hangs, the eager measurement above is the line.  When it completes
     # it is the headline (same step, same K, same tables continuing) and the eager run is reported beside it.
@@ -321,7 +333,7 @@ def main(args, world, rank, local_rank):
                 eager = {"value": round(K * w["B"] * world / wall, 1), "unit": "edges/s", "us_per_step": round(1e6 * wall / K, 2),
                          "launch": "eager launches, pull of step s+1 overlapped with step s"}
                 wall, sums = float(tg.item()), sums_g
-                desc = desc.split("(parameter-server semantics, RCCL);")[0] + (
+                desc = desc.split("(parameter-server semantics, RCCL")[0] + (
                     "(parameter-server semantics, RCCL); kernels AND collectives of <= %d steps replay from one hipGraph "
                     "(synchronous schedule, host synchronises per replay); sampling + plan on the device inside the timed region" % Gd)
                 overflow += _de.check_overflow()
@@ -358,6 +370,27 @@ def main(args, world, rank, local_rank):
                 tabs = ltabs
         except Exception as e:          # noqa: BLE001
             leg = {"error": repr(e)}
+        # the SAME per-GPU workload without its exchanges: every rank steps through a one-rank engine over a shard-sized table
+        # (the N = 1 point of this curve, `python bench.py --gpus 1 --workload ...`, measured inside this job: bench.py's own
+        # N = 1 default is configs[1], a different workload)
+        try:
+            if os.environ.get("KGE_DIST_LOCAL_LEG", "1") != "0":
+                seng, srun, _, _, _ = _a2a_setup(args, 1, 0, dev, w, (n_ent + world - 1) // world, d_e, emb_init, allow_force_coll=False)
+                s_steps = max(20, min(K, 240))
+                srun(min(20, s_steps))
+                torch.cuda.synchronize(); dist.barrier()
+                t0 = time.perf_counter()
+                srun(s_steps)
+                torch.cuda.synchronize()
+                sw = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+                dist.all_reduce(sw, op=dist.ReduceOp.MAX)
+                local_leg = {"us_per_step": round(1e6 * float(sw.item()) / s_steps, 2), "steps": s_steps,
+                             "edges_per_s_per_gpu": round(s_steps * w["B"] / float(sw.item()), 1),
+                             "what": "the same per-GPU step on a one-rank engine over a shard-sized table (no exchange), "
+                                     "hipGraph of [1 sampler launch + G steps], max over ranks"}
+                del seng, srun
+        except Exception as e:          # noqa: BLE001
+            local_leg = {"error": repr(e)}
         done.set()
     line = emit(leg, now=False)
     try:

@@ -470,7 +470,8 @@ def test_sharded_engine_world1_equals_fused_step():
     try:
         n_ent, n_rel, hidden, B, N = 5000, 40, 64, 128, 32
         rng = np.random.RandomState(11)
-        for model, de_, dr_ in (("TransE_l2", False, False), ("RotatE", True, False)):
+        for model, de_, dr_, direct in (("TransE_l2", False, False, False), ("RotatE", True, False, False),
+                                        ("RotatE", True, False, True), ("TransE_l2", False, False, True)):
             a = StepEngine(model, n_ent, n_rel, hidden, 12.0, 0.1, DEV, de_, dr_, True, 1.0, 1e-6, 3)
             b = StepEngine(model, 1, n_rel, hidden, 12.0, 0.1, DEV, de_, dr_, True, 1.0, 1e-6, 3)
             b.rel.copy_(a.rel)
@@ -478,8 +479,12 @@ def test_sharded_engine_world1_equals_fused_step():
             state = torch.zeros(n_ent, device=DEV)
             # RotatE: through the RCCL calls too (equal-split all_to_all_single / all_gather_into_tensor with one rank) and the
             # one-step pull pipeline's streams and events - with a single batch in flight the pipeline is the synchronous step
-            coll = model == "RotatE"
-            deng = kd.DistEngine(b, kd.ShardSpec(n_ent, 1, 0), ent, state, always_collective=coll)
+            # direct: the collectives through dist.RcclComm (librccl by ctypes on the step's streams, its own one-rank communicator,
+            # the push exchanges as one grouped launch) instead of the c10d wrappers
+            coll = model == "RotatE" or direct
+            comm = kd.RcclComm() if direct else None
+            assert comm is None or (comm.world, comm.rank) == (1, 0)
+            deng = kd.DistEngine(b, kd.ShardSpec(n_ent, 1, 0), ent, state, always_collective=coll, comm=comm)
             for step in range(1, 4):
                 bt = O.synth_batch(rng, n_ent, n_rel, B, N, N, step)
                 a.step(plan.make_batch(bt["h"], bt["t"], bt["r"], bt["neg"], N, N, bt["neg_head"], DEV))
@@ -501,6 +506,8 @@ def test_sharded_engine_world1_equals_fused_step():
             _close(b.rel_state.cpu(), a.rel_state.cpu(), 1e-5, 1e-8, model + " relation state")
             la, lb_ = a.read_loss_sums(), b.read_loss_sums()
             _close(lb_, la, 1e-5, 1e-6, model + " loss sums")
+            if comm is not None:
+                comm.close()
     finally:
         dist.destroy_process_group()
 
