@@ -428,7 +428,7 @@ def main():
         run_t = lambda: run_groups(len(seq_w), len(seq))
         launch_desc = (("hipGraph of %d steps; sampler launch for the next group: %s" % (G, {
             "streams": "concurrently on a second stream", "fork": "on a forked branch of the graph",
-            "serial": "serially in front of the group"}[args.sampler_mode])) if use_graph else "eager, sampler mode " + args.sampler_mode)
+            "serial": "serially behind the group's steps"}[args.sampler_mode])) if use_graph else "eager, sampler mode " + args.sampler_mode)
         data_desc = ("triples in HBM; batch ids, negatives and plan built ON THE DEVICE inside the timed region "
                      "(double-buffered: group g+1 is sampled while group g trains)")
     else:

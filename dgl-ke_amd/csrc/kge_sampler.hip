@@ -20,6 +20,7 @@
 // Many batches are built concurrently (grid = number of slots), ahead of the training steps, so the
 // sampler is off the critical path exactly like the reference's prefetching sampler threads.
 #include <cstring>
+#include <rocprim/block/block_radix_sort.hpp>
 #include "kge_common.hpp"
 KGE_TL_DEFINE(sampler)
 
@@ -328,6 +329,7 @@ __global__ __launch_bounds__(SP_THREADS) void sample_plan_kernel(SamplerArgs a) 
         neg_ids[j] = id;
         ek[2 * B + j] = ((K)id << SP_CODE_BITS) | (K)(2 * B + j);
     }
+#ifdef SP_BITONIC
     int n2 = 1;
     while (n2 < NE) n2 <<= 1;
     for (int i = NE + t; i < n2; i += SP_THREADS) ek[i] = ~(K)0;
@@ -337,6 +339,29 @@ __global__ __launch_bounds__(SP_THREADS) void sample_plan_kernel(SamplerArgs a) 
 #endif
     // ---- 2. sort by (entity, code) ----
     bitonic_sort<K>(ek, n2);
+#else
+    for (int i = NE + t; i < SP_MAXE; i += SP_THREADS) ek[i] = ~(K)0;
+    __syncthreads();
+#ifdef KGE_TL_MARKS
+    KGE_TL_MARK(0);              // ids sampled, keys in LDS
+#endif
+    // ---- 2. sort by (entity, code): the codes ARE the positions, so a STABLE sort by the id bits alone gives that order -
+    // a block radix sort (rocPRIM: 8 bits per pass, ranks by wavefront matching) over the bits of n_ent - 1: 2 passes for
+    // FB15k's 14 951 entities, 4 for Freebase's 86 M, instead of the 78 compare-exchange stages of the bitonic network
+    {
+        typedef rocprim::block_radix_sort<K, SP_THREADS, SP_MAXE / SP_THREADS> BlockSort;
+        __shared__ typename BlockSort::storage_type sort_tmp;
+        K item[SP_MAXE / SP_THREADS];
+#pragma unroll
+        for (int e = 0; e < SP_MAXE / SP_THREADS; ++e) item[e] = ek[(SP_MAXE / SP_THREADS) * t + e];
+        unsigned idbits = 1;
+        while (idbits < 8 * sizeof(K) - SP_CODE_BITS && ((uint64_t)(a.n_ent - 1) >> idbits)) ++idbits;
+        BlockSort().sort(item, sort_tmp, SP_CODE_BITS, SP_CODE_BITS + idbits);
+#pragma unroll
+        for (int e = 0; e < SP_MAXE / SP_THREADS; ++e) ek[(SP_MAXE / SP_THREADS) * t + e] = item[e];
+        __syncthreads();
+    }
+#endif
 #ifdef KGE_TL_MARKS
     KGE_TL_MARK(1);              // sorted
 #endif

@@ -217,7 +217,7 @@ class PrefetchedGroups(object):
     """Groups of training steps over a double-buffered slot array: while group g trains, the batches of group g+1 are built
     into the other half (the prefetching of the reference's sampler workers, dataloader/sampler.py:823-876:
     `NewBidirectionalOneShotIterator` over `num_workers` sampler threads).  Where the sampler launch of group g+1 runs:
-      'serial'  - in front of group g's steps, on the same stream (one launch per group; the steps replay from a hipGraph);
+      'serial'  - behind group g's steps, on the same stream (one launch per group; the steps replay from a hipGraph);
       'streams' - on a second stream next to the steps, joined by an event at the end of the group;
       'fork'    - on a second branch inside the group's hipGraph.
     Measured on MI355X / ROCm 7.0 (profiles/r03_merged_fwd.txt): the two concurrent modes hide the ~45 us launch but make every
@@ -287,8 +287,6 @@ class PrefetchedGroups(object):
             self.side.wait_stream(cur)          # the half it overwrites was read by the group before this one
             with th.cuda.stream(self.side):
                 nxt = self._sample_next(n_next)
-        elif n_next:                            # 'serial': the sampler launch in front of the group, same stream
-            nxt = self._sample_next(n_next)
         if not graph:
             for b in self.ready:
                 self.step_fn(b)
@@ -301,6 +299,10 @@ class PrefetchedGroups(object):
                         self.step_fn(b)
                 self.graphs[key] = g
             self.graphs[key].replay()
+        if n_next and self.mode == "serial":
+            # 'serial': the sampler launch BEHIND the group's steps on the same stream (it fills the other half of the slots): the
+            # GPU starts on the steps at once and the host builds the next group's batch descriptors while they run
+            nxt = self._sample_next(n_next)
         if n_next and self.mode == "streams":
             cur.wait_stream(self.side)          # join: the next group's batches are complete
         self.ready = nxt

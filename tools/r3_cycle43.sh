@@ -1,0 +1,9 @@
+#!/bin/bash
+R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$(pwd); O=$R/gpurun_out; mkdir -p $O; cd $R
+B="--no-cpu-baseline --hogwild 0 --no-async-update"
+for M in "" "--host-plan" "--no-graph"; do
+echo "=== bench.py --steps 20 --warmup 5 $M"
+cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_w && timeout 200 rocprofv3 --kernel-trace -d /tmp/prof_w -- python $R/bench.py $B --steps 20 --warmup 5 $M > /tmp/prof_w.log 2>&1
+python $R/tools/wake_gaps.py $(ls /tmp/prof_w/*/*_results.db | head -1) | tail -40
+cd $R
+done 2>&1 | tee $O/c43_wake_gaps.txt
