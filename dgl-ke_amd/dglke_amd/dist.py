@@ -152,6 +152,28 @@ class RcclComm(object):
             self._comm = C.c_void_p()
 
 
+class HostStagedComm(object):
+    """the same collectives carried by a host-side (gloo) process group through host copies.  Only for ranks that SHARE a
+    device (`--gpu 0 0`: how the multi-process path is exercised on a one-GPU box - RCCL refuses two ranks on one GPU); the
+    step synchronises the stream around every exchange."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+
+    def all_to_all(self, out, inp):
+        torch.cuda.current_stream().synchronize()
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(o, inp.cpu().contiguous(), group=self.group)
+        out.copy_(o)
+
+    def all_gather(self, out, inp):
+        torch.cuda.current_stream().synchronize()
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(o, inp.cpu().contiguous(), group=self.group)
+        out.copy_(o)
+
+
 def make_comm(group=None, kind=None):
     """communicator of the sharded step: librccl called directly (default; KGE_DIST_COMM=torch or any failure to set it up on
     ANY rank: the c10d wrappers).  Every rank of the group must call it."""
@@ -168,7 +190,7 @@ def make_comm(group=None, kind=None):
     else:
         ok = 0
     if world > 1 and kind == "rccl" and torch.cuda.is_available():
-        flag = torch.tensor([ok], device="cuda")
+        flag = torch.tensor([ok], device="cpu" if dist.get_backend(group) == "gloo" else "cuda")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
         if int(flag.item()) == 0 and comm is not None:
             comm.close()

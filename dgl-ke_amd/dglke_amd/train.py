@@ -80,6 +80,10 @@ class ArgParser(argparse.ArgumentParser):
         a('--async_update_rel', action='store_true',
           help='with --async_update: defer the relation-table update by one step as well (the reference defers the entity '
                'table only); the next step\'s gather then shares a launch with this step\'s backward (fastest mode)')
+        a('--dist_mode', default='a2a', choices=['a2a', 'p2p'],
+          help='multi-GPU training (--gpu g0 g1 ...): a2a = entity table range-sharded, relation table replicated, RCCL '
+               'all-to-all pull / push with owner-side Adagrad (parameter-server semantics); p2p = both tables sharded and '
+               'mapped peer to peer (hipIpc), Hogwild across the trainers, no collective')
         a('--seed', type=int, default=0, help='seed of the table initialisation and of the device sampler')
         a('--graph_steps', type=int, default=100, help='steps per captured hipGraph (0: eager launches)')
         a('--target_mrr', type=float, default=None,
@@ -434,6 +438,15 @@ class ShardedTrainer(object):
         part = np.array_split(np.random.RandomState(args.seed).permutation(len(tr[0])), world)[rank]
         self.lane = _Lane(self, rank, self.engine, tuple(np.asarray(x)[part] for x in tr[:3]), None)
 
+    def _enqueue(self, n):
+        self.lane.enqueue(n)
+
+    def sync_tables(self):
+        """collective point in front of rank 0's validation / test / save (the peer-mapped tables need nothing)."""
+
+    def close(self):
+        self.tabs.close()
+
     def full_tables(self):
         """the whole entity / relation tables read through the shard map (rank-local copies)."""
         ds = self.dataset
@@ -482,7 +495,7 @@ class ShardedTrainer(object):
         for nxt in sorted(marks):
             n = nxt - step
             if n > 0:
-                self.lane.enqueue(n)
+                self._enqueue(n)
                 th.cuda.synchronize()
                 step, since_log = nxt, since_log + n
             if args.log_interval > 0 and step % args.log_interval == 0 and since_log:
@@ -494,6 +507,7 @@ class ShardedTrainer(object):
                 since_log, start = 0, time.time()
             if args.valid and step % args.eval_interval == 0 and step > 1 and self.dataset.valid is not None:
                 dist.barrier()                   # like the reference: all trainers stop for the validation
+                self.sync_tables()
                 if rank == 0:
                     valid_start = time.time()
                     self.evaluate('valid', 'Valid')
@@ -503,6 +517,89 @@ class ShardedTrainer(object):
         th.cuda.synchronize()
         print('proc {} takes {:.3f} seconds'.format(rank, time.time() - train_start))
         dist.barrier()
+
+
+class A2ATrainer(ShardedTrainer):
+    """`--gpu g0 g1 ... --dist_mode a2a`: the partitioning BASELINE.json's north_star names - the entity table range-sharded
+    over the GPUs, the relation table REPLICATED (every relation row local to every trainer: what the reference's relation
+    partitioning is after, general_models.py:590-637), parameter-server semantics as collectives (dglke_amd/dist.py
+    DistEngine: pull -> compute -> push, the owner applies the sparse Adagrad in rank order; reference:
+    general_models.py:650-680, kvserver.py:41-51).  Collectives: librccl called directly when every rank has its own GPU;
+    ranks that share a GPU (`--gpu 0 0`) exchange through the gloo group (dist.HostStagedComm).  Rank 0 gathers the shards
+    for validation / test / saving."""
+
+    def __init__(self, args, dataset, rank, world):
+        from . import dist as kd
+        from .dataloader import DeviceSampler
+        from .engine import StepEngine
+        self.args, self.dataset, self.rank, self.world = args, dataset, rank, world
+        th.cuda.set_device(args.gpu[rank])
+        self.dev = th.device("cuda", args.gpu[rank])
+        B, N = args.batch_size, args.neg_sample_size
+        self.chunk = N if N <= B else B
+        self.fused, self.n_lanes, self.async_ok = True, 1, False
+        self.device_sampler = 2 * B + (B // self.chunk) * N <= 4096
+        if args.has_edge_importance or not self.device_sampler:
+            raise KgeError("multi-GPU training uses the on-device sampler: no --has_edge_importance, "
+                           "and 2*batch + chunks*neg <= 4096")
+        if args.model_name in ('RESCAL', 'TransR') or args.neg_deg_sample:
+            raise KgeError("--dist_mode a2a covers TransE_l1/l2, DistMult, ComplEx, RotatE, SimplE without --neg_deg_sample "
+                           "(use --dist_mode p2p)")
+        d_e = args.hidden_dim * (2 if args.double_ent else 1)
+        self.emb_init = (args.gamma + 2.0) / args.hidden_dim
+        self.spec = kd.ShardSpec(dataset.n_entities, world, rank)
+        th.manual_seed(args.seed + 7919 * (rank + 1))
+        self.ent = th.empty(self.spec.n_local, d_e, dtype=th.float32, device=self.dev).uniform_(-self.emb_init, self.emb_init)
+        self.ent_state = th.zeros(self.spec.n_local, dtype=th.float32, device=self.dev)
+        th.manual_seed(args.seed)                       # identical relation replicas on every rank
+        self.engine = StepEngine(args.model_name, 1, dataset.n_relations, args.hidden_dim, args.gamma, args.lr, self.dev,
+                                 args.double_ent, args.double_rel, args.neg_adversarial_sampling,
+                                 args.adversarial_temperature, args.regularization_coef, args.regularization_norm,
+                                 args.loss_genre, args.pairwise, args.margin)
+        own_gpu = len(set(args.gpu)) == world
+        self.comm = kd.make_comm() if own_gpu else kd.HostStagedComm()
+        self.de = kd.DistEngine(self.engine, self.spec, self.ent, self.ent_state, comm=self.comm)
+        tr = dataset.train
+        part = np.array_split(np.random.RandomState(args.seed).permutation(len(tr[0])), world)[rank]
+        if len(part) < B:
+            raise KgeError("--batch_size %d is larger than a trainer's share of the training triples (%d over %d trainers)"
+                           % (B, len(tr[0]), world))
+        h, r, t = (np.asarray(x)[part] for x in tr[:3])
+        self.sampler = DeviceSampler(h, r, t, dataset.n_entities, B, N, self.dev, n_slots=max(2, args.graph_steps or 2),
+                                     neg_chunk_size=self.chunk, seed=args.seed + 1000 * rank)
+        self._full = None
+        if rank == 0:
+            print("multi-GPU mode a2a: entity rows %d per GPU, relations replicated, collectives: %s"
+                  % (self.spec.shard, type(self.comm).__name__))
+
+    def _enqueue(self, n):
+        """n sharded steps, eagerly (every rank issues the same collectives in the same order); inside a group of sampled
+        batches the pull of step s+1 overlaps step s."""
+        smp, done = self.sampler, 0
+        while done < n:
+            k = min(smp.n_slots, n - done)
+            dbs = smp.sample(k)
+            for i, b in enumerate(dbs):
+                self.de.step_pipelined(b, dbs[i + 1] if i + 1 < k else None)
+            done += k
+        lost = self.de.check_overflow()
+        if lost:
+            print('[proc {}] {} bucket entries did not fit their owner bucket (raise KGE_DIST_SLACK)'.format(self.rank, lost))
+
+    def sync_tables(self):
+        import torch.distributed as dist
+        th.cuda.synchronize()
+        parts = [None] * self.world if self.rank == 0 else None
+        dist.gather_object(self.ent.cpu(), parts, dst=0)
+        if self.rank == 0:
+            self._full = (th.cat(parts).to(self.dev), self.engine.rel)
+
+    def full_tables(self):
+        return self._full
+
+    def close(self):
+        if hasattr(self.comm, "close"):
+            self.comm.close()
 
 
 def _mp_worker(rank, args, port):
@@ -516,12 +613,13 @@ def _mp_worker(rank, args, port):
         dataset = get_dataset(args.data_path, args.dataset, args.format, args.delimiter, args.data_files,
                               args.has_edge_importance)
         sys.stdout = sys.__stdout__
-        trainer = ShardedTrainer(args, dataset, rank, world)
+        trainer = (A2ATrainer if args.dist_mode == 'a2a' else ShardedTrainer)(args, dataset, rank, world)
         if rank == 0:
             print('Total initialize time {:.3f} seconds'.format(time.time() - init_time_start))
         start = time.time()
         trainer.train()
         failure = None
+        trainer.sync_tables()
         if rank == 0:
             # whatever happens in rank 0's save / test section, every rank must still reach the barrier below
             # (a rank-0-only exception used to leave the others waiting for the gloo timeout)
@@ -543,7 +641,7 @@ def _mp_worker(rank, args, port):
             except Exception as e:      # noqa: BLE001 - re-raised after the barrier
                 failure = e
         dist.barrier()
-        trainer.tabs.close()
+        trainer.close()
         if failure is not None:
             raise failure
     finally:

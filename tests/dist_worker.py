@@ -17,24 +17,6 @@ N_ENT, N_REL, HID, B, N, LR, STEPS = 2003, 31, 64, 128, 32, 0.1, 4
 MODELS = (("TransE_l2", False, False), ("DistMult", False, False), ("RotatE", True, False))
 
 
-class GlooStagedComm(object):
-    """test double of dglke_amd.dist.TorchComm: same equal-split collectives, carried by gloo on host copies."""
-    def __init__(self):
-        self.world, self.rank = dist.get_world_size(), dist.get_rank()
-
-    def all_to_all(self, out, inp):
-        torch.cuda.current_stream().synchronize()
-        o = torch.empty(out.shape, dtype=out.dtype)
-        dist.all_to_all_single(o, inp.cpu().contiguous())
-        out.copy_(o)
-
-    def all_gather(self, out, inp):
-        torch.cuda.current_stream().synchronize()
-        o = torch.empty(out.shape, dtype=out.dtype)
-        dist.all_gather_into_tensor(o, inp.cpu().contiguous())
-        out.copy_(o)
-
-
 def batches(world, steps, mode, seed=5):
     """per step and rank one batch of GLOBAL ids.  mode 'disjoint': rank k draws entities / relations from its own slice, so the
     synchronous step equals processing the ranks' batches one after the other on ONE table."""
@@ -76,7 +58,7 @@ def main():
         spec = kd.ShardSpec(N_ENT, world, rank)
         ent = ent0[spec.lo:spec.hi].to(dev).contiguous()
         state = torch.zeros(spec.n_local, device=dev)
-        de = kd.DistEngine(eng, spec, ent, state, comm=GlooStagedComm(), cap=None, slack=1.6)
+        de = kd.DistEngine(eng, spec, ent, state, comm=kd.HostStagedComm(), cap=None, slack=1.6)
         bts = batches(world, STEPS, "disjoint" if mode == "disjoint" else "random")
         ue_bound = 2 * B + (B // N) * N
         devb = []

@@ -185,11 +185,14 @@ def test_train_cli_transr_lanes_and_rejected_flags(tmp_path, capsys):
         T.main(_base(tmp_path) + ["--max_step", "10", "--log_interval", "0"])
 
 
-@pytest.mark.parametrize("extra,nproc", [([], 2), (["--num_proc", "4"], 4)], ids=["one_per_gpu", "num_proc_4"])
+@pytest.mark.parametrize("extra,nproc", [(["--dist_mode", "p2p"], 2), (["--dist_mode", "p2p", "--num_proc", "4"], 4), ([], 2)],
+                         ids=["p2p_one_per_gpu", "p2p_num_proc_4", "a2a_default"])
 def test_train_cli_multi_process_shared_tables(tmp_path, extra, nproc):
-    """`--gpu 0 0`: two trainer processes (here on one GPU) on peer-to-peer shared tables - the multi-GPU mode
-    of the CLI; hipIpc mapping, sharded fused step, gather for evaluation and saving.  `--num_proc 4` on two listed
-    GPUs = two processes per GPU like the reference (train.py:94-100, 115-119)."""
+    """`--gpu 0 0`: two trainer processes (here on one GPU).  --dist_mode p2p: peer-to-peer shared tables - hipIpc mapping,
+    sharded fused step, gather for evaluation and saving; `--num_proc 4` on two listed GPUs = two processes per GPU like the
+    reference (train.py:94-100, 115-119).  Default (a2a): entity table range-sharded, relations replicated, pull / push
+    exchanges with owner-side Adagrad (dglke_amd/dist.py; the two ranks share the GPU, so the exchanges travel through the
+    gloo group here - RCCL needs one GPU per rank)."""
     import subprocess
     data = str(tmp_path / "kg")
     _planted(data)
