@@ -562,13 +562,24 @@ template <int L> __device__ __forceinline__ float rowb(float v) {    // lane L o
 // workgroups per (chunk, slab) and rows per wavefront: at least as many workgroups as keep every wavefront at
 // <= LC_RTMAX rows; more (down to 8 rows per wavefront) while the launch still fits TWO workgroups per CU (the
 // kernel is bound by the instruction issue of its wavefronts: measured 31 -> 24 us for TransE_l1 at cfg-T)
+// TransE_l1 (measured at cfg-T, us/step): its backward is bound by LDS traffic per pair (operands and GN partials through LDS
+// per quad) rather than by VALU issue - more rows per wavefront amortise it, split negatives restore the workgroup count:
+// 8 rows x 455 workgroups 58.3; 8 rows, 2 splits 58.6; 10-12 rows x 325 workgroups x 3 splits 55.9 (taken); 13-16 rows x 260 x 3
+// 59.6; 9 rows x 390 x 2 64.7; 10-12 rows unsplit 64.0
+#ifndef LC_RPW_MIN_REAL
+#define LC_RPW_MIN_REAL 10                       // TransE_l1: fewest rows a wavefront keeps when the launch can afford more workgroups
+#endif
+#ifndef LC_NO_SPLIT_REAL
+#define LC_SPLIT_REAL 1
+#endif
 static inline void lc_shape(int model, int C, int chunk, int d_e, int &nslab, int &nrw, int &rpw) {
     const int K = model == KGE_ROTATE ? d_e / 2 : d_e;
     nslab = (K + LC_CW - 1) / LC_CW;
     const int rtmax = model == KGE_ROTATE ? 16 : LC_RTMAX;
     nrw = 1;
     while ((chunk + 4 * nrw - 1) / (4 * nrw) > rtmax) ++nrw;
-    while ((int64_t)C * nslab * (nrw + 1) <= 512 && (chunk + 4 * (nrw + 1) - 1) / (4 * (nrw + 1)) >= 8) ++nrw;
+    const int rpw_min = model == KGE_ROTATE ? 8 : LC_RPW_MIN_REAL;
+    while ((int64_t)C * nslab * (nrw + 1) <= 512 && (chunk + 4 * (nrw + 1) - 1) / (4 * (nrw + 1)) >= rpw_min) ++nrw;
     rpw = (chunk + 4 * nrw - 1) / (4 * nrw);
 }
 bool neg_bwd_lc_supported(int model, int d_e) {
@@ -817,9 +828,10 @@ __global__ __launch_bounds__(KGE_BLOCK) void gn_reduce_kernel(NegArgs a, int nrw
 
 // split the negatives while the launch stays within ~4 workgroups per CU and a workgroup keeps >= 2 groups of quads
 int neg_bwd_lc_splits(int model, int C, int chunk, int N, int d_e) {
-    // (TransE_l1: measured no gain - 58.6 vs 58.3 us/step with 2 x 455 workgroups at four per CU, its backward is not bound by
-    // the instruction issue of its wavefronts)
-    if (model != KGE_ROTATE || !neg_bwd_lc_supported(model, d_e) || N % 4 || d_e % 4) return 1;
+#ifndef LC_SPLIT_REAL
+    if (model != KGE_ROTATE) return 1;
+#endif
+    if (!neg_bwd_lc_supported(model, d_e) || N % 4 || d_e % 4) return 1;
     int nslab, nrw, rpw;
     lc_shape(model, C, chunk, d_e, nslab, nrw, rpw);
     const int gq = model == KGE_ROTATE ? LC_GQ_CPLX : LC_GQ_REAL;
