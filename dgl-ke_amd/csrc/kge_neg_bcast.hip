@@ -569,6 +569,9 @@ template <int L> __device__ __forceinline__ float rowb(float v) {    // lane L o
 #ifndef LC_RPW_MIN_REAL
 #define LC_RPW_MIN_REAL 10                       // TransE_l1: fewest rows a wavefront keeps when the launch can afford more workgroups
 #endif
+#ifndef LC_RPW_MIN_CPLX
+#define LC_RPW_MIN_CPLX 8
+#endif
 #ifndef LC_NO_SPLIT_REAL
 #define LC_SPLIT_REAL 1
 #endif
@@ -578,7 +581,7 @@ static inline void lc_shape(int model, int C, int chunk, int d_e, int &nslab, in
     const int rtmax = model == KGE_ROTATE ? 16 : LC_RTMAX;
     nrw = 1;
     while ((chunk + 4 * nrw - 1) / (4 * nrw) > rtmax) ++nrw;
-    const int rpw_min = model == KGE_ROTATE ? 8 : LC_RPW_MIN_REAL;
+    const int rpw_min = model == KGE_ROTATE ? LC_RPW_MIN_CPLX : LC_RPW_MIN_REAL;
     while ((int64_t)C * nslab * (nrw + 1) <= 512 && (chunk + 4 * (nrw + 1) - 1) / (4 * (nrw + 1)) >= rpw_min) ++nrw;
     rpw = (chunk + 4 * nrw - 1) / (4 * nrw);
 }
