@@ -186,7 +186,8 @@ def make_comm(group=None, kind=None):
             comm = RcclComm(group)
         except Exception as e:           # noqa: BLE001 - anything: fall back together
             ok = 0
-            print("RcclComm unavailable (%r): using torch.distributed collectives" % (e,))
+            import sys
+            print("RcclComm unavailable (%r): using torch.distributed collectives" % (e,), file=sys.stderr)
     else:
         ok = 0
     if world > 1 and kind == "rccl" and torch.cuda.is_available():
