@@ -660,14 +660,21 @@ __device__ __forceinline__ void row_stats(const GemmArgs &a, int64_t gi, int tj,
 // DENSE (round 3): both operands are dense arrays (negative rows: the per-step copy Bn written by the edge-forward half of the
 // first launch) - row numbers are arithmetic, so there is no index table, no LDS and NO BARRIER: the first operand requests leave
 // with the wavefront's first instructions instead of after an id round + LDS round (never with FACT: its factor table lives in LDS)
-template <bool L2, bool FACT, bool ISGA, bool DENSE = false>   // FACT: the streamed weights are u_ij and get the per-(row, tile) factor here
+// KS (round 3): wavefronts per tile along the reduction.  KS = 2: a workgroup = 8 wavefronts = 4 tiles x 2 halves of the macro
+// steps (the second half also takes the tail step); two wavefronts per SIMD overlap each other's operand latency - with one
+// wavefront per tile the MFMA pipe of a SIMD was busy 35 % of the wavefront's life; the second half hands its accumulators over
+// through LDS (17 floats per lane) and the first half runs the epilogue.  Sums: first half + second half, a fixed order.
+template <bool L2, bool FACT, bool ISGA, bool DENSE = false, int KS = 1>   // FACT: the streamed weights are u_ij and get the per-(row, tile) factor here
 __device__ __forceinline__ void neg_bwd_gemm_tile(const GemmArgs &a, int ti, int tj, int td, int c, int bcl, int maxK,
                                                   float *smem) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = (threadIdx.x >> 6) & (KGE_WAVES_PER_BLOCK - 1);
+    const int kh = KS == 1 ? 0 : (int)(threadIdx.x >> 6) / KGE_WAVES_PER_BLOCK;     // which part of the reduction (wave-uniform)
     constexpr bool isGA = ISGA;
-    const int tl = bcl * KGE_WAVES_PER_BLOCK + wv;       // 4 consecutive tiles of the same (chunk, product) per workgroup
+    const int tl0 = bcl * KGE_WAVES_PER_BLOCK + wv;      // 4 consecutive tiles of the same (chunk, product) per workgroup
     const int tr = isGA ? ti : tj;                       // row tiles of this product
-    const bool tile_ok = tl < tr * td;
+    const bool tile_ok = tl0 < tr * td;
+    // (a wavefront without a tile repeats the last one and stores nothing: KS > 1 needs every wavefront at the hand-over barrier)
+    const int tl = KS == 1 ? tl0 : min(tl0, tr * td - 1);
     const int dt = tl % td, rt = tl / td;                // (row tile fastest - 4 wavefronts sharing a column slab - measured the same)
     const int D = a.D, N = a.N, chunk = a.chunk;
     const int m = lane & 15, q = lane >> 4;
@@ -720,11 +727,11 @@ __device__ __forceinline__ void neg_bwd_gemm_tile(const GemmArgs &a, int ti, int
     // (3) the index table
     if (!DENSE) {
         if (k0 < K) rix[k0] = rix0;
-        for (int k = k0 + KGE_BLOCK; k < K; k += KGE_BLOCK)                   // K > 256
+        for (int k = k0 + KS * KGE_BLOCK; k < K; k += KS * KGE_BLOCK)         // K > the workgroup's threads
             rix[k] = isGA ? (a.nidx ? a.nidx[(int64_t)c * N + k] : (int64_t)c * N + k) : (int64_t)c * chunk + k;
     }
     if (FACT && !isGA) {
-        for (int k = threadIdx.x; k < K; k += KGE_BLOCK) {
+        for (int k = threadIdx.x; k < K; k += KS * KGE_BLOCK) {
             float M, coef, lr;
             row_stats<false>(a, (int64_t)c * chunk + k, tj, M, coef, lr, ftab + k * GB_TJP);
         }
@@ -736,7 +743,7 @@ __device__ __forceinline__ void neg_bwd_gemm_tile(const GemmArgs &a, int ti, int
     if (FACT && isGA) {
         const int rowg = min(rt * 16 + m, chunk - 1);
         const int64_t gi = (int64_t)c * chunk + rowg;
-        const bool do_loss = dt == 0 && (a.row_neg || a.acc);
+        const bool do_loss = dt == 0 && kh == 0 && (a.row_neg || a.acc);
         float lrow = 0.f;
         if (do_loss) row_stats<true>(a, gi, tj, rM, rcoef, lrow);
         else row_stats<false>(a, gi, tj, rM, rcoef, lrow);
@@ -751,7 +758,7 @@ __device__ __forceinline__ void neg_bwd_gemm_tile(const GemmArgs &a, int ti, int
         }
     }
     if (!DENSE) __syncthreads();
-    if (!tile_ok) return;
+    if (KS == 1 && !tile_ok) return;
     const float *ft = ftab + rt;                         // GN: factor of reduction row k = ft[k * GB_TJP]
 
     const float *Wc = a.W + (int64_t)c * chunk * N;
@@ -773,10 +780,13 @@ __device__ __forceinline__ void neg_bwd_gemm_tile(const GemmArgs &a, int ti, int
     // addresses = kernel-argument base + LDS index (global loads, vmcnt only).  One predicated tail
     // step handles K % 16.
 #ifdef BWD_PROBE_NOLOOP            // tuning probe (wrong results): wavefront time without the main loop
-    const int msfull = 0;
+    const int msall = 0;
 #else
-    const int msfull = K >> 4;
+    const int msall = K >> 4;
 #endif
+    // this wavefront's full macro steps [mlo, msfull): all of them (KS = 1), or the first / second half
+    const int mlo = KS == 1 ? 0 : kh * (msall / KS);
+    const int msfull = (KS == 1 || kh == KS - 1) ? msall : (kh + 1) * (msall / KS);
     const float *Xb = (isGA ? a.nbase : a.A) + dc;                 // operand base (global address space)
     const float *Wq = Wrow + (int64_t)(q * 4) * wstride;
 
@@ -825,8 +835,8 @@ __device__ __forceinline__ void neg_bwd_gemm_tile(const GemmArgs &a, int ti, int
 #define BWD_MMA_G(ST, MS0) _Pragma("unroll") for (int u = 0; u < BU; ++u) { if ((MS0) + u < msfull) { BWD_MMA1(ST, u) } }
 #define BWD_PIPE(VECW)                                                                         \
     {                                                                                          \
-        BWD_LOAD(s0, 0, VECW);                                                                 \
-        int g = 0;                                                                             \
+        BWD_LOAD(s0, mlo, VECW);                                                               \
+        int g = mlo;                                                                           \
         for (; g + 2 * BU <= msfull; g += 2 * BU) {                                            \
             BWD_LOAD(s1, g + BU, VECW);                                                        \
             KGE_ORDER();                           /* requests first, then the MFMAs on the other buffer */ \
@@ -856,14 +866,14 @@ __device__ __forceinline__ void neg_bwd_gemm_tile(const GemmArgs &a, int ti, int
     float4 tx[4];
     float tpm = 0.f;
     {   // (requested unconditionally - indices clamped, zero weight beyond K - so that the waits after this point count exactly)
-        const int kk = msfull * 16 + q * 4;
+        const int kk = msall * 16 + q * 4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int kc = min(kk + e, K - 1);
             tw[e] = Wrow[(int64_t)kc * wstride];
             tx[e] = ldg4(Xb + (DENSE ? rbase + kc : rix[kc]) * D);
         }
-        if (FACT && isGA) tpm = PMrow[min(msfull, tj - 1)];
+        if (FACT && isGA) tpm = PMrow[min(msall, tj - 1)];
     }
     // GN: the own rows, now that their (gathered) numbers have arrived under the barrier
     if (!isGA && need_self) {
@@ -873,7 +883,7 @@ __device__ __forceinline__ void neg_bwd_gemm_tile(const GemmArgs &a, int ti, int
 #ifdef KGE_TL_MARKS
     KGE_TL_MARK_K(3, 0);           // prologue done: ids, own rows, first operands and the tail operands have arrived
 #endif
-    if (msfull > 0) {
+    if (msfull > mlo) {
         if (isGA && vecW) BWD_PIPE(true) else BWD_PIPE(false)
     }
 #ifdef KGE_TL_MARKS
@@ -885,8 +895,8 @@ __device__ __forceinline__ void neg_bwd_gemm_tile(const GemmArgs &a, int ti, int
 #undef BWD_MMA
 #undef BWD_MMA_G
 #undef BWD_PIPE
-    if (has_tail) {
-        const int kk = msfull * 16 + q * 4;
+    if (has_tail && kh == KS - 1) {
+        const int kk = msall * 16 + q * 4;
         float ftail = 1.f;
         if (FACT && isGA) ftail = a.lp.adv ? __expf(tpm - rM) * rcoef : rcoef;
 #pragma unroll
@@ -905,6 +915,30 @@ __device__ __forceinline__ void neg_bwd_gemm_tile(const GemmArgs &a, int ti, int
 #ifdef KGE_TL_MARKS
     KGE_TL_MARK_K(3, 2);           // tail macro step issued
 #endif
+    if constexpr (KS > 1) {
+        // hand-over: the later parts park accumulators + weight sum in LDS ([tile][value][lane]: conflict-free), the first adds
+        __shared__ float kred[(KS - 1) * KGE_WAVES_PER_BLOCK * 17 * 64];
+        float *rb = kred + ((max(kh, 1) - 1) * KGE_WAVES_PER_BLOCK + wv) * 17 * 64 + lane;
+        if (kh > 0) {
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rb[(s_ * 4 + r) * 64] = acc[s_][r];
+            rb[16 * 64] = wsum;
+        }
+        __syncthreads();
+        if (kh > 0) return;
+#pragma unroll
+        for (int p = 0; p < KS - 1; ++p) {
+            const float *pb = kred + (p * KGE_WAVES_PER_BLOCK + wv) * 17 * 64 + lane;
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[s_][r] += pb[(s_ * 4 + r) * 64];
+            wsum += pb[16 * 64];
+        }
+        if (!tile_ok) return;
+    }
     // lanes with equal (lane&15) hold partial sums of the same W row/column: combine the 4 groups
     wsum += __shfl_xor(wsum, 16, 64);
     wsum += __shfl_xor(wsum, 32, 64);
@@ -942,22 +976,28 @@ __device__ __forceinline__ void neg_bwd_gemm_tile(const GemmArgs &a, int ti, int
 
 // `bid` / `nblk`: this workgroup's index and the number of workgroups doing GEMM work (the body is also one half of the
 // horizontally fused launch below); workgroup -> (chunk, product, 4 consecutive tiles)
-template <bool L2, bool FACT, bool DENSE = false>
+template <bool L2, bool FACT, bool DENSE = false, int KS = 1>
 __device__ __forceinline__ void neg_bwd_gemm_body(const GemmArgs &a, int ti, int tj, int td, int bpA, int bpN, int maxK,
                                                   int bid, int nblk, float *smem) {
     const int blk = xcd_remap(bid, nblk);
     const int c = blk / (bpA + bpN);
     const int bc = blk % (bpA + bpN);
-    if (bc < bpA) neg_bwd_gemm_tile<L2, FACT, true, DENSE>(a, ti, tj, td, c, bc, maxK, smem);
-    else neg_bwd_gemm_tile<L2, FACT, false, DENSE>(a, ti, tj, td, c, bc - bpA, maxK, smem);
+    if (bc < bpA) neg_bwd_gemm_tile<L2, FACT, true, DENSE, KS>(a, ti, tj, td, c, bc, maxK, smem);
+    else neg_bwd_gemm_tile<L2, FACT, false, DENSE, KS>(a, ti, tj, td, c, bc - bpA, maxK, smem);
 }
 
+// measured (MI355X, us/step, GB_KS 1 -> 2): cfg-T 30.65 -> 31.49, DistMult 35.7 -> 35.7, ComplEx wikikg2 38.4 -> 38.4, SimplE 57.7 ->
+// 58.2 - the second wavefront per SIMD repeats the prologue (ids, own rows, first operands) and adds a barrier + LDS hand-over;
+// what bounds the launch is not the overlap inside the k-loop.  Kept as a compile-time option, off.
+#ifndef GB_KS
+#define GB_KS 1                       // wavefronts per backward tile along the reduction (stand-alone launch)
+#endif
 template <bool L2, bool FACT, bool DENSE = false>
-__global__ __launch_bounds__(KGE_BLOCK) void neg_bwd_gemm_kernel(GemmArgs a, int ti, int tj, int td,
-                                                                 int bpA, int bpN, int maxK) {
+__global__ __launch_bounds__(GB_KS * KGE_BLOCK) void neg_bwd_gemm_kernel(GemmArgs a, int ti, int tj, int td,
+                                                                         int bpA, int bpN, int maxK) {
     KGE_TL(3);
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    neg_bwd_gemm_body<L2, FACT, DENSE>(a, ti, tj, td, bpA, bpN, maxK, (int)blockIdx.x, (int)gridDim.x, smem);
+    neg_bwd_gemm_body<L2, FACT, DENSE, GB_KS>(a, ti, tj, td, bpA, bpN, maxK, (int)blockIdx.x, (int)gridDim.x, smem);
 }
 
 // --async_update pipeline, horizontal fusion.  The pipeline (kge_step_async) keeps the exact one-step staleness of the
@@ -997,7 +1037,7 @@ int launch_neg_bwd_gemm(const GemmArgs &a, hipStream_t s) {
     // row indices [mk] int64 (+ factorised: the factor table [mk][GB_TJP])
     const size_t sm = (size_t)mk * 8 + (fact ? (size_t)mk * GB_TJP * 4 : 0);
     const bool l2 = a.model == KGE_TRANSE_L2;
-    const dim3 g(nb), b(KGE_BLOCK);
+    const dim3 g(nb), b(GB_KS * KGE_BLOCK);
     if (!fact && !a.nidx) {                                      // dense operands: the instance without index table / LDS / barrier
         if (l2) hipLaunchKernelGGL((neg_bwd_gemm_kernel<true, false, true>), g, b, 0, s, a, ti, tj, td, bpA, bpN, mk);
         else hipLaunchKernelGGL((neg_bwd_gemm_kernel<false, false, true>), g, b, 0, s, a, ti, tj, td, bpA, bpN, mk);
