@@ -182,8 +182,22 @@ def ptr(t):
     return t.data_ptr()
 
 
+_STREAM_OVERRIDE = None
+
+
 def stream_ptr():
+    """the stream the library calls are enqueued on: torch's current stream, or the one set by use_stream()"""
+    if _STREAM_OVERRIDE is not None:
+        return _STREAM_OVERRIDE
     return torch.cuda.current_stream().cuda_stream
+
+
+def use_stream(ptr):
+    """make every following library call go to the HIP stream `ptr` (None: back to torch's current stream).  A cheap
+    stand-in for `with torch.cuda.stream(...)` around ctypes calls (dist.DistEngine's pull pipeline); returns the previous value."""
+    global _STREAM_OVERRIDE
+    prev, _STREAM_OVERRIDE = _STREAM_OVERRIDE, ptr
+    return prev
 
 
 def model_id(name):

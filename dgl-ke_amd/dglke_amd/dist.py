@@ -247,20 +247,27 @@ class HipOps(object):
     def step_grads(self, engine, lb, cache, ent_msg, rel_msg, zero_state):
         """run kge_step_grads against the row cache, emitting packed messages at the rows' cache positions:
         ent_msg[row] = [g0 | g1 | gs0 gs1 . .],  rel_msg[u] = [gr | gsr | id_lo id_hi .]"""
-        d_e, d_r = cache.shape[1], engine.rel.shape[1]
-        tb = _lib.KgeTables()
-        tb.ent, tb.ent_state = _lib.ptr(cache), _lib.ptr(zero_state)
-        tb.rel, tb.rel_state = _lib.ptr(engine.rel), _lib.ptr(engine.rel_state)
-        tb.n_ent, tb.n_rel = cache.shape[0], engine.rel.shape[0]
-        em = _lib.KgeEmit()
-        e0, r0 = ent_msg.data_ptr(), rel_msg.data_ptr()
-        em.g0, em.g1 = e0, e0 + 4 * d_e
-        em.gs0, em.gs1 = e0 + 8 * d_e, e0 + 8 * d_e + 4
-        em.gr, em.gsr, em.rid = r0, r0 + 4 * d_r, r0 + 4 * d_r + 4
-        em.ld_e, em.ld_r = ent_msg.shape[1], rel_msg.shape[1]
-        em.ent_by_id = 1
-        out = _lib.KgeStepOut()
-        out.loss_accum = _lib.ptr(engine.loss_accum)
+        key = (cache.data_ptr(), ent_msg.data_ptr(), rel_msg.data_ptr(), zero_state.data_ptr(), engine.rel.data_ptr())
+        st = self._structs.get(key) if hasattr(self, "_structs") else None
+        if st is None:                                   # the argument structs of a (cache, message buffers) pair: built once
+            d_e, d_r = cache.shape[1], engine.rel.shape[1]
+            tb = _lib.KgeTables()
+            tb.ent, tb.ent_state = _lib.ptr(cache), _lib.ptr(zero_state)
+            tb.rel, tb.rel_state = _lib.ptr(engine.rel), _lib.ptr(engine.rel_state)
+            tb.n_ent, tb.n_rel = cache.shape[0], engine.rel.shape[0]
+            em = _lib.KgeEmit()
+            e0, r0 = ent_msg.data_ptr(), rel_msg.data_ptr()
+            em.g0, em.g1 = e0, e0 + 4 * d_e
+            em.gs0, em.gs1 = e0 + 8 * d_e, e0 + 8 * d_e + 4
+            em.gr, em.gsr, em.rid = r0, r0 + 4 * d_r, r0 + 4 * d_r + 4
+            em.ld_e, em.ld_r = ent_msg.shape[1], rel_msg.shape[1]
+            em.ent_by_id = 1
+            out = _lib.KgeStepOut()
+            out.loss_accum = _lib.ptr(engine.loss_accum)
+            if not hasattr(self, "_structs"):
+                self._structs = {}
+            st = self._structs[key] = (tb, em, out)
+        tb, em, out = st
         ws = engine.workspace_for(lb)
         _lib.check(_lib.lib().kge_step_grads(C.byref(engine.hp), C.byref(tb), C.byref(lb.c),
                                              C.byref(out), C.byref(em), _lib.ptr(ws),
@@ -380,6 +387,20 @@ class DistEngine(object):
         self._compute(lb)
         self._push_apply(lb)
 
+    def _pull_ahead(self, next_batch, nslot, ev):
+        """the pull of the NEXT step (route, id exchange, owner gather, row exchange) on the side stream"""
+        sp, s, W = self.spec, self.slots[nslot], self.spec.world      # (the buffers exist: the first step's own pull made them)
+        nlb = self.ops.route(next_batch, W, sp.shard, self.cap, s)
+        nlb.slot = nslot
+        if self.coll:
+            self.comm.all_to_all(s.recv_ids, s.req_ids)
+        self.ops.gather_req(self.ent, s.recv_ids, sp.lo, s.rows_out)
+        ev["gather"].record(self._side)
+        if self.coll:
+            self.comm.all_to_all(s.cache[:W * self.cap], s.rows_out)
+        ev["rows"].record(self._side)
+        return nlb
+
     def step_pipelined(self, batch, next_batch=None):
         """one step with the pull of `next_batch` (the batch of the following call) overlapped: its rows are gathered on a
         side stream after update s-1 and before update s lands (exact one-step staleness: the reference's --async_update
@@ -387,6 +408,11 @@ class DistEngine(object):
         main = torch.cuda.current_stream(self.dev)
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.dev)
+            # events are reused (one set per slot): creating them per step costs more host time than the calls they order
+            self._ev = [dict(main=torch.cuda.Event(), gather=torch.cuda.Event(), rows=torch.cuda.Event()) for _ in range(2)]
+            # communicators that take the stream from _lib.stream_ptr() (RcclComm, like every library call) need no
+            # `with torch.cuda.stream(...)` around the side-stream section
+            self._explicit = isinstance(self.comm, RcclComm) and isinstance(self.ops, HipOps)
         if self._pre is not None and self._pre[0] is batch:
             _, lb, ev_rows = self._pre
             main.wait_event(ev_rows)
@@ -395,24 +421,21 @@ class DistEngine(object):
         self._pre = None
         ev_gather = None
         if next_batch is not None:
-            self._side.wait_stream(main)              # behind everything enqueued so far: the apply of step s-1
-            with torch.cuda.stream(self._side):
-                nslot = lb.slot ^ 1
-                if self.slots is None:
-                    self._setup(next_batch)
-                sp, s, W = self.spec, self.slots[nslot], self.spec.world
-                nlb = self.ops.route(next_batch, W, sp.shard, self.cap, s)
-                nlb.slot = nslot
-                if self.coll:
-                    self.comm.all_to_all(s.recv_ids, s.req_ids)
-                self.ops.gather_req(self.ent, s.recv_ids, sp.lo, s.rows_out)
-                ev_gather = torch.cuda.Event()
-                ev_gather.record(self._side)
-                if self.coll:
-                    self.comm.all_to_all(s.cache[:W * self.cap], s.rows_out)
-                ev_rows = torch.cuda.Event()
-                ev_rows.record(self._side)
-            self._pre = (next_batch, nlb, ev_rows)
+            nslot = lb.slot ^ 1
+            ev = self._ev[nslot]
+            ev["main"].record(main)
+            self._side.wait_event(ev["main"])         # behind everything enqueued so far: the apply of step s-1
+            if self._explicit:
+                prev = _lib.use_stream(self._side.cuda_stream)
+                try:
+                    nlb = self._pull_ahead(next_batch, nslot, ev)
+                finally:
+                    _lib.use_stream(prev)
+            else:
+                with torch.cuda.stream(self._side):
+                    nlb = self._pull_ahead(next_batch, nslot, ev)
+            ev_gather = ev["gather"]
+            self._pre = (next_batch, nlb, ev["rows"])
         self._compute(lb)
         # the apply of step s must not start before the gather of step s+1 has read the shard (else the staleness is a race)
         self._push_apply(lb, (lambda: main.wait_event(ev_gather)) if ev_gather is not None else None)

@@ -508,6 +508,35 @@ def test_sharded_engine_world1_equals_fused_step():
             _close(lb_, la, 1e-5, 1e-6, model + " loss sums")
             if comm is not None:
                 comm.close()
+        # the pull pipeline (pull of step s+1 on the side stream while step s computes): through the c10d wrappers (side-stream
+        # section under `with torch.cuda.stream`) and through RcclComm (stream handed to the calls, events reused) - same
+        # one-step-stale schedule, same bits
+        res = []
+        for direct in (False, True):
+            rng = np.random.RandomState(23)
+            b = StepEngine("DistMult", 1, n_rel, hidden, 12.0, 0.1, DEV, False, False, True, 1.0, 1e-6, 3)
+            torch.manual_seed(5)
+            b.rel.uniform_(-0.2, 0.2)
+            ent = torch.empty(n_ent, hidden, device=DEV).uniform_(-0.2, 0.2)
+            state = torch.zeros(n_ent, device=DEV)
+            comm = kd.RcclComm() if direct else None
+            deng = kd.DistEngine(b, kd.ShardSpec(n_ent, 1, 0), ent, state, always_collective=True, comm=comm)
+            gbs = []
+            for step in range(1, 6):
+                bt = O.synth_batch(rng, n_ent, n_rel, B, N, N, step)
+                gb = plan.make_batch(bt["h"], bt["t"], bt["r"], bt["neg"], N, N, bt["neg_head"], DEV)
+                gb.UE = 2 * B + (B // N) * N
+                gbs.append(gb)
+            for k, gb in enumerate(gbs):
+                deng.step_pipelined(gb, gbs[k + 1] if k + 1 < len(gbs) else None)
+            torch.cuda.synchronize()
+            assert deng.check_overflow() == 0
+            res.append((ent.cpu(), state.cpu(), b.rel.cpu().clone(), b.rel_state.cpu().clone()))
+            if comm is not None:
+                comm.close()
+        for x, y in zip(res[0], res[1]):
+            assert torch.equal(x, y)
+        assert not torch.equal(res[0][0], torch.empty(n_ent, hidden).fill_(0))
     finally:
         dist.destroy_process_group()
 
