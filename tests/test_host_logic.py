@@ -132,3 +132,18 @@ def test_torch_port_matches_reference(name):
         np.testing.assert_allclose(out["log"][2], z[p + "log"][2], rtol=1e-5)
     np.testing.assert_allclose(m.ent.numpy(), z["final_entity"], rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(m.rel.numpy(), z["final_relation"], rtol=1e-4, atol=1e-5)
+
+
+def test_dist_make_comm_without_gpu_is_the_c10d_wrapper_and_stream_override_nests():
+    """dist.make_comm(): no GPU (or KGE_DIST_COMM=torch) -> the torch.distributed wrappers; _lib.use_stream() returns the
+    previous override so that sections nest"""
+    from dglke_amd import dist as kd, _lib
+    import torch
+    if not torch.cuda.is_available():
+        assert isinstance(kd.make_comm(), kd.TorchComm)
+    assert isinstance(kd.make_comm(kind="torch"), kd.TorchComm)
+    assert _lib.use_stream(123) is None
+    assert _lib.stream_ptr() == 123
+    assert _lib.use_stream(456) == 123 and _lib.stream_ptr() == 456
+    assert _lib.use_stream(None) == 456
+    assert kd.default_cap(3000, 8, 1.5) % 64 == 0 and kd.default_cap(3000, 8, 1.5) >= 3000 * 1.5 / 8
