@@ -147,3 +147,28 @@ def test_dist_make_comm_without_gpu_is_the_c10d_wrapper_and_stream_override_nest
     assert _lib.use_stream(456) == 123 and _lib.stream_ptr() == 456
     assert _lib.use_stream(None) == 456
     assert kd.default_cap(3000, 8, 1.5) % 64 == 0 and kd.default_cap(3000, 8, 1.5) >= 3000 * 1.5 / 8
+
+
+def test_workspace_accounts_for_the_gradient_parts_of_the_shared_pair_backward():
+    """kge_step_workspace_bytes (host arithmetic only): RotatE / TransE_l1 reserve room for GA in parts (the shared-pair backward
+    splits a chunk's negatives over workgroups, kge_neg_bcast.hip neg_bwd_lc_splits) - exactly (parts - 1) more [B, d_e] blocks
+    than with the two-pass kernels, a whole number of them and at most 7; the matrix-core models reserve none"""
+    import ctypes as C
+    from dglke_amd import _lib
+    L = _lib.lib()
+
+    def ws(model, d_e, d_r, B, Cn, chunk, N, flags):
+        hp = _lib.KgeHParams()
+        hp.model, hp.d_e, hp.d_r, hp.flags = _lib.model_id(model), d_e, d_r, flags
+        hp.gamma, hp.lr, hp.adv_temp, hp.reg_norm = 12.0, 0.1, 1.0, 3
+        return L.kge_step_workspace_bytes(C.byref(hp), B, Cn, chunk, N, 2 * B + Cn * N, B)
+    for model, d_e, d_r, B, Cn, chunk, N in (("RotatE", 400, 200, 1024, 4, 256, 256), ("RotatE", 800, 400, 1024, 4, 256, 256),
+                                           ("TransE_l1", 400, 400, 1000, 5, 200, 200)):
+        full, two_pass = ws(model, d_e, d_r, B, Cn, chunk, N, 0), ws(model, d_e, d_r, B, Cn, chunk, N, _lib.FLAG_TWO_PASS_PAIR)
+        extra = full - two_pass
+        block = B * d_e * 4
+        assert extra > 0 and extra % block == 0 and 1 <= extra // block <= 7, (model, extra, block)
+    for model in ("TransE_l2", "DistMult", "ComplEx"):
+        d_e = 400
+        assert ws(model, d_e, d_e if model != "ComplEx" else d_e, 1000, 5, 200, 200, 0) == \
+               ws(model, d_e, d_e if model != "ComplEx" else d_e, 1000, 5, 200, 200, _lib.FLAG_TWO_PASS_PAIR)
