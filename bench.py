@@ -388,7 +388,7 @@ def main():
         # ---- sampling + plan ON THE DEVICE, inside the timed region: one sampler launch per group of <= G steps over
         # double-buffered slots (dataloader.PrefetchedGroups): every timed group trains on batches built during the group before
         # it and builds the batches of the group after it - the timed region contains exactly K steps and the sampling of K
-        # batches.  --sampler-mode serial (default): the launch sits in front of the group's steps on the same stream ----
+        # batches.  --sampler-mode serial (default): the launch follows the group's steps on the same stream ----
         from dglke_amd.dataloader import DeviceSampler, PrefetchedGroups
         smp = DeviceSampler(h, r, t, w["n_ent"], w["B"], w["N"], dev, n_slots=2 * G, seed=0)
         dbs = smp.sample(G)

@@ -11,7 +11,8 @@
 // One workgroup (1024 threads) builds one batch entirely in LDS:
 //   1. positives: whole batches of the epoch's edge order (base permutation re-keyed per epoch) -> (h, r, t);  negatives: counter-based hash
 //      RNG keyed by (seed, step, j) -> uniform id in [0, n_ent)
-//   2. bitonic sort of <= 4096 64-bit keys  (entity id << 12 | element code), code = edge*2+side
+//   2. sort of <= 4096 keys  (entity id << 12 | element code), code = edge*2+side  (a stable block radix sort over the id bits:
+//      the codes are the positions; the relation plan keeps the register bitonic network)
 //      for positive edge ends, 2B + slot for negatives  -> elements grouped by entity, ascending
 //      code inside a group (= the order of the host plan and of index_add_)
 //   3. one block-wide scan of packed (unique, positive, negative) flags -> unique entity list,
