@@ -480,13 +480,12 @@ def main():
         launch_desc = "hipGraph of %d steps" % G if use_graph else "eager"
         data_desc = "id batches + plan built on the host and pre-staged in HBM, sampler excluded"
 
-    run_w()
-    torch.cuda.synchronize()
-    eng.loss_accum.zero_()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    run_w()
+    eng.loss_accum.zero_()            # (stream order: behind the warm-up steps) the sums of the timed steps only
     torch.cuda.synchronize()
+    ev0.record()                      # (in front of the clock: the GPU is idle, its time stamp precedes the first kernel)
     t0 = time.perf_counter()
-    ev0.record()
     run_t()
     ev1.record()
     torch.cuda.synchronize()
