@@ -420,10 +420,11 @@ def main():
         if use_graph:                    # dry run of the whole schedule: captures one graph per distinct
             start()                      # (group size, next size, buffer half); then start again from fresh parameters
             run_groups(0, len(seq))
-            torch.cuda.synchronize()
+        # (no synchronise here or behind the warm-up's preparation: everything is stream-ordered, and a queue that pauses for the
+        #  host's bookkeeping starts its next burst with a ~50-us stall, profiles/r03_v2_driver_shape.txt - the one synchronise
+        #  that opens the timed region is the contract's)
         eng.reset_parameters()
         start()
-        torch.cuda.synchronize()
         run_w = lambda: run_groups(0, len(seq_w))
         run_t = lambda: run_groups(len(seq_w), len(seq))
         launch_desc = (("hipGraph of %d steps; sampler launch for the next group: %s" % (G, {
