@@ -687,7 +687,7 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         KGE_TRY(launch_loss(la, s));
     }
 
-    bool fuse_gnred = false;
+    bool fuse_gnred = false, ew_bwd = false;
     if (phases & PH_BWD) {
     // 4. gradients w.r.t. the pos-side vectors and the negative rows
     if (transr) {
@@ -703,6 +703,17 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         g.reg_coef = (reg && !nd) ? hp->reg_coef : 0.f; g.reg_norm = hp->reg_norm;   // nd: the update adds it (sampled rows only)
         g.row_neg = (fused_loss && want4) ? row_neg : nullptr;
         g.acc = fused_loss ? acc : nullptr;
+        // DistMult, strict step on local tables: the GA tiles write the per-edge gradient rows in their epilogue (GemmArgs::ew_*) -
+        // no edge_bwd launch (5 -> 4 launches per step)
+        ew_bwd = hp->model == KGE_DISTMULT && !pipelined && !co_prep && !nd && !sh && !fused_loss && !qfuse && d_e % 4 == 0 &&
+                 d_r == d_e && !src.em.n && !src.rm.n && src.hidx && src.tidx && src.ridx &&
+                 !(hp->flags & KGE_FLAG_NO_TRANSE_FAST);      // (the flag that keeps TransE on edge_bwd keeps DistMult there too)
+        if (ew_bwd) {
+            g.ew_ent = src.hbase; g.ew_rel = src.rbase; g.ew_h = src.hidx; g.ew_t = src.tidx; g.ew_r = src.ridx;
+            g.ew_dpos = dP; g.ew_GH = GH; g.ew_GT = GT; g.ew_GR = GR;
+            g.ew_reg_coef = reg ? hp->reg_coef : 0.f; g.ew_reg_norm = hp->reg_norm; g.ew_neg_head = b->neg_head;
+            if (!(out && out->g_rel)) g.GA = nullptr;         // nobody reads GA itself then
+        }
         bool fused_launch = false;
         if (co_prep) {                        // async pipeline: backward GEMM(s) + PREP(s+1) in ONE launch
             const int rc = launch_neg_bwd_gemm_with_prep(g, *co_prep, s);
@@ -772,7 +783,7 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         ru.dpos = dP; ru.GA = GA; ru.ur_id = b->ur_id; ru.ur_ptr = b->ur_ptr; ru.ur_edge = b->ur_edge;
         ru.counts_dev = b->counts_dev; ru.reg_rel = want4 ? reg_rel : nullptr; ru.acc = acc;
         KGE_TRY(launch_rescal_update_rel(ru, s));
-    } else if (!transe_fast) {
+    } else if (!transe_fast && !ew_bwd) {
         EdgeBwdArgs eb{};
         eb.src = src_bwd; eb.B = B; eb.d_e = d_e; eb.d_r = d_r; eb.neg_head = b->neg_head; eb.model = hp->model;
         eb.gamma = hp->gamma; eb.rot_div = rot_div;

@@ -158,9 +158,13 @@ template <> __device__ __forceinline__ void st_nt<1>(float *p, const Pack<1> &x)
 // write-through store (system-coherent cache policy, no streaming hint): the line goes to the memory side (Infinity Cache)
 // at once instead of staying dirty in this XCD's L2 until the end-of-kernel write-back
 template <int V> __device__ __forceinline__ void st_wt(float *p, const Pack<V> &x);
+// (s_nop 1: a VMEM store of more than 64 bits reads its data registers for a few cycles after issue, and a VALU instruction that
+//  overwrites them needs 2 wait states behind it on gfx940+.  The compiler's hazard recogniser inserts them for its own stores
+//  but does not look inside inline assembly: without the nop, a following instruction that reused the data registers corrupted
+//  x / y of the stored vector in the last lanes of every row - found when three of these stores ran back to back)
 template <> __device__ __forceinline__ void st_wt<4>(float *p, const Pack<4> &x) {
     f32x4 v = {x.v[0], x.v[1], x.v[2], x.v[3]};
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
 }
 template <> __device__ __forceinline__ void st_wt<1>(float *p, const Pack<1> &x) {
     asm volatile("global_store_dword %0, %1, off sc0 sc1" : : "v"(p), "v"(x.v[0]) : "memory");
@@ -464,6 +468,12 @@ struct GemmArgs {                   // LDS-staged fp32-MFMA negative scoring (kg
     // exactly the gradient of the corrupted-side entity row and, up to the sign, of the relation row, so that the update
     // reads ONE row per list entry instead of two (P and GA).  null: not emitted.
     float *Q; const float *QP; float qc;
+    // DistMult (round 3): the GA tiles chain GA through the pos-side transform in their epilogue and write the per-edge gradient
+    // rows themselves - GH = dp r.t (+ GA.r), GT = dp h.r (+ GA.r), GR = dp h.t + GA.x + regulariser (elementwise in the
+    // column, so a 16 x 64 tile has everything it needs) - no edge_bwd launch.  ew_GR != null switches it on; rows gathered from
+    // the tables through the batch's edge-end / relation ids
+    const float *ew_ent, *ew_rel; const int64_t *ew_h, *ew_t, *ew_r; const float *ew_dpos;
+    float *ew_GH, *ew_GT, *ew_GR; float ew_reg_coef; int ew_reg_norm, ew_neg_head;
     float reg_coef; int reg_norm;
     float *row_neg;                  // [B] per-row negative loss terms or null
     float *acc;                      // running sums or null

@@ -664,7 +664,7 @@ __device__ __forceinline__ void row_stats(const GemmArgs &a, int64_t gi, int tj,
 // steps (the second half also takes the tail step); two wavefronts per SIMD overlap each other's operand latency - with one
 // wavefront per tile the MFMA pipe of a SIMD was busy 35 % of the wavefront's life; the second half hands its accumulators over
 // through LDS (17 floats per lane) and the first half runs the epilogue.  Sums: first half + second half, a fixed order.
-template <bool L2, bool FACT, bool ISGA, bool DENSE = false, int KS = 1>   // FACT: the streamed weights are u_ij and get the per-(row, tile) factor here
+template <bool L2, bool FACT, bool ISGA, bool DENSE = false, int KS = 1, bool EW = false>   // FACT: the streamed weights are u_ij and get the per-(row, tile) factor here
 __device__ __forceinline__ void neg_bwd_gemm_tile(const GemmArgs &a, int ti, int tj, int td, int c, int bcl, int maxK,
                                                   float *smem) {
     const int lane = threadIdx.x & 63, wv = (threadIdx.x >> 6) & (KGE_WAVES_PER_BLOCK - 1);
@@ -712,6 +712,16 @@ __device__ __forceinline__ void neg_bwd_gemm_tile(const GemmArgs &a, int ti, int
     int64_t srow[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) { selfv[r] = zero4(); pq[r] = zero4(); srow[r] = (int64_t)c * R + min(rt * 16 + q * 4 + r, R - 1); }
+    // EW (DistMult, GA tiles): ids of the output rows' edge ends and relations - requested now, the row slices behind the barrier
+    int64_t ewh[4], ewt[4], ewr[4];
+    float ewdp[4];
+    if constexpr (EW && ISGA) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            ewh[r] = a.ew_h[srow[r]]; ewt[r] = a.ew_t[srow[r]]; ewr[r] = a.ew_r[srow[r]];
+            ewdp[r] = a.ew_dpos ? a.ew_dpos[srow[r]] : 0.f;
+        }
+    }
     if (isGA) {
         if (L2) {
 #pragma unroll
@@ -880,6 +890,14 @@ __device__ __forceinline__ void neg_bwd_gemm_tile(const GemmArgs &a, int ti, int
 #pragma unroll
         for (int r = 0; r < 4; ++r) selfv[r] = ldg4(a.nbase + srow[r] * D + dc);
     }
+    float4 ehv[4], etv[4], erv[4];
+    if constexpr (EW && ISGA) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            ehv[r] = ldg4(a.ew_ent + ewh[r] * D + dc); etv[r] = ldg4(a.ew_ent + ewt[r] * D + dc);
+            erv[r] = ldg4(a.ew_rel + ewr[r] * D + dc);
+        }
+    }
 #ifdef KGE_TL_MARKS
     KGE_TL_MARK_K(3, 0);           // prologue done: ids, own rows, first operands and the tail operands have arrived
 #endif
@@ -964,6 +982,26 @@ __device__ __forceinline__ void neg_bwd_gemm_tile(const GemmArgs &a, int ti, int
             // write-through store: GA / GN are consumed by the update kernel (any XCD); lines left dirty in this XCD's L2 only
             // lengthen the write-back before the next launch (profiles/r02_store_policy.txt)
             if (O) { Pack<4> ov; ov.v[0] = o.x; ov.v[1] = o.y; ov.v[2] = o.z; ov.v[3] = o.w; st_wt<4>(O + ((int64_t)c * R + ro) * D + d, ov); }
+            if constexpr (EW && ISGA) {
+                // per-edge gradient rows of DistMult (kge_rowwise.hip edge_bwd_body, same expressions)
+                const float dp = ewdp[r];
+                const float gx[4] = {o.x, o.y, o.z, o.w};
+                const float hh[4] = {ehv[r].x, ehv[r].y, ehv[r].z, ehv[r].w}, tt[4] = {etv[r].x, etv[r].y, etv[r].z, etv[r].w};
+                const float rr[4] = {erv[r].x, erv[r].y, erv[r].z, erv[r].w};
+                Pack<4> gh, gt, gr;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float o_h = dp * rr[e] * tt[e], o_r = dp * hh[e] * tt[e], o_t = dp * hh[e] * rr[e];
+                    if (a.ew_neg_head) { o_t += gx[e] * rr[e]; o_r += gx[e] * tt[e]; }
+                    else               { o_h += gx[e] * rr[e]; o_r += gx[e] * hh[e]; }
+                    if (a.ew_reg_coef > 0.f && a.ew_reg_norm > 0) o_r += reg_grad(rr[e], a.ew_reg_coef, a.ew_reg_norm);
+                    gh.v[e] = o_h; gt.v[e] = o_t; gr.v[e] = o_r;
+                }
+                const int64_t eo = ((int64_t)c * R + ro) * D + d;
+                if (a.ew_GH) st_wt<4>(a.ew_GH + eo, gh);
+                if (a.ew_GT) st_wt<4>(a.ew_GT + eo, gt);
+                st_wt<4>(a.ew_GR + eo, gr);
+            }
             if (wantQ) {
                 Pack<4> qv;
                 qv.v[0] = o.x + a.qc * pq[r].x; qv.v[1] = o.y + a.qc * pq[r].y;
@@ -976,14 +1014,14 @@ __device__ __forceinline__ void neg_bwd_gemm_tile(const GemmArgs &a, int ti, int
 
 // `bid` / `nblk`: this workgroup's index and the number of workgroups doing GEMM work (the body is also one half of the
 // horizontally fused launch below); workgroup -> (chunk, product, 4 consecutive tiles)
-template <bool L2, bool FACT, bool DENSE = false, int KS = 1>
+template <bool L2, bool FACT, bool DENSE = false, int KS = 1, bool EW = false>
 __device__ __forceinline__ void neg_bwd_gemm_body(const GemmArgs &a, int ti, int tj, int td, int bpA, int bpN, int maxK,
                                                   int bid, int nblk, float *smem) {
     const int blk = xcd_remap(bid, nblk);
     const int c = blk / (bpA + bpN);
     const int bc = blk % (bpA + bpN);
-    if (bc < bpA) neg_bwd_gemm_tile<L2, FACT, true, DENSE, KS>(a, ti, tj, td, c, bc, maxK, smem);
-    else neg_bwd_gemm_tile<L2, FACT, false, DENSE, KS>(a, ti, tj, td, c, bc - bpA, maxK, smem);
+    if (bc < bpA) neg_bwd_gemm_tile<L2, FACT, true, DENSE, KS, EW>(a, ti, tj, td, c, bc, maxK, smem);
+    else neg_bwd_gemm_tile<L2, FACT, false, DENSE, KS, false>(a, ti, tj, td, c, bc - bpA, maxK, smem);
 }
 
 // measured (MI355X, us/step, GB_KS 1 -> 2): cfg-T 30.65 -> 31.49, DistMult 35.7 -> 35.7, ComplEx wikikg2 38.4 -> 38.4, SimplE 57.7 ->
@@ -992,12 +1030,12 @@ __device__ __forceinline__ void neg_bwd_gemm_body(const GemmArgs &a, int ti, int
 #ifndef GB_KS
 #define GB_KS 1                       // wavefronts per backward tile along the reduction (stand-alone launch)
 #endif
-template <bool L2, bool FACT, bool DENSE = false>
+template <bool L2, bool FACT, bool DENSE = false, bool EW = false>
 __global__ __launch_bounds__(GB_KS * KGE_BLOCK) void neg_bwd_gemm_kernel(GemmArgs a, int ti, int tj, int td,
                                                                          int bpA, int bpN, int maxK) {
     KGE_TL(3);
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    neg_bwd_gemm_body<L2, FACT, DENSE, GB_KS>(a, ti, tj, td, bpA, bpN, maxK, (int)blockIdx.x, (int)gridDim.x, smem);
+    neg_bwd_gemm_body<L2, FACT, DENSE, GB_KS, EW>(a, ti, tj, td, bpA, bpN, maxK, (int)blockIdx.x, (int)gridDim.x, smem);
 }
 
 // --async_update pipeline, horizontal fusion.  The pipeline (kge_step_async) keeps the exact one-step staleness of the
@@ -1038,6 +1076,13 @@ int launch_neg_bwd_gemm(const GemmArgs &a, hipStream_t s) {
     const size_t sm = (size_t)mk * 8 + (fact ? (size_t)mk * GB_TJP * 4 : 0);
     const bool l2 = a.model == KGE_TRANSE_L2;
     const dim3 g(nb), b(GB_KS * KGE_BLOCK);
+    if (a.ew_GR) {                                               // DistMult: per-edge gradient rows from the GA tiles' epilogue
+        if (fact || l2 || a.model != KGE_DISTMULT || !a.ew_ent || !a.ew_rel || !a.ew_h || !a.ew_t || !a.ew_r || a.D % 4)
+            return KGE_ERR_ARG;
+        if (!a.nidx) hipLaunchKernelGGL((neg_bwd_gemm_kernel<false, false, true, true>), g, b, 0, s, a, ti, tj, td, bpA, bpN, mk);
+        else hipLaunchKernelGGL((neg_bwd_gemm_kernel<false, false, false, true>), g, b, sm, s, a, ti, tj, td, bpA, bpN, mk);
+        return check_launch_g();
+    }
     if (!fact && !a.nidx) {                                      // dense operands: the instance without index table / LDS / barrier
         if (l2) hipLaunchKernelGGL((neg_bwd_gemm_kernel<true, false, true>), g, b, 0, s, a, ti, tj, td, bpA, bpN, mk);
         else hipLaunchKernelGGL((neg_bwd_gemm_kernel<false, false, true>), g, b, 0, s, a, ti, tj, td, bpA, bpN, mk);

@@ -65,8 +65,9 @@ enum kge_status {
  * GEMM kernels for the models that have a GEMM form (validation aid; TransE_l1 / RotatE always
  * use the pairwise kernels). */
 #define KGE_FLAG_FORCE_PAIRWISE 1u
-/* keep the generic edge-gradient kernel for TransE instead of rebuilding the per-edge gradients
- * inside the update kernel (validation aid) */
+/* keep the generic edge-gradient kernel: TransE - instead of rebuilding the per-edge gradients inside the
+ * update kernel; DistMult - instead of writing them from the epilogue of the backward GEMM's GA tiles
+ * (validation aid) */
 #define KGE_FLAG_NO_TRANSE_FAST 2u
 /* matrix-core path: read the negative rows from a dense per-step copy instead of gathering them
  * from the entity table through neg_ids (tuning aid) */
