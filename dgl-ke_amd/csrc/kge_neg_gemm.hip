@@ -664,7 +664,7 @@ __device__ __forceinline__ void row_stats(const GemmArgs &a, int64_t gi, int tj,
 // steps (the second half also takes the tail step); two wavefronts per SIMD overlap each other's operand latency - with one
 // wavefront per tile the MFMA pipe of a SIMD was busy 35 % of the wavefront's life; the second half hands its accumulators over
 // through LDS (17 floats per lane) and the first half runs the epilogue.  Sums: first half + second half, a fixed order.
-template <bool L2, bool FACT, bool ISGA, bool DENSE = false, int KS = 1, bool EW = false>   // FACT: the streamed weights are u_ij and get the per-(row, tile) factor here
+template <bool L2, bool FACT, bool ISGA, bool DENSE = false, int KS = 1, int EW = 0>   // FACT: the streamed weights are u_ij and get the per-(row, tile) factor here
 __device__ __forceinline__ void neg_bwd_gemm_tile(const GemmArgs &a, int ti, int tj, int td, int c, int bcl, int maxK,
                                                   float *smem) {
     const int lane = threadIdx.x & 63, wv = (threadIdx.x >> 6) & (KGE_WAVES_PER_BLOCK - 1);
@@ -672,8 +672,12 @@ __device__ __forceinline__ void neg_bwd_gemm_tile(const GemmArgs &a, int ti, int
     constexpr bool isGA = ISGA;
     const int tl0 = bcl * KGE_WAVES_PER_BLOCK + wv;      // 4 consecutive tiles of the same (chunk, product) per workgroup
     const int tr = isGA ? ti : tj;                       // row tiles of this product
-    const bool tile_ok = tl0 < tr * td;
     // (a wavefront without a tile repeats the last one and stores nothing: KS > 1 needs every wavefront at the hand-over barrier)
+    // EW == 2 (ComplEx, GA tiles): a tile = 32 real columns + the 32 imaginary columns of the SAME complex elements (lanes m < 8 /
+    // m >= 8 of every 16-lane row), so that the epilogue's chain through a = x o r finds both halves inside the tile
+    constexpr bool PAIRED = EW == 2 && ISGA;
+    if (PAIRED) td = (a.D / 2 + 31) / 32;
+    const bool tile_ok = tl0 < tr * td;
     const int tl = KS == 1 ? tl0 : min(tl0, tr * td - 1);
     const int dt = tl % td, rt = tl / td;                // (row tile fastest - 4 wavefronts sharing a column slab - measured the same)
     const int D = a.D, N = a.N, chunk = a.chunk;
@@ -682,8 +686,10 @@ __device__ __forceinline__ void neg_bwd_gemm_tile(const GemmArgs &a, int ti, int
     const int R = isGA ? chunk : N;                      // output rows per chunk
 
     // ---- prologue: every request is issued as early as its address is known, oldest first where something waits for it ----
-    const int d = dt * 64 + m * 4;                       // this lane's 4 output columns
-    const bool dok = d < D;                              // D % 4 == 0: all-or-nothing
+    const int Kc = a.D / 2;                              // (PAIRED) complex elements per row
+    const int dre = dt * 32 + (m & 7) * 4;               // (PAIRED) this lane's 4 complex elements
+    const int d = PAIRED ? (m < 8 ? dre : Kc + dre) : dt * 64 + m * 4;       // this lane's 4 output columns
+    const bool dok = PAIRED ? dre < Kc : d < D;          // D % 4 == 0 (PAIRED: Kc % 4 == 0): all-or-nothing
     const int dc = dok ? d : 0;
     // workgroup-shared table in LDS: rix[k] = row index of reduction element k in the streamed operand (GA: negative row,
     // gathered through neg_ids or dense; GN: positive row of the chunk).  INDICES, not pointers: a pointer read back from
@@ -982,7 +988,54 @@ __device__ __forceinline__ void neg_bwd_gemm_tile(const GemmArgs &a, int ti, int
             // write-through store: GA / GN are consumed by the update kernel (any XCD); lines left dirty in this XCD's L2 only
             // lengthen the write-back before the next launch (profiles/r02_store_policy.txt)
             if (O) { Pack<4> ov; ov.v[0] = o.x; ov.v[1] = o.y; ov.v[2] = o.z; ov.v[3] = o.w; st_wt<4>(O + ((int64_t)c * R + ro) * D + d, ov); }
-            if constexpr (EW && ISGA) {
+            if constexpr (EW == 2 && ISGA) {
+                // per-edge gradient rows of ComplEx (kge_rowwise.hip edge_bwd_body, same expressions): this lane holds the real
+                // (m < 8) or the imaginary (m >= 8) part of 4 complex elements, lane m ^ 8 the other part
+                auto other = [](float v) {       // DPP row_ror:8 - the value of lane m ^ 8 of the same 16-lane row
+                    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x128, 0xF, 0xF, true));
+                };
+                const bool isim = m >= 8;
+                const float dp = ewdp[r];
+                const float go[4] = {o.x, o.y, o.z, o.w};
+                const float ho[4] = {ehv[r].x, ehv[r].y, ehv[r].z, ehv[r].w}, to[4] = {etv[r].x, etv[r].y, etv[r].z, etv[r].w};
+                const float ro_[4] = {erv[r].x, erv[r].y, erv[r].z, erv[r].w};
+                Pack<4> gh, gt, gr;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float gp = other(go[e]), hp_ = other(ho[e]), tp_ = other(to[e]), rp = other(ro_[e]);
+                    const float a_rh = isim ? hp_ : ho[e], a_ih = isim ? ho[e] : hp_;
+                    const float a_rt = isim ? tp_ : to[e], a_it = isim ? to[e] : tp_;
+                    const float cc = isim ? rp : ro_[e], ss = isim ? ro_[e] : rp;
+                    const float gr_ = isim ? gp : go[e], gi_ = isim ? go[e] : gp;
+                    float v_rh = dp * (a_rt * cc + a_it * ss);
+                    float v_ih = dp * (a_it * cc - a_rt * ss);
+                    float v_rt = dp * (a_rh * cc - a_ih * ss);
+                    float v_it = dp * (a_ih * cc + a_rh * ss);
+                    float v_rr = dp * (a_rh * a_rt + a_ih * a_it);
+                    float v_ir = dp * (a_rh * a_it - a_ih * a_rt);
+                    if (a.ew_neg_head) {   // a = t o conj(r)
+                        v_rt += gr_ * cc - gi_ * ss;
+                        v_it += gr_ * ss + gi_ * cc;
+                        v_rr += gr_ * a_rt + gi_ * a_it;
+                        v_ir += gr_ * a_it - gi_ * a_rt;
+                    } else {               // a = h o r
+                        v_rh += gr_ * cc + gi_ * ss;
+                        v_ih += -gr_ * ss + gi_ * cc;
+                        v_rr += gr_ * a_rh + gi_ * a_ih;
+                        v_ir += -gr_ * a_ih + gi_ * a_rh;
+                    }
+                    if (a.ew_reg_coef > 0.f && a.ew_reg_norm > 0) {
+                        v_rr += reg_grad(cc, a.ew_reg_coef, a.ew_reg_norm);
+                        v_ir += reg_grad(ss, a.ew_reg_coef, a.ew_reg_norm);
+                    }
+                    gh.v[e] = isim ? v_ih : v_rh; gt.v[e] = isim ? v_it : v_rt; gr.v[e] = isim ? v_ir : v_rr;
+                }
+                const int64_t eo = ((int64_t)c * R + ro) * D + d;
+                if (a.ew_GH) st_wt<4>(a.ew_GH + eo, gh);
+                if (a.ew_GT) st_wt<4>(a.ew_GT + eo, gt);
+                st_wt<4>(a.ew_GR + eo, gr);
+            }
+            if constexpr (EW == 1 && ISGA) {
                 // per-edge gradient rows of DistMult (kge_rowwise.hip edge_bwd_body, same expressions)
                 const float dp = ewdp[r];
                 const float gx[4] = {o.x, o.y, o.z, o.w};
@@ -1014,14 +1067,14 @@ __device__ __forceinline__ void neg_bwd_gemm_tile(const GemmArgs &a, int ti, int
 
 // `bid` / `nblk`: this workgroup's index and the number of workgroups doing GEMM work (the body is also one half of the
 // horizontally fused launch below); workgroup -> (chunk, product, 4 consecutive tiles)
-template <bool L2, bool FACT, bool DENSE = false, int KS = 1, bool EW = false>
+template <bool L2, bool FACT, bool DENSE = false, int KS = 1, int EW = 0>
 __device__ __forceinline__ void neg_bwd_gemm_body(const GemmArgs &a, int ti, int tj, int td, int bpA, int bpN, int maxK,
                                                   int bid, int nblk, float *smem) {
     const int blk = xcd_remap(bid, nblk);
     const int c = blk / (bpA + bpN);
     const int bc = blk % (bpA + bpN);
     if (bc < bpA) neg_bwd_gemm_tile<L2, FACT, true, DENSE, KS, EW>(a, ti, tj, td, c, bc, maxK, smem);
-    else neg_bwd_gemm_tile<L2, FACT, false, DENSE, KS, false>(a, ti, tj, td, c, bc - bpA, maxK, smem);
+    else neg_bwd_gemm_tile<L2, FACT, false, DENSE, KS, 0>(a, ti, tj, td, c, bc - bpA, maxK, smem);
 }
 
 // measured (MI355X, us/step, GB_KS 1 -> 2): cfg-T 30.65 -> 31.49, DistMult 35.7 -> 35.7, ComplEx wikikg2 38.4 -> 38.4, SimplE 57.7 ->
@@ -1030,7 +1083,7 @@ __device__ __forceinline__ void neg_bwd_gemm_body(const GemmArgs &a, int ti, int
 #ifndef GB_KS
 #define GB_KS 1                       // wavefronts per backward tile along the reduction (stand-alone launch)
 #endif
-template <bool L2, bool FACT, bool DENSE = false, bool EW = false>
+template <bool L2, bool FACT, bool DENSE = false, int EW = 0>
 __global__ __launch_bounds__(GB_KS * KGE_BLOCK) void neg_bwd_gemm_kernel(GemmArgs a, int ti, int tj, int td,
                                                                          int bpA, int bpN, int maxK) {
     KGE_TL(3);
@@ -1076,11 +1129,21 @@ int launch_neg_bwd_gemm(const GemmArgs &a, hipStream_t s) {
     const size_t sm = (size_t)mk * 8 + (fact ? (size_t)mk * GB_TJP * 4 : 0);
     const bool l2 = a.model == KGE_TRANSE_L2;
     const dim3 g(nb), b(GB_KS * KGE_BLOCK);
-    if (a.ew_GR) {                                               // DistMult: per-edge gradient rows from the GA tiles' epilogue
-        if (fact || l2 || a.model != KGE_DISTMULT || !a.ew_ent || !a.ew_rel || !a.ew_h || !a.ew_t || !a.ew_r || a.D % 4)
+    if (a.ew_GR) {                                               // DistMult / ComplEx: per-edge gradient rows from the GA tiles' epilogue
+        const bool cplx = a.model == KGE_COMPLEX;
+        if (fact || l2 || (a.model != KGE_DISTMULT && !cplx) || !a.ew_ent || !a.ew_rel || !a.ew_h || !a.ew_t || !a.ew_r ||
+            a.D % (cplx ? 8 : 4))
             return KGE_ERR_ARG;
-        if (!a.nidx) hipLaunchKernelGGL((neg_bwd_gemm_kernel<false, false, true, true>), g, b, 0, s, a, ti, tj, td, bpA, bpN, mk);
-        else hipLaunchKernelGGL((neg_bwd_gemm_kernel<false, false, false, true>), g, b, sm, s, a, ti, tj, td, bpA, bpN, mk);
+        if (cplx) {                                              // GA tiles: 32 complex elements (real + imaginary columns) each
+            const int tdA = (a.D / 2 + 31) / 32;
+            const int bpAc = (ti * tdA + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK;
+            const dim3 gc(a.C * (bpAc + bpN));
+            if (!a.nidx) hipLaunchKernelGGL((neg_bwd_gemm_kernel<false, false, true, 2>), gc, b, 0, s, a, ti, tj, td, bpAc, bpN, mk);
+            else hipLaunchKernelGGL((neg_bwd_gemm_kernel<false, false, false, 2>), gc, b, sm, s, a, ti, tj, td, bpAc, bpN, mk);
+            return check_launch_g();
+        }
+        if (!a.nidx) hipLaunchKernelGGL((neg_bwd_gemm_kernel<false, false, true, 1>), g, b, 0, s, a, ti, tj, td, bpA, bpN, mk);
+        else hipLaunchKernelGGL((neg_bwd_gemm_kernel<false, false, false, 1>), g, b, sm, s, a, ti, tj, td, bpA, bpN, mk);
         return check_launch_g();
     }
     if (!fact && !a.nidx) {                                      // dense operands: the instance without index table / LDS / barrier
