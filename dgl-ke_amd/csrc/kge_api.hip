@@ -703,9 +703,10 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         g.reg_coef = (reg && !nd) ? hp->reg_coef : 0.f; g.reg_norm = hp->reg_norm;   // nd: the update adds it (sampled rows only)
         g.row_neg = (fused_loss && want4) ? row_neg : nullptr;
         g.acc = fused_loss ? acc : nullptr;
-        // DistMult / ComplEx, strict step on local tables: the GA tiles write the per-edge gradient rows in their epilogue
+        // DistMult / ComplEx / SimplE, strict step on local tables: the GA tiles write the per-edge gradient rows in their epilogue
         // (GemmArgs::ew_*) - no edge_bwd launch (5 -> 4 launches per step)
-        ew_bwd = ((hp->model == KGE_DISTMULT && d_e % 4 == 0) || (hp->model == KGE_COMPLEX && d_e % 8 == 0)) &&
+        ew_bwd = ((hp->model == KGE_DISTMULT && d_e % 4 == 0) ||
+                  ((hp->model == KGE_COMPLEX || hp->model == KGE_SIMPLE) && d_e % 8 == 0)) &&
                  !pipelined && !co_prep && !nd && !sh && !fused_loss && !qfuse &&
                  d_r == d_e && !src.em.n && !src.rm.n && src.hidx && src.tidx && src.ridx &&
                  !(hp->flags & KGE_FLAG_NO_TRANSE_FAST);      // (the flag that keeps TransE on edge_bwd keeps DistMult there too)

@@ -675,7 +675,7 @@ __device__ __forceinline__ void neg_bwd_gemm_tile(const GemmArgs &a, int ti, int
     // (a wavefront without a tile repeats the last one and stores nothing: KS > 1 needs every wavefront at the hand-over barrier)
     // EW == 2 (ComplEx, GA tiles): a tile = 32 real columns + the 32 imaginary columns of the SAME complex elements (lanes m < 8 /
     // m >= 8 of every 16-lane row), so that the epilogue's chain through a = x o r finds both halves inside the tile
-    constexpr bool PAIRED = EW == 2 && ISGA;
+    constexpr bool PAIRED = EW >= 2 && ISGA;             // 2: ComplEx, 3: SimplE (first / second half of the row instead of re / im)
     if (PAIRED) td = (a.D / 2 + 31) / 32;
     const bool tile_ok = tl0 < tr * td;
     const int tl = KS == 1 ? tl0 : min(tl0, tr * td - 1);
@@ -988,7 +988,7 @@ __device__ __forceinline__ void neg_bwd_gemm_tile(const GemmArgs &a, int ti, int
             // write-through store: GA / GN are consumed by the update kernel (any XCD); lines left dirty in this XCD's L2 only
             // lengthen the write-back before the next launch (profiles/r02_store_policy.txt)
             if (O) { Pack<4> ov; ov.v[0] = o.x; ov.v[1] = o.y; ov.v[2] = o.z; ov.v[3] = o.w; st_wt<4>(O + ((int64_t)c * R + ro) * D + d, ov); }
-            if constexpr (EW == 2 && ISGA) {
+            if constexpr (EW >= 2 && ISGA) {
                 // per-edge gradient rows of ComplEx (kge_rowwise.hip edge_bwd_body, same expressions): this lane holds the real
                 // (m < 8) or the imaginary (m >= 8) part of 4 complex elements, lane m ^ 8 the other part
                 auto other = [](float v) {       // DPP row_ror:8 - the value of lane m ^ 8 of the same 16-lane row
@@ -1007,12 +1007,21 @@ __device__ __forceinline__ void neg_bwd_gemm_tile(const GemmArgs &a, int ti, int
                     const float a_rt = isim ? tp_ : to[e], a_it = isim ? to[e] : tp_;
                     const float cc = isim ? rp : ro_[e], ss = isim ? ro_[e] : rp;
                     const float gr_ = isim ? gp : go[e], gi_ = isim ? go[e] : gp;
-                    float v_rh = dp * (a_rt * cc + a_it * ss);
-                    float v_ih = dp * (a_it * cc - a_rt * ss);
-                    float v_rt = dp * (a_rh * cc - a_ih * ss);
-                    float v_it = dp * (a_ih * cc + a_rh * ss);
-                    float v_rr = dp * (a_rh * a_rt + a_ih * a_it);
-                    float v_ir = dp * (a_rh * a_it - a_ih * a_rt);
+                    float v_rh, v_ih, v_rt, v_it, v_rr, v_ir;
+                    if constexpr (EW == 3) {
+                        // SimplE: (h_i, h_j) = (a_rh, a_ih), (t_i, t_j) = (a_rt, a_it), (rel, rel_inv) = (cc, ss); the 1/2 of the score
+                        const float g1 = 0.5f * gr_, g2 = 0.5f * gi_, dh = 0.5f * dp;
+                        v_rh = dh * cc * a_it; v_ih = dh * a_rt * ss; v_rt = dh * ss * a_ih; v_it = dh * a_rh * cc;
+                        v_rr = dh * a_rh * a_it; v_ir = dh * a_rt * a_ih;
+                        if (a.ew_neg_head) { v_it += g1 * cc; v_rr += g1 * a_it; v_rt += g2 * ss; v_ir += g2 * a_rt; }
+                        else               { v_ih += g1 * ss; v_ir += g1 * a_ih; v_rh += g2 * cc; v_rr += g2 * a_rh; }
+                    } else {
+                    v_rh = dp * (a_rt * cc + a_it * ss);
+                    v_ih = dp * (a_it * cc - a_rt * ss);
+                    v_rt = dp * (a_rh * cc - a_ih * ss);
+                    v_it = dp * (a_ih * cc + a_rh * ss);
+                    v_rr = dp * (a_rh * a_rt + a_ih * a_it);
+                    v_ir = dp * (a_rh * a_it - a_ih * a_rt);
                     if (a.ew_neg_head) {   // a = t o conj(r)
                         v_rt += gr_ * cc - gi_ * ss;
                         v_it += gr_ * ss + gi_ * cc;
@@ -1023,6 +1032,7 @@ __device__ __forceinline__ void neg_bwd_gemm_tile(const GemmArgs &a, int ti, int
                         v_ih += -gr_ * ss + gi_ * cc;
                         v_rr += gr_ * a_rh + gi_ * a_ih;
                         v_ir += -gr_ * a_ih + gi_ * a_rh;
+                    }
                     }
                     if (a.ew_reg_coef > 0.f && a.ew_reg_norm > 0) {
                         v_rr += reg_grad(cc, a.ew_reg_coef, a.ew_reg_norm);
@@ -1130,7 +1140,7 @@ int launch_neg_bwd_gemm(const GemmArgs &a, hipStream_t s) {
     const bool l2 = a.model == KGE_TRANSE_L2;
     const dim3 g(nb), b(GB_KS * KGE_BLOCK);
     if (a.ew_GR) {                                               // DistMult / ComplEx: per-edge gradient rows from the GA tiles' epilogue
-        const bool cplx = a.model == KGE_COMPLEX;
+        const bool simple = a.model == KGE_SIMPLE, cplx = a.model == KGE_COMPLEX || simple;
         if (fact || l2 || (a.model != KGE_DISTMULT && !cplx) || !a.ew_ent || !a.ew_rel || !a.ew_h || !a.ew_t || !a.ew_r ||
             a.D % (cplx ? 8 : 4))
             return KGE_ERR_ARG;
@@ -1138,7 +1148,10 @@ int launch_neg_bwd_gemm(const GemmArgs &a, hipStream_t s) {
             const int tdA = (a.D / 2 + 31) / 32;
             const int bpAc = (ti * tdA + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK;
             const dim3 gc(a.C * (bpAc + bpN));
-            if (!a.nidx) hipLaunchKernelGGL((neg_bwd_gemm_kernel<false, false, true, 2>), gc, b, 0, s, a, ti, tj, td, bpAc, bpN, mk);
+            if (simple) {
+                if (!a.nidx) hipLaunchKernelGGL((neg_bwd_gemm_kernel<false, false, true, 3>), gc, b, 0, s, a, ti, tj, td, bpAc, bpN, mk);
+                else hipLaunchKernelGGL((neg_bwd_gemm_kernel<false, false, false, 3>), gc, b, sm, s, a, ti, tj, td, bpAc, bpN, mk);
+            } else if (!a.nidx) hipLaunchKernelGGL((neg_bwd_gemm_kernel<false, false, true, 2>), gc, b, 0, s, a, ti, tj, td, bpAc, bpN, mk);
             else hipLaunchKernelGGL((neg_bwd_gemm_kernel<false, false, false, 2>), gc, b, sm, s, a, ti, tj, td, bpAc, bpN, mk);
             return check_launch_g();
         }

@@ -42,7 +42,7 @@ def main():
             # (flag 2: DistMult / ComplEx on local tables would otherwise take their per-edge gradients from the backward GEMM's
             #  epilogue, the sharded step from the edge-gradient kernel - same formulas, not the same bits)
             ref = StepEngine(model, n_ent, n_rel, hidden, 12.0, 0.1, dev, de_, dr_, True, 1.0, 1e-6, 3,
-                             flags=2 if model in ("DistMult", "ComplEx") else 0)
+                             flags=2 if model in ("DistMult", "ComplEx", "SimplE") else 0)
             ref.load_tables(ent0.to(dev), rel0.to(dev))
         rng = np.random.RandomState(3)
         torch.cuda.synchronize()

@@ -30,7 +30,7 @@ def test_emulated_shards_equal_single_table(model, de_, dr_, hidden, n_shards, f
     # (DistMult / ComplEx on local tables write their per-edge gradient rows from the backward GEMM's epilogue; the sharded step keeps the
     #  edge-gradient kernel - flag 2 puts the single-table reference on the same kernels, which is what this bar is about)
     ref = StepEngine(model, n_ent, n_rel, hidden, 10.0, 0.1, DEV, de_, dr_, True, 1.0, 1e-5, 3,
-                     flags=flags | (2 if model in ("DistMult", "ComplEx") else 0))
+                     flags=flags | (2 if model in ("DistMult", "ComplEx", "SimplE") else 0))
     tabs = p2p.ShardedTables(n_ent, n_rel, d_e, d_r, DEV, emulate=n_shards)
     tabs.load_full(ref.ent, ref.rel)
     eng = StepEngine(model, n_ent, n_rel, hidden, 10.0, 0.1, DEV, de_, dr_, True, 1.0, 1e-5, 3, flags=flags, shards=tabs)

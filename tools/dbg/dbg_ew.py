@@ -6,11 +6,11 @@ from dglke_amd.engine import StepEngine
 from oracle import kge_oracle as O
 dev = "cuda:0"
 import itertools
-for (model, (n_ent, n_rel, hidden, B, N)) in itertools.product(("DistMult", "ComplEx"), ((500, 20, 64, 64, 16), (3000, 40, 100, 256, 64), (3000, 40, 200, 200, 200))):
+for (model, (n_ent, n_rel, hidden, B, N)) in itertools.product(("SimplE", "ComplEx"), ((500, 20, 64, 64, 16), (3000, 40, 100, 256, 64), (3000, 40, 200, 200, 200))):
     rng = np.random.RandomState(0)
     bt = O.synth_batch(rng, n_ent, n_rel, B, N, N, 1)
     outs = []
-    cx = model == "ComplEx"
+    cx = model in ("ComplEx", "SimplE")
     for flags in (0, 2):
         torch.manual_seed(0)
         eng = StepEngine(model, n_ent, n_rel, hidden, 12.0, 0.1, dev, cx, cx, True, 1.0, 1e-6, 3, flags=flags)
