@@ -134,11 +134,11 @@ def step_kernels(model, force_pairwise=False):
     if model == "TransE_l2":
         return ("one training step = 4 dependent launches ([forward GEMM tiles || edge-forward rows], loss, neg_bwd_gemm, "
                 "update); the first and the third take ~9 us each (roofline.dominant_kernel: the committed profile's)")
-    if model == "DistMult":
-        return ("one training step = 5 dependent launches ([forward GEMM tiles || edge-forward rows], loss, neg_bwd_gemm, "
-                "edge_bwd, update); dominant: the first launch / neg_bwd_gemm_kernel")
-    return ("one training step = 6 dependent kernels (edge_fwd, neg_fwd_gemm, loss, neg_bwd_gemm, edge_bwd, update); "
-            "dominant: neg_bwd_gemm_kernel")
+    if model in ("DistMult", "ComplEx"):
+        return ("one training step = 4 dependent launches ([forward GEMM tiles || edge-forward rows], loss, neg_bwd_gemm with the "
+                "per-edge gradient rows written by the GA tiles' epilogue, update); dominant: the first launch / neg_bwd_gemm_kernel")
+    return ("one training step = 5 dependent kernels (edge_fwd, neg_fwd_gemm, loss, neg_bwd_gemm with the per-edge gradient rows "
+            "written by the GA tiles' epilogue, update); dominant: neg_bwd_gemm_kernel")
 
 
 def cpu_baseline(w, plans, budget_s=12.0, max_steps=200):
