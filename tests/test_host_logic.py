@@ -172,3 +172,21 @@ def test_workspace_accounts_for_the_gradient_parts_of_the_shared_pair_backward()
         d_e = 400
         assert ws(model, d_e, d_e if model != "ComplEx" else d_e, 1000, 5, 200, 200, 0) == \
                ws(model, d_e, d_e if model != "ComplEx" else d_e, 1000, 5, 200, 200, _lib.FLAG_TWO_PASS_PAIR)
+
+
+def test_inline_assembly_wide_stores_carry_their_wait_states():
+    """a 128-bit global store written as inline assembly must be followed by two wait states before its data registers may be
+    overwritten (gfx940+ VMEM store-data hazard) - the compiler does not see inside the asm statement, so the statement itself
+    carries the s_nop (kge_common.hpp st_wt<4>; found in round 3 when three such stores ran back to back)"""
+    import re
+    src_dir = os.path.join(ROOT, "dgl-ke_amd", "csrc")
+    n = 0
+    for f in os.listdir(src_dir):
+        if not f.endswith((".hip", ".hpp")):
+            continue
+        for m in re.finditer(r'asm\s+volatile\(\s*"((?:[^"\\]|\\.)*)"', open(os.path.join(src_dir, f)).read()):
+            text = m.group(1)
+            if re.search(r"(global|flat|buffer)_store_dwordx[34]", text):
+                n += 1
+                assert "s_nop" in text, "%s: wide store without wait states: %s" % (f, text)
+    assert n >= 1
