@@ -397,6 +397,8 @@ def main(args, world, rank, local_rank):
         dist.barrier()
         if tabs is not None:
             tabs.close()
+        if mode != "p2p" and hasattr(_de.comm, "close"):
+            _de.comm.close()             # the engine's own RCCL communicator (dist.RcclComm)
     finally:
         dist.destroy_process_group()
     if line is not None:
