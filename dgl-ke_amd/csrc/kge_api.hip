@@ -582,6 +582,13 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     const bool merged_pair = !gemm && !pipelined && !pairwise && !nd && !sh && !rescal && !transr &&
                              (phases & (PH_PREP | PH_FWD)) == (PH_PREP | PH_FWD) && !build_prep && !co_update &&
                              !(hp->flags & KGE_FLAG_SPLIT_FWD) && neg_fwd_bcast_with_edge_supported(hp->model, d_e, d_r);
+    // round 4, KGE_FLAG_LOSS_IN_FWD: ... and LossGenerator too - the forward tiles store final scores and the workgroup of a 16-row
+    // strip that arrives last runs the strip's loss rows (kge_neg_gemm.hip, neg_fwd_loss_edge_kernel): 3 launches per TransE_l2 /
+    // DistMult / ComplEx step.  Needs the caller's ticket words (kge_step_out.tickets); pointwise criteria; |a|^2 and |b|^2 of the
+    // TransE_l2 distance are then computed by the tiles, not by the edge half.  Opt-in: slower than the loss launch on MI355X
+    // (profiles/r04_loss_fold.txt).
+    const bool fold_loss = merged_fwd && out && out->tickets && (hp->flags & KGE_FLAG_LOSS_IN_FWD) && !(hp->flags & KGE_FLAG_FWD_DIRECT) &&
+                           neg_fwd_loss_fold_supported(hp->model, C, chunk, N, d_e, d_r);
     EdgeFwdArgs ef{};
     if (phases & PH_PREP) {
     // 1. gather + positive score + pos-side vectors (+ positive-loss part, + P rows for TransE)
@@ -597,7 +604,7 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     const bool dense_bwd = merged_fwd && (hp->flags & KGE_FLAG_DENSE_BWD);
     ef.Bn = (dense_neg || dense_bwd) ? Bn : nullptr;  // the pairwise kernels read a dense copy
     ef.Hc = Hc; ef.Tc = Tc; ef.Rc = Rc;
-    ef.asq = l2g ? asq : nullptr; ef.bsq = l2g ? bsq : nullptr;
+    ef.asq = (l2g && !fold_loss) ? asq : nullptr; ef.bsq = (l2g && !fold_loss) ? bsq : nullptr;
     ef.do_pos_loss = pairwise ? 0 : 1; ef.lp = lp; ef.w = b->edge_w;
     ef.dpos = dP; ef.row_pos = want4 ? row_pos : nullptr; ef.acc = acc;
     ef.P = transe_fast ? Pg : nullptr;
@@ -653,7 +660,18 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
             if (merged_fwd) {
                 g.xbase = tb->ent; g.xidx = b->neg_head ? b->t_gid : b->h_gid; g.rbase = tb->rel; g.ridx = b->rel_ids;
                 g.asign = b->neg_head ? -1.f : 1.f; g.lds_off = (hp->flags & KGE_FLAG_FWD_DIRECT) ? 1 : 0;
-                KGE_TRY(launch_neg_fwd_gemm_with_edge(g, ef, s));
+                if (fold_loss) {
+                    LossArgs la{};
+                    la.B = B; la.N = N; la.genre = hp->loss_genre; la.adv = hp->adv; la.pairwise = 0;
+                    la.adv_temp = hp->adv_temp; la.margin = hp->margin;
+                    la.pos = P; la.neg = S; la.w = b->edge_w; la.dpos = dP; la.dneg = S;
+                    la.row_pos = nullptr; la.row_neg = want4 ? row_neg : nullptr;      // (row_pos: written by the edge half)
+                    la.acc = acc;
+                    la.l2_scale = is_l2 ? 1 : 0; la.gamma = hp->gamma; la.clampv = clamp_of(hp->model);
+                    la.neg_copy = out->neg_score;
+                    la.skip_pos = 1;
+                    KGE_TRY(launch_neg_fwd_gemm_with_edge_loss(g, ef, la, out->tickets, s));
+                } else KGE_TRY(launch_neg_fwd_gemm_with_edge(g, ef, s));
             } else if (!fused_launch) KGE_TRY(launch_neg_fwd_gemm(g, s));
         }
     } else {
@@ -672,7 +690,7 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     }
 
     // 3. stand-alone loss kernel (only when the loss is not fused into the backward GEMM)
-    if (!fused_loss && (phases & PH_FWD)) {
+    if (!fused_loss && !fold_loss && (phases & PH_FWD)) {
         LossArgs la{};
         la.B = B; la.N = N; la.genre = hp->loss_genre; la.adv = hp->adv; la.pairwise = hp->pairwise;
         la.adv_temp = hp->adv_temp; la.margin = hp->margin;

@@ -489,6 +489,10 @@ int launch_neg_fwd_gemm_with_update(const GemmArgs &a, const UpdateArgs &u, hipS
 // (KGE_ERR_ARG: no fused instantiation for the combination)
 bool neg_fwd_gemm_with_edge_supported(int model, int d_e, int d_r);
 int launch_neg_fwd_gemm_with_edge(const GemmArgs &a, const EdgeFwdArgs &e, hipStream_t s);
+// ... and with the loss rows inside (round 4; `tickets`: kge_step_out.tickets, zero on entry and on exit)
+struct LossArgs;
+bool neg_fwd_loss_fold_supported(int model, int C, int chunk, int N, int d_e, int d_r);
+int launch_neg_fwd_gemm_with_edge_loss(const GemmArgs &a, const EdgeFwdArgs &e, const LossArgs &la, int *tickets, hipStream_t s);
 int launch_neg_bwd_gemm_with_prep(const GemmArgs &a, const EdgeFwdArgs &e, hipStream_t s);
 int launch_neg_fwd_pair(const NegArgs &a, hipStream_t s);
 int launch_neg_bwd_pair(const NegArgs &a, hipStream_t s);

@@ -39,6 +39,7 @@
 #include "kge_common.hpp"
 #include "kge_update_body.hpp"
 #include "kge_edge_fwd_body.hpp"
+#include "kge_loss_body.hpp"
 
 using namespace kge;
 KGE_TL_DEFINE(gemm)
@@ -384,9 +385,18 @@ __device__ __forceinline__ void neg_fwd_gemm_wide_body(const GemmArgs &a, int ti
 // Row stride of the tile: whole k-steps + 4 floats (the 16-byte fragment reads of a quarter wavefront fall on different banks).
 static inline int fwd_lds_stride(int D) { return ((D + 15) & ~15) + 4; }
 static inline size_t fwd_lds_bytes(int D) { return (size_t)16 * fwd_lds_stride(D) * sizeof(float); }
+// loss-fold instance (round 4): + |a_i|^2 of the 16 rows + the "this workgroup arrived last" word, in the SAME shared array
+static inline size_t fwd_lds_bytes_lf(int D) { return fwd_lds_bytes(D) + 32 * sizeof(float); }
 
-template <int AM>
-__device__ __forceinline__ void neg_fwd_gemm_ldsa_body(const GemmArgs &a, int ti, int tj, int bid, int nblk, float *As) {
+// LF (round 4, the strict step's 3-launch form): the loss rows of a 16-row strip run INSIDE this launch.  The tiles store final
+// scores (TransE_l2: |a_i|^2 from the LDS tile, |b_j|^2 accumulated from the B fragments under the MFMAs) write-through, every
+// workgroup of the strip draws an arrival ticket, and the workgroup that arrives last runs LossGenerator on the strip's rows
+// (kge_loss_body.hpp - the stand-alone kernel's code) with L1-bypassing loads.  Placement-independent hand-off
+// (MI355X_MICROARCH.md, Workgroup dispatch: sc1 stores -> vmcnt(0) -> barrier -> relaxed agent-scope fetch_add; reader: sc1 loads);
+// no workgroup ever waits for another one.  The ticket word is returned to 0 by the last arriver (kge_step_out.tickets).
+template <int AM, bool LF = false, bool LLEAN = false>
+__device__ __forceinline__ void neg_fwd_gemm_ldsa_body(const GemmArgs &a, int ti, int tj, int bid, int nblk, float *As,
+                                                       const LossArgs *lap = nullptr, int *tickets = nullptr) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int tjg = (tj + 3) >> 2;
     const int L = xcd_remap(bid, nblk);
@@ -411,6 +421,7 @@ __device__ __forceinline__ void neg_fwd_gemm_ldsa_body(const GemmArgs &a, int ti
     float4 a0[FU], b0[FU], a1[FU], b1[FU];
     // the A tile: 8 passes of 16 x 16 bytes per row and source (512 floats per row) requested together, then the first B fragments
     float4 xv[8], rv[8];
+    float asq_t = 0.f, bs0 = 0.f, bs1 = 0.f;             // LF, TransE_l2: partial |a_i|^2 (A build) / |b_j|^2 (main loop)
     if constexpr (AM == 3) {
         // ComplEx: rows are [re | im] halves; a = x o r (tail-corrupted step) / x o conj(r) (head-corrupted, x = tail):
         //   a_re = x_re c -/+ x_im s,  a_im = +/- x_re s + x_im c   (score_fun.py:347-371; same fmaf forms as edge_fwd_body)
@@ -450,7 +461,11 @@ __device__ __forceinline__ void neg_fwd_gemm_ldsa_body(const GemmArgs &a, int ti
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int c4 = j * 16 + ac;
-        if (c4 < n4) *reinterpret_cast<float4 *>(Adst + c4 * 4) = LA_COMB(xv[j], rv[j]);
+        if (c4 < n4) {
+            const float4 av = LA_COMB(xv[j], rv[j]);
+            *reinterpret_cast<float4 *>(Adst + c4 * 4) = av;
+            if constexpr (LF && AM == 1) asq_t = fmaf(av.x, av.x, fmaf(av.y, av.y, fmaf(av.z, av.z, fmaf(av.w, av.w, asq_t))));
+        }
     }
     for (int c0 = 16 * 8; c0 < n4; c0 += 16 * 8) {       // rows longer than 512 floats
 #pragma unroll
@@ -458,25 +473,38 @@ __device__ __forceinline__ void neg_fwd_gemm_ldsa_body(const GemmArgs &a, int ti
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int c4 = c0 + j * 16 + ac;
-            if (c4 < n4) *reinterpret_cast<float4 *>(Adst + c4 * 4) = LA_COMB(xv[j], rv[j]);
+            if (c4 < n4) {
+                const float4 av = LA_COMB(xv[j], rv[j]);
+                *reinterpret_cast<float4 *>(Adst + c4 * 4) = av;
+                if constexpr (LF && AM == 1) asq_t = fmaf(av.x, av.x, fmaf(av.y, av.y, fmaf(av.z, av.z, fmaf(av.w, av.w, asq_t))));
+            }
         }
     }
 #undef LA_COMB
     }
+    float *Aq = As + 16 * KP;                            // LF: |a_i|^2 of the tile's 16 rows, then the last-arriver word
+    if constexpr (LF && AM == 1) {
+        asq_t = kge::row_sum16(asq_t);                   // the 16 threads of a row are one DPP row
+        if (ac == 0) Aq[arow] = asq_t;
+    }
     if (ac < (KP - D) / 4) *reinterpret_cast<float4 *>(Adst + D + ac * 4) = zero4();   // columns D .. KP-1 (D % 4 == 0): zeros
     __syncthreads();
-    if (!tile_ok) return;
+    if (!LF && !tile_ok) return;
+    if (tile_ok) {
 #define LA_LOAD(AV, BV, KS0)                                                     \
     { int k0_ = (KS0); asm volatile("" : "+s"(k0_));                             \
       _Pragma("unroll") for (int u = 0; u < FU; ++u) {                           \
         const int ks_ = min(k0_ + u, kfull - 1);                                 \
         AV[u] = *reinterpret_cast<const float4 *>(Ap + ks_ * 16); BV[u] = ldg4(Bp + ks_ * 16); \
     } }
+    // (LF, TransE_l2: four VALU fmas per k-step on the B fragment just fed to the matrix core - |b_j|^2 of this lane's quarter row)
 #define LA_MMA1(AV, BV, u)                                                       \
     { acc0 = MFMA16(AV[u].x, BV[u].x, acc0);                                     \
       acc1 = MFMA16(AV[u].y, BV[u].y, acc1);                                     \
       acc0 = MFMA16(AV[u].z, BV[u].z, acc0);                                     \
-      acc1 = MFMA16(AV[u].w, BV[u].w, acc1); }
+      acc1 = MFMA16(AV[u].w, BV[u].w, acc1);                                     \
+      if constexpr (LF && AM == 1) { bs0 = fmaf(BV[u].x, BV[u].x, bs0); bs1 = fmaf(BV[u].y, BV[u].y, bs1);   \
+                                     bs0 = fmaf(BV[u].z, BV[u].z, bs0); bs1 = fmaf(BV[u].w, BV[u].w, bs1); } }
 #define LA_MMA(AV, BV) _Pragma("unroll") for (int u = 0; u < FU; ++u) LA_MMA1(AV, BV, u)
 #define LA_MMA_G(AV, BV, KS0) _Pragma("unroll") for (int u = 0; u < FU; ++u) { if ((KS0) + u < kfull) LA_MMA1(AV, BV, u) }
     if (kfull > 0) {
@@ -511,12 +539,78 @@ __device__ __forceinline__ void neg_fwd_gemm_ldsa_body(const GemmArgs &a, int ti
         acc1 = MFMA16(av.y, bv.y, acc1);
         acc0 = MFMA16(av.z, bv.z, acc0);
         acc1 = MFMA16(av.w, bv.w, acc1);
+        if constexpr (LF && AM == 1) { bs0 = fmaf(bv.x, bv.x, bs0); bs1 = fmaf(bv.y, bv.y, bs1);
+                                       bs0 = fmaf(bv.z, bv.z, bs0); bs1 = fmaf(bv.w, bv.w, bs1); }
     }
     const int j = jt * 16 + m;
+    if constexpr (!LF) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int i = it * 16 + q * 4 + r;
-        if (j < a.N && i < a.chunk) a.S[((int64_t)c * a.chunk + i) * a.N + j] = acc0[r] + acc1[r];
+        for (int r = 0; r < 4; ++r) {
+            const int i = it * 16 + q * 4 + r;
+            if (j < a.N && i < a.chunk) a.S[((int64_t)c * a.chunk + i) * a.N + j] = acc0[r] + acc1[r];
+        }
+    } else {
+        // final scores, written through to the memory side (sc1): whichever workgroup of the strip arrives last reads them
+        float bsq = 0.f;
+        if constexpr (AM == 1) {             // the four quarter rows of column j sit in lanes m, m + 16, m + 32, m + 48
+            bsq = bs0 + bs1;
+            bsq += __shfl_xor(bsq, 16);
+            bsq += __shfl_xor(bsq, 32);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = it * 16 + q * 4 + r;
+            float x = acc0[r] + acc1[r];
+            if constexpr (AM == 1) x = a.gamma - sqrtf(fmaxf(fmaf(-2.f, x, Aq[q * 4 + r] + bsq), 1e-30f));   // score_fun.py:26-34
+            if (j < a.N && i < a.chunk)
+                __hip_atomic_store(a.S + ((int64_t)c * a.chunk + i) * a.N + j, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    }   // tile_ok
+    if constexpr (LF) {
+        // ---- hand-off: every workgroup of the strip (16 positives of chunk c) draws a ticket; the last one runs the loss rows ----
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wavefront's score stores have been acknowledged
+        __syncthreads();
+        int *lastw = reinterpret_cast<int *>(Aq + 16);
+        if (threadIdx.x == 0) {
+            int *tk = tickets + (c * ti + it);
+            const int old = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = old == tjg - 1;
+            if (last) __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // ready for the next step
+            else if (old < 0 || old >= tjg) __builtin_trap();         // the caller did not hand over zeroed tickets
+            *lastw = last;
+        }
+        __syncthreads();
+        if (!*lastw) return;
+        LossArgs la = *lap;
+        if constexpr (LLEAN) loss_args_lean(la);
+        constexpr int NPER = 4;                   // N <= 256 (checked by the launcher)
+        const int N = la.N;
+        const int row0 = it * 16 + wv * 4;        // this wavefront's four rows of the strip
+        // all four rows requested together, L1-bypassing (the lines were written by other CUs - possibly other XCDs - during this
+        // launch); indices clamped instead of predicated (no branch joins in front of the waits)
+        float nv[4][NPER];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t gi = (int64_t)c * a.chunk + min(row0 + r, a.chunk - 1);
+#pragma unroll
+            for (int u = 0; u < NPER; ++u)
+                nv[r][u] = __hip_atomic_load(a.S + gi * N + min(lane + 64 * u, N - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        float wr[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wr[r] = la.w ? la.w[(int64_t)c * a.chunk + min(row0 + r, a.chunk - 1)] : 1.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (row0 + r < a.chunk) {             // (wave-uniform)
+                const int64_t gi = (int64_t)c * a.chunk + row0 + r;
+#pragma unroll
+                for (int u = 0; u < NPER; ++u) if (lane + 64 * u >= N) nv[r][u] = 0.f;
+                // the edge half of this launch adds the row's positive share to slot gi of the running total: this half takes
+                // the slot B further on (one add per slot and launch keeps the sums order-independent while 2 B <= KGE_ACC_SLOTS)
+                loss_row_regs<NPER>(la, gi, nv[r], wr[r], 0.f, lane, (int)((gi + la.B) & (KGE_ACC_SLOTS - 1)));
+            }
+        }
     }
 }
 
@@ -537,6 +631,20 @@ __global__ __launch_bounds__(KGE_BLOCK) void neg_fwd_edge_kernel(GemmArgs a, int
         if constexpr (LDSA) neg_fwd_gemm_ldsa_body<AM>(a, ti, tj, (int)blockIdx.x, nbG, smem);
         else if constexpr (KGE_FWD_NB == 1) neg_fwd_gemm_body<L2, false, AM>(a, ti, tj, (int)blockIdx.x, nbG);
         else neg_fwd_gemm_wide_body<AM, KGE_FWD_NB>(a, ti, (tj + KGE_FWD_NB - 1) / KGE_FWD_NB, (int)blockIdx.x, nbG);
+    } else {
+        KGE_TL(0);
+        edge_fwd_body<MODEL, 4, LEAN>(e, (int)blockIdx.x - nbG);
+    }
+}
+
+// round 4: the same launch with the loss rows inside (LF tiles, see neg_fwd_gemm_ldsa_body) - the strict step's first of THREE launches
+template <int AM, int MODEL, bool LEAN>
+__global__ __launch_bounds__(KGE_BLOCK) void neg_fwd_loss_edge_kernel(GemmArgs a, int ti, int tj, int nbG, EdgeFwdArgs e, LossArgs la,
+                                                                      int *tickets) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    if ((int)blockIdx.x < nbG) {
+        KGE_TL(1);
+        neg_fwd_gemm_ldsa_body<AM, true, LEAN>(a, ti, tj, (int)blockIdx.x, nbG, smem, &la, tickets);
     } else {
         KGE_TL(0);
         edge_fwd_body<MODEL, 4, LEAN>(e, (int)blockIdx.x - nbG);
@@ -576,6 +684,41 @@ int launch_neg_fwd_gemm_with_edge(const GemmArgs &a, const EdgeFwdArgs &e, hipSt
     else KGE_FE(false, 2, KGE_DISTMULT);
 #undef KGE_FE
 #undef KGE_FE2
+    return check_launch_g();
+}
+
+// loss rows inside the first launch: LDS-tile instance only, one register-resident score row per wavefront (N <= 256), every
+// strip's block of S on its own 128-byte lines (a line shared by two strips could be cached by one strip's reader before the
+// other strip's tiles have written their part), ticket words for every strip
+bool neg_fwd_loss_fold_supported(int model, int C, int chunk, int N, int d_e, int d_r) {
+    if (!neg_fwd_gemm_with_edge_supported(model, d_e, d_r) || fwd_lds_bytes_lf(d_e) > 64 * 1024) return false;
+    if (N > 256 || (N & 1) || (((int64_t)chunk * N) & 31)) return false;
+    return (int64_t)C * ((chunk + 15) / 16) <= KGE_TICKET_INTS;
+}
+
+int launch_neg_fwd_gemm_with_edge_loss(const GemmArgs &a, const EdgeFwdArgs &e, const LossArgs &la, int *tickets, hipStream_t s) {
+    if (a.C == 0 || a.PM || !a.xbase || !a.rbase || !a.xidx || !a.ridx || !tickets || a.lds_off) return KGE_ERR_ARG;
+    if (!neg_fwd_loss_fold_supported(a.model, a.C, a.chunk, a.N, a.D, e.d_r) || e.model != a.model || e.d_e != a.D) return KGE_ERR_ARG;
+    if (e.src.em.n || e.src.rm.n || e.nd_own || la.pairwise || !la.skip_pos || la.l2_raw || la.diag_chunk > 0 || la.neg != a.S ||
+        la.dneg != a.S || la.N != a.N || la.B != a.C * a.chunk) return KGE_ERR_ARG;
+    const bool negjob = e.bsq || e.Bn;
+    const int64_t waves = (int64_t)e.B + (negjob ? e.n_neg : 0);
+    EdgeFwdArgs ee = e;
+    if (!negjob) ee.n_neg = 0;
+    const int nbP = (int)((waves + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK);
+    const int ti = (a.chunk + 15) / 16, tj = (a.N + 15) / 16;
+    const size_t lds = fwd_lds_bytes_lf(a.D);
+    const int nbG = a.C * ti * ((tj + 3) / 4);
+    // ONE lean switch for both halves: Logsigmoid, no per-step outputs
+    const bool lean = e.lp.genre == KGE_LOSS_LOGSIGMOID && !e.row_pos && !e.Hc &&
+                      la.genre == KGE_LOSS_LOGSIGMOID && la.clampv == 0.f && !la.neg_copy && !la.row_pos && !la.row_neg;
+    const dim3 g(nbG + nbP), b(KGE_BLOCK);
+#define KGE_FL(AM_, M_) do { if (lean) hipLaunchKernelGGL((neg_fwd_loss_edge_kernel<AM_, M_, true>), g, b, lds, s, a, ti, tj, nbG, ee, la, tickets); \
+                             else hipLaunchKernelGGL((neg_fwd_loss_edge_kernel<AM_, M_, false>), g, b, lds, s, a, ti, tj, nbG, ee, la, tickets); } while (0)
+    if (a.model == KGE_COMPLEX) KGE_FL(3, KGE_COMPLEX);
+    else if (a.model == KGE_TRANSE_L2) KGE_FL(1, KGE_TRANSE_L2);
+    else KGE_FL(2, KGE_DISTMULT);
+#undef KGE_FL
     return check_launch_g();
 }
 

@@ -11,6 +11,7 @@
 #include "kge_common.hpp"
 #include "kge_update_body.hpp"
 #include "kge_edge_fwd_body.hpp"
+#include "kge_loss_body.hpp"
 
 using namespace kge;
 KGE_TL_DEFINE(rowwise)
@@ -482,7 +483,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void loss_kernel(LossArgs a) {
             const bool uq = a.B <= KGE_ACC_SLOTS;
             if (!a.skip_pos) acc_add(&a.acc[0 * KGE_ACC_SLOTS + slot], plw, uq);
             acc_add(&a.acc[1 * KGE_ACC_SLOTS + slot], acc, uq);
-            acc_add(&a.acc[2 * KGE_ACC_SLOTS + slot], 0.5f * (plw + acc), uq);
+            acc_add(&a.acc[2 * KGE_ACC_SLOTS + (int)((a.skip_pos ? i + a.B : i) & (KGE_ACC_SLOTS - 1))], 0.5f * (plw + acc), uq);
         }
     }
 }
@@ -493,21 +494,17 @@ __global__ __launch_bounds__(KGE_BLOCK) void loss_kernel(LossArgs a) {
 // criterion switch, the pairwise variant and the option handling (2.1 k instructions vs ~0.7 k)
 // RAW: the row holds the raw products a_i . b_j of the merged forward launch (LossArgs::l2_raw): the TransE_l2 score
 // gamma - sqrt(|a_i|^2 + |b_j|^2 - 2 a_i.b_j) is rebuilt here, from one more coalesced row of |b|^2 requested with the scores
+// (the arithmetic on the register-resident row lives in kge_loss_body.hpp: the forward tiles' last arriver runs the same code)
 template <int NPER, bool LEAN, bool RAW>
 __global__ __launch_bounds__(KGE_BLOCK) void loss_kernel_reg(LossArgs a_in) {
     KGE_TL(2);
     LossArgs a = a_in;
-    if constexpr (LEAN) {
-        a.genre = KGE_LOSS_LOGSIGMOID; a.pairwise = 0; a.skip_pos = 1; a.clampv = 0.f; a.neg_copy = nullptr;
-        a.row_pos = nullptr; a.row_neg = nullptr; a.diag_chunk = 0;
-    }
+    if constexpr (LEAN) loss_args_lean(a);
     const int64_t i = WAVE_ID();
     if (i >= a.B) return;
     const int lane = LANE();
     const int N = a.N;
     const float *n = a.neg + i * (int64_t)N;
-    float *dn = a.dneg + i * (int64_t)N;
-    float *cp = a.neg_copy ? a.neg_copy + i * (int64_t)N : nullptr;
     float nv[NPER];
     // neg_deg_sample: the positive edge itself sits in column i % chunk - score 0, no gradient
     const int jd = a.diag_chunk > 0 ? (int)(i % a.diag_chunk) : -1;
@@ -532,89 +529,12 @@ __global__ __launch_bounds__(KGE_BLOCK) void loss_kernel_reg(LossArgs a_in) {
 #ifdef KGE_TL_MARKS
     KGE_TL_MARK(0);              // score row, positive score, weight have arrived
 #endif
-    const float invB = 1.f / (float)a.B;
-    const int slot = (int)(i & (KGE_ACC_SLOTS - 1));
-    if (a.pairwise) {   // loss.py:76-80
-        const float sc = w / ((float)a.B * (float)N);
-        float lsum = 0.f, dsum = 0.f;
-#pragma unroll
-        for (int u = 0; u < NPER; ++u) {
-            const int j = lane + 64 * u;
-            if (j < N) {
-                float val, dv;
-                criterion_fast(a.genre, p - nv[u], 1.f, a.margin, val, dv);
-                lsum += val * sc;
-                const float dd = dv * sc;
-                dsum += dd;
-                if (cp) cp[j] = nv[u];
-                float g = -dd;
-                if (a.l2_scale) { const float d = a.gamma - nv[u]; g = d > 1e-15f ? g / d : 0.f; }
-                if (a.clampv > 0.f && fabsf(nv[u]) >= a.clampv) g = 0.f;
-                dn[j] = j == jd ? 0.f : g;
-            }
-        }
-        lsum = wave_sum(lsum);
-        dsum = wave_sum(dsum);
-        if (lane == 0) {
-            a.dpos[i] = (a.clampv > 0.f && fabsf(p) >= a.clampv) ? 0.f : dsum;
-            if (a.row_pos) { a.row_pos[i] = 0.f; a.row_neg[i] = lsum; }
-            if (a.acc) acc_add(&a.acc[2 * KGE_ACC_SLOTS + slot], lsum, a.B <= KGE_ACC_SLOTS);
-        }
-        return;
-    }
-    float plw = 0.f;
-    if (lane == 0 && !a.skip_pos) {
-        float pl, dpl;
-        criterion(a.genre, p, 1.f, a.margin, pl, dpl);
-        a.dpos[i] = (a.clampv > 0.f && fabsf(p) >= a.clampv) ? 0.f : dpl * w * 0.5f * invB;
-        plw = pl * w * invB;
-        if (a.row_pos) a.row_pos[i] = plw;
-    }
-    const float neg_label = a.genre == KGE_LOSS_BCE ? 0.f : -1.f;
-    float mx = -INFINITY, Z = 1.f;
-    float ex[NPER];
-    if (a.adv) {   // softmax(neg * T) over the row, detached (loss.py:87-88)
-#pragma unroll
-        for (int u = 0; u < NPER; ++u) if (lane + 64 * u < N) mx = fmaxf(mx, nv[u] * a.adv_temp);
-        mx = wave_max(mx);
-        float z = 0.f;
-#pragma unroll
-        for (int u = 0; u < NPER; ++u) {
-            ex[u] = (lane + 64 * u < N) ? __expf(nv[u] * a.adv_temp - mx) : 0.f;
-            z += ex[u];
-        }
-        Z = wave_sum(z);
-    }
-    const float invZ = 1.f / Z, invN = 1.f / (float)N;
-    float acc = 0.f;
-#pragma unroll
-    for (int u = 0; u < NPER; ++u) {
-        const int j = lane + 64 * u;
-        if (j < N) {
-            float nl, dnl;
-            criterion_fast(a.genre, nv[u], neg_label, a.margin, nl, dnl);
-            const float A = a.adv ? ex[u] * invZ : invN;
-            acc += A * nl * w;
-            float g = dnl * w * A * 0.5f * invB;
-            if (cp) cp[j] = nv[u];
-            if (a.l2_scale) { const float d = a.gamma - nv[u]; g = d > 1e-15f ? g / d : 0.f; }
-            if (a.clampv > 0.f && fabsf(nv[u]) >= a.clampv) g = 0.f;
-            dn[j] = j == jd ? 0.f : g;
-        }
-    }
-    acc = wave_sum(acc) * invB;
+    // (the row's share of the running total: when the positive share comes from edge_fwd, B slots further on than edge_fwd's add -
+    //  the same two adds as the strict step's in-launch loss rows, whose other half runs in the SAME launch)
+    loss_row_regs<NPER>(a, i, nv, w, p, lane, (int)((a.skip_pos ? i + a.B : i) & (KGE_ACC_SLOTS - 1)));
 #ifdef KGE_TL_MARKS
     KGE_TL_MARK(1);              // softmax, criterion, reductions done; gradient stores acknowledged
 #endif
-    if (lane == 0) {
-        if (a.row_neg) a.row_neg[i] = acc;
-        if (a.acc) {
-            const bool uq = a.B <= KGE_ACC_SLOTS;
-            if (!a.skip_pos) acc_add(&a.acc[0 * KGE_ACC_SLOTS + slot], plw, uq);
-            acc_add(&a.acc[1 * KGE_ACC_SLOTS + slot], acc, uq);
-            acc_add(&a.acc[2 * KGE_ACC_SLOTS + slot], 0.5f * (plw + acc), uq);
-        }
-    }
 }
 
 int launch_loss(const LossArgs &a, hipStream_t s) {

@@ -6,13 +6,14 @@ with a non-CUDA tensor raises.
 """
 import ctypes as C
 import os
+import threading
 
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KGE_LIB") or os.path.join(_HERE, "libkge_hip.so")   # KGE_LIB: A/B builds
 
-KGE_ABI_VERSION = 5
+KGE_ABI_VERSION = 6
 MODEL_IDS = {"TransE_l1": 0, "TransE_l2": 1, "TransE": 1, "DistMult": 2, "ComplEx": 3, "RotatE": 4, "SimplE": 5, "RESCAL": 6, "TransR": 7}
 LOSS_IDS = {"Logsigmoid": 0, "Logistic": 1, "Hinge": 2, "BCE": 3}
 FLAG_FORCE_PAIRWISE = 1
@@ -24,6 +25,8 @@ FLAG_NEG_DEG_SAMPLE = 32
 FLAG_ASYNC_REL = 64
 FLAG_DENSE_BWD = 256        # merged first launch: backward GEMM reads a dense copy of the negative rows (A-B aid)
 FLAG_FWD_DIRECT = 512       # merged first launch: direct fragment loads instead of the LDS pos-side tile (A-B aid)
+FLAG_LOSS_IN_FWD = 1024     # strict step: LossGenerator inside the first launch (3 launches; opt-in: measured slower, A-B aid)
+TICKET_INTS = 4096          # kge_step_out.tickets: int32 words, zero when first handed over
 FLAG_SPLIT_FWD = 128        # strict step: edge-forward and forward GEMM as two launches (validation / A-B aid)
 PHASE_GATHER, PHASE_FORWARD, PHASE_BACKWARD, PHASE_UPDATE = 1, 2, 4, 8
 ACC_SLOTS = 4096
@@ -60,7 +63,7 @@ class KgeTables(C.Structure):
 
 class KgeStepOut(C.Structure):
     _fields_ = [("loss4", c_p), ("loss_accum", c_p), ("pos_score", c_p), ("neg_score", c_p),
-                ("g_pos_ent", c_p), ("g_neg", c_p), ("g_rel", c_p)]
+                ("g_pos_ent", c_p), ("g_neg", c_p), ("g_rel", c_p), ("tickets", c_p)]
 
 
 class KgeEmit(C.Structure):
@@ -182,21 +185,23 @@ def ptr(t):
     return t.data_ptr()
 
 
-_STREAM_OVERRIDE = None
+_STREAM_TLS = threading.local()       # per-thread: trainer lanes / evaluation threads keep their own streams
 
 
 def stream_ptr():
-    """the stream the library calls are enqueued on: torch's current stream, or the one set by use_stream()"""
-    if _STREAM_OVERRIDE is not None:
-        return _STREAM_OVERRIDE
+    """the stream the library calls are enqueued on: torch's current stream, or the one set by use_stream() IN THIS THREAD"""
+    ov = getattr(_STREAM_TLS, "ptr", None)
+    if ov is not None:
+        return ov
     return torch.cuda.current_stream().cuda_stream
 
 
 def use_stream(ptr):
-    """make every following library call go to the HIP stream `ptr` (None: back to torch's current stream).  A cheap
-    stand-in for `with torch.cuda.stream(...)` around ctypes calls (dist.DistEngine's pull pipeline); returns the previous value."""
-    global _STREAM_OVERRIDE
-    prev, _STREAM_OVERRIDE = _STREAM_OVERRIDE, ptr
+    """make every following library call OF THE CALLING THREAD go to the HIP stream `ptr` (None: back to torch's current
+    stream).  A cheap stand-in for `with torch.cuda.stream(...)` around ctypes calls (dist.DistEngine's pull pipeline);
+    returns the previous value."""
+    prev = getattr(_STREAM_TLS, "ptr", None)
+    _STREAM_TLS.ptr = ptr
     return prev
 
 

@@ -196,7 +196,13 @@ def make_comm(group=None, kind=None):
         if int(flag.item()) == 0 and comm is not None:
             comm.close()
             comm = None
-    return comm if comm is not None else TorchComm(group)
+    if comm is not None:
+        return comm
+    # the c10d wrappers need a backend that moves device tensors (nccl = RCCL); a host-side (gloo) group - the CLI's - carries the
+    # messages through host copies instead (gloo's all_to_all takes CPU tensors only)
+    if world > 1 and dist.get_backend(group) == "gloo":
+        return HostStagedComm(group)
+    return TorchComm(group)
 
 
 class LocalBatch(object):
@@ -264,6 +270,7 @@ class HipOps(object):
             em.ent_by_id = 1
             out = _lib.KgeStepOut()
             out.loss_accum = _lib.ptr(engine.loss_accum)
+            out.tickets = _lib.ptr(engine.tickets)
             if not hasattr(self, "_structs"):
                 self._structs = {}
             st = self._structs[key] = (tb, em, out)
@@ -417,6 +424,10 @@ class DistEngine(object):
             _, lb, ev_rows = self._pre
             main.wait_event(ev_rows)
         else:
+            if self._pre is not None:
+                # a pull that ran ahead for ANOTHER batch is dropped: the side stream may still be filling its slot (and using the
+                # communicator) - the fresh pull below must start behind it
+                main.wait_event(self._pre[2])
             lb = self.pull(batch, self._parity)
         self._pre = None
         ev_gather = None

@@ -77,6 +77,8 @@ class StepEngine(object):
         self.loss4 = torch.zeros(4, dtype=torch.float32, device=self.device)
         self.loss_accum = torch.zeros(4 * _lib.ACC_SLOTS, dtype=torch.float32, device=self.device)
         self._sum4 = torch.zeros(4, dtype=torch.float32, device=self.device)
+        # hand-off words of the strict step's first launch (kge_step_out.tickets): zero now, every step returns them to zero
+        self.tickets = torch.zeros(_lib.TICKET_INTS, dtype=torch.int32, device=self.device)
         self._ws = None
         self._ws_bytes = 0
         self._graphs = 0               # graphs captured with this engine's workspace baked in (the workspace may not move then)
@@ -130,6 +132,7 @@ class StepEngine(object):
         if want is not None or per_step_loss:
             out.loss4 = ptr(self.loss4)
         out.loss_accum = ptr(self.loss_accum)
+        out.tickets = ptr(self.tickets)
         if want:
             for k, t in want.items():
                 setattr(out, k, ptr(t))

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define KGE_ABI_VERSION 5
+#define KGE_ABI_VERSION 6
 
 /* score functions (models/general_models.py:248-268 model_name strings) */
 enum kge_model {
@@ -106,6 +106,14 @@ enum kge_status {
 /* merged first launch: forward tiles with direct fragment loads of x, r and b (three gathered loads per k-step) instead of the
  * pos-side tile built once per workgroup in LDS (tuning / A-B aid) */
 #define KGE_FLAG_FWD_DIRECT 512u
+
+/* strict step, TransE_l2 / DistMult / ComplEx on the merged first launch, kge_step_out.tickets given: run LossGenerator INSIDE
+ * that launch (3 launches per step): the forward tiles store final scores write-through, the workgroups of a 16-row strip draw
+ * an arrival ticket and the last one runs the strip's loss rows.  Opt-in: measured SLOWER on MI355X (34.6 vs 30.6 us per cfg-T
+ * step, profiles/r04_loss_fold.txt - the last arrivers' four wavefronts run 16 loss rows where the loss launch runs one row per
+ * wavefront, and drain + ticket + re-read cost what the launch boundary costs).  DistMult / ComplEx results are bit-identical to
+ * the 4-launch step, TransE_l2 equal within the rounding of |a|^2, |b|^2 (summed by the tiles instead of by edge_fwd). */
+#define KGE_FLAG_LOSS_IN_FWD 1024u
 
 int         kge_abi_version(void);
 const char *kge_last_error(void);
@@ -252,9 +260,15 @@ typedef struct kge_step_out {
     float *g_pos_ent;  /* [UE, d_e] trace-0 gradient per union entry (0 if not a pos node)   */
     float *g_neg;      /* [C*N, d_e]  trace-1 gradient                                       */
     float *g_rel;      /* [B, d_r]    relation-trace gradient                                */
+    int32_t *tickets;  /* [KGE_TICKET_INTS] hand-off words of KGE_FLAG_LOSS_IN_FWD (ABI 6): ZERO when    */
+                       /* first handed over, returned to zero by every step; one array per stream of */
+                       /* steps (concurrent steps must not share it).  NULL: the flag is ignored.    */
+                       /* A step that finds a word outside [0, workgroups per strip) traps           */
+                       /* (hipErrorLaunchFailure at the next synchronisation).                        */
 } kge_step_out;
 
 #define KGE_ACC_SLOTS 4096
+#define KGE_TICKET_INTS 4096
 /* out4 = per-quantity sums of the running-sum slots (divide by the number of steps for the
  * averages the reference prints, train_pytorch.py:165-167); optionally zero the slots. */
 int kge_reduce_loss(float *loss_accum, float *out4, int zero_after, void *stream);

@@ -1,7 +1,10 @@
 """worker of tests/test_gpu_dist.py: one of `world` processes sharing ONE GPU; the device arithmetic of the range-sharded step
 (dglke_amd.dist.HipOps: kge_route_build, kge_gather_rows_req, kge_step_grads, kge_adagrad_apply_merged) runs for real, the
 fixed-size messages travel through gloo (staged through the host: RCCL refuses two ranks on one device).
-argv: rank world port out_dir mode"""
+With a 6th argument "rccl" every rank takes its OWN device (cuda:rank) and the messages travel through the real transport of the
+product - dist.make_comm(): librccl called directly on the step's streams (RcclComm), the push grouped, the pull on the side
+stream - which needs >= world GPUs (tests/test_gpu_dist.py skips it on a one-GPU box).
+argv: rank world port out_dir mode [transport]"""
 import os
 import sys
 
@@ -41,12 +44,17 @@ def batches(world, steps, mode, seed=5):
 
 def main():
     rank, world, port, out_dir, mode = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5]
+    transport = sys.argv[6] if len(sys.argv) > 6 else "host"
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", port
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from dglke_amd import dist as kd, plan
     from dglke_amd.engine import StepEngine
-    dev = "cuda:0"
-    torch.cuda.set_device(0)
+    dev = "cuda:%d" % (rank if transport == "rccl" else 0)
+    torch.cuda.set_device(torch.device(dev))
+    comm = None
+    if transport == "rccl":
+        comm = kd.make_comm(kind="rccl")
+        assert type(comm).__name__ == "RcclComm", "the direct librccl communicator could not be set up: %r" % (comm,)
     res = {}
     for model, de_, dr_ in MODELS:
         d_e = 2 * HID if de_ else HID
@@ -58,7 +66,7 @@ def main():
         spec = kd.ShardSpec(N_ENT, world, rank)
         ent = ent0[spec.lo:spec.hi].to(dev).contiguous()
         state = torch.zeros(spec.n_local, device=dev)
-        de = kd.DistEngine(eng, spec, ent, state, comm=kd.HostStagedComm(), cap=None, slack=1.6)
+        de = kd.DistEngine(eng, spec, ent, state, comm=comm or kd.HostStagedComm(), cap=None, slack=1.6)
         bts = batches(world, STEPS, "disjoint" if mode == "disjoint" else "random")
         ue_bound = 2 * B + (B // N) * N
         devb = []
@@ -95,6 +103,9 @@ def main():
                                                          if not isinstance(v, list)},
                  **{m + "_rel%d" % i: r for m, d in res.items() for i, r in enumerate(d["rels"])},
                  **{m + "_relstate%d" % i: r for m, d in res.items() for i, r in enumerate(d["rel_states"])})
+    if comm is not None and hasattr(comm, "close"):
+        torch.cuda.synchronize()
+        comm.close()
     dist.destroy_process_group()
 
 

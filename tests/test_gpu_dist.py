@@ -120,11 +120,11 @@ def test_apply_merged_equals_sequential_apply(nsrc, cap, dim, n_rows):
     assert torch.equal(t2, t_d) and torch.equal(s2, s_d)
 
 
-def _run_workers(tmp_path, mode, world=2):
-    port = str(29700 + os.getpid() % 250 + {"random": 0, "disjoint": 1, "pipelined": 2}[mode])
+def _run_workers(tmp_path, mode, world=2, transport="host"):
+    port = str(29700 + os.getpid() % 250 + {"random": 0, "disjoint": 1, "pipelined": 2}[mode] + (3 if transport == "rccl" else 0))
     env = dict(os.environ)
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), str(r), str(world), port, str(tmp_path), mode],
-                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), str(r), str(world), port, str(tmp_path), mode,
+                               transport], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
     outs = []
     for p in procs:
         try:
@@ -161,10 +161,15 @@ def _oracle_statement(model, de_, dr_, z, world, mode):
     return ent, es, rel, rs
 
 
-@pytest.mark.parametrize("mode", ["random", "pipelined"])
-def test_world2_hip_ops_match_the_oracle_statement(tmp_path, mode):
+@pytest.mark.parametrize("mode,transport", [("random", "host"), ("pipelined", "host"), ("random", "rccl"), ("pipelined", "rccl")])
+def test_world2_hip_ops_match_the_oracle_statement(tmp_path, mode, transport):
+    """`host`: two processes on ONE device, messages staged through gloo.  `rccl`: two processes on TWO devices, the product's
+    transport - dist.RcclComm (ncclAllToAll / ncclAllGather on the step's streams, grouped push, side-stream pull) - against
+    the same fp64 statement: what a multi-GPU box checks before it benches (skipped when there is one GPU)."""
     import dist_worker as W
-    z = _run_workers(tmp_path, mode)
+    if transport == "rccl" and torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
+    z = _run_workers(tmp_path, mode, transport=transport)
     for model, de_, dr_ in W.MODELS:
         ent, es, rel, rs = _oracle_statement(model, de_, dr_, z, 2, mode)
         lr = W.LR

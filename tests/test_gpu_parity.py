@@ -295,6 +295,106 @@ def test_merged_forward_launch_equals_split_launches_bit_for_bit(model, gamma, d
     assert np.isfinite(results[0][4]).all()
 
 
+def _run_steps(model, gamma, dbl, D, flags, plans, n_ent, n_rel, lr=0.25, graph=False, replays=1, scores=True, background=None):
+    from dglke_amd import plan
+    from dglke_amd.engine import StepEngine
+    torch.manual_seed(0)
+    eng = StepEngine(model, n_ent, n_rel, D, gamma, lr, DEV, dbl, dbl, True, 1.0, 1e-9, 3, flags=flags)
+    batches = plan.upload(plans, DEV)
+    sc = []
+    if graph:
+        eng.workspace_for(batches[0])
+        g = eng.capture(batches)
+        if background is not None:
+            background(True)
+        for _ in range(replays):
+            g.replay()
+        if background is not None:
+            background(False)
+    else:
+        for b in batches:
+            want = dict(neg_score=torch.empty(b.C, b.chunk, b.N, device=DEV)) if scores else None
+            eng.step(b, want)
+            if scores:
+                sc.append(want["neg_score"].cpu().numpy().copy())
+    torch.cuda.synchronize()
+    assert int(eng.tickets.abs().max().item()) == 0, "hand-off tickets not returned to zero"
+    return (eng.ent.cpu().numpy().copy(), eng.rel.cpu().numpy().copy(), eng.ent_state.cpu().numpy().copy(),
+            eng.rel_state.cpu().numpy().copy(), np.array(eng.read_loss_sums()), np.stack(sc) if sc else np.zeros(1))
+
+
+@pytest.mark.parametrize("model,gamma,dbl,D,B,N", [("TransE_l2", 19.9, False, 400, 1000, 200), ("DistMult", 143.0, False, 400, 1000, 200),
+                                                   ("ComplEx", 143.0, True, 200, 1024, 256), ("TransE_l2", 19.9, False, 400, 1000, 40),
+                                                   ("DistMult", 143.0, False, 100, 192, 96)])
+def test_loss_rows_inside_the_first_launch_equal_the_loss_launch(model, gamma, dbl, D, B, N):
+    """round 4, KGE_FLAG_LOSS_IN_FWD: the strict step as THREE launches - the forward tiles store final scores, every workgroup of
+    a 16-row strip draws a ticket and the last one runs LossGenerator on the strip's rows (kge_neg_gemm.hip,
+    neg_fwd_loss_edge_kernel) - against the default 4-launch sequence (same tiles, raw products, stand-alone loss kernel).
+    DistMult / ComplEx: the same instructions on the same values - scores, tables, states and loss sums bit for bit.  TransE_l2:
+    |a|^2 and |b|^2 of the distance are summed by the tiles in another order than by edge_fwd - equal within that rounding.  With
+    and without per-step outputs (the LEAN and the generic instance), both corruption modes, the dense-backward variant.
+    (Opt-in: correct, and slower than the loss launch - profiles/r04_loss_fold.txt.)"""
+    from dglke_amd import plan, _lib
+    rng = np.random.RandomState(19)
+    n_ent, n_rel, lr = 14951, 1345, 0.25
+    plans = []
+    for step in range(1, 5):
+        bt = O.synth_batch(rng, n_ent, n_rel, B, N, N, step)
+        plans.append(plan.build_plan(bt["h"], bt["t"], bt["r"], bt["neg"], N, N, bt["neg_head"]))
+    LF = _lib.FLAG_LOSS_IN_FWD
+    for with_scores in (True, False):
+        ref = _run_steps(model, gamma, dbl, D, 0, plans, n_ent, n_rel, lr, scores=with_scores)
+        for flags in (LF, LF | _lib.FLAG_DENSE_BWD):
+            got = _run_steps(model, gamma, dbl, D, flags, plans, n_ent, n_rel, lr, scores=with_scores)
+            for k in range(6):
+                if model == "TransE_l2":
+                    tol = 1e-4 * lr if k < 2 else 2e-5 * np.abs(ref[k]).max()       # (rows: the per-step error bound of the step itself)
+                    err = np.abs(got[k] - ref[k]).max()
+                    assert err <= tol, \
+                        "TransE_l2 flags %d output %d: in-launch loss rows differ from the loss launch by %.3e" % (flags, k, err)
+                else:
+                    assert np.array_equal(got[k], ref[k]), "%s flags %d output %d differs from the loss launch" % (model, flags, k)
+        assert np.isfinite(ref[4]).all() and np.abs(ref[0]).max() > 0
+
+
+@pytest.mark.parametrize("model,gamma,dbl,D", [("TransE_l2", 19.9, False, 400), ("DistMult", 143.0, False, 400)])
+def test_in_launch_hand_off_under_load_and_replay(model, gamma, dbl, D):
+    """the hand-off of the 3-launch step (KGE_FLAG_LOSS_IN_FWD; write-through score stores -> ticket -> L1-bypassing loads by the last arriver) must
+    hold on a busy chip and with warm caches: 40 graph replays of 6 steps (every replay re-uses the same score lines) while a
+    second stream streams 256 MB copies, twice - bit-identical tables, states and loss sums run to run, and (DistMult: bit for
+    bit; TransE_l2: within rounding) equal to the 4-launch sequence run without the load."""
+    from dglke_amd import plan, _lib
+    rng = np.random.RandomState(23)
+    n_ent, n_rel, B, N, lr = 14951, 1345, 1000, 200, 0.25
+    plans = []
+    for step in range(1, 7):
+        bt = O.synth_batch(rng, n_ent, n_rel, B, N, N, step)
+        plans.append(plan.build_plan(bt["h"], bt["t"], bt["r"], bt["neg"], N, N, bt["neg_head"]))
+    side = torch.cuda.Stream()
+    big_a = torch.empty(64 << 20, dtype=torch.float32, device=DEV)
+    big_b = torch.empty(64 << 20, dtype=torch.float32, device=DEV)
+
+    def background(start):
+        if start:
+            with torch.cuda.stream(side):
+                for _ in range(12):
+                    big_b.copy_(big_a)
+                    big_a.copy_(big_b)
+        else:
+            side.synchronize()
+    ref = _run_steps(model, gamma, dbl, D, 0, plans, n_ent, n_rel, lr, graph=True, replays=40)
+    runs = [_run_steps(model, gamma, dbl, D, _lib.FLAG_LOSS_IN_FWD, plans, n_ent, n_rel, lr, graph=True, replays=40, background=background)
+            for _ in range(2)]
+    for k in range(5):
+        assert np.array_equal(runs[0][k], runs[1][k]), "3-launch step under load: run-to-run difference in output %d" % k
+        if model == "DistMult":
+            assert np.array_equal(runs[0][k], ref[k]), "3-launch step under load differs from the 4-launch step in output %d" % k
+        else:
+            tol = 1e-3 * lr if k < 2 else 1e-3 * np.abs(ref[k]).max()     # (240 steps: rounding differences compound)
+            assert np.abs(runs[0][k] - ref[k]).max() <= tol, "output %d: %.3e" % (k, np.abs(runs[0][k] - ref[k]).max())
+    assert np.isfinite(ref[4]).all()
+
+
 @pytest.mark.parametrize("model,de_,B,N,hidden,gamma,lr", [("RotatE", True, 1024, 256, 200, 12.0, 0.009),
                                                            ("TransE_l1", False, 1000, 200, 400, 16.0, 0.01)])
 def test_pairwise_fused_launches_equal_separate_launches_bit_for_bit(model, de_, B, N, hidden, gamma, lr):
