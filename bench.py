@@ -323,6 +323,49 @@ def skew_measure(w, dev, steps, G, flags, seed=0):
                    "hub entity ~1 % of the heads / tails (FB15k's proportions)"}
 
 
+def other_configs(steps=600, timeout_s=150.0, only=None):
+    """BASELINE.json configs[2..4] at N = 1, each as a bounded leg in its OWN process (a leg that fails or hangs can never hide
+    `value`; its tables - 4 GB for wikikg2, 34 GB for the Freebase shard - are gone when it returns): the strict step of
+    DistMult FB15k, ComplEx on the real 2 500 604-entity wikikg2 table, and cfg-R's per-GPU step (RotatE hidden 400 -de over one
+    10 756 769-row shard of the Freebase entity table) through the all-to-all engine at world 1 and through the peer-to-peer shard
+    map.  Every entry: us_per_step, edges_per_s, the algorithmic bytes of its step and the fraction of the 8 TB/s roofline."""
+    import subprocess
+    legs = [("distmult_fb15k", ["--workload", "distmult_fb15k"], {}),
+            ("complex_wikikg2", ["--workload", "complex_wikikg2"], {}),
+            ("rotate_freebase_a2a", ["--workload", "rotate_freebase"], {"KGE_DIST_MODE": "a2a"}),
+            ("rotate_freebase_p2p", ["--workload", "rotate_freebase"], {"KGE_DIST_MODE": "p2p"})]
+    res = {}
+    for name, extra, env_extra in legs:
+        if only is not None and name not in only:
+            continue
+        env = dict(os.environ)
+        env.update(env_extra)
+        env.update({"KGE_DIST_OTHER_LEG": "0", "WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0",
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(29600 + (os.getpid() + len(res)) % 300)})
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps), "--warmup", str(min(120, steps)),
+               "--no-cpu-baseline", "--hogwild", "0", "--no-async-update", "--no-configs"] + extra
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s, text=True)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not line:
+                res[name] = {"error": "exit %d: %s" % (r.returncode, (r.stderr or "")[-300:])}
+                continue
+            d = json.loads(line[-1])
+            rf = d.get("roofline", {})
+            res[name] = {"us_per_step": round(1e3 * d["ms_per_step"], 3), "edges_per_s": d["value"], "steps": d["steps"],
+                         "algorithmic_bytes_per_step": rf.get("algorithmic_bytes_per_step", rf.get("algorithmic_bytes_per_rank_step")),
+                         "frac": rf.get("frac"), "mean_loss": d.get("mean_loss"),
+                         "leg_wall_s": round(time.perf_counter() - t0, 1)}
+            if "mode" in d.get("config", {}):
+                res[name]["mode"] = d["config"]["mode"]
+        except subprocess.TimeoutExpired:
+            res[name] = {"error": "leg exceeded %.0f s" % timeout_s}
+        except Exception as e:  # noqa: BLE001 - a leg must never hide the headline
+            res[name] = {"error": repr(e)}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -346,6 +389,12 @@ def main():
                          "same stream (default), concurrently on a second stream, or on a forked branch of the group's hipGraph - the "
                          "concurrent modes make the steps 3.5 us slower each on ROCm 7.0 (profiles/r03_merged_fwd.txt)")
     ap.add_argument("--hogwild", type=int, default=4, help="also measure K concurrent Hogwild trainers (0 = skip)")
+    ap.add_argument("--no-configs", dest="configs", action="store_false",
+                    help="skip the bounded legs of BASELINE configs[2..4] (the `configs` object of the default line)")
+    ap.add_argument("--min-untimed", type=int, default=120,
+                    help="steps run back to back right in front of the timed region: max(--warmup, this).  The first ~250 us of step "
+                         "kernels after a pause of the queue run ~50 us late (clock ramp of the idle GPU, "
+                         "profiles/r03_v2_driver_shape.txt); 0 = exactly --warmup steps")
     ap.add_argument("--no-async-update", dest="async_update", action="store_false",
                     help="skip the --async_update pipeline measurement (reported as its own object)")
     args = ap.parse_args()
@@ -406,7 +455,8 @@ def main():
 
         def sizes(count):
             return [G] * (count // G) + ([count % G] if count % G else [])
-        seq_w, seq_t = sizes(args.warmup), sizes(args.steps)
+        n_warm = max(args.warmup, args.min_untimed)
+        seq_w, seq_t = sizes(n_warm), sizes(args.steps)
         seq = seq_w + seq_t
         pg = PrefetchedGroups(smp, eng.step, group_max=G, mode=args.sampler_mode)
 
@@ -430,6 +480,10 @@ def main():
         launch_desc = (("hipGraph of %d steps; sampler launch for the next group: %s" % (G, {
             "streams": "concurrently on a second stream", "fork": "on a forked branch of the graph",
             "serial": "serially behind the group's steps"}[args.sampler_mode])) if use_graph else "eager, sampler mode " + args.sampler_mode)
+        launch_desc += ("; untimed before the timed region: %s%d warm-up steps (max(--warmup %d, --min-untimed %d): the GPU's clocks "
+                        "have ramped when the one synchronise opens the timed region)"
+                        % (("a dry run of the whole schedule (%d steps, graph capture), then fresh parameters and " % (n_warm + args.steps))
+                           if use_graph else "", n_warm, args.warmup, args.min_untimed))
         data_desc = ("triples in HBM; batch ids, negatives and plan built ON THE DEVICE inside the timed region "
                      "(double-buffered: group g+1 is sampled while group g trains)")
     else:
@@ -458,7 +512,8 @@ def main():
                 count -= n
             return items, pos
 
-        warm_items, pos = schedule(0, args.warmup)
+        n_warm = max(args.warmup, args.min_untimed)
+        warm_items, pos = schedule(0, n_warm)
         timed_items, pos = schedule(pos, args.steps)
         if use_graph:
             eng.step(batches[0])
@@ -560,6 +615,10 @@ def main():
             out["heavy_tailed_ids"] = skew_measure(w, dev, min(K, 1200), G, eng.hp.flags)
         except Exception as e:
             out["heavy_tailed_ids"] = {"error": repr(e)}
+    if args.configs and args.workload == "transe_l2_fb15k" and not args.skew and not args.flags:
+        del eng                        # (the legs run in their own processes; the 34-GB shard needs the HBM this one holds)
+        torch.cuda.empty_cache()
+        out["configs"] = other_configs()
     if not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(w, plans)

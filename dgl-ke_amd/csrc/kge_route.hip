@@ -88,6 +88,34 @@ __global__ __launch_bounds__(RT_THREADS) void route_build_kernel(RouteArgs a) {
     }
 }
 
+// largest owner-bucket fill over a GROUP of batches (one workgroup per batch; batch k's sorted id array / counts sit `stride` bytes
+// behind batch k-1's - consecutive slots of the device sampler - or there is one batch).  The caller reads the word once per group,
+// BEFORE the group's steps run, and grows the bucket capacity when needed: no entry ever trains against the dump row.
+__global__ __launch_bounds__(RT_THREADS) void route_fill_kernel(const char *ue0, const char *cnt0, int64_t stride, int UEmax, int world,
+                                                                int64_t per, int32_t *max_fill) {
+    __shared__ int start[RT_MAX_WORLD + 1];
+    const int t = threadIdx.x;
+    const int64_t *ue_id = reinterpret_cast<const int64_t *>(ue0 + (int64_t)blockIdx.x * stride);
+    const int cnt = cnt0 ? min(reinterpret_cast<const int32_t *>(cnt0 + (int64_t)blockIdx.x * stride)[0], UEmax) : UEmax;
+    const bool small = per < 0x7fffffffLL && (per * world) < 0x7fffffffLL;
+    auto owner_of = [&](int64_t id) -> int {
+        return small ? (int)((uint32_t)id / (uint32_t)per) : (int)(id / per);
+    };
+    for (int o = t; o <= world; o += RT_THREADS) start[o] = cnt;
+    __syncthreads();
+    for (int u = t; u < cnt; u += RT_THREADS) {
+        const int o = owner_of(ue_id[u]);
+        const int op = u ? owner_of(ue_id[u - 1]) : -1;
+        for (int k = op + 1; k <= o && k < world; ++k) start[k] = u;
+    }
+    __syncthreads();
+    // (ids beyond the last shard's range belong to the last owner, like in route_build_kernel)
+    for (int o = t; o < world; o += RT_THREADS) {
+        const int hi = o + 1 < world ? start[o + 1] : cnt;
+        atomicMax(max_fill, hi - start[o]);
+    }
+}
+
 template <int V>
 __global__ __launch_bounds__(KGE_BLOCK) void gather_req_kernel(const float *__restrict__ table, int dim, const int64_t *__restrict__ ids,
                                                                int64_t id_offset, int64_t n_rows, int64_t n, float *__restrict__ out) {
@@ -212,6 +240,17 @@ int kge_route_build(const kge_batch *b, int world, int64_t rows_per_shard, int c
     a.overflow = overflow;
     const int items = a.UEmax > world * cap ? a.UEmax : world * cap;
     hipLaunchKernelGGL(route_build_kernel, dim3((items + RT_THREADS - 1) / RT_THREADS), dim3(RT_THREADS), 0, (hipStream_t)stream, a);
+    return check_launch_r();
+}
+
+int kge_route_fill(const kge_batch *b0, int n_batches, size_t stride_bytes, int world, int64_t rows_per_shard, int32_t *max_fill,
+                   void *stream) {
+    if (!b0 || !b0->ue_id || !max_fill || n_batches < 1 || world < 1 || world > RT_MAX_WORLD || rows_per_shard <= 0 ||
+        (n_batches > 1 && (stride_bytes == 0 || !b0->counts_dev)))
+        return KGE_ERR_ARG;
+    hipLaunchKernelGGL(route_fill_kernel, dim3(n_batches), dim3(RT_THREADS), 0, (hipStream_t)stream,
+                       reinterpret_cast<const char *>(b0->ue_id), reinterpret_cast<const char *>(b0->counts_dev), (int64_t)stride_bytes,
+                       b0->UE, world, rows_per_shard, max_fill);
     return check_launch_r();
 }
 

@@ -109,6 +109,7 @@ _SIGNATURES = {
     "kge_transr_project_bwd": (c_i, [c_p, c_p, c_p, c_i64, c_i, c_i, c_p, c_p, c_i, c_p]),
     "kge_transr_project_neg": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     "kge_transr_project_neg_bwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p]),
+    "kge_route_fill": (c_i, [c_p, c_i, c_sz, c_i, c_i64, c_p, c_p]),
     "kge_route_build": (c_i, [c_p, c_i, c_i64, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "kge_batch_localized": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "kge_gather_rows_req": (c_i, [c_p, c_i64, c_i, c_p, c_i64, c_i64, c_p, c_p]),

@@ -230,6 +230,20 @@ class HipOps(object):
                                          _lib.ptr(bf.ue_loc), _lib.ptr(bf.ue_rec_loc), C.byref(kb)))
         return LocalBatch(batch, kb, bf)
 
+    def route_fill(self, batches, world, per, out):
+        """out[0] = max(out[0], the largest owner-bucket fill over `batches`): ONE launch when the batches are consecutive slots of a
+        device sampler, one per batch otherwise (host-built plans)."""
+        L = _lib.lib()
+        b0 = batches[0]
+        smp = getattr(b0, "sampler", None)
+        slots = [getattr(b, "slot", None) for b in batches]
+        if (smp is not None and len(batches) > 1 and all(getattr(b, "sampler", None) is smp for b in batches) and
+                slots == list(range(slots[0], slots[0] + len(slots)))):
+            _lib.check(L.kge_route_fill(C.byref(b0.c), len(batches), smp.slot_bytes, world, per, _lib.ptr(out), _lib.stream_ptr()))
+            return
+        for b in batches:
+            _lib.check(L.kge_route_fill(C.byref(b.c), 1, 0, world, per, _lib.ptr(out), _lib.stream_ptr()))
+
     def gather_req(self, table, ids, lo, out):
         _lib.check(_lib.lib().kge_gather_rows_req(_lib.ptr(table), table.shape[0], table.shape[1], _lib.ptr(ids), int(lo),
                                                   ids.shape[0], _lib.ptr(out), _lib.stream_ptr()))
@@ -318,14 +332,28 @@ class DistEngine(object):
         W = self.spec.world
         if self.cap is None:
             self.cap = default_cap(b.UE, W, self.slack)
-        cap, dt, dev = self.cap, self.ent.dtype, self.dev
         self.geom = (b.B, b.C * b.N, b.UE)
+        self.grown = []               # (old cap, new cap, fill that asked for it): ensure_capacity's record
+        self.overflow = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        self.fill = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        self.fill_all = torch.zeros(W, dtype=torch.int32, device=self.dev)
+        self._alloc(b)
+
+    def _alloc(self, b):
+        """the exchange buffers for the current `cap` (again after ensure_capacity grew it; nothing of a step is in flight then)"""
+        W = self.spec.world
+        cap, dt, dev = self.cap, self.ent.dtype, self.dev
         ld_e, ld_r = 2 * self.d_e + 4, self.d_r + 4
 
         def z(shape, dtype):
             return torch.zeros(shape, dtype=dtype, device=dev)
+        if dev.type == "cuda":
+            torch.cuda.current_stream(dev).synchronize()        # the old buffers may still be read by the previous group's steps
+            if self._side is not None:
+                self._side.synchronize()
+        if hasattr(self.ops, "_structs"):
+            self.ops._structs = {}    # HipOps caches its argument structs per buffer set (keyed by the buffers' addresses)
         self.slots = []
-        self.overflow = z(1, torch.int32)
         for _ in range(2):
             s = _Slot()
             s.req_ids = z(W * cap, torch.int64)
@@ -341,6 +369,36 @@ class DistEngine(object):
         self.rel_msg = z((b.B, ld_r), dt)
         self.all_rel = self.rel_msg if not self.coll else z((W * b.B, ld_r), dt)
         self.zero_state = z(W * cap + 1, dt)
+
+    def ensure_capacity(self, batches, log=None):
+        """call with every freshly sampled GROUP of batches before its steps: measures the largest owner-bucket fill of the group on
+        the device (one launch + one small read, all ranks' values exchanged so that every rank takes the same decision) and, when
+        a bucket would overflow, grows `cap` (all exchange buffers are re-allocated) BEFORE any of the group's steps runs - no
+        entity is ever trained against the dump row.  Heavy-tailed graphs cluster their hubs in a few shards: the default
+        capacity (1.5 x the mean share) is a starting point, not a bound.  Returns the capacity in use."""
+        if self.slots is None:
+            self._setup(batches[0])
+        W = self.spec.world
+        if W == 1:
+            return self.cap                       # one owner: cap = the batch's bound on unique entities
+        if self._pre is not None:
+            raise _lib.KgeError("ensure_capacity: a pull is still in flight (call it between groups)")
+        self.fill.zero_()
+        self.ops.route_fill(batches, W, self.spec.shard, self.fill)
+        if self.coll:
+            self.comm.all_gather(self.fill_all, self.fill)
+            need = int(self.fill_all.max().item())
+        else:
+            need = int(self.fill.item())
+        if need > self.cap:
+            ue_bound = self.geom[2]
+            new = int(min(max(ue_bound, need), (int(need * 1.25) + 63) // 64 * 64))
+            if log is not None:
+                log("owner buckets grow from %d to %d rows (largest fill of the next group: %d)" % (self.cap, new, need))
+            self.grown.append((self.cap, new, need))
+            self.cap = new
+            self._alloc(batches[0])
+        return self.cap
 
     def check_overflow(self):
         """entries that did not fit their owner bucket since the last call (one 4-byte D2H read: call at the log interval)."""

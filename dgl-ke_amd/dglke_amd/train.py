@@ -80,6 +80,14 @@ class ArgParser(argparse.ArgumentParser):
         a('--async_update_rel', action='store_true',
           help='with --async_update: defer the relation-table update by one step as well (the reference defers the entity '
                'table only); the next step\'s gather then shares a launch with this step\'s backward (fastest mode)')
+        a('--async_update_pipeline', action='store_true',
+          help='with --async_update (entity table only, the reference\'s semantics): run the one-step-stale pipeline anyway.  By '
+               'default the flag maps onto the STRICT step, which is faster on this GPU than a pipeline that must still land the '
+               'relation trace between two steps (profiles/r03_v3_workloads_kernels.txt: 32.9 vs 30.7 us per cfg-T step) and is '
+               'within the licence of the flag (staleness <= 1 step; here 0)')
+        a('--dist_slack', type=float, default=None,
+          help='--dist_mode a2a: initial capacity of an owner bucket as a multiple of the mean share of a batch\'s unique entities '
+               '(default 1.5, or KGE_DIST_SLACK); buckets grow by themselves when a group of batches needs more')
         a('--dist_mode', default='a2a', choices=['a2a', 'p2p'],
           help='multi-GPU training (--gpu g0 g1 ...): a2a = entity table range-sharded, relation table replicated, RCCL '
                'all-to-all pull / push with owner-side Adagrad (parameter-server semantics); p2p = both tables sharded and '
@@ -146,7 +154,7 @@ class _Lane(object):
         # --async_update (reference: tensor_models.py:136-175, general_models.py:639-647): the one-step-stale pipeline of
         # kge_step_async - the entity update of step s-1 shares a launch with the backward of step s; every captured /
         # enqueued group of steps ends with a flush
-        self.async_update = bool(getattr(a, 'async_update', False)) and trainer.async_ok
+        self.async_update = bool(getattr(a, 'async_update', False)) and trainer.async_ok and trainer.async_pipeline
 
     def _steps(self, batches):
         eng = self.engine
@@ -263,8 +271,14 @@ class Trainer(object):
         self.device_sampler = self.fused and not args.has_edge_importance and 2 * B + C * N <= 4096
         self.n_lanes = max(1, int(args.num_proc))
         self.async_ok = self.fused and args.model_name not in ('TransR', 'RESCAL')
+        # entity-only deferral (the reference's --async_update) runs as the strict step unless the pipeline is asked for: with the
+        # relation trace landing between two steps the pipeline needs one more launch than it hides
+        self.async_pipeline = bool(getattr(args, 'async_update_rel', False) or getattr(args, 'async_update_pipeline', False))
         if getattr(args, 'async_update', False) and not self.async_ok:
             print('--async_update: not available for this model / option combination; running the strict step')
+        elif getattr(args, 'async_update', False) and not self.async_pipeline:
+            print('--async_update: running the strict step (no staleness; faster on this GPU than the entity-only one-step-stale '
+                  'pipeline - pass --async_update_rel to defer the relation trace too, or --async_update_pipeline to force it)')
         if self.n_lanes > 1 and not self.fused:
             raise KgeError("--num_proc > 1 needs the fused step (not available with --neg_deg_sample)")
         # the lanes share the tables; every lane trains on its own random share of the triples
@@ -558,7 +572,11 @@ class A2ATrainer(ShardedTrainer):
                                  args.loss_genre, args.pairwise, args.margin)
         own_gpu = len(set(args.gpu)) == world
         self.comm = kd.make_comm() if own_gpu else kd.HostStagedComm()
-        self.de = kd.DistEngine(self.engine, self.spec, self.ent, self.ent_state, comm=self.comm)
+        slack = args.dist_slack if getattr(args, 'dist_slack', None) else float(os.environ.get("KGE_DIST_SLACK", "1.5"))
+        self.de = kd.DistEngine(self.engine, self.spec, self.ent, self.ent_state, comm=self.comm, slack=slack)
+        # the pull of step s+1 may overlap step s only under the staleness --async_update licenses (tensor_models.py:136-175);
+        # without the flag every step gathers after its predecessor's update has landed, like the reference
+        self.pipelined = bool(getattr(args, 'async_update', False))
         tr = dataset.train
         part = np.array_split(np.random.RandomState(args.seed).permutation(len(tr[0])), world)[rank]
         if len(part) < B:
@@ -579,12 +597,17 @@ class A2ATrainer(ShardedTrainer):
         while done < n:
             k = min(smp.n_slots, n - done)
             dbs = smp.sample(k)
+            # owner buckets are sized BEFORE the group runs (one small device read per group; every rank takes the same decision)
+            self.de.ensure_capacity(dbs, log=(lambda m: print('[proc {}] {}'.format(self.rank, m))) if self.rank == 0 else None)
             for i, b in enumerate(dbs):
-                self.de.step_pipelined(b, dbs[i + 1] if i + 1 < k else None)
+                if self.pipelined:
+                    self.de.step_pipelined(b, dbs[i + 1] if i + 1 < k else None)
+                else:
+                    self.de.step(b)
             done += k
         lost = self.de.check_overflow()
-        if lost:
-            print('[proc {}] {} bucket entries did not fit their owner bucket (raise KGE_DIST_SLACK)'.format(self.rank, lost))
+        if lost:                                 # cannot happen behind ensure_capacity: a bug, not a tuning matter
+            raise KgeError('[proc {}] {} entities did not fit their owner bucket although the capacity was checked'.format(self.rank, lost))
 
     def sync_tables(self):
         import torch.distributed as dist
@@ -613,7 +636,14 @@ def _mp_worker(rank, args, port):
         dataset = get_dataset(args.data_path, args.dataset, args.format, args.delimiter, args.data_files,
                               args.has_edge_importance)
         sys.stdout = sys.__stdout__
-        trainer = (A2ATrainer if args.dist_mode == 'a2a' else ShardedTrainer)(args, dataset, rank, world)
+        a2a = args.dist_mode == 'a2a'
+        if a2a and (args.model_name in ('RESCAL', 'TransR') or args.neg_deg_sample):
+            # what the all-to-all step does not cover runs on the peer-to-peer shared tables instead of failing
+            if rank == 0:
+                print('--dist_mode a2a does not cover {}: using --dist_mode p2p'.format(
+                    '--neg_deg_sample' if args.neg_deg_sample else args.model_name))
+            a2a = False
+        trainer = (A2ATrainer if a2a else ShardedTrainer)(args, dataset, rank, world)
         if rank == 0:
             print('Total initialize time {:.3f} seconds'.format(time.time() - init_time_start))
         start = time.time()

@@ -479,6 +479,12 @@ int kge_transr_project_neg_bwd(const float *proj, const float *neg, const float 
  *   int64 array: stride 2; ids inside the messages: stride ld) minus id_offset; negative ids are pads.  Within a source the
  *   ids are ascending with the pads at the end and unique; the same row may come from several sources: the wavefront of its
  *   first source applies every occurrence in source order (trace order inside a message) - deterministic, one launch. */
+/* kge_route_fill: *max_fill = max(*max_fill, the largest owner-bucket fill) over n_batches batches - b0 and, for n_batches > 1, the
+ *   batches whose ue_id / counts_dev arrays lie k * stride_bytes behind b0's (consecutive slots of kge_sample_batches: stride =
+ *   the slot size).  One launch per GROUP of batches; the caller reads the word before the group's steps run and grows `cap`
+ *   when needed, so that no entry ever overflows its bucket (dglke_amd/dist.py DistEngine.ensure_capacity). */
+int kge_route_fill(const kge_batch *b0, int n_batches, size_t stride_bytes, int world, int64_t rows_per_shard, int32_t *max_fill,
+                   void *stream);
 int kge_route_build(const kge_batch *b, int world, int64_t rows_per_shard, int cap, int64_t *req_ids, int64_t *h_loc,
                     int64_t *t_loc, int64_t *neg_loc, int64_t *ue_loc, int32_t *ue_rec_loc, int32_t *overflow, void *stream);
 int kge_batch_localized(const kge_batch *b, const int64_t *h_loc, const int64_t *t_loc, const int64_t *neg_loc,

@@ -31,7 +31,7 @@ def test_skewed_triples_have_fb15k_like_hubs():
 @pytest.mark.gpu
 def test_bench_line_has_the_contract_fields():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
-                          "--no-cpu-baseline", "--hogwild", "0", "--no-async-update"],
+                          "--no-cpu-baseline", "--hogwild", "0", "--no-async-update", "--no-configs"],
                          stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=300, cwd=ROOT)
     assert out.returncode == 0
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -48,3 +48,14 @@ def test_bench_line_has_the_contract_fields():
         assert k in r, k
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
     assert 5e6 < d["value"] < 1e9 and abs(d["value"] - 1000 * 1e3 / d["ms_per_step"]) / d["value"] < 0.02
+
+
+@pytest.mark.gpu
+def test_bench_line_carries_the_other_baseline_configs():
+    """the default line's `configs` object (BASELINE.json configs[2..4] as bounded legs in their own processes): checked here on the
+    two FB15k / wikikg2 legs' machinery with a short leg (the Freebase-shard legs need 40 GB and run in the real bench only)."""
+    import bench
+    legs = bench.other_configs(steps=40, timeout_s=280.0, only=("distmult_fb15k",))
+    d = legs["distmult_fb15k"]
+    assert "error" not in d, d
+    assert d["steps"] == 40 and 10.0 < d["us_per_step"] < 500.0 and d["algorithmic_bytes_per_step"] > 1e7 and 0 < d["frac"] < 1

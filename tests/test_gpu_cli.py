@@ -157,7 +157,7 @@ def test_train_cli_async_update(tmp_path, capsys, model):
     """--async_update: the one-step-stale pipeline (kge_step_async) behind the reference's flag; it still learns, and
     the run is reproducible bit for bit"""
     from dglke_amd import train as T
-    argv = _base(tmp_path, model) + ["--max_step", "1200", "--async_update"] + (["-de"] if model == "RotatE" else [])
+    argv = _base(tmp_path, model) + ["--max_step", "1200", "--async_update", "--async_update_pipeline"] + (["-de"] if model == "RotatE" else [])
     tr = T.main(argv)
     out = capsys.readouterr().out
     assert tr.lanes[0].async_update and "--async_update pipeline" in out
@@ -168,6 +168,24 @@ def test_train_cli_async_update(tmp_path, capsys, model):
     capsys.readouterr()
     import torch
     assert torch.equal(tr.model.entity_emb.emb, tr2.model.entity_emb.emb)
+
+
+def test_train_cli_async_update_alone_runs_the_strict_step(tmp_path, capsys):
+    """the reference's flag by itself (entity table only) maps onto the strict step - zero staleness is within the flag's licence
+    and faster here than a pipeline that still lands the relation trace between two steps; the log says so and the tables equal
+    a run without the flag bit for bit"""
+    import torch
+    from dglke_amd import train as T
+    base = _base(tmp_path, "TransE_l2") + ["--max_step", "300"]
+    tr = T.main(base + ["--async_update"])
+    out = capsys.readouterr().out
+    assert not tr.lanes[0].async_update and "--async_update: running the strict step" in out
+    tr2 = T.main(base)
+    capsys.readouterr()
+    assert torch.equal(tr.model.entity_emb.emb, tr2.model.entity_emb.emb)
+    tr3 = T.main(base + ["--async_update", "--async_update_rel"])
+    assert tr3.lanes[0].async_update
+    capsys.readouterr()
 
 
 def test_train_cli_transr_lanes_and_rejected_flags(tmp_path, capsys):

@@ -60,6 +60,60 @@ def test_route_build_matches_numpy():
         assert lb.c.B == B and lb.c.UE == b.UE
 
 
+def test_route_fill_and_capacity_growth():
+    """kge_route_fill (largest owner-bucket fill of a GROUP of batches: host-built plans one by one, consecutive sampler slots in
+    one launch) against numpy, and DistEngine.ensure_capacity on top of it: heavy-tailed ids whose hubs sit in the first shard,
+    a deliberately small capacity - the buckets grow BEFORE the group runs and the overflow counter of the routing kernel stays 0
+    (the exchange itself is covered by the world-2 tests below, the decision across ranks by tests/test_dist_gloo.py at world 8)."""
+    from dglke_amd import plan
+    from dglke_amd import dist as kd
+    from dglke_amd.dataloader import DeviceSampler
+    rng = np.random.RandomState(9)
+    ops = kd.HipOps()
+    world, n_ent, B, N = 8, 4000, 128, 32
+    per = (n_ent + world - 1) // world
+    host = []
+    for k in range(5):
+        bt = O.synth_batch(rng, n_ent, 7, B, N, N, k + 1)
+        skew = lambda x: np.where(rng.rand(len(x)) < 0.7, x % per, x)          # 70 % of the ids fall into shard 0
+        host.append(plan.make_batch(skew(bt["h"]), skew(bt["t"]), bt["r"], skew(bt["neg"]), N, N, bt["neg_head"], DEV))
+    out = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ops.route_fill(host, world, per, out)
+    want = max(int(np.bincount(np.minimum(b.p["ue_id"] // per, world - 1), minlength=world).max()) for b in host)
+    assert int(out.item()) == want and want > 150
+    # consecutive sampler slots: ONE launch
+    h = rng.randint(0, n_ent, 20000); t = rng.randint(0, n_ent, 20000); r = rng.randint(0, 7, 20000)
+    h = np.where(rng.rand(20000) < 0.6, h % per, h)
+    smp = DeviceSampler(h, r, t, n_ent, B, N, DEV, n_slots=6, seed=3)
+    dbs = smp.sample()
+    out.zero_()
+    ops.route_fill(dbs, world, per, out)
+    torch.cuda.synchronize()
+    fills = []
+    for k in range(6):
+        a = smp.slot_arrays(k)
+        ue = a["ue_id"][:a["counts"][0]]
+        fills.append(int(np.bincount(np.minimum(ue // per, world - 1), minlength=world).max()))
+    assert int(out.item()) == max(fills)
+    # ensure_capacity at world 1 is a no-op (one owner: the bound); the growth rule itself on a world-8 spec without collectives
+    class _NoComm(object):
+        world, rank = 8, 0
+    eng = type("E", (), {})()
+    eng.lr, eng.rel = 0.1, torch.zeros(7, 16, device=DEV)
+    spec = kd.ShardSpec(n_ent, 8, 0)
+    de = kd.DistEngine(eng, spec, torch.zeros(spec.n_local, 16, device=DEV), torch.zeros(spec.n_local, device=DEV), ops=ops,
+                       comm=_NoComm(), cap=64)
+    de.coll = False                                   # (no peers in this process: only the local measurement)
+    logs = []
+    cap = de.ensure_capacity(dbs, log=logs.append)
+    assert cap >= max(fills) > 64 and cap % 64 == 0 and logs and de.grown[0][0] == 64
+    assert de.ensure_capacity(dbs) == cap and len(de.grown) == 1         # nothing to grow the second time
+    for b in dbs:                                     # every entry now fits its bucket
+        de.ops.route(b, 8, spec.shard, de.cap, de.slots[0])
+    torch.cuda.synchronize()
+    assert de.check_overflow() == 0
+
+
 def test_gather_rows_req_skips_pads_and_foreign_ids():
     from dglke_amd import dist as kd
     t = torch.arange(0, 80, dtype=torch.float32, device=DEV).reshape(10, 8)
