@@ -470,8 +470,10 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     // neg_deg_sample: the scoring / loss / gradient kernels see N = chunk + (sampled negatives) rows per chunk; the
     // plan of the batch keeps indexing the sampled ones (b->N)
     const bool nd = (hp->flags & KGE_FLAG_NEG_DEG_SAMPLE) != 0;
-    if (nd && (hp->model == KGE_RESCAL || hp->model == KGE_TRANSR || emit))
-        return fail(KGE_ERR_ARG, "neg_deg_sample is not available for RESCAL / TransR and in the gradient-emitting step");
+    // (round 4: also in the gradient-emitting step - the in-batch rows' gradients join the row's positive-trace message g0 through
+    //  edge_bwd, the sampled rows' the negative-trace message g1 through the update's slot remap, exactly as in the fused step)
+    if (nd && (hp->model == KGE_RESCAL || hp->model == KGE_TRANSR))
+        return fail(KGE_ERR_ARG, "neg_deg_sample is not available for RESCAL / TransR");
     const int B = b->B, C = b->C, chunk = b->chunk, N = nd ? b->chunk + b->N : b->N, CN = C * N;
     const int d_e = hp->d_e, d_r = hp->d_r, tj16 = (N + 15) / 16;
     const bool reg = hp->reg_coef > 0.f && hp->reg_norm > 0;

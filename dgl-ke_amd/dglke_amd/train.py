@@ -556,9 +556,8 @@ class A2ATrainer(ShardedTrainer):
         if args.has_edge_importance or not self.device_sampler:
             raise KgeError("multi-GPU training uses the on-device sampler: no --has_edge_importance, "
                            "and 2*batch + chunks*neg <= 4096")
-        if args.model_name in ('RESCAL', 'TransR') or args.neg_deg_sample:
-            raise KgeError("--dist_mode a2a covers TransE_l1/l2, DistMult, ComplEx, RotatE, SimplE without --neg_deg_sample "
-                           "(use --dist_mode p2p)")
+        if args.model_name in ('RESCAL', 'TransR'):
+            raise KgeError("--dist_mode a2a covers TransE_l1/l2, DistMult, ComplEx, RotatE, SimplE (use --dist_mode p2p)")
         d_e = args.hidden_dim * (2 if args.double_ent else 1)
         self.emb_init = (args.gamma + 2.0) / args.hidden_dim
         self.spec = kd.ShardSpec(dataset.n_entities, world, rank)
@@ -569,7 +568,8 @@ class A2ATrainer(ShardedTrainer):
         self.engine = StepEngine(args.model_name, 1, dataset.n_relations, args.hidden_dim, args.gamma, args.lr, self.dev,
                                  args.double_ent, args.double_rel, args.neg_adversarial_sampling,
                                  args.adversarial_temperature, args.regularization_coef, args.regularization_norm,
-                                 args.loss_genre, args.pairwise, args.margin)
+                                 args.loss_genre, args.pairwise, args.margin,
+                                 flags=_lib.FLAG_NEG_DEG_SAMPLE if args.neg_deg_sample else 0)
         own_gpu = len(set(args.gpu)) == world
         self.comm = kd.make_comm() if own_gpu else kd.HostStagedComm()
         slack = args.dist_slack if getattr(args, 'dist_slack', None) else float(os.environ.get("KGE_DIST_SLACK", "1.5"))
@@ -637,11 +637,10 @@ def _mp_worker(rank, args, port):
                               args.has_edge_importance)
         sys.stdout = sys.__stdout__
         a2a = args.dist_mode == 'a2a'
-        if a2a and (args.model_name in ('RESCAL', 'TransR') or args.neg_deg_sample):
+        if a2a and args.model_name in ('RESCAL', 'TransR'):
             # what the all-to-all step does not cover runs on the peer-to-peer shared tables instead of failing
             if rank == 0:
-                print('--dist_mode a2a does not cover {}: using --dist_mode p2p'.format(
-                    '--neg_deg_sample' if args.neg_deg_sample else args.model_name))
+                print('--dist_mode a2a does not cover {}: using --dist_mode p2p'.format(args.model_name))
             a2a = False
         trainer = (A2ATrainer if a2a else ShardedTrainer)(args, dataset, rank, world)
         if rank == 0:

@@ -88,7 +88,8 @@ enum kge_status {
  * gradients of the in-batch rows join the POSITIVE trace of their entity.  kge_batch is unchanged
  * (N and the plan describe the SAMPLED negatives); kge_step_workspace_bytes accounts for N';
  * kge_step_out.neg_score is [B, N'], g_neg [C*N', d_e] (rows c*N' + chunk.. are the sampled ones).
- * Not available for RESCAL / TransR and in kge_step_grads. */
+ * Not available for RESCAL / TransR.  kge_step_grads (ABI 6): the in-batch rows' gradients are part of the positive-trace
+ * message g0 of their entity, the sampled rows' of g1 - the traces the reference pushes. */
 #define KGE_FLAG_NEG_DEG_SAMPLE 32u
 /* kge_step_async: defer the relation-table update by one step as well (the reference's --async_update defers the
  * entity table only, general_models.py:639-647; with this flag no update at all sits between two steps' scoring) */

@@ -60,7 +60,8 @@ def main():
         d_e = 2 * HID if de_ else HID
         g = torch.Generator().manual_seed(5)
         ent0 = ((torch.rand(N_ENT, d_e, generator=g) - 0.5) * 0.4)
-        eng = StepEngine(model, 1, N_REL, HID, 12.0, LR, dev, de_, dr_, True, 1.0, 1e-6, 3)
+        eng = StepEngine(model, 1, N_REL, HID, 12.0, LR, dev, de_, dr_, True, 1.0, 1e-6, 3,
+                         flags=32 if mode == "nd" else 0)          # nd: --neg_deg_sample in the gradient-emitting step
         rel0 = ((torch.rand(N_REL, eng.d_r, generator=g) - 0.5) * 0.4)
         eng.rel.copy_(rel0)
         spec = kd.ShardSpec(N_ENT, world, rank)

@@ -194,13 +194,22 @@ def land(model, args):
         q.items = []
 
 
-def run_case(name, case):
+def run_case(name, case, fp64=False):
+    """fp64=True (`--noise`): the SAME reference code on the same batches with its tables cast to float64 after construction
+    (same float32-rounded initial values) - nothing is written; returns the final tables so that main() can record how far the
+    float32 reference itself is from exact arithmetic for this case (tests/golden/noise.json: the yardstick of the GPU row
+    tolerance, tests/test_gpu_parity.py)."""
     from dglke.models import KEModel
     th.manual_seed(case["seed"])
     rng = np.random.RandomState(case["seed"])
     args = make_args(case)
     model = KEModel(args, case["model"], case["n_ent"], case["n_rel"], case["hidden"],
                     case["gamma"], double_entity_emb=case["de"], double_relation_emb=case["dr"])
+    if fp64:
+        embs = [model.entity_emb, model.relation_emb] + ([model.score_func.projection_emb] if case["model"] == "TransR" else [])
+        for e in embs:
+            e.emb = e.emb.double()
+            e.state_sum = e.state_sum.double()
     out = {}
     out["init_entity"] = model.entity_emb.emb.numpy().copy()
     out["init_relation"] = model.relation_emb.emb.numpy().copy()
@@ -267,6 +276,8 @@ def run_case(name, case):
     out["final_relation"] = model.relation_emb.emb.numpy().copy()
     out["final_entity_state"] = model.entity_emb.state_sum.numpy().copy()
     out["final_relation_state"] = model.relation_emb.state_sum.numpy().copy()
+    if fp64:
+        return out
     out["case_json"] = np.array(json.dumps(case))
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
     print("wrote", name, "loss", out["s%d_loss_total" % case["steps"]])
@@ -383,7 +394,25 @@ def main():
     install_stubs()
     sys.path.insert(0, REF)
     th.set_num_threads(1)
-    only = sys.argv[1:]
+    only = [a for a in sys.argv[1:] if not a.startswith("--")]
+    if "--noise" in sys.argv:
+        # distance of the float32 reference (the committed goldens) from the same code in float64, per case: max |difference| of
+        # the final tables and of every recorded per-step table, in units of lr
+        noise = {}
+        for name, case in CASES.items():
+            if only and name not in only:
+                continue
+            z = np.load(os.path.join(OUT, name + ".npz"))
+            o64 = run_case(name, case, fp64=True)
+            rec = {}
+            for tab in ("entity", "relation"):
+                keys = [k for k in z.files if (k == "final_" + tab or (k.startswith("s") and k.endswith("_" + tab)))]
+                rec[tab] = max(float(np.abs(z[k].astype(np.float64) - o64[k]).max()) for k in keys) / case["lr"]
+            noise[name] = rec
+            print("%-40s entity %.3e lr   relation %.3e lr" % (name, rec["entity"], rec["relation"]))
+        with open(os.path.join(OUT, "noise.json"), "w") as f:
+            json.dump(noise, f, indent=1, sort_keys=True)
+        return
     for name, case in CASES.items():
         if only and name not in only:
             continue

@@ -175,7 +175,7 @@ def test_apply_merged_equals_sequential_apply(nsrc, cap, dim, n_rows):
 
 
 def _run_workers(tmp_path, mode, world=2, transport="host"):
-    port = str(29700 + os.getpid() % 250 + {"random": 0, "disjoint": 1, "pipelined": 2}[mode] + (3 if transport == "rccl" else 0))
+    port = str(29700 + os.getpid() % 250 + {"random": 0, "disjoint": 1, "pipelined": 2, "nd": 6}[mode] + (3 if transport == "rccl" else 0))
     env = dict(os.environ)
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), str(r), str(world), port, str(tmp_path), mode,
                                transport], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
@@ -197,7 +197,8 @@ def _oracle_statement(model, de_, dr_, z, world, mode):
     then trace 1 per rank), relations in rank order.  mode 'pipelined': the ENTITY rows of step s were pulled before update s-1
     landed (exact one-step staleness); the replicated relation table is always current."""
     import dist_worker as W
-    cfg = O.Config(model, 12.0, W.HID, W.LR, adv=True, adv_temp=1.0, reg_coef=1e-6, reg_norm=3, double_ent=de_, double_rel=dr_)
+    cfg = O.Config(model, 12.0, W.HID, W.LR, adv=True, adv_temp=1.0, reg_coef=1e-6, reg_norm=3, double_ent=de_, double_rel=dr_,
+                   neg_deg=(mode == "nd"))
     ent, rel = z[model + "_init_ent"].astype(np.float64), z[model + "_init_rel"].astype(np.float64)
     es, rs = np.zeros(W.N_ENT), np.zeros(W.N_REL)
     bts = W.batches(world, W.STEPS, "random")
@@ -215,7 +216,8 @@ def _oracle_statement(model, de_, dr_, z, world, mode):
     return ent, es, rel, rs
 
 
-@pytest.mark.parametrize("mode,transport", [("random", "host"), ("pipelined", "host"), ("random", "rccl"), ("pipelined", "rccl")])
+@pytest.mark.parametrize("mode,transport", [("random", "host"), ("pipelined", "host"), ("nd", "host"), ("random", "rccl"),
+                                            ("pipelined", "rccl")])
 def test_world2_hip_ops_match_the_oracle_statement(tmp_path, mode, transport):
     """`host`: two processes on ONE device, messages staged through gloo.  `rccl`: two processes on TWO devices, the product's
     transport - dist.RcclComm (ncclAllToAll / ncclAllGather on the step's streams, grouped push, side-stream pull) - against

@@ -82,6 +82,38 @@ def golden_batch(z, case, s):
                            case["N"], bool(z[p + "neg_head"]), DEV, w)
 
 
+_NOISE = None
+ROW_ERRORS = {}          # name -> largest row error / lr seen in this session (written to gpurun_out/golden_row_errors.txt)
+
+
+def rows_close(got, ref, name, tab, lr, what):
+    """post-update table rows against a golden: |difference| <= max(1e-4 * lr, 3 x the distance of the float32 REFERENCE itself
+    from the same reference code run in float64 on this golden (tests/golden/noise.json, `gen_golden.py --noise`)) - round 3's
+    blanket 5e-3 * lr was argued, this bound is measured per case."""
+    global _NOISE
+    if _NOISE is None:
+        import json
+        _NOISE = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "noise.json")))
+    noise = _NOISE[name][tab]
+    tol = max(1e-4, 3.0 * noise) * lr
+    got = np.asarray(got, dtype=np.float64)
+    err = float(np.abs(got - np.asarray(ref, dtype=np.float64)).max())
+    key = "%s %s" % (name, tab)
+    ROW_ERRORS[key] = max(ROW_ERRORS.get(key, 0.0), err / lr)
+    try:
+        out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "golden_row_errors.txt"), "w") as f:
+            f.write("golden table: largest |GPU - golden| / lr over every path tested this session   (reference fp32-vs-fp64 noise / lr)\n")
+            for k in sorted(ROW_ERRORS):
+                n_, t_ = k.split()
+                f.write("%-44s %.3e   (%.3e)\n" % (k, ROW_ERRORS[k], _NOISE[n_][t_]))
+    except OSError:
+        pass
+    assert err <= tol + 1e-6 * float(np.abs(ref).max()), \
+        "%s %s: max|err| %.3e = %.3e lr > %.3e lr (reference's own fp32 noise: %.3e lr)" % (name, what, err, err / lr, tol / lr, noise)
+
+
 def grad_tol(ref):
     return 3e-4 * max(float(np.abs(ref).max()), 1e-12)
 
@@ -123,10 +155,10 @@ def test_dropin_model_matches_reference(name):
             _close(pe.state_sum.cpu(), z[p + "projection_state"], 2e-3, 1e-9, name + " projection state")
             _close(pe.emb.cpu(), z[p + "projection"], 1e-4, 5e-3 * case["lr"], name + " projection rows")
         if (p + "entity") in z:
-            _close(m.entity_emb.emb.cpu(), z[p + "entity"], 1e-4, 5e-3 * case["lr"], name + " entity rows")
-            _close(m.relation_emb.emb.cpu(), z[p + "relation"], 1e-4, 5e-3 * case["lr"], name + " relation rows")
-    _close(m.entity_emb.emb.cpu(), z["final_entity"], 1e-4, 1e-2 * case["lr"], name + " final entity")
-    _close(m.relation_emb.emb.cpu(), z["final_relation"], 1e-4, 1e-2 * case["lr"], name + " final relation")
+            rows_close(m.entity_emb.emb.cpu(), z[p + "entity"], name, "entity", case["lr"], "entity rows (drop-in)")
+            rows_close(m.relation_emb.emb.cpu(), z[p + "relation"], name, "relation", case["lr"], "relation rows (drop-in)")
+    rows_close(m.entity_emb.emb.cpu(), z["final_entity"], name, "entity", case["lr"], "final entity (drop-in)")
+    rows_close(m.relation_emb.emb.cpu(), z["final_relation"], name, "relation", case["lr"], "final relation (drop-in)")
 
 
 @pytest.mark.parametrize("flags", [0, 1, 2, 8, 128, 512], ids=["auto", "force_pairwise", "no_transe_fast", "fused_loss", "split_fwd", "direct_tiles"])
@@ -162,10 +194,10 @@ def test_fused_step_matches_reference(name, flags):
         _close(eng.ent_state.cpu(), z[p + "entity_state"], 2e-3, 1e-9, name + " ent state")
         _close(eng.rel_state.cpu(), z[p + "relation_state"], 2e-3, 1e-9, name + " rel state")
         if (p + "entity") in z:
-            _close(eng.ent.cpu(), z[p + "entity"], 1e-4, 5e-3 * case["lr"], name + " entity rows")
-            _close(eng.rel.cpu(), z[p + "relation"], 1e-4, 5e-3 * case["lr"], name + " relation rows")
-    _close(eng.ent.cpu(), z["final_entity"], 1e-4, 1e-2 * case["lr"], name + " final entity")
-    _close(eng.rel.cpu(), z["final_relation"], 1e-4, 1e-2 * case["lr"], name + " final relation")
+            rows_close(eng.ent.cpu(), z[p + "entity"], name, "entity", case["lr"], "entity rows")
+            rows_close(eng.rel.cpu(), z[p + "relation"], name, "relation", case["lr"], "relation rows")
+    rows_close(eng.ent.cpu(), z["final_entity"], name, "entity", case["lr"], "final entity")
+    rows_close(eng.rel.cpu(), z["final_relation"], name, "relation", case["lr"], "final relation")
 
 
 # ---------------------------------------------------------------------------------------------
@@ -739,11 +771,42 @@ def test_fused_step_neg_deg_sample_matches_reference(name, flags):
         _close(eng.ent_state.cpu(), z[p + "entity_state"], 2e-3, 1e-9, name + " ent state")
         _close(eng.rel_state.cpu(), z[p + "relation_state"], 2e-3, 1e-9, name + " rel state")
         if (p + "entity") in z:
-            _close(eng.ent.cpu(), z[p + "entity"], 1e-4, 5e-3 * case["lr"], name + " entity rows")
-            _close(eng.rel.cpu(), z[p + "relation"], 1e-4, 5e-3 * case["lr"], name + " relation rows")
+            rows_close(eng.ent.cpu(), z[p + "entity"], name, "entity", case["lr"], "entity rows")
+            rows_close(eng.rel.cpu(), z[p + "relation"], name, "relation", case["lr"], "relation rows")
         prev_ent = eng.ent.cpu().numpy()
-    _close(eng.ent.cpu(), z["final_entity"], 1e-4, 1e-2 * case["lr"], name + " final entity")
-    _close(eng.rel.cpu(), z["final_relation"], 1e-4, 1e-2 * case["lr"], name + " final relation")
+    rows_close(eng.ent.cpu(), z["final_entity"], name, "entity", case["lr"], "final entity")
+    rows_close(eng.rel.cpu(), z["final_relation"], name, "relation", case["lr"], "final relation")
+
+
+@pytest.mark.parametrize("name", golden_names(nd=True))
+def test_dist_engine_neg_deg_sample_matches_reference(name):
+    """round 4: --neg_deg_sample in the gradient-emitting step (kge_step_grads), i.e. in the north_star multi-GPU mode - the
+    12 nd_* goldens through a world-1 DistEngine (route -> pull -> step against the row cache -> packed messages -> owner-side
+    merged apply): both Adagrad states after every step and the final tables against the reference's."""
+    from dglke_amd import dist as kd
+    z, case = load_golden(name)
+    m = build_model(case, z)
+    eng = m.engine
+    eng.hp.flags = 32
+    ent, state = eng.ent, eng.ent_state
+    deng = kd.DistEngine(eng, kd.ShardSpec(case["n_ent"], 1, 0), ent, state)
+    ue_bound = 2 * case["B"] + case["C"] * case["N"] if "B" in case else None
+    for s in range(1, case["steps"] + 1):
+        p = "s%d_" % s
+        b = golden_batch(z, case, s)
+        if s == 1:
+            ue_bound = 2 * b.B + b.C * b.N
+        b.UE = ue_bound                       # the engine sizes its buffers once, for the bound
+        deng.step(b)
+        torch.cuda.synchronize()
+        _close(state.cpu(), z[p + "entity_state"], 2e-3, 1e-9, name + " ent state")
+        _close(eng.rel_state.cpu(), z[p + "relation_state"], 2e-3, 1e-9, name + " rel state")
+        if (p + "entity") in z:
+            rows_close(ent.cpu(), z[p + "entity"], name, "entity", case["lr"], "entity rows (DistEngine)")
+            rows_close(eng.rel.cpu(), z[p + "relation"], name, "relation", case["lr"], "relation rows (DistEngine)")
+    assert deng.check_overflow() == 0
+    rows_close(ent.cpu(), z["final_entity"], name, "entity", case["lr"], "final entity (DistEngine)")
+    rows_close(eng.rel.cpu(), z["final_relation"], name, "relation", case["lr"], "final relation (DistEngine)")
 
 
 def _random_step_case(seed):
