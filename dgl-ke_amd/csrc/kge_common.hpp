@@ -182,12 +182,19 @@ __device__ __forceinline__ float sgnf(float x) { return (x > 0.f) ? 1.f : ((x < 
 // Branch-free on purpose (hardware exp2 / log2, ~1e-6 relative): a chain of `if (q == 3) ... else powf` at every
 // use is unswitched / inlined by the compiler into several copies of every loop and made the update kernel
 // 11 k instructions - larger than the instruction cache (measured 15.6 -> 12.4 us just from removing powf).
+// (q known at compile time to be 3 - the reference's default regularization_norm and every BASELINE recipe's; the LEAN kernel
+//  instances fix it - : plain multiplies, exact; the general form costs two quarter-rate transcendentals per element, which at four
+//  wavefronts per SIMD was ~1 us of the update kernel, round 4)
+__device__ __forceinline__ float reg_grad3(float x, float coef) { return 3.f * coef * x * fabsf(x); }
+__device__ __forceinline__ float reg_val3(float x) { const float ax = fabsf(x); return ax * ax * ax; }
 __device__ __forceinline__ float reg_grad(float x, float coef, int q) {
+    if (__builtin_constant_p(q) && q == 3) return reg_grad3(x, coef);
     const float ax = fabsf(x);
     const float pw = __builtin_amdgcn_exp2f((float)(q - 1) * __builtin_amdgcn_logf(ax));     // |x|^(q-1)
     return ax > 0.f ? copysignf(coef * (float)q * pw, x) : 0.f;
 }
 __device__ __forceinline__ float reg_val(float x, int q) {
+    if (__builtin_constant_p(q) && q == 3) return reg_val3(x);
     const float ax = fabsf(x);
     return ax > 0.f ? __builtin_amdgcn_exp2f((float)q * __builtin_amdgcn_logf(ax)) : 0.f;    // |x|^q
 }

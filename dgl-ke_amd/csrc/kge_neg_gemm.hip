@@ -1122,10 +1122,15 @@ __device__ __forceinline__ void neg_bwd_gemm_tile(const GemmArgs &a, int ti, int
                 const float4 sv = selfv[r];
                 if (L2) { o.x -= sv.x * rs; o.y -= sv.y * rs; o.z -= sv.z * rs; o.w -= sv.w * rs; }
                 if (reg) {
-                    o.x += reg_grad(sv.x, a.reg_coef, a.reg_norm);
-                    o.y += reg_grad(sv.y, a.reg_coef, a.reg_norm);
-                    o.z += reg_grad(sv.z, a.reg_coef, a.reg_norm);
-                    o.w += reg_grad(sv.w, a.reg_coef, a.reg_norm);
+                    if (a.reg_norm == 3) {      // (wave-uniform branch: the default norm without the two transcendentals per element)
+                        o.x += reg_grad3(sv.x, a.reg_coef); o.y += reg_grad3(sv.y, a.reg_coef);
+                        o.z += reg_grad3(sv.z, a.reg_coef); o.w += reg_grad3(sv.w, a.reg_coef);
+                    } else {
+                        o.x += reg_grad(sv.x, a.reg_coef, a.reg_norm);
+                        o.y += reg_grad(sv.y, a.reg_coef, a.reg_norm);
+                        o.z += reg_grad(sv.z, a.reg_coef, a.reg_norm);
+                        o.w += reg_grad(sv.w, a.reg_coef, a.reg_norm);
+                    }
                 }
             }
             // write-through store: GA / GN are consumed by the update kernel (any XCD); lines left dirty in this XCD's L2 only
@@ -1178,8 +1183,8 @@ __device__ __forceinline__ void neg_bwd_gemm_tile(const GemmArgs &a, int ti, int
                     }
                     }
                     if (a.ew_reg_coef > 0.f && a.ew_reg_norm > 0) {
-                        v_rr += reg_grad(cc, a.ew_reg_coef, a.ew_reg_norm);
-                        v_ir += reg_grad(ss, a.ew_reg_coef, a.ew_reg_norm);
+                        if (a.ew_reg_norm == 3) { v_rr += reg_grad3(cc, a.ew_reg_coef); v_ir += reg_grad3(ss, a.ew_reg_coef); }
+                        else { v_rr += reg_grad(cc, a.ew_reg_coef, a.ew_reg_norm); v_ir += reg_grad(ss, a.ew_reg_coef, a.ew_reg_norm); }
                     }
                     gh.v[e] = isim ? v_ih : v_rh; gt.v[e] = isim ? v_it : v_rt; gr.v[e] = isim ? v_ir : v_rr;
                 }
@@ -1200,7 +1205,10 @@ __device__ __forceinline__ void neg_bwd_gemm_tile(const GemmArgs &a, int ti, int
                     float o_h = dp * rr[e] * tt[e], o_r = dp * hh[e] * tt[e], o_t = dp * hh[e] * rr[e];
                     if (a.ew_neg_head) { o_t += gx[e] * rr[e]; o_r += gx[e] * tt[e]; }
                     else               { o_h += gx[e] * rr[e]; o_r += gx[e] * hh[e]; }
-                    if (a.ew_reg_coef > 0.f && a.ew_reg_norm > 0) o_r += reg_grad(rr[e], a.ew_reg_coef, a.ew_reg_norm);
+                    if (a.ew_reg_coef > 0.f && a.ew_reg_norm > 0) {
+                        if (a.ew_reg_norm == 3) o_r += reg_grad3(rr[e], a.ew_reg_coef);
+                        else o_r += reg_grad(rr[e], a.ew_reg_coef, a.ew_reg_norm);
+                    }
                     gh.v[e] = o_h; gt.v[e] = o_t; gr.v[e] = o_r;
                 }
                 const int64_t eo = ((int64_t)c * R + ro) * D + d;

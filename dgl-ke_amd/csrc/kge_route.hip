@@ -145,8 +145,8 @@ __device__ __forceinline__ int64_t merge_id(const MergeArgs &a, int64_t k) {
 __device__ __forceinline__ uint64_t merge_key(int64_t id) { return id < 0 ? ~0ull : (uint64_t)id; }    // pads sort last
 
 template <int NIT>      // row width <= 256 * NIT floats, dim % 4 == 0
-__global__ __launch_bounds__(KGE_BLOCK) void apply_merged_kernel(MergeArgs a) {
-    const int64_t k = (int64_t)blockIdx.x * KGE_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+__device__ __forceinline__ void apply_merged_body(const MergeArgs &a, int bid) {
+    const int64_t k = (int64_t)bid * KGE_WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if (k >= (int64_t)a.nsrc * a.cap) return;
     const int lane = threadIdx.x & 63;
     const int src = (int)(k / a.cap);
@@ -224,6 +224,15 @@ __global__ __launch_bounds__(KGE_BLOCK) void apply_merged_kernel(MergeArgs a) {
     for (int q = 0; q < NIT; ++q) if (lane + 64 * q < nit) st_wt<4>(row + (lane + 64 * q) * 4, x[q]);
     if (lane == 0) a.state[id] = st;
 }
+template <int NIT>
+__global__ __launch_bounds__(KGE_BLOCK) void apply_merged_kernel(MergeArgs a) { apply_merged_body<NIT>(a, (int)blockIdx.x); }
+// the entity-shard apply and the relation-replica apply of one step in ONE launch (independent tables, independent messages): one
+// launch boundary less, and the two fill the chip together (round 4)
+template <int NIT>
+__global__ __launch_bounds__(KGE_BLOCK) void apply_merged_pair_kernel(MergeArgs a, MergeArgs b, int nbA) {
+    if ((int)blockIdx.x < nbA) apply_merged_body<NIT>(a, (int)blockIdx.x);
+    else apply_merged_body<NIT>(b, (int)blockIdx.x - nbA);
+}
 
 extern "C" {
 
@@ -271,6 +280,32 @@ int kge_gather_rows_req(const float *table, int64_t n_rows, int dim, const int64
         hipLaunchKernelGGL(gather_req_kernel<4>, dim3(nb), dim3(KGE_BLOCK), 0, (hipStream_t)stream, table, dim, ids, id_offset, n_rows, n_ids, out);
     else
         hipLaunchKernelGGL(gather_req_kernel<1>, dim3(nb), dim3(KGE_BLOCK), 0, (hipStream_t)stream, table, dim, ids, id_offset, n_rows, n_ids, out);
+    return check_launch_r();
+}
+
+static int merge_args(MergeArgs &a, const kge_merge_job *j, float lr, float eps) {
+    if (!j || !j->table || !j->state_sum || j->n_rows < 0 || j->dim <= 0 || j->dim % 4 || j->dim > 1024 || j->nsrc < 1 ||
+        j->nsrc > RT_MAX_WORLD || j->cap <= 0 || !j->id_words || j->id_stride_words < 2 || !j->msg ||
+        j->ld < j->ntraces * j->dim + j->ntraces || j->ld % 4 || j->ntraces < 1)
+        return KGE_ERR_ARG;
+    a = MergeArgs{};
+    a.table = j->table; a.state = j->state_sum; a.n_rows = j->n_rows; a.id_offset = j->id_offset; a.dim = j->dim; a.nsrc = j->nsrc;
+    a.cap = j->cap; a.ld = j->ld; a.ntraces = j->ntraces; a.idw = j->id_words; a.id_stride = j->id_stride_words; a.msg = j->msg;
+    a.lr = lr; a.eps = eps;
+    return KGE_OK;
+}
+
+int kge_adagrad_apply_merged_pair(const kge_merge_job *ja, const kge_merge_job *jb, float lr, float eps, void *stream) {
+    MergeArgs a, b;
+    if (int rc = merge_args(a, ja, lr, eps)) return rc;
+    if (int rc = merge_args(b, jb, lr, eps)) return rc;
+    const int nbA = (int)(((int64_t)a.nsrc * a.cap + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK);
+    const int nbB = (int)(((int64_t)b.nsrc * b.cap + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK);
+    const dim3 g((unsigned)(nbA + nbB)), bl(KGE_BLOCK);
+    const int dmax = a.dim > b.dim ? a.dim : b.dim;      // one instance for both jobs: the narrower row just leaves packs unused
+    if (dmax <= 256) hipLaunchKernelGGL(apply_merged_pair_kernel<1>, g, bl, 0, (hipStream_t)stream, a, b, nbA);
+    else if (dmax <= 512) hipLaunchKernelGGL(apply_merged_pair_kernel<2>, g, bl, 0, (hipStream_t)stream, a, b, nbA);
+    else hipLaunchKernelGGL(apply_merged_pair_kernel<4>, g, bl, 0, (hipStream_t)stream, a, b, nbA);
     return check_launch_r();
 }
 

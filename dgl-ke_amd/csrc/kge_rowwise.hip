@@ -797,7 +797,9 @@ int launch_update(const UpdateArgs &a, hipStream_t s) {
                          !a.dry;
     if ((a.Hs || a.Rs || a.Ns) && !(vec && dmax <= 1024)) return KGE_ERR_ARG;      // stale-row regulariser: register-resident kernel only
     if (a.Q && !a.transe_fast) return KGE_ERR_ARG;
-    const int lean = (!inplace || a.nd_chunk) ? 0 : (a.transe_fast ? (a.Q ? 3 : 1) : 2);
+    // (the LEAN instances fix the regulariser's norm at 3: plain multiplies instead of exp2 / log2 per element)
+    const bool reg3 = !(a.reg_coef > 0.f && a.reg_norm > 0) || a.reg_norm == 3;
+    const int lean = (!inplace || a.nd_chunk || !reg3) ? 0 : (a.transe_fast ? (a.Q ? 3 : 1) : 2);
     const int nit = dmax <= 256 ? 1 : (dmax <= 512 ? 2 : 4);
 #define KGE_UPD(N, SH, LE) hipLaunchKernelGGL((update_kernel_reg<N, SH, LE>), g, b, 0, s, a, nbE)
 #define KGE_UPD_L(N, SH)                                                         \

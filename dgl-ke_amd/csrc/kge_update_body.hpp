@@ -309,6 +309,7 @@ __device__ __forceinline__ void update_reg_body(const UpdateArgs &a_in, int nb_e
         a.transe_fast = (LEAN == 1 || LEAN == 3) ? 1 : 0; a.emit_ent = 0; a.emit_rel = 0;
         if (LEAN != 3) a.Q = nullptr;
         a.g0 = a.g1 = a.gs0 = a.gs1 = a.gr = a.gsr = nullptr; a.rid = nullptr; a.dry = 0; a.nd_chunk = 0; a.emit_by_id = 0;
+        a.reg_norm = 3;             // (launch_update sends any other norm to the generic instance)
     }
     const int lane = LANE();
     const bool reg = a.reg_coef > 0.f && a.reg_norm > 0;

@@ -71,6 +71,12 @@ class KgeEmit(C.Structure):
                 ("ld_e", c_i32), ("ld_r", c_i32), ("rid", c_p), ("ent_by_id", c_i32), ("reserved", c_i32)]
 
 
+class KgeMergeJob(C.Structure):
+    _fields_ = [("table", c_p), ("state_sum", c_p), ("n_rows", c_i64), ("dim", c_i32), ("nsrc", c_i32), ("cap", c_i32),
+                ("ld", c_i32), ("ntraces", c_i32), ("reserved", c_i32), ("id_words", c_p), ("id_stride_words", c_i64),
+                ("id_offset", c_i64), ("msg", c_p)]
+
+
 class KgeShards(C.Structure):
     _fields_ = [("n_shards", c_i32), ("reserved", c_i32), ("ent_rows_per_shard", c_i64),
                 ("rel_rows_per_shard", c_i64), ("ent_rows", c_p), ("ent_state", c_p),
@@ -114,6 +120,7 @@ _SIGNATURES = {
     "kge_batch_localized": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "kge_gather_rows_req": (c_i, [c_p, c_i64, c_i, c_p, c_i64, c_i64, c_p, c_p]),
     "kge_adagrad_apply_merged": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_i, c_p, c_i64, c_i64, c_p, c_i, c_i, c_f, c_f, c_p]),
+    "kge_adagrad_apply_merged_pair": (c_i, [C.POINTER(KgeMergeJob), C.POINTER(KgeMergeJob), c_f, c_f, c_p]),
     "kge_adagrad_apply_rows": (c_i, [c_p, c_p, c_i64, c_i, c_p, c_p, c_p, c_i64, c_f, c_f, c_p]),
     "kge_step_workspace_bytes": (c_sz, [C.POINTER(KgeHParams), c_i, c_i, c_i, c_i, c_i, c_i]),
     "kge_step_fused": (c_i, [C.POINTER(KgeHParams), C.POINTER(KgeTables), C.POINTER(KgeBatch),

@@ -259,6 +259,24 @@ class HipOps(object):
                                                        stride, int(lo), _lib.ptr(msg), ld, ntraces, float(lr), 1e-10,
                                                        _lib.stream_ptr()))
 
+    @staticmethod
+    def _job(table, state, nsrc, cap, ids, lo, msg, ntraces):
+        dim, ld = table.shape[1], msg.shape[1]
+        j = _lib.KgeMergeJob()
+        j.table, j.state_sum, j.n_rows = _lib.ptr(table), _lib.ptr(state), table.shape[0]
+        j.dim, j.nsrc, j.cap, j.ld, j.ntraces = dim, nsrc, cap, ld, ntraces
+        if ids is not None:
+            j.id_words, j.id_stride_words = ids.data_ptr(), 2
+        else:
+            j.id_words, j.id_stride_words = msg.data_ptr() + 4 * (ntraces * dim + ntraces), ld
+        j.id_offset, j.msg = int(lo), _lib.ptr(msg)
+        return j
+
+    def apply_merged_pair(self, job_a, job_b, lr):
+        """two apply_merged jobs (tuples of its arguments without lr) in ONE launch: the entity-shard and the relation-replica apply"""
+        ja, jb = self._job(*job_a), self._job(*job_b)
+        _lib.check(_lib.lib().kge_adagrad_apply_merged_pair(C.byref(ja), C.byref(jb), float(lr), 1e-10, _lib.stream_ptr()))
+
     def reset_rel_pads(self, rel_msg, d_r, first):
         """host-built plans: message rows >= the batch's unique-relation count are pads (device-built plans: the kernel writes them)"""
         if first < rel_msg.shape[0]:
@@ -443,8 +461,13 @@ class DistEngine(object):
                 self.comm.all_gather(self.all_rel.view(-1), self.rel_msg.view(-1))
         if before_apply is not None:
             before_apply()
-        self.ops.apply_merged(self.ent, self.ent_state, W, self.cap, s.recv_ids, sp.lo, self.recv_msg, 2, self.lr)
-        self.ops.apply_merged(self.engine.rel, self.engine.rel_state, W, lb.B, None, 0, self.all_rel, 1, self.lr)
+        pair = getattr(self.ops, "apply_merged_pair", None)
+        if pair is not None and self.d_e % 4 == 0 and self.d_r % 4 == 0:      # both applies in one launch (same results)
+            pair((self.ent, self.ent_state, W, self.cap, s.recv_ids, sp.lo, self.recv_msg, 2),
+                 (self.engine.rel, self.engine.rel_state, W, lb.B, None, 0, self.all_rel, 1), self.lr)
+        else:
+            self.ops.apply_merged(self.ent, self.ent_state, W, self.cap, s.recv_ids, sp.lo, self.recv_msg, 2, self.lr)
+            self.ops.apply_merged(self.engine.rel, self.engine.rel_state, W, lb.B, None, 0, self.all_rel, 1, self.lr)
 
     def step(self, batch):
         """one synchronous sharded step (pull, compute, push, apply), all enqueued on the current stream."""

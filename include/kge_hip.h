@@ -496,6 +496,17 @@ int kge_adagrad_apply_merged(float *table, float *state_sum, int64_t n_rows, int
                              int64_t id_stride_words, int64_t id_offset, const float *msg, int ld, int ntraces, float lr, float eps,
                              void *stream);
 
+/* two kge_adagrad_apply_merged jobs - the entity-shard apply and the relation-replica apply of one sharded step - as ONE launch
+ * (independent tables and messages; same arithmetic and order per job as two separate calls: bit-identical results) */
+typedef struct kge_merge_job {
+    float *table, *state_sum;
+    int64_t n_rows;
+    int32_t dim, nsrc, cap, ld, ntraces, reserved;
+    const int32_t *id_words; int64_t id_stride_words, id_offset;
+    const float *msg;
+} kge_merge_job;
+int kge_adagrad_apply_merged_pair(const kge_merge_job *a, const kge_merge_job *b, float lr, float eps, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

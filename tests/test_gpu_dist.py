@@ -172,6 +172,30 @@ def test_apply_merged_equals_sequential_apply(nsrc, cap, dim, n_rows):
     kd.HipOps().apply_merged(t2, s2, nsrc, cap, None, lo, torch.from_numpy(m2).to(DEV), T, lr)
     torch.cuda.synchronize()
     assert torch.equal(t2, t_d) and torch.equal(s2, s_d)
+    # round 4: the step's two applies as ONE launch (kge_adagrad_apply_merged_pair: this job next to a second, narrower,
+    # single-trace job with the ids inside its messages - the relation replica's) - bit-identical to the two separate calls
+    if dim % 4 == 0:
+        d2 = max(4, dim // 2 // 4 * 4)
+        tab_b = rng.randn(37, d2).astype(np.float32)
+        st_b = rng.rand(37).astype(np.float32)
+        ids_b = np.full((nsrc, 8), -1, np.int64)
+        for s in range(nsrc):
+            k = rng.randint(1, 9)
+            ids_b[s, :k] = np.sort(rng.choice(37, k, replace=False))
+        msg_b = (rng.randn(nsrc * 8, d2 + 4) * 0.05).astype(np.float32)
+        msg_b[:, d2] = rng.rand(nsrc * 8).astype(np.float32) * 0.01
+        msg_b.view(np.int32)[:, d2 + 1] = (ids_b.reshape(-1) & 0xffffffff).astype(np.uint32).view(np.int32)
+        msg_b.view(np.int32)[:, d2 + 2] = (ids_b.reshape(-1) >> 32).astype(np.int32)
+        ops = kd.HipOps()
+        ta, sa = torch.from_numpy(table).to(DEV), torch.from_numpy(state).to(DEV)
+        tb1, sb1 = torch.from_numpy(tab_b).to(DEV), torch.from_numpy(st_b).to(DEV)
+        tb2, sb2 = tb1.clone(), sb1.clone()
+        ids_d, msg_d, msgb_d = torch.from_numpy(ids.reshape(-1)).to(DEV), torch.from_numpy(msg).to(DEV), torch.from_numpy(msg_b).to(DEV)
+        ops.apply_merged(tb1, sb1, nsrc, 8, None, 0, msgb_d, 1, lr)
+        ops.apply_merged_pair((ta, sa, nsrc, cap, ids_d, lo, msg_d, T), (tb2, sb2, nsrc, 8, None, 0, msgb_d, 1), lr)
+        torch.cuda.synchronize()
+        assert torch.equal(ta, t_d) and torch.equal(sa, s_d) and torch.equal(tb2, tb1) and torch.equal(sb2, sb1)
+        assert not torch.equal(tb1.cpu(), torch.from_numpy(tab_b))
 
 
 def _run_workers(tmp_path, mode, world=2, transport="host"):
