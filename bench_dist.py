@@ -456,6 +456,15 @@ def main(args, world, rank, local_rank):
     _progress("warmup")
     eng.loss_accum.zero_()
     torch.cuda.synchronize()
+    if os.environ.get("KGE_DIST_PROFILE") == "1" and rank == 0:      # developer aid: where the HOST time of the eager step goes
+        import cProfile
+        import pstats
+        pr = cProfile.Profile()
+        pr.enable()
+        run(args.steps)
+        pr.disable()
+        torch.cuda.synchronize()
+        pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(22)
     t0 = time.perf_counter()
     run(args.steps)
     torch.cuda.synchronize()

@@ -7,6 +7,8 @@ loss 1e-5 rel/abs, gradients 3e-4 of the largest gradient component (fp32 cancel
 the reference's own |a|^2+|b|^2-2ab formulation, see tests/test_oracle_golden.py), post-update
 rows 5e-3*lr (Adagrad's first steps normalise the gradient).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
