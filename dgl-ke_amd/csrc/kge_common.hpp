@@ -243,6 +243,18 @@ __device__ __forceinline__ void criterion(int genre, float s, float label, float
     criterion_fast(genre, s, label, margin, val, dval);
 }
 
+// Edge importance and the POSITIVE loss part: the reference multiplies `pos_loss [B]` by `edge_weight.view(-1, 1) [B, 1]`
+// (loss.py:75, 82) - a [B, B] broadcast whose mean is mean_j crit(p_j) * mean_i w_i: every positive edge is weighted by the MEAN
+// importance of the batch, not by its own (the negative part, [B, N] * [B, 1], is weighted per edge).  Kept as it is (found in
+// round 4 by the per-golden row tolerance: goldens/transe_l2_impts).  Every wavefront that needs it sums the B weights itself
+// (lane-strided, then the fixed-order wave reduction: deterministic).
+__device__ __forceinline__ float mean_edge_weight(const float *w, int B, int lane) {
+    if (!w) return 1.f;
+    float s = 0.f;
+    for (int j = lane; j < B; j += KGE_WAVE) s += w[j];
+    return wave_sum(s) / (float)B;
+}
+
 // bijective XCD-aware remap: hardware block b runs on XCD b%8; give the blocks of one XCD
 // consecutive logical ids (L2 locality only, never correctness).
 __device__ __forceinline__ int xcd_remap(int b, int nb) {

@@ -58,12 +58,15 @@ __device__ __forceinline__ void loss_row_regs(const LossArgs &a, int64_t i, floa
         return;
     }
     float plw = 0.f;
-    if (lane == 0 && !a.skip_pos) {
-        float pl, dpl;
-        criterion(a.genre, p, 1.f, a.margin, pl, dpl);
-        a.dpos[i] = (a.clampv > 0.f && fabsf(p) >= a.clampv) ? 0.f : dpl * w * 0.5f * invB;
-        plw = pl * w * invB;
-        if (a.row_pos) a.row_pos[i] = plw;
+    if (!a.skip_pos) {
+        const float wm = mean_edge_weight(a.w, a.B, lane);     // positive part: the batch's MEAN importance (kge_common.hpp)
+        if (lane == 0) {
+            float pl, dpl;
+            criterion(a.genre, p, 1.f, a.margin, pl, dpl);
+            a.dpos[i] = (a.clampv > 0.f && fabsf(p) >= a.clampv) ? 0.f : dpl * wm * 0.5f * invB;
+            plw = pl * wm * invB;
+            if (a.row_pos) a.row_pos[i] = plw;
+        }
     }
     const float neg_label = a.genre == KGE_LOSS_BCE ? 0.f : -1.f;
     float mx = -INFINITY, Z = 1.f;

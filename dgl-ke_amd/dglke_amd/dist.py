@@ -341,6 +341,8 @@ class DistEngine(object):
         # a single rank needs no collective (the buffers alias); always_collective keeps the calls (tests: the RCCL path at world 1)
         self.coll = spec.world > 1 or bool(always_collective)
         self.slots = None
+        import os
+        self._pair_ok = os.environ.get("KGE_DIST_PAIR_APPLY", "1") != "0"      # (A/B aid: the two owner-side applies as two launches)
         self._pre = None              # (batch, LocalBatch, slot index, event) of a pull that ran ahead
         self._side = None
         self._parity = 0
@@ -461,7 +463,7 @@ class DistEngine(object):
                 self.comm.all_gather(self.all_rel.view(-1), self.rel_msg.view(-1))
         if before_apply is not None:
             before_apply()
-        pair = getattr(self.ops, "apply_merged_pair", None)
+        pair = getattr(self.ops, "apply_merged_pair", None) if self._pair_ok else None
         if pair is not None and self.d_e % 4 == 0 and self.d_r % 4 == 0:      # both applies in one launch (same results)
             pair((self.ent, self.ent_state, W, self.cap, s.recv_ids, sp.lo, self.recv_msg, 2),
                  (self.engine.rel, self.engine.rel_state, W, lb.B, None, 0, self.all_rel, 1), self.lr)

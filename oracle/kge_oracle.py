@@ -344,7 +344,11 @@ def loss_fwd_bwd(pos, neg, w=None, genre="Logsigmoid", adv=False, adv_temp=1.0, 
     neg_label = 0 if genre == "BCE" else -1
     pl, dpl = _criterion(genre, pos, 1, margin)
     nl, dnl = _criterion(genre, neg, neg_label, margin)
-    pl = pl * wcol[:, 0]
+    # loss.py:82: `pos_loss [B] * edge_weight.view(-1, 1) [B, 1]` broadcasts to [B, B]; its mean (:92) is mean(pl) * mean(w) - every
+    # positive edge carries the batch's MEAN importance (the negative part, [B, N] * [B, 1], is per edge).  Pinned by
+    # goldens/transe_l2_impts (round 4: the earlier per-edge form was 0.5 % off in pos_loss, hidden by saturated positives)
+    wmean = wcol.mean()
+    pl = pl * wmean
     nl = nl * wcol
     if adv:
         # loss.py:87-88 ; softmax is detached
@@ -359,7 +363,7 @@ def loss_fwd_bwd(pos, neg, w=None, genre="Logsigmoid", adv=False, adv_temp=1.0, 
     neg_loss = neg_i.mean()
     pos_loss = pl.mean()
     loss = (neg_loss + pos_loss) / 2
-    dpos = dpl * wcol[:, 0] / dt.type(2 * B)
+    dpos = dpl * wmean / dt.type(2 * B)
     dneg = dnl * wcol * A / dt.type(2 * B)
     return (pos_loss, neg_loss, loss), dpos.astype(dt), dneg.astype(dt)
 

@@ -7,6 +7,23 @@ from golden_util import async_golden_names, eval_golden_names, golden_names, loa
 from oracle import kge_oracle as O
 
 
+_NOISE = None
+
+
+def _rows(got, ref, name, tab, lr, what):
+    """post-update rows against the golden: within max(1e-4 * lr, 3 x the reference's own fp32-vs-fp64 distance on this case)
+    (tests/golden/noise.json, `gen_golden.py --noise`; round 3's blanket 5e-3 * lr hid a 1.7e-3 * lr semantic difference in the
+    edge-importance case: the reference weights the positive loss by the batch's MEAN importance, loss.py:75,82)"""
+    global _NOISE
+    if _NOISE is None:
+        import json
+        import os
+        _NOISE = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "noise.json")))
+    tol = max(1e-4, 3.0 * _NOISE[name][tab]) * lr
+    err = float(np.abs(np.asarray(got, np.float64) - np.asarray(ref, np.float64)).max())
+    assert err <= tol + 1e-6 * float(np.abs(ref).max()), "%s %s: %.3e lr > %.3e lr" % (name, what, err / lr, tol / lr)
+
+
 def _close(a, b, rtol, atol, what):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
@@ -73,10 +90,10 @@ def test_step_matches_reference(name, dtype):
         _close(ent_state, z[p + "entity_state"], 1e-3, 1e-9, name + " ent state")
         _close(rel_state, z[p + "relation_state"], 1e-3, 1e-9, name + " rel state")
         if (p + "entity") in z:
-            _close(ent, z[p + "entity"], 1e-4, 5e-3 * case["lr"], name + " entity table step %d" % s)
-            _close(rel, z[p + "relation"], 1e-4, 5e-3 * case["lr"], name + " relation table step %d" % s)
-    _close(ent, z["final_entity"], 1e-4, 1e-2 * case["lr"], name + " final entity")
-    _close(rel, z["final_relation"], 1e-4, 1e-2 * case["lr"], name + " final relation")
+            _rows(ent, z[p + "entity"], name, "entity", case["lr"], "entity table step %d" % s)
+            _rows(rel, z[p + "relation"], name, "relation", case["lr"], "relation table step %d" % s)
+    _rows(ent, z["final_entity"], name, "entity", case["lr"], "final entity")
+    _rows(rel, z["final_relation"], name, "relation", case["lr"], "final relation")
 
 
 def test_duplicate_adagrad_semantics():
