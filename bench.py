@@ -32,6 +32,8 @@ for p in (ROOT, os.path.join(ROOT, "dgl-ke_amd")):
 import numpy as np
 import torch
 
+from dglke_amd import _lib as _kge_lib
+
 WORKLOADS = {
     # BASELINE.json configs[1]
     "transe_l2_fb15k": dict(model="TransE_l2", n_ent=14951, n_rel=1345, n_train=483142, hidden=400,
@@ -268,7 +270,7 @@ def async_measure(w, dev, steps, G, flags, seed=0, skew=False):
     torch.cuda.synchronize()
     eng.reset_parameters()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with _kge_lib.graph_capture(g):
         eng.steps_async(smp.sample())
     nrep = max(1, steps // G)
     for _ in range(2):
@@ -303,7 +305,7 @@ def skew_measure(w, dev, steps, G, flags, seed=0):
     torch.cuda.synchronize()
     eng.reset_parameters()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with _kge_lib.graph_capture(g):
         for b in smp.sample():
             eng.step(b)
     nrep = max(1, steps // G)

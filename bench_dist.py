@@ -29,6 +29,8 @@ import time
 
 import numpy as np
 import torch
+
+from dglke_amd import _lib as _kge_lib
 import torch.distributed as dist
 
 DIST_WORKLOADS = {
@@ -75,7 +77,7 @@ def _p2p_setup(args, world, rank, dev, w, n_ent, d_e, d_r, emb_init):
     gr = None
     if not args.no_graph:
         gr = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gr):
+        with _kge_lib.graph_capture(gr):
             group()
         torch.cuda.synchronize()
 
@@ -86,7 +88,7 @@ def _p2p_setup(args, world, rank, dev, w, n_ent, d_e, d_r, emb_init):
     if gr is not None:
         for n in {args.warmup % G, args.steps % G} - {0}:
             rem_graphs[n] = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(rem_graphs[n]):
+            with _kge_lib.graph_capture(rem_graphs[n]):
                 partial(n)
         torch.cuda.synchronize()
 
@@ -100,7 +102,7 @@ def _p2p_setup(args, world, rank, dev, w, n_ent, d_e, d_r, emb_init):
             if gr is not None:
                 if count % G not in rem_graphs:         # (a size nobody announced: captured on first use)
                     rem_graphs[count % G] = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(rem_graphs[count % G]):
+                    with _kge_lib.graph_capture(rem_graphs[count % G]):
                         partial(count % G)
                 rem_graphs[count % G].replay()
             else:
@@ -168,7 +170,7 @@ def _a2a_setup(args, world, rank, dev, w, n_ent, d_e, emb_init, allow_force_coll
             if use_graph:
                 if n not in graphs:
                     graphs[n] = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(graphs[n]):
+                    with _kge_lib.graph_capture(graphs[n]):
                         steps(smp.sample(n))
                 graphs[n].replay()
             else:
@@ -179,7 +181,7 @@ def _a2a_setup(args, world, rank, dev, w, n_ent, d_e, emb_init, allow_force_coll
     if use_graph:                       # capture outside the timed region
         for n in {G, args.warmup % G, args.steps % G} - {0}:
             graphs[n] = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graphs[n]):
+            with _kge_lib.graph_capture(graphs[n]):
                 steps(smp.sample(n))
         torch.cuda.synchronize()
     def graph_runner():
@@ -191,7 +193,7 @@ def _a2a_setup(args, world, rank, dev, w, n_ent, d_e, emb_init, allow_force_coll
 
         def cap(n):
             gg[n] = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gg[n]):
+            with _kge_lib.graph_capture(gg[n]):
                 for b in smp.sample(n):
                     de.step(b)
         for n in {Gd, args.warmup % Gd, args.steps % Gd} - {0}:

@@ -4,7 +4,9 @@ The library is the product: every op in this package runs through it.  There is 
 fallback - if the shared object is missing (not built) importing an op raises, and calling an op
 with a non-CUDA tensor raises.
 """
+import contextlib
 import ctypes as C
+import gc
 import os
 import threading
 
@@ -211,6 +213,22 @@ def use_stream(ptr):
     prev = getattr(_STREAM_TLS, "ptr", None)
     _STREAM_TLS.ptr = ptr
     return prev
+
+
+@contextlib.contextmanager
+def graph_capture(g, stream=None):
+    """`with torch.cuda.graph(g, stream=stream)` with Python's cyclic garbage collector held off for the duration of the capture: a
+    collection that runs DURING capture may destroy an older engine's graphs / tensors (hipFree, hipGraphDestroy), which
+    invalidates the capture and aborts the process (seen when several trainers are built one after the other in one process)."""
+    gc.collect()
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        with torch.cuda.graph(g, stream=stream):
+            yield
+    finally:
+        if was:
+            gc.enable()
 
 
 def model_id(name):

@@ -7,6 +7,8 @@ head/tail iterator of dataloader/sampler.py:823-876."""
 import numpy as np
 import torch as th
 
+from . import _lib
+
 from . import plan as _plan
 
 
@@ -274,7 +276,7 @@ class PrefetchedGroups(object):
                 g.replay()
             else:
                 g = th.cuda.CUDAGraph()
-                with th.cuda.graph(g):
+                with _lib.graph_capture(g):
                     nxt = self._enqueue_fork(n_next)
                 self.graphs[key] = (g, nxt)
                 g.replay()
@@ -294,7 +296,7 @@ class PrefetchedGroups(object):
             key = (n_cur, self.buf)
             if key not in self.graphs:
                 g = th.cuda.CUDAGraph()
-                with th.cuda.graph(g):
+                with _lib.graph_capture(g):
                     for b in self.ready:
                         self.step_fn(b)
                 self.graphs[key] = g

@@ -239,7 +239,7 @@ class StepEngine(object):
             (self.async_workspace_for if async_update else self.workspace_for)(b)
         # warm-up on a side stream is not needed: the library allocates nothing
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=stream):
+        with _lib.graph_capture(g, stream=stream):
             if async_update:
                 self.steps_async(batches)
             else:

@@ -210,7 +210,7 @@ class _Lane(object):
                     if n - done >= G:
                         self.stream.synchronize()
                         g = th.cuda.CUDAGraph()
-                        with th.cuda.graph(g, stream=self.stream if t.n_lanes > 1 else None):
+                        with _lib.graph_capture(g, stream=self.stream if t.n_lanes > 1 else None):
                             self._steps(smp.sample(G))
                         self._graph = g
                         smp.host_step -= G            # the capture itself did not run the steps
@@ -227,7 +227,7 @@ class _Lane(object):
                     # ~6 eager launches per step every time (56 -> 44 us/step at log_interval 1000, eval 500)
                     self.stream.synchronize()
                     g = th.cuda.CUDAGraph()
-                    with th.cuda.graph(g, stream=self.stream if t.n_lanes > 1 else None):
+                    with _lib.graph_capture(g, stream=self.stream if t.n_lanes > 1 else None):
                         self._steps(smp.sample(k))
                     smp.host_step -= k                # the capture itself did not run the steps
                     self._rem_graphs[key] = g

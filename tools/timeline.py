@@ -37,6 +37,7 @@ def main():
     args = ap.parse_args()
     import bench
     from dglke_amd import _lib
+    _kge_lib = _lib
     from dglke_amd.dataloader import DeviceSampler
     from dglke_amd.engine import StepEngine
     w = dict(bench.WORKLOADS[args.workload])
@@ -66,7 +67,7 @@ def main():
     run_group()
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with _kge_lib.graph_capture(g):
         run_group()
     for _ in range(args.reps):
         g.replay()
