@@ -399,8 +399,20 @@ __device__ __forceinline__ void neg_fwd_gemm_ldsa_body(const GemmArgs &a, int ti
                                                        const LossArgs *lap = nullptr, int *tickets = nullptr) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int tjg = (tj + 3) >> 2;
-    const int L = xcd_remap(bid, nblk);
-    const int jg = L % tjg, it = (L / tjg) % ti, c = L / (tjg * ti);
+    // workgroup -> (chunk, strip, column group).  Round 4: when the last column group of a strip is partial (N = 200: 13 tiles =
+    // 4 + 4 + 4 + 1) the FULL groups take the first block ids and the partial ones the last: at cfg-T 260 workgroups meet 256
+    // CUs, and the four CUs that get a second workgroup should get a 1-tile one, not a second set of four loops (the doubled
+    // CUs set the end of the launch: tile wavefronts p90 7.0 us, max 8.2 us, profiles/r04_loss_fold.txt).  Same tiles, same
+    // arithmetic; only where they run changes.
+    int jg, sidx;
+#ifndef KGE_FWD_PLAIN_ORDER
+    const int nfull = (tj & 3) ? tjg - 1 : tjg, nheavy = a.C * ti * nfull;
+    if (bid < nheavy) { const int L = xcd_remap(bid, nheavy); jg = L % nfull; sidx = L / nfull; }
+    else { sidx = xcd_remap(bid - nheavy, nblk - nheavy); jg = tjg - 1; }
+#else
+    { const int L = xcd_remap(bid, nblk); jg = L % tjg; sidx = L / tjg; }
+#endif
+    const int it = sidx % ti, c = sidx / ti;
     const int jt = min(jg * 4 + wv, tj - 1);             // (a wavefront beyond the last column tile helps building A, then leaves)
     const bool tile_ok = jg * 4 + wv < tj;
     const int D = a.D, KP = ((D + 15) & ~15) + 4, n4 = D >> 2;

