@@ -137,8 +137,12 @@ def _a2a_setup(args, world, rank, dev, w, n_ent, d_e, emb_init, allow_force_coll
     force_coll = allow_force_coll and os.environ.get("KGE_DIST_FORCE_COLL", "0") == "1"
     # collectives: librccl called directly on the step's streams (dist.RcclComm; KGE_DIST_COMM=torch: the c10d wrappers)
     comm = kd.make_comm() if (world > 1 or force_coll) else None
+    # relation partitioning (the reference's multi-GPU Freebase recipe passes --rel_part, examples/freebase/multi_gpu.sh:100-116): every
+    # rank's triples use its own relations (r = rank mod world), relation rows are updated where their edges are - no relation
+    # exchange.  KGE_DIST_REL_PART=0: uniform relations on every rank, relation messages all-gathered and applied by everyone
+    rel_part = world > 1 and os.environ.get("KGE_DIST_REL_PART", "1") != "0"
     de = kd.DistEngine(eng, spec, ent, ent_state, comm=comm, slack=float(os.environ.get("KGE_DIST_SLACK", "1.5")),
-                       always_collective=force_coll)
+                       always_collective=force_coll, rel_local=rel_part)
     # this rank's edge shard: synthetic uniform triples over the GLOBAL id space, generated in HBM
     n_train = int(os.environ.get("KGE_DIST_TRIPLES", min(338586276 // world, 48_000_000)))
     g = torch.Generator(device=dev)
@@ -146,6 +150,8 @@ def _a2a_setup(args, world, rank, dev, w, n_ent, d_e, emb_init, allow_force_coll
     H = torch.randint(0, n_ent, (n_train,), device=dev, generator=g)
     T = torch.randint(0, n_ent, (n_train,), device=dev, generator=g)
     R = torch.randint(0, w["n_rel"], (n_train,), device=dev, generator=g)
+    if rel_part:
+        R = torch.clamp((R // world) * world + rank, max=(w["n_rel"] - 1 - rank) // world * world + rank)
     G = max(2, min(120, args.graph_steps) // 2 * 2)
     smp = DeviceSampler(H, R, T, n_ent, w["B"], w["N"], dev, n_slots=G, seed=rank + 1)
     pipelined = (world > 1 or force_coll) and os.environ.get("KGE_DIST_PIPELINE", "1") != "0"
@@ -212,15 +218,20 @@ def _a2a_setup(args, world, rank, dev, w, n_ent, d_e, emb_init, allow_force_coll
     a_ = smp.slot_arrays(0)
     u_pos = int(np.unique(np.concatenate([a_["h_gid"], a_["t_gid"]])).shape[0])
     ue = int(np.unique(np.concatenate([a_["h_gid"], a_["t_gid"], a_["neg_ids"]])).shape[0])
-    rows = dict(UE=ue, R_e=u_pos + C * w["N"], B=w["B"], cap=de.cap, graph_runner=None if use_graph else graph_runner)
+    rows = dict(UE=ue, R_e=u_pos + C * w["N"], B=w["B"], cap=de.cap, graph_runner=None if use_graph else graph_runner,
+                rel_part=rel_part)
+    rel_desc = ("triples partitioned by relation (--rel_part of the reference's recipe): relation rows updated on their owner rank, "
+                "no relation exchange" if rel_part else "relation gradients all-gathered")
+    comm_desc = ((": librccl called directly" + ("" if rel_part else ", push + relation exchange grouped"))
+                 if type(de.comm).__name__ == "RcclComm" else ": torch.distributed wrappers") if de.coll else ""
+    launch_desc = ("hipGraph of [1 sampler launch + %d steps]" % G if use_graph else
+                   ("eager launches, pull of step s+1 overlapped with step s (one-step-stale rows, --async_update licence)"
+                    if pipelined else "eager launches"))
     desc = ("entity table range-sharded, relation table replicated; per step: device-side routing into %d-row owner buckets, "
             "all-to-all pull of the unique rows, the single-GPU kernels against the row cache, all-to-all push of one packed "
-            "gradient message per row, owner-side Adagrad in rank order (one merged launch), relation gradients all-gathered "
+            "gradient message per row, owner-side Adagrad in rank order (one merged launch), %s "
             "(parameter-server semantics, RCCL%s); %s; sampling + plan on the device inside the timed region"
-            % (de.cap, (": librccl called directly, push + relation exchange grouped" if type(de.comm).__name__ == "RcclComm" else
-                        ": torch.distributed wrappers") if de.coll else "", "hipGraph of [1 sampler launch + %d steps]" % G if use_graph else
-               ("eager launches, pull of step s+1 overlapped with step s (one-step-stale rows, --async_update licence)"
-                if pipelined else "eager launches")))
+            % (de.cap, rel_desc, comm_desc, launch_desc))
     return eng, run, rows, desc, de
 
 
@@ -634,7 +645,8 @@ def _result_line(args, w, n_ent, world, wall, K, rows, d_e, d_r, desc, mode, why
             xgmi_step = 3.0 * (rows["R_e"] * d_e + rows["B"] * d_r) * 4 * (world - 1) / world
         else:
             cap = rows.get("cap") or rows["UE"]
-            xgmi_step = ((world - 1) * cap * (8 + 4 * d_e + 4 * (2 * d_e + 4)) + (world - 1) * rows["B"] * 4 * (d_r + 4)) * 1.0
+            rel_bytes = 0 if rows.get("rel_part") else (world - 1) * rows["B"] * 4 * (d_r + 4)      # (no relation exchange under --rel_part)
+            xgmi_step = ((world - 1) * cap * (8 + 4 * d_e + 4 * (2 * d_e + 4)) + rel_bytes) * 1.0
         out = {
             "metric": "positive edges/sec (whole node)",
             "value": round(K * w["B"] * world / wall, 1), "unit": "edges/s",
@@ -663,6 +675,7 @@ def _result_line(args, w, n_ent, world, wall, K, rows, d_e, d_r, desc, mode, why
                                 else "python bench.py --gpus 1 --workload rotate_freebase",
         }
         if mode == "a2a":
+            out["config"]["relation_partition"] = bool(rows.get("rel_part"))
             out["config"]["bucket_rows"] = rows.get("cap")
             out["config"]["bucket_growth"] = rows.get("grown")
             out["config"]["bucket_overflows"] = overflow

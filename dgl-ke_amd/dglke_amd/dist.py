@@ -324,7 +324,7 @@ class DistEngine(object):
     rank's shard.  Batches carry GLOBAL entity ids and their plan (DeviceSampler slots or plan.upload)."""
 
     def __init__(self, engine, spec, ent_shard, ent_state_shard, ops=None, comm=None, cap=None, slack=1.5,
-                 always_collective=False):
+                 always_collective=False, rel_local=False):
         self.engine = engine
         self.spec = spec
         self.ent = ent_shard
@@ -340,6 +340,11 @@ class DistEngine(object):
         self.cap, self.slack = cap, slack
         # a single rank needs no collective (the buffers alias); always_collective keeps the calls (tests: the RCCL path at world 1)
         self.coll = spec.world > 1 or bool(always_collective)
+        # rel_local: the training triples are PARTITIONED BY RELATION over the ranks (the reference's --rel_part,
+        # dataloader/sampler.py:150-254, general_models.py:590-637 - the recipe of its multi-GPU Freebase runs): a relation's edges all
+        # live on one rank, so its row is updated there and nowhere else - no relation exchange at all (no all-gather, no W-fold
+        # apply); the owners' rows are collected when the tables are read (relation_rows_from_owners)
+        self.rel_local = bool(rel_local)
         self.slots = None
         import os
         self._pair_ok = os.environ.get("KGE_DIST_PAIR_APPLY", "1") != "0"      # (A/B aid: the two owner-side applies as two launches)
@@ -387,7 +392,7 @@ class DistEngine(object):
         self.ent_msg = z((W * cap + 1, ld_e), dt)
         self.recv_msg = self.ent_msg[:W * cap] if not self.coll else z((W * cap, ld_e), dt)
         self.rel_msg = z((b.B, ld_r), dt)
-        self.all_rel = self.rel_msg if not self.coll else z((W * b.B, ld_r), dt)
+        self.all_rel = self.rel_msg if (not self.coll or self.rel_local) else z((W * b.B, ld_r), dt)
         self.zero_state = z(W * cap + 1, dt)
 
     def ensure_capacity(self, batches, log=None):
@@ -454,7 +459,10 @@ class DistEngine(object):
 
     def _push_apply(self, lb, before_apply=None):
         sp, s, W = self.spec, self.slots[lb.slot], self.spec.world
-        if self.coll:                     # both exchanges depend on step_grads only: one grouped launch where the communicator can
+        Wr = 1 if self.rel_local else W    # sources of relation messages: this rank alone under relation partitioning
+        if self.coll and self.rel_local:
+            self.comm.all_to_all(self.recv_msg, self.ent_msg[:W * self.cap])
+        elif self.coll:                   # both exchanges depend on step_grads only: one grouped launch where the communicator can
             pair = getattr(self.comm, "push_pair", None)
             if pair is not None:
                 pair(self.recv_msg, self.ent_msg[:W * self.cap], self.all_rel.view(-1), self.rel_msg.view(-1))
@@ -466,10 +474,10 @@ class DistEngine(object):
         pair = getattr(self.ops, "apply_merged_pair", None) if self._pair_ok else None
         if pair is not None and self.d_e % 4 == 0 and self.d_r % 4 == 0:      # both applies in one launch (same results)
             pair((self.ent, self.ent_state, W, self.cap, s.recv_ids, sp.lo, self.recv_msg, 2),
-                 (self.engine.rel, self.engine.rel_state, W, lb.B, None, 0, self.all_rel, 1), self.lr)
+                 (self.engine.rel, self.engine.rel_state, Wr, lb.B, None, 0, self.all_rel, 1), self.lr)
         else:
             self.ops.apply_merged(self.ent, self.ent_state, W, self.cap, s.recv_ids, sp.lo, self.recv_msg, 2, self.lr)
-            self.ops.apply_merged(self.engine.rel, self.engine.rel_state, W, lb.B, None, 0, self.all_rel, 1, self.lr)
+            self.ops.apply_merged(self.engine.rel, self.engine.rel_state, Wr, lb.B, None, 0, self.all_rel, 1, self.lr)
 
     def step(self, batch):
         """one synchronous sharded step (pull, compute, push, apply), all enqueued on the current stream."""
@@ -534,6 +542,39 @@ class DistEngine(object):
         # the apply of step s must not start before the gather of step s+1 has read the shard (else the staleness is a race)
         self._push_apply(lb, (lambda: main.wait_event(ev_gather)) if ev_gather is not None else None)
         self._parity = lb.slot ^ 1
+
+
+def relation_partition(rels, world):
+    """whole relations to ranks, most frequent first, each to the rank with the fewest edges so far (the reference's
+    BalancedRelationPartition, dataloader/sampler.py:150-254, WITHOUT its splitting of a relation over several partitions: a split
+    relation needs the cross-relation machinery - dual writes to a global table, general_models.py:590-637 - that relation-local
+    updates are there to avoid; the price is a less even edge split when one relation holds more than 1 / world of the edges).
+    Returns (owner[n_rel_seen_max + 1] with -1 for relations without edges, part[i] = rank of edge i)."""
+    rels = np.asarray(rels, np.int64)
+    uniq, cnts = np.unique(rels, return_counts=True)
+    order = np.argsort(-cnts, kind="stable")
+    load = np.zeros(world, np.int64)
+    owner = np.full(int(uniq.max()) + 1 if len(uniq) else 0, -1, np.int64)
+    for k in order:
+        w = int(np.argmin(load))
+        owner[uniq[k]] = w
+        load[w] += cnts[k]
+    return owner, owner[rels]
+
+
+def relation_rows_from_owners(rel, rel_state, owner, group=None):
+    """after training with rel_local: every rank's replica holds the current rows of ITS relations only - collect the owners' rows
+    into rank 0's replica (gather through the process group; relations nobody owns keep their initial rows)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    own = torch.as_tensor(np.nonzero(np.asarray(owner) == rank)[0], dtype=torch.int64)
+    mine = (own, rel[own.to(rel.device)].cpu(), rel_state[own.to(rel.device)].cpu())
+    parts = [None] * world if rank == 0 else None
+    dist.gather_object(mine, parts, dst=0, group=group)
+    if rank == 0:
+        for ids, rows, st in parts:
+            if len(ids):
+                rel[ids.to(rel.device)] = rows.to(rel.device)
+                rel_state[ids.to(rel.device)] = st.to(rel.device)
 
 
 def localize_plan(h, t, r, neg, chunk, N, neg_head, edge_w=None):

@@ -573,12 +573,25 @@ class A2ATrainer(ShardedTrainer):
         own_gpu = len(set(args.gpu)) == world
         self.comm = kd.make_comm() if own_gpu else kd.HostStagedComm()
         slack = args.dist_slack if getattr(args, 'dist_slack', None) else float(os.environ.get("KGE_DIST_SLACK", "1.5"))
-        self.de = kd.DistEngine(self.engine, self.spec, self.ent, self.ent_state, comm=self.comm, slack=slack)
+        # --rel_part (the reference's multi-GPU recipes pass it, examples/freebase/multi_gpu.sh): the triples are split BY RELATION,
+        # every relation row is updated on the one rank that owns its edges - no relation exchange (dist.DistEngine rel_local)
+        self.rel_part = bool(getattr(args, 'rel_part', False))
+        self.de = kd.DistEngine(self.engine, self.spec, self.ent, self.ent_state, comm=self.comm, slack=slack,
+                                rel_local=self.rel_part)
         # the pull of step s+1 may overlap step s only under the staleness --async_update licenses (tensor_models.py:136-175);
         # without the flag every step gathers after its predecessor's update has landed, like the reference
         self.pipelined = bool(getattr(args, 'async_update', False))
         tr = dataset.train
-        part = np.array_split(np.random.RandomState(args.seed).permutation(len(tr[0])), world)[rank]
+        self.rel_owner = None
+        if self.rel_part:
+            self.rel_owner, edge_rank = kd.relation_partition(tr[1], world)
+            part = np.nonzero(edge_rank == rank)[0]
+            if rank == 0:
+                cnt = np.bincount(edge_rank, minlength=world)
+                print("relation partition: %d relations over %d trainers, edges per trainer %s" % (
+                    int((self.rel_owner >= 0).sum()), world, cnt.tolist()))
+        else:
+            part = np.array_split(np.random.RandomState(args.seed).permutation(len(tr[0])), world)[rank]
         if len(part) < B:
             raise KgeError("--batch_size %d is larger than a trainer's share of the training triples (%d over %d trainers)"
                            % (B, len(tr[0]), world))
@@ -614,6 +627,9 @@ class A2ATrainer(ShardedTrainer):
         th.cuda.synchronize()
         parts = [None] * self.world if self.rank == 0 else None
         dist.gather_object(self.ent.cpu(), parts, dst=0)
+        if self.rel_part:                    # every replica holds the current rows of ITS relations only: collect them on rank 0
+            from . import dist as kd
+            kd.relation_rows_from_owners(self.engine.rel, self.engine.rel_state, self.rel_owner)
         if self.rank == 0:
             self._full = (th.cat(parts).to(self.dev), self.engine.rel)
 

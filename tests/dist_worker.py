@@ -37,6 +37,9 @@ def batches(world, steps, mode, seed=5):
                 bt["r"] = bt["r"] + k * nr
             else:
                 bt = O.synth_batch(rng, N_ENT, N_REL, B, N, N, s + 1)
+                if mode == "relpart":        # rank k's triples use the relations r = k mod world only (the reference's --rel_part)
+                    top = (N_REL - 1 - k) // world * world + k
+                    bt["r"] = np.minimum((bt["r"] // world) * world + k, top)
             row.append(bt)
         out.append(row)
     return out
@@ -67,8 +70,9 @@ def main():
         spec = kd.ShardSpec(N_ENT, world, rank)
         ent = ent0[spec.lo:spec.hi].to(dev).contiguous()
         state = torch.zeros(spec.n_local, device=dev)
-        de = kd.DistEngine(eng, spec, ent, state, comm=comm or kd.HostStagedComm(), cap=None, slack=1.6)
-        bts = batches(world, STEPS, "disjoint" if mode == "disjoint" else "random")
+        de = kd.DistEngine(eng, spec, ent, state, comm=comm or kd.HostStagedComm(), cap=None, slack=1.6,
+                           rel_local=(mode == "relpart"))
+        bts = batches(world, STEPS, mode if mode in ("disjoint", "relpart") else "random")
         ue_bound = 2 * B + (B // N) * N
         devb = []
         for row in bts:
@@ -83,6 +87,8 @@ def main():
                 de.step(b)
         torch.cuda.synchronize()
         assert de.check_overflow() == 0
+        if mode == "relpart":                # the owners' relation rows are collected on rank 0, like A2ATrainer.sync_tables does
+            kd.relation_rows_from_owners(eng.rel, eng.rel_state, np.arange(N_REL) % world)
         shards = [None] * world
         dist.all_gather_object(shards, (ent.cpu().numpy(), state.cpu().numpy(), eng.rel.cpu().numpy(), eng.rel_state.cpu().numpy()))
         if rank == 0:

@@ -113,12 +113,16 @@ class OracleOps(object):
         rm[:len(ur), dr + 1] = ur
 
 
-def _batches(world, steps, heavy=False):
+def _batches(world, steps, heavy=False, relpart=False):
     """heavy: a heavy-tailed graph whose hubs are clustered in the first shard (ids remapped so that 3 of 4 edge ends and
     negatives fall into the lowest eighth of the id range) - what real graphs with popularity-sorted ids look like."""
     from oracle import kge_oracle as O
     rng = np.random.RandomState(5)
     out = [[O.synth_batch(rng, N_ENT, N_REL, B, N, CHUNK, s + 1) for _ in range(world)] for s in range(steps)]
+    if relpart:          # the reference's --rel_part: rank k's triples use relations r = k mod world only
+        for row in out:
+            for k, bt in enumerate(row):
+                bt["r"] = np.minimum((bt["r"] // world) * world + k, (N_REL - 1 - k) // world * world + k)
     if heavy:
         lowest = max(2, N_ENT // 8)
         for row in out:
@@ -131,7 +135,7 @@ def _batches(world, steps, heavy=False):
     return out
 
 
-def _worker(rank, world, port, ret, cap=CAP, heavy=False, group=1):
+def _worker(rank, world, port, ret, cap=CAP, heavy=False, group=1, relpart=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "dgl-ke_amd"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -148,9 +152,9 @@ def _worker(rank, world, port, ret, cap=CAP, heavy=False, group=1):
         ent_shard = torch.from_numpy(ent[spec.lo:spec.hi].copy())
         state_shard = torch.zeros(spec.n_local, dtype=torch.float64)
         eng = FakeEngine(torch.from_numpy(rel.copy()), torch.zeros(N_REL, dtype=torch.float64), LR)
-        de = kd.DistEngine(eng, spec, ent_shard, state_shard, ops=OracleOps(cfg), cap=cap)
+        de = kd.DistEngine(eng, spec, ent_shard, state_shard, ops=OracleOps(cfg), cap=cap, rel_local=relpart)
         mine = []
-        for step_batches in _batches(world, 3 if not heavy else 4, heavy):
+        for step_batches in _batches(world, 3 if not heavy else 4, heavy, relpart):
             bt = step_batches[rank]
             p = plan.build_plan(bt["h"], bt["t"], bt["r"], bt["neg"], CHUNK, N, bt["neg_head"])     # GLOBAL ids
             p["UE_exact"] = p["UE"]
@@ -167,6 +171,8 @@ def _worker(rank, world, port, ret, cap=CAP, heavy=False, group=1):
                 assert de.check_overflow() == 0
         if rank == 0:
             ret["cap"], ret["grown"], ret["logs"] = de.cap, list(getattr(de, "grown", [])), logs
+        if relpart:          # no relation exchange happened: collect the owners' rows on rank 0 (what A2ATrainer.sync_tables does)
+            kd.relation_rows_from_owners(eng.rel, eng.rel_state, np.arange(N_REL) % world)
         # collect the shards on rank 0
         shards = [None] * world
         dist.all_gather_object(shards, (ent_shard.numpy(), state_shard.numpy(), eng.rel.numpy(), eng.rel_state.numpy()))
@@ -179,7 +185,7 @@ def _worker(rank, world, port, ret, cap=CAP, heavy=False, group=1):
         dist.destroy_process_group()
 
 
-def _expected(world, heavy=False):
+def _expected(world, heavy=False, relpart=False):
     """single-process statement of the synchronous sharded step: every rank's gradients are
     computed from the SAME pre-step tables, then applied owner-side in rank order (trace 0 then
     trace 1 per rank; relations in rank order)."""
@@ -189,7 +195,7 @@ def _expected(world, heavy=False):
     ent = rng.uniform(-1, 1, (N_ENT, HID))
     rel = rng.uniform(-1, 1, (N_REL, HID))
     es, rs = np.zeros(N_ENT), np.zeros(N_REL)
-    for step_batches in _batches(world, 3 if not heavy else 4, heavy):
+    for step_batches in _batches(world, 3 if not heavy else 4, heavy, relpart):
         outs = [O.forward_backward(cfg, ent, rel, bt["nid"], bt["h_local"], bt["t_local"], bt["r"],
                                    bt["neg"], bt["neg_head"], CHUNK, N) for bt in step_batches]
         for bt, out in zip(step_batches, outs):
@@ -245,3 +251,31 @@ def test_heavy_tailed_ids_world8_grow_the_buckets_and_drop_nothing():
     for r_, s_ in zip(ret["rels"], ret["rel_states"]):
         np.testing.assert_allclose(r_, rel, rtol=1e-9, atol=1e-11)
         np.testing.assert_allclose(s_, rs, rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.timeout(180)
+def test_relation_partition_needs_no_relation_exchange():
+    """the reference's --rel_part (dataloader/sampler.py:150-254; its multi-GPU Freebase recipe passes it): every rank's triples use
+    its own relations, so a relation row is updated on one rank only - DistEngine(rel_local=True) skips the relation all-gather
+    and applies its own messages alone; rank 0's table, completed from the owners' rows, equals the single-process statement
+    (which applies the ranks' relation traces in rank order - on disjoint rows here), and the partition helper assigns whole
+    relations, most frequent first, to the rank with the fewest edges."""
+    sys.path.insert(0, os.path.join(ROOT, "dgl-ke_amd"))
+    from dglke_amd.dist import relation_partition
+    rels = np.array([0] * 50 + [1] * 30 + [2] * 20 + [3] * 10 + [5] * 5)
+    owner, part = relation_partition(rels, 2)
+    assert owner[4] == -1 and set(owner[[0, 1, 2, 3, 5]].tolist()) == {0, 1}
+    assert (part == owner[rels]).all() and abs(int((part == 0).sum()) - int((part == 1).sum())) <= 15
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, ret, CAP, False, 1, True), nprocs=world, join=True)
+    ent, es, rel, rs = _expected(world, relpart=True)
+    np.testing.assert_allclose(ret["ent"], ent, rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(ret["state"], es, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(ret["rels"][0], rel, rtol=1e-9, atol=1e-11)          # rank 0: completed from the owners
+    np.testing.assert_allclose(ret["rel_states"][0], rs, rtol=1e-9, atol=1e-12)
+    own1 = np.arange(N_REL) % world == 1
+    np.testing.assert_allclose(ret["rels"][1][own1], rel[own1], rtol=1e-9, atol=1e-11)   # rank 1: its own relations are current
+    assert np.abs(ret["rels"][1][~own1] - rel[~own1]).max() > 1e-6                  # ... and the others were never exchanged

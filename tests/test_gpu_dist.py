@@ -199,7 +199,7 @@ def test_apply_merged_equals_sequential_apply(nsrc, cap, dim, n_rows):
 
 
 def _run_workers(tmp_path, mode, world=2, transport="host"):
-    port = str(29700 + os.getpid() % 250 + {"random": 0, "disjoint": 1, "pipelined": 2, "nd": 6}[mode] + (3 if transport == "rccl" else 0))
+    port = str(29700 + os.getpid() % 250 + {"random": 0, "disjoint": 1, "pipelined": 2, "nd": 6, "relpart": 7}[mode] + (3 if transport == "rccl" else 0))
     env = dict(os.environ)
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), str(r), str(world), port, str(tmp_path), mode,
                                transport], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
@@ -225,7 +225,7 @@ def _oracle_statement(model, de_, dr_, z, world, mode):
                    neg_deg=(mode == "nd"))
     ent, rel = z[model + "_init_ent"].astype(np.float64), z[model + "_init_rel"].astype(np.float64)
     es, rs = np.zeros(W.N_ENT), np.zeros(W.N_REL)
-    bts = W.batches(world, W.STEPS, "random")
+    bts = W.batches(world, W.STEPS, "relpart" if mode == "relpart" else "random")
     pulled = ent.copy()                    # what the pull of the current step saw
     for s, row in enumerate(bts):
         src = pulled if mode == "pipelined" else ent
@@ -240,8 +240,8 @@ def _oracle_statement(model, de_, dr_, z, world, mode):
     return ent, es, rel, rs
 
 
-@pytest.mark.parametrize("mode,transport", [("random", "host"), ("pipelined", "host"), ("nd", "host"), ("random", "rccl"),
-                                            ("pipelined", "rccl")])
+@pytest.mark.parametrize("mode,transport", [("random", "host"), ("pipelined", "host"), ("nd", "host"), ("relpart", "host"),
+                                            ("random", "rccl"), ("pipelined", "rccl"), ("relpart", "rccl")])
 def test_world2_hip_ops_match_the_oracle_statement(tmp_path, mode, transport):
     """`host`: two processes on ONE device, messages staged through gloo.  `rccl`: two processes on TWO devices, the product's
     transport - dist.RcclComm (ncclAllToAll / ncclAllGather on the step's streams, grouped push, side-stream pull) - against
@@ -256,9 +256,15 @@ def test_world2_hip_ops_match_the_oracle_statement(tmp_path, mode, transport):
         assert np.abs(z[model + "_ent"] - z[model + "_init_ent"]).max() > 1e-3, "training did not move the table"
         np.testing.assert_allclose(z[model + "_state"], es, rtol=2e-3, atol=1e-9, err_msg=model + " entity state")
         np.testing.assert_allclose(z[model + "_ent"], ent, rtol=1e-4, atol=5e-3 * lr, err_msg=model + " entity rows")
-        for r in range(2):
+        for r in range(1 if mode == "relpart" else 2):
             np.testing.assert_allclose(z[model + "_relstate%d" % r], rs, rtol=2e-3, atol=1e-9, err_msg=model + " relation state")
             np.testing.assert_allclose(z[model + "_rel%d" % r], rel, rtol=1e-4, atol=5e-3 * lr, err_msg=model + " relation rows")
+        if mode == "relpart":
+            # relation partitioning: no relation exchange - rank 1's replica holds current rows for ITS relations only; rank 0's was
+            # completed from the owners (checked against the statement above)
+            own1 = np.arange(W.N_REL) % 2 == 1
+            assert np.array_equal(z[model + "_rel0"][own1], z[model + "_rel1"][own1])
+            continue
         assert np.array_equal(z[model + "_rel0"], z[model + "_rel1"]), "relation replicas differ"
         assert np.array_equal(z[model + "_relstate0"], z[model + "_relstate1"])
 
