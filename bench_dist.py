@@ -67,6 +67,8 @@ def _p2p_setup(args, world, rank, dev, w, n_ent, d_e, d_r, emb_init):
     smp = DeviceSampler(H, R, T, n_ent, w["B"], w["N"], dev, n_slots=G, seed=rank + 1)
     dbs = smp.sample()
     eng.workspace_for(dbs[0])
+    torch.cuda.synchronize()
+    _progress("tables")
     for b in dbs:                       # eager warm-up of every kernel before capture
         eng.step(b)
     torch.cuda.synchronize()
@@ -164,6 +166,8 @@ def _a2a_setup(args, world, rank, dev, w, n_ent, d_e, emb_init, allow_force_coll
                 de.step(b)
     dbs = smp.sample()
     eng.workspace_for(dbs[0])
+    torch.cuda.synchronize()
+    _progress("tables")                 # everything local is in place; what follows is the first contact with the peers
     steps(dbs[:4])                      # eager warm-up: allocates every persistent buffer
     torch.cuda.synchronize()
     graphs = {}
@@ -258,9 +262,15 @@ def _deliver(line):
 # what the orchestrator tries, in order, until one attempt delivers a line on every rank: the north_star mode
 # on the direct librccl communicator, the same on the c10d wrappers, the peer-to-peer shared tables, and - so that a node whose
 # links do not come up still yields a measured line that says so - N independent replicas of the per-GPU step without any exchange
-ATTEMPTS = (("a2a", "rccl"), ("a2a", "torch"), ("p2p", ""), ("replicas", ""))
-# per-phase budgets in seconds (a hang shows up as a phase that does not end; KGE_DIST_PHASE_TIMEOUTS="a,b,c,d,e" overrides)
-PHASE_BUDGET = {"start": 420.0, "setup": 120.0, "warmup": 90.0, "timed": 180.0, "headline": 200.0}
+ATTEMPTS = (("a2a", "rccl"), ("a2a", "rccl-sync"), ("a2a", "torch"), ("p2p", ""), ("replicas", ""))
+# ("rccl-sync": the same direct communicator with the synchronous schedule - no pull on a side stream, one stream issues every
+#  collective: if two streams sharing one communicator are what hangs, this attempt still measures the north_star mode)
+# seconds allowed until the named progress mark appears (a hang shows up as a mark that does not come;
+# KGE_DIST_PHASE_TIMEOUTS="start,tables,setup,warmup,timed,headline" overrides): start = interpreter + torch import + build check;
+# tables = local allocations; setup = communicator + the first eager steps (first contact with the links); headline .. end =
+# the secondary legs
+PHASE_ORDER = ("start", "tables", "setup", "warmup", "timed", "headline", "end")
+PHASE_BUDGET = {"start": 300.0, "tables": 120.0, "setup": 90.0, "warmup": 90.0, "timed": 120.0, "headline": 60.0, "end": 200.0}
 
 
 def orchestrate(args, world, rank, local_rank):
@@ -278,13 +288,13 @@ def orchestrate(args, world, rank, local_rank):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     budgets = dict(PHASE_BUDGET)
     if os.environ.get("KGE_DIST_PHASE_TIMEOUTS"):
-        for k, v in zip(("start", "setup", "warmup", "timed", "headline"), os.environ["KGE_DIST_PHASE_TIMEOUTS"].split(",")):
+        for k, v in zip(PHASE_ORDER, os.environ["KGE_DIST_PHASE_TIMEOUTS"].split(",")):
             budgets[k] = float(v)
-    order = {"start": "setup", "setup": "warmup", "warmup": "timed", "timed": "headline"}
+    order = {a: b for a, b in zip(PHASE_ORDER[:-1], PHASE_ORDER[1:])}
     first = os.environ.get("KGE_DIST_MODE", "a2a")
     attempts = [a for a in ATTEMPTS if a[0] == first] + [a for a in ATTEMPTS if a[0] != first]
     if os.environ.get("KGE_DIST_COMM") == "torch":
-        attempts = [a for a in attempts if a != ("a2a", "rccl")]
+        attempts = [a for a in attempts if a[1] not in ("rccl", "rccl-sync")]
     history, line = [], None
     tmpdir = tempfile.mkdtemp(prefix="kge_dist_%d_" % rank)
     for ai, (mode, comm) in enumerate(attempts):
@@ -294,7 +304,9 @@ def orchestrate(args, world, rank, local_rank):
         env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
         env.update({"KGE_DIST_WORKER": "1", "KGE_DIST_MODE": mode, "KGE_DIST_RESULT": res_path, "KGE_DIST_PROGRESS": prog_path,
                     "MASTER_PORT": str(base_port + 1 + ai), "RANK": str(rank), "LOCAL_RANK": str(local_rank), "WORLD_SIZE": str(world)})
-        if comm:
+        if comm == "rccl-sync":
+            env["KGE_DIST_COMM"], env["KGE_DIST_PIPELINE"] = "rccl", "0"
+        elif comm:
             env["KGE_DIST_COMM"] = comm
         # (KGE_DIST_WORKER_SCRIPT: the CPU test of this supervisor substitutes a scripted worker, tests/test_bench_supervisor.py)
         cmd = [sys.executable, os.environ.get("KGE_DIST_WORKER_SCRIPT") or
@@ -310,13 +322,15 @@ def orchestrate(args, world, rank, local_rank):
             if len(marks) > seen:                       # a phase ended: the next one gets its own budget
                 seen = len(marks)
                 phase = marks[-1]
-                deadline = time.time() + budgets.get(order.get(phase, "headline"), budgets["headline"])
+                # (after the headline the secondary legs set up engines of their own and repeat earlier marks: one budget for all that)
+                deadline = time.time() + (budgets["end"] if "headline" in marks else budgets.get(order.get(phase, "end"), budgets["end"]))
             if rc is not None:
                 if rc != 0:
                     why = "worker exited with status %d in the phase after '%s'" % (rc, phase)
                 break
             if time.time() > deadline:
-                why = "no progress for %.0f s in the phase after '%s' (watchdog)" % (budgets.get(order.get(phase, "headline"), 0.0), phase)
+                why = "no progress for %.0f s in the phase after '%s' (watchdog)" % (
+                    budgets.get(order.get(phase, "end"), 0.0) if seen else budgets["start"], phase if seen else "launch")
                 try:
                     os.killpg(child.pid, signal.SIGKILL)
                 except OSError:

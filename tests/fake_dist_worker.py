@@ -4,6 +4,7 @@ KGE_FAKE_PLAN environment variable says - "mode/comm=behaviour,..." with behavio
   crash        exits with status 3 after 'start'
   hang_rank1   rank 1 hangs after 'setup', rank 0 runs through   (one rank stuck: the other ranks' lines must not count)
   leg_hang     delivers the headline, then hangs             (a secondary leg that never ends)
+  ok_rank0_only rank 1 crashes, rank 0 delivers a line       (the line of a rank whose peers failed must not count)
   ok           all marks, delivers a line"""
 import json
 import os
@@ -27,9 +28,10 @@ def deliver(obj):
 
 
 mark("start")
+mark("tables")
 if what == "hang_setup":
     time.sleep(3600)
-if what == "crash":
+if what == "crash" or (what == "ok_rank0_only" and rank == 1):
     sys.exit(3)
 mark("setup")
 if what == "hang_rank1" and rank == 1:

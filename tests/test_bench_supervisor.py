@@ -25,7 +25,7 @@ def _run(plan, world=2, timeout=120):
         env = dict(os.environ)
         env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1",
                     "MASTER_PORT": str(port), "KGE_DIST_WORKER_SCRIPT": os.path.join(HERE, "fake_dist_worker.py"),
-                    "KGE_FAKE_PLAN": plan, "KGE_DIST_PHASE_TIMEOUTS": "3,3,3,3,3"})
+                    "KGE_FAKE_PLAN": plan, "KGE_DIST_PHASE_TIMEOUTS": "5,3,3,3,3,3,3"})
         env.pop("KGE_DIST_MODE", None)
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "20",
                                        "--warmup", "5"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
@@ -54,18 +54,19 @@ def test_first_attempt_succeeds():
 
 @pytest.mark.timeout(300)
 def test_hang_then_crash_then_one_stuck_rank_then_p2p():
-    d = _run("a2a/rccl=hang_setup,a2a/torch=crash,p2p=ok")
+    d = _run("a2a/rccl=hang_setup,a2a/rccl-sync=hang_setup,a2a/torch=crash,p2p=ok")
     at = d["config"]["attempts"]
-    assert [(h["mode"], h["comm"], h["ok"]) for h in at] == [("a2a", "rccl", False), ("a2a", "torch", False), ("p2p", None, True)]
-    assert "watchdog" in at[0]["why"] and "status 3" in at[1]["why"]
+    assert [(h["mode"], h["comm"], h["ok"]) for h in at] == [("a2a", "rccl", False), ("a2a", "rccl-sync", False),
+                                                             ("a2a", "torch", False), ("p2p", None, True)]
+    assert "watchdog" in at[0]["why"] and "tables" in at[0]["why"] and "status 3" in at[2]["why"]
     assert d["config"]["mode"] == "p2p" and "a2a/rccl" in d["config"]["fallback_reason"] and d["value"] == 123.0
 
 
 @pytest.mark.timeout(300)
 def test_one_stuck_rank_fails_the_attempt_and_replicas_close_the_chain():
-    d = _run("a2a/rccl=hang_rank1,a2a/torch=hang_rank1,p2p=crash,replicas=ok")
+    d = _run("a2a/rccl=hang_rank1,a2a/rccl-sync=ok_rank0_only,a2a/torch=hang_rank1,p2p=crash,replicas=ok")
     at = d["config"]["attempts"]
-    assert [h["ok"] for h in at] == [False, False, False, True] and at[-1]["mode"] == "replicas"
+    assert [h["ok"] for h in at] == [False, False, False, False, True] and at[-1]["mode"] == "replicas"
     assert d["config"]["mode"] == "replicas" and d["n_gpus"] == 2 and d["value"] > 0
     assert d["config"]["parallelism"] == "replicas only" and len(d["per_rank_us_per_step"]) == 2
 
@@ -79,5 +80,5 @@ def test_a_leg_that_hangs_after_the_headline_costs_only_itself():
 
 @pytest.mark.timeout(300)
 def test_every_attempt_failing_still_prints_a_line():
-    d = _run("a2a/rccl=crash,a2a/torch=crash,p2p=crash,replicas=crash")
-    assert d["value"] == 0.0 and d["config"]["fallback_reason"] == "every attempt failed" and len(d["config"]["attempts"]) == 4
+    d = _run("a2a/rccl=crash,a2a/rccl-sync=crash,a2a/torch=crash,p2p=crash,replicas=crash")
+    assert d["value"] == 0.0 and d["config"]["fallback_reason"] == "every attempt failed" and len(d["config"]["attempts"]) == 5
