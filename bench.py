@@ -290,13 +290,13 @@ def async_measure(w, dev, steps, G, flags, seed=0, skew=False):
                          "bit-reproducible); groups of %d steps, flushed at the end of each group" % G}
 
 
-def skew_measure(w, dev, steps, G, flags, seed=0):
+def skew_measure(w, dev, steps, G, flags, seed=0, skew=True):
     """the strict step on heavy-tailed ids (synth_triples(skew=True): FB15k's hub proportions) on its own tables, sampler inside
     the timed region: what uniform synthetic ids hide - rows with 20 - 40 contributions per batch.  Reported next to the
     headline (uniform ids, the shape BASELINE.json's synthetic metric is defined on), never as `value`."""
     from dglke_amd.dataloader import DeviceSampler
     from dglke_amd.engine import StepEngine
-    h, r, t = synth_triples(w, seed, True)
+    h, r, t = synth_triples(w, seed, skew)
     eng = StepEngine(w["model"], w["n_ent"], w["n_rel"], w["hidden"], w["gamma"], w["lr"], dev, w["de"], w["dr"], w["adv"],
                      w["adv_temp"], w["reg_coef"], w["reg_norm"], flags=flags)
     smp = DeviceSampler(h, r, t, w["n_ent"], w["B"], w["N"], dev, n_slots=G, seed=seed)
@@ -321,8 +321,8 @@ def skew_measure(w, dev, steps, G, flags, seed=0):
     sums = eng.read_loss_sums()
     return {"value": round(nrep * G * w["B"] / wall, 1), "unit": "edges/s", "steps": nrep * G,
             "us_per_step": round(1e6 * wall / (nrep * G), 3), "mean_loss": round(sums[2] / (nrep * G), 6),
-            "ids": "entity k with weight 1/(k+10)^0.9, relation k with 1/(k+5): most frequent relation ~3.6 % of the edges, "
-                   "hub entity ~1 % of the heads / tails (FB15k's proportions)"}
+            "ids": ("entity k with weight 1/(k+10)^0.9, relation k with 1/(k+5): most frequent relation ~3.6 % of the edges, "
+                    "hub entity ~1 % of the heads / tails (FB15k's proportions)") if skew else "uniform"}
 
 
 def other_configs(steps=600, timeout_s=150.0, only=None):
@@ -617,6 +617,16 @@ def main():
             out["heavy_tailed_ids"] = skew_measure(w, dev, min(K, 1200), G, eng.hp.flags)
         except Exception as e:
             out["heavy_tailed_ids"] = {"error": repr(e)}
+    if args.async_update and dev_sampler and not args.skew and not args.flags and w["model"] in ("TransE_l2", "DistMult", "ComplEx"):
+        # the 3-launch form of the strict step (KGE_FLAG_LOSS_IN_FWD: LossGenerator inside the first launch through a
+        # last-arriver hand-off; built in round 4, parity-tested, SLOWER - profiles/r04_loss_fold.txt): measured beside the
+        # default 4-launch step on every run so that the record stays current
+        try:
+            m3 = skew_measure(w, dev, min(K, 1200), G, eng.hp.flags | 1024, skew=False)
+            m3["what"] = "strict step as 3 launches (KGE_FLAG_LOSS_IN_FWD, opt-in); `value` is the default 4-launch step"
+            out["strict_step_3_launches"] = m3
+        except Exception as e:
+            out["strict_step_3_launches"] = {"error": repr(e)}
     if args.configs and args.workload == "transe_l2_fb15k" and not args.skew and not args.flags:
         del eng                        # (the legs run in their own processes; the 34-GB shard needs the HBM this one holds)
         torch.cuda.empty_cache()

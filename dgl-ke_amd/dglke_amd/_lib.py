@@ -220,9 +220,8 @@ def graph_capture(g, stream=None):
     """`with torch.cuda.graph(g, stream=stream)` with Python's cyclic garbage collector held off for the duration of the capture: a
     collection that runs DURING capture may destroy an older engine's graphs / tensors (hipFree, hipGraphDestroy), which
     invalidates the capture and aborts the process (seen when several trainers are built one after the other in one process)."""
-    gc.collect()
-    was = gc.isenabled()
-    gc.disable()
+    was = gc.isenabled()          # (torch.cuda.graph.__enter__ runs one full collection itself: no second one here - it costs
+    gc.disable()                  #  tens of milliseconds and the CLI captures inside its timed training loop)
     try:
         with torch.cuda.graph(g, stream=stream):
             yield

@@ -279,3 +279,28 @@ def test_relation_partition_needs_no_relation_exchange():
     own1 = np.arange(N_REL) % world == 1
     np.testing.assert_allclose(ret["rels"][1][own1], rel[own1], rtol=1e-9, atol=1e-11)   # rank 1: its own relations are current
     assert np.abs(ret["rels"][1][~own1] - rel[~own1]).max() > 1e-6                  # ... and the others were never exchanged
+
+
+def _comm_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "dgl-ke_amd"))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dglke_amd import dist as kd
+        c = kd.make_comm(kind="torch")              # what KGE_DIST_COMM=torch (or a failed librccl set-up) selects
+        if rank == 0:
+            ret["kind"] = type(c).__name__
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_fallback_communicator_on_a_gloo_group_stages_through_the_host():
+    """the CLI's process group is gloo; its all_to_all takes CPU tensors only, so the fallback from the direct librccl
+    communicator must be the host-staged one there (the c10d wrappers are for nccl groups)."""
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_comm_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert ret["kind"] == "HostStagedComm"
