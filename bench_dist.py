@@ -168,10 +168,20 @@ def _a2a_setup(args, world, rank, dev, w, n_ent, d_e, emb_init, allow_force_coll
     eng.workspace_for(dbs[0])
     torch.cuda.synchronize()
     _progress("tables")                 # everything local is in place; what follows is the first contact with the peers
+    de.prepare_group(dbs)               # bucket capacity + the routing of the whole group in one launch (allocates the route pool)
     steps(dbs[:4])                      # eager warm-up: allocates every persistent buffer
+    n_cg = 0
+    if de.coll:                         # eager step (collectives): its kernels between pull and push replay from small hipGraphs
+        torch.cuda.synchronize()
+        n_cg = de.precapture(smp)
     torch.cuda.synchronize()
     graphs = {}
     use_graph = world == 1 and not force_coll and not args.no_graph      # no collective at world 1: the group replays from a hipGraph
+
+    def group_(n):                      # one sampler launch, the group's buckets checked and ALL its batches routed in one launch,
+        dbs_ = smp.sample(n)            # then the steps (world 1: no device read in prepare_group, so the whole thing is capturable)
+        de.prepare_group(dbs_)
+        steps(dbs_)
 
     def run(count):                     # EXACTLY count steps: groups of G, then one partial group (one sampler launch each)
         left = count
@@ -181,18 +191,16 @@ def _a2a_setup(args, world, rank, dev, w, n_ent, d_e, emb_init, allow_force_coll
                 if n not in graphs:
                     graphs[n] = torch.cuda.CUDAGraph()
                     with _kge_lib.graph_capture(graphs[n]):
-                        steps(smp.sample(n))
+                        group_(n)
                 graphs[n].replay()
             else:
-                dbs_ = smp.sample(n)
-                de.ensure_capacity(dbs_)        # owner buckets sized before the group runs (a no-op read at world 1)
-                steps(dbs_)
+                group_(n)
             left -= n
     if use_graph:                       # capture outside the timed region
         for n in {G, args.warmup % G, args.steps % G} - {0}:
             graphs[n] = torch.cuda.CUDAGraph()
             with _kge_lib.graph_capture(graphs[n]):
-                steps(smp.sample(n))
+                group_(n)
         torch.cuda.synchronize()
     def graph_runner():
         """the same step with the RCCL collectives RECORDED into hipGraphs (synchronous schedule, groups of <= 20 steps, the host
@@ -229,8 +237,9 @@ def _a2a_setup(args, world, rank, dev, w, n_ent, d_e, emb_init, allow_force_coll
     comm_desc = ((": librccl called directly" + ("" if rel_part else ", push + relation exchange grouped"))
                  if type(de.comm).__name__ == "RcclComm" else ": torch.distributed wrappers") if de.coll else ""
     launch_desc = ("hipGraph of [1 sampler launch + %d steps]" % G if use_graph else
-                   ("eager launches, pull of step s+1 overlapped with step s (one-step-stale rows, --async_update licence)"
-                    if pipelined else "eager launches"))
+                   (("eager launches, pull of step s+1 overlapped with step s (one-step-stale rows, --async_update licence)"
+                     if pipelined else "eager launches") +
+                    (", the step's kernels between pull and push replayed from %d small hipGraphs" % n_cg if n_cg else "")))
     desc = ("entity table range-sharded, relation table replicated; per step: device-side routing into %d-row owner buckets, "
             "all-to-all pull of the unique rows, the single-GPU kernels against the row cache, all-to-all push of one packed "
             "gradient message per row, owner-side Adagrad in rank order (one merged launch), %s "

@@ -300,11 +300,13 @@ __device__ __forceinline__ void update_rel_row(const UpdateArgs &a, int bx, int 
 // instruction cache together, every launch starts cold, and the full-featured kernel was 11 k instructions.
 // `bid` / `nblk`: this workgroup's index and the number of workgroups doing update work (the body also runs as one
 // half of a horizontally fused launch, see neg_bwd_update_kernel in kge_neg_gemm.hip).
-template <int NIT, bool SHARDED, int LEAN>      // LEAN: 0 = everything at run time, 1 = in-place + TransE fast path,
+template <int NIT, bool SHARDED, int LEAN_>     // LEAN: 0 = everything at run time, 1 = in-place + TransE fast path,
 __device__ __forceinline__ void update_reg_body(const UpdateArgs &a_in, int nb_ent, int bid, int nblk) {   // 2 = in-place + per-edge gradients
-    using namespace kge;
+    using namespace kge;                         // 3 = 1 with Q rows; 4 (round 4) = 0 with the regulariser's norm fixed at 3 - the
+    constexpr int LEAN = LEAN_ == 4 ? 0 : LEAN_; // gradient-emitting (sharded all-to-all) step of every BASELINE recipe
     UpdateArgs a = a_in;
     if constexpr (!SHARDED) { a.em.n = 0; a.rm.n = 0; }
+    if constexpr (LEAN_ == 4) a.reg_norm = 3;
     if constexpr (LEAN != 0) {
         a.transe_fast = (LEAN == 1 || LEAN == 3) ? 1 : 0; a.emit_ent = 0; a.emit_rel = 0;
         if (LEAN != 3) a.Q = nullptr;

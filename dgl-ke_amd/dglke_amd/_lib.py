@@ -119,6 +119,7 @@ _SIGNATURES = {
     "kge_transr_project_neg_bwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p]),
     "kge_route_fill": (c_i, [c_p, c_i, c_sz, c_i, c_i64, c_p, c_p]),
     "kge_route_build": (c_i, [c_p, c_i, c_i64, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "kge_route_build_group": (c_i, [c_p, c_i, c_sz, c_i, c_i64, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_sz, c_p, c_p]),
     "kge_batch_localized": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "kge_gather_rows_req": (c_i, [c_p, c_i64, c_i, c_p, c_i64, c_i64, c_p, c_p]),
     "kge_adagrad_apply_merged": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_i, c_p, c_i64, c_i64, c_p, c_i, c_i, c_f, c_f, c_p]),
@@ -213,6 +214,61 @@ def use_stream(ptr):
     prev = getattr(_STREAM_TLS, "ptr", None)
     _STREAM_TLS.ptr = ptr
     return prev
+
+
+_hip = None
+
+
+def hip():
+    """the HIP runtime by ctypes (already loaded by torch): only for the three event calls of RawEvent"""
+    global _hip
+    if _hip is None:
+        h = C.CDLL("libamdhip64.so")
+        h.hipEventCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
+        h.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]
+        h.hipStreamWaitEvent.argtypes = [C.c_void_p, C.c_void_p, C.c_uint]
+        h.hipEventDestroy.argtypes = [C.c_void_p]
+        _hip = h
+    return _hip
+
+
+class RawEvent(object):
+    """hipEvent without timing, recorded on / waited for by raw stream pointers: ~1 us of host time per call where
+    torch.cuda.Event.record / Stream.wait_event cost 4-5 us each - the eager multi-GPU step issues six of them per step and is
+    host-bound (dist.DistEngine.step_pipelined)."""
+
+    def __init__(self):
+        self._e = C.c_void_p()
+        if hip().hipEventCreateWithFlags(C.byref(self._e), 0x2) != 0:        # hipEventDisableTiming
+            raise KgeError("hipEventCreateWithFlags failed")
+
+    def record(self, stream):
+        if hip().hipEventRecord(self._e, getattr(stream, "cuda_stream", stream)) != 0:
+            raise KgeError("hipEventRecord failed")
+
+    def wait(self, stream):
+        if hip().hipStreamWaitEvent(getattr(stream, "cuda_stream", stream), self._e, 0) != 0:
+            raise KgeError("hipStreamWaitEvent failed")
+
+    def __del__(self):
+        try:
+            if self._e:
+                hip().hipEventDestroy(self._e)
+        except Exception:       # noqa: BLE001 - interpreter shutdown
+            pass
+
+
+class TorchEvent(object):
+    """the same two calls on a torch.cuda.Event (communicators / ops that follow torch's current stream)"""
+
+    def __init__(self):
+        self._e = torch.cuda.Event()
+
+    def record(self, stream):
+        self._e.record(stream)
+
+    def wait(self, stream):
+        stream.wait_event(self._e)
 
 
 @contextlib.contextmanager

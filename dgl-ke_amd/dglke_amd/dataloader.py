@@ -175,6 +175,7 @@ class DeviceSampler(object):
         self.slot_bytes = int(_lib.lib().kge_sampler_slot_bytes(self.B, self.C, self.N))
         self.slots = th.zeros(self.n_slots * self.slot_bytes, dtype=th.uint8, device=self.dev)
         self.host_step = 1                                                     # next step to be sampled
+        self._batches = {}                                                     # (slot, corrupt-head) -> DeviceBatch
 
     def sample(self, n=None, slot0=0):
         """enqueue the construction of the next `n` (default: all slots) batches into slots slot0..slot0+n-1;
@@ -190,7 +191,15 @@ class DeviceSampler(object):
             _lib.ptr(self.perm) if self.perm is not None else None, self.n_train, self.n_entities, self.B,
             self.C, self.chunk, self.N, self.seed, _lib.ptr(self.state),
             self.slots.data_ptr() + slot0 * self.slot_bytes, self.slot_bytes, n, _lib.stream_ptr()))
-        out = [DeviceBatch(self, slot0 + k, (self.host_step + k) % 2 == 0) for k in range(n)]
+        # (a DeviceBatch is pointer arithmetic on a slot: built once per slot and corruption mode - a group of 120 fresh ones was
+        #  ~1 ms of ctypes calls in front of every group of the eager multi-GPU step)
+        out = []
+        for k in range(n):
+            key = (slot0 + k, (self.host_step + k) % 2 == 0)
+            b = self._batches.get(key)
+            if b is None:
+                b = self._batches[key] = DeviceBatch(self, key[0], key[1])
+            out.append(b)
         self.host_step += n
         return out
 

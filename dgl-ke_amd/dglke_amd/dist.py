@@ -228,7 +228,43 @@ class HipOps(object):
         kb = _lib.KgeBatch()
         _lib.check(L.kge_batch_localized(C.byref(batch.c), _lib.ptr(bf.h_loc), _lib.ptr(bf.t_loc), _lib.ptr(bf.neg_loc),
                                          _lib.ptr(bf.ue_loc), _lib.ptr(bf.ue_rec_loc), C.byref(kb)))
-        return LocalBatch(batch, kb, bf)
+        lb = LocalBatch(batch, kb, bf)
+        lb.req_ids = bf.req_ids
+        return lb
+
+    @staticmethod
+    def route_layout(batch, world, cap):
+        """byte offsets of one batch's routing outputs inside a pool row (32-byte aligned) and the row stride"""
+        al = lambda x: (x + 31) & ~31
+        o, off = 0, {}
+        for name, nbytes in (("req_ids", 8 * world * cap), ("h_loc", 8 * batch.B), ("t_loc", 8 * batch.B),
+                             ("neg_loc", 8 * batch.C * batch.N), ("ue_loc", 8 * batch.UE), ("ue_rec_loc", 32 * batch.UE)):
+            off[name] = o
+            o = al(o + nbytes)
+        return off, al(o)
+
+    def route_group(self, batches, world, per, cap, pool, off, stride, overflow):
+        """kge_route_build for a GROUP of consecutive sampler slots in ONE launch: batch k's outputs go to pool row (its sampler
+        slot) - see routed_batch for the re-addressed batch of a slot."""
+        L = _lib.lib()
+        b0 = batches[0]
+        base = pool.data_ptr() + b0.slot * stride
+        _lib.check(L.kge_route_build_group(C.byref(b0.c), len(batches), b0.sampler.slot_bytes, world, per, cap,
+                                           base + off["req_ids"], base + off["h_loc"], base + off["t_loc"], base + off["neg_loc"],
+                                           base + off["ue_loc"], base + off["ue_rec_loc"], stride, _lib.ptr(overflow),
+                                           _lib.stream_ptr()))
+
+    def routed_batch(self, b, world, cap, pool, off, stride):
+        """the re-addressed batch of sampler slot b.slot inside the route pool (pure pointer arithmetic: built once per slot and
+        corruption mode, then reused - the eager multi-GPU step is host-bound, 15 us of ctypes per batch showed)"""
+        row = pool.data_ptr() + b.slot * stride
+        kb = _lib.KgeBatch()
+        _lib.check(_lib.lib().kge_batch_localized(C.byref(b.c), row + off["h_loc"], row + off["t_loc"], row + off["neg_loc"],
+                                                  row + off["ue_loc"], row + off["ue_rec_loc"], C.byref(kb)))
+        lb = LocalBatch(b, kb, pool)
+        o0 = b.slot * stride + off["req_ids"]
+        lb.req_ids = pool[o0:o0 + 8 * world * cap].view(torch.int64)
+        return lb
 
     def route_fill(self, batches, world, per, out):
         """out[0] = max(out[0], the largest owner-bucket fill over `batches`): ONE launch when the batches are consecutive slots of a
@@ -274,8 +310,17 @@ class HipOps(object):
 
     def apply_merged_pair(self, job_a, job_b, lr):
         """two apply_merged jobs (tuples of its arguments without lr) in ONE launch: the entity-shard and the relation-replica apply"""
-        ja, jb = self._job(*job_a), self._job(*job_b)
-        _lib.check(_lib.lib().kge_adagrad_apply_merged_pair(C.byref(ja), C.byref(jb), float(lr), 1e-10, _lib.stream_ptr()))
+        # (the two argument structs of a given buffer set are built once: the eager multi-GPU step is host-bound)
+        key = (job_a[0].data_ptr(), job_a[4].data_ptr() if job_a[4] is not None else 0, job_a[6].data_ptr(), job_a[2], job_a[3],
+               job_b[0].data_ptr(), job_b[6].data_ptr(), job_b[2], job_b[3])
+        if not hasattr(self, "_jobs"):
+            self._jobs = {}
+        st = self._jobs.get(key)
+        if st is None:
+            if len(self._jobs) > 64:
+                self._jobs.clear()
+            st = self._jobs[key] = (self._job(*job_a), self._job(*job_b))
+        _lib.check(_lib.lib().kge_adagrad_apply_merged_pair(C.byref(st[0]), C.byref(st[1]), float(lr), 1e-10, _lib.stream_ptr()))
 
     def reset_rel_pads(self, rel_msg, d_r, first):
         """host-built plans: message rows >= the batch's unique-relation count are pads (device-built plans: the kernel writes them)"""
@@ -348,6 +393,11 @@ class DistEngine(object):
         self.slots = None
         import os
         self._pair_ok = os.environ.get("KGE_DIST_PAIR_APPLY", "1") != "0"      # (A/B aid: the two owner-side applies as two launches)
+        # (compute graphs - precapture() - are OPT-IN: measured slower than six eager launches, 180 vs 172 us per forced-collective
+        #  step at cfg-R: a graph launch costs more host time than the launches it replaces at this size)
+        self._cg_on = os.environ.get("KGE_DIST_COMPUTE_GRAPH", "0") == "1" and isinstance(self.ops, HipOps)
+        self._cgraphs = {}
+        self._routed, self._route_pool, self._route_key, self._route_lb = {}, None, None, {}   # prepare_group: routed ahead, per sampler slot
         self._pre = None              # (batch, LocalBatch, slot index, event) of a pull that ran ahead
         self._side = None
         self._parity = 0
@@ -378,6 +428,9 @@ class DistEngine(object):
                 self._side.synchronize()
         if hasattr(self.ops, "_structs"):
             self.ops._structs = {}    # HipOps caches its argument structs per buffer set (keyed by the buffers' addresses)
+        if hasattr(self.ops, "_jobs"):
+            self.ops._jobs = {}
+        self._cgraphs = {}            # compute graphs hold the old buffers' addresses
         self.slots = []
         for _ in range(2):
             s = _Slot()
@@ -425,6 +478,73 @@ class DistEngine(object):
             self._alloc(batches[0])
         return self.cap
 
+    def prepare_group(self, batches, log=None):
+        """everything a freshly sampled GROUP of batches needs before its steps: the bucket capacity (ensure_capacity) and - for
+        consecutive slots of a device sampler - the routing of ALL its batches in ONE launch (kge_route_build_group), so that a
+        step starts with the id exchange instead of a routing kernel (one launch per group instead of one per step)."""
+        self.ensure_capacity(batches, log)
+        self._routed = {}
+        group = getattr(self.ops, "route_group", None)
+        b0 = batches[0]
+        smp = getattr(b0, "sampler", None)
+        slots = [getattr(b, "slot", None) for b in batches]
+        if (group is None or smp is None or any(getattr(b, "sampler", None) is not smp for b in batches) or
+                slots != list(range(slots[0], slots[0] + len(slots)))):
+            return                                   # host-built plans: routed one by one in the step
+        W = self.spec.world
+        off, stride = self.ops.route_layout(b0, W, self.cap)
+        need = smp.n_slots * stride
+        if self._route_pool is None or self._route_pool.numel() != need or self._route_key != (id(smp), self.cap):
+            if self.dev.type == "cuda":
+                torch.cuda.current_stream(self.dev).synchronize()
+            self._route_pool = torch.zeros(need, dtype=torch.uint8, device=self.dev)
+            self._route_key = (id(smp), self.cap)
+            self._route_lb = {}
+            self._cgraphs = {}
+        group(batches, W, self.spec.shard, self.cap, self._route_pool, off, stride, self.overflow)
+        for b in batches:
+            key = (b.slot, b.neg_head)
+            lb = self._route_lb.get(key)
+            if lb is None:
+                lb = self._route_lb[key] = self.ops.routed_batch(b, W, self.cap, self._route_pool, off, stride)
+            self._routed[id(b)] = lb
+
+    def precapture(self, sampler):
+        """record the compute graphs of EVERY (sampler slot, corruption mode, cache slot) combination - pointer arithmetic only,
+        nothing executes - so that no capture ever falls into a timed step.  Call once after the first prepare_group (buffers and
+        route pool exist) and before training; a later change of the bucket capacity drops the graphs (the steps then launch
+        their kernels one by one again until precapture is called again).  Returns the number of graphs, 0 if switched off
+        (KGE_DIST_COMPUTE_GRAPH=0) or not applicable."""
+        from .dataloader import DeviceBatch
+        if not self._cg_on or self.dev.type != "cuda" or self._route_pool is None or self._route_key[0] != id(sampler):
+            return 0
+        W = self.spec.world
+        b0 = sampler._batches.get((0, False)) or sampler._batches.get((0, True)) or DeviceBatch(sampler, 0, False)
+        off, stride = self.ops.route_layout(b0, W, self.cap)
+        self.engine.workspace_for(b0)
+        try:
+            for slot in range(sampler.n_slots):
+                for nh in (False, True):
+                    key = (slot, nh)
+                    b = sampler._batches.get(key)
+                    if b is None:
+                        b = sampler._batches[key] = DeviceBatch(sampler, slot, nh)
+                    lb = self._route_lb.get(key)
+                    if lb is None:
+                        lb = self._route_lb[key] = self.ops.routed_batch(b, W, self.cap, self._route_pool, off, stride)
+                    for par in (0, 1):
+                        g = torch.cuda.CUDAGraph()
+                        with _lib.graph_capture(g):
+                            self.ops.step_grads(self.engine, lb, self.slots[par].cache, self.ent_msg, self.rel_msg, self.zero_state)
+                        self._cgraphs[(id(lb), par)] = g
+            if hasattr(self.engine, "_graphs"):
+                self.engine._graphs += 1             # the workspace's address is baked in: it may not move any more
+        except Exception as e:                       # noqa: BLE001 - the eager launches are always available
+            import sys
+            print("DistEngine: compute graphs switched off (%r)" % (e,), file=sys.stderr)
+            self._cgraphs, self._cg_on = {}, False
+        return len(self._cgraphs)
+
     def check_overflow(self):
         """entries that did not fit their owner bucket since the last call (one 4-byte D2H read: call at the log interval)."""
         if self.slots is None:
@@ -441,10 +561,13 @@ class DistEngine(object):
         if (batch.B, batch.C * batch.N, batch.UE) != self.geom:
             raise _lib.KgeError("DistEngine: batch geometry changed (B, C*N, UE bound) %r -> %r" % (self.geom, (batch.B, batch.C * batch.N, batch.UE)))
         sp, s, W = self.spec, self.slots[slot], self.spec.world
-        lb = self.ops.route(batch, W, sp.shard, self.cap, s)
+        lb = self._routed.get(id(batch)) or self.ops.route(batch, W, sp.shard, self.cap, s)     # (routed ahead by prepare_group, or now)
         if self.coll:
-            self.comm.all_to_all(s.recv_ids, s.req_ids)
-        self.ops.gather_req(self.ent, s.recv_ids, sp.lo, s.rows_out)
+            self.comm.all_to_all(s.recv_ids, lb.req_ids)
+            lb.recv_ids = s.recv_ids
+        else:
+            lb.recv_ids = lb.req_ids
+        self.ops.gather_req(self.ent, lb.recv_ids, sp.lo, s.rows_out)
         if self.coll:
             self.comm.all_to_all(s.cache[:W * self.cap], s.rows_out)
         lb.slot = slot
@@ -455,6 +578,14 @@ class DistEngine(object):
         s = self.slots[lb.slot]
         if not lb.c.counts_dev:
             self.ops.reset_rel_pads(self.rel_msg, self.d_r, lb.UR)      # host-built plan: UR is exact, the rows behind it are pads
+        # The step's kernels between the pull and the push replay from a small hipGraph per (routed batch, cache slot) when
+        # precapture() recorded one (opt-in, KGE_DIST_COMPUTE_GRAPH=1: bit-identical, and SLOWER than the six eager launches it
+        # replaces - 180 vs 172 us per step).  The collectives stay eager launches (captured RCCL calls hang on this stack).
+        if self._cgraphs and not torch.cuda.is_current_stream_capturing():
+            g = self._cgraphs.get((id(lb), lb.slot))
+            if g is not None:
+                g.replay()
+                return
         self.ops.step_grads(self.engine, lb, s.cache, self.ent_msg, self.rel_msg, self.zero_state)
 
     def _push_apply(self, lb, before_apply=None):
@@ -473,10 +604,10 @@ class DistEngine(object):
             before_apply()
         pair = getattr(self.ops, "apply_merged_pair", None) if self._pair_ok else None
         if pair is not None and self.d_e % 4 == 0 and self.d_r % 4 == 0:      # both applies in one launch (same results)
-            pair((self.ent, self.ent_state, W, self.cap, s.recv_ids, sp.lo, self.recv_msg, 2),
+            pair((self.ent, self.ent_state, W, self.cap, lb.recv_ids, sp.lo, self.recv_msg, 2),
                  (self.engine.rel, self.engine.rel_state, Wr, lb.B, None, 0, self.all_rel, 1), self.lr)
         else:
-            self.ops.apply_merged(self.ent, self.ent_state, W, self.cap, s.recv_ids, sp.lo, self.recv_msg, 2, self.lr)
+            self.ops.apply_merged(self.ent, self.ent_state, W, self.cap, lb.recv_ids, sp.lo, self.recv_msg, 2, self.lr)
             self.ops.apply_merged(self.engine.rel, self.engine.rel_state, Wr, lb.B, None, 0, self.all_rel, 1, self.lr)
 
     def step(self, batch):
@@ -488,11 +619,14 @@ class DistEngine(object):
     def _pull_ahead(self, next_batch, nslot, ev):
         """the pull of the NEXT step (route, id exchange, owner gather, row exchange) on the side stream"""
         sp, s, W = self.spec, self.slots[nslot], self.spec.world      # (the buffers exist: the first step's own pull made them)
-        nlb = self.ops.route(next_batch, W, sp.shard, self.cap, s)
+        nlb = self._routed.get(id(next_batch)) or self.ops.route(next_batch, W, sp.shard, self.cap, s)
         nlb.slot = nslot
         if self.coll:
-            self.comm.all_to_all(s.recv_ids, s.req_ids)
-        self.ops.gather_req(self.ent, s.recv_ids, sp.lo, s.rows_out)
+            self.comm.all_to_all(s.recv_ids, nlb.req_ids)
+            nlb.recv_ids = s.recv_ids
+        else:
+            nlb.recv_ids = nlb.req_ids
+        self.ops.gather_req(self.ent, nlb.recv_ids, sp.lo, s.rows_out)
         ev["gather"].record(self._side)
         if self.coll:
             self.comm.all_to_all(s.cache[:W * self.cap], s.rows_out)
@@ -506,42 +640,51 @@ class DistEngine(object):
         main = torch.cuda.current_stream(self.dev)
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.dev)
-            # events are reused (one set per slot): creating them per step costs more host time than the calls they order
-            self._ev = [dict(main=torch.cuda.Event(), gather=torch.cuda.Event(), rows=torch.cuda.Event()) for _ in range(2)]
             # communicators that take the stream from _lib.stream_ptr() (RcclComm, like every library call) need no
-            # `with torch.cuda.stream(...)` around the side-stream section
+            # `with torch.cuda.stream(...)` around the side-stream section; their events are raw hipEvents on raw stream pointers
+            # (~1 us of host time per call instead of 4-5: the eager step is host-bound)
             self._explicit = isinstance(self.comm, RcclComm) and isinstance(self.ops, HipOps)
-        if self._pre is not None and self._pre[0] is batch:
-            _, lb, ev_rows = self._pre
-            main.wait_event(ev_rows)
-        else:
-            if self._pre is not None:
-                # a pull that ran ahead for ANOTHER batch is dropped: the side stream may still be filling its slot (and using the
-                # communicator) - the fresh pull below must start behind it
-                main.wait_event(self._pre[2])
-            lb = self.pull(batch, self._parity)
-        self._pre = None
-        ev_gather = None
-        if next_batch is not None:
-            nslot = lb.slot ^ 1
-            ev = self._ev[nslot]
-            ev["main"].record(main)
-            self._side.wait_event(ev["main"])         # behind everything enqueued so far: the apply of step s-1
-            if self._explicit:
-                prev = _lib.use_stream(self._side.cuda_stream)
-                try:
-                    nlb = self._pull_ahead(next_batch, nslot, ev)
-                finally:
-                    _lib.use_stream(prev)
+            E = _lib.RawEvent if self._explicit else _lib.TorchEvent
+            # events are reused (one set per slot): creating them per step costs more host time than the calls they order
+            self._ev = [dict(main=E(), gather=E(), rows=E()) for _ in range(2)]
+        # every library call of this step takes its stream from the thread-local override: torch.cuda.current_stream() costs
+        # ~5 us per call, and a step makes a dozen calls
+        outer = _lib.use_stream(main.cuda_stream) if self._explicit else None
+        try:
+            if self._pre is not None and self._pre[0] is batch:
+                _, lb, ev_rows = self._pre
+                ev_rows.wait(main)
             else:
-                with torch.cuda.stream(self._side):
-                    nlb = self._pull_ahead(next_batch, nslot, ev)
-            ev_gather = ev["gather"]
-            self._pre = (next_batch, nlb, ev["rows"])
-        self._compute(lb)
-        # the apply of step s must not start before the gather of step s+1 has read the shard (else the staleness is a race)
-        self._push_apply(lb, (lambda: main.wait_event(ev_gather)) if ev_gather is not None else None)
-        self._parity = lb.slot ^ 1
+                if self._pre is not None:
+                    # a pull that ran ahead for ANOTHER batch is dropped: the side stream may still be filling its slot (and using
+                    # the communicator) - the fresh pull below must start behind it
+                    self._pre[2].wait(main)
+                lb = self.pull(batch, self._parity)
+            self._pre = None
+            ev_gather = None
+            if next_batch is not None:
+                nslot = lb.slot ^ 1
+                ev = self._ev[nslot]
+                ev["main"].record(main)
+                ev["main"].wait(self._side)               # behind everything enqueued so far: the apply of step s-1
+                if self._explicit:
+                    _lib.use_stream(self._side.cuda_stream)
+                    try:
+                        nlb = self._pull_ahead(next_batch, nslot, ev)
+                    finally:
+                        _lib.use_stream(main.cuda_stream)
+                else:
+                    with torch.cuda.stream(self._side):
+                        nlb = self._pull_ahead(next_batch, nslot, ev)
+                ev_gather = ev["gather"]
+                self._pre = (next_batch, nlb, ev["rows"])
+            self._compute(lb)
+            # the apply of step s must not start before the gather of step s+1 has read the shard (else the staleness is a race)
+            self._push_apply(lb, (lambda: ev_gather.wait(main)) if ev_gather is not None else None)
+            self._parity = lb.slot ^ 1
+        finally:
+            if self._explicit:
+                _lib.use_stream(outer)
 
 
 def relation_partition(rels, world):

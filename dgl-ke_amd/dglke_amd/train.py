@@ -611,7 +611,10 @@ class A2ATrainer(ShardedTrainer):
             k = min(smp.n_slots, n - done)
             dbs = smp.sample(k)
             # owner buckets are sized BEFORE the group runs (one small device read per group; every rank takes the same decision)
-            self.de.ensure_capacity(dbs, log=(lambda m: print('[proc {}] {}'.format(self.rank, m))) if self.rank == 0 else None)
+            # and the whole group is routed in one launch
+            self.de.prepare_group(dbs, log=(lambda m: print('[proc {}] {}'.format(self.rank, m))) if self.rank == 0 else None)
+            if not self.de._cgraphs and self.de._cg_on:      # first group (or after the buckets grew): record the compute graphs
+                self.de.precapture(smp)
             for i, b in enumerate(dbs):
                 if self.pipelined:
                     self.de.step_pipelined(b, dbs[i + 1] if i + 1 < k else None)

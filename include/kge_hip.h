@@ -488,6 +488,13 @@ int kge_route_fill(const kge_batch *b0, int n_batches, size_t stride_bytes, int 
                    void *stream);
 int kge_route_build(const kge_batch *b, int world, int64_t rows_per_shard, int cap, int64_t *req_ids, int64_t *h_loc,
                     int64_t *t_loc, int64_t *neg_loc, int64_t *ue_loc, int32_t *ue_rec_loc, int32_t *overflow, void *stream);
+/* kge_route_build for a whole GROUP of batches in one launch (round 4): batch k's plan arrays lie k * in_stride_bytes behind b0's
+ * (consecutive slots of kge_sample_batches), its six outputs k * out_stride_bytes behind the pointers given (one pool per group).
+ * Same results per batch as kge_route_build.  Called once per sampled group, after the bucket capacity was checked (kge_route_fill):
+ * the step itself then starts with the id exchange. */
+int kge_route_build_group(const kge_batch *b0, int n_batches, size_t in_stride_bytes, int world, int64_t rows_per_shard, int cap,
+                          int64_t *req_ids, int64_t *h_loc, int64_t *t_loc, int64_t *neg_loc, int64_t *ue_loc, int32_t *ue_rec_loc,
+                          size_t out_stride_bytes, int32_t *overflow, void *stream);
 int kge_batch_localized(const kge_batch *b, const int64_t *h_loc, const int64_t *t_loc, const int64_t *neg_loc,
                         const int64_t *ue_loc, const int32_t *ue_rec_loc, kge_batch *out);
 int kge_gather_rows_req(const float *table, int64_t n_rows, int dim, const int64_t *ids, int64_t id_offset, int64_t n_ids,

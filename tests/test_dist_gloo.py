@@ -62,7 +62,9 @@ class OracleOps(object):
         row_of = dict(zip(ue.tolist(), cr.tolist()))
         lp = dict(nid=np.array([row_of[x] for x in p["nid"].tolist()], np.int64),
                   neg=np.array([row_of[x] for x in p["neg_ids"].tolist()], np.int64))
-        return OracleLocalBatch(batch, lp)
+        lb = OracleLocalBatch(batch, lp)
+        lb.req_ids = bf.req_ids
+        return lb
 
     def route_fill(self, batches, world, per, out):
         for b in batches:

@@ -112,6 +112,71 @@ def test_route_fill_and_capacity_growth():
         de.ops.route(b, 8, spec.shard, de.cap, de.slots[0])
     torch.cuda.synchronize()
     assert de.check_overflow() == 0
+    # kge_route_build_group (round 4): the whole group routed in ONE launch into a pool row per sampler slot - the same arrays as
+    # routing the batches one by one
+    de.prepare_group(dbs)
+    torch.cuda.synchronize()
+    off, stride = ops.route_layout(dbs[0], 8, de.cap)
+    pool = de._route_pool.cpu().numpy()
+    for b in dbs:
+        lb = de._routed[id(b)]
+        s0 = de.slots[0]
+        de.ops.route(b, 8, spec.shard, de.cap, s0)
+        torch.cuda.synchronize()
+        row = pool[b.slot * stride:(b.slot + 1) * stride]
+        cnt = int(smp.slot_arrays(b.slot)["counts"][0])
+        for name, ref, n, dt in (("req_ids", s0.req_ids, 8 * de.cap, np.int64), ("h_loc", s0.h_loc, B, np.int64),
+                                 ("t_loc", s0.t_loc, B, np.int64), ("neg_loc", s0.neg_loc, dbs[0].C * N, np.int64),
+                                 ("ue_loc", s0.ue_loc, cnt, np.int64), ("ue_rec_loc", s0.ue_rec_loc, 8 * cnt, np.int32)):
+            got = row[off[name]:off[name] + n * np.dtype(dt).itemsize].view(dt)
+            assert np.array_equal(got, ref.cpu().numpy()[:n]), "%s of slot %d differs between group and single routing" % (name, b.slot)
+        assert np.array_equal(lb.req_ids.cpu().numpy(), s0.req_ids.cpu().numpy())
+    assert de.check_overflow() == 0
+
+
+def test_precaptured_compute_graphs_equal_eager_launches():
+    """the eager sharded step with its kernels between pull and push replayed from small hipGraphs (DistEngine.precapture:
+    one per sampler slot, corruption mode and cache slot; the collectives stay eager) against the same steps launched kernel by
+    kernel: bit-identical shard, state and relation table; world 1 through the collective code path (RCCL calls with one rank,
+    pipelined pull on the side stream) on device-sampled batches routed by prepare_group."""
+    import torch.distributed as dist
+    from dglke_amd import dist as kd
+    from dglke_amd.dataloader import DeviceSampler
+    from dglke_amd.engine import StepEngine
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29547")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        n_ent, n_rel, hidden, B, N = 6000, 40, 64, 128, 32
+        rng = np.random.RandomState(31)
+        h, r, t = rng.randint(0, n_ent, 30000), rng.randint(0, n_rel, 30000), rng.randint(0, n_ent, 30000)
+        res = []
+        for graphs in (False, True):
+            torch.manual_seed(3)
+            eng = StepEngine("RotatE", 1, n_rel, hidden, 12.0, 0.05, DEV, True, False, True, 1.0, 1e-6, 3)
+            ent = torch.empty(n_ent, 2 * hidden, device=DEV).uniform_(-0.2, 0.2)
+            state = torch.zeros(n_ent, device=DEV)
+            smp = DeviceSampler(h, r, t, n_ent, B, N, DEV, n_slots=6, seed=5)
+            comm = kd.RcclComm()
+            de = kd.DistEngine(eng, kd.ShardSpec(n_ent, 1, 0), ent, state, always_collective=True, comm=comm)
+            de._cg_on = graphs
+            for grp in range(5):                     # 5 groups: sizes 6, 5 (odd: the corruption mode of every slot flips), 6, 6, 3
+                dbs = smp.sample((6, 5, 6, 6, 3)[grp])
+                de.prepare_group(dbs)
+                if grp == 0:
+                    n = de.precapture(smp)
+                    assert n == (6 * 2 * 2 if graphs else 0)
+                for k, b in enumerate(dbs):
+                    de.step_pipelined(b, dbs[k + 1] if k + 1 < len(dbs) else None)
+            torch.cuda.synchronize()
+            assert de.check_overflow() == 0
+            res.append((ent.cpu(), state.cpu(), eng.rel.cpu().clone(), eng.rel_state.cpu().clone()))
+            comm.close()
+        for x, y in zip(res[0], res[1]):
+            assert torch.equal(x, y)
+        assert float((res[0][1] > 0).sum()) > 100
+    finally:
+        dist.destroy_process_group()
 
 
 def test_gather_rows_req_skips_pads_and_foreign_ids():
