@@ -752,7 +752,8 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         na.GNp = gemm ? nullptr : GNp;
         // shared-pair backward followed by edge_bwd: the sum of its GN partials shares the edge_bwd launch (same inputs' producer,
         // independent jobs).  Not with neg_deg_sample (edge_bwd reads GN) and not on the TransE fast path (no edge_bwd)
-        fuse_gnred = na.GNp && !nd && !transe_fast && !rescal && !transr && !sh && d_e % 4 == 0 && na.N % 4 == 0 &&
+        // (round 4: on peer-to-peer sharded tables too - edge_bwd resolves its rows through the shard map, the reduction is local)
+        fuse_gnred = na.GNp && !nd && !transe_fast && !rescal && !transr && d_e % 4 == 0 && na.N % 4 == 0 &&
                      (hp->model == KGE_ROTATE || hp->model == KGE_TRANSE_L1) && !(hp->flags & KGE_FLAG_TWO_PASS_PAIR) &&
                      !(hp->flags & KGE_FLAG_SPLIT_FWD);
         na.defer_reduce = fuse_gnred ? 1 : 0;

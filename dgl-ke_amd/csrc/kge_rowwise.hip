@@ -354,8 +354,9 @@ static int launch_edge_bwd_gnred_m(const EdgeBwdArgs &a, const NegArgs &n, int n
     const bool cx = is_complex_model(MODEL);
     const bool vec = cx ? ((a.d_e / 2) % 4 == 0 && a.d_r % 4 == 0) : (a.d_e % 4 == 0);
     const bool local = a.src.em.n == 0 && a.src.rm.n == 0;
-    if (!vec || !local) return KGE_ERR_ARG;
-    hipLaunchKernelGGL((edge_bwd_gnred_kernel<MODEL, 4, true>), dim3(nbE + nbR), dim3(KGE_BLOCK), 0, s, a, n, nrw, nbE);
+    if (!vec) return KGE_ERR_ARG;
+    if (local) hipLaunchKernelGGL((edge_bwd_gnred_kernel<MODEL, 4, true>), dim3(nbE + nbR), dim3(KGE_BLOCK), 0, s, a, n, nrw, nbE);
+    else hipLaunchKernelGGL((edge_bwd_gnred_kernel<MODEL, 4, false>), dim3(nbE + nbR), dim3(KGE_BLOCK), 0, s, a, n, nrw, nbE);   // sharded tables (round 4)
     return check_launch();
 }
 

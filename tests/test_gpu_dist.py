@@ -334,6 +334,26 @@ def test_world2_hip_ops_match_the_oracle_statement(tmp_path, mode, transport):
         assert np.array_equal(z[model + "_relstate0"], z[model + "_relstate1"])
 
 
+@pytest.mark.parametrize("mode", ["pipelined", "relpart"])
+def test_world4_on_one_device_matches_the_oracle_statement(tmp_path, mode):
+    """four ranks (four processes sharing this GPU, messages through gloo): owner buckets for four shards, the merged apply with
+    four sources and rows that arrive from several ranks at once, the one-step-stale pipeline / relation partitioning at a
+    world size beyond two - against the fp64 statement of the same schedule."""
+    import dist_worker as W
+    world = 4
+    z = _run_workers(tmp_path, mode, world=world)
+    for model, de_, dr_ in W.MODELS:
+        ent, es, rel, rs = _oracle_statement(model, de_, dr_, z, world, mode)
+        lr = W.LR
+        np.testing.assert_allclose(z[model + "_state"], es, rtol=2e-3, atol=1e-9, err_msg=model + " entity state")
+        np.testing.assert_allclose(z[model + "_ent"], ent, rtol=1e-4, atol=5e-3 * lr, err_msg=model + " entity rows")
+        np.testing.assert_allclose(z[model + "_relstate0"], rs, rtol=2e-3, atol=1e-9, err_msg=model + " relation state")
+        np.testing.assert_allclose(z[model + "_rel0"], rel, rtol=1e-4, atol=5e-3 * lr, err_msg=model + " relation rows")
+        if mode != "relpart":
+            for r in range(1, world):
+                assert np.array_equal(z[model + "_rel0"], z[model + "_rel%d" % r]), "relation replicas differ"
+
+
 def test_world2_equals_single_table_step_on_disjoint_batches(tmp_path):
     """rank k's batches only touch rank-k entities / relations: the synchronous sharded step is then the fused single-GPU step
     applied rank after rank on one table (same kernels; the gradient-emitting update + owner-side apply is a different
