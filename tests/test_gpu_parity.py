@@ -823,8 +823,8 @@ def _random_step_case(seed):
     chunk = int(rng.choice([1, 3, 4, 7, 8, 16, 17, 24, 32, 40]))
     C = int(rng.randint(1, 5))
     N = int(rng.choice([1, 2, 4, 5, 8, 12, 16, 20, 32, 36, 64]))
-    flags = int(rng.choice([0, 0, 0, 1, 2, 8, 10, 16, 32, 33, 128, 130, 512, 256, 768]))
-    return dict(model=model, de=de, dr=dr, hidden=hidden, chunk=chunk, C=C, N=N, flags=flags,
+    flags = int(rng.choice([0, 0, 0, 1, 2, 8, 10, 16, 32, 33, 128, 130, 512, 256, 768, 1024, 1024 + 256]))    # 1024: loss rows in the first launch
+    return dict(model=model, de=de, dr=dr, hidden=hidden, chunk=chunk, C=C, N=N, flags=flags, impts=bool(rng.randint(4) == 0),
                 n_ent=int(rng.choice([30, 200, 2000])), n_rel=int(rng.choice([3, 17])),
                 adv=bool(rng.randint(2)), reg=float(rng.choice([0.0, 1e-4])), gamma=float(rng.choice([6.0, 12.0])),
                 lr=float(rng.choice([0.05, 0.2])))
@@ -857,13 +857,15 @@ def test_fused_step_random_shapes_match_oracle(seed):
         es64 = eng.ent_state.cpu().numpy().astype(np.float64)
         rs64 = eng.rel_state.cpu().numpy().astype(np.float64)
         bt = O.synth_batch(rng, k["n_ent"], k["n_rel"], B, N, chunk, step)
-        b = plan.make_batch(bt["h"], bt["t"], bt["r"], bt["neg"], chunk, N, bt["neg_head"], DEV)
+        # edge importance in a quarter of the cases (loss.py:72-83: the negative part per edge, the positive part by the batch mean)
+        w = rng.uniform(0.5, 1.5, size=B).astype(np.float32) if k["impts"] else None
+        b = plan.make_batch(bt["h"], bt["t"], bt["r"], bt["neg"], chunk, N, bt["neg_head"], DEV, w)
         want = eng.alloc_outputs(b)
         eng.step(b, want)
         torch.cuda.synchronize()
         negrows = ent64[bt["neg"]]
         out = O.train_step(cfg, ent64, es64, rel64, rs64, bt["nid"], bt["h_local"], bt["t_local"],
-                           bt["r"], bt["neg"], bt["neg_head"], chunk, N)
+                           bt["r"], bt["neg"], bt["neg_head"], chunk, N, None if w is None else w.astype(np.float64))
         tag = "%s step %d" % (tag0, step)
         _close(want["pos_score"].cpu(), out["pos_score"], 1e-4, 1e-4, tag + " pos_score")
         _close(want["neg_score"].cpu(), out["neg_score"], 1e-4, 1e-4, tag + " neg_score")
