@@ -390,6 +390,8 @@ def orchestrate(args, world, rank, local_rank):
         print(line, flush=True)
     dist.barrier()
     dist.destroy_process_group()
+    import shutil
+    shutil.rmtree(tmpdir, ignore_errors=True)
 
 
 def _replicas_line(args, world, alls, history):
