@@ -82,15 +82,25 @@ __device__ __forceinline__ void fwd_step(const float (&xc)[16], const float *ly,
 #pragma unroll
         for (int r = 0; r < RW; ++r) {
             const float *yp = ly + r * 64 + (LB >= 0 ? LB : lbr) + e;
+#ifdef PROBE_FWD_NOY            // tuning probes (wrong results): timing without one ingredient of the loop
+            (void)yp;
+            const v2f y0 = {xc[(e + 2 * r) & 7], xc[(e + 2 * r + 1) & 7]};
+            v2f y1 = {xc[8 + ((e + 2 * r) & 7)], xc[8 + ((e + 2 * r + 1) & 7)]};
+#else
             const v2f y0 = *reinterpret_cast<const v2f *>(yp);
             v2f y1 = {0.f, 0.f};
             if constexpr (CPLX) y1 = *reinterpret_cast<const v2f *>(yp + RW * 64);
+#endif
             const v2f x0 = {xc[e], xc[e + 1]};
             if constexpr (CPLX) {
                 const v2f x1 = {xc[8 + e], xc[9 + e]};
                 const v2f dr = y0 - x0, di = y1 - x1;
                 const v2f m2 = __builtin_elementwise_fma(di, di, dr * dr);
+#ifdef PROBE_FWD_NOSQRT
+                acc[r] += m2;
+#else
                 acc[r] += (v2f){fast_sqrt(m2.x), fast_sqrt(m2.y)};
+#endif
             } else if constexpr (MODEL == KGE_TRANSE_L1) {
                 // one packed subtraction, then |.| as the free source modifier of two scalar additions (written
                 // as asm: the vectoriser otherwise re-packs the additions and pays two v_and for the |.|)
@@ -322,10 +332,145 @@ __device__ __forceinline__ void neg_fwd_bcast_body(const NegArgs &a, int ns, int
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// RotatE forward, round 4: the lanes' OWN rows (the 64 negatives of the strip) through LDS.
+// PMC of the body above at the FB15k recipe (profiles/r04_rotate_pmc.txt): 7.9 M L1 accesses and 1.4 M L1->L2 line requests per
+// launch (~180 MB: 10 TB/s out of the L2s over the kernel's 17 us) for 26 MB of distinct x data - a per-lane row load touches 64
+// lines for 16 bytes each, the line comes back for the next sub-slab and for the three other tasks of the workgroup, and the 64 KB
+// of lines a workgroup has open do not fit the 32-KB L1; the VALU is busy 40 % of the launch.
+// Here the SB_TPB tasks of a run group (same strip, same run of the reduction) share ONE staged image of the strip's rows:
+// 16 complex columns per stage, fetched in 64-byte segments (4 lanes per segment: 16 lines per load instruction instead of 64),
+// one ds_write_b128 per thread and row half, read back "lane = row" with ds_read_b128 (row stride 36 dwords = 4 x odd:
+// conflict-free, MI355X_MICROARCH.md LDS table).  Two buffers per run group, the next stage's global loads issued before the
+// stage's arithmetic and written after it, one workgroup barrier per stage.  Same sums in the same order as the body above
+// (sub-slab by sub-slab, even / odd accumulators, runs added in run order): bit-identical scores.
+// ---------------------------------------------------------------------------------------------
+#ifndef SB_XLDS
+#define SB_XLDS 1
+#endif
+#define SB_XST 16                                // complex columns per stage
+#define SB_XRS 36                                // dwords per staged row: 16 re | 16 im | 4 pad
+__device__ __forceinline__ void neg_fwd_rot_xlds_body(const NegArgs &a, int ns, int ng, int bid) {
+    typedef FwdShape<KGE_ROTATE> FS;
+    constexpr int RW = FS::RW, SB_KS = FS::KS, SB_TPB = FS::TPB, WAVES = FS::WAVES, BLOCK = FS::BLOCK, NE = SB_KC;
+    static_assert(SB_TPB * 64 == 256 && SB_XST == 2 * NE, "staging map: 256 threads per run group, two sub-slabs per stage");
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const int tw = wave % SB_TPB, kw = wave / SB_TPB;
+    const int ntask = a.C * ns * ng;
+    const int task = min(bid * SB_TPB + tw, ntask - 1);
+    const int g = task % ng, st = (task / ng) % ns, c = task / (ng * ns);
+    // the strip whose rows this run group stages: the strip of the workgroup's FIRST task (a workgroup whose tasks straddle two
+    // strips - ng % SB_TPB != 0 - is sent to the per-lane body by the launcher)
+    const int D = a.d_e, K = D / 2;
+    const int nsl = K / NE;
+    const int k_lo = (kw * nsl / SB_KS) * NE, k_hi = ((kw + 1) * nsl / SB_KS) * NE;
+    const int lmax = (nsl + SB_KS - 1) / SB_KS;                  // sub-slabs of the longest run
+    const int nst = (lmax + 1) / 2;                              // stages every wavefront walks (same barrier count for all)
+    const int i0 = g * RW;
+    const int j = st * 64 + lane;
+    const float *y[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) y[r] = a.A + ((int64_t)c * a.chunk + min(i0 + r, a.chunk - 1)) * D;
+    v2f acc[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) acc[r] = (v2f){0.f, 0.f};
+
+    __shared__ __attribute__((aligned(16))) float ylds[WAVES][2 * RW * 64];
+    __shared__ __attribute__((aligned(16))) float xs[SB_KS][2][64 * SB_XRS];
+    __shared__ float part[WAVES][RW][64];
+    float *ly = ylds[wave];
+    auto loady = [&](float (&yr)[RW], float (&yi)[RW], int kb) {
+        const int k = min(kb + lane, K - 1);
+#pragma unroll
+        for (int r = 0; r < RW; ++r) { yr[r] = y[r][k]; yi[r] = y[r][K + k]; }
+    };
+    auto puty = [&](const float (&yr_)[RW], const float (&yi_)[RW]) {
+#pragma unroll
+        for (int r = 0; r < RW; ++r) { ly[r * 64 + lane] = yr_[r]; ly[(RW + r) * 64 + lane] = yi_[r]; }
+    };
+    // staging map of the run group's 256 threads: thread tg -> rows tg / 8 and tg / 8 + 32, piece tg % 8 of the row's 32 staged
+    // floats (pieces 0-3: re columns, 4-7: im columns); 8 consecutive lanes write 32 consecutive dwords
+    const int tg = tw * 64 + lane, srow = tg >> 3, sp = tg & 7, scomp = sp >> 2, sq4 = (sp & 3) * 4;
+    const float *xg0 = row_ptr(a.nbase, a.nidx, (int64_t)c * a.N + min(st * 64 + srow, a.N - 1), D) + scomp * K;
+    const float *xg1 = row_ptr(a.nbase, a.nidx, (int64_t)c * a.N + min(st * 64 + srow + 32, a.N - 1), D) + scomp * K;
+    float *xw = &xs[kw][0][srow * SB_XRS + sp * 4];
+    const float *xr_ = &xs[kw][0][lane * SB_XRS];
+    float4 sx0, sx1;
+    auto gx = [&](int k0) {                                      // global -> registers (columns clamped: in bounds, unused beyond k_hi)
+        const int kc = min(k0 + sq4, K - 4);
+        sx0 = *reinterpret_cast<const float4 *>(xg0 + kc);
+        sx1 = *reinterpret_cast<const float4 *>(xg1 + kc);
+    };
+    auto sxw = [&](int bf) {                                     // registers -> LDS buffer bf
+        *reinterpret_cast<float4 *>(xw + bf * (64 * SB_XRS)) = sx0;
+        *reinterpret_cast<float4 *>(xw + bf * (64 * SB_XRS) + 32 * SB_XRS) = sx1;
+    };
+    auto xread = [&](float (&xc)[16], int bf, int sub) {         // this lane's row: 8 re + 8 im columns of sub-slab `sub` of the stage
+        const float *p = xr_ + bf * (64 * SB_XRS) + sub * NE;
+        const float4 t0 = *reinterpret_cast<const float4 *>(p), t1 = *reinterpret_cast<const float4 *>(p + 4);
+        const float4 u0 = *reinterpret_cast<const float4 *>(p + 16), u1 = *reinterpret_cast<const float4 *>(p + 20);
+        xc[0] = t0.x; xc[1] = t0.y; xc[2] = t0.z; xc[3] = t0.w; xc[4] = t1.x; xc[5] = t1.y; xc[6] = t1.z; xc[7] = t1.w;
+        xc[8] = u0.x; xc[9] = u0.y; xc[10] = u0.z; xc[11] = u0.w; xc[12] = u1.x; xc[13] = u1.y; xc[14] = u1.z; xc[15] = u1.w;
+    };
+    float yr[RW], yi[RW], ynr[RW], yni[RW], xa[16], xb[16];
+    gx(k_lo);
+    loady(yr, yi, k_lo);
+    sxw(0);
+    __syncthreads();
+    int bf = 0;
+    for (int s0 = 0; s0 < nst; s0 += 4) {                        // blocks of 64 columns = 4 stages
+        const int kb = k_lo + s0 * SB_XST;
+        loady(ynr, yni, kb + 64);                                // next block, one block ahead
+        puty(yr, yi);
+        const int send = min(4, nst - s0);
+#pragma unroll 1
+        for (int s = 0; s < send; ++s) {
+            const int k0 = kb + s * SB_XST;
+#ifdef PROBE_FWD_NOX            // tuning probe (wrong results): no staging, no barrier, x read once
+            if (s0 == 0 && s == 0) { xread(xa, bf, 0); xread(xb, bf, 1); }
+            if (k0 < k_hi) fwd_step<KGE_ROTATE, RW, NE, -1>(xa, ly, acc, k0 - kb);
+            if (k0 + NE < k_hi) fwd_step<KGE_ROTATE, RW, NE, -1>(xb, ly, acc, k0 + NE - kb);
+#else
+            gx(k0 + SB_XST);                                     // next stage (past the run: a harmless clamped re-read)
+            xread(xa, bf, 0);
+            xread(xb, bf, 1);
+            if (k0 < k_hi) fwd_step<KGE_ROTATE, RW, NE, -1>(xa, ly, acc, k0 - kb);            // (wave-uniform)
+            if (k0 + NE < k_hi) fwd_step<KGE_ROTATE, RW, NE, -1>(xb, ly, acc, k0 + NE - kb);
+            sxw(bf ^ 1);
+            __syncthreads();
+            bf ^= 1;
+#endif
+        }
+#pragma unroll
+        for (int r = 0; r < RW; ++r) { yr[r] = ynr[r]; yi[r] = yni[r]; }
+    }
+#pragma unroll
+    for (int r = 0; r < RW; ++r) part[wave][r][lane] = acc[r].x + acc[r].y;
+    __syncthreads();
+    for (int o = threadIdx.x; o < SB_TPB * RW * 64; o += BLOCK) {
+        const int l = o & 63, r = (o >> 6) % RW, tw2 = (o >> 6) / RW;
+        const int t2 = bid * SB_TPB + tw2;
+        if (t2 >= ntask) continue;
+        const int g2 = t2 % ng, st2 = (t2 / ng) % ns, c2 = t2 / (ng * ns);
+        const int i2 = g2 * RW + r, j2 = st2 * 64 + l;
+        if (j2 >= a.N || i2 >= a.chunk) continue;
+        float v = part[tw2][r][l];
+#pragma unroll
+        for (int q = 1; q < SB_KS; ++q) v += part[q * SB_TPB + tw2][r][l];
+        a.S[((int64_t)c2 * a.chunk + i2) * a.N + j2] = a.gamma - v;
+    }
+    (void)j;
+}
+
 template <int MODEL>
 __global__ __launch_bounds__(FwdShape<MODEL>::BLOCK) void neg_fwd_bcast_kernel(NegArgs a, int ns, int ng) {
     KGE_TL(1);
     neg_fwd_bcast_body<MODEL, false>(a, ns, ng, (int)blockIdx.x);
+}
+__global__ __launch_bounds__(FwdShape<KGE_ROTATE>::BLOCK) void neg_fwd_rot_xlds_kernel(NegArgs a, int ns, int ng) {
+    KGE_TL(1);
+    neg_fwd_rot_xlds_body(a, ns, ng, (int)blockIdx.x);
 }
 
 // TransE_l1, strict step: forward pairwise tasks (first nbF workgroups) + the edge-forward rows of the SAME step (the rest: one
@@ -366,6 +511,13 @@ template <int MODEL> static int fwd_launch(const NegArgs &a, hipStream_t s) {
     const int ns = (a.N + 63) / 64, ng = (a.chunk + RW - 1) / RW;
     const int64_t nb = ((int64_t)a.C * ns * ng + SB_TPB - 1) / SB_TPB;
     if (nb == 0) return KGE_OK;
+    if constexpr (MODEL == KGE_ROTATE && SB_XLDS) {
+        // staged-row instance: the tasks of a workgroup share their strip (ng % SB_TPB == 0) and a stage of 16 columns exists
+        if (ng % SB_TPB == 0 && a.d_e / 2 >= SB_XST && (a.d_e / 2) % 4 == 0) {
+            hipLaunchKernelGGL(neg_fwd_rot_xlds_kernel, dim3((unsigned)nb), dim3(SB_FWD_BLOCK), 0, s, a, ns, ng);
+            return check_launch_b();
+        }
+    }
     hipLaunchKernelGGL(neg_fwd_bcast_kernel<MODEL>, dim3((unsigned)nb), dim3(SB_FWD_BLOCK), 0, s, a, ns, ng);
     return check_launch_b();
 }
@@ -582,8 +734,12 @@ static inline void lc_shape(int model, int C, int chunk, int d_e, int &nslab, in
     nrw = 1;
     while ((chunk + 4 * nrw - 1) / (4 * nrw) > rtmax) ++nrw;
     const int rpw_min = model == KGE_ROTATE ? LC_RPW_MIN_CPLX : LC_RPW_MIN_REAL;
-    while ((int64_t)C * nslab * (nrw + 1) <= 512 && (chunk + 4 * (nrw + 1) - 1) / (4 * (nrw + 1)) >= rpw_min) ++nrw;
-    rpw = (chunk + 4 * nrw - 1) / (4 * nrw);
+    // (one more row group only while it still SHORTENS the wavefronts' row blocks: chunk = 256 went to nrw = 9 with 8 rows per
+    //  wavefront - the ninth group held no rows and ran the whole arithmetic on zero weights, 11 % of the launch; round 4)
+    auto rows = [&](int n) { return (chunk + 4 * n - 1) / (4 * n); };
+    for (int n = nrw + 1; (int64_t)C * nslab * n <= 512 && rows(n) >= rpw_min; ++n)
+        if (rows(n) < rows(nrw)) nrw = n;
+    rpw = rows(nrw);
 }
 bool neg_bwd_lc_supported(int model, int d_e) {
     if (model == KGE_ROTATE) return d_e % 4 == 0 && neg_bcast_supported(model, d_e);
@@ -704,6 +860,10 @@ __global__ __launch_bounds__(KGE_BLOCK) LC_OCC void neg_bwd_lc_kernel(NegArgs a,
     };
     // operands of one quad out of LDS buffer bf: y = b_s[cols] (s = quad g, lane row sg), raw W values
     auto lread = [&](int bf, int g, v2f &yr_, v2f &yi_, float &w0_, float &w1_) {
+#ifdef PROBE_BWD_NOLREAD        // tuning probe (wrong results): operands of a quad without the LDS round
+        yr_ = xr[g & 3] * 0.5f; yi_ = xi[g & 3] * 0.5f; w0_ = xr[0].x; w1_ = 0.f; (void)bf;
+        return;
+#endif
         const float *yb = ybuf + (bf * LC_SG + 4 * g + sg) * YF + 2 * kk;
         yr_ = *reinterpret_cast<const v2f *>(yb);
         yi_ = CPLX ? *reinterpret_cast<const v2f *>(yb + LC_CW) : (v2f){0.f, 0.f};
@@ -720,7 +880,11 @@ __global__ __launch_bounds__(KGE_BLOCK) LC_OCC void neg_bwd_lc_kernel(NegArgs a,
             if constexpr (CPLX) {
                 const v2f dr = xr[n] - yr_, di = xi[n] - yi_;
                 const v2f m2 = __builtin_elementwise_fma(di, di, __builtin_elementwise_fma(dr, dr, (v2f){1e-30f, 1e-30f}));
+#ifdef PROBE_BWD_NORSQ
+                const v2f iv = m2 * w;
+#else
                 const v2f iv = (v2f){fast_rsq(m2.x), fast_rsq(m2.y)} * w;   // + tiny: zero difference -> zero gradient
+#endif
                 gr[n] = __builtin_elementwise_fma(dr, -iv, gr[n]);
                 gi[n] = __builtin_elementwise_fma(di, -iv, gi[n]);
                 nr = __builtin_elementwise_fma(dr, iv, nr);
@@ -736,8 +900,13 @@ __global__ __launch_bounds__(KGE_BLOCK) LC_OCC void neg_bwd_lc_kernel(NegArgs a,
             }
         });
         float *slot = redb + ((g * KGE_WAVES_PER_BLOCK + wave) * 64 + lane) * NV;
+#ifdef PROBE_BWD_NORED          // tuning probe (wrong results): the GN partials stay in registers (folded into GA so that they are not dead)
+        gr[0] += nr; if constexpr (CPLX) gi[0] += ni;
+        (void)slot;
+#else
         if constexpr (CPLX) *reinterpret_cast<float4 *>(slot) = make_float4(nr.x, nr.y, ni.x, ni.y);
         else *reinterpret_cast<v2f *>(slot) = nr;
+#endif
     };
     gload(min(q_lo, nq - 1));
     lstore(0, q_lo);
@@ -767,6 +936,10 @@ __global__ __launch_bounds__(KGE_BLOCK) LC_OCC void neg_bwd_lc_kernel(NegArgs a,
         }
         lstore(buf ^ 1, qb + LC_GQ);
         __syncthreads();
+#ifdef PROBE_BWD_NORED
+        buf ^= 1;
+        continue;
+#endif
         // fixed-order sum over the 4 wavefronts: one partial per (workgroup row group, negative, column).  The
         // LDS buffers alternate, so the next group needs no second barrier.
         for (int e = tid; e < LC_GQ * 64; e += KGE_BLOCK) {
