@@ -640,6 +640,8 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     }
     }   // PH_PREP
 
+    bool fold_upd = false;                   // (TransE_l1: the update sums the backward's GN partials / GA parts, see PH_BWD)
+    int fold_nrw = 0, fold_ga_parts = 1;
     if (phases & PH_SCORE) {
     // 2. chunked negative scores (+ per-16-column partial row statistics for the adversarial softmax)
     GemmArgs g{}; NegArgs na{};
@@ -756,12 +758,23 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         fuse_gnred = na.GNp && !nd && !transe_fast && !rescal && !transr && d_e % 4 == 0 && na.N % 4 == 0 &&
                      (hp->model == KGE_ROTATE || hp->model == KGE_TRANSE_L1) && !(hp->flags & KGE_FLAG_TWO_PASS_PAIR) &&
                      !(hp->flags & KGE_FLAG_SPLIT_FWD);
-        na.defer_reduce = fuse_gnred ? 1 : 0;
+        // TransE_l1 (fast path: no edge_bwd launch to share): the update kernel sums the GN partials and GA parts itself - the
+        // stand-alone reduction launch (5.2 us + a boundary) leaves the strict step.  One-call strict step on local tables, no
+        // gradient outputs (they read the summed buffers).
+        fold_nrw = neg_bwd_lc_nrw(hp->model, C, chunk, d_e);
+        fold_upd = phases == PH_ALL && na.GNp && transe_fast && hp->model == KGE_TRANSE_L1 && !nd && !sh && !emit && !build_update &&
+                   !co_update && !co_prep && !(out && (out->g_neg || out->g_rel || out->g_pos_ent)) && d_e % 4 == 0 && d_e <= 512 &&
+                   na.N % 4 == 0 && neg_bwd_lc_supported(hp->model, d_e) && fold_nrw <= 6 && ga_parts <= 4 &&
+                   !(hp->flags & (KGE_FLAG_TWO_PASS_PAIR | KGE_FLAG_SPLIT_FWD)) && (!reg || hp->reg_norm == 3);
+        na.defer_reduce = (fuse_gnred || fold_upd) ? 1 : 0;
         // GA in parts only where the shared-pair kernel runs: its stand-alone partial reduction adds them up in place, the
         // edge_bwd launch that carries the reduction (fuse_gnred) adds them while it reads the row
         const bool ga_split = ga_parts > 1 && na.GNp && !na.nidx && na.N % 4 == 0 && !rescal && !transr &&
                               neg_bwd_lc_supported(hp->model, d_e);
         na.ga_parts = ga_split ? ga_parts : 1; na.ga_stride = (int64_t)B * d_e;
+        fold_upd = fold_upd && !na.nidx;         // (gathered negatives run the two-pass kernels: no partials)
+        if (!fold_upd && !fuse_gnred) na.defer_reduce = 0;
+        fold_ga_parts = na.ga_parts;
         KGE_TRY(launch_neg_bwd_pair(na, s));
         if (co_prep) KGE_TRY(launch_edge_fwd(*co_prep, s));
     }
@@ -854,6 +867,11 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     ua.acc = acc;
     ua.ld_e = d_e; ua.ld_r = d_r; ua.ld_gs_e = 1; ua.ld_gs_r = 1;
     if (nd) { ua.nd_chunk = chunk; ua.nd_Ns = b->N; ua.nd_Np = N; }
+    if (fold_upd) {
+        ua.GNp = GNp; ua.gn_parts = fold_nrw; ua.gn_stride = (int64_t)CN * d_e;
+        ua.gn_reg_coef = reg ? hp->reg_coef : 0.f; ua.gn_reg_norm = hp->reg_norm;
+        ua.ga_parts = fold_ga_parts; ua.ga_stride = (int64_t)B * d_e;
+    }
     if (async && reg) {
         // the regulariser of the positive-trace rows is part of the gradient the reference computes in forward, from the
         // rows as gathered: evaluate it on PREP's copies.  (The relation trace is only deferred with KGE_FLAG_ASYNC_REL;

@@ -419,6 +419,12 @@ struct UpdateArgs {
     // neg_deg_sample (nd_chunk > 0): GN has nd_Np = nd_chunk + nd_Ns rows per chunk, plan slot k (sampled negative)
     // is row (k / nd_Ns) * nd_Np + nd_chunk + k % nd_Ns, and the regulariser of the negative rows is added here
     int nd_chunk, nd_Ns, nd_Np;
+    // TransE_l1 strict step, round 4 (gn_parts > 0): the shared-pair backward's outputs are consumed UNSUMMED - a negative-slot row
+    // is the sum of gn_parts rows of GNp gn_stride floats apart (+ the regulariser gradient of the row, gn_reg_*: what
+    // gn_reduce_body adds), a GA row the sum of ga_parts rows ga_stride apart; same additions in the same order as the
+    // stand-alone reduction launch this replaces (5.2 us + a launch boundary per step)
+    const float *GNp; int gn_parts; int64_t gn_stride; float gn_reg_coef; int gn_reg_norm;
+    int ga_parts; int64_t ga_stride;
 };
 __device__ __forceinline__ int64_t gn_row(const UpdateArgs &a, int slot) {
     return a.nd_chunk ? (int64_t)(slot / a.nd_Ns) * a.nd_Np + a.nd_chunk + slot % a.nd_Ns : (int64_t)slot;

@@ -19,10 +19,30 @@ __device__ __forceinline__ void acc_add(float *p, float v, bool unique) {
     atomicAdd(p, v);
 }
 
+// sum of `parts` rows `stride` floats apart, added in part order; MAXP requests are issued unconditionally (part index clamped: the
+// surplus ones re-read the last part) so that they fly together
+template <int MAXP>
+__device__ __forceinline__ kge::Pack<4> ld_parts(const float *p, int parts, int64_t stride) {
+    using namespace kge;
+    Pack<4> v[MAXP];
+#pragma unroll
+    for (int q = 0; q < MAXP; ++q) v[q] = ld<4>(p + (int64_t)min(q, parts - 1) * stride);
+#pragma unroll
+    for (int q = 1; q < MAXP; ++q) {
+        if (q < parts) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[0].v[e] += v[q].v[e];
+        }
+    }
+    return v[0];
+}
+#define KGE_GA_MAXP 4          // most GA parts / GN partials the folded update takes (the launcher falls back to the reduction launch)
+#define KGE_GN_MAXP 6
+
 // one relation row per wavefront (second half of update_reg_body).  COOP: the instance for batches with a long relation list.
 // (Sums of squares are written as explicit fmaf: left to the compiler, the two instances contracted `ss += g * g` differently and
 //  a row without any shared list came out 1 ulp apart - device-built batches pick the instance per batch, host plans always COOP.)
-template <int NIT, bool SHARDED, int LEAN, bool COOP>
+template <int NIT, bool SHARDED, int LEAN, bool COOP, bool FOLD = false>
 __device__ __forceinline__ void update_rel_row(const UpdateArgs &a, int bx, int nb_ent, int lane, bool reg, bool qm) {
     using namespace kge;
     constexpr int LB2 = NIT <= 2 ? 2 : 1;
@@ -86,7 +106,9 @@ __device__ __forceinline__ void update_rel_row(const UpdateArgs &a, int bx, int 
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {                         // every pack requested before the first use
         x[k] = ld<4>(row + itc[k]);
-        fva[k] = ld<4>(pA + itc[k]); fvb[k] = ld<4>(pB + itc[k]);
+        fva[k] = ld<4>(pA + itc[k]);
+        if constexpr (FOLD) fvb[k] = ld_parts<KGE_GA_MAXP>(pB + itc[k], a.ga_parts, a.ga_stride);    // (FOLD: fast path without Q - pB is a GA row)
+        else fvb[k] = ld<4>(pB + itc[k]);
         xr[k] = ld<4>(pX + itc[k]);
     }
 #pragma unroll
@@ -116,7 +138,11 @@ __device__ __forceinline__ void update_rel_row(const UpdateArgs &a, int bx, int 
             for (int j = 0; j < LB2; ++j) {
                 const int64_t eo = (int64_t)__builtin_amdgcn_readlane(edgev, min(i0 + j, nex64 - 1)) * d;
 #pragma unroll
-                for (int k = 0; k < NIT; ++k) { vp[j][k] = ld<4>(a.P + eo + itc[k]); vg[j][k] = ld<4>(a.GA + eo + itc[k]); }
+                for (int k = 0; k < NIT; ++k) {
+                    vp[j][k] = ld<4>(a.P + eo + itc[k]);
+                    if constexpr (FOLD) vg[j][k] = ld_parts<KGE_GA_MAXP>(a.GA + eo + itc[k], a.ga_parts, a.ga_stride);
+                    else vg[j][k] = ld<4>(a.GA + eo + itc[k]);
+                }
             }
 #pragma unroll
             for (int j = 0; j < LB2; ++j) {
@@ -174,7 +200,10 @@ __device__ __forceinline__ void update_rel_row(const UpdateArgs &a, int bx, int 
         for (int k = 0; k < NIT; ++k) {
             if (lane + 64 * k < nit) {
                 if (a.transe_fast) {
-                    const Pack<4> pv = ld<4>((qm ? a.Q : a.P) + eo + itc[k]), gv = ld<4>((qm ? a.Q : a.GA) + eo + itc[k]);
+                    const Pack<4> pv = ld<4>((qm ? a.Q : a.P) + eo + itc[k]);
+                    Pack<4> gv;
+                    if constexpr (FOLD) gv = ld_parts<KGE_GA_MAXP>(a.GA + eo + itc[k], a.ga_parts, a.ga_stride);
+                    else gv = ld<4>((qm ? a.Q : a.GA) + eo + itc[k]);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float g = qm ? sgr * pv.v[e] : sgr * gv.v[e] - pv.v[e];
@@ -303,7 +332,8 @@ __device__ __forceinline__ void update_rel_row(const UpdateArgs &a, int bx, int 
 template <int NIT, bool SHARDED, int LEAN_>     // LEAN: 0 = everything at run time, 1 = in-place + TransE fast path,
 __device__ __forceinline__ void update_reg_body(const UpdateArgs &a_in, int nb_ent, int bid, int nblk) {   // 2 = in-place + per-edge gradients
     using namespace kge;                         // 3 = 1 with Q rows; 4 (round 4) = 0 with the regulariser's norm fixed at 3 - the
-    constexpr int LEAN = LEAN_ == 4 ? 0 : LEAN_; // gradient-emitting (sharded all-to-all) step of every BASELINE recipe
+    constexpr int LEAN = LEAN_ == 4 ? 0 : (LEAN_ == 5 ? 1 : LEAN_); // gradient-emitting (sharded all-to-all) step of every BASELINE recipe
+    constexpr bool FOLD = LEAN_ == 5;            // 5 (round 4) = 1 with the shared-pair backward's GN partials / GA parts summed HERE (UpdateArgs::gn_parts)
     UpdateArgs a = a_in;
     if constexpr (!SHARDED) { a.em.n = 0; a.rm.n = 0; }
     if constexpr (LEAN_ == 4) a.reg_norm = 3;
@@ -386,7 +416,11 @@ __device__ __forceinline__ void update_reg_body(const UpdateArgs &a_in, int nb_e
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
             x[k] = ld<4>(row + itc[k]);
-            fva[k] = ld<4>(pA + itc[k]); fvb[k] = ld<4>(pB + itc[k]); fvc[k] = ld<4>(pC + itc[k]);
+            fva[k] = ld<4>(pA + itc[k]);
+            if constexpr (FOLD) {
+                fvb[k] = ld_parts<KGE_GA_MAXP>(pB + itc[k], (ga0 && !qm) ? a.ga_parts : 1, a.ga_stride);
+                fvc[k] = ld_parts<KGE_GN_MAXP>((has_neg ? a.GNp + gn_row(a, slot0) * d : row) + itc[k], has_neg ? a.gn_parts : 1, a.gn_stride);
+            } else { fvb[k] = ld<4>(pB + itc[k]); fvc[k] = ld<4>(pC + itc[k]); }
             fxr[k] = ld<4>(pX + itc[k]);                    // aliases the row itself outside the async pipeline
             xn[k] = ndreg ? ld<4>(pXn + itc[k]) : x[k];
         }
@@ -401,6 +435,7 @@ __device__ __forceinline__ void update_reg_body(const UpdateArgs &a_in, int nb_e
                     if (has_pos) g += (qm && ga0) ? va.v[e] : sg0 * va.v[e] + (ga0 ? vb.v[e] : 0.f);
                     g0[k].v[e] = g;
                     float gn = has_neg ? vc.v[e] : 0.f;
+                    if constexpr (FOLD) { if (has_neg && a.gn_reg_coef > 0.f) gn += reg_grad(x[k].v[e], a.gn_reg_coef, a.gn_reg_norm); }   // (gn_reduce_body's term, on the row as it is)
                     if (ndreg && has_neg) gn += reg_grad(xn[k].v[e], a.reg_coef, a.reg_norm);
                     g1[k].v[e] = gn;
                     s1 = fmaf(gn, gn, s1);
@@ -423,7 +458,8 @@ __device__ __forceinline__ void update_reg_body(const UpdateArgs &a_in, int nb_e
 #pragma unroll
                     for (int k = 0; k < NIT; ++k) {
                         vp[j][k] = ld<4>(a.P + eo + itc[k]);
-                        vg[j][k] = ld<4>((wg[j] ? a.GA : a.P) + eo + itc[k]);
+                        if constexpr (FOLD) vg[j][k] = ld_parts<KGE_GA_MAXP>((wg[j] ? a.GA : a.P) + eo + itc[k], wg[j] ? a.ga_parts : 1, a.ga_stride);
+                        else vg[j][k] = ld<4>((wg[j] ? a.GA : a.P) + eo + itc[k]);
                     }
                 }
 #pragma unroll
@@ -473,13 +509,35 @@ __device__ __forceinline__ void update_reg_body(const UpdateArgs &a_in, int nb_e
             const float *src2 = (wga && !qm) ? a.GA + eo : src;
 #pragma unroll
             for (int k = 0; k < NIT; ++k) {
-                const Pack<4> g = ld<4>(src + itc[k]), g2 = ld<4>(src2 + itc[k]);
+                const Pack<4> g = ld<4>(src + itc[k]);
+                Pack<4> g2;
+                if constexpr (FOLD) g2 = ld_parts<KGE_GA_MAXP>(src2 + itc[k], (wga && !qm) ? a.ga_parts : 1, a.ga_stride);
+                else g2 = ld<4>(src2 + itc[k]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) g0[k].v[e] += sg * g.v[e] + ((wga && !qm) ? g2.v[e] : 0.f);
             }
         }
         // ---- rest of the negative list (rows of GN) ----
-        const int nnx64 = nnx < 64 ? nnx : 64;
+        if constexpr (FOLD) {                                  // partial rows summed here: one entry (gn_parts requests per pack) at a time
+#pragma unroll 1
+            for (int i = 0; i < nnx; ++i) {
+                const float *src = a.GNp + gn_row(a, a.ue_neg_slot[n0 + 1 + i]) * d;
+#pragma unroll
+                for (int k = 0; k < NIT; ++k) {
+                    Pack<4> g = ld_parts<KGE_GN_MAXP>(src + itc[k], a.gn_parts, a.gn_stride);
+                    if (a.gn_reg_coef > 0.f) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) g.v[e] += reg_grad(x[k].v[e], a.gn_reg_coef, a.gn_reg_norm);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (lane + 64 * k < nit) s1 = fmaf(g.v[e], g.v[e], s1);
+                        g1[k].v[e] += g.v[e];
+                    }
+                }
+            }
+        }
+        const int nnx64 = FOLD ? 0 : (nnx < 64 ? nnx : 64);
 #pragma unroll 1
         for (int i0 = 0; i0 < nnx64; i0 += LB1) {
             Pack<4> vv[LB1][NIT];
@@ -510,7 +568,7 @@ __device__ __forceinline__ void update_reg_body(const UpdateArgs &a_in, int nb_e
             }
         }
 #pragma unroll 1
-        for (int i = 64; i < nnx; ++i) {
+        for (int i = FOLD ? nnx : 64; i < nnx; ++i) {
             const float *src = a.GN + gn_row(a, a.ue_neg_slot[n0 + 1 + i]) * d;
 #pragma unroll
             for (int k = 0; k < NIT; ++k) {
@@ -595,7 +653,8 @@ __device__ __forceinline__ void update_reg_body(const UpdateArgs &a_in, int nb_e
         // there (registers, code layout; profiles/r02_heavy_lists.txt)
         constexpr int COOP_MIN_R = 2 * (NIT <= 2 ? 6 : 2) + 1;
         const bool coop = !(a.transe_fast && !qm) && (!a.counts_dev || a.counts_dev[3] - 1 >= COOP_MIN_R);
-        if (coop) update_rel_row<NIT, SHARDED, LEAN, true>(a, bx, nb_ent, lane, reg, qm);
+        if constexpr (FOLD) update_rel_row<NIT, SHARDED, LEAN, false, true>(a, bx, nb_ent, lane, reg, qm);   // (fast path without Q: never the shared-list instance)
+        else if (coop) update_rel_row<NIT, SHARDED, LEAN, true>(a, bx, nb_ent, lane, reg, qm);
         else update_rel_row<NIT, SHARDED, LEAN, false>(a, bx, nb_ent, lane, reg, qm);
     }
 }
