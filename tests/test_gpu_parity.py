@@ -461,8 +461,10 @@ def test_pairwise_fused_launches_equal_separate_launches_bit_for_bit(model, de_,
 @pytest.mark.parametrize("model,de_,dr_,hidden,flags", [("TransE_l2", False, False, 64, 0), ("RotatE", True, False, 32, 0),
                                                         ("DistMult", False, False, 64, 0), ("TransR", False, False, 16, 0),
                                                         ("RESCAL", False, False, 16, 0), ("TransE_l2", False, False, 64, 32),
-                                                        ("RotatE", True, False, 32, 32)],
-                         ids=["TransE_l2", "RotatE", "DistMult", "TransR", "RESCAL", "TransE_l2-neg_deg", "RotatE-neg_deg"])
+                                                        ("RotatE", True, False, 32, 32), ("TransE_l1", False, False, 64, 0),
+                                                        ("TransE_l1", False, False, 64, -1)],
+                         ids=["TransE_l2", "RotatE", "DistMult", "TransR", "RESCAL", "TransE_l2-neg_deg", "RotatE-neg_deg",
+                              "TransE_l1", "TransE_l1-5-partials-3-parts"])
 def test_four_phase_calls_equal_the_fused_step_bit_for_bit(model, de_, dr_, hidden, flags):
     """kge_step_phase (the reference's sample / forward / backward / update timers, train_pytorch.py:127-177; runs once per
     log interval in every dglke_train run): the four phase groups issued one after the other ARE kge_step_fused - same
@@ -471,6 +473,10 @@ def test_four_phase_calls_equal_the_fused_step_bit_for_bit(model, de_, dr_, hidd
     from dglke_amd import _lib, plan
     from dglke_amd.engine import StepEngine
     n_ent, n_rel, B, N = 800, 11, 96, 32
+    if flags == -1:
+        # TransE_l1 at the recipe's chunk shape: the fused call's update kernel sums the shared-pair backward's 5 GN partials and
+        # 3 GA parts itself (UpdateArgs::gn_parts), the phase calls run the stand-alone reduction launch - same additions, same order
+        n_ent, B, N, flags = 3000, 400, 200, 0
     rng = np.random.RandomState(17)
     plans = []
     for step in range(1, 4):
