@@ -169,6 +169,17 @@ template <> __device__ __forceinline__ void st_wt<4>(float *p, const Pack<4> &x)
 template <> __device__ __forceinline__ void st_wt<1>(float *p, const Pack<1> &x) {
     asm volatile("global_store_dword %0, %1, off sc0 sc1" : : "v"(p), "v"(x.v[0]) : "memory");
 }
+// round 4: the pairwise models' intermediates that the NEXT launch consumes leave write-through (GN partials and GA parts of the
+// shared-pair backward, the summed GN rows, the dense copy of the negative rows): lines left dirty in the XCDs' L2s are written
+// back at the end of the kernel, in front of the next launch (RotatE: 3.1 us instead of 1.2 between the shared-pair backward and
+// edge_bwd).  Measured on one box (profiles/r04_store_policy.txt): RotatE FB15k shape 60.7 -> 58.3 us/step, cfg-R per GPU 99.5 ->
+// 97.5 (p2p) / 116.4 -> 114.9 (a2a); the a2a engine's gradient messages and gathered cache rows stay plain (write-through: +1.2 us).
+// -DKGE_PLAIN_INTERMEDIATES: plain stores everywhere, -DKGE_PLAIN_NEXT: all but the partials (A/B aids)
+#if defined(KGE_PLAIN_INTERMEDIATES) || defined(KGE_PLAIN_NEXT)
+#define KGE_ST_NEXT kge::st
+#else
+#define KGE_ST_NEXT kge::st_wt
+#endif
 template <int V> __device__ __forceinline__ Pack<V> zero_pack() {
     Pack<V> r;
 #pragma unroll
@@ -364,7 +375,7 @@ __device__ __forceinline__ void gn_reduce_body(const NegArgs &a, int nrw, int64_
         acc.x += kge::reg_grad(x.x, a.reg_coef, a.reg_norm); acc.y += kge::reg_grad(x.y, a.reg_coef, a.reg_norm);
         acc.z += kge::reg_grad(x.z, a.reg_coef, a.reg_norm); acc.w += kge::reg_grad(x.w, a.reg_coef, a.reg_norm);
     }
-    *reinterpret_cast<float4 *>(a.GN + 4 * t) = acc;
+    { kge::Pack<4> o; o.v[0] = acc.x; o.v[1] = acc.y; o.v[2] = acc.z; o.v[3] = acc.w; KGE_ST_NEXT<4>(a.GN + 4 * t, o); }
 }
 
 struct LossArgs {

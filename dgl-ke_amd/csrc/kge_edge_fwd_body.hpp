@@ -240,7 +240,7 @@ __device__ __forceinline__ void edge_fwd_body(const EdgeFwdArgs &a_in, int bid) 
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 if (lane + 64 * k < nitn) {
-                    if (cp) st<V>(cp + (lane + 64 * k) * V, v2[k]);
+                    if (cp) KGE_ST_NEXT<V>(cp + (lane + 64 * k) * V, v2[k]);
 #pragma unroll
                     for (int e = 0; e < V; ++e) s += v2[k].v[e] * v2[k].v[e];
                 }
@@ -248,7 +248,7 @@ __device__ __forceinline__ void edge_fwd_body(const EdgeFwdArgs &a_in, int bid) 
         } else
         for (int it = lane; it < nitn; it += 64) {
             const Pack<V> v = ld<V>(x + it * V);
-            if (cp) st<V>(cp + it * V, v);
+            if (cp) KGE_ST_NEXT<V>(cp + it * V, v);
 #pragma unroll
             for (int e = 0; e < V; ++e) s += v.v[e] * v.v[e];
         }

@@ -707,6 +707,15 @@ __global__ __launch_bounds__(KGE_BLOCK) void neg_bwd_bcast_kernel(NegArgs a, int
 #define LC_RTMAX 20                              // most positive rows a wavefront keeps in registers (RotatE: 16)
 
 __device__ __forceinline__ float4 zero4b() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+// the GN partials / GA parts leave write-through (kge_common.hpp KGE_ST_NEXT): 13 MB (FB15k shape) - 26 MB (cfg-R) of lines left dirty in the XCDs' L2s
+// were written back at the end of the kernel, in front of the next launch (gap 3.1 us instead of 1.2-1.3, tools/timeline.py)
+__device__ __forceinline__ void st_v2(float *p, v2f x) {
+#ifdef KGE_PLAIN_INTERMEDIATES
+    *reinterpret_cast<v2f *>(p) = x;
+#else
+    asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" : : "v"(p), "v"(x) : "memory");
+#endif
+}
 template <int L> __device__ __forceinline__ float rowb(float v) {    // lane L of every row of 16 lanes
     return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x150 + L, 0xF, 0xF, true));
 }
@@ -952,13 +961,13 @@ __global__ __launch_bounds__(KGE_BLOCK) LC_OCC void neg_bwd_lc_kernel(NegArgs a,
                 const float4 v0 = *reinterpret_cast<const float4 *>(p), v1 = *reinterpret_cast<const float4 *>(p + 64 * NV);
                 const float4 v2 = *reinterpret_cast<const float4 *>(p + 2 * 64 * NV), v3 = *reinterpret_cast<const float4 *>(p + 3 * 64 * NV);
                 if (sN < N && cl < K) {
-                    *reinterpret_cast<v2f *>(o) = (v2f){((v0.x + v1.x) + v2.x) + v3.x, ((v0.y + v1.y) + v2.y) + v3.y};
-                    *reinterpret_cast<v2f *>(o + K) = (v2f){((v0.z + v1.z) + v2.z) + v3.z, ((v0.w + v1.w) + v2.w) + v3.w};
+                    st_v2(o, (v2f){((v0.x + v1.x) + v2.x) + v3.x, ((v0.y + v1.y) + v2.y) + v3.y});
+                    st_v2(o + K, (v2f){((v0.z + v1.z) + v2.z) + v3.z, ((v0.w + v1.w) + v2.w) + v3.w});
                 }
             } else {
                 const v2f v0 = *reinterpret_cast<const v2f *>(p), v1 = *reinterpret_cast<const v2f *>(p + 64 * NV);
                 const v2f v2 = *reinterpret_cast<const v2f *>(p + 2 * 64 * NV), v3 = *reinterpret_cast<const v2f *>(p + 3 * 64 * NV);
-                if (sN < N && cl < K) *reinterpret_cast<v2f *>(o) = ((v0 + v1) + v2) + v3;
+                if (sN < N && cl < K) st_v2(o, ((v0 + v1) + v2) + v3);
             }
         }
         buf ^= 1;
@@ -978,8 +987,8 @@ __global__ __launch_bounds__(KGE_BLOCK) LC_OCC void neg_bwd_lc_kernel(NegArgs a,
         }
         if (sg == 0 && colok && r0 + n < rend) {
             float *o = a.GA + sp * a.ga_stride + ((int64_t)c * chunk + r0 + n) * D + col;
-            *reinterpret_cast<v2f *>(o) = gr[n];
-            if constexpr (CPLX) *reinterpret_cast<v2f *>(o + K) = gi[n];
+            st_v2(o, gr[n]);
+            if constexpr (CPLX) st_v2(o + K, gi[n]);
         }
     }
 }

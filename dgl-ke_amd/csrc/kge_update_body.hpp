@@ -622,7 +622,7 @@ __device__ __forceinline__ void update_reg_body(const UpdateArgs &a_in, int nb_e
                     }
                     KGE_ST_ROW<4>(row + it * 4, y);
                 }
-                if (a.g0) st<4>(a.g0 + mu * (int64_t)a.ld_e + it * 4, g0[k]);
+                if (a.g0) st<4>(a.g0 + mu * (int64_t)a.ld_e + it * 4, g0[k]);      // (messages: plain - write-through measured 1.2 us slower on the a2a step)
                 if (a.g1) st<4>(a.g1 + mu * (int64_t)a.ld_e + it * 4, g1[k]);
             }
         }

@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--async-update", action="store_true")
     ap.add_argument("--skew", action="store_true", help="heavy-tailed ids (bench.py --skew)")
+    ap.add_argument("--per-cu", type=int, default=-1, help="kernel id: wavefronts per CU / SIMD and their life by occupancy class")
     args = ap.parse_args()
     import bench
     from dglke_amd import _lib
@@ -112,6 +113,25 @@ def main():
             print("               marks since wave start: " + " | ".join(parts))
     if order:
         print("step span (first start -> last end): %.2f us" % (t1.max() - base))
+    if args.per_cu >= 0:
+        # HW_ID (gfx9 layout): wave 3:0, simd 5:4, pipe 7:6, cu 11:8, sh 12, se 15:13
+        m = kid == args.per_cu
+        hw = a[m][:, 0] & 0xffffffff
+        simd, cu, sh, se = (hw >> 4) & 3, (hw >> 8) & 0xf, (hw >> 12) & 1, (hw >> 13) & 7
+        cuid = ((xcc[m] * 8 + se) * 2 + sh) * 16 + cu
+        sid = cuid * 4 + simd
+        d = (t1 - t0)[m]
+        e = (t1 - base)[m]
+        ncu, nsimd = len(set(cuid.tolist())), len(set(sid.tolist()))
+        print("# kernel %d: %d wavefronts on %d CUs / %d SIMDs" % (args.per_cu, m.sum(), ncu, nsimd))
+        cnt = {}
+        for x in sid.tolist():
+            cnt[x] = cnt.get(x, 0) + 1
+        occ = np.array([cnt[x] for x in sid.tolist()])
+        for c in sorted(set(occ.tolist())):
+            mm = occ == c
+            print("#   SIMDs holding %d wavefronts: %4d SIMDs, wavefront life p50 %.2f max %.2f, last end %.2f us" % (
+                c, len(set(sid[mm].tolist())), np.percentile(d[mm], 50), d[mm].max(), e[mm].max()))
 
 
 if __name__ == "__main__":
