@@ -951,6 +951,34 @@ __global__ __launch_bounds__(KGE_BLOCK) LC_OCC void neg_bwd_lc_kernel(NegArgs a,
 #endif
         // fixed-order sum over the 4 wavefronts: one partial per (workgroup row group, negative, column).  The
         // LDS buffers alternate, so the next group needs no second barrier.
+#if !defined(KGE_PLAIN_INTERMEDIATES) && !defined(LC_ST8)
+        constexpr bool ST16 = !CPLX;
+#else
+        constexpr bool ST16 = false;
+#endif
+        if constexpr (ST16) {
+        // (real-valued models, write-through stores: 16 bytes each - an 8-byte sc1 store costs 2.7 x a 16-byte one per byte,
+        //  MI355X_MICROARCH.md - so a thread sums the partials of TWO adjacent lanes = four consecutive columns; per element the
+        //  same additions in the same wavefront order as the per-lane form.  Measured: TransE_l1 53.7 -> 53.0 us/step; RotatE
+        //  (two halves per lane) is 0.5-0.9 us FASTER with the per-lane 8-byte stores and keeps them; profiles/r04_store_policy.txt)
+        for (int e = tid; e < LC_GQ * (CPLX ? 64 : 32); e += KGE_BLOCK) {
+            const int g = CPLX ? e >> 6 : e >> 5, r = CPLX ? e & 63 : (e & 31) * 2;
+            const int l0 = r & ~1, part = CPLX ? r & 1 : 0;
+            const float *p = redb + (g * KGE_WAVES_PER_BLOCK * 64 + l0) * NV + 2 * part;
+            const int sN = 4 * (qb + g) + (l0 >> 4);
+            const int cl = slab * LC_CW + 2 * (l0 & 15);
+            v2f s0 = *reinterpret_cast<const v2f *>(p), s1 = *reinterpret_cast<const v2f *>(p + NV);
+#pragma unroll
+            for (int w = 1; w < KGE_WAVES_PER_BLOCK; ++w) {
+                s0 += *reinterpret_cast<const v2f *>(p + w * 64 * NV);
+                s1 += *reinterpret_cast<const v2f *>(p + w * 64 * NV + NV);
+            }
+            if (sN < N && cl < K) {                              // K % 4 == 0: four columns or none
+                Pack<4> o4; o4.v[0] = s0.x; o4.v[1] = s0.y; o4.v[2] = s1.x; o4.v[3] = s1.y;
+                st_wt<4>(a.GNp + (((int64_t)rw * a.C + c) * N + sN) * D + cl + part * K, o4);
+            }
+        }
+        } else {
         for (int e = tid; e < LC_GQ * 64; e += KGE_BLOCK) {
             const int g = e >> 6, l = e & 63;
             const float *p = redb + (g * KGE_WAVES_PER_BLOCK * 64 + l) * NV;
@@ -969,6 +997,7 @@ __global__ __launch_bounds__(KGE_BLOCK) LC_OCC void neg_bwd_lc_kernel(NegArgs a,
                 const v2f v2 = *reinterpret_cast<const v2f *>(p + 2 * 64 * NV), v3 = *reinterpret_cast<const v2f *>(p + 3 * 64 * NV);
                 if (sN < N && cl < K) st_v2(o, ((v0 + v1) + v2) + v3);
             }
+        }
         }
         buf ^= 1;
         if constexpr (NRED == 1) __syncthreads();                // the partials are read before the next group overwrites them
