@@ -11,7 +11,7 @@ kt = "kernels" if "kernels" in tabs else [t for t in tabs if "kernel" in t.lower
 cols = [r[1] for r in cur.execute("pragma table_info(%s)" % kt)]
 name_col = "name" if "name" in cols else [c for c in cols if "name" in c][0]
 rows = cur.execute("select %s, start, end from %s order by start" % (name_col, kt)).fetchall()
-keys = ("neg_", "loss_", "update_", "edge_", "sample_")
+keys = ("neg_", "loss_", "update_", "edge_", "sample_", "gather_req", "apply_merged", "route_", "gn_reduce", "transr_", "rescal_")
 seq = [(n.split("(")[0].replace("void ", "")[:44], s, e) for n, s, e in rows if any(k in n for k in keys)]
 skip = int(sys.argv[2]) if len(sys.argv) > 2 else len(seq) // 3
 seq = seq[skip:]
