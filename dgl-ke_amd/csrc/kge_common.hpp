@@ -354,6 +354,11 @@ struct NegArgs {                     // chunked negative scoring, forward and ba
     // shared-pair backward, RotatE: the negatives of a chunk split over ga_parts (> 1) workgroups per (chunk, slab, row group) -
     // GA then leaves as ga_parts partial sums ga_stride floats apart and the CONSUMER adds them (edge_bwd: EdgeBwdArgs.ga_parts)
     int ga_parts; int64_t ga_stride;
+    // balanced split (round 4, filled by the launcher; lc_P > 0): exactly 1024 workgroups = 4 per CU - the first lc_nB columns
+    // (chunk, slab, row group) are cut into lc_P parts, the others into lc_P + 1, and the workgroups are dealt heaviest-first in
+    // alternating direction over four rounds of 256 block ids, so that the block ids k, k + 256, k + 512, k + 768 (observed: one
+    // CU; for speed only) carry equal work.  ga_parts = the larger part count; a shorter column's last part zero-fills the rest.
+    int lc_P, lc_nB;
     // forward, merged launch (launch_neg_fwd_bcast_with_edge, TransE_l1): pos-side vectors built on the fly, a = x + asign * r
     const float *xbase; const int64_t *xidx; const float *rbase; const int64_t *ridx; float asign;
 };

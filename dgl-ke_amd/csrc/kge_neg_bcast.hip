@@ -794,8 +794,30 @@ __global__ __launch_bounds__(KGE_BLOCK) LC_OCC void neg_bwd_lc_kernel(NegArgs a,
     // or four wavefronts per SIMD instead of one (the kernel is bound by the instruction issue of its wavefronts,
     // tools/valu_rate_probe.hip); every negative still has ONE workgroup per row group (GN partials unchanged), GA leaves as
     // ga_parts partial sums that the consumer adds
-    const int nsp = max(a.ga_parts, 1);
-    const int sp = (int)blockIdx.x % nsp, blk = (int)blockIdx.x / nsp;
+    const int nq = (a.N + 3) >> 2;
+    const int ngr = (nq + LC_GQ - 1) / LC_GQ;                    // groups of quads of a column
+    int nsp = max(a.ga_parts, 1), sp, blk;                       // this workgroup: part sp of nsp of column blk
+    int g_lo, g_hi;                                              // ... = groups [g_lo, g_hi)
+    if (a.lc_P > 0) {
+        // balanced split (NegArgs::lc_P): sorted index i of this block id (rounds of 256 ids, odd rounds reversed), then the
+        // i-th heaviest workgroup: classes in descending size - big / small parts of the lc_P-part columns, then of the others
+        const int b = (int)blockIdx.x, k = b & 255, rnd = b >> 8;
+        int t = (rnd << 8) + ((rnd & 1) ? 255 - k : k);
+        const int P = a.lc_P, nB = a.lc_nB, ncol = a.C * nslab * nrw, nA = ncol - nB;
+        const int remB = ngr % P, remA = ngr % (P + 1);
+        const int n1 = nB * remB, n2 = nB * (P - remB), n3 = nA * remA;
+        int j;
+        if (t < n1) { blk = t / remB; j = t % remB; nsp = P; }
+        else if (t < n1 + n2) { t -= n1; blk = t / (P - remB); j = remB + t % (P - remB); nsp = P; }
+        else if (t < n1 + n2 + n3) { t -= n1 + n2; blk = nB + t / remA; j = t % remA; nsp = P + 1; }
+        else { t -= n1 + n2 + n3; blk = nB + t / (P + 1 - remA); j = remA + t % (P + 1 - remA); nsp = P + 1; }
+        sp = j;
+        const int base = ngr / nsp, rem = ngr % nsp;             // the first `rem` parts hold one group more
+        g_lo = j * base + min(j, rem); g_hi = g_lo + base + (j < rem ? 1 : 0);
+    } else {
+        sp = (int)blockIdx.x % nsp; blk = (int)blockIdx.x / nsp;
+        g_lo = sp * ngr / nsp; g_hi = (sp + 1) * ngr / nsp;
+    }
     const int rw = blk % nrw, slab = (blk / nrw) % nslab, c = blk / (nrw * nslab);
     const int D = a.d_e, K = CPLX ? D / 2 : D, N = a.N, chunk = a.chunk;
     const int col = slab * LC_CW + 2 * kk;
@@ -814,9 +836,7 @@ __global__ __launch_bounds__(KGE_BLOCK) LC_OCC void neg_bwd_lc_kernel(NegArgs a,
         gi[n] = (v2f){0.f, 0.f};
     }
     const float *Wc = a.W + (int64_t)c * chunk * N;
-    const int nq = (N + 3) >> 2;
-    const int ngr = (nq + LC_GQ - 1) / LC_GQ;                    // groups of quads; this workgroup: groups [sp, sp + 1) * ngr / nsp
-    const int q_lo = (sp * ngr / nsp) * LC_GQ, q_hi = min(((sp + 1) * ngr / nsp) * LC_GQ, nq);
+    const int q_lo = g_lo * LC_GQ, q_hi = min(g_hi * LC_GQ, nq);
     // ---- operand staging through LDS, one group of LC_GQ quads (= LC_SG negatives) at a time ----------------
     // The 4 wavefronts of the workgroup need the SAME negative rows (their slab columns) and each its own block
     // of W.  The global loads of group i+1 are issued BEFORE the arithmetic of group i and written to the other
@@ -1018,6 +1038,10 @@ __global__ __launch_bounds__(KGE_BLOCK) LC_OCC void neg_bwd_lc_kernel(NegArgs a,
             float *o = a.GA + sp * a.ga_stride + ((int64_t)c * chunk + r0 + n) * D + col;
             st_v2(o, gr[n]);
             if constexpr (CPLX) st_v2(o + K, gi[n]);
+            if (a.lc_P > 0 && sp == nsp - 1 && nsp < a.ga_parts) {       // (balanced split: this column has one part less than the consumer adds)
+                st_v2(o + a.ga_stride, (v2f){0.f, 0.f});
+                if constexpr (CPLX) st_v2(o + a.ga_stride + K, (v2f){0.f, 0.f});
+            }
         }
     }
 }
@@ -1040,8 +1064,34 @@ __global__ __launch_bounds__(KGE_BLOCK) void gn_reduce_kernel(NegArgs a, int nrw
     }
 }
 
+// balanced split (NegArgs::lc_P): RotatE at <= 8 rows per wavefront (the instance that holds four workgroups per CU), every part
+// >= 2 groups of quads, at most 8 parts.  Measured (tools/timeline.py --per-cu, rotate_fb15k): 896 equal workgroups = 3.5 per CU -
+// the CUs holding four end 3.5 us after those holding three (wavefront life p50 17.6 vs 15.4 us); cfg-R: 832 = 3.25 per CU.
+#ifndef LC_NO_BALANCE
+#define LC_BALANCE 1
+#endif
+static bool lc_balance(int model, int C, int chunk, int N, int d_e, int &P, int &nB) {
+    P = 0; nB = 0;
+#ifdef LC_BALANCE
+    if (model != KGE_ROTATE || !neg_bwd_lc_supported(model, d_e) || N % 4 || d_e % 4) return false;
+    int nslab, nrw, rpw;
+    lc_shape(model, C, chunk, d_e, nslab, nrw, rpw);
+    if (rpw > 8) return false;
+    const int ncol = C * nslab * nrw, ngr = ((N + 3) / 4 + LC_GQ_CPLX - 1) / LC_GQ_CPLX;
+    if (ncol < 1 || ncol > 1024) return false;
+    const int p = 1024 / ncol, nA = 1024 - ncol * p;
+    if (nA == 0 || p + 1 > 8 || ngr / (p + 1) < 2) return false;      // (nA == 0: the uniform split already fills the chip evenly)
+    P = p; nB = ncol - nA;
+    return true;
+#else
+    (void)model; (void)C; (void)chunk; (void)N; (void)d_e;
+    return false;
+#endif
+}
+
 // split the negatives while the launch stays within ~4 workgroups per CU and a workgroup keeps >= 2 groups of quads
 int neg_bwd_lc_splits(int model, int C, int chunk, int N, int d_e) {
+    { int P, nB; if (lc_balance(model, C, chunk, N, d_e, P, nB)) return P + 1; }
 #ifndef LC_SPLIT_REAL
     if (model != KGE_ROTATE) return 1;
 #endif
@@ -1064,11 +1114,18 @@ template <int MODEL> static int lc_launch(const NegArgs &a, hipStream_t s) {
     int nslab, nrw, rpw;
     lc_shape(MODEL, a.C, a.chunk, a.d_e, nslab, nrw, rpw);
     if (a.ga_parts > 1 && a.d_e % 4) return KGE_ERR_ARG;
-    const int64_t nb = (int64_t)a.C * nslab * nrw * max(a.ga_parts, 1);
+    int64_t nb = (int64_t)a.C * nslab * nrw * max(a.ga_parts, 1);
     if (nb == 0) return KGE_OK;
+    NegArgs ab = a;
+    ab.lc_P = 0; ab.lc_nB = 0;
+    {   // the balanced split when the caller's part count is the one it asks for (neg_bwd_lc_splits)
+        int P, nB;
+        if (lc_balance(MODEL, a.C, a.chunk, a.N, a.d_e, P, nB) && a.ga_parts == P + 1) { ab.lc_P = P; ab.lc_nB = nB; nb = 1024; }
+    }
+    const NegArgs &a_ = ab;
     const dim3 g((unsigned)nb), b(KGE_BLOCK);
     // rows per wavefront rounded up to the next instantiation (the padding rows carry W = 0)
-    if (rpw <= 8) hipLaunchKernelGGL((neg_bwd_lc_kernel<MODEL, 8>), g, b, 0, s, a, nslab, nrw, rpw);
+    if (rpw <= 8) hipLaunchKernelGGL((neg_bwd_lc_kernel<MODEL, 8>), g, b, 0, s, a_, nslab, nrw, rpw);
     else if (rpw <= 12) hipLaunchKernelGGL((neg_bwd_lc_kernel<MODEL, 12>), g, b, 0, s, a, nslab, nrw, rpw);
     else if (rpw <= 16) hipLaunchKernelGGL((neg_bwd_lc_kernel<MODEL, 16>), g, b, 0, s, a, nslab, nrw, rpw);
     else if constexpr (MODEL != KGE_ROTATE) hipLaunchKernelGGL((neg_bwd_lc_kernel<MODEL, LC_RTMAX>), g, b, 0, s, a, nslab, nrw, rpw);
