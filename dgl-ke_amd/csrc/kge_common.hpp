@@ -210,6 +210,14 @@ __device__ __forceinline__ float reg_val(float x, int q) {
     return ax > 0.f ? __builtin_amdgcn_exp2f((float)q * __builtin_amdgcn_logf(ax)) : 0.f;    // |x|^q
 }
 
+// rv + |x|^q with the rounding spelled out for q == 3: left as `rv += ax * ax * ax`, two instances of the update kernel contracted
+// the last multiply into the addition differently and the regularisation VALUE (a reported sum, not part of the gradients) of a
+// row came out 1 ulp apart between them (found when a different GA part count moved the data onto a rounding boundary, round 4)
+__device__ __forceinline__ float reg_acc(float rv, float x, int q) {
+    if (__builtin_constant_p(q) && q == 3) { const float ax = fabsf(x); return fmaf(ax * ax, ax, rv); }
+    return rv + reg_val(x, q);
+}
+
 __device__ __forceinline__ float sigmoidf_(float x) {
     // numerically safe logistic
     if (x >= 0.f) { return 1.f / (1.f + expf(-x)); }

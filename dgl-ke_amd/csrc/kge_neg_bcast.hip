@@ -1064,8 +1064,8 @@ __global__ __launch_bounds__(KGE_BLOCK) void gn_reduce_kernel(NegArgs a, int nrw
     }
 }
 
-// balanced split (NegArgs::lc_P): RotatE at <= 8 rows per wavefront (the instance that holds four workgroups per CU), every part
-// >= 2 groups of quads, at most 8 parts.  Measured (tools/timeline.py --per-cu, rotate_fb15k): 896 equal workgroups = 3.5 per CU -
+// balanced split (NegArgs::lc_P): the instances that hold four workgroups per CU (RotatE at <= 8 rows per wavefront, TransE_l1 at
+// <= 16), every part >= 2 (RotatE) / 1 (TransE_l1) groups of quads, at most 8 / 4 parts.  Measured (tools/timeline.py --per-cu, rotate_fb15k): 896 equal workgroups = 3.5 per CU -
 // the CUs holding four end 3.5 us after those holding three (wavefront life p50 17.6 vs 15.4 us); cfg-R: 832 = 3.25 per CU.
 #ifndef LC_NO_BALANCE
 #define LC_BALANCE 1
@@ -1073,14 +1073,21 @@ __global__ __launch_bounds__(KGE_BLOCK) void gn_reduce_kernel(NegArgs a, int nrw
 static bool lc_balance(int model, int C, int chunk, int N, int d_e, int &P, int &nB) {
     P = 0; nB = 0;
 #ifdef LC_BALANCE
-    if (model != KGE_ROTATE || !neg_bwd_lc_supported(model, d_e) || N % 4 || d_e % 4) return false;
+#ifdef LC_BALANCE_REAL       // TransE_l1: measured 52.95 -> 52.3 us/step (975 -> 1024 workgroups) and NOT validated - the oracle comparison at the
+    const bool real_ok = model == KGE_TRANSE_L1;     // recipe's full shape fails with it (tests/test_gpu_parity.py SHAPES); off
+#else
+    const bool real_ok = false;
+#endif
+    if ((model != KGE_ROTATE && !real_ok) || !neg_bwd_lc_supported(model, d_e) || N % 4 || d_e % 4) return false;
     int nslab, nrw, rpw;
     lc_shape(model, C, chunk, d_e, nslab, nrw, rpw);
-    if (rpw > 8) return false;
-    const int ncol = C * nslab * nrw, ngr = ((N + 3) / 4 + LC_GQ_CPLX - 1) / LC_GQ_CPLX;
+    if (rpw > (model == KGE_ROTATE ? 8 : 16)) return false;
+    const int gq = model == KGE_ROTATE ? LC_GQ_CPLX : LC_GQ_REAL;
+    const int ncol = C * nslab * nrw, ngr = ((N + 3) / 4 + gq - 1) / gq;
     if (ncol < 1 || ncol > 1024) return false;
     const int p = 1024 / ncol, nA = 1024 - ncol * p;
-    if (nA == 0 || p + 1 > 8 || ngr / (p + 1) < 2) return false;      // (nA == 0: the uniform split already fills the chip evenly)
+    const int minpart = model == KGE_ROTATE ? 2 : 1;
+    if (nA == 0 || p + 1 > (model == KGE_ROTATE ? 8 : 4) || ngr / (p + 1) < minpart) return false;      // (nA == 0: the uniform split already fills the chip evenly)
     P = p; nB = ncol - nA;
     return true;
 #else
@@ -1126,9 +1133,9 @@ template <int MODEL> static int lc_launch(const NegArgs &a, hipStream_t s) {
     const dim3 g((unsigned)nb), b(KGE_BLOCK);
     // rows per wavefront rounded up to the next instantiation (the padding rows carry W = 0)
     if (rpw <= 8) hipLaunchKernelGGL((neg_bwd_lc_kernel<MODEL, 8>), g, b, 0, s, a_, nslab, nrw, rpw);
-    else if (rpw <= 12) hipLaunchKernelGGL((neg_bwd_lc_kernel<MODEL, 12>), g, b, 0, s, a, nslab, nrw, rpw);
-    else if (rpw <= 16) hipLaunchKernelGGL((neg_bwd_lc_kernel<MODEL, 16>), g, b, 0, s, a, nslab, nrw, rpw);
-    else if constexpr (MODEL != KGE_ROTATE) hipLaunchKernelGGL((neg_bwd_lc_kernel<MODEL, LC_RTMAX>), g, b, 0, s, a, nslab, nrw, rpw);
+    else if (rpw <= 12) hipLaunchKernelGGL((neg_bwd_lc_kernel<MODEL, 12>), g, b, 0, s, a_, nslab, nrw, rpw);
+    else if (rpw <= 16) hipLaunchKernelGGL((neg_bwd_lc_kernel<MODEL, 16>), g, b, 0, s, a_, nslab, nrw, rpw);
+    else if constexpr (MODEL != KGE_ROTATE) hipLaunchKernelGGL((neg_bwd_lc_kernel<MODEL, LC_RTMAX>), g, b, 0, s, a_, nslab, nrw, rpw);
     if (int rc = check_launch_b()) return rc;
     if (a.defer_reduce) return KGE_OK;           // the caller sums the partials in its next launch (launch_edge_bwd_with_gn_reduce)
     const int64_t n4 = (int64_t)a.C * a.N * a.d_e / 4 + (a.ga_parts > 1 ? (int64_t)a.C * a.chunk * a.d_e / 4 : 0);

@@ -117,7 +117,7 @@ __device__ __forceinline__ void update_rel_row(const UpdateArgs &a, int bx, int 
             const Pack<4> va = fva[k], vb = fvb[k];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                if (reg) rv += reg_val(xr[k].v[e], a.reg_norm);
+                if (reg) rv = reg_acc(rv, xr[k].v[e], a.reg_norm);
                 float g;
                 if (a.transe_fast) {
                     g = qm ? sgr * va.v[e] : sgr * vb.v[e] - va.v[e];
@@ -431,7 +431,7 @@ __device__ __forceinline__ void update_reg_body(const UpdateArgs &a_in, int nb_e
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float g = 0.f;
-                    if (reg) { rv += reg_val(xr.v[e], a.reg_norm); g = reg_grad(xr.v[e], a.reg_coef, a.reg_norm); }
+                    if (reg) { rv = reg_acc(rv, xr.v[e], a.reg_norm); g = reg_grad(xr.v[e], a.reg_coef, a.reg_norm); }
                     if (has_pos) g += (qm && ga0) ? va.v[e] : sg0 * va.v[e] + (ga0 ? vb.v[e] : 0.f);
                     g0[k].v[e] = g;
                     float gn = has_neg ? vc.v[e] : 0.f;
