@@ -264,6 +264,23 @@ def test_fused_step_matches_oracle_at_config_shapes(shape, flags):
         _close(eng.rel.cpu(), rel64, 1e-4, 1e-3 * lr, tag + " relation rows")     #  per-step error, profiles/r03_row_error_trajectory.txt)
 
 
+# RotatE shapes that put the shared-pair backward's balanced split (kge_neg_bcast.hip, NegArgs::lc_P) through its cases: columns
+# (chunk, slab, row group) = C * ceil(K / 32) * chunk / 32, quad groups = N / 16; P = 1024 / columns parts for most columns,
+# P + 1 for the rest, with and without remainders in either class, P = 1 included
+BALANCED = [
+    # model, n_ent, n_rel, hidden (= complex columns K), de, dr, B, N, chunk, gamma, lr, adv, reg
+    ("RotatE", 30000, 300, 400, True, False, 512, 256, 256, 12.0, 0.01, True, 1e-7),     # 208 columns: 4 parts of 4 | 5 parts of 4,3,3,3,3
+    ("RotatE", 30000, 300, 320, True, False, 1024, 128, 256, 12.0, 0.01, True, 1e-7),    # 320 columns, 8 groups: 3 parts of 3,3,2 | 4 of 2
+    ("RotatE", 30000, 300, 96, True, False, 2048, 256, 256, 12.0, 0.01, True, 1e-7),     # 192 columns: 5 parts of 4,3,3,3,3 | 6 of 3,3,3,3,2,2
+    ("RotatE", 30000, 300, 400, True, False, 2048, 256, 256, 12.0, 0.01, True, 1e-7),    # 832 columns: 1 part of 16 | 2 parts of 8
+]
+
+
+@pytest.mark.parametrize("shape", BALANCED, ids=lambda s: "%s-B%d-N%d-K%d" % (s[0], s[6], s[7], s[3]))
+def test_balanced_split_of_the_shared_pair_backward_matches_oracle(shape):
+    test_fused_step_matches_oracle_at_config_shapes(shape, 0)
+
+
 def test_fused_step_is_deterministic_and_graph_replay_matches_eager():
     """size-independent property at the full cfg-T shape: the owner-computes update has no atomics,
     so two runs are bit-identical, and a HIP-graph replay equals eager launches."""

@@ -190,3 +190,57 @@ def test_inline_assembly_wide_stores_carry_their_wait_states():
                 n += 1
                 assert "s_nop" in text, "%s: wide store without wait states: %s" % (f, text)
     assert n >= 1
+
+
+def _lc_balanced_map(ncol, ngr, P, nB):
+    """Python statement of the block -> (column, part, groups) map of the shared-pair backward's balanced split
+    (dgl-ke_amd/csrc/kge_neg_bcast.hip, neg_bwd_lc_kernel, NegArgs::lc_P): 1024 block ids, rounds of 256, odd rounds reversed,
+    classes in descending part size."""
+    nA = ncol - nB
+    remB, remA = ngr % P, ngr % (P + 1)
+    n1, n2, n3 = nB * remB, nB * (P - remB), nA * remA
+    out = []
+    for b in range(1024):
+        k, rnd = b & 255, b >> 8
+        t = (rnd << 8) + ((255 - k) if (rnd & 1) else k)
+        if t < n1:
+            col, j, nsp = t // remB, t % remB, P
+        elif t < n1 + n2:
+            t -= n1
+            col, j, nsp = t // (P - remB), remB + t % (P - remB), P
+        elif t < n1 + n2 + n3:
+            t -= n1 + n2
+            col, j, nsp = nB + t // remA, t % remA, P + 1
+        else:
+            t -= n1 + n2 + n3
+            col, j, nsp = nB + t // (P + 1 - remA), remA + t % (P + 1 - remA), P + 1
+        base, rem = ngr // nsp, ngr % nsp
+        g_lo = j * base + min(j, rem)
+        out.append((col, j, nsp, g_lo, g_lo + base + (1 if j < rem else 0)))
+    return out
+
+
+def test_balanced_split_map_covers_every_group_once_and_balances_the_cus():
+    """every column's quad groups are covered exactly once by its P or P + 1 parts, and the four block ids that share a CU
+    (k, k + 256, k + 512, k + 768) carry almost equal work - the property the dealing order exists for"""
+    for ncol, ngr in [(224, 16), (416, 16), (208, 16), (320, 8), (192, 16), (832, 16), (325, 7), (513, 9), (1023, 4)]:
+        P = 1024 // ncol
+        nA = 1024 - ncol * P
+        if nA == 0:
+            continue
+        nB = ncol - nA
+        m = _lc_balanced_map(ncol, ngr, P, nB)
+        cover = {}
+        for col, j, nsp, lo, hi in m:
+            assert 0 <= col < ncol and 0 <= j < nsp and nsp == (P if col < nB else P + 1)
+            assert 0 <= lo <= hi <= ngr
+            cover.setdefault(col, []).append((lo, hi, j))
+        assert len(cover) == ncol
+        for col, parts in cover.items():
+            parts.sort()
+            assert len(parts) == (P if col < nB else P + 1) and sorted(p[2] for p in parts) == list(range(len(parts)))
+            assert parts[0][0] == 0 and parts[-1][1] == ngr
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(len(parts) - 1))
+        per_cu = [sum(m[k + 256 * r][4] - m[k + 256 * r][3] for r in range(4)) for k in range(256)]
+        sizes = sorted(hi - lo for _, _, _, lo, hi in m)
+        assert max(per_cu) - min(per_cu) <= 2 * (sizes[-1] - sizes[0]), (ncol, ngr, min(per_cu), max(per_cu))
