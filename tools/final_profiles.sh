@@ -9,5 +9,7 @@ cd $R && python tools/rocpd_stats.py $(ls /tmp/prof_f/*/*_results.db | head -1) 
 bash $R/tools/pmc_cycle.sh $TAG --hogwild 0 --no-async-update > /dev/null 2>&1
 cp $O/${TAG}_pmc_FETCH_SIZE.txt $O/${TAG}_pmc_fetch_size_$W.txt; cp $O/${TAG}_pmc_WRITE_SIZE.txt $O/${TAG}_pmc_write_size_$W.txt
 rm -f $O/${TAG}_pmc_*.db
+# (the timeline build: tools/build_variant.sh tl -DKGE_TIMELINE - hipcc, no GPU needed; built here when it is missing)
+[ -f $R/dgl-ke_amd/variants/libkge_tl.so ] || bash $R/tools/build_variant.sh tl -DKGE_TIMELINE > /dev/null 2>&1
 cd $R && KGE_LIB=$R/dgl-ke_amd/variants/libkge_tl.so timeout 100 python tools/timeline.py > $O/${TAG}_timeline.txt 2>&1; tail -8 $O/${TAG}_timeline.txt
 KGE_LIB=$R/dgl-ke_amd/variants/libkge_tl.so timeout 100 python tools/timeline.py --skew > $O/${TAG}_timeline_skew.txt 2>&1
