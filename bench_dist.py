@@ -212,7 +212,11 @@ def _a2a_setup(args, world, rank, dev, w, n_ent, d_e, emb_init, allow_force_coll
         def cap(n):
             gg[n] = torch.cuda.CUDAGraph()
             with _kge_lib.graph_capture(gg[n]):
-                for b in smp.sample(n):
+                dbs_ = smp.sample(n)
+                # (the routing of the group and the group's id exchange are part of the graph; nothing may be read back inside a
+                #  capture, so the bucket capacity is the one the eager run settled on and the overflow counter is the check)
+                de.prepare_group(dbs_, check_capacity=False)
+                for b in dbs_:
                     de.step(b)
         for n in {Gd, args.warmup % Gd, args.steps % Gd} - {0}:
             cap(n)

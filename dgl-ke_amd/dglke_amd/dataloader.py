@@ -176,6 +176,7 @@ class DeviceSampler(object):
         self.slots = th.zeros(self.n_slots * self.slot_bytes, dtype=th.uint8, device=self.dev)
         self.host_step = 1                                                     # next step to be sampled
         self._batches = {}                                                     # (slot, corrupt-head) -> DeviceBatch
+        self.launches = 0                                                      # sample() calls so far (a batch's `gen`)
 
     def sample(self, n=None, slot0=0):
         """enqueue the construction of the next `n` (default: all slots) batches into slots slot0..slot0+n-1;
@@ -199,7 +200,11 @@ class DeviceSampler(object):
             b = self._batches.get(key)
             if b is None:
                 b = self._batches[key] = DeviceBatch(self, key[0], key[1])
+            # the SAME object comes back whenever its slot is refilled: `gen` tells consumers that cache per-batch work keyed by the
+            # object (DistEngine's routing) which filling they are looking at
+            b.gen = self.launches + 1
             out.append(b)
+        self.launches += 1
         self.host_step += n
         return out
 

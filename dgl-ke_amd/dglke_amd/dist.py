@@ -310,9 +310,9 @@ class HipOps(object):
 
     def apply_merged_pair(self, job_a, job_b, lr):
         """two apply_merged jobs (tuples of its arguments without lr) in ONE launch: the entity-shard and the relation-replica apply"""
-        # (the two argument structs of a given buffer set are built once: the eager multi-GPU step is host-bound)
-        key = (job_a[0].data_ptr(), job_a[4].data_ptr() if job_a[4] is not None else 0, job_a[6].data_ptr(), job_a[2], job_a[3],
-               job_b[0].data_ptr(), job_b[6].data_ptr(), job_b[2], job_b[3])
+        # (the two argument structs of a given buffer set are built once: the eager multi-GPU step is host-bound.  The key names
+        #  everything the structs hold EXCEPT the id arrays, which change with every step of a group - they are set per call)
+        key = tuple((j[0].data_ptr(), j[1].data_ptr(), j[6].data_ptr(), j[2], j[3], int(j[5]), j[7]) for j in (job_a, job_b))
         if not hasattr(self, "_jobs"):
             self._jobs = {}
         st = self._jobs.get(key)
@@ -320,6 +320,9 @@ class HipOps(object):
             if len(self._jobs) > 64:
                 self._jobs.clear()
             st = self._jobs[key] = (self._job(*job_a), self._job(*job_b))
+        for j, args in zip(st, (job_a, job_b)):
+            if args[4] is not None:
+                j.id_words = args[4].data_ptr()
         _lib.check(_lib.lib().kge_adagrad_apply_merged_pair(C.byref(st[0]), C.byref(st[1]), float(lr), 1e-10, _lib.stream_ptr()))
 
     def reset_rel_pads(self, rel_msg, d_r, first):
@@ -431,6 +434,9 @@ class DistEngine(object):
         if hasattr(self.ops, "_jobs"):
             self.ops._jobs = {}
         self._cgraphs = {}            # compute graphs hold the old buffers' addresses
+        # whatever was routed ahead was routed for the OLD capacity (cache rows = owner * cap + position): drop it with the buffers
+        self._routed, self._route_lb, self._route_pool, self._route_key = {}, {}, None, None
+        self._gsend = self._graw = self._grecv = None
         self.slots = []
         for _ in range(2):
             s = _Slot()
@@ -478,11 +484,18 @@ class DistEngine(object):
             self._alloc(batches[0])
         return self.cap
 
-    def prepare_group(self, batches, log=None):
-        """everything a freshly sampled GROUP of batches needs before its steps: the bucket capacity (ensure_capacity) and - for
-        consecutive slots of a device sampler - the routing of ALL its batches in ONE launch (kge_route_build_group), so that a
-        step starts with the id exchange instead of a routing kernel (one launch per group instead of one per step)."""
-        self.ensure_capacity(batches, log)
+    def prepare_group(self, batches, log=None, check_capacity=True):
+        """everything a freshly sampled GROUP of batches needs before its steps: the bucket capacity (ensure_capacity), - for
+        consecutive slots of a device sampler - the routing of ALL its batches in ONE launch (kge_route_build_group) and, with
+        peers, ONE all-to-all of the whole group's request ids (round 5): the ids every owner will be asked for during the group
+        are known as soon as the group is sampled, so a step is left with two exchanges (rows, gradients) and its pull is one
+        collective deep instead of two dependent ones.
+        check_capacity=False (callers that record the group into a hipGraph, where nothing may be read back): the buckets keep
+        their size and the overflow counter of the routing kernel is the check (check_overflow())."""
+        if check_capacity:
+            self.ensure_capacity(batches, log)
+        elif self.slots is None:
+            self._setup(batches[0])
         self._routed = {}
         group = getattr(self.ops, "route_group", None)
         b0 = batches[0]
@@ -491,23 +504,50 @@ class DistEngine(object):
         if (group is None or smp is None or any(getattr(b, "sampler", None) is not smp for b in batches) or
                 slots != list(range(slots[0], slots[0] + len(slots)))):
             return                                   # host-built plans: routed one by one in the step
-        W = self.spec.world
-        off, stride = self.ops.route_layout(b0, W, self.cap)
+        W, cap, n = self.spec.world, self.cap, len(batches)
+        off, stride = self.ops.route_layout(b0, W, cap)
         need = smp.n_slots * stride
-        if self._route_pool is None or self._route_pool.numel() != need or self._route_key != (id(smp), self.cap):
+        if self._route_pool is None or self._route_pool.numel() != need or self._route_key != (id(smp), cap):
             if self.dev.type == "cuda":
                 torch.cuda.current_stream(self.dev).synchronize()
             self._route_pool = torch.zeros(need, dtype=torch.uint8, device=self.dev)
-            self._route_key = (id(smp), self.cap)
+            self._route_key = (id(smp), cap)
             self._route_lb = {}
             self._cgraphs = {}
-        group(batches, W, self.spec.shard, self.cap, self._route_pool, off, stride, self.overflow)
+            if self.coll:                            # the group's id exchange: [owner][slot][cap] out, [source][slot][cap] in, and the
+                z = lambda *sh: torch.full(sh, -1, dtype=torch.int64, device=self.dev)          # noqa: E731
+                self._gsend, self._graw = z(W * smp.n_slots * cap), z(W * smp.n_slots * cap)    # per-step view [slot][source][cap]
+                self._grecv = z(smp.n_slots, W * cap)
+        group(batches, W, self.spec.shard, cap, self._route_pool, off, stride, self.overflow)
+        if self.coll:
+            # every owner's share of the group's request ids in one piece: pool rows hold [owner][cap] per slot
+            pool64 = self._route_pool.view(torch.int64)
+            req = torch.as_strided(pool64, (n, W, cap), (stride // 8, cap, 1), (slots[0] * stride + off["req_ids"]) // 8)
+            send, raw = self._gsend[:W * n * cap], self._graw[:W * n * cap]
+            send.view(W, n, cap).copy_(req.permute(1, 0, 2))
+            self.comm.all_to_all(raw, send)
+            self._grecv[slots[0]:slots[0] + n].view(n, W, cap).copy_(raw.view(W, n, cap).permute(1, 0, 2))
         for b in batches:
             key = (b.slot, b.neg_head)
-            lb = self._route_lb.get(key)
-            if lb is None:
-                lb = self._route_lb[key] = self.ops.routed_batch(b, W, self.cap, self._route_pool, off, stride)
-            self._routed[id(b)] = lb
+            self._routed[id(b)] = (self._slot_lb(b, off, stride), getattr(b, "gen", None))
+
+    def _slot_lb(self, b, off, stride):
+        """the re-addressed batch of a sampler slot (pointer arithmetic into the route pool: built once per slot and corruption mode)"""
+        key = (b.slot, b.neg_head)
+        lb = self._route_lb.get(key)
+        if lb is None:
+            lb = self._route_lb[key] = self.ops.routed_batch(b, self.spec.world, self.cap, self._route_pool, off, stride)
+            lb.recv_ids = self._grecv[b.slot] if self.coll else lb.req_ids            # (filled by the group's id exchange)
+        return lb
+
+    def _routed_ahead(self, batch):
+        """the re-addressed batch prepare_group made for `batch` - unless the sampler has overwritten the slot since (a DeviceBatch
+        is one object per slot: its `gen` is the sampler launch that filled it), in which case the routing is stale and the
+        step routes for itself"""
+        hit = self._routed.get(id(batch))
+        if hit is not None and hit[1] == getattr(batch, "gen", None):
+            return hit[0]
+        return None
 
     def precapture(self, sampler):
         """record the compute graphs of EVERY (sampler slot, corruption mode, cache slot) combination - pointer arithmetic only,
@@ -529,9 +569,7 @@ class DistEngine(object):
                     b = sampler._batches.get(key)
                     if b is None:
                         b = sampler._batches[key] = DeviceBatch(sampler, slot, nh)
-                    lb = self._route_lb.get(key)
-                    if lb is None:
-                        lb = self._route_lb[key] = self.ops.routed_batch(b, W, self.cap, self._route_pool, off, stride)
+                    lb = self._slot_lb(b, off, stride)
                     for par in (0, 1):
                         g = torch.cuda.CUDAGraph()
                         with _lib.graph_capture(g):
@@ -561,12 +599,14 @@ class DistEngine(object):
         if (batch.B, batch.C * batch.N, batch.UE) != self.geom:
             raise _lib.KgeError("DistEngine: batch geometry changed (B, C*N, UE bound) %r -> %r" % (self.geom, (batch.B, batch.C * batch.N, batch.UE)))
         sp, s, W = self.spec, self.slots[slot], self.spec.world
-        lb = self._routed.get(id(batch)) or self.ops.route(batch, W, sp.shard, self.cap, s)     # (routed ahead by prepare_group, or now)
-        if self.coll:
-            self.comm.all_to_all(s.recv_ids, lb.req_ids)
-            lb.recv_ids = s.recv_ids
-        else:
-            lb.recv_ids = lb.req_ids
+        lb = self._routed_ahead(batch)               # routed by prepare_group - the owners already hold this step's request ids
+        if lb is None:
+            lb = self.ops.route(batch, W, sp.shard, self.cap, s)
+            if self.coll:
+                self.comm.all_to_all(s.recv_ids, lb.req_ids)
+                lb.recv_ids = s.recv_ids
+            else:
+                lb.recv_ids = lb.req_ids
         self.ops.gather_req(self.ent, lb.recv_ids, sp.lo, s.rows_out)
         if self.coll:
             self.comm.all_to_all(s.cache[:W * self.cap], s.rows_out)
@@ -619,13 +659,15 @@ class DistEngine(object):
     def _pull_ahead(self, next_batch, nslot, ev):
         """the pull of the NEXT step (route, id exchange, owner gather, row exchange) on the side stream"""
         sp, s, W = self.spec, self.slots[nslot], self.spec.world      # (the buffers exist: the first step's own pull made them)
-        nlb = self._routed.get(id(next_batch)) or self.ops.route(next_batch, W, sp.shard, self.cap, s)
+        nlb = self._routed_ahead(next_batch)
+        if nlb is None:
+            nlb = self.ops.route(next_batch, W, sp.shard, self.cap, s)
+            if self.coll:
+                self.comm.all_to_all(s.recv_ids, nlb.req_ids)
+                nlb.recv_ids = s.recv_ids
+            else:
+                nlb.recv_ids = nlb.req_ids
         nlb.slot = nslot
-        if self.coll:
-            self.comm.all_to_all(s.recv_ids, nlb.req_ids)
-            nlb.recv_ids = s.recv_ids
-        else:
-            nlb.recv_ids = nlb.req_ids
         self.ops.gather_req(self.ent, nlb.recv_ids, sp.lo, s.rows_out)
         ev["gather"].record(self._side)
         if self.coll:

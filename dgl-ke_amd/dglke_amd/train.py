@@ -73,7 +73,11 @@ class ArgParser(argparse.ArgumentParser):
         a('--gpu', type=int, default=[-1], nargs='+')
         a('--mix_cpu_gpu', action='store_true')
         a('--valid', action='store_true')
-        a('--rel_part', action='store_true')
+        a('--rel_part', action='store_true',
+          help='multi-GPU a2a mode: split the training triples BY RELATION over the trainers (whole relations, most frequent first, '
+               'to the trainer with the fewest edges); a relation row is updated only where its edges are - no relation exchange.  '
+               'Unlike the reference, one relation is never split over several trainers: a relation with more than 1 / trainers '
+               'of the edges unbalances the split (a warning says so)')
         a('--async_update', action='store_true')
         a('--has_edge_importance', action='store_true')
         # additions of this build
@@ -91,7 +95,9 @@ class ArgParser(argparse.ArgumentParser):
         a('--dist_mode', default='a2a', choices=['a2a', 'p2p'],
           help='multi-GPU training (--gpu g0 g1 ...): a2a = entity table range-sharded, relation table replicated, RCCL '
                'all-to-all pull / push with owner-side Adagrad (parameter-server semantics); p2p = both tables sharded and '
-               'mapped peer to peer (hipIpc), Hogwild across the trainers, no collective')
+               'mapped peer to peer (hipIpc), Hogwild across the trainers, no collective.  TransR and RESCAL (projection / '
+               'relation-matrix tables) train on one GPU or with p2p (TransR only): a2a hands TransR to p2p, and multi-GPU RESCAL is '
+               'not covered')
         a('--seed', type=int, default=0, help='seed of the table initialisation and of the device sampler')
         a('--graph_steps', type=int, default=100, help='steps per captured hipGraph (0: eager launches)')
         a('--target_mrr', type=float, default=None,
@@ -586,10 +592,20 @@ class A2ATrainer(ShardedTrainer):
         if self.rel_part:
             self.rel_owner, edge_rank = kd.relation_partition(tr[1], world)
             part = np.nonzero(edge_rank == rank)[0]
+            cnt = np.bincount(edge_rank, minlength=world)
             if rank == 0:
-                cnt = np.bincount(edge_rank, minlength=world)
                 print("relation partition: %d relations over %d trainers, edges per trainer %s" % (
                     int((self.rel_owner >= 0).sum()), world, cnt.tolist()))
+                if cnt.max() > 1.5 * cnt.mean():
+                    # whole relations only (no split relations, dist.relation_partition): a relation with more than 1 / world of the
+                    # edges unbalances the trainers; every trainer runs max_step steps, so the light trainers revisit their edges more
+                    # often than the reference's BalancedRelationPartition (which splits such a relation) would
+                    print("WARNING: --rel_part leaves trainer %d with %.2f x the mean edge share (relations are not split over "
+                          "trainers here; the most frequent relation holds %.1f %% of the edges)"
+                          % (int(cnt.argmax()), cnt.max() / cnt.mean(), 100.0 * np.bincount(np.asarray(tr[1])).max() / len(tr[1])))
+            if cnt.min() < B:            # the partition is the same on every rank: every rank sees the short one and stops HERE, before
+                raise KgeError("--rel_part: trainer %d gets %d training triples, fewer than --batch_size %d (%d relations over %d "
+                               "trainers)" % (int(cnt.argmin()), int(cnt.min()), B, int((self.rel_owner >= 0).sum()), world))   # any collective
         else:
             part = np.array_split(np.random.RandomState(args.seed).permutation(len(tr[0])), world)[rank]
         if len(part) < B:

@@ -72,9 +72,38 @@ def main():
         state = torch.zeros(spec.n_local, device=dev)
         de = kd.DistEngine(eng, spec, ent, state, comm=comm or kd.HostStagedComm(), cap=None, slack=1.6,
                            rel_local=(mode == "relpart"))
-        bts = batches(world, STEPS, mode if mode in ("disjoint", "relpart") else "random")
+        if mode.startswith("sampled"):
+            # device-sampled batches, the trainer's order (sample a group, prepare_group = capacity + routing of the whole group +
+            # ONE id exchange for the group, then its steps): two groups of two steps over the same two sampler slots, so the
+            # second group runs on REFILLED slots.  The ids the kernel drew are read back for the test's fp64 statement.
+            from dglke_amd.dataloader import DeviceSampler
+            G = 2
+            rk = np.random.RandomState(100 + rank)
+            n_train = 3 * STEPS * B
+            smp = DeviceSampler(rk.randint(0, N_ENT, n_train), rk.randint(0, N_REL, n_train), rk.randint(0, N_ENT, n_train),
+                                N_ENT, B, N, dev, n_slots=G, seed=7 + rank)
+            drawn = []
+            for _ in range(STEPS // G):
+                dbs = smp.sample(G)
+                de.prepare_group(dbs)
+                torch.cuda.synchronize()
+                for b in dbs:
+                    a = smp.slot_arrays(b.slot)
+                    drawn.append(dict(h=a["h_gid"], t=a["t_gid"], r=a["rel_ids"], neg=a["neg_ids"], neg_head=np.int64(b.neg_head)))
+                for k, b in enumerate(dbs):
+                    if mode == "sampled_pipelined":
+                        de.step_pipelined(b, dbs[k + 1] if k + 1 < G else None)
+                    else:
+                        de.step(b)
+            everybody = [None] * world
+            dist.all_gather_object(everybody, drawn)
+            bts, devb = [], []
+            if rank == 0:
+                res.setdefault("_drawn", {})[model] = everybody
+        else:
+            bts = batches(world, STEPS, mode if mode in ("disjoint", "relpart") else "random")
+            devb = []
         ue_bound = 2 * B + (B // N) * N
-        devb = []
         for row in bts:
             bt = row[rank]
             b = plan.make_batch(bt["h"], bt["t"], bt["r"], bt["neg"], N, N, bt["neg_head"], dev)
@@ -105,8 +134,14 @@ def main():
                 res[model].update(ref_ent=ref.ent.cpu().numpy(), ref_state=ref.ent_state.cpu().numpy(),
                                   ref_rel=ref.rel.cpu().numpy(), ref_rel_state=ref.rel_state.cpu().numpy())
         dist.barrier()
+    drawn_all = res.pop("_drawn", {})
+    extra = {}
+    for m, everybody in drawn_all.items():          # [rank][step] -> arrays [step, rank, ...]
+        for key in ("h", "t", "r", "neg", "neg_head"):
+            extra["%s_drawn_%s" % (m, key)] = np.stack([np.stack([everybody[k][s_][key] for k in range(world)])
+                                                        for s_ in range(len(everybody[0]))])
     if rank == 0:
-        np.savez(os.path.join(out_dir, "result.npz"), **{m + "_" + k: v for m, d in res.items() for k, v in d.items()
+        np.savez(os.path.join(out_dir, "result.npz"), **extra, **{m + "_" + k: v for m, d in res.items() for k, v in d.items()
                                                          if not isinstance(v, list)},
                  **{m + "_rel%d" % i: r for m, d in res.items() for i, r in enumerate(d["rels"])},
                  **{m + "_relstate%d" % i: r for m, d in res.items() for i, r in enumerate(d["rel_states"])})

@@ -66,6 +66,29 @@ class OracleOps(object):
         lb.req_ids = bf.req_ids
         return lb
 
+    # ---- the group path (device-sampled batches: prepare_group routes the whole group and exchanges its request ids once) ----
+    @staticmethod
+    def route_layout(batch, world, cap):
+        return {"req_ids": 0}, 8 * world * cap + 32          # one pool row per sampler slot: [owner][cap] ids (+ padding)
+
+    def route_group(self, batches, world, per, cap, pool, off, stride, overflow):
+        self._slot = getattr(self, "_slot", {})
+        pool64 = pool.view(torch.int64)
+        for b in batches:
+            class _Bf(object):
+                req_ids = pool64[b.slot * stride // 8:b.slot * stride // 8 + world * cap]
+            self._slot[b.slot] = self.route(b, world, per, cap, _Bf)
+
+    def routed_batch(self, b, world, cap, pool, off, stride):
+        ops, slot = self, b.slot
+
+        class _SlotLb(object):                              # built ONCE per slot (like HipOps.routed_batch): reads the slot's current routing
+            def __getattr__(self, name):
+                return getattr(ops._slot[slot], name)
+        lb = _SlotLb()
+        lb.req_ids = pool.view(torch.int64)[slot * stride // 8:slot * stride // 8 + world * cap]
+        return lb
+
     def route_fill(self, batches, world, per, out):
         for b in batches:
             owner = np.minimum(b.p["ue_id"] // per, world - 1)
@@ -137,7 +160,19 @@ def _batches(world, steps, heavy=False, relpart=False):
     return out
 
 
-def _worker(rank, world, port, ret, cap=CAP, heavy=False, group=1, relpart=False):
+class _FakeSampler(object):
+    """what DistEngine.prepare_group reads of a DeviceSampler: consecutive slots of one sampler, refilled group after group"""
+    def __init__(self, n_slots):
+        self.n_slots, self.slot_bytes, self.launches = n_slots, 0, 0
+
+    def fill(self, batches):
+        self.launches += 1
+        for k, b in enumerate(batches):
+            b.sampler, b.slot, b.gen = self, k, self.launches
+        return batches
+
+
+def _worker(rank, world, port, ret, cap=CAP, heavy=False, group=1, relpart=False, slots=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "dgl-ke_amd"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -164,13 +199,32 @@ def _worker(rank, world, port, ret, cap=CAP, heavy=False, group=1, relpart=False
             b.UE = UE_BOUND                       # the engine's buffers are sized once, for the bound
             mine.append(b)
         logs = []
+        smp = _FakeSampler(group) if slots else None
+        calls = {"a2a": 0}
+        if slots:                                 # count the all-to-alls: ids once per GROUP, then rows + gradients per step
+            a2a0 = de.comm.all_to_all
+
+            def counted(out, inp):
+                calls["a2a"] += 1
+                a2a0(out, inp)
+            de.comm.all_to_all = counted
         for g0 in range(0, len(mine), group):
             grp = mine[g0:g0 + group]
-            if heavy:                             # the trainer's order: size the buckets for the group, then run it
+            if slots:                             # the trainer's order with a device sampler: sample, prepare the group, run it
+                de.prepare_group(smp.fill(grp), log=logs.append)
+            elif heavy:                           # the trainer's order: size the buckets for the group, then run it
                 de.ensure_capacity(grp, log=logs.append)
-            for b in grp:
+            for i, b in enumerate(grp):
                 de.step(b)                        # (OracleOps.route asserts that every entry fits its bucket)
                 assert de.check_overflow() == 0
+        if slots and rank == 0:
+            ret["a2a_calls"], ret["groups"], ret["steps"] = calls["a2a"], (len(mine) + group - 1) // group, len(mine)
+        if slots == "stale" :                     # a refilled slot without prepare_group must be routed afresh, not reuse
+            b = smp.fill([mine[0]])[0]            # the pool rows of the batch that had the slot before
+            n0 = calls["a2a"]
+            de.step(b)
+            if rank == 0:
+                ret["stale_a2a"] = calls["a2a"] - n0
         if rank == 0:
             ret["cap"], ret["grown"], ret["logs"] = de.cap, list(getattr(de, "grown", [])), logs
         if relpart:          # no relation exchange happened: collect the owners' rows on rank 0 (what A2ATrainer.sync_tables does)
@@ -187,7 +241,7 @@ def _worker(rank, world, port, ret, cap=CAP, heavy=False, group=1, relpart=False
         dist.destroy_process_group()
 
 
-def _expected(world, heavy=False, relpart=False):
+def _expected(world, heavy=False, relpart=False, repeat_first=False):
     """single-process statement of the synchronous sharded step: every rank's gradients are
     computed from the SAME pre-step tables, then applied owner-side in rank order (trace 0 then
     trace 1 per rank; relations in rank order)."""
@@ -197,7 +251,8 @@ def _expected(world, heavy=False, relpart=False):
     ent = rng.uniform(-1, 1, (N_ENT, HID))
     rel = rng.uniform(-1, 1, (N_REL, HID))
     es, rs = np.zeros(N_ENT), np.zeros(N_REL)
-    for step_batches in _batches(world, 3 if not heavy else 4, heavy, relpart):
+    steps = _batches(world, 3 if not heavy else 4, heavy, relpart)
+    for step_batches in steps + (steps[:1] if repeat_first else []):
         outs = [O.forward_backward(cfg, ent, rel, bt["nid"], bt["h_local"], bt["t_local"], bt["r"],
                                    bt["neg"], bt["neg_head"], CHUNK, N) for bt in step_batches]
         for bt, out in zip(step_batches, outs):
@@ -231,6 +286,43 @@ def test_sharded_step_world2_matches_single_process_statement():
     for r_, s_ in zip(ret["rels"], ret["rel_states"]):
         np.testing.assert_allclose(r_, rel, rtol=1e-9, atol=1e-11)     # replicas identical
         np.testing.assert_allclose(s_, rs, rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.timeout(180)
+def test_group_id_exchange_world2_one_id_all_to_all_per_group():
+    """batches are sampled and routed a whole GROUP ahead, so the request ids of all its steps are exchanged
+    ONCE when the group is prepared; a step is left with two all-to-alls (rows, gradients) and the tables equal the
+    single-process statement.  ADVICE r04 (medium): a slot the sampler refilled WITHOUT prepare_group is routed afresh by the
+    step (three all-to-alls: its own id exchange) instead of reusing the previous filling's routing."""
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, ret, CAP, False, 2, False, "stale"), nprocs=world, join=True)
+    assert ret["a2a_calls"] == ret["groups"] + 2 * ret["steps"], dict(ret)
+    assert ret["stale_a2a"] == 3
+    ent, es, rel, rs = _expected(world, repeat_first=True)
+    np.testing.assert_allclose(ret["ent"], ent, rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(ret["state"], es, rtol=1e-9, atol=1e-12)
+    for r_, s_ in zip(ret["rels"], ret["rel_states"]):
+        np.testing.assert_allclose(r_, rel, rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(s_, rs, rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.timeout(300)
+def test_group_id_exchange_world8_heavy_tailed_growing_buckets():
+    """the same group path at world 8 on heavy-tailed ids with a deliberately small initial capacity: the buckets grow between
+    groups (the route pool and the id-exchange buffers are rebuilt for the new capacity), nothing is dropped"""
+    world = 8
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, ret, 4, True, 2, False, True), nprocs=world, join=True)
+    assert ret["grown"] and ret["cap"] > 4
+    assert ret["a2a_calls"] == ret["groups"] + 2 * ret["steps"], dict(ret)
+    ent, es, rel, rs = _expected(world, heavy=True)
+    np.testing.assert_allclose(ret["ent"], ent, rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(ret["state"], es, rtol=1e-9, atol=1e-12)
 
 
 @pytest.mark.timeout(300)

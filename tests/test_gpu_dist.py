@@ -264,7 +264,7 @@ def test_apply_merged_equals_sequential_apply(nsrc, cap, dim, n_rows):
 
 
 def _run_workers(tmp_path, mode, world=2, transport="host"):
-    port = str(29700 + os.getpid() % 250 + {"random": 0, "disjoint": 1, "pipelined": 2, "nd": 6, "relpart": 7}[mode] + (3 if transport == "rccl" else 0))
+    port = str(29700 + os.getpid() % 250 + {"random": 0, "disjoint": 1, "pipelined": 2, "nd": 6, "relpart": 7, "sampled": 8, "sampled_pipelined": 9}[mode] + (3 if transport == "rccl" else 0))
     env = dict(os.environ)
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), str(r), str(world), port, str(tmp_path), mode,
                                transport], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
@@ -290,10 +290,22 @@ def _oracle_statement(model, de_, dr_, z, world, mode):
                    neg_deg=(mode == "nd"))
     ent, rel = z[model + "_init_ent"].astype(np.float64), z[model + "_init_rel"].astype(np.float64)
     es, rs = np.zeros(W.N_ENT), np.zeros(W.N_REL)
-    bts = W.batches(world, W.STEPS, "relpart" if mode == "relpart" else "random")
+    if mode.startswith("sampled"):         # the ids the device sampler drew (read back by the workers), groups of two steps
+        d = {k: z["%s_drawn_%s" % (model, k)] for k in ("h", "t", "r", "neg", "neg_head")}
+        bts = []
+        for s in range(d["h"].shape[0]):
+            row = []
+            for k in range(world):
+                nid, inv = np.unique(np.concatenate([d["h"][s, k], d["t"][s, k]]), return_inverse=True)
+                row.append(dict(nid=nid, h_local=inv[:W.B], t_local=inv[W.B:], r=d["r"][s, k], neg=d["neg"][s, k],
+                                neg_head=bool(d["neg_head"][s, k])))
+            bts.append(row)
+    else:
+        bts = W.batches(world, W.STEPS, "relpart" if mode == "relpart" else "random")
     pulled = ent.copy()                    # what the pull of the current step saw
     for s, row in enumerate(bts):
-        src = pulled if mode == "pipelined" else ent
+        # (sampled_pipelined: the first step of every group of two pulls for itself, behind its predecessor's update)
+        src = pulled if mode == "pipelined" or (mode == "sampled_pipelined" and s % 2 == 1) else ent
         outs = [O.forward_backward(cfg, src, rel, bt["nid"], bt["h_local"], bt["t_local"], bt["r"], bt["neg"], bt["neg_head"],
                                    W.N, W.N) for bt in row]
         pulled = ent.copy()                # the pull of step s+1 runs now: after update s-1, before update s
@@ -306,7 +318,8 @@ def _oracle_statement(model, de_, dr_, z, world, mode):
 
 
 @pytest.mark.parametrize("mode,transport", [("random", "host"), ("pipelined", "host"), ("nd", "host"), ("relpart", "host"),
-                                            ("random", "rccl"), ("pipelined", "rccl"), ("relpart", "rccl")])
+                                            ("sampled", "host"), ("sampled_pipelined", "host"),
+                                            ("random", "rccl"), ("pipelined", "rccl"), ("relpart", "rccl"), ("sampled", "rccl")])
 def test_world2_hip_ops_match_the_oracle_statement(tmp_path, mode, transport):
     """`host`: two processes on ONE device, messages staged through gloo.  `rccl`: two processes on TWO devices, the product's
     transport - dist.RcclComm (ncclAllToAll / ncclAllGather on the step's streams, grouped push, side-stream pull) - against
@@ -334,7 +347,7 @@ def test_world2_hip_ops_match_the_oracle_statement(tmp_path, mode, transport):
         assert np.array_equal(z[model + "_relstate0"], z[model + "_relstate1"])
 
 
-@pytest.mark.parametrize("mode", ["pipelined", "relpart"])
+@pytest.mark.parametrize("mode", ["pipelined", "relpart", "sampled", "sampled_pipelined"])
 def test_world4_on_one_device_matches_the_oracle_statement(tmp_path, mode):
     """four ranks (four processes sharing this GPU, messages through gloo): owner buckets for four shards, the merged apply with
     four sources and rows that arrive from several ranks at once, the one-step-stale pipeline / relation partitioning at a

@@ -212,14 +212,56 @@ SHAPES = [
     ("ComplEx", 50000, 535, 200, True, True, 1024, 256, 256, 143.0, 0.1, True, 2e-6),        # cfg-C shape
     ("RotatE", 20000, 300, 200, True, False, 512, 128, 128, 12.0, 0.01, True, 1e-7),
     ("TransE_l1", 14951, 1345, 400, False, False, 400, 200, 200, 16.0, 0.01, True, 1e-7),
-    # the FB15k recipe's full shape of RotatE: the shared-pair backward runs its balanced split here (1024 workgroups).  (TransE_l1
-    # at B = 1000 is not in this list: sign(a - b) of a difference that fp32 and fp64 round to opposite sides of zero moves one
-    # gradient element in ~750 000 by 2 w_ij - 1 element at 9.9e-7 against a 1e-9-scale tolerance; the B = 400 case above stays)
+    # TransE_l1 at the full cfg shape: sign(a - b) of a difference that fp32 and fp64 round to opposite sides of zero moves one
+    # gradient element in ~750 000 by 2 w_ij (9.9e-7 against a 1e-9-scale tolerance).  Those elements are found from the fp64
+    # operands (_l1_ambiguous) and the gradient / table rows they feed are excluded - a handful of 3 000 rows, asserted
+    ("TransE_l1", 14951, 1345, 400, False, False, 1000, 200, 200, 16.0, 0.01, True, 1e-7),
+    # the FB15k recipe's full shape of RotatE: the shared-pair backward runs its balanced split here (1024 workgroups)
     ("RotatE", 14951, 1345, 200, True, False, 1024, 256, 256, 12.0, 0.009, True, 1e-7),
     ("TransE_l2", 300, 10, 36, False, False, 120, 24, 40, 10.0, 0.1, False, 0.0),             # chunk != N, dups
     ("DistMult", 5000, 50, 64, False, False, 128, 288, 64, 143.0, 0.08, True, 1e-6),          # N > 256: stand-alone loss kernel
     ("TransE_l2", 5000, 50, 64, False, False, 96, 250, 48, 12.0, 0.1, True, 1e-6),            # ragged last column tile, fused loss
 ]
+
+
+def _l1_ambiguous(bt, ent64, rel64, chunk, N, tau=4e-9):
+    """TransE_l1's gradient is sign(a_id - b_jd): where |a_id - b_jd| < tau in fp64 the fp32 pos-side vector fl(x +- r) (half an
+    ulp of its ~0.09 magnitude = 3.7e-9; the subtraction of two nearly equal floats is exact) may sit on the other side of b and
+    the element moves by 2 w_ij.  Returns the gradient rows such elements feed - negative slots, positive
+    entities (indices into bt['nid']), edges - and the table rows (entity ids, relation ids) whose Adagrad step they enter (the
+    row mean of g^2 scales the WHOLE row's step, so the row is excluded, not the column)."""
+    h, t, r, neg = ent64[bt["h"]], ent64[bt["t"]], rel64[bt["r"]], bt["neg"]
+    a = (t - r) if bt["neg_head"] else (h + r)                      # pos-side vector of edge i
+    B = a.shape[0]
+    slots, edges = set(), set()
+    for i in range(B):                                              # positive score |h + r - t|
+        if (np.abs(h[i] + r[i] - t[i]) < tau).any():
+            edges.add(i)
+    both = set(edges)                                               # (a positive-score flip reaches head AND tail)
+    for c in range(B // chunk):
+        bn = ent64[neg[c * N:(c + 1) * N]]                          # [N, D]
+        d = np.abs(a[c * chunk:(c + 1) * chunk, None, :] - bn[None, :, :]) < tau
+        ii, jj = np.nonzero(d.any(axis=2))
+        edges.update((c * chunk + ii).tolist())
+        slots.update((c * N + jj).tolist())
+    ent_ids, rel_ids, pos_local = set(), set(), set()
+    for i in edges:
+        side = bt["t"][i] if bt["neg_head"] else bt["h"][i]
+        ents = [side] + ([bt["h"][i], bt["t"][i]] if i in both else [])
+        ent_ids.update(int(x) for x in ents)
+        rel_ids.add(int(bt["r"][i]))
+    for j in slots:
+        ent_ids.add(int(neg[j]))
+    pos_local = set(np.searchsorted(bt["nid"], [e for e in ent_ids if e in set(bt["nid"].tolist())]).tolist())
+    return dict(slots=sorted(slots), edges=sorted(edges), pos_local=sorted(pos_local), ent=sorted(ent_ids), rel=sorted(rel_ids))
+
+
+def _masked(got, want, rows):
+    """`got` with the listed rows replaced by the oracle's (rows excluded from a comparison)"""
+    got = np.array(got, dtype=np.float64, copy=True)
+    if len(rows):
+        got[rows] = np.asarray(want, dtype=np.float64)[rows]
+    return got
 
 
 @pytest.mark.parametrize("flags", [0, 8, 128, 512 + 256], ids=["loss_kernel", "fused_loss", "split_fwd", "direct_tiles_dense_bwd"])
@@ -246,6 +288,10 @@ def test_fused_step_matches_oracle_at_config_shapes(shape, flags):
         want = eng.alloc_outputs(b)
         eng.step(b, want)
         torch.cuda.synchronize()
+        amb = dict(slots=[], edges=[], pos_local=[], ent=[], rel=[])
+        if model == "TransE_l1":           # rows fed by a sign(a - b) whose operands differ by less than fp32 resolves: excluded
+            amb = _l1_ambiguous(bt, ent64, rel64, chunk, N)
+            assert len(amb["ent"]) <= 30 and len(amb["rel"]) <= 15, "too many sign-ambiguous rows to call this a comparison: %r" % amb
         out = O.train_step(cfg, ent64, es64, rel64, rs64, bt["nid"], bt["h_local"], bt["t_local"],
                            bt["r"], bt["neg"], bt["neg_head"], chunk, N)
         tag = "%s step %d" % (model, step)
@@ -255,13 +301,15 @@ def test_fused_step_matches_oracle_at_config_shapes(shape, flags):
         _close(l4[:3], out["log"][:3], 1e-4, 1e-5, tag + " loss")
         _close(l4[3], out["log"][3], 1e-3, 1e-7, tag + " reg")
         sel = np.searchsorted(b.p["ue_id"], bt["nid"])
-        _close(want["g_pos_ent"].cpu().numpy()[sel], out["g_pos_ent"], 3e-4, grad_tol(out["g_pos_ent"]), tag + " g_pos_ent")
-        _close(want["g_neg"].cpu(), out["g_neg"], 3e-4, grad_tol(out["g_neg"]), tag + " g_neg")
-        _close(want["g_rel"].cpu(), out["g_rel"], 3e-4, grad_tol(out["g_rel"]), tag + " g_rel")
-        _close(eng.ent_state.cpu(), es64, 2e-3, 1e-9, tag + " ent state")
-        _close(eng.rel_state.cpu(), rs64, 2e-3, 1e-9, tag + " rel state")
-        _close(eng.ent.cpu(), ent64, 1e-4, 1e-3 * lr, tag + " entity rows")       # (fp64 oracle from the SAME fp32 tables: the
-        _close(eng.rel.cpu(), rel64, 1e-4, 1e-3 * lr, tag + " relation rows")     #  per-step error, profiles/r03_row_error_trajectory.txt)
+        _close(_masked(want["g_pos_ent"].cpu().numpy()[sel], out["g_pos_ent"], amb["pos_local"]), out["g_pos_ent"], 3e-4,
+               grad_tol(out["g_pos_ent"]), tag + " g_pos_ent")
+        _close(_masked(want["g_neg"].cpu(), out["g_neg"], amb["slots"]), out["g_neg"], 3e-4, grad_tol(out["g_neg"]), tag + " g_neg")
+        _close(_masked(want["g_rel"].cpu(), out["g_rel"], amb["edges"]), out["g_rel"], 3e-4, grad_tol(out["g_rel"]), tag + " g_rel")
+        _close(_masked(eng.ent_state.cpu(), es64, amb["ent"]), es64, 2e-3, 1e-9, tag + " ent state")
+        _close(_masked(eng.rel_state.cpu(), rs64, amb["rel"]), rs64, 2e-3, 1e-9, tag + " rel state")
+        _close(_masked(eng.ent.cpu(), ent64, amb["ent"]), ent64, 1e-4, 1e-3 * lr, tag + " entity rows")   # (fp64 oracle from the SAME
+        _close(_masked(eng.rel.cpu(), rel64, amb["rel"]), rel64, 1e-4, 1e-3 * lr, tag + " relation rows")  #  fp32 tables: the per-step
+        #                                                                                error, profiles/r03_row_error_trajectory.txt)
 
 
 # RotatE shapes that put the shared-pair backward's balanced split (kge_neg_bcast.hip, NegArgs::lc_P) through its cases: columns
@@ -1037,8 +1085,8 @@ def test_fused_step_matches_oracle_at_real_table_sizes(shape):
         _close(want["g_rel"].cpu(), out["g_rel"], 3e-4, grad_tol(out["g_rel"]), tag + " g_rel")
         _close(eng.ent_state[tix].cpu(), es_sub, 2e-3, 1e-9, tag + " ent state")
         _close(eng.rel_state.cpu(), rs64, 2e-3, 1e-9, tag + " rel state")
-        _close(eng.ent[tix].cpu(), ent_sub, 1e-4, 5e-3 * lr, tag + " entity rows")
-        _close(eng.rel.cpu(), rel64, 1e-4, 5e-3 * lr, tag + " relation rows")
+        _close(eng.ent[tix].cpu(), ent_sub, 1e-4, 1e-3 * lr, tag + " entity rows")      # (the bound of the config-shape test above)
+        _close(eng.rel.cpu(), rel64, 1e-4, 1e-3 * lr, tag + " relation rows")
         # every row the step did not name is bit-identical
         keep = torch.ones(n_ent, dtype=torch.bool, device=DEV)
         keep[tix] = False
