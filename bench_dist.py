@@ -156,6 +156,7 @@ def _a2a_setup(args, world, rank, dev, w, n_ent, d_e, emb_init, allow_force_coll
         R = torch.clamp((R // world) * world + rank, max=(w["n_rel"] - 1 - rank) // world * world + rank)
     G = max(2, min(120, args.graph_steps) // 2 * 2)
     smp = DeviceSampler(H, R, T, n_ent, w["B"], w["N"], dev, n_slots=G, seed=rank + 1)
+    de.bench_sampler = smp
     pipelined = (world > 1 or force_coll) and os.environ.get("KGE_DIST_PIPELINE", "1") != "0"
 
     def steps(dbs):
@@ -171,7 +172,13 @@ def _a2a_setup(args, world, rank, dev, w, n_ent, d_e, emb_init, allow_force_coll
     de.prepare_group(dbs)               # bucket capacity + the routing of the whole group in one launch (allocates the route pool)
     steps(dbs[:4])                      # eager warm-up: allocates every persistent buffer
     n_cg = 0
-    if de.coll:                         # eager step (collectives): its kernels between pull and push replay from small hipGraphs
+    # with collectives (N > 1, or forced at world 1): every group = [sampler launch, capacity check (the group's one device read)]
+    # eagerly, then [routing of the group + ONE id exchange + its steps with their collectives] replayed from one hipGraph
+    # (DistEngine.run_group; round 5 - captured RCCL collectives replay fine, see dist.RcclComm.close).  KGE_DIST_GRAPH=0 / a
+    # communicator that cannot be recorded: the same calls launched one by one (host-bound)
+    graph_coll = (de.coll and not args.no_graph and os.environ.get("KGE_DIST_GRAPH", "1") != "0" and
+                  getattr(de.comm, "capturable", False))
+    if de.coll and not graph_coll:      # eager step (collectives): its kernels between pull and push may replay from small hipGraphs
         torch.cuda.synchronize()
         n_cg = de.precapture(smp)
     torch.cuda.synchronize()
@@ -180,13 +187,17 @@ def _a2a_setup(args, world, rank, dev, w, n_ent, d_e, emb_init, allow_force_coll
 
     def group_(n):                      # one sampler launch, the group's buckets checked and ALL its batches routed in one launch,
         dbs_ = smp.sample(n)            # then the steps (world 1: no device read in prepare_group, so the whole thing is capturable)
-        de.prepare_group(dbs_)
-        steps(dbs_)
+        if de.coll:
+            de.run_group(dbs_, graph=graph_coll, pipelined=pipelined)
+        else:
+            de.prepare_group(dbs_)
+            steps(dbs_)
+
+    def sizes(count):
+        return [G] * (count // G) + ([count % G] if count % G else [])
 
     def run(count):                     # EXACTLY count steps: groups of G, then one partial group (one sampler launch each)
-        left = count
-        while left > 0:
-            n = min(G, left)
+        for n in sizes(count):
             if use_graph:
                 if n not in graphs:
                     graphs[n] = torch.cuda.CUDAGraph()
@@ -195,54 +206,32 @@ def _a2a_setup(args, world, rank, dev, w, n_ent, d_e, emb_init, allow_force_coll
                 graphs[n].replay()
             else:
                 group_(n)
-            left -= n
     if use_graph:                       # capture outside the timed region
-        for n in {G, args.warmup % G, args.steps % G} - {0}:
+        for n in set(sizes(args.warmup) + sizes(args.steps)):
             graphs[n] = torch.cuda.CUDAGraph()
             with _kge_lib.graph_capture(graphs[n]):
                 group_(n)
         torch.cuda.synchronize()
-    def graph_runner():
-        """the same step with the RCCL collectives RECORDED into hipGraphs (synchronous schedule, groups of <= 20 steps, the host
-        synchronises after every replay: a long chain of unsynchronised replays of captured collectives hangs on this stack,
-        tools/dbg/rccl_capture_probe2.py).  Returns run(count)."""
-        Gd = max(2, min(20, G) // 2 * 2)
-        gg = {}
-
-        def cap(n):
-            gg[n] = torch.cuda.CUDAGraph()
-            with _kge_lib.graph_capture(gg[n]):
-                dbs_ = smp.sample(n)
-                # (the routing of the group and the group's id exchange are part of the graph; nothing may be read back inside a
-                #  capture, so the bucket capacity is the one the eager run settled on and the overflow counter is the check)
-                de.prepare_group(dbs_, check_capacity=False)
-                for b in dbs_:
-                    de.step(b)
-        for n in {Gd, args.warmup % Gd, args.steps % Gd} - {0}:
-            cap(n)
+    elif graph_coll:                    # the first group of every size runs eagerly and is recorded behind it: outside the timed region
+        for n in sorted(set(sizes(args.warmup) + sizes(args.steps))):
+            group_(n)
         torch.cuda.synchronize()
-
-        def run_g(count):
-            left = count
-            while left > 0:
-                n = min(Gd, left)
-                gg[n].replay()
-                torch.cuda.current_stream().synchronize()
-                left -= n
-        return run_g, Gd
     C = w["B"] // w["N"]
     a_ = smp.slot_arrays(0)
     u_pos = int(np.unique(np.concatenate([a_["h_gid"], a_["t_gid"]])).shape[0])
     ue = int(np.unique(np.concatenate([a_["h_gid"], a_["t_gid"], a_["neg_ids"]])).shape[0])
-    rows = dict(UE=ue, R_e=u_pos + C * w["N"], B=w["B"], cap=de.cap, graph_runner=None if use_graph else graph_runner,
-                rel_part=rel_part)
+    rows = dict(UE=ue, R_e=u_pos + C * w["N"], B=w["B"], cap=de.cap, rel_part=rel_part,
+                launch="graph" if (use_graph or graph_coll) else "eager")
     rel_desc = ("triples partitioned by relation (--rel_part of the reference's recipe): relation rows updated on their owner rank, "
                 "no relation exchange" if rel_part else "relation gradients all-gathered")
     comm_desc = ((": librccl called directly" + ("" if rel_part else ", push + relation exchange grouped"))
                  if type(de.comm).__name__ == "RcclComm" else ": torch.distributed wrappers") if de.coll else ""
+    pipe_desc = "pull of step s+1 overlapped with step s (one-step-stale rows, --async_update licence)"
     launch_desc = ("hipGraph of [1 sampler launch + %d steps]" % G if use_graph else
-                   (("eager launches, pull of step s+1 overlapped with step s (one-step-stale rows, --async_update licence)"
-                     if pipelined else "eager launches") +
+                   ("per group of <= %d steps: sampler launch + bucket-capacity check (one device read), then ONE hipGraph of [routing of "
+                    "the group, one id all-to-all for the group, the steps with their RCCL collectives]%s" % (G, ("; " + pipe_desc + ", as a "
+                    "fork inside the graph") if pipelined else "; synchronous schedule")) if graph_coll else
+                   (("eager launches, " + pipe_desc if pipelined else "eager launches") +
                     (", the step's kernels between pull and push replayed from %d small hipGraphs" % n_cg if n_cg else "")))
     desc = ("entity table range-sharded, relation table replicated; per step: device-side routing into %d-row owner buckets, "
             "all-to-all pull of the unique rows, the single-GPU kernels against the row cache, all-to-all push of one packed "
@@ -275,7 +264,9 @@ def _deliver(line):
 # what the orchestrator tries, in order, until one attempt delivers a line on every rank: the north_star mode
 # on the direct librccl communicator, the same on the c10d wrappers, the peer-to-peer shared tables, and - so that a node whose
 # links do not come up still yields a measured line that says so - N independent replicas of the per-GPU step without any exchange
-ATTEMPTS = (("a2a", "rccl"), ("a2a", "rccl-sync"), ("a2a", "torch"), ("p2p", ""), ("replicas", ""))
+ATTEMPTS = (("a2a", "rccl-graph"), ("a2a", "rccl"), ("a2a", "rccl-sync"), ("a2a", "torch"), ("p2p", ""), ("replicas", ""))
+# ("rccl-graph", round 5: kernels AND collectives of a group of steps replay from one hipGraph - DistEngine.run_group; "rccl": the
+#  same calls as eager launches, the pull of step s+1 on a side stream)
 # ("rccl-sync": the same direct communicator with the synchronous schedule - no pull on a side stream, one stream issues every
 #  collective: if two streams sharing one communicator are what hangs, this attempt still measures the north_star mode)
 # seconds allowed until the named progress mark appears (a hang shows up as a mark that does not come;
@@ -307,7 +298,7 @@ def orchestrate(args, world, rank, local_rank):
     first = os.environ.get("KGE_DIST_MODE", "a2a")
     attempts = [a for a in ATTEMPTS if a[0] == first] + [a for a in ATTEMPTS if a[0] != first]
     if os.environ.get("KGE_DIST_COMM") == "torch":
-        attempts = [a for a in attempts if a[1] not in ("rccl", "rccl-sync")]
+        attempts = [a for a in attempts if a[1] not in ("rccl-graph", "rccl", "rccl-sync")]
     history, line = [], None
     tmpdir = tempfile.mkdtemp(prefix="kge_dist_%d_" % rank)
     for ai, (mode, comm) in enumerate(attempts):
@@ -317,10 +308,14 @@ def orchestrate(args, world, rank, local_rank):
         env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
         env.update({"KGE_DIST_WORKER": "1", "KGE_DIST_MODE": mode, "KGE_DIST_RESULT": res_path, "KGE_DIST_PROGRESS": prog_path,
                     "MASTER_PORT": str(base_port + 1 + ai), "RANK": str(rank), "LOCAL_RANK": str(local_rank), "WORLD_SIZE": str(world)})
-        if comm == "rccl-sync":
-            env["KGE_DIST_COMM"], env["KGE_DIST_PIPELINE"] = "rccl", "0"
+        env["KGE_DIST_ATTEMPT"] = comm
+        if comm == "rccl-graph":         # (synchronous schedule: at world 1 the forked pull costs 8 us per step, profiles/r05_dist_graph.txt;
+            env["KGE_DIST_COMM"], env["KGE_DIST_GRAPH"] = "rccl", "1"       # the pipelined graph is measured as a secondary leg)
+            env.setdefault("KGE_DIST_PIPELINE", "0")
+        elif comm == "rccl-sync":
+            env["KGE_DIST_COMM"], env["KGE_DIST_PIPELINE"], env["KGE_DIST_GRAPH"] = "rccl", "0", "0"
         elif comm:
-            env["KGE_DIST_COMM"] = comm
+            env["KGE_DIST_COMM"], env["KGE_DIST_GRAPH"] = comm, "0"
         # (KGE_DIST_WORKER_SCRIPT: the CPU test of this supervisor substitutes a scripted worker, tests/test_bench_supervisor.py)
         cmd = [sys.executable, os.environ.get("KGE_DIST_WORKER_SCRIPT") or
                os.path.join(os.path.dirname(os.path.abspath(__file__)), "bench.py")] + sys.argv[1:]
@@ -453,6 +448,9 @@ def main(args, world, rank, local_rank):
         return _replica_worker(args, rank, local_rank)
     import __graft_entry__
     __graft_entry__.build()      # serialised by a file lock; a no-op when the .so is current
+    if os.environ.get("KGE_FAULTHANDLER"):      # developer aid: every thread's Python stack to stderr after N seconds (a hang's address)
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["KGE_FAULTHANDLER"]), repeat=True, file=sys.stderr)
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -539,6 +537,8 @@ def main(args, world, rank, local_rank):
         res = _result_line(args, w, n_ent, world, wall, K, rows, d_e, eng.d_r, desc, mode, why, sums, other, leg, overflow)
         if eager is not None:
             res["a2a_eager"] = eager
+        if pipe_leg is not None:
+            res["a2a_graph_pipelined"] = pipe_leg
         if local_leg is not None:
             res["per_gpu_step_without_exchange"] = local_leg
         line = json.dumps(res)
@@ -554,44 +554,55 @@ def main(args, world, rank, local_rank):
         _deliver(json.dumps(_result_line(args, w, n_ent, world, wall, K, dict(rows), d_e, eng.d_r, desc, mode, why, sums, other,
                                          None, overflow)))
     _progress("headline")
-    # a2a with collectives (N > 1): the SAME K steps once more with the collectives recorded into hipGraphs - no host work between
-    # the kernels of a step.  Under a watchdog: if the replay hangs, the eager measurement above is the line.  When it completes
-    # it is the headline (same step, same K, same tables continuing) and the eager run is reported beside it.
-    gr_fn = rows.pop("graph_runner", None) if mode == "a2a" else None
-    # OPT-IN (KGE_DIST_GRAPH=1): on ROCm 7.0 / RCCL 2.26 the replay of this step's graphs hangs until the process-group watchdog
-    # aborts the process - with a host synchronise after every replay too, although a probe with small messages replays fine
-    # that way (tools/dbg/rccl_capture_probe2.py; profiles/r03_merged_fwd.txt)
-    if gr_fn is not None and not args.no_graph and os.environ.get("KGE_DIST_GRAPH", "0") == "1":
-        done_g = threading.Event()
+    # the same engine's groups once more with the pull of step s+1 forked next to step s INSIDE the graph (--async_update licence):
+    # which schedule wins depends on what a row pull costs on the links - measured beside the headline at N > 1
+    pipe_leg = None
+    if (mode == "a2a" and _de.coll and rows.get("launch") == "graph" and os.environ.get("KGE_DIST_PIPELINE", "1") == "0" and
+            (world > 1 or os.environ.get("KGE_DIST_PIPE_LEG") == "1") and os.environ.get("KGE_DIST_PIPE_LEG") != "0"):
+        done_p = threading.Event()
 
-        def watchdog_g():
-            if not done_g.wait(float(os.environ.get("KGE_DIST_GRAPH_TIMEOUT", "90"))):
-                emit({"error": "skipped: the graph-replay leg did not finish in time (watchdog)"})
+        def watchdog_p():
+            if not done_p.wait(float(os.environ.get("KGE_DIST_LEG_TIMEOUT", "120"))):
+                emit({"error": "the pipelined-graph leg did not finish in time (watchdog)"})
                 os._exit(0)
-        threading.Thread(target=watchdog_g, daemon=True).start()
+        threading.Thread(target=watchdog_p, daemon=True).start()
         try:
-            run_g, Gd = gr_fn()
-            run_g(args.warmup)
-            torch.cuda.synchronize(); dist.barrier()
-            eng.loss_accum.zero_()
-            t0 = time.perf_counter()
-            run_g(args.steps)
-            torch.cuda.synchronize(); dist.barrier()
-            tg = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-            dist.all_reduce(tg, op=dist.ReduceOp.MAX)
-            sums_g = eng.read_loss_sums()
-            if all(np.isfinite(sums_g[:3])):
-                eager = {"value": round(K * w["B"] * world / wall, 1), "unit": "edges/s", "us_per_step": round(1e6 * wall / K, 2),
-                         "launch": "eager launches, pull of step s+1 overlapped with step s"}
-                wall, sums = float(tg.item()), sums_g
-                desc = desc.split("(parameter-server semantics, RCCL")[0] + (
-                    "(parameter-server semantics, RCCL); kernels AND collectives of <= %d steps replay from one hipGraph "
-                    "(synchronous schedule, host synchronises per replay); sampling + plan on the device inside the timed region" % Gd)
-                overflow += _de.check_overflow()
-        except Exception as e:          # noqa: BLE001 - the eager measurement stands
-            eager = {"graph_leg_error": repr(e)}
-        done_g.set()
-    rows.pop("graph_runner", None)
+            l_steps = max(20, min(K, 240))
+            smp_ = _de.bench_sampler
+            for _ in range(3):               # pass 1 records the graphs (eager), pass 2 warms, pass 3 is timed
+                torch.cuda.synchronize(); dist.barrier()
+                t0 = time.perf_counter()
+                left = l_steps
+                while left > 0:
+                    n = min(smp_.n_slots, left)
+                    _de.run_group(smp_.sample(n), graph=True, pipelined=True)
+                    left -= n
+                torch.cuda.synchronize(); dist.barrier()
+                tp_ = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            dist.all_reduce(tp_, op=dist.ReduceOp.MAX)
+            pipe_leg = {"us_per_step": round(1e6 * float(tp_.item()) / l_steps, 2), "steps": l_steps,
+                        "value": round(l_steps * w["B"] * world / float(tp_.item()), 1), "unit": "edges/s",
+                        "launch": "the same hipGraph groups with the pull of step s+1 forked next to step s (one-step-stale rows)"}
+        except Exception as e:          # noqa: BLE001
+            pipe_leg = {"error": repr(e)}
+        done_p.set()
+    # (KGE_DIST_EAGER_LEG=1: the same engine's steps once more as eager launches - what the graph replay is measured against)
+    if mode == "a2a" and os.environ.get("KGE_DIST_EAGER_LEG") == "1" and _de.coll:
+        try:
+            l_steps = max(20, min(K, 240))
+            smp_ = _de.bench_sampler
+            for _ in range(2):
+                t0 = time.perf_counter()
+                left = l_steps
+                while left > 0:
+                    n = min(smp_.n_slots, left)
+                    _de.run_group(smp_.sample(n), graph=False, pipelined=os.environ.get("KGE_DIST_PIPELINE", "1") != "0")
+                    left -= n
+                torch.cuda.synchronize()
+                te = time.perf_counter() - t0
+            eager = {"us_per_step": round(1e6 * te / l_steps, 2), "steps": l_steps, "launch": "eager launches (run_group(graph=False))"}
+        except Exception as e:          # noqa: BLE001
+            eager = {"error": repr(e)}
     if want_other:
         done = threading.Event()
 
@@ -648,8 +659,9 @@ def main(args, world, rank, local_rank):
         dist.barrier()
         if tabs is not None:
             tabs.close()
-        if mode != "p2p" and hasattr(_de.comm, "close"):
-            _de.comm.close()             # the engine's own RCCL communicator (dist.RcclComm)
+        if mode != "p2p":
+            _de.close()                  # the group graphs first, THEN the engine's own RCCL communicator (ncclCommDestroy waits for
+            #                              every hipGraph that recorded one of its collectives - dist.RcclComm.close)
     finally:
         dist.destroy_process_group()
     if line is not None:
@@ -705,6 +717,7 @@ def _result_line(args, w, n_ent, world, wall, K, rows, d_e, d_r, desc, mode, why
         }
         if mode == "a2a":
             out["config"]["relation_partition"] = bool(rows.get("rel_part"))
+            out["config"]["launch"] = rows.get("launch")            # "graph": kernels + collectives of a group from one hipGraph
             out["config"]["bucket_rows"] = rows.get("cap")
             out["config"]["bucket_growth"] = rows.get("grown")
             out["config"]["bucket_overflows"] = overflow

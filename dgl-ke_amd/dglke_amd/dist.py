@@ -62,6 +62,7 @@ def default_cap(ue_max, world, slack=1.5):
 
 class TorchComm(object):
     """equal-split collectives on device tensors (backend nccl = RCCL over xGMI)."""
+    capturable = False          # (kept eager: the c10d wrappers are the fallback transport)
 
     def __init__(self, group=None):
         self.group = group
@@ -85,6 +86,9 @@ class RcclComm(object):
     collectives of the push leave as ONE grouped launch.  The communicator is this class's own (ncclCommInitRank with an id
     broadcast over the torch.distributed group); byte counts, so any dtype."""
     _INT8 = 0                                       # ncclInt8
+    # its calls may be recorded into a hipGraph (round 5: captured RCCL collectives replay fine on ROCm 7.0 / RCCL 2.26 - what
+    # rounds 2-4 took for a replay hang was ncclCommDestroy waiting for the graphs that still referenced the communicator, see close())
+    capturable = True
 
     class _Uid(C.Structure):
         _fields_ = [("internal", C.c_char * 128)]
@@ -147,6 +151,8 @@ class RcclComm(object):
             self._ck(self._L.ncclGroupEnd(), "ncclGroupEnd")
 
     def close(self):
+        """ncclCommDestroy BLOCKS for as long as a hipGraph that recorded one of this communicator's collectives is alive (the graph
+        holds a reference on the communicator's persistent plans): destroy such graphs first (DistEngine.close_graphs())."""
         if self._comm:
             self._L.ncclCommDestroy(self._comm)
             self._comm = C.c_void_p()
@@ -156,6 +162,8 @@ class HostStagedComm(object):
     """the same collectives carried by a host-side (gloo) process group through host copies.  Only for ranks that SHARE a
     device (`--gpu 0 0`: how the multi-process path is exercised on a one-GPU box - RCCL refuses two ranks on one GPU); the
     step synchronises the stream around every exchange."""
+
+    capturable = False          # host copies
 
     def __init__(self, group=None):
         self.group = group
@@ -400,6 +408,7 @@ class DistEngine(object):
         #  step at cfg-R: a graph launch costs more host time than the launches it replaces at this size)
         self._cg_on = os.environ.get("KGE_DIST_COMPUTE_GRAPH", "0") == "1" and isinstance(self.ops, HipOps)
         self._cgraphs = {}
+        self._ggraphs = {}            # run_group: (sampler, slot range, corruption parity, capacity, schedule) -> hipGraph of a whole group
         self._routed, self._route_pool, self._route_key, self._route_lb = {}, None, None, {}   # prepare_group: routed ahead, per sampler slot
         self._pre = None              # (batch, LocalBatch, slot index, event) of a pull that ran ahead
         self._side = None
@@ -434,6 +443,7 @@ class DistEngine(object):
         if hasattr(self.ops, "_jobs"):
             self.ops._jobs = {}
         self._cgraphs = {}            # compute graphs hold the old buffers' addresses
+        self.close_graphs()           # ... and so do the group graphs
         # whatever was routed ahead was routed for the OLD capacity (cache rows = owner * cap + position): drop it with the buffers
         self._routed, self._route_lb, self._route_pool, self._route_key = {}, {}, None, None
         self._gsend = self._graw = self._grecv = None
@@ -548,6 +558,66 @@ class DistEngine(object):
         if hit is not None and hit[1] == getattr(batch, "gen", None):
             return hit[0]
         return None
+
+    def close_graphs(self):
+        """destroy the group graphs (they hold the exchange buffers' addresses and - through the recorded collectives - a reference
+        on the communicator: RcclComm.close() blocks while one of them is alive)"""
+        for g in getattr(self, "_ggraphs", {}).values():
+            try:
+                g.reset()
+            except Exception:       # noqa: BLE001 - teardown
+                pass
+        self._ggraphs = {}
+
+    def close(self):
+        if self.dev.type == "cuda":
+            torch.cuda.synchronize(self.dev)
+        self.close_graphs()
+        if hasattr(self.comm, "close"):
+            self.comm.close()
+
+    def _steps(self, batches, pipelined):
+        for k, b in enumerate(batches):
+            if pipelined:
+                self.step_pipelined(b, batches[k + 1] if k + 1 < len(batches) else None)
+            else:
+                self.step(b)
+
+    def run_group(self, batches, log=None, graph=True, pipelined=False):
+        """one freshly sampled GROUP of batches, the trainer's order: size the owner buckets for it (ensure_capacity: the one device
+        read of the group, every rank decides alike), then [route the whole group, exchange its request ids once, run its steps]
+        - replayed from ONE hipGraph per (slot range, corruption parity, capacity, schedule) when the communicator can be recorded
+        (RcclComm; no collective at world 1): kernels AND collectives of the group without a host call in between (round 5: the
+        eager step was host-bound, 154 us against 138 us per cfg-R step at world 1 with the collectives forced).  The first
+        group of a geometry runs eagerly (it allocates every buffer) and is recorded afterwards; a capacity change drops the graphs.
+        pipelined: the pull of step s+1 on the side stream next to step s (--async_update licence), inside the graph as a fork."""
+        self.ensure_capacity(batches, log)
+        b0 = batches[0]
+        smp = getattr(b0, "sampler", None)
+        slots = [getattr(b, "slot", None) for b in batches]
+        ok = (graph and self.dev.type == "cuda" and smp is not None and isinstance(self.ops, HipOps) and
+              (not self.coll or getattr(self.comm, "capturable", False)) and
+              all(getattr(b, "sampler", None) is smp for b in batches) and slots == list(range(slots[0], slots[0] + len(slots))) and
+              not torch.cuda.is_current_stream_capturing())
+        if not ok:
+            self.prepare_group(batches, check_capacity=False)
+            self._steps(batches, pipelined)
+            return False
+        key = (id(smp), slots[0], len(slots), tuple(b.neg_head for b in batches[:2]), self.cap, bool(pipelined))
+        g = self._ggraphs.get(key)
+        if g is None:
+            self.prepare_group(batches, check_capacity=False)      # this group: eagerly (allocates the pool and every buffer) ...
+            self._steps(batches, pipelined)
+            g = torch.cuda.CUDAGraph()                             # ... and recorded (nothing executes) for the groups to come
+            with _lib.graph_capture(g):
+                self.prepare_group(batches, check_capacity=False)
+                self._steps(batches, pipelined)
+            self._ggraphs[key] = g
+            if hasattr(self.engine, "_graphs"):
+                self.engine._graphs += 1                           # the workspace's address is baked in: it may not move any more
+            return False
+        g.replay()
+        return True
 
     def precapture(self, sampler):
         """record the compute graphs of EVERY (sampler slot, corruption mode, cache slot) combination - pointer arithmetic only,

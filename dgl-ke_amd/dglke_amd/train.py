@@ -626,16 +626,11 @@ class A2ATrainer(ShardedTrainer):
         while done < n:
             k = min(smp.n_slots, n - done)
             dbs = smp.sample(k)
-            # owner buckets are sized BEFORE the group runs (one small device read per group; every rank takes the same decision)
-            # and the whole group is routed in one launch
-            self.de.prepare_group(dbs, log=(lambda m: print('[proc {}] {}'.format(self.rank, m))) if self.rank == 0 else None)
-            if not self.de._cgraphs and self.de._cg_on:      # first group (or after the buckets grew): record the compute graphs
-                self.de.precapture(smp)
-            for i, b in enumerate(dbs):
-                if self.pipelined:
-                    self.de.step_pipelined(b, dbs[i + 1] if i + 1 < k else None)
-                else:
-                    self.de.step(b)
+            # owner buckets are sized BEFORE the group runs (one small device read per group; every rank takes the same decision);
+            # then the routing of the whole group, ONE exchange of its request ids and its steps - with their collectives - replay
+            # from one hipGraph (dist.DistEngine.run_group; --graph_steps 0 or a host-staged transport: eager launches)
+            self.de.run_group(dbs, log=(lambda m: print('[proc {}] {}'.format(self.rank, m))) if self.rank == 0 else None,
+                              graph=bool(self.args.graph_steps), pipelined=self.pipelined)
             done += k
         lost = self.de.check_overflow()
         if lost:                                 # cannot happen behind ensure_capacity: a bug, not a tuning matter
@@ -656,8 +651,7 @@ class A2ATrainer(ShardedTrainer):
         return self._full
 
     def close(self):
-        if hasattr(self.comm, "close"):
-            self.comm.close()
+        self.de.close()              # the group graphs first, then the communicator (dist.RcclComm.close)
 
 
 def _mp_worker(rank, args, port):

@@ -11,7 +11,7 @@ import os
 import sys
 import time
 
-mode, comm = os.environ["KGE_DIST_MODE"], os.environ.get("KGE_DIST_COMM", "")
+mode, comm = os.environ["KGE_DIST_MODE"], os.environ.get("KGE_DIST_ATTEMPT", os.environ.get("KGE_DIST_COMM", ""))
 rank = int(os.environ["RANK"])
 plan = dict(item.split("=") for item in os.environ["KGE_FAKE_PLAN"].split(","))
 what = plan.get("%s/%s" % (mode, comm), plan.get(mode, "ok"))

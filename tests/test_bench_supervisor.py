@@ -47,38 +47,38 @@ def _run(plan, world=2, timeout=120):
 
 @pytest.mark.timeout(300)
 def test_first_attempt_succeeds():
-    d = _run("a2a/rccl=ok")
+    d = _run("a2a/rccl-graph=ok")
     assert d["value"] == 123.0 and d["config"]["mode"] == "a2a" and d["config"]["fallback_reason"] is None
     assert [h["ok"] for h in d["config"]["attempts"]] == [True]
 
 
 @pytest.mark.timeout(300)
 def test_hang_then_crash_then_one_stuck_rank_then_p2p():
-    d = _run("a2a/rccl=hang_setup,a2a/rccl-sync=hang_setup,a2a/torch=crash,p2p=ok")
+    d = _run("a2a/rccl-graph=hang_setup,a2a/rccl=hang_setup,a2a/rccl-sync=hang_setup,a2a/torch=crash,p2p=ok")
     at = d["config"]["attempts"]
-    assert [(h["mode"], h["comm"], h["ok"]) for h in at] == [("a2a", "rccl", False), ("a2a", "rccl-sync", False),
-                                                             ("a2a", "torch", False), ("p2p", None, True)]
-    assert "watchdog" in at[0]["why"] and "tables" in at[0]["why"] and "status 3" in at[2]["why"]
+    assert [(h["mode"], h["comm"], h["ok"]) for h in at] == [("a2a", "rccl-graph", False), ("a2a", "rccl", False),
+                                                             ("a2a", "rccl-sync", False), ("a2a", "torch", False), ("p2p", None, True)]
+    assert "watchdog" in at[0]["why"] and "tables" in at[0]["why"] and "status 3" in at[3]["why"]
     assert d["config"]["mode"] == "p2p" and "a2a/rccl" in d["config"]["fallback_reason"] and d["value"] == 123.0
 
 
 @pytest.mark.timeout(300)
 def test_one_stuck_rank_fails_the_attempt_and_replicas_close_the_chain():
-    d = _run("a2a/rccl=hang_rank1,a2a/rccl-sync=ok_rank0_only,a2a/torch=hang_rank1,p2p=crash,replicas=ok")
+    d = _run("a2a/rccl-graph=hang_rank1,a2a/rccl=hang_rank1,a2a/rccl-sync=ok_rank0_only,a2a/torch=hang_rank1,p2p=crash,replicas=ok")
     at = d["config"]["attempts"]
-    assert [h["ok"] for h in at] == [False, False, False, False, True] and at[-1]["mode"] == "replicas"
+    assert [h["ok"] for h in at] == [False, False, False, False, False, True] and at[-1]["mode"] == "replicas"
     assert d["config"]["mode"] == "replicas" and d["n_gpus"] == 2 and d["value"] > 0
     assert d["config"]["parallelism"] == "replicas only" and len(d["per_rank_us_per_step"]) == 2
 
 
 @pytest.mark.timeout(300)
 def test_a_leg_that_hangs_after_the_headline_costs_only_itself():
-    d = _run("a2a/rccl=leg_hang")
+    d = _run("a2a/rccl-graph=leg_hang")
     assert d["value"] == 123.0 and d["config"]["mode"] == "a2a"
     assert d["config"]["attempts"][0]["ok"] and "watchdog" in (d["config"]["attempts"][0]["why"] or "")
 
 
 @pytest.mark.timeout(300)
 def test_every_attempt_failing_still_prints_a_line():
-    d = _run("a2a/rccl=crash,a2a/rccl-sync=crash,a2a/torch=crash,p2p=crash,replicas=crash")
-    assert d["value"] == 0.0 and d["config"]["fallback_reason"] == "every attempt failed" and len(d["config"]["attempts"]) == 5
+    d = _run("a2a/rccl-graph=crash,a2a/rccl=crash,a2a/rccl-sync=crash,a2a/torch=crash,p2p=crash,replicas=crash")
+    assert d["value"] == 0.0 and d["config"]["fallback_reason"] == "every attempt failed" and len(d["config"]["attempts"]) == 6

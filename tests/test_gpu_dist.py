@@ -119,7 +119,7 @@ def test_route_fill_and_capacity_growth():
     off, stride = ops.route_layout(dbs[0], 8, de.cap)
     pool = de._route_pool.cpu().numpy()
     for b in dbs:
-        lb = de._routed[id(b)]
+        lb = de._routed_ahead(b)
         s0 = de.slots[0]
         de.ops.route(b, 8, spec.shard, de.cap, s0)
         torch.cuda.synchronize()
@@ -177,6 +177,39 @@ def test_precaptured_compute_graphs_equal_eager_launches():
         assert float((res[0][1] > 0).sum()) > 100
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("pipelined", [False, True], ids=["synchronous", "pipelined_pull"])
+def test_group_graph_with_recorded_collectives_equals_eager_launches(pipelined):
+    """DistEngine.run_group replays [routing of the group + ONE id exchange + the group's steps WITH their RCCL
+    collectives] from one hipGraph (RcclComm at world 1 through the collective code path: ncclAllToAll / grouped push recorded
+    into the graph).  Against the same groups as eager launches: shard, state and relation table bit-identical; group sizes
+    6, 6, 5 (odd: the corruption mode of every slot flips -> another graph), 5, 6, 6; and the teardown order that rounds 2-4
+    mistook for a replay hang - the graphs die before ncclCommDestroy (DistEngine.close)."""
+    from dglke_amd import dist as kd
+    from dglke_amd.dataloader import DeviceSampler
+    from dglke_amd.engine import StepEngine
+    n_ent, n_rel, hidden, B, N = 6000, 40, 64, 128, 32
+    rng = np.random.RandomState(31)
+    h, r, t = rng.randint(0, n_ent, 30000), rng.randint(0, n_rel, 30000), rng.randint(0, n_ent, 30000)
+    res = []
+    for graph in (False, True):
+        torch.manual_seed(3)
+        eng = StepEngine("RotatE", 1, n_rel, hidden, 12.0, 0.05, DEV, True, False, True, 1.0, 1e-6, 3)
+        ent = torch.empty(n_ent, 2 * hidden, device=DEV).uniform_(-0.2, 0.2)
+        state = torch.zeros(n_ent, device=DEV)
+        smp = DeviceSampler(h, r, t, n_ent, B, N, DEV, n_slots=6, seed=5)
+        de = kd.DistEngine(eng, kd.ShardSpec(n_ent, 1, 0), ent, state, always_collective=True, comm=kd.RcclComm())
+        replayed = [de.run_group(smp.sample(n), graph=graph, pipelined=pipelined) for n in (6, 6, 5, 5, 6, 6, 6)]
+        torch.cuda.synchronize()
+        assert de.check_overflow() == 0
+        # first group of a (size, parity) geometry: eager + recorded; 6/even, 6/even -> replay, 5/even, 5/odd, 6/even(after 2 x 5) ...
+        assert replayed == ([False, True, False, False, True, True, True] if graph else [False] * 7), replayed
+        res.append((ent.cpu(), state.cpu(), eng.rel.cpu().clone(), eng.rel_state.cpu().clone()))
+        de.close()                                   # returns: the graphs are destroyed before the communicator
+    for x, y in zip(res[0], res[1]):
+        assert torch.equal(x, y)
+    assert float((res[0][1] > 0).sum()) > 100
 
 
 def test_gather_rows_req_skips_pads_and_foreign_ids():
