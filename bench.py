@@ -60,6 +60,11 @@ WORKLOADS = {
     "transr_fb15k": dict(model="TransR", n_ent=14951, n_rel=1345, n_train=483142, hidden=200,
                          de=False, dr=False, B=1024, N=256, gamma=8.0, lr=0.015, adv=True,
                          adv_temp=1.0, reg_coef=5e-8, reg_norm=3),
+    # cfg-R's per-GPU step on ONE local table (BASELINE configs[4] without its exchange: D_e = 800 / D_r = 400, batch 1024, neg 256, a
+    # 1 M-row shard stand-in = 3.2 GB): the shape the pairwise kernels are profiled at (tools/timeline.py, rocprofv3)
+    "rotate_wide": dict(model="RotatE", n_ent=1000003, n_rel=14824, n_train=2000000, hidden=400,
+                        de=True, dr=False, B=1024, N=256, gamma=12.0, lr=0.01, adv=True,
+                        adv_temp=1.0, reg_coef=1e-7, reg_norm=3),
     "transe_l1_fb15k": dict(model="TransE_l1", n_ent=14951, n_rel=1345, n_train=483142, hidden=400,
                             de=False, dr=False, B=1000, N=200, gamma=16.0, lr=0.01, adv=True,
                             adv_temp=1.0, reg_coef=1e-7, reg_norm=3),
@@ -435,7 +440,7 @@ def main():
     ap.add_argument("--reg-coef", type=float, default=None, help="tuning: override the regularisation coefficient")
     ap.add_argument("--host-plan", action="store_true",
                     help="pre-stage host-built batches instead of sampling on the device inside the timed region")
-    ap.add_argument("--sampler-mode", default="serial", choices=["streams", "fork", "serial"],
+    ap.add_argument("--sampler-mode", default="serial", choices=["streams", "fork", "fork_tail", "serial"],
                     help="device sampler: the next group's batches are built by one sampler launch in front of every group on the "
                          "same stream (default), concurrently on a second stream, or on a forked branch of the group's hipGraph - the "
                          "concurrent modes make the steps 3.5 us slower each on ROCm 7.0 (profiles/r03_merged_fwd.txt)")
@@ -530,6 +535,7 @@ def main():
         run_t = lambda: run_groups(len(seq_w), len(seq))
         launch_desc = (("hipGraph of %d steps; sampler launch for the next group: %s" % (G, {
             "streams": "concurrently on a second stream", "fork": "on a forked branch of the graph",
+            "fork_tail": "on a branch of the graph forked in front of the group's last step",
             "serial": "serially behind the group's steps"}[args.sampler_mode])) if use_graph else "eager, sampler mode " + args.sampler_mode)
         launch_desc += ("; untimed before the timed region: %s%d warm-up steps (max(--warmup %d, --min-untimed %d): the GPU's clocks "
                         "have ramped when the one synchronise opens the timed region)"

@@ -376,8 +376,16 @@ __device__ __forceinline__ void gn_reduce_body(const NegArgs &a, int nrw, int64_
     const int64_t n4 = (int64_t)a.C * a.N * a.d_e / 4;
     if (t >= n4) return;
     const int64_t stride = (int64_t)a.C * a.N * a.d_e;
-    float4 acc = *reinterpret_cast<const float4 *>(a.GNp + 4 * t);
-    for (int r = 1; r < nrw; ++r) {
+    // the first eight partials are requested together (part index clamped: surplus requests re-read the last part), then added in
+    // part order - the same sum as one load -> add round per partial, without eight dependent rounds (cfg-R: nrw = 8)
+    float4 pv[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) pv[r] = *reinterpret_cast<const float4 *>(a.GNp + (int64_t)(r < nrw ? r : nrw - 1) * stride + 4 * t);
+    float4 acc = pv[0];
+#pragma unroll
+    for (int r = 1; r < 8; ++r)
+        if (r < nrw) { acc.x += pv[r].x; acc.y += pv[r].y; acc.z += pv[r].z; acc.w += pv[r].w; }
+    for (int r = 8; r < nrw; ++r) {
         const float4 v = *reinterpret_cast<const float4 *>(a.GNp + r * stride + 4 * t);
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }

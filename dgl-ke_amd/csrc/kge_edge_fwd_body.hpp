@@ -93,17 +93,15 @@ __device__ __forceinline__ void edge_fwd_body(const EdgeFwdArgs &a_in, int bid) 
         } else {
             const int hd = a.d_e / 2;
             const int nit = hd / V;
-            for (int it = lane; it < nit; it += 64) {
-                const int off = it * V;
-                const Pack<V> rh = ld<V>(h + off), ih = ld<V>(h + hd + off);
-                const Pack<V> rt = ld<V>(t + off), it_ = ld<V>(t + hd + off);
+            // one column pack of the row: rr_in / ir_in are the relation's (re | im) halves - RotatE: rr_in is the phase pack
+            auto cx_pack = [&](int off, const Pack<V> &rh, const Pack<V> &ih, const Pack<V> &rt, const Pack<V> &it_,
+                               const Pack<V> &rr_in, const Pack<V> &ir_in) {
                 Pack<V> rr, ir;
                 if constexpr (MODEL == KGE_COMPLEX || MODEL == KGE_SIMPLE) {
-                    rr = ld<V>(r + off); ir = ld<V>(r + hd + off);     // SimplE: rel | rel_inv
+                    rr = rr_in; ir = ir_in;                            // SimplE: rel | rel_inv
                 } else {
-                    const Pack<V> ph = ld<V>(r + off);
 #pragma unroll
-                    for (int e = 0; e < V; ++e) sincosf(ph.v[e] / a.rot_div, &ir.v[e], &rr.v[e]);
+                    for (int e = 0; e < V; ++e) sincosf(rr_in.v[e] / a.rot_div, &ir.v[e], &rr.v[e]);
                 }
                 Pack<V> are, aim;
 #pragma unroll
@@ -136,6 +134,33 @@ __device__ __forceinline__ void edge_fwd_body(const EdgeFwdArgs &a_in, int bid) 
                     as += are.v[e] * are.v[e] + aim.v[e] * aim.v[e];
                 }
                 if (A) { KGE_ST_A<V>(A + off, are); KGE_ST_A<V>(A + hd + off, aim); }
+            };
+            constexpr bool RPH = MODEL == KGE_ROTATE;                  // the relation row is one pack of phases per column pack
+            if (nit > 64 && nit <= 64 * EK) {
+                // rows of 65 .. 128 column packs (cfg-R: 100): every pack of both passes requested before the first use, lane offsets
+                // clamped - the loop below takes one dependent load round PER 64 packs (round 5: edge_fwd's wavefronts lived
+                // 6.4 us at D_e = 800 against 3.1 us at 400, tools/timeline.py).  Same packs, same order: bit-identical sums.
+                Pack<V> rhv[EK], ihv[EK], rtv[EK], itv[EK], r0v[EK], r1v[EK];
+#pragma unroll
+                for (int k = 0; k < EK; ++k) {
+                    const int off = min(lane + 64 * k, nit - 1) * V;
+                    rhv[k] = ld<V>(h + off); ihv[k] = ld<V>(h + hd + off);
+                    rtv[k] = ld<V>(t + off); itv[k] = ld<V>(t + hd + off);
+                    r0v[k] = ld<V>(r + off);
+                    if constexpr (!RPH) r1v[k] = ld<V>(r + hd + off); else r1v[k] = r0v[k];
+                }
+#pragma unroll
+                for (int k = 0; k < EK; ++k)
+                    if (lane + 64 * k < nit) cx_pack((lane + 64 * k) * V, rhv[k], ihv[k], rtv[k], itv[k], r0v[k], r1v[k]);
+            } else
+            for (int it = lane; it < nit; it += 64) {
+                const int off = it * V;
+                const Pack<V> rh = ld<V>(h + off), ih = ld<V>(h + hd + off);
+                const Pack<V> rt = ld<V>(t + off), it_ = ld<V>(t + hd + off);
+                const Pack<V> r0 = ld<V>(r + off);
+                Pack<V> r1 = r0;
+                if constexpr (!RPH) r1 = ld<V>(r + hd + off);
+                cx_pack(off, rh, ih, rt, it_, r0, r1);
             }
         }
         if (a.pos_score || a.do_pos_loss) {
@@ -243,6 +268,18 @@ __device__ __forceinline__ void edge_fwd_body(const EdgeFwdArgs &a_in, int bid) 
                     if (cp) KGE_ST_NEXT<V>(cp + (lane + 64 * k) * V, v2[k]);
 #pragma unroll
                     for (int e = 0; e < V; ++e) s += v2[k].v[e] * v2[k].v[e];
+                }
+            }
+        } else if (nitn <= 256) {        // ... and the four packs of a D_e = 800 row (cfg-R; same order of the sum as the loop below)
+            Pack<V> v4[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v4[k] = ld<V>(x + min(lane + 64 * k, nitn - 1) * V);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (lane + 64 * k < nitn) {
+                    if (cp) KGE_ST_NEXT<V>(cp + (lane + 64 * k) * V, v4[k]);
+#pragma unroll
+                    for (int e = 0; e < V; ++e) s += v4[k].v[e] * v4[k].v[e];
                 }
             }
         } else

@@ -124,10 +124,24 @@ int launch_edge_fwd(const EdgeFwdArgs &a, hipStream_t s) {
 //   = dpos_i * d p_i/d(h,r,t)  +  chain of GA_i = dL/da_i through a_i = T(x_i, r_i)
 //   (+ regularisation gradient of the relation row copy)
 // ------------------------------------------------------------------------------------------
+// wavefronts per edge of edge_bwd (see edge_bwd_body): one per 64 column packs for the column-wise models, vector instances only
+__host__ __device__ inline int edge_bwd_wpe(int model, int V, int d_e) {
+    if (V != 4) return 1;
+    if (model == KGE_ROTATE || model == KGE_COMPLEX) return (d_e / 2 / V + 63) / 64 > 0 ? (d_e / 2 / V + 63) / 64 : 1;
+    if (model == KGE_DISTMULT || model == KGE_TRANSE_L1) return (d_e / V + 63) / 64 > 0 ? (d_e / V + 63) / 64 : 1;
+    return 1;
+}
 template <int MODEL, int V, bool LOCAL>       // LOCAL: un-sharded tables (no shard-map divisions compiled in)
-__device__ __forceinline__ void edge_bwd_body(const EdgeBwdArgs &a_in, int64_t i) {
+__device__ __forceinline__ void edge_bwd_body(const EdgeBwdArgs &a_in, int64_t w_) {
     EdgeBwdArgs a = a_in;
     if constexpr (LOCAL) { a.src.em.n = 0; a.src.rm.n = 0; }
+    // wide rows (round 5): an edge's columns are dealt to `wpe` wavefronts, 64 column packs each - the models whose gradient is
+    // elementwise in the column (no row norm / clamp: RotatE, ComplEx, DistMult, TransE_l1).  A wavefront looping over 100 packs took
+    // one dependent [rows -> arithmetic -> stores] round per 64 of them: 11.0 us of life at D_e = 800 against 6.4 us at 400
+    // (tools/timeline.py), the longest chain of the edge_bwd launch.  Same arithmetic per column: bit-identical gradients.
+    const int wpe = edge_bwd_wpe(MODEL, V, a.d_e);
+    const int64_t i = w_ / wpe;
+    const int part = (int)(w_ % wpe);
     if (i >= a.B) return;
     const int lane = LANE();
     const float *h = table_row(a.src.em, a.src.hbase, a.src.hidx, i, a.d_e);
@@ -136,12 +150,25 @@ __device__ __forceinline__ void edge_bwd_body(const EdgeBwdArgs &a_in, int64_t i
     const float dp_in = a.dpos ? a.dpos[i] : 0.f;
     const float *ga = a.GA ? a.GA + i * (int64_t)a.d_e : nullptr;
     // GA in parts (shared-pair backward with split negatives): added in part order
+    // (the first four parts are requested together - part index clamped, surplus requests re-read the last part - and added in
+    //  part order: the same sum as one dependent load -> add round per part)
     auto ld_ga = [&](const float *p) {
-        Pack<V> v = ld<V>(p);
-        for (int q = 1; q < a.ga_parts; ++q) {
-            const Pack<V> u = ld<V>(p + q * a.ga_stride);
+        const int np = a.ga_parts > 1 ? a.ga_parts : 1;
+        Pack<V> u[4];
 #pragma unroll
-            for (int e = 0; e < V; ++e) v.v[e] += u.v[e];
+        for (int q = 0; q < 4; ++q) u[q] = ld<V>(p + (int64_t)(q < np ? q : np - 1) * a.ga_stride);
+        Pack<V> v = u[0];
+#pragma unroll
+        for (int q = 1; q < 4; ++q) {
+            if (q < np) {
+#pragma unroll
+                for (int e = 0; e < V; ++e) v.v[e] += u[q].v[e];
+            }
+        }
+        for (int q = 4; q < np; ++q) {
+            const Pack<V> w = ld<V>(p + q * a.ga_stride);
+#pragma unroll
+            for (int e = 0; e < V; ++e) v.v[e] += w.v[e];
         }
         return v;
     };
@@ -169,7 +196,7 @@ __device__ __forceinline__ void edge_bwd_body(const EdgeBwdArgs &a_in, int64_t i
                 inv = ss > 0.f ? 1.f / ss : 0.f;
             }
         }
-        for (int it = lane; it < nit; it += 64) {
+        for (int it = part * 64 + lane; it < nit; it += 64 * wpe) {
             const int off = it * V;
             const Pack<V> hv = ld<V>(h + off), rv = ld<V>(r + off), tv = ld<V>(t + off);
             const Pack<V> gav = ga ? ld_ga(ga + off) : zero_pack<V>();
@@ -218,7 +245,7 @@ __device__ __forceinline__ void edge_bwd_body(const EdgeBwdArgs &a_in, int64_t i
                 if (fabsf(wave_sum(ps)) >= KGE_SIMPLE_CLAMP) dp = 0.f;
             }
         }
-        for (int it = lane; it < nit; it += 64) {
+        for (int it = part * 64 + lane; it < nit; it += 64 * wpe) {
             const int off = it * V;
             const Pack<V> rh = ld<V>(h + off), ih = ld<V>(h + hd + off);
             const Pack<V> rt = ld<V>(t + off), it_ = ld<V>(t + hd + off);
@@ -342,13 +369,14 @@ __global__ __launch_bounds__(KGE_BLOCK) void edge_bwd_gnred_kernel(EdgeBwdArgs a
         KGE_TL(5);
         edge_bwd_body<MODEL, V, LOCAL>(a, WAVE_ID());
     } else {
+        KGE_TL(6);
         gn_reduce_body(n, nrw, ((int64_t)blockIdx.x - nbE) * KGE_BLOCK + threadIdx.x);
     }
 }
 
 template <int MODEL>
 static int launch_edge_bwd_gnred_m(const EdgeBwdArgs &a, const NegArgs &n, int nrw, hipStream_t s) {
-    const int nbE = blocks_for_waves(a.B);
+    const int nbE = blocks_for_waves((int64_t)a.B * edge_bwd_wpe(MODEL, 4, a.d_e));      // (vector instances only, checked below)
     const int64_t n4 = (int64_t)n.C * n.N * n.d_e / 4;
     const int nbR = (int)((n4 + KGE_BLOCK - 1) / KGE_BLOCK);
     const bool cx = is_complex_model(MODEL);
@@ -371,9 +399,9 @@ int launch_edge_bwd_with_gn_reduce(const EdgeBwdArgs &a, const NegArgs &n, int n
 
 template <int MODEL>
 static int launch_edge_bwd_m(const EdgeBwdArgs &a, hipStream_t s) {
-    const int nb = blocks_for_waves(a.B);
     const bool cx = is_complex_model(MODEL);
     const bool vec = cx ? ((a.d_e / 2) % 4 == 0 && a.d_r % 4 == 0) : (a.d_e % 4 == 0);
+    const int nb = blocks_for_waves((int64_t)a.B * (vec ? edge_bwd_wpe(MODEL, 4, a.d_e) : 1));
     const bool local = a.src.em.n == 0 && a.src.rm.n == 0;
     if (vec && local)
         hipLaunchKernelGGL((edge_bwd_kernel<MODEL, 4, true>), dim3(nb), dim3(KGE_BLOCK), 0, s, a);

@@ -235,7 +235,9 @@ class PrefetchedGroups(object):
     `NewBidirectionalOneShotIterator` over `num_workers` sampler threads).  Where the sampler launch of group g+1 runs:
       'serial'  - behind group g's steps, on the same stream (one launch per group; the steps replay from a hipGraph);
       'streams' - on a second stream next to the steps, joined by an event at the end of the group;
-      'fork'    - on a second branch inside the group's hipGraph.
+      'fork'    - on a second branch inside the group's hipGraph;
+      'fork_tail' - the same, but the branch forks in front of the group's LAST step only (round 5: the second queue is then active for
+                  one step instead of the whole group).
     Measured on MI355X / ROCm 7.0 (profiles/r03_merged_fwd.txt): the two concurrent modes hide the ~45 us launch but make every
     STEP ~3.5 us slower (a second active queue next to the graph's), so 'serial' is what bench.py uses.
 
@@ -246,8 +248,8 @@ class PrefetchedGroups(object):
         self.half = sampler.n_slots // 2 if group_max is None else int(group_max)
         if 2 * self.half > sampler.n_slots:
             raise ValueError("the sampler needs 2 x group_max slots")
-        if mode not in ("streams", "fork", "serial"):
-            raise ValueError("mode: streams | fork | serial")
+        if mode not in ("streams", "fork", "fork_tail", "serial"):
+            raise ValueError("mode: streams | fork | fork_tail | serial")
         self.mode = mode
         self.side = th.cuda.Stream(device=sampler.dev)      # (its priority makes no difference: profiles/r03_merged_fwd.txt)
         self.buf = 0                  # half holding the batches of the NEXT group to train
@@ -264,11 +266,17 @@ class PrefetchedGroups(object):
     def _enqueue_fork(self, n_next):
         cur = th.cuda.current_stream(self.smp.dev)
         batches, nxt = self.ready, None
-        if n_next:
+        late = self.mode == "fork_tail" and len(batches) > 1
+
+        def fork():
             self.side.wait_stream(cur)                                  # fork
             with th.cuda.stream(self.side):
-                nxt = self._sample_next(n_next)
-        for b in batches:
+                return self._sample_next(n_next)
+        if n_next and not late:
+            nxt = fork()
+        for k, b in enumerate(batches):
+            if n_next and late and k == len(batches) - 1:
+                nxt = fork()
             self.step_fn(b)
         if n_next:
             cur.wait_stream(self.side)                                  # join
@@ -280,7 +288,7 @@ class PrefetchedGroups(object):
         n_cur = len(self.ready)
         if n_next > self.half:
             raise ValueError("group larger than half of the slots")
-        if self.mode == "fork":
+        if self.mode in ("fork", "fork_tail"):
             key = (n_cur, n_next, self.buf)
             if not graph:
                 nxt = self._enqueue_fork(n_next)

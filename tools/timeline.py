@@ -21,7 +21,7 @@ for p in (ROOT, os.path.join(ROOT, "dgl-ke_amd")):
 import numpy as np
 import torch
 
-NAMES = {0: "edge_fwd", 1: "neg_fwd_gemm", 2: "loss", 3: "neg_bwd_gemm", 4: "update(ent)", 5: "edge_bwd", 6: "fwd_fused", 7: "update(rel)"}
+NAMES = {0: "edge_fwd", 1: "neg_fwd_gemm", 2: "loss", 3: "neg_bwd_gemm", 4: "update(ent)", 5: "edge_bwd", 6: "fwd_fused/gn_reduce", 7: "update(rel)"}
 PER = 8192
 NK = 8
 
