@@ -440,7 +440,7 @@ def main():
     ap.add_argument("--reg-coef", type=float, default=None, help="tuning: override the regularisation coefficient")
     ap.add_argument("--host-plan", action="store_true",
                     help="pre-stage host-built batches instead of sampling on the device inside the timed region")
-    ap.add_argument("--sampler-mode", default="serial", choices=["streams", "fork", "fork_tail", "serial"],
+    ap.add_argument("--sampler-mode", default="auto", choices=["auto", "fused", "streams", "fork", "fork_tail", "serial"],
                     help="device sampler: the next group's batches are built by one sampler launch in front of every group on the "
                          "same stream (default), concurrently on a second stream, or on a forked branch of the group's hipGraph - the "
                          "concurrent modes make the steps 3.5 us slower each on ROCm 7.0 (profiles/r03_merged_fwd.txt)")
@@ -514,6 +514,12 @@ def main():
         n_warm = max(args.warmup, args.min_untimed)
         seq_w, seq_t = sizes(n_warm), sizes(args.steps)
         seq = seq_w + seq_t
+        if args.sampler_mode == "auto":
+            # round 5: the step's own launches build the next group's batches (tail workgroups, kge_step_fused_sampling) where the step
+            # is the 4-launch strict step of the matrix-core family; everything else keeps the launch behind the group
+            plain = args.flags == 0 and not args.force_pairwise
+            args.sampler_mode = "fused" if (w["model"] in ("TransE_l2", "DistMult", "ComplEx") and plain and
+                                            eng.d_e % (8 if w["model"] == "ComplEx" else 4) == 0 and eng.d_r == eng.d_e) else "serial"
         pg = PrefetchedGroups(smp, eng.step, group_max=G, mode=args.sampler_mode)
 
         def run_groups(lo, hi):          # groups seq[lo:hi]; group i builds the batches of group i + 1 (the last one: of a
@@ -536,6 +542,8 @@ def main():
         launch_desc = (("hipGraph of %d steps; sampler launch for the next group: %s" % (G, {
             "streams": "concurrently on a second stream", "fork": "on a forked branch of the graph",
             "fork_tail": "on a branch of the graph forked in front of the group's last step",
+            "fused": "NO sampler launch - step k of a group builds batch k of the next group with 4 + 5 + 5 tail workgroups on its "
+                     "own first / backward / update launches (kge_step_fused_sampling)",
             "serial": "serially behind the group's steps"}[args.sampler_mode])) if use_graph else "eager, sampler mode " + args.sampler_mode)
         launch_desc += ("; untimed before the timed region: %s%d warm-up steps (max(--warmup %d, --min-untimed %d): the GPU's clocks "
                         "have ramped when the one synchronise opens the timed region)"

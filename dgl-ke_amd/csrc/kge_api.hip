@@ -7,6 +7,7 @@
 #include <cstring>
 #include <new>
 #include "kge_common.hpp"
+#include "kge_sampler_common.hpp"
 
 namespace {
 
@@ -441,7 +442,8 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
                      UpdateArgs *build_update = nullptr,      // PH_UPD_*: fill the launch arguments instead of launching
                      const UpdateArgs *co_update = nullptr,   // PH_FWD: another step's update to run alongside the forward
                      EdgeFwdArgs *build_prep = nullptr,       // PH_PREP: fill the launch arguments instead of launching
-                     const EdgeFwdArgs *co_prep = nullptr) {  // PH_BWD: the NEXT step's PREP to run alongside the backward
+                     const EdgeFwdArgs *co_prep = nullptr,    // PH_BWD: the NEXT step's PREP to run alongside the backward
+                     const SmpTail *tail = nullptr) {         // the sampler job this step's launches carry as tail workgroups
     if (!hp || !tb || !b || !ws) return fail(KGE_ERR_ARG, "kge_step: null argument");
     kge::ShardMap em{}, rm{};
     if (sh) {
@@ -591,6 +593,12 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     // (profiles/r04_loss_fold.txt).
     const bool fold_loss = merged_fwd && out && out->tickets && (hp->flags & KGE_FLAG_LOSS_IN_FWD) && !(hp->flags & KGE_FLAG_FWD_DIRECT) &&
                            neg_fwd_loss_fold_supported(hp->model, C, chunk, N, d_e, d_r);
+    // round 5: a batch of the NEXT group is built by tail workgroups of this step's first, backward and update launches
+    // (kge_sampler_tail.hpp) - the one-call strict step of the matrix-core family in its 4-launch form
+    if (tail && !(merged_fwd && !fold_loss && gemm && phases == PH_ALL && !co_prep && !co_update && !build_update && !build_prep &&
+                  !transr && !rescal && hp->d_e % 4 == 0 && hp->d_r % 4 == 0 && (hp->d_e > hp->d_r ? hp->d_e : hp->d_r) <= 1024))
+        return fail(KGE_ERR_ARG, "kge_step_fused_sampling: this step's launches cannot carry the sampler (matrix-core models, strict "
+                                 "4-launch step on local tables only)");
     EdgeFwdArgs ef{};
     if (phases & PH_PREP) {
     // 1. gather + positive score + pos-side vectors (+ positive-loss part, + P rows for TransE)
@@ -675,7 +683,7 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
                     la.neg_copy = out->neg_score;
                     la.skip_pos = 1;
                     KGE_TRY(launch_neg_fwd_gemm_with_edge_loss(g, ef, la, out->tickets, s));
-                } else KGE_TRY(launch_neg_fwd_gemm_with_edge(g, ef, s));
+                } else KGE_TRY(launch_neg_fwd_gemm_with_edge(g, ef, s, tail));
             } else if (!fused_launch) KGE_TRY(launch_neg_fwd_gemm(g, s));
         }
     } else {
@@ -745,7 +753,7 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
             else if (rc != KGE_ERR_ARG) return fail(rc, "launch_neg_bwd_gemm_with_prep failed (%d)", rc);
         }
         if (!fused_launch) {
-            KGE_TRY(launch_neg_bwd_gemm(g, s));
+            KGE_TRY(launch_neg_bwd_gemm(g, s, tail));
             if (co_prep) KGE_TRY(launch_edge_fwd(*co_prep, s));  // no fused instantiation: one after the other
         }
     } else {
@@ -893,7 +901,7 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         ua.g0 = out->g_pos_ent;
     }
     if (build_update) { *build_update = ua; return KGE_OK; }
-    KGE_TRY(launch_update(ua, s));
+    KGE_TRY(launch_update(ua, s, tail));
     // 7. deterministic reduction of this step's loss terms (only when the caller wants the
     //    per-step values; running sums are accumulated by the kernels above without it)
     if (want4 && (phases & PH_UPD_ENT)) {
@@ -911,6 +919,31 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
 int kge_step_fused(const kge_hparams *hp, const kge_tables *tb, const kge_batch *b,
                    const kge_step_out *out, void *ws, size_t ws_bytes, void *stream) {
     return step_impl(hp, tb, b, out, nullptr, ws, ws_bytes, stream);
+}
+
+// ---- round 5: the strict step that also BUILDS a batch of the next group (sampler tail workgroups, kge_sampler_tail.hpp) ----
+size_t kge_sampler_tail_scratch_bytes(int B, int C, int N, int64_t n_ent) {
+    if (B <= 0 || C <= 0 || N <= 0) return 0;
+    return (size_t)tail_scratch(B, C * N, n_ent > ((int64_t)1 << (32 - SP_CODE_BITS))).total;
+}
+
+int kge_step_fused_sampling(const kge_hparams *hp, const kge_tables *tb, const kge_batch *b, const kge_step_out *out, void *ws,
+                            size_t ws_bytes, const kge_sampler_job *job, void *stream) {
+    if (!job) return step_impl(hp, tb, b, out, nullptr, ws, ws_bytes, stream);
+    if (!job->heads || !job->rels || !job->tails || !job->state || !job->slot || !job->scratch || job->n_train <= 0 || job->n_ent <= 0 ||
+        job->B <= 0 || job->C <= 0 || job->chunk <= 0 || job->N <= 0 || job->C * job->chunk != job->B || job->k < 0 || job->advance < 0)
+        return fail(KGE_ERR_ARG, "kge_step_fused_sampling: bad sampler job");
+    if (job->n_train < job->B) return fail(KGE_ERR_ARG, "kge_step_fused_sampling: fewer training triples than one batch (n_train < batch)");
+    if (2 * job->B + job->C * job->N > SP_MAXE || job->B > SP_MAXE / 2 || job->n_ent >= ((int64_t)1 << 51))
+        return fail(KGE_ERR_ARG, "kge_step_fused_sampling: 2 * batch + chunks * neg <= 4096 (larger batches: build the plan on the host)");
+    if (job->scratch_bytes < kge_sampler_tail_scratch_bytes(job->B, job->C, job->N, job->n_ent))
+        return fail(KGE_ERR_WORKSPACE, "kge_step_fused_sampling: scratch too small (kge_sampler_tail_scratch_bytes)");
+    SmpTail t{};
+    t.a.H = job->heads; t.a.R = job->rels; t.a.T = job->tails; t.a.perm = job->perm; t.a.n_train = job->n_train; t.a.n_ent = job->n_ent;
+    t.a.B = job->B; t.a.C = job->C; t.a.chunk = job->chunk; t.a.N = job->N; t.a.seed = job->seed; t.a.state = job->state;
+    t.a.slots = (char *)job->slot; t.a.slot_bytes = 0; t.a.preperm = job->pre_permuted ? 1 : 0; t.slot3 = (char *)job->prev_slot;
+    t.scratch = (char *)job->scratch; t.k = job->k; t.advance = job->advance; t.phase = 1;
+    return step_impl(hp, tb, b, out, nullptr, ws, ws_bytes, stream, nullptr, PH_ALL, nullptr, nullptr, nullptr, nullptr, &t);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -478,7 +478,8 @@ int launch_edge_fwd(const EdgeFwdArgs &a, hipStream_t s);
 int launch_edge_bwd(const EdgeBwdArgs &a, hipStream_t s);
 int launch_loss(const LossArgs &a, hipStream_t s);
 int launch_finalize(const FinalizeArgs &a, hipStream_t s);
-int launch_update(const UpdateArgs &a, hipStream_t s);
+struct SmpTail;                  // sampler tail workgroups riding on a step launch (kge_sampler_tail.hpp); null / phase 0: none
+int launch_update(const UpdateArgs &a, hipStream_t s, const SmpTail *tail = nullptr);
 int launch_adagrad_scatter(float *table, float *state, int dim, const int64_t *idx,
                            const float *grad, int64_t n, float lr, float eps, hipStream_t s);
 int launch_adagrad_apply_packed(float *table, float *state, int dim, const int64_t *idx, const float *msg,
@@ -538,14 +539,14 @@ struct GemmArgs {                   // LDS-staged fp32-MFMA negative scoring (kg
 bool neg_mfma_supported(int model, int d_e, int N);
 bool neg_gemm_fused_loss_supported(int chunk, int N);   // fused loss of the matrix-core path (else: stand-alone loss kernel)
 int launch_neg_fwd_gemm(const GemmArgs &a, hipStream_t s);
-int launch_neg_bwd_gemm(const GemmArgs &a, hipStream_t s);
+int launch_neg_bwd_gemm(const GemmArgs &a, hipStream_t s, const SmpTail *tail = nullptr);
 struct UpdateArgs;
 // horizontally fused launches of the --async_update pipeline (KGE_ERR_ARG: no fused instantiation for the combination)
 int launch_neg_fwd_gemm_with_update(const GemmArgs &a, const UpdateArgs &u, hipStream_t s);
 // the strict step's first launch: forward GEMM tiles with on-the-fly pos-side fragments + the edge-forward rows of the SAME step
 // (KGE_ERR_ARG: no fused instantiation for the combination)
 bool neg_fwd_gemm_with_edge_supported(int model, int d_e, int d_r);
-int launch_neg_fwd_gemm_with_edge(const GemmArgs &a, const EdgeFwdArgs &e, hipStream_t s);
+int launch_neg_fwd_gemm_with_edge(const GemmArgs &a, const EdgeFwdArgs &e, hipStream_t s, const SmpTail *tail = nullptr);
 // ... and with the loss rows inside (round 4; `tickets`: kge_step_out.tickets, zero on entry and on exit)
 struct LossArgs;
 bool neg_fwd_loss_fold_supported(int model, int C, int chunk, int N, int d_e, int d_r);

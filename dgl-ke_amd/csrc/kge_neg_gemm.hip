@@ -39,6 +39,7 @@
 #include "kge_common.hpp"
 #include "kge_update_body.hpp"
 #include "kge_edge_fwd_body.hpp"
+#include "kge_sampler_tail.hpp"
 #include "kge_loss_body.hpp"
 
 using namespace kge;
@@ -635,17 +636,21 @@ __device__ __forceinline__ void neg_fwd_gemm_ldsa_body(const GemmArgs &a, int ti
 #ifndef KGE_FWD_NB
 #define KGE_FWD_NB 1               // direct-load instance: negative fragments per forward wavefront (tuning: 1, 2, 3; measured:
 #endif                             // wider is SLOWER - 9.3 / 11.7 / 14 us wave life, the time follows the loads per wavefront)
+// (round 5) ... + the phase-1 workgroups of the sampler tail building a batch of the NEXT group (kge_sampler_tail.hpp): the last
+// workgroups of the grid, behind the nbM workgroups of the step itself
 template <bool L2, int AM, int MODEL, bool LEAN, bool LDSA>
-__global__ __launch_bounds__(KGE_BLOCK) void neg_fwd_edge_kernel(GemmArgs a, int ti, int tj, int nbG, EdgeFwdArgs e) {
+__global__ __launch_bounds__(KGE_BLOCK) void neg_fwd_edge_kernel(GemmArgs a, int ti, int tj, int nbG, EdgeFwdArgs e, int nbM, SmpTail st) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     if ((int)blockIdx.x < nbG) {
         KGE_TL(1);
         if constexpr (LDSA) neg_fwd_gemm_ldsa_body<AM>(a, ti, tj, (int)blockIdx.x, nbG, smem);
         else if constexpr (KGE_FWD_NB == 1) neg_fwd_gemm_body<L2, false, AM>(a, ti, tj, (int)blockIdx.x, nbG);
         else neg_fwd_gemm_wide_body<AM, KGE_FWD_NB>(a, ti, (tj + KGE_FWD_NB - 1) / KGE_FWD_NB, (int)blockIdx.x, nbG);
-    } else {
+    } else if ((int)blockIdx.x < nbM) {
         KGE_TL(0);
         edge_fwd_body<MODEL, 4, LEAN>(e, (int)blockIdx.x - nbG);
+    } else {
+        sampler_tail_p1(st, (int)blockIdx.x - nbM);
     }
 }
 
@@ -668,8 +673,10 @@ bool neg_fwd_gemm_with_edge_supported(int model, int d_e, int d_r) {
     return (model == KGE_TRANSE_L2 || model == KGE_DISTMULT) && d_e % 4 == 0 && d_r == d_e;
 }
 
-int launch_neg_fwd_gemm_with_edge(const GemmArgs &a, const EdgeFwdArgs &e, hipStream_t s) {
+int launch_neg_fwd_gemm_with_edge(const GemmArgs &a, const EdgeFwdArgs &e, hipStream_t s, const SmpTail *tail) {
     if (a.C == 0 || a.PM || !a.xbase || !a.rbase || !a.xidx || !a.ridx) return KGE_ERR_ARG;
+    SmpTail st{};
+    if (tail && tail->phase) { st = *tail; st.phase = 1; }
     if (!neg_fwd_gemm_with_edge_supported(a.model, a.D, e.d_r) || e.model != a.model || e.d_e != a.D) return KGE_ERR_ARG;
     if (e.src.em.n || e.src.rm.n || e.nd_own) return KGE_ERR_ARG;
     const bool negjob = e.bsq || e.Bn;
@@ -684,14 +691,15 @@ int launch_neg_fwd_gemm_with_edge(const GemmArgs &a, const EdgeFwdArgs &e, hipSt
     const int64_t ntiles = (int64_t)a.C * ti * ((tj + KGE_FWD_NB - 1) / KGE_FWD_NB);
     const int nbG = ldsa ? a.C * ti * ((tj + 3) / 4) : (int)((ntiles + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK);
     const bool lean = e.lp.genre == KGE_LOSS_LOGSIGMOID && !e.row_pos && !e.Hc;
-    const dim3 g(nbG + nbP), b(KGE_BLOCK);
-#define KGE_FE2(L2_, AM_, M_, LE_) do { if (ldsa) hipLaunchKernelGGL((neg_fwd_edge_kernel<L2_, AM_, M_, LE_, true>), g, b, lds, s, a, ti, tj, nbG, ee); \
-                                        else hipLaunchKernelGGL((neg_fwd_edge_kernel<L2_, AM_, M_, LE_, false>), g, b, 0, s, a, ti, tj, nbG, ee); } while (0)
+    const int nbM = nbG + nbP;
+    const dim3 g(nbM + (st.phase ? ST_P1_WGS + (st.slot3 ? ST_P3_WGS : 0) : 0)), b(KGE_BLOCK);
+#define KGE_FE2(L2_, AM_, M_, LE_) do { if (ldsa) hipLaunchKernelGGL((neg_fwd_edge_kernel<L2_, AM_, M_, LE_, true>), g, b, lds, s, a, ti, tj, nbG, ee, nbM, st); \
+                                        else hipLaunchKernelGGL((neg_fwd_edge_kernel<L2_, AM_, M_, LE_, false>), g, b, 0, s, a, ti, tj, nbG, ee, nbM, st); } while (0)
 #define KGE_FE(L2_, AM_, M_) do { if (lean) KGE_FE2(L2_, AM_, M_, true); else KGE_FE2(L2_, AM_, M_, false); } while (0)
     if (a.model == KGE_COMPLEX) {
         if (!ldsa) return KGE_ERR_ARG;
-        if (lean) hipLaunchKernelGGL((neg_fwd_edge_kernel<false, 3, KGE_COMPLEX, true, true>), g, b, lds, s, a, ti, tj, nbG, ee);
-        else hipLaunchKernelGGL((neg_fwd_edge_kernel<false, 3, KGE_COMPLEX, false, true>), g, b, lds, s, a, ti, tj, nbG, ee);
+        if (lean) hipLaunchKernelGGL((neg_fwd_edge_kernel<false, 3, KGE_COMPLEX, true, true>), g, b, lds, s, a, ti, tj, nbG, ee, nbM, st);
+        else hipLaunchKernelGGL((neg_fwd_edge_kernel<false, 3, KGE_COMPLEX, false, true>), g, b, lds, s, a, ti, tj, nbG, ee, nbM, st);
     } else if (a.model == KGE_TRANSE_L2) KGE_FE(true, 1, KGE_TRANSE_L2);
     else KGE_FE(false, 2, KGE_DISTMULT);
 #undef KGE_FE
@@ -1258,10 +1266,18 @@ __device__ __forceinline__ void neg_bwd_gemm_body(const GemmArgs &a, int ti, int
 #endif
 template <bool L2, bool FACT, bool DENSE = false, int EW = 0>
 __global__ __launch_bounds__(GB_KS * KGE_BLOCK) void neg_bwd_gemm_kernel(GemmArgs a, int ti, int tj, int td,
-                                                                         int bpA, int bpN, int maxK) {
-    KGE_TL(3);
+                                                                         int bpA, int bpN, int maxK, int nbM, SmpTail st) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    neg_bwd_gemm_body<L2, FACT, DENSE, GB_KS, EW>(a, ti, tj, td, bpA, bpN, maxK, (int)blockIdx.x, (int)gridDim.x, smem);
+    // (round 5) phase 2 of the sampler tail: the grid's FIRST 8 workgroups when the launch carries one (its chain - counts, keys, a
+    // two-pass radix sort, totals - is as long as the tiles': it must not also wait for 230 workgroups to be dispatched; 8 keeps the
+    // tiles' block id -> XCD mapping)
+    const int toff = st.phase ? 8 : 0;
+    if ((int)blockIdx.x < toff) {
+        if constexpr (GB_KS == 1) sampler_tail_p2(st, (int)blockIdx.x);
+        return;
+    }
+    KGE_TL(3);
+    neg_bwd_gemm_body<L2, FACT, DENSE, GB_KS, EW>(a, ti, tj, td, bpA, bpN, maxK, (int)blockIdx.x - toff, nbM, smem);
 }
 
 // --async_update pipeline, horizontal fusion.  The pipeline (kge_step_async) keeps the exact one-step staleness of the
@@ -1285,8 +1301,11 @@ __global__ __launch_bounds__(KGE_BLOCK) void neg_bwd_prep_kernel(GemmArgs a, int
     }
 }
 
-int launch_neg_bwd_gemm(const GemmArgs &a, hipStream_t s) {
-    if (a.C == 0) return KGE_OK;
+int launch_neg_bwd_gemm(const GemmArgs &a, hipStream_t s, const SmpTail *tail) {
+    if (a.C == 0) return tail && tail->phase ? KGE_ERR_ARG : KGE_OK;
+    SmpTail st{};
+    if (tail && tail->phase && GB_KS == 1) { st = *tail; st.phase = 2; }
+    const int nbT = st.phase ? 8 : 0;            // (ST_P2_WGS <= 8 tail workgroups in front of the tiles, see the kernel)
     if (!a.W) return KGE_ERR_ARG;
     const bool fact = a.PM != nullptr;                           // W holds u_ij: factorised fused loss
     if (fact && (a.lp.pairwise || !a.PS || !a.PL)) return KGE_ERR_ARG;
@@ -1301,7 +1320,7 @@ int launch_neg_bwd_gemm(const GemmArgs &a, hipStream_t s) {
     // row indices [mk] int64 (+ factorised: the factor table [mk][GB_TJP])
     const size_t sm = (size_t)mk * 8 + (fact ? (size_t)mk * GB_TJP * 4 : 0);
     const bool l2 = a.model == KGE_TRANSE_L2;
-    const dim3 g(nb), b(GB_KS * KGE_BLOCK);
+    const dim3 g(nb + nbT), b(GB_KS * KGE_BLOCK);
     if (a.ew_GR) {                                               // DistMult / ComplEx: per-edge gradient rows from the GA tiles' epilogue
         const bool simple = a.model == KGE_SIMPLE, cplx = a.model == KGE_COMPLEX || simple;
         if (fact || l2 || (a.model != KGE_DISTMULT && !cplx) || !a.ew_ent || !a.ew_rel || !a.ew_h || !a.ew_t || !a.ew_r ||
@@ -1310,27 +1329,28 @@ int launch_neg_bwd_gemm(const GemmArgs &a, hipStream_t s) {
         if (cplx) {                                              // GA tiles: 32 complex elements (real + imaginary columns) each
             const int tdA = (a.D / 2 + 31) / 32;
             const int bpAc = (ti * tdA + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK;
-            const dim3 gc(a.C * (bpAc + bpN));
+            const int nbc = a.C * (bpAc + bpN);
+            const dim3 gc(nbc + nbT);
             if (simple) {
-                if (!a.nidx) hipLaunchKernelGGL((neg_bwd_gemm_kernel<false, false, true, 3>), gc, b, 0, s, a, ti, tj, td, bpAc, bpN, mk);
-                else hipLaunchKernelGGL((neg_bwd_gemm_kernel<false, false, false, 3>), gc, b, sm, s, a, ti, tj, td, bpAc, bpN, mk);
-            } else if (!a.nidx) hipLaunchKernelGGL((neg_bwd_gemm_kernel<false, false, true, 2>), gc, b, 0, s, a, ti, tj, td, bpAc, bpN, mk);
-            else hipLaunchKernelGGL((neg_bwd_gemm_kernel<false, false, false, 2>), gc, b, sm, s, a, ti, tj, td, bpAc, bpN, mk);
+                if (!a.nidx) hipLaunchKernelGGL((neg_bwd_gemm_kernel<false, false, true, 3>), gc, b, 0, s, a, ti, tj, td, bpAc, bpN, mk, nbc, st);
+                else hipLaunchKernelGGL((neg_bwd_gemm_kernel<false, false, false, 3>), gc, b, sm, s, a, ti, tj, td, bpAc, bpN, mk, nbc, st);
+            } else if (!a.nidx) hipLaunchKernelGGL((neg_bwd_gemm_kernel<false, false, true, 2>), gc, b, 0, s, a, ti, tj, td, bpAc, bpN, mk, nbc, st);
+            else hipLaunchKernelGGL((neg_bwd_gemm_kernel<false, false, false, 2>), gc, b, sm, s, a, ti, tj, td, bpAc, bpN, mk, nbc, st);
             return check_launch_g();
         }
-        if (!a.nidx) hipLaunchKernelGGL((neg_bwd_gemm_kernel<false, false, true, 1>), g, b, 0, s, a, ti, tj, td, bpA, bpN, mk);
-        else hipLaunchKernelGGL((neg_bwd_gemm_kernel<false, false, false, 1>), g, b, sm, s, a, ti, tj, td, bpA, bpN, mk);
+        if (!a.nidx) hipLaunchKernelGGL((neg_bwd_gemm_kernel<false, false, true, 1>), g, b, 0, s, a, ti, tj, td, bpA, bpN, mk, nb, st);
+        else hipLaunchKernelGGL((neg_bwd_gemm_kernel<false, false, false, 1>), g, b, sm, s, a, ti, tj, td, bpA, bpN, mk, nb, st);
         return check_launch_g();
     }
     if (!fact && !a.nidx) {                                      // dense operands: the instance without index table / LDS / barrier
-        if (l2) hipLaunchKernelGGL((neg_bwd_gemm_kernel<true, false, true>), g, b, 0, s, a, ti, tj, td, bpA, bpN, mk);
-        else hipLaunchKernelGGL((neg_bwd_gemm_kernel<false, false, true>), g, b, 0, s, a, ti, tj, td, bpA, bpN, mk);
+        if (l2) hipLaunchKernelGGL((neg_bwd_gemm_kernel<true, false, true>), g, b, 0, s, a, ti, tj, td, bpA, bpN, mk, nb, st);
+        else hipLaunchKernelGGL((neg_bwd_gemm_kernel<false, false, true>), g, b, 0, s, a, ti, tj, td, bpA, bpN, mk, nb, st);
         return check_launch_g();
     }
-    if (l2 && fact) hipLaunchKernelGGL((neg_bwd_gemm_kernel<true, true>), g, b, sm, s, a, ti, tj, td, bpA, bpN, mk);
-    else if (l2) hipLaunchKernelGGL((neg_bwd_gemm_kernel<true, false>), g, b, sm, s, a, ti, tj, td, bpA, bpN, mk);
-    else if (fact) hipLaunchKernelGGL((neg_bwd_gemm_kernel<false, true>), g, b, sm, s, a, ti, tj, td, bpA, bpN, mk);
-    else hipLaunchKernelGGL((neg_bwd_gemm_kernel<false, false>), g, b, sm, s, a, ti, tj, td, bpA, bpN, mk);
+    if (l2 && fact) hipLaunchKernelGGL((neg_bwd_gemm_kernel<true, true>), g, b, sm, s, a, ti, tj, td, bpA, bpN, mk, nb, st);
+    else if (l2) hipLaunchKernelGGL((neg_bwd_gemm_kernel<true, false>), g, b, sm, s, a, ti, tj, td, bpA, bpN, mk, nb, st);
+    else if (fact) hipLaunchKernelGGL((neg_bwd_gemm_kernel<false, true>), g, b, sm, s, a, ti, tj, td, bpA, bpN, mk, nb, st);
+    else hipLaunchKernelGGL((neg_bwd_gemm_kernel<false, false>), g, b, sm, s, a, ti, tj, td, bpA, bpN, mk, nb, st);
     return check_launch_g();
 }
 

@@ -10,6 +10,7 @@
 // reductions by cross-lane shuffles, no LDS, no atomics on the fused path.
 #include "kge_common.hpp"
 #include "kge_update_body.hpp"
+#include "kge_sampler_tail.hpp"
 #include "kge_edge_fwd_body.hpp"
 #include "kge_loss_body.hpp"
 
@@ -813,15 +814,19 @@ __global__ __launch_bounds__(KGE_BLOCK) void update_kernel(UpdateArgs a, int nb_
 
 // single-pass register-resident variant: body in kge_update_body.hpp
 template <int NIT, bool SHARDED, int LEAN>
-__global__ __launch_bounds__(KGE_BLOCK) void update_kernel_reg(UpdateArgs a, int nb_ent) {
-    KGE_TL(((int)blockIdx.x < (int)gridDim.x - nb_ent) ? 7 : 4);      // timeline: relation workgroups come first (id 7)
-    update_reg_body<NIT, SHARDED, LEAN>(a, nb_ent, (int)blockIdx.x, (int)gridDim.x);
+__global__ __launch_bounds__(KGE_BLOCK) void update_kernel_reg(UpdateArgs a, int nb_ent, int nbM, SmpTail st) {
+    if ((int)blockIdx.x >= nbM) { sampler_tail_p3(st, (int)blockIdx.x - nbM); return; }   // (round 5) phase 3 of the sampler tail
+    KGE_TL(((int)blockIdx.x < nbM - nb_ent) ? 7 : 4);      // timeline: relation workgroups come first (id 7)
+    update_reg_body<NIT, SHARDED, LEAN>(a, nb_ent, (int)blockIdx.x, nbM);
 }
 
-int launch_update(const UpdateArgs &a, hipStream_t s) {
+int launch_update(const UpdateArgs &a, hipStream_t s, const SmpTail *tail) {
     const int nbE = blocks_for_waves(a.UE), nbR = blocks_for_waves(a.UR);
-    if (nbE + nbR == 0) return KGE_OK;
-    const dim3 g(nbE + nbR), b(KGE_BLOCK);
+    if (nbE + nbR == 0) return tail && tail->phase ? KGE_ERR_ARG : KGE_OK;
+    SmpTail st{};
+    if (tail && tail->phase && tail->advance > 0) { st = *tail; st.phase = 3; }       // (only the group's last job finishes under its own update launch)
+    const int nbM = nbE + nbR;
+    const dim3 g(nbM + (st.phase ? ST_P3_WGS : 0)), b(KGE_BLOCK);
     const int dmax = a.model_d_e > a.d_r ? a.model_d_e : a.d_r;
     const bool vec = a.model_d_e % 4 == 0 && a.d_r % 4 == 0;
     const bool sharded = a.em.n != 0 || a.rm.n != 0;
@@ -844,7 +849,7 @@ int launch_update(const UpdateArgs &a, hipStream_t s) {
             return KGE_ERR_ARG;
         lean = 5;
     }
-#define KGE_UPD(N, SH, LE) hipLaunchKernelGGL((update_kernel_reg<N, SH, LE>), g, b, 0, s, a, nbE)
+#define KGE_UPD(N, SH, LE) hipLaunchKernelGGL((update_kernel_reg<N, SH, LE>), g, b, 0, s, a, nbE, nbM, st)
 #define KGE_UPD_L(N, SH)                                                         \
     do { if (lean == 1) KGE_UPD(N, SH, 1); else if (lean == 2) KGE_UPD(N, SH, 2); else if (lean == 3) KGE_UPD(N, SH, 3); \
          else if (lean == 4) KGE_UPD(N, SH, 4); else if (lean == 6) KGE_UPD(N, SH, 6); else KGE_UPD(N, SH, 0); } while (0)
@@ -857,8 +862,11 @@ int launch_update(const UpdateArgs &a, hipStream_t s) {
 #undef KGE_UPD_N
 #undef KGE_UPD_L
 #undef KGE_UPD
-    else if (vec) hipLaunchKernelGGL(update_kernel<4>, g, b, 0, s, a, nbE);
-    else hipLaunchKernelGGL(update_kernel<1>, g, b, 0, s, a, nbE);
+    else {
+        if (st.phase) return KGE_ERR_ARG;                    // (the generic kernels carry no sampler tail)
+        if (vec) hipLaunchKernelGGL(update_kernel<4>, g, b, 0, s, a, nbE);
+        else hipLaunchKernelGGL(update_kernel<1>, g, b, 0, s, a, nbE);
+    }
     return check_launch();
 }
 

@@ -25,56 +25,7 @@
 #include "kge_common.hpp"
 KGE_TL_DEFINE(sampler)
 
-#define SP_THREADS 1024
-#define SP_MAXE 4096                 // max elements (2B + C*N) and max B handled on the device
-#define SP_CODE_BITS 12
-
-struct SamplerArgs {
-    const int64_t *H, *R, *T;        // training triples [n_train]
-    const int64_t *perm;             // epoch permutation [n_train] or null (identity)
-    int64_t n_train, n_ent;
-    int B, C, chunk, N;
-    uint64_t seed;
-    int64_t *state;                  // device {pos, step, ticket, -}: advanced by the launch's last workgroup
-    char *slots; int64_t slot_bytes; // output slots
-};
-
-// slot layout (must match kge_sampler_slot_* in kge_api.hip)
-struct SlotLayout {
-    int64_t h_gid, t_gid, rel_ids, neg_ids, ue_id, ur_id;                       // int64 arrays
-    int64_t ue_pos_ptr, ue_pos_adj, ue_neg_ptr, ue_neg_slot, ur_ptr, ur_edge;   // int32 arrays
-    int64_t ue_rec, ur_rec, counts;
-    int64_t total;
-};
-__host__ __device__ inline int64_t al32(int64_t x) { return (x + 31) & ~(int64_t)31; }
-__host__ __device__ inline SlotLayout slot_layout(int B, int CN) {
-    const int64_t NE = 2 * (int64_t)B + CN;
-    SlotLayout L; int64_t o = 0;
-    L.h_gid = o; o = al32(o + 8 * B);
-    L.t_gid = o; o = al32(o + 8 * B);
-    L.rel_ids = o; o = al32(o + 8 * B);
-    L.neg_ids = o; o = al32(o + 8 * CN);
-    L.ue_id = o; o = al32(o + 8 * NE);
-    L.ur_id = o; o = al32(o + 8 * B);
-    L.ue_pos_ptr = o; o = al32(o + 4 * (NE + 1));
-    L.ue_pos_adj = o; o = al32(o + 4 * 2 * B);
-    L.ue_neg_ptr = o; o = al32(o + 4 * (NE + 1));
-    L.ue_neg_slot = o; o = al32(o + 4 * CN);
-    L.ur_ptr = o; o = al32(o + 4 * (B + 1));
-    L.ur_edge = o; o = al32(o + 4 * B);
-    L.ue_rec = o; o = al32(o + 32 * NE);
-    L.ur_rec = o; o = al32(o + 32 * B);
-    L.counts = o; o = al32(o + 16);
-    L.total = al32(o);
-    return L;
-}
-
-__device__ __forceinline__ uint64_t mix64(uint64_t x) {   // splitmix64 finaliser
-    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ULL;
-    x ^= x >> 27; x *= 0x94d049bb133111ebULL;
-    x ^= x >> 31;
-    return x;
-}
+#include "kge_sampler_common.hpp"
 
 // in-LDS bitonic sort of n2 (power of two) keys by all SP_THREADS threads - generic version: one
 // compare-exchange stage per barrier
@@ -187,23 +138,6 @@ __device__ uint32_t block_exclusive_scan(uint32_t *v, int n, uint32_t *wsum /*[S
     return total;
 }
 
-// (pos * mul + add) mod n for pos, add < n: 64-bit arithmetic when n < 2^32 (then mul < 2^32 too), else a shift-and-add
-// product modulo n (graphs beyond 4 G triples: 64 iterations per index, once per sampled edge)
-__device__ __forceinline__ uint64_t epoch_index(uint64_t pos, uint64_t mul, uint64_t add, uint64_t n) {
-    if (n < (1ull << 32)) return (pos * mul + add) % n;
-    uint64_t acc = add % n, x = pos % n, m = mul;
-    while (m) {
-        if (m & 1ull) { acc += x; if (acc >= n) acc -= n; }
-        x += x; if (x >= n) x -= n;
-        m >>= 1;
-    }
-    return acc;
-}
-__device__ __forceinline__ uint64_t gcd_u64(uint64_t x, uint64_t y) {
-    while (y) { const uint64_t r = x % y; x = y; y = r; }
-    return x;
-}
-
 template <typename K>             // key type of the entity plan: uint32_t when (id << SP_CODE_BITS) fits, else uint64_t
 __global__ __launch_bounds__(SP_THREADS) void sample_plan_kernel(SamplerArgs a) {
     __shared__ uint64_t keys[SP_MAXE];         // 32 KB (the entity plan with 32-bit keys uses half of it)
@@ -254,17 +188,8 @@ __global__ __launch_bounds__(SP_THREADS) void sample_plan_kernel(SamplerArgs a) 
     const int64_t gk = step - 1, ep = gk / nb, pos1 = (gk % nb) * B;
     // (multiplier AND offset are hashed from (seed, epoch): a table of eight multipliers made epochs e and e + 8 walk the same
     //  cyclic sequence, and graphs of >= 2^31 triples got mul = 1 - every epoch a rotation of epoch 0)
-    uint64_t mul = 1, add = 0;
-    if (a.perm && ep > 0) {
-        const uint64_t n = (uint64_t)a.n_train;
-        add = mix64(a.seed ^ (0xD6E8FEB86659FD93ULL * (uint64_t)ep)) % n;
-        uint64_t m = mix64(a.seed ^ (0xA0761D6478BD642FULL * (uint64_t)(ep + 1)));
-        m = (n < (1ull << 32)) ? (m & 0xffffffffull) : (m % n);          // (keeps pos * mul inside what epoch_index multiplies)
-        m |= 1ull;
-        if (m < 3) m = 3;
-        while (gcd_u64(m, n) != 1) m += 2;                               // bijection needs gcd(mul, n_train) = 1
-        mul = m;
-    }
+    uint64_t mul, add;
+    epoch_affine(a, ep, mul, add);
     (void)pos0;
     if (part == 1) {
         // ---- relations of the batch's edges (part 1) ----
@@ -325,8 +250,7 @@ __global__ __launch_bounds__(SP_THREADS) void sample_plan_kernel(SamplerArgs a) 
         ek[2 * i + 1] = ((K)tl << SP_CODE_BITS) | (K)(2 * i + 1);
     }
     for (int j = t; j < CN; j += SP_THREADS) {
-        const uint64_t x = mix64(mix64(a.seed ^ (uint64_t)step * 0x9E3779B97F4A7C15ULL) + (uint64_t)j);
-        const int64_t id = (int64_t)__umul64hi(x, (uint64_t)a.n_ent);      // uniform in [0, n_ent)
+        const int64_t id = sample_negative(a, step, j);
         neg_ids[j] = id;
         ek[2 * B + j] = ((K)id << SP_CODE_BITS) | (K)(2 * B + j);
     }

@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KGE_LIB") or os.path.join(_HERE, "libkge_hip.so")   # KGE_LIB: A/B builds
 
-KGE_ABI_VERSION = 6
+KGE_ABI_VERSION = 7
 MODEL_IDS = {"TransE_l1": 0, "TransE_l2": 1, "TransE": 1, "DistMult": 2, "ComplEx": 3, "RotatE": 4, "SimplE": 5, "RESCAL": 6, "TransR": 7}
 LOSS_IDS = {"Logsigmoid": 0, "Logistic": 1, "Hinge": 2, "BCE": 3}
 FLAG_FORCE_PAIRWISE = 1
@@ -66,6 +66,14 @@ class KgeTables(C.Structure):
 class KgeStepOut(C.Structure):
     _fields_ = [("loss4", c_p), ("loss_accum", c_p), ("pos_score", c_p), ("neg_score", c_p),
                 ("g_pos_ent", c_p), ("g_neg", c_p), ("g_rel", c_p), ("tickets", c_p)]
+
+
+class KgeSamplerJob(C.Structure):
+    """kge_sampler_job (ABI 7): one batch of the NEXT group, built by tail workgroups of a training step's launches"""
+    _fields_ = [("heads", c_p), ("rels", c_p), ("tails", c_p), ("perm", c_p), ("n_train", c_i64), ("n_ent", c_i64),
+                ("B", c_i32), ("C", c_i32), ("chunk", c_i32), ("N", c_i32), ("seed", C.c_uint64), ("state", c_p), ("slot", c_p),
+                ("scratch", c_p), ("scratch_bytes", c_sz), ("k", c_i32), ("advance", c_i32), ("pre_permuted", c_i32),
+                ("reserved", c_i32), ("prev_slot", c_p)]
 
 
 class KgeEmit(C.Structure):
@@ -128,6 +136,9 @@ _SIGNATURES = {
     "kge_step_workspace_bytes": (c_sz, [C.POINTER(KgeHParams), c_i, c_i, c_i, c_i, c_i, c_i]),
     "kge_step_fused": (c_i, [C.POINTER(KgeHParams), C.POINTER(KgeTables), C.POINTER(KgeBatch),
                              C.POINTER(KgeStepOut), c_p, c_sz, c_p]),
+    "kge_sampler_tail_scratch_bytes": (c_sz, [c_i, c_i, c_i, c_i64]),
+    "kge_step_fused_sampling": (c_i, [C.POINTER(KgeHParams), C.POINTER(KgeTables), C.POINTER(KgeBatch),
+                                      C.POINTER(KgeStepOut), c_p, c_sz, C.POINTER(KgeSamplerJob), c_p]),
     "kge_pipe_create": (c_i, [C.POINTER(c_p)]),
     "kge_pipe_destroy": (c_i, [c_p]),
     "kge_step_async_workspace_bytes": (c_sz, [C.POINTER(KgeHParams), c_i, c_i, c_i, c_i, c_i, c_i]),

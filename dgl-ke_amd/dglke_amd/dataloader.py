@@ -170,7 +170,7 @@ class DeviceSampler(object):
         g = th.Generator(device=self.dev)
         g.manual_seed(self.seed)
         self.perm = th.randperm(self.n_train, device=self.dev, generator=g) if shuffle else None
-        self.state = th.tensor([0, 1, 0, 0], dtype=th.int64, device=self.dev)   # {position, step (1-based), ticket, -}
+        self.state = th.tensor([0, 1, 0, 0, -1, 0, 0, 0], dtype=th.int64, device=self.dev)   # {position, step (1-based), ticket, -; cached epoch, mul, add, 1/n (tail jobs)}
         self.n_slots = int(n_slots)
         self.slot_bytes = int(_lib.lib().kge_sampler_slot_bytes(self.B, self.C, self.N))
         self.slots = th.zeros(self.n_slots * self.slot_bytes, dtype=th.uint8, device=self.dev)
@@ -208,6 +208,48 @@ class DeviceSampler(object):
         self.host_step += n
         return out
 
+    def tail_jobs(self, n, slot0=0):
+        """the next `n` batches as JOBS for the training steps' own launches instead of a launch of their own (round 5,
+        kge_step_fused_sampling): returns (jobs, batches) - jobs[k] is handed to the step that should build batches[k] (any n steps
+        of the current group, CONSECUTIVE steps in order: the step of job k + 1 also finishes batch k; the last job finishes its own
+        batch and advances the device state), batches may be trained on once the step of the last job has run.  Same ids and plan, bit for bit, as sample(n, slot0) would give from the same state."""
+        from . import _lib
+        import ctypes as C
+        n, slot0 = int(n), int(slot0)
+        if n <= 0 or slot0 < 0 or slot0 + n > self.n_slots:
+            raise ValueError("more batches than slots")
+        if getattr(self, "_tail_scratch", None) is None:
+            nb = int(_lib.lib().kge_sampler_tail_scratch_bytes(self.B, self.C, self.N, self.n_entities))
+            self._tail_scratch = th.zeros(nb, dtype=th.uint8, device=self.dev)
+        if self.perm is not None and getattr(self, "_Hp", None) is None:
+            # the jobs read the triples in base-permutation order (copies made once): their first phase is a chain of dependent
+            # memory rounds under a 9-us launch, and perm[e] was one of them
+            self._Hp, self._Rp, self._Tp = self.H[self.perm].contiguous(), self.R[self.perm].contiguous(), self.T[self.perm].contiguous()
+        Hs, Rs, Ts = (self._Hp, self._Rp, self._Tp) if self.perm is not None else (self.H, self.R, self.T)
+        jobs, out = [], []
+        for k in range(n):
+            j = _lib.KgeSamplerJob()
+            j.heads, j.rels, j.tails = _lib.ptr(Hs), _lib.ptr(Rs), _lib.ptr(Ts)
+            j.pre_permuted = 1 if self.perm is not None else 0
+            j.perm = _lib.ptr(self.perm) if self.perm is not None else None
+            j.n_train, j.n_ent = self.n_train, self.n_entities
+            j.B, j.C, j.chunk, j.N, j.seed = self.B, self.C, self.chunk, self.N, self.seed
+            j.state = _lib.ptr(self.state)
+            j.slot = self.slots.data_ptr() + (slot0 + k) * self.slot_bytes
+            j.scratch, j.scratch_bytes = _lib.ptr(self._tail_scratch), self._tail_scratch.numel()
+            j.k, j.advance = k, (n if k == n - 1 else 0)
+            j.prev_slot = (self.slots.data_ptr() + (slot0 + k - 1) * self.slot_bytes) if k > 0 else None
+            jobs.append(j)
+            key = (slot0 + k, (self.host_step + k) % 2 == 0)
+            b = self._batches.get(key)
+            if b is None:
+                b = self._batches[key] = DeviceBatch(self, key[0], key[1])
+            b.gen = self.launches + 1
+            out.append(b)
+        self.launches += 1
+        self.host_step += n
+        return jobs, out
+
     def slot_arrays(self, slot):
         """copy one slot back to the host as numpy arrays (tests / debugging)."""
         B, CN = self.B, self.C * self.N
@@ -236,21 +278,27 @@ class PrefetchedGroups(object):
       'serial'  - behind group g's steps, on the same stream (one launch per group; the steps replay from a hipGraph);
       'streams' - on a second stream next to the steps, joined by an event at the end of the group;
       'fork'    - on a second branch inside the group's hipGraph;
-      'fork_tail' - the same, but the branch forks in front of the group's LAST step only (round 5: the second queue is then active for
+      'fused'   - (round 5) NO launch: step k of group g builds batch k of group g + 1 with a few tail workgroups on its own
+                  launches (kge_step_fused_sampling; step_fn must accept sample_job=); a next group larger than the current one
+                  is sampled by a launch like 'serial';
+      'fork_tail' - the same as 'fork', but the branch forks in front of the group's LAST step only (round 5: the second queue is then active for
                   one step instead of the whole group).
     Measured on MI355X / ROCm 7.0 (profiles/r03_merged_fwd.txt): the two concurrent modes hide the ~45 us launch but make every
     STEP ~3.5 us slower (a second active queue next to the graph's), so 'serial' is what bench.py uses.
 
     sampler: a DeviceSampler with n_slots >= 2 * the largest group; step_fn(batch): enqueues one training step."""
 
-    def __init__(self, sampler, step_fn, group_max=None, mode="serial"):
+    def __init__(self, sampler, step_fn, group_max=None, mode="serial", fused_max=48):
         self.smp, self.step_fn = sampler, step_fn
         self.half = sampler.n_slots // 2 if group_max is None else int(group_max)
         if 2 * self.half > sampler.n_slots:
             raise ValueError("the sampler needs 2 x group_max slots")
-        if mode not in ("streams", "fork", "fork_tail", "serial"):
-            raise ValueError("mode: streams | fork | fork_tail | serial")
+        if mode not in ("streams", "fork", "fork_tail", "serial", "fused"):
+            raise ValueError("mode: streams | fork | fork_tail | serial | fused")
         self.mode = mode
+        # 'fused': groups of more steps than this keep the launch (its 33 us per 120 batches = 0.28 us per step are less than the
+        # 0.25 us per step the tails add to the backward launch; at 20 steps the launch costs 1.25 us per step)
+        self.fused_max = int(fused_max)
         self.side = th.cuda.Stream(device=sampler.dev)      # (its priority makes no difference: profiles/r03_merged_fwd.txt)
         self.buf = 0                  # half holding the batches of the NEXT group to train
         self.ready = None             # DeviceBatch objects in that half
@@ -305,6 +353,33 @@ class PrefetchedGroups(object):
             self.ready = nxt
             self.buf ^= 1
             return
+        if self.mode == "fused" and 0 < n_next <= n_cur <= self.fused_max:
+            key = (n_cur, n_next, self.buf)
+            if graph and key in self.graphs:
+                g, nxt = self.graphs[key]
+                self.smp.host_step += n_next
+                self.smp.launches += 1
+                for b in nxt:
+                    b.gen = self.smp.launches
+                g.replay()
+            else:
+                def enqueue():
+                    jobs, nb = self.smp.tail_jobs(n_next, slot0=(self.buf ^ 1) * self.half)
+                    for k, b in enumerate(self.ready):
+                        self.step_fn(b, sample_job=jobs[k] if k < n_next else None)
+                    return nb, jobs
+                if graph:
+                    g = th.cuda.CUDAGraph()
+                    with _lib.graph_capture(g):
+                        nxt, jobs = enqueue()
+                    self.graphs[key] = (g, nxt)
+                    self._jobs_alive = getattr(self, "_jobs_alive", []) + [jobs]
+                    g.replay()
+                else:
+                    nxt, _ = enqueue()
+            self.ready = nxt
+            self.buf ^= 1
+            return
         cur = th.cuda.current_stream(self.smp.dev)
         nxt = None
         if n_next and self.mode == "streams":
@@ -323,7 +398,7 @@ class PrefetchedGroups(object):
                         self.step_fn(b)
                 self.graphs[key] = g
             self.graphs[key].replay()
-        if n_next and self.mode == "serial":
+        if n_next and self.mode in ("serial", "fused"):
             # 'serial': the sampler launch BEHIND the group's steps on the same stream (it fills the other half of the slots): the
             # GPU starts on the steps at once and the host builds the next group's batch descriptors while they run
             nxt = self._sample_next(n_next)

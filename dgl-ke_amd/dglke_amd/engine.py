@@ -124,9 +124,10 @@ class StepEngine(object):
             self._ws_bytes = self._ws.numel()
         return self._ws
 
-    def step(self, batch, want=None, emit=None, per_step_loss=False):
+    def step(self, batch, want=None, emit=None, per_step_loss=False, sample_job=None):
         """enqueue one fused step.  `want`: dict of optional output tensors (pos_score, neg_score,
-        g_pos_ent, g_neg, g_rel).  `emit`: KgeEmit for the sharded path."""
+        g_pos_ent, g_neg, g_rel).  `emit`: KgeEmit for the sharded path.  `sample_job` (KgeSamplerJob, DeviceSampler.tail_jobs):
+        the step's launches also BUILD that batch of the next group (kge_step_fused_sampling; strict step on local tables)."""
         ws = self.workspace_for(batch)
         out = _lib.KgeStepOut()
         if want is not None or per_step_loss:
@@ -136,11 +137,16 @@ class StepEngine(object):
         if want:
             for k, t in want.items():
                 setattr(out, k, ptr(t))
+        if sample_job is not None and (self.shards is not None or emit is not None):
+            raise _lib.KgeError("the sampler tail rides on the strict single-table step only")
         if self.shards is not None:
             if emit is not None:
                 raise _lib.KgeError("gradient emission and peer-to-peer sharding are different multi-GPU modes")
             check(lib().kge_step_sharded(C.byref(self.hp), C.byref(self.shards.c), C.byref(batch.c),
                                          C.byref(out), ptr(ws), self._ws_bytes, stream_ptr()))
+        elif emit is None and sample_job is not None:
+            check(lib().kge_step_fused_sampling(C.byref(self.hp), C.byref(self.tb), C.byref(batch.c),
+                                                C.byref(out), ptr(ws), self._ws_bytes, C.byref(sample_job), stream_ptr()))
         elif emit is None:
             check(lib().kge_step_fused(C.byref(self.hp), C.byref(self.tb), C.byref(batch.c),
                                        C.byref(out), ptr(ws), self._ws_bytes, stream_ptr()))

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define KGE_ABI_VERSION 6
+#define KGE_ABI_VERSION 7
 
 /* score functions (models/general_models.py:248-268 model_name strings) */
 enum kge_model {
@@ -431,6 +431,39 @@ int kge_sample_batches(const int64_t *heads, const int64_t *rels, const int64_t 
                        const int64_t *perm, int64_t n_train, int64_t n_ent, int B, int C, int chunk,
                        int N, uint64_t seed, int64_t *state, void *slots, size_t slot_bytes,
                        int n_slots, void *stream);
+/* ---- ABI 7 (round 5): the sampler as TAIL WORKGROUPS of the training step's own launches (csrc/kge_sampler_tail.hpp) ----
+ * kge_step_fused_sampling = kge_step_fused of batch `b` whose first, backward and update launches each carry a few extra
+ * 256-thread workgroups that build ONE other batch - the one kge_sample_batches would build as batch `k` of its next launch
+ * (step state[1] + k: same ids from the same counter RNG / epoch permutation, same plan, bit for bit) - into `slot`, a phase per
+ * launch (ids + bucketed keys | per-bucket sort + scans | relocation to the final lists and records - that last phase on the NEXT
+ * step's first launch, `prev_slot`; the group's last job: on its own update launch).  Batch k is complete one launch into the
+ * step that carries job k + 1 (the last one: when its step ends); nothing is launched for it.
+ * The reference's counterpart: the EdgeSampler worker threads that build the next batches while a step runs
+ * (dataloader/sampler.py:823-876).  `state` is NOT advanced by a job unless `advance` > 0 (the group's last job: advance by that
+ * many batches, after every job of the group has read it).  `scratch`: kge_sampler_tail_scratch_bytes(), one buffer shared by
+ * all jobs of a stream.  Steps whose launches cannot carry the tail (everything but the 4-launch strict step of TransE_l2 /
+ * DistMult / ComplEx on local tables) return KGE_ERR_ARG: use kge_sample_batches then.  job == NULL: plain kge_step_fused. */
+typedef struct kge_sampler_job {
+    const int64_t *heads, *rels, *tails, *perm;   /* as kge_sample_batches */
+    int64_t  n_train, n_ent;
+    int      B, C, chunk, N;
+    uint64_t seed;
+    int64_t *state;             /* int64[8]: {position, step (1-based), ticket, -} as kge_sample_batches uses them + {epoch, mul, add, reciprocal}: the epoch constants the jobs cache (initialise word 4 to -1) */
+    void    *slot;              /* output slot of THIS batch (kge_sampler_slot_bytes) */
+    void    *scratch; size_t scratch_bytes;
+    int      k;                 /* index of the batch within the group under construction */
+    int      advance;           /* > 0: last job of the group - advance `state` by this many batches */
+    int      pre_permuted;      /* != 0: heads / rels / tails are already in base-permutation order (x[perm[i]] at i): the job skips
+                                 * the perm lookup - one dependent memory round less in its first phase; perm != NULL still means
+                                 * "a new edge order every epoch" */
+    int      reserved;
+    void    *prev_slot;         /* slot of the job the PREVIOUS step carried (k - 1), whose last phase rides on this step's first launch; NULL for k = 0.
+                                 * The group's last job (advance > 0) finishes under its own step's update launch. */
+} kge_sampler_job;
+size_t kge_sampler_tail_scratch_bytes(int B, int C, int N, int64_t n_ent);
+int kge_step_fused_sampling(const kge_hparams *hp, const kge_tables *tb, const kge_batch *b, const kge_step_out *out,
+                            void *ws, size_t ws_bytes, const kge_sampler_job *job, void *stream);
+
 /* host-side: point a kge_batch at slot `slot` (pure pointer arithmetic, no device access) */
 int kge_batch_from_slot(void *slots, size_t slot_bytes, int slot, int B, int C, int chunk, int N,
                         int neg_head, kge_batch *out);

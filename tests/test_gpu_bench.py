@@ -48,6 +48,9 @@ def test_bench_line_has_the_contract_fields():
         assert k in r, k
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
     assert 5e6 < d["value"] < 1e9 and abs(d["value"] - 1000 * 1e3 / d["ms_per_step"]) / d["value"] < 0.02
+    # round 5: what ran untimed is said, and the 20 timed steps build the next 20 batches on their own launches (no sampler launch)
+    assert d["warmup_effective"] == 120 and "kge_step_fused_sampling" in d["config"]["launch"]
+    assert r.get("traffic_ratio") is None or r["traffic_ratio"] > 1.0
 
 
 @pytest.mark.gpu

@@ -140,3 +140,125 @@ def test_step_from_device_batch_equals_step_from_host_plan(rel_hub):
     assert torch.equal(e1.ent, e2.ent) and torch.equal(e1.rel, e2.rel)
     assert torch.equal(e1.ent_state, e2.ent_state) and torch.equal(e1.rel_state, e2.rel_state)
     assert np.allclose(e1.read_loss_sums(), e2.read_loss_sums(), rtol=1e-6)
+
+
+@pytest.mark.parametrize("n_ent,n_rel,B,N,chunk,model,skewed", [
+    (14951, 1345, 1000, 200, 200, "TransE_l2", False),       # cfg-T: 32-bit keys, ~750 keys per bucket
+    (500, 7, 120, 24, 40, "TransE_l2", False),               # chunk != N, tiny id range: long duplicate runs
+    (60000, 40, 1024, 256, 256, "ComplEx", True),            # ids sorted by popularity: one bucket takes most keys (big instance)
+    (9, 2, 16, 4, 4, "DistMult", False),
+])
+def test_sampler_tail_on_the_step_launches_builds_the_same_batches(n_ent, n_rel, B, N, chunk, model, skewed):
+    """VERDICT r04 next-3 (round 5): kge_step_fused_sampling - tail workgroups on the step's first / backward / update launches
+    build, phase by phase, one batch of the NEXT group per step.  Every array of every slot equals, bit for bit, what the
+    stand-alone sampler launch (kge_sample_batches) builds from the same state - ids from the same counter RNG and epoch
+    permutation, the same plan - over three groups (the third crosses an epoch boundary), the device state advances alike, and
+    the step that carries the tail trains exactly as without it."""
+    from dglke_amd.dataloader import DeviceSampler
+    from dglke_amd.engine import StepEngine
+    rng = np.random.RandomState(11)
+    n_train = 7 * B + 5
+    if skewed:                                               # 85 % of the edge ends in the lowest 2 % of the id range
+        hot = lambda n: np.where(rng.rand(n) < 0.85, rng.randint(0, max(2, n_ent // 50), n), rng.randint(0, n_ent, n))
+        h, t = hot(n_train), hot(n_train)
+    else:
+        h, t = rng.randint(0, n_ent, n_train), rng.randint(0, n_ent, n_train)
+    r = rng.randint(0, n_rel, n_train)
+    hidden = 32
+    G = 3
+    de = model == "ComplEx"
+
+    def make():
+        torch.manual_seed(1)
+        e_ = StepEngine(model, n_ent, n_rel, hidden, 12.0, 0.1, DEV, de, de, True, 1.0, 1e-6, 3)
+        s_ = DeviceSampler(h, r, t, n_ent, B, N, DEV, n_slots=2 * G, neg_chunk_size=chunk, seed=3)
+        return e_, s_
+    eng_a, smp_a = make()          # reference: stand-alone sampler launches
+    eng_b, smp_b = make()          # tail jobs
+    cur_a, cur_b = smp_a.sample(G, slot0=0), smp_b.sample(G, slot0=0)
+    half = 0
+    for grp in range(3):
+        nxt_a = smp_a.sample(G, slot0=(half ^ 1) * G)
+        jobs, nxt_b = smp_b.tail_jobs(G, slot0=(half ^ 1) * G)
+        for k in range(G):
+            eng_a.step(cur_a[k])
+            eng_b.step(cur_b[k], sample_job=jobs[k])
+        torch.cuda.synchronize()
+        for k in range(G):
+            a, b = smp_a.slot_arrays((half ^ 1) * G + k), smp_b.slot_arrays((half ^ 1) * G + k)
+            UE, UR = int(a["counts"][0]), int(a["counts"][1])
+            assert np.array_equal(a["counts"], b["counts"]), (grp, k, a["counts"], b["counts"])
+            for name, n in (("h_gid", B), ("t_gid", B), ("rel_ids", B), ("neg_ids", (B // chunk) * N), ("ue_id", UE), ("ur_id", UR),
+                            ("ue_pos_ptr", UE + 1), ("ue_pos_adj", 2 * B), ("ue_neg_ptr", UE + 1), ("ue_neg_slot", (B // chunk) * N),
+                            ("ur_ptr", UR + 1), ("ur_edge", B), ("ue_rec", 8 * UE), ("ur_rec", 8 * UR)):
+                assert np.array_equal(a[name][:n], b[name][:n]), "group %d batch %d: %s differs" % (grp, k, name)
+            assert nxt_a[k].neg_head == nxt_b[k].neg_head
+        assert torch.equal(smp_a.state[:2], smp_b.state[:2]), "device state"
+        cur_a, cur_b, half = nxt_a, nxt_b, half ^ 1
+    assert torch.equal(eng_a.ent, eng_b.ent) and torch.equal(eng_a.rel, eng_b.rel) and torch.equal(eng_a.ent_state, eng_b.ent_state)
+    assert smp_a.host_step == smp_b.host_step
+
+
+def test_sampler_tail_64bit_keys():
+    """entity ids beyond 2^20 (Freebase: 86 M) take the 64-bit key instances of the three phases: the triples' ids span the whole
+    range, the table of the carrying steps is a small stand-in (a step trains on device batches of ANOTHER, small-id sampler with
+    the same geometry while its launches build the big-id batches)."""
+    from dglke_amd.dataloader import DeviceSampler
+    from dglke_amd.engine import StepEngine
+    rng = np.random.RandomState(5)
+    n_ent, n_rel, B, N = 86054151, 14824, 1024, 256
+    n_train = 4 * B + 9
+    h, r, t = rng.randint(0, n_ent, n_train), rng.randint(0, n_rel, n_train), rng.randint(0, n_ent, n_train)
+    eng = StepEngine("DistMult", 5000, n_rel, 32, 12.0, 0.1, DEV, False, False, True, 1.0, 1e-6, 3)
+    carrier = DeviceSampler(h % 5000, r, t % 5000, 5000, B, N, DEV, n_slots=3, seed=1)
+    cur = carrier.sample(3)
+    smp_a = DeviceSampler(h, r, t, n_ent, B, N, DEV, n_slots=3, seed=3)
+    smp_b = DeviceSampler(h, r, t, n_ent, B, N, DEV, n_slots=3, seed=3)
+    for rnd in range(2):                                     # the second round crosses the epoch boundary
+        smp_a.sample(3)
+        jobs, _ = smp_b.tail_jobs(3)
+        for k in range(3):
+            eng.step(cur[k], sample_job=jobs[k])
+        torch.cuda.synchronize()
+        for k in range(3):
+            a, b = smp_a.slot_arrays(k), smp_b.slot_arrays(k)
+            UE, UR = int(a["counts"][0]), int(a["counts"][1])
+            assert np.array_equal(a["counts"], b["counts"])
+            for name, n in (("h_gid", B), ("t_gid", B), ("rel_ids", B), ("neg_ids", N * 4), ("ue_id", UE), ("ur_id", UR), ("ue_pos_ptr", UE + 1),
+                            ("ue_pos_adj", 2 * B), ("ue_neg_ptr", UE + 1), ("ue_neg_slot", N * 4), ("ur_ptr", UR + 1), ("ur_edge", B),
+                            ("ue_rec", 8 * UE), ("ur_rec", 8 * UR)):
+                assert np.array_equal(a[name][:n], b[name][:n]), "round %d batch %d: %s differs" % (rnd, k, name)
+        assert torch.equal(smp_a.state[:2], smp_b.state[:2])
+
+
+@pytest.mark.parametrize("graph", [False, True], ids=["eager", "hipGraph"])
+def test_prefetched_groups_fused_trains_exactly_like_the_sampler_launch(graph):
+    """dataloader.PrefetchedGroups(mode='fused'): step k of a group builds batch k of the next group on its own launches - the
+    tables after four groups (sizes 6, 6, 4, 6: a smaller next group, then a LARGER one, which falls back to the launch) equal
+    those of mode='serial' bit for bit, eagerly and replayed from hipGraphs (captured once per group geometry, replayed)."""
+    from dglke_amd.dataloader import DeviceSampler, PrefetchedGroups
+    from dglke_amd.engine import StepEngine
+    rng = np.random.RandomState(2)
+    n_ent, n_rel, B, N = 3000, 30, 256, 64
+    n_train = 9 * B + 3
+    h, r, t = rng.randint(0, n_ent, n_train), rng.randint(0, n_rel, n_train), rng.randint(0, n_ent, n_train)
+    res = []
+    for mode in ("serial", "fused"):
+        torch.manual_seed(4)
+        eng = StepEngine("TransE_l2", n_ent, n_rel, 64, 12.0, 0.1, DEV, False, False, True, 1.0, 1e-6, 3)
+        smp = DeviceSampler(h, r, t, n_ent, B, N, DEV, n_slots=12, seed=9)
+        pg = PrefetchedGroups(smp, eng.step, group_max=6, mode=mode)
+        eng.workspace_for(smp.sample(1)[0])
+        smp.state[:2] = torch.tensor([0, 1], device=DEV)     # (the probe batch above is not part of the run)
+        smp.host_step = 1
+        sizes = [6, 6, 4, 6, 6, 6, 4, 6]
+        for rep in range(2):                                 # the second round replays the graphs captured in the first
+            pg.buf, pg.ready = 0, None
+            pg.prefill(sizes[0])
+            for i in range(len(sizes) - 1):
+                pg.run(sizes[i + 1], graph=graph)
+        torch.cuda.synchronize()
+        res.append((eng.ent.clone(), eng.rel.clone(), eng.ent_state.clone(), smp.state[:2].clone(), smp.host_step))
+    for x, y in zip(res[0][:4], res[1][:4]):
+        assert torch.equal(x, y)
+    assert res[0][4] == res[1][4]

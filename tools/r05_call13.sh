@@ -1,0 +1,19 @@
+#!/bin/bash
+export GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+R=$GRAFT_REPO_ROOT; O=gpurun_out/r05c13; mkdir -p $O
+( timeout 600 python -m pytest tests/test_gpu_sampler.py -m gpu -q --timeout=300 -x 2>&1 | grep -v amdgpu.ids | tail -5 ) > $O/pytest_sampler.log; tail -3 $O/pytest_sampler.log
+for rep in 1 2; do for m in serial fused; do
+  timeout 120 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-configs --no-async-update --hogwild 0 --sampler-mode $m > $O/drv_${m}_$rep.json 2> $O/err_$m.txt
+  python -c "
+import json;d=json.loads(open('$O/drv_${m}_$rep.json').read().strip().splitlines()[-1]);print('driver-shape $m', d['ms_per_step'], d['roofline']['event_ms_per_step'], d['value'], d['mean_loss'])" || tail -5 $O/err_$m.txt
+done; done
+for m in serial fused; do
+  timeout 120 python bench.py --steps 1200 --warmup 120 --no-cpu-baseline --no-configs --no-async-update --hogwild 0 --sampler-mode $m > $O/long_$m.json 2> $O/err_$m.txt
+  python -c "
+import json;d=json.loads(open('$O/long_$m.json').read().strip().splitlines()[-1]);print('long $m', d['ms_per_step'], d['roofline']['event_ms_per_step'], d['value'], d['mean_loss'])" || tail -5 $O/err_$m.txt
+done
+for m in fused; do
+cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $R/$O/prof_$m -- python $R/bench.py --no-cpu-baseline --no-configs --no-async-update --hogwild 0 --steps 1200 --warmup 120 --sampler-mode $m > $R/$O/prof_$m.log 2>&1
+cd $R && python tools/rocpd_stats.py $(ls $O/prof_$m/*/*_results.db | head -1) > $O/kernel_stats_$m.txt 2>&1; echo "== $m"; head -6 $O/kernel_stats_$m.txt | cut -c1-150
+rm -rf $O/prof_$m
+done

@@ -21,7 +21,7 @@ for p in (ROOT, os.path.join(ROOT, "dgl-ke_amd")):
 import numpy as np
 import torch
 
-NAMES = {0: "edge_fwd", 1: "neg_fwd_gemm", 2: "loss", 3: "neg_bwd_gemm", 4: "update(ent)", 5: "edge_bwd", 6: "fwd_fused/gn_reduce", 7: "update(rel)"}
+NAMES = {0: "edge_fwd", 1: "neg_fwd_gemm", 2: "loss", 3: "neg_bwd_gemm", 4: "update(ent)", 5: "edge_bwd", 6: "aux(gn_red/smp_tail)", 7: "update(rel)"}
 PER = 8192
 NK = 8
 
@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--async-update", action="store_true")
     ap.add_argument("--skew", action="store_true", help="heavy-tailed ids (bench.py --skew)")
+    ap.add_argument("--tail", action="store_true", help="every step carries a sampler job (kge_step_fused_sampling): the tail workgroups are kernel id 6")
     ap.add_argument("--per-cu", type=int, default=-1, help="kernel id: wavefronts per CU / SIMD and their life by occupancy class")
     args = ap.parse_args()
     import bench
@@ -58,9 +59,14 @@ def main():
         bufs[tu] = torch.zeros(NK * PER * 8, dtype=torch.int64, device=dev)
         assert fn(bufs[tu].data_ptr()) == 0
     G = args.graph_steps
-    smp = DeviceSampler(h, r, t, w["n_ent"], w["B"], w["N"], dev, n_slots=G, seed=0)
+    smp = DeviceSampler(h, r, t, w["n_ent"], w["B"], w["N"], dev, n_slots=2 * G if args.tail else G, seed=0)
+    cur = smp.sample(G) if args.tail else None
     def run_group():
-        if args.async_update:
+        if args.tail:
+            jobs, _ = smp.tail_jobs(G, slot0=G)
+            for k, b in enumerate(cur):
+                eng.step(b, sample_job=jobs[k])
+        elif args.async_update:
             eng.steps_async(smp.sample())
         else:
             for b in smp.sample():
