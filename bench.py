@@ -86,12 +86,15 @@ def measured_traffic(workload):
     """HBM bytes per step from the rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
     separate passes, tools/pmc_cycle.sh), recorded in profiles/latest_traffic.json for the build that
     produced it; bench.py cannot collect PMC counters itself."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "latest_traffic.json")) as f:
-            d = json.load(f)
-        return d["hbm_bytes_per_step"] if d.get("workload") == workload else None
-    except Exception:
-        return None
+    for name in ("latest_traffic_%s.json" % workload, "latest_traffic.json"):      # (per-workload files: the other BASELINE configs' legs)
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                d = json.load(f)
+            if d.get("workload") == workload:
+                return d["hbm_bytes_per_step"]
+        except Exception:
+            pass
+    return None
 
 
 def profiled_kernels(workload):
@@ -413,6 +416,12 @@ def other_configs(steps=600, timeout_s=150.0, only=None):
                          "algorithmic_bytes_per_step": rf.get("algorithmic_bytes_per_step", rf.get("algorithmic_bytes_per_rank_step")),
                          "frac": rf.get("frac"), "mean_loss": d.get("mean_loss"),
                          "leg_wall_s": round(time.perf_counter() - t0, 1)}
+            # measured fabric bytes per step of this leg (committed PMC passes, profiles/latest_traffic_<leg>.json) and their ratio
+            # to the algorithmic bytes
+            tr = rf.get("traffic") or measured_traffic(name)
+            if tr and res[name]["algorithmic_bytes_per_step"]:
+                res[name]["traffic"] = tr
+                res[name]["traffic_ratio"] = round(tr / res[name]["algorithmic_bytes_per_step"], 3)
             if "mode" in d.get("config", {}):
                 res[name]["mode"] = d["config"]["mode"]
         except subprocess.TimeoutExpired:

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""tools/traffic_json.py FETCH.txt WRITE.txt BUILD WORKLOAD [G] -> profiles/latest_traffic.json
+"""tools/traffic_json.py FETCH.txt WRITE.txt BUILD WORKLOAD [G] [OUT] -> profiles/latest_traffic.json (or OUT, e.g.
+profiles/latest_traffic_<leg>.json: what bench.py reports as that leg's roofline.traffic)
 (per-launch PMC means from tools/rocpd_stats.py --pmc; FETCH_SIZE doubled per MI355X_MICROARCH.md).
 Only the kernels of the training step are summed; the sampler kernel builds G batches per launch
 (G = --graph-steps of the profiled run, default 120) and is added as 1/G of its per-launch traffic."""
@@ -13,12 +14,13 @@ def parse(path):
     return out
 f, w = parse(sys.argv[1]), parse(sys.argv[2])
 G = int(sys.argv[5]) if len(sys.argv) > 5 else 120
-ours = lambda d: {k: (v / G if "sample_plan" in k else v) for k, v in d.items()
+# (once-per-GROUP kernels - the sampler and the a2a engine's routing - count 1 / G of their per-launch traffic)
+ours = lambda d: {k: (v / G if ("sample_plan" in k or "route_" in k) else v) for k, v in d.items()
                   if "at::native" not in k and "rocclr" not in k and "reduce_acc" not in k and "rocprim" not in k
                   and "randperm" not in k and "elementwise" not in k and "anonymous namespace" not in k}
 f, w = ours(f), ours(w)
 tot = sum(2 * v * 1024 for v in f.values()) + sum(v * 1024 for v in w.values())
 json.dump({"build": sys.argv[3], "workload": sys.argv[4], "fetch_kb_per_launch": f, "write_kb_per_launch": w,
            "correction": "FETCH_SIZE x2 (gfx950 counts 128-B requests at 64 B, MI355X_MICROARCH.md HBM section); WRITE_SIZE uncorrected",
-           "hbm_bytes_per_step": tot}, open("profiles/latest_traffic.json", "w"), indent=1)
+           "hbm_bytes_per_step": tot}, open(sys.argv[6] if len(sys.argv) > 6 else "profiles/latest_traffic.json", "w"), indent=1)
 print("hbm MB/step", tot / 1e6)
