@@ -392,7 +392,11 @@ def other_configs(steps=600, timeout_s=150.0, only=None):
     legs = [("distmult_fb15k", ["--workload", "distmult_fb15k"], {}),
             ("complex_wikikg2", ["--workload", "complex_wikikg2"], {}),
             ("rotate_freebase_a2a", ["--workload", "rotate_freebase"], {"KGE_DIST_MODE": "a2a"}),
-            ("rotate_freebase_p2p", ["--workload", "rotate_freebase"], {"KGE_DIST_MODE": "p2p"})]
+            ("rotate_freebase_p2p", ["--workload", "rotate_freebase"], {"KGE_DIST_MODE": "p2p"}),
+            # the N > 1 code path on one GPU: the SAME a2a step with its RCCL collectives kept at world 1 (ids once per group, rows
+            # and gradient messages per step, relation all-gather), kernels + collectives replayed from one hipGraph per group
+            ("rotate_freebase_a2a_forced_exchange", ["--workload", "rotate_freebase"],
+             {"KGE_DIST_MODE": "a2a", "KGE_DIST_FORCE_COLL": "1", "KGE_DIST_PIPELINE": "0"})]
     res = {}
     for name, extra, env_extra in legs:
         if only is not None and name not in only:
@@ -424,6 +428,8 @@ def other_configs(steps=600, timeout_s=150.0, only=None):
                 res[name]["traffic_ratio"] = round(tr / res[name]["algorithmic_bytes_per_step"], 3)
             if "mode" in d.get("config", {}):
                 res[name]["mode"] = d["config"]["mode"]
+            if len(str(d.get("config", {}).get("launch") or "")) in range(1, 40):      # (a2a engine: "graph" / "eager")
+                res[name]["launch"] = d["config"]["launch"]
         except subprocess.TimeoutExpired:
             res[name] = {"error": "leg exceeded %.0f s" % timeout_s}
         except Exception as e:  # noqa: BLE001 - a leg must never hide the headline

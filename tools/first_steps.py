@@ -32,3 +32,12 @@ print("largest gap inside the window: %.2f us after dispatch %d" % (g / 1e3, j -
 for q in range(max(lo, j - 6), min(hi, j + 7)):
     print("  %3d %-44s start %9.2f  dur %7.2f  gap_before %6.2f" % (q - lo, rows[q][0][:44], (rows[q][1] - t0) / 1e3, (rows[q][2] - rows[q][1]) / 1e3,
           (rows[q][1] - rows[q - 1][2]) / 1e3))
+# every kernel between the first dispatch of the window and the end of the trace, by name (round 5: is there a sampler launch among or
+# behind the timed steps?)
+cnt = {}
+for q in range(lo, len(rows)):
+    k = rows[q][0].split("(")[0].replace("void ", "")[:48]
+    cnt[k] = cnt.get(k, 0) + 1
+print("dispatches from the window's first kernel to the end of the trace:")
+for k, v in sorted(cnt.items(), key=lambda kv: -kv[1]):
+    print("  %4d  %s" % (v, k))
