@@ -208,6 +208,21 @@ class DeviceSampler(object):
         self.host_step += n
         return out
 
+    def prepare_tail(self):
+        """what tail_jobs needs once: the scratch buffer and - the jobs read the triples in base-permutation order, their first phase
+        is a chain of dependent memory rounds under a 9-us launch and perm[e] was one of them - permuted copies of the triples.
+        NEVER inside a graph capture: the three gather kernels would become part of the graph and run with every replay (they did:
+        24 us per replayed group, profiles/r05_sampler_tail.txt) - callers that capture call this first."""
+        from . import _lib
+        if getattr(self, "_tail_scratch", None) is not None:
+            return
+        if th.cuda.is_current_stream_capturing():
+            raise _lib.KgeError("DeviceSampler.prepare_tail() must run before the graph capture that uses tail_jobs()")
+        nb = int(_lib.lib().kge_sampler_tail_scratch_bytes(self.B, self.C, self.N, self.n_entities))
+        if self.perm is not None:
+            self._Hp, self._Rp, self._Tp = self.H[self.perm].contiguous(), self.R[self.perm].contiguous(), self.T[self.perm].contiguous()
+        self._tail_scratch = th.zeros(nb, dtype=th.uint8, device=self.dev)
+
     def tail_jobs(self, n, slot0=0):
         """the next `n` batches as JOBS for the training steps' own launches instead of a launch of their own (round 5,
         kge_step_fused_sampling): returns (jobs, batches) - jobs[k] is handed to the step that should build batches[k] (any n steps
@@ -218,13 +233,7 @@ class DeviceSampler(object):
         n, slot0 = int(n), int(slot0)
         if n <= 0 or slot0 < 0 or slot0 + n > self.n_slots:
             raise ValueError("more batches than slots")
-        if getattr(self, "_tail_scratch", None) is None:
-            nb = int(_lib.lib().kge_sampler_tail_scratch_bytes(self.B, self.C, self.N, self.n_entities))
-            self._tail_scratch = th.zeros(nb, dtype=th.uint8, device=self.dev)
-        if self.perm is not None and getattr(self, "_Hp", None) is None:
-            # the jobs read the triples in base-permutation order (copies made once): their first phase is a chain of dependent
-            # memory rounds under a 9-us launch, and perm[e] was one of them
-            self._Hp, self._Rp, self._Tp = self.H[self.perm].contiguous(), self.R[self.perm].contiguous(), self.T[self.perm].contiguous()
+        self.prepare_tail()
         Hs, Rs, Ts = (self._Hp, self._Rp, self._Tp) if self.perm is not None else (self.H, self.R, self.T)
         jobs, out = [], []
         for k in range(n):
@@ -299,6 +308,8 @@ class PrefetchedGroups(object):
         # 'fused': groups of more steps than this keep the launch (its 33 us per 120 batches = 0.28 us per step are less than the
         # 0.25 us per step the tails add to the backward launch; at 20 steps the launch costs 1.25 us per step)
         self.fused_max = int(fused_max)
+        if mode == "fused":
+            sampler.prepare_tail()    # (outside any capture)
         self.side = th.cuda.Stream(device=sampler.dev)      # (its priority makes no difference: profiles/r03_merged_fwd.txt)
         self.buf = 0                  # half holding the batches of the NEXT group to train
         self.ready = None             # DeviceBatch objects in that half

@@ -20,3 +20,4 @@ KGE_LIB=$R/dgl-ke_amd/variants/libkge_tl.so timeout 100 python tools/timeline.py
 KGE_DIST_FORCE_COLL=1 KGE_DIST_MODE=a2a KGE_DIST_OTHER_LEG=0 KGE_DIST_PIPELINE=0 KGE_DIST_EAGER_LEG=1 timeout 200 python bench.py --workload rotate_freebase --steps 600 --warmup 40 --no-cpu-baseline > $O/proxy_forced_exchange.json 2> $O/proxy.err
 python -c "
 import json;d=json.loads(open('$O/proxy_forced_exchange.json').read().strip().splitlines()[-1]);print('proxy', d['ms_per_step'], d.get('a2a_eager'), d['config'].get('launch'))"
+timeout 300 python tools/ab_driver_shape.py 40 2>&1 | grep -v amdgpu.ids | tail -4 > $O/ab_driver_shape.txt; cat $O/ab_driver_shape.txt
