@@ -6,7 +6,8 @@ import json, re, sys
 out = {}
 for line in open(sys.argv[1]):
     m = re.match(r"^(.*?)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s*$", line)
-    if m and ("_kernel" in m.group(1)) and "at::native" not in m.group(1) and "rocprim" not in m.group(1):
+    if m and ("_kernel" in m.group(1)) and "at::native" not in m.group(1) and "rocprim" not in m.group(1) and \
+            "anonymous namespace" not in m.group(1) and "rocclr" not in m.group(1):
         out[m.group(1).strip()] = {"calls": int(m.group(2)), "avg_us": float(m.group(4)), "pct": float(m.group(7))}
 json.dump({"build": sys.argv[2], "workload": sys.argv[3], "kernels": out,
            "source": "rocprofv3 --kernel-trace --stats of `python bench.py --no-cpu-baseline --steps 1200 --warmup 120`"},
