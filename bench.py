@@ -535,7 +535,7 @@ def main():
             plain = args.flags == 0 and not args.force_pairwise
             args.sampler_mode = "fused" if (w["model"] in ("TransE_l2", "DistMult", "ComplEx") and plain and
                                             eng.d_e % (8 if w["model"] == "ComplEx" else 4) == 0 and eng.d_r == eng.d_e) else "serial"
-        pg = PrefetchedGroups(smp, eng.step, group_max=G, mode=args.sampler_mode, fused_max=int(os.environ.get("KGE_FUSED_MAX", "48")))
+        pg = PrefetchedGroups(smp, eng.step, group_max=G, mode=args.sampler_mode, fused_max=int(os.environ.get("KGE_FUSED_MAX", "64")))
 
         def run_groups(lo, hi):          # groups seq[lo:hi]; group i builds the batches of group i + 1 (the last one: of a
             for i in range(lo, hi):      # group like the first timed one, so that K batches are sampled per K timed steps)

@@ -297,7 +297,7 @@ class PrefetchedGroups(object):
 
     sampler: a DeviceSampler with n_slots >= 2 * the largest group; step_fn(batch): enqueues one training step."""
 
-    def __init__(self, sampler, step_fn, group_max=None, mode="serial", fused_max=48):
+    def __init__(self, sampler, step_fn, group_max=None, mode="serial", fused_max=64):
         self.smp, self.step_fn = sampler, step_fn
         self.half = sampler.n_slots // 2 if group_max is None else int(group_max)
         if 2 * self.half > sampler.n_slots:
@@ -305,8 +305,8 @@ class PrefetchedGroups(object):
         if mode not in ("streams", "fork", "fork_tail", "serial", "fused"):
             raise ValueError("mode: streams | fork | fork_tail | serial | fused")
         self.mode = mode
-        # 'fused': groups of more steps than this keep the launch (its 33 us per 120 batches = 0.28 us per step are less than the
-        # 0.25 us per step the tails add to the backward launch; at 20 steps the launch costs 1.25 us per step)
+        # 'fused': groups of more steps than this keep the launch.  Back-to-back groups, us/step launch vs tail (tools/ab_long.py,
+        # profiles/r05_sampler_tail.txt): 20 steps 32.26 / 31.38, 40: 31.52 / 31.22, 60: 31.25 / 31.16, 120: 31.02 / 31.06
         self.fused_max = int(fused_max)
         if mode == "fused":
             sampler.prepare_tail()    # (outside any capture)
