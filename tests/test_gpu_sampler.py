@@ -262,3 +262,21 @@ def test_prefetched_groups_fused_trains_exactly_like_the_sampler_launch(graph):
     for x, y in zip(res[0][:4], res[1][:4]):
         assert torch.equal(x, y)
     assert res[0][4] == res[1][4]
+
+
+def test_prepare_tail_refuses_to_run_inside_a_graph_capture():
+    """the permuted triple copies the tail jobs read are made ONCE, outside any capture: made lazily inside the capture of a group graph
+    (round 5's first version) the three gather kernels were replayed with every group - 24 us per replay"""
+    from dglke_amd import _lib
+    from dglke_amd.dataloader import DeviceSampler
+    rng = np.random.RandomState(0)
+    h, r, t = rng.randint(0, 100, 1000), rng.randint(0, 5, 1000), rng.randint(0, 100, 1000)
+    s = DeviceSampler(h, r, t, 100, 64, 16, DEV, n_slots=4, seed=1)
+    g = torch.cuda.CUDAGraph()
+    with pytest.raises(_lib.KgeError):
+        with torch.cuda.graph(g):
+            s.tail_jobs(2)
+    s.prepare_tail()
+    assert torch.equal(s._Hp, s.H[s.perm]) and s._tail_scratch.numel() > 0
+    jobs, batches = s.tail_jobs(2)                       # (fine now, also while capturing)
+    assert len(jobs) == 2 and jobs[0].pre_permuted == 1 and jobs[1].prev_slot and not jobs[0].prev_slot and jobs[1].advance == 2

@@ -1,4 +1,6 @@
-"""does capturing RCCL collectives into a hipGraph work on this stack? (world = 1, run under `timeout`)"""
+"""(round 5: what this probe ran into was NOT a replay hang - dist.destroy_process_group / ncclCommDestroy wait for every live hipGraph
+that recorded the communicator's collectives; see tools/dbg/rccl_capture_matrix.py, profiles/r05_rccl_capture_diagnosis.txt)
+does capturing RCCL collectives into a hipGraph work on this stack? (world = 1, run under `timeout`)"""
 import os, sys, time, torch, torch.distributed as dist
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
 dev = torch.device("cuda", 0); torch.cuda.set_device(0)

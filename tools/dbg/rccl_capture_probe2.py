@@ -1,4 +1,6 @@
-"""RCCL collectives inside a hipGraph (world 1): does replay work when the host synchronises every k replays?
+"""(round 5: what this probe ran into was NOT a replay hang - dist.destroy_process_group / ncclCommDestroy wait for every live hipGraph
+that recorded the communicator's collectives; see tools/dbg/rccl_capture_matrix.py, profiles/r05_rccl_capture_diagnosis.txt)
+RCCL collectives inside a hipGraph (world 1): does replay work when the host synchronises every k replays?
 (round 2 found that a loop of 100 unsynchronised replays hangs; run under `timeout`)"""
 import os, sys, time, torch, torch.distributed as dist
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29578")
