@@ -280,6 +280,17 @@ class DeviceSampler(object):
         return out
 
 
+class _GraphSeq(object):
+    """hipGraphs replayed one after the other (a group of steps cut in two, PrefetchedGroups.head)"""
+
+    def __init__(self, graphs):
+        self.graphs = graphs
+
+    def replay(self):
+        for g in self.graphs:
+            g.replay()
+
+
 class PrefetchedGroups(object):
     """Groups of training steps over a double-buffered slot array: while group g trains, the batches of group g+1 are built
     into the other half (the prefetching of the reference's sampler workers, dataloader/sampler.py:823-876:
@@ -297,7 +308,7 @@ class PrefetchedGroups(object):
 
     sampler: a DeviceSampler with n_slots >= 2 * the largest group; step_fn(batch): enqueues one training step."""
 
-    def __init__(self, sampler, step_fn, group_max=None, mode="serial", fused_max=64):
+    def __init__(self, sampler, step_fn, group_max=None, mode="serial", fused_max=64, head=0):
         self.smp, self.step_fn = sampler, step_fn
         self.half = sampler.n_slots // 2 if group_max is None else int(group_max)
         if 2 * self.half > sampler.n_slots:
@@ -308,6 +319,7 @@ class PrefetchedGroups(object):
         # 'fused': groups of more steps than this keep the launch.  Back-to-back groups, us/step launch vs tail (tools/ab_long.py,
         # profiles/r05_sampler_tail.txt): 20 steps 32.26 / 31.38, 40: 31.52 / 31.22, 60: 31.25 / 31.16, 120: 31.02 / 31.06
         self.fused_max = int(fused_max)
+        self.head = int(head)         # > 0: a group's graph is cut into [head steps | rest] (see run)
         if mode == "fused":
             sampler.prepare_tail()    # (outside any capture)
         self.side = th.cuda.Stream(device=sampler.dev)      # (its priority makes no difference: profiles/r03_merged_fwd.txt)
@@ -380,9 +392,19 @@ class PrefetchedGroups(object):
                         self.step_fn(b, sample_job=jobs[k] if k < n_next else None)
                     return nb, jobs
                 if graph:
-                    g = th.cuda.CUDAGraph()
-                    with _lib.graph_capture(g):
-                        nxt, jobs = enqueue()
+                    # `head` > 0: the group as TWO graphs, [first `head` steps | rest] - after a pause of the queue the GPU starts
+                    # when the first graph's packets are written instead of the whole group's
+                    head = self.head if 0 < self.head and 2 * self.head <= n_cur else 0
+                    jobs, nxt = self.smp.tail_jobs(n_next, slot0=(self.buf ^ 1) * self.half)
+                    parts = [(0, head), (head, n_cur)] if head else [(0, n_cur)]
+                    gs = []
+                    for lo, hi in parts:
+                        g1 = th.cuda.CUDAGraph()
+                        with _lib.graph_capture(g1):
+                            for k in range(lo, hi):
+                                self.step_fn(self.ready[k], sample_job=jobs[k] if k < n_next else None)
+                        gs.append(g1)
+                    g = _GraphSeq(gs)
                     self.graphs[key] = (g, nxt)
                     self._jobs_alive = getattr(self, "_jobs_alive", []) + [jobs]
                     g.replay()
@@ -403,11 +425,15 @@ class PrefetchedGroups(object):
         else:
             key = (n_cur, self.buf)
             if key not in self.graphs:
-                g = th.cuda.CUDAGraph()
-                with _lib.graph_capture(g):
-                    for b in self.ready:
-                        self.step_fn(b)
-                self.graphs[key] = g
+                head = self.head if 0 < self.head and 2 * self.head <= n_cur else 0
+                gs = []
+                for lo, hi in ([(0, head), (head, n_cur)] if head else [(0, n_cur)]):
+                    g1 = th.cuda.CUDAGraph()
+                    with _lib.graph_capture(g1):
+                        for b in self.ready[lo:hi]:
+                            self.step_fn(b)
+                    gs.append(g1)
+                self.graphs[key] = _GraphSeq(gs)
             self.graphs[key].replay()
         if n_next and self.mode in ("serial", "fused"):
             # 'serial': the sampler launch BEHIND the group's steps on the same stream (it fills the other half of the slots): the

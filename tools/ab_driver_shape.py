@@ -17,13 +17,14 @@ w = dict(bench.WORKLOADS["transe_l2_fb15k"])
 dev = torch.device("cuda", 0)
 h, r, t = bench.synth_triples(w, 0)
 G = 120
-for mode in ("serial", "fused", "serial", "fused"):
+HEAD = [int(x) for x in os.environ.get("AB_HEADS", "0").split(",")]
+for mode, head in [(m, hd) for hd in HEAD for m in ("serial", "fused")] * 2:
     torch.manual_seed(0)
     eng = StepEngine(w["model"], w["n_ent"], w["n_rel"], w["hidden"], w["gamma"], w["lr"], dev, w["de"], w["dr"], w["adv"], w["adv_temp"],
                      w["reg_coef"], w["reg_norm"])
     smp = DeviceSampler(h, r, t, w["n_ent"], w["B"], w["N"], dev, n_slots=2 * G, seed=0)
     eng.workspace_for(smp.sample(1)[0])
-    pg = PrefetchedGroups(smp, eng.step, group_max=G, mode=mode)
+    pg = PrefetchedGroups(smp, eng.step, group_max=G, mode=mode, head=head)
     seq = [120, 20, 20] * (R + 2)
     pg.buf, pg.ready = 0, None
     pg.prefill(seq[0])
@@ -43,6 +44,6 @@ for mode in ("serial", "fused", "serial", "fused"):
             evs.append(ev0.elapsed_time(ev1) * 1e3 / 20)
     torch.cuda.synchronize()
     walls, evs = np.array(walls), np.array(evs)
-    print("%-6s  wall us/step: median %.2f  min %.2f  p90 %.2f   events: median %.2f  min %.2f   (%d timed 20-step groups)"
-          % (mode, np.median(walls), walls.min(), np.percentile(walls, 90), np.median(evs), evs.min(), len(walls)), flush=True)
+    print("%-6s head=%d  wall us/step: median %.2f  min %.2f  p90 %.2f   events: median %.2f  min %.2f   (%d timed 20-step groups)"
+          % (mode, head, np.median(walls), walls.min(), np.percentile(walls, 90), np.median(evs), evs.min(), len(walls)), flush=True)
     del pg, smp, eng
