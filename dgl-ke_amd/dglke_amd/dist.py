@@ -22,11 +22,16 @@ host (no `.cpu()`, no numpy, no count exchange) and all collectives are equal-sp
   rels    packed relation gradients (ids inside) are all-gathered and EVERY rank applies all of them with the same
           merged kernel, so the replicated relation tables stay bit-identical.
 
+Round 5: the request ids of a whole sampled GROUP are exchanged once (`prepare_group`): a step is two exchanges (rows, gradients);
+and a group - routing, id exchange, steps WITH their collectives - replays from one hipGraph (`run_group`; RcclComm's calls can be
+recorded - what looked like a replay hang in rounds 2-4 was ncclCommDestroy waiting for live graphs, `close()`).
+
 `step_pipelined` overlaps the pull of step s+1 (side stream) with the compute of step s under the staleness the
 reference's `--async_update` licenses (tensor_models.py:136-175): the rows of step s+1 are gathered after update
 s-1 and before update s has landed - exact one-step staleness, deterministic.
 
-The routing arithmetic is in `HipOps` (libkge_hip); the collectives in `TorchComm` (torch.distributed: backend nccl = RCCL).
+The routing arithmetic is in `HipOps` (libkge_hip); the collectives in `RcclComm` (librccl called directly) / `TorchComm`
+(torch.distributed: backend nccl = RCCL) / `HostStagedComm` (ranks sharing a GPU).
 CPU tests run the same `DistEngine` under gloo with numpy stand-ins (tests/test_dist_gloo.py); GPU tests run HipOps at
 world 2 with two processes on one device (tests/test_gpu_dist.py).  The product path uses HipOps and refuses host tensors.
 """
@@ -690,7 +695,7 @@ class DistEngine(object):
             self.ops.reset_rel_pads(self.rel_msg, self.d_r, lb.UR)      # host-built plan: UR is exact, the rows behind it are pads
         # The step's kernels between the pull and the push replay from a small hipGraph per (routed batch, cache slot) when
         # precapture() recorded one (opt-in, KGE_DIST_COMPUTE_GRAPH=1: bit-identical, and SLOWER than the six eager launches it
-        # replaces - 180 vs 172 us per step).  The collectives stay eager launches (captured RCCL calls hang on this stack).
+        # replaces - 180 vs 172 us per step).  These small per-step graphs predate run_group (round 5), which records the whole group WITH its collectives.
         if self._cgraphs and not torch.cuda.is_current_stream_capturing():
             g = self._cgraphs.get((id(lb), lb.slot))
             if g is not None:
