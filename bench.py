@@ -181,7 +181,7 @@ def cpu_baseline_reference(w, plans, budget_s=12.0):
     shape = "%s, B=%d N=%d D=%d" % (w["model"], w["B"], w["N"], w["hidden"])
     out = {"value": one["value"], "unit": "edges/s", "cores": one["threads"], "kind": "reference",
            "sample": "%d steps of the same workload (%s) by the reference's own train() / KEModel.forward / backward / update "
-                     "(the six files of SURVEY 8(a), staged unmodified into oracle/_ref; DGL stubbed, sampler excluded on both "
+                     "(the six files of SURVEY 8(a), compiled unmodified into oracle/_ref; DGL stubbed, sampler excluded on both "
                      "sides); intra-op threads = the fastest of the probed counts on this %d-core host"
                      % (one["steps"], shape, nthreads),
            "ms_per_step": round(1e3 * w["B"] / one["value"], 3), "edges_per_s_by_threads": one["edges_per_s_by_threads"],
@@ -196,7 +196,7 @@ def cpu_baseline_reference(w, plans, budget_s=12.0):
             out["ms_per_step"] = round(1e3 * w["B"] / hv, 3)          # aggregate: one step of ANY process every ... ms
             out["sample"] = ("%d steps in %.1f s by %d single-thread processes sharing one KEModel (reference --num_proc %d; %s): "
                              "the reference's own train() / KEModel.forward / backward / update on the six files of SURVEY 8(a), "
-                             "staged unmodified into oracle/_ref (DGL stubbed, sampler excluded on both sides); the "
+                             "compiled unmodified into oracle/_ref (DGL stubbed, sampler excluded on both sides); the "
                              "single-process run with %d intra-op threads: %.0f edges/s"
                              % (hsteps, hwall, procs, procs, shape, one["threads"], one["value"]))
     except Exception as e:  # noqa: BLE001 - the multi-process leg must never hide the single-process number

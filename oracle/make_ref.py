@@ -1,18 +1,20 @@
 #!/usr/bin/env python3
 """Stage the reference's own hot-path modules into oracle/_ref so that the GPU box can TIME THE REFERENCE ITSELF.
 
-*** TEST / MEASUREMENT INFRASTRUCTURE ONLY. ***  Recipe, not sources: the six files SURVEY.md 8(a) names are copied at build()
-time from where they lie under /root/reference into oracle/_ref/ (git-ignored - reference sources never enter this repository's
-history - but NOT gpurun-ignored, so the staged copy travels to the GPU box next to the built libkge_hip.so).  /root/reference
-does not exist on the GPU box; there `stage()` is a no-op and `available()` says whether an earlier build() staged the files.
+*** TEST / MEASUREMENT INFRASTRUCTURE ONLY. ***  Recipe, not sources: the six files SURVEY.md 8(a) names are COMPILED at build()
+time (py_compile: CPython bytecode, the only "build" a pure-Python reference has) from where they lie under /root/reference into
+oracle/_ref/ - binaries only, like a C reference's .so: no reference source text is written anywhere in this repository, and the
+directory is git-ignored (but NOT gpurun-ignored: it travels to the GPU box next to the built libkge_hip.so; same image, same
+interpreter).  /root/reference does not exist on the GPU box; there `stage()` is a no-op and `available()` says whether an earlier
+build() staged the files.
 
-The reference is pure Python on torch + DGL: nothing to compile.  The package skeleton around the six files (the `__init__.py`
+The reference is pure Python on torch + DGL: no native code to compile.  The package skeleton around the six files (the `__init__.py`
 files and the two modules train_pytorch.py imports but the step never calls - `dglke.utils`, `dglke.dataloader`) is written
 here as stubs; DGL itself is replaced by oracle/ref_stub.py.  bench.py's `cpu_baseline` then reports `kind: "reference"`
 (oracle/ref_baseline.py); without the staged files it falls back to the torch-CPU port (`kind: "port"`).
 """
 import os
-import shutil
+import py_compile
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -42,24 +44,31 @@ SKELETON = {
 }
 
 
+def _pyc(f):
+    return os.path.join(DST, "dglke", f[:-3] + ".pyc")          # sourceless module: <name>.pyc next to the package's __init__.py
+
+
 def available():
-    return all(os.path.exists(os.path.join(DST, "dglke", f)) for f in FILES)
+    return all(os.path.exists(_pyc(f)) for f in FILES)
 
 
 def stage(force=False):
-    """copy the six files (when the reference is present: the build container) and write the skeleton; returns True if oracle/_ref
+    """compile the six files (when the reference is present: the build container) and write the skeleton; returns True if oracle/_ref
     is usable afterwards."""
     src_root = os.path.join(REF, "dglke")
     if not os.path.isdir(src_root):
         return available()                     # GPU box: use what an earlier build() staged, or nothing
     if available() and not force:
-        fresh = all(os.path.getmtime(os.path.join(DST, "dglke", f)) >= os.path.getmtime(os.path.join(src_root, f)) for f in FILES)
+        fresh = all(os.path.getmtime(_pyc(f)) >= os.path.getmtime(os.path.join(src_root, f)) for f in FILES)
         if fresh:
             return True
     for f in FILES:
-        d = os.path.join(DST, "dglke", f)
+        d = _pyc(f)
         os.makedirs(os.path.dirname(d), exist_ok=True)
-        shutil.copyfile(os.path.join(src_root, f), d)
+        stale_src = os.path.join(DST, "dglke", f)               # (an earlier version of this recipe staged the .py itself)
+        if os.path.exists(stale_src):
+            os.remove(stale_src)
+        py_compile.compile(os.path.join(src_root, f), cfile=d, dfile="dglke/" + f, doraise=True)
     for f, text in SKELETON.items():
         d = os.path.join(DST, "dglke", f)
         os.makedirs(os.path.dirname(d), exist_ok=True)

@@ -1,5 +1,5 @@
 """bench.py's CPU baseline of kind "reference" (oracle/make_ref.py + oracle/ref_baseline.py): the reference's own six hot-path
-files, staged unmodified into oracle/_ref at build() time, drive the timed CPU step.  These tests pin that what is staged IS the
+files, compiled unmodified (py_compile: sourceless .pyc modules) into oracle/_ref at build() time, drive the timed CPU step.  These tests pin that what is staged IS the
 reference (one golden case reproduced through the staged package) and that the baseline harness runs.  Skipped where neither
 /root/reference nor a staged copy exists."""
 import os
@@ -25,6 +25,11 @@ def test_make_ref_recipe_names_the_six_hot_path_files_and_keeps_them_out_of_git(
     assert "oracle/_ref/" in ign                                     # never committed ...
     gpi = open(os.path.join(ROOT, ".gpurunignore")).read().split()
     assert not any(x.startswith("oracle") for x in gpi)             # ... but it travels to the GPU box
+    if make_ref.stage():                                            # binaries only: no reference source text in the tree
+        staged = [f for _, _, fs in os.walk(make_ref.DST) for f in fs]
+        assert sum(f.endswith(".pyc") for f in staged) == 6
+        own = {"__init__.py", "utils.py"}
+        assert all(f.endswith(".pyc") or f in own for f in staged), staged
 
 
 def test_staged_reference_reproduces_a_golden_step():
