@@ -26,7 +26,7 @@ def test_make_ref_recipe_names_the_six_hot_path_files_and_keeps_them_out_of_git(
     gpi = open(os.path.join(ROOT, ".gpurunignore")).read().split()
     assert not any(x.startswith("oracle") for x in gpi)             # ... but it travels to the GPU box
     if make_ref.stage():                                            # binaries only: no reference source text in the tree
-        staged = [f for _, _, fs in os.walk(make_ref.DST) for f in fs]
+        staged = [f for d, _, fs in os.walk(make_ref.DST) if "__pycache__" not in d for f in fs]
         assert sum(f.endswith(".pyc") for f in staged) == 6
         own = {"__init__.py", "utils.py"}
         assert all(f.endswith(".pyc") or f in own for f in staged), staged
