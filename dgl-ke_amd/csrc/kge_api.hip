@@ -420,8 +420,8 @@ size_t kge_step_workspace_bytes(const kge_hparams *hp, int B, int C, int chunk, 
         add((size_t)TRANSR_GN_GROUPS * CN * d_e);
     }
     if (hp->model == KGE_RESCAL) {   // V = M t, M^T h, M^T GA (no [B, d_r] buffer) + update scratch
-        add(B * d_e); add(B * d_e); add(B * d_e);
-        add((size_t)B * RESCAL_RB); add(UR); add((size_t)UR * RESCAL_RB);
+        add(B * d_e); add(B * d_e * RESCAL_RBN); add(B * d_e * RESCAL_RBN);   // V; parts of M^T h, M^T GA per row block
+        add((size_t)B * RESCAL_RB); add(UR); add((size_t)UR * (RESCAL_RB > RESCAL_RBN ? RESCAL_RB : RESCAL_RBN)); add((size_t)B * RESCAL_RBN);
     }
     else add(B * d_r);            // GR
     add(B); add(B); add(UE); add(UR);           // row_pos, row_neg, reg_ent, reg_rel
@@ -507,11 +507,12 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     const int ga_parts = (!gemm && !(hp->flags & KGE_FLAG_TWO_PASS_PAIR)) ? neg_bwd_lc_splits(hp->model, C, chunk, N, d_e) : 1;
     float *GA = cv.f((size_t)B * d_e * ga_parts), *GN = cv.f((size_t)CN * d_e);
     const bool rescal = hp->model == KGE_RESCAL;
+    const bool rescal_rel = rescal && d_e % 4 == 0;      // RESCAL's passes over M per unique relation (16-byte accesses)
     float *GH = cv.f((size_t)B * d_e), *GT = cv.f((size_t)B * d_e);
-    float *RV = rescal ? cv.f((size_t)B * d_e) : nullptr, *RC1 = rescal ? cv.f((size_t)B * d_e) : nullptr;
-    float *RC2 = rescal ? cv.f((size_t)B * d_e) : nullptr;
+    float *RV = rescal ? cv.f((size_t)B * d_e) : nullptr, *RC1 = rescal ? cv.f((size_t)B * d_e * RESCAL_RBN) : nullptr;
+    float *RC2 = rescal ? cv.f((size_t)B * d_e * RESCAL_RBN) : nullptr;
     float *Rgs = rescal ? cv.f((size_t)B * RESCAL_RB) : nullptr, *Rstd = rescal ? cv.f(b->UR) : nullptr;
-    float *Rreg = rescal ? cv.f((size_t)b->UR * RESCAL_RB) : nullptr;
+    float *Rreg = rescal ? cv.f((size_t)b->UR * (RESCAL_RB > RESCAL_RBN ? RESCAL_RB : RESCAL_RBN)) : nullptr, *Rpp = rescal ? cv.f((size_t)B * RESCAL_RBN) : nullptr;
     float *GR = rescal ? nullptr : cv.f((size_t)B * d_r);
     const bool transr = hp->model == KGE_TRANSR;
     TransRArgs tr{};
@@ -630,12 +631,21 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         KGE_TRY(launch_transr_fwd(tr, s));
     } else if (rescal) {
         // V = M t (always: p = h.V), A = M x with x = h in tail mode (then a second product of the same pass)
-        RescalMatvecArgs m{};
-        m.B = B; m.D = d_e; m.rel = tb->rel; m.ridx = b->rel_ids;
-        m.y1 = tb->ent; m.y1idx = b->t_gid; m.r1 = b->neg_head ? A : RV;
-        if (!b->neg_head) { m.y2 = tb->ent; m.y2idx = b->h_gid; m.r2 = A; }
-        m.pd = tb->ent; m.pdidx = b->h_gid; m.p = P;
-        KGE_TRY(launch_rescal_matvec(m, s));
+        if (!rescal_rel) {               // d_e not a multiple of 4: one pass over M per EDGE
+            RescalMatvecArgs m{};
+            m.B = B; m.D = d_e; m.rel = tb->rel; m.ridx = b->rel_ids;
+            m.y1 = tb->ent; m.y1idx = b->t_gid; m.r1 = b->neg_head ? A : RV;
+            if (!b->neg_head) { m.y2 = tb->ent; m.y2idx = b->h_gid; m.r2 = A; }
+            m.pd = tb->ent; m.pdidx = b->h_gid; m.p = P;
+            KGE_TRY(launch_rescal_matvec(m, s));
+        } else {
+        // (one pass over M per UNIQUE relation of the batch; the row blocks' parts of p are added by a one-thread-per-edge launch)
+        RescalRelFwdArgs m{};
+        m.B = B; m.D = d_e; m.UR = b->UR; m.rel = tb->rel; m.ent = tb->ent; m.hidx = b->h_gid; m.tidx = b->t_gid;
+        m.ur_id = b->ur_id; m.ur_ptr = b->ur_ptr; m.ur_edge = b->ur_edge; m.counts_dev = b->counts_dev;
+        m.V = b->neg_head ? A : RV; m.W = b->neg_head ? nullptr : A; m.ppart = Rpp; m.P = P;
+        KGE_TRY(launch_rescal_rel_fwd(m, s));
+        }
         if (dense_neg) {                 // pairwise fallback kernels read a dense copy of the negative rows
             EdgeFwdArgs nb{};
             nb.B = 0; nb.d_e = d_e; nb.d_r = d_e; nb.model = KGE_DISTMULT; nb.nbase = tb->ent; nb.nidx = nids;
@@ -800,15 +810,18 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         // projection table first: the entity update below changes the h / t rows its rank-1 trace reads
         KGE_TRY(launch_transr_proj_update(tr, s));
     } else if (rescal) {
-        // one pass over M per edge: M^T h and M^T GA;  GH = dp M t (+ M^T GA, tail mode),
-        // GT = dp M^T h (+ M^T GA, head mode);  the relation gradient stays factored (update below)
-        RescalMatvecArgs m{};
-        m.B = B; m.D = d_e; m.rel = tb->rel; m.ridx = b->rel_ids;
-        m.z1 = tb->ent; m.z1idx = b->h_gid; m.c1 = RC1;
-        m.z2 = GA; m.c2 = RC2;
-        KGE_TRY(launch_rescal_matvec(m, s));
-        KGE_TRY(launch_rescal_axpy(dP, Vr, b->neg_head ? nullptr : RC2, B, d_e, GH, s));
-        KGE_TRY(launch_rescal_axpy(dP, RC1, b->neg_head ? RC2 : nullptr, B, d_e, GT, s));
+        // M^T h and M^T GA come out of the relation update's own pass over M (one per unique relation, row-block parts);
+        // GH = dp M t (+ M^T GA, tail mode), GT = dp M^T h (+ M^T GA, head mode) are combined after it;  the relation
+        // gradient stays factored.  (d_e not a multiple of 4: a pass over M per edge for the two products, then the update's own)
+        if (!rescal_rel) {
+            RescalMatvecArgs m{};
+            m.B = B; m.D = d_e; m.rel = tb->rel; m.ridx = b->rel_ids;
+            m.z1 = tb->ent; m.z1idx = b->h_gid; m.c1 = RC1;
+            m.z2 = GA; m.c2 = RC2;
+            KGE_TRY(launch_rescal_matvec(m, s));
+            KGE_TRY(launch_rescal_axpy(dP, Vr, b->neg_head ? nullptr : RC2, B, d_e, GH, s));
+            KGE_TRY(launch_rescal_axpy(dP, RC1, b->neg_head ? RC2 : nullptr, B, d_e, GT, s));
+        }
         if (out && out->g_rel) {        // test / debugging output: materialise dp h t^T + GA x^T + regulariser
             RescalOuterArgs o{};
             o.B = B; o.D = d_e; o.c = dP; o.u = tb->ent; o.uidx = b->h_gid; o.v = tb->ent; o.vidx = b->t_gid;
@@ -826,7 +839,13 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         ru.rel = tb->rel; ru.rel_state = tb->rel_state; ru.ent = tb->ent; ru.hidx = b->h_gid; ru.tidx = b->t_gid;
         ru.dpos = dP; ru.GA = GA; ru.ur_id = b->ur_id; ru.ur_ptr = b->ur_ptr; ru.ur_edge = b->ur_edge;
         ru.counts_dev = b->counts_dev; ru.reg_rel = want4 ? reg_rel : nullptr; ru.acc = acc;
+        if (rescal_rel) { ru.c1p = RC1; ru.c2p = RC2; }
         KGE_TRY(launch_rescal_update_rel(ru, s));
+        if (rescal_rel) {
+            RescalCombineArgs cb{};
+            cb.B = B; cb.D = d_e; cb.neg_head = b->neg_head; cb.dpos = dP; cb.V = Vr; cb.c1p = RC1; cb.c2p = RC2; cb.GH = GH; cb.GT = GT;
+            KGE_TRY(launch_rescal_combine(cb, s));
+        }
     } else if (!transe_fast && !ew_bwd) {
         EdgeBwdArgs eb{};
         eb.src = src_bwd; eb.B = B; eb.d_e = d_e; eb.d_r = d_r; eb.neg_head = b->neg_head; eb.model = hp->model;

@@ -575,6 +575,9 @@ struct RescalOuterArgs {             // G_i = c_i * u_i v_i^T (+ G_i) (+ regular
     float *G;                                // [B, D*D]
 };
 #define RESCAL_RB 8                  // row blocks per relation matrix in the update kernels
+#ifndef RESCAL_RBN
+#define RESCAL_RBN 16                // row blocks per relation matrix in the per-unique-relation passes of the fused step
+#endif
 struct RescalUpdateArgs {            // fused Adagrad of the relation matrices (kge_rescal.hip)
     int B, D, UE, UR, neg_head, reg_norm;
     float lr, eps, reg_coef;
@@ -586,12 +589,30 @@ struct RescalUpdateArgs {            // fused Adagrad of the relation matrices (
     float *inv_std;                  // scratch [UR]
     float *reg_part;                 // scratch [UR, RESCAL_RB] or null (no regularisation value wanted)
     float *reg_rel, *acc;
+    float *c1p, *c2p;                // [B, RESCAL_RBN, D] or null.  Non-null: the Adagrad pass over M also produces the backward's
+                                     // column products M^T h (c1p) and M^T GA (c2p), one part per row block (ONE pass over M)
+};
+struct RescalRelFwdArgs {            // forward products per UNIQUE relation: one pass over M serves every edge of the relation
+    int B, D, UR;
+    const float *rel, *ent; const int64_t *hidx, *tidx;
+    const int64_t *ur_id; const int32_t *ur_ptr, *ur_edge; const int32_t *counts_dev;
+    float *V;                        // [B, D]  M t
+    float *W;                        // [B, D]  M h, or null
+    float *ppart;                    // [B, RESCAL_RBN] parts of p = h . (M t)
+    float *P;                        // [B]
+};
+struct RescalCombineArgs {           // GH = dp V (+ M^T GA, tail mode), GT = dp M^T h (+ M^T GA, head mode) from the row-block parts
+    int B, D, neg_head;
+    const float *dpos, *V, *c1p, *c2p;
+    float *GH, *GT;
 };
 int launch_rescal_matvec(const RescalMatvecArgs &a, hipStream_t s);
 int launch_rescal_axpy(const float *s1, const float *u1, const float *u2, int B, int D, float *out, hipStream_t s,
                        float alpha = 1.f);      // out_i = alpha * s1_i * u1_i + u2_i
 int launch_rescal_outer(const RescalOuterArgs &a, hipStream_t s);
 int launch_rescal_update_rel(const RescalUpdateArgs &a, hipStream_t s);
+int launch_rescal_rel_fwd(const RescalRelFwdArgs &a, hipStream_t s);
+int launch_rescal_combine(const RescalCombineArgs &a, hipStream_t s);
 // ---- TransR (kge_transr.hip) ----
 struct TransRArgs {
     int B, C, chunk, N, De, Dr, neg_head, UR, reg_norm;

@@ -9,6 +9,7 @@
 // (M^T h, M^T GA).  The relation gradient dp h t^T + GA x^T (+ regulariser) is never materialised on the
 // fused path: the relation update kernel rebuilds it per element from the rank-1 factors.
 #include "kge_common.hpp"
+#include <type_traits>
 
 using namespace kge;
 
@@ -358,11 +359,311 @@ __global__ __launch_bounds__(KGE_BLOCK) void rescal_apply_vec_kernel(RescalUpdat
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// fused step, per UNIQUE relation (the batch plan's ur_id / ur_ptr / ur_edge; D % 4 == 0): a relation matrix is streamed from
+// HBM once in the forward and once in the backward + update, however many edges of the batch carry the relation - the per-edge
+// kernel above streams it once per edge and the stand-alone Adagrad pass a third time.
+// Workgroup = (unique relation, row block of RESCAL_RBN); a wavefront owns whole rows, a lane the columns 4 lane + 256 k .. + 3
+// (16-byte accesses); the edges of the relation are taken EG at a time with their vectors in registers (further groups re-read
+// the row block from L2).
+// ---------------------------------------------------------------------------------------------
+#define RESCAL_RMAX ((1024 + RESCAL_RBN - 1) / RESCAL_RBN)     // rows of one block at the widest supported matrix
+#ifndef RESCAL_UNR
+#define RESCAL_UNR 2                 // rows in flight per wavefront in the backward + update pass
+#endif
+#ifndef RESCAL_EG
+#define RESCAL_EG 1                  // edges of a relation whose vectors are held in registers per pass (D <= 512)
+#endif
+
+__device__ __forceinline__ float4 ld4z(const float *p, bool ok) {
+    return ok ? *reinterpret_cast<const float4 *>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+__device__ __forceinline__ float dot4(const float4 &a, const float4 &b, float acc) {
+    return fmaf(a.w, b.w, fmaf(a.z, b.z, fmaf(a.y, b.y, fmaf(a.x, b.x, acc))));
+}
+__device__ __forceinline__ void axpy4(float4 &acc, const float4 &m, float s) {
+    acc.x = fmaf(m.x, s, acc.x); acc.y = fmaf(m.y, s, acc.y); acc.z = fmaf(m.z, s, acc.z); acc.w = fmaf(m.w, s, acc.w);
+}
+
+template <int NC4, int EG, bool W2>
+__global__ __launch_bounds__(KGE_BLOCK) void rescal_rel_fwd_kernel(RescalRelFwdArgs a) {
+    __shared__ float s_h[EG][RESCAL_RMAX];
+    __shared__ float s_p[EG][KGE_WAVES_PER_BLOCK];
+    const int u = blockIdx.x / RESCAL_RBN, rb = blockIdx.x % RESCAL_RBN;
+    if (u >= (a.counts_dev ? a.counts_dev[1] : a.UR)) return;
+    const int D = a.D, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int rows = (D + RESCAL_RBN - 1) / RESCAL_RBN, r0 = rb * rows, r1 = min(D, r0 + rows);
+    const float *M = a.rel + a.ur_id[u] * (int64_t)D * D;
+    const int e0 = a.ur_ptr[u], e1 = a.ur_ptr[u + 1];
+    for (int q0 = e0; q0 < e1; q0 += EG) {
+        int64_t e[EG], ho[EG];
+        bool on[EG];
+        float4 yt[EG][NC4], yh[EG][NC4];
+#pragma unroll
+        for (int g = 0; g < EG; ++g) {
+            on[g] = q0 + g < e1;
+            e[g] = a.ur_edge[on[g] ? q0 + g : q0];
+            ho[g] = a.hidx[e[g]] * (int64_t)D;
+            const float *tp = a.ent + a.tidx[e[g]] * (int64_t)D, *hp = a.ent + ho[g];
+#pragma unroll
+            for (int k = 0; k < NC4; ++k) {
+                const int b = 4 * lane + 256 * k;
+                yt[g][k] = ld4z(tp + b, b < D);
+                yh[g][k] = ld4z(hp + b, W2 && b < D);
+            }
+        }
+        __syncthreads();                               // the previous group's readers of s_h are done
+#pragma unroll
+        for (int g = 0; g < EG; ++g)
+            for (int r = threadIdx.x; r < r1 - r0; r += KGE_BLOCK) s_h[g][r] = a.ent[ho[g] + r0 + r];
+        __syncthreads();
+        float pa[EG];
+#pragma unroll
+        for (int g = 0; g < EG; ++g) pa[g] = 0.f;
+        // two rows per iteration by hand (the wavefront reductions keep the compiler from unrolling a loop of unknown length)
+        for (int r = r0 + wave; r < r1; r += 2 * KGE_WAVES_PER_BLOCK) {
+            const int rB = r + KGE_WAVES_PER_BLOCK;
+            const bool hasB = rB < r1;
+            const float *rowA = M + (int64_t)r * D, *rowB = M + (int64_t)(hasB ? rB : r) * D;
+            float4 mA[NC4], mB[NC4];
+#pragma unroll
+            for (int k = 0; k < NC4; ++k) { const int b = 4 * lane + 256 * k; mA[k] = ld4z(rowA + b, b < D); }
+#pragma unroll
+            for (int k = 0; k < NC4; ++k) { const int b = 4 * lane + 256 * k; mB[k] = ld4z(rowB + b, b < D); }
+#pragma unroll
+            for (int g = 0; g < EG; ++g) {
+                float d1A = 0.f, d2A = 0.f, d1B = 0.f, d2B = 0.f;
+#pragma unroll
+                for (int k = 0; k < NC4; ++k) {
+                    d1A = dot4(mA[k], yt[g][k], d1A); d1B = dot4(mB[k], yt[g][k], d1B);
+                    if (W2) { d2A = dot4(mA[k], yh[g][k], d2A); d2B = dot4(mB[k], yh[g][k], d2B); }
+                }
+                d1A = wave_sum(d1A); d1B = wave_sum(d1B);
+                if (W2) { d2A = wave_sum(d2A); d2B = wave_sum(d2B); }
+                if (lane == 0 && on[g]) {
+                    a.V[e[g] * D + r] = d1A;
+                    if (W2) a.W[e[g] * D + r] = d2A;
+                    pa[g] = fmaf(s_h[g][r - r0], d1A, pa[g]);
+                    if (hasB) {
+                        a.V[e[g] * D + rB] = d1B;
+                        if (W2) a.W[e[g] * D + rB] = d2B;
+                        pa[g] = fmaf(s_h[g][rB - r0], d1B, pa[g]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < EG; ++g) if (lane == 0) s_p[g][wave] = pa[g];
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < EG; ++g)
+            if ((int)threadIdx.x == g && on[g]) {
+                float sp = 0.f;
+#pragma unroll
+                for (int w = 0; w < KGE_WAVES_PER_BLOCK; ++w) sp += s_p[g][w];
+                a.ppart[e[g] * RESCAL_RBN + rb] = sp;
+            }
+    }
+}
+
+__global__ void rescal_psum_kernel(RescalRelFwdArgs a) {       // p = the row blocks' parts in a fixed order
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.B) return;
+    float sp = 0.f;
+#pragma unroll
+    for (int k = 0; k < RESCAL_RBN; ++k) sp += a.ppart[(int64_t)i * RESCAL_RBN + k];
+    a.P[i] = sp;
+}
+
+int launch_rescal_rel_fwd(const RescalRelFwdArgs &a, hipStream_t s) {
+    if (a.B == 0 || a.UR == 0) return KGE_OK;
+    if (a.D % 4 != 0 || a.D > 1024) return KGE_ERR_ARG;
+    const dim3 g(a.UR * RESCAL_RBN), b(KGE_BLOCK);
+    const bool w2 = a.W != nullptr;
+#define RF(NC4, EG) do { if (w2) hipLaunchKernelGGL((rescal_rel_fwd_kernel<NC4, EG, true>), g, b, 0, s, a); \
+                         else hipLaunchKernelGGL((rescal_rel_fwd_kernel<NC4, EG, false>), g, b, 0, s, a); } while (0)
+    if (a.D <= 256) RF(1, RESCAL_EG);
+    else if (a.D <= 512) RF(2, RESCAL_EG);
+    else RF(4, 1);
+#undef RF
+    hipLaunchKernelGGL(rescal_psum_kernel, dim3((a.B + 255) / 256), dim3(256), 0, s, a);
+    return check_launch_r();
+}
+
+// backward + Adagrad in ONE pass over the row block: the column products M^T h_e and M^T GA_e of every edge of the relation
+// (parts per row block, summed by rescal_combine) from the rows as loaded, then the rows' update
+//   M -= lr / std * sum_e (dp_e h_e t_e^T + GA_e x_e^T (+ R))      (edges in plan order, like rescal_apply)
+// with the last EG edges' t / x vectors in registers and the earlier ones (relations with more than EG edges) read through L1.
+template <int NC4, int EG>
+__global__ __launch_bounds__(KGE_BLOCK) void rescal_rel_bwd_apply_kernel(RescalUpdateArgs a) {
+    __shared__ float s_h[EG][RESCAL_RMAX], s_g[EG][RESCAL_RMAX];
+    __shared__ float s_c[KGE_WAVES_PER_BLOCK][NC4 * 256];
+    __shared__ float red[KGE_WAVES_PER_BLOCK];
+    const int u = blockIdx.x / RESCAL_RBN, rb = blockIdx.x % RESCAL_RBN;
+    if (u >= (a.counts_dev ? a.counts_dev[1] : a.UR)) return;
+    const int D = a.D, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int rows = (D + RESCAL_RBN - 1) / RESCAL_RBN, r0 = rb * rows, r1 = min(D, r0 + rows);
+    const int e0 = a.ur_ptr[u], e1 = a.ur_ptr[u + 1];
+    float *M = a.rel + a.ur_id[u] * (int64_t)D * D;
+    const bool reg = a.reg_coef > 0.f && a.reg_norm > 0;
+    const float cnt = (float)(e1 - e0), step = -a.lr * a.inv_std[u];
+    const int ngr = (e1 - e0 + EG - 1) / EG;
+    float rv = 0.f;
+    for (int j = 0; j < ngr; ++j) {
+        const bool last = j == ngr - 1;
+        const int qb = e0 + j * EG;
+        int64_t e[EG], ho[EG], go[EG];
+        bool on[EG];
+        float dp[EG];
+        float4 tv[EG][NC4], xv[EG][NC4];
+#pragma unroll
+        for (int g = 0; g < EG; ++g) {
+            on[g] = qb + g < e1;
+            e[g] = a.ur_edge[on[g] ? qb + g : qb];
+            ho[g] = a.hidx[e[g]] * (int64_t)D;
+            go[g] = e[g] * (int64_t)D;
+            dp[g] = on[g] ? a.dpos[e[g]] : 0.f;
+            const int64_t to = a.tidx[e[g]] * (int64_t)D, xo = a.neg_head ? to : ho[g];
+#pragma unroll
+            for (int k = 0; k < NC4; ++k) {
+                const int b = 4 * lane + 256 * k;
+                tv[g][k] = ld4z(a.ent + to + b, last && on[g] && b < D);
+                xv[g][k] = ld4z(a.ent + xo + b, last && on[g] && b < D);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < EG; ++g)
+            for (int r = threadIdx.x; r < r1 - r0; r += KGE_BLOCK) {
+                s_h[g][r] = on[g] ? a.ent[ho[g] + r0 + r] : 0.f;
+                s_g[g][r] = on[g] ? a.GA[go[g] + r0 + r] : 0.f;
+            }
+        __syncthreads();
+        float4 c1[EG][NC4], c2[EG][NC4];
+#pragma unroll
+        for (int g = 0; g < EG; ++g)
+#pragma unroll
+            for (int k = 0; k < NC4; ++k) { c1[g][k] = make_float4(0.f, 0.f, 0.f, 0.f); c2[g][k] = c1[g][k]; }
+        // one row: column products from the row as loaded, then (last group) its update.  EARLIER: the relation has edges before
+        // the register group - a variable-length inner loop, kept out of the common instance so that its row loop unrolls
+        auto do_row = [&](int r, auto earlier) {
+            constexpr bool EARLIER = decltype(earlier)::value;
+            float *row = M + (int64_t)r * D;
+            float4 m[NC4];
+            float hr[EG], gr[EG];
+#pragma unroll
+            for (int k = 0; k < NC4; ++k) { const int b = 4 * lane + 256 * k; m[k] = ld4z(row + b, b < D); }
+#pragma unroll
+            for (int g = 0; g < EG; ++g) {
+                hr[g] = s_h[g][r - r0]; gr[g] = s_g[g][r - r0];
+#pragma unroll
+                for (int k = 0; k < NC4; ++k) { axpy4(c1[g][k], m[k], hr[g]); axpy4(c2[g][k], m[k], gr[g]); }
+            }
+            if (last) {
+                float4 gk[NC4];
+#pragma unroll
+                for (int k = 0; k < NC4; ++k) {
+                    gk[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (reg) {
+                        gk[k].x = cnt * reg_grad(m[k].x, a.reg_coef, a.reg_norm); gk[k].y = cnt * reg_grad(m[k].y, a.reg_coef, a.reg_norm);
+                        gk[k].z = cnt * reg_grad(m[k].z, a.reg_coef, a.reg_norm); gk[k].w = cnt * reg_grad(m[k].w, a.reg_coef, a.reg_norm);
+                        rv += reg_val(m[k].x, a.reg_norm) + reg_val(m[k].y, a.reg_norm) + reg_val(m[k].z, a.reg_norm) +
+                              reg_val(m[k].w, a.reg_norm);
+                    }
+                }
+                if constexpr (EARLIER)
+                    for (int q = e0; q < qb; ++q) {        // edges before the register group (> EG edges of one relation)
+                        const int64_t eq = a.ur_edge[q];
+                        const int64_t hq = a.hidx[eq] * (int64_t)D, tq = a.tidx[eq] * (int64_t)D, xq = a.neg_head ? tq : hq;
+                        const float dh = a.dpos[eq] * a.ent[hq + r], gq = a.GA[eq * (int64_t)D + r];
+#pragma unroll
+                        for (int k = 0; k < NC4; ++k) {
+                            const int b = 4 * lane + 256 * k;
+                            const float4 t4 = ld4z(a.ent + tq + b, b < D), x4 = ld4z(a.ent + xq + b, b < D);
+                            gk[k].x = fmaf(dh, t4.x, fmaf(gq, x4.x, gk[k].x)); gk[k].y = fmaf(dh, t4.y, fmaf(gq, x4.y, gk[k].y));
+                            gk[k].z = fmaf(dh, t4.z, fmaf(gq, x4.z, gk[k].z)); gk[k].w = fmaf(dh, t4.w, fmaf(gq, x4.w, gk[k].w));
+                        }
+                    }
+#pragma unroll
+                for (int g = 0; g < EG; ++g) {
+                    const float dh = dp[g] * hr[g];        // (an absent edge of the group: dp = 0, GA = 0, vectors = 0)
+#pragma unroll
+                    for (int k = 0; k < NC4; ++k) {
+                        gk[k].x = fmaf(dh, tv[g][k].x, fmaf(gr[g], xv[g][k].x, gk[k].x));
+                        gk[k].y = fmaf(dh, tv[g][k].y, fmaf(gr[g], xv[g][k].y, gk[k].y));
+                        gk[k].z = fmaf(dh, tv[g][k].z, fmaf(gr[g], xv[g][k].z, gk[k].z));
+                        gk[k].w = fmaf(dh, tv[g][k].w, fmaf(gr[g], xv[g][k].w, gk[k].w));
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < NC4; ++k) {
+                    const int b = 4 * lane + 256 * k;
+                    if (b < D)
+                        *reinterpret_cast<float4 *>(row + b) = make_float4(fmaf(step, gk[k].x, m[k].x), fmaf(step, gk[k].y, m[k].y),
+                                                                           fmaf(step, gk[k].z, m[k].z), fmaf(step, gk[k].w, m[k].w));
+                }
+            }
+        };
+        if (qb > e0) {
+            for (int r = r0 + wave; r < r1; r += KGE_WAVES_PER_BLOCK) do_row(r, std::true_type{});
+        } else {
+#pragma unroll RESCAL_UNR
+            for (int r = r0 + wave; r < r1; r += KGE_WAVES_PER_BLOCK) do_row(r, std::false_type{});
+        }
+        // column products of this row block: the four wavefronts' sums in a fixed order
+#pragma unroll
+        for (int g = 0; g < EG; ++g)
+#pragma unroll
+            for (int which = 0; which < 2; ++which) {
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < NC4; ++k)
+                    *reinterpret_cast<float4 *>(&s_c[wave][4 * lane + 256 * k]) = which ? c2[g][k] : c1[g][k];
+                __syncthreads();
+                if (on[g]) {
+                    float *out = (which ? a.c2p : a.c1p) + (e[g] * RESCAL_RBN + rb) * (int64_t)D;
+                    for (int b = threadIdx.x; b < D; b += KGE_BLOCK) {
+                        float sc = 0.f;
+#pragma unroll
+                        for (int w = 0; w < KGE_WAVES_PER_BLOCK; ++w) sc += s_c[w][b];
+                        out[b] = sc;
+                    }
+                }
+            }
+    }
+    if (a.reg_part) {
+        const float tot = reg ? block_sum(rv, red) : 0.f;
+        if (threadIdx.x == 0) a.reg_part[(int64_t)u * RESCAL_RBN + rb] = a.reg_coef * tot * cnt;
+    }
+}
+
+__global__ __launch_bounds__(KGE_BLOCK) void rescal_combine_kernel(RescalCombineArgs a) {     // one wavefront per edge
+    const int64_t i = (int64_t)blockIdx.x * KGE_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (i >= a.B) return;
+    const int lane = threadIdx.x & 63, D = a.D;
+    const float dp = a.dpos[i];
+    const float *p1 = a.c1p + i * RESCAL_RBN * (int64_t)D, *p2 = a.c2p + i * RESCAL_RBN * (int64_t)D;
+    for (int b = lane; b < D; b += 64) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < RESCAL_RBN; ++k) { s1 += p1[(int64_t)k * D + b]; s2 += p2[(int64_t)k * D + b]; }
+        a.GH[i * D + b] = dp * a.V[i * D + b] + (a.neg_head ? 0.f : s2);
+        a.GT[i * D + b] = dp * s1 + (a.neg_head ? s2 : 0.f);
+    }
+}
+
+int launch_rescal_combine(const RescalCombineArgs &a, hipStream_t s) {
+    if (a.B == 0) return KGE_OK;
+    hipLaunchKernelGGL(rescal_combine_kernel, dim3((a.B + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK), dim3(KGE_BLOCK), 0, s, a);
+    return check_launch_r();
+}
+
 __global__ void rescal_reg_finalize_kernel(RescalUpdateArgs a) {
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= (a.counts_dev ? a.counts_dev[1] : a.UR)) return;
     float v = 0.f;
-    for (int k = 0; k < RESCAL_RB; ++k) v += a.reg_part[(int64_t)u * RESCAL_RB + k];
+    const int np = (a.c1p && a.c2p) ? RESCAL_RBN : RESCAL_RB;      // parts per relation as the pass that wrote them laid them out
+    for (int k = 0; k < np; ++k) v += a.reg_part[(int64_t)u * np + k];
     if (a.reg_rel) a.reg_rel[u] = v;
     if (a.acc) {
         float *slot = &a.acc[3 * KGE_ACC_SLOTS + (int)((u + a.UE) & (KGE_ACC_SLOTS - 1))];
@@ -376,8 +677,13 @@ int launch_rescal_update_rel(const RescalUpdateArgs &a, hipStream_t s) {
     if (reg) hipLaunchKernelGGL(rescal_edge_sq_reg_kernel, dim3(a.B * RESCAL_RB), dim3(KGE_BLOCK), 0, s, a);
     else hipLaunchKernelGGL(rescal_edge_sq_kernel, dim3((a.B + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK), dim3(KGE_BLOCK), 0, s, a);
     hipLaunchKernelGGL(rescal_rel_state_kernel, dim3((a.UR + 255) / 256), dim3(256), 0, s, a, reg ? RESCAL_RB : 1);
-    const dim3 ga(a.UR * RESCAL_RB), ba(KGE_BLOCK);
-    if (a.D % 4 == 0) {
+    const dim3 ga(a.UR * RESCAL_RB), ba(KGE_BLOCK), gn(a.UR * RESCAL_RBN);
+    if (a.c1p && a.c2p) {                                  // backward products + update in one pass per unique relation
+        if (a.D % 4 != 0 || a.D > 1024) return KGE_ERR_ARG;
+        if (a.D <= 256) hipLaunchKernelGGL((rescal_rel_bwd_apply_kernel<1, RESCAL_EG>), gn, ba, 0, s, a);
+        else if (a.D <= 512) hipLaunchKernelGGL((rescal_rel_bwd_apply_kernel<2, RESCAL_EG>), gn, ba, 0, s, a);
+        else hipLaunchKernelGGL((rescal_rel_bwd_apply_kernel<4, 1>), gn, ba, 0, s, a);
+    } else if (a.D % 4 == 0) {
         int tpr = 64;                                      // >= one wavefront per row: the row factors stay uniform
         while (tpr * 4 < a.D) tpr *= 2;
         hipLaunchKernelGGL(rescal_apply_vec_kernel, ga, ba, 0, s, a, tpr);
