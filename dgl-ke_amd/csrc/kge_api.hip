@@ -418,6 +418,7 @@ size_t kge_step_workspace_bytes(const kge_hparams *hp, int B, int C, int chunk, 
         add((size_t)B * d_e * d_r);
         add(B); add(B); add(UR); add(UR);
         add((size_t)TRANSR_GN_GROUPS * CN * d_e);
+        add((size_t)B * ((d_e + 63) / 64) * ((d_r + 63) / 64));       // sum of squares per 64 x 64 tile of the projection gradients
     }
     if (hp->model == KGE_RESCAL) {   // V = M t, M^T h, M^T GA (no [B, d_r] buffer) + update scratch
         add(B * d_e); add(B * d_e * RESCAL_RBN); add(B * d_e * RESCAL_RBN);   // V; parts of M^T h, M^T GA per row block
@@ -528,6 +529,7 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         tr.gs0 = cv.f(B); tr.gs1 = cv.f(B); tr.k0 = cv.f(b->UR); tr.k1 = cv.f(b->UR);
         tr.nG = chunk < TRANSR_GN_GROUPS ? chunk : TRANSR_GN_GROUPS;
         tr.GNp = cv.f((size_t)TRANSR_GN_GROUPS * CN * d_e);
+        tr.gs1p = cv.f((size_t)B * ((d_e + 63) / 64) * ((d_r + 63) / 64));
     }
     float *row_pos = cv.f(B), *row_neg = cv.f(B), *reg_ent = cv.f(b->UE), *reg_rel = cv.f(b->UR);
     float *GNp = (neg_bwd_lc_supported(hp->model, d_e) && !(hp->flags & KGE_FLAG_TWO_PASS_PAIR))

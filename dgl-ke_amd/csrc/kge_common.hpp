@@ -627,9 +627,12 @@ struct TransRArgs {
     const float *dpos;
     const int64_t *ur_id; const int32_t *ur_ptr, *ur_edge, *counts_dev;
     float *gs0, *gs1, *k0, *k1;      // [B], [B], [UR], [UR] scratch of the projection update
+    float *gs1p;                     // [B, tiles of the D_e x D_r matrix]: sum of squares of every tile of GP, written by its producer
     int nG; float *GNp;              // split-K groups of the negative-row gradient and their partial tiles [nG, C*N, De]
 };
+#ifndef TRANSR_GN_GROUPS
 #define TRANSR_GN_GROUPS 16
+#endif
 int launch_transr_pos(const TransRArgs &a, hipStream_t s);
 int launch_transr_fwd(const TransRArgs &a, hipStream_t s);
 int launch_transr_bwd(const TransRArgs &a, hipStream_t s);

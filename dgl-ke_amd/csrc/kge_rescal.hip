@@ -93,10 +93,111 @@ __global__ __launch_bounds__(KGE_BLOCK) void rescal_matvec_kernel(RescalMatvecAr
     }
 }
 
+// the same pass with 16-byte accesses (columns % 4 == 0): a lane owns the columns 4 lane + 256 k .. + 3
+template <int NC4>
+__global__ __launch_bounds__(KGE_BLOCK) void rescal_matvec4_kernel(RescalMatvecArgs a) {
+    __shared__ float colsum[2][KGE_WAVES_PER_BLOCK][NC4 * 256];
+    __shared__ float pred[KGE_WAVES_PER_BLOCK];
+    const int i = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int D = a.D, Dc = a.Dc > 0 ? a.Dc : a.D;
+    const float *M = a.rel + (a.ridx ? a.ridx[i] : (int64_t)i) * (int64_t)D * Dc;
+    auto vec = [&](const float *base, const int64_t *idx, int len) -> const float * {
+        return base ? base + (idx ? idx[i] : (int64_t)i) * (int64_t)len : nullptr;
+    };
+    const float *y1 = vec(a.y1, a.y1idx, Dc), *y2 = vec(a.y2, a.y2idx, Dc);
+    const float *z1 = vec(a.z1, a.z1idx, D), *z2 = vec(a.z2, a.z2idx, D);
+    const float *pd = vec(a.pd, a.pdidx, D);
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float pacc = 0.f;
+    float4 y1v[NC4], y2v[NC4], c1[NC4], c2[NC4];
+#pragma unroll
+    for (int k = 0; k < NC4; ++k) {
+        const int b = 4 * lane + 256 * k;
+        y1v[k] = (y1 && b < Dc) ? *reinterpret_cast<const float4 *>(y1 + b) : zero4;
+        y2v[k] = (y2 && b < Dc) ? *reinterpret_cast<const float4 *>(y2 + b) : zero4;
+        c1[k] = zero4; c2[k] = zero4;
+    }
+    const bool rowdots = a.r1 || a.r2 || a.p;
+    // U rows of this wavefront per iteration, all requested before the first is used (a wavefront walks D / 4 rows one after the
+    // other: with one row in flight the pass is a chain of round trips).  Rows past the matrix are clamped and dropped.
+    constexpr int U = NC4 == 1 ? 8 : (NC4 == 2 ? 4 : 2);
+    for (int rbase = wave; rbase < D; rbase += U * KGE_WAVES_PER_BLOCK) {
+        float4 m[U][NC4];
+        float zz1[U], zz2[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int r = rbase + j * KGE_WAVES_PER_BLOCK, rc = min(r, D - 1);
+            const float *row = M + (int64_t)rc * Dc;
+#pragma unroll
+            for (int k = 0; k < NC4; ++k) {
+                const int b = 4 * lane + 256 * k;
+                m[j][k] = (b < Dc && r < D) ? *reinterpret_cast<const float4 *>(row + b) : zero4;
+            }
+            zz1[j] = (z1 && r < D) ? z1[rc] : 0.f;
+            zz2[j] = (z2 && r < D) ? z2[rc] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int r = rbase + j * KGE_WAVES_PER_BLOCK;
+            float d1 = 0.f, d2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < NC4; ++k) {
+                const float4 mm = m[j][k];
+                d1 = fmaf(mm.w, y1v[k].w, fmaf(mm.z, y1v[k].z, fmaf(mm.y, y1v[k].y, fmaf(mm.x, y1v[k].x, d1))));
+                d2 = fmaf(mm.w, y2v[k].w, fmaf(mm.z, y2v[k].z, fmaf(mm.y, y2v[k].y, fmaf(mm.x, y2v[k].x, d2))));
+                c1[k].x = fmaf(mm.x, zz1[j], c1[k].x); c1[k].y = fmaf(mm.y, zz1[j], c1[k].y);
+                c1[k].z = fmaf(mm.z, zz1[j], c1[k].z); c1[k].w = fmaf(mm.w, zz1[j], c1[k].w);
+                c2[k].x = fmaf(mm.x, zz2[j], c2[k].x); c2[k].y = fmaf(mm.y, zz2[j], c2[k].y);
+                c2[k].z = fmaf(mm.z, zz2[j], c2[k].z); c2[k].w = fmaf(mm.w, zz2[j], c2[k].w);
+            }
+            if (rowdots) {
+                d1 = wave_sum(d1); d2 = wave_sum(d2);
+                if (lane == 0 && r < D) {
+                    if (a.r1) a.r1[(int64_t)i * D + r] = d1;
+                    if (a.r2) a.r2[(int64_t)i * D + r] = d2;
+                    if (pd) pacc = fmaf(pd[r], d1, pacc);
+                }
+            }
+        }
+    }
+    if (a.p) {
+        if (lane == 0) pred[wave] = pacc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float sp = 0.f;
+#pragma unroll
+            for (int w = 0; w < KGE_WAVES_PER_BLOCK; ++w) sp += pred[w];
+            a.p[i] = sp;
+        }
+    }
+    if (a.c1 || a.c2) {
+#pragma unroll
+        for (int k = 0; k < NC4; ++k) {
+            *reinterpret_cast<float4 *>(&colsum[0][wave][4 * lane + 256 * k]) = c1[k];
+            *reinterpret_cast<float4 *>(&colsum[1][wave][4 * lane + 256 * k]) = c2[k];
+        }
+        __syncthreads();
+        for (int b = threadIdx.x; b < Dc; b += KGE_BLOCK) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < KGE_WAVES_PER_BLOCK; ++w) { s1 += colsum[0][w][b]; s2 += colsum[1][w][b]; }
+            if (a.c1) a.c1[(int64_t)i * Dc + b] = s1;
+            if (a.c2) a.c2[(int64_t)i * Dc + b] = s2;
+        }
+    }
+}
+
 int launch_rescal_matvec(const RescalMatvecArgs &a, hipStream_t s) {
     if (a.B == 0) return KGE_OK;
     const dim3 g(a.B), b(KGE_BLOCK);
     const int cols = a.Dc > 0 ? a.Dc : a.D;
+    if (cols % 4 == 0 && cols <= 1024) {
+        if (cols <= 256) hipLaunchKernelGGL(rescal_matvec4_kernel<1>, g, b, 0, s, a);
+        else if (cols <= 512) hipLaunchKernelGGL(rescal_matvec4_kernel<2>, g, b, 0, s, a);
+        else hipLaunchKernelGGL(rescal_matvec4_kernel<4>, g, b, 0, s, a);
+        return check_launch_r();
+    }
     if (cols <= 256) hipLaunchKernelGGL(rescal_matvec_kernel<4>, g, b, 0, s, a);
     else if (cols <= 512) hipLaunchKernelGGL(rescal_matvec_kernel<8>, g, b, 0, s, a);
     else if (cols <= 1024) hipLaunchKernelGGL(rescal_matvec_kernel<16>, g, b, 0, s, a);

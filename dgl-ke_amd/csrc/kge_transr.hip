@@ -24,25 +24,53 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 static inline int check_launch_t() { return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH; }
 
+// Operand loads may return RAW data (sign bytes + a scale) that is converted to fp32 only when it is written to LDS, one slab
+// later: a conversion inside the load would make the wavefront wait for the load before the slab's MFMAs instead of under them
+// (seen in the ISA as a vmcnt(0) right after the prefetch; profiles/r05_transr_rescal.txt).
+struct Sgn4 { int w; float s; };                 // four sign bytes (one aligned 32-bit word) times a scale
+struct Sgn1 { signed char z; float s; };
+__device__ __forceinline__ float4 cvt_op(const float4 &v) { return v; }
+__device__ __forceinline__ float cvt_op(float v) { return v; }
+__device__ __forceinline__ float4 cvt_op(const Sgn4 &v) {
+    return make_float4(v.s * (float)(signed char)(v.w & 0xff), v.s * (float)(signed char)((v.w >> 8) & 0xff),
+                       v.s * (float)(signed char)((v.w >> 16) & 0xff), v.s * (float)(signed char)(v.w >> 24));
+}
+__device__ __forceinline__ float cvt_op(const Sgn1 &v) { return v.s * (float)v.z; }
+
+__device__ __forceinline__ float block_sum_t(float v, float *red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < KGE_WAVES_PER_BLOCK; ++w) s += red[w];
+    return s;
+}
+
 // one K sweep of a 64 x 64 tile: acc[ct][r] = C[wave*16 + 4*(lane/16) + r][ct*16 + lane%16].
-// loadA(row, k) / loadB(k, col) return the (zero-padded) operand elements; AKF / BKF say whether consecutive
+// loadA(row, k0, kk) / loadB(k0, kk, col) return the (zero-padded) operand elements at reduction index k0 + kk (k0 = the slab's
+// first index, uniform over the workgroup: index arithmetic on it stays on the scalar unit); AKF / BKF say whether consecutive
 // threads should walk the reduction index (operand rows contiguous along k) or the tile row / column.
 // Software pipeline: the global loads of slab s+1 are issued BEFORE the MFMAs of slab s and land in the other LDS
 // buffer after them - one barrier per slab, load latency under the matrix work (the single-buffered version
 // exposed a full global-load round trip per 16-deep slab: 50 TFLOP/s).
-template <bool AKF, bool BKF, class LA, class LB>
-__device__ __forceinline__ void tile_sweep(f32x4 (&acc)[4], int Ktot, LA loadA, LB loadB, float (*As)[TR_K][TR_LD],
-                                           float (*Bs)[TR_K][TR_LD]) {
+// NCT: the 16-column blocks of the tile this wavefront multiplies (0: none - its rows, or the whole tile, hold no real data; it
+// still takes part in the loads and barriers).  A 200-wide operand fills 13 of the 16 blocks of its four tiles.
+template <bool AKF, bool BKF, int NCT, class LA, class LB>
+__device__ __forceinline__ void tile_sweep_n(f32x4 (&acc)[4], int Ktot, LA loadA, LB loadB, float (*As)[TR_K][TR_LD],
+                                             float (*Bs)[TR_K][TR_LD]) {
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63, m = lane & 15, q = lane >> 4;
-    float av[4], bv[4];
+    decltype(loadA(0, 0, 0)) av[4];
+    decltype(loadB(0, 0, 0)) bv[4];
     auto gload = [&](int k0) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int lin = t + KGE_BLOCK * e;
             const int ar = AKF ? lin >> 4 : lin & 63, ak = AKF ? lin & 15 : lin >> 6;
             const int bc = BKF ? lin >> 4 : lin & 63, bk = BKF ? lin & 15 : lin >> 6;
-            av[e] = loadA(ar, k0 + ak);
-            bv[e] = loadB(k0 + bk, bc);
+            av[e] = loadA(ar, k0, ak);
+            bv[e] = loadB(k0, bk, bc);
         }
     };
     if (Ktot > 0) gload(0);                    // (an empty reduction must not touch the operands at all)
@@ -54,16 +82,18 @@ __device__ __forceinline__ void tile_sweep(f32x4 (&acc)[4], int Ktot, LA loadA, 
             const int lin = t + KGE_BLOCK * e;
             const int ar = AKF ? lin >> 4 : lin & 63, ak = AKF ? lin & 15 : lin >> 6;
             const int bc = BKF ? lin >> 4 : lin & 63, bk = BKF ? lin & 15 : lin >> 6;
-            As[buf][ak][ar] = av[e];
-            Bs[buf][bk][bc] = bv[e];
+            As[buf][ak][ar] = cvt_op(av[e]);
+            Bs[buf][bk][bc] = cvt_op(bv[e]);
         }
         __syncthreads();
         if (k0 + TR_K < Ktot) gload(k0 + TR_K);
+        if constexpr (NCT > 0) {
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-            const float a = As[buf][4 * s4 + q][wave * 16 + m];
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const float a = As[buf][4 * s4 + q][wave * 16 + m];
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) acc[ct] = MFMA16(a, Bs[buf][4 * s4 + q][ct * 16 + m], acc[ct]);
+                for (int ct = 0; ct < NCT; ++ct) acc[ct] = MFMA16(a, Bs[buf][4 * s4 + q][ct * 16 + m], acc[ct]);
+            }
         }
     }
 }
@@ -71,38 +101,59 @@ __device__ __forceinline__ void tile_sweep(f32x4 (&acc)[4], int Ktot, LA loadA, 
 // Same sweep with 16-byte operand loads (D_e % 4 == 0 and D_r % 4 == 0): every thread fetches ONE float4 (or four
 // sign bytes as one 32-bit word) per operand and slab instead of four scalars.  AROW / BROW: the four elements are
 // consecutive tile rows (columns) at one k - a float4 store into LDS; otherwise they are consecutive k of one row.
-template <bool AROW, bool BROW, class LA, class LB>
-__device__ __forceinline__ void tile_sweep4(f32x4 (&acc)[4], int Ktot, LA loadA4, LB loadB4, float (*As)[TR_K][TR_LD],
-                                            float (*Bs)[TR_K][TR_LD]) {
+template <bool AROW, bool BROW, int NCT, class LA, class LB>
+__device__ __forceinline__ void tile_sweep4_n(f32x4 (&acc)[4], int Ktot, LA loadA4, LB loadB4, float (*As)[TR_K][TR_LD],
+                                              float (*Bs)[TR_K][TR_LD]) {
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63, m = lane & 15, q = lane >> 4;
     const int ai = AROW ? (t & 15) * 4 : t >> 2, ak = AROW ? t >> 4 : (t & 3) * 4;
     const int bi = BROW ? (t & 15) * 4 : t >> 2, bk = BROW ? t >> 4 : (t & 3) * 4;
-    float4 av, bv;
-    if (Ktot > 0) { av = loadA4(ai, ak); bv = loadB4(bk, bi); }
+    decltype(loadA4(0, 0, 0)) ra{};
+    decltype(loadB4(0, 0, 0)) rb{};
+    if (Ktot > 0) { ra = loadA4(ai, 0, ak); rb = loadB4(0, bk, bi); }
     int buf = 0;
     __syncthreads();
     for (int k0 = 0; k0 < Ktot; k0 += TR_K, buf ^= 1) {
+        const float4 av = cvt_op(ra), bv = cvt_op(rb);
         if constexpr (AROW) *reinterpret_cast<float4 *>(&As[buf][ak][ai]) = av;
         else { As[buf][ak][ai] = av.x; As[buf][ak + 1][ai] = av.y; As[buf][ak + 2][ai] = av.z; As[buf][ak + 3][ai] = av.w; }
         if constexpr (BROW) *reinterpret_cast<float4 *>(&Bs[buf][bk][bi]) = bv;
         else { Bs[buf][bk][bi] = bv.x; Bs[buf][bk + 1][bi] = bv.y; Bs[buf][bk + 2][bi] = bv.z; Bs[buf][bk + 3][bi] = bv.w; }
         __syncthreads();
-        if (k0 + TR_K < Ktot) { av = loadA4(ai, k0 + TR_K + ak); bv = loadB4(k0 + TR_K + bk, bi); }
+        if (k0 + TR_K < Ktot) { ra = loadA4(ai, k0 + TR_K, ak); rb = loadB4(k0 + TR_K, bk, bi); }
+        if constexpr (NCT > 0) {
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-            const float a = As[buf][4 * s4 + q][wave * 16 + m];
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const float a = As[buf][4 * s4 + q][wave * 16 + m];
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) acc[ct] = MFMA16(a, Bs[buf][4 * s4 + q][ct * 16 + m], acc[ct]);
+                for (int ct = 0; ct < NCT; ++ct) acc[ct] = MFMA16(a, Bs[buf][4 * s4 + q][ct * 16 + m], acc[ct]);
+            }
         }
     }
 }
-__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
-// four sign bytes (one aligned 32-bit word) times a scale
-__device__ __forceinline__ float4 sign4(const signed char *z, float scale) {
-    const int w = *reinterpret_cast<const int *>(z);
-    return make_float4(scale * (float)(signed char)(w & 0xff), scale * (float)(signed char)((w >> 8) & 0xff),
-                       scale * (float)(signed char)((w >> 16) & 0xff), scale * (float)(signed char)(w >> 24));
+// the sweep for `nct` real column blocks (wavefront-uniform; every instance runs the same loads and barriers)
+template <bool AKF, bool BKF, class LA, class LB>
+__device__ __forceinline__ void tile_sweep(f32x4 (&acc)[4], int Ktot, LA loadA, LB loadB, float (*As)[TR_K][TR_LD],
+                                           float (*Bs)[TR_K][TR_LD], int nct = 4) {
+    switch (nct) {
+    case 0: tile_sweep_n<AKF, BKF, 0>(acc, Ktot, loadA, loadB, As, Bs); break;
+    case 1: tile_sweep_n<AKF, BKF, 1>(acc, Ktot, loadA, loadB, As, Bs); break;
+    case 2: tile_sweep_n<AKF, BKF, 2>(acc, Ktot, loadA, loadB, As, Bs); break;
+    case 3: tile_sweep_n<AKF, BKF, 3>(acc, Ktot, loadA, loadB, As, Bs); break;
+    default: tile_sweep_n<AKF, BKF, 4>(acc, Ktot, loadA, loadB, As, Bs); break;
+    }
 }
+template <bool AROW, bool BROW, class LA, class LB>
+__device__ __forceinline__ void tile_sweep4(f32x4 (&acc)[4], int Ktot, LA loadA4, LB loadB4, float (*As)[TR_K][TR_LD],
+                                            float (*Bs)[TR_K][TR_LD], int nct = 4) {
+    switch (nct) {
+    case 0: tile_sweep4_n<AROW, BROW, 0>(acc, Ktot, loadA4, loadB4, As, Bs); break;
+    case 1: tile_sweep4_n<AROW, BROW, 1>(acc, Ktot, loadA4, loadB4, As, Bs); break;
+    case 2: tile_sweep4_n<AROW, BROW, 2>(acc, Ktot, loadA4, loadB4, As, Bs); break;
+    case 3: tile_sweep4_n<AROW, BROW, 3>(acc, Ktot, loadA4, loadB4, As, Bs); break;
+    default: tile_sweep4_n<AROW, BROW, 4>(acc, Ktot, loadA4, loadB4, As, Bs); break;
+    }
+}
+__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
 // ---------------------------------------------------------------------------------------------
 // positive score, sign vector, q = x P - r   (one wavefront per edge; hp / tp from the projection pass)
@@ -142,16 +193,18 @@ __global__ __launch_bounds__(KGE_BLOCK) void transr_fwd_kernel(TransRArgs a, int
         f32x4 acc[4];
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int nct = min(4, (Dr - dr0 + 15) / 16);
+        const bool won = j0 + wave * 16 < N;
         if constexpr (VEC)
             tile_sweep4<false, true>(acc, De,
-                [&](int row, int k) { const int64_t o = rowoff[row];
+                [&](int row, int k0_, int kk_) { const int k = k0_ + kk_; const int64_t o = rowoff[row];
                                       return (o >= 0 && k < De) ? *reinterpret_cast<const float4 *>(a.ent + o + k) : f4zero(); },
-                [&](int k, int col) { return (k < De && dr0 + col < Dr) ? *reinterpret_cast<const float4 *>(Pi + (int64_t)k * Dr + dr0 + col)
-                                                                        : f4zero(); }, As, Bs);
+                [&](int k0_, int kk_, int col) { const int k = k0_ + kk_; return (k < De && dr0 + col < Dr) ? *reinterpret_cast<const float4 *>(Pi + (int64_t)k * Dr + dr0 + col)
+                                                                        : f4zero(); }, As, Bs, won ? nct : 0);
         else
         tile_sweep<true, false>(acc, De,
-            [&](int row, int k) { const int64_t o = rowoff[row]; return (o >= 0 && k < De) ? a.ent[o + k] : 0.f; },
-            [&](int k, int col) { return (k < De && dr0 + col < Dr) ? Pi[(int64_t)k * Dr + dr0 + col] : 0.f; }, As, Bs);
+            [&](int row, int k0_, int kk_) { const int k = k0_ + kk_; const int64_t o = rowoff[row]; return (o >= 0 && k < De) ? a.ent[o + k] : 0.f; },
+            [&](int k0_, int kk_, int col) { const int k = k0_ + kk_; return (k < De && dr0 + col < Dr) ? Pi[(int64_t)k * Dr + dr0 + col] : 0.f; }, As, Bs, won ? nct : 0);
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
             const int col = dr0 + ct * 16 + m;
@@ -228,6 +281,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void transr_dq_kernel(TransRArgs a) {
 template <bool VEC>
 __global__ __launch_bounds__(KGE_BLOCK) void transr_gn_kernel(TransRArgs a, int nJB, int nEB) {
     __shared__ float As[2][TR_K][TR_LD], Bs[2][TR_K][TR_LD];
+    extern __shared__ char gn_dyn[];             // per positive of the group: its projection matrix's offset, -W_ij of the 64 negatives
     const int g = blockIdx.x % a.nG;
     const int blk = blockIdx.x / a.nG;
     const int eb = blk % nEB, jb = (blk / nEB) % nJB, c = blk / (nEB * nJB);
@@ -235,35 +289,46 @@ __global__ __launch_bounds__(KGE_BLOCK) void transr_gn_kernel(TransRArgs a, int 
     const int DrP = (Dr + TR_K - 1) / TR_K * TR_K;              // every positive contributes whole slabs
     const int ipg = (chunk + a.nG - 1) / a.nG, i0 = g * ipg, i1 = min(chunk, i0 + ipg);
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63, m = lane & 15, q = lane >> 4;
+    // (the sweep's operand loads would otherwise each wait for a dependent id / weight load of their own, once per slab)
+    int64_t *s_pb = reinterpret_cast<int64_t *>(gn_dyn);
+    float *s_w = reinterpret_cast<float *>(s_pb + ipg);
+    for (int k = t; k < i1 - i0; k += KGE_BLOCK) s_pb[k] = a.rel_ids[(int64_t)c * chunk + i0 + k] * (int64_t)De * Dr;
+    for (int k = t; k < (i1 - i0) * TR_T; k += KGE_BLOCK) {
+        const int il = k / TR_T, j = j0 + (k % TR_T);
+        s_w[k] = j < N ? -a.S[((int64_t)c * chunk + i0 + il) * N + j] : 0.f;
+    }
+    __syncthreads();
     f32x4 acc[4];
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nct = min(4, (De - de0 + 15) / 16);
+    const bool won = j0 + wave * 16 < N;
     if constexpr (VEC)
         tile_sweep4<false, false>(acc, max(0, i1 - i0) * DrP,
-            [&](int row, int k) {          // 4 consecutive d_r of one (positive, negative): one word of sign bytes
-                const int il = i0 + k / DrP, dr = k % DrP, j = j0 + row;
-                if (j >= N || dr >= Dr) return f4zero();
-                const int64_t ij = ((int64_t)c * chunk + il) * N + j;
-                return sign4(a.Z + ij * Dr + dr, -a.S[ij]);
+            [&](int row, int k0_, int kk_) {          // 4 consecutive d_r of one (positive, negative): one word of sign bytes
+                const int il = k0_ / DrP, dr = k0_ % DrP + kk_, j = j0 + row;
+                if (j >= N || dr >= Dr) return Sgn4{0, 0.f};
+                const int64_t ij = ((int64_t)c * chunk + i0 + il) * N + j;
+                return Sgn4{*reinterpret_cast<const int *>(a.Z + ij * Dr + dr), s_w[il * TR_T + row]};
             },
-            [&](int k, int col) {          // P_i[de][dr .. dr+3]
-                const int il = i0 + k / DrP, dr = k % DrP, de = de0 + col;
+            [&](int k0_, int kk_, int col) {          // P_i[de][dr .. dr+3]
+                const int il = k0_ / DrP, dr = k0_ % DrP + kk_, de = de0 + col;
                 if (de >= De || dr >= Dr) return f4zero();
-                return *reinterpret_cast<const float4 *>(a.proj + a.rel_ids[(int64_t)c * chunk + il] * (int64_t)De * Dr + (int64_t)de * Dr + dr);
-            }, As, Bs);
+                return *reinterpret_cast<const float4 *>(a.proj + s_pb[il] + (int64_t)de * Dr + dr);
+            }, As, Bs, won ? nct : 0);
     else
     tile_sweep<true, true>(acc, max(0, i1 - i0) * DrP,
-        [&](int row, int k) {
-            const int il = i0 + k / DrP, dr = k % DrP, j = j0 + row;
-            if (j >= N || dr >= Dr) return 0.f;
-            const int64_t ij = ((int64_t)c * chunk + il) * N + j;
-            return -a.S[ij] * (float)a.Z[ij * Dr + dr];
+        [&](int row, int k0_, int kk_) {
+            const int il = k0_ / DrP, dr = k0_ % DrP + kk_, j = j0 + row;
+            if (j >= N || dr >= Dr) return Sgn1{0, 0.f};
+            const int64_t ij = ((int64_t)c * chunk + i0 + il) * N + j;
+            return Sgn1{a.Z[ij * Dr + dr], s_w[il * TR_T + row]};
         },
-        [&](int k, int col) {
-            const int il = i0 + k / DrP, dr = k % DrP, de = de0 + col;
+        [&](int k0_, int kk_, int col) {
+            const int il = k0_ / DrP, dr = k0_ % DrP + kk_, de = de0 + col;
             if (de >= De || dr >= Dr) return 0.f;
-            return a.proj[a.rel_ids[(int64_t)c * chunk + il] * (int64_t)De * Dr + (int64_t)de * Dr + dr];
-        }, As, Bs);
+            return a.proj[s_pb[il] + (int64_t)de * Dr + dr];
+        }, As, Bs, won ? nct : 0);
     float *out = a.GNp + (int64_t)g * a.C * N * De;
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
@@ -298,46 +363,65 @@ __global__ __launch_bounds__(KGE_BLOCK) void transr_gn_reduce_kernel(TransRArgs 
 template <bool VEC>
 __global__ __launch_bounds__(KGE_BLOCK) void transr_gp_kernel(TransRArgs a, int nEB, int nRB) {
     __shared__ float As[2][TR_K][TR_LD], Bs[2][TR_K][TR_LD];
+    extern __shared__ char gp_dyn[];             // per negative of the chunk: its row's offset in the entity table, -W_ij
     const int rb = blockIdx.x % nRB, eb = (blockIdx.x / nRB) % nEB, i = blockIdx.x / (nRB * nEB);
     const int de0 = eb * TR_T, dr0 = rb * TR_T, De = a.De, Dr = a.Dr, N = a.N;
     const int c = i / a.chunk;
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63, m = lane & 15, q = lane >> 4;
+    int64_t *s_off = reinterpret_cast<int64_t *>(gp_dyn);
+    float *s_w = reinterpret_cast<float *>(s_off + N);
+    for (int k = t; k < N; k += KGE_BLOCK) {
+        s_off[k] = a.neg_ids[(int64_t)c * N + k] * (int64_t)De;
+        s_w[k] = -a.S[(int64_t)i * N + k];
+    }
+    __syncthreads();
     f32x4 acc[4];
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nct = min(4, (Dr - dr0 + 15) / 16);
+    const bool won = de0 + wave * 16 < De;
     if constexpr (VEC)
         tile_sweep4<true, true>(acc, N,
-            [&](int row, int k) {          // Neg_k[de0 + row .. +3]
-                return (k < N && de0 + row < De) ? *reinterpret_cast<const float4 *>(a.ent + a.neg_ids[(int64_t)c * N + k] * (int64_t)De + de0 + row)
-                                                 : f4zero();
+            [&](int row, int k0_, int kk_) {          // Neg_k[de0 + row .. +3]
+                const int k = k0_ + kk_;
+                return (k < N && de0 + row < De) ? *reinterpret_cast<const float4 *>(a.ent + s_off[k] + de0 + row) : f4zero();
             },
-            [&](int k, int col) {          // dY_ik[dr0 + col .. +3]: one word of sign bytes
-                if (k >= N || dr0 + col >= Dr) return f4zero();
-                const int64_t ij = (int64_t)i * N + k;
-                return sign4(a.Z + ij * Dr + dr0 + col, -a.S[ij]);
-            }, As, Bs);
+            [&](int k0_, int kk_, int col) {          // dY_ik[dr0 + col .. +3]: one word of sign bytes
+                const int k = k0_ + kk_;
+                if (k >= N || dr0 + col >= Dr) return Sgn4{0, 0.f};
+                return Sgn4{*reinterpret_cast<const int *>(a.Z + ((int64_t)i * N + k) * Dr + dr0 + col), s_w[k]};
+            }, As, Bs, won ? nct : 0);
     else
     tile_sweep<false, false>(acc, N,
-        [&](int row, int k) {
-            return (k < N && de0 + row < De) ? a.ent[a.neg_ids[(int64_t)c * N + k] * (int64_t)De + de0 + row] : 0.f;
+        [&](int row, int k0_, int kk_) {
+            const int k = k0_ + kk_;
+            return (k < N && de0 + row < De) ? a.ent[s_off[k] + de0 + row] : 0.f;
         },
-        [&](int k, int col) {
-            if (k >= N || dr0 + col >= Dr) return 0.f;
-            const int64_t ij = (int64_t)i * N + k;
-            return -a.S[ij] * (float)a.Z[ij * Dr + dr0 + col];
-        }, As, Bs);
+        [&](int k0_, int kk_, int col) {
+            const int k = k0_ + kk_;
+            if (k >= N || dr0 + col >= Dr) return Sgn1{0, 0.f};
+            return Sgn1{a.Z[((int64_t)i * N + k) * Dr + dr0 + col], s_w[k]};
+        }, As, Bs, won ? nct : 0);
     const float *x = a.ent + (a.neg_head ? a.t_gid[i] : a.h_gid[i]) * (int64_t)De;
     const float *dq = a.DQ + (int64_t)i * Dr;
     float *G = a.GP + (int64_t)i * De * Dr;
+    float ss = 0.f;                               // Adagrad needs mean(GP_i^2): summed here, tile by tile, instead of re-reading GP
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
         const int dr = dr0 + ct * 16 + m;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int de = de0 + wave * 16 + 4 * q + r;
-            if (de < De && dr < Dr) G[(int64_t)de * Dr + dr] = acc[ct][r] + x[de] * dq[dr];
+            if (de < De && dr < Dr) {
+                const float v = acc[ct][r] + x[de] * dq[dr];
+                G[(int64_t)de * Dr + dr] = v;
+                ss = fmaf(v, v, ss);
+            }
         }
     }
+    __shared__ float red[KGE_WAVES_PER_BLOCK];
+    ss = block_sum_t(ss, red);
+    if (t == 0) a.gs1p[((int64_t)i * nEB + eb) * nRB + rb] = ss;
 }
 
 // relation-vector gradient per edge: GR_i = -dp_i s_i - dq_i (+ regulariser of the traced copy)
@@ -362,34 +446,22 @@ __global__ __launch_bounds__(KGE_BLOCK) void transr_gr_kernel(TransRArgs a) {
 //   st0 = st + sum_e mean(G0_e^2), P -= lr sum_e G0_e / (sqrt(st0) + eps);  st1 = st0 + sum_e mean(G1_e^2), ...
 // both gradients were taken before any update, so one pass applies both.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float block_sum_t(float v, float *red) {
-    v = wave_sum(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    float s = 0.f;
-#pragma unroll
-    for (int w = 0; w < KGE_WAVES_PER_BLOCK; ++w) s += red[w];
-    return s;
-}
 
-__global__ __launch_bounds__(KGE_BLOCK) void transr_proj_sq_kernel(TransRArgs a) {      // one workgroup per edge
-    __shared__ float red[KGE_WAVES_PER_BLOCK];
-    const int e = blockIdx.x, De = a.De, Dr = a.Dr;
-    const int64_t n = (int64_t)De * Dr;
-    const float *G = a.GP + (int64_t)e * n;
-    float ss = 0.f;
-    for (int64_t k = threadIdx.x; k < n; k += KGE_BLOCK) ss = fmaf(G[k], G[k], ss);
-    const float s1 = block_sum_t(ss, red);
+__global__ __launch_bounds__(KGE_BLOCK) void transr_proj_sq_kernel(TransRArgs a, int ntiles) {      // one wavefront per edge
+    const int64_t e = (int64_t)blockIdx.x * KGE_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (e >= a.B) return;
+    const int lane = threadIdx.x & 63, De = a.De, Dr = a.Dr;
+    const float n = (float)De * (float)Dr;
     const float *h = a.ent + a.h_gid[e] * (int64_t)De, *t = a.ent + a.t_gid[e] * (int64_t)De;
-    float dd = 0.f, sg = 0.f;
-    for (int k = threadIdx.x; k < De; k += KGE_BLOCK) { const float u = t[k] - h[k]; dd = fmaf(u, u, dd); }
-    for (int k = threadIdx.x; k < Dr; k += KGE_BLOCK) { const float v = a.SG[(int64_t)e * Dr + k]; sg = fmaf(v, v, sg); }
-    const float d2 = block_sum_t(dd, red), s2 = block_sum_t(sg, red);
-    if (threadIdx.x == 0) {
+    float dd = 0.f, sg = 0.f, s1 = 0.f;
+    for (int k = lane; k < De; k += 64) { const float u = t[k] - h[k]; dd = fmaf(u, u, dd); }
+    for (int k = lane; k < Dr; k += 64) { const float v = a.SG[e * Dr + k]; sg = fmaf(v, v, sg); }
+    for (int k = lane; k < ntiles; k += 64) s1 += a.gs1p[e * ntiles + k];      // (tile sums of GP_e^2 from transr_gp_kernel)
+    dd = wave_sum(dd); sg = wave_sum(sg); s1 = wave_sum(s1);
+    if (lane == 0) {
         const float dp = a.dpos[e];
-        a.gs0[e] = dp * dp * d2 * s2 / (float)n;
-        a.gs1[e] = s1 / (float)n;
+        a.gs0[e] = dp * dp * dd * sg / n;
+        a.gs1[e] = s1 / n;
     }
 }
 
@@ -428,6 +500,52 @@ __global__ __launch_bounds__(KGE_BLOCK) void transr_proj_apply_kernel(TransRArgs
     }
 }
 
+// 16-byte variant (D_r % 4 == 0): TPR = power of two >= D_r / 4 threads cover one row with one float4 each, the workgroup walks
+// 256 / TPR rows per iteration
+__global__ __launch_bounds__(KGE_BLOCK) void transr_proj_apply_vec_kernel(TransRArgs a, int tpr) {
+    const int u = blockIdx.x / TR_RB, rb = blockIdx.x % TR_RB;
+    if (u >= (a.counts_dev ? a.counts_dev[1] : a.UR)) return;
+    const int De = a.De, Dr = a.Dr;
+    const int rows = (De + TR_RB - 1) / TR_RB, r0 = rb * rows, r1 = min(De, r0 + rows);
+    const int e0 = a.ur_ptr[u], e1 = a.ur_ptr[u + 1];
+    float *Pm = a.proj + a.ur_id[u] * (int64_t)De * Dr;
+    const float k0 = a.k0[u], k1 = a.k1[u];
+    constexpr int NEC = 32;                        // per-edge metadata does not depend on the row: fetched once
+    __shared__ int64_t s_ho[NEC], s_to[NEC];
+    __shared__ float s_dp[NEC];
+    __shared__ int s_e[NEC];
+    const int nec = min(NEC, e1 - e0);
+    if ((int)threadIdx.x < nec) {
+        const int e = a.ur_edge[e0 + threadIdx.x];
+        s_e[threadIdx.x] = e;
+        s_ho[threadIdx.x] = a.h_gid[e] * (int64_t)De;
+        s_to[threadIdx.x] = a.t_gid[e] * (int64_t)De;
+        s_dp[threadIdx.x] = a.dpos[e];
+    }
+    __syncthreads();
+    const int rpi = KGE_BLOCK / tpr, rsub = threadIdx.x / tpr, b = (threadIdx.x % tpr) * 4;
+    if (b >= Dr) return;
+#pragma unroll 2
+    for (int rr = r0; rr < r1; rr += rpi) {
+        const int r = rr + rsub;
+        if (r >= r1) continue;
+        float4 p = *reinterpret_cast<const float4 *>(Pm + (int64_t)r * Dr + b);
+        float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0;
+        for (int q = 0; q < e1 - e0; ++q) {
+            int64_t e, ho, to; float dp;
+            if (q < NEC) { e = s_e[q]; ho = s_ho[q]; to = s_to[q]; dp = s_dp[q]; }
+            else { e = a.ur_edge[e0 + q]; ho = a.h_gid[e] * (int64_t)De; to = a.t_gid[e] * (int64_t)De; dp = a.dpos[e]; }
+            const float th = dp * (a.ent[to + r] - a.ent[ho + r]);
+            const float4 sg = *reinterpret_cast<const float4 *>(a.SG + e * Dr + b);
+            const float4 gp = *reinterpret_cast<const float4 *>(a.GP + e * De * Dr + (int64_t)r * Dr + b);
+            g0.x = fmaf(th, sg.x, g0.x); g0.y = fmaf(th, sg.y, g0.y); g0.z = fmaf(th, sg.z, g0.z); g0.w = fmaf(th, sg.w, g0.w);
+            g1.x += gp.x; g1.y += gp.y; g1.z += gp.z; g1.w += gp.w;
+        }
+        p.x += k0 * g0.x + k1 * g1.x; p.y += k0 * g0.y + k1 * g1.y; p.z += k0 * g0.z + k1 * g1.z; p.w += k0 * g0.w + k1 * g1.w;
+        *reinterpret_cast<float4 *>(Pm + (int64_t)r * Dr + b) = p;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------------------------
@@ -449,19 +567,28 @@ int launch_transr_bwd(const TransRArgs &a, hipStream_t s) {
     const dim3 gw((a.B + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK), b(KGE_BLOCK);
     hipLaunchKernelGGL(transr_dq_kernel, dim3(a.B), b, 0, s, a);
     const bool vec = a.De % 4 == 0 && a.Dr % 4 == 0;      // 16-byte operand loads (4 sign bytes per word)
-    if (vec) hipLaunchKernelGGL(transr_gn_kernel<true>, dim3(a.C * nJB * nEB * a.nG), b, 0, s, a, nJB, nEB);
-    else hipLaunchKernelGGL(transr_gn_kernel<false>, dim3(a.C * nJB * nEB * a.nG), b, 0, s, a, nJB, nEB);
+    const int ipg = (a.chunk + a.nG - 1) / a.nG;
+    const size_t gn_lds = (size_t)ipg * (sizeof(int64_t) + TR_T * sizeof(float)), gp_lds = (size_t)a.N * (sizeof(int64_t) + sizeof(float));
+    if (gn_lds > 44 * 1024 || gp_lds > 44 * 1024) return KGE_ERR_ARG;      // (64 KB of LDS per workgroup: chunk <= 2 700, N <= 3 700)
+    if (vec) hipLaunchKernelGGL(transr_gn_kernel<true>, dim3(a.C * nJB * nEB * a.nG), b, gn_lds, s, a, nJB, nEB);
+    else hipLaunchKernelGGL(transr_gn_kernel<false>, dim3(a.C * nJB * nEB * a.nG), b, gn_lds, s, a, nJB, nEB);
     hipLaunchKernelGGL(transr_gn_reduce_kernel, dim3(((int64_t)a.C * a.N + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK), b, 0, s, a);
-    if (vec) hipLaunchKernelGGL(transr_gp_kernel<true>, dim3(a.B * nEB * nRB), b, 0, s, a, nEB, nRB);
-    else hipLaunchKernelGGL(transr_gp_kernel<false>, dim3(a.B * nEB * nRB), b, 0, s, a, nEB, nRB);
+    if (vec) hipLaunchKernelGGL(transr_gp_kernel<true>, dim3(a.B * nEB * nRB), b, gp_lds, s, a, nEB, nRB);
+    else hipLaunchKernelGGL(transr_gp_kernel<false>, dim3(a.B * nEB * nRB), b, gp_lds, s, a, nEB, nRB);
     hipLaunchKernelGGL(transr_gr_kernel, gw, b, 0, s, a);
     return check_launch_t();
 }
 int launch_transr_proj_update(const TransRArgs &a, hipStream_t s) {
     if (a.B == 0 || a.UR == 0) return KGE_OK;
-    hipLaunchKernelGGL(transr_proj_sq_kernel, dim3(a.B), dim3(KGE_BLOCK), 0, s, a);
+    const int ntiles = ((a.De + TR_T - 1) / TR_T) * ((a.Dr + TR_T - 1) / TR_T);
+    hipLaunchKernelGGL(transr_proj_sq_kernel, dim3((a.B + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK), dim3(KGE_BLOCK), 0, s, a, ntiles);
     hipLaunchKernelGGL(transr_proj_state_kernel, dim3((a.UR + 255) / 256), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(transr_proj_apply_kernel, dim3(a.UR * TR_RB), dim3(KGE_BLOCK), 0, s, a);
+    if (a.Dr % 4 == 0 && a.Dr <= 1024) {
+        int tpr = 16;
+        while (tpr * 4 < a.Dr) tpr *= 2;
+        hipLaunchKernelGGL(transr_proj_apply_vec_kernel, dim3(a.UR * TR_RB), dim3(KGE_BLOCK), 0, s, a, tpr);
+    } else
+        hipLaunchKernelGGL(transr_proj_apply_kernel, dim3(a.UR * TR_RB), dim3(KGE_BLOCK), 0, s, a);
     return check_launch_t();
 }
 
@@ -493,13 +620,13 @@ __global__ __launch_bounds__(KGE_BLOCK) void transr_pn_fwd_kernel(PnArgs a, int 
     for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if constexpr (VEC)
         tile_sweep4<false, true>(acc, De,
-            [&](int row, int k) { return (j0 + row < N && k < De) ? *reinterpret_cast<const float4 *>(Nc + (int64_t)(j0 + row) * De + k) : f4zero(); },
-            [&](int k, int col) { return (k < De && dr0 + col < Dr) ? *reinterpret_cast<const float4 *>(Pi + (int64_t)k * Dr + dr0 + col) : f4zero(); },
+            [&](int row, int k0_, int kk_) { const int k = k0_ + kk_; return (j0 + row < N && k < De) ? *reinterpret_cast<const float4 *>(Nc + (int64_t)(j0 + row) * De + k) : f4zero(); },
+            [&](int k0_, int kk_, int col) { const int k = k0_ + kk_; return (k < De && dr0 + col < Dr) ? *reinterpret_cast<const float4 *>(Pi + (int64_t)k * Dr + dr0 + col) : f4zero(); },
             As, Bs);
     else
         tile_sweep<true, false>(acc, De,
-            [&](int row, int k) { return (j0 + row < N && k < De) ? Nc[(int64_t)(j0 + row) * De + k] : 0.f; },
-            [&](int k, int col) { return (k < De && dr0 + col < Dr) ? Pi[(int64_t)k * Dr + dr0 + col] : 0.f; }, As, Bs);
+            [&](int row, int k0_, int kk_) { const int k = k0_ + kk_; return (j0 + row < N && k < De) ? Nc[(int64_t)(j0 + row) * De + k] : 0.f; },
+            [&](int k0_, int kk_, int col) { const int k = k0_ + kk_; return (k < De && dr0 + col < Dr) ? Pi[(int64_t)k * Dr + dr0 + col] : 0.f; }, As, Bs);
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
         const int col = dr0 + ct * 16 + m;
@@ -524,24 +651,24 @@ __global__ __launch_bounds__(KGE_BLOCK) void transr_pn_bwd_neg_kernel(PnArgs a, 
     for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if constexpr (VEC)
         tile_sweep4<false, false>(acc, chunk * DrP,
-            [&](int row, int k) {
-                const int il = k / DrP, dr = k % DrP, j = j0 + row;
+            [&](int row, int k0_, int kk_) { const int k = k0_ + kk_;
+                const int il = k0_ / DrP, dr = k0_ % DrP + kk_, j = j0 + row;
                 if (j >= N || dr >= Dr) return f4zero();
                 return *reinterpret_cast<const float4 *>(a.Y + (((int64_t)c * chunk + il) * N + j) * Dr + dr);
             },
-            [&](int k, int col) {
-                const int il = k / DrP, dr = k % DrP, de = de0 + col;
+            [&](int k0_, int kk_, int col) { const int k = k0_ + kk_;
+                const int il = k0_ / DrP, dr = k0_ % DrP + kk_, de = de0 + col;
                 if (de >= De || dr >= Dr) return f4zero();
                 return *reinterpret_cast<const float4 *>(a.proj + ((int64_t)c * chunk + il) * De * Dr + (int64_t)de * Dr + dr);
             }, As, Bs);
     else
         tile_sweep<true, true>(acc, chunk * DrP,
-            [&](int row, int k) {
-                const int il = k / DrP, dr = k % DrP, j = j0 + row;
+            [&](int row, int k0_, int kk_) { const int k = k0_ + kk_;
+                const int il = k0_ / DrP, dr = k0_ % DrP + kk_, j = j0 + row;
                 return (j >= N || dr >= Dr) ? 0.f : a.Y[(((int64_t)c * chunk + il) * N + j) * Dr + dr];
             },
-            [&](int k, int col) {
-                const int il = k / DrP, dr = k % DrP, de = de0 + col;
+            [&](int k0_, int kk_, int col) { const int k = k0_ + kk_;
+                const int il = k0_ / DrP, dr = k0_ % DrP + kk_, de = de0 + col;
                 return (de >= De || dr >= Dr) ? 0.f : a.proj[((int64_t)c * chunk + il) * De * Dr + (int64_t)de * Dr + dr];
             }, As, Bs);
 #pragma unroll
@@ -566,15 +693,17 @@ __global__ __launch_bounds__(KGE_BLOCK) void transr_pn_bwd_proj_kernel(PnArgs a,
     f32x4 acc[4];
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nct = min(4, (Dr - dr0 + 15) / 16);
+    const bool won = de0 + wave * 16 < De;
     if constexpr (VEC)
         tile_sweep4<true, true>(acc, N,
-            [&](int row, int k) { return (k < N && de0 + row < De) ? *reinterpret_cast<const float4 *>(Nc + (int64_t)k * De + de0 + row) : f4zero(); },
-            [&](int k, int col) { return (k < N && dr0 + col < Dr) ? *reinterpret_cast<const float4 *>(Yi + (int64_t)k * Dr + dr0 + col) : f4zero(); },
-            As, Bs);
+            [&](int row, int k0_, int kk_) { const int k = k0_ + kk_; return (k < N && de0 + row < De) ? *reinterpret_cast<const float4 *>(Nc + (int64_t)k * De + de0 + row) : f4zero(); },
+            [&](int k0_, int kk_, int col) { const int k = k0_ + kk_; return (k < N && dr0 + col < Dr) ? *reinterpret_cast<const float4 *>(Yi + (int64_t)k * Dr + dr0 + col) : f4zero(); },
+            As, Bs, won ? nct : 0);
     else
         tile_sweep<false, false>(acc, N,
-            [&](int row, int k) { return (k < N && de0 + row < De) ? Nc[(int64_t)k * De + de0 + row] : 0.f; },
-            [&](int k, int col) { return (k < N && dr0 + col < Dr) ? Yi[(int64_t)k * Dr + dr0 + col] : 0.f; }, As, Bs);
+            [&](int row, int k0_, int kk_) { const int k = k0_ + kk_; return (k < N && de0 + row < De) ? Nc[(int64_t)k * De + de0 + row] : 0.f; },
+            [&](int k0_, int kk_, int col) { const int k = k0_ + kk_; return (k < N && dr0 + col < Dr) ? Yi[(int64_t)k * Dr + dr0 + col] : 0.f; }, As, Bs, won ? nct : 0);
     float *G = a.gproj + (int64_t)i * De * Dr;
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
