@@ -417,7 +417,7 @@ size_t kge_step_workspace_bytes(const kge_hparams *hp, int B, int C, int chunk, 
         add(((size_t)B * N * d_r + 3) / 4);
         add((size_t)B * d_e * d_r);
         add(B); add(B); add(UR); add(UR);
-        add((size_t)TRANSR_GN_GROUPS * CN * d_e);
+        add((size_t)TRANSR_GN_GROUPS_WIDE * CN * d_e);
         add((size_t)B * ((d_e + 63) / 64) * ((d_r + 63) / 64));       // sum of squares per 64 x 64 tile of the projection gradients
     }
     if (hp->model == KGE_RESCAL) {   // V = M t, M^T h, M^T GA (no [B, d_r] buffer) + update scratch
@@ -527,8 +527,8 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         tr.Z = reinterpret_cast<signed char *>(cv.f(((size_t)B * N * d_r + 3) / 4));
         tr.GP = cv.f((size_t)B * d_e * d_r);
         tr.gs0 = cv.f(B); tr.gs1 = cv.f(B); tr.k0 = cv.f(b->UR); tr.k1 = cv.f(b->UR);
-        tr.nG = chunk < TRANSR_GN_GROUPS ? chunk : TRANSR_GN_GROUPS;
-        tr.GNp = cv.f((size_t)TRANSR_GN_GROUPS * CN * d_e);
+        tr.nG = transr_gn_groups(d_e, d_r, chunk, N);
+        tr.GNp = cv.f((size_t)TRANSR_GN_GROUPS_WIDE * CN * d_e);
         tr.gs1p = cv.f((size_t)B * ((d_e + 63) / 64) * ((d_r + 63) / 64));
     }
     float *row_pos = cv.f(B), *row_neg = cv.f(B), *reg_ent = cv.f(b->UE), *reg_rel = cv.f(b->UR);

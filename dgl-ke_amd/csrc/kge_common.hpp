@@ -633,6 +633,10 @@ struct TransRArgs {
 #ifndef TRANSR_GN_GROUPS
 #define TRANSR_GN_GROUPS 16
 #endif
+#ifndef TRANSR_GN_GROUPS_WIDE
+#define TRANSR_GN_GROUPS_WIDE 64     // split-K groups of the 128 x 208-tile kernel (kge_transr_wide.hpp): 4 chunks x 2 row tiles need them
+#endif
+int transr_gn_groups(int De, int Dr, int chunk, int N);      // how many groups launch_transr_bwd will use for this shape
 int launch_transr_pos(const TransRArgs &a, hipStream_t s);
 int launch_transr_fwd(const TransRArgs &a, hipStream_t s);
 int launch_transr_bwd(const TransRArgs &a, hipStream_t s);

@@ -351,7 +351,15 @@ __global__ __launch_bounds__(KGE_BLOCK) void transr_gn_reduce_kernel(TransRArgs 
     const float *x = a.ent + a.neg_ids[row] * (int64_t)De;
     for (int d = lane; d < De; d += 64) {
         float v = 0.f;
-        for (int g = 0; g < a.nG; ++g) v += a.GNp[((int64_t)g * rows + row) * De + d];
+        int g = 0;
+        for (; g + 8 <= a.nG; g += 8) {               // eight groups' partials in flight (up to 64 groups; same order of additions)
+            float pv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) pv[k] = a.GNp[((int64_t)(g + k) * rows + row) * De + d];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v += pv[k];
+        }
+        for (; g < a.nG; ++g) v += a.GNp[((int64_t)g * rows + row) * De + d];
         if (reg) v += reg_grad(x[d], a.reg_coef, a.reg_norm);
         a.GN[row * De + d] = v;
     }
@@ -423,6 +431,8 @@ __global__ __launch_bounds__(KGE_BLOCK) void transr_gp_kernel(TransRArgs a, int 
     ss = block_sum_t(ss, red);
     if (t == 0) a.gs1p[((int64_t)i * nEB + eb) * nRB + rb] = ss;
 }
+
+#include "kge_transr_wide.hpp"
 
 // relation-vector gradient per edge: GR_i = -dp_i s_i - dq_i (+ regulariser of the traced copy)
 __global__ __launch_bounds__(KGE_BLOCK) void transr_gr_kernel(TransRArgs a) {
@@ -554,8 +564,22 @@ int launch_transr_pos(const TransRArgs &a, hipStream_t s) {
     hipLaunchKernelGGL(transr_pos_kernel, dim3((a.B + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK), dim3(KGE_BLOCK), 0, s, a);
     return check_launch_t();
 }
+// the 128 x 208-tile kernels: operand widths, and their per-workgroup id / weight tables beside 45 KB of tiles
+static bool transr_use_wide(int De, int Dr, int chunk, int N) {
+    const int nG = chunk < TRANSR_GN_GROUPS_WIDE ? chunk : TRANSR_GN_GROUPS_WIDE, ipg = nG > 0 ? (chunk + nG - 1) / nG : 0;
+    return transr_wide_supported(De, Dr) && (size_t)N * 12 <= 16 * 1024 && (size_t)ipg * (8 + TW_R * 4) <= 16 * 1024;
+}
+int transr_gn_groups(int De, int Dr, int chunk, int N) {
+    const int cap = transr_use_wide(De, Dr, chunk, N) ? TRANSR_GN_GROUPS_WIDE : TRANSR_GN_GROUPS;
+    return chunk < cap ? chunk : cap;
+}
 int launch_transr_fwd(const TransRArgs &a, hipStream_t s) {
     if (a.B == 0) return KGE_OK;
+    if (transr_use_wide(a.De, a.Dr, a.chunk, a.N)) {
+        const int nJW = (a.N + TW_R - 1) / TW_R;
+        hipLaunchKernelGGL(transr_fwd_wide_kernel, dim3(a.B * nJW), dim3(KGE_BLOCK), 0, s, a, nJW);
+        return check_launch_t();
+    }
     const int nJB = (a.N + TR_T - 1) / TR_T;
     if (a.De % 4 == 0 && a.Dr % 4 == 0) hipLaunchKernelGGL(transr_fwd_kernel<true>, dim3(a.B * nJB), dim3(KGE_BLOCK), 0, s, a, nJB);
     else hipLaunchKernelGGL(transr_fwd_kernel<false>, dim3(a.B * nJB), dim3(KGE_BLOCK), 0, s, a, nJB);
@@ -565,6 +589,13 @@ int launch_transr_bwd(const TransRArgs &a, hipStream_t s) {
     if (a.B == 0) return KGE_OK;
     const int nJB = (a.N + TR_T - 1) / TR_T, nEB = (a.De + TR_T - 1) / TR_T, nRB = (a.Dr + TR_T - 1) / TR_T;
     const dim3 gw((a.B + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK), b(KGE_BLOCK);
+    if (transr_use_wide(a.De, a.Dr, a.chunk, a.N)) {      // (dq and GR come out of the projection-gradient kernel's own sweep)
+        const int nJW = (a.N + TW_R - 1) / TW_R, nEW = (a.De + TW_R - 1) / TW_R, ipgw = (a.chunk + a.nG - 1) / a.nG;
+        hipLaunchKernelGGL(transr_gn_wide_kernel, dim3(a.C * nJW * a.nG), b, (size_t)ipgw * (sizeof(int64_t) + TW_R * sizeof(float)), s, a, nJW);
+        hipLaunchKernelGGL(transr_gn_reduce_kernel, dim3(((int64_t)a.C * a.N + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK), b, 0, s, a);
+        hipLaunchKernelGGL(transr_gp_wide_kernel, dim3(a.B * nEW), b, (size_t)a.N * (sizeof(int64_t) + sizeof(float)), s, a, nEW);
+        return check_launch_t();
+    }
     hipLaunchKernelGGL(transr_dq_kernel, dim3(a.B), b, 0, s, a);
     const bool vec = a.De % 4 == 0 && a.Dr % 4 == 0;      // 16-byte operand loads (4 sign bytes per word)
     const int ipg = (a.chunk + a.nG - 1) / a.nG;
@@ -580,7 +611,8 @@ int launch_transr_bwd(const TransRArgs &a, hipStream_t s) {
 }
 int launch_transr_proj_update(const TransRArgs &a, hipStream_t s) {
     if (a.B == 0 || a.UR == 0) return KGE_OK;
-    const int ntiles = ((a.De + TR_T - 1) / TR_T) * ((a.Dr + TR_T - 1) / TR_T);
+    const int ntiles = transr_use_wide(a.De, a.Dr, a.chunk, a.N) ? (a.De + TW_R - 1) / TW_R
+                                                                  : ((a.De + TR_T - 1) / TR_T) * ((a.Dr + TR_T - 1) / TR_T);
     hipLaunchKernelGGL(transr_proj_sq_kernel, dim3((a.B + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK), dim3(KGE_BLOCK), 0, s, a, ntiles);
     hipLaunchKernelGGL(transr_proj_state_kernel, dim3((a.UR + 255) / 256), dim3(256), 0, s, a);
     if (a.Dr % 4 == 0 && a.Dr <= 1024) {
