@@ -130,11 +130,14 @@ def synth_triples(w, seed, skew=False):
 def step_kernels(model, force_pairwise=False):
     """the launches of one strict training step per model family and the dominant one."""
     if model == "TransR":
-        return ("one training step = projections (matvec), transr_pos, transr_fwd, loss, transr_dq / gn / gp / gr, "
-                "projection Adagrad, update; dominant: transr_gp_kernel / transr_gn_kernel (fp32 MFMA)")
+        return ("one training step = projections (matvec), transr_pos, transr_fwd_wide, loss, transr_gn_wide / gn_reduce / "
+                "gp_wide (dq, GR and the gradient's sum of squares in its sweep), projection Adagrad, update; dominant: the three "
+                "64 x 208-tile fp32-MFMA products (kge_transr_wide.hpp)")
     if model == "RESCAL":
-        return ("one training step = rescal_matvec x2, neg_fwd_gemm, loss, neg_bwd_gemm, relation-matrix Adagrad, update; "
-                "dominant: rescal_apply / rescal_matvec (HBM streaming of the relation matrices)")
+        return ("one training step = rescal_rel_fwd (one pass over M per UNIQUE relation), neg_fwd_gemm, loss, neg_bwd_gemm, "
+                "rescal_rel_bwd_apply (backward products + Adagrad in one pass per unique relation), combine, update; dominant: "
+                "rescal_rel_bwd_apply / rescal_rel_fwd (HBM streaming of the relation matrices; the algorithmic bytes count every "
+                "traced row, the kernels read a relation carried by several edges once)")
     if model == "TransE_l1" and not force_pairwise:
         return ("one training step = [neg_fwd_bcast tasks || edge-forward rows], loss, neg_bwd_lc, gn_reduce, update; "
                 "dominant: neg_bwd_lc_kernel (VALU, packed fp32)")
