@@ -567,7 +567,7 @@ int launch_transr_pos(const TransRArgs &a, hipStream_t s) {
 // the 128 x 208-tile kernels: operand widths, and their per-workgroup id / weight tables beside 45 KB of tiles
 static bool transr_use_wide(int De, int Dr, int chunk, int N) {
     const int nG = chunk < TRANSR_GN_GROUPS_WIDE ? chunk : TRANSR_GN_GROUPS_WIDE, ipg = nG > 0 ? (chunk + nG - 1) / nG : 0;
-    return transr_wide_supported(De, Dr) && (size_t)N * 12 <= 16 * 1024 && (size_t)ipg * (8 + TW_R * 4) <= 16 * 1024;
+    return transr_wide_supported(De, Dr) && (size_t)N * 12 + TW_C * 4 <= 16 * 1024 && (size_t)ipg * (8 + TW_R * 4) <= 16 * 1024;
 }
 int transr_gn_groups(int De, int Dr, int chunk, int N) {
     const int cap = transr_use_wide(De, Dr, chunk, N) ? TRANSR_GN_GROUPS_WIDE : TRANSR_GN_GROUPS;
@@ -593,7 +593,12 @@ int launch_transr_bwd(const TransRArgs &a, hipStream_t s) {
         const int nJW = (a.N + TW_R - 1) / TW_R, nEW = (a.De + TW_R - 1) / TW_R, ipgw = (a.chunk + a.nG - 1) / a.nG;
         hipLaunchKernelGGL(transr_gn_wide_kernel, dim3(a.C * nJW * a.nG), b, (size_t)ipgw * (sizeof(int64_t) + TW_R * sizeof(float)), s, a, nJW);
         hipLaunchKernelGGL(transr_gn_reduce_kernel, dim3(((int64_t)a.C * a.N + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK), b, 0, s, a);
-        hipLaunchKernelGGL(transr_gp_wide_kernel, dim3(a.B * nEW), b, (size_t)a.N * (sizeof(int64_t) + sizeof(float)), s, a, nEW);
+        #ifndef TW_GP_PER_EDGE
+        const int gp_blocks = a.B * nEW;
+#else
+        const int gp_blocks = a.B;
+#endif
+        hipLaunchKernelGGL(transr_gp_wide_kernel, dim3(gp_blocks), b, (size_t)a.N * (sizeof(int64_t) + sizeof(float)) + TW_C * sizeof(float), s, a, nEW);
         return check_launch_t();
     }
     hipLaunchKernelGGL(transr_dq_kernel, dim3(a.B), b, 0, s, a);

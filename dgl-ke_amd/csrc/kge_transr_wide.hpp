@@ -248,73 +248,88 @@ __global__ __launch_bounds__(KGE_BLOCK) void transr_gn_wide_kernel(TransRArgs a,
 __global__ __launch_bounds__(KGE_BLOCK) void transr_gp_wide_kernel(TransRArgs a, int nEB) {
     __shared__ float As[2][TR_K][TW_LDA], Bs[2][TR_K][TW_LDB];
     __shared__ float red[KGE_WAVES_PER_BLOCK];
-    extern __shared__ char gpw_dyn[];            // per negative of the chunk: its row's offset in the entity table, -W_ij
-    const int eb = blockIdx.x % nEB, i = blockIdx.x / nEB;
-    const int de0 = eb * TW_R, De = a.De, Dr = a.Dr, N = a.N;
+    extern __shared__ char gpw_dyn[];            // per negative of the chunk: its row's offset in the entity table, -W_ij; then dq_i [208]
+#ifndef TW_GP_PER_EDGE
+    const int eb_first = blockIdx.x % nEB, eb_last = eb_first + 1, i = blockIdx.x / nEB;
+#else
+    // (measured: one workgroup per positive walking its row tiles - ids / weights staged once, dq from the first sweep only - needs
+    //  180 VGPRs, 2 wavefronts per SIMD: 334 us against 303 with a workgroup per tile)
+    const int eb_first = 0, eb_last = nEB, i = blockIdx.x;
+#endif
+    const int De = a.De, Dr = a.Dr, N = a.N;
     const int c = i / a.chunk;
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63, m = lane & 15, q = lane >> 4;
     int64_t *s_off = reinterpret_cast<int64_t *>(gpw_dyn);
-    float *s_w = reinterpret_cast<float *>(s_off + N);
+    float *s_w = reinterpret_cast<float *>(s_off + N), *s_dq = s_w + N;
     for (int k = t; k < N; k += KGE_BLOCK) {
         s_off[k] = a.neg_ids[(int64_t)c * N + k] * (int64_t)De;
         s_w[k] = -a.S[(int64_t)i * N + k];
     }
     __syncthreads();
-    f32x4 acc[TW_NRB][TW_NCB];
-#pragma unroll
-    for (int rbk = 0; rbk < TW_NRB; ++rbk)
-#pragma unroll
-        for (int ct = 0; ct < TW_NCB; ++ct) acc[rbk][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int nrb = max(0, min(TW_NRB, (De - (de0 + wave * TW_WR) + 15) / 16));
-    float4 bsum = f4zero();
-    wide_sweep<true, true, true>(acc, N,
-        [&](int row, int k0_, int kk_) {              // Neg_k[de0 + row .. + 3]
-            const int k = k0_ + kk_;
-            return (k < N && de0 + row < De) ? *reinterpret_cast<const float4 *>(a.ent + s_off[k] + de0 + row) : f4zero();
-        },
-        [&](int k0_, int kk_, int col) {              // dY_ik[col .. + 3]: one word of sign bytes
-            const int k = k0_ + kk_;
-            if (k >= N || col >= Dr) return Sgn4{0, 0.f};
-            return Sgn4{*reinterpret_cast<const int *>(a.Z + ((int64_t)i * N + k) * Dr + col), s_w[k]};
-        }, As, Bs, nrb, (Dr + 15) / 16, bsum);
-    // dq_i = -sum_j dY_ij: thread t < 208 summed the k-rows t / 52 + 4 e of every slab for its column group; the four k-classes are
-    // added in a fixed order.  The tile buffers are free after the sweep.
-    float *part = &Bs[0][0][0], *s_dq = &As[0][0][0];
-    __syncthreads();
-    if (t < TW_C) *reinterpret_cast<float4 *>(part + (t / (TW_C / 4)) * TW_C + (t % (TW_C / 4)) * 4) = bsum;
-    __syncthreads();
-    if (t < TW_C) {
-        float sdq = 0.f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) sdq += part[k * TW_C + t];
-        s_dq[t] = -sdq;
-        if (eb == 0 && t < Dr) {                      // the edge's first tile also writes dq and the relation-vector gradient
-            a.DQ[(int64_t)i * Dr + t] = -sdq;         // GR_i = -dp_i s_i - dq_i (+ regulariser of the traced copy)
-            float gr = -a.dpos[i] * a.SG[(int64_t)i * Dr + t] + sdq;
-            if (a.reg_coef > 0.f && a.reg_norm > 0) gr += reg_grad(a.rel[a.rel_ids[i] * (int64_t)Dr + t], a.reg_coef, a.reg_norm);
-            a.GR[(int64_t)i * Dr + t] = gr;
-        }
-    }
-    __syncthreads();
     const float *x = a.ent + (a.neg_head ? a.t_gid[i] : a.h_gid[i]) * (int64_t)De;
     float *G = a.GP + (int64_t)i * De * Dr;
-    float ss = 0.f;
+    auto loadA = [&](int de0) {
+        return [&, de0](int row, int k0_, int kk_) {  // Neg_k[de0 + row .. + 3]
+            const int k = k0_ + kk_;
+            return (k < N && de0 + row < De) ? *reinterpret_cast<const float4 *>(a.ent + s_off[k] + de0 + row) : f4zero();
+        };
+    };
+    auto loadB = [&](int k0_, int kk_, int col) {     // dY_ik[col .. + 3]: one word of sign bytes
+        const int k = k0_ + kk_;
+        if (k >= N || col >= Dr) return Sgn4{0, 0.f};
+        return Sgn4{*reinterpret_cast<const int *>(a.Z + ((int64_t)i * N + k) * Dr + col), s_w[k]};
+    };
+    for (int eb = eb_first; eb < eb_last; ++eb) {
+        const int de0 = eb * TW_R;
+        f32x4 acc[TW_NRB][TW_NCB];
 #pragma unroll
-    for (int rbk = 0; rbk < TW_NRB; ++rbk)
+        for (int rbk = 0; rbk < TW_NRB; ++rbk)
 #pragma unroll
-        for (int ct = 0; ct < TW_NCB; ++ct) {
-            const int dr = ct * 16 + m;
-            const float dqv = s_dq[dr];
+            for (int ct = 0; ct < TW_NCB; ++ct) acc[rbk][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int nrb = max(0, min(TW_NRB, (De - (de0 + wave * TW_WR) + 15) / 16));
+        float4 bsum = f4zero();
+        if (eb == eb_first) {
+            wide_sweep<true, true, true>(acc, N, loadA(de0), loadB, As, Bs, nrb, (Dr + 15) / 16, bsum);
+            // dq_i = -sum_j dY_ij: thread t < 208 summed the k-rows t / 52 + 4 e of every slab for its column group; the four
+            // k-classes are added in a fixed order.  The tile buffers are free after the sweep.
+            float *part = &Bs[0][0][0];
+            __syncthreads();
+            if (t < TW_C) *reinterpret_cast<float4 *>(part + (t / (TW_C / 4)) * TW_C + (t % (TW_C / 4)) * 4) = bsum;
+            __syncthreads();
+            if (t < TW_C) {
+                float sdq = 0.f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int de = de0 + wave * TW_WR + rbk * 16 + 4 * q + r;
-                if (de < De && dr < Dr) {
-                    const float v = acc[rbk][ct][r] + x[de] * dqv;
-                    G[(int64_t)de * Dr + dr] = v;
-                    ss = fmaf(v, v, ss);
+                for (int k = 0; k < 4; ++k) sdq += part[k * TW_C + t];
+                s_dq[t] = -sdq;
+                if (eb == 0 && t < Dr) {              // the edge's first tile also writes dq and the relation-vector gradient
+                    a.DQ[(int64_t)i * Dr + t] = -sdq; // GR_i = -dp_i s_i - dq_i (+ regulariser of the traced copy)
+                    float gr = -a.dpos[i] * a.SG[(int64_t)i * Dr + t] + sdq;
+                    if (a.reg_coef > 0.f && a.reg_norm > 0) gr += reg_grad(a.rel[a.rel_ids[i] * (int64_t)Dr + t], a.reg_coef, a.reg_norm);
+                    a.GR[(int64_t)i * Dr + t] = gr;
                 }
             }
+            __syncthreads();
+        } else {
+            wide_sweep<true, true, false>(acc, N, loadA(de0), loadB, As, Bs, nrb, (Dr + 15) / 16, bsum);
         }
-    ss = block_sum_t(ss, red);
-    if (t == 0) a.gs1p[(int64_t)i * nEB + eb] = ss;
+        float ss = 0.f;
+#pragma unroll
+        for (int rbk = 0; rbk < TW_NRB; ++rbk)
+#pragma unroll
+            for (int ct = 0; ct < TW_NCB; ++ct) {
+                const int dr = ct * 16 + m;
+                const float dqv = s_dq[dr];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int de = de0 + wave * TW_WR + rbk * 16 + 4 * q + r;
+                    if (de < De && dr < Dr) {
+                        const float v = acc[rbk][ct][r] + x[de] * dqv;
+                        G[(int64_t)de * Dr + dr] = v;
+                        ss = fmaf(v, v, ss);
+                    }
+                }
+            }
+        ss = block_sum_t(ss, red);
+        if (t == 0) a.gs1p[(int64_t)i * nEB + eb] = ss;
+    }
 }
