@@ -47,6 +47,15 @@ __device__ __forceinline__ void wide_sweep_n(f32x4 (&acc)[TW_NRB][TW_NCB], int K
         bi[e] = BROW ? (t % (TW_C / 4)) * 4 : u >> 2;
         bk[e] = BROW ? t / (TW_C / 4) + 4 * e : (u & 3) * 4;
     }
+    // LDS columns are rotated by one 16-column block on the k-rows with (k / 4) odd.  Row strides of 16 (mod 32) banks keep the MFMA
+    // operand reads conflict-free, but a thread that scatters four consecutive k of one column (!AROW / !BROW) shares its column with
+    // the three lanes holding the other k-groups: 4 lanes on one bank, 20 such stores per thread and slab in the negative-row
+    // product (~1 us per slab at 4 workgroups per CU).  Rotated, the k-groups alternate bank halves: 2 lanes per bank, the floor.
+    int aic[TW_AUNITS], bic[4];
+#pragma unroll
+    for (int e = 0; e < TW_AUNITS; ++e) aic[e] = (ai[e] + 16 * ((ak[e] >> 2) & 1)) & (TW_R - 1);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const int cc = bi[e] + 16 * ((bk[e] >> 2) & 1); bic[e] = cc >= TW_C ? cc - TW_C : cc; }
     decltype(loadA4(0, 0, 0)) ra[TW_AUNITS]{};
     decltype(loadB4(0, 0, 0)) rb[4]{};
     auto gload = [&](int k0) {
@@ -62,16 +71,16 @@ __device__ __forceinline__ void wide_sweep_n(f32x4 (&acc)[TW_NRB][TW_NCB], int K
 #pragma unroll
         for (int e = 0; e < TW_AUNITS; ++e) {
             const float4 v = cvt_op(ra[e]);
-            if constexpr (AROW) *reinterpret_cast<float4 *>(&As[buf][ak[e]][ai[e]]) = v;
-            else { As[buf][ak[e]][ai[e]] = v.x; As[buf][ak[e] + 1][ai[e]] = v.y; As[buf][ak[e] + 2][ai[e]] = v.z; As[buf][ak[e] + 3][ai[e]] = v.w; }
+            if constexpr (AROW) *reinterpret_cast<float4 *>(&As[buf][ak[e]][aic[e]]) = v;
+            else { As[buf][ak[e]][aic[e]] = v.x; As[buf][ak[e] + 1][aic[e]] = v.y; As[buf][ak[e] + 2][aic[e]] = v.z; As[buf][ak[e] + 3][aic[e]] = v.w; }
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             if (!bon[e]) continue;
             const float4 v = cvt_op(rb[e]);
             if constexpr (BSUM) { bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w; }
-            if constexpr (BROW) *reinterpret_cast<float4 *>(&Bs[buf][bk[e]][bi[e]]) = v;
-            else { Bs[buf][bk[e]][bi[e]] = v.x; Bs[buf][bk[e] + 1][bi[e]] = v.y; Bs[buf][bk[e] + 2][bi[e]] = v.z; Bs[buf][bk[e] + 3][bi[e]] = v.w; }
+            if constexpr (BROW) *reinterpret_cast<float4 *>(&Bs[buf][bk[e]][bic[e]]) = v;
+            else { Bs[buf][bk[e]][bic[e]] = v.x; Bs[buf][bk[e] + 1][bic[e]] = v.y; Bs[buf][bk[e] + 2][bic[e]] = v.z; Bs[buf][bk[e] + 3][bic[e]] = v.w; }
         }
         __syncthreads();
         if (k0 + TR_K < Ktot) gload(k0 + TR_K);
@@ -81,9 +90,10 @@ __device__ __forceinline__ void wide_sweep_n(f32x4 (&acc)[TW_NRB][TW_NCB], int K
             float av[2][NRB], bq[2][NCB];
             auto lds_fetch = [&](int s4, int w) {
 #pragma unroll
-                for (int rbk = 0; rbk < NRB; ++rbk) av[w][rbk] = As[buf][4 * s4 + q][wave * TW_WR + rbk * 16 + m];
+                for (int rbk = 0; rbk < NRB; ++rbk)
+                    av[w][rbk] = As[buf][4 * s4 + q][((wave * TW_NRB + rbk + (s4 & 1)) & (TW_R / 16 - 1)) * 16 + m];
 #pragma unroll
-                for (int ct = 0; ct < NCB; ++ct) bq[w][ct] = Bs[buf][4 * s4 + q][ct * 16 + m];
+                for (int ct = 0; ct < NCB; ++ct) bq[w][ct] = Bs[buf][4 * s4 + q][((ct + (s4 & 1)) % TW_NCB) * 16 + m];
             };
             lds_fetch(0, 0);
 #pragma unroll
