@@ -59,3 +59,84 @@ def test_rescal_fused_step_matches_oracle(case):
         _close(eng.rel_state.cpu(), rs64, 2e-3, 1e-9, tag + " rel state")
         _close(eng.ent.cpu(), ent64, 1e-4, 1e-3 * lr, tag + " entity rows")
         _close(eng.rel.cpu(), rel64, 1e-4, 1e-3 * lr, tag + " relation rows")
+
+
+def _random_matrix_model_case(seed):
+    rng = np.random.RandomState(7000 + seed)
+    model = ["RESCAL", "TransR"][seed % 2]
+    return dict(model=model, hidden=int(rng.choice([8, 12, 20, 36, 52, 68, 100, 132, 212, 260] if model == "RESCAL" else [8, 12, 18, 36, 52, 68, 100, 108])),
+                dr=bool(model == "TransR" and rng.randint(2)), chunk=int(rng.choice([1, 3, 8, 16, 17, 32])), C=int(rng.randint(1, 4)),
+                N=int(rng.choice([1, 4, 5, 16, 20, 64, 70, 130])), n_ent=int(rng.choice([60, 400, 3000])), n_rel=int(rng.choice([2, 9, 40])),
+                adv=bool(rng.randint(2)), reg=float(rng.choice([0.0, 1e-5])), lr=float(rng.choice([0.05, 0.2])))
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("KGE_FUZZ_N", "32"))))
+def test_matrix_models_random_shapes_match_oracle(seed):
+    """fuzz over RESCAL / TransR: random widths (through every instance of the per-relation passes and every tile routine), ragged
+    chunk / N, relation tables of 2 - 40 rows (many edges per relation), regulariser and adversarial weighting on and off - two fused
+    steps (tail then head corruption) against the fp64 oracle restarted from the GPU's own tables."""
+    from dglke_amd import plan
+    from dglke_amd.engine import StepEngine
+    k = _random_matrix_model_case(seed)
+    transr = k["model"] == "TransR"
+    cfg = O.Config(k["model"], 8.0, k["hidden"], k["lr"], adv=k["adv"], adv_temp=1.0, reg_coef=k["reg"], reg_norm=3, double_rel=k["dr"])
+    rng = np.random.RandomState(9000 + seed)
+    eng = StepEngine(k["model"], k["n_ent"], k["n_rel"], k["hidden"], 8.0, k["lr"], DEV, False, k["dr"], k["adv"], 1.0, k["reg"], 3)
+    B, chunk, N = k["C"] * k["chunk"], k["chunk"], k["N"]
+    tag0 = "seed %d %s" % (seed, k)
+    for step in (1, 2):
+        ent64, rel64 = eng.ent.cpu().numpy().astype(np.float64), eng.rel.cpu().numpy().astype(np.float64)
+        es64, rs64 = eng.ent_state.cpu().numpy().astype(np.float64), eng.rel_state.cpu().numpy().astype(np.float64)
+        ent0, rs_before = ent64.copy(), rs64.copy()
+        if transr:
+            pj64, ps64 = eng.proj.cpu().numpy().astype(np.float64), eng.proj_state.cpu().numpy().astype(np.float64)
+            ps_before = ps64.copy()
+        bt = O.synth_batch(rng, k["n_ent"], k["n_rel"], B, N, chunk, step)
+        b = plan.make_batch(bt["h"], bt["t"], bt["r"], bt["neg"], chunk, N, bt["neg_head"], DEV)
+        want = eng.alloc_outputs(b)
+        eng.step(b, want)
+        torch.cuda.synchronize()
+        if transr:
+            out = O.transr_train_step(cfg, ent64, es64, rel64, rs64, pj64, ps64, bt["nid"], bt["h_local"], bt["t_local"], bt["r"],
+                                      bt["neg"], bt["neg_head"], chunk, N)
+        else:
+            out = O.train_step(cfg, ent64, es64, rel64, rs64, bt["nid"], bt["h_local"], bt["t_local"], bt["r"], bt["neg"],
+                               bt["neg_head"], chunk, N)
+        tag = "%s step %d" % (tag0, step)
+        _close(want["pos_score"].cpu(), out["pos_score"], 1e-4, 1e-4, tag + " pos_score")
+        _close(want["neg_score"].cpu(), out["neg_score"], 1e-4, 2e-4, tag + " neg_score")
+        sel = np.searchsorted(b.p["ue_id"], bt["nid"])
+        _close(want["g_pos_ent"].cpu().numpy()[sel], out["g_pos_ent"], 3e-4, grad_tol(out["g_pos_ent"]), tag + " g_pos_ent")
+        _close(want["g_neg"].cpu(), out["g_neg"], 3e-4, grad_tol(out["g_neg"]), tag + " g_neg")
+        _close(want["g_rel"].cpu(), out["g_rel"], 3e-4, grad_tol(out["g_rel"]), tag + " g_rel")
+        _close(eng.rel_state.cpu(), rs64, 2e-3, 1e-9, tag + " rel state")
+        # A traced row whose gradient is the small difference of large terms has no digits to compare: Adagrad's first steps move a
+        # row by lr * g / rms(g) whatever the size of g, so fp32 rounding residue becomes a full-size move.  It happens by
+        # construction in tiny graphs: RESCAL with the corrupted entity equal to the true one (g = (dp + dn) h t^T, dp + dn ~ 0 at
+        # p = n ~ 0), TransR with a self-loop as a relation's only edge.  Such rows - Adagrad increment below 1e-4 of the batch's
+        # median - are left out of the ROW comparison (at most two, asserted); their gradients and states are compared above.
+        def weak_rows(inc, ids):
+            tr = np.unique(ids)
+            med = np.median(inc[tr])
+            return tr[inc[tr] < 1e-4 * med]
+        dead_r = weak_rows(rs64 - rs_before, bt["r"])
+        assert len(dead_r) <= 2, (tag, dead_r)
+        got_rel = eng.rel.cpu().numpy().astype(np.float64)
+        got_rel[dead_r] = rel64[dead_r]
+        _close(got_rel, rel64, 1e-4, 5e-3 * k["lr"], tag + " relation rows")
+        if transr:
+            _close(eng.proj_state.cpu(), ps64, 2e-3, 1e-9, tag + " projection state")
+            dead = weak_rows(ps64 - ps_before, bt["r"])
+            assert len(dead) <= 2, (tag, dead)
+            got_pj = eng.proj.cpu().numpy().astype(np.float64)
+            got_pj[dead] = pj64[dead]
+            _close(got_pj, pj64, 1e-4, 5e-3 * k["lr"], tag + " projection rows")
+        # the head = tail entity of a self-loop edge: its TransR gradient is (h - t) P = 0 in exact arithmetic, rounding residue in
+        # fp32 / fp64, and Adagrad's first steps move a row by lr * g / rms(g) whatever the size of g - no digits to compare
+        touched = set(bt["nid"].tolist()) | set(bt["neg"].tolist())
+        starved = np.unique(bt["h"][bt["h"] == bt["t"]]) if transr else np.zeros(0, np.int64)
+        assert len(starved) <= max(2, len(touched) // 10), (tag, len(starved), len(touched))
+        got_ent = eng.ent.cpu().numpy().astype(np.float64)
+        got_ent[starved] = ent64[starved]
+        _close(got_ent, ent64, 1e-4, 5e-3 * k["lr"], tag + " entity rows")
+        assert np.array_equal(got_ent[sorted(set(range(k["n_ent"])) - touched)], ent0[sorted(set(range(k["n_ent"])) - touched)])
