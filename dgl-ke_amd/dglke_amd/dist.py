@@ -822,6 +822,81 @@ def relation_partition(rels, world):
     return owner, owner[rels]
 
 
+def soft_relation_partition(rels, world, threshold=0.05):
+    """the partition the reference's `--rel_part` really computes (`TrainDataset` calls SoftRelationPartition,
+    dataloader/sampler.py:32-148, 363-365): relations most frequent first (the reference's order: `np.flip(np.argsort(cnts))`, ties
+    included); a LARGE relation - more than min(threshold * |E|, |E| / world) edges - is dealt evenly over ALL ranks (`cnt // world + 1`
+    edges to rank 0, 1, ... until it is used up; these are the reference's `cross_rels`), every other relation goes whole to the rank
+    with the fewest edges so far.  A relation's edges fill its ranks in the order of the edge list.
+    Returns (part[i] = rank of edge i, rel_parts[k] = the relations rank k holds in the order they were dealt, cross_rels).
+    Pinned against the reference's own function: tests/golden/relpart_*.npz (tests/golden/gen_golden_relpart.py)."""
+    rels = np.asarray(rels, np.int64)
+    n_edges = len(rels)
+    uniq, cnts = np.unique(rels, return_counts=True)
+    order = np.flip(np.argsort(cnts))
+    large = min(int(n_edges * threshold), int(n_edges / world))
+    load = np.zeros(world, np.int64)
+    rel_parts = [[] for _ in range(world)]
+    cross = []
+    # one (first rank-in-relation, rank) segment per (relation, rank) pair: edge number k of relation r (k counted along the edge list)
+    # belongs to the last segment of r that starts at or below k
+    seg_rel, seg_start, seg_rank = [], [], []
+    for k in order:
+        r, cnt = int(uniq[k]), int(cnts[k])
+        if cnt > large:
+            share, done = cnt // world + 1, 0
+            for w in range(world):
+                take = min(share, cnt - done)
+                rel_parts[w].append(r)            # (the reference lists r on every rank, also on one whose share came out empty)
+                if take > 0:
+                    seg_rel.append(r); seg_start.append(done); seg_rank.append(w)
+                load[w] += take
+                done += take
+            cross.append(r)
+        else:
+            w = int(np.argmin(load))
+            rel_parts[w].append(r)
+            seg_rel.append(r); seg_start.append(0); seg_rank.append(w)
+            load[w] += cnt
+    # k = position of every edge among the edges of its relation, in edge-list order
+    by_rel = np.argsort(rels, kind="stable")
+    first = np.searchsorted(rels[by_rel], uniq)
+    k_in_rel = np.empty(n_edges, np.int64)
+    k_in_rel[by_rel] = np.arange(n_edges) - np.repeat(first, cnts)
+    if n_edges == 0:
+        return np.zeros(0, np.int64), [np.asarray(x, np.int64) for x in rel_parts], np.asarray(cross, np.int64)
+    span = int(cnts.max()) + 1
+    seg_key = np.asarray(seg_rel, np.int64) * span + np.asarray(seg_start, np.int64)
+    so = np.argsort(seg_key, kind="stable")
+    seg = np.searchsorted(seg_key[so], rels * span + k_in_rel, side="right") - 1
+    part = np.asarray(seg_rank, np.int64)[so][seg]
+    return part, [np.asarray(x, np.int64) for x in rel_parts], np.asarray(cross, np.int64)
+
+
+def choose_relation_partition(rels, world, policy="auto", tolerance=1.1):
+    """what `--rel_part` does with the training triples (`--rel_part_policy`):
+      whole  whole relations to ranks (relation_partition): every relation row has ONE owner, no relation exchange at all;
+      soft   the reference's partition (soft_relation_partition): large relations dealt over all ranks - an even edge split, and as
+             soon as one relation lives on several ranks the relation gradients are all-gathered and applied by every rank
+             (DistEngine(rel_local=False): exact for ANY edge split);
+      auto   whole while the fullest rank stays within `tolerance` x the mean edge share, soft otherwise.
+    Returns (mode, part[i] = rank of edge i, owner[r] = the rank of relation r / -1 no edges / -2 split over ranks, cross_rels)."""
+    if policy not in ("auto", "soft", "whole"):
+        raise ValueError("relation partition policy %r" % (policy,))
+    rels = np.asarray(rels, np.int64)
+    if policy in ("auto", "whole"):
+        owner, part = relation_partition(rels, world)
+        cnt = np.bincount(part, minlength=world)
+        if policy == "whole" or cnt.max() <= tolerance * cnt.mean():
+            return "whole", part, owner, np.zeros(0, np.int64)
+    part, rel_parts, cross = soft_relation_partition(rels, world)
+    owner = np.full(int(rels.max()) + 1 if len(rels) else 0, -1, np.int64)
+    for k, rs in enumerate(rel_parts):
+        owner[rs] = k
+    owner[cross] = -2
+    return "soft", part, owner, cross
+
+
 def relation_rows_from_owners(rel, rel_state, owner, group=None):
     """after training with rel_local: every rank's replica holds the current rows of ITS relations only - collect the owners' rows
     into rank 0's replica (gather through the process group; relations nobody owns keep their initial rows)."""

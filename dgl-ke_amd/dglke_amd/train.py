@@ -74,10 +74,14 @@ class ArgParser(argparse.ArgumentParser):
         a('--mix_cpu_gpu', action='store_true')
         a('--valid', action='store_true')
         a('--rel_part', action='store_true',
-          help='multi-GPU a2a mode: split the training triples BY RELATION over the trainers (whole relations, most frequent first, '
-               'to the trainer with the fewest edges); a relation row is updated only where its edges are - no relation exchange.  '
-               'Unlike the reference, one relation is never split over several trainers: a relation with more than 1 / trainers '
-               'of the edges unbalances the split (a warning says so)')
+          help='multi-GPU a2a mode: split the training triples BY RELATION over the trainers (see --rel_part_policy); while every '
+               'relation lives on one trainer its row is updated only there - no relation exchange')
+        a('--rel_part_policy', default='auto', choices=['auto', 'soft', 'whole'],
+          help='whole: whole relations, most frequent first, to the trainer with the fewest edges (never split: a relation with more '
+               'than 1 / trainers of the edges unbalances the split).  soft: the reference\'s partition (SoftRelationPartition: '
+               'relations with more than min(5 %%, 1 / trainers) of the edges are dealt evenly over all trainers) - even edge shares; '
+               'the relation gradients are then all-gathered and applied by every trainer.  auto (default): whole while the fullest '
+               'trainer stays within 1.1 x the mean edge share, soft otherwise')
         a('--async_update', action='store_true')
         a('--has_edge_importance', action='store_true')
         # additions of this build
@@ -579,34 +583,39 @@ class A2ATrainer(ShardedTrainer):
         own_gpu = len(set(args.gpu)) == world
         self.comm = kd.make_comm() if own_gpu else kd.HostStagedComm()
         slack = args.dist_slack if getattr(args, 'dist_slack', None) else float(os.environ.get("KGE_DIST_SLACK", "1.5"))
-        # --rel_part (the reference's multi-GPU recipes pass it, examples/freebase/multi_gpu.sh): the triples are split BY RELATION,
-        # every relation row is updated on the one rank that owns its edges - no relation exchange (dist.DistEngine rel_local)
+        # --rel_part (the reference's multi-GPU recipes pass it, examples/freebase/multi_gpu.sh): the triples are split BY RELATION
+        # (dist.choose_relation_partition: whole relations while that balances, else the reference's SoftRelationPartition with its
+        # large relations dealt over all trainers).  While every relation lives on ONE trainer its row is updated there and nowhere
+        # else - no relation exchange (dist.DistEngine rel_local); with split relations the relation gradients are all-gathered
+        # and applied by every trainer like without --rel_part (exact for any edge split), only the edge shares are the reference's
         self.rel_part = bool(getattr(args, 'rel_part', False))
-        self.de = kd.DistEngine(self.engine, self.spec, self.ent, self.ent_state, comm=self.comm, slack=slack,
-                                rel_local=self.rel_part)
-        # the pull of step s+1 may overlap step s only under the staleness --async_update licenses (tensor_models.py:136-175);
-        # without the flag every step gathers after its predecessor's update has landed, like the reference
-        self.pipelined = bool(getattr(args, 'async_update', False))
         tr = dataset.train
-        self.rel_owner = None
+        self.rel_owner, self.rel_local, part = None, False, None
         if self.rel_part:
-            self.rel_owner, edge_rank = kd.relation_partition(tr[1], world)
+            mode, edge_rank, self.rel_owner, cross = kd.choose_relation_partition(
+                tr[1], world, getattr(args, 'rel_part_policy', 'auto'))
+            self.rel_local = len(cross) == 0
             part = np.nonzero(edge_rank == rank)[0]
             cnt = np.bincount(edge_rank, minlength=world)
             if rank == 0:
-                print("relation partition: %d relations over %d trainers, edges per trainer %s" % (
-                    int((self.rel_owner >= 0).sum()), world, cnt.tolist()))
+                print("relation partition (%s): %d relations over %d trainers, edges per trainer %s%s" % (
+                    mode, int((self.rel_owner != -1).sum()), world, cnt.tolist(),
+                    "" if self.rel_local else "; %d relations split over the trainers: relation gradients all-gathered" % len(cross)))
                 if cnt.max() > 1.5 * cnt.mean():
-                    # whole relations only (no split relations, dist.relation_partition): a relation with more than 1 / world of the
-                    # edges unbalances the trainers; every trainer runs max_step steps, so the light trainers revisit their edges more
-                    # often than the reference's BalancedRelationPartition (which splits such a relation) would
-                    print("WARNING: --rel_part leaves trainer %d with %.2f x the mean edge share (relations are not split over "
-                          "trainers here; the most frequent relation holds %.1f %% of the edges)"
+                    # (--rel_part_policy whole only: a relation with more than 1 / world of the edges unbalances the trainers; every
+                    # trainer runs max_step steps, so the light trainers revisit their edges more often than under the reference's split)
+                    print("WARNING: --rel_part leaves trainer %d with %.2f x the mean edge share (whole relations only; the most "
+                          "frequent relation holds %.1f %% of the edges; --rel_part_policy soft splits it)"
                           % (int(cnt.argmax()), cnt.max() / cnt.mean(), 100.0 * np.bincount(np.asarray(tr[1])).max() / len(tr[1])))
             if cnt.min() < B:            # the partition is the same on every rank: every rank sees the short one and stops HERE, before
                 raise KgeError("--rel_part: trainer %d gets %d training triples, fewer than --batch_size %d (%d relations over %d "
-                               "trainers)" % (int(cnt.argmin()), int(cnt.min()), B, int((self.rel_owner >= 0).sum()), world))   # any collective
-        else:
+                               "trainers)" % (int(cnt.argmin()), int(cnt.min()), B, int((self.rel_owner != -1).sum()), world))   # any collective
+        self.de = kd.DistEngine(self.engine, self.spec, self.ent, self.ent_state, comm=self.comm, slack=slack,
+                                rel_local=self.rel_local)
+        # the pull of step s+1 may overlap step s only under the staleness --async_update licenses (tensor_models.py:136-175);
+        # without the flag every step gathers after its predecessor's update has landed, like the reference
+        self.pipelined = bool(getattr(args, 'async_update', False))
+        if part is None:
             part = np.array_split(np.random.RandomState(args.seed).permutation(len(tr[0])), world)[rank]
         if len(part) < B:
             raise KgeError("--batch_size %d is larger than a trainer's share of the training triples (%d over %d trainers)"
@@ -641,7 +650,7 @@ class A2ATrainer(ShardedTrainer):
         th.cuda.synchronize()
         parts = [None] * self.world if self.rank == 0 else None
         dist.gather_object(self.ent.cpu(), parts, dst=0)
-        if self.rel_part:                    # every replica holds the current rows of ITS relations only: collect them on rank 0
+        if self.rel_local:                   # every replica holds the current rows of ITS relations only: collect them on rank 0
             from . import dist as kd
             kd.relation_rows_from_owners(self.engine.rel, self.engine.rel_state, self.rel_owner)
         if self.rank == 0:

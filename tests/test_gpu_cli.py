@@ -205,9 +205,9 @@ def test_train_cli_transr_lanes_and_rejected_flags(tmp_path, capsys):
 
 @pytest.mark.parametrize("extra,nproc", [(["--dist_mode", "p2p"], 2), (["--dist_mode", "p2p", "--num_proc", "4"], 4), ([], 2),
                                          (["--neg_deg_sample", "--async_update"], 2), (["--dist_slack", "0.05"], 2),
-                                         (["--rel_part"], 2)],
+                                         (["--rel_part"], 2), (["--rel_part", "--rel_part_policy", "soft"], 2)],
                          ids=["p2p_one_per_gpu", "p2p_num_proc_4", "a2a_default", "a2a_neg_deg_sample_pipelined", "a2a_buckets_grow",
-                              "a2a_rel_part"])
+                              "a2a_rel_part", "a2a_rel_part_soft"])
 def test_train_cli_multi_process_shared_tables(tmp_path, extra, nproc):
     """`--gpu 0 0`: two trainer processes (here on one GPU).  --dist_mode p2p: peer-to-peer shared tables - hipIpc mapping,
     sharded fused step, gather for evaluation and saving; `--num_proc 4` on two listed GPUs = two processes per GPU like the
@@ -232,7 +232,9 @@ def test_train_cli_multi_process_shared_tables(tmp_path, extra, nproc):
         assert "[proc %d][Train](600/600) average loss:" % k in out, out[-2000:]
     assert "[0]Valid average MRR:" in out and "[0]Test average MRR:" in out
     if "--rel_part" in extra:            # triples split by relation, relation rows updated on their owner, collected on rank 0
-        assert "relation partition:" in out and "over 2 trainers" in out, out[-2000:]
+        assert "relation partition (" in out and "over 2 trainers" in out, out[-2000:]
+        # the reference's own partition splits the large relations over the trainers: their gradients are exchanged like without the flag
+        assert ("split over the trainers: relation gradients all-gathered" in out) == ("soft" in extra), out[-2000:]
     if "--dist_slack" in extra:          # buckets of 0.05 x the mean share (+ 64 rows) cannot hold a batch: they grow before the first group runs
         assert "owner buckets grow from" in out, out[-2000:]
     mrr = float([l for l in out.split("\n") if l.startswith("[0]Test average MRR:")][0].split(":")[1])
