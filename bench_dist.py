@@ -13,10 +13,12 @@ bench's step on the same tables.
 Two multi-GPU modes (KGE_DIST_MODE), one is the headline, the other a bounded secondary leg on the same line:
   a2a (default)  BASELINE.json's north_star partitioning: entity table range-sharded, relation table replicated, the
                  parameter-server semantics (pull -> compute -> push, owner applies) as RCCL all-to-all collectives
-                 (dglke_amd/dist.py): routing on the device, fixed-size messages, no host work in the step; the pull of
-                 step s+1 overlaps step s (one-step-stale rows, the reference's --async_update licence).  Eager launches
-                 (RCCL collectives do not replay reliably from hipGraphs on this stack); at N = 1 there is no collective
-                 and [1 sampler launch + G steps] replay from a hipGraph.
+                 (dglke_amd/dist.py): routing on the device, fixed-size messages, no host work in the step.  Per sampled group
+                 one sampler launch + the bucket-capacity check, then ONE hipGraph of [routing of the group, one all-to-all of
+                 the group's request ids, the steps with their row / gradient exchanges] (DistEngine.run_group, round 5: RCCL
+                 collectives DO replay from hipGraphs - profiles/r05_rccl_capture_diagnosis.txt); the supervisor falls back to
+                 eager launches with the pull of step s+1 overlapping step s (one-step-stale rows, the reference's
+                 --async_update licence), then to the synchronous eager step, the c10d wrappers, p2p and independent replicas.
   p2p            the shared-table Hogwild mode of the reference's multi-GPU trainer with the shared table living in the
                  union of the GPUs' HBM: every rank maps all peer shards (hipIpc) and kge_step_sharded reads / updates
                  remote rows directly over xGMI (BOTH tables sharded).  No collective and no host work per step.
