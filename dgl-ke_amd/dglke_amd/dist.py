@@ -829,7 +829,7 @@ def soft_relation_partition(rels, world, threshold=0.05):
     edges to rank 0, 1, ... until it is used up; these are the reference's `cross_rels`), every other relation goes whole to the rank
     with the fewest edges so far.  A relation's edges fill its ranks in the order of the edge list.
     Returns (part[i] = rank of edge i, rel_parts[k] = the relations rank k holds in the order they were dealt, cross_rels).
-    Pinned against the reference's own function: tests/golden/relpart_*.npz (tests/golden/gen_golden_relpart.py)."""
+    Pinned against the reference's own function: tests/golden/relpart/*.npz (tests/golden/gen_golden_relpart.py)."""
     rels = np.asarray(rels, np.int64)
     n_edges = len(rels)
     uniq, cnts = np.unique(rels, return_counts=True)

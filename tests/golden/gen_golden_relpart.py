@@ -2,7 +2,7 @@
 """Golden vectors for `--rel_part`: the UNMODIFIED reference's SoftRelationPartition (dataloader/sampler.py:32-148 - the function
 its TrainDataset calls for `--rel_part`, sampler.py:363-365) run on seeded relation-id lists.
 
-TEST INFRASTRUCTURE ONLY; runs in the build container (needs /root/reference), writes tests/golden/relpart_*.npz, which
+TEST INFRASTRUCTURE ONLY; runs in the build container (needs /root/reference), writes tests/golden/relpart/relpart_*.npz, which
 tests/test_relpart.py holds dglke_amd.dist.soft_relation_partition against.
 
 The reference permutes the triples in place and returns index RANGES; the heads passed in are the edge numbers 0 .. E-1, so that the
@@ -53,7 +53,7 @@ def main():
                    cross_rels=np.asarray(cross_rels, np.int64))
         for k in range(W):
             out["rel_parts_%d" % k] = np.asarray(rel_parts[k], np.int64)
-        np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+        np.savez_compressed(os.path.join(OUT, "relpart", name + ".npz"), **out)
         print(name, "edges per rank", np.bincount(part_of_edge, minlength=W).tolist(), "cross", cross_rels.tolist())
 
 

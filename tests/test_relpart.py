@@ -9,7 +9,7 @@ import pytest
 
 from dglke_amd import dist as kd
 
-GOLD = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "relpart_*.npz")))
+GOLD = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "relpart", "relpart_*.npz")))
 
 
 def test_golden_files_present():
