@@ -399,7 +399,15 @@ def other_configs(steps=600, timeout_s=150.0, only=None):
             # the N > 1 code path on one GPU: the SAME a2a step with its RCCL collectives kept at world 1 (ids once per group, rows
             # and gradient messages per step, relation all-gather), kernels + collectives replayed from one hipGraph per group
             ("rotate_freebase_a2a_forced_exchange", ["--workload", "rotate_freebase"],
-             {"KGE_DIST_MODE": "a2a", "KGE_DIST_FORCE_COLL": "1", "KGE_DIST_PIPELINE": "0"})]
+             {"KGE_DIST_MODE": "a2a", "KGE_DIST_FORCE_COLL": "1", "KGE_DIST_PIPELINE": "0"}),
+            # ... and as `bench.py --gpus N` runs it at N > 1: triples partitioned by relation (no relation exchange), synchronous, then
+            # with every exchange off the compute stream (DistEngine._steps_overlapped: push + owner-side apply of step s and the
+            # pull of step s+2 next to step s+1; one-step-stale entity rows - the reference's --async_update licence, which its own
+            # recipe for this config passes)
+            ("rotate_freebase_a2a_forced_exchange_relpart", ["--workload", "rotate_freebase"],
+             {"KGE_DIST_MODE": "a2a", "KGE_DIST_FORCE_COLL": "1", "KGE_DIST_PIPELINE": "0", "KGE_DIST_REL_PART": "force"}),
+            ("rotate_freebase_a2a_forced_exchange_relpart_overlapped", ["--workload", "rotate_freebase"],
+             {"KGE_DIST_MODE": "a2a", "KGE_DIST_FORCE_COLL": "1", "KGE_DIST_PIPELINE": "overlap", "KGE_DIST_REL_PART": "force"})]
     res = {}
     for name, extra, env_extra in legs:
         if only is not None and name not in only:
@@ -433,6 +441,9 @@ def other_configs(steps=600, timeout_s=150.0, only=None):
                 res[name]["mode"] = d["config"]["mode"]
             if len(str(d.get("config", {}).get("launch") or "")) in range(1, 40):      # (a2a engine: "graph" / "eager")
                 res[name]["launch"] = d["config"]["launch"]
+            for k in ("schedule", "relation_partition"):
+                if k in d.get("config", {}):
+                    res[name][k] = d["config"][k]
         except subprocess.TimeoutExpired:
             res[name] = {"error": "leg exceeded %.0f s" % timeout_s}
         except Exception as e:  # noqa: BLE001 - a leg must never hide the headline

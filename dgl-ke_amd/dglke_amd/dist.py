@@ -468,6 +468,7 @@ class DistEngine(object):
         self.rel_msg = z((b.B, ld_r), dt)
         self.all_rel = self.rel_msg if (not self.coll or self.rel_local) else z((W * b.B, ld_r), dt)
         self.zero_state = z(W * cap + 1, dt)
+        self._ent_msg_alt = None      # the second entity-message buffer of the overlapped schedule (_steps_overlapped): made on first use
 
     def ensure_capacity(self, batches, log=None):
         """call with every freshly sampled GROUP of batches before its steps: measures the largest owner-bucket fill of the group on
@@ -582,11 +583,103 @@ class DistEngine(object):
             self.comm.close()
 
     def _steps(self, batches, pipelined):
+        if pipelined == "overlap":
+            return self._steps_overlapped(batches)
         for k, b in enumerate(batches):
             if pipelined:
                 self.step_pipelined(b, batches[k + 1] if k + 1 < len(batches) else None)
             else:
                 self.step(b)
+
+    def _steps_overlapped(self, batches):
+        """the steps of one group with EVERY exchange off the compute stream (round 5; the same --async_update licence as
+        step_pipelined and the SAME results bit for bit: step s+1 computes on entity rows gathered after update s-1 and before
+        update s, relation rows are never stale):
+
+            main   pull(0) | compute(0) rel(0) | compute(1) rel(1) | compute(2) rel(2) | ...                         | join
+            side           | pull(1)           | push(0) apply(0) pull(2) | push(1) apply(1) pull(3) | ... push(n-1) apply(n-1)
+
+        compute(k) waits for pull(k) only; push(k) = the reverse all-to-all of step k's entity messages, apply(k) = the owner-side
+        Adagrad on the shard, pull(k+2) = owner gather + row all-to-all into the cache slot compute(k) has just left.  The step's
+        time is max(compute, its exchanges) instead of their sum (step_pipelined hides the pull only; the reference's
+        --async_update hides the update the same way, tensor_models.py:136-175).  rel(k): the relation exchange (none under
+        relation partitioning) and the relation apply stay on the compute stream, in step order - compute(k+1) reads the
+        relation table itself.  Entity messages alternate between two buffers (push(k) reads one while compute(k+1) writes the
+        other); the first step of a group pulls for itself behind the previous group's last apply, the group ends joined."""
+        n = len(batches)
+        main = torch.cuda.current_stream(self.dev)
+        if self.slots is None:
+            self._setup(batches[0])
+        if self._side is None:
+            import os
+            # (KGE_DIST_SIDE_PRIORITY=-1: the exchange stream ahead of the compute stream in the hardware queues - A/B aid)
+            self._side = torch.cuda.Stream(device=self.dev, priority=int(os.environ.get("KGE_DIST_SIDE_PRIORITY", "0")))
+            self._explicit = isinstance(self.comm, RcclComm) and isinstance(self.ops, HipOps)
+            E = _lib.RawEvent if self._explicit else _lib.TorchEvent
+            self._ev = [dict(main=E(), gather=E(), rows=E()) for _ in range(2)]
+        if getattr(self, "_ev_ov", None) is None:
+            E = _lib.RawEvent if self._explicit else _lib.TorchEvent
+            self._ev_ov = [dict(comp=E()) for _ in range(2)] + [dict(done=E())]
+        W, sp = self.spec.world, self.spec
+        if self._ent_msg_alt is None:
+            self._ent_msg_alt = torch.zeros_like(self.ent_msg)
+        msgs = (self.ent_msg, self._ent_msg_alt)
+        side = self._side
+
+        def on_side(fn):
+            if self._explicit:
+                _lib.use_stream(side.cuda_stream)
+                try:
+                    return fn()
+                finally:
+                    _lib.use_stream(main.cuda_stream)
+            with torch.cuda.stream(side):
+                return fn()
+
+        outer = _lib.use_stream(main.cuda_stream) if self._explicit else None
+        try:
+            if self._pre is not None:                 # a pull that ran ahead outside this schedule: behind it, then dropped
+                self._pre[2].wait(main)
+                self._pre = None
+            p0 = self._parity
+            lbs = [None] * n
+            lbs[0] = self.pull(batches[0], p0)        # behind everything enqueued so far: the last apply of the previous group
+            if n > 1:
+                ev = self._ev[p0 ^ 1]
+                ev["main"].record(main)
+                ev["main"].wait(side)
+                lbs[1] = on_side(lambda: self._pull_ahead(batches[1], p0 ^ 1, ev))
+            Wr = 1 if self.rel_local else W
+            for k in range(n):
+                par = k & 1
+                lb = lbs[k]
+                if k > 0:
+                    self._ev[lb.slot]["rows"].wait(main)
+                msg = msgs[par]
+                self._compute(lb, msg)
+                # the relation half on the compute stream, in step order (compute(k+1) reads the table it updates)
+                if self.coll and not self.rel_local:
+                    self.comm.all_gather(self.all_rel.view(-1), self.rel_msg.view(-1))
+                self.ops.apply_merged(self.engine.rel, self.engine.rel_state, Wr, lb.B, None, 0, self.all_rel, 1, self.lr)
+                evc = self._ev_ov[par]["comp"]
+                evc.record(main)
+                evc.wait(side)
+
+                def side_chain(k=k, lb=lb, msg=msg):
+                    recv = self.recv_msg if self.coll else msg[:W * self.cap]
+                    if self.coll:
+                        self.comm.all_to_all(self.recv_msg, msg[:W * self.cap])
+                    self.ops.apply_merged(self.ent, self.ent_state, W, self.cap, lb.recv_ids, sp.lo, recv, 2, self.lr)
+                    if k + 2 < n:                     # into the cache slot compute(k) has just left
+                        lbs[k + 2] = self._pull_ahead(batches[k + 2], lb.slot, self._ev[lb.slot])
+                on_side(side_chain)
+            done = self._ev_ov[2]["done"]
+            done.record(side)
+            done.wait(main)
+            self._parity = p0 ^ (n & 1)
+        finally:
+            if self._explicit:
+                _lib.use_stream(outer)
 
     def run_group(self, batches, log=None, graph=True, pipelined=False):
         """one freshly sampled GROUP of batches, the trainer's order: size the owner buckets for it (ensure_capacity: the one device
@@ -595,7 +688,8 @@ class DistEngine(object):
         (RcclComm; no collective at world 1): kernels AND collectives of the group without a host call in between (round 5: the
         eager step was host-bound, 154 us against 138 us per cfg-R step at world 1 with the collectives forced).  The first
         group of a geometry runs eagerly (it allocates every buffer) and is recorded afterwards; a capacity change drops the graphs.
-        pipelined: the pull of step s+1 on the side stream next to step s (--async_update licence), inside the graph as a fork."""
+        pipelined: the pull of step s+1 on the side stream next to step s (--async_update licence), inside the graph as a fork;
+        pipelined="overlap": push, owner-side apply and pull all on the side stream (_steps_overlapped) - the same results."""
         self.ensure_capacity(batches, log)
         b0 = batches[0]
         smp = getattr(b0, "sampler", None)
@@ -608,7 +702,8 @@ class DistEngine(object):
             self.prepare_group(batches, check_capacity=False)
             self._steps(batches, pipelined)
             return False
-        key = (id(smp), slots[0], len(slots), tuple(b.neg_head for b in batches[:2]), self.cap, bool(pipelined))
+        key = (id(smp), slots[0], len(slots), tuple(b.neg_head for b in batches[:2]), self.cap,
+               pipelined if isinstance(pipelined, str) else bool(pipelined))
         g = self._ggraphs.get(key)
         if g is None:
             self.prepare_group(batches, check_capacity=False)      # this group: eagerly (allocates the pool and every buffer) ...
@@ -689,19 +784,20 @@ class DistEngine(object):
         return lb
 
     # ---- compute + push + owner-side apply -----------------------------------------------------------------------------
-    def _compute(self, lb):
+    def _compute(self, lb, ent_msg=None):
         s = self.slots[lb.slot]
+        ent_msg = self.ent_msg if ent_msg is None else ent_msg
         if not lb.c.counts_dev:
             self.ops.reset_rel_pads(self.rel_msg, self.d_r, lb.UR)      # host-built plan: UR is exact, the rows behind it are pads
         # The step's kernels between the pull and the push replay from a small hipGraph per (routed batch, cache slot) when
         # precapture() recorded one (opt-in, KGE_DIST_COMPUTE_GRAPH=1: bit-identical, and SLOWER than the six eager launches it
         # replaces - 180 vs 172 us per step).  These small per-step graphs predate run_group (round 5), which records the whole group WITH its collectives.
-        if self._cgraphs and not torch.cuda.is_current_stream_capturing():
+        if self._cgraphs and ent_msg is self.ent_msg and not torch.cuda.is_current_stream_capturing():
             g = self._cgraphs.get((id(lb), lb.slot))
             if g is not None:
                 g.replay()
                 return
-        self.ops.step_grads(self.engine, lb, s.cache, self.ent_msg, self.rel_msg, self.zero_state)
+        self.ops.step_grads(self.engine, lb, s.cache, ent_msg, self.rel_msg, self.zero_state)
 
     def _push_apply(self, lb, before_apply=None):
         sp, s, W = self.spec, self.slots[lb.slot], self.spec.world

@@ -612,9 +612,13 @@ class A2ATrainer(ShardedTrainer):
                                "trainers)" % (int(cnt.argmin()), int(cnt.min()), B, int((self.rel_owner != -1).sum()), world))   # any collective
         self.de = kd.DistEngine(self.engine, self.spec, self.ent, self.ent_state, comm=self.comm, slack=slack,
                                 rel_local=self.rel_local)
-        # the pull of step s+1 may overlap step s only under the staleness --async_update licenses (tensor_models.py:136-175);
+        # exchanges may overlap the steps only under the staleness --async_update licenses (tensor_models.py:136-175): then push,
+        # owner-side apply and the pull of step s+2 run on a side stream next to step s+1 (DistEngine._steps_overlapped: entity rows
+        # exactly one step stale, relation rows current; KGE_DIST_PIPELINE=1: the pull only, the same tables bit for bit);
         # without the flag every step gathers after its predecessor's update has landed, like the reference
         self.pipelined = bool(getattr(args, 'async_update', False))
+        if self.pipelined and os.environ.get("KGE_DIST_PIPELINE", "overlap") == "overlap":
+            self.pipelined = "overlap"
         if part is None:
             part = np.array_split(np.random.RandomState(args.seed).permutation(len(tr[0])), world)[rank]
         if len(part) < B:

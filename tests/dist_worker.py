@@ -90,6 +90,9 @@ def main():
                 for b in dbs:
                     a = smp.slot_arrays(b.slot)
                     drawn.append(dict(h=a["h_gid"], t=a["t_gid"], r=a["rel_ids"], neg=a["neg_ids"], neg_head=np.int64(b.neg_head)))
+                if mode == "sampled_overlap":     # push, apply and pull on the side stream: the same statement as sampled_pipelined
+                    de._steps(dbs, "overlap")
+                    continue
                 for k, b in enumerate(dbs):
                     if mode == "sampled_pipelined":
                         de.step_pipelined(b, dbs[k + 1] if k + 1 < G else None)
@@ -109,6 +112,9 @@ def main():
             b = plan.make_batch(bt["h"], bt["t"], bt["r"], bt["neg"], N, N, bt["neg_head"], dev)
             b.UE = ue_bound                  # buffers are sized once for the bound (like the device sampler's slots)
             devb.append(b)
+        if mode == "overlap" and devb:            # all steps as ONE group of the overlapped schedule: the 'pipelined' statement
+            de._steps(devb, "overlap")
+            devb = []
         for s, b in enumerate(devb):
             if mode == "pipelined":
                 de.step_pipelined(b, devb[s + 1] if s + 1 < len(devb) else None)

@@ -212,6 +212,40 @@ def test_group_graph_with_recorded_collectives_equals_eager_launches(pipelined):
     assert float((res[0][1] > 0).sum()) > 100
 
 
+def test_overlapped_schedule_equals_pipelined_pull():
+    """DistEngine._steps_overlapped (push, owner-side apply and pull on the side stream; the compute stream runs compute + the
+    relation half back to back) is the SAME dataflow as step_pipelined - entity rows of step s+1 gathered after update s-1 and
+    before update s, relations never stale - so shard, state and relation table must come out bit-identical: as eager launches and
+    replayed from the group graphs, with the relation all-gather and under relation-local updates; world 1 through the collective
+    code path (RcclComm), group sizes 6, 6, 5, 5, 1, 6, 2."""
+    from dglke_amd import dist as kd
+    from dglke_amd.dataloader import DeviceSampler
+    from dglke_amd.engine import StepEngine
+    n_ent, n_rel, hidden, B, N = 6000, 40, 64, 128, 32
+    rng = np.random.RandomState(31)
+    h, r, t = rng.randint(0, n_ent, 30000), rng.randint(0, n_rel, 30000), rng.randint(0, n_ent, 30000)
+    for rel_local in (False, True):
+        res = []
+        for sched, graph in ((True, False), ("overlap", False), ("overlap", True)):
+            torch.manual_seed(3)
+            eng = StepEngine("RotatE", 1, n_rel, hidden, 12.0, 0.05, DEV, True, False, True, 1.0, 1e-6, 3)
+            ent = torch.empty(n_ent, 2 * hidden, device=DEV).uniform_(-0.2, 0.2)
+            state = torch.zeros(n_ent, device=DEV)
+            smp = DeviceSampler(h, r, t, n_ent, B, N, DEV, n_slots=6, seed=5)
+            de = kd.DistEngine(eng, kd.ShardSpec(n_ent, 1, 0), ent, state, always_collective=True, comm=kd.RcclComm(),
+                               rel_local=rel_local)
+            replayed = [de.run_group(smp.sample(n), graph=graph, pipelined=sched) for n in (6, 6, 5, 5, 1, 6, 2)]
+            torch.cuda.synchronize()
+            assert de.check_overflow() == 0
+            assert any(replayed) == graph
+            res.append((ent.cpu(), state.cpu(), eng.rel.cpu().clone(), eng.rel_state.cpu().clone()))
+            de.close()
+        for other in res[1:]:
+            for x, y in zip(res[0], other):
+                assert torch.equal(x, y)
+        assert float((res[0][1] > 0).sum()) > 100
+
+
 def test_gather_rows_req_skips_pads_and_foreign_ids():
     from dglke_amd import dist as kd
     t = torch.arange(0, 80, dtype=torch.float32, device=DEV).reshape(10, 8)
@@ -297,7 +331,7 @@ def test_apply_merged_equals_sequential_apply(nsrc, cap, dim, n_rows):
 
 
 def _run_workers(tmp_path, mode, world=2, transport="host"):
-    port = str(29700 + os.getpid() % 250 + {"random": 0, "disjoint": 1, "pipelined": 2, "nd": 6, "relpart": 7, "sampled": 8, "sampled_pipelined": 9}[mode] + (3 if transport == "rccl" else 0))
+    port = str(29700 + os.getpid() % 250 + {"random": 0, "disjoint": 1, "pipelined": 2, "nd": 6, "relpart": 7, "sampled": 8, "sampled_pipelined": 9, "overlap": 10, "sampled_overlap": 11}[mode] + (3 if transport == "rccl" else 0))
     env = dict(os.environ)
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), str(r), str(world), port, str(tmp_path), mode,
                                transport], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
@@ -338,7 +372,7 @@ def _oracle_statement(model, de_, dr_, z, world, mode):
     pulled = ent.copy()                    # what the pull of the current step saw
     for s, row in enumerate(bts):
         # (sampled_pipelined: the first step of every group of two pulls for itself, behind its predecessor's update)
-        src = pulled if mode == "pipelined" or (mode == "sampled_pipelined" and s % 2 == 1) else ent
+        src = pulled if mode in ("pipelined", "overlap") or (mode in ("sampled_pipelined", "sampled_overlap") and s % 2 == 1) else ent
         outs = [O.forward_backward(cfg, src, rel, bt["nid"], bt["h_local"], bt["t_local"], bt["r"], bt["neg"], bt["neg_head"],
                                    W.N, W.N) for bt in row]
         pulled = ent.copy()                # the pull of step s+1 runs now: after update s-1, before update s
@@ -351,7 +385,8 @@ def _oracle_statement(model, de_, dr_, z, world, mode):
 
 
 @pytest.mark.parametrize("mode,transport", [("random", "host"), ("pipelined", "host"), ("nd", "host"), ("relpart", "host"),
-                                            ("sampled", "host"), ("sampled_pipelined", "host"),
+                                            ("sampled", "host"), ("sampled_pipelined", "host"), ("overlap", "host"),
+                                            ("sampled_overlap", "host"), ("overlap", "rccl"),
                                             ("random", "rccl"), ("pipelined", "rccl"), ("relpart", "rccl"), ("sampled", "rccl")])
 def test_world2_hip_ops_match_the_oracle_statement(tmp_path, mode, transport):
     """`host`: two processes on ONE device, messages staged through gloo.  `rccl`: two processes on TWO devices, the product's
@@ -380,7 +415,7 @@ def test_world2_hip_ops_match_the_oracle_statement(tmp_path, mode, transport):
         assert np.array_equal(z[model + "_relstate0"], z[model + "_relstate1"])
 
 
-@pytest.mark.parametrize("mode", ["pipelined", "relpart", "sampled", "sampled_pipelined"])
+@pytest.mark.parametrize("mode", ["pipelined", "relpart", "sampled", "sampled_pipelined", "overlap", "sampled_overlap"])
 def test_world4_on_one_device_matches_the_oracle_statement(tmp_path, mode):
     """four ranks (four processes sharing this GPU, messages through gloo): owner buckets for four shards, the merged apply with
     four sources and rows that arrive from several ranks at once, the one-step-stale pipeline / relation partitioning at a
