@@ -604,7 +604,8 @@ class DistEngine(object):
         time is max(compute, its exchanges) instead of their sum (step_pipelined hides the pull only; the reference's
         --async_update hides the update the same way, tensor_models.py:136-175).  rel(k): the relation exchange (none under
         relation partitioning) and the relation apply stay on the compute stream, in step order - compute(k+1) reads the
-        relation table itself.  Entity messages alternate between two buffers (push(k) reads one while compute(k+1) writes the
+        relation table itself (with all-gathered relations the exchange itself heads the side chain: one stream issues every
+        collective).  Entity messages alternate between two buffers (push(k) reads one while compute(k+1) writes the
         other); the first step of a group pulls for itself behind the previous group's last apply, the group ends joined."""
         n = len(batches)
         main = torch.cuda.current_stream(self.dev)
@@ -619,7 +620,7 @@ class DistEngine(object):
             self._ev = [dict(main=E(), gather=E(), rows=E()) for _ in range(2)]
         if getattr(self, "_ev_ov", None) is None:
             E = _lib.RawEvent if self._explicit else _lib.TorchEvent
-            self._ev_ov = [dict(comp=E()) for _ in range(2)] + [dict(done=E())]
+            self._ev_ov = [dict(comp=E(), rel=E()) for _ in range(2)] + [dict(done=E())]
         W, sp = self.spec.world, self.spec
         if self._ent_msg_alt is None:
             self._ent_msg_alt = torch.zeros_like(self.ent_msg)
@@ -657,13 +658,19 @@ class DistEngine(object):
                     self._ev[lb.slot]["rows"].wait(main)
                 msg = msgs[par]
                 self._compute(lb, msg)
-                # the relation half on the compute stream, in step order (compute(k+1) reads the table it updates)
-                if self.coll and not self.rel_local:
-                    self.comm.all_gather(self.all_rel.view(-1), self.rel_msg.view(-1))
-                self.ops.apply_merged(self.engine.rel, self.engine.rel_state, Wr, lb.B, None, 0, self.all_rel, 1, self.lr)
                 evc = self._ev_ov[par]["comp"]
                 evc.record(main)
                 evc.wait(side)
+                # the relation half: applied on the compute stream, in step order (compute(k+1) reads the table it updates); its
+                # exchange - none under relation partitioning - heads the side chain, so that ONE stream issues every collective
+                # of the communicator (two streams driving one communicator concurrently is what the supervisor's rccl-sync attempt
+                # exists to rule out) and the compute stream waits for this one exchange only
+                if self.coll and not self.rel_local:
+                    on_side(lambda: self.comm.all_gather(self.all_rel.view(-1), self.rel_msg.view(-1)))
+                    evr = self._ev_ov[par]["rel"]
+                    evr.record(side)
+                    evr.wait(main)
+                self.ops.apply_merged(self.engine.rel, self.engine.rel_state, Wr, lb.B, None, 0, self.all_rel, 1, self.lr)
 
                 def side_chain(k=k, lb=lb, msg=msg):
                     recv = self.recv_msg if self.coll else msg[:W * self.cap]
