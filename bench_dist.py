@@ -271,8 +271,9 @@ def _deliver(line):
 # on the direct librccl communicator, the same on the c10d wrappers, the peer-to-peer shared tables, and - so that a node whose
 # links do not come up still yields a measured line that says so - N independent replicas of the per-GPU step without any exchange
 ATTEMPTS = (("a2a", "rccl-graph"), ("a2a", "rccl"), ("a2a", "rccl-sync"), ("a2a", "torch"), ("p2p", ""), ("replicas", ""))
-# ("rccl-graph", round 5: kernels AND collectives of a group of steps replay from one hipGraph - DistEngine.run_group; "rccl": the
-#  same calls as eager launches, the pull of step s+1 on a side stream)
+# ("rccl-graph", round 5: kernels AND collectives of a group of steps replay from one hipGraph - DistEngine.run_group: the synchronous
+#  schedule is timed and delivered, then the overlapped one, and the faster is the line's value; "rccl": the same calls as eager
+#  launches, every exchange on a side stream - DistEngine._steps_overlapped)
 # ("rccl-sync": the same direct communicator with the synchronous schedule - no pull on a side stream, one stream issues every
 #  collective: if two streams sharing one communicator are what hangs, this attempt still measures the north_star mode)
 # seconds allowed until the named progress mark appears (a hang shows up as a mark that does not come;
@@ -322,6 +323,8 @@ def orchestrate(args, world, rank, local_rank):
             env["KGE_DIST_COMM"], env["KGE_DIST_PIPELINE"], env["KGE_DIST_GRAPH"] = "rccl", "0", "0"
         elif comm:
             env["KGE_DIST_COMM"], env["KGE_DIST_GRAPH"] = comm, "0"
+            if comm == "rccl":           # eager launches: every exchange on the side stream (117.7 vs 136.7 us synchronous on the world-1 proxy)
+                env.setdefault("KGE_DIST_PIPELINE", "overlap")
         # (KGE_DIST_WORKER_SCRIPT: the CPU test of this supervisor substitutes a scripted worker, tests/test_bench_supervisor.py)
         cmd = [sys.executable, os.environ.get("KGE_DIST_WORKER_SCRIPT") or
                os.path.join(os.path.dirname(os.path.abspath(__file__)), "bench.py")] + sys.argv[1:]
