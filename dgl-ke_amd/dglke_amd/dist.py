@@ -908,10 +908,11 @@ class DistEngine(object):
 
 
 def relation_partition(rels, world):
-    """whole relations to ranks, most frequent first, each to the rank with the fewest edges so far (the reference's
-    BalancedRelationPartition, dataloader/sampler.py:150-254, WITHOUT its splitting of a relation over several partitions: a split
-    relation needs the cross-relation machinery - dual writes to a global table, general_models.py:590-637 - that relation-local
-    updates are there to avoid; the price is a less even edge split when one relation holds more than 1 / world of the edges).
+    """whole relations to ranks, most frequent first, each to the rank with the fewest edges so far (the greedy core of the
+    reference's partitioners, dataloader/sampler.py:32-254, WITHOUT their splitting of a large relation over several partitions:
+    a split relation needs the cross-relation machinery - dual writes to a global table, general_models.py:590-637 - that
+    relation-local updates are there to avoid; the price is a less even edge split when one relation holds more than 1 / world of
+    the edges - soft_relation_partition / choose_relation_partition below take over then).
     Returns (owner[n_rel_seen_max + 1] with -1 for relations without edges, part[i] = rank of edge i)."""
     rels = np.asarray(rels, np.int64)
     uniq, cnts = np.unique(rels, return_counts=True)
