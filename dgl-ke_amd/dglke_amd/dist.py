@@ -608,27 +608,39 @@ class DistEngine(object):
         collective).  Entity messages alternate between two buffers (push(k) reads one while compute(k+1) writes the
         other); the first step of a group pulls for itself behind the previous group's last apply, the group ends joined."""
         n = len(batches)
-        main = torch.cuda.current_stream(self.dev)
         if self.slots is None:
             self._setup(batches[0])
-        if self._side is None:
-            import os
-            # (KGE_DIST_SIDE_PRIORITY=-1: the exchange stream ahead of the compute stream in the hardware queues - A/B aid)
-            self._side = torch.cuda.Stream(device=self.dev, priority=int(os.environ.get("KGE_DIST_SIDE_PRIORITY", "0")))
-            self._explicit = isinstance(self.comm, RcclComm) and isinstance(self.ops, HipOps)
-            E = _lib.RawEvent if self._explicit else _lib.TorchEvent
-            self._ev = [dict(main=E(), gather=E(), rows=E()) for _ in range(2)]
-        if getattr(self, "_ev_ov", None) is None:
-            E = _lib.RawEvent if self._explicit else _lib.TorchEvent
-            self._ev_ov = [dict(comp=E(), rel=E()) for _ in range(2)] + [dict(done=E())]
+        host = self.dev.type != "cuda"                # CPU tensors (the gloo schedule tests): no streams - every call runs where it is
+        if host:                                      # issued, which IS one valid serialisation of the two queues below
+            class _Now(object):
+                def record(self, stream): pass
+                def wait(self, stream): pass
+            main = side = None
+            explicit = False
+            ev_pull = [dict(main=_Now(), gather=_Now(), rows=_Now()) for _ in range(2)]
+            ev_ov = [dict(comp=_Now(), rel=_Now()) for _ in range(2)] + [dict(done=_Now())]
+        else:
+            main = torch.cuda.current_stream(self.dev)
+            if self._side is None:
+                import os
+                # (KGE_DIST_SIDE_PRIORITY=-1: the exchange stream ahead of the compute stream in the hardware queues - A/B aid)
+                self._side = torch.cuda.Stream(device=self.dev, priority=int(os.environ.get("KGE_DIST_SIDE_PRIORITY", "0")))
+                self._explicit = isinstance(self.comm, RcclComm) and isinstance(self.ops, HipOps)
+                E = _lib.RawEvent if self._explicit else _lib.TorchEvent
+                self._ev = [dict(main=E(), gather=E(), rows=E()) for _ in range(2)]
+            if getattr(self, "_ev_ov", None) is None:
+                E = _lib.RawEvent if self._explicit else _lib.TorchEvent
+                self._ev_ov = [dict(comp=E(), rel=E()) for _ in range(2)] + [dict(done=E())]
+            side, explicit, ev_pull, ev_ov = self._side, self._explicit, self._ev, self._ev_ov
         W, sp = self.spec.world, self.spec
         if self._ent_msg_alt is None:
             self._ent_msg_alt = torch.zeros_like(self.ent_msg)
         msgs = (self.ent_msg, self._ent_msg_alt)
-        side = self._side
 
         def on_side(fn):
-            if self._explicit:
+            if host:
+                return fn()
+            if explicit:
                 _lib.use_stream(side.cuda_stream)
                 try:
                     return fn()
@@ -637,7 +649,7 @@ class DistEngine(object):
             with torch.cuda.stream(side):
                 return fn()
 
-        outer = _lib.use_stream(main.cuda_stream) if self._explicit else None
+        outer = _lib.use_stream(main.cuda_stream) if explicit else None
         try:
             if self._pre is not None:                 # a pull that ran ahead outside this schedule: behind it, then dropped
                 self._pre[2].wait(main)
@@ -646,7 +658,7 @@ class DistEngine(object):
             lbs = [None] * n
             lbs[0] = self.pull(batches[0], p0)        # behind everything enqueued so far: the last apply of the previous group
             if n > 1:
-                ev = self._ev[p0 ^ 1]
+                ev = ev_pull[p0 ^ 1]
                 ev["main"].record(main)
                 ev["main"].wait(side)
                 lbs[1] = on_side(lambda: self._pull_ahead(batches[1], p0 ^ 1, ev))
@@ -655,10 +667,10 @@ class DistEngine(object):
                 par = k & 1
                 lb = lbs[k]
                 if k > 0:
-                    self._ev[lb.slot]["rows"].wait(main)
+                    ev_pull[lb.slot]["rows"].wait(main)
                 msg = msgs[par]
                 self._compute(lb, msg)
-                evc = self._ev_ov[par]["comp"]
+                evc = ev_ov[par]["comp"]
                 evc.record(main)
                 evc.wait(side)
                 # the relation half: applied on the compute stream, in step order (compute(k+1) reads the table it updates); its
@@ -667,7 +679,7 @@ class DistEngine(object):
                 # exists to rule out) and the compute stream waits for this one exchange only
                 if self.coll and not self.rel_local:
                     on_side(lambda: self.comm.all_gather(self.all_rel.view(-1), self.rel_msg.view(-1)))
-                    evr = self._ev_ov[par]["rel"]
+                    evr = ev_ov[par]["rel"]
                     evr.record(side)
                     evr.wait(main)
                 self.ops.apply_merged(self.engine.rel, self.engine.rel_state, Wr, lb.B, None, 0, self.all_rel, 1, self.lr)
@@ -678,14 +690,14 @@ class DistEngine(object):
                         self.comm.all_to_all(self.recv_msg, msg[:W * self.cap])
                     self.ops.apply_merged(self.ent, self.ent_state, W, self.cap, lb.recv_ids, sp.lo, recv, 2, self.lr)
                     if k + 2 < n:                     # into the cache slot compute(k) has just left
-                        lbs[k + 2] = self._pull_ahead(batches[k + 2], lb.slot, self._ev[lb.slot])
+                        lbs[k + 2] = self._pull_ahead(batches[k + 2], lb.slot, ev_pull[lb.slot])
                 on_side(side_chain)
-            done = self._ev_ov[2]["done"]
+            done = ev_ov[2]["done"]
             done.record(side)
             done.wait(main)
             self._parity = p0 ^ (n & 1)
         finally:
-            if self._explicit:
+            if explicit:
                 _lib.use_stream(outer)
 
     def run_group(self, batches, log=None, graph=True, pipelined=False):

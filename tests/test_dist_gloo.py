@@ -172,7 +172,7 @@ class _FakeSampler(object):
         return batches
 
 
-def _worker(rank, world, port, ret, cap=CAP, heavy=False, group=1, relpart=False, slots=False):
+def _worker(rank, world, port, ret, cap=CAP, heavy=False, group=1, relpart=False, slots=False, sched=None):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "dgl-ke_amd"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -214,6 +214,13 @@ def _worker(rank, world, port, ret, cap=CAP, heavy=False, group=1, relpart=False
                 de.prepare_group(smp.fill(grp), log=logs.append)
             elif heavy:                           # the trainer's order: size the buckets for the group, then run it
                 de.ensure_capacity(grp, log=logs.append)
+            if sched == "overlap":                # every exchange on the "side" queue (on CPU tensors: issued inline, in queue order)
+                if slots:                         # the trainer's order with a device sampler: the group routed ahead, ids exchanged once
+                    grp = smp.fill(grp)
+                    de.prepare_group(grp, log=logs.append)
+                de._steps(grp, "overlap")
+                assert de.check_overflow() == 0
+                continue
             for i, b in enumerate(grp):
                 de.step(b)                        # (OracleOps.route asserts that every entry fits its bucket)
                 assert de.check_overflow() == 0
@@ -241,10 +248,12 @@ def _worker(rank, world, port, ret, cap=CAP, heavy=False, group=1, relpart=False
         dist.destroy_process_group()
 
 
-def _expected(world, heavy=False, relpart=False, repeat_first=False):
+def _expected(world, heavy=False, relpart=False, repeat_first=False, stale_group=0):
     """single-process statement of the synchronous sharded step: every rank's gradients are
     computed from the SAME pre-step tables, then applied owner-side in rank order (trace 0 then
-    trace 1 per rank; relations in rank order)."""
+    trace 1 per rank; relations in rank order).  stale_group = g > 0: the one-step-stale schedules (step_pipelined,
+    _steps_overlapped) in groups of g steps - the ENTITY rows of a step that is not the first of its group were pulled before
+    its predecessor's update landed; relation rows are always current."""
     from oracle import kge_oracle as O
     cfg = O.Config(MODEL, GAMMA, HID, LR, adv=True, reg_coef=1e-3)
     rng = np.random.RandomState(1)
@@ -252,9 +261,12 @@ def _expected(world, heavy=False, relpart=False, repeat_first=False):
     rel = rng.uniform(-1, 1, (N_REL, HID))
     es, rs = np.zeros(N_ENT), np.zeros(N_REL)
     steps = _batches(world, 3 if not heavy else 4, heavy, relpart)
-    for step_batches in steps + (steps[:1] if repeat_first else []):
-        outs = [O.forward_backward(cfg, ent, rel, bt["nid"], bt["h_local"], bt["t_local"], bt["r"],
+    pulled = ent.copy()
+    for si, step_batches in enumerate(steps + (steps[:1] if repeat_first else [])):
+        src = pulled if (stale_group and si % stale_group) else ent
+        outs = [O.forward_backward(cfg, src, rel, bt["nid"], bt["h_local"], bt["t_local"], bt["r"],
                                    bt["neg"], bt["neg_head"], CHUNK, N) for bt in step_batches]
+        pulled = ent.copy()                       # the pull of the NEXT step happens here: before this step's update lands
         for bt, out in zip(step_batches, outs):
             O.adagrad_update(ent, es, bt["nid"], out["g_pos_ent"], LR)
             O.adagrad_update(ent, es, bt["neg"], out["g_neg"], LR)
@@ -307,6 +319,27 @@ def test_group_id_exchange_world2_one_id_all_to_all_per_group():
     for r_, s_ in zip(ret["rels"], ret["rel_states"]):
         np.testing.assert_allclose(r_, rel, rtol=1e-9, atol=1e-11)
         np.testing.assert_allclose(s_, rs, rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world,relpart,slots", [(2, False, False), (2, True, True), (4, False, True)])
+def test_overlapped_schedule_matches_the_one_step_stale_statement(world, relpart, slots):
+    """DistEngine._steps_overlapped (push, owner-side apply and the pull of step s+2 on the side queue, compute + the relation half
+    on the main one; --async_update licence) over gloo: groups of 3 steps, host-built plans and sampler-slot batches routed by the
+    step / ahead by the group, all-gathered and partitioned relations - against the fp64 statement in which a step that is not
+    the first of its group computes on entity rows pulled before its predecessor's update."""
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, ret, CAP, False, 3, relpart, slots, "overlap"), nprocs=world, join=True)
+    ent, es, rel, rs = _expected(world, relpart=relpart, stale_group=3)
+    np.testing.assert_allclose(ret["ent"], ent, rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(ret["state"], es, rtol=1e-9, atol=1e-12)
+    for r_, s_ in list(zip(ret["rels"], ret["rel_states"]))[:1 if relpart else world]:
+        np.testing.assert_allclose(r_, rel, rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(s_, rs, rtol=1e-9, atol=1e-12)
+    # a stale step really differs from the synchronous statement (the test would not notice a schedule that is secretly synchronous)
+    assert np.abs(_expected(world, relpart=relpart)[0] - ent).max() > 1e-6
 
 
 @pytest.mark.timeout(300)
