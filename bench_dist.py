@@ -146,7 +146,10 @@ def _a2a_setup(args, world, rank, dev, w, n_ent, d_e, emb_init, allow_force_coll
     # exchange.  KGE_DIST_REL_PART=0: uniform relations on every rank, relation messages all-gathered and applied by everyone
     # (KGE_DIST_REL_PART=force: also at world 1 - the forced-exchange proxy of the N > 1 default on one GPU)
     rel_part = (world > 1 and os.environ.get("KGE_DIST_REL_PART", "1") != "0") or os.environ.get("KGE_DIST_REL_PART") == "force"
-    de = kd.DistEngine(eng, spec, ent, ent_state, comm=comm, slack=float(os.environ.get("KGE_DIST_SLACK", "1.5")),
+    # owner buckets start at 1.25 x the mean share: every exchange moves whole buckets, pads included, and the uniform synthetic ids
+    # fill a bucket to mean + 3.5 sigma = 1.17 x the mean at world 8 (384 +- 18 of 3 072 rows per owner); a group that needs more
+    # grows them before it runs (ensure_capacity; config.bucket_growth says so).  The CLI's default stays 1.5 (real ids are skewed)
+    de = kd.DistEngine(eng, spec, ent, ent_state, comm=comm, slack=float(os.environ.get("KGE_DIST_SLACK", "1.25")),
                        always_collective=force_coll, rel_local=rel_part)
     # this rank's edge shard: synthetic uniform triples over the GLOBAL id space, generated in HBM
     n_train = int(os.environ.get("KGE_DIST_TRIPLES", min(338586276 // world, 48_000_000)))
