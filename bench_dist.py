@@ -167,7 +167,7 @@ def _a2a_setup(args, world, rank, dev, w, n_ent, d_e, emb_init, allow_force_coll
     # apply and pull all on the side stream, the compute stream runs the steps' kernels back to back (DistEngine._steps_overlapped:
     # the same one-step-stale dataflow, bit-identical tables)
     pipelined = (world > 1 or force_coll) and os.environ.get("KGE_DIST_PIPELINE", "1") != "0"
-    if pipelined and os.environ.get("KGE_DIST_PIPELINE") == "overlap":
+    if os.environ.get("KGE_DIST_PIPELINE") == "overlap":      # (also without collectives: owner-side apply + gather next to the steps)
         pipelined = "overlap"
 
     def steps(dbs):
@@ -503,8 +503,8 @@ def main(args, world, rank, local_rank):
 
     # which schedule the headline run uses (a2a): KGE_DIST_PIPELINE 0 / 1 / overlap (_a2a_setup)
     _pl = os.environ.get("KGE_DIST_PIPELINE", "1")
-    sched_name = ("synchronous" if (_pl == "0" or not (world > 1 or os.environ.get("KGE_DIST_FORCE_COLL") == "1")) else
-                  "overlapped" if _pl == "overlap" else "pipelined_pull")
+    sched_name = ("overlapped" if _pl == "overlap" else
+                  "synchronous" if (_pl == "0" or not (world > 1 or os.environ.get("KGE_DIST_FORCE_COLL") == "1")) else "pipelined_pull")
     sched_desc = "synchronous schedule"
     _progress("setup")
     run(args.warmup)
