@@ -343,6 +343,24 @@ def test_overlapped_schedule_matches_the_one_step_stale_statement(world, relpart
 
 
 @pytest.mark.timeout(300)
+def test_overlapped_schedule_world8_heavy_tailed_growing_buckets():
+    """the overlapped schedule at world 8 on heavy-tailed ids with a deliberately small initial capacity: the buckets grow between
+    groups - every exchange buffer, the second entity-message buffer and the route pool are rebuilt for the new capacity - and the
+    tables equal the one-step-stale statement (groups of 2: every second step computes on rows pulled before its predecessor's
+    update)."""
+    world = 8
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, ret, 4, True, 2, False, True, "overlap"), nprocs=world, join=True)
+    assert ret["grown"] and ret["cap"] > 4
+    ent, es, rel, rs = _expected(world, heavy=True, stale_group=2)
+    np.testing.assert_allclose(ret["ent"], ent, rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(ret["state"], es, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(ret["rels"][0], rel, rtol=1e-9, atol=1e-11)
+
+
+@pytest.mark.timeout(300)
 def test_group_id_exchange_world8_heavy_tailed_growing_buckets():
     """the same group path at world 8 on heavy-tailed ids with a deliberately small initial capacity: the buckets grow between
     groups (the route pool and the id-exchange buffers are rebuilt for the new capacity), nothing is dropped"""
