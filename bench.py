@@ -467,6 +467,8 @@ def main():
     ap.add_argument("--flags", type=int, default=0, help="extra kge_hparams.flags bits (tuning)")
     ap.add_argument("--no-adv", action="store_true", help="tuning: disable -adv")
     ap.add_argument("--reg-coef", type=float, default=None, help="tuning: override the regularisation coefficient")
+    ap.add_argument("--hidden", type=int, default=None,
+                    help="tuning: override the workload's hidden dimension (the line's config.workload names the dimension that ran)")
     ap.add_argument("--host-plan", action="store_true",
                     help="pre-stage host-built batches instead of sampling on the device inside the timed region")
     ap.add_argument("--sampler-mode", default="auto", choices=["auto", "fused", "streams", "fork", "fork_tail", "serial"],
@@ -504,6 +506,8 @@ def main():
         w["adv"] = False
     if args.reg_coef is not None:
         w["reg_coef"] = args.reg_coef
+    if args.hidden is not None:
+        w["hidden"] = args.hidden
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     torch.manual_seed(0)
