@@ -16,9 +16,11 @@ Two multi-GPU modes (KGE_DIST_MODE), one is the headline, the other a bounded se
                  (dglke_amd/dist.py): routing on the device, fixed-size messages, no host work in the step.  Per sampled group
                  one sampler launch + the bucket-capacity check, then ONE hipGraph of [routing of the group, one all-to-all of
                  the group's request ids, the steps with their row / gradient exchanges] (DistEngine.run_group, round 5: RCCL
-                 collectives DO replay from hipGraphs - profiles/r05_rccl_capture_diagnosis.txt); the supervisor falls back to
-                 eager launches with the pull of step s+1 overlapping step s (one-step-stale rows, the reference's
-                 --async_update licence), then to the synchronous eager step, the c10d wrappers, p2p and independent replicas.
+                 collectives DO replay from hipGraphs - profiles/r05_rccl_capture_diagnosis.txt): the synchronous schedule is
+                 timed and delivered, then the same K steps with every exchange on a side stream (DistEngine._steps_overlapped:
+                 one-step-stale entity rows, the reference's --async_update licence) - the faster one is the line's value.  The
+                 supervisor falls back to eager launches (overlapped), then to the synchronous eager step, the c10d wrappers, p2p
+                 and independent replicas.
   p2p            the shared-table Hogwild mode of the reference's multi-GPU trainer with the shared table living in the
                  union of the GPUs' HBM: every rank maps all peer shards (hipIpc) and kge_step_sharded reads / updates
                  remote rows directly over xGMI (BOTH tables sharded).  No collective and no host work per step.
@@ -233,20 +235,24 @@ def _a2a_setup(args, world, rank, dev, w, n_ent, d_e, emb_init, allow_force_coll
                 "no relation exchange" if rel_part else "relation gradients all-gathered")
     comm_desc = ((": librccl called directly" + ("" if rel_part else ", push + relation exchange grouped"))
                  if type(de.comm).__name__ == "RcclComm" else ": torch.distributed wrappers") if de.coll else ""
-    pipe_desc = ("every exchange off the compute stream: push + owner-side apply of step s and the pull of step s+2 run next to step "
-                 "s+1 (one-step-stale entity rows, --async_update licence)" if pipelined == "overlap" else
-                 "pull of step s+1 overlapped with step s (one-step-stale rows, --async_update licence)")
-    launch_desc = ("hipGraph of [1 sampler launch + %d steps]" % G if use_graph else
-                   ("per group of <= %d steps: sampler launch + bucket-capacity check (one device read), then ONE hipGraph of [routing of "
-                    "the group, one id all-to-all for the group, the steps with their RCCL collectives]%s" % (G, ("; " + pipe_desc + ", as a "
-                    "fork inside the graph") if pipelined else "; synchronous schedule")) if graph_coll else
-                   (("eager launches, " + pipe_desc if pipelined else "eager launches") +
-                    (", the step's kernels between pull and push replayed from %d small hipGraphs" % n_cg if n_cg else "")))
-    desc = ("entity table range-sharded, relation table replicated; per step: device-side routing into %d-row owner buckets, "
-            "all-to-all pull of the unique rows, the single-GPU kernels against the row cache, all-to-all push of one packed "
-            "gradient message per row, owner-side Adagrad in rank order (one merged launch), %s "
-            "(parameter-server semantics, RCCL%s); %s; sampling + plan on the device inside the timed region"
-            % (de.cap, rel_desc, comm_desc, launch_desc))
+    def describe(sched):
+        """the line's description of this set-up for a schedule: False (synchronous), True (pull pipeline), "overlap" """
+        pipe_desc = ("every exchange off the compute stream: push + owner-side apply of step s and the pull of step s+2 run next to step "
+                     "s+1 (one-step-stale entity rows, --async_update licence)" if sched == "overlap" else
+                     "pull of step s+1 overlapped with step s (one-step-stale rows, --async_update licence)")
+        launch_desc = ("hipGraph of [1 sampler launch + %d steps]" % G if use_graph else
+                       ("per group of <= %d steps: sampler launch + bucket-capacity check (one device read), then ONE hipGraph of [routing of "
+                        "the group, one id all-to-all for the group, the steps with their RCCL collectives]%s" % (G, ("; " + pipe_desc + ", as a "
+                        "fork inside the graph") if sched else "; synchronous schedule")) if graph_coll else
+                       (("eager launches, " + pipe_desc if sched else "eager launches") +
+                        (", the step's kernels between pull and push replayed from %d small hipGraphs" % n_cg if n_cg else "")))
+        return ("entity table range-sharded, relation table replicated; per step: device-side routing into %d-row owner buckets, "
+                "all-to-all pull of the unique rows, the single-GPU kernels against the row cache, all-to-all push of one packed "
+                "gradient message per row, owner-side Adagrad in rank order (one merged launch), %s "
+                "(parameter-server semantics, RCCL%s); %s; sampling + plan on the device inside the timed region"
+                % (de.cap, rel_desc, comm_desc, launch_desc))
+    de.describe = describe
+    desc = describe(pipelined)
     return eng, run, rows, desc, de
 
 
@@ -505,7 +511,6 @@ def main(args, world, rank, local_rank):
     _pl = os.environ.get("KGE_DIST_PIPELINE", "1")
     sched_name = ("overlapped" if _pl == "overlap" else
                   "synchronous" if (_pl == "0" or not (world > 1 or os.environ.get("KGE_DIST_FORCE_COLL") == "1")) else "pipelined_pull")
-    sched_desc = "synchronous schedule"
     _progress("setup")
     run(args.warmup)
     torch.cuda.synchronize()
@@ -560,8 +565,7 @@ def main(args, world, rank, local_rank):
             # --async_update); the schedule measured first stays beside it
             first = {"schedule": sched_name, "value": res["value"], "ms_per_step": res["ms_per_step"], "steps": K,
                      "what": "the schedule this worker timed first (delivered before the other one ran)"}
-            res = _result_line(args, w, n_ent, world, pipe_leg["wall_s"], K, rows, d_e, eng.d_r,
-                               desc.replace(sched_desc, pipe_leg["launch"]) if sched_desc in desc else desc + "; " + pipe_leg["launch"],
+            res = _result_line(args, w, n_ent, world, pipe_leg["wall_s"], K, rows, d_e, eng.d_r, _de.describe(other_sched),
                                mode, why, sums, other, leg, overflow)
             res["config"]["schedule"] = pipe_leg["schedule"]
             res["mean_loss_of"] = "the %s run (timed first)" % sched_name
