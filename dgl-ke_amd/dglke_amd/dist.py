@@ -623,8 +623,10 @@ class DistEngine(object):
             main = torch.cuda.current_stream(self.dev)
             if self._side is None:
                 import os
-                # (KGE_DIST_SIDE_PRIORITY=-1: the exchange stream ahead of the compute stream in the hardware queues - A/B aid)
-                self._side = torch.cuda.Stream(device=self.dev, priority=int(os.environ.get("KGE_DIST_SIDE_PRIORITY", "0")))
+                # the exchange stream goes ahead of the compute stream in the hardware queues: its chain is what the next-but-one
+                # step waits for (world-1 proxy: 122.8 vs 125.8 us with all-gathered relations, neutral with partitioned ones;
+                # KGE_DIST_SIDE_PRIORITY=0: equal priorities)
+                self._side = torch.cuda.Stream(device=self.dev, priority=int(os.environ.get("KGE_DIST_SIDE_PRIORITY", "-1")))
                 self._explicit = isinstance(self.comm, RcclComm) and isinstance(self.ops, HipOps)
                 E = _lib.RawEvent if self._explicit else _lib.TorchEvent
                 self._ev = [dict(main=E(), gather=E(), rows=E()) for _ in range(2)]

@@ -18,6 +18,6 @@ run "pull pipeline, all-gathered relations" KGE_DIST_PIPELINE=1
 run "overlapped, all-gathered relations" KGE_DIST_PIPELINE=overlap
 run "synchronous, relation partitioning" KGE_DIST_PIPELINE=0 KGE_DIST_REL_PART=force
 run "overlapped, relation partitioning" KGE_DIST_PIPELINE=overlap KGE_DIST_REL_PART=force
-run "overlapped, relation partitioning, side prio" KGE_DIST_PIPELINE=overlap KGE_DIST_REL_PART=force KGE_DIST_SIDE_PRIORITY=-1
+run "overlapped, relation partitioning, equal prio" KGE_DIST_PIPELINE=overlap KGE_DIST_REL_PART=force KGE_DIST_SIDE_PRIORITY=0
 run "overlapped, relation partitioning, eager" KGE_DIST_PIPELINE=overlap KGE_DIST_REL_PART=force KGE_DIST_GRAPH=0
 done | tee $O/ab_schedules.txt
