@@ -842,6 +842,9 @@ int launch_update(const UpdateArgs &a, hipStream_t s, const SmpTail *tail) {
 #ifndef UPD_NO_EMIT6
     if (lean == 4 && a.emit_ent && a.emit_rel && a.g0 && a.g1 && a.gr && !a.transe_fast && !a.nd_chunk && !a.Hs && !a.Ts && !a.Rs && !a.Ns && !a.dry)
         lean = 6;                    // the all-to-all engine's step for the models with per-edge gradient rows
+    else if (lean == 4 && a.emit_ent && !a.emit_rel && a.g0 && a.g1 && !a.gr && !a.gsr && !a.rid && !a.transe_fast && !a.nd_chunk && !a.Hs &&
+             !a.Ts && !a.Rs && !a.Ns && !a.dry)
+        lean = 7;                    // ... under relation partitioning: entity messages out, the relation trace applied in place
 #endif
     if (a.gn_parts > 0) {            // unsummed GN partials / GA parts (see UpdateArgs): the folded instance or nothing
         if (lean != 1 || sharded || !(vec && dmax <= 512) || !a.GNp || a.gn_parts > KGE_GN_MAXP || a.ga_parts < 1 || a.ga_parts > KGE_GA_MAXP ||
@@ -852,7 +855,8 @@ int launch_update(const UpdateArgs &a, hipStream_t s, const SmpTail *tail) {
 #define KGE_UPD(N, SH, LE) hipLaunchKernelGGL((update_kernel_reg<N, SH, LE>), g, b, 0, s, a, nbE, nbM, st)
 #define KGE_UPD_L(N, SH)                                                         \
     do { if (lean == 1) KGE_UPD(N, SH, 1); else if (lean == 2) KGE_UPD(N, SH, 2); else if (lean == 3) KGE_UPD(N, SH, 3); \
-         else if (lean == 4) KGE_UPD(N, SH, 4); else if (lean == 6) KGE_UPD(N, SH, 6); else KGE_UPD(N, SH, 0); } while (0)
+         else if (lean == 4) KGE_UPD(N, SH, 4); else if (lean == 6) KGE_UPD(N, SH, 6); else if (lean == 7) KGE_UPD(N, SH, 7); \
+         else KGE_UPD(N, SH, 0); } while (0)
 #define KGE_UPD_N(N) do { if (sharded) KGE_UPD_L(N, true); else KGE_UPD_L(N, false); } while (0)
     if (lean == 5) { if (nit == 1) KGE_UPD(1, false, 5); else KGE_UPD(2, false, 5); }
     else

@@ -332,18 +332,22 @@ __device__ __forceinline__ void update_rel_row(const UpdateArgs &a, int bx, int 
 template <int NIT, bool SHARDED, int LEAN_>     // LEAN: 0 = everything at run time, 1 = in-place + TransE fast path,
 __device__ __forceinline__ void update_reg_body(const UpdateArgs &a_in, int nb_ent, int bid, int nblk) {   // 2 = in-place + per-edge gradients
     using namespace kge;                         // 3 = 1 with Q rows; 4 (round 4) = 0 with the regulariser's norm fixed at 3 - the
-    constexpr int LEAN = (LEAN_ == 4 || LEAN_ == 6) ? 0 : (LEAN_ == 5 ? 1 : LEAN_); // gradient-emitting (sharded all-to-all) step of every BASELINE recipe
+    constexpr int LEAN = (LEAN_ == 4 || LEAN_ == 6 || LEAN_ == 7) ? 0 : (LEAN_ == 5 ? 1 : LEAN_); // gradient-emitting (sharded all-to-all) step of every BASELINE recipe
     // 6 (round 4) = 4 narrowed to what the all-to-all engine's step asks for when the model has per-edge gradient rows (RotatE /
     // cfg-R): messages out, no TransE fast path, no neg_deg_sample, no stale-row copies - the generic instance allocates 155 VGPRs
     // (three wavefronts per SIMD for the step's 4 096 rows of 800 floats)
-    constexpr bool EMIT6 = LEAN_ == 6;
+    // 7 (round 5) = 6 with the RELATION trace applied in place (entity messages out, no relation messages): the all-to-all engine
+    // under relation partitioning, where every relation row of a batch belongs to this rank - no relation apply launch at all
+    constexpr bool EMIT6 = LEAN_ == 6 || LEAN_ == 7;
+    constexpr bool EMIT7 = LEAN_ == 7;
     constexpr bool FOLD = LEAN_ == 5;            // 5 (round 4) = 1 with the shared-pair backward's GN partials / GA parts summed HERE (UpdateArgs::gn_parts)
     UpdateArgs a = a_in;
     if constexpr (!SHARDED) { a.em.n = 0; a.rm.n = 0; }
     if constexpr (LEAN_ == 4 || EMIT6) a.reg_norm = 3;
     if constexpr (EMIT6) {
         a.transe_fast = 0; a.Q = nullptr; a.P = nullptr; a.GA = nullptr; a.dry = 0; a.nd_chunk = 0;
-        a.Hs = a.Ts = a.Rs = a.Ns = nullptr; a.emit_ent = 1; a.emit_rel = 1;
+        a.Hs = a.Ts = a.Rs = a.Ns = nullptr; a.emit_ent = 1; a.emit_rel = EMIT7 ? 0 : 1;
+        if constexpr (EMIT7) { a.gr = a.gsr = nullptr; a.rid = nullptr; }
     }
     if constexpr (LEAN != 0) {
         a.transe_fast = (LEAN == 1 || LEAN == 3) ? 1 : 0; a.emit_ent = 0; a.emit_rel = 0;

@@ -346,7 +346,10 @@ class HipOps(object):
     def step_grads(self, engine, lb, cache, ent_msg, rel_msg, zero_state):
         """run kge_step_grads against the row cache, emitting packed messages at the rows' cache positions:
         ent_msg[row] = [g0 | g1 | gs0 gs1 . .],  rel_msg[u] = [gr | gsr | id_lo id_hi .]"""
-        key = (cache.data_ptr(), ent_msg.data_ptr(), rel_msg.data_ptr(), zero_state.data_ptr(), engine.rel.data_ptr())
+        # rel_msg None: no relation messages - the step applies the relation trace to engine.rel itself (relation partitioning:
+        # every relation row of the batch belongs to this rank)
+        key = (cache.data_ptr(), ent_msg.data_ptr(), rel_msg.data_ptr() if rel_msg is not None else 0, zero_state.data_ptr(),
+               engine.rel.data_ptr())
         st = self._structs.get(key) if hasattr(self, "_structs") else None
         if st is None:                                   # the argument structs of a (cache, message buffers) pair: built once
             d_e, d_r = cache.shape[1], engine.rel.shape[1]
@@ -355,11 +358,14 @@ class HipOps(object):
             tb.rel, tb.rel_state = _lib.ptr(engine.rel), _lib.ptr(engine.rel_state)
             tb.n_ent, tb.n_rel = cache.shape[0], engine.rel.shape[0]
             em = _lib.KgeEmit()
-            e0, r0 = ent_msg.data_ptr(), rel_msg.data_ptr()
+            e0 = ent_msg.data_ptr()
             em.g0, em.g1 = e0, e0 + 4 * d_e
             em.gs0, em.gs1 = e0 + 8 * d_e, e0 + 8 * d_e + 4
-            em.gr, em.gsr, em.rid = r0, r0 + 4 * d_r, r0 + 4 * d_r + 4
-            em.ld_e, em.ld_r = ent_msg.shape[1], rel_msg.shape[1]
+            em.ld_e = ent_msg.shape[1]
+            if rel_msg is not None:
+                r0 = rel_msg.data_ptr()
+                em.gr, em.gsr, em.rid = r0, r0 + 4 * d_r, r0 + 4 * d_r + 4
+                em.ld_r = rel_msg.shape[1]
             em.ent_by_id = 1
             out = _lib.KgeStepOut()
             out.loss_accum = _lib.ptr(engine.loss_accum)
@@ -406,6 +412,11 @@ class DistEngine(object):
         # live on one rank, so its row is updated there and nowhere else - no relation exchange at all (no all-gather, no W-fold
         # apply); the owners' rows are collected when the tables are read (relation_rows_from_owners)
         self.rel_local = bool(rel_local)
+        import os as _os
+        # (KGE_DIST_REL_INPLACE=0: the relation trace as messages + an apply launch also under relation partitioning - A/B aid; ops
+        #  without the capability - test doubles - say so with `rel_inplace = False`)
+        self._rel_inplace = (self.rel_local and _os.environ.get("KGE_DIST_REL_INPLACE", "1") != "0" and
+                             getattr(self.ops, "rel_inplace", True))
         self.slots = None
         import os
         self._pair_ok = os.environ.get("KGE_DIST_PAIR_APPLY", "1") != "0"      # (A/B aid: the two owner-side applies as two launches)
@@ -684,7 +695,8 @@ class DistEngine(object):
                     evr = ev_ov[par]["rel"]
                     evr.record(side)
                     evr.wait(main)
-                self.ops.apply_merged(self.engine.rel, self.engine.rel_state, Wr, lb.B, None, 0, self.all_rel, 1, self.lr)
+                if not self._rel_inplace:
+                    self.ops.apply_merged(self.engine.rel, self.engine.rel_state, Wr, lb.B, None, 0, self.all_rel, 1, self.lr)
 
                 def side_chain(k=k, lb=lb, msg=msg):
                     recv = self.recv_msg if self.coll else msg[:W * self.cap]
@@ -764,7 +776,8 @@ class DistEngine(object):
                     for par in (0, 1):
                         g = torch.cuda.CUDAGraph()
                         with _lib.graph_capture(g):
-                            self.ops.step_grads(self.engine, lb, self.slots[par].cache, self.ent_msg, self.rel_msg, self.zero_state)
+                            self.ops.step_grads(self.engine, lb, self.slots[par].cache, self.ent_msg,
+                                                None if self._rel_inplace else self.rel_msg, self.zero_state)
                         self._cgraphs[(id(lb), par)] = g
             if hasattr(self.engine, "_graphs"):
                 self.engine._graphs += 1             # the workspace's address is baked in: it may not move any more
@@ -808,7 +821,10 @@ class DistEngine(object):
     def _compute(self, lb, ent_msg=None):
         s = self.slots[lb.slot]
         ent_msg = self.ent_msg if ent_msg is None else ent_msg
-        if not lb.c.counts_dev:
+        # relation partitioning: every relation row of the batch belongs to this rank - the step applies the relation trace to the
+        # table itself (no relation messages, no relation apply launch; round 5, last session)
+        rel_msg = None if self._rel_inplace else self.rel_msg
+        if rel_msg is not None and not lb.c.counts_dev:
             self.ops.reset_rel_pads(self.rel_msg, self.d_r, lb.UR)      # host-built plan: UR is exact, the rows behind it are pads
         # The step's kernels between the pull and the push replay from a small hipGraph per (routed batch, cache slot) when
         # precapture() recorded one (opt-in, KGE_DIST_COMPUTE_GRAPH=1: bit-identical, and SLOWER than the six eager launches it
@@ -818,7 +834,7 @@ class DistEngine(object):
             if g is not None:
                 g.replay()
                 return
-        self.ops.step_grads(self.engine, lb, s.cache, ent_msg, self.rel_msg, self.zero_state)
+        self.ops.step_grads(self.engine, lb, s.cache, ent_msg, rel_msg, self.zero_state)
 
     def _push_apply(self, lb, before_apply=None):
         sp, s, W = self.spec, self.slots[lb.slot], self.spec.world
@@ -834,6 +850,9 @@ class DistEngine(object):
                 self.comm.all_gather(self.all_rel.view(-1), self.rel_msg.view(-1))
         if before_apply is not None:
             before_apply()
+        if self._rel_inplace:             # the relation trace was applied by the step itself
+            self.ops.apply_merged(self.ent, self.ent_state, W, self.cap, lb.recv_ids, sp.lo, self.recv_msg, 2, self.lr)
+            return
         pair = getattr(self.ops, "apply_merged_pair", None) if self._pair_ok else None
         if pair is not None and self.d_e % 4 == 0 and self.d_r % 4 == 0:      # both applies in one launch (same results)
             pair((self.ent, self.ent_state, W, self.cap, lb.recv_ids, sp.lo, self.recv_msg, 2),

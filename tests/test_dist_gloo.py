@@ -131,6 +131,16 @@ class OracleOps(object):
         ent_msg.copy_(torch.from_numpy(em))
         ur = p["ur_id"]
         inv = np.searchsorted(ur, p["rel_ids"])
+        if rel_msg is None:                   # relation partitioning: the step applies the relation trace itself (HipOps: update instance 7)
+            g = np.zeros((len(ur), dr))
+            inc = np.zeros(len(ur))
+            np.add.at(g, inv, out["g_rel"])
+            np.add.at(inc, inv, (out["g_rel"] ** 2).mean(1))
+            st = engine.rel_state.numpy()
+            tb = engine.rel.numpy()
+            st[ur] += inc
+            tb[ur] += (-engine.lr * g) / (np.sqrt(st[ur])[:, None] + 1e-10)
+            return
         rm = rel_msg.numpy()
         rm[:len(ur), :dr + 1] = 0
         np.add.at(rm[:, :dr], inv, out["g_rel"])
