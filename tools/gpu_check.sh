@@ -1,6 +1,6 @@
 #!/bin/bash
 export GRAFT_REPO_ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-O=gpurun_out/r05check2; mkdir -p $O
+O=gpurun_out/r05check3; mkdir -p $O
 ( timeout 1500 python -m pytest tests -m gpu -q --timeout=300 2>&1 | grep -v amdgpu.ids | tail -8 ) > $O/pytest_all.log; tail -4 $O/pytest_all.log
 python -c "import __graft_entry__ as g; g.build(); g.smoke()" 2>&1 | grep -v amdgpu | tail -2
 timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; python -c "
