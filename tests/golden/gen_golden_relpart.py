@@ -28,6 +28,11 @@ CASES = {
     "relpart_flat_w4": (4000, 25, 4, 0.1, 4),          # nearly uniform relations: 1 / ranks of the edges is the smaller bound
     "relpart_hub_w8": (4000, 12, 8, 2.0, 5),           # one relation with most of the edges, a few edges per rank in the tail
     "relpart_small_w3": (97, 7, 3, 0.7, 6),            # odd sizes, shares that do not divide
+    # many relations with EQUAL counts: the order among ties is the reference's np.flip(np.argsort(cnts)) - it decides who gets which rank
+    "relpart_ties_w2": (240, 60, 2, 0.3, 7),
+    "relpart_ties_w4": (400, 90, 4, 0.2, 8),
+    "relpart_ties_w5": (333, 45, 5, 0.5, 9),
+    "relpart_ties_w8": (900, 150, 8, 0.4, 10),
 }
 
 

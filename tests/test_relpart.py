@@ -13,7 +13,7 @@ GOLD = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)),
 
 
 def test_golden_files_present():
-    assert len(GOLD) >= 6
+    assert len(GOLD) >= 10
 
 
 @pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[:-4] for p in GOLD])
