@@ -256,6 +256,18 @@ def _a2a_setup(args, world, rank, dev, w, n_ent, d_e, emb_init, allow_force_coll
     return eng, run, rows, desc, de
 
 
+def second_schedule_wins(first_value, leg, K):
+    """may the schedule measured SECOND (the leg dict of main()) become the line's value?  Only when it ran exactly the K steps the
+    line reports, between the same barriers (its wall time is there), finished without an error and is more than 2 % faster than
+    the schedule timed first - whose line has already been delivered, so a leg that hangs or fails can only cost itself.
+    KGE_DIST_PROMOTE=0: never."""
+    if not leg or leg.get("error") or os.environ.get("KGE_DIST_PROMOTE", "1") == "0":
+        return False
+    if not leg.get("wall_s") or leg.get("steps") != K or not leg.get("value"):
+        return False
+    return leg["value"] > 1.02 * first_value
+
+
 def _progress(mark):
     """worker -> orchestrator: one line per finished phase (the orchestrator's per-phase watchdog resets on every new line)"""
     path = os.environ.get("KGE_DIST_PROGRESS")
@@ -558,8 +570,7 @@ def main(args, world, rank, local_rank):
             return None
         res = _result_line(args, w, n_ent, world, wall, K, rows, d_e, eng.d_r, desc, mode, why, sums, other, leg, overflow)
         res["config"]["schedule"] = sched_name
-        if (pipe_leg is not None and pipe_leg.get("wall_s") and pipe_leg.get("steps") == K and
-                pipe_leg["value"] > 1.02 * res["value"] and os.environ.get("KGE_DIST_PROMOTE", "1") != "0"):
+        if second_schedule_wins(res["value"], pipe_leg, K):
             # the OTHER schedule of the same engine ran exactly K steps between the same barriers and is faster: it is the line's
             # value (both are valid training under the flags of the reference's recipe for this config, which passes
             # --async_update); the schedule measured first stays beside it

@@ -82,3 +82,23 @@ def test_a_leg_that_hangs_after_the_headline_costs_only_itself():
 def test_every_attempt_failing_still_prints_a_line():
     d = _run("a2a/rccl-graph=crash,a2a/rccl=crash,a2a/rccl-sync=crash,a2a/torch=crash,p2p=crash,replicas=crash")
     assert d["value"] == 0.0 and d["config"]["fallback_reason"] == "every attempt failed" and len(d["config"]["attempts"]) == 6
+
+
+def test_second_schedule_becomes_the_value_only_on_equal_terms():
+    """bench_dist.second_schedule_wins: the schedule measured behind the delivered headline replaces its value only when it timed
+    exactly the K steps of the line, carries its wall time, did not fail and is more than 2 % faster."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "dgl-ke_amd"))
+    import bench_dist as bd
+    leg = {"schedule": "overlapped", "value": 120.0, "steps": 20, "wall_s": 0.01}
+    assert bd.second_schedule_wins(100.0, leg, 20)
+    assert not bd.second_schedule_wins(118.0, leg, 20)                       # within 2 %
+    assert not bd.second_schedule_wins(100.0, dict(leg, steps=240), 20)      # another number of steps than the line reports
+    assert not bd.second_schedule_wins(100.0, dict(leg, wall_s=None), 20)
+    assert not bd.second_schedule_wins(100.0, {"error": "x", "schedule": "overlapped"}, 20)
+    assert not bd.second_schedule_wins(100.0, None, 20)
+    os.environ["KGE_DIST_PROMOTE"] = "0"
+    try:
+        assert not bd.second_schedule_wins(100.0, leg, 20)
+    finally:
+        del os.environ["KGE_DIST_PROMOTE"]
