@@ -83,7 +83,9 @@ class ArgParser(argparse.ArgumentParser):
                'the relation gradients are then all-gathered and applied by every trainer.  auto (default): whole while the fullest '
                'trainer stays within 1.1 x the mean edge share, soft otherwise')
         a('--async_update', action='store_true')
-        a('--has_edge_importance', action='store_true')
+        a('--has_edge_importance', action='store_true',
+          help='train.txt carries a 4th column of edge weights (reference flag).  Batches then come from the host sampler; with several '
+               'GPUs the all-to-all mode takes them step by step (eager launches), --dist_mode p2p does not cover it')
         # additions of this build
         a('--async_update_rel', action='store_true',
           help='with --async_update: defer the relation-table update by one step as well (the reference defers the entity '
@@ -562,10 +564,10 @@ class A2ATrainer(ShardedTrainer):
         B, N = args.batch_size, args.neg_sample_size
         self.chunk = N if N <= B else B
         self.fused, self.n_lanes, self.async_ok = True, 1, False
-        self.device_sampler = 2 * B + (B // self.chunk) * N <= 4096
-        if args.has_edge_importance or not self.device_sampler:
-            raise KgeError("multi-GPU training uses the on-device sampler: no --has_edge_importance, "
-                           "and 2*batch + chunks*neg <= 4096")
+        # the on-device sampler builds the batches of a whole group ahead (group routing, one id exchange, group graphs); batches it
+        # cannot build - edge importance, or more than 4096 ids per batch - come from the host sampler: plans built on the host,
+        # routed and exchanged step by step, eager launches (the same sharded step; slower: the host builds a plan per step)
+        self.device_sampler = 2 * B + (B // self.chunk) * N <= 4096 and not args.has_edge_importance
         if args.model_name in ('RESCAL', 'TransR'):
             raise KgeError("--dist_mode a2a covers TransE_l1/l2, DistMult, ComplEx, RotatE, SimplE (use --dist_mode p2p)")
         d_e = args.hidden_dim * (2 if args.double_ent else 1)
@@ -625,8 +627,15 @@ class A2ATrainer(ShardedTrainer):
             raise KgeError("--batch_size %d is larger than a trainer's share of the training triples (%d over %d trainers)"
                            % (B, len(tr[0]), world))
         h, r, t = (np.asarray(x)[part] for x in tr[:3])
-        self.sampler = DeviceSampler(h, r, t, dataset.n_entities, B, N, self.dev, n_slots=max(2, args.graph_steps or 2),
-                                     neg_chunk_size=self.chunk, seed=args.seed + 1000 * rank)
+        if self.device_sampler:
+            self.sampler = DeviceSampler(h, r, t, dataset.n_entities, B, N, self.dev, n_slots=max(2, args.graph_steps or 2),
+                                         neg_chunk_size=self.chunk, seed=args.seed + 1000 * rank)
+        else:
+            from .dataloader import UniformChunkedSampler
+            w = np.asarray(tr[3])[part] if args.has_edge_importance else None
+            self.sampler = UniformChunkedSampler(h, r, t, dataset.n_entities, B, N, self.dev, neg_chunk_size=self.chunk,
+                                                 seed=args.seed + 1000 * rank, edge_importance=w)
+            self._ue_bound = 2 * B + (B // self.chunk) * N       # the exchange buffers are sized once, for the bound
         self._full = None
         if rank == 0:
             print("multi-GPU mode a2a: entity rows %d per GPU, relations replicated, collectives: %s"
@@ -636,14 +645,22 @@ class A2ATrainer(ShardedTrainer):
         """n sharded steps, eagerly (every rank issues the same collectives in the same order); inside a group of sampled
         batches the pull of step s+1 overlaps step s."""
         smp, done = self.sampler, 0
+        log = (lambda m: print('[proc {}] {}'.format(self.rank, m))) if self.rank == 0 else None
+        while not self.device_sampler and done < n:          # host-built plans: groups of <= 16 steps, each routed by its own step
+            k = min(16, n - done)
+            bs = smp.next_batches(k)
+            for b in bs:
+                b.UE = self._ue_bound
+            self.de.ensure_capacity(bs, log)                 # (one device read per group; every rank decides alike)
+            self.de._steps(bs, self.pipelined)
+            done += k
         while done < n:
             k = min(smp.n_slots, n - done)
             dbs = smp.sample(k)
             # owner buckets are sized BEFORE the group runs (one small device read per group; every rank takes the same decision);
             # then the routing of the whole group, ONE exchange of its request ids and its steps - with their collectives - replay
             # from one hipGraph (dist.DistEngine.run_group; --graph_steps 0 or a host-staged transport: eager launches)
-            self.de.run_group(dbs, log=(lambda m: print('[proc {}] {}'.format(self.rank, m))) if self.rank == 0 else None,
-                              graph=bool(self.args.graph_steps), pipelined=self.pipelined)
+            self.de.run_group(dbs, log=log, graph=bool(self.args.graph_steps), pipelined=self.pipelined)
             done += k
         lost = self.de.check_overflow()
         if lost:                                 # cannot happen behind ensure_capacity: a bug, not a tuning matter
@@ -740,8 +757,9 @@ def main(argv=None):
             raise KgeError("dglke_amd trains on the GPU only: pass --gpu <ids> (there is no CPU fallback)")
         if args.model_name in ('RESCAL', 'TransR'):
             raise KgeError("%s is not available on the multi-GPU sharded tables: train it on one GPU" % args.model_name)
-        if args.has_edge_importance:
-            raise KgeError("multi-GPU training uses the on-device sampler: no --has_edge_importance")
+        if args.has_edge_importance and getattr(args, 'dist_mode', 'a2a') == 'p2p':
+            raise KgeError("--dist_mode p2p uses the on-device sampler: no --has_edge_importance (the default all-to-all mode takes "
+                           "host-built batches for it)")
         if args.log_interval <= 0:
             raise KgeError("--log_interval must be positive")
         if args.num_proc > len(args.gpu):            # reference: several trainer processes per GPU (train.py:94-100, 115-119)

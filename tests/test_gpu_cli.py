@@ -110,6 +110,33 @@ def test_train_cli_host_sampler_paths(tmp_path, capsys):
     assert out.count("(300/300) average loss:") == 2
 
 
+def test_train_cli_multi_process_edge_importance_host_batches(tmp_path):
+    """`--gpu 0 0 --has_edge_importance` (all-to-all mode): the device sampler carries no edge weights, so the sharded trainer takes
+    host-built batches - routed and exchanged step by step, eager launches - and still learns; with `--async_update` the same
+    batches go through the overlapped schedule."""
+    import subprocess
+    data = str(tmp_path / "kg")
+    train, _, _ = _planted(data)
+    w = np.random.RandomState(0).uniform(0.5, 1.5, len(train))
+    with open(os.path.join(data, "train_w.txt"), "w") as f:
+        for (h, r, t), x in zip(train.tolist(), w):
+            f.write("%d\t%d\t%d\t%.4f\n" % (h, r, t, x))
+    for extra in ([], ["--async_update"]):
+        cmd = [sys.executable, os.path.join(ROOT, "dgl-ke_amd", "dglke_train"), "--model_name", "TransE_l2", "--format",
+               "udd_hrt", "--dataset", "toy", "--data_path", data, "--data_files", "e.dict", "r.dict", "train_w.txt",
+               "valid.txt", "test.txt", "--has_edge_importance", "--save_path", str(tmp_path / "ckpts"), "--gpu", "0", "0",
+               "--batch_size", "256", "--neg_sample_size", "64", "--hidden_dim", "32", "-g", "8", "--lr", "0.25", "-adv",
+               "-rc", "1e-7", "--max_step", "400", "--log_interval", "200", "--test", "--no_save_emb"] + extra
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+        out = r.stdout.decode(errors="replace")
+        assert r.returncode == 0, out[-3000:]
+        assert "[proc 1][Train](400/400) average loss:" in out, out[-2000:]
+        mrr = float([l for l in out.split("\n") if l.startswith("[0]Test average MRR:")][0].split(":")[1])
+        assert mrr > 10 * 2.0 / 400, out[-1500:]
+
+
 def test_train_cli_hogwild_lanes(tmp_path, capsys):
     """--num_proc 3 on one GPU: three concurrent lock-free trainers (streams) on the shared tables, each on
     its own share of the triples - the reference's multi-process mode; it must still learn."""
