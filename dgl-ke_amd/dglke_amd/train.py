@@ -85,7 +85,7 @@ class ArgParser(argparse.ArgumentParser):
         a('--async_update', action='store_true')
         a('--has_edge_importance', action='store_true',
           help='train.txt carries a 4th column of edge weights (reference flag).  Batches then come from the host sampler; with several '
-               'GPUs the all-to-all mode takes them step by step (eager launches), --dist_mode p2p does not cover it')
+               'GPUs both modes take them step by step (eager launches)')
         # additions of this build
         a('--async_update_rel', action='store_true',
           help='with --async_update: defer the relation-table update by one step as well (the reference defers the entity '
@@ -440,10 +440,8 @@ class ShardedTrainer(object):
         B, N = args.batch_size, args.neg_sample_size
         self.chunk = N if N <= B else B
         self.fused, self.n_lanes, self.async_ok = True, 1, False
-        self.device_sampler = 2 * B + (B // self.chunk) * N <= 4096
-        if args.has_edge_importance or not self.device_sampler:
-            raise KgeError("multi-GPU training uses the on-device sampler: no --has_edge_importance, "
-                           "and 2*batch + chunks*neg <= 4096")
+        # (edge importance / more than 4096 ids per batch: host-built batches, like the single-GPU trainer's host sampler path)
+        self.device_sampler = 2 * B + (B // self.chunk) * N <= 4096 and not args.has_edge_importance
         if args.model_name == 'RESCAL':
             raise KgeError("RESCAL is not available on sharded tables")
         if args.neg_deg_sample and args.model_name == 'TransR':
@@ -462,7 +460,8 @@ class ShardedTrainer(object):
                                  flags=_lib.FLAG_NEG_DEG_SAMPLE if args.neg_deg_sample else 0, shards=self.tabs)
         tr = dataset.train
         part = np.array_split(np.random.RandomState(args.seed).permutation(len(tr[0])), world)[rank]
-        self.lane = _Lane(self, rank, self.engine, tuple(np.asarray(x)[part] for x in tr[:3]), None)
+        self.lane = _Lane(self, rank, self.engine, tuple(np.asarray(x)[part] for x in tr[:3]),
+                          np.asarray(tr[3])[part] if args.has_edge_importance else None)
 
     def _enqueue(self, n):
         self.lane.enqueue(n)
@@ -757,9 +756,6 @@ def main(argv=None):
             raise KgeError("dglke_amd trains on the GPU only: pass --gpu <ids> (there is no CPU fallback)")
         if args.model_name in ('RESCAL', 'TransR'):
             raise KgeError("%s is not available on the multi-GPU sharded tables: train it on one GPU" % args.model_name)
-        if args.has_edge_importance and getattr(args, 'dist_mode', 'a2a') == 'p2p':
-            raise KgeError("--dist_mode p2p uses the on-device sampler: no --has_edge_importance (the default all-to-all mode takes "
-                           "host-built batches for it)")
         if args.log_interval <= 0:
             raise KgeError("--log_interval must be positive")
         if args.num_proc > len(args.gpu):            # reference: several trainer processes per GPU (train.py:94-100, 115-119)

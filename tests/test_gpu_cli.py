@@ -121,7 +121,7 @@ def test_train_cli_multi_process_edge_importance_host_batches(tmp_path):
     with open(os.path.join(data, "train_w.txt"), "w") as f:
         for (h, r, t), x in zip(train.tolist(), w):
             f.write("%d\t%d\t%d\t%.4f\n" % (h, r, t, x))
-    for extra in ([], ["--async_update"]):
+    for extra in ([], ["--async_update"], ["--dist_mode", "p2p"]):      # (p2p: the peer-to-peer shared tables take host batches too)
         cmd = [sys.executable, os.path.join(ROOT, "dgl-ke_amd", "dglke_train"), "--model_name", "TransE_l2", "--format",
                "udd_hrt", "--dataset", "toy", "--data_path", data, "--data_files", "e.dict", "r.dict", "train_w.txt",
                "valid.txt", "test.txt", "--has_edge_importance", "--save_path", str(tmp_path / "ckpts"), "--gpu", "0", "0",
