@@ -102,8 +102,8 @@ class ArgParser(argparse.ArgumentParser):
           help='multi-GPU training (--gpu g0 g1 ...): a2a = entity table range-sharded, relation table replicated, RCCL '
                'all-to-all pull / push with owner-side Adagrad (parameter-server semantics); p2p = both tables sharded and '
                'mapped peer to peer (hipIpc), Hogwild across the trainers, no collective.  TransR and RESCAL (projection / '
-               'relation-matrix tables) train on one GPU or with p2p (TransR only): a2a hands TransR to p2p, and multi-GPU RESCAL is '
-               'not covered')
+               'relation-matrix tables) train on ONE GPU (--num_proc K there: K lock-free trainers on the shared tables); the '
+               'multi-GPU modes cover TransE_l1/l2, DistMult, ComplEx, RotatE and SimplE and say so when asked for the other two')
         a('--seed', type=int, default=0, help='seed of the table initialisation and of the device sampler')
         a('--graph_steps', type=int, default=100, help='steps per captured hipGraph (0: eager launches)')
         a('--target_mrr', type=float, default=None,
