@@ -57,7 +57,8 @@ class ArgParser(argparse.ArgumentParser):
         a('--test', action='store_true')
         a('--num_proc', type=int, default=1)
         a('--num_thread', type=int, default=1)
-        a('--force_sync_interval', type=int, default=-1)
+        a('--force_sync_interval', type=int, default=-1,
+          help='multi-GPU: every trainer waits at a barrier every this many steps (reference flag; -1: never)')
         a('--hidden_dim', type=int, default=400)
         a('--lr', type=float, default=0.01)
         a('-g', '--gamma', type=float, default=12.0)
@@ -513,6 +514,11 @@ class ShardedTrainer(object):
             if iv and iv > 0:
                 marks.update(range(iv, args.max_step + 1, iv))
         marks.add(args.max_step)
+        # --force_sync_interval (reference train_pytorch.py:181-187: every trainer waits at a barrier every so many steps, so that no
+        # process of the lock-free shared-table mode runs far ahead of the others); the all-to-all mode is in step by construction
+        fsi = int(getattr(args, 'force_sync_interval', -1) or -1)
+        if fsi > 0:
+            marks.update(range(fsi, args.max_step + 1, fsi))
         th.cuda.synchronize()
         dist.barrier()
         train_start = start = time.time()
@@ -523,6 +529,8 @@ class ShardedTrainer(object):
                 self._enqueue(n)
                 th.cuda.synchronize()
                 step, since_log = nxt, since_log + n
+            if fsi > 0 and step % fsi == 0:
+                dist.barrier()
             if args.log_interval > 0 and step % args.log_interval == 0 and since_log:
                 sums = self.engine.read_loss_sums()
                 for k in keys:

@@ -230,7 +230,7 @@ def test_train_cli_transr_lanes_and_rejected_flags(tmp_path, capsys):
         T.main(_base(tmp_path) + ["--max_step", "10", "--log_interval", "0"])
 
 
-@pytest.mark.parametrize("extra,nproc", [(["--dist_mode", "p2p"], 2), (["--dist_mode", "p2p", "--num_proc", "4"], 4), ([], 2),
+@pytest.mark.parametrize("extra,nproc", [(["--dist_mode", "p2p", "--force_sync_interval", "150"], 2), (["--dist_mode", "p2p", "--num_proc", "4"], 4), ([], 2),
                                          (["--neg_deg_sample", "--async_update"], 2), (["--dist_slack", "0.05"], 2),
                                          (["--rel_part"], 2), (["--rel_part", "--rel_part_policy", "soft"], 2)],
                          ids=["p2p_one_per_gpu", "p2p_num_proc_4", "a2a_default", "a2a_neg_deg_sample_pipelined", "a2a_buckets_grow",
