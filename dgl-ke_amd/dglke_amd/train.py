@@ -365,6 +365,11 @@ class Trainer(object):
             if iv and iv > 0:
                 marks.update(range(iv, args.max_step + 1, iv))
         marks.add(args.max_step)
+        # --force_sync_interval with --num_proc K lanes on one GPU: the lanes are streams of this process - the synchronise at a mark
+        # IS the reference's barrier between its trainer processes (train_pytorch.py:181-187)
+        fsi = int(getattr(args, 'force_sync_interval', -1) or -1)
+        if fsi > 0 and self.n_lanes > 1:
+            marks.update(range(fsi, args.max_step + 1, fsi))
         since_log = 0
         timed = None
         t_interval = 0.0

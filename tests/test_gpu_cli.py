@@ -147,7 +147,7 @@ def test_train_cli_hogwild_lanes(tmp_path, capsys):
                  "--data_files", "e.dict", "r.dict", "train.txt", "valid.txt", "test.txt", "--save_path",
                  str(tmp_path / "ckpts"), "--gpu", "0", "--batch_size", "256", "--neg_sample_size", "64",
                  "--hidden_dim", "32", "-g", "8", "--lr", "0.25", "-adv", "-rc", "1e-7", "--max_step", "600",
-                 "--log_interval", "300", "--num_proc", "3", "--test", "--no_save_emb", "--graph_steps", "100"])
+                 "--log_interval", "300", "--num_proc", "3", "--force_sync_interval", "250", "--test", "--no_save_emb", "--graph_steps", "100"])
     out = capsys.readouterr().out
     assert len(tr.lanes) == 3 and len({id(l.engine) for l in tr.lanes}) == 3
     assert tr.lanes[1].engine.ent.data_ptr() == tr.model.entity_emb.emb.data_ptr()     # shared tables
