@@ -91,10 +91,24 @@ def measured_traffic(workload):
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 d = json.load(f)
             if d.get("workload") == workload:
+                _PROFILE_HASHES["traffic"] = d.get("source_hash")
                 return d["hbm_bytes_per_step"]
         except Exception:
             pass
     return None
+
+
+_PROFILE_HASHES = {}      # source hashes of the committed profile summaries this line quotes (measured_traffic, profiled_kernels)
+
+
+def profile_matches_build():
+    """True when every committed profile summary quoted in the line (roofline.traffic, dominant_kernel_us, profiled_step_us) was
+    taken from the source set the running libkge_hip.so was built from (__graft_entry__.source_hash, written into
+    profiles/latest_*.json by tools/kernel_stats_json.py / traffic_json.py); False when one of them is older or carries no hash."""
+    import __graft_entry__
+    cur = __graft_entry__.source_hash()
+    return {"matches": bool(_PROFILE_HASHES) and all(v == cur for v in _PROFILE_HASHES.values()), "build_source_hash": cur,
+            "profile_source_hashes": dict(_PROFILE_HASHES)}
 
 
 def profiled_kernels(workload):
@@ -103,7 +117,10 @@ def profiled_kernels(workload):
     try:
         with open(os.path.join(ROOT, "profiles", "latest_kernel_stats.json")) as f:
             d = json.load(f)
-        return d if d.get("workload") == workload else None
+        if d.get("workload") != workload:
+            return None
+        _PROFILE_HASHES["kernel_stats"] = d.get("source_hash")
+        return d
     except Exception:
         return None
 
@@ -184,8 +201,8 @@ def cpu_baseline_reference(w, plans, budget_s=12.0):
     shape = "%s, B=%d N=%d D=%d" % (w["model"], w["B"], w["N"], w["hidden"])
     out = {"value": one["value"], "unit": "edges/s", "cores": one["threads"], "kind": "reference",
            "sample": "%d steps of the same workload (%s) by the reference's own train() / KEModel.forward / backward / update "
-                     "(the six files of SURVEY 8(a), compiled unmodified into oracle/_ref; DGL stubbed, sampler excluded on both "
-                     "sides); intra-op threads = the fastest of the probed counts on this %d-core host"
+                     "(the six files of SURVEY 8(a), compiled unmodified into oracle/_ref; DGL stubbed: the CPU side runs "
+                     "WITHOUT its sampler, the GPU `value` INCLUDES sampling and plan construction - conservative for the GPU); intra-op threads = the fastest of the probed counts on this %d-core host"
                      % (one["steps"], shape, nthreads),
            "ms_per_step": round(1e3 * w["B"] / one["value"], 3), "edges_per_s_by_threads": one["edges_per_s_by_threads"],
            "single_process": {"value": one["value"], "threads": one["threads"]}}
@@ -199,7 +216,8 @@ def cpu_baseline_reference(w, plans, budget_s=12.0):
             out["ms_per_step"] = round(1e3 * w["B"] / hv, 3)          # aggregate: one step of ANY process every ... ms
             out["sample"] = ("%d steps in %.1f s by %d single-thread processes sharing one KEModel (reference --num_proc %d; %s): "
                              "the reference's own train() / KEModel.forward / backward / update on the six files of SURVEY 8(a), "
-                             "compiled unmodified into oracle/_ref (DGL stubbed, sampler excluded on both sides); the "
+                             "compiled unmodified into oracle/_ref (DGL stubbed: the CPU side runs WITHOUT its sampler, the GPU `value` "
+                             "INCLUDES sampling and plan construction - conservative for the GPU); the "
                              "single-process run with %d intra-op threads: %.0f edges/s"
                              % (hsteps, hwall, procs, procs, shape, one["threads"], one["value"]))
     except Exception as e:  # noqa: BLE001 - the multi-process leg must never hide the single-process number
@@ -243,7 +261,7 @@ def cpu_baseline_port(w, plans, budget_s=12.0, max_steps=200):
     single = n * w["B"] / dt
     out = {"value": round(single, 1), "unit": "edges/s", "cores": best, "kind": "port",
            "sample": "%d steps of the same workload (%s, B=%d N=%d D=%d), torch-CPU port of the "
-                     "reference ops (oracle/torch_port.py), sampler excluded on both sides; intra-op "
+                     "reference ops (oracle/torch_port.py); the CPU side runs WITHOUT a sampler, the GPU `value` INCLUDES sampling; intra-op "
                      "threads = the fastest of the probed counts on this %d-core host"
                      % (n, w["model"], w["B"], w["N"], w["hidden"], nthreads),
            "ms_per_step": round(1e3 * dt / max(n, 1), 3), "edges_per_s_by_threads": tried,
@@ -259,8 +277,8 @@ def cpu_baseline_port(w, plans, budget_s=12.0, max_steps=200):
             out["value"], out["cores"] = round(hv, 1), procs
             out["ms_per_step"] = round(1e3 * w["B"] / hv, 3)          # aggregate: one step of ANY process every ... ms
             out["sample"] = ("%d steps in 5 s by %d single-thread processes sharing the tables (reference --num_proc %d; "
-                             "%s, B=%d N=%d D=%d), torch-CPU port of the reference ops (oracle/torch_port.py), sampler "
-                             "excluded on both sides; the single-process run with %d intra-op threads: %.0f edges/s"
+                             "%s, B=%d N=%d D=%d), torch-CPU port of the reference ops (oracle/torch_port.py); the CPU side runs "
+                             "WITHOUT a sampler, the GPU `value` INCLUDES sampling; the single-process run with %d intra-op threads: %.0f edges/s"
                              % (hsteps, procs, procs, w["model"], w["B"], w["N"], w["hidden"], best, single))
     except Exception as e:  # noqa: BLE001 - the multi-process leg must never hide the single-process number
         out["num_proc"] = {"error": repr(e)}
@@ -451,6 +469,69 @@ def other_configs(steps=600, timeout_s=150.0, only=None):
     return res
 
 
+def time_to_mrr(timeout_s=240.0, target=0.65):
+    """the second half of BASELINE.json's metric as a bounded leg in its own process: `dglke_train` with the reference's FB15k
+    TransE_l2 recipe (examples/fb15k/multi_gpu.sh:83-95: batch 1000, neg 200, dim 400, gamma 19.9, lr 0.25, -adv, rc 1e-9,
+    max_step 24000), filtered validation every 500 steps, stop at validation MRR >= 0.65.  Real FB15k files are used when an
+    operator supplied them (FB15K_DIR, $KGE_DATA_PATH/FB15k, data/FB15k); there is no network here, so otherwise the graph is the
+    FB15k-shaped PLANTED one of tools/make_planted_fb15k.py and the entry says so (`graph`)."""
+    import re
+    import subprocess
+    import tempfile
+    real = os.environ.get("FB15K_DIR") or os.path.join(os.environ.get("KGE_DATA_PATH", os.path.join(ROOT, "data")), "FB15k")
+    common = ["--model_name", "TransE_l2", "--no_save_emb", "--gpu", "0", "--batch_size", "1000", "--neg_sample_size", "200",
+              "--hidden_dim", "400", "--gamma", "19.9", "--lr", "0.25", "-adv", "--regularization_coef", "1e-9", "--max_step", "24000",
+              "--log_interval", "1000", "--eval_interval", "500", "--valid", "--test", "--target_mrr", str(target),
+              "--graph_steps", "100", "--batch_size_eval", "16"]
+    cli = os.path.join(ROOT, "dgl-ke_amd", "dglke_train")
+    t0 = time.perf_counter()
+    with tempfile.TemporaryDirectory(prefix="kge_ttm_") as tmp:
+        if os.path.isfile(os.path.join(real, "train.txt")) and os.path.isfile(os.path.join(real, "entities.dict")):
+            graph = "fb15k"
+            data = ["--dataset", "FB15k", "--data_path", os.path.dirname(os.path.abspath(real))]
+        else:
+            graph = "planted"
+            d = os.path.join(tmp, "fb15k_planted")
+            g = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_planted_fb15k.py"), d], stdout=subprocess.PIPE,
+                               stderr=subprocess.PIPE, text=True, timeout=timeout_s)
+            if g.returncode != 0:
+                return {"error": "planted graph: %s" % (g.stderr or "")[-300:]}
+            data = ["--format", "udd_hrt", "--dataset", "fb15k_planted", "--data_path", d,
+                    "--data_files", "entities.dict", "relations.dict", "train.txt", "valid.txt", "test.txt"]
+        try:
+            r = subprocess.run([sys.executable, cli] + data + ["--save_path", os.path.join(tmp, "ckpts")] + common,
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                               timeout=max(10.0, timeout_s - (time.perf_counter() - t0)))
+        except subprocess.TimeoutExpired:
+            return {"graph": graph, "error": "leg exceeded %.0f s" % timeout_s}
+    if r.returncode != 0:
+        return {"graph": graph, "error": "exit %d: %s" % (r.returncode, (r.stderr or "")[-300:])}
+    txt = r.stdout
+    hit = re.search(r"validation MRR ([0-9.]+) >= [0-9.]+ after (\d+) steps, ([0-9.]+) s of training", txt)
+    valid_mrr = [float(x) for x in re.findall(r"\]Valid average MRR: ([0-9.eE+-]+)", txt)]
+    evals = [float(x) for x in re.findall(r"validation take ([0-9.]+) seconds", txt)]
+    test_mrr = re.search(r"\]Test average MRR: ([0-9.eE+-]+)", txt)
+    test_s = re.search(r"testing takes ([0-9.]+) seconds", txt)
+    out = {"graph": graph, "target_mrr": target, "reached": bool(hit),
+           "mrr": float(hit.group(1)) if hit else (valid_mrr[-1] if valid_mrr else None),
+           "steps": int(hit.group(2)) if hit else 24000,
+           "train_seconds": float(hit.group(3)) if hit else None,
+           "eval_seconds": round(sum(evals), 3), "validations": len(evals),
+           "test_mrr": float(test_mrr.group(1)) if test_mrr else None,
+           "test_seconds": float(test_s.group(1)) if test_s else None,
+           "leg_wall_s": round(time.perf_counter() - t0, 1),
+           "recipe": "dglke_train TransE_l2, the reference's FB15k recipe (examples/fb15k/multi_gpu.sh:83-95), --valid every 500 steps "
+                     "(filtered ranking of every validation triple against all entities, both sides), stop at MRR >= %g; "
+                     "train_seconds = the training steps only, eval_seconds = the validations up to the stop" % target,
+           "note": ("REAL FB15k (operator-supplied files): this is BASELINE.json's time-to-MRR metric" if graph == "fb15k" else
+                    "PLANTED FB15k-shaped graph (14 951 entities, 1 345 relations, 483 142 / 50 000 / 59 071 triples, 10 % noisy tails; "
+                    "tools/make_planted_fb15k.py) - real FB15k is not available offline, so the MRR trajectory is NOT FB15k's: only the step "
+                    "and evaluation rates carry over (reference: MRR 0.649 after 24 000 steps = 167 s on one V100)")}
+    if not hit and not valid_mrr:
+        out["error"] = "no validation line in the CLI output: %s" % txt[-300:]
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -478,6 +559,8 @@ def main():
     ap.add_argument("--hogwild", type=int, default=4, help="also measure K concurrent Hogwild trainers (0 = skip)")
     ap.add_argument("--no-configs", dest="configs", action="store_false",
                     help="skip the bounded legs of BASELINE configs[2..4] (the `configs` object of the default line)")
+    ap.add_argument("--no-time-to-mrr", dest="time_to_mrr", action="store_false",
+                    help="skip the bounded time-to-MRR@0.65 leg (dglke_train on real FB15k when supplied, else on the planted graph)")
     ap.add_argument("--min-untimed", type=int, default=120,
                     help="steps run back to back right in front of the timed region: max(--warmup, this).  The first ~250 us of step "
                          "kernels after a pause of the queue run ~50 us late (clock ramp of the idle GPU, "
@@ -584,16 +667,30 @@ def main():
         start()
         run_w = lambda: run_groups(0, len(seq_w))
         run_t = lambda: run_groups(len(seq_w), len(seq))
-        launch_desc = (("hipGraph of %d steps; sampler launch for the next group: %s" % (G, {
-            "streams": "concurrently on a second stream", "fork": "on a forked branch of the graph",
-            "fork_tail": "on a branch of the graph forked in front of the group's last step",
-            "fused": "NO sampler launch - step k of a group builds batch k of the next group with 4 + 5 + 5 tail workgroups on its "
-                     "own first / backward / update launches (kge_step_fused_sampling)",
-            "serial": "serially behind the group's steps"}[args.sampler_mode])) if use_graph else "eager, sampler mode " + args.sampler_mode)
-        launch_desc += ("; untimed before the timed region: %s%d warm-up steps (max(--warmup %d, --min-untimed %d): the GPU's clocks "
-                        "have ramped when the one synchronise opens the timed region)"
-                        % (("a dry run of the whole schedule (%d steps, graph capture), then fresh parameters and " % (n_warm + args.steps))
-                           if use_graph else "", n_warm, args.warmup, args.min_untimed))
+        def launch_desc():
+            # what the TIMED groups actually did (PrefetchedGroups.stats, reset behind the warm-up): a group's successor is built by
+            # tail workgroups of the group's own launches only when 0 < next <= current <= fused_max steps, else by a sampler launch
+            st = pg.stats
+            ng = st["fused"] + st["launch"] + st["none"]
+            how = {"streams": "a sampler launch on a second stream next to the group", "fork": "a sampler launch on a forked branch of the graph",
+                   "fork_tail": "a sampler launch on a branch of the graph forked in front of the group's last step",
+                   "serial": "ONE sampler launch behind the group's steps on the same stream",
+                   "fused": "ONE sampler launch behind the group's steps on the same stream"}[args.sampler_mode]
+            parts = []
+            if st["fused"]:
+                parts.append("%d of the %d timed groups: NO sampler launch - step k of the group builds batch k of the next group with 4 + 5 + 5 "
+                             "tail workgroups on its own first / backward / update launches (kge_step_fused_sampling; groups of <= %d steps)"
+                             % (st["fused"], ng, pg.fused_max))
+            if st["launch"]:
+                parts.append("%d of the %d timed groups: %s" % (st["launch"], ng, how))
+            d = (("hipGraph per group of <= %d steps (timed groups: %s); the next group's batches: %s"
+                  % (G, "+".join(str(x) for x in seq_t), "; ".join(parts) or "none built"))
+                 if use_graph else "eager, sampler mode " + args.sampler_mode)
+            d += ("; untimed before the timed region: %s%d warm-up steps (max(--warmup %d, --min-untimed %d): the GPU's clocks "
+                  "have ramped when the one synchronise opens the timed region; the warm-up groups of more than %d steps use the sampler launch)"
+                  % (("a dry run of the whole schedule (%d steps, graph capture), then fresh parameters and " % (n_warm + args.steps))
+                     if use_graph else "", n_warm, args.warmup, args.min_untimed, pg.fused_max))
+            return d
         data_desc = ("triples in HBM; batch ids, negatives and plan built ON THE DEVICE inside the timed region "
                      "(double-buffered: group g+1 is sampled while group g trains)")
     else:
@@ -643,11 +740,14 @@ def main():
                         eng.step(batches[(start + k) % pool])
         run_w = lambda: run(warm_items)
         run_t = lambda: run(timed_items)
-        launch_desc = "hipGraph of %d steps" % G if use_graph else "eager"
+        launch_desc = lambda: "hipGraph of %d steps" % G if use_graph else "eager"
+        pg = None
         data_desc = "id batches + plan built on the host and pre-staged in HBM, sampler excluded"
 
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     run_w()
+    if pg is not None:
+        pg.reset_stats()              # (host-side counters: which sampler path the TIMED groups take)
     eng.loss_accum.zero_()            # (stream order: behind the warm-up steps) the sums of the timed steps only
     torch.cuda.synchronize()
     ev0.record()                      # (in front of the clock: the GPU is idle, its time stamp precedes the first kernel)
@@ -679,7 +779,8 @@ def main():
                                    w["model"], "heavy-tailed" if args.skew else "uniform", w["n_ent"], w["n_rel"], w["B"],
                                    w["N"], w["hidden"], w["gamma"], w["lr"], w["adv"], w["reg_coef"], data_desc),
                    "global_batch": w["B"], "parallelism": "1 GPU",
-                   "launch": launch_desc,
+                   "launch": launch_desc(),
+                   "sampler_groups_timed": dict(pg.stats) if pg is not None else None,
                    "neg_kernels": "pairwise" if args.force_pairwise else "auto"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                      "frac": round(achieved / 8000.0, 5), "traffic": measured_traffic(args.workload),
@@ -705,6 +806,10 @@ def main():
             d_row = w["hidden"] * (2 if w["de"] else 1)
             tf = 4.0 * w["B"] * w["N"] * d_row / (ks[dom]["avg_us"] * 1e-6) / 1e12
             out["roofline"]["mfma_dominant_frac"] = round(tf / 157.3, 5)
+    pm = profile_matches_build()
+    out["roofline"]["profile_matches_build"] = pm["matches"]
+    out["roofline"]["build_source_hash"] = pm["build_source_hash"]
+    out["roofline"]["profile_source_hashes"] = pm["profile_source_hashes"]
     if w["model"] in ("TransE_l2", "DistMult", "ComplEx", "SimplE") and not args.force_pairwise:
         # second bound of SURVEY 8(d): the chunked negative score and its two gradient products on the
         # fp32 matrix cores, 2·B·N·D forward + 4·B·N·D backward, against the dense fp32 MFMA peak
@@ -749,6 +854,13 @@ def main():
         del eng                        # (the legs run in their own processes; the 34-GB shard needs the HBM this one holds)
         torch.cuda.empty_cache()
         out["configs"] = other_configs()
+    if args.time_to_mrr and args.configs and args.workload == "transe_l2_fb15k" and not args.skew and not args.flags:
+        try:
+            eng = None                 # (the leg runs in its own process)
+            torch.cuda.empty_cache()
+            out["time_to_mrr"] = time_to_mrr()
+        except Exception as e:  # noqa: BLE001 - a leg must never hide the headline
+            out["time_to_mrr"] = {"error": repr(e)}
     if not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(w, plans)

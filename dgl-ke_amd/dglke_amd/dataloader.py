@@ -212,7 +212,9 @@ class DeviceSampler(object):
         """what tail_jobs needs once: the scratch buffer and - the jobs read the triples in base-permutation order, their first phase
         is a chain of dependent memory rounds under a 9-us launch and perm[e] was one of them - permuted copies of the triples.
         NEVER inside a graph capture: the three gather kernels would become part of the graph and run with every replay (they did:
-        24 us per replayed group, profiles/r05_sampler_tail.txt) - callers that capture call this first."""
+        24 us per replayed group, profiles/r05_sampler_tail.txt) - callers that capture call this first.
+        HBM cost: the permuted copies of H, R and T are 24 bytes per training triple (FB15k: 11.6 MB; 338 M Freebase edges: 8.1 GB),
+        held for the sampler's lifetime."""
         from . import _lib
         if getattr(self, "_tail_scratch", None) is not None:
             return
@@ -326,6 +328,13 @@ class PrefetchedGroups(object):
         self.buf = 0                  # half holding the batches of the NEXT group to train
         self.ready = None             # DeviceBatch objects in that half
         self.graphs = {}
+        # how the NEXT group's batches were built, per run() call since the last reset_stats(): by tail workgroups of the steps'
+        # own launches ('fused'), by a sampler launch ('launch': serial / streams / fork), or not at all (n_next == 0)
+        self.stats = {"fused": 0, "launch": 0, "none": 0}
+
+    def reset_stats(self):
+        for k in self.stats:
+            self.stats[k] = 0
 
     def prefill(self, n):
         """build the first group's batches on the current stream (outside any graph)."""
@@ -359,8 +368,12 @@ class PrefetchedGroups(object):
         n_cur = len(self.ready)
         if n_next > self.half:
             raise ValueError("group larger than half of the slots")
+        # (graph keys carry the corruption parity of the group's first batch and of the next group's: the cached DeviceBatch objects
+        #  of a replayed graph must be the ones sampler.host_step would hand out now - an odd-sized group flips the parity)
+        par = (bool(self.ready[0].neg_head) if n_cur else None, self.smp.host_step % 2)
         if self.mode in ("fork", "fork_tail"):
-            key = (n_cur, n_next, self.buf)
+            self.stats["launch" if n_next else "none"] += 1
+            key = (n_cur, n_next, self.buf, par)
             if not graph:
                 nxt = self._enqueue_fork(n_next)
             elif key in self.graphs:
@@ -377,9 +390,10 @@ class PrefetchedGroups(object):
             self.buf ^= 1
             return
         if self.mode == "fused" and 0 < n_next <= n_cur <= self.fused_max:
-            key = (n_cur, n_next, self.buf)
+            self.stats["fused"] += 1
+            key = (n_cur, n_next, self.buf, par)
             if graph and key in self.graphs:
-                g, nxt = self.graphs[key]
+                g, nxt, _ = self.graphs[key]
                 self.smp.host_step += n_next
                 self.smp.launches += 1
                 for b in nxt:
@@ -405,14 +419,14 @@ class PrefetchedGroups(object):
                                 self.step_fn(self.ready[k], sample_job=jobs[k] if k < n_next else None)
                         gs.append(g1)
                     g = _GraphSeq(gs)
-                    self.graphs[key] = (g, nxt)
-                    self._jobs_alive = getattr(self, "_jobs_alive", []) + [jobs]
+                    self.graphs[key] = (g, nxt, jobs)      # (the job structs live as long as the graph that was recorded with them)
                     g.replay()
                 else:
                     nxt, _ = enqueue()
             self.ready = nxt
             self.buf ^= 1
             return
+        self.stats["launch" if n_next else "none"] += 1
         cur = th.cuda.current_stream(self.smp.dev)
         nxt = None
         if n_next and self.mode == "streams":
@@ -423,7 +437,7 @@ class PrefetchedGroups(object):
             for b in self.ready:
                 self.step_fn(b)
         else:
-            key = (n_cur, self.buf)
+            key = (n_cur, self.buf, par[0])
             if key not in self.graphs:
                 head = self.head if 0 < self.head and 2 * self.head <= n_cur else 0
                 gs = []

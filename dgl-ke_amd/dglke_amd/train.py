@@ -425,7 +425,8 @@ class Trainer(object):
                     print('[proc 0]validation MRR {:.4f} >= {:.4f} after {} steps, {:.3f} s of training'.format(
                         m['MRR'], args.target_mrr, step, t_train))
                     break
-                start = time.time()
+                # (no reset of `start` here: the reference's '[Train] N steps take' interval includes a validation that falls
+                #  inside it, train_pytorch.py:168-176)
         print('proc {} takes {:.3f} seconds'.format(0, time.time() - train_start))
         return reached
 
@@ -550,8 +551,7 @@ class ShardedTrainer(object):
                     valid_start = time.time()
                     self.evaluate('valid', 'Valid')
                     print('[proc {}]validation take {:.3f} seconds:'.format(rank, time.time() - valid_start))
-                dist.barrier()
-                start = time.time()
+                dist.barrier()           # (`start` is not reset: the interval includes the validation, train_pytorch.py:168-176)
         th.cuda.synchronize()
         print('proc {} takes {:.3f} seconds'.format(rank, time.time() - train_start))
         dist.barrier()

@@ -4,7 +4,9 @@ profiles/latest_traffic_<leg>.json: what bench.py reports as that leg's roofline
 (per-launch PMC means from tools/rocpd_stats.py --pmc; FETCH_SIZE doubled per MI355X_MICROARCH.md).
 Only the kernels of the training step are summed; the sampler kernel builds G batches per launch
 (G = --graph-steps of the profiled run, default 120) and is added as 1/G of its per-launch traffic."""
-import json, re, sys
+import json, os, re, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from __graft_entry__ import source_hash
 def parse(path):
     out = {}
     for line in open(path):
@@ -20,7 +22,7 @@ ours = lambda d: {k: (v / G if ("sample_plan" in k or "route_" in k) else v) for
                   and "randperm" not in k and "elementwise" not in k and "anonymous namespace" not in k}
 f, w = ours(f), ours(w)
 tot = sum(2 * v * 1024 for v in f.values()) + sum(v * 1024 for v in w.values())
-json.dump({"build": sys.argv[3], "workload": sys.argv[4], "fetch_kb_per_launch": f, "write_kb_per_launch": w,
+json.dump({"build": sys.argv[3], "source_hash": source_hash(), "workload": sys.argv[4], "fetch_kb_per_launch": f, "write_kb_per_launch": w,
            "correction": "FETCH_SIZE x2 (gfx950 counts 128-B requests at 64 B, MI355X_MICROARCH.md HBM section); WRITE_SIZE uncorrected",
            "hbm_bytes_per_step": tot}, open(sys.argv[6] if len(sys.argv) > 6 else "profiles/latest_traffic.json", "w"), indent=1)
 print("hbm MB/step", tot / 1e6)
