@@ -246,11 +246,17 @@ def _a2a_setup(args, world, rank, dev, w, n_ent, d_e, emb_init, allow_force_coll
                         "fork inside the graph") if sched else "; synchronous schedule")) if graph_coll else
                        (("eager launches, " + pipe_desc if sched else "eager launches") +
                         (", the step's kernels between pull and push replayed from %d small hipGraphs" % n_cg if n_cg else "")))
+        if getattr(de, "local_only", False):
+            return ("entity table range-sharded (world 1: ONE shard = this GPU's 10.76 M-row table), relation table replicated; every row of a "
+                    "batch is local, so the all-to-all engine runs the in-place step on the shard - no routing, no row cache, no gradient "
+                    "messages, no owner-side apply launch (dist.DistEngine.local_only; the N > 1 path with its exchanges kept at world 1 "
+                    "is the `rotate_freebase_a2a_forced_exchange*` legs); %s; sampling + plan on the device inside the timed region"
+                    % launch_desc)
         return ("entity table range-sharded, relation table replicated; per step: device-side routing into %d-row owner buckets, "
                 "all-to-all pull of the unique rows, the single-GPU kernels against the row cache, all-to-all push of one packed "
                 "gradient message per row, owner-side Adagrad in rank order (one merged launch), %s "
                 "(parameter-server semantics, RCCL%s); %s; sampling + plan on the device inside the timed region"
-                % (de.cap, rel_desc, comm_desc, launch_desc))
+                % (de.cap or 0, rel_desc, comm_desc, launch_desc))
     de.describe = describe
     desc = describe(pipelined)
     return eng, run, rows, desc, de

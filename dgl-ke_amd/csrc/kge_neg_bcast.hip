@@ -463,14 +463,26 @@ __device__ __forceinline__ void neg_fwd_rot_xlds_body(const NegArgs &a, int ns, 
     (void)j;
 }
 
+// XCD-aware block order (round 6).  Hardware block b runs on XCD b % 8 and every XCD has its own L2.  Consecutive LOGICAL workgroups
+// share operands - the forward's 16 workgroups of a (chunk, strip) read the same 64 negative rows (205 KB at cfg-R), the backward's
+// workgroups of a (chunk, column slab) the same slab of A and of the negatives - and in hardware order they sat on eight different
+// XCDs: every L2 fetched every strip (PMC FETCH_SIZE of the forward 29 MB for 6.6 MB of distinct operands at cfg-R,
+// profiles/r05_rotate_wide_pmc_FETCH_SIZE.txt).  xcd_remap hands an XCD a contiguous range of logical ids.  -DSB_NO_XCD: hardware order.
+__device__ __forceinline__ int sb_block(int b, int nb) {
+#ifdef SB_NO_XCD
+    (void)nb; return b;
+#else
+    return kge::xcd_remap(b, nb);
+#endif
+}
 template <int MODEL>
 __global__ __launch_bounds__(FwdShape<MODEL>::BLOCK) void neg_fwd_bcast_kernel(NegArgs a, int ns, int ng) {
     KGE_TL(1);
-    neg_fwd_bcast_body<MODEL, false>(a, ns, ng, (int)blockIdx.x);
+    neg_fwd_bcast_body<MODEL, false>(a, ns, ng, sb_block((int)blockIdx.x, (int)gridDim.x));
 }
 __global__ __launch_bounds__(FwdShape<KGE_ROTATE>::BLOCK) void neg_fwd_rot_xlds_kernel(NegArgs a, int ns, int ng) {
     KGE_TL(1);
-    neg_fwd_rot_xlds_body(a, ns, ng, (int)blockIdx.x);
+    neg_fwd_rot_xlds_body(a, ns, ng, sb_block((int)blockIdx.x, (int)gridDim.x));
 }
 
 // TransE_l1, strict step: forward pairwise tasks (first nbF workgroups) + the edge-forward rows of the SAME step (the rest: one
@@ -478,7 +490,7 @@ __global__ __launch_bounds__(FwdShape<KGE_ROTATE>::BLOCK) void neg_fwd_rot_xlds_
 template <bool LEAN>
 __global__ __launch_bounds__(FwdShape<KGE_TRANSE_L1>::BLOCK) void neg_fwd_bcast_edge_kernel(NegArgs a, int ns, int ng, int nbF, EdgeFwdArgs e) {
     static_assert(FwdShape<KGE_TRANSE_L1>::WAVES % KGE_WAVES_PER_BLOCK == 0, "edge_fwd_body counts workgroups of KGE_WAVES_PER_BLOCK wavefronts");
-    if ((int)blockIdx.x < nbF) neg_fwd_bcast_body<KGE_TRANSE_L1, true>(a, ns, ng, (int)blockIdx.x);
+    if ((int)blockIdx.x < nbF) neg_fwd_bcast_body<KGE_TRANSE_L1, true>(a, ns, ng, sb_block((int)blockIdx.x, nbF));
     else edge_fwd_body<KGE_TRANSE_L1, 4, LEAN>(e, ((int)blockIdx.x - nbF) * (FwdShape<KGE_TRANSE_L1>::WAVES / KGE_WAVES_PER_BLOCK));
 }
 
@@ -801,7 +813,15 @@ __global__ __launch_bounds__(KGE_BLOCK) LC_OCC void neg_bwd_lc_kernel(NegArgs a,
     if (a.lc_P > 0) {
         // balanced split (NegArgs::lc_P): sorted index i of this block id (rounds of 256 ids, odd rounds reversed), then the
         // i-th heaviest workgroup: classes in descending size - big / small parts of the lc_P-part columns, then of the others
-        const int b = (int)blockIdx.x, k = b & 255, rnd = b >> 8;
+        // (round 6: inside a round of 256 block ids the XCD of id k - k % 8 - takes the 32 consecutive sorted indices
+        //  [32 (k % 8), 32 (k % 8) + 32): parts of the same (chunk, slab) columns share an L2; the heaviest-first dealing over the
+        //  rounds is unchanged per CU slot)
+        const int b = (int)blockIdx.x, rnd = b >> 8;
+#ifdef SB_NO_XCD
+        const int k = b & 255;
+#else
+        const int k = ((b & 7) << 5) | ((b & 255) >> 3);
+#endif
         int t = (rnd << 8) + ((rnd & 1) ? 255 - k : k);
         const int P = a.lc_P, nB = a.lc_nB, ncol = a.C * nslab * nrw, nA = ncol - nB;
         const int remB = ngr % P, remA = ngr % (P + 1);
@@ -815,7 +835,8 @@ __global__ __launch_bounds__(KGE_BLOCK) LC_OCC void neg_bwd_lc_kernel(NegArgs a,
         const int base = ngr / nsp, rem = ngr % nsp;             // the first `rem` parts hold one group more
         g_lo = j * base + min(j, rem); g_hi = g_lo + base + (j < rem ? 1 : 0);
     } else {
-        sp = (int)blockIdx.x % nsp; blk = (int)blockIdx.x / nsp;
+        const int lb = sb_block((int)blockIdx.x, (int)gridDim.x);
+        sp = lb % nsp; blk = lb / nsp;
         g_lo = sp * ngr / nsp; g_hi = (sp + 1) * ngr / nsp;
     }
     const int rw = blk % nrw, slab = (blk / nrw) % nslab, c = blk / (nrw * nslab);

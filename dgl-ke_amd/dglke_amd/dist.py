@@ -343,6 +343,28 @@ class HipOps(object):
         if first < rel_msg.shape[0]:
             rel_msg.view(torch.int32)[first:, d_r + 1:d_r + 3] = -1
 
+    def step_local(self, engine, batch, ent, ent_state):
+        """world 1 without collectives: every row of the batch is a row of THIS rank's shard (global id == shard row), so the step is
+        the in-place single-table step on the shard - no routing, no row cache, no gradient messages, no apply launch (round 6:
+        the cache copy and the messages were 66 MB of the a2a engine's 277 MB per step at world 1)."""
+        key = ("local", ent.data_ptr(), ent_state.data_ptr(), engine.rel.data_ptr())
+        if not hasattr(self, "_structs"):
+            self._structs = {}
+        st = self._structs.get(key)
+        if st is None:
+            tb = _lib.KgeTables()
+            tb.ent, tb.ent_state = _lib.ptr(ent), _lib.ptr(ent_state)
+            tb.rel, tb.rel_state = _lib.ptr(engine.rel), _lib.ptr(engine.rel_state)
+            tb.n_ent, tb.n_rel = ent.shape[0], engine.rel.shape[0]
+            out = _lib.KgeStepOut()
+            out.loss_accum = _lib.ptr(engine.loss_accum)
+            out.tickets = _lib.ptr(engine.tickets)
+            st = self._structs[key] = (tb, out)
+        tb, out = st
+        ws = engine.workspace_for(batch)
+        _lib.check(_lib.lib().kge_step_fused(C.byref(engine.hp), C.byref(tb), C.byref(batch.c), C.byref(out), _lib.ptr(ws),
+                                             engine._ws_bytes, _lib.stream_ptr()))
+
     def step_grads(self, engine, lb, cache, ent_msg, rel_msg, zero_state):
         """run kge_step_grads against the row cache, emitting packed messages at the rows' cache positions:
         ent_msg[row] = [g0 | g1 | gs0 gs1 . .],  rel_msg[u] = [gr | gsr | id_lo id_hi .]"""
@@ -419,6 +441,10 @@ class DistEngine(object):
                              getattr(self.ops, "rel_inplace", True))
         self.slots = None
         import os
+        # world 1 and no collective asked for: all rows are local - the in-place step on the shard (HipOps.step_local; test doubles
+        # without it and KGE_DIST_LOCAL_SHORTCUT=0 keep the route -> gather -> step -> messages -> apply path)
+        self.local_only = (spec.world == 1 and not self.coll and hasattr(self.ops, "step_local") and
+                           os.environ.get("KGE_DIST_LOCAL_SHORTCUT", "1") != "0")
         self._pair_ok = os.environ.get("KGE_DIST_PAIR_APPLY", "1") != "0"      # (A/B aid: the two owner-side applies as two launches)
         # (compute graphs - precapture() - are OPT-IN: measured slower than six eager launches, 180 vs 172 us per forced-collective
         #  step at cfg-R: a graph launch costs more host time than the launches it replaces at this size)
@@ -487,6 +513,8 @@ class DistEngine(object):
         a bucket would overflow, grows `cap` (all exchange buffers are re-allocated) BEFORE any of the group's steps runs - no
         entity is ever trained against the dump row.  Heavy-tailed graphs cluster their hubs in a few shards: the default
         capacity (1.5 x the mean share) is a starting point, not a bound.  Returns the capacity in use."""
+        if self.local_only:
+            return self.cap
         if self.slots is None:
             self._setup(batches[0])
         W = self.spec.world
@@ -519,6 +547,8 @@ class DistEngine(object):
         collective deep instead of two dependent ones.
         check_capacity=False (callers that record the group into a hipGraph, where nothing may be read back): the buckets keep
         their size and the overflow counter of the routing kernel is the check (check_overflow())."""
+        if self.local_only:
+            return                                   # every row is a row of this rank's table: nothing to size, route or exchange
         if check_capacity:
             self.ensure_capacity(batches, log)
         elif self.slots is None:
@@ -594,6 +624,10 @@ class DistEngine(object):
             self.comm.close()
 
     def _steps(self, batches, pipelined):
+        if self.local_only:                           # (no exchange to overlap: every schedule is the same in-place steps)
+            for b in batches:
+                self.ops.step_local(self.engine, b, self.ent, self.ent_state)
+            return
         if pipelined == "overlap":
             return self._steps_overlapped(batches)
         for k, b in enumerate(batches):
@@ -789,7 +823,7 @@ class DistEngine(object):
 
     def check_overflow(self):
         """entries that did not fit their owner bucket since the last call (one 4-byte D2H read: call at the log interval)."""
-        if self.slots is None:
+        if self.slots is None or self.local_only:
             return 0
         n = int(self.overflow.item())
         if n:
@@ -863,6 +897,8 @@ class DistEngine(object):
 
     def step(self, batch):
         """one synchronous sharded step (pull, compute, push, apply), all enqueued on the current stream."""
+        if self.local_only:
+            return self.ops.step_local(self.engine, batch, self.ent, self.ent_state)
         lb = self.pull(batch, 0)
         self._compute(lb)
         self._push_apply(lb)
@@ -890,6 +926,8 @@ class DistEngine(object):
         """one step with the pull of `next_batch` (the batch of the following call) overlapped: its rows are gathered on a
         side stream after update s-1 and before update s lands (exact one-step staleness: the reference's --async_update
         licence, tensor_models.py:136-175), while this step computes."""
+        if self.local_only:
+            return self.ops.step_local(self.engine, batch, self.ent, self.ent_state)
         main = torch.cuda.current_stream(self.dev)
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.dev)

@@ -446,3 +446,60 @@ def test_world2_equals_single_table_step_on_disjoint_batches(tmp_path):
         np.testing.assert_allclose(z[model + "_state"], z[model + "_ref_state"], rtol=1e-5, atol=1e-8, err_msg=model)
         np.testing.assert_allclose(z[model + "_rel0"], z[model + "_ref_rel"], rtol=1e-5, atol=5e-6, err_msg=model)
         np.testing.assert_allclose(z[model + "_relstate0"], z[model + "_ref_rel_state"], rtol=1e-5, atol=1e-8, err_msg=model)
+
+
+@pytest.mark.parametrize("model", ["RotatE", "TransE_l2"])
+def test_world1_local_shortcut_is_the_single_table_step(model):
+    """round 6: the all-to-all engine at world 1 without collectives runs the in-place step on its shard (DistEngine.local_only - no
+    routing, no row cache, no gradient messages, no apply launch).  Bit-identical to StepEngine on the same table, eagerly and
+    through run_group's group graphs; the route -> gather -> messages -> apply path (KGE_DIST_LOCAL_SHORTCUT=0: what every rank runs at
+    world > 1) agrees with it within the row tolerance of the sharded tests."""
+    from dglke_amd import dist as kd
+    from dglke_amd.dataloader import DeviceSampler
+    from dglke_amd.engine import StepEngine
+    n_ent, n_rel, hidden, B, N = 6000, 40, 64, 128, 32
+    de_flag = model == "RotatE"
+    rng = np.random.RandomState(41)
+    h, r, t = rng.randint(0, n_ent, 30000), rng.randint(0, n_rel, 30000), rng.randint(0, n_ent, 30000)
+    d_e = hidden * (2 if de_flag else 1)
+    torch.manual_seed(11)
+    ent0 = torch.empty(n_ent, d_e, device=DEV).uniform_(-0.2, 0.2)
+    rel0 = torch.empty(n_rel, hidden, device=DEV).uniform_(-0.2, 0.2)
+    lr = 0.05
+
+    def fresh(n_rows):
+        eng = StepEngine(model, n_rows, n_rel, hidden, 12.0, lr, DEV, de_flag, False, True, 1.0, 1e-6, 3)
+        eng.rel.copy_(rel0); eng.rel_state.zero_()
+        return eng
+    # reference: the single-table step
+    eng = fresh(n_ent)
+    eng.ent.copy_(ent0); eng.ent_state.zero_()
+    smp = DeviceSampler(h, r, t, n_ent, B, N, DEV, n_slots=6, seed=5)
+    for n in (6, 5, 6, 6):
+        for b in smp.sample(n):
+            eng.step(b)
+    torch.cuda.synchronize()
+    want = (eng.ent.clone(), eng.ent_state.clone(), eng.rel.clone(), eng.rel_state.clone())
+    got = {}
+    for name, env, graph in (("shortcut", "1", False), ("shortcut_graph", "1", True), ("routed", "0", False)):
+        os.environ["KGE_DIST_LOCAL_SHORTCUT"] = env
+        try:
+            e2 = fresh(1)
+            ent, state = ent0.clone(), torch.zeros(n_ent, device=DEV)
+            de = kd.DistEngine(e2, kd.ShardSpec(n_ent, 1, 0), ent, state)
+            assert de.local_only == (env == "1")
+            s2 = DeviceSampler(h, r, t, n_ent, B, N, DEV, n_slots=6, seed=5)
+            for n in (6, 5, 6, 6):
+                de.run_group(s2.sample(n), graph=graph)
+            torch.cuda.synchronize()
+            assert de.check_overflow() == 0
+            got[name] = (ent, state, e2.rel.clone(), e2.rel_state.clone())
+            de.close()
+        finally:
+            os.environ.pop("KGE_DIST_LOCAL_SHORTCUT", None)
+    for name in ("shortcut", "shortcut_graph"):
+        for x, y in zip(want, got[name]):
+            assert torch.equal(x, y), name
+    for x, y in zip(want, got["routed"]):
+        assert float((x - y).abs().max()) <= 1e-3 * lr, "routed path vs in-place step"
+    assert float((want[1] > 0).sum()) > 100
