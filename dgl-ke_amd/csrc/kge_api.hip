@@ -428,6 +428,9 @@ size_t kge_step_workspace_bytes(const kge_hparams *hp, int B, int C, int chunk, 
     add(B); add(B); add(UE); add(UR);           // row_pos, row_neg, reg_ent, reg_rel
     if (neg_bwd_lc_supported(hp->model, hp->d_e))   // TransE_l1 / RotatE: GN partials of the shared-pair backward
         add(neg_bwd_lc_partial_floats(hp->model, C, chunk, N, hp->d_e));
+    if (hp->model == KGE_TRANSR || hp->model == KGE_RESCAL) {      // sharded entity tables: dense [h | t | negative] rows + identity ids
+        add((size_t)(2 * B + CN) * d_e); add((size_t)2 * (2 * B + CN));
+    }
     return n;
 }
 
@@ -448,15 +451,16 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     if (!hp || !tb || !b || !ws) return fail(KGE_ERR_ARG, "kge_step: null argument");
     kge::ShardMap em{}, rm{};
     if (sh) {
-        if (sh->n_shards < 1 || sh->ent_rows_per_shard <= 0 || sh->rel_rows_per_shard <= 0 ||
-            !sh->ent_rows || !sh->ent_state || !sh->rel_rows || !sh->rel_state)
+        const bool rl = sh->rel_local != nullptr;      // ABI 8: relation-side tables local to this rank (relation partitioning)
+        if (sh->n_shards < 1 || sh->ent_rows_per_shard <= 0 || !sh->ent_rows || !sh->ent_state ||
+            (!rl && (sh->rel_rows_per_shard <= 0 || !sh->rel_rows || !sh->rel_state)) || (rl && !sh->rel_state_local))
             return fail(KGE_ERR_ARG, "kge_step_sharded: bad shard map");
         em = kge::ShardMap{sh->ent_rows, sh->ent_state, sh->ent_rows_per_shard, sh->n_shards};
-        rm = kge::ShardMap{sh->rel_rows, sh->rel_state, sh->rel_rows_per_shard, sh->n_shards};
+        if (!rl) rm = kge::ShardMap{sh->rel_rows, sh->rel_state, sh->rel_rows_per_shard, sh->n_shards};
     }
     if (int rc = check_model(hp->model, hp->d_e, hp->d_r)) return rc;
-    if (hp->model == KGE_RESCAL && (sh || emit))
-        return fail(KGE_ERR_ARG, "RESCAL is not available in the sharded / gradient-emitting steps");
+    if (hp->model == KGE_RESCAL && (emit || (sh && !sh->rel_local)))
+        return fail(KGE_ERR_ARG, "RESCAL: not in the gradient-emitting step; on sharded tables it needs kge_shards.rel_local (ABI 8)");
     if (b->B <= 0 || b->C <= 0 || b->chunk <= 0 || b->N <= 0 || (int64_t)b->C * b->chunk != b->B)
         return fail(KGE_ERR_ARG, "kge_step: need C*chunk == B (B=%d C=%d chunk=%d)", b->B, b->C, b->chunk);
     if (hp->loss_genre < KGE_LOSS_LOGSIGMOID || hp->loss_genre > KGE_LOSS_BCE)
@@ -518,9 +522,31 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     const bool transr = hp->model == KGE_TRANSR;
     TransRArgs tr{};
     float *TR1 = nullptr, *TR2 = nullptr;
+    // ---- TransR / RESCAL on peer-to-peer sharded ENTITY tables (round 6, ABI 8; the reference trains TransR on 8 GPUs with
+    // --rel_part, examples/freebase/multi_gpu.sh:80-89).  Their kernels address `table + id * width`; here the batch's entity rows
+    // are first gathered through the shard map into ONE dense block [h rows | t rows | negative rows] and the kernels run on that
+    // block with identity index arrays - no kernel of the two families changes.  The relation-side tables (relation rows /
+    // matrices, TransR's projection table) are local to the rank (kge_shards.rel_local: relation partitioning); the entity update
+    // goes through the shard map by global id like every other model's.
+    const bool sh_dense = sh && (transr || rescal);
+    kge_tables tbd = *tb; kge_batch bd = *b;
+    float *Xd = nullptr; int64_t *iota = nullptr;
+    if (transr || rescal) {                       // (always carved: the workspace size does not depend on the table layout)
+        Xd = cv.f((size_t)(2 * B + C * b->N) * d_e);
+        iota = reinterpret_cast<int64_t *>(cv.f((size_t)2 * (2 * B + C * b->N)));
+    }
+    if (sh_dense) {
+        tbd.ent = Xd; tbd.ent_state = nullptr; tbd.n_ent = 2 * B + C * b->N;
+        tbd.rel = sh->rel_local; tbd.rel_state = sh->rel_state_local; tbd.n_rel = sh->n_rel;
+        tbd.proj = sh->proj_local; tbd.proj_state = sh->proj_state_local;
+        bd.h_gid = iota; bd.t_gid = iota + B; bd.neg_ids = iota + 2 * B;
+    }
+    const kge_tables *tbx = sh_dense ? &tbd : tb;  // what the TransR / RESCAL kernels read
+    const kge_batch *bx = sh_dense ? &bd : b;
     if (transr) {
-        if (sh || emit) return fail(KGE_ERR_ARG, "TransR is not available in the sharded / gradient-emitting steps");
-        if (!tb->proj || !tb->proj_state) return fail(KGE_ERR_ARG, "TransR needs kge_tables.proj / proj_state");
+        if (emit) return fail(KGE_ERR_ARG, "TransR is not available in the gradient-emitting step");
+        if (sh && !sh->rel_local) return fail(KGE_ERR_ARG, "TransR on sharded tables needs kge_shards.rel_local / proj_local (ABI 8)");
+        if (!tbx->proj || !tbx->proj_state) return fail(KGE_ERR_ARG, "TransR needs kge_tables.proj / proj_state");
         tr.HP = cv.f((size_t)B * d_r); tr.TP = cv.f((size_t)B * d_r); tr.Q = cv.f((size_t)B * d_r);
         tr.SG = cv.f((size_t)B * d_r); tr.DQ = cv.f((size_t)B * d_r);
         TR1 = cv.f((size_t)B * d_e); TR2 = cv.f((size_t)B * d_e);
@@ -559,8 +585,8 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         tr.B = B; tr.C = C; tr.chunk = chunk; tr.N = N; tr.De = d_e; tr.Dr = d_r; tr.neg_head = b->neg_head;
         tr.UR = b->UR; tr.reg_norm = hp->reg_norm; tr.gamma = hp->gamma; tr.lr = hp->lr; tr.eps = hp->eps;
         tr.reg_coef = reg ? hp->reg_coef : 0.f;
-        tr.ent = tb->ent; tr.h_gid = b->h_gid; tr.t_gid = b->t_gid; tr.neg_ids = b->neg_ids; tr.rel_ids = b->rel_ids;
-        tr.rel = tb->rel; tr.proj = tb->proj; tr.proj_state = tb->proj_state;
+        tr.ent = tbx->ent; tr.h_gid = bx->h_gid; tr.t_gid = bx->t_gid; tr.neg_ids = bx->neg_ids; tr.rel_ids = b->rel_ids;
+        tr.rel = tbx->rel; tr.proj = tbx->proj; tr.proj_state = tbx->proj_state;
         tr.P = P; tr.S = S; tr.GN = GN; tr.GR = GR; tr.dpos = dP;
         tr.ur_id = b->ur_id; tr.ur_ptr = b->ur_ptr; tr.ur_edge = b->ur_edge; tr.counts_dev = b->counts_dev;
     }
@@ -603,6 +629,8 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         return fail(KGE_ERR_ARG, "kge_step_fused_sampling: this step's launches cannot carry the sampler (matrix-core models, strict "
                                  "4-launch step on local tables only)");
     EdgeFwdArgs ef{};
+    if (sh_dense && (phases & PH_PREP))
+        KGE_TRY(launch_gather3_sharded(em, d_e, b->h_gid, b->t_gid, b->neg_ids, B, C * b->N, Xd, iota, s));
     if (phases & PH_PREP) {
     // 1. gather + positive score + pos-side vectors (+ positive-loss part, + P rows for TransE)
     ef.src = src; ef.B = B; ef.d_e = d_e; ef.d_r = d_r; ef.neg_head = b->neg_head; ef.model = hp->model;
@@ -618,16 +646,16 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     ef.Bn = (dense_neg || dense_bwd) ? Bn : nullptr;  // the pairwise kernels read a dense copy
     ef.Hc = Hc; ef.Tc = Tc; ef.Rc = Rc;
     ef.asq = (l2g && !fold_loss) ? asq : nullptr; ef.bsq = (l2g && !fold_loss) ? bsq : nullptr;
-    ef.do_pos_loss = pairwise ? 0 : 1; ef.lp = lp; ef.w = b->edge_w;
+    ef.do_pos_loss = pairwise ? 0 : 1; ef.lp = lp; ef.w = b->edge_w; ef.w_mean = b->edge_w_mean;
     ef.dpos = dP; ef.row_pos = want4 ? row_pos : nullptr; ef.acc = acc;
     ef.P = transe_fast ? Pg : nullptr;
     if (transr) {
         // hp = h P, tp = t P in one pass over every edge's projection matrix; then p, sign(u), q; then the
         // batched projection of the chunk's negatives with the L1 epilogue (scores + sign bytes)
         RescalMatvecArgs m{};
-        m.B = B; m.D = d_e; m.Dc = d_r; m.rel = tb->proj; m.ridx = b->rel_ids;
-        m.z1 = tb->ent; m.z1idx = b->h_gid; m.c1 = tr.HP;
-        m.z2 = tb->ent; m.z2idx = b->t_gid; m.c2 = tr.TP;
+        m.B = B; m.D = d_e; m.Dc = d_r; m.rel = tbx->proj; m.ridx = b->rel_ids;
+        m.z1 = tbx->ent; m.z1idx = bx->h_gid; m.c1 = tr.HP;
+        m.z2 = tbx->ent; m.z2idx = bx->t_gid; m.c2 = tr.TP;
         KGE_TRY(launch_rescal_matvec(m, s));
         KGE_TRY(launch_transr_pos(tr, s));
         KGE_TRY(launch_transr_fwd(tr, s));
@@ -635,22 +663,22 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         // V = M t (always: p = h.V), A = M x with x = h in tail mode (then a second product of the same pass)
         if (!rescal_rel) {               // d_e not a multiple of 4: one pass over M per EDGE
             RescalMatvecArgs m{};
-            m.B = B; m.D = d_e; m.rel = tb->rel; m.ridx = b->rel_ids;
-            m.y1 = tb->ent; m.y1idx = b->t_gid; m.r1 = b->neg_head ? A : RV;
-            if (!b->neg_head) { m.y2 = tb->ent; m.y2idx = b->h_gid; m.r2 = A; }
-            m.pd = tb->ent; m.pdidx = b->h_gid; m.p = P;
+            m.B = B; m.D = d_e; m.rel = tbx->rel; m.ridx = b->rel_ids;
+            m.y1 = tbx->ent; m.y1idx = bx->t_gid; m.r1 = b->neg_head ? A : RV;
+            if (!b->neg_head) { m.y2 = tbx->ent; m.y2idx = bx->h_gid; m.r2 = A; }
+            m.pd = tbx->ent; m.pdidx = bx->h_gid; m.p = P;
             KGE_TRY(launch_rescal_matvec(m, s));
         } else {
         // (one pass over M per UNIQUE relation of the batch; the row blocks' parts of p are added by a one-thread-per-edge launch)
         RescalRelFwdArgs m{};
-        m.B = B; m.D = d_e; m.UR = b->UR; m.rel = tb->rel; m.ent = tb->ent; m.hidx = b->h_gid; m.tidx = b->t_gid;
+        m.B = B; m.D = d_e; m.UR = b->UR; m.rel = tbx->rel; m.ent = tbx->ent; m.hidx = bx->h_gid; m.tidx = bx->t_gid;
         m.ur_id = b->ur_id; m.ur_ptr = b->ur_ptr; m.ur_edge = b->ur_edge; m.counts_dev = b->counts_dev;
         m.V = b->neg_head ? A : RV; m.W = b->neg_head ? nullptr : A; m.ppart = Rpp; m.P = P;
         KGE_TRY(launch_rescal_rel_fwd(m, s));
         }
         if (dense_neg) {                 // pairwise fallback kernels read a dense copy of the negative rows
             EdgeFwdArgs nb{};
-            nb.B = 0; nb.d_e = d_e; nb.d_r = d_e; nb.model = KGE_DISTMULT; nb.nbase = tb->ent; nb.nidx = nids;
+            nb.B = 0; nb.d_e = d_e; nb.d_r = d_e; nb.model = KGE_DISTMULT; nb.nbase = tbx->ent; nb.nidx = sh_dense ? bx->neg_ids : nids;
             nb.n_neg = CN; nb.Bn = Bn;
             KGE_TRY(launch_edge_fwd(nb, s));
         }
@@ -688,7 +716,7 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
                     LossArgs la{};
                     la.B = B; la.N = N; la.genre = hp->loss_genre; la.adv = hp->adv; la.pairwise = 0;
                     la.adv_temp = hp->adv_temp; la.margin = hp->margin;
-                    la.pos = P; la.neg = S; la.w = b->edge_w; la.dpos = dP; la.dneg = S;
+                    la.pos = P; la.neg = S; la.w = b->edge_w; la.w_mean = b->edge_w_mean; la.dpos = dP; la.dneg = S;
                     la.row_pos = nullptr; la.row_neg = want4 ? row_neg : nullptr;      // (row_pos: written by the edge half)
                     la.acc = acc;
                     la.l2_scale = is_l2 ? 1 : 0; la.gamma = hp->gamma; la.clampv = clamp_of(hp->model);
@@ -718,7 +746,7 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         LossArgs la{};
         la.B = B; la.N = N; la.genre = hp->loss_genre; la.adv = hp->adv; la.pairwise = hp->pairwise;
         la.adv_temp = hp->adv_temp; la.margin = hp->margin;
-        la.pos = P; la.neg = S; la.w = b->edge_w; la.dpos = dP; la.dneg = S;
+        la.pos = P; la.neg = S; la.w = b->edge_w; la.w_mean = b->edge_w_mean; la.dpos = dP; la.dneg = S;
         la.row_pos = want4 ? row_pos : nullptr; la.row_neg = want4 ? row_neg : nullptr;
         la.acc = acc;
         la.l2_scale = is_l2 ? 1 : 0; la.gamma = hp->gamma; la.clampv = clamp_of(hp->model);
@@ -804,7 +832,7 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     if (transr) {
         // entity gradients through the projections: GH = P (-dp s) (+ P dq, tail mode), GT = P (+dp s) (+ P dq, head mode)
         RescalMatvecArgs m{};
-        m.B = B; m.D = d_e; m.Dc = d_r; m.rel = tb->proj; m.ridx = b->rel_ids;
+        m.B = B; m.D = d_e; m.Dc = d_r; m.rel = tbx->proj; m.ridx = b->rel_ids;
         m.y1 = tr.SG; m.r1 = TR1; m.y2 = tr.DQ; m.r2 = TR2;
         KGE_TRY(launch_rescal_matvec(m, s));
         KGE_TRY(launch_rescal_axpy(dP, TR1, b->neg_head ? nullptr : TR2, B, d_e, GH, s, -1.f));
@@ -817,8 +845,8 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         // gradient stays factored.  (d_e not a multiple of 4: a pass over M per edge for the two products, then the update's own)
         if (!rescal_rel) {
             RescalMatvecArgs m{};
-            m.B = B; m.D = d_e; m.rel = tb->rel; m.ridx = b->rel_ids;
-            m.z1 = tb->ent; m.z1idx = b->h_gid; m.c1 = RC1;
+            m.B = B; m.D = d_e; m.rel = tbx->rel; m.ridx = b->rel_ids;
+            m.z1 = tbx->ent; m.z1idx = bx->h_gid; m.c1 = RC1;
             m.z2 = GA; m.c2 = RC2;
             KGE_TRY(launch_rescal_matvec(m, s));
             KGE_TRY(launch_rescal_axpy(dP, Vr, b->neg_head ? nullptr : RC2, B, d_e, GH, s));
@@ -826,11 +854,11 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         }
         if (out && out->g_rel) {        // test / debugging output: materialise dp h t^T + GA x^T + regulariser
             RescalOuterArgs o{};
-            o.B = B; o.D = d_e; o.c = dP; o.u = tb->ent; o.uidx = b->h_gid; o.v = tb->ent; o.vidx = b->t_gid;
+            o.B = B; o.D = d_e; o.c = dP; o.u = tbx->ent; o.uidx = bx->h_gid; o.v = tbx->ent; o.vidx = bx->t_gid;
             o.G = out->g_rel;
             KGE_TRY(launch_rescal_outer(o, s));
-            o.c = nullptr; o.u = GA; o.uidx = nullptr; o.vidx = b->neg_head ? b->t_gid : b->h_gid; o.accumulate = 1;
-            if (reg) { o.rel = tb->rel; o.ridx = b->rel_ids; o.reg_coef = hp->reg_coef; o.reg_norm = hp->reg_norm; }
+            o.c = nullptr; o.u = GA; o.uidx = nullptr; o.vidx = b->neg_head ? bx->t_gid : bx->h_gid; o.accumulate = 1;
+            if (reg) { o.rel = tbx->rel; o.ridx = b->rel_ids; o.reg_coef = hp->reg_coef; o.reg_norm = hp->reg_norm; }
             KGE_TRY(launch_rescal_outer(o, s));
         }
         // relation matrices first: the entity update below changes the h / t rows this kernel reads
@@ -838,7 +866,7 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         ru.B = B; ru.D = d_e; ru.UE = b->UE; ru.UR = b->UR; ru.neg_head = b->neg_head; ru.reg_norm = hp->reg_norm;
         ru.rel_ids = b->rel_ids; ru.gs = Rgs; ru.inv_std = Rstd; ru.reg_part = (want4 || (reg && acc)) ? Rreg : nullptr;
         ru.lr = hp->lr; ru.eps = hp->eps; ru.reg_coef = reg ? hp->reg_coef : 0.f;
-        ru.rel = tb->rel; ru.rel_state = tb->rel_state; ru.ent = tb->ent; ru.hidx = b->h_gid; ru.tidx = b->t_gid;
+        ru.rel = tbx->rel; ru.rel_state = tbx->rel_state; ru.ent = tbx->ent; ru.hidx = bx->h_gid; ru.tidx = bx->t_gid;
         ru.dpos = dP; ru.GA = GA; ru.ur_id = b->ur_id; ru.ur_ptr = b->ur_ptr; ru.ur_edge = b->ur_edge;
         ru.counts_dev = b->counts_dev; ru.reg_rel = want4 ? reg_rel : nullptr; ru.acc = acc;
         if (rescal_rel) { ru.c1p = RC1; ru.c2p = RC2; }
@@ -885,6 +913,7 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     ua.lr = hp->lr; ua.eps = hp->eps; ua.reg_coef = reg ? hp->reg_coef : 0.f;
     ua.ent = tb->ent; ua.ent_state = tb->ent_state; ua.rel = tb->rel; ua.rel_state = tb->rel_state;
     ua.em = em; ua.rm = rm;
+    if (sh && sh->rel_local) { ua.rel = sh->rel_local; ua.rel_state = sh->rel_state_local; }    // (rm.n == 0: rank-local relation table)
     ua.ue_id = b->ue_id; ua.ue_pos_ptr = b->ue_pos_ptr; ua.ue_pos_adj = b->ue_pos_adj;
     ua.ue_neg_ptr = b->ue_neg_ptr; ua.ue_neg_slot = b->ue_neg_slot;
     ua.ur_id = b->ur_id; ua.ur_ptr = b->ur_ptr; ua.ur_edge = b->ur_edge;
@@ -1194,10 +1223,15 @@ int kge_rank_eval_ex(int model, int neg_head, const float *ent, int64_t n_ent, c
 int kge_step_sharded(const kge_hparams *hp, const kge_shards *sh, const kge_batch *b,
                      const kge_step_out *out, void *ws, size_t ws_bytes, void *stream) {
     if (!sh) return fail(KGE_ERR_ARG, "kge_step_sharded: null shard map");
-    if (hp && (hp->d_e % 4 || hp->d_r % 4 || hp->d_e > 1024 || hp->d_r > 1024))
+    // (RESCAL's relation "row" is a d_e x d_e matrix streamed by its own kernels: only the entity width is bounded)
+    if (hp && (hp->d_e % 4 || hp->d_e > 1024 || (hp->model != KGE_RESCAL && (hp->d_r % 4 || hp->d_r > 1024))))
         return fail(KGE_ERR_ARG, "kge_step_sharded: row widths must be multiples of 4 and <= 1024 floats");
     kge_tables tb{};
     tb.n_ent = sh->n_ent; tb.n_rel = sh->n_rel;
+    if (sh->rel_local) {              // ABI 8: relation-side tables local to this rank (relation ids resolve to them directly)
+        tb.rel = sh->rel_local; tb.rel_state = sh->rel_state_local;
+        tb.proj = sh->proj_local; tb.proj_state = sh->proj_state_local;
+    }
     return step_impl(hp, &tb, b, out, nullptr, ws, ws_bytes, stream, sh);
 }
 

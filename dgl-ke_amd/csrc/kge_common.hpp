@@ -265,10 +265,12 @@ __device__ __forceinline__ void criterion(int genre, float s, float label, float
 // Edge importance and the POSITIVE loss part: the reference multiplies `pos_loss [B]` by `edge_weight.view(-1, 1) [B, 1]`
 // (loss.py:75, 82) - a [B, B] broadcast whose mean is mean_j crit(p_j) * mean_i w_i: every positive edge is weighted by the MEAN
 // importance of the batch, not by its own (the negative part, [B, N] * [B, 1], is weighted per edge).  Kept as it is (found in
-// round 4 by the per-golden row tolerance: goldens/transe_l2_impts).  Every wavefront that needs it sums the B weights itself
-// (lane-strided, then the fixed-order wave reduction: deterministic).
-__device__ __forceinline__ float mean_edge_weight(const float *w, int B, int lane) {
+// round 4 by the per-golden row tolerance: goldens/transe_l2_impts).  `pre` > 0: the mean computed ONCE per batch by the batch's
+// builder (kge_batch.edge_w_mean, ABI 8); otherwise (modular ops, older callers) every wavefront that needs it sums the B weights
+// itself (lane-strided, then the fixed-order wave reduction: deterministic).
+__device__ __forceinline__ float mean_edge_weight(const float *w, int B, int lane, float pre = 0.f) {
     if (!w) return 1.f;
+    if (pre > 0.f) return pre;
     float s = 0.f;
     for (int j = lane; j < B; j += KGE_WAVE) s += w[j];
     return wave_sum(s) / (float)B;
@@ -310,7 +312,7 @@ struct EdgeFwdArgs {
     float *bsq;                      // [n_neg] or null
     float *Bn;                       // [n_neg,d_e] dense copy of the negative rows or null
     // positive-loss part (pointwise losses): dpos_i = dL/dp_i needs only p_i
-    int do_pos_loss; LossParams lp; const float *w;
+    int do_pos_loss; LossParams lp; const float *w; float w_mean;   // w_mean: kge_batch.edge_w_mean (0: summed by the kernel)
     float *dpos;                     // [B] or null
     float *row_pos;                  // [B] per-row positive loss terms or null
     float *acc;                      // running sums or null
@@ -403,6 +405,7 @@ struct LossArgs {
     int B, N, genre, adv, pairwise;
     float adv_temp, margin;
     const float *pos, *neg, *w;
+    float w_mean;                    // kge_batch.edge_w_mean (0: the rows' wavefronts sum the weights themselves)
     float *dpos, *dneg;              // dneg may alias neg (in place)
     float *row_pos, *row_neg;        // [B] per-row loss terms (already divided by B), or null
     float *acc;                      // [4][KGE_ACC_SLOTS] running loss sums (slot = row & mask) or null
@@ -472,6 +475,8 @@ struct FinalizeArgs {
 int kge_fail(int code, const char *msg);      // records the message kge_last_error() returns (kge_api.hip); returns code
 int launch_gather_rows(const float *table, int dim, const int64_t *idx, int64_t n, float *out,
                        hipStream_t s);
+int launch_gather3_sharded(const kge::ShardMap &m, int dim, const int64_t *h, const int64_t *t, const int64_t *neg, int B, int n_neg,
+                           float *out, int64_t *iota, hipStream_t s);     // [h | t | neg] rows through the shard map + identity ids
 int launch_gather_rows_sharded(float *const *shard_rows, int n_shards, int64_t per, int dim,
                                const int64_t *idx, int64_t n, float *out, hipStream_t s);
 int launch_edge_fwd(const EdgeFwdArgs &a, hipStream_t s);

@@ -173,7 +173,7 @@ __device__ __forceinline__ void edge_fwd_body(const EdgeFwdArgs &a_in, int bid) 
             if (lane == 0 && a.pos_score) a.pos_score[i] = p;
             if (a.do_pos_loss) {
                 // pointwise losses: d loss / d p_i depends on p_i only (loss.py:82-94)
-                const float w = mean_edge_weight(a.w, a.B, lane);      // (the batch's MEAN importance: see kge_common.hpp)
+                const float w = mean_edge_weight(a.w, a.B, lane, a.w_mean);      // (the batch's MEAN importance: see kge_common.hpp)
                 const float invB = 1.f / (float)a.B;
                 float pl, dpl;
                 criterion(a.lp.genre, p, 1.f, a.lp.margin, pl, dpl);

@@ -59,7 +59,7 @@ __device__ __forceinline__ void loss_row_regs(const LossArgs &a, int64_t i, floa
     }
     float plw = 0.f;
     if (!a.skip_pos) {
-        const float wm = mean_edge_weight(a.w, a.B, lane);     // positive part: the batch's MEAN importance (kge_common.hpp)
+        const float wm = mean_edge_weight(a.w, a.B, lane, a.w_mean);     // positive part: the batch's MEAN importance (kge_common.hpp)
         if (lane == 0) {
             float pl, dpl;
             criterion(a.genre, p, 1.f, a.margin, pl, dpl);

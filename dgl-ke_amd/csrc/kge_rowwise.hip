@@ -77,6 +77,31 @@ int launch_gather_rows_sharded(float *const *shard_rows, int n_shards, int64_t p
     return check_launch();
 }
 
+// TransR / RESCAL on sharded entity tables (round 6): the batch's head, tail and negative rows through the shard map into ONE dense
+// block [B | B | n_neg] x dim + the identity index array the kernels of the two families address it with (kge_api.hip sh_dense)
+__global__ __launch_bounds__(KGE_BLOCK) void gather3_sharded_kernel(ShardMap m, int dim, const int64_t *__restrict__ h,
+                                                                    const int64_t *__restrict__ t, const int64_t *__restrict__ neg,
+                                                                    int B, int n_neg, float *__restrict__ out,
+                                                                    int64_t *__restrict__ iota) {
+    const int64_t k = WAVE_ID();
+    if (k >= 2 * (int64_t)B + n_neg) return;
+    const int lane = LANE();
+    const int64_t id = k < B ? h[k] : (k < 2 * (int64_t)B ? t[k - B] : neg[k - 2 * (int64_t)B]);
+    const float *src = shard_row(m, nullptr, id, dim);
+    float *dst = out + k * (int64_t)dim;
+    for (int it = lane; it < dim / 4; it += 64) st<4>(dst + it * 4, ld<4>(src + it * 4));
+    if (lane == 0) iota[k] = k;
+}
+
+int launch_gather3_sharded(const ShardMap &m, int dim, const int64_t *h, const int64_t *t, const int64_t *neg, int B, int n_neg,
+                           float *out, int64_t *iota, hipStream_t s) {
+    if (dim % 4 || m.n < 1) return KGE_ERR_ARG;
+    const int64_t n = 2 * (int64_t)B + n_neg;
+    if (n == 0) return KGE_OK;
+    hipLaunchKernelGGL(gather3_sharded_kernel, dim3(blocks_for_waves(n)), dim3(KGE_BLOCK), 0, s, m, dim, h, t, neg, B, n_neg, out, iota);
+    return check_launch();
+}
+
 // ------------------------------------------------------------------------------------------
 // edge forward: positive score p_i, pos-side vector a_i (and |a_i|^2), |neg_j|^2
 // ------------------------------------------------------------------------------------------
@@ -476,7 +501,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void loss_kernel(LossArgs a) {
     }
     float plw = 0.f;
     if (!a.skip_pos) {
-        const float wm = mean_edge_weight(a.w, a.B, lane);     // positive part: the batch's MEAN importance (kge_common.hpp)
+        const float wm = mean_edge_weight(a.w, a.B, lane, a.w_mean);     // positive part: the batch's MEAN importance (kge_common.hpp)
         if (lane == 0) {
             float pl, dpl;
             criterion(a.genre, p, 1.f, a.margin, pl, dpl);

@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KGE_LIB") or os.path.join(_HERE, "libkge_hip.so")   # KGE_LIB: A/B builds
 
-KGE_ABI_VERSION = 7
+KGE_ABI_VERSION = 8
 MODEL_IDS = {"TransE_l1": 0, "TransE_l2": 1, "TransE": 1, "DistMult": 2, "ComplEx": 3, "RotatE": 4, "SimplE": 5, "RESCAL": 6, "TransR": 7}
 LOSS_IDS = {"Logsigmoid": 0, "Logistic": 1, "Hinge": 2, "BCE": 3}
 FLAG_FORCE_PAIRWISE = 1
@@ -48,7 +48,8 @@ class KgeBatch(C.Structure):
                 ("h_gid", c_p), ("t_gid", c_p), ("rel_ids", c_p), ("neg_ids", c_p), ("edge_w", c_p),
                 ("ue_id", c_p), ("ue_pos_ptr", c_p), ("ue_pos_adj", c_p), ("ue_neg_ptr", c_p),
                 ("ue_neg_slot", c_p), ("ur_id", c_p), ("ur_ptr", c_p), ("ur_edge", c_p),
-                ("ue_rec", c_p), ("ur_rec", c_p), ("counts_dev", c_p)]
+                ("ue_rec", c_p), ("ur_rec", c_p), ("counts_dev", c_p),
+                ("edge_w_mean", c_f), ("reserved_", c_i32)]        # ABI 8
 
 
 class KgeHParams(C.Structure):
@@ -90,7 +91,8 @@ class KgeMergeJob(C.Structure):
 class KgeShards(C.Structure):
     _fields_ = [("n_shards", c_i32), ("reserved", c_i32), ("ent_rows_per_shard", c_i64),
                 ("rel_rows_per_shard", c_i64), ("ent_rows", c_p), ("ent_state", c_p),
-                ("rel_rows", c_p), ("rel_state", c_p), ("n_ent", c_i64), ("n_rel", c_i64)]
+                ("rel_rows", c_p), ("rel_state", c_p), ("n_ent", c_i64), ("n_rel", c_i64),
+                ("rel_local", c_p), ("rel_state_local", c_p), ("proj_local", c_p), ("proj_state_local", c_p)]   # ABI 8
 
 
 IPC_HANDLE_BYTES = 64

@@ -46,6 +46,17 @@ class StepEngine(object):
         hp.reg_coef = float(regularization_coef)
         hp.eps = 1e-10
         self.hp = hp
+        import os
+        if (shards is not None and shards.n_shards == 1 and not shards.emulate and tables is None and
+                os.environ.get("KGE_P2P_LOCAL_SHORTCUT", "1") != "0"):
+            # ONE shard (world 1): every row is a row of this process's own arena - the plain single-table step on it (round 6:
+            # no shard-map division per row, no dense copy of the negative rows; the emulated-shard tests keep the map)
+            if (shards.d_e, shards.d_r) != (self.d_e, self.d_r):
+                raise _lib.KgeError("sharded tables have row widths (%d, %d), model needs (%d, %d)"
+                                    % (shards.d_e, shards.d_r, self.d_e, self.d_r))
+            tables = (shards.ent(0), shards.ent_state(0), shards.rel(0), shards.rel_state(0))
+            self.shards_local = shards     # (keeps the arena alive)
+            shards = None
         self.shards = shards           # p2p.ShardedTables: the tables live in the peers' HBM
         if shards is not None:
             if (shards.d_e, shards.d_r) != (self.d_e, self.d_r):
@@ -54,10 +65,14 @@ class StepEngine(object):
             self.ent, self.ent_state = shards.ent(0), shards.ent_state(0)
             self.rel, self.rel_state = shards.rel(0), shards.rel_state(0)
         self.proj = self.proj_state = None      # TransR: projection_emb of the score function (score_fun.py:114-118)
-        if model_name == 'TransR' and (shards is not None):
-            raise _lib.KgeError("TransR is not available on sharded tables")
         if shards is not None:
-            pass
+            if model_name in ('TransR', 'RESCAL') and not getattr(shards, 'rel_local', False):
+                raise _lib.KgeError("%s on sharded tables needs ShardedTables(rel_local=True%s): relation-side tables local to the rank"
+                                    % (model_name, ", proj_dim=d_e*d_r" if model_name == 'TransR' else ""))
+            if model_name == 'TransR':
+                if shards.proj_tab is None or shards.proj_tab.shape[1] != self.d_e * self.d_r:
+                    raise _lib.KgeError("TransR on sharded tables needs ShardedTables(proj_dim=%d)" % (self.d_e * self.d_r))
+                self.proj, self.proj_state = shards.proj_tab, shards.proj_state_tab
         elif tables is None:
             if model_name == 'TransR':
                 self.proj = torch.empty(n_relations, self.d_e * self.d_r, dtype=torch.float32, device=self.device)

@@ -13,6 +13,14 @@ update stays owner-computes and deterministic, across ranks it is Hogwild like t
 
 `ShardedTables(..., emulate=k)` builds k shards inside ONE process (no IPC) so that the shard
 addressing of the kernels can be parity-tested on a single GPU.
+
+`rel_local=True` (round 6, ABI 8 `kge_shards.rel_local`): only the ENTITY table is spread over the GPUs; the
+relation-side tables - relation rows (RESCAL: d_e x d_e matrices) and, with `proj_dim`, TransR's projection table
+(score_fun.py:114-118) - are whole tables LOCAL to every rank.  That is the reference's `--rel_part` layout
+(general_models.py:590-637; its multi-GPU TransR recipe passes it, examples/freebase/multi_gpu.sh:80-89): the
+trainer that holds a relation's edges holds and updates its rows; `collect_relations()` brings the owners' rows
+together when the tables are read.  TransR and RESCAL train on sharded tables this way (their kernels read the
+batch's entity rows from dense copies gathered through the shard map, kge_api.hip `sh_dense`).
 """
 import ctypes as C
 
@@ -27,7 +35,7 @@ def _align(x, a=256):
 
 class ShardedTables(object):
     def __init__(self, n_entities, n_relations, d_e, d_r, device, world=1, rank=0, group=None,
-                 emulate=0):
+                 emulate=0, rel_local=False, proj_dim=0):
         self.dev = torch.device(device)
         if self.dev.type != 'cuda':
             raise _lib.KgeError("ShardedTables needs a CUDA (HIP) device; there is no CPU path")
@@ -37,11 +45,16 @@ class ShardedTables(object):
         self.rank = 0 if emulate else int(rank)
         self.emulate = bool(emulate)
         self.group = group
+        self.rel_local = bool(rel_local)
+        self.proj_dim = int(proj_dim)
+        if self.proj_dim and not self.rel_local:
+            raise _lib.KgeError("a projection table needs rel_local=True (TransR on sharded tables)")
         self.ent_per = (self.n_entities + self.n_shards - 1) // self.n_shards
-        self.rel_per = (self.n_relations + self.n_shards - 1) // self.n_shards
+        # (rel_local: no relation rows in the arenas - one padding row keeps the layout arithmetic)
+        self.rel_per = 1 if self.rel_local else (self.n_relations + self.n_shards - 1) // self.n_shards
         # arena of one shard: [entity rows | entity state | relation rows | relation state]
         self._off = [0]
-        for nbytes in (self.ent_per * self.d_e * 4, self.ent_per * 4, self.rel_per * self.d_r * 4,
+        for nbytes in (self.ent_per * self.d_e * 4, self.ent_per * 4, (4 if self.rel_local else self.rel_per * self.d_r) * 4,
                        self.rel_per * 4):
             self._off.append(self._off[-1] + _align(nbytes))
         self.arena_bytes = self._off[-1]
@@ -62,6 +75,15 @@ class ShardedTables(object):
         sh.ent_rows, sh.ent_state = p0, p0 + 8 * self.n_shards
         sh.rel_rows, sh.rel_state = p0 + 16 * self.n_shards, p0 + 24 * self.n_shards
         sh.n_ent, sh.n_rel = self.n_entities, self.n_relations
+        self.rel_tab = self.rel_state_tab = self.proj_tab = self.proj_state_tab = None
+        if self.rel_local:
+            self.rel_tab = torch.zeros(self.n_relations, self.d_r, dtype=torch.float32, device=self.dev)
+            self.rel_state_tab = torch.zeros(self.n_relations, dtype=torch.float32, device=self.dev)
+            sh.rel_local, sh.rel_state_local = _lib.ptr(self.rel_tab), _lib.ptr(self.rel_state_tab)
+            if self.proj_dim:
+                self.proj_tab = torch.zeros(self.n_relations, self.proj_dim, dtype=torch.float32, device=self.dev)
+                self.proj_state_tab = torch.zeros(self.n_relations, dtype=torch.float32, device=self.dev)
+                sh.proj_local, sh.proj_state_local = _lib.ptr(self.proj_tab), _lib.ptr(self.proj_state_tab)
         self.c = sh
 
     # ---- IPC ---------------------------------------------------------------------------------
@@ -115,9 +137,13 @@ class ShardedTables(object):
         return self._view(shard, 1, self.ent_per, 1)
 
     def rel(self, shard=0):
+        if self.rel_local:
+            return self.rel_tab
         return self._view(shard, 2, self.rel_per, self.d_r)
 
     def rel_state(self, shard=0):
+        if self.rel_local:
+            return self.rel_state_tab
         return self._view(shard, 3, self.rel_per, 1)
 
     def init_uniform(self, emb_init, seed):
@@ -127,18 +153,33 @@ class ShardedTables(object):
         for s in range(len(self.arenas)):
             g.manual_seed(int(seed) * 1000003 + self.rank * 101 + s)
             self.ent(s).uniform_(-emb_init, emb_init, generator=g)
-            self.rel(s).uniform_(-emb_init, emb_init, generator=g)
+            if not self.rel_local:
+                self.rel(s).uniform_(-emb_init, emb_init, generator=g)
+                self.rel_state(s).zero_()
             self.ent_state(s).zero_()
-            self.rel_state(s).zero_()
+        if self.rel_local:
+            # identical replicas on every rank (rank-independent seed): a rank only ever changes the rows of ITS relations
+            g.manual_seed(int(seed) * 1000003 + 77)
+            self.rel_tab.uniform_(-emb_init, emb_init, generator=g)
+            self.rel_state_tab.zero_()
+            if self.proj_tab is not None:         # TransRScore.reset_parameters: projection_emb.init(1.0)
+                self.proj_tab.uniform_(-1.0, 1.0, generator=g)
+                self.proj_state_tab.zero_()
 
-    def load_full(self, ent, rel, ent_state=None, rel_state=None):
+    def load_full(self, ent, rel, ent_state=None, rel_state=None, proj=None, proj_state=None):
         """scatter full tables over the LOCAL shards (emulation: all of them; multi-process: the own
-        range) - test / checkpoint-load helper."""
+        range) - test / checkpoint-load helper.  rel_local: the relation-side tables are whole local tables."""
+        if self.rel_local:
+            for full, tab in ((rel, self.rel_tab), (rel_state, self.rel_state_tab), (proj, self.proj_tab),
+                              (proj_state, self.proj_state_tab)):
+                if full is not None and tab is not None:
+                    tab.copy_(torch.as_tensor(full).to(self.dev).view(tab.shape))
+            rel = rel_state = None
         for s in range(len(self.arenas)):
             k = s if self.emulate else self.rank
-            for full, view, per in ((ent, self.ent(s), self.ent_per), (rel, self.rel(s), self.rel_per),
+            for full, view, per in ((ent, self.ent(s), self.ent_per), (rel, None if self.rel_local else self.rel(s), self.rel_per),
                                     (ent_state, self.ent_state(s), self.ent_per),
-                                    (rel_state, self.rel_state(s), self.rel_per)):
+                                    (rel_state, None if self.rel_local else self.rel_state(s), self.rel_per)):
                 if full is None:
                     continue
                 full = torch.as_tensor(full)
@@ -151,6 +192,8 @@ class ShardedTables(object):
             raise _lib.KgeError("full() needs all shards in this process (emulate mode)")
         fn, n = {"ent": (self.ent, self.n_entities), "ent_state": (self.ent_state, self.n_entities),
                  "rel": (self.rel, self.n_relations), "rel_state": (self.rel_state, self.n_relations)}[which]
+        if self.rel_local and which in ("rel", "rel_state"):
+            return fn(0).clone()
         return torch.cat([fn(s) for s in range(self.n_shards)], 0)[:n].clone()
 
     def gather(self, which, idx):
@@ -158,11 +201,33 @@ class ShardedTables(object):
         k, dim, per = {"ent": (0, self.d_e, self.ent_per), "ent_state": (1, 1, self.ent_per),
                        "rel": (2, self.d_r, self.rel_per), "rel_state": (3, 1, self.rel_per)}[which]
         idx = idx.contiguous()
+        if self.rel_local and which in ("rel", "rel_state"):
+            return (self.rel_tab if which == "rel" else self.rel_state_tab)[idx]
         out = torch.empty(idx.shape[0], dim, dtype=torch.float32, device=self.dev)
         _lib.check(_lib.lib().kge_gather_rows_sharded(
             self.ptr_table.data_ptr() + 8 * self.n_shards * k, self.n_shards, per, dim, _lib.ptr(idx),
             idx.shape[0], _lib.ptr(out), _lib.stream_ptr()))
         return out if dim > 1 else out.view(-1)
+
+    def collect_relations(self, owner, group=None):
+        """rel_local: every rank's relation-side tables hold the current rows of ITS relations only (owner[r] = rank of relation r,
+        dist.relation_partition) - bring the owners' rows (relation rows + state, projection rows + state) into rank 0's tables.
+        Collective over the process group."""
+        import numpy as np
+        import torch.distributed as dist
+        if not self.rel_local:
+            return
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        own = torch.as_tensor(np.nonzero(np.asarray(owner) == rank)[0], dtype=torch.int64)
+        tabs = [t for t in (self.rel_tab, self.rel_state_tab, self.proj_tab, self.proj_state_tab) if t is not None]
+        mine = (own, [t[own.to(self.dev)].cpu() for t in tabs])
+        parts = [None] * world if rank == 0 else None
+        dist.gather_object(mine, parts, dst=0, group=group)
+        if rank == 0:
+            for ids, rows in parts[1:]:
+                if len(ids):
+                    for t, r in zip(tabs, rows):
+                        t[ids.to(self.dev)] = r.to(self.dev)
 
     def probe(self):
         """write a marker into the own shard, read every shard's marker through the map: proves

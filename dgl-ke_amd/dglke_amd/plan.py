@@ -127,6 +127,10 @@ class Batch(object):
                   "ue_neg_ptr", "ue_neg_slot", "ur_id", "ur_ptr", "ur_edge", "ue_rec", "ur_rec"):
             setattr(kb, k, base + offs[k])
         kb.edge_w = (base + offs["edge_w"]) if "edge_w" in offs else None
+        if "edge_w" in offs:
+            # the batch's MEAN importance, once per batch (ABI 8 kge_batch.edge_w_mean: the weight of every positive edge in the
+            # reference's loss, loss.py:75,82); accumulated in fp64, rounded to fp32 like the reference's mean over a float32 tensor
+            kb.edge_w_mean = float(np.float32(np.asarray(plan["edge_w"], np.float64).mean()))
         self.c = kb
 
     def view(self, name):

@@ -102,9 +102,10 @@ class ArgParser(argparse.ArgumentParser):
         a('--dist_mode', default='a2a', choices=['a2a', 'p2p'],
           help='multi-GPU training (--gpu g0 g1 ...): a2a = entity table range-sharded, relation table replicated, RCCL '
                'all-to-all pull / push with owner-side Adagrad (parameter-server semantics); p2p = both tables sharded and '
-               'mapped peer to peer (hipIpc), Hogwild across the trainers, no collective.  TransR and RESCAL (projection / '
-               'relation-matrix tables) train on ONE GPU (--num_proc K there: K lock-free trainers on the shared tables); the '
-               'multi-GPU modes cover TransE_l1/l2, DistMult, ComplEx, RotatE and SimplE and say so when asked for the other two')
+               'mapped peer to peer (hipIpc), Hogwild across the trainers, no collective.  TransR and RESCAL train in p2p mode: entity '
+               'table sharded, relation rows / matrices and the projection table local to the trainers, triples partitioned by '
+               'relation (the reference\'s --rel_part layout); a2a covers TransE_l1/l2, DistMult, ComplEx, RotatE and SimplE and '
+               'hands the other two to p2p')
         a('--seed', type=int, default=0, help='seed of the table initialisation and of the device sampler')
         a('--graph_steps', type=int, default=100, help='steps per captured hipGraph (0: eager launches)')
         a('--target_mrr', type=float, default=None,
@@ -449,14 +450,33 @@ class ShardedTrainer(object):
         self.fused, self.n_lanes, self.async_ok = True, 1, False
         # (edge importance / more than 4096 ids per batch: host-built batches, like the single-GPU trainer's host sampler path)
         self.device_sampler = 2 * B + (B // self.chunk) * N <= 4096 and not args.has_edge_importance
-        if args.model_name == 'RESCAL':
-            raise KgeError("RESCAL is not available on sharded tables")
-        if args.neg_deg_sample and args.model_name == 'TransR':
-            raise KgeError("--neg_deg_sample is not available for TransR on sharded tables")
+        if args.neg_deg_sample and args.model_name in ('TransR', 'RESCAL'):
+            raise KgeError("--neg_deg_sample is not available for %s on sharded tables" % args.model_name)
         d_e = args.hidden_dim * (2 if args.double_ent else 1)
         d_r = args.hidden_dim * (2 if args.double_rel else 1)
         self.emb_init = (args.gamma + 2.0) / args.hidden_dim
-        self.tabs = p2p.ShardedTables(dataset.n_entities, dataset.n_relations, d_e, d_r, self.dev, world, rank)
+        # TransR / RESCAL (round 6): the entity table is spread over the GPUs like every model's; the relation-side tables - relation
+        # rows / matrices and TransR's projection table - are whole tables LOCAL to every trainer and the triples are partitioned BY
+        # RELATION (whole relations, dist.relation_partition), so that a relation's rows are trained on exactly one GPU: the
+        # reference's --rel_part layout, which its own multi-GPU TransR recipe passes (examples/freebase/multi_gpu.sh:80-89,
+        # general_models.py:590-637).  The owners' rows are collected when the tables are read (sync_tables).
+        self.rel_side_local = args.model_name in ('TransR', 'RESCAL')
+        self.rel_owner, part = None, None
+        if self.rel_side_local:
+            from . import dist as kd
+            self.rel_owner, edge_rank = kd.relation_partition(dataset.train[1], world)
+            part = np.nonzero(edge_rank == rank)[0]
+            cnt = np.bincount(edge_rank, minlength=world)
+            if rank == 0:
+                print("%s on %d GPUs: entity table sharded peer to peer, relation-side tables local, triples partitioned by relation "
+                      "(whole relations; edges per trainer %s)" % (args.model_name, world, cnt.tolist()))
+            if cnt.min() < B:
+                raise KgeError("relation partition: trainer %d gets %d training triples, fewer than --batch_size %d"
+                               % (int(cnt.argmin()), int(cnt.min()), B))
+        self.tabs = p2p.ShardedTables(dataset.n_entities, dataset.n_relations, d_e,
+                                      d_r * d_e if args.model_name == 'RESCAL' else d_r, self.dev, world, rank,
+                                      rel_local=self.rel_side_local,
+                                      proj_dim=d_e * d_r if args.model_name == 'TransR' else 0)
         if not self.tabs.probe():
             raise KgeError("peer mappings do not reach the other GPUs' memory")
         self.tabs.init_uniform(self.emb_init, args.seed)
@@ -466,7 +486,8 @@ class ShardedTrainer(object):
                                  args.loss_genre, args.pairwise, args.margin,
                                  flags=_lib.FLAG_NEG_DEG_SAMPLE if args.neg_deg_sample else 0, shards=self.tabs)
         tr = dataset.train
-        part = np.array_split(np.random.RandomState(args.seed).permutation(len(tr[0])), world)[rank]
+        if part is None:
+            part = np.array_split(np.random.RandomState(args.seed).permutation(len(tr[0])), world)[rank]
         self.lane = _Lane(self, rank, self.engine, tuple(np.asarray(x)[part] for x in tr[:3]),
                           np.asarray(tr[3])[part] if args.has_edge_importance else None)
 
@@ -474,7 +495,11 @@ class ShardedTrainer(object):
         self.lane.enqueue(n)
 
     def sync_tables(self):
-        """collective point in front of rank 0's validation / test / save (the peer-mapped tables need nothing)."""
+        """collective point in front of rank 0's validation / test / save: the peer-mapped tables need nothing; relation-side tables
+        that are local to the trainers (TransR / RESCAL) are collected from the relations' owners into rank 0's."""
+        if self.rel_side_local:
+            th.cuda.synchronize()
+            self.tabs.collect_relations(self.rel_owner)
 
     def close(self):
         self.tabs.close()
@@ -483,7 +508,7 @@ class ShardedTrainer(object):
         """the whole entity / relation tables read through the shard map (rank-local copies)."""
         ds = self.dataset
         ent = self.tabs.gather("ent", th.arange(ds.n_entities, device=self.dev))
-        rel = self.tabs.gather("rel", th.arange(ds.n_relations, device=self.dev))
+        rel = self.tabs.rel_tab if self.tabs.rel_local else self.tabs.gather("rel", th.arange(ds.n_relations, device=self.dev))
         return ent, rel
 
     def evaluate(self, which, mode):
@@ -502,7 +527,10 @@ class ShardedTrainer(object):
             known = tuple(np.concatenate([np.asarray(p[k]) for p in parts]) for k in range(3))
         ent, rel = self.full_tables()
         Eb = int(max(1, min(max(args.batch_size_eval, 1024), (1 << 31) // (4 * ds.n_entities), len(h))))
-        metrics = kev.evaluate(args.model_name, ent, rel, args.gamma, self.emb_init, (h, r, t), known, batch=Eb,
+        proj = getattr(getattr(self, 'tabs', None), 'proj_tab', None) if args.model_name == 'TransR' else None
+        if proj is not None:
+            Eb = min(Eb, 64)                  # TransR projects every candidate with every test triple's matrix
+        metrics = kev.evaluate(args.model_name, ent, rel, args.gamma, self.emb_init, (h, r, t), known, batch=Eb, proj=proj,
                                n_cand=args.neg_sample_size_eval, chunk=args.batch_size_eval, seed=args.seed + 29)
         for k, v in metrics.items():
             print('[{}]{} average {}: {}'.format(self.rank, mode, k, v))
@@ -730,6 +758,9 @@ def _mp_worker(rank, args, port):
                     print('Save model to {}'.format(args.save_path))
                     np.save(os.path.join(args.save_path, '%s_%s_entity.npy' % (args.dataset, args.model_name)), ent.cpu().numpy())
                     np.save(os.path.join(args.save_path, '%s_%s_relation.npy' % (args.dataset, args.model_name)), rel.cpu().numpy())
+                    if args.model_name == 'TransR':      # TransRScore.save (score_fun.py:190-191): <dataset>_<model>projection.npy
+                        np.save(os.path.join(args.save_path, '%s_%sprojection.npy' % (args.dataset, args.model_name)),
+                                trainer.tabs.proj_tab.cpu().numpy())
                     conf = dict(vars(args))
                     conf.update({'emp_file': dataset.emap_fname, 'rmap_file': dataset.rmap_fname})
                     with open(os.path.join(args.save_path, 'config.json'), 'w') as f:
@@ -767,8 +798,6 @@ def main(argv=None):
     if len(args.gpu) > 1:                        # multi-GPU: one process per GPU on peer-to-peer shared tables
         if min(args.gpu) < 0:
             raise KgeError("dglke_amd trains on the GPU only: pass --gpu <ids> (there is no CPU fallback)")
-        if args.model_name in ('RESCAL', 'TransR'):
-            raise KgeError("%s is not available on the multi-GPU sharded tables: train it on one GPU" % args.model_name)
         if args.log_interval <= 0:
             raise KgeError("--log_interval must be positive")
         if args.num_proc > len(args.gpu):            # reference: several trainer processes per GPU (train.py:94-100, 115-119)

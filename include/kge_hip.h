@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define KGE_ABI_VERSION 7
+#define KGE_ABI_VERSION 8
 
 /* score functions (models/general_models.py:248-268 model_name strings) */
 enum kge_model {
@@ -225,6 +225,11 @@ typedef struct kge_batch {
     /* kernels read the actual counts from this device array of FOUR int32 {UE, UR, corrupt-head */
     /* flag of the step, edges of the batch's most frequent relation}; NULL for host-built plans */
     const int32_t *counts_dev;
+    /* ABI 8: mean of edge_w[0..B) in fp32, computed ONCE per batch by whoever builds it (dglke_amd/plan.py).  The reference weights */
+    /* every positive edge by the batch's MEAN importance (loss.py:75,82: a [B] * [B,1] broadcast); <= 0 (or edge_w NULL): the     */
+    /* kernels sum the weights themselves, every row's wavefront for itself (what ABI <= 7 always did).                             */
+    float edge_w_mean;
+    int32_t reserved_;
 } kge_batch;
 
 typedef struct kge_hparams {
@@ -401,6 +406,15 @@ typedef struct kge_shards {
     float *const *ent_rows;  float *const *ent_state;
     float *const *rel_rows;  float *const *rel_state;
     int64_t n_ent, n_rel;    /* global row counts (ids in the batch are global) */
+    /* ABI 8 - TransR / RESCAL on sharded ENTITY tables (the reference trains TransR on 8 GPUs with --rel_part,                    */
+    /* examples/freebase/multi_gpu.sh:80-89: every trainer holds the rows of ITS relations on its own GPU,                         */
+    /* general_models.py:590-637).  rel_local != NULL: the relation-side tables are LOCAL to the calling rank - [n_rel, d_r] rows   */
+    /* (RESCAL: d_e x d_e matrices) + state, and for TransR the projection table [n_rel, d_e * d_r] + state                        */
+    /* (score_fun.py:114-118) - and rel_rows / rel_state are ignored.  The step gathers the batch's entity rows through the shard   */
+    /* map into dense copies, runs the TransR / RESCAL kernels on those, updates relation-side rows in place and entity rows        */
+    /* through the shard map.  Required for KGE_TRANSR / KGE_RESCAL, optional (relation table replicated per rank) otherwise.       */
+    float *rel_local, *rel_state_local;
+    float *proj_local, *proj_state_local;
 } kge_shards;
 int kge_step_sharded(const kge_hparams *hp, const kge_shards *sh, const kge_batch *b,
                      const kge_step_out *out, void *ws, size_t ws_bytes, void *stream);

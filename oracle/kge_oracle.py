@@ -552,15 +552,29 @@ def transr_forward_backward(cfg, ent, rel, proj, nid, h_local, t_local, rel_ids,
     # NOTE: BOTH closures subtract the relation (score_fun.py:203-204 head mode: tails - relations; :212-213
     # tail mode: heads - relations - not heads + relations); kept as the reference computes it
     q = xp - r                                                           # [B, Dr]
+    nd = getattr(cfg, "neg_deg", False)
+    N_sampled, neg_s = N, neg
+    if nd:
+        # --neg_deg_sample is model-agnostic in the reference (general_models.py:396-402, 417-423): the corrupted-side entities of the
+        # chunk's own positives are concatenated IN FRONT of the sampled negatives BEFORE head_neg_prepare / tail_neg_prepare, so
+        # TransR projects them like every other negative; the chunk x chunk diagonal is multiplied by 0 (:401, :429-432).  The
+        # in-batch rows are slices of pos_g.ndata['emb']: their gradient joins the positive trace, the regulariser does not see them.
+        y_own = (h if neg_head else t).reshape(C, chunk, De)
+        neg = np.concatenate([y_own, neg.reshape(C, N, De)], axis=1).reshape(C * (chunk + N), De)
+        N = chunk + N
+        mask = np.ones((C, chunk, N), dtype=dt)
+        mask[:, np.arange(chunk), np.arange(chunk)] = 0
     Y = np.einsum("cjd,cide->cije", neg.reshape(C, N, De), P.reshape(C, chunk, De, Dr))   # [C, chunk, N, Dr]
     D = Y - q.reshape(C, chunk, 1, Dr)                                   # head mode: heads - tails; tail mode: its negative
     n = gamma - np.abs(D).sum(-1)
+    if nd:
+        n = n * mask
     (pl, nl, loss), dpos, dneg = loss_fwd_bwd(p, n.reshape(B, N), w, cfg.loss_genre, cfg.adv, cfg.adv_temp,
                                               cfg.pairwise, cfg.margin)
     reg = 0.0
     use_reg = cfg.reg_coef > 0.0 and cfg.reg_norm > 0
     if use_reg:
-        reg = reg_value([pos_emb, neg], cfg.reg_coef, cfg.reg_norm) + reg_value([r], cfg.reg_coef, cfg.reg_norm)
+        reg = reg_value([pos_emb, neg_s], cfg.reg_coef, cfg.reg_norm) + reg_value([r], cfg.reg_coef, cfg.reg_norm)
     # positive score: p = gamma - |hp + r - tp|_1
     s = np.sign(u)
     ghp, gtp = -dpos[:, None] * s, dpos[:, None] * s
@@ -568,6 +582,8 @@ def transr_forward_backward(cfg, ent, rel, proj, nid, h_local, t_local, rel_ids,
     g_proj0 = h[:, :, None] * ghp[:, None, :] + t[:, :, None] * gtp[:, None, :]
     gh, gt = np.einsum("abc,ac->ab", P, ghp), np.einsum("abc,ac->ab", P, gtp)
     # negative scores: n = gamma - sum |Y - q|  (either sign convention): dY = -W sign(Y - q), dq = -sum_j dY
+    if nd:
+        dneg = (dneg.reshape(C, chunk, N) * mask).reshape(B, N)
     dY = -dneg.reshape(C, chunk, N, 1) * np.sign(D)
     dq = -dY.sum(2).reshape(B, Dr)
     g_neg = np.einsum("cije,cide->cjd", dY, P.reshape(C, chunk, De, Dr)).reshape(C * N, De)
@@ -578,13 +594,21 @@ def transr_forward_backward(cfg, ent, rel, proj, nid, h_local, t_local, rel_ids,
         gt = gt + gx
     else:
         gh = gh + gx
+    if nd:
+        g_all = g_neg.reshape(C, N, De)
+        g_inb = g_all[:, :chunk].reshape(B, De)          # gradient w.r.t. the in-batch negative rows -> positive trace
+        g_neg = g_all[:, chunk:].reshape(C * N_sampled, De)
+        if neg_head:
+            gh = gh + g_inb
+        else:
+            gt = gt + g_inb
     g_pos = np.zeros_like(pos_emb)
     np.add.at(g_pos, h_local, gh)
     np.add.at(g_pos, t_local, gt)
     g_neg = g_neg.astype(dt)
     if use_reg:
         g_pos += reg_grad(pos_emb, cfg.reg_coef, cfg.reg_norm)
-        g_neg = g_neg + reg_grad(neg, cfg.reg_coef, cfg.reg_norm)
+        g_neg = g_neg + reg_grad(neg_s, cfg.reg_coef, cfg.reg_norm)
         gr = gr + reg_grad(r, cfg.reg_coef, cfg.reg_norm)
     return dict(pos_score=p, neg_score=n, log=(pl, nl, loss, reg), loss_total=loss + reg,
                 g_pos_ent=g_pos.astype(dt), g_rel=gr.astype(dt), g_neg=g_neg.astype(dt),

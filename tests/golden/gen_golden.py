@@ -287,6 +287,15 @@ CASES = {
     "nd_transe_l1_mid": base("TransE_l1", n_ent=400, n_rel=30, hidden=64, gamma=16.0, B=96, N=32,
                              chunk=32, lr=0.01, reg_coef=1e-7, steps=2, neg_deg=True, seed=82,
                              save_tables_each_step=False),
+    # round 6: --neg_deg_sample with the relation-matrix models (the concat-and-mask of general_models.py:396-402, 417-432 sits in front
+    # of head_neg_prepare / tail_neg_prepare, so TransR projects the in-batch rows like every other negative)
+    "nd_transr_small": base("TransR", gamma=8.0, hidden=8, neg_deg=True, seed=83),
+    "nd_transr_ragged": base("TransR", gamma=8.0, hidden=6, B=30, N=7, chunk=10, neg_deg=True, seed=84),
+    "nd_transr_dups": base("TransR", gamma=8.0, hidden=8, n_ent=9, n_rel=2, steps=4, neg_deg=True, seed=85),
+    "nd_transr_mid": base("TransR", n_ent=200, n_rel=12, hidden=32, gamma=12.0, B=64, N=32, chunk=32, lr=0.05,
+                          reg_coef=1e-7, steps=2, neg_deg=True, seed=86),
+    "nd_rescal_small": base("RESCAL", gamma=6.0, hidden=8, neg_deg=True, seed=87),
+    "nd_rescal_ragged": base("RESCAL", gamma=6.0, hidden=6, B=30, N=7, chunk=10, neg_deg=True, seed=88),
     # --async_update: the reference's own async_update body applies the entity traces one step late (HeldQueue above); the
     # duplicate-heavy cases make the staleness visible in every row
     "async_transe_l2_small": base("TransE_l2", steps=4, seed=91, **{"async": True}),

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(h, name), "libkge_hip.so does not export " + name
     assert declared == set(_lib.EXPORTED_SYMBOLS), (declared ^ set(_lib.EXPORTED_SYMBOLS))
-    assert _lib.lib().kge_abi_version() == _lib.KGE_ABI_VERSION == 7
+    assert _lib.lib().kge_abi_version() == _lib.KGE_ABI_VERSION == 8
 
 
 def test_argument_errors_are_reported_without_a_gpu():
