@@ -431,6 +431,7 @@ size_t kge_step_workspace_bytes(const kge_hparams *hp, int B, int C, int chunk, 
     if (hp->model == KGE_TRANSR || hp->model == KGE_RESCAL) {      // sharded entity tables: dense [h | t | negative] rows + identity ids
         add((size_t)(2 * B + CN) * d_e); add((size_t)2 * (2 * B + CN));
     }
+    if (hp->model == KGE_TRANSR && nd) add((size_t)2 * CN);        // neg_deg_sample: the combined [own | sampled] id list
     return n;
 }
 
@@ -479,8 +480,10 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     const bool nd = (hp->flags & KGE_FLAG_NEG_DEG_SAMPLE) != 0;
     // (round 4: also in the gradient-emitting step - the in-batch rows' gradients join the row's positive-trace message g0 through
     //  edge_bwd, the sampled rows' the negative-trace message g1 through the update's slot remap, exactly as in the fused step)
-    if (nd && (hp->model == KGE_RESCAL || hp->model == KGE_TRANSR))
-        return fail(KGE_ERR_ARG, "neg_deg_sample is not available for RESCAL / TransR");
+    // (round 6: TransR and RESCAL too - the reference's concat-and-mask sits in front of head_neg_prepare / tail_neg_prepare,
+    //  general_models.py:396-402, 417-432: model-agnostic.  Not on sharded tables / in the gradient-emitting step.)
+    if (nd && (hp->model == KGE_RESCAL || hp->model == KGE_TRANSR) && (sh || emit))
+        return fail(KGE_ERR_ARG, "neg_deg_sample for RESCAL / TransR: single-table step only");
     const int B = b->B, C = b->C, chunk = b->chunk, N = nd ? b->chunk + b->N : b->N, CN = C * N;
     const int d_e = hp->d_e, d_r = hp->d_r, tj16 = (N + 15) / 16;
     const bool reg = hp->reg_coef > 0.f && hp->reg_norm > 0;
@@ -541,6 +544,8 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         tbd.proj = sh->proj_local; tbd.proj_state = sh->proj_state_local;
         bd.h_gid = iota; bd.t_gid = iota + B; bd.neg_ids = iota + 2 * B;
     }
+    // TransR with neg_deg_sample: its kernels address the negatives through ONE id list - the combined [own | sampled] ids per chunk
+    int64_t *ndids = (transr && nd) ? reinterpret_cast<int64_t *>(cv.f((size_t)2 * CN)) : nullptr;
     const kge_tables *tbx = sh_dense ? &tbd : tb;  // what the TransR / RESCAL kernels read
     const kge_batch *bx = sh_dense ? &bd : b;
     if (transr) {
@@ -589,6 +594,7 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         tr.rel = tbx->rel; tr.proj = tbx->proj; tr.proj_state = tbx->proj_state;
         tr.P = P; tr.S = S; tr.GN = GN; tr.GR = GR; tr.dpos = dP;
         tr.ur_id = b->ur_id; tr.ur_ptr = b->ur_ptr; tr.ur_edge = b->ur_edge; tr.counts_dev = b->counts_dev;
+        if (nd) { tr.neg_ids = ndids; tr.nd_chunk = chunk; }     // (N = chunk + sampled; the update adds the sampled rows' regulariser)
     }
     const float rot_div = rot_div_of(hp->emb_init);
     // --async_update pipeline: everything after PREP must read the rows as PREP gathered them (the previous step's
@@ -652,6 +658,7 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     if (transr) {
         // hp = h P, tp = t P in one pass over every edge's projection matrix; then p, sign(u), q; then the
         // batched projection of the chunk's negatives with the L1 epilogue (scores + sign bytes)
+        if (nd) KGE_TRY(launch_nd_ids(b->neg_head ? b->h_gid : b->t_gid, b->neg_ids, C, chunk, b->N, ndids, s));
         RescalMatvecArgs m{};
         m.B = B; m.D = d_e; m.Dc = d_r; m.rel = tbx->proj; m.ridx = b->rel_ids;
         m.z1 = tbx->ent; m.z1idx = bx->h_gid; m.c1 = tr.HP;
@@ -680,6 +687,7 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
             EdgeFwdArgs nb{};
             nb.B = 0; nb.d_e = d_e; nb.d_r = d_e; nb.model = KGE_DISTMULT; nb.nbase = tbx->ent; nb.nidx = sh_dense ? bx->neg_ids : nids;
             nb.n_neg = CN; nb.Bn = Bn;
+            if (nd) { nb.nd_own = b->neg_head ? b->h_gid : b->t_gid; nb.nd_chunk = chunk; nb.nd_Ns = b->N; }
             KGE_TRY(launch_edge_fwd(nb, s));
         }
     } else {
@@ -837,6 +845,8 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         KGE_TRY(launch_rescal_matvec(m, s));
         KGE_TRY(launch_rescal_axpy(dP, TR1, b->neg_head ? nullptr : TR2, B, d_e, GH, s, -1.f));
         KGE_TRY(launch_rescal_axpy(dP, TR1, b->neg_head ? TR2 : nullptr, B, d_e, GT, s, 1.f));
+        // neg_deg_sample: the in-batch negative rows are slices of the positive trace - their gradient joins GH (head mode) / GT
+        if (nd) KGE_TRY(launch_nd_fold(GN, b->neg_head ? GH : GT, B, chunk, N, d_e, s));
         // projection table first: the entity update below changes the h / t rows its rank-1 trace reads
         KGE_TRY(launch_transr_proj_update(tr, s));
     } else if (rescal) {
@@ -851,6 +861,7 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
             KGE_TRY(launch_rescal_matvec(m, s));
             KGE_TRY(launch_rescal_axpy(dP, Vr, b->neg_head ? nullptr : RC2, B, d_e, GH, s));
             KGE_TRY(launch_rescal_axpy(dP, RC1, b->neg_head ? RC2 : nullptr, B, d_e, GT, s));
+            if (nd) KGE_TRY(launch_nd_fold(GN, b->neg_head ? GH : GT, B, chunk, N, d_e, s));
         }
         if (out && out->g_rel) {        // test / debugging output: materialise dp h t^T + GA x^T + regulariser
             RescalOuterArgs o{};
@@ -875,6 +886,7 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
             RescalCombineArgs cb{};
             cb.B = B; cb.D = d_e; cb.neg_head = b->neg_head; cb.dpos = dP; cb.V = Vr; cb.c1p = RC1; cb.c2p = RC2; cb.GH = GH; cb.GT = GT;
             KGE_TRY(launch_rescal_combine(cb, s));
+            if (nd) KGE_TRY(launch_nd_fold(GN, b->neg_head ? GH : GT, B, chunk, N, d_e, s));
         }
     } else if (!transe_fast && !ew_bwd) {
         EdgeBwdArgs eb{};

@@ -475,6 +475,8 @@ struct FinalizeArgs {
 int kge_fail(int code, const char *msg);      // records the message kge_last_error() returns (kge_api.hip); returns code
 int launch_gather_rows(const float *table, int dim, const int64_t *idx, int64_t n, float *out,
                        hipStream_t s);
+int launch_nd_ids(const int64_t *own, const int64_t *neg_ids, int C, int chunk, int Ns, int64_t *out, hipStream_t s);   // [own | sampled] ids per chunk
+int launch_nd_fold(const float *GN, float *G, int B, int chunk, int Np, int d, hipStream_t s);   // G[i] += GN[in-batch row of edge i]
 int launch_gather3_sharded(const kge::ShardMap &m, int dim, const int64_t *h, const int64_t *t, const int64_t *neg, int B, int n_neg,
                            float *out, int64_t *iota, hipStream_t s);     // [h | t | neg] rows through the shard map + identity ids
 int launch_gather_rows_sharded(float *const *shard_rows, int n_shards, int64_t per, int dim,
@@ -633,6 +635,8 @@ struct TransRArgs {
     const int64_t *ur_id; const int32_t *ur_ptr, *ur_edge, *counts_dev;
     float *gs0, *gs1, *k0, *k1;      // [B], [B], [UR], [UR] scratch of the projection update
     float *gs1p;                     // [B, tiles of the D_e x D_r matrix]: sum of squares of every tile of GP, written by its producer
+    int nd_chunk;                    // > 0: neg_deg_sample - neg_ids is the combined [own | sampled] list of N = nd_chunk + sampled ids per chunk,
+                                     // the negative rows' regulariser is left to the update kernel (sampled rows only)
     int nG; float *GNp;              // split-K groups of the negative-row gradient and their partial tiles [nG, C*N, De]
 };
 #ifndef TRANSR_GN_GROUPS

@@ -77,6 +77,38 @@ int launch_gather_rows_sharded(float *const *shard_rows, int n_shards, int64_t p
     return check_launch();
 }
 
+// --neg_deg_sample for the relation-matrix models (round 6; general_models.py:396-402, 417-432).  nd_ids: the combined id list of a
+// chunk's negatives, [the chunk's own corrupted-side entities | the sampled ids] (TransR's kernels address the negatives through one
+// list).  nd_fold: the gradient of the in-batch negative row of edge i - row (i / chunk) * Np + i % chunk of GN - joins the
+// positive-trace gradient row of that entity (GH in head mode, GT in tail mode): the row is a slice of pos_g.ndata['emb'].
+__global__ __launch_bounds__(256) void nd_ids_kernel(const int64_t *__restrict__ own, const int64_t *__restrict__ neg_ids, int C, int chunk,
+                                                     int Ns, int64_t *__restrict__ out) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int Np = chunk + Ns;
+    if (k >= (int64_t)C * Np) return;
+    const int c = (int)(k / Np), jj = (int)(k % Np);
+    out[k] = jj < chunk ? own[(int64_t)c * chunk + jj] : neg_ids[(int64_t)c * Ns + jj - chunk];
+}
+int launch_nd_ids(const int64_t *own, const int64_t *neg_ids, int C, int chunk, int Ns, int64_t *out, hipStream_t s) {
+    const int64_t n = (int64_t)C * (chunk + Ns);
+    if (n == 0) return KGE_OK;
+    hipLaunchKernelGGL(nd_ids_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, own, neg_ids, C, chunk, Ns, out);
+    return check_launch();
+}
+__global__ __launch_bounds__(KGE_BLOCK) void nd_fold_kernel(const float *__restrict__ GN, float *__restrict__ G, int B, int chunk, int Np, int d) {
+    const int64_t i = WAVE_ID();
+    if (i >= B) return;
+    const int lane = LANE();
+    const float *src = GN + ((i / chunk) * Np + i % chunk) * (int64_t)d;
+    float *dst = G + i * (int64_t)d;
+    for (int k = lane; k < d; k += 64) dst[k] += src[k];
+}
+int launch_nd_fold(const float *GN, float *G, int B, int chunk, int Np, int d, hipStream_t s) {
+    if (B == 0) return KGE_OK;
+    hipLaunchKernelGGL(nd_fold_kernel, dim3(blocks_for_waves(B)), dim3(KGE_BLOCK), 0, s, GN, G, B, chunk, Np, d);
+    return check_launch();
+}
+
 // TransR / RESCAL on sharded entity tables (round 6): the batch's head, tail and negative rows through the shard map into ONE dense
 // block [B | B | n_neg] x dim + the identity index array the kernels of the two families address it with (kge_api.hip sh_dense)
 __global__ __launch_bounds__(KGE_BLOCK) void gather3_sharded_kernel(ShardMap m, int dim, const int64_t *__restrict__ h,

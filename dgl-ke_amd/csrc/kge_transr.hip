@@ -347,7 +347,7 @@ __global__ __launch_bounds__(KGE_BLOCK) void transr_gn_reduce_kernel(TransRArgs 
     const int64_t rows = (int64_t)a.C * a.N;
     if (row >= rows) return;
     const int lane = threadIdx.x & 63, De = a.De;
-    const bool reg = a.reg_coef > 0.f && a.reg_norm > 0;
+    const bool reg = a.reg_coef > 0.f && a.reg_norm > 0 && !a.nd_chunk;      // (neg_deg_sample: added by the update kernel, sampled rows only)
     const float *x = a.ent + a.neg_ids[row] * (int64_t)De;
     for (int d = lane; d < De; d += 64) {
         float v = 0.f;

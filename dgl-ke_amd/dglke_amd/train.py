@@ -272,13 +272,10 @@ class Trainer(object):
         B, N = args.batch_size, args.neg_sample_size
         self.chunk = N if N <= B else B
         C = B // self.chunk
-        # --neg_deg_sample runs on the fused step too (KGE_FLAG_NEG_DEG_SAMPLE); TransR / RESCAL keep the drop-in path for it
-        if args.neg_deg_sample and args.model_name == 'TransR':
-            # TransRScore has no per-op route (its prepare / create_neg closures raise) and the fused step has no
-            # --neg_deg_sample for TransR: refuse before any table is allocated
-            raise KgeError("--neg_deg_sample is not available for TransR")
-        self.fused = not (args.neg_deg_sample and args.model_name == 'RESCAL')
-        self.step_flags = _lib.FLAG_NEG_DEG_SAMPLE if (args.neg_deg_sample and self.fused) else 0
+        # --neg_deg_sample runs on the fused step (KGE_FLAG_NEG_DEG_SAMPLE) for every model - round 6: TransR and RESCAL too (the
+        # reference's concat-and-mask is model-agnostic, general_models.py:396-402, 417-432), also with --num_proc lanes
+        self.fused = True
+        self.step_flags = _lib.FLAG_NEG_DEG_SAMPLE if args.neg_deg_sample else 0
         if getattr(args, 'async_update', False) and getattr(args, 'async_update_rel', False):
             self.step_flags |= _lib.FLAG_ASYNC_REL
             self.model.engine.hp.flags |= _lib.FLAG_ASYNC_REL

@@ -318,6 +318,9 @@ def main():
         # distance of the float32 reference (the committed goldens) from the same code in float64, per case: max |difference| of
         # the final tables and of every recorded per-step table, in units of lr
         noise = {}
+        if only and os.path.exists(os.path.join(OUT, "noise.json")):      # named cases only: the other entries stay as they are
+            with open(os.path.join(OUT, "noise.json")) as f:
+                noise = json.load(f)
         for name, case in CASES.items():
             if only and name not in only:
                 continue

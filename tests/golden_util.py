@@ -23,7 +23,7 @@ def golden_names(transr=None, nd=False):
         names = [n for n in names if n.startswith("nd_") == bool(nd)]
     if transr is None:
         return names
-    return [n for n in names if n.startswith("transr_") == bool(transr)]
+    return [n for n in names if ("transr_" in n) == bool(transr)]          # (transr_*, nd_transr_*)
 
 
 def eval_golden_names():

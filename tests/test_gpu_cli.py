@@ -216,16 +216,21 @@ def test_train_cli_async_update_alone_runs_the_strict_step(tmp_path, capsys):
 
 
 def test_train_cli_transr_lanes_and_rejected_flags(tmp_path, capsys):
-    """--num_proc 2 with TransR: every lane shares the projection table too; TransR + --neg_deg_sample is refused
-    before anything is allocated; a non-positive --log_interval is refused"""
+    """--num_proc 2 with TransR: every lane shares the projection table too; TransR / RESCAL + --neg_deg_sample run on the fused
+    step (round 6); a non-positive --log_interval is refused"""
     from dglke_amd import train as T
     from dglke_amd._lib import KgeError
     tr = T.main(_base(tmp_path, "TransR") + ["--max_step", "300", "--num_proc", "2", "--lr", "0.05"])
     out = capsys.readouterr().out
     assert len(tr.lanes) == 2 and tr.lanes[1].engine.proj.data_ptr() == tr.model.score_func.projection_emb.emb.data_ptr()
     assert "[proc 1][Train](300/300) average loss:" in out
-    with pytest.raises(KgeError):
-        T.main(_base(tmp_path, "TransR") + ["--max_step", "10", "--neg_deg_sample"])
+    # round 6: --neg_deg_sample on the fused step for TransR and RESCAL too (was refused / a drop-in detour), also with lanes
+    for model, lanes in (("TransR", "1"), ("TransR", "2"), ("RESCAL", "2")):
+        tr2 = T.main(_base(tmp_path, model) + ["--max_step", "300", "--neg_deg_sample", "--num_proc", lanes, "--lr", "0.05"])
+        out = capsys.readouterr().out
+        assert tr2.fused and tr2.step_flags & 32 and len(tr2.lanes) == int(lanes)
+        loss = float([l for l in out.split("\n") if "(300/300) average loss:" in l][0].split(":")[1])
+        assert np.isfinite(loss) and 0.0 < loss < 5.0, out[-800:]
     with pytest.raises(KgeError):
         T.main(_base(tmp_path) + ["--max_step", "10", "--log_interval", "0"])
 
