@@ -142,7 +142,9 @@ def _a2a_setup(args, world, rank, dev, w, n_ent, d_e, emb_init, allow_force_coll
     # KGE_DIST_FORCE_COLL=1: keep the RCCL calls and the pull pipeline at world 1 too (smoke test of the N > 1 code path on one GPU)
     force_coll = allow_force_coll and os.environ.get("KGE_DIST_FORCE_COLL", "0") == "1"
     # collectives: librccl called directly on the step's streams (dist.RcclComm; KGE_DIST_COMM=torch: the c10d wrappers)
+    t_comm = time.perf_counter()
     comm = kd.make_comm() if (world > 1 or force_coll) else None
+    t_comm = time.perf_counter() - t_comm        # (communicator creation: ncclCommInitRank over the id broadcast - the first contact with the peers)
     # relation partitioning (the reference's multi-GPU Freebase recipe passes --rel_part, examples/freebase/multi_gpu.sh:100-116): every
     # rank's triples use its own relations (r = rank mod world), relation rows are updated where their edges are - no relation
     # exchange.  KGE_DIST_REL_PART=0: uniform relations on every rank, relation messages all-gathered and applied by everyone
@@ -165,6 +167,7 @@ def _a2a_setup(args, world, rank, dev, w, n_ent, d_e, emb_init, allow_force_coll
     G = max(2, min(120, args.graph_steps) // 2 * 2)
     smp = DeviceSampler(H, R, T, n_ent, w["B"], w["N"], dev, n_slots=G, seed=rank + 1)
     de.bench_sampler = smp
+    de.comm_create_s = round(t_comm, 3) if comm is not None else None
     # KGE_DIST_PIPELINE: 0 = synchronous steps; 1 = the pull of step s+1 next to step s (step_pipelined); overlap = push, owner-side
     # apply and pull all on the side stream, the compute stream runs the steps' kernels back to back (DistEngine._steps_overlapped:
     # the same one-step-stale dataflow, bit-identical tables)
@@ -359,9 +362,11 @@ def orchestrate(args, world, rank, local_rank):
         t_start = time.time()
         child = subprocess.Popen(cmd, env=env, stdout=errf, stderr=errf, start_new_session=True)
         phase, deadline, why, seen = "start", time.time() + budgets["start"], "", 0
+        mark_times = []
         while True:
             rc = child.poll()
             marks = open(prog_path).read().split("\n") if os.path.exists(prog_path) else []
+            mark_times = [(m.split()[0], float(m.split()[1])) for m in marks if len(m.split()) >= 2]
             marks = [m.split()[0] for m in marks if m.strip()]
             if len(marks) > seen:                       # a phase ended: the next one gets its own budget
                 seen = len(marks)
@@ -391,8 +396,17 @@ def orchestrate(args, world, rank, local_rank):
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         reasons = [None] * world
         dist.all_gather_object(reasons, why)
+        # seconds every rank spent until each progress mark of the worker (start = interpreter + import + build check, tables = local
+        # allocations, setup = communicator + first eager steps, warmup, timed, headline): where a slow or failed attempt's time went
+        spans, prev = {}, t_start
+        for name, t in mark_times:
+            if name not in spans:
+                spans[name] = round(t - prev, 2)
+            prev = t
+        all_spans = [None] * world
+        dist.all_gather_object(all_spans, spans)
         rec = {"mode": mode, "comm": comm or None, "ok": bool(int(flag.item())), "seconds": round(time.time() - t_start, 1),
-               "why": next((r for r in reasons if r), None)}
+               "why": next((r for r in reasons if r), None), "phase_seconds_per_rank": all_spans}
         if rec["why"] and not rec["ok"]:
             try:
                 tail = open(os.path.join(tmpdir, "stderr_%d.txt" % ai)).read()[-400:]
@@ -409,6 +423,8 @@ def orchestrate(args, world, rank, local_rank):
                     line = _replicas_line(args, world, alls, history)
             elif rank == 0:
                 d = json.loads(open(res_path).read())
+                if "diagnostics" in d.get("config", {}):       # the worker's per-rank diagnostics belong to the attempt that produced them
+                    history[-1]["diagnostics"] = d["config"].pop("diagnostics")
                 d["config"]["attempts"] = history
                 if len(history) > 1:
                     d["config"]["fallback_reason"] = "; ".join("%s%s: %s" % (h["mode"], "/" + h["comm"] if h["comm"] else "", h["why"])
@@ -593,6 +609,8 @@ def main(args, world, rank, local_rank):
             res["a2a_eager"] = eager
         if local_leg is not None:
             res["per_gpu_step_without_exchange"] = local_leg
+        if diag is not None:
+            res["config"]["diagnostics"] = diag
         line = json.dumps(res)
         if now:
             if _deliver(line):
@@ -612,6 +630,33 @@ def main(args, world, rank, local_rank):
     # pull pipeline; --async_update licence).  Exactly K steps between barriers, like the headline: when it is faster, emit()
     # makes it the line's value and keeps the first measurement beside it.  Which one wins depends on what the exchanges cost on
     # the links; at world 1 with forced collectives: 136.7 (synchronous) / 117.7 us (overlapped), profiles/r05_overlap_schedule.txt
+    # ---- diagnostics (round 6): per rank, the communicator's creation time, the owner buckets' capacity and growth
+    # events, and ONE group of eager synchronous steps with a HIP event behind every phase (route / ids a2a / gather / rows a2a /
+    # compute / push / apply, DistEngine.profile_phases) - so that the first run on a multi-GPU node explains itself in one shot.
+    # Behind the delivered headline and under its own watchdog; the supervisor files it under config.attempts[-1].diagnostics.
+    diag = None
+    if mode == "a2a" and os.environ.get("KGE_DIST_DIAG", "1") != "0":
+        done_d = threading.Event()
+
+        def watchdog_d():
+            if not done_d.wait(float(os.environ.get("KGE_DIST_LEG_TIMEOUT", "120"))):
+                emit({"error": "the diagnostics leg did not finish in time (watchdog)"})
+                os._exit(0)
+        threading.Thread(target=watchdog_d, daemon=True).start()
+        try:
+            smp_ = _de.bench_sampler
+            torch.cuda.synchronize(); dist.barrier()
+            ph = _de.profile_phases(smp_.sample(min(smp_.n_slots, 20)))
+            mine = {"rank": rank, "communicator": type(_de.comm).__name__ if _de.coll else None,
+                    "communicator_create_s": getattr(_de, "comm_create_s", None), "bucket_rows": _de.cap,
+                    "bucket_growth": [list(g) for g in getattr(_de, "grown", [])] or None,
+                    "phase_us_per_step": ph}
+            alls = [None] * world
+            dist.all_gather_object(alls, mine)
+            diag = alls
+        except Exception as e:          # noqa: BLE001 - a diagnostic must never cost the line
+            diag = [{"rank": rank, "error": repr(e)}]
+        done_d.set()
     pipe_leg = None
     other_sched = False if sched_name != "synchronous" else "overlap"
     if (mode == "a2a" and _de.coll and rows.get("launch") == "graph" and

@@ -455,6 +455,7 @@ class DistEngine(object):
         self._pre = None              # (batch, LocalBatch, slot index, event) of a pull that ran ahead
         self._side = None
         self._parity = 0
+        self._mark = None             # profile_phases(): called with a phase name behind every phase of the synchronous step
 
     # ---- buffers (allocated once, for the geometry of the first batch) -----------------------------------------------
     def _setup(self, b):
@@ -576,6 +577,8 @@ class DistEngine(object):
                 self._gsend, self._graw = z(W * smp.n_slots * cap), z(W * smp.n_slots * cap)    # per-step view [slot][source][cap]
                 self._grecv = z(smp.n_slots, W * cap)
         group(batches, W, self.spec.shard, cap, self._route_pool, off, stride, self.overflow)
+        if self._mark:
+            self._mark("route")
         if self.coll:
             # every owner's share of the group's request ids in one piece: pool rows hold [owner][cap] per slot
             pool64 = self._route_pool.view(torch.int64)
@@ -584,6 +587,8 @@ class DistEngine(object):
             send.view(W, n, cap).copy_(req.permute(1, 0, 2))
             self.comm.all_to_all(raw, send)
             self._grecv[slots[0]:slots[0] + n].view(n, W, cap).copy_(raw.view(W, n, cap).permute(1, 0, 2))
+            if self._mark:
+                self._mark("ids_a2a")
         for b in batches:
             key = (b.slot, b.neg_head)
             self._routed[id(b)] = (self._slot_lb(b, off, stride), getattr(b, "gen", None))
@@ -845,9 +850,15 @@ class DistEngine(object):
                 lb.recv_ids = s.recv_ids
             else:
                 lb.recv_ids = lb.req_ids
+        if self._mark:
+            self._mark("route")                     # (only when this step routed for itself: a no-op span otherwise)
         self.ops.gather_req(self.ent, lb.recv_ids, sp.lo, s.rows_out)
+        if self._mark:
+            self._mark("gather")
         if self.coll:
             self.comm.all_to_all(s.cache[:W * self.cap], s.rows_out)
+            if self._mark:
+                self._mark("rows_a2a")
         lb.slot = slot
         return lb
 
@@ -869,6 +880,8 @@ class DistEngine(object):
                 g.replay()
                 return
         self.ops.step_grads(self.engine, lb, s.cache, ent_msg, rel_msg, self.zero_state)
+        if self._mark:
+            self._mark("compute")
 
     def _push_apply(self, lb, before_apply=None):
         sp, s, W = self.spec, self.slots[lb.slot], self.spec.world
@@ -884,8 +897,12 @@ class DistEngine(object):
                 self.comm.all_gather(self.all_rel.view(-1), self.rel_msg.view(-1))
         if before_apply is not None:
             before_apply()
+        if self._mark:
+            self._mark("push")
         if self._rel_inplace:             # the relation trace was applied by the step itself
             self.ops.apply_merged(self.ent, self.ent_state, W, self.cap, lb.recv_ids, sp.lo, self.recv_msg, 2, self.lr)
+            if self._mark:
+                self._mark("apply")
             return
         pair = getattr(self.ops, "apply_merged_pair", None) if self._pair_ok else None
         if pair is not None and self.d_e % 4 == 0 and self.d_r % 4 == 0:      # both applies in one launch (same results)
@@ -894,6 +911,49 @@ class DistEngine(object):
         else:
             self.ops.apply_merged(self.ent, self.ent_state, W, self.cap, lb.recv_ids, sp.lo, self.recv_msg, 2, self.lr)
             self.ops.apply_merged(self.engine.rel, self.engine.rel_state, Wr, lb.B, None, 0, self.all_rel, 1, self.lr)
+        if self._mark:
+            self._mark("apply")
+
+    def profile_phases(self, batches):
+        """diagnostic (round 6, VERDICT r05 next-7: the first run on a multi-GPU node must explain itself): ONE group of batches as
+        eager, SYNCHRONOUS steps with a HIP event behind every phase - group level: route (kge_route_build_group), ids_a2a (the
+        group's request ids); per step: gather (owner-side kge_gather_rows_req), rows_a2a, compute (kge_step_grads: the step's
+        kernels against the row cache), push (gradient all-to-all + relation all-gather), apply (owner-side Adagrad).  Trains the
+        batches like any other step.  Returns {phase: microseconds per STEP} of this rank (+ 'steps'); at world 1 without
+        collectives (local_only) the step is the in-place single-table step: one 'compute' phase."""
+        if self.dev.type != "cuda":
+            raise _lib.KgeError("profile_phases needs the device path")
+        n = len(batches)
+        marks = []
+
+        def mark(name):
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            marks.append((name, ev))
+        torch.cuda.synchronize(self.dev)
+        mark("start")
+        if self.local_only:
+            for b in batches:
+                self.ops.step_local(self.engine, b, self.ent, self.ent_state)
+            mark("compute")
+        else:
+            self.ensure_capacity(batches)
+            mark("capacity_check")
+            self._mark = mark
+            try:
+                self.prepare_group(batches, check_capacity=False)
+                for b in batches:
+                    self.step(b)
+            finally:
+                self._mark = None
+        torch.cuda.synchronize(self.dev)
+        out = {}
+        for (_, e0), (name, e1) in zip(marks[:-1], marks[1:]):
+            out[name] = out.get(name, 0.0) + e0.elapsed_time(e1) * 1e3
+        res = {k: round(v / n, 2) for k, v in out.items()}
+        res["steps"] = n
+        res["sum_us_per_step"] = round(sum(out.values()) / n, 2)
+        return res
 
     def step(self, batch):
         """one synchronous sharded step (pull, compute, push, apply), all enqueued on the current stream."""

@@ -42,7 +42,12 @@ if mode == "replicas":
     deliver({"wall": 0.002 * (rank + 1), "rank": rank})
 elif rank == 0:
     deliver({"metric": "positive edges/sec (whole node)", "value": 123.0, "unit": "edges/s",
-             "config": {"mode": mode, "fallback_reason": None, "comm": comm}})
+             "config": {"mode": mode, "fallback_reason": None, "comm": comm,
+                        # (what the real worker's diagnostics leg adds: per rank communicator creation time, bucket growth, phase us)
+                        "diagnostics": [{"rank": r, "communicator": "RcclComm", "communicator_create_s": 0.5, "bucket_rows": 512,
+                                         "bucket_growth": None, "phase_us_per_step": {"route": 1.0, "ids_a2a": 2.0, "gather": 3.0,
+                                                                                      "rows_a2a": 4.0, "compute": 90.0, "push": 5.0,
+                                                                                      "apply": 6.0, "steps": 20}} for r in range(2)]}})
 mark("headline")
 if what == "leg_hang":
     time.sleep(3600)

@@ -50,6 +50,16 @@ def test_first_attempt_succeeds():
     d = _run("a2a/rccl-graph=ok")
     assert d["value"] == 123.0 and d["config"]["mode"] == "a2a" and d["config"]["fallback_reason"] is None
     assert [h["ok"] for h in d["config"]["attempts"]] == [True]
+    # round 6: the attempt explains itself - seconds per progress mark of every rank, and the worker's per-rank diagnostics
+    # (communicator creation time, bucket capacity / growth, microseconds per phase of the synchronous step) filed under the attempt
+    at = d["config"]["attempts"][0]
+    assert len(at["phase_seconds_per_rank"]) == 2
+    for spans in at["phase_seconds_per_rank"]:
+        assert list(spans) == ["start", "tables", "setup", "warmup", "timed", "headline"] and all(v >= 0 for v in spans.values())
+    assert "diagnostics" not in d["config"] and len(at["diagnostics"]) == 2
+    for r, dg in enumerate(at["diagnostics"]):
+        assert dg["rank"] == r and dg["communicator_create_s"] is not None and "bucket_growth" in dg
+        assert set(dg["phase_us_per_step"]) >= {"route", "ids_a2a", "gather", "rows_a2a", "compute", "push", "apply"}
 
 
 @pytest.mark.timeout(300)
@@ -59,6 +69,7 @@ def test_hang_then_crash_then_one_stuck_rank_then_p2p():
     assert [(h["mode"], h["comm"], h["ok"]) for h in at] == [("a2a", "rccl-graph", False), ("a2a", "rccl", False),
                                                              ("a2a", "rccl-sync", False), ("a2a", "torch", False), ("p2p", None, True)]
     assert "watchdog" in at[0]["why"] and "tables" in at[0]["why"] and "status 3" in at[3]["why"]
+    assert list(at[0]["phase_seconds_per_rank"][0]) == ["start", "tables"]          # a failed attempt still says how far every rank got
     assert d["config"]["mode"] == "p2p" and "a2a/rccl" in d["config"]["fallback_reason"] and d["value"] == 123.0
 
 

@@ -51,6 +51,43 @@ def test_bench_line_has_the_contract_fields():
     # round 5: what ran untimed is said, and the 20 timed steps build the next 20 batches on their own launches (no sampler launch)
     assert d["warmup_effective"] == 120 and "kge_step_fused_sampling" in d["config"]["launch"]
     assert r.get("traffic_ratio") is None or r["traffic_ratio"] > 1.0
+    # round 6: the launch description is built from what the TIMED groups did, and the line says whether the committed
+    # profile summaries it quotes were taken from this build's source set
+    assert d["config"]["sampler_groups_timed"] == {"fused": 1, "launch": 0, "none": 0} and "1 of the 1 timed groups: NO sampler launch" in d["config"]["launch"]
+    assert isinstance(r["profile_matches_build"], bool) and len(r["build_source_hash"]) == 16
+
+
+@pytest.mark.gpu
+def test_bench_time_to_mrr_leg_reports_the_second_half_of_the_metric():
+    """round 6: the bounded time-to-MRR@0.65 leg of the default line - dglke_train with the reference's FB15k
+    TransE_l2 recipe on real FB15k when supplied, else on the labelled PLANTED graph."""
+    import bench
+    d = bench.time_to_mrr(timeout_s=280.0)
+    assert "error" not in d, d
+    assert d["graph"] in ("planted", "fb15k") and d["target_mrr"] == 0.65
+    assert d["reached"] and d["mrr"] >= 0.65 and 500 <= d["steps"] <= 24000 and d["steps"] % 500 == 0
+    assert 0 < d["train_seconds"] < 60 and d["eval_seconds"] > 0 and d["validations"] == d["steps"] // 500
+    assert d["test_mrr"] is not None and ("PLANTED" in d["note"]) == (d["graph"] == "planted")
+
+
+@pytest.mark.gpu
+def test_forced_exchange_line_carries_per_rank_diagnostics():
+    """round 6: the multi-GPU worker's line explains itself - communicator creation time, bucket capacity and
+    growth, microseconds per phase of the synchronous step (here: the N > 1 code path at world 1 with its RCCL exchanges kept)."""
+    env = dict(os.environ)
+    env.update({"KGE_DIST_MODE": "a2a", "KGE_DIST_FORCE_COLL": "1", "KGE_DIST_PIPELINE": "0", "KGE_DIST_OTHER_LEG": "0",
+                "KGE_DIST_ENTITIES": "2000000", "KGE_DIST_TRIPLES": "2000000", "WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0",
+                "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(29700 + os.getpid() % 200)})
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "40", "--warmup", "20",
+                          "--workload", "rotate_freebase", "--no-cpu-baseline"],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    dg = d["config"]["diagnostics"]
+    assert len(dg) == 1 and dg[0]["rank"] == 0 and dg[0]["communicator"] == "RcclComm" and dg[0]["communicator_create_s"] > 0
+    ph = dg[0]["phase_us_per_step"]
+    assert set(ph) >= {"route", "ids_a2a", "gather", "rows_a2a", "compute", "push", "apply", "steps"}, ph
+    assert ph["compute"] > 20.0 and ph["steps"] == 20 and dg[0]["bucket_rows"] > 0
 
 
 @pytest.mark.gpu
