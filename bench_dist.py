@@ -232,7 +232,7 @@ def _a2a_setup(args, world, rank, dev, w, n_ent, d_e, emb_init, allow_force_coll
     a_ = smp.slot_arrays(0)
     u_pos = int(np.unique(np.concatenate([a_["h_gid"], a_["t_gid"]])).shape[0])
     ue = int(np.unique(np.concatenate([a_["h_gid"], a_["t_gid"], a_["neg_ids"]])).shape[0])
-    rows = dict(UE=ue, R_e=u_pos + C * w["N"], B=w["B"], cap=de.cap, rel_part=rel_part,
+    rows = dict(UE=ue, R_e=u_pos + C * w["N"], B=w["B"], cap=de.cap, cap2=getattr(de, "cap2", 0), rel_part=rel_part,
                 launch="graph" if (use_graph or graph_coll) else "eager")
     rel_desc = ("triples partitioned by relation (--rel_part of the reference's recipe): relation rows updated on their owner rank, "
                 "no relation exchange" if rel_part else "relation gradients all-gathered")
@@ -257,7 +257,8 @@ def _a2a_setup(args, world, rank, dev, w, n_ent, d_e, emb_init, allow_force_coll
                     % launch_desc)
         return ("entity table range-sharded, relation table replicated; per step: device-side routing into %d-row owner buckets, "
                 "all-to-all pull of the unique rows, the single-GPU kernels against the row cache, all-to-all push of one packed "
-                "gradient message per row, owner-side Adagrad in rank order (one merged launch), %s "
+                "single-trace gradient message per row (a second one, in the bucket's small extra region, only for a row that is in both "
+                "traces of the batch), owner-side Adagrad in rank order (one merged launch), %s "
                 "(parameter-server semantics, RCCL%s); %s; sampling + plan on the device inside the timed region"
                 % (de.cap or 0, rel_desc, comm_desc, launch_desc))
     de.describe = describe
@@ -575,6 +576,7 @@ def main(args, world, rank, local_rank):
     overflow = _de.check_overflow() if mode != "p2p" else 0
     if mode != "p2p":
         rows["cap"], rows["grown"] = _de.cap, [list(g) for g in getattr(_de, "grown", [])] or None
+        rows["cap2"], rows["grown_extra"] = getattr(_de, "cap2", 0), [list(g) for g in getattr(_de, "grown_extra", [])] or None
     eager = None
     other = "p2p" if mode == "a2a" else "a2a"
     # (KGE_DIST_OTHER_LEG=force: run the secondary legs at N = 1 too - a smoke test of this code path on one GPU)
@@ -650,6 +652,8 @@ def main(args, world, rank, local_rank):
             mine = {"rank": rank, "communicator": type(_de.comm).__name__ if _de.coll else None,
                     "communicator_create_s": getattr(_de, "comm_create_s", None), "bucket_rows": _de.cap,
                     "bucket_growth": [list(g) for g in getattr(_de, "grown", [])] or None,
+                    "message_extra_rows": getattr(_de, "cap2", 0) or None,
+                    "message_extra_growth": [list(g) for g in getattr(_de, "grown_extra", [])] or None,
                     "phase_us_per_step": ph}
             alls = [None] * world
             dist.all_gather_object(alls, mine)
@@ -790,7 +794,9 @@ def _result_line(args, w, n_ent, world, wall, K, rows, d_e, d_r, desc, mode, why
         else:
             cap = rows.get("cap") or rows["UE"]
             rel_bytes = 0 if rows.get("rel_part") else (world - 1) * rows["B"] * 4 * (d_r + 4)      # (no relation exchange under --rel_part)
-            xgmi_step = ((world - 1) * cap * (8 + 4 * d_e + 4 * (2 * d_e + 4)) + rel_bytes) * 1.0
+            # gradient messages per bucket: packed single-trace (round 6): (cap + cap2) rows of d_e + 4 floats; else cap rows of 2 d_e + 4
+            msg_bytes = ((cap + rows["cap2"]) * 4 * (d_e + 4)) if rows.get("cap2") else (cap * 4 * (2 * d_e + 4))
+            xgmi_step = ((world - 1) * (cap * (8 + 4 * d_e) + msg_bytes) + rel_bytes) * 1.0
         out = {
             "metric": "positive edges/sec (whole node)",
             "value": round(K * w["B"] * world / wall, 1), "unit": "edges/s",
@@ -823,6 +829,11 @@ def _result_line(args, w, n_ent, world, wall, K, rows, d_e, d_r, desc, mode, why
             out["config"]["launch"] = rows.get("launch")            # "graph": kernels + collectives of a group from one hipGraph
             out["config"]["bucket_rows"] = rows.get("cap")
             out["config"]["bucket_growth"] = rows.get("grown")
+            # packed single-trace gradient messages (round 6): rows of a bucket's extra region (second messages of the rows that are in
+            # both traces of a batch); null / 0 = two-trace messages
+            out["config"]["message_extra_rows"] = rows.get("cap2") or None
+            out["config"]["message_extra_growth"] = rows.get("grown_extra")
+            out["config"]["message_floats"] = (d_e + 4) if rows.get("cap2") else (2 * d_e + 4)
             out["config"]["bucket_overflows"] = overflow
         if leg is not None:
             out[other] = leg

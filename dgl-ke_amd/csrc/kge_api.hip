@@ -955,6 +955,12 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         ua.gr = emit->gr; ua.gsr = emit->gsr; ua.rid = emit->rid;
         ua.emit_ent = 1; ua.emit_rel = emit->gr ? 1 : 0;
         ua.emit_by_id = emit->ent_by_id ? 1 : 0;
+        if (emit->msg_rows) {                     // packed single-trace entity messages (ABI 8)
+            if (!emit->g0 || emit->ld_e < d_e + 4 || emit->msg_cap < 1 || emit->msg_cap_extra < 1)
+                return fail(KGE_ERR_ARG, "kge_step_grads: packed messages need g0, ld_e >= d_e + 4 and the bucket geometry");
+            ua.msg_rows = emit->msg_rows; ua.msg_cap = emit->msg_cap; ua.msg_capT = emit->msg_cap + emit->msg_cap_extra;
+            ua.g1 = nullptr; ua.gs0 = nullptr; ua.gs1 = nullptr;
+        }
         if (emit->ld_e > 0) { ua.ld_e = emit->ld_e; ua.ld_gs_e = emit->ld_e; }
         if (emit->ld_r > 0) { ua.ld_r = emit->ld_r; ua.ld_gs_r = emit->ld_r; }
     }
@@ -1127,8 +1133,8 @@ int kge_step_phase(const kge_hparams *hp, const kge_tables *tb, const kge_batch 
 int kge_step_grads(const kge_hparams *hp, const kge_tables *tb, const kge_batch *b,
                    const kge_step_out *out, const kge_emit *emit, void *ws, size_t ws_bytes,
                    void *stream) {
-    if (!emit || !emit->g0 || !emit->gs0 || !emit->g1 || !emit->gs1)
-        return fail(KGE_ERR_ARG, "kge_step_grads: emit buffers g0/gs0/g1/gs1 are required");
+    if (!emit || !emit->g0 || (!emit->msg_rows && (!emit->gs0 || !emit->g1 || !emit->gs1)))
+        return fail(KGE_ERR_ARG, "kge_step_grads: emit buffers g0/gs0/g1/gs1 are required (packed messages: g0 + msg_rows)");
     if ((emit->gr == nullptr) != (emit->gsr == nullptr))
         return fail(KGE_ERR_ARG, "kge_step_grads: gr and gsr must be given together");
     return step_impl(hp, tb, b, out, emit, ws, ws_bytes, stream);

@@ -441,6 +441,8 @@ struct UpdateArgs {
     float *g0, *gs0, *g1, *gs1, *gr, *gsr;
     int emit_ent, emit_rel;
     int emit_by_id;                  // entity messages are written at row `id` (the cache row of dist.py) instead of union entry u
+    const int32_t *msg_rows;         // packed single-trace entity messages (kge_emit.msg_rows, ABI 8): [UE][2] {message row, position of the
+    int msg_cap, msg_capT;           // second message in its bucket's extra region or -1}, or null; bucket = msg_capT rows, extra region from msg_cap
     int ld_e, ld_r;                  // row strides of the emit buffers (floats)
     int32_t *rid;                    // optional relation-id words inside the relation message
     int ld_gs_e, ld_gs_r;            // strides of gs0/gs1 and gsr

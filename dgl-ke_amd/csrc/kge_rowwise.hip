@@ -897,9 +897,9 @@ int launch_update(const UpdateArgs &a, hipStream_t s, const SmpTail *tail) {
     int lean = !reg3 ? 0 : ((!inplace || a.nd_chunk) ? 4 : (a.transe_fast ? (a.Q ? 3 : 1) : 2));
     const int nit = dmax <= 256 ? 1 : (dmax <= 512 ? 2 : 4);
 #ifndef UPD_NO_EMIT6
-    if (lean == 4 && a.emit_ent && a.emit_rel && a.g0 && a.g1 && a.gr && !a.transe_fast && !a.nd_chunk && !a.Hs && !a.Ts && !a.Rs && !a.Ns && !a.dry)
+    if (lean == 4 && a.emit_ent && a.emit_rel && a.g0 && (a.g1 || a.msg_rows) && a.gr && !a.transe_fast && !a.nd_chunk && !a.Hs && !a.Ts && !a.Rs && !a.Ns && !a.dry)
         lean = 6;                    // the all-to-all engine's step for the models with per-edge gradient rows
-    else if (lean == 4 && a.emit_ent && !a.emit_rel && a.g0 && a.g1 && !a.gr && !a.gsr && !a.rid && !a.transe_fast && !a.nd_chunk && !a.Hs &&
+    else if (lean == 4 && a.emit_ent && !a.emit_rel && a.g0 && (a.g1 || a.msg_rows) && !a.gr && !a.gsr && !a.rid && !a.transe_fast && !a.nd_chunk && !a.Hs &&
              !a.Ts && !a.Rs && !a.Ns && !a.dry)
         lean = 7;                    // ... under relation partitioning: entity messages out, the relation trace applied in place
 #endif

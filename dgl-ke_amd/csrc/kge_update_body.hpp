@@ -352,7 +352,7 @@ __device__ __forceinline__ void update_reg_body(const UpdateArgs &a_in, int nb_e
     if constexpr (LEAN != 0) {
         a.transe_fast = (LEAN == 1 || LEAN == 3) ? 1 : 0; a.emit_ent = 0; a.emit_rel = 0;
         if (LEAN != 3) a.Q = nullptr;
-        a.g0 = a.g1 = a.gs0 = a.gs1 = a.gr = a.gsr = nullptr; a.rid = nullptr; a.dry = 0; a.nd_chunk = 0; a.emit_by_id = 0;
+        a.g0 = a.g1 = a.gs0 = a.gs1 = a.gr = a.gsr = nullptr; a.rid = nullptr; a.dry = 0; a.nd_chunk = 0; a.emit_by_id = 0; a.msg_rows = nullptr;
         a.reg_norm = 3;             // (launch_update sends any other norm to the generic instance)
     }
     const int lane = LANE();
@@ -615,6 +615,14 @@ __device__ __forceinline__ void update_reg_body(const UpdateArgs &a_in, int nb_e
         const float sA = has_pos ? st0 + s0 : st0;
         const float sB = has_neg ? sA + s1 : sA;
         const int64_t mu = a.emit_by_id ? id : u;       // message row: union entry, or the row id itself (cache rows, dist.py)
+        int mr0 = 0, mr1 = -1, mlink = -1;              // packed messages: rows of the first / second message, the second one's bucket position
+        if (a.msg_rows) {
+            const int2 mr = reinterpret_cast<const int2 *>(a.msg_rows)[u];
+            mr0 = mr.x; mlink = mr.y;
+            // (second message: position mlink of the extra region of the SAME owner bucket - buckets are msg_capT rows apart, the
+            //  extra region starts msg_cap rows in; a division per wavefront, only for the rare rows that are in both traces)
+            if (mlink >= 0) mr1 = (mr0 / a.msg_capT) * a.msg_capT + a.msg_cap + mlink;
+        }
         // one division per row (-lr / std), then multiply-adds: 24 IEEE division sequences per wavefront were
         // 10 % of this kernel's instructions (<= 1 ulp from the reference's per-element division)
         const float k0 = -a.lr / (sqrtf(sA) + a.eps), k1 = -a.lr / (sqrtf(sB) + a.eps);
@@ -634,14 +642,31 @@ __device__ __forceinline__ void update_reg_body(const UpdateArgs &a_in, int nb_e
                     }
                     KGE_ST_ROW<4>(row + it * 4, y);
                 }
+                if (a.msg_rows) {
+                    // packed single-trace messages (round 6): ONE message [g | gs | link] per row - its positive trace, or its negative
+                    // trace when it has no positive one; a row in BOTH traces writes the negative trace as a second message into the
+                    // owner bucket's extra region (row mr1 >= 0, assigned by kge_route_build)
+                    st<4>(a.g0 + (int64_t)mr0 * a.ld_e + it * 4, has_pos ? g0[k] : g1[k]);
+                    if (has_pos && has_neg && mr1 >= 0) st<4>(a.g0 + (int64_t)mr1 * a.ld_e + it * 4, g1[k]);
+                } else {
                 if (a.g0) st<4>(a.g0 + mu * (int64_t)a.ld_e + it * 4, g0[k]);      // (messages: plain - write-through measured 1.2 us slower on the a2a step)
                 if (a.g1) st<4>(a.g1 + mu * (int64_t)a.ld_e + it * 4, g1[k]);
+                }
             }
         }
         if (lane == 0) {
             if (!a.emit_ent) *srow = sB;
+            if (a.msg_rows) {
+                const bool two = has_pos && has_neg && mr1 >= 0;
+                float *h0 = a.g0 + (int64_t)mr0 * a.ld_e + d;
+                h0[0] = has_pos ? s0 : (has_neg ? s1 : 0.f);
+                // link: the second message's position inside the bucket's extra region (the bucket keeps its layout through the all-to-all)
+                h0[1] = __int_as_float(two ? mlink : -1);
+                if (two) { float *h1 = a.g0 + (int64_t)mr1 * a.ld_e + d; h1[0] = s1; h1[1] = __int_as_float(-1); }
+            } else {
             if (a.gs0) a.gs0[mu * (int64_t)a.ld_gs_e] = has_pos ? s0 : 0.f;
             if (a.gs1) a.gs1[mu * (int64_t)a.ld_gs_e] = has_neg ? s1 : 0.f;
+            }
         }
 #ifdef UPD_PROBE_NOACC
         if (false) {

@@ -79,12 +79,13 @@ class KgeSamplerJob(C.Structure):
 
 class KgeEmit(C.Structure):
     _fields_ = [("g0", c_p), ("gs0", c_p), ("g1", c_p), ("gs1", c_p), ("gr", c_p), ("gsr", c_p),
-                ("ld_e", c_i32), ("ld_r", c_i32), ("rid", c_p), ("ent_by_id", c_i32), ("reserved", c_i32)]
+                ("ld_e", c_i32), ("ld_r", c_i32), ("rid", c_p), ("ent_by_id", c_i32), ("reserved", c_i32),
+                ("msg_rows", c_p), ("msg_cap", c_i32), ("msg_cap_extra", c_i32)]      # ABI 8: packed single-trace entity messages
 
 
 class KgeMergeJob(C.Structure):
     _fields_ = [("table", c_p), ("state_sum", c_p), ("n_rows", c_i64), ("dim", c_i32), ("nsrc", c_i32), ("cap", c_i32),
-                ("ld", c_i32), ("ntraces", c_i32), ("reserved", c_i32), ("id_words", c_p), ("id_stride_words", c_i64),
+                ("ld", c_i32), ("ntraces", c_i32), ("cap_extra", c_i32), ("id_words", c_p), ("id_stride_words", c_i64),
                 ("id_offset", c_i64), ("msg", c_p)]
 
 
@@ -128,11 +129,11 @@ _SIGNATURES = {
     "kge_transr_project_neg": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     "kge_transr_project_neg_bwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p]),
     "kge_route_fill": (c_i, [c_p, c_i, c_sz, c_i, c_i64, c_p, c_p]),
-    "kge_route_build": (c_i, [c_p, c_i, c_i64, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
-    "kge_route_build_group": (c_i, [c_p, c_i, c_sz, c_i, c_i64, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_sz, c_p, c_p]),
+    "kge_route_build": (c_i, [c_p, c_i, c_i64, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p]),
+    "kge_route_build_group": (c_i, [c_p, c_i, c_sz, c_i, c_i64, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_sz, c_p, c_i, c_p, c_p]),
     "kge_batch_localized": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "kge_gather_rows_req": (c_i, [c_p, c_i64, c_i, c_p, c_i64, c_i64, c_p, c_p]),
-    "kge_adagrad_apply_merged": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_i, c_p, c_i64, c_i64, c_p, c_i, c_i, c_f, c_f, c_p]),
+    "kge_adagrad_apply_merged": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_i, c_p, c_i64, c_i64, c_p, c_i, c_i, c_i, c_f, c_f, c_p]),
     "kge_adagrad_apply_merged_pair": (c_i, [C.POINTER(KgeMergeJob), C.POINTER(KgeMergeJob), c_f, c_f, c_p]),
     "kge_adagrad_apply_rows": (c_i, [c_p, c_p, c_i64, c_i, c_p, c_p, c_p, c_i64, c_f, c_f, c_p]),
     "kge_step_workspace_bytes": (c_sz, [C.POINTER(KgeHParams), c_i, c_i, c_i, c_i, c_i, c_i]),

@@ -45,10 +45,13 @@ class OracleLocalBatch(object):
 class OracleOps(object):
     """stand-in for dglke_amd.dist.HipOps (same calls, same message layout): the routing restated in numpy, the arithmetic
     by the CPU oracle."""
-    def __init__(self, cfg):
+    def __init__(self, cfg, packed=False):
         self.cfg = cfg
+        # round 6: PACKED single-trace entity messages like HipOps' default - [g | gs | link] rows of D + 4 floats in buckets of
+        # cap + cap2 rows, a row that is in both traces puts its negative trace into the bucket's extra region
+        self.packed_messages = bool(packed)
 
-    def route(self, batch, world, per, cap, bf):
+    def route(self, batch, world, per, cap, bf, cap2=0):
         p = batch.p
         ue = p["ue_id"]
         owner = ue // per
@@ -64,6 +67,17 @@ class OracleOps(object):
                   neg=np.array([row_of[x] for x in p["neg_ids"].tolist()], np.int64))
         lb = OracleLocalBatch(batch, lp)
         lb.req_ids = bf.req_ids
+        if cap2:
+            capT = cap + cap2
+            both = np.isin(ue, p["nid"]) & np.isin(ue, p["neg_ids"])
+            rank = np.zeros(len(ue), np.int64)
+            for o in range(world):
+                m = owner == o
+                rank[m] = np.cumsum(both[m]) - both[m]
+            assert (rank[both] < cap2).all(), "extra region overflow in the test"
+            lb.msg_main = dict(zip(cr.tolist(), (owner * capT + pos).tolist()))                      # cache row -> message row
+            lb.msg_link = dict(zip(cr[both].tolist(), rank[both].tolist()))                          # cache row -> position in the extra region
+            lb.msg_geom = (cap, cap2)
         return lb
 
     # ---- the group path (device-sampled batches: prepare_group routes the whole group and exchanges its request ids once) ----
@@ -71,13 +85,13 @@ class OracleOps(object):
     def route_layout(batch, world, cap):
         return {"req_ids": 0}, 8 * world * cap + 32          # one pool row per sampler slot: [owner][cap] ids (+ padding)
 
-    def route_group(self, batches, world, per, cap, pool, off, stride, overflow):
+    def route_group(self, batches, world, per, cap, pool, off, stride, overflow, cap2=0):
         self._slot = getattr(self, "_slot", {})
         pool64 = pool.view(torch.int64)
         for b in batches:
             class _Bf(object):
                 req_ids = pool64[b.slot * stride // 8:b.slot * stride // 8 + world * cap]
-            self._slot[b.slot] = self.route(b, world, per, cap, _Bf)
+            self._slot[b.slot] = self.route(b, world, per, cap, _Bf, cap2=cap2)
 
     def routed_batch(self, b, world, cap, pool, off, stride):
         ops, slot = self, b.slot
@@ -93,6 +107,8 @@ class OracleOps(object):
         for b in batches:
             owner = np.minimum(b.p["ue_id"] // per, world - 1)
             out[0] = max(int(out[0]), int(np.bincount(owner, minlength=world).max()))
+            both = np.isin(b.p["ue_id"], b.p["nid"]) & np.isin(b.p["ue_id"], b.p["neg_ids"])
+            out[1] = max(int(out[1]), int(np.bincount(owner[both], minlength=world).max()))
 
     def gather_req(self, table, ids, lo, out):
         for k, i in enumerate(ids.tolist()):
@@ -102,8 +118,24 @@ class OracleOps(object):
     def reset_rel_pads(self, rel_msg, d_r, first):
         rel_msg[first:, d_r + 1] = -1          # id kept as a number in the test double
 
-    def apply_merged(self, table, state, nsrc, cap, ids, lo, msg, ntraces, lr):
+    def apply_merged(self, table, state, nsrc, cap, ids, lo, msg, ntraces, lr, cap_extra=0):
         dim = table.shape[1]
+        if cap_extra:                          # packed single-trace messages: first message, then - link >= 0 - the one in the extra region
+            capT = cap + cap_extra
+            for k in range(nsrc * cap):
+                i = int(ids[k])
+                if i < 0:
+                    continue
+                i -= lo
+                s_, pos = divmod(k, cap)
+                link = int(msg[s_ * capT + pos, dim + 1])
+                for r in [s_ * capT + pos] + ([s_ * capT + cap + link] if link >= 0 else []):
+                    inc = msg[r, dim]
+                    if float(inc) == 0.0:
+                        continue
+                    state[i] += inc
+                    table[i] += (-lr * msg[r, :dim]) / (torch.sqrt(state[i]) + 1e-10)
+            return
         for k in range(nsrc * cap):            # source-major order = per row: sources in rank order, traces in order
             i = int(ids[k]) if ids is not None else int(msg[k, ntraces * dim + ntraces])
             if i < 0:
@@ -123,12 +155,34 @@ class OracleOps(object):
         out = O.forward_backward(self.cfg, cache.numpy().astype(np.float64), engine.rel.numpy().astype(np.float64),
                                  lp["nid"], p["h_local"], p["t_local"], p["rel_ids"], lp["neg"],
                                  bool(p["neg_head"]), p["chunk"], p["N"])
-        em = np.zeros((ent_msg.shape[0], 2 * D + 4))        # one message per unique row, AT THE ROW'S CACHE POSITION
-        em[lp["nid"], :D] = out["g_pos_ent"]
-        em[lp["nid"], 2 * D] = (out["g_pos_ent"] ** 2).mean(1)
-        np.add.at(em[:, D:2 * D], lp["neg"], out["g_neg"])
-        np.add.at(em[:, 2 * D + 1], lp["neg"], (out["g_neg"] ** 2).mean(1))
-        ent_msg.copy_(torch.from_numpy(em))
+        if ent_msg.shape[1] == D + 4:                       # packed: ONE trace per message row, the negative trace of a both-trace row
+            cap, cap2 = lb.msg_geom                         # in its bucket's extra region
+            capT = cap + cap2
+            n_cache = max(max(lb.msg_main), 0) + 1
+            gneg, sneg = np.zeros((n_cache, D)), np.zeros(n_cache)
+            np.add.at(gneg, lp["neg"], out["g_neg"])
+            np.add.at(sneg, lp["neg"], (out["g_neg"] ** 2).mean(1))
+            em = np.zeros((ent_msg.shape[0], D + 4))
+            em[:, D + 1] = -1
+            pos_rows = set(lp["nid"].tolist())
+            for k, cr in enumerate(lp["nid"].tolist()):
+                m = lb.msg_main[cr]
+                em[m, :D], em[m, D] = out["g_pos_ent"][k], (out["g_pos_ent"][k] ** 2).mean()
+            for cr in sorted(set(lp["neg"].tolist())):
+                m = lb.msg_main[cr]
+                if cr in pos_rows:
+                    link = lb.msg_link[cr]
+                    em[m, D + 1] = link
+                    m = (m // capT) * capT + cap + link
+                em[m, :D], em[m, D] = gneg[cr], sneg[cr]
+            ent_msg.copy_(torch.from_numpy(em))
+        else:
+            em = np.zeros((ent_msg.shape[0], 2 * D + 4))        # one message per unique row, AT THE ROW'S CACHE POSITION
+            em[lp["nid"], :D] = out["g_pos_ent"]
+            em[lp["nid"], 2 * D] = (out["g_pos_ent"] ** 2).mean(1)
+            np.add.at(em[:, D:2 * D], lp["neg"], out["g_neg"])
+            np.add.at(em[:, 2 * D + 1], lp["neg"], (out["g_neg"] ** 2).mean(1))
+            ent_msg.copy_(torch.from_numpy(em))
         ur = p["ur_id"]
         inv = np.searchsorted(ur, p["rel_ids"])
         if rel_msg is None:                   # relation partitioning: the step applies the relation trace itself (HipOps: update instance 7)
@@ -182,7 +236,7 @@ class _FakeSampler(object):
         return batches
 
 
-def _worker(rank, world, port, ret, cap=CAP, heavy=False, group=1, relpart=False, slots=False, sched=None):
+def _worker(rank, world, port, ret, cap=CAP, heavy=False, group=1, relpart=False, slots=False, sched=None, packed=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "dgl-ke_amd"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -199,7 +253,9 @@ def _worker(rank, world, port, ret, cap=CAP, heavy=False, group=1, relpart=False
         ent_shard = torch.from_numpy(ent[spec.lo:spec.hi].copy())
         state_shard = torch.zeros(spec.n_local, dtype=torch.float64)
         eng = FakeEngine(torch.from_numpy(rel.copy()), torch.zeros(N_REL, dtype=torch.float64), LR)
-        de = kd.DistEngine(eng, spec, ent_shard, state_shard, ops=OracleOps(cfg), cap=cap, rel_local=relpart)
+        de = kd.DistEngine(eng, spec, ent_shard, state_shard, ops=OracleOps(cfg, packed=packed), cap=cap, rel_local=relpart)
+        if packed:
+            de.cap2_start = 2                     # (a tiny extra region: the groups must grow it before they run)
         mine = []
         for step_batches in _batches(world, 3 if not heavy else 4, heavy, relpart):
             bt = step_batches[rank]
@@ -222,8 +278,8 @@ def _worker(rank, world, port, ret, cap=CAP, heavy=False, group=1, relpart=False
             grp = mine[g0:g0 + group]
             if slots:                             # the trainer's order with a device sampler: sample, prepare the group, run it
                 de.prepare_group(smp.fill(grp), log=logs.append)
-            elif heavy:                           # the trainer's order: size the buckets for the group, then run it
-                de.ensure_capacity(grp, log=logs.append)
+            elif heavy or packed:                 # the trainer's order: size the buckets (and the packed messages' extra region) for the
+                de.ensure_capacity(grp, log=logs.append)        # group, then run it
             if sched == "overlap":                # every exchange on the "side" queue (on CPU tensors: issued inline, in queue order)
                 if slots:                         # the trainer's order with a device sampler: the group routed ahead, ids exchanged once
                     grp = smp.fill(grp)
@@ -244,6 +300,7 @@ def _worker(rank, world, port, ret, cap=CAP, heavy=False, group=1, relpart=False
                 ret["stale_a2a"] = calls["a2a"] - n0
         if rank == 0:
             ret["cap"], ret["grown"], ret["logs"] = de.cap, list(getattr(de, "grown", [])), logs
+            ret["cap2"], ret["grown_extra"] = getattr(de, "cap2", 0), list(getattr(de, "grown_extra", []))
         if relpart:          # no relation exchange happened: collect the owners' rows on rank 0 (what A2ATrainer.sync_tables does)
             kd.relation_rows_from_owners(eng.rel, eng.rel_state, np.arange(N_REL) % world)
         # collect the shards on rank 0
@@ -296,12 +353,17 @@ def test_shard_spec_covers_all_ids():
 
 
 @pytest.mark.timeout(180)
-def test_sharded_step_world2_matches_single_process_statement():
+@pytest.mark.parametrize("packed", [False, True], ids=["two_trace_messages", "packed_messages"])
+def test_sharded_step_world2_matches_single_process_statement(packed):
+    """packed (round 6, HipOps' default message format): ONE trace per gradient message, the negative trace of a row that is in both
+    traces in a small extra region of its owner bucket that is sized per group like the bucket itself (it starts at 2 rows here)"""
     world = 2
     port = _free_port()
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, ret, CAP, False, 1, False, False, None, packed), nprocs=world, join=True)
+    if packed:
+        assert ret["grown_extra"] and ret["cap2"] > 2 and all(new > old and new >= need for old, new, need in ret["grown_extra"])
     ent, es, rel, rs = _expected(world)
     np.testing.assert_allclose(ret["ent"], ent, rtol=1e-9, atol=1e-11)
     np.testing.assert_allclose(ret["state"], es, rtol=1e-9, atol=1e-12)
@@ -332,8 +394,9 @@ def test_group_id_exchange_world2_one_id_all_to_all_per_group():
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("world,relpart,slots", [(2, False, False), (2, True, True), (4, False, True)])
-def test_overlapped_schedule_matches_the_one_step_stale_statement(world, relpart, slots):
+@pytest.mark.parametrize("world,relpart,slots,packed", [(2, False, False, False), (2, True, True, False), (4, False, True, False),
+                                                        (2, True, True, True), (4, False, True, True)])
+def test_overlapped_schedule_matches_the_one_step_stale_statement(world, relpart, slots, packed):
     """DistEngine._steps_overlapped (push, owner-side apply and the pull of step s+2 on the side queue, compute + the relation half
     on the main one; --async_update licence) over gloo: groups of 3 steps, host-built plans and sampler-slot batches routed by the
     step / ahead by the group, all-gathered and partitioned relations - against the fp64 statement in which a step that is not
@@ -341,7 +404,7 @@ def test_overlapped_schedule_matches_the_one_step_stale_statement(world, relpart
     port = _free_port()
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, port, ret, CAP, False, 3, relpart, slots, "overlap"), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, ret, CAP, False, 3, relpart, slots, "overlap", packed), nprocs=world, join=True)
     ent, es, rel, rs = _expected(world, relpart=relpart, stale_group=3)
     np.testing.assert_allclose(ret["ent"], ent, rtol=1e-9, atol=1e-11)
     np.testing.assert_allclose(ret["state"], es, rtol=1e-9, atol=1e-12)
@@ -353,7 +416,8 @@ def test_overlapped_schedule_matches_the_one_step_stale_statement(world, relpart
 
 
 @pytest.mark.timeout(300)
-def test_overlapped_schedule_world8_heavy_tailed_growing_buckets():
+@pytest.mark.parametrize("packed", [False, True], ids=["two_trace_messages", "packed_messages"])
+def test_overlapped_schedule_world8_heavy_tailed_growing_buckets(packed):
     """the overlapped schedule at world 8 on heavy-tailed ids with a deliberately small initial capacity: the buckets grow between
     groups - every exchange buffer, the second entity-message buffer and the route pool are rebuilt for the new capacity - and the
     tables equal the one-step-stale statement (groups of 2: every second step computes on rows pulled before its predecessor's
@@ -362,8 +426,9 @@ def test_overlapped_schedule_world8_heavy_tailed_growing_buckets():
     port = _free_port()
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, port, ret, 4, True, 2, False, True, "overlap"), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, ret, 4, True, 2, False, True, "overlap", packed), nprocs=world, join=True)
     assert ret["grown"] and ret["cap"] > 4
+    assert bool(ret["grown_extra"]) == packed and (ret["cap2"] > 2) == packed
     ent, es, rel, rs = _expected(world, heavy=True, stale_group=2)
     np.testing.assert_allclose(ret["ent"], ent, rtol=1e-9, atol=1e-11)
     np.testing.assert_allclose(ret["state"], es, rtol=1e-9, atol=1e-12)
@@ -371,14 +436,15 @@ def test_overlapped_schedule_world8_heavy_tailed_growing_buckets():
 
 
 @pytest.mark.timeout(300)
-def test_group_id_exchange_world8_heavy_tailed_growing_buckets():
+@pytest.mark.parametrize("packed", [False, True], ids=["two_trace_messages", "packed_messages"])
+def test_group_id_exchange_world8_heavy_tailed_growing_buckets(packed):
     """the same group path at world 8 on heavy-tailed ids with a deliberately small initial capacity: the buckets grow between
     groups (the route pool and the id-exchange buffers are rebuilt for the new capacity), nothing is dropped"""
     world = 8
     port = _free_port()
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, port, ret, 4, True, 2, False, True), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, ret, 4, True, 2, False, True, None, packed), nprocs=world, join=True)
     assert ret["grown"] and ret["cap"] > 4
     assert ret["a2a_calls"] == ret["groups"] + 2 * ret["steps"], dict(ret)
     ent, es, rel, rs = _expected(world, heavy=True)

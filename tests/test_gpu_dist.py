@@ -77,10 +77,15 @@ def test_route_fill_and_capacity_growth():
         bt = O.synth_batch(rng, n_ent, 7, B, N, N, k + 1)
         skew = lambda x: np.where(rng.rand(len(x)) < 0.7, x % per, x)          # 70 % of the ids fall into shard 0
         host.append(plan.make_batch(skew(bt["h"]), skew(bt["t"]), bt["r"], skew(bt["neg"]), N, N, bt["neg_head"], DEV))
-    out = torch.zeros(1, dtype=torch.int32, device=DEV)
+    out = torch.zeros(2, dtype=torch.int32, device=DEV)      # ABI 8: {largest bucket fill, most both-trace entries of one bucket}
     ops.route_fill(host, world, per, out)
     want = max(int(np.bincount(np.minimum(b.p["ue_id"] // per, world - 1), minlength=world).max()) for b in host)
-    assert int(out.item()) == want and want > 150
+
+    def both_max(ue, rec):
+        both = (rec[:, 3] > rec[:, 2]) & (rec[:, 5] > rec[:, 4])
+        return int(np.bincount(np.minimum(ue // per, world - 1)[both], minlength=world).max())
+    want2 = max(both_max(b.p["ue_id"], b.p["ue_rec"].reshape(-1, 8)) for b in host)
+    assert out.tolist() == [want, want2] and want > 150 and want2 > 0
     # consecutive sampler slots: ONE launch
     h = rng.randint(0, n_ent, 20000); t = rng.randint(0, n_ent, 20000); r = rng.randint(0, 7, 20000)
     h = np.where(rng.rand(20000) < 0.6, h % per, h)
@@ -94,7 +99,7 @@ def test_route_fill_and_capacity_growth():
         a = smp.slot_arrays(k)
         ue = a["ue_id"][:a["counts"][0]]
         fills.append(int(np.bincount(np.minimum(ue // per, world - 1), minlength=world).max()))
-    assert int(out.item()) == max(fills)
+    assert int(out[0].item()) == max(fills)
     # ensure_capacity at world 1 is a no-op (one owner: the bound); the growth rule itself on a world-8 spec without collectives
     class _NoComm(object):
         world, rank = 8, 0
@@ -503,3 +508,93 @@ def test_world1_local_shortcut_is_the_single_table_step(model):
     for x, y in zip(want, got["routed"]):
         assert float((x - y).abs().max()) <= 1e-3 * lr, "routed path vs in-place step"
     assert float((want[1] > 0).sum()) > 100
+
+
+
+def test_route_build_packed_message_rows_match_numpy():
+    """round 6 (ABI 8): kge_route_build with ue_msg - per union entry the row of its single-trace message, owner * (cap + cap2) +
+    position, and for an entry that is in BOTH traces the position of its second message in the bucket's extra region (its rank
+    among the both-trace entries of the bucket); entries beyond cap2 are counted in the overflow word."""
+    from dglke_amd import plan
+    from dglke_amd import dist as kd
+    rng = np.random.RandomState(13)
+    for world, n_ent, B, N, cap, cap2 in ((1, 300, 64, 16, None, 64), (2, 301, 64, 16, 120, 40), (4, 600, 96, 32, 90, 24),
+                                          (8, 900, 128, 32, 64, 3), (3, 5000, 512, 128, 700, 16)):     # (8, .., 3): the extra region overflows
+        bt = O.synth_batch(rng, n_ent, 7, B, N, N, 1)
+        b = plan.make_batch(bt["h"], bt["t"], bt["r"], bt["neg"], N, N, bt["neg_head"], DEV)
+        per = (n_ent + world - 1) // world
+        cap = cap or b.UE
+        bf = type("S", (), {})()
+        z = lambda n, dt: torch.zeros(n, dtype=dt, device=DEV)
+        bf.req_ids, bf.h_loc, bf.t_loc, bf.neg_loc = z(world * cap, torch.int64), z(B, torch.int64), z(B, torch.int64), z(b.C * N, torch.int64)
+        bf.ue_loc, bf.ue_rec_loc, bf.overflow, bf.ue_msg = z(b.UE, torch.int64), z(b.UE * 8, torch.int32), z(1, torch.int32), z(b.UE * 2, torch.int32)
+        lb = kd.HipOps().route(b, world, per, cap, bf, cap2=cap2)
+        torch.cuda.synchronize()
+        assert lb.msg_rows == bf.ue_msg.data_ptr()
+        ue, rec = b.p["ue_id"], b.p["ue_rec"].reshape(-1, 8)
+        owner = np.minimum(ue // per, world - 1)
+        start = np.searchsorted(owner, np.arange(world + 1))
+        pos = np.arange(len(ue)) - start[owner]
+        both = (rec[:, 3] > rec[:, 2]) & (rec[:, 5] > rec[:, 4])
+        rank = np.zeros(len(ue), np.int64)
+        for o in range(world):
+            m = owner == o
+            rank[m] = np.cumsum(both[m]) - both[m]
+        capT = cap + cap2
+        fits = pos < cap
+        want_main = np.where(fits, owner * capT + pos, world * capT)
+        want_extra = np.where(both & fits & (rank < cap2), rank, -1)
+        got = bf.ue_msg.cpu().numpy().reshape(-1, 2)[:len(ue)]
+        assert np.array_equal(got[:, 0], want_main) and np.array_equal(got[:, 1], want_extra), (world, cap2)
+        assert int(bf.overflow.item()) == int((~fits).sum()) + int((both & fits & (rank >= cap2)).sum())
+        assert both.sum() > 0
+
+
+@pytest.mark.parametrize("nsrc,cap,cap2,dim,n_rows", [(1, 40, 8, 8, 64), (2, 33, 5, 8, 40), (3, 100, 17, 64, 120), (8, 257, 64, 400, 600),
+                                                      (5, 7, 7, 1024, 12), (64, 9, 2, 8, 30)])
+def test_apply_merged_packed_messages_equal_sequential_apply(nsrc, cap, cap2, dim, n_rows):
+    """round 6 (ABI 8): packed single-trace messages [g | gs | link] - a row's first message, and for link >= 0 a second one in the
+    extra region of the SAME source's bucket, applied behind the first; rows from several sources in source order.  Against the
+    sequential numpy statement (kvserver.py:41-51 per pushed trace, tensor_models.py:316 trace order)."""
+    from dglke_amd import dist as kd
+    rng = np.random.RandomState(nsrc * 1000 + cap + cap2)
+    lo, lr = 1000, 0.1
+    ld, capT = dim + 4, cap + cap2
+    table = rng.randn(n_rows, dim).astype(np.float32)
+    state = rng.rand(n_rows).astype(np.float32)
+    ids = np.full((nsrc, cap), -1, np.int64)
+    msg = (rng.randn(nsrc * capT, ld) * 0.05).astype(np.float32)
+    msg[:, dim] = rng.rand(nsrc * capT).astype(np.float32) * 0.01
+    link = np.full((nsrc, cap), -1, np.int64)
+    for s in range(nsrc):
+        k = rng.randint(0, min(cap, n_rows) + 1)
+        ids[s, :k] = np.sort(rng.choice(n_rows, k, replace=False)) + lo
+        two = np.nonzero(rng.rand(k) < 0.3)[0][:cap2]            # rows that also carry a second (negative-trace) message
+        link[s, two] = rng.permutation(cap2)[:len(two)]          # any injective placement inside the extra region
+    sil = rng.rand(nsrc * capT) < 0.15
+    msg[sil, dim] = 0.0                                          # silent traces (increment 0) are skipped
+    mv = msg.view(np.int32)
+    for s in range(nsrc):
+        mv[s * capT:s * capT + cap, dim + 1] = link[s]
+    t_d, s_d = torch.from_numpy(table).to(DEV), torch.from_numpy(state).to(DEV)
+    kd.HipOps().apply_merged(t_d, s_d, nsrc, cap, torch.from_numpy(ids.reshape(-1)).to(DEV), lo, torch.from_numpy(msg).to(DEV), 1, lr,
+                             cap_extra=cap2)
+    torch.cuda.synchronize()
+    t64, s64 = table.astype(np.float64), state.astype(np.float64)
+    n_two = 0
+    for s in range(nsrc):
+        for p in range(cap):
+            i = ids[s, p]
+            if i < 0:
+                continue
+            rows = [s * capT + p] + ([s * capT + cap + link[s, p]] if link[s, p] >= 0 else [])
+            n_two += len(rows) == 2
+            for r in rows:
+                m = msg[r].astype(np.float64)
+                if m[dim] == 0.0:
+                    continue
+                s64[i - lo] += m[dim]
+                t64[i - lo] += -lr * m[:dim] / (np.sqrt(s64[i - lo]) + 1e-10)
+    np.testing.assert_allclose(s_d.cpu().numpy(), s64, rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(t_d.cpu().numpy(), t64, rtol=1e-5, atol=2e-6)
+    assert n_two > 0 or cap2 < 3
