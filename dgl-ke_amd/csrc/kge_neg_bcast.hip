@@ -748,17 +748,34 @@ template <int L> __device__ __forceinline__ float rowb(float v) {    // lane L o
 #ifndef LC_NO_SPLIT_REAL
 #define LC_SPLIT_REAL 1
 #endif
+// Wavefronts per workgroup (round 6).  The GN partials are one per WORKGROUP row group: a workgroup of 4 wavefronts x 8 rows sums 32
+// positives in LDS and cfg-R (chunk 256, D_e 800) left 8 partials per negative row - 26 MB written write-through and read back by the
+// reduction, the largest single item of that step's fabric traffic (profiles/r05_rotate_wide_pmc_*).  8 wavefronts per workgroup (64
+// positives meet in LDS) halve them at the same rows per wavefront, the same occupancy (two workgroups of 8 instead of four of 4 per
+// CU) and the same order of additions inside a wavefront; round 4 measured the launch times a wash (backward +0.5 us, reduction -0.4)
+// and dropped it, round 6 takes it for the bytes.  Wide RotatE rows only: at the FB15k shapes the partials are small.
+#ifndef LC_WPB8_MIN_DE
+#define LC_WPB8_MIN_DE 512
+#endif
+static inline int lc_wpb(int model, int d_e) {
+#ifdef LC_NO_WPB8
+    (void)model; (void)d_e; return 4;
+#else
+    return (model == KGE_ROTATE && d_e >= LC_WPB8_MIN_DE) ? 8 : 4;
+#endif
+}
 static inline void lc_shape(int model, int C, int chunk, int d_e, int &nslab, int &nrw, int &rpw) {
     const int K = model == KGE_ROTATE ? d_e / 2 : d_e;
+    const int wpb = lc_wpb(model, d_e);
     nslab = (K + LC_CW - 1) / LC_CW;
     const int rtmax = model == KGE_ROTATE ? 16 : LC_RTMAX;
     nrw = 1;
-    while ((chunk + 4 * nrw - 1) / (4 * nrw) > rtmax) ++nrw;
+    while ((chunk + wpb * nrw - 1) / (wpb * nrw) > rtmax) ++nrw;
     const int rpw_min = model == KGE_ROTATE ? LC_RPW_MIN_CPLX : LC_RPW_MIN_REAL;
     // (one more row group only while it still SHORTENS the wavefronts' row blocks: chunk = 256 went to nrw = 9 with 8 rows per
     //  wavefront - the ninth group held no rows and ran the whole arithmetic on zero weights, 11 % of the launch; round 4)
-    auto rows = [&](int n) { return (chunk + 4 * n - 1) / (4 * n); };
-    for (int n = nrw + 1; (int64_t)C * nslab * n <= 512 && rows(n) >= rpw_min; ++n)
+    auto rows = [&](int n) { return (chunk + wpb * n - 1) / (wpb * n); };
+    for (int n = nrw + 1; (int64_t)C * nslab * n <= 2048 / wpb && rows(n) >= rpw_min; ++n)
         if (rows(n) < rows(nrw)) nrw = n;
     rpw = rows(nrw);
 }
@@ -787,9 +804,10 @@ size_t neg_bwd_lc_partial_floats(int model, int C, int chunk, int N, int d_e) {
 #ifndef LC_WG_CAP
 #define LC_WG_CAP 1024                           // negatives are split while the launch stays within this many workgroups
 #endif
-template <int MODEL, int RT>
-__global__ __launch_bounds__(KGE_BLOCK) LC_OCC void neg_bwd_lc_kernel(NegArgs a, int nslab, int nrw, int rpw) {
+template <int MODEL, int RT, int WPB = KGE_WAVES_PER_BLOCK>
+__global__ __launch_bounds__(64 * WPB) LC_OCC void neg_bwd_lc_kernel(NegArgs a, int nslab, int nrw, int rpw) {
     KGE_TL(3);
+    constexpr int LC_BLOCK = 64 * WPB;                           // threads of the workgroup (WPB wavefronts: lc_wpb)
     constexpr bool CPLX = MODEL == KGE_ROTATE;
     constexpr int NV = CPLX ? 4 : 2;                             // floats per lane in a GN partial
     constexpr int LC_GQ = CPLX ? LC_GQ_CPLX : LC_GQ_REAL, LC_SG = 4 * LC_GQ;   // quads / negatives per group
@@ -798,8 +816,8 @@ __global__ __launch_bounds__(KGE_BLOCK) LC_OCC void neg_bwd_lc_kernel(NegArgs a,
 #else
     constexpr int NRED = 2;                                      // two alternating buffers
 #endif
-    __shared__ __attribute__((aligned(16))) float red[NRED * LC_GQ * KGE_WAVES_PER_BLOCK * 64 * NV];   // GN partials
-    __shared__ __attribute__((aligned(16))) float stage[2 * LC_SG * LC_CW * (CPLX ? 2 : 1) + 2 * KGE_WAVES_PER_BLOCK * LC_SG * (RT > 16 ? 32 : 16)];
+    __shared__ __attribute__((aligned(16))) float red[NRED * LC_GQ * WPB * 64 * NV];   // GN partials
+    __shared__ __attribute__((aligned(16))) float stage[2 * LC_SG * LC_CW * (CPLX ? 2 : 1) + 2 * WPB * LC_SG * (RT > 16 ? 32 : 16)];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63, sg = lane >> 4, kk = lane & 15;
     // a.ga_parts > 1: the quads of the chunk's negatives are split over that many workgroups per (chunk, slab, row group) - three
@@ -844,7 +862,7 @@ __global__ __launch_bounds__(KGE_BLOCK) LC_OCC void neg_bwd_lc_kernel(NegArgs a,
     const int col = slab * LC_CW + 2 * kk;
     const bool colok = col < K;                                  // K is even: both columns or none
     const int colc = colok ? col : 0;
-    const int r0 = (rw * KGE_WAVES_PER_BLOCK + wave) * rpw;      // first positive row of this wavefront
+    const int r0 = (rw * WPB + wave) * rpw;                      // first positive row of this wavefront
     const int rend = min(r0 + rpw, chunk);                       // rows [r0, rend)
 
     v2f xr[RT], xi[RT], gr[RT], gi[RT];
@@ -898,7 +916,7 @@ __global__ __launch_bounds__(KGE_BLOCK) LC_OCC void neg_bwd_lc_kernel(NegArgs a,
             *reinterpret_cast<float4 *>(yb + yp4) = sy0;
             if constexpr (CPLX) *reinterpret_cast<float4 *>(yb + LC_CW + yp4) = sy1;
         }
-        float *wb = wbuf + ((bf * KGE_WAVES_PER_BLOCK + wave) * LC_SG + wp4) * RTW + wrow;
+        float *wb = wbuf + ((bf * WPB + wave) * LC_SG + wp4) * RTW + wrow;
         const int s4 = 4 * qb + wp4;
         const bool sval = qb < nq && s4 + 3 < N;                 // N % 4 == 0: a float4 of negatives is all in or all out
 #pragma unroll
@@ -917,7 +935,7 @@ __global__ __launch_bounds__(KGE_BLOCK) LC_OCC void neg_bwd_lc_kernel(NegArgs a,
         const float *yb = ybuf + (bf * LC_SG + 4 * g + sg) * YF + 2 * kk;
         yr_ = *reinterpret_cast<const v2f *>(yb);
         yi_ = CPLX ? *reinterpret_cast<const v2f *>(yb + LC_CW) : (v2f){0.f, 0.f};
-        const float *wb = wbuf + ((bf * KGE_WAVES_PER_BLOCK + wave) * LC_SG + 4 * g + sg) * RTW + kk;
+        const float *wb = wbuf + ((bf * WPB + wave) * LC_SG + 4 * g + sg) * RTW + kk;
         w0_ = wb[0];
         w1_ = RT > 16 ? wb[16] : 0.f;
     };
@@ -949,7 +967,7 @@ __global__ __launch_bounds__(KGE_BLOCK) LC_OCC void neg_bwd_lc_kernel(NegArgs a,
                 nr = __builtin_elementwise_fma(sgn, wv, nr);
             }
         });
-        float *slot = redb + ((g * KGE_WAVES_PER_BLOCK + wave) * 64 + lane) * NV;
+        float *slot = redb + ((g * WPB + wave) * 64 + lane) * NV;
 #ifdef PROBE_BWD_NORED          // tuning probe (wrong results): the GN partials stay in registers (folded into GA so that they are not dead)
         gr[0] += nr; if constexpr (CPLX) gi[0] += ni;
         (void)slot;
@@ -970,7 +988,7 @@ __global__ __launch_bounds__(KGE_BLOCK) LC_OCC void neg_bwd_lc_kernel(NegArgs a,
 #endif
     int buf = 0;
     for (int qb = q_lo; qb < q_hi; qb += LC_GQ) {
-        float *redb = red + (NRED == 2 ? buf : 0) * (LC_GQ * KGE_WAVES_PER_BLOCK * 64 * NV);
+        float *redb = red + (NRED == 2 ? buf : 0) * (LC_GQ * WPB * 64 * NV);
         gload(min(qb + LC_GQ, nq - 1));                          // next group (past the end: a harmless re-read)
         v2f ya, yia, yb_, yib;
         float wa0, wa1, wb0, wb1;
@@ -1002,15 +1020,15 @@ __global__ __launch_bounds__(KGE_BLOCK) LC_OCC void neg_bwd_lc_kernel(NegArgs a,
         //  MI355X_MICROARCH.md - so a thread sums the partials of TWO adjacent lanes = four consecutive columns; per element the
         //  same additions in the same wavefront order as the per-lane form.  Measured: TransE_l1 53.7 -> 53.0 us/step; RotatE
         //  (two halves per lane) is 0.5-0.9 us FASTER with the per-lane 8-byte stores and keeps them; profiles/r04_store_policy.txt)
-        for (int e = tid; e < LC_GQ * (CPLX ? 64 : 32); e += KGE_BLOCK) {
+        for (int e = tid; e < LC_GQ * (CPLX ? 64 : 32); e += LC_BLOCK) {
             const int g = CPLX ? e >> 6 : e >> 5, r = CPLX ? e & 63 : (e & 31) * 2;
             const int l0 = r & ~1, part = CPLX ? r & 1 : 0;
-            const float *p = redb + (g * KGE_WAVES_PER_BLOCK * 64 + l0) * NV + 2 * part;
+            const float *p = redb + (g * WPB * 64 + l0) * NV + 2 * part;
             const int sN = 4 * (qb + g) + (l0 >> 4);
             const int cl = slab * LC_CW + 2 * (l0 & 15);
             v2f s0 = *reinterpret_cast<const v2f *>(p), s1 = *reinterpret_cast<const v2f *>(p + NV);
 #pragma unroll
-            for (int w = 1; w < KGE_WAVES_PER_BLOCK; ++w) {
+            for (int w = 1; w < WPB; ++w) {
                 s0 += *reinterpret_cast<const v2f *>(p + w * 64 * NV);
                 s1 += *reinterpret_cast<const v2f *>(p + w * 64 * NV + NV);
             }
@@ -1020,23 +1038,29 @@ __global__ __launch_bounds__(KGE_BLOCK) LC_OCC void neg_bwd_lc_kernel(NegArgs a,
             }
         }
         } else {
-        for (int e = tid; e < LC_GQ * 64; e += KGE_BLOCK) {
+        for (int e = tid; e < LC_GQ * 64; e += LC_BLOCK) {
             const int g = e >> 6, l = e & 63;
-            const float *p = redb + (g * KGE_WAVES_PER_BLOCK * 64 + l) * NV;
+            const float *p = redb + (g * WPB * 64 + l) * NV;
             const int sN = 4 * (qb + g) + (l >> 4);
             const int cl = slab * LC_CW + 2 * (l & 15);
             float *o = a.GNp + (((int64_t)rw * a.C + c) * N + sN) * D + cl;
             if constexpr (CPLX) {
-                const float4 v0 = *reinterpret_cast<const float4 *>(p), v1 = *reinterpret_cast<const float4 *>(p + 64 * NV);
-                const float4 v2 = *reinterpret_cast<const float4 *>(p + 2 * 64 * NV), v3 = *reinterpret_cast<const float4 *>(p + 3 * 64 * NV);
+                // (the wavefronts' partials in wavefront order: ((v0 + v1) + v2) + v3 [+ v4 ... + v7])
+                float4 pv[WPB];
+#pragma unroll
+                for (int w = 0; w < WPB; ++w) pv[w] = *reinterpret_cast<const float4 *>(p + w * 64 * NV);
+                float4 acc = pv[0];
+#pragma unroll
+                for (int w = 1; w < WPB; ++w) { acc.x += pv[w].x; acc.y += pv[w].y; acc.z += pv[w].z; acc.w += pv[w].w; }
                 if (sN < N && cl < K) {
-                    st_v2(o, (v2f){((v0.x + v1.x) + v2.x) + v3.x, ((v0.y + v1.y) + v2.y) + v3.y});
-                    st_v2(o + K, (v2f){((v0.z + v1.z) + v2.z) + v3.z, ((v0.w + v1.w) + v2.w) + v3.w});
+                    st_v2(o, (v2f){acc.x, acc.y});
+                    st_v2(o + K, (v2f){acc.z, acc.w});
                 }
             } else {
-                const v2f v0 = *reinterpret_cast<const v2f *>(p), v1 = *reinterpret_cast<const v2f *>(p + 64 * NV);
-                const v2f v2 = *reinterpret_cast<const v2f *>(p + 2 * 64 * NV), v3 = *reinterpret_cast<const v2f *>(p + 3 * 64 * NV);
-                if (sN < N && cl < K) st_v2(o, ((v0 + v1) + v2) + v3);
+                v2f acc = *reinterpret_cast<const v2f *>(p);
+#pragma unroll
+                for (int w = 1; w < WPB; ++w) acc += *reinterpret_cast<const v2f *>(p + w * 64 * NV);
+                if (sN < N && cl < K) st_v2(o, acc);
             }
         }
         }
@@ -1105,8 +1129,9 @@ static bool lc_balance(int model, int C, int chunk, int N, int d_e, int &P, int 
     if (rpw > (model == KGE_ROTATE ? 8 : 16)) return false;
     const int gq = model == KGE_ROTATE ? LC_GQ_CPLX : LC_GQ_REAL;
     const int ncol = C * nslab * nrw, ngr = ((N + 3) / 4 + gq - 1) / gq;
-    if (ncol < 1 || ncol > 1024) return false;
-    const int p = 1024 / ncol, nA = 1024 - ncol * p;
+    const int total = 4096 / lc_wpb(model, d_e);                 // workgroups of the balanced launch: 16 wavefronts per CU
+    if (ncol < 1 || ncol > total) return false;
+    const int p = total / ncol, nA = total - ncol * p;
     const int minpart = model == KGE_ROTATE ? 2 : 1;
     if (nA == 0 || p + 1 > (model == KGE_ROTATE ? 8 : 4) || ngr / (p + 1) < minpart) return false;      // (nA == 0: the uniform split already fills the chip evenly)
     P = p; nB = ncol - nA;
@@ -1129,7 +1154,7 @@ int neg_bwd_lc_splits(int model, int C, int chunk, int N, int d_e) {
     const int gq = model == KGE_ROTATE ? LC_GQ_CPLX : LC_GQ_REAL;
     const int ngr = ((N + 3) / 4 + gq - 1) / gq;
     int nsp = 1;
-    while (nsp < 8 && (int64_t)C * nslab * nrw * (nsp + 1) <= LC_WG_CAP && ngr / (nsp + 1) >= 2) ++nsp;
+    while (nsp < 8 && (int64_t)C * nslab * nrw * (nsp + 1) <= LC_WG_CAP * 4 / lc_wpb(model, d_e) && ngr / (nsp + 1) >= 2) ++nsp;
     return nsp;
 }
 int neg_bwd_lc_nrw(int model, int C, int chunk, int d_e) {
@@ -1148,11 +1173,24 @@ template <int MODEL> static int lc_launch(const NegArgs &a, hipStream_t s) {
     ab.lc_P = 0; ab.lc_nB = 0;
     {   // the balanced split when the caller's part count is the one it asks for (neg_bwd_lc_splits)
         int P, nB;
-        if (lc_balance(MODEL, a.C, a.chunk, a.N, a.d_e, P, nB) && a.ga_parts == P + 1) { ab.lc_P = P; ab.lc_nB = nB; nb = 1024; }
+        if (lc_balance(MODEL, a.C, a.chunk, a.N, a.d_e, P, nB) && a.ga_parts == P + 1) { ab.lc_P = P; ab.lc_nB = nB; nb = 4096 / lc_wpb(MODEL, a.d_e); }
     }
     const NegArgs &a_ = ab;
     const dim3 g((unsigned)nb), b(KGE_BLOCK);
     // rows per wavefront rounded up to the next instantiation (the padding rows carry W = 0)
+    if constexpr (MODEL == KGE_ROTATE) {
+        if (lc_wpb(MODEL, a.d_e) == 8) {          // wide rows: 8 wavefronts per workgroup (lc_wpb)
+            const dim3 b8(512);
+            if (rpw <= 8) hipLaunchKernelGGL((neg_bwd_lc_kernel<MODEL, 8, 8>), g, b8, 0, s, a_, nslab, nrw, rpw);
+            else if (rpw <= 12) hipLaunchKernelGGL((neg_bwd_lc_kernel<MODEL, 12, 8>), g, b8, 0, s, a_, nslab, nrw, rpw);
+            else hipLaunchKernelGGL((neg_bwd_lc_kernel<MODEL, 16, 8>), g, b8, 0, s, a_, nslab, nrw, rpw);
+            if (int rc = check_launch_b()) return rc;
+            if (a.defer_reduce) return KGE_OK;
+            const int64_t n4w = (int64_t)a.C * a.N * a.d_e / 4 + (a.ga_parts > 1 ? (int64_t)a.C * a.chunk * a.d_e / 4 : 0);
+            hipLaunchKernelGGL(gn_reduce_kernel, dim3((unsigned)((n4w + KGE_BLOCK - 1) / KGE_BLOCK)), dim3(KGE_BLOCK), 0, s, a, nrw);
+            return check_launch_b();
+        }
+    }
     if (rpw <= 8) hipLaunchKernelGGL((neg_bwd_lc_kernel<MODEL, 8>), g, b, 0, s, a_, nslab, nrw, rpw);
     else if (rpw <= 12) hipLaunchKernelGGL((neg_bwd_lc_kernel<MODEL, 12>), g, b, 0, s, a_, nslab, nrw, rpw);
     else if (rpw <= 16) hipLaunchKernelGGL((neg_bwd_lc_kernel<MODEL, 16>), g, b, 0, s, a_, nslab, nrw, rpw);
