@@ -632,35 +632,7 @@ def main(args, world, rank, local_rank):
     # pull pipeline; --async_update licence).  Exactly K steps between barriers, like the headline: when it is faster, emit()
     # makes it the line's value and keeps the first measurement beside it.  Which one wins depends on what the exchanges cost on
     # the links; at world 1 with forced collectives: 136.7 (synchronous) / 117.7 us (overlapped), profiles/r05_overlap_schedule.txt
-    # ---- diagnostics (round 6, VERDICT r05 next-7): per rank, the communicator's creation time, the owner buckets' capacity and growth
-    # events, and ONE group of eager synchronous steps with a HIP event behind every phase (route / ids a2a / gather / rows a2a /
-    # compute / push / apply, DistEngine.profile_phases) - so that the first run on a multi-GPU node explains itself in one shot.
-    # Behind the delivered headline and under its own watchdog; the supervisor files it under config.attempts[-1].diagnostics.
     diag = None
-    if mode == "a2a" and os.environ.get("KGE_DIST_DIAG", "1") != "0":
-        done_d = threading.Event()
-
-        def watchdog_d():
-            if not done_d.wait(float(os.environ.get("KGE_DIST_LEG_TIMEOUT", "120"))):
-                emit({"error": "the diagnostics leg did not finish in time (watchdog)"})
-                os._exit(0)
-        threading.Thread(target=watchdog_d, daemon=True).start()
-        try:
-            smp_ = _de.bench_sampler
-            torch.cuda.synchronize(); dist.barrier()
-            ph = _de.profile_phases(smp_.sample(min(smp_.n_slots, 20)))
-            mine = {"rank": rank, "communicator": type(_de.comm).__name__ if _de.coll else None,
-                    "communicator_create_s": getattr(_de, "comm_create_s", None), "bucket_rows": _de.cap,
-                    "bucket_growth": [list(g) for g in getattr(_de, "grown", [])] or None,
-                    "message_extra_rows": getattr(_de, "cap2", 0) or None,
-                    "message_extra_growth": [list(g) for g in getattr(_de, "grown_extra", [])] or None,
-                    "phase_us_per_step": ph}
-            alls = [None] * world
-            dist.all_gather_object(alls, mine)
-            diag = alls
-        except Exception as e:          # noqa: BLE001 - a diagnostic must never cost the line
-            diag = [{"rank": rank, "error": repr(e)}]
-        done_d.set()
     pipe_leg = None
     other_sched = False if sched_name != "synchronous" else "overlap"
     if (mode == "a2a" and _de.coll and rows.get("launch") == "graph" and
@@ -761,6 +733,34 @@ def main(args, world, rank, local_rank):
         except Exception as e:          # noqa: BLE001
             local_leg = {"error": repr(e)}
         done.set()
+    # ---- diagnostics (round 6, VERDICT r05 next-7): per rank, the communicator's creation time, the owner buckets' capacity and growth
+    # events, and ONE group of eager synchronous steps with a HIP event behind every phase (route / ids a2a / gather / rows a2a /
+    # compute / push / apply, DistEngine.profile_phases) - so that the first run on a multi-GPU node explains itself in one shot.
+    # The LAST leg (a hang here costs nothing else), behind the delivered headline and under its own watchdog; the supervisor files it under config.attempts[-1].diagnostics.
+    if mode == "a2a" and os.environ.get("KGE_DIST_DIAG", "1") != "0":
+        done_d = threading.Event()
+
+        def watchdog_d():
+            if not done_d.wait(float(os.environ.get("KGE_DIST_LEG_TIMEOUT", "120"))):
+                emit({"error": "the diagnostics leg did not finish in time (watchdog)"})
+                os._exit(0)
+        threading.Thread(target=watchdog_d, daemon=True).start()
+        try:
+            smp_ = _de.bench_sampler
+            torch.cuda.synchronize(); dist.barrier()
+            ph = _de.profile_phases(smp_.sample(min(smp_.n_slots, 20)))
+            mine = {"rank": rank, "communicator": type(_de.comm).__name__ if _de.coll else None,
+                    "communicator_create_s": getattr(_de, "comm_create_s", None), "bucket_rows": _de.cap,
+                    "bucket_growth": [list(g) for g in getattr(_de, "grown", [])] or None,
+                    "message_extra_rows": getattr(_de, "cap2", 0) or None,
+                    "message_extra_growth": [list(g) for g in getattr(_de, "grown_extra", [])] or None,
+                    "phase_us_per_step": ph}
+            alls = [None] * world
+            dist.all_gather_object(alls, mine)
+            diag = alls
+        except Exception as e:          # noqa: BLE001 - a diagnostic must never cost the line
+            diag = [{"rank": rank, "error": repr(e)}]
+        done_d.set()
     line = emit(leg, now=False)
     try:
         dist.barrier()

@@ -460,8 +460,12 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         if (!rl) rm = kge::ShardMap{sh->rel_rows, sh->rel_state, sh->rel_rows_per_shard, sh->n_shards};
     }
     if (int rc = check_model(hp->model, hp->d_e, hp->d_r)) return rc;
-    if (hp->model == KGE_RESCAL && (emit || (sh && !sh->rel_local)))
-        return fail(KGE_ERR_ARG, "RESCAL: not in the gradient-emitting step; on sharded tables it needs kge_shards.rel_local (ABI 8)");
+    // (round 6: the relation-matrix models in the gradient-emitting step when the relation side is applied IN PLACE - emit->gr NULL,
+    //  the all-to-all engine under relation partitioning: their kernels run against the row cache like every model's, the relation
+    //  matrices / projection rows of the batch belong to this rank and are updated here, only entity messages leave)
+    if (hp->model == KGE_RESCAL && ((emit && emit->gr) || (sh && !sh->rel_local)))
+        return fail(KGE_ERR_ARG, "RESCAL: the gradient-emitting step needs the relation trace in place (emit.gr NULL: relation partitioning); "
+                                 "on sharded tables it needs kge_shards.rel_local (ABI 8)");
     if (b->B <= 0 || b->C <= 0 || b->chunk <= 0 || b->N <= 0 || (int64_t)b->C * b->chunk != b->B)
         return fail(KGE_ERR_ARG, "kge_step: need C*chunk == B (B=%d C=%d chunk=%d)", b->B, b->C, b->chunk);
     if (hp->loss_genre < KGE_LOSS_LOGSIGMOID || hp->loss_genre > KGE_LOSS_BCE)
@@ -549,7 +553,7 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
     const kge_tables *tbx = sh_dense ? &tbd : tb;  // what the TransR / RESCAL kernels read
     const kge_batch *bx = sh_dense ? &bd : b;
     if (transr) {
-        if (emit) return fail(KGE_ERR_ARG, "TransR is not available in the gradient-emitting step");
+        if (emit && emit->gr) return fail(KGE_ERR_ARG, "TransR: the gradient-emitting step needs the relation trace in place (emit.gr NULL: relation partitioning)");
         if (sh && !sh->rel_local) return fail(KGE_ERR_ARG, "TransR on sharded tables needs kge_shards.rel_local / proj_local (ABI 8)");
         if (!tbx->proj || !tbx->proj_state) return fail(KGE_ERR_ARG, "TransR needs kge_tables.proj / proj_state");
         tr.HP = cv.f((size_t)B * d_r); tr.TP = cv.f((size_t)B * d_r); tr.Q = cv.f((size_t)B * d_r);

@@ -391,6 +391,8 @@ class HipOps(object):
             tb.ent, tb.ent_state = _lib.ptr(cache), _lib.ptr(zero_state)
             tb.rel, tb.rel_state = _lib.ptr(engine.rel), _lib.ptr(engine.rel_state)
             tb.n_ent, tb.n_rel = cache.shape[0], engine.rel.shape[0]
+            if getattr(engine, "proj", None) is not None:      # TransR: the rank's own projection table (relation partitioning)
+                tb.proj, tb.proj_state = _lib.ptr(engine.proj), _lib.ptr(engine.proj_state)
             em = _lib.KgeEmit()
             e0 = ent_msg.data_ptr()
             if ent_msg.shape[1] == d_e + 4:            # packed single-trace messages: [g | gs | link . .]; rows from lb.msg_rows
@@ -534,7 +536,8 @@ class DistEngine(object):
             self.slots.append(s)
         self.ent_msg = z((W * capT + 1, ld_e), dt)
         self.recv_msg = self.ent_msg[:W * capT] if not self.coll else z((W * capT, ld_e), dt)
-        self.rel_msg = z((b.B, ld_r), dt)
+        # (relation trace applied in place - relation partitioning: no relation messages at all; RESCAL's "row" is a d_e x d_e matrix)
+        self.rel_msg = z((b.B, ld_r), dt) if not self._rel_inplace else z((1, 4), dt)
         self.all_rel = self.rel_msg if (not self.coll or self.rel_local) else z((W * b.B, ld_r), dt)
         self.zero_state = z(W * cap + 1, dt)
         self._ent_msg_alt = None      # the second entity-message buffer of the overlapped schedule (_steps_overlapped): made on first use

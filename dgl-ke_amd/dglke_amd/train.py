@@ -102,10 +102,9 @@ class ArgParser(argparse.ArgumentParser):
         a('--dist_mode', default='a2a', choices=['a2a', 'p2p'],
           help='multi-GPU training (--gpu g0 g1 ...): a2a = entity table range-sharded, relation table replicated, RCCL '
                'all-to-all pull / push with owner-side Adagrad (parameter-server semantics); p2p = both tables sharded and '
-               'mapped peer to peer (hipIpc), Hogwild across the trainers, no collective.  TransR and RESCAL train in p2p mode: entity '
-               'table sharded, relation rows / matrices and the projection table local to the trainers, triples partitioned by '
-               'relation (the reference\'s --rel_part layout); a2a covers TransE_l1/l2, DistMult, ComplEx, RotatE and SimplE and '
-               'hands the other two to p2p')
+               'mapped peer to peer (hipIpc), Hogwild across the trainers, no collective.  TransR and RESCAL train in both modes '
+               'with the entity table sharded, relation rows / matrices and the projection table local to the trainers and the '
+               'triples partitioned by relation (the reference\'s --rel_part layout)')
         a('--seed', type=int, default=0, help='seed of the table initialisation and of the device sampler')
         a('--graph_steps', type=int, default=100, help='steps per captured hipGraph (0: eager launches)')
         a('--target_mrr', type=float, default=None,
@@ -501,6 +500,10 @@ class ShardedTrainer(object):
     def close(self):
         self.tabs.close()
 
+    def projection(self):
+        """TransR: the projection table as rank 0 holds it after sync_tables()"""
+        return self.tabs.proj_tab
+
     def full_tables(self):
         """the whole entity / relation tables read through the shard map (rank-local copies)."""
         ds = self.dataset
@@ -524,7 +527,7 @@ class ShardedTrainer(object):
             known = tuple(np.concatenate([np.asarray(p[k]) for p in parts]) for k in range(3))
         ent, rel = self.full_tables()
         Eb = int(max(1, min(max(args.batch_size_eval, 1024), (1 << 31) // (4 * ds.n_entities), len(h))))
-        proj = getattr(getattr(self, 'tabs', None), 'proj_tab', None) if args.model_name == 'TransR' else None
+        proj = self.projection() if args.model_name == 'TransR' else None
         if proj is not None:
             Eb = min(Eb, 64)                  # TransR projects every candidate with every test triple's matrix
         metrics = kev.evaluate(args.model_name, ent, rel, args.gamma, self.emb_init, (h, r, t), known, batch=Eb, proj=proj,
@@ -605,8 +608,12 @@ class A2ATrainer(ShardedTrainer):
         # cannot build - edge importance, or more than 4096 ids per batch - come from the host sampler: plans built on the host,
         # routed and exchanged step by step, eager launches (the same sharded step; slower: the host builds a plan per step)
         self.device_sampler = 2 * B + (B // self.chunk) * N <= 4096 and not args.has_edge_importance
-        if args.model_name in ('RESCAL', 'TransR'):
-            raise KgeError("--dist_mode a2a covers TransE_l1/l2, DistMult, ComplEx, RotatE, SimplE (use --dist_mode p2p)")
+        # TransR / RESCAL (round 6): the relation side - relation rows / matrices, TransR's projection table - is applied IN PLACE on the
+        # trainer that holds the relation's edges, so the triples are always partitioned by whole relations for these two (the
+        # reference's own multi-GPU TransR recipe passes --rel_part, examples/freebase/multi_gpu.sh:80-89); only entity messages travel
+        self.rel_side_local = args.model_name in ('RESCAL', 'TransR')
+        if self.rel_side_local and args.neg_deg_sample:
+            raise KgeError("--neg_deg_sample is not available for %s on more than one GPU" % args.model_name)
         d_e = args.hidden_dim * (2 if args.double_ent else 1)
         self.emb_init = (args.gamma + 2.0) / args.hidden_dim
         self.spec = kd.ShardSpec(dataset.n_entities, world, rank)
@@ -627,12 +634,12 @@ class A2ATrainer(ShardedTrainer):
         # large relations dealt over all trainers).  While every relation lives on ONE trainer its row is updated there and nowhere
         # else - no relation exchange (dist.DistEngine rel_local); with split relations the relation gradients are all-gathered
         # and applied by every trainer like without --rel_part (exact for any edge split), only the edge shares are the reference's
-        self.rel_part = bool(getattr(args, 'rel_part', False))
+        self.rel_part = bool(getattr(args, 'rel_part', False)) or self.rel_side_local
         tr = dataset.train
         self.rel_owner, self.rel_local, part = None, False, None
         if self.rel_part:
             mode, edge_rank, self.rel_owner, cross = kd.choose_relation_partition(
-                tr[1], world, getattr(args, 'rel_part_policy', 'auto'))
+                tr[1], world, 'whole' if self.rel_side_local else getattr(args, 'rel_part_policy', 'auto'))
             self.rel_local = len(cross) == 0
             part = np.nonzero(edge_rank == rank)[0]
             cnt = np.bincount(edge_rank, minlength=world)
@@ -677,6 +684,10 @@ class A2ATrainer(ShardedTrainer):
         if rank == 0:
             print("multi-GPU mode a2a: entity rows %d per GPU, relations replicated, collectives: %s"
                   % (self.spec.shard, type(self.comm).__name__))
+            if self.rel_side_local:
+                print("%s on %d GPUs (a2a): entity messages exchanged, relation-side tables (relation rows%s) applied in place on the "
+                      "trainer that holds the relation's edges" % (args.model_name, world,
+                                                                    ", projection matrices" if args.model_name == 'TransR' else " = matrices"))
 
     def _enqueue(self, n):
         """n sharded steps, eagerly (every rank issues the same collectives in the same order); inside a group of sampled
@@ -711,11 +722,16 @@ class A2ATrainer(ShardedTrainer):
         if self.rel_local:                   # every replica holds the current rows of ITS relations only: collect them on rank 0
             from . import dist as kd
             kd.relation_rows_from_owners(self.engine.rel, self.engine.rel_state, self.rel_owner)
+            if self.engine.proj is not None:     # TransR: the projection rows live with their relation
+                kd.relation_rows_from_owners(self.engine.proj, self.engine.proj_state, self.rel_owner)
         if self.rank == 0:
             self._full = (th.cat(parts).to(self.dev), self.engine.rel)
 
     def full_tables(self):
         return self._full
+
+    def projection(self):
+        return self.engine.proj
 
     def close(self):
         self.de.close()              # the group graphs first, then the communicator (dist.RcclComm.close)
@@ -733,11 +749,6 @@ def _mp_worker(rank, args, port):
                               args.has_edge_importance)
         sys.stdout = sys.__stdout__
         a2a = args.dist_mode == 'a2a'
-        if a2a and args.model_name in ('RESCAL', 'TransR'):
-            # what the all-to-all step does not cover runs on the peer-to-peer shared tables instead of failing
-            if rank == 0:
-                print('--dist_mode a2a does not cover {}: using --dist_mode p2p'.format(args.model_name))
-            a2a = False
         trainer = (A2ATrainer if a2a else ShardedTrainer)(args, dataset, rank, world)
         if rank == 0:
             print('Total initialize time {:.3f} seconds'.format(time.time() - init_time_start))
@@ -757,7 +768,7 @@ def _mp_worker(rank, args, port):
                     np.save(os.path.join(args.save_path, '%s_%s_relation.npy' % (args.dataset, args.model_name)), rel.cpu().numpy())
                     if args.model_name == 'TransR':      # TransRScore.save (score_fun.py:190-191): <dataset>_<model>projection.npy
                         np.save(os.path.join(args.save_path, '%s_%sprojection.npy' % (args.dataset, args.model_name)),
-                                trainer.tabs.proj_tab.cpu().numpy())
+                                trainer.projection().cpu().numpy())
                     conf = dict(vars(args))
                     conf.update({'emp_file': dataset.emap_fname, 'rmap_file': dataset.rmap_fname})
                     with open(os.path.join(args.save_path, 'config.json'), 'w') as f:
