@@ -432,7 +432,7 @@ class DistEngine(object):
     rank's shard.  Batches carry GLOBAL entity ids and their plan (DeviceSampler slots or plan.upload)."""
 
     def __init__(self, engine, spec, ent_shard, ent_state_shard, ops=None, comm=None, cap=None, slack=1.5,
-                 always_collective=False, rel_local=False):
+                 always_collective=False, rel_local=False, ue_bound=None):
         self.engine = engine
         self.spec = spec
         self.ent = ent_shard
@@ -446,6 +446,10 @@ class DistEngine(object):
         self.d_e = ent_shard.shape[1]
         self.d_r = engine.rel.shape[1]
         self.cap, self.slack = cap, slack
+        # ue_bound: the number of unique entities the exchange buffers are sized for, when the batches carry their EXACT count
+        # (host-built plans; ADVICE r05: callers used to overwrite batch.UE with the bound).  None: the first batch's UE is the bound
+        # (device-sampled batches, whose UE already is one)
+        self.ue_bound = int(ue_bound) if ue_bound else None
         # packed single-trace entity messages (HipOps.packed_messages, round 6): cap2 = rows of a bucket's extra region (second
         # messages of the rows that are in both traces); 0 = two-trace messages (test doubles, KGE_DIST_PACKED=0)
         self.packed = bool(getattr(self.ops, "packed_messages", False))
@@ -484,13 +488,13 @@ class DistEngine(object):
     def _setup(self, b):
         W = self.spec.world
         if self.cap is None:
-            self.cap = default_cap(b.UE, W, self.slack)
+            self.cap = default_cap(self.ue_bound or b.UE, W, self.slack)
         if self.packed:
             # an entry is in both traces when a positive entity is also drawn as a negative: rare on large graphs (Freebase shard:
             # ~0.02 per batch), common on small ones - start small, ensure_capacity sizes it per group like the buckets.  Without an
             # exchange (world 1, no collective) nothing is read back per group: the region then holds a whole bucket
             self.cap2 = self.cap if not self.coll else max(1, min(self.cap, int(getattr(self, "cap2_start", 64))))
-        self.geom = (b.B, b.C * b.N, b.UE)
+        self.geom = (b.B, b.C * b.N, self.ue_bound or b.UE)
         self.grown = []               # (old cap, new cap, fill that asked for it): ensure_capacity's record
         self.grown_extra = []         # the same for the extra region of the packed messages
         self.overflow = torch.zeros(1, dtype=torch.int32, device=self.dev)
@@ -528,8 +532,9 @@ class DistEngine(object):
             s.req_ids = z(W * cap, torch.int64)
             s.recv_ids = s.req_ids if not self.coll else z(W * cap, torch.int64)
             s.h_loc, s.t_loc, s.neg_loc = z(b.B, torch.int64), z(b.B, torch.int64), z(b.C * b.N, torch.int64)
-            s.ue_loc, s.ue_rec_loc = z(b.UE, torch.int64), z(b.UE * 8, torch.int32)
-            s.ue_msg = z(b.UE * 2, torch.int32)
+            ue = self.ue_bound or b.UE
+            s.ue_loc, s.ue_rec_loc = z(ue, torch.int64), z(ue * 8, torch.int32)
+            s.ue_msg = z(ue * 2, torch.int32)
             s.cache = z((W * cap + 1, self.d_e), dt)              # + the dump row of overflowing entries
             s.rows_out = s.cache[:W * cap] if not self.coll else z((W * cap, self.d_e), dt)
             s.overflow = self.overflow
@@ -676,6 +681,12 @@ class DistEngine(object):
         self.close_graphs()
         if hasattr(self.comm, "close"):
             self.comm.close()
+
+    def run_steps(self, batches, pipelined=False):
+        """the steps of one group of batches, eagerly, under the given schedule (False: synchronous; True: the pull of step s+1 next
+        to step s; "overlap": every exchange on the side stream) - what run_group records into its graphs; callers with host-built
+        plans (no sampler slots) use this after ensure_capacity()."""
+        return self._steps(batches, pipelined)
 
     def _steps(self, batches, pipelined):
         if self.local_only:                           # (no exchange to overlap: every schedule is the same in-place steps)
@@ -828,6 +839,14 @@ class DistEngine(object):
                pipelined if isinstance(pipelined, str) else bool(pipelined))
         g = self._ggraphs.get(key)
         if g is None:
+            # (marks that are not multiples of each other produce many distinct group lengths; every graph pins buffers and
+            #  - through its recorded collectives - communicator plans.  The cache is bounded: the oldest graph goes first)
+            while len(self._ggraphs) >= int(getattr(self, "max_group_graphs", 16)):
+                old = next(iter(self._ggraphs))
+                try:
+                    self._ggraphs.pop(old).reset()
+                except Exception:       # noqa: BLE001
+                    pass
             self.prepare_group(batches, check_capacity=False)      # this group: eagerly (allocates the pool and every buffer) ...
             self._steps(batches, pipelined)
             g = torch.cuda.CUDAGraph()                             # ... and recorded (nothing executes) for the groups to come
@@ -889,7 +908,7 @@ class DistEngine(object):
     def pull(self, batch, slot):
         if self.slots is None:
             self._setup(batch)
-        if (batch.B, batch.C * batch.N, batch.UE) != self.geom:
+        if (batch.B, batch.C * batch.N) != self.geom[:2] or (batch.UE > self.geom[2] if self.ue_bound else batch.UE != self.geom[2]):
             raise _lib.KgeError("DistEngine: batch geometry changed (B, C*N, UE bound) %r -> %r" % (self.geom, (batch.B, batch.C * batch.N, batch.UE)))
         sp, s, W = self.spec, self.slots[slot], self.spec.world
         lb = self._routed_ahead(batch)               # routed by prepare_group - the owners already hold this step's request ids

@@ -105,6 +105,12 @@ class ArgParser(argparse.ArgumentParser):
                'mapped peer to peer (hipIpc), Hogwild across the trainers, no collective.  TransR and RESCAL train in both modes '
                'with the entity table sharded, relation rows / matrices and the projection table local to the trainers and the '
                'triples partitioned by relation (the reference\'s --rel_part layout)')
+        a('--dist_schedule', default=None, choices=['sync', 'pull', 'overlap'],
+          help='--dist_mode a2a: where a step\'s exchanges run.  sync: on the compute stream, every step pulls after its predecessor\'s '
+               'update has landed (default without --async_update); pull / overlap (need --async_update: one-step-stale entity rows): the '
+               'next step\'s pull, or every exchange, on a side stream next to the compute (overlap: default with --async_update).  '
+               'With --graph_steps > 0 the group - kernels and RCCL collectives - replays from one hipGraph; --graph_steps 0 launches '
+               'eagerly (the way out if a recorded schedule ever stalls on a new software stack)')
         a('--seed', type=int, default=0, help='seed of the table initialisation and of the device sampler')
         a('--graph_steps', type=int, default=100, help='steps per captured hipGraph (0: eager launches)')
         a('--target_mrr', type=float, default=None,
@@ -657,7 +663,8 @@ class A2ATrainer(ShardedTrainer):
                 raise KgeError("--rel_part: trainer %d gets %d training triples, fewer than --batch_size %d (%d relations over %d "
                                "trainers)" % (int(cnt.argmin()), int(cnt.min()), B, int((self.rel_owner != -1).sum()), world))   # any collective
         self.de = kd.DistEngine(self.engine, self.spec, self.ent, self.ent_state, comm=self.comm, slack=slack,
-                                rel_local=self.rel_local)
+                                rel_local=self.rel_local,
+                                ue_bound=None if self.device_sampler else 2 * B + (B // self.chunk) * N)
         # exchanges may overlap the steps only under the staleness --async_update licenses (tensor_models.py:136-175): then push,
         # owner-side apply and the pull of step s+2 run on a side stream next to step s+1 (DistEngine._steps_overlapped: entity rows
         # exactly one step stale, relation rows current; KGE_DIST_PIPELINE=1: the pull only, the same tables bit for bit);
@@ -665,6 +672,14 @@ class A2ATrainer(ShardedTrainer):
         self.pipelined = bool(getattr(args, 'async_update', False))
         if self.pipelined and os.environ.get("KGE_DIST_PIPELINE", "overlap") == "overlap":
             self.pipelined = "overlap"
+        # --dist_schedule (the schedule used to be reachable through an environment variable only): sync = every step pulls
+        # after its predecessor's update (what runs without --async_update), pull = the pull of step s+1 next to step s, overlap = every
+        # exchange on a side stream (the default with --async_update); the two stale schedules need the flag's licence
+        sched = getattr(args, 'dist_schedule', None)
+        if sched:
+            if sched != 'sync' and not getattr(args, 'async_update', False):
+                raise KgeError("--dist_schedule %s computes on one-step-stale entity rows: it needs --async_update" % sched)
+            self.pipelined = {'sync': False, 'pull': True, 'overlap': 'overlap'}[sched]
         if part is None:
             part = np.array_split(np.random.RandomState(args.seed).permutation(len(tr[0])), world)[rank]
         if len(part) < B:
@@ -679,7 +694,6 @@ class A2ATrainer(ShardedTrainer):
             w = np.asarray(tr[3])[part] if args.has_edge_importance else None
             self.sampler = UniformChunkedSampler(h, r, t, dataset.n_entities, B, N, self.dev, neg_chunk_size=self.chunk,
                                                  seed=args.seed + 1000 * rank, edge_importance=w)
-            self._ue_bound = 2 * B + (B // self.chunk) * N       # the exchange buffers are sized once, for the bound
         self._full = None
         if rank == 0:
             print("multi-GPU mode a2a: entity rows %d per GPU, relations replicated, collectives: %s"
@@ -697,10 +711,8 @@ class A2ATrainer(ShardedTrainer):
         while not self.device_sampler and done < n:          # host-built plans: groups of <= 16 steps, each routed by its own step
             k = min(16, n - done)
             bs = smp.next_batches(k)
-            for b in bs:
-                b.UE = self._ue_bound
             self.de.ensure_capacity(bs, log)                 # (one device read per group; every rank decides alike)
-            self.de._steps(bs, self.pipelined)
+            self.de.run_steps(bs, self.pipelined)
             done += k
         while done < n:
             k = min(smp.n_slots, n - done)
