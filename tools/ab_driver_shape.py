@@ -7,6 +7,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "dgl-ke_amd")):
     sys.path.insert(0, p)
 import numpy as np
+if os.environ.get("AB_SPIN"):      # experiment: spin-wait synchronise (hipDeviceScheduleSpin = 1, Yield = 2, BlockingSync = 4) set before the context exists
+    import ctypes
+    _hip = ctypes.CDLL("libamdhip64.so")
+    print("hipSetDeviceFlags(%s) ->" % os.environ["AB_SPIN"], _hip.hipSetDeviceFlags(ctypes.c_uint(int(os.environ["AB_SPIN"]))), flush=True)
 import torch
 import bench
 from dglke_amd.dataloader import DeviceSampler, PrefetchedGroups
