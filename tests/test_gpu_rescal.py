@@ -140,3 +140,47 @@ def test_matrix_models_random_shapes_match_oracle(seed):
         got_ent[starved] = ent64[starved]
         _close(got_ent, ent64, 1e-4, 5e-3 * k["lr"], tag + " entity rows")
         assert np.array_equal(got_ent[sorted(set(range(k["n_ent"])) - touched)], ent0[sorted(set(range(k["n_ent"])) - touched)])
+
+
+@pytest.mark.parametrize("case", [CASES[0], CASES[1], CASES[4]], ids=lambda c: "nd-D%d-rel%d-B%d" % (c[2], c[1], c[3]))
+def test_rescal_neg_deg_sample_matches_oracle(case):
+    """round 6: --neg_deg_sample on the fused RESCAL step (was a drop-in detour) at the recipe's width, with relations carried by many
+    edges and at a width that takes the per-edge passes: N' = chunk + N rows per chunk, masked diagonal, in-batch rows' gradients in the
+    positive trace - against the fp64 oracle (generic forward_backward with neg_deg; pinned by the nd_rescal_* goldens)."""
+    from dglke_amd import plan
+    from dglke_amd.engine import StepEngine
+    n_ent, n_rel, hidden, B, chunk, N, reg, adv = case
+    lr, gamma = 0.05, 6.0
+    cfg = O.Config("RESCAL", gamma, hidden, lr, adv=adv, adv_temp=1.0, reg_coef=reg, reg_norm=3, neg_deg=True)
+    rng = np.random.RandomState(hidden * 11 + n_rel)
+    ent = rng.uniform(-cfg.emb_init, cfg.emb_init, size=(n_ent, cfg.ent_dim)).astype(np.float32)
+    rel = rng.uniform(-cfg.emb_init, cfg.emb_init, size=(n_rel, hidden * hidden)).astype(np.float32)
+    eng = StepEngine("RESCAL", n_ent, n_rel, hidden, gamma, lr, DEV, False, False, adv, 1.0, reg, 3, flags=32)
+    eng.load_tables(ent, rel)
+    Np = chunk + N
+    for step in (1, 2):
+        ent64, rel64 = eng.ent.cpu().numpy().astype(np.float64), eng.rel.cpu().numpy().astype(np.float64)
+        es64, rs64 = eng.ent_state.cpu().numpy().astype(np.float64), eng.rel_state.cpu().numpy().astype(np.float64)
+        bt = O.synth_batch(rng, n_ent, n_rel, B, N, chunk, step)
+        b = plan.make_batch(bt["h"], bt["t"], bt["r"], bt["neg"], chunk, N, bt["neg_head"], DEV)
+        want = eng.alloc_outputs(b)
+        eng.step(b, want)
+        torch.cuda.synchronize()
+        negrows = ent64[bt["neg"]].copy()
+        out = O.train_step(cfg, ent64, es64, rel64, rs64, bt["nid"], bt["h_local"], bt["t_local"], bt["r"], bt["neg"],
+                           bt["neg_head"], chunk, N)
+        tag = "RESCAL nd %r step %d" % (case, step)
+        assert tuple(want["neg_score"].shape) == (B // chunk, chunk, Np)
+        _close(want["pos_score"].cpu(), out["pos_score"], 1e-4, 1e-4, tag + " pos_score")
+        _close(want["neg_score"].cpu(), out["neg_score"], 1e-4, 1e-4, tag + " neg_score")
+        gn = want["g_neg"].cpu().numpy().reshape(-1, Np, hidden)[:, chunk:].reshape(-1, hidden)
+        if reg > 0:
+            gn = gn + O.reg_grad(negrows, reg, 3)
+        _close(gn, out["g_neg"], 3e-4, grad_tol(out["g_neg"]), tag + " g_neg")
+        sel = np.searchsorted(b.p["ue_id"], bt["nid"])
+        _close(want["g_pos_ent"].cpu().numpy()[sel], out["g_pos_ent"], 3e-4, grad_tol(out["g_pos_ent"]), tag + " g_pos_ent")
+        _close(want["g_rel"].cpu(), out["g_rel"], 3e-4, grad_tol(out["g_rel"]), tag + " g_rel")
+        _close(eng.ent_state.cpu(), es64, 2e-3, 1e-9, tag + " ent state")
+        _close(eng.rel_state.cpu(), rs64, 2e-3, 1e-9, tag + " rel state")
+        _close(eng.ent.cpu(), ent64, 1e-4, 1e-3 * lr, tag + " entity rows")
+        _close(eng.rel.cpu(), rel64, 1e-4, 1e-3 * lr, tag + " relation matrices")

@@ -155,3 +155,45 @@ def test_transr_projection_ops_match_torch_autograd(C, chunk, N, De, Dr):
     np.testing.assert_allclose(xd.grad.cpu().numpy(), x64.grad.numpy(), rtol=2e-5, atol=3e-5)
     np.testing.assert_allclose(nd.grad.cpu().numpy(), n64.grad.numpy(), rtol=2e-5, atol=2e-4)
     np.testing.assert_allclose(pd.grad.cpu().numpy(), p64.grad.numpy(), rtol=2e-5, atol=2e-4)
+
+
+@pytest.mark.parametrize("shape", [TILE_SHAPES[0], TILE_SHAPES[3], TILE_SHAPES[4]],
+                         ids=lambda c: "nd-De%d-%s-B%d-N%d" % (c[2], "dr" if c[3] else "sq", c[4], c[5]))
+def test_transr_neg_deg_sample_matches_oracle_at_tile_shapes(shape):
+    """round 6: --neg_deg_sample on the fused TransR step at shapes that span several tiles (N' = chunk + N: 105, 320, 146 negative rows per
+    chunk through the wide and the 64 x 64 routines) - scores incl. the masked diagonal, the three trace gradients (in-batch rows in the
+    positive trace), the three tables - against the fp64 oracle (`transr_forward_backward` with neg_deg, pinned by the nd_transr_* goldens)."""
+    from dglke_amd import plan
+    from dglke_amd.engine import StepEngine
+    from oracle import kge_oracle as O
+    n_ent, n_rel, hidden, dr, B, N, chunk, adv = shape
+    rng = np.random.RandomState(6)
+    eng = StepEngine("TransR", n_ent, n_rel, hidden, 10.0, 0.05, DEV, False, dr, adv, 1.0, 1e-6, 3, flags=32)
+    cfg = O.Config("TransR", 10.0, hidden, 0.05, adv=adv, adv_temp=1.0, reg_coef=1e-6, reg_norm=3, double_rel=dr, neg_deg=True)
+    ent, rel, proj = (x.cpu().numpy().astype(np.float64) for x in (eng.ent, eng.rel, eng.proj))
+    es, rs, ps = np.zeros(n_ent), np.zeros(n_rel), np.zeros(n_rel)
+    Np = chunk + N
+    for step in range(1, 3):
+        bt = O.synth_batch(rng, n_ent, n_rel, B, N, chunk, step)
+        b = plan.make_batch(bt["h"], bt["t"], bt["r"], bt["neg"], chunk, N, bt["neg_head"], DEV)
+        want = eng.alloc_outputs(b)
+        eng.step(b, want)
+        negrows = ent[bt["neg"]].copy()
+        out = O.transr_train_step(cfg, ent, es, rel, rs, proj, ps, bt["nid"], bt["h_local"], bt["t_local"], bt["r"],
+                                  bt["neg"], bt["neg_head"], chunk, N)
+        torch.cuda.synchronize()
+        assert tuple(want["neg_score"].shape) == (B // chunk, chunk, Np)
+        _close(want["pos_score"].cpu(), out["pos_score"], 1e-4, 1e-4, "pos")
+        _close(want["neg_score"].cpu(), out["neg_score"], 1e-4, 2e-4, "neg (masked diagonal = 0)")
+        gn = want["g_neg"].cpu().numpy().reshape(-1, Np, hidden)[:, chunk:].reshape(-1, hidden)       # the sampled rows of every chunk's block
+        gn = gn + O.reg_grad(negrows, 1e-6, 3)                                                          # (their regulariser: added by the update kernel)
+        _close(gn, out["g_neg"], 3e-4, grad_tol(out["g_neg"]), "g_neg")
+        _close(want["g_rel"].cpu(), out["g_rel"], 3e-4, grad_tol(out["g_rel"]), "g_rel")
+        sel = np.searchsorted(b.p["ue_id"], bt["nid"])
+        _close(want["g_pos_ent"].cpu().numpy()[sel], out["g_pos_ent"], 3e-4, grad_tol(out["g_pos_ent"]), "g_pos_ent (+ in-batch negative rows)")
+        _close(eng.proj_state.cpu(), ps, 2e-3, 1e-9, "projection state")
+        _close(eng.proj.cpu(), proj, 1e-4, 5e-3 * 0.05, "projection rows")
+        _close(eng.rel.cpu(), rel, 1e-4, 5e-3 * 0.05, "relation rows")
+        _close(eng.ent_state.cpu(), es, 2e-3, 1e-9, "entity state")
+        ent[:], rel[:], proj[:] = (x.cpu().numpy().astype(np.float64) for x in (eng.ent, eng.rel, eng.proj))
+        es[:], rs[:], ps[:] = (x.cpu().numpy().astype(np.float64) for x in (eng.ent_state, eng.rel_state, eng.proj_state))
