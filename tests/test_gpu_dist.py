@@ -598,3 +598,45 @@ def test_apply_merged_packed_messages_equal_sequential_apply(nsrc, cap, cap2, di
     np.testing.assert_allclose(s_d.cpu().numpy(), s64, rtol=2e-6, atol=1e-7)
     np.testing.assert_allclose(t_d.cpu().numpy(), t64, rtol=1e-5, atol=2e-6)
     assert n_two > 0 or cap2 < 3
+
+
+def test_packed_messages_extra_region_grows_on_a_small_graph():
+    """round 6: on a small graph most rows of a batch are in BOTH traces - the extra region of the packed gradient messages (64 rows to start
+    with) must grow before the first group runs (DistEngine.ensure_capacity: kge_route_fill's second word), every exchange buffer and the
+    route pool are rebuilt, the group graphs are recorded for the new geometry, and the tables equal the single-table step (world 1 through
+    RcclComm, synchronous and overlapped, eager first group + replayed groups)."""
+    from dglke_amd import dist as kd
+    from dglke_amd.dataloader import DeviceSampler
+    from dglke_amd.engine import StepEngine
+    n_ent, n_rel, hidden, B, N = 260, 9, 32, 128, 64
+    rng = np.random.RandomState(77)
+    h, r, t = rng.randint(0, n_ent, 20000), rng.randint(0, n_rel, 20000), rng.randint(0, n_ent, 20000)
+    torch.manual_seed(21)
+    ent0 = torch.empty(n_ent, hidden, device=DEV).uniform_(-0.3, 0.3)
+    rel0 = torch.empty(n_rel, hidden, device=DEV).uniform_(-0.3, 0.3)
+    lr = 0.05
+    ref = StepEngine("DistMult", n_ent, n_rel, hidden, 6.0, lr, DEV, False, False, True, 1.0, 1e-6, 3)
+    ref.ent.copy_(ent0); ref.rel.copy_(rel0); ref.ent_state.zero_(); ref.rel_state.zero_()
+    smp = DeviceSampler(h, r, t, n_ent, B, N, DEV, n_slots=4, seed=9)
+    for _ in range(4):
+        for b in smp.sample(4):
+            ref.step(b)
+    torch.cuda.synchronize()
+    for sched in (False,):          # (the synchronous schedule: the overlapped one is one step stale inside a group by design)
+        e2 = StepEngine("DistMult", 1, n_rel, hidden, 6.0, lr, DEV, False, False, True, 1.0, 1e-6, 3)
+        e2.rel.copy_(rel0); e2.rel_state.zero_()
+        ent, state = ent0.clone(), torch.zeros(n_ent, device=DEV)
+        comm = kd.RcclComm()
+        de = kd.DistEngine(e2, kd.ShardSpec(n_ent, 1, 0), ent, state, always_collective=True, comm=comm)
+        s2 = DeviceSampler(h, r, t, n_ent, B, N, DEV, n_slots=4, seed=9)
+        logs = []
+        replayed = 0
+        for _ in range(4):
+            replayed += bool(de.run_group(s2.sample(4), log=logs.append, graph=True, pipelined=sched))
+        torch.cuda.synchronize()
+        assert de.packed and de.grown_extra and de.cap2 > 64, (de.cap2, de.grown_extra)
+        assert any("extra region of the packed gradient messages grows" in m for m in logs)
+        assert de.check_overflow() == 0 and replayed >= 2
+        assert float((ref.ent.cpu() - ent.cpu()).abs().max()) <= 1e-3 * lr and float((ref.rel.cpu() - e2.rel.cpu()).abs().max()) <= 1e-3 * lr
+        assert float((ref.ent_state.cpu() - state.cpu()).abs().max()) <= 1e-5 * float(ref.ent_state.max())
+        de.close()
