@@ -335,8 +335,27 @@ def test_apply_merged_equals_sequential_apply(nsrc, cap, dim, n_rows):
         assert not torch.equal(tb1.cpu(), torch.from_numpy(tab_b))
 
 
+@pytest.mark.parametrize("mode", ["sampled", "sampled_overlap"])
+def test_world8_on_one_device_matches_the_oracle_statement(tmp_path, mode):
+    """round 6: BASELINE's world size - eight ranks (eight processes sharing this GPU, messages through gloo): owner buckets for eight
+    shards, packed single-trace messages with their extra regions, the merged apply with eight sources, device-sampled groups routed
+    ahead with one id exchange per group; synchronous and with every exchange on the side stream - against the fp64 statement."""
+    import dist_worker as W
+    world = 8
+    z = _run_workers(tmp_path, mode, world=world)
+    for model, de_, dr_ in W.MODELS:
+        ent, es, rel, rs = _oracle_statement(model, de_, dr_, z, world, mode)
+        lr = W.LR
+        np.testing.assert_allclose(z[model + "_state"], es, rtol=2e-3, atol=1e-9, err_msg=model + " entity state")
+        np.testing.assert_allclose(z[model + "_ent"], ent, rtol=1e-4, atol=5e-3 * lr, err_msg=model + " entity rows")
+        np.testing.assert_allclose(z[model + "_relstate0"], rs, rtol=2e-3, atol=1e-9, err_msg=model + " relation state")
+        np.testing.assert_allclose(z[model + "_rel0"], rel, rtol=1e-4, atol=5e-3 * lr, err_msg=model + " relation rows")
+        for r in range(1, world):
+            assert np.array_equal(z[model + "_rel0"], z[model + "_rel%d" % r]), "relation replicas differ"
+
+
 def _run_workers(tmp_path, mode, world=2, transport="host"):
-    port = str(29700 + os.getpid() % 250 + {"random": 0, "disjoint": 1, "pipelined": 2, "nd": 6, "relpart": 7, "sampled": 8, "sampled_pipelined": 9, "overlap": 10, "sampled_overlap": 11}[mode] + (3 if transport == "rccl" else 0))
+    port = str(29700 + 13 * (world // 8) + os.getpid() % 250 + {"random": 0, "disjoint": 1, "pipelined": 2, "nd": 6, "relpart": 7, "sampled": 8, "sampled_pipelined": 9, "overlap": 10, "sampled_overlap": 11}[mode] + (3 if transport == "rccl" else 0))
     env = dict(os.environ)
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), str(r), str(world), port, str(tmp_path), mode,
                                transport], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
