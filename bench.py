@@ -426,6 +426,16 @@ def other_configs(steps=600, timeout_s=150.0, only=None):
              {"KGE_DIST_MODE": "a2a", "KGE_DIST_FORCE_COLL": "1", "KGE_DIST_PIPELINE": "0", "KGE_DIST_REL_PART": "force"}),
             ("rotate_freebase_a2a_forced_exchange_relpart_overlapped", ["--workload", "rotate_freebase"],
              {"KGE_DIST_MODE": "a2a", "KGE_DIST_FORCE_COLL": "1", "KGE_DIST_PIPELINE": "overlap", "KGE_DIST_REL_PART": "force"})]
+    # BASELINE configs[1]'s own graph through the N > 1 code path (north_star: FB15k-shaped triples at 1/2/4/8 GPUs): the a2a engine
+    # with its RCCL collectives kept at world 1, relation partitioning like the reference's 8-GPU FB15k recipe
+    # (examples/fb15k/multi_gpu.sh:111-126), synchronous and with every exchange off the compute stream.  A 31-us step against
+    # three collectives per step: what the exchange costs when nothing is big enough to hide it
+    legs += [("transe_l2_fb15k_a2a_forced_exchange_relpart", ["--workload", "transe_l2_fb15k"],
+              {"KGE_FORCE_DIST": "1", "KGE_DIST_MODE": "a2a", "KGE_DIST_FORCE_COLL": "1", "KGE_DIST_PIPELINE": "0",
+               "KGE_DIST_REL_PART": "force"}),
+             ("transe_l2_fb15k_a2a_forced_exchange_relpart_overlapped", ["--workload", "transe_l2_fb15k"],
+              {"KGE_FORCE_DIST": "1", "KGE_DIST_MODE": "a2a", "KGE_DIST_FORCE_COLL": "1", "KGE_DIST_PIPELINE": "overlap",
+               "KGE_DIST_REL_PART": "force"})]
     res = {}
     for name, extra, env_extra in legs:
         if only is not None and name not in only:
@@ -568,6 +578,9 @@ def main():
     ap.add_argument("--no-async-update", dest="async_update", action="store_false",
                     help="skip the --async_update pipeline measurement (reported as its own object)")
     args = ap.parse_args()
+    # (bench_dist.dist_workload_name: `transe_l2_fb15k` on the sharded engines only when it was asked for; without the flag the
+    #  N > 1 headline is BASELINE configs[4])
+    args.workload_explicit = any(a == "--workload" or a.startswith("--workload=") for a in sys.argv[1:])
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

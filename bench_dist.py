@@ -44,7 +44,38 @@ DIST_WORKLOADS = {
     "rotate_freebase": dict(model="RotatE", n_ent=86054151, n_rel=14824, hidden=400, de=True, dr=False,
                             B=1024, N=256, gamma=12.0, lr=0.01, adv=True, adv_temp=1.0,
                             reg_coef=1e-7, reg_norm=3),
+    # BASELINE configs[1]'s graph on N GPUs (north_star: "edges/sec on synthetic FB15k-shaped triples reported at 1/2/4/8 GPUs"; the
+    # reference's own 8-GPU FB15k recipe, examples/fb15k/multi_gpu.sh:111-126: every trainer its own batches of 1000 over ONE
+    # 14 951-entity table, --rel_part --async_update): the graph stays FB15k-sized at every N - the table is NOT weak-scaled, each
+    # rank holds 1/N of its rows and 1/N of the 483 142 triples.  A 31-us step against three collectives: latency-bound on purpose
+    "transe_l2_fb15k": dict(model="TransE_l2", n_ent=14951, n_rel=1345, hidden=400, de=False, dr=False,
+                            B=1000, N=200, gamma=19.9, lr=0.25, adv=True, adv_temp=1.0,
+                            reg_coef=1e-9, reg_norm=3, n_train=483142, fixed_graph=True),
 }
+
+
+def dist_workload_name(args):
+    """the sharded workload of this invocation: `--workload` when it names one of DIST_WORKLOADS - for `transe_l2_fb15k` only when it
+    was passed EXPLICITLY (it is bench.py's argparse default = the N = 1 headline, configs[1]; without the flag the N > 1 headline is
+    BASELINE configs[4], the Freebase-scale RotatE config the north_star's scaling target is stated on)."""
+    if args.workload in DIST_WORKLOADS and (args.workload != "transe_l2_fb15k" or getattr(args, "workload_explicit", False)):
+        return args.workload
+    return "rotate_freebase"
+
+
+def dist_entities(w, world):
+    """entities of the sharded graph at this world size: the graph itself (fixed_graph) or world / 8 of it (weak-scaled table:
+    every GPU holds 1/8 of the Freebase entity table, N = 8 is the full graph); KGE_DIST_ENTITIES overrides"""
+    if os.environ.get("KGE_DIST_ENTITIES"):
+        return int(os.environ["KGE_DIST_ENTITIES"])
+    return w["n_ent"] if w.get("fixed_graph") else (w["n_ent"] + 7) // 8 * world
+
+
+def dist_triples(w, world):
+    """this rank's edge shard (reference: RandomPartition of the training triples, sampler.py:256-290); KGE_DIST_TRIPLES overrides"""
+    if os.environ.get("KGE_DIST_TRIPLES"):
+        return int(os.environ["KGE_DIST_TRIPLES"])
+    return w["n_train"] // world if w.get("fixed_graph") else min(338586276 // world, 48_000_000)
 
 
 def _p2p_setup(args, world, rank, dev, w, n_ent, d_e, d_r, emb_init):
@@ -61,7 +92,7 @@ def _p2p_setup(args, world, rank, dev, w, n_ent, d_e, d_r, emb_init):
                      w["adv"], w["adv_temp"], w["reg_coef"], w["reg_norm"], shards=tabs)
     # this rank's edge shard (reference: RandomPartition of the training triples, sampler.py:256-290):
     # synthetic uniform triples over the GLOBAL id space, generated in HBM
-    n_train = int(os.environ.get("KGE_DIST_TRIPLES", min(338586276 // world, 48_000_000)))
+    n_train = dist_triples(w, world)
     g = torch.Generator(device=dev)
     g.manual_seed(777 + rank)
     H = torch.randint(0, n_ent, (n_train,), device=dev, generator=g)
@@ -156,7 +187,7 @@ def _a2a_setup(args, world, rank, dev, w, n_ent, d_e, emb_init, allow_force_coll
     de = kd.DistEngine(eng, spec, ent, ent_state, comm=comm, slack=float(os.environ.get("KGE_DIST_SLACK", "1.25")),
                        always_collective=force_coll, rel_local=rel_part)
     # this rank's edge shard: synthetic uniform triples over the GLOBAL id space, generated in HBM
-    n_train = int(os.environ.get("KGE_DIST_TRIPLES", min(338586276 // world, 48_000_000)))
+    n_train = dist_triples(w, world)
     g = torch.Generator(device=dev)
     g.manual_seed(777 + rank)
     H = torch.randint(0, n_ent, (n_train,), device=dev, generator=g)
@@ -250,11 +281,11 @@ def _a2a_setup(args, world, rank, dev, w, n_ent, d_e, emb_init, allow_force_coll
                        (("eager launches, " + pipe_desc if sched else "eager launches") +
                         (", the step's kernels between pull and push replayed from %d small hipGraphs" % n_cg if n_cg else "")))
         if getattr(de, "local_only", False):
-            return ("entity table range-sharded (world 1: ONE shard = this GPU's 10.76 M-row table), relation table replicated; every row of a "
+            return ("entity table range-sharded (world 1: ONE shard = this GPU's %d-row table), relation table replicated; every row of a "
                     "batch is local, so the all-to-all engine runs the in-place step on the shard - no routing, no row cache, no gradient "
                     "messages, no owner-side apply launch (dist.DistEngine.local_only; the N > 1 path with its exchanges kept at world 1 "
-                    "is the `rotate_freebase_a2a_forced_exchange*` legs); %s; sampling + plan on the device inside the timed region"
-                    % launch_desc)
+                    "is the `*_a2a_forced_exchange*` legs); %s; sampling + plan on the device inside the timed region"
+                    % (spec.n_local, launch_desc))
         return ("entity table range-sharded, relation table replicated; per step: device-side routing into %d-row owner buckets, "
                 "all-to-all pull of the unique rows, the single-GPU kernels against the row cache, all-to-all push of one packed "
                 "single-trace gradient message per row (a second one, in the bucket's small extra region, only for a row that is in both "
@@ -449,8 +480,7 @@ def orchestrate(args, world, rank, local_rank):
 def _replicas_line(args, world, alls, history):
     """last resort of the fallback chain: N independent replicas of the per-GPU step (no exchange at all): value = N x K x B over the
     slowest replica's wall time.  Says what it is; not a scaling measurement of the sharded step."""
-    name = args.workload if args.workload in DIST_WORKLOADS else "rotate_freebase"
-    w = DIST_WORKLOADS[name]
+    w = DIST_WORKLOADS[dist_workload_name(args)]
     wall = max(a["wall"] for a in alls)
     K = args.steps
     return json.dumps({
@@ -471,12 +501,11 @@ def _replica_worker(args, rank, local_rank):
     __graft_entry__.build()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    name = args.workload if args.workload in DIST_WORKLOADS else "rotate_freebase"
-    w = dict(DIST_WORKLOADS[name])
+    w = dict(DIST_WORKLOADS[dist_workload_name(args)])
     d_e = 2 * w["hidden"] if w["de"] else w["hidden"]
     _progress("start")
     world = max(1, int(os.environ.get("WORLD_SIZE", "1")))
-    n_shard = int(os.environ.get("KGE_DIST_ENTITIES", "0")) // world or (w["n_ent"] + 7) // 8
+    n_shard = dist_entities(w, world) if w.get("fixed_graph") else dist_entities(w, world) // world
     eng, run, rows, desc, _ = _a2a_setup(args, 1, 0, dev, w, n_shard, d_e, (w["gamma"] + 2.0) / w["hidden"],
                                          allow_force_coll=False)
     _progress("setup")
@@ -490,6 +519,47 @@ def _replica_worker(args, rank, local_rank):
     _progress("timed")
     _deliver(json.dumps({"wall": wall, "rank": rank}))
     _progress("headline")
+
+
+def _fb15k_leg(args, world, rank, dev):
+    """secondary leg of a Freebase-scale line: the FB15k-shaped graph (BASELINE configs[1]: TransE_l2, batch 1000, neg 200, dim 400,
+    14 951 entities range-sharded over the ranks, 483 142 / N triples per rank) through the same all-to-all engine with the schedule
+    of the headline, exactly --steps steps between barriers, and the same step on a one-rank engine over the whole table (the
+    N = 1 point of THIS curve, = bench.py's own N = 1 headline workload)."""
+    w2 = dict(DIST_WORKLOADS["transe_l2_fb15k"])
+    emb2 = (w2["gamma"] + 2.0) / w2["hidden"]
+    out = {"workload": "TransE_l2 synthetic FB15k-shaped (BASELINE configs[1]): n_ent=%d n_rel=%d, per-GPU batch=%d neg=%d dim=%d, "
+                       "entity table range-sharded over %d GPU%s (graph NOT weak-scaled), %d triples per rank"
+                       % (w2["n_ent"], w2["n_rel"], w2["B"], w2["N"], w2["hidden"], world, "" if world == 1 else "s",
+                          dist_triples(w2, world))}
+    eng2, run2, rows2, desc2, de2 = _a2a_setup(args, world, rank, dev, w2, w2["n_ent"], w2["hidden"], emb2)
+    try:
+        run2(args.warmup)
+        torch.cuda.synchronize(); dist.barrier()
+        t0 = time.perf_counter()
+        run2(args.steps)                 # (the group sizes _a2a_setup recorded: warm-up and --steps)
+        torch.cuda.synchronize(); dist.barrier()
+        tw = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        n = args.steps
+        out.update({"value": round(n * w2["B"] * world / float(tw.item()), 1), "unit": "edges/s", "steps": n,
+                    "us_per_step": round(1e6 * float(tw.item()) / n, 2), "launch": rows2.get("launch"),
+                    "bucket_rows": de2.cap, "message_extra_rows": getattr(de2, "cap2", 0) or None,
+                    "bucket_overflows": de2.check_overflow(), "desc": desc2})
+    finally:
+        de2.close()
+    seng, srun, _, _, sde = _a2a_setup(args, 1, 0, dev, w2, w2["n_ent"], w2["hidden"], emb2, allow_force_coll=False)
+    s_steps = max(20, min(args.steps, 240))
+    srun(min(20, s_steps))
+    torch.cuda.synchronize(); dist.barrier()
+    t0 = time.perf_counter()
+    srun(s_steps)
+    torch.cuda.synchronize()
+    sw = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    dist.all_reduce(sw, op=dist.ReduceOp.MAX)
+    out["per_gpu_step_without_exchange"] = {"us_per_step": round(1e6 * float(sw.item()) / s_steps, 2), "steps": s_steps,
+                                            "edges_per_s_per_gpu": round(s_steps * w2["B"] / float(sw.item()), 1)}
+    return out
 
 
 def main(args, world, rank, local_rank):
@@ -512,10 +582,10 @@ def main(args, world, rank, local_rank):
         if "MASTER_ADDR" not in os.environ:
             os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29533"
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    name = args.workload if args.workload in DIST_WORKLOADS else "rotate_freebase"
+    name = dist_workload_name(args)
     w = dict(DIST_WORKLOADS[name])
-    # weak scaling of the table as well: every GPU holds 1/8 of the Freebase entity table, N = 8 is the full graph
-    n_ent = int(os.environ.get("KGE_DIST_ENTITIES", (w["n_ent"] + 7) // 8 * world))
+    # weak scaling of the table as well: every GPU holds 1/8 of the Freebase entity table, N = 8 is the full graph (dist_entities)
+    n_ent = dist_entities(w, world)
     d_e = 2 * w["hidden"] if w["de"] else w["hidden"]
     d_r = 2 * w["hidden"] if w["dr"] else w["hidden"]
     emb_init = (w["gamma"] + 2.0) / w["hidden"]
@@ -611,6 +681,8 @@ def main(args, world, rank, local_rank):
             res["a2a_eager"] = eager
         if local_leg is not None:
             res["per_gpu_step_without_exchange"] = local_leg
+        if fb_leg is not None:
+            res["fb15k_shaped"] = fb_leg
         if diag is not None:
             res["config"]["diagnostics"] = diag
         line = json.dumps(res)
@@ -621,6 +693,7 @@ def main(args, world, rank, local_rank):
 
     leg = None
     local_leg = None
+    fb_leg = None
     # the headline is delivered NOW (result file of the orchestrator): a secondary leg that hangs or dies can only cost itself
     if rank == 0 and os.environ.get("KGE_DIST_RESULT"):
         _deliver(json.dumps(_result_line(args, w, n_ent, world, wall, K, dict(rows), d_e, eng.d_r, desc, mode, why, sums, other,
@@ -716,7 +789,8 @@ def main(args, world, rank, local_rank):
         # N = 1 default is configs[1], a different workload)
         try:
             if os.environ.get("KGE_DIST_LOCAL_LEG", "1") != "0":
-                seng, srun, _, _, _ = _a2a_setup(args, 1, 0, dev, w, (n_ent + world - 1) // world, d_e, emb_init, allow_force_coll=False)
+                seng, srun, _, _, _ = _a2a_setup(args, 1, 0, dev, w, n_ent if w.get("fixed_graph") else (n_ent + world - 1) // world, d_e,
+                                                 emb_init, allow_force_coll=False)
                 s_steps = max(20, min(K, 240))
                 srun(min(20, s_steps))
                 torch.cuda.synchronize(); dist.barrier()
@@ -727,12 +801,31 @@ def main(args, world, rank, local_rank):
                 dist.all_reduce(sw, op=dist.ReduceOp.MAX)
                 local_leg = {"us_per_step": round(1e6 * float(sw.item()) / s_steps, 2), "steps": s_steps,
                              "edges_per_s_per_gpu": round(s_steps * w["B"] / float(sw.item()), 1),
-                             "what": "the same per-GPU step on a one-rank engine over a shard-sized table (no exchange), "
-                                     "hipGraph of [1 sampler launch + G steps], max over ranks"}
+                             "what": "the same per-GPU step on a one-rank engine over %s (no exchange), "
+                                     "hipGraph of [1 sampler launch + G steps], max over ranks"
+                                     % ("the whole graph's table" if w.get("fixed_graph") else "a shard-sized table")}
                 del seng, srun
         except Exception as e:          # noqa: BLE001
             local_leg = {"error": repr(e)}
         done.set()
+    # north_star: "edges/sec on synthetic FB15k-shaped triples reported at 1/2/4/8 GPUs" - BASELINE configs[1]'s graph through the
+    # same engine at this world size (DIST_WORKLOADS["transe_l2_fb15k"]), next to its own N = 1 point; a leg of its own, under
+    # its own watchdog
+    if want_other and mode == "a2a" and not w.get("fixed_graph") and os.environ.get("KGE_DIST_FB15K_LEG", "1") != "0":
+        done_f = threading.Event()
+
+        def watchdog_f():
+            nonlocal fb_leg
+            if not done_f.wait(float(os.environ.get("KGE_DIST_LEG_TIMEOUT", "120"))):
+                fb_leg = {"error": "the FB15k-shaped leg did not finish in time (watchdog)"}
+                emit(leg)
+                os._exit(0)
+        threading.Thread(target=watchdog_f, daemon=True).start()
+        try:
+            fb_leg = _fb15k_leg(args, world, rank, dev)
+        except Exception as e:          # noqa: BLE001
+            fb_leg = {"error": repr(e)}
+        done_f.set()
     # ---- diagnostics (round 6): per rank, the communicator's creation time, the owner buckets' capacity and growth
     # events, and ONE group of eager synchronous steps with a HIP event behind every phase (route / ids a2a / gather / rows a2a /
     # compute / push / apply, DistEngine.profile_phases) - so that the first run on a multi-GPU node explains itself in one shot.
@@ -804,11 +897,16 @@ def _result_line(args, w, n_ent, world, wall, K, rows, d_e, d_r, desc, mode, why
             "ms_per_step": round(1e3 * wall / K, 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s synthetic Freebase-scale (BASELINE configs[4], weak-scaled: %d/8 of the 86 054 151-entity "
-                                   "graph): n_ent=%d n_rel=%d, per-GPU batch=%d neg=%d hidden=%d (D_e=%d) over %d GPU%s "
-                                   "(%.1f GB of entity rows per GPU); %s"
-                                   % (w["model"], world, n_ent, w["n_rel"], w["B"], w["N"], w["hidden"], d_e, world,
-                                      "" if world == 1 else "s", (n_ent + world - 1) // world * d_e * 4 / 1e9, desc),
+            "config": {"workload": ("%s synthetic FB15k-shaped (BASELINE configs[1]'s graph, NOT weak-scaled: the 14 951-entity table "
+                                    "range-sharded over the ranks, %d triples per rank): n_ent=%d n_rel=%d, per-GPU batch=%d neg=%d "
+                                    "hidden=%d (D_e=%d) over %d GPU%s; %s"
+                                    % (w["model"], dist_triples(w, world), n_ent, w["n_rel"], w["B"], w["N"], w["hidden"], d_e, world,
+                                       "" if world == 1 else "s", desc)) if w.get("fixed_graph") else
+                                   ("%s synthetic Freebase-scale (BASELINE configs[4], weak-scaled: %d/8 of the 86 054 151-entity "
+                                    "graph): n_ent=%d n_rel=%d, per-GPU batch=%d neg=%d hidden=%d (D_e=%d) over %d GPU%s "
+                                    "(%.1f GB of entity rows per GPU); %s"
+                                    % (w["model"], world, n_ent, w["n_rel"], w["B"], w["N"], w["hidden"], d_e, world,
+                                       "" if world == 1 else "s", (n_ent + world - 1) // world * d_e * 4 / 1e9, desc)),
                        "global_batch": w["B"] * world,
                        "parallelism": ("shared tables over %d GPUs' HBM, peer-to-peer xGMI (Hogwild)" % world)
                        if mode == "p2p" else ("entity-shard x%d, relations replicated (RCCL all-to-all)" % world),
@@ -821,8 +919,9 @@ def _result_line(args, w, n_ent, world, wall, K, rows, d_e, d_r, desc, mode, why
                          "xgmi_GBps_per_gpu": round(xgmi_step / (wall / K) / 1e9, 2),
                          "xgmi_peak_GBps_per_gpu": 1071.0},
             "mean_loss": round(sums[2] / K, 6),
-            "n1_same_workload": "python bench.py --gpus 1 --workload %s" % args.workload if args.workload in DIST_WORKLOADS
-                                else "python bench.py --gpus 1 --workload rotate_freebase",
+            # the N = 1 point of this line's curve (bench.py's own N = 1 default is configs[1]; measured inside an N > 1 job as
+            # `per_gpu_step_without_exchange`)
+            "n1_same_workload": "python bench.py --gpus 1 --workload %s" % dist_workload_name(args),
         }
         if mode == "a2a":
             out["config"]["relation_partition"] = bool(rows.get("rel_part"))

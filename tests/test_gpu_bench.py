@@ -28,6 +28,28 @@ def test_skewed_triples_have_fb15k_like_hubs():
     assert np.bincount(ru, minlength=w["n_rel"]).max() / n < 0.002
 
 
+def test_sharded_workload_of_an_invocation():
+    """`bench.py --gpus N` without --workload measures BASELINE configs[4] (Freebase-scale RotatE); the FB15k-shaped graph of
+    configs[1] runs on the sharded engines only when it is asked for - `transe_l2_fb15k` is also bench.py's argparse default - and is
+    not weak-scaled: the same 14 951 entities and 483 142 triples at every world size."""
+    import types
+    import bench_dist as bd
+    mk = lambda wl, ex: types.SimpleNamespace(workload=wl, workload_explicit=ex)
+    assert bd.dist_workload_name(mk("transe_l2_fb15k", False)) == "rotate_freebase"
+    assert bd.dist_workload_name(mk("transe_l2_fb15k", True)) == "transe_l2_fb15k"
+    assert bd.dist_workload_name(mk("transe_l2_freebase", False)) == "transe_l2_freebase"
+    assert bd.dist_workload_name(mk("distmult_fb15k", True)) == "rotate_freebase"
+    fb, fr = bd.DIST_WORKLOADS["transe_l2_fb15k"], bd.DIST_WORKLOADS["rotate_freebase"]
+    old = {k: os.environ.pop(k, None) for k in ("KGE_DIST_ENTITIES", "KGE_DIST_TRIPLES")}
+    try:
+        assert [bd.dist_entities(fb, n) for n in (1, 2, 8)] == [14951] * 3
+        assert [bd.dist_triples(fb, n) for n in (1, 2, 8)] == [483142, 241571, 60392]
+        assert bd.dist_entities(fr, 8) == 86054152 and bd.dist_entities(fr, 1) == 10756769
+        assert bd.dist_triples(fr, 8) == 338586276 // 8 and bd.dist_triples(fr, 1) == 48_000_000
+    finally:
+        os.environ.update({k: v for k, v in old.items() if v is not None})
+
+
 @pytest.mark.gpu
 def test_bench_line_has_the_contract_fields():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
@@ -88,6 +110,39 @@ def test_forced_exchange_line_carries_per_rank_diagnostics():
     ph = dg[0]["phase_us_per_step"]
     assert set(ph) >= {"route", "ids_a2a", "gather", "rows_a2a", "compute", "push", "apply", "steps"}, ph
     assert ph["compute"] > 20.0 and ph["steps"] == 20 and dg[0]["bucket_rows"] > 0
+
+
+@pytest.mark.gpu
+def test_fb15k_shaped_graph_through_the_sharded_path():
+    """north_star: FB15k-shaped triples at 1/2/4/8 GPUs.  (a) `--workload transe_l2_fb15k` through the all-to-all engine with its RCCL
+    exchanges kept at world 1 (the `transe_l2_fb15k_a2a_forced_exchange_relpart` leg of the default line); (b) the `fb15k_shaped` leg
+    of a Freebase-scale line, with the N = 1 point of its own curve beside it."""
+    env = dict(os.environ)
+    env.update({"KGE_FORCE_DIST": "1", "KGE_DIST_MODE": "a2a", "KGE_DIST_FORCE_COLL": "1", "KGE_DIST_PIPELINE": "0",
+                "KGE_DIST_REL_PART": "force", "KGE_DIST_OTHER_LEG": "0", "KGE_DIST_DIAG": "0", "WORLD_SIZE": "1", "RANK": "0",
+                "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(29900 + os.getpid() % 90)})
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "40", "--warmup", "20",
+                          "--workload", "transe_l2_fb15k", "--no-cpu-baseline"],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert "FB15k-shaped" in d["config"]["workload"] and "n_ent=14951" in d["config"]["workload"] and d["config"]["mode"] == "a2a"
+    assert d["config"]["relation_partition"] is True and d["config"]["bucket_overflows"] == 0 and d["config"]["bucket_rows"] > 2000
+    assert d["steps"] == 40 and 20.0 < 1e3 * d["ms_per_step"] < 1000.0 and 0.3 < d["mean_loss"] < 2.0
+    assert d["n1_same_workload"].endswith("--workload transe_l2_fb15k")
+    # (b) a small Freebase-shaped headline with its secondary legs forced at world 1
+    env.update({"KGE_DIST_OTHER_LEG": "force", "KGE_DIST_ENTITIES": "2000000", "KGE_DIST_TRIPLES": "2000000",
+                "MASTER_PORT": str(29990 - os.getpid() % 90)})
+    env.pop("KGE_FORCE_DIST")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "40", "--warmup", "20",
+                          "--workload", "rotate_freebase", "--no-cpu-baseline"],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=400, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    fb = d["fb15k_shaped"]
+    assert "error" not in fb, fb
+    assert fb["steps"] == 40 and fb["bucket_overflows"] == 0 and fb["value"] > 1e6 and "n_ent=14951" in fb["workload"]
+    assert 15.0 < fb["per_gpu_step_without_exchange"]["us_per_step"] < fb["us_per_step"]
 
 
 @pytest.mark.gpu
