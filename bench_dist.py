@@ -548,6 +548,24 @@ def _fb15k_leg(args, world, rank, dev):
                     "bucket_overflows": de2.check_overflow(), "desc": desc2})
     finally:
         de2.close()
+    # the same graph on the peer-to-peer shared tables (no collective in the step: at this size the exchange is latency, and a
+    # remote row costs one xGMI round instead of a share of three RCCL launches)
+    try:
+        peng, prun, prows, pdesc, ptabs = _p2p_setup(args, world, rank, dev, w2, w2["n_ent"], w2["hidden"], w2["hidden"], emb2)
+        try:
+            prun(args.warmup)
+            torch.cuda.synchronize(); dist.barrier()
+            t0 = time.perf_counter()
+            prun(args.steps)
+            torch.cuda.synchronize(); dist.barrier()
+            tp = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            dist.all_reduce(tp, op=dist.ReduceOp.MAX)
+            out["p2p"] = {"value": round(args.steps * w2["B"] * world / float(tp.item()), 1), "unit": "edges/s", "steps": args.steps,
+                          "us_per_step": round(1e6 * float(tp.item()) / args.steps, 2)}
+        finally:
+            ptabs.close()
+    except Exception as e:              # noqa: BLE001
+        out["p2p"] = {"error": repr(e)}
     seng, srun, _, _, sde = _a2a_setup(args, 1, 0, dev, w2, w2["n_ent"], w2["hidden"], emb2, allow_force_coll=False)
     s_steps = max(20, min(args.steps, 240))
     srun(min(20, s_steps))
