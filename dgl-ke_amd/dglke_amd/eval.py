@@ -38,6 +38,33 @@ def build_filter(known_h, known_r, known_t, test_h, test_r, test_t, neg_head, n_
     return rng, val.astype(np.int64)
 
 
+def build_filter_device(known, test, neg_head, n_relations, n_entities, dev):
+    """`build_filter` with the sort on the device: the same lists in the same order (unique (key, entity) pairs sorted by key, then
+    entity; per test triple the [left, right) range of its key), as int64 DEVICE tensors ready for `Ranker.ranks`.  One composite
+    key `(key * n_entities + entity)` through `torch.unique` instead of a host `np.lexsort` over every known triple - 0.09 s per
+    corruption side at FB15k's 592 k known triples, which was 87 % of a validation (tools/eval_timing.py).  Returns None when the
+    composite key does not fit int64 (Freebase-sized graphs: the host lists)."""
+    R, NE = int(n_relations), int(n_entities)
+    if NE * R * NE >= (1 << 62):
+        return None
+
+    def put(x):
+        if isinstance(x, torch.Tensor):
+            return x.to(dev, torch.int64)
+        return torch.as_tensor(np.ascontiguousarray(np.asarray(x, np.int64))).to(dev)
+    kh, kr, kt = (put(x) for x in known)
+    th_, tr_, tt_ = (put(x) for x in test)
+    if neg_head:
+        key, val, tkey = kt * R + kr, kh, tt_ * R + tr_
+    else:
+        key, val, tkey = kh * R + kr, kt, th_ * R + tr_
+    comp = torch.unique(key * NE + val)                      # sorted unique (key, entity) pairs
+    key = torch.div(comp, NE, rounding_mode='floor')
+    val = comp - key * NE
+    rng = torch.stack([torch.searchsorted(key, tkey, right=False), torch.searchsorted(key, tkey, right=True)], 1)
+    return rng.contiguous(), val.contiguous()
+
+
 class Ranker(object):
     """device-resident evaluation of one (ent, rel) table pair."""
 
@@ -135,22 +162,38 @@ def sampled_ranks(rk, h, r, t, neg_head, filt, n_entities, n_cand, chunk, rng, c
 
 
 def evaluate(model_name, ent, rel, gamma, emb_init, test, known=None, batch=1024, modes=("head", "tail"), proj=None,
-             n_cand=None, chunk=None, seed=0):
+             n_cand=None, chunk=None, seed=0, cache=None):
     """filtered (known given) or raw ranking metrics over both corruption modes, averaged over all
     2E rankings like the reference (logs of the head and the tail sampler are concatenated,
     train_pytorch.py:221-231).  test / known: (h, r, t) triples of int64 arrays.  n_cand (< number of entities):
-    rank against n_cand sampled candidates per chunk of `chunk` triples instead of all entities."""
+    rank against n_cand sampled candidates per chunk of `chunk` triples instead of all entities.
+    cache: a dict the caller keeps per (split, known set) - the filter lists and the test triples stay on the device between
+    calls (a training run validates the SAME split against the SAME known triples every --eval_interval steps)."""
     rk = Ranker(model_name, ent, rel, gamma, emb_init, batch, proj=proj)
     th_, tr_, tt_ = test
     n_ent = int(ent.shape[0])
     sampled = n_cand is not None and 0 < n_cand < n_ent
     rng = np.random.RandomState(seed)
+    dev = ent.device
+    if cache is not None and not sampled:
+        if "test" not in cache:
+            cache["test"] = tuple(torch.as_tensor(np.ascontiguousarray(np.asarray(x, np.int64))).to(dev) for x in test)
+        th_, tr_, tt_ = cache["test"]
     allr = []
     for mode in modes:
         neg_head = mode == "head"
         filt = None
         if known is not None:
-            filt = build_filter(known[0], known[1], known[2], th_, tr_, tt_, neg_head, rel.shape[0])
+            if cache is not None and ("filt", mode, sampled) in cache:
+                filt = cache[("filt", mode, sampled)]
+            else:
+                if not sampled:          # lists built and kept on the device (sampled candidates: the host maps them to columns)
+                    filt = build_filter_device(known, (th_, tr_, tt_), neg_head, rel.shape[0], n_ent, dev)
+                if filt is None:
+                    filt = build_filter(known[0], known[1], known[2], *(x.cpu().numpy() if isinstance(x, torch.Tensor) else x
+                                                                        for x in (th_, tr_, tt_)), neg_head, rel.shape[0])
+                if cache is not None:
+                    cache[("filt", mode, sampled)] = filt
         if sampled:
             allr.append(sampled_ranks(rk, th_, tr_, tt_, neg_head, filt, n_ent, int(n_cand), int(chunk or batch), rng))
         else:

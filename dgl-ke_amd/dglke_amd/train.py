@@ -346,9 +346,11 @@ class Trainer(object):
         proj = m.score_func.projection_emb.emb if args.model_name == 'TransR' else None
         if proj is not None:
             Eb = min(Eb, 64)                  # TransR projects every candidate with every test triple's matrix
+        # (the split and the known set do not change during a run: filter lists and test ids stay on the device between validations)
+        cache = self.__dict__.setdefault('_eval_cache', {}).setdefault(which, {})
         metrics = kev.evaluate(args.model_name, m.entity_emb.emb, m.relation_emb.emb, args.gamma, m.emb_init,
                                (h, r, t), known, batch=Eb, proj=proj, n_cand=args.neg_sample_size_eval,
-                               chunk=args.batch_size_eval, seed=args.seed + 29)   # sampled candidates if < n_entities
+                               chunk=args.batch_size_eval, seed=args.seed + 29, cache=cache)   # sampled candidates if < n_entities
         for k, v in metrics.items():
             print('[{}]{} average {}: {}'.format(0, mode, k, v))
         return metrics
@@ -536,8 +538,9 @@ class ShardedTrainer(object):
         proj = self.projection() if args.model_name == 'TransR' else None
         if proj is not None:
             Eb = min(Eb, 64)                  # TransR projects every candidate with every test triple's matrix
+        cache = self.__dict__.setdefault('_eval_cache', {}).setdefault(which, {})
         metrics = kev.evaluate(args.model_name, ent, rel, args.gamma, self.emb_init, (h, r, t), known, batch=Eb, proj=proj,
-                               n_cand=args.neg_sample_size_eval, chunk=args.batch_size_eval, seed=args.seed + 29)
+                               n_cand=args.neg_sample_size_eval, chunk=args.batch_size_eval, seed=args.seed + 29, cache=cache)
         for k, v in metrics.items():
             print('[{}]{} average {}: {}'.format(self.rank, mode, k, v))
         return metrics

@@ -169,3 +169,28 @@ def test_sampled_candidate_ranking_is_consistent_with_full_ranking():
             lo = 1 + int(((sc >= pos[i] + 1e-4) & keep).sum())
             hi = 1 + int(((sc >= pos[i] - 1e-4) & keep).sum())
             assert lo <= got[i] <= hi, (i, got[i], lo, hi)
+
+
+def test_evaluate_with_a_cache_returns_the_same_metrics():
+    """eval.evaluate(cache=...) - what dglke_train's validations use: filter lists built on the device once and kept there with the
+    test ids - gives exactly the metrics of the uncached call with host-built lists, on the first call and on the calls that hit
+    the cache (tables changed in between: only the lists are reused)."""
+    from dglke_amd import eval as kev
+    rng = np.random.RandomState(5)
+    n_ent, n_rel, D = 3000, 40, 64
+    known = tuple(rng.randint(0, n, 30000) for n in (n_ent, n_rel, n_ent))
+    test = tuple(k[:2000] for k in known)
+    torch.manual_seed(1)
+    ent = torch.empty(n_ent, D, device=DEV).uniform_(-0.3, 0.3)
+    rel = torch.empty(n_rel, D, device=DEV).uniform_(-0.3, 0.3)
+    cache = {}
+    for it in range(3):
+        want = {}
+        for mode in ("head", "tail"):      # the uncached reference: host lists, one mode at a time
+            filt = kev.build_filter(known[0], known[1], known[2], test[0], test[1], test[2], mode == "head", n_rel)
+            want[mode] = kev.Ranker("TransE_l2", ent, rel, 12.0, 0.3, 512).ranks(test[0], test[1], test[2], mode == "head", filt)
+        m_want = kev.metrics_from_ranks(torch.cat([want["head"], want["tail"]]))
+        m_got = kev.evaluate("TransE_l2", ent, rel, 12.0, 0.3, test, known, batch=512, cache=cache)
+        assert m_got == m_want, (it, m_got, m_want)
+        assert ("filt", "head", False) in cache and cache["test"][0].is_cuda
+        ent.add_(torch.empty_like(ent).uniform_(-0.05, 0.05))      # "training" between the validations

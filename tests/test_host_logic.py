@@ -244,3 +244,24 @@ def test_balanced_split_map_covers_every_group_once_and_balances_the_cus():
         per_cu = [sum(m[k + 256 * r][4] - m[k + 256 * r][3] for r in range(4)) for k in range(256)]
         sizes = sorted(hi - lo for _, _, _, lo, hi in m)
         assert max(per_cu) - min(per_cu) <= 2 * (sizes[-1] - sizes[0]), (ncol, ngr, min(per_cu), max(per_cu))
+
+
+def test_device_filter_lists_equal_the_host_lists():
+    """eval.build_filter_device (one composite key through torch.unique - runs on any torch device, here the CPU) returns the lists
+    of eval.build_filter (np.lexsort): unique (key, entity) pairs in the same order, the same [left, right) range per test triple -
+    duplicates among the known triples, test triples without any known match, both corruption sides; None when the composite
+    key would not fit int64."""
+    import numpy as np
+    import torch
+    from dglke_amd import eval as E
+    rng = np.random.RandomState(3)
+    n_ent, n_rel = 97, 7
+    known = tuple(rng.randint(0, n, 4000) for n in (n_ent, n_rel, n_ent))           # many duplicates
+    test = (np.concatenate([known[0][:300], rng.randint(0, n_ent, 50)]), np.concatenate([known[1][:300], rng.randint(0, n_rel, 50)]),
+            np.concatenate([known[2][:300], rng.randint(0, n_ent, 50)]))
+    for neg_head in (True, False):
+        want = E.build_filter(known[0], known[1], known[2], test[0], test[1], test[2], neg_head, n_rel)
+        got = E.build_filter_device(known, test, neg_head, n_rel, n_ent, torch.device("cpu"))
+        assert got[0].dtype == torch.int64 and got[1].dtype == torch.int64
+        assert np.array_equal(got[0].numpy(), want[0]) and np.array_equal(got[1].numpy(), want[1])
+    assert E.build_filter_device(known, test, True, 14824, 86054151, torch.device("cpu")) is None
