@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <algorithm>
 #include "kge_common.hpp"
 #include "kge_sampler_common.hpp"
 
@@ -1149,7 +1150,7 @@ size_t kge_rank_workspace_bytes(int Eb, int64_t n_cand, int d_e) {
     n += align_up((size_t)Eb * d_e * sizeof(float));        // A
     n += 2 * align_up((size_t)Eb * sizeof(float));          // asq, P
     n += align_up((size_t)n_cand * sizeof(float));          // bsq
-    n += align_up((size_t)Eb * (size_t)n_cand * sizeof(float));   // S
+    n += align_up(std::max((size_t)Eb * (size_t)n_cand * sizeof(float), rank_gemm_mask_bytes(Eb, n_cand)));   // S / the comparison mask
     n += align_up((size_t)Eb * d_e * sizeof(float));        // V = M t (RESCAL)
     n += 4 * align_up((size_t)Eb * 1024 * sizeof(float));   // TransR: hp, tp, q, sign rows (d_r <= 1024)
     return n;
@@ -1182,7 +1183,7 @@ int kge_rank_eval_ex(int model, int neg_head, const float *ent, int64_t n_ent, c
     hipStream_t s = (hipStream_t)stream;
     Carver cv(ws, ws_bytes);
     float *A = cv.f((size_t)Eb * d_e), *asq = cv.f(Eb), *P = cv.f(Eb), *bsq = cv.f((size_t)N);
-    float *S = cv.f((size_t)Eb * (size_t)N);
+    float *S = cv.f(std::max((size_t)Eb * (size_t)N, rank_gemm_mask_bytes(Eb, N) / sizeof(float)));
     float *RV = cv.f((size_t)Eb * d_e);
     float *THP = cv.f((size_t)Eb * 1024), *TTP = cv.f((size_t)Eb * 1024), *TQ = cv.f((size_t)Eb * 1024), *TSG = cv.f((size_t)Eb * 1024);
     if (!cv.ok()) return fail(KGE_ERR_WORKSPACE, "kge_rank_eval: workspace too small (%zu < %zu)", ws_bytes,
@@ -1228,6 +1229,11 @@ int kge_rank_eval_ex(int model, int neg_head, const float *ent, int64_t n_ent, c
         }
         if (model == KGE_TRANSR) {
             // scores already in S
+        } else if (gemm && rank_gemm_supported(model, d_e)) {
+            // one tiled GEMM per batch whose epilogue keeps the comparison bits; ranks from the mask (kge_rank_gemm.hip)
+            KGE_TRY(launch_rank_gemm(model, A, rows, ent, cand, N, d_e, gamma, clamp_of(model), asq, bsq,
+                                     pos_score_out ? pos_score_out + e0 : P, S, filt_ptr, filt_ids, e0, ranks, s));
+            continue;
         } else if (gemm) {
             GemmArgs g; fill_gemm(g, model, 1, rows, (int)N, d_e, gamma, A, ent, cand);
             g.S = S; g.asq = asq; g.bsq = bsq;

@@ -504,6 +504,11 @@ int launch_mask_diag(float *x, int C, int chunk, int Np, hipStream_t s);
 int launch_rank_mask(const float *neg, const float *pos, const float *bias, int64_t E, int64_t N, int64_t *ranks, hipStream_t s);
 int launch_rank_count(const float *S, const float *P, int rows, int64_t N, const int64_t *filt_ptr,
                       const int64_t *filt_ids, int64_t e0, int32_t *ranks, hipStream_t s);
+bool rank_gemm_supported(int model, int d_e);          // kge_rank_gemm.hip: LDS-tiled fp32-MFMA ranking of the matrix-form models
+size_t rank_gemm_mask_bytes(int rows, int64_t N);
+int launch_rank_gemm(int model, const float *A, int rows, const float *nbase, const int64_t *nidx, int64_t N, int D, float gamma,
+                     float clampv, const float *asq, const float *bsq, const float *P, void *mask, const int64_t *filt_ptr,
+                     const int64_t *filt_ids, int64_t e0, int32_t *ranks, hipStream_t s);
 struct GemmArgs {                   // LDS-staged fp32-MFMA negative scoring (kge_neg_gemm.hip)
     int model, C, chunk, N, D;
     float gamma;

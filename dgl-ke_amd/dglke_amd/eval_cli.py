@@ -80,7 +80,7 @@ def main(argv=None):
     if args.eval_filter:
         parts = [p for p in (ds.train, ds.valid, ds.test) if p is not None]
         known = tuple(np.concatenate([np.asarray(p[k]) for p in parts]) for k in range(3))
-    Eb = int(max(1, min(max(args.batch_size_eval, 1024), (1 << 31) // (4 * ds.n_entities), len(h))))
+    Eb = int(max(1, min(max(args.batch_size_eval, 4096), (1 << 31) // (4 * ds.n_entities), len(h))))
     if proj is not None:
         Eb = min(Eb, 64)
     start = time.time()

@@ -342,7 +342,7 @@ class Trainer(object):
             known = tuple(np.concatenate([np.asarray(p[k]) for p in parts]) for k in range(3))
         m = self.model
         n_cand = m.n_entities
-        Eb = int(max(1, min(max(args.batch_size_eval, 1024), (1 << 31) // (4 * n_cand), len(h))))
+        Eb = int(max(1, min(max(args.batch_size_eval, 4096), (1 << 31) // (4 * n_cand), len(h))))
         proj = m.score_func.projection_emb.emb if args.model_name == 'TransR' else None
         if proj is not None:
             Eb = min(Eb, 64)                  # TransR projects every candidate with every test triple's matrix
@@ -534,7 +534,7 @@ class ShardedTrainer(object):
             parts = [p for p in (ds.train, ds.valid, ds.test) if p is not None]
             known = tuple(np.concatenate([np.asarray(p[k]) for p in parts]) for k in range(3))
         ent, rel = self.full_tables()
-        Eb = int(max(1, min(max(args.batch_size_eval, 1024), (1 << 31) // (4 * ds.n_entities), len(h))))
+        Eb = int(max(1, min(max(args.batch_size_eval, 4096), (1 << 31) // (4 * ds.n_entities), len(h))))
         proj = self.projection() if args.model_name == 'TransR' else None
         if proj is not None:
             Eb = min(Eb, 64)                  # TransR projects every candidate with every test triple's matrix

@@ -194,3 +194,45 @@ def test_evaluate_with_a_cache_returns_the_same_metrics():
         assert m_got == m_want, (it, m_got, m_want)
         assert ("filt", "head", False) in cache and cache["test"][0].is_cuda
         ent.add_(torch.empty_like(ent).uniform_(-0.05, 0.05))      # "training" between the validations
+
+
+@pytest.mark.parametrize("model,de_,dr_,hidden", [("TransE_l2", False, False, 36), ("DistMult", False, False, 100), ("SimplE", True, True, 20),
+                                                  ("ComplEx", True, True, 66), ("RESCAL", False, False, 24)])
+def test_tiled_rank_gemm_agrees_with_the_score_block_path(model, de_, dr_, hidden):
+    """kge_rank_gemm.hip (128 x 128 tiles, one comparison bit per pair, ranks from the mask) against the score block +
+    rank_count_kernel (flags = KGE_FLAG_FORCE_PAIRWISE: the pairwise kernels' fp32 scores): several row blocks with a partial
+    last one, a candidate count that is no multiple of 128 (and one below a tile), widths that are no multiple of the 32-column
+    stage, filtered and raw, explicit candidate lists with repeats.  fp32 sums in another order may flip a comparison within an ulp
+    of the true triple's score: ranks equal on >= 99.5 % of the triples and never more than 2 apart; both inside the oracle's band."""
+    from dglke_amd import eval as E
+    rng = np.random.RandomState(11)
+    n_ent, n_rel, Et = 1000, 7, 300
+    d_e = 2 * hidden if de_ else hidden
+    d_r = d_e * d_e if model == "RESCAL" else (2 * hidden if dr_ else hidden)
+    gamma, emb_init = 12.0, 14.0 / hidden
+    ent = (rng.rand(n_ent, d_e).astype(np.float32) - 0.5) * 2 * emb_init
+    rel = (rng.rand(n_rel, d_r).astype(np.float32) - 0.5) * 2 * emb_init
+    known = np.stack([rng.randint(0, n_ent, 6000), rng.randint(0, n_rel, 6000), rng.randint(0, n_ent, 6000)], 1)
+    h, r, t = known[:Et, 0], known[:Et, 1], known[:Et, 2]
+    te, tr = torch.from_numpy(ent).to(DEV), torch.from_numpy(rel).to(DEV)
+    new, old = E.Ranker(model, te, tr, gamma, emb_init, batch=160), E.Ranker(model, te, tr, gamma, emb_init, batch=160, flags=1)
+    for neg_head in (False, True):
+        filt = E.build_filter(known[:, 0], known[:, 1], known[:, 2], h, r, t, neg_head, n_rel)
+        # filtered: the true triple's own column is in the list, so its comparison cancels in both paths
+        a, b = new.ranks(h, r, t, neg_head, filt).cpu().numpy(), old.ranks(h, r, t, neg_head, filt).cpu().numpy()
+        assert (a != b).mean() <= 0.005 and np.abs(a - b).max() <= 2, (neg_head, np.nonzero(a != b)[0][:10])
+        assert a.min() >= 1 and a.max() <= n_ent
+        mask = np.zeros((Et, n_ent), bool)
+        for i in range(Et):
+            mask[i, filt[1][filt[0][i, 0]:filt[0][i, 1]]] = True
+        # raw: the true entity is a candidate whose score equals the positive score up to rounding (a coin flip in any fp32
+        # implementation, the reference's included): the oracle's tolerance band is the bar, as everywhere in this file
+        for f, mk in ((filt, mask), (None, None)):
+            (lo, hi), _, _ = O.rank_eval(model, ent.astype(np.float64), rel.astype(np.float64), h, r, t, neg_head, gamma, emb_init, mk, tol=TOL)
+            got = new.ranks(h, r, t, neg_head, f).cpu().numpy()
+            assert np.all((lo <= got) & (got <= hi)), (neg_head, f is None)
+    for n_c in (70, 257):                  # below one tile; three column tiles with a 1-candidate tail; repeats in the list
+        cand = rng.randint(0, n_ent, n_c).astype(np.int64)
+        a, b = new.ranks(h, r, t, False, None, cand=cand).cpu().numpy(), old.ranks(h, r, t, False, None, cand=cand).cpu().numpy()
+        own = np.array([(cand == t[i]).sum() for i in range(Et)])      # (copies of the true tail in the list: coin flips, see above)
+        assert np.all(np.abs(a - b) <= own + 1) and (np.abs(a - b) > own).mean() <= 0.01 and a.max() <= n_c + 1
