@@ -377,8 +377,11 @@ int kge_adagrad_apply_rows(float *table, float *state_sum, int64_t n_rows, int d
  * filt_i = filt_ids[filt_ptr[2i] .. filt_ptr[2i+1]) are candidate COLUMNS whose corrupted triple
  * exists in the graph (the reference's bias == -1 mask, :463-475; unique within a list; filt_ptr
  * is [E][2] begin/end so that triples with the same (h,r) or (r,t) share one list; NULL =
- * --no_eval_filter, where the true triple itself counts exactly as in the reference).  Scores are
- * the training kernels' chunked negative scores (one chunk of Eb triples per pass).
+ * --no_eval_filter, where the true triple itself counts exactly as in the reference).  One pass per
+ * Eb triples.  Matrix-form models (TransE_l2, DistMult, ComplEx, SimplE, RESCAL): a tiled fp32-MFMA
+ * GEMM whose epilogue keeps the comparison bit of every (triple, candidate) pair, ranks from the
+ * bit mask (csrc/kge_rank_gemm.hip); KGE_FLAG_FORCE_PAIRWISE, the pairwise models and TransR: the
+ * training kernels' chunked negative scores as a block + a counting kernel.
  * pos_score_out (optional) receives the E true-triple scores. */
 size_t kge_rank_workspace_bytes(int Eb, int64_t n_cand, int d_e);
 int kge_rank_eval(int model, int neg_head, const float *ent, int64_t n_ent, const float *rel,
