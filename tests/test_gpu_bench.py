@@ -93,6 +93,16 @@ def test_bench_time_to_mrr_leg_reports_the_second_half_of_the_metric():
 
 
 @pytest.mark.gpu
+def test_bench_rank_eval_leg():
+    """the default line's `rank_eval` object: one filtered evaluation at FB15k's shape as the trainers run it, with its rate against the
+    fp32-MFMA peak (checked here on a smaller test set)."""
+    import bench
+    d = bench.rank_eval_leg(n_test=6000)
+    assert d["triples"] == 12000 and d["candidates"] == 14951 and 0 < d["cached_call_s"] <= d["first_call_s"]
+    assert 0.05 < d["frac_fp32_mfma_peak"] < 1.0 and abs(d["tflops"] - d["frac_fp32_mfma_peak"] * 157.3) < 0.2
+
+
+@pytest.mark.gpu
 def test_forced_exchange_line_carries_per_rank_diagnostics():
     """round 6: the multi-GPU worker's line explains itself - communicator creation time, bucket capacity and
     growth, microseconds per phase of the synchronous step (here: the N > 1 code path at world 1 with its RCCL exchanges kept)."""
