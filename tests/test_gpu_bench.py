@@ -153,6 +153,7 @@ def test_fb15k_shaped_graph_through_the_sharded_path():
     assert "error" not in fb, fb
     assert fb["steps"] == 40 and fb["bucket_overflows"] == 0 and fb["value"] > 1e6 and "n_ent=14951" in fb["workload"]
     assert 15.0 < fb["per_gpu_step_without_exchange"]["us_per_step"] < fb["us_per_step"]
+    assert fb["schedule"] == "synchronous" and fb["other_schedule"]["schedule"] == "overlapped" and fb["other_schedule"]["steps"] == 40
     assert "error" not in fb["p2p"] and fb["p2p"]["steps"] == 40 and fb["p2p"]["us_per_step"] < fb["us_per_step"], fb["p2p"]
 
 
