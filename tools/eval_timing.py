@@ -25,7 +25,7 @@ dev = "cuda:0"
 torch.manual_seed(0)
 emb_init = (gamma + 2.0) / D
 ent = torch.empty(n_ent, D, device=dev).uniform_(-emb_init, emb_init)
-rel = torch.empty(n_rel, D, device=dev).uniform_(-emb_init, emb_init)
+rel = torch.empty(n_rel, D // 2 if model == "RotatE" else D, device=dev).uniform_(-emb_init, emb_init)
 for it in range(3):
     t0 = time.perf_counter()
     filts = [E.build_filter(known[0], known[1], known[2], test[0], test[1], test[2], nh, n_rel) for nh in (True, False)]
