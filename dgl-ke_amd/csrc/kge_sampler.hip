@@ -11,7 +11,7 @@
 // One workgroup (1024 threads) builds one batch entirely in LDS:
 //   1. positives: whole batches of the epoch's edge order (base permutation re-keyed per epoch) -> (h, r, t);  negatives: counter-based hash
 //      RNG keyed by (seed, step, j) -> uniform id in [0, n_ent)
-//   2. sort of <= 4096 keys  (entity id << 12 | element code), code = edge*2+side  (a stable block radix sort over the id bits:
+//   2. sort of <= 4096 keys (wide instance: 8192)  (entity id << 12 (13) | element code), code = edge*2+side  (a stable block radix sort over the id bits:
 //      the codes are the positions; the relation plan keeps the register bitonic network)
 //      for positive edge ends, 2B + slot for negatives  -> elements grouped by entity, ascending
 //      code inside a group (= the order of the host plan and of index_add_)
@@ -114,13 +114,14 @@ __device__ void bitonic_sort(K *keys, int n2) {
     else bitonic_sort_lds<K>(keys, n2);
 }
 
-// block-wide exclusive scan of n (<= SP_MAXE) uint32 values in `v` (in place); returns the total.
-// Each thread owns 4 consecutive elements.
+// block-wide exclusive scan of n (<= EPT * SP_THREADS) uint32 values in `v` (in place); returns the total.
+// Each thread owns EPT consecutive elements.
+template <int EPT = 4>
 __device__ uint32_t block_exclusive_scan(uint32_t *v, int n, uint32_t *wsum /*[SP_THREADS/64]*/) {
     const int t = threadIdx.x;
-    uint32_t loc[4], s = 0;
+    uint32_t loc[EPT], s = 0;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { const int i = 4 * t + e; loc[e] = i < n ? v[i] : 0; s += loc[e]; }
+    for (int e = 0; e < EPT; ++e) { const int i = EPT * t + e; loc[e] = i < n ? v[i] : 0; s += loc[e]; }
     uint32_t inc = s;                        // inclusive scan of s across the wavefront
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -133,15 +134,25 @@ __device__ uint32_t block_exclusive_scan(uint32_t *v, int n, uint32_t *wsum /*[S
     for (int w = 0; w < SP_THREADS / 64; ++w) { const uint32_t x = wsum[w]; if (w < (t >> 6)) base += x; total += x; }
     uint32_t run = base + inc - s;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { const int i = 4 * t + e; if (i < n) v[i] = run; run += loc[e]; }
+    for (int e = 0; e < EPT; ++e) { const int i = EPT * t + e; if (i < n) v[i] = run; run += loc[e]; }
     __syncthreads();
     return total;
 }
 
-template <typename K>             // key type of the entity plan: uint32_t when (id << SP_CODE_BITS) fits, else uint64_t
+// K: key type of the entity plan - uint32_t when (id << CBITS) fits, else uint64_t.  MAXE / CBITS: SP_MAXE / SP_CODE_BITS (4 keys
+// per thread: every BASELINE config) or the wide instance SP_MAXE_BIG / SP_CODE_BITS_BIG (8 keys per thread; B <= MAXE / 2)
+template <typename K, int MAXE = SP_MAXE, int CBITS = SP_CODE_BITS>
 __global__ __launch_bounds__(SP_THREADS) void sample_plan_kernel(SamplerArgs a) {
-    __shared__ uint64_t keys[SP_MAXE];         // 32 KB (the entity plan with 32-bit keys uses half of it)
-    __shared__ uint32_t scan[SP_MAXE];         // 16 KB
+    constexpr int EPT = MAXE / SP_THREADS;
+    typedef rocprim::block_radix_sort<K, SP_THREADS, EPT> BlockSort;
+    // keys: the relation plan sorts <= MAXE / 2 64-bit keys, the entity plan MAXE keys of type K.  The radix sort's scratch and the
+    // scan's flags are never live together: one buffer (wide instance with 64-bit keys: 64 + 72 KB instead of 168)
+    constexpr size_t KEY_BYTES = sizeof(K) * MAXE > 8 * (size_t)(MAXE / 2) ? sizeof(K) * MAXE : 8 * (size_t)(MAXE / 2);
+    constexpr size_t SCR_BYTES = sizeof(typename BlockSort::storage_type) > 4 * (size_t)MAXE ? sizeof(typename BlockSort::storage_type) : 4 * (size_t)MAXE;
+    __shared__ __attribute__((aligned(16))) unsigned char keys_raw[KEY_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char scr_raw[SCR_BYTES];
+    uint64_t *keys = reinterpret_cast<uint64_t *>(keys_raw);
+    uint32_t *scan = reinterpret_cast<uint32_t *>(scr_raw);
     __shared__ uint32_t wsum[SP_THREADS / 64];
     const int t = threadIdx.x;
     KGE_TL((int)(blockIdx.x & 1));             // developer timeline: kid 0 = entity-plan workgroups, 1 = relation-plan workgroups
@@ -202,23 +213,23 @@ __global__ __launch_bounds__(SP_THREADS) void sample_plan_kernel(SamplerArgs a) 
                 if (a.perm) e = a.perm[e];
                 const int64_t r = a.R[e];
                 rel_ids[i] = r;
-                key = ((uint64_t)r << SP_CODE_BITS) | (uint64_t)i;
+                key = ((uint64_t)r << CBITS) | (uint64_t)i;
             }
             keys[i] = key;
         }
         __syncthreads();
         bitonic_sort<uint64_t>(keys, b2);
         for (int k = t; k < B; k += SP_THREADS) {
-            const uint64_t id = keys[k] >> SP_CODE_BITS;
-            scan[k] = (k == 0 || (keys[k - 1] >> SP_CODE_BITS) != id) ? 1u : 0u;
+            const uint64_t id = keys[k] >> CBITS;
+            scan[k] = (k == 0 || (keys[k - 1] >> CBITS) != id) ? 1u : 0u;
         }
         __syncthreads();
-        const int UR = (int)block_exclusive_scan(scan, B, wsum);
+        const int UR = (int)block_exclusive_scan<EPT>(scan, B, wsum);
         for (int k = t; k < B; k += SP_THREADS) {
-            const uint64_t id = keys[k] >> SP_CODE_BITS;
-            const bool uniq = k == 0 || (keys[k - 1] >> SP_CODE_BITS) != id;
+            const uint64_t id = keys[k] >> CBITS;
+            const bool uniq = k == 0 || (keys[k - 1] >> CBITS) != id;
             const int u = (int)scan[k];
-            ur_edge[k] = (int)(keys[k] & ((1u << SP_CODE_BITS) - 1));
+            ur_edge[k] = (int)(keys[k] & ((1u << CBITS) - 1));
             if (uniq) { ur_id[u] = (int64_t)id; ur_ptr[u] = k; }
         }
         __shared__ int maxlen_sh;
@@ -246,13 +257,13 @@ __global__ __launch_bounds__(SP_THREADS) void sample_plan_kernel(SamplerArgs a) 
         if (a.perm) e = a.perm[e];
         const int64_t h = a.H[e], tl = a.T[e];
         h_gid[i] = h; t_gid[i] = tl;
-        ek[2 * i] = ((K)h << SP_CODE_BITS) | (K)(2 * i);
-        ek[2 * i + 1] = ((K)tl << SP_CODE_BITS) | (K)(2 * i + 1);
+        ek[2 * i] = ((K)h << CBITS) | (K)(2 * i);
+        ek[2 * i + 1] = ((K)tl << CBITS) | (K)(2 * i + 1);
     }
     for (int j = t; j < CN; j += SP_THREADS) {
         const int64_t id = sample_negative(a, step, j);
         neg_ids[j] = id;
-        ek[2 * B + j] = ((K)id << SP_CODE_BITS) | (K)(2 * B + j);
+        ek[2 * B + j] = ((K)id << CBITS) | (K)(2 * B + j);
     }
 #ifdef SP_BITONIC
     int n2 = 1;
@@ -265,7 +276,7 @@ __global__ __launch_bounds__(SP_THREADS) void sample_plan_kernel(SamplerArgs a) 
     // ---- 2. sort by (entity, code) ----
     bitonic_sort<K>(ek, n2);
 #else
-    for (int i = NE + t; i < SP_MAXE; i += SP_THREADS) ek[i] = ~(K)0;
+    for (int i = NE + t; i < MAXE; i += SP_THREADS) ek[i] = ~(K)0;
     __syncthreads();
 #ifdef KGE_TL_MARKS
     KGE_TL_MARK(0);              // ids sampled, keys in LDS
@@ -274,16 +285,15 @@ __global__ __launch_bounds__(SP_THREADS) void sample_plan_kernel(SamplerArgs a) 
     // a block radix sort (rocPRIM: 8 bits per pass, ranks by wavefront matching) over the bits of n_ent - 1: 2 passes for
     // FB15k's 14 951 entities, 4 for Freebase's 86 M, instead of the 78 compare-exchange stages of the bitonic network
     {
-        typedef rocprim::block_radix_sort<K, SP_THREADS, SP_MAXE / SP_THREADS> BlockSort;
-        __shared__ typename BlockSort::storage_type sort_tmp;
-        K item[SP_MAXE / SP_THREADS];
+        typename BlockSort::storage_type &sort_tmp = *reinterpret_cast<typename BlockSort::storage_type *>(scr_raw);
+        K item[EPT];
 #pragma unroll
-        for (int e = 0; e < SP_MAXE / SP_THREADS; ++e) item[e] = ek[(SP_MAXE / SP_THREADS) * t + e];
+        for (int e = 0; e < EPT; ++e) item[e] = ek[(EPT) * t + e];
         unsigned idbits = 1;
-        while (idbits < 8 * sizeof(K) - SP_CODE_BITS && ((uint64_t)(a.n_ent - 1) >> idbits)) ++idbits;
-        BlockSort().sort(item, sort_tmp, SP_CODE_BITS, SP_CODE_BITS + idbits);
+        while (idbits < 8 * sizeof(K) - CBITS && ((uint64_t)(a.n_ent - 1) >> idbits)) ++idbits;
+        BlockSort().sort(item, sort_tmp, CBITS, CBITS + idbits);
 #pragma unroll
-        for (int e = 0; e < SP_MAXE / SP_THREADS; ++e) ek[(SP_MAXE / SP_THREADS) * t + e] = item[e];
+        for (int e = 0; e < EPT; ++e) ek[(EPT) * t + e] = item[e];
         __syncthreads();
     }
 #endif
@@ -292,17 +302,17 @@ __global__ __launch_bounds__(SP_THREADS) void sample_plan_kernel(SamplerArgs a) 
 #endif
     // ---- 3. packed flags: bit fields {unique: 0..15, positive: 16..31}; negative rank = k - positive rank ----
     for (int k = t; k < NE; k += SP_THREADS) {
-        const uint64_t id = ek[k] >> SP_CODE_BITS, code = ek[k] & ((1u << SP_CODE_BITS) - 1);
-        const bool uniq = k == 0 || ((uint64_t)(ek[k - 1] >> SP_CODE_BITS)) != id;
+        const uint64_t id = ek[k] >> CBITS, code = ek[k] & ((1u << CBITS) - 1);
+        const bool uniq = k == 0 || ((uint64_t)(ek[k - 1] >> CBITS)) != id;
         scan[k] = (uniq ? 1u : 0u) | (code < (uint64_t)(2 * B) ? (1u << 16) : 0u);
     }
     __syncthreads();
-    const uint32_t tot = block_exclusive_scan(scan, NE, wsum);
+    const uint32_t tot = block_exclusive_scan<EPT>(scan, NE, wsum);
     const int UE = (int)(tot & 0xFFFF);
     for (int k = t; k < NE; k += SP_THREADS) {
-        const uint64_t id = ek[k] >> SP_CODE_BITS;
-        const int code = (int)(ek[k] & ((1u << SP_CODE_BITS) - 1));
-        const bool uniq = k == 0 || ((uint64_t)(ek[k - 1] >> SP_CODE_BITS)) != id;
+        const uint64_t id = ek[k] >> CBITS;
+        const int code = (int)(ek[k] & ((1u << CBITS) - 1));
+        const bool uniq = k == 0 || ((uint64_t)(ek[k - 1] >> CBITS)) != id;
         const uint32_t ex = scan[k];
         const int u = (int)(ex & 0xFFFF), pp = (int)(ex >> 16), pn = k - pp;
         if (uniq) { ue_id[u] = (int64_t)id; ue_pos_ptr[u] = pp; ue_neg_ptr[u] = pn; }
@@ -327,7 +337,11 @@ __global__ __launch_bounds__(SP_THREADS) void sample_plan_kernel(SamplerArgs a) 
 
 int launch_sample_batches(const SamplerArgs &a, int n_slots, hipStream_t s) {
     if (n_slots <= 0) return KGE_OK;
-    if (a.n_ent <= (1ll << (32 - SP_CODE_BITS))) hipLaunchKernelGGL(sample_plan_kernel<uint32_t>, dim3(2 * n_slots), dim3(SP_THREADS), 0, s, a);
+    if (2 * a.B + a.C * a.N > SP_MAXE || a.B > SP_MAXE / 2) {      // the wide instance: 8 keys per thread, 13 code bits
+        if (a.n_ent <= (1ll << (32 - SP_CODE_BITS_BIG)))
+            hipLaunchKernelGGL((sample_plan_kernel<uint32_t, SP_MAXE_BIG, SP_CODE_BITS_BIG>), dim3(2 * n_slots), dim3(SP_THREADS), 0, s, a);
+        else hipLaunchKernelGGL((sample_plan_kernel<uint64_t, SP_MAXE_BIG, SP_CODE_BITS_BIG>), dim3(2 * n_slots), dim3(SP_THREADS), 0, s, a);
+    } else if (a.n_ent <= (1ll << (32 - SP_CODE_BITS))) hipLaunchKernelGGL(sample_plan_kernel<uint32_t>, dim3(2 * n_slots), dim3(SP_THREADS), 0, s, a);
     else hipLaunchKernelGGL(sample_plan_kernel<uint64_t>, dim3(2 * n_slots), dim3(SP_THREADS), 0, s, a);
     return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
 }
@@ -348,7 +362,7 @@ int kge_sample_batches(const int64_t *heads, const int64_t *rels, const int64_t 
     if (!heads || !rels || !tails || !state || !slots || n_train <= 0 || n_ent <= 0 || B <= 0 || C <= 0 ||
         chunk <= 0 || N <= 0 || C * chunk != B)
         return KGE_ERR_ARG;
-    if (2 * B + C * N > SP_MAXE || B > SP_MAXE || n_ent >= ((int64_t)1 << 51))
+    if (2 * B + C * N > SP_MAXE_BIG || B > SP_MAXE_BIG / 2 || n_ent >= ((int64_t)1 << (64 - SP_CODE_BITS_BIG)))
         return KGE_ERR_ARG;                      // larger batches: build the plan on the host
     if (slot_bytes < kge_sampler_slot_bytes(B, C, N)) return KGE_ERR_WORKSPACE;
     SamplerArgs a{};

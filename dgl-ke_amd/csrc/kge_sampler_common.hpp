@@ -5,8 +5,12 @@
 #include "kge_common.hpp"
 
 #define SP_THREADS 1024
-#define SP_MAXE 4096                 // max elements (2B + C*N) and max B handled on the device
+#define SP_MAXE 4096                 // elements (2B + C*N) of a batch in the sampler's fast instance and in the tail path
 #define SP_CODE_BITS 12
+// (round 6) the sampler LAUNCH also has a wide instance: 8 keys per thread, 13 code bits - the reference's batch-2048 recipes
+// (14 of its example scripts: 2 * 2048 + 8 * 256 = 6144 elements) were built on the host at ~1 ms per step
+#define SP_MAXE_BIG 8192
+#define SP_CODE_BITS_BIG 13
 
 struct SamplerArgs {
     const int64_t *H, *R, *T;        // training triples [n_train]

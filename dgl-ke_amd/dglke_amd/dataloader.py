@@ -156,9 +156,9 @@ class DeviceSampler(object):
         if self.B % self.chunk:
             raise ValueError("batch_size should be divisible by the chunk size")
         self.C = self.B // self.chunk
-        if 2 * self.B + self.C * self.N > 4096:
-            raise _lib.KgeError("DeviceSampler handles 2*batch + chunks*neg <= 4096 elements per step; "
-                                "use UniformChunkedSampler (host plan) for larger batches")
+        if 2 * self.B + self.C * self.N > self.MAX_ELEMENTS:
+            raise _lib.KgeError("DeviceSampler handles 2*batch + chunks*neg <= %d elements per step; "
+                                "use UniformChunkedSampler (host plan) for larger batches" % self.MAX_ELEMENTS)
         self.n_entities = int(n_entities)
         def put(x):       # triples may already live in HBM (generated or loaded there)
             if isinstance(x, th.Tensor):
@@ -208,6 +208,11 @@ class DeviceSampler(object):
         self.host_step += n
         return out
 
+    # elements (2 * batch + chunks * neg) of a batch the sampler LAUNCH builds (csrc/kge_sampler_common.hpp SP_MAXE_BIG: the reference's
+    # batch-2048 recipes are 6144) and the tail jobs that ride on a step's launches (SP_MAXE)
+    MAX_ELEMENTS = 8192
+    MAX_ELEMENTS_TAIL = 4096
+
     def prepare_tail(self):
         """what tail_jobs needs once: the scratch buffer and - the jobs read the triples in base-permutation order, their first phase
         is a chain of dependent memory rounds under a 9-us launch and perm[e] was one of them - permuted copies of the triples.
@@ -220,6 +225,9 @@ class DeviceSampler(object):
             return
         if th.cuda.is_current_stream_capturing():
             raise _lib.KgeError("DeviceSampler.prepare_tail() must run before the graph capture that uses tail_jobs()")
+        if 2 * self.B + self.C * self.N > self.MAX_ELEMENTS_TAIL:
+            raise _lib.KgeError("sampler tail jobs handle 2*batch + chunks*neg <= %d elements per step (larger batches: the sampler "
+                                "launch)" % self.MAX_ELEMENTS_TAIL)
         nb = int(_lib.lib().kge_sampler_tail_scratch_bytes(self.B, self.C, self.N, self.n_entities))
         if self.perm is not None:
             self._Hp, self._Rp, self._Tp = self.H[self.perm].contiguous(), self.R[self.perm].contiguous(), self.T[self.perm].contiguous()

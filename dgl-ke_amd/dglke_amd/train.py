@@ -284,7 +284,7 @@ class Trainer(object):
         if getattr(args, 'async_update', False) and getattr(args, 'async_update_rel', False):
             self.step_flags |= _lib.FLAG_ASYNC_REL
             self.model.engine.hp.flags |= _lib.FLAG_ASYNC_REL
-        self.device_sampler = self.fused and not args.has_edge_importance and 2 * B + C * N <= 4096
+        self.device_sampler = self.fused and not args.has_edge_importance and 2 * B + C * N <= 8192
         self.n_lanes = max(1, int(args.num_proc))
         self.async_ok = self.fused and args.model_name not in ('TransR', 'RESCAL')
         # entity-only deferral (the reference's --async_update) runs as the strict step unless the pipeline is asked for: with the
@@ -452,8 +452,8 @@ class ShardedTrainer(object):
         B, N = args.batch_size, args.neg_sample_size
         self.chunk = N if N <= B else B
         self.fused, self.n_lanes, self.async_ok = True, 1, False
-        # (edge importance / more than 4096 ids per batch: host-built batches, like the single-GPU trainer's host sampler path)
-        self.device_sampler = 2 * B + (B // self.chunk) * N <= 4096 and not args.has_edge_importance
+        # (edge importance / more than 8192 ids per batch: host-built batches, like the single-GPU trainer's host sampler path)
+        self.device_sampler = 2 * B + (B // self.chunk) * N <= 8192 and not args.has_edge_importance
         if args.neg_deg_sample and args.model_name in ('TransR', 'RESCAL'):
             raise KgeError("--neg_deg_sample is not available for %s on sharded tables" % args.model_name)
         d_e = args.hidden_dim * (2 if args.double_ent else 1)
@@ -614,9 +614,9 @@ class A2ATrainer(ShardedTrainer):
         self.chunk = N if N <= B else B
         self.fused, self.n_lanes, self.async_ok = True, 1, False
         # the on-device sampler builds the batches of a whole group ahead (group routing, one id exchange, group graphs); batches it
-        # cannot build - edge importance, or more than 4096 ids per batch - come from the host sampler: plans built on the host,
+        # cannot build - edge importance, or more than 8192 ids per batch - come from the host sampler: plans built on the host,
         # routed and exchanged step by step, eager launches (the same sharded step; slower: the host builds a plan per step)
-        self.device_sampler = 2 * B + (B // self.chunk) * N <= 4096 and not args.has_edge_importance
+        self.device_sampler = 2 * B + (B // self.chunk) * N <= 8192 and not args.has_edge_importance
         # TransR / RESCAL (round 6): the relation side - relation rows / matrices, TransR's projection table - is applied IN PLACE on the
         # trainer that holds the relation's edges, so the triples are always partitioned by whole relations for these two (the
         # reference's own multi-GPU TransR recipe passes --rel_part, examples/freebase/multi_gpu.sh:80-89); only entity messages travel

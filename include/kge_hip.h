@@ -449,7 +449,8 @@ int kge_ipc_close(void *base);
  * floor(n_train / B) WHOLE batches (the trailing partial batch is dropped, dataloader/sampler.py:503-504) and
  * every epoch has its own edge order (shuffle=True): epoch 0 = perm, epoch e > 0 = perm composed with an affine
  * bijection of [0, n_train) keyed by (seed, e).  n_train >= B.
- * Limits: 2B + C*N <= 4096 (one workgroup sorts a batch in LDS). */
+ * Limits: 2B + C*N <= 8192 (one workgroup sorts a batch in LDS: 4 keys per thread up to 4096 elements, the
+ * wide instance 8 keys per thread - the reference's batch-2048 recipes are 6144). */
 size_t kge_sampler_slot_bytes(int B, int C, int N);
 int kge_sample_batches(const int64_t *heads, const int64_t *rels, const int64_t *tails,
                        const int64_t *perm, int64_t n_train, int64_t n_ent, int B, int C, int chunk,

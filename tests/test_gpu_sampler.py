@@ -9,7 +9,12 @@ DEV = "cuda:0"
 
 
 @pytest.mark.parametrize("n_ent,n_rel,B,N,chunk", [(14951, 1345, 1000, 200, 200), (9, 2, 16, 4, 4), (86054151, 14824, 1024, 256, 256),
-                                                    (500, 7, 120, 24, 40)])
+                                                    (500, 7, 120, 24, 40),
+                                                    # the sampler launch's wide instance (round 6: 8 keys per thread, 13 code bits): the
+                                                    # reference's batch-2048 recipes (6144 elements), the largest shape (8192), 64-bit keys
+                                                    # (more than 2^19 entities), a tiny id range with long duplicate runs
+                                                    (14951, 1345, 2048, 256, 256), (40943, 18, 2048, 128, 128), (3000, 11, 3072, 512, 1536),
+                                                    (86054151, 14824, 2048, 512, 512), (50, 3, 2048, 64, 64), (20000, 30, 2048, 1024, 512)])
 def test_device_plan_equals_host_plan(n_ent, n_rel, B, N, chunk):
     from dglke_amd import plan
     from dglke_amd.dataloader import DeviceSampler
