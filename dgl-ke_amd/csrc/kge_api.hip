@@ -686,6 +686,11 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         m.B = B; m.D = d_e; m.UR = b->UR; m.rel = tbx->rel; m.ent = tbx->ent; m.hidx = bx->h_gid; m.tidx = bx->t_gid;
         m.ur_id = b->ur_id; m.ur_ptr = b->ur_ptr; m.ur_edge = b->ur_edge; m.counts_dev = b->counts_dev;
         m.V = b->neg_head ? A : RV; m.W = b->neg_head ? nullptr : A; m.ppart = Rpp; m.P = P;
+        if (reg) {      // the regulariser's products ride on this pass (they live in the front of RC1, which the update's pass over
+            //             the matrices overwrites only AFTER the traced rows' mean squares were taken from them)
+            m.PV = RC1; m.PW = RC1 + (size_t)B * d_e; m.rho = RC1 + 2 * (size_t)B * d_e;
+            m.reg_coef = hp->reg_coef; m.reg_norm = hp->reg_norm;
+        }
         KGE_TRY(launch_rescal_rel_fwd(m, s));
         }
         if (dense_neg) {                 // pairwise fallback kernels read a dense copy of the negative rows
@@ -886,6 +891,7 @@ static int step_impl(const kge_hparams *hp, const kge_tables *tb, const kge_batc
         ru.dpos = dP; ru.GA = GA; ru.ur_id = b->ur_id; ru.ur_ptr = b->ur_ptr; ru.ur_edge = b->ur_edge;
         ru.counts_dev = b->counts_dev; ru.reg_rel = want4 ? reg_rel : nullptr; ru.acc = acc;
         if (rescal_rel) { ru.c1p = RC1; ru.c2p = RC2; }
+        if (rescal_rel && reg) { ru.PV = RC1; ru.PW = RC1 + (size_t)B * d_e; ru.rho = RC1 + 2 * (size_t)B * d_e; }
         KGE_TRY(launch_rescal_update_rel(ru, s));
         if (rescal_rel) {
             RescalCombineArgs cb{};

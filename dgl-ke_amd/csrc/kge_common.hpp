@@ -605,6 +605,9 @@ struct RescalUpdateArgs {            // fused Adagrad of the relation matrices (
     float *reg_rel, *acc;
     float *c1p, *c2p;                // [B, RESCAL_RBN, D] or null.  Non-null: the Adagrad pass over M also produces the backward's
                                      // column products M^T h (c1p) and M^T GA (c2p), one part per row block (ONE pass over M)
+    // regulariser products of the forward pass (RescalRelFwdArgs.PV / PW / rho) or null: with them the traced rows' mean squares
+    // come in closed form and the regulariser costs no pass over the matrices of its own (kge_rescal.hip rescal_edge_sq_regx_kernel)
+    const float *PV, *PW, *rho;
 };
 struct RescalRelFwdArgs {            // forward products per UNIQUE relation: one pass over M serves every edge of the relation
     int B, D, UR;
@@ -614,6 +617,9 @@ struct RescalRelFwdArgs {            // forward products per UNIQUE relation: on
     float *W;                        // [B, D]  M h, or null
     float *ppart;                    // [B, RESCAL_RBN] parts of p = h . (M t)
     float *P;                        // [B]
+    // round 6: with R = the regulariser's gradient of M (elementwise), the same pass also leaves R t (PV [B, D]), R h (PW [B, D], with W)
+    // and the row blocks' parts of sum(R^2) per edge (rho [B, RESCAL_RBN]); all null: no regulariser
+    float *PV, *PW, *rho; float reg_coef; int reg_norm;
 };
 struct RescalCombineArgs {           // GH = dp V (+ M^T GA, tail mode), GT = dp M^T h (+ M^T GA, head mode) from the row-block parts
     int B, D, neg_head;

@@ -296,7 +296,39 @@ __global__ __launch_bounds__(KGE_BLOCK) void rescal_edge_sq_kernel(RescalUpdateA
     }
 }
 
-__global__ __launch_bounds__(KGE_BLOCK) void rescal_edge_sq_reg_kernel(RescalUpdateArgs a) {  // with regulariser
+// with regulariser, closed form (round 6): g = dp h t^T + GA x^T + R  ->
+//   sum g^2 = [dp^2 |h|^2 |t|^2 + |GA|^2 |x|^2 + 2 dp (h.GA)(t.x)] + 2 [dp h.(R t) + GA.(R x)] + sum R^2
+// with R t / R x / sum R^2 left by the forward pass over the matrices (rescal_rel_fwd_kernel<.., REG>): no pass over M here
+// (rescal_edge_sq_reg_kernel below read every traced matrix once more: 328 us of the FB15k recipe's 923-us step)
+__global__ __launch_bounds__(KGE_BLOCK) void rescal_edge_sq_regx_kernel(RescalUpdateArgs a) {
+    const int64_t e = (int64_t)blockIdx.x * KGE_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (e >= a.B) return;
+    const int lane = threadIdx.x & 63, D = a.D;
+    const float *h = a.ent + a.hidx[e] * (int64_t)D, *t = a.ent + a.tidx[e] * (int64_t)D, *x = a.neg_head ? t : h;
+    const float *ga = a.GA + e * (int64_t)D;
+    const float *pv = a.PV + e * (int64_t)D, *px = a.neg_head ? pv : a.PW + e * (int64_t)D;
+    float hh = 0.f, tt = 0.f, gg = 0.f, xx = 0.f, hg = 0.f, tx = 0.f, hp = 0.f, gp = 0.f;
+    for (int b = lane; b < D; b += 64) {
+        const float hv = h[b], tv = t[b], gv = ga[b], xv = x[b];
+        hh = fmaf(hv, hv, hh); tt = fmaf(tv, tv, tt); gg = fmaf(gv, gv, gg);
+        xx = fmaf(xv, xv, xx); hg = fmaf(hv, gv, hg); tx = fmaf(tv, xv, tx);
+        hp = fmaf(hv, pv[b], hp); gp = fmaf(gv, px[b], gp);
+    }
+    float rr = lane < RESCAL_RBN ? a.rho[e * RESCAL_RBN + lane] : 0.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        hh += __shfl_xor(hh, o, 64); tt += __shfl_xor(tt, o, 64); gg += __shfl_xor(gg, o, 64);
+        xx += __shfl_xor(xx, o, 64); hg += __shfl_xor(hg, o, 64); tx += __shfl_xor(tx, o, 64);
+        hp += __shfl_xor(hp, o, 64); gp += __shfl_xor(gp, o, 64); rr += __shfl_xor(rr, o, 64);
+    }
+    if (lane == 0) {
+        const float dp = a.dpos[e];
+        const float ss = dp * dp * hh * tt + gg * xx + 2.f * dp * hg * tx + 2.f * (dp * hp + gp) + rr;
+        a.gs[e * RESCAL_RB] = fmaxf(ss, 0.f) / ((float)D * (float)D);
+    }
+}
+
+__global__ __launch_bounds__(KGE_BLOCK) void rescal_edge_sq_reg_kernel(RescalUpdateArgs a) {  // with regulariser, one pass over M per edge
     __shared__ float red[KGE_WAVES_PER_BLOCK];
     const int e = blockIdx.x / RESCAL_RB, rb = blockIdx.x % RESCAL_RB;
     const int D = a.D;
@@ -486,10 +518,20 @@ __device__ __forceinline__ void axpy4(float4 &acc, const float4 &m, float s) {
     acc.x = fmaf(m.x, s, acc.x); acc.y = fmaf(m.y, s, acc.y); acc.z = fmaf(m.z, s, acc.z); acc.w = fmaf(m.w, s, acc.w);
 }
 
-template <int NC4, int EG, bool W2>
+__device__ __forceinline__ float4 reg_grad4(const float4 &m, float coef, int q) {
+    if (q == 3)                                        // (wave-uniform; the default norm: plain multiplies instead of exp2 / log)
+        return make_float4(reg_grad3(m.x, coef), reg_grad3(m.y, coef), reg_grad3(m.z, coef), reg_grad3(m.w, coef));
+    return make_float4(reg_grad(m.x, coef, q), reg_grad(m.y, coef, q), reg_grad(m.z, coef, q), reg_grad(m.w, coef, q));
+}
+
+// REG (round 6): the pass also applies the regulariser's gradient R = reg_grad(M) to the edges' vectors - R t (and R h with W2) per row,
+// sum(R^2) per row block - so that the update needs no pass of its own for the traced rows' mean squares (rescal_edge_sq_regx_kernel)
+template <int NC4, int EG, bool W2, bool REG>
 __global__ __launch_bounds__(KGE_BLOCK) void rescal_rel_fwd_kernel(RescalRelFwdArgs a) {
     __shared__ float s_h[EG][RESCAL_RMAX];
     __shared__ float s_p[EG][KGE_WAVES_PER_BLOCK];
+    __shared__ float s_r[KGE_WAVES_PER_BLOCK];
+    float rsum = 0.f;                                  // this lane's share of sum(R^2) over the row block (first edge group only)
     const int u = blockIdx.x / RESCAL_RBN, rb = blockIdx.x % RESCAL_RBN;
     if (u >= (a.counts_dev ? a.counts_dev[1] : a.UR)) return;
     const int D = a.D, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -531,23 +573,42 @@ __global__ __launch_bounds__(KGE_BLOCK) void rescal_rel_fwd_kernel(RescalRelFwdA
             for (int k = 0; k < NC4; ++k) { const int b = 4 * lane + 256 * k; mA[k] = ld4z(rowA + b, b < D); }
 #pragma unroll
             for (int k = 0; k < NC4; ++k) { const int b = 4 * lane + 256 * k; mB[k] = ld4z(rowB + b, b < D); }
+            float4 pA[REG ? NC4 : 1], pB[REG ? NC4 : 1];
+            if constexpr (REG) {
+#pragma unroll
+                for (int k = 0; k < NC4; ++k) { pA[k] = reg_grad4(mA[k], a.reg_coef, a.reg_norm); pB[k] = reg_grad4(mB[k], a.reg_coef, a.reg_norm); }
+                if (q0 == e0) {
+#pragma unroll
+                    for (int k = 0; k < NC4; ++k) { rsum = dot4(pA[k], pA[k], rsum); if (hasB) rsum = dot4(pB[k], pB[k], rsum); }
+                }
+            }
 #pragma unroll
             for (int g = 0; g < EG; ++g) {
-                float d1A = 0.f, d2A = 0.f, d1B = 0.f, d2B = 0.f;
+                float d1A = 0.f, d2A = 0.f, d1B = 0.f, d2B = 0.f, d3A = 0.f, d4A = 0.f, d3B = 0.f, d4B = 0.f;
 #pragma unroll
                 for (int k = 0; k < NC4; ++k) {
                     d1A = dot4(mA[k], yt[g][k], d1A); d1B = dot4(mB[k], yt[g][k], d1B);
                     if (W2) { d2A = dot4(mA[k], yh[g][k], d2A); d2B = dot4(mB[k], yh[g][k], d2B); }
+                    if constexpr (REG) {
+                        d3A = dot4(pA[k], yt[g][k], d3A); d3B = dot4(pB[k], yt[g][k], d3B);
+                        if (W2) { d4A = dot4(pA[k], yh[g][k], d4A); d4B = dot4(pB[k], yh[g][k], d4B); }
+                    }
                 }
                 d1A = wave_sum(d1A); d1B = wave_sum(d1B);
                 if (W2) { d2A = wave_sum(d2A); d2B = wave_sum(d2B); }
+                if constexpr (REG) {
+                    d3A = wave_sum(d3A); d3B = wave_sum(d3B);
+                    if (W2) { d4A = wave_sum(d4A); d4B = wave_sum(d4B); }
+                }
                 if (lane == 0 && on[g]) {
                     a.V[e[g] * D + r] = d1A;
                     if (W2) a.W[e[g] * D + r] = d2A;
+                    if constexpr (REG) { a.PV[e[g] * D + r] = d3A; if (W2) a.PW[e[g] * D + r] = d4A; }
                     pa[g] = fmaf(s_h[g][r - r0], d1A, pa[g]);
                     if (hasB) {
                         a.V[e[g] * D + rB] = d1B;
                         if (W2) a.W[e[g] * D + rB] = d2B;
+                        if constexpr (REG) { a.PV[e[g] * D + rB] = d3B; if (W2) a.PW[e[g] * D + rB] = d4B; }
                         pa[g] = fmaf(s_h[g][rB - r0], d1B, pa[g]);
                     }
                 }
@@ -565,6 +626,16 @@ __global__ __launch_bounds__(KGE_BLOCK) void rescal_rel_fwd_kernel(RescalRelFwdA
                 a.ppart[e[g] * RESCAL_RBN + rb] = sp;
             }
     }
+    if constexpr (REG) {                               // sum(R^2) of this row block: the same value for every edge of the relation
+        rsum = wave_sum(rsum);
+        __syncthreads();
+        if (lane == 0) s_r[wave] = rsum;
+        __syncthreads();
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < KGE_WAVES_PER_BLOCK; ++w) tot += s_r[w];
+        for (int q = e0 + (int)threadIdx.x; q < e1; q += KGE_BLOCK) a.rho[(int64_t)a.ur_edge[q] * RESCAL_RBN + rb] = tot;
+    }
 }
 
 __global__ void rescal_psum_kernel(RescalRelFwdArgs a) {       // p = the row blocks' parts in a fixed order
@@ -581,8 +652,11 @@ int launch_rescal_rel_fwd(const RescalRelFwdArgs &a, hipStream_t s) {
     if (a.D % 4 != 0 || a.D > 1024) return KGE_ERR_ARG;
     const dim3 g(a.UR * RESCAL_RBN), b(KGE_BLOCK);
     const bool w2 = a.W != nullptr;
-#define RF(NC4, EG) do { if (w2) hipLaunchKernelGGL((rescal_rel_fwd_kernel<NC4, EG, true>), g, b, 0, s, a); \
-                         else hipLaunchKernelGGL((rescal_rel_fwd_kernel<NC4, EG, false>), g, b, 0, s, a); } while (0)
+    const bool rg = a.PV && a.rho && a.reg_coef > 0.f && a.reg_norm > 0 && (!w2 || a.PW);
+#define RF(NC4, EG) do { if (w2 && rg) hipLaunchKernelGGL((rescal_rel_fwd_kernel<NC4, EG, true, true>), g, b, 0, s, a); \
+                         else if (w2) hipLaunchKernelGGL((rescal_rel_fwd_kernel<NC4, EG, true, false>), g, b, 0, s, a); \
+                         else if (rg) hipLaunchKernelGGL((rescal_rel_fwd_kernel<NC4, EG, false, true>), g, b, 0, s, a); \
+                         else hipLaunchKernelGGL((rescal_rel_fwd_kernel<NC4, EG, false, false>), g, b, 0, s, a); } while (0)
     if (a.D <= 256) RF(1, RESCAL_EG);
     else if (a.D <= 512) RF(2, RESCAL_EG);
     else RF(4, 1);
@@ -775,9 +849,12 @@ __global__ void rescal_reg_finalize_kernel(RescalUpdateArgs a) {
 int launch_rescal_update_rel(const RescalUpdateArgs &a, hipStream_t s) {
     if (a.UR == 0 || a.B == 0) return KGE_OK;
     const bool reg = a.reg_coef > 0.f && a.reg_norm > 0;
-    if (reg) hipLaunchKernelGGL(rescal_edge_sq_reg_kernel, dim3(a.B * RESCAL_RB), dim3(KGE_BLOCK), 0, s, a);
+    const bool regx = reg && a.PV && a.rho && (a.neg_head || a.PW);      // the forward pass left the regulariser's products
+    static_assert(RESCAL_RBN <= 64, "rescal_edge_sq_regx_kernel: one lane per row-block part of sum(R^2)");
+    if (regx) hipLaunchKernelGGL(rescal_edge_sq_regx_kernel, dim3((a.B + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK), dim3(KGE_BLOCK), 0, s, a);
+    else if (reg) hipLaunchKernelGGL(rescal_edge_sq_reg_kernel, dim3(a.B * RESCAL_RB), dim3(KGE_BLOCK), 0, s, a);
     else hipLaunchKernelGGL(rescal_edge_sq_kernel, dim3((a.B + KGE_WAVES_PER_BLOCK - 1) / KGE_WAVES_PER_BLOCK), dim3(KGE_BLOCK), 0, s, a);
-    hipLaunchKernelGGL(rescal_rel_state_kernel, dim3((a.UR + 255) / 256), dim3(256), 0, s, a, reg ? RESCAL_RB : 1);
+    hipLaunchKernelGGL(rescal_rel_state_kernel, dim3((a.UR + 255) / 256), dim3(256), 0, s, a, (reg && !regx) ? RESCAL_RB : 1);
     const dim3 ga(a.UR * RESCAL_RB), ba(KGE_BLOCK), gn(a.UR * RESCAL_RBN);
     if (a.c1p && a.c2p) {                                  // backward products + update in one pass per unique relation
         if (a.D % 4 != 0 || a.D > 1024) return KGE_ERR_ARG;
