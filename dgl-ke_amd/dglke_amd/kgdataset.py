@@ -49,7 +49,22 @@ class KGDataset(object):
         if path is None:
             return None
         print('Reading {} triples....'.format(what))
-        df = _read_table(path, delimiter, 4 if (self.has_edge_importance and what == "train") else 3)
+        want_w = self.has_edge_importance and what == "train"
+        df = None
+        if not by_name and len(delimiter) == 1:
+            # id triples: parsed as integers straight away (8 bytes per id instead of a Python string each - Freebase's 338 M
+            # training triples are 8 GB this way and would not fit as strings); anything that is not a plain integer column
+            # falls through to the string path below, which reports it like the reference does
+            try:
+                dt = {0: np.int64, 1: np.int64, 2: np.int64}
+                if want_w:
+                    dt[3] = np.float32
+                df = pd.read_csv(path, sep=delimiter, header=None, usecols=list(range(4 if want_w else 3)), dtype=dt,
+                                 engine="c", quoting=3)
+            except (ValueError, TypeError, OverflowError):
+                df = None
+        if df is None:
+            df = _read_table(path, delimiter, 4 if want_w else 3)
         cols = [df[order[0]], df[order[1]], df[order[2]]]
         if by_name:
             h = cols[0].map(self.entity2id)

@@ -64,6 +64,20 @@ def test_udd_ids_edge_importance_and_checks(tmp_path):
         K.get_dataset(str(tmp_path), "toy", "udd_hrt", "|", ["e.txt", "r.txt", "bad2.txt"])
     with pytest.raises(ValueError):
         K.get_dataset(str(tmp_path), "toy", "udd_hrt", "|", ["e.txt", "r.txt"])
+    # id triples are parsed as integers straight away (round 6: no Python string per id); column orders, extra columns, padded
+    # tokens (which only the string path accepts) and a multi-character delimiter give the same arrays
+    _write(tmp_path / "trh.txt", [(4, 1, 0, "x"), (2, 0, 3, "y")], "|")
+    ds = K.get_dataset(str(tmp_path), "toy", "udd_trh", "|", ["e.txt", "r.txt", "trh.txt"])
+    assert np.array_equal(ds.train[0], [0, 3]) and np.array_equal(ds.train[1], [1, 0]) and np.array_equal(ds.train[2], [4, 2])
+    with open(tmp_path / "pad.txt", "w") as f:
+        f.write("0| 1|4\n3|0 |2\n")
+    ds = K.get_dataset(str(tmp_path), "toy", "udd_hrt", "|", ["e.txt", "r.txt", "pad.txt"])
+    assert np.array_equal(ds.train[0], [0, 3]) and np.array_equal(ds.train[1], [1, 0]) and ds.train[0].dtype == np.int64
+    _write(tmp_path / "e2.txt", [(i, "e%d" % i) for i in range(5)], "||")
+    _write(tmp_path / "r2.txt", [(i, "r%d" % i) for i in range(2)], "||")
+    _write(tmp_path / "tr2.txt", [(0, 1, 4), (3, 0, 2)], "||")
+    ds = K.get_dataset(str(tmp_path), "toy", "udd_hrt", "||", ["e2.txt", "r2.txt", "tr2.txt"])
+    assert np.array_equal(ds.train[2], [4, 2])
 
 
 def test_flag_surface_matches_reference_defaults():
