@@ -38,15 +38,20 @@ def build_filter(known_h, known_r, known_t, test_h, test_r, test_t, neg_head, n_
     return rng, val.astype(np.int64)
 
 
+_FORCE_TWO_KEY_SORT = False      # tests: take the large-graph path of build_filter_device on a small graph
+
+
 def build_filter_device(known, test, neg_head, n_relations, n_entities, dev):
     """`build_filter` with the sort on the device: the same lists in the same order (unique (key, entity) pairs sorted by key, then
     entity; per test triple the [left, right) range of its key), as int64 DEVICE tensors ready for `Ranker.ranks`.  One composite
     key `(key * n_entities + entity)` through `torch.unique` instead of a host `np.lexsort` over every known triple - 0.09 s per
-    corruption side at FB15k's 592 k known triples, which was 87 % of a validation (tools/eval_timing.py).  Returns None when the
-    composite key does not fit int64 (Freebase-sized graphs: the host lists)."""
+    corruption side at FB15k's 592 k known triples, which was 87 % of a validation (tools/eval_timing.py).  When the composite key
+    does not fit int64 (Freebase: 86 M entities x 14 824 relations x 86 M) the same order comes from two stable device sorts
+    (entity, then key).  Returns None only when even `key` would overflow."""
     R, NE = int(n_relations), int(n_entities)
-    if NE * R * NE >= (1 << 62):
+    if NE * R >= (1 << 62):
         return None
+    two_key = NE * R * NE >= (1 << 62) or _FORCE_TWO_KEY_SORT
 
     def put(x):
         if isinstance(x, torch.Tensor):
@@ -58,9 +63,18 @@ def build_filter_device(known, test, neg_head, n_relations, n_entities, dev):
         key, val, tkey = kt * R + kr, kh, tt_ * R + tr_
     else:
         key, val, tkey = kh * R + kr, kt, th_ * R + tr_
-    comp = torch.unique(key * NE + val)                      # sorted unique (key, entity) pairs
-    key = torch.div(comp, NE, rounding_mode='floor')
-    val = comp - key * NE
+    if two_key:
+        o = torch.argsort(val, stable=True)
+        o = o[torch.argsort(key[o], stable=True)]            # lexicographic (key, entity) order
+        key, val = key[o], val[o]
+        if key.shape[0]:
+            keep = torch.ones(key.shape[0], dtype=torch.bool, device=key.device)
+            keep[1:] = (key[1:] != key[:-1]) | (val[1:] != val[:-1])
+            key, val = key[keep], val[keep]
+    else:
+        comp = torch.unique(key * NE + val)                  # sorted unique (key, entity) pairs
+        key = torch.div(comp, NE, rounding_mode='floor')
+        val = comp - key * NE
     rng = torch.stack([torch.searchsorted(key, tkey, right=False), torch.searchsorted(key, tkey, right=True)], 1)
     return rng.contiguous(), val.contiguous()
 
@@ -187,8 +201,10 @@ def evaluate(model_name, ent, rel, gamma, emb_init, test, known=None, batch=1024
             if cache is not None and ("filt", mode, sampled) in cache:
                 filt = cache[("filt", mode, sampled)]
             else:
-                if not sampled:          # lists built and kept on the device (sampled candidates: the host maps them to columns)
-                    filt = build_filter_device(known, (th_, tr_, tt_), neg_head, rel.shape[0], n_ent, dev)
+                # lists built on the device - and kept there, unless candidates are sampled: then the host maps them to columns
+                filt = build_filter_device(known, (th_, tr_, tt_), neg_head, rel.shape[0], n_ent, dev)
+                if sampled and filt is not None:
+                    filt = (filt[0].cpu().numpy(), filt[1].cpu().numpy())
                 if filt is None:
                     filt = build_filter(known[0], known[1], known[2], *(x.cpu().numpy() if isinstance(x, torch.Tensor) else x
                                                                         for x in (th_, tr_, tt_)), neg_head, rel.shape[0])

@@ -264,4 +264,16 @@ def test_device_filter_lists_equal_the_host_lists():
         got = E.build_filter_device(known, test, neg_head, n_rel, n_ent, torch.device("cpu"))
         assert got[0].dtype == torch.int64 and got[1].dtype == torch.int64
         assert np.array_equal(got[0].numpy(), want[0]) and np.array_equal(got[1].numpy(), want[1])
-    assert E.build_filter_device(known, test, True, 14824, 86054151, torch.device("cpu")) is None
+    # Freebase-sized id spaces (the composite key would overflow): two stable sorts give the same lists
+    E._FORCE_TWO_KEY_SORT = True
+    try:
+        for neg_head in (True, False):
+            want = E.build_filter(known[0], known[1], known[2], test[0], test[1], test[2], neg_head, n_rel)
+            got = E.build_filter_device(known, test, neg_head, n_rel, n_ent, torch.device("cpu"))
+            assert np.array_equal(got[0].numpy(), want[0]) and np.array_equal(got[1].numpy(), want[1])
+    finally:
+        E._FORCE_TWO_KEY_SORT = False
+    big = E.build_filter_device(tuple(np.asarray(x[:50]) for x in known), tuple(np.asarray(x[:5]) for x in test), True, 14824, 86054151,
+                                torch.device("cpu"))
+    assert big is not None and big[0].shape == (5, 2)
+    assert E.build_filter_device(known, test, True, 1 << 40, 1 << 30, torch.device("cpu")) is None
